@@ -1,0 +1,170 @@
+/*
+ * passion_hip.h -- C ABI of libpassion_hip.so: the MI355X (gfx950) kernels behind the
+ * PASSION training hot path (mmformer / RFNet encoder-decoder forward+backward and the
+ * self-distillation / Dice / weighted-CE losses).
+ *
+ * The reference (Jun-Jie-Shi/PASSION) has no native layer: every entry point below replaces a
+ * stock torch/ATen op that the reference calls from code/models/{mmformer,rfnet,blocks}.py and
+ * code/utils/criterions.py (file:line cited per function).  The Python host side
+ * (passion_amd/ops.py) binds these with ctypes and wraps them in torch.autograd.Function.
+ *
+ * Conventions
+ *  - Every pointer is a DEVICE pointer owned by the caller (torch allocates); the library never
+ *    allocates, frees or synchronises.  `stream` is a hipStream_t passed as void*.
+ *  - Activations are channels-last: [B][D][H][W][C], C fastest.  dtype is PASSION_F32 or
+ *    PASSION_BF16 (storage only -- accumulation is always f32).
+ *  - Return value: 0 on success, -(hipError_t) on a HIP failure, -1000-k for argument errors.
+ *  - Thread-safe given distinct streams.
+ */
+#ifndef PASSION_HIP_H
+#define PASSION_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PASSION_F32 0
+#define PASSION_BF16 1
+#define PASSION_PAD_ZEROS 0
+#define PASSION_PAD_REFLECT 1
+#define PASSION_MAX_SEG 4
+
+int passion_abi_version(void);
+
+/* ---- InstanceNorm statistics ------------------------------------------------------------
+ * Replaces the reduction half of nn.InstanceNorm3d(affine=False) (code/models/blocks.py:18,
+ * applied at blocks.py:313 / :368): per (b,c) mean and 1/sqrt(biased_var + eps) over D*H*W.
+ * x: [B][V][C] (batch stride `bstride` elements); scratch: B*C*2 doubles (zeroed by the call);
+ * stats out: [B][C][2] f32 = (mean, rstd).  C must be a multiple of 4. */
+int passion_instnorm_stats(const void* x, int dtype, int B, int64_t V, int C, int64_t bstride,
+                           float eps, double* scratch, float* stats, void* stream);
+
+/* ---- fused (InstanceNorm -> LeakyReLU ->) Conv3d ----------------------------------------
+ * Replaces general_conv3d_prenorm (code/models/blocks.py:300-316), bare nn.Conv3d
+ * (code/models/mmformer.py:28,90,136-140,337-340,355) and, with several segments, the
+ * MaskModal + torch.stack/cat feeding it (mmformer.py:316-325,405-409; Decoder cat at :96,:162).
+ * An input "segment" is one tensor of the virtual channel concatenation. */
+typedef struct {
+    const void* x;        /* [B][Vin][C] */
+    const float* stats;   /* [B][C][2] (mean, rstd): apply (x-mean)*rstd then LeakyReLU; NULL: raw */
+    const uint8_t* mask;  /* [B][mask_ld] modality-present flags; NULL: present. Absent => contributes 0 */
+    void* dx;             /* backward only: gradient wrt x, same shape/dtype as x; NULL: not needed */
+    int64_t bstride;      /* batch stride of x (and dx) in elements */
+    int32_t C;
+    int32_t mask_col;
+    int32_t mask_ld;
+    int32_t _pad;
+} passion_seg_t;
+
+typedef struct {
+    int32_t x_dtype;      /* dtype of segments (and of dx) */
+    int32_t y_dtype;      /* dtype of y / residual / dy */
+    int32_t B, D, H, W;   /* input spatial size */
+    int32_t ksize;        /* 1 or 3 (padding = ksize/2) */
+    int32_t stride;       /* 1 or 2 */
+    int32_t pad_mode;     /* PASSION_PAD_* */
+    int32_t nseg;
+    int32_t Cout;         /* multiple of 4 */
+    float lrelu_slope;
+    passion_seg_t seg[PASSION_MAX_SEG];
+} passion_conv_desc_t;
+
+/* Size in floats of the packed-weight workspace for a conv (forward pack + dgrad pack). */
+int64_t passion_conv_pack_floats(int Cin, int Cout, int ksize);
+/* weight: f32 [Cout][Cin][k][k][k] (the reference nn.Conv3d layout) -> packed workspace. */
+int passion_conv_pack_weight(const float* weight, int Cin, int Cout, int ksize, float* packed,
+                             void* stream);
+/* y[b][vo][co] = bias[co] + residual + sum_{tap,ci} W * act(x_padded).  residual may be NULL. */
+int passion_conv3d_fwd(const passion_conv_desc_t* d, const float* packed, const float* bias,
+                       const void* residual, void* y, void* stream);
+/* Backward of the whole block.  dy: [B][Vout][Cout].
+ *  dweight: f32 [Cout][Cin][k^3] and dbias f32 [Cout] are ACCUMULATED into (caller zeroes), either may be NULL.
+ *  For every segment with dx != NULL the gradient wrt its raw x is written (through LeakyReLU and
+ *  InstanceNorm when stats != NULL).  sums: f32 scratch [B][Cin][2]. */
+int passion_conv3d_bwd(const passion_conv_desc_t* d, const float* packed, const void* dy,
+                       float* dweight, float* dbias, float* sums, void* stream);
+
+/* ---- trilinear resampling, align_corners=True ---------------------------------------------
+ * Replaces nn.Upsample(scale_factor=k, mode='trilinear', align_corners=True)
+ * (code/models/mmformer.py:70,143,366-370).  x: [B][D][H][W][C] -> y: [B][kD][kH][kW][C]. */
+int passion_upsample_fwd(const void* x, void* y, int dtype, int B, int D, int H, int W, int C,
+                         int k, void* stream);
+int passion_upsample_bwd(const void* dy, void* dx, int dtype, int B, int D, int H, int W, int C,
+                         int k, void* stream);
+
+/* ---- layout / softmax -----------------------------------------------------------------------
+ * softmax over the class axis (nn.Softmax(dim=1), mmformer.py:91,543,635; criterions.py:93-94
+ * with 1/T).  Element (b,v,c) of a tensor lives at b*sb + v*sv + c*sc. */
+int passion_softmax_fwd(const float* logits, int64_t lsb, int64_t lsv, int64_t lsc, float* probs,
+                        int64_t psb, int64_t psv, int64_t psc, int B, int64_t V, int C,
+                        float inv_temp, void* stream);
+int passion_softmax_bwd(const float* probs, int64_t psb, int64_t psv, int64_t psc,
+                        const float* dprobs, int64_t gsb, int64_t gsv, int64_t gsc, float* dlogits,
+                        int64_t lsb, int64_t lsv, int64_t lsc, int B, int64_t V, int C,
+                        float inv_temp, void* stream);
+/* target one-hot (f64 or f32, [B][C][V]) -> f32 channels-last [B][V][C] (datasets_nii.py:151-153 output). */
+int passion_target_to_cl(const void* target, int is_f64, float* out, int B, int64_t V, int C,
+                         void* stream);
+/* generic strided f32/bf16 -> strided f32/bf16 copy of a [B][V][C] tensor (layout changes). */
+int passion_copy_strided(const void* src, int sdtype, int64_t ssb, int64_t ssv, int64_t ssc,
+                         void* dst, int ddtype, int64_t dsb, int64_t dsv, int64_t dsc, int B,
+                         int64_t V, int C, void* stream);
+
+/* ---- segmentation losses --------------------------------------------------------------------
+ * softmax_weighted_loss_bs + dice_loss_bs (code/utils/criterions.py:59-76, 25-38) on
+ * probabilities.  probs strided as above; target f32 channels-last [B][V][C], C = 4.
+ * sums: f32 scratch [B][4*C] (num, l, r, celog per class; zeroed by the call).
+ * out: [B][2] = (weighted CE, Dice loss). */
+int passion_wce_dice_fwd(const float* probs, int64_t psb, int64_t psv, int64_t psc,
+                         const float* target, int B, int64_t V, int C, float* sums, float* out,
+                         void* stream);
+/* dprobs (same strides as probs) = g[b][0]*dCE/dp + g[b][1]*dDice/dp ; g: [B][2] */
+int passion_wce_dice_bwd(const float* probs, int64_t psb, int64_t psv, int64_t psc,
+                         const float* target, const float* sums, const float* g, float* dprobs,
+                         int B, int64_t V, int C, void* stream);
+/* temp_kl_loss_bs (criterions.py:92-103) on already softmaxed(/T) [and upsampled] probabilities.
+ * out[b] = T^2 * mean_{c,v} pt*(log pt - log ps) with both clamped to [0.005,1]. */
+int passion_kl_fwd(const float* ps, const float* pt, int B, int64_t V, int C, float temp,
+                   float* out, void* stream);
+int passion_kl_bwd(const float* ps, const float* pt, const float* g, float* dps, int B, int64_t V,
+                   int C, float temp, void* stream);
+/* prototype_passion_loss_bs (criterions.py:144-180).  fs, ft: [B][V][Cf] features (dtype),
+ * target [B][V][4] f32.  work: f32 scratch of passion_proto_work_floats(B,Cf) floats.
+ * out: [B][2] = (proto_loss, dist).  Backward writes dfs (dtype) given g[b] = dL/dproto_loss[b]. */
+int64_t passion_proto_work_floats(int B, int Cf);
+int passion_proto_fwd(const void* fs, const void* ft, int dtype, const float* target, int B,
+                      int64_t V, int Cf, float* work, float* out, void* stream);
+int passion_proto_bwd(const void* fs, const void* ft, int dtype, const float* target,
+                      const float* g, int B, int64_t V, int Cf, float* work, void* dfs,
+                      void* stream);
+
+/* ---- attention ------------------------------------------------------------------------------
+ * SelfAttention core (code/models/mmformer.py:220-224): softmax(q k^T * scale) v per (batch, head).
+ * qkv: [B][N][3][H][Dh] (the nn.Linear(dim,3*dim) output), out: [B][N][H][Dh].
+ * probs: [B][H][N][N] f32, kept for the backward.  Split in two so that the host can apply
+ * attention dropout (mmformer.py:222) between the softmax and the PV product.
+ * scores_fwd: probs = softmax_rows(scale * q k^T) */
+int passion_attn_scores_fwd(const void* qkv, int dtype, int B, int N, int H, int Dh, float scale,
+                            float* probs, void* stream);
+/* out[b][n][h][:] = sum_key probs[b][h][n][key] * v[b][key][h][:]  (probs may have had dropout applied) */
+int passion_attn_pv_fwd(const float* probs, const void* qkv, int dtype, int B, int N, int H, int Dh,
+                        void* out, void* stream);
+/* writes the V slot of dqkv and dprobs = dout v^T */
+int passion_attn_pv_bwd(const float* probs, const void* qkv, const void* dout, int dtype, int B,
+                        int N, int H, int Dh, float* dprobs, void* dqkv, void* stream);
+/* softmax backward in place on dprobs (x scale), then writes the Q and K slots of dqkv */
+int passion_attn_scores_bwd(const float* probs, float* dprobs, const void* qkv, int dtype, int B,
+                            int N, int H, int Dh, float scale, void* dqkv, void* stream);
+
+/* ---- in-library kernel timing (bench.py roofline leg) ------------------------------------------
+ * When enabled, conv3d launches are bracketed by hipEvents on their own stream and their
+ * algorithmic bytes recorded.  passion_prof_read drains up to `cap` records:
+ * rec[i] = {kind, ms, bytes, flops}. kind: 0 fwd k3, 1 fwd k1, 2 dgrad, 3 wgrad. */
+typedef struct { int32_t kind; float ms; double bytes; double flops; } passion_prof_rec_t;
+void passion_prof_enable(int on);
+int passion_prof_read(passion_prof_rec_t* rec, int cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,133 @@
+"""ctypes binding of libpassion_hip.so (C ABI declared in include/passion_hip.h).
+
+The product path has no CPU or eager fallback: if the shared library is missing, or a kernel is
+asked to run on a non-GPU tensor, this module raises.
+"""
+import ctypes
+import os
+from ctypes import (POINTER, Structure, c_double, c_float, c_int, c_int32, c_int64, c_uint8,
+                    c_void_p)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libpassion_hip.so")
+
+F32, BF16 = 0, 1
+PAD_ZEROS, PAD_REFLECT = 0, 1
+MAX_SEG = 4
+
+
+class Seg(Structure):
+    _fields_ = [("x", c_void_p), ("stats", c_void_p), ("mask", c_void_p), ("dx", c_void_p),
+                ("bstride", c_int64), ("C", c_int32), ("mask_col", c_int32),
+                ("mask_ld", c_int32), ("_pad", c_int32)]
+
+
+class ConvDesc(Structure):
+    _fields_ = [("x_dtype", c_int32), ("y_dtype", c_int32), ("B", c_int32), ("D", c_int32),
+                ("H", c_int32), ("W", c_int32), ("ksize", c_int32), ("stride", c_int32),
+                ("pad_mode", c_int32), ("nseg", c_int32), ("Cout", c_int32),
+                ("lrelu_slope", c_float), ("seg", Seg * MAX_SEG)]
+
+
+class ProfRec(Structure):
+    _fields_ = [("kind", c_int32), ("ms", c_float), ("bytes", c_double), ("flops", c_double)]
+
+
+# name -> (restype, argtypes).  Must list every symbol include/passion_hip.h declares
+# (tests/test_abi.py cross-checks the header against this table and against the .so).
+SIGNATURES = {
+    "passion_abi_version": (c_int, []),
+    "passion_instnorm_stats": (c_int, [c_void_p, c_int, c_int, c_int64, c_int, c_int64, c_float,
+                                       c_void_p, c_void_p, c_void_p]),
+    "passion_conv_pack_floats": (c_int64, [c_int, c_int, c_int]),
+    "passion_conv_pack_weight": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "passion_conv3d_fwd": (c_int, [POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p,
+                                   c_void_p]),
+    "passion_conv3d_bwd": (c_int, [POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p,
+                                   c_void_p, c_void_p]),
+    "passion_upsample_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
+                                     c_int, c_void_p]),
+    "passion_upsample_bwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
+                                     c_int, c_void_p]),
+    "passion_softmax_fwd": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int64,
+                                    c_int64, c_int64, c_int, c_int64, c_int, c_float, c_void_p]),
+    "passion_softmax_bwd": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int64,
+                                    c_int64, c_int64, c_void_p, c_int64, c_int64, c_int64, c_int,
+                                    c_int64, c_int, c_float, c_void_p]),
+    "passion_target_to_cl": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int64, c_int, c_void_p]),
+    "passion_copy_strided": (c_int, [c_void_p, c_int, c_int64, c_int64, c_int64, c_void_p, c_int,
+                                     c_int64, c_int64, c_int64, c_int, c_int64, c_int, c_void_p]),
+    "passion_wce_dice_fwd": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int,
+                                     c_int64, c_int, c_void_p, c_void_p, c_void_p]),
+    "passion_wce_dice_bwd": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p,
+                                     c_void_p, c_void_p, c_int, c_int64, c_int, c_void_p]),
+    "passion_kl_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int, c_float, c_void_p,
+                               c_void_p]),
+    "passion_kl_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int,
+                               c_float, c_void_p]),
+    "passion_proto_work_floats": (c_int64, [c_int, c_int]),
+    "passion_proto_fwd": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int64, c_int,
+                                  c_void_p, c_void_p, c_void_p]),
+    "passion_proto_bwd": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int64,
+                                  c_int, c_void_p, c_void_p, c_void_p]),
+    "passion_attn_scores_fwd": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_float,
+                                        c_void_p, c_void_p]),
+    "passion_attn_pv_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                                    c_void_p, c_void_p]),
+    "passion_attn_pv_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+                                    c_int, c_void_p, c_void_p, c_void_p]),
+    "passion_attn_scores_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+                                        c_int, c_float, c_void_p, c_void_p]),
+    "passion_prof_enable": (None, [c_int]),
+    "passion_prof_read": (c_int, [POINTER(ProfRec), c_int]),
+}
+
+_lib = None
+
+
+class PassionHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libpassion_hip.so (once).  Raises if it has not been built -- there is no fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise PassionHipError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C passion_amd/csrc`.  passion_amd has no CPU/eager fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise PassionHipError(f"{what} failed with code {rc}")
+
+
+def dtype_code(t):
+    import torch
+    if t == torch.float32:
+        return F32
+    if t == torch.bfloat16:
+        return BF16
+    raise PassionHipError(f"unsupported activation dtype {t}")
+
+
+def require_gpu(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise PassionHipError("passion_amd kernels need GPU tensors (no CPU fallback); got a "
+                                  f"{t.device} tensor")
+
+
+def stream_ptr():
+    import torch
+    return c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -1,0 +1,52 @@
+// Library-level entry points: ABI version and the optional hipEvent timing of conv launches.
+#include <hip/hip_runtime.h>
+#include <mutex>
+#include <vector>
+#include "passion_hip.h"
+#include "prof.h"
+
+int g_passion_prof_on = 0;
+
+namespace {
+struct Pending { int kind; double bytes, flops; hipEvent_t e0, e1; bool closed; };
+std::mutex g_mu;
+std::vector<Pending> g_pending;
+}  // namespace
+
+void passion_prof_begin(int kind, double bytes, double flops, hipStream_t st) {
+    Pending p{kind, bytes, flops, nullptr, nullptr, false};
+    if (hipEventCreate(&p.e0) != hipSuccess || hipEventCreate(&p.e1) != hipSuccess) return;
+    hipEventRecord(p.e0, st);
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_pending.push_back(p);
+}
+
+void passion_prof_end(hipStream_t st) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    for (size_t i = g_pending.size(); i-- > 0;) {
+        if (!g_pending[i].closed) { hipEventRecord(g_pending[i].e1, st); g_pending[i].closed = true; break; }
+    }
+}
+
+extern "C" int passion_abi_version(void) { return 1; }
+
+extern "C" void passion_prof_enable(int on) { g_passion_prof_on = on; }
+
+// Drains finished records (synchronises on their events: call outside the timed region).
+extern "C" int passion_prof_read(passion_prof_rec_t* rec, int cap) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    int n = 0;
+    size_t i = 0;
+    for (; i < g_pending.size() && n < cap; ++i) {
+        Pending& p = g_pending[i];
+        if (!p.closed) break;
+        float ms = 0.f;
+        hipEventSynchronize(p.e1);
+        hipEventElapsedTime(&ms, p.e0, p.e1);
+        hipEventDestroy(p.e0); hipEventDestroy(p.e1);
+        rec[n].kind = p.kind; rec[n].ms = ms; rec[n].bytes = p.bytes; rec[n].flops = p.flops;
+        ++n;
+    }
+    g_pending.erase(g_pending.begin(), g_pending.begin() + i);
+    return n;
+}

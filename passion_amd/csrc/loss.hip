@@ -1,0 +1,588 @@
+// Class-axis softmax, layout conversion and the segmentation / self-distillation losses.
+//   softmax                         <- nn.Softmax(dim=1) / F.softmax(x/T, dim=1)   (mmformer.py:91,543,635; criterions.py:93-94)
+//   wce_dice                        <- softmax_weighted_loss_bs + dice_loss_bs     (criterions.py:59-76, 25-38)
+//   kl                              <- temp_kl_loss_bs                             (criterions.py:92-103)
+//   proto                           <- prototype_passion_loss_bs                   (criterions.py:144-180)
+// All are HBM-bound streaming reductions over D*H*W: one pass, 16-byte loads per voxel, per-thread
+// register partials, wavefront shuffle reduction, one atomic per workgroup per scalar.
+#include "common.h"
+#include "passion_hip.h"
+
+namespace {
+
+constexpr int NC = 4;  // classes
+
+// ---------------------------------------------------------------- softmax
+__global__ void softmax_fwd_kernel(const float* __restrict__ lg, long lsb, long lsv, long lsc, float* __restrict__ pr,
+                                   long psb, long psv, long psc, int B, long V, float inv_temp) {
+    const long total = (long)B * V;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long b = i / V, v = i % V;
+        float z[NC], m = -INFINITY;
+        if (lsc == 1) {
+            f32x4 t = load4(lg + b * lsb + v * lsv);
+#pragma unroll
+            for (int c = 0; c < NC; ++c) z[c] = t[c] * inv_temp;
+        } else {
+#pragma unroll
+            for (int c = 0; c < NC; ++c) z[c] = lg[b * lsb + v * lsv + c * lsc] * inv_temp;
+        }
+#pragma unroll
+        for (int c = 0; c < NC; ++c) m = fmaxf(m, z[c]);
+        float s = 0.f;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) { z[c] = expf(z[c] - m); s += z[c]; }
+        const float inv = 1.f / s;
+        if (psc == 1) {
+            f32x4 o = {z[0] * inv, z[1] * inv, z[2] * inv, z[3] * inv};
+            store4(pr + b * psb + v * psv, o);
+        } else {
+#pragma unroll
+            for (int c = 0; c < NC; ++c) pr[b * psb + v * psv + c * psc] = z[c] * inv;
+        }
+    }
+}
+
+__global__ void softmax_bwd_kernel(const float* __restrict__ pr, long psb, long psv, long psc,
+                                   const float* __restrict__ dp, long gsb, long gsv, long gsc, float* __restrict__ dl,
+                                   long lsb, long lsv, long lsc, int B, long V, float inv_temp) {
+    const long total = (long)B * V;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long b = i / V, v = i % V;
+        float p[NC], g[NC], dot = 0.f;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            p[c] = pr[b * psb + v * psv + c * psc];
+            g[c] = dp[b * gsb + v * gsv + c * gsc];
+            dot += p[c] * g[c];
+        }
+#pragma unroll
+        for (int c = 0; c < NC; ++c) dl[b * lsb + v * lsv + c * lsc] = p[c] * (g[c] - dot) * inv_temp;
+    }
+}
+
+template <typename TS>
+__global__ void target_to_cl_kernel(const TS* __restrict__ t, float* __restrict__ out, int B, long V) {
+    const long total = (long)B * V;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long b = i / V, v = i % V;
+        f32x4 o;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) o[c] = (float)t[(b * NC + c) * V + v];
+        store4(out + i * 4, o);
+    }
+}
+
+template <typename TS, typename TD>
+__global__ void copy_strided_kernel(const TS* __restrict__ s, long ssb, long ssv, long ssc, TD* __restrict__ d,
+                                    long dsb, long dsv, long dsc, int B, long V, int C) {
+    const long total = (long)B * V * C;
+    // iterate with the destination-contiguous index fastest
+    const bool c_fast = (dsc == 1);
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        long b, v; int c;
+        if (c_fast) { c = (int)(i % C); v = (i / C) % V; b = i / ((long)C * V); }
+        else { v = i % V; c = (int)((i / V) % C); b = i / ((long)C * V); }
+        d[b * dsb + v * dsv + c * dsc] = from_f32<TD>(to_f32(s[b * ssb + v * ssv + c * ssc]));
+    }
+}
+
+// ---------------------------------------------------------------- weighted CE + Dice
+// sums[b][0..3]=num_c, [4..7]=l_c (sum p), [8..11]=r_c (sum t), [12..15]=sum t_c*log(clamp p_c)
+__global__ __launch_bounds__(256) void wce_dice_sums_kernel(const float* __restrict__ pr, long psb, long psv, long psc,
+                                                            const float* __restrict__ tg, long V,
+                                                            float* __restrict__ sums) {
+    __shared__ float red[4][16];
+    const int b = blockIdx.y;
+    float a[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) a[j] = 0.f;
+    for (long v = (long)blockIdx.x * blockDim.x + threadIdx.x; v < V; v += (long)gridDim.x * blockDim.x) {
+        float p[NC];
+        if (psc == 1) {
+            f32x4 t = load4(pr + b * psb + v * psv);
+#pragma unroll
+            for (int c = 0; c < NC; ++c) p[c] = t[c];
+        } else {
+#pragma unroll
+            for (int c = 0; c < NC; ++c) p[c] = pr[b * psb + v * psv + c * psc];
+        }
+        const f32x4 t = load4(tg + ((long)b * V + v) * 4);
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            a[c] += p[c] * t[c];
+            a[4 + c] += p[c];
+            a[8 + c] += t[c];
+            a[12 + c] += t[c] * logf(fminf(fmaxf(p[c], 0.005f), 1.0f));
+        }
+    }
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const float s = wave_sum(a[j]);
+        if (lane == 0) red[wv][j] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < 16) {
+        const float s = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+        atomicAdd(&sums[b * 16 + threadIdx.x], s);
+    }
+}
+
+__global__ void wce_dice_final_kernel(const float* __restrict__ sums, int B, long V, float* __restrict__ out) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const float* s = sums + b * 16;
+    const float rt = s[8] + s[9] + s[10] + s[11];
+    float ce = 0.f, dice = 0.f;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const float w = 1.0f - s[8 + c] / rt;
+        ce += -w * s[12 + c];
+        dice += 2.0f * s[c] / (s[4 + c] + s[8 + c] + 1e-7f);
+    }
+    out[b * 2 + 0] = ce / (float)V;
+    out[b * 2 + 1] = 1.0f - dice / (float)NC;
+}
+
+__global__ void wce_dice_bwd_kernel(const float* __restrict__ pr, long psb, long psv, long psc,
+                                    const float* __restrict__ tg, const float* __restrict__ sums,
+                                    const float* __restrict__ g, float* __restrict__ dp, long V) {
+    const int b = blockIdx.y;
+    const float* s = sums + b * 16;
+    const float rt = s[8] + s[9] + s[10] + s[11];
+    const float g_ce = g[b * 2 + 0], g_dice = g[b * 2 + 1];
+    float kce[NC], kd1[NC], kd2[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const float w = 1.0f - s[8 + c] / rt;
+        const float den = s[4 + c] + s[8 + c] + 1e-7f;
+        kce[c] = -g_ce * w / (float)V;                 // * t / p (inside the clamp window)
+        kd1[c] = -g_dice * 2.0f / ((float)NC * den);   // * t
+        kd2[c] = g_dice * 2.0f * s[c] / ((float)NC * den * den);
+    }
+    for (long v = (long)blockIdx.x * blockDim.x + threadIdx.x; v < V; v += (long)gridDim.x * blockDim.x) {
+        const f32x4 t = load4(tg + ((long)b * V + v) * 4);
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const float p = pr[b * psb + v * psv + c * psc];
+            float d = kd1[c] * t[c] + kd2[c];
+            if (p >= 0.005f && p <= 1.0f) d += kce[c] * t[c] / p;
+            dp[b * psb + v * psv + c * psc] = d;
+        }
+    }
+}
+
+// ---------------------------------------------------------------- temperature KL
+__global__ __launch_bounds__(256) void kl_fwd_kernel(const float* __restrict__ ps, const float* __restrict__ pt, long V,
+                                                     float k, float* __restrict__ out) {
+    __shared__ float red[4];
+    const int b = blockIdx.y;
+    float a = 0.f;
+    for (long v = (long)blockIdx.x * blockDim.x + threadIdx.x; v < V; v += (long)gridDim.x * blockDim.x) {
+        const f32x4 s = load4(ps + ((long)b * V + v) * 4), t = load4(pt + ((long)b * V + v) * 4);
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const float sc = fminf(fmaxf(s[c], 0.005f), 1.0f), tc = fminf(fmaxf(t[c], 0.005f), 1.0f);
+            a += tc * (logf(tc) - logf(sc));
+        }
+    }
+    a = wave_sum(a);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(&out[b], k * (red[0] + red[1] + red[2] + red[3]));
+}
+
+__global__ void kl_bwd_kernel(const float* __restrict__ ps, const float* __restrict__ pt, const float* __restrict__ g,
+                              float* __restrict__ dps, long V, float k) {
+    const int b = blockIdx.y;
+    const float gk = g[b] * k;
+    for (long v = (long)blockIdx.x * blockDim.x + threadIdx.x; v < V; v += (long)gridDim.x * blockDim.x) {
+        const f32x4 s = load4(ps + ((long)b * V + v) * 4), t = load4(pt + ((long)b * V + v) * 4);
+        f32x4 d;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const float tc = fminf(fmaxf(t[c], 0.005f), 1.0f);
+            d[c] = (s[c] >= 0.005f && s[c] <= 1.0f) ? -gk * tc / s[c] : 0.f;
+        }
+        store4(dps + ((long)b * V + v) * 4, d);
+    }
+}
+
+// ---------------------------------------------------------------- prototype loss (Cf = 8 feature channels)
+constexpr int CF = 8;
+// work layout (floats), per batch b: PW = 4 + 2*4*CF + 4*CF + 8
+//   [0..3] count_c | [4 .. 4+4CF) sum_s[c][ch] | [.. +4CF) sum_t[c][ch] | [.. +4CF) Gp[c][ch] | loss, dist, pad..
+// followed (after B*PW) by 4 floats: class validity flags, then 1 float: number of valid classes.
+constexpr int PW = 4 + 3 * 4 * CF + 8;
+__host__ __device__ inline int pw_sums(int c, int ch) { return 4 + c * CF + ch; }
+__host__ __device__ inline int pw_sumt(int c, int ch) { return 4 + 4 * CF + c * CF + ch; }
+__host__ __device__ inline int pw_gp(int c, int ch) { return 4 + 8 * CF + c * CF + ch; }
+constexpr int PW_LOSS = 4 + 12 * CF, PW_DIST = PW_LOSS + 1;
+
+template <typename T> __device__ __forceinline__ void load8(const T* p, float* o) {
+    f32x4 a = load4(p), b = load4(p + 4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { o[j] = a[j]; o[4 + j] = b[j]; }
+}
+template <typename T> __device__ __forceinline__ void store8(T* p, const float* o) {
+    f32x4 a = {o[0], o[1], o[2], o[3]}, b = {o[4], o[5], o[6], o[7]};
+    store4(p, a); store4(p + 4, b);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void proto_sums_kernel(const T* __restrict__ fs, const T* __restrict__ ft,
+                                                         const float* __restrict__ tg, long V, float* __restrict__ work) {
+    __shared__ float red[4][4 + 8 * CF];
+    const int b = blockIdx.y;
+    float cnt[NC], ss[NC][CF], st[NC][CF];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        cnt[c] = 0.f;
+#pragma unroll
+        for (int h = 0; h < CF; ++h) { ss[c][h] = 0.f; st[c][h] = 0.f; }
+    }
+    for (long v = (long)blockIdx.x * blockDim.x + threadIdx.x; v < V; v += (long)gridDim.x * blockDim.x) {
+        float a[CF], e[CF];
+        load8(fs + ((long)b * V + v) * CF, a);
+        load8(ft + ((long)b * V + v) * CF, e);
+        const f32x4 t = load4(tg + ((long)b * V + v) * 4);
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            cnt[c] += t[c];
+#pragma unroll
+            for (int h = 0; h < CF; ++h) { ss[c][h] += a[h] * t[c]; st[c][h] += e[h] * t[c]; }
+        }
+    }
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        float s = wave_sum(cnt[c]);
+        if (lane == 0) red[wv][c] = s;
+#pragma unroll
+        for (int h = 0; h < CF; ++h) {
+            s = wave_sum(ss[c][h]);
+            if (lane == 0) red[wv][4 + c * CF + h] = s;
+            s = wave_sum(st[c][h]);
+            if (lane == 0) red[wv][4 + 4 * CF + c * CF + h] = s;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 4 + 8 * CF) {
+        const int j = threadIdx.x;
+        atomicAdd(&work[(long)b * PW + j], red[0][j] + red[1][j] + red[2][j] + red[3][j]);
+    }
+}
+
+// class c counts only if every sample of the (local) batch contains it (criterions.py:157)
+__global__ void proto_valid_kernel(float* __restrict__ work, int B) {
+    if (threadIdx.x < NC) {
+        bool ok = true;
+        for (int b = 0; b < B; ++b) ok = ok && (work[(long)b * PW + threadIdx.x] > 0.f);
+        work[(long)B * PW + threadIdx.x] = ok ? 1.f : 0.f;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float n = 0.f;
+        for (int c = 0; c < NC; ++c) n += work[(long)B * PW + c];
+        work[(long)B * PW + 4] = n;
+    }
+}
+
+struct Protos { float ps[NC][CF], pt[NC][CF], nps[NC], npt[NC], cnt[NC], valid[NC], nvalid; };
+
+__device__ __forceinline__ void load_protos(const float* __restrict__ work, int b, int B, Protos& P) {
+    const float eps = 1e-5f;
+    P.nvalid = work[(long)B * PW + 4];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        P.cnt[c] = work[(long)b * PW + c];
+        P.valid[c] = work[(long)B * PW + c];
+        float a = 0.f, e = 0.f;
+#pragma unroll
+        for (int h = 0; h < CF; ++h) {
+            P.ps[c][h] = work[(long)b * PW + pw_sums(c, h)] / (P.cnt[c] + eps);
+            P.pt[c][h] = work[(long)b * PW + pw_sumt(c, h)] / (P.cnt[c] + eps);
+            a += P.ps[c][h] * P.ps[c][h];
+            e += P.pt[c][h] * P.pt[c][h];
+        }
+        P.nps[c] = sqrtf(a); P.npt[c] = sqrtf(e);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void proto_loss_kernel(const T* __restrict__ fs, const T* __restrict__ ft, long V,
+                                                         int B, float* __restrict__ work) {
+    __shared__ float red[4][2];
+    const int b = blockIdx.y;
+    const float eps = 1e-5f;
+    Protos P;
+    load_protos(work, b, B, P);
+    float al = 0.f, ad = 0.f;
+    for (long v = (long)blockIdx.x * blockDim.x + threadIdx.x; v < V; v += (long)gridDim.x * blockDim.x) {
+        float a[CF], e[CF];
+        load8(fs + ((long)b * V + v) * CF, a);
+        load8(ft + ((long)b * V + v) * CF, e);
+        float na = 0.f, ne = 0.f;
+#pragma unroll
+        for (int h = 0; h < CF; ++h) { na += a[h] * a[h]; ne += e[h] * e[h]; }
+        const float ia = 1.f / fmaxf(sqrtf(na), eps), ie = 1.f / fmaxf(sqrtf(ne), eps);
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            if (P.valid[c] == 0.f) continue;
+            float da = 0.f, de = 0.f;
+#pragma unroll
+            for (int h = 0; h < CF; ++h) { da += a[h] * P.ps[c][h]; de += e[h] * P.pt[c][h]; }
+            const float sim_s = da * ia / fmaxf(P.nps[c], eps), sim_t = de * ie / fmaxf(P.npt[c], eps);
+            const float d = sim_s - sim_t;
+            al += d * d;
+            ad += sqrtf(d * d);
+        }
+    }
+    al = wave_sum(al); ad = wave_sum(ad);
+    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6][0] = al; red[threadIdx.x >> 6][1] = ad; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float k = 1.0f / (P.nvalid * (float)V);
+        atomicAdd(&work[(long)b * PW + PW_LOSS], k * (red[0][0] + red[1][0] + red[2][0] + red[3][0]));
+        atomicAdd(&work[(long)b * PW + PW_DIST], k * (red[0][1] + red[1][1] + red[2][1] + red[3][1]));
+    }
+}
+
+__global__ void proto_out_kernel(const float* __restrict__ work, int B, float* __restrict__ out) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    out[b * 2 + 0] = work[(long)b * PW + PW_LOSS];
+    out[b * 2 + 1] = work[(long)b * PW + PW_DIST];
+}
+
+// backward pass 1: direct term of d loss / d fs and the prototype-gradient sums Gp[c][ch]
+template <typename T>
+__global__ __launch_bounds__(256) void proto_bwd1_kernel(const T* __restrict__ fs, const T* __restrict__ ft,
+                                                         const float* __restrict__ g, long V, int B,
+                                                         float* __restrict__ work, T* __restrict__ dfs) {
+    __shared__ float red[4][NC * CF];
+    const int b = blockIdx.y;
+    const float eps = 1e-5f;
+    Protos P;
+    load_protos(work, b, B, P);
+    const float kk = g[b] * 2.0f / (P.nvalid * (float)V);
+    float gp[NC][CF];
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+#pragma unroll
+        for (int h = 0; h < CF; ++h) gp[c][h] = 0.f;
+    for (long v = (long)blockIdx.x * blockDim.x + threadIdx.x; v < V; v += (long)gridDim.x * blockDim.x) {
+        float a[CF], e[CF], da_[CF];
+        load8(fs + ((long)b * V + v) * CF, a);
+        load8(ft + ((long)b * V + v) * CF, e);
+        float na = 0.f, ne = 0.f;
+#pragma unroll
+        for (int h = 0; h < CF; ++h) { na += a[h] * a[h]; ne += e[h] * e[h]; da_[h] = 0.f; }
+        const float nra = sqrtf(na), nre = sqrtf(ne);
+        const float Na = fmaxf(nra, eps), ia = 1.f / Na, ie = 1.f / fmaxf(nre, eps);
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            if (P.valid[c] == 0.f) continue;
+            float da = 0.f, de = 0.f;
+#pragma unroll
+            for (int h = 0; h < CF; ++h) { da += a[h] * P.ps[c][h]; de += e[h] * P.pt[c][h]; }
+            const float Np = fmaxf(P.nps[c], eps);
+            const float sim_s = da * ia / Np, sim_t = de * ie / fmaxf(P.npt[c], eps);
+            const float gs = kk * (sim_s - sim_t);  // dL/dsim_s
+            // d sim / d fs = p/(Na Np) - [|fs|>eps] sim fs/(|fs| Na) ;  d sim / d p = fs/(Na Np) - [|p|>eps] sim p/(|p| Np)
+            const float ca = (nra > eps) ? sim_s / (nra * Na) : 0.f;
+            const float cp = (P.nps[c] > eps) ? sim_s / (P.nps[c] * Np) : 0.f;
+#pragma unroll
+            for (int h = 0; h < CF; ++h) {
+                da_[h] += gs * (P.ps[c][h] * ia / Np - ca * a[h]);
+                gp[c][h] += gs * (a[h] * ia / Np - cp * P.ps[c][h]);
+            }
+        }
+        store8(dfs + ((long)b * V + v) * CF, da_);
+    }
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+#pragma unroll
+        for (int h = 0; h < CF; ++h) {
+            const float s = wave_sum(gp[c][h]);
+            if (lane == 0) red[wv][c * CF + h] = s;
+        }
+    __syncthreads();
+    if (threadIdx.x < NC * CF) {
+        const int j = threadIdx.x;
+        atomicAdd(&work[(long)b * PW + 4 + 8 * CF + j], red[0][j] + red[1][j] + red[2][j] + red[3][j]);
+    }
+}
+
+// backward pass 2: prototypes are masked means of fs, so every voxel of class c receives Gp[c]/(count_c+eps)
+template <typename T>
+__global__ void proto_bwd2_kernel(const float* __restrict__ tg, long V, const float* __restrict__ work,
+                                  T* __restrict__ dfs) {
+    const int b = blockIdx.y;
+    const float eps = 1e-5f;
+    float gpn[NC][CF];
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+#pragma unroll
+        for (int h = 0; h < CF; ++h) gpn[c][h] = work[(long)b * PW + pw_gp(c, h)] / (work[(long)b * PW + c] + eps);
+    for (long v = (long)blockIdx.x * blockDim.x + threadIdx.x; v < V; v += (long)gridDim.x * blockDim.x) {
+        float d[CF];
+        load8(dfs + ((long)b * V + v) * CF, d);
+        const f32x4 t = load4(tg + ((long)b * V + v) * 4);
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+#pragma unroll
+            for (int h = 0; h < CF; ++h) d[h] += t[c] * gpn[c][h];
+        store8(dfs + ((long)b * V + v) * CF, d);
+    }
+}
+
+inline int vgrid(long V) { return (int)hmin((V + 255) / 256, 2048); }
+inline int vgrid_red(long V) { return (int)hmin((V + 256 * 4 - 1) / (256 * 4), 1024); }
+
+}  // namespace
+
+extern "C" int passion_softmax_fwd(const float* logits, int64_t lsb, int64_t lsv, int64_t lsc, float* probs, int64_t psb,
+                                   int64_t psv, int64_t psc, int B, int64_t V, int C, float inv_temp, void* stream) {
+    if (C != NC) return -1012;
+    hipLaunchKernelGGL(softmax_fwd_kernel, dim3(vgrid((long)B * V)), dim3(256), 0, (hipStream_t)stream, logits, (long)lsb,
+                       (long)lsv, (long)lsc, probs, (long)psb, (long)psv, (long)psc, B, (long)V, inv_temp);
+    LAUNCH_RET();
+    return 0;
+}
+
+extern "C" int passion_softmax_bwd(const float* probs, int64_t psb, int64_t psv, int64_t psc, const float* dprobs,
+                                   int64_t gsb, int64_t gsv, int64_t gsc, float* dlogits, int64_t lsb, int64_t lsv,
+                                   int64_t lsc, int B, int64_t V, int C, float inv_temp, void* stream) {
+    if (C != NC) return -1012;
+    hipLaunchKernelGGL(softmax_bwd_kernel, dim3(vgrid((long)B * V)), dim3(256), 0, (hipStream_t)stream, probs, (long)psb,
+                       (long)psv, (long)psc, dprobs, (long)gsb, (long)gsv, (long)gsc, dlogits, (long)lsb, (long)lsv,
+                       (long)lsc, B, (long)V, inv_temp);
+    LAUNCH_RET();
+    return 0;
+}
+
+extern "C" int passion_target_to_cl(const void* target, int is_f64, float* out, int B, int64_t V, int C, void* stream) {
+    if (C != NC) return -1012;
+    if (is_f64)
+        hipLaunchKernelGGL(target_to_cl_kernel<double>, dim3(vgrid((long)B * V)), dim3(256), 0, (hipStream_t)stream,
+                           (const double*)target, out, B, (long)V);
+    else
+        hipLaunchKernelGGL(target_to_cl_kernel<float>, dim3(vgrid((long)B * V)), dim3(256), 0, (hipStream_t)stream,
+                           (const float*)target, out, B, (long)V);
+    LAUNCH_RET();
+    return 0;
+}
+
+extern "C" int passion_copy_strided(const void* src, int sdtype, int64_t ssb, int64_t ssv, int64_t ssc, void* dst,
+                                    int ddtype, int64_t dsb, int64_t dsv, int64_t dsc, int B, int64_t V, int C,
+                                    void* stream) {
+    const int g = vgrid((long)B * V * C);
+    hipStream_t st = (hipStream_t)stream;
+#define CPY(TS, TD)                                                                                               \
+    hipLaunchKernelGGL((copy_strided_kernel<TS, TD>), dim3(g), dim3(256), 0, st, (const TS*)src, (long)ssb, (long)ssv, \
+                       (long)ssc, (TD*)dst, (long)dsb, (long)dsv, (long)dsc, B, (long)V, C)
+    if (sdtype == PASSION_F32 && ddtype == PASSION_F32) CPY(float, float);
+    else if (sdtype == PASSION_F32 && ddtype == PASSION_BF16) CPY(float, bf16_t);
+    else if (sdtype == PASSION_BF16 && ddtype == PASSION_F32) CPY(bf16_t, float);
+    else if (sdtype == PASSION_BF16 && ddtype == PASSION_BF16) CPY(bf16_t, bf16_t);
+    else return -1007;
+#undef CPY
+    LAUNCH_RET();
+    return 0;
+}
+
+extern "C" int passion_wce_dice_fwd(const float* probs, int64_t psb, int64_t psv, int64_t psc, const float* target,
+                                    int B, int64_t V, int C, float* sums, float* out, void* stream) {
+    if (C != NC) return -1012;
+    hipStream_t st = (hipStream_t)stream;
+    HIP_RET(hipMemsetAsync(sums, 0, sizeof(float) * 16 * (size_t)B, st));
+    hipLaunchKernelGGL(wce_dice_sums_kernel, dim3(vgrid_red(V), B), dim3(256), 0, st, probs, (long)psb, (long)psv,
+                       (long)psc, target, (long)V, sums);
+    LAUNCH_RET();
+    hipLaunchKernelGGL(wce_dice_final_kernel, dim3((B + 63) / 64), dim3(64), 0, st, sums, B, (long)V, out);
+    LAUNCH_RET();
+    return 0;
+}
+
+extern "C" int passion_wce_dice_bwd(const float* probs, int64_t psb, int64_t psv, int64_t psc, const float* target,
+                                    const float* sums, const float* g, float* dprobs, int B, int64_t V, int C,
+                                    void* stream) {
+    if (C != NC) return -1012;
+    hipLaunchKernelGGL(wce_dice_bwd_kernel, dim3(vgrid(V), B), dim3(256), 0, (hipStream_t)stream, probs, (long)psb,
+                       (long)psv, (long)psc, target, sums, g, dprobs, (long)V);
+    LAUNCH_RET();
+    return 0;
+}
+
+extern "C" int passion_kl_fwd(const float* ps, const float* pt, int B, int64_t V, int C, float temp, float* out,
+                              void* stream) {
+    if (C != NC) return -1012;
+    hipStream_t st = (hipStream_t)stream;
+    HIP_RET(hipMemsetAsync(out, 0, sizeof(float) * (size_t)B, st));
+    const float k = temp * temp / ((float)NC * (float)V);
+    hipLaunchKernelGGL(kl_fwd_kernel, dim3(vgrid_red(V), B), dim3(256), 0, st, ps, pt, (long)V, k, out);
+    LAUNCH_RET();
+    return 0;
+}
+
+extern "C" int passion_kl_bwd(const float* ps, const float* pt, const float* g, float* dps, int B, int64_t V, int C,
+                              float temp, void* stream) {
+    if (C != NC) return -1012;
+    const float k = temp * temp / ((float)NC * (float)V);
+    hipLaunchKernelGGL(kl_bwd_kernel, dim3(vgrid(V), B), dim3(256), 0, (hipStream_t)stream, ps, pt, g, dps, (long)V, k);
+    LAUNCH_RET();
+    return 0;
+}
+
+extern "C" int64_t passion_proto_work_floats(int B, int Cf) { (void)Cf; return (int64_t)B * PW + 8; }
+
+extern "C" int passion_proto_fwd(const void* fs, const void* ft, int dtype, const float* target, int B, int64_t V,
+                                 int Cf, float* work, float* out, void* stream) {
+    if (Cf != CF) return -1013;
+    hipStream_t st = (hipStream_t)stream;
+    HIP_RET(hipMemsetAsync(work, 0, sizeof(float) * (size_t)passion_proto_work_floats(B, Cf), st));
+    dim3 grid(vgrid_red(V), B);
+    if (dtype == PASSION_F32)
+        hipLaunchKernelGGL(proto_sums_kernel<float>, grid, dim3(256), 0, st, (const float*)fs, (const float*)ft, target, (long)V, work);
+    else if (dtype == PASSION_BF16)
+        hipLaunchKernelGGL(proto_sums_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)fs, (const bf16_t*)ft, target, (long)V, work);
+    else
+        return -1007;
+    LAUNCH_RET();
+    hipLaunchKernelGGL(proto_valid_kernel, dim3(1), dim3(64), 0, st, work, B);
+    LAUNCH_RET();
+    if (dtype == PASSION_F32)
+        hipLaunchKernelGGL(proto_loss_kernel<float>, grid, dim3(256), 0, st, (const float*)fs, (const float*)ft, (long)V, B, work);
+    else
+        hipLaunchKernelGGL(proto_loss_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)fs, (const bf16_t*)ft, (long)V, B, work);
+    LAUNCH_RET();
+    hipLaunchKernelGGL(proto_out_kernel, dim3((B + 63) / 64), dim3(64), 0, st, work, B, out);
+    LAUNCH_RET();
+    return 0;
+}
+
+extern "C" int passion_proto_bwd(const void* fs, const void* ft, int dtype, const float* target, const float* g, int B,
+                                 int64_t V, int Cf, float* work, void* dfs, void* stream) {
+    if (Cf != CF) return -1013;
+    hipStream_t st = (hipStream_t)stream;
+    // `work` still holds the forward's sums / validity; only the Gp block is re-zeroed
+    for (int b = 0; b < B; ++b)
+        HIP_RET(hipMemsetAsync(work + (long)b * PW + 4 + 8 * CF, 0, sizeof(float) * 4 * CF, st));
+    dim3 grid(vgrid_red(V), B);
+    dim3 grid2(vgrid(V), B);
+    if (dtype == PASSION_F32) {
+        hipLaunchKernelGGL(proto_bwd1_kernel<float>, grid, dim3(256), 0, st, (const float*)fs, (const float*)ft, g, (long)V, B, work, (float*)dfs);
+        LAUNCH_RET();
+        hipLaunchKernelGGL(proto_bwd2_kernel<float>, grid2, dim3(256), 0, st, target, (long)V, work, (float*)dfs);
+    } else if (dtype == PASSION_BF16) {
+        hipLaunchKernelGGL(proto_bwd1_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)fs, (const bf16_t*)ft, g, (long)V, B, work, (bf16_t*)dfs);
+        LAUNCH_RET();
+        hipLaunchKernelGGL(proto_bwd2_kernel<bf16_t>, grid2, dim3(256), 0, st, target, (long)V, work, (bf16_t*)dfs);
+    } else
+        return -1007;
+    LAUNCH_RET();
+    return 0;
+}

@@ -1,0 +1,155 @@
+// Trilinear x k resampling with align_corners=True on channels-last volumes.
+// Replaces nn.Upsample(scale_factor=k, mode='trilinear', align_corners=True)
+// (reference code/models/mmformer.py:70,75,80,85,143,366-370).  Source index arithmetic follows
+// ATen's area_pixel_compute_source_index: src = dst * (in-1)/(out-1) evaluated in f32.
+// Forward is an 8-tap gather; backward is the exact adjoint written as a gather as well (every input
+// voxel sums the output voxels that referenced it), so there are no atomics and the result is
+// deterministic.  For large k a whole wavefront shares one input voxel and reduces with shuffles.
+#include "common.h"
+#include "passion_hip.h"
+
+namespace {
+
+struct Src { int i0, i1; float l0, l1; };
+
+__device__ __forceinline__ Src src_index(int o, float scale, int in) {
+    Src s;
+    const float r = scale * (float)o;
+    s.i0 = (int)r;
+    if (s.i0 > in - 1) s.i0 = in - 1;
+    s.i1 = s.i0 + (s.i0 < in - 1 ? 1 : 0);
+    s.l1 = r - (float)s.i0;
+    s.l0 = 1.f - s.l1;
+    return s;
+}
+
+__host__ __device__ inline float axis_scale(int in, int out) { return out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f; }
+
+template <typename T>
+__global__ __launch_bounds__(256) void upsample_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int B, int D,
+                                                           int H, int W, int C, int k) {
+    const int Do = D * k, Ho = H * k, Wo = W * k, cvn = C / 4;
+    const float sd = axis_scale(D, Do), sh = axis_scale(H, Ho), sw = axis_scale(W, Wo);
+    const long total = (long)B * Do * Ho * Wo * cvn;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int cv = (int)(i % cvn);
+        long v = i / cvn;
+        const int ow = (int)(v % Wo); v /= Wo;
+        const int oh = (int)(v % Ho); v /= Ho;
+        const int od = (int)(v % Do);
+        const int b = (int)(v / Do);
+        const Src a = src_index(od, sd, D), e = src_index(oh, sh, H), f = src_index(ow, sw, W);
+        const T* xb = x + (long)b * D * H * W * C + cv * 4;
+#define AT(dd, hh, ww) load4(xb + ((((long)(dd)) * H + (hh)) * W + (ww)) * C)
+        f32x4 r = a.l0 * (e.l0 * (f.l0 * AT(a.i0, e.i0, f.i0) + f.l1 * AT(a.i0, e.i0, f.i1)) +
+                          e.l1 * (f.l0 * AT(a.i0, e.i1, f.i0) + f.l1 * AT(a.i0, e.i1, f.i1))) +
+                  a.l1 * (e.l0 * (f.l0 * AT(a.i1, e.i0, f.i0) + f.l1 * AT(a.i1, e.i0, f.i1)) +
+                          e.l1 * (f.l0 * AT(a.i1, e.i1, f.i0) + f.l1 * AT(a.i1, e.i1, f.i1)));
+#undef AT
+        store4(y + i * 4, r);
+    }
+}
+
+// weight with which output index o reads input index i along one axis
+__device__ __forceinline__ float axis_weight(int o, int i, float scale, int in) {
+    const Src s = src_index(o, scale, in);
+    float w = 0.f;
+    if (s.i0 == i) w += s.l0;
+    if (s.i1 == i && s.i1 != s.i0) w += s.l1;
+    if (s.i1 == i && s.i1 == s.i0) w += s.l1;  // clamped edge: both taps hit the same voxel
+    return w;
+}
+
+__device__ __forceinline__ void axis_range(int i, float scale, int out, int& lo, int& hi) {
+    // outputs whose source coordinate lies in (i-1, i+1); widened by one on each side for rounding safety
+    if (scale <= 0.f) { lo = 0; hi = out - 1; return; }
+    lo = (int)floorf((float)(i - 1) / scale) - 1;
+    hi = (int)ceilf((float)(i + 1) / scale) + 1;
+    if (lo < 0) lo = 0;
+    if (hi > out - 1) hi = out - 1;
+}
+
+// G lanes cooperate on one (input voxel, 4-channel vector).
+template <typename T, int G>
+__global__ __launch_bounds__(256) void upsample_bwd_kernel(const T* __restrict__ dy, T* __restrict__ dx, int B, int D,
+                                                           int H, int W, int C, int k) {
+    const int Do = D * k, Ho = H * k, Wo = W * k, cvn = C / 4;
+    const float sd = axis_scale(D, Do), sh = axis_scale(H, Ho), sw = axis_scale(W, Wo);
+    const long items = (long)B * D * H * W * cvn;
+    const int sub = threadIdx.x % G;
+    for (long it = ((long)blockIdx.x * blockDim.x + threadIdx.x) / G; it < items + (G > 1 ? 0 : 0);
+         it += ((long)gridDim.x * blockDim.x) / G) {
+        const int cv = (int)(it % cvn);
+        long v = it / cvn;
+        const int iw = (int)(v % W); v /= W;
+        const int ih = (int)(v % H); v /= H;
+        const int id = (int)(v % D);
+        const int b = (int)(v / D);
+        int dlo, dhi, hlo, hhi, wlo, whi;
+        axis_range(id, sd, Do, dlo, dhi);
+        axis_range(ih, sh, Ho, hlo, hhi);
+        axis_range(iw, sw, Wo, wlo, whi);
+        const int nd = dhi - dlo + 1, nh = hhi - hlo + 1, nw = whi - wlo + 1;
+        const T* dyb = dy + (long)b * Do * Ho * Wo * C + cv * 4;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int j = sub; j < nd * nh * nw; j += G) {
+            const int ow = wlo + j % nw, oh = hlo + (j / nw) % nh, od = dlo + j / (nw * nh);
+            const float wd = axis_weight(od, id, sd, D);
+            if (wd == 0.f) continue;
+            const float wh = axis_weight(oh, ih, sh, H);
+            if (wh == 0.f) continue;
+            const float ww = axis_weight(ow, iw, sw, W);
+            if (ww == 0.f) continue;
+            acc += (wd * wh * ww) * load4(dyb + ((((long)od) * Ho + oh) * Wo + ow) * C);
+        }
+        if (G > 1) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] = wave_sum(acc[j]);
+        }
+        if (sub == 0) store4(dx + it * 4, acc);
+    }
+}
+
+}  // namespace
+
+extern "C" int passion_upsample_fwd(const void* x, void* y, int dtype, int B, int D, int H, int W, int C, int k,
+                                    void* stream) {
+    if (C % 4 || k < 1) return -1011;
+    const long total = (long)B * D * k * H * k * W * k * (C / 4);
+    const int blocks = (int)hmin((total + 255) / 256, 8192);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == PASSION_F32)
+        hipLaunchKernelGGL(upsample_fwd_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)x, (float*)y, B, D, H, W, C, k);
+    else if (dtype == PASSION_BF16)
+        hipLaunchKernelGGL(upsample_fwd_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y, B, D, H, W, C, k);
+    else
+        return -1007;
+    LAUNCH_RET();
+    return 0;
+}
+
+extern "C" int passion_upsample_bwd(const void* dy, void* dx, int dtype, int B, int D, int H, int W, int C, int k,
+                                    void* stream) {
+    if (C % 4 || k < 1) return -1011;
+    const long items = (long)B * D * H * W * (C / 4);
+    hipStream_t st = (hipStream_t)stream;
+    if (k <= 2) {
+        const int blocks = (int)hmin((items + 255) / 256, 8192);
+        if (dtype == PASSION_F32)
+            hipLaunchKernelGGL((upsample_bwd_kernel<float, 1>), dim3(blocks), dim3(256), 0, st, (const float*)dy, (float*)dx, B, D, H, W, C, k);
+        else if (dtype == PASSION_BF16)
+            hipLaunchKernelGGL((upsample_bwd_kernel<bf16_t, 1>), dim3(blocks), dim3(256), 0, st, (const bf16_t*)dy, (bf16_t*)dx, B, D, H, W, C, k);
+        else
+            return -1007;
+    } else {
+        const int blocks = (int)hmin((items + 3) / 4, 16384);
+        if (dtype == PASSION_F32)
+            hipLaunchKernelGGL((upsample_bwd_kernel<float, 64>), dim3(blocks), dim3(256), 0, st, (const float*)dy, (float*)dx, B, D, H, W, C, k);
+        else if (dtype == PASSION_BF16)
+            hipLaunchKernelGGL((upsample_bwd_kernel<bf16_t, 64>), dim3(blocks), dim3(256), 0, st, (const bf16_t*)dy, (bf16_t*)dx, B, D, H, W, C, k);
+        else
+            return -1007;
+    }
+    LAUNCH_RET();
+    return 0;
+}

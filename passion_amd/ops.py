@@ -1,0 +1,468 @@
+"""torch.autograd.Function wrappers over the C ABI of libpassion_hip.so.
+
+Internal activation layout is channels-last 5-D: (B, D, H, W, C) contiguous, f32 or bf16.
+torch is used for memory, streams and autograd bookkeeping only -- every op below runs a
+hand-written HIP kernel, and raises if the library or a GPU tensor is missing.
+"""
+from ctypes import byref, c_void_p
+
+import torch
+
+from . import _lib as L
+
+
+def _p(t):
+    return c_void_p(t.data_ptr()) if t is not None else c_void_p(0)
+
+
+def _p_off(t, off_elems):
+    return c_void_p(t.data_ptr() + off_elems * t.element_size())
+
+
+# ------------------------------------------------------------------------------------------------
+# InstanceNorm statistics
+# ------------------------------------------------------------------------------------------------
+def instnorm_stats(x, eps=1e-5):
+    """(mean, rstd) per (b, c) of a channels-last (B,D,H,W,C) tensor -> f32 (B, C, 2).
+    Statistics half of nn.InstanceNorm3d (reference blocks.py:18); not differentiated directly:
+    the conv block's backward carries the InstanceNorm gradient analytically."""
+    L.require_gpu(x)
+    assert x.dim() == 5 and x.is_contiguous()
+    B, D, H, W, C = x.shape
+    V = D * H * W
+    scratch = torch.empty(B * C * 2, dtype=torch.float64, device=x.device)
+    stats = torch.empty(B, C, 2, dtype=torch.float32, device=x.device)
+    rc = L.load().passion_instnorm_stats(_p(x), L.dtype_code(x.dtype), B, V, C, V * C, eps,
+                                         _p(scratch), _p(stats), L.stream_ptr())
+    L.check(rc, "passion_instnorm_stats")
+    return stats
+
+
+# ------------------------------------------------------------------------------------------------
+# conv block
+# ------------------------------------------------------------------------------------------------
+class SegIn:
+    """One tensor of the virtual channel concatenation feeding a conv.
+
+    x        : channels-last (B,D,H,W,C) tensor -- or any tensor when C/offset/bstride are given
+               explicitly (used for the raw NCDHW input, one modality = one C=1 segment).
+    stats    : (B,C,2) from instnorm_stats -> loader applies InstanceNorm + LeakyReLU; None -> raw.
+    mask     : (B,K) bool tensor of present modalities and the column to read; absent => zeros.
+    """
+
+    def __init__(self, x, stats=None, mask=None, mask_col=0, C=None, offset=0, bstride=None):
+        self.x, self.stats, self.mask, self.mask_col = x, stats, mask, mask_col
+        self.C = x.shape[-1] if C is None else C
+        self.offset = offset
+        self.bstride = (x[0].numel() if bstride is None else bstride)
+
+
+class _ConvCfg:
+    __slots__ = ("segs", "D", "H", "W", "ksize", "stride", "pad_mode", "slope", "out_dtype", "B")
+
+
+def pack_weight(weight, cache=None):
+    """f32 (Cout,Cin,k,k,k) -> packed MFMA operand images (fwd + dgrad); cached per weight version."""
+    key = (weight.data_ptr(), weight._version)
+    if cache is not None and cache.get("key") == key:
+        return cache["packed"]
+    L.require_gpu(weight)
+    Cout, Cin, k = weight.shape[0], weight.shape[1], weight.shape[2]
+    lib = L.load()
+    n = lib.passion_conv_pack_floats(Cin, Cout, k)
+    packed = torch.empty(n, dtype=torch.float32, device=weight.device)
+    w = weight.detach()
+    if w.dtype != torch.float32 or not w.is_contiguous():
+        w = w.float().contiguous()
+    L.check(lib.passion_conv_pack_weight(_p(w), Cin, Cout, k, _p(packed), L.stream_ptr()),
+            "passion_conv_pack_weight")
+    if cache is not None:
+        cache["key"], cache["packed"] = key, packed
+    return packed
+
+
+def _fill_desc(cfg, xs, dxs=None):
+    d = L.ConvDesc()
+    d.x_dtype = L.dtype_code(xs[0].dtype) if xs[0].dtype != torch.float64 else L.F32
+    d.y_dtype = L.dtype_code(cfg.out_dtype)
+    d.B, d.D, d.H, d.W = cfg.B, cfg.D, cfg.H, cfg.W
+    d.ksize, d.stride, d.pad_mode = cfg.ksize, cfg.stride, cfg.pad_mode
+    d.nseg = len(cfg.segs)
+    d.lrelu_slope = cfg.slope
+    for i, (s, x) in enumerate(zip(cfg.segs, xs)):
+        sg = d.seg[i]
+        sg.x = x.data_ptr() + s.offset * x.element_size()
+        sg.stats = s.stats.data_ptr() if s.stats is not None else None
+        sg.mask = s.mask.data_ptr() if s.mask is not None else None
+        sg.mask_col = s.mask_col
+        sg.mask_ld = s.mask.shape[1] if s.mask is not None else 0
+        sg.C = s.C
+        sg.bstride = s.bstride
+        sg.dx = dxs[i].data_ptr() if (dxs is not None and dxs[i] is not None) else None
+    return d
+
+
+class ConvBlockFn(torch.autograd.Function):
+    """y = Conv3d(LeakyReLU(InstanceNorm(masked concat(xs)))) + bias (+ residual)
+    -- general_conv3d_prenorm (reference blocks.py:300-316) with the norm/activation/mask/pad/concat
+    folded into the conv's loader; with stats=None it is a bare nn.Conv3d."""
+
+    @staticmethod
+    def forward(ctx, cfg, weight, bias, residual, packed, *xs):
+        L.require_gpu(weight, *xs)
+        lib = L.load()
+        Cout = weight.shape[0]
+        pad = cfg.ksize // 2
+        Do = (cfg.D + 2 * pad - cfg.ksize) // cfg.stride + 1
+        Ho = (cfg.H + 2 * pad - cfg.ksize) // cfg.stride + 1
+        Wo = (cfg.W + 2 * pad - cfg.ksize) // cfg.stride + 1
+        y = torch.empty(cfg.B, Do, Ho, Wo, Cout, dtype=cfg.out_dtype, device=weight.device)
+        d = _fill_desc(cfg, xs)
+        d.Cout = Cout
+        b32 = bias.detach().float() if bias is not None else None
+        if residual is not None:
+            assert residual.shape == y.shape and residual.dtype == y.dtype and residual.is_contiguous()
+        L.check(lib.passion_conv3d_fwd(byref(d), _p(packed), _p(b32), _p(residual), _p(y),
+                                       L.stream_ptr()), "passion_conv3d_fwd")
+        ctx.cfg, ctx.packed, ctx.has_bias, ctx.has_res = cfg, packed, bias is not None, residual is not None
+        ctx.wshape = weight.shape
+        ctx.save_for_backward(*xs)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        cfg, xs = ctx.cfg, ctx.saved_tensors
+        lib = L.load()
+        dy = dy.contiguous()
+        need_w = ctx.needs_input_grad[1]
+        need_b = ctx.has_bias and ctx.needs_input_grad[2]
+        dev = dy.device
+        dW = torch.zeros(ctx.wshape, dtype=torch.float32, device=dev) if need_w else None
+        db = torch.zeros(ctx.wshape[0], dtype=torch.float32, device=dev) if need_b else None
+        dxs = []
+        for i, (s, x) in enumerate(zip(cfg.segs, xs)):
+            if ctx.needs_input_grad[5 + i]:
+                assert s.offset == 0, "gradient wrt an offset view is not supported"
+                dxs.append(torch.empty_like(x))
+            else:
+                dxs.append(None)
+        d = _fill_desc(cfg, xs, dxs)
+        d.Cout = ctx.wshape[0]
+        cin = sum(s.C for s in cfg.segs)
+        sums = torch.empty(cfg.B * cin * 2, dtype=torch.float32, device=dev)
+        L.check(lib.passion_conv3d_bwd(byref(d), _p(ctx.packed), _p(dy), _p(dW), _p(db), _p(sums),
+                                       L.stream_ptr()), "passion_conv3d_bwd")
+        dres = dy if (ctx.has_res and ctx.needs_input_grad[3]) else None
+        return (None, dW, db, dres, None, *dxs)
+
+
+def conv_block(segs, weight, bias, D, H, W, ksize=3, stride=1, pad_mode=L.PAD_REFLECT,
+               residual=None, out_dtype=None, slope=0.2, pack_cache=None):
+    cfg = _ConvCfg()
+    cfg.segs, cfg.D, cfg.H, cfg.W = segs, D, H, W
+    cfg.ksize, cfg.stride, cfg.pad_mode, cfg.slope = ksize, stride, pad_mode, slope
+    cfg.B = segs[0].x.shape[0]
+    x0 = segs[0].x
+    cfg.out_dtype = out_dtype if out_dtype is not None else (x0.dtype if x0.dtype != torch.float64 else torch.float32)
+    packed = pack_weight(weight, pack_cache)
+    return ConvBlockFn.apply(cfg, weight, bias, residual, packed, *[s.x for s in segs])
+
+
+# ------------------------------------------------------------------------------------------------
+# trilinear upsampling
+# ------------------------------------------------------------------------------------------------
+class UpsampleFn(torch.autograd.Function):
+    """nn.Upsample(scale_factor=k, mode='trilinear', align_corners=True) on (B,D,H,W,C)."""
+
+    @staticmethod
+    def forward(ctx, x, k):
+        L.require_gpu(x)
+        x = x.contiguous()
+        B, D, H, W, C = x.shape
+        y = torch.empty(B, D * k, H * k, W * k, C, dtype=x.dtype, device=x.device)
+        L.check(L.load().passion_upsample_fwd(_p(x), _p(y), L.dtype_code(x.dtype), B, D, H, W, C, k,
+                                              L.stream_ptr()), "passion_upsample_fwd")
+        ctx.k, ctx.shape = k, (B, D, H, W, C)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, D, H, W, C = ctx.shape
+        dy = dy.contiguous()
+        dx = torch.empty(B, D, H, W, C, dtype=dy.dtype, device=dy.device)
+        L.check(L.load().passion_upsample_bwd(_p(dy), _p(dx), L.dtype_code(dy.dtype), B, D, H, W, C,
+                                              ctx.k, L.stream_ptr()), "passion_upsample_bwd")
+        return dx, None
+
+
+def upsample(x, k):
+    return x if k == 1 else UpsampleFn.apply(x, k)
+
+
+# ------------------------------------------------------------------------------------------------
+# class softmax, target layout
+# ------------------------------------------------------------------------------------------------
+def _strides(t, layout):
+    """element strides (batch, voxel, class) of a 4-class f32 tensor in 'cl' or 'ncdhw' layout"""
+    if layout == "cl":
+        B, D, H, W, C = t.shape
+        V = D * H * W
+        return B, V, C, (V * C, C, 1)
+    B, C, D, H, W = t.shape
+    V = D * H * W
+    return B, V, C, (C * V, 1, V)
+
+
+class SoftmaxFn(torch.autograd.Function):
+    """softmax(logits * inv_temp) over the class axis.  logits: f32 channels-last (B,D,H,W,4);
+    output channels-last or NCDHW (B,4,D,H,W) -- the layout the reference Model returns."""
+
+    @staticmethod
+    def forward(ctx, logits, inv_temp, out_layout):
+        L.require_gpu(logits)
+        logits = logits.contiguous()
+        assert logits.dtype == torch.float32
+        B, D, H, W, C = logits.shape
+        V = D * H * W
+        if out_layout == "cl":
+            probs = torch.empty_like(logits)
+        else:
+            probs = torch.empty(B, C, D, H, W, dtype=torch.float32, device=logits.device)
+        _, _, _, ps = _strides(probs, out_layout)
+        L.check(L.load().passion_softmax_fwd(_p(logits), V * C, C, 1, _p(probs), *ps, B, V, C,
+                                             float(inv_temp), L.stream_ptr()), "passion_softmax_fwd")
+        ctx.inv_temp, ctx.layout = float(inv_temp), out_layout
+        ctx.save_for_backward(probs)
+        return probs
+
+    @staticmethod
+    def backward(ctx, dprobs):
+        (probs,) = ctx.saved_tensors
+        dprobs = dprobs.contiguous()
+        B, V, C, ps = _strides(probs, ctx.layout)
+        if ctx.layout == "cl":
+            dl = torch.empty_like(probs)
+        else:
+            dl = torch.empty(B, probs.shape[2], probs.shape[3], probs.shape[4], C, dtype=torch.float32,
+                             device=probs.device)
+        L.check(L.load().passion_softmax_bwd(_p(probs), *ps, _p(dprobs), *ps, _p(dl), V * C, C, 1, B, V, C,
+                                             ctx.inv_temp, L.stream_ptr()), "passion_softmax_bwd")
+        return dl, None, None
+
+
+def softmax_classes(logits, inv_temp=1.0, out_layout="cl"):
+    return SoftmaxFn.apply(logits, inv_temp, out_layout)
+
+
+def target_to_cl(target):
+    """one-hot target (B,4,D,H,W) f64/f32 (datasets_nii.py:151-153) -> f32 channels-last (B,D,H,W,4)"""
+    L.require_gpu(target)
+    cached = getattr(target, "_passion_cl", None)
+    if cached is not None and cached[0] == target._version:
+        return cached[1]
+    t = target.contiguous()
+    B, C, D, H, W = t.shape
+    out = torch.empty(B, D, H, W, C, dtype=torch.float32, device=t.device)
+    if t.dtype not in (torch.float32, torch.float64):
+        t = t.float()
+    L.check(L.load().passion_target_to_cl(_p(t), 1 if t.dtype == torch.float64 else 0, _p(out), B, D * H * W, C,
+                                          L.stream_ptr()), "passion_target_to_cl")
+    try:
+        target._passion_cl = (target._version, out)
+    except Exception:
+        pass
+    return out
+
+
+def to_channels_last(x, dtype=None):
+    """(B,C,D,H,W) -> (B,D,H,W,C) in `dtype` through the strided-copy kernel (no autograd)."""
+    L.require_gpu(x)
+    x = x.contiguous()
+    B, C, D, H, W = x.shape
+    V = D * H * W
+    dtype = dtype or x.dtype
+    out = torch.empty(B, D, H, W, C, dtype=dtype, device=x.device)
+    L.check(L.load().passion_copy_strided(_p(x), L.dtype_code(x.dtype), C * V, 1, V, _p(out), L.dtype_code(dtype),
+                                          V * C, C, 1, B, V, C, L.stream_ptr()), "passion_copy_strided")
+    return out
+
+
+def to_ncdhw(x, dtype=None):
+    L.require_gpu(x)
+    x = x.contiguous()
+    B, D, H, W, C = x.shape
+    V = D * H * W
+    dtype = dtype or x.dtype
+    out = torch.empty(B, C, D, H, W, dtype=dtype, device=x.device)
+    L.check(L.load().passion_copy_strided(_p(x), L.dtype_code(x.dtype), V * C, C, 1, _p(out), L.dtype_code(dtype),
+                                          C * V, 1, V, B, V, C, L.stream_ptr()), "passion_copy_strided")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# losses
+# ------------------------------------------------------------------------------------------------
+class WceDiceFn(torch.autograd.Function):
+    """(weighted CE, Dice) per sample -- softmax_weighted_loss_bs + dice_loss_bs
+    (reference criterions.py:59-76, 25-38) in one pass over the probabilities."""
+
+    @staticmethod
+    def forward(ctx, probs, target_cl, layout):
+        L.require_gpu(probs, target_cl)
+        probs = probs.contiguous()
+        assert probs.dtype == torch.float32 and target_cl.dtype == torch.float32
+        B, V, C, ps = _strides(probs, layout)
+        sums = torch.empty(B, 16, dtype=torch.float32, device=probs.device)
+        out = torch.empty(B, 2, dtype=torch.float32, device=probs.device)
+        L.check(L.load().passion_wce_dice_fwd(_p(probs), *ps, _p(target_cl), B, V, C, _p(sums), _p(out),
+                                              L.stream_ptr()), "passion_wce_dice_fwd")
+        ctx.layout = layout
+        ctx.save_for_backward(probs, target_cl, sums)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        probs, target_cl, sums = ctx.saved_tensors
+        B, V, C, ps = _strides(probs, ctx.layout)
+        g = g.contiguous().float()
+        dp = torch.empty_like(probs)
+        L.check(L.load().passion_wce_dice_bwd(_p(probs), *ps, _p(target_cl), _p(sums), _p(g), _p(dp), B, V, C,
+                                              L.stream_ptr()), "passion_wce_dice_bwd")
+        return dp, None, None
+
+
+def wce_dice(probs, target_cl, layout="cl"):
+    """-> (B,2): [:,0] weighted cross-entropy, [:,1] Dice loss"""
+    return WceDiceFn.apply(probs, target_cl, layout)
+
+
+class KLFn(torch.autograd.Function):
+    """temp_kl_loss_bs (reference criterions.py:92-103) on probabilities that were already
+    softmaxed with 1/T (and upsampled).  Teacher side carries no gradient (it is detached upstream)."""
+
+    @staticmethod
+    def forward(ctx, ps, pt, temp):
+        L.require_gpu(ps, pt)
+        ps, pt = ps.contiguous(), pt.contiguous()
+        B, D, H, W, C = ps.shape
+        out = torch.empty(B, dtype=torch.float32, device=ps.device)
+        L.check(L.load().passion_kl_fwd(_p(ps), _p(pt), B, D * H * W, C, float(temp), _p(out), L.stream_ptr()),
+                "passion_kl_fwd")
+        ctx.temp = float(temp)
+        ctx.save_for_backward(ps, pt)
+        return out.unsqueeze(1)
+
+    @staticmethod
+    def backward(ctx, g):
+        ps, pt = ctx.saved_tensors
+        B, D, H, W, C = ps.shape
+        g = g.contiguous().float().view(-1)
+        dps = torch.empty_like(ps)
+        L.check(L.load().passion_kl_bwd(_p(ps), _p(pt), _p(g), _p(dps), B, D * H * W, C, ctx.temp, L.stream_ptr()),
+                "passion_kl_bwd")
+        return dps, None, None
+
+
+def kl_probs(ps, pt, temp):
+    return KLFn.apply(ps, pt.detach(), temp)
+
+
+class ProtoFn(torch.autograd.Function):
+    """prototype_passion_loss_bs (reference criterions.py:144-180): per-class masked-mean prototypes,
+    cosine-similarity maps of student and teacher, mean squared / absolute difference."""
+
+    @staticmethod
+    def forward(ctx, fs, ft, target_cl):
+        L.require_gpu(fs, ft, target_cl)
+        fs, ft = fs.contiguous(), ft.contiguous()
+        B, D, H, W, Cf = fs.shape
+        lib = L.load()
+        work = torch.empty(lib.passion_proto_work_floats(B, Cf), dtype=torch.float32, device=fs.device)
+        out = torch.empty(B, 2, dtype=torch.float32, device=fs.device)
+        L.check(lib.passion_proto_fwd(_p(fs), _p(ft), L.dtype_code(fs.dtype), _p(target_cl), B, D * H * W, Cf,
+                                      _p(work), _p(out), L.stream_ptr()), "passion_proto_fwd")
+        ctx.save_for_backward(fs, ft, target_cl, work)
+        loss, dist = out[:, 0:1].clone(), out[:, 1:2].clone()
+        ctx.mark_non_differentiable(dist)
+        return loss, dist
+
+    @staticmethod
+    def backward(ctx, g, _gd):
+        fs, ft, target_cl, work = ctx.saved_tensors
+        B, D, H, W, Cf = fs.shape
+        g = g.contiguous().float().view(-1)
+        dfs = torch.empty_like(fs)
+        L.check(L.load().passion_proto_bwd(_p(fs), _p(ft), L.dtype_code(fs.dtype), _p(target_cl), _p(g), B,
+                                           D * H * W, Cf, _p(work), _p(dfs), L.stream_ptr()), "passion_proto_bwd")
+        return dfs, None, None
+
+
+def proto_loss(fs, ft, target_cl):
+    return ProtoFn.apply(fs, ft.detach(), target_cl)
+
+
+# ------------------------------------------------------------------------------------------------
+# attention
+# ------------------------------------------------------------------------------------------------
+class AttentionFn(torch.autograd.Function):
+    """softmax(q k^T * scale) v for qkv (B,N,3,H,Dh) -> (B,N,H*Dh)  (reference mmformer.py:220-224).
+    `drop_p` > 0 applies attention dropout to the probabilities (mmformer.py:222)."""
+
+    @staticmethod
+    def forward(ctx, qkv, heads, scale, drop_p):
+        L.require_gpu(qkv)
+        qkv = qkv.contiguous()
+        B, N, C3 = qkv.shape
+        Dh = C3 // 3 // heads
+        lib = L.load()
+        dt = L.dtype_code(qkv.dtype)
+        probs = torch.empty(B, heads, N, N, dtype=torch.float32, device=qkv.device)
+        L.check(lib.passion_attn_scores_fwd(_p(qkv), dt, B, N, heads, Dh, float(scale), _p(probs), L.stream_ptr()),
+                "passion_attn_scores_fwd")
+        keep = None
+        pd = probs
+        if drop_p > 0.0:
+            keep = (torch.rand_like(probs) >= drop_p)
+            pd = probs * keep * (1.0 / (1.0 - drop_p))
+        out = torch.empty(B, N, heads * Dh, dtype=qkv.dtype, device=qkv.device)
+        L.check(lib.passion_attn_pv_fwd(_p(pd), _p(qkv), dt, B, N, heads, Dh, _p(out), L.stream_ptr()),
+                "passion_attn_pv_fwd")
+        ctx.heads, ctx.scale, ctx.drop_p = heads, float(scale), drop_p
+        ctx.save_for_backward(qkv, probs, pd if keep is not None else None, keep)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        qkv, probs, pd, keep = ctx.saved_tensors
+        B, N, C3 = qkv.shape
+        H = ctx.heads
+        Dh = C3 // 3 // H
+        lib = L.load()
+        dt = L.dtype_code(qkv.dtype)
+        dout = dout.contiguous()
+        dqkv = torch.empty_like(qkv)
+        dprobs = torch.empty_like(probs)
+        L.check(lib.passion_attn_pv_bwd(_p(pd if pd is not None else probs), _p(qkv), _p(dout), dt, B, N, H, Dh,
+                                        _p(dprobs), _p(dqkv), L.stream_ptr()), "passion_attn_pv_bwd")
+        if keep is not None:
+            dprobs = dprobs * keep * (1.0 / (1.0 - ctx.drop_p))
+        L.check(lib.passion_attn_scores_bwd(_p(probs), _p(dprobs), _p(qkv), dt, B, N, H, Dh, ctx.scale, _p(dqkv),
+                                            L.stream_ptr()), "passion_attn_scores_bwd")
+        return dqkv, None, None, None
+
+
+def attention(qkv, heads, scale, drop_p=0.0):
+    return AttentionFn.apply(qkv, heads, scale, drop_p)
+
+
+# ------------------------------------------------------------------------------------------------
+# kernel timing hooks (bench.py)
+# ------------------------------------------------------------------------------------------------
+def prof_enable(on):
+    L.load().passion_prof_enable(1 if on else 0)
+
+
+def prof_read(cap=65536):
+    recs = (L.ProfRec * cap)()
+    n = L.load().passion_prof_read(recs, cap)
+    return [(recs[i].kind, recs[i].ms, recs[i].bytes, recs[i].flops) for i in range(n)]

@@ -1,0 +1,305 @@
+"""GPU parity of every HIP op (through the C ABI) against plain PyTorch CPU float64 references of
+the reference's ops (F.conv3d / F.instance_norm / F.leaky_relu / F.interpolate / softmax / the
+criterions formulas).  Tolerances: f32 storage 2e-4 relative to the tensor scale, bf16 storage 3e-2."""
+import itertools
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    return torch.device("cuda:0")
+
+
+def cl(x):  # NCDHW -> channels-last 5-D
+    return x.permute(0, 2, 3, 4, 1).contiguous()
+
+
+def nc(x):  # channels-last -> NCDHW
+    return x.permute(0, 4, 1, 2, 3).contiguous()
+
+
+def relerr(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return ((a - b).abs().max() / (b.abs().max() + 1e-12)).item()
+
+
+TOL = {torch.float32: 2e-4, torch.bfloat16: 3e-2}
+
+
+def ref_conv_block(xs, norms, masks, weight, bias, k, stride, pad_mode, residual):
+    parts = []
+    for x, nrm, m in zip(xs, norms, masks):
+        xm = x if m is None else x * m.view(-1, 1, 1, 1, 1).to(x.dtype)
+        parts.append(F.leaky_relu(F.instance_norm(xm, eps=1e-5), 0.2) if nrm else xm)
+    inp = torch.cat(parts, 1)
+    if k == 3:
+        inp = F.pad(inp, (1,) * 6, mode="reflect" if pad_mode == 1 else "constant")
+    y = F.conv3d(inp, weight, bias, stride=stride)
+    if residual is not None:
+        y = y + residual
+    return y
+
+
+CONV_CASES = [
+    # (segC list, Cout, k, stride, pad_mode, (D,H,W), norm, use_mask, residual)
+    ([8], 8, 3, 1, 1, (8, 8, 8), True, False, True),
+    ([8], 16, 3, 2, 1, (8, 16, 8), True, False, False),
+    ([8, 8], 8, 3, 1, 1, (4, 8, 16), True, False, False),
+    ([8], 8, 3, 1, 0, (6, 10, 12), True, False, False),
+    ([8, 8, 8, 8], 8, 1, 1, 0, (8, 8, 8), True, True, False),
+    ([16], 4, 1, 1, 0, (5, 7, 9), False, False, False),
+    ([32], 32, 3, 1, 1, (4, 4, 4), True, False, False),
+    ([128], 128, 3, 1, 1, (2, 2, 2), True, False, False),
+    ([64], 128, 3, 2, 1, (4, 4, 4), True, False, False),
+    ([128, 128], 64, 3, 1, 1, (4, 4, 4), True, False, False),
+    ([2048], 512, 1, 1, 0, (2, 2, 2), False, False, False),
+    ([8], 8, 3, 1, 1, (3, 5, 2), True, False, False),
+]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("case", CONV_CASES, ids=[str(i) for i in range(len(CONV_CASES))])
+def test_conv_block_fwd_bwd(case, dtype):
+    from passion_amd import ops
+    dev = _dev()
+    segC, Cout, k, stride, pad_mode, (D, H, W), norm, use_mask, use_res = case
+    B = 2
+    g = torch.Generator().manual_seed(11)
+    xs = [torch.randn(B, c, D, H, W, generator=g, dtype=torch.float64) * 1.5 + 0.3 for c in segC]
+    cin = sum(segC)
+    w = torch.randn(Cout, cin, k, k, k, generator=g, dtype=torch.float64) / (cin * k ** 3) ** 0.5
+    b = torch.randn(Cout, generator=g, dtype=torch.float64)
+    mask = None
+    if use_mask:
+        mask = torch.tensor([[True, False, True, True], [False, True, True, False]])[:, :len(segC)]
+    # quantise inputs to the storage dtype so both sides see identical values
+    xs = [x.to(dtype).double() for x in xs]
+    pad = k // 2
+    Do, Ho, Wo = [(s + 2 * pad - k) // stride + 1 for s in (D, H, W)]
+    res = (torch.randn(B, Cout, Do, Ho, Wo, generator=g, dtype=torch.float64).to(dtype).double()
+           if use_res else None)
+    gy = torch.randn(B, Cout, Do, Ho, Wo, generator=g, dtype=torch.float64).to(dtype).double()
+
+    xr = [x.clone().requires_grad_(True) for x in xs]
+    wr, br = w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    masks = [None if mask is None else mask[:, i].double() for i in range(len(segC))]
+    yr = ref_conv_block(xr, [norm] * len(segC), masks, wr, br, k, stride, pad_mode, res)
+    yr.backward(gy)
+
+    xd = [cl(x).to(dev, dtype).requires_grad_(True) for x in xs]
+    wd = w.float().to(dev).requires_grad_(True)
+    bd = b.float().to(dev).requires_grad_(True)
+    md = mask.to(dev) if mask is not None else None
+    segs = [ops.SegIn(x, stats=ops.instnorm_stats(x.detach()) if norm else None, mask=md, mask_col=i)
+            for i, x in enumerate(xd)]
+    resd = cl(res).to(dev, dtype) if res is not None else None
+    y = ops.conv_block(segs, wd, bd, D, H, W, ksize=k, stride=stride, pad_mode=pad_mode, residual=resd)
+    y.backward(cl(gy).to(dev, dtype))
+    torch.cuda.synchronize()
+    tol = TOL[dtype]
+    assert relerr(nc(y.detach().float()), yr) < tol, f"fwd {relerr(nc(y.detach().float()), yr)}"
+    assert relerr(wd.grad, wr.grad) < tol * 2, f"dW {relerr(wd.grad, wr.grad)}"
+    assert relerr(bd.grad, br.grad) < tol * 2, f"db {relerr(bd.grad, br.grad)}"
+    for i in range(len(segC)):
+        e = relerr(nc(xd[i].grad.float()), xr[i].grad)
+        assert e < tol * 3, f"dx[{i}] {e}"
+
+
+def test_conv_raw_input_segments():
+    """first encoder conv: one modality of the NCDHW input = one C=1 segment, masked per sample"""
+    from passion_amd import ops
+    dev = _dev()
+    B, S = 2, 8
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(B, 4, S, S, S, generator=g)
+    w = torch.randn(8, 1, 3, 3, 3, generator=g) / 5
+    b = torch.randn(8, generator=g)
+    mask = torch.tensor([[True, False, True, True], [False, True, True, False]])
+    xd, md = x.to(dev), mask.to(dev)
+    wd, bd = w.to(dev).requires_grad_(True), b.to(dev).requires_grad_(True)
+    for m in range(4):
+        seg = ops.SegIn(xd, mask=md, mask_col=m, C=1, offset=m * S ** 3, bstride=4 * S ** 3)
+        y = ops.conv_block([seg], wd, bd, S, S, S, ksize=3, stride=1, pad_mode=1)
+        xm = (x[:, m:m + 1] * mask[:, m].view(B, 1, 1, 1, 1)).double()
+        yr = F.conv3d(F.pad(xm, (1,) * 6, mode="reflect"), w.double(), b.double())
+        assert relerr(nc(y.detach()), yr) < 2e-4
+    y.sum().backward()
+    assert wd.grad is not None and torch.isfinite(wd.grad).all()
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_instnorm_stats(dtype):
+    from passion_amd import ops
+    dev = _dev()
+    x = torch.randn(2, 6, 10, 12, 16, generator=torch.Generator().manual_seed(0)) * 3 + 5
+    x = x.to(dtype)
+    st = ops.instnorm_stats(x.to(dev)).cpu().double()
+    xf = x.double().reshape(2, -1, 16)
+    mean, var = xf.mean(1), xf.var(1, unbiased=False)
+    assert relerr(st[..., 0], mean) < 1e-5
+    assert relerr(st[..., 1], 1 / torch.sqrt(var + 1e-5)) < 1e-5
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("k,C,shape", [(2, 8, (4, 6, 8)), (2, 128, (2, 2, 2)), (4, 4, (4, 4, 4)), (8, 4, (2, 4, 2)),
+                                       (16, 4, (2, 2, 2))])
+def test_upsample(k, C, shape, dtype):
+    from passion_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, C, *shape, generator=g).to(dtype).double()
+    xr = x.clone().requires_grad_(True)
+    yr = F.interpolate(xr, scale_factor=k, mode="trilinear", align_corners=True)
+    gy = torch.randn(yr.shape, generator=g, dtype=torch.float64).to(dtype).double()
+    yr.backward(gy)
+    xd = cl(x).to(dev, dtype).requires_grad_(True)
+    y = ops.upsample(xd, k)
+    y.backward(cl(gy).to(dev, dtype))
+    tol = TOL[dtype]
+    assert relerr(nc(y.detach().float()), yr) < tol
+    assert relerr(nc(xd.grad.float()), xr.grad) < tol * 2
+
+
+def _ref_wce(p, t):
+    B = p.shape[0]
+    out = 0
+    for i in range(4):
+        w = 1.0 - t[:, i].sum((1, 2, 3)) / t.sum((1, 2, 3, 4))
+        out = out - w.view(B, 1, 1, 1) * t[:, i] * torch.log(torch.clamp(p[:, i], 0.005, 1))
+    return out.mean((1, 2, 3))
+
+
+def _ref_dice(p, t):
+    d = 0
+    for i in range(4):
+        num = (p[:, i] * t[:, i]).sum((1, 2, 3))
+        d = d + 2.0 * num / (p[:, i].sum((1, 2, 3)) + t[:, i].sum((1, 2, 3)) + 1e-7)
+    return 1.0 - d / 4
+
+
+def _onehot(B, S, g):
+    lab = torch.randint(0, 4, (B, S, S, S), generator=g)
+    return F.one_hot(lab, 4).permute(0, 4, 1, 2, 3).double()
+
+
+@pytest.mark.parametrize("layout", ["cl", "ncdhw"])
+def test_softmax_wce_dice(layout):
+    from passion_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(9)
+    B, S = 2, 12
+    logits = (torch.randn(B, 4, S, S, S, generator=g) * 4).double()
+    target = _onehot(B, S, g)
+    lr = logits.clone().requires_grad_(True)
+    pr = torch.softmax(lr / 2.0, 1)
+    ce, dice = _ref_wce(pr, target), _ref_dice(pr, target)
+    (ce * torch.tensor([1.0, 2.0]) + dice * torch.tensor([0.5, 3.0])).sum().backward()
+
+    ld = cl(logits).float().to(dev).requires_grad_(True)
+    tcl = ops.target_to_cl(target.to(dev))
+    p = ops.softmax_classes(ld, 0.5, layout)
+    out = ops.wce_dice(p, tcl, layout)
+    (out[:, 0] * torch.tensor([1.0, 2.0], device=dev) + out[:, 1] * torch.tensor([0.5, 3.0], device=dev)).sum().backward()
+    pn = p.detach() if layout == "ncdhw" else nc(p.detach())
+    assert relerr(pn, pr.detach()) < 1e-5
+    assert relerr(out[:, 0].detach(), ce.detach()) < 1e-5
+    assert relerr(out[:, 1].detach(), dice.detach()) < 1e-5
+    assert relerr(nc(ld.grad), lr.grad) < 1e-4
+
+
+def test_kl():
+    from passion_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(10)
+    B, S, T = 2, 10, 4.0
+    ls = (torch.randn(B, 4, S, S, S, generator=g) * 6).double()
+    lt = (torch.randn(B, 4, S, S, S, generator=g) * 6).double()
+    lsr = ls.clone().requires_grad_(True)
+    ps, pt = torch.softmax(lsr / T, 1), torch.softmax(lt / T, 1)
+    psc, ptc = torch.clamp(ps, 0.005, 1), torch.clamp(pt, 0.005, 1)
+    kl = (T * T * ptc * (torch.log(ptc) - torch.log(psc))).mean((1, 2, 3, 4))
+    (kl * torch.tensor([1.0, 2.0])).sum().backward()
+    lsd = cl(ls).float().to(dev).requires_grad_(True)
+    ltd = cl(lt).float().to(dev)
+    out = ops.kl_probs(ops.softmax_classes(lsd, 1 / T), ops.softmax_classes(ltd, 1 / T), T)
+    (out[:, 0] * torch.tensor([1.0, 2.0], device=dev)).sum().backward()
+    assert relerr(out[:, 0].detach(), kl.detach()) < 1e-5
+    assert relerr(nc(lsd.grad), lsr.grad) < 1e-4
+
+
+def _ref_proto(fs, ft, target):
+    eps = 1e-5
+    s, t = [], []
+    for i in range(4):
+        ti = target[:, i]
+        if (ti.sum((-3, -2, -1)) > 0).all():
+            den = ti[:, None].sum((-3, -2, -1)) + eps
+            ps = (fs * ti[:, None]).sum((-3, -2, -1)) / den
+            pt = (ft * ti[:, None]).sum((-3, -2, -1)) / den
+            s.append(F.cosine_similarity(fs, ps[:, :, None, None, None], dim=1, eps=eps).unsqueeze(1))
+            t.append(F.cosine_similarity(ft, pt[:, :, None, None, None], dim=1, eps=eps).unsqueeze(1))
+    s, t = torch.cat(s, 1), torch.cat(t, 1)
+    return ((s - t) ** 2).mean((1, 2, 3, 4)), torch.sqrt((s - t) ** 2).mean((1, 2, 3, 4))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("drop_class", [False, True])
+def test_proto(dtype, drop_class):
+    from passion_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(12)
+    B, S = 2, 8
+    fs = torch.randn(B, 8, S, S, S, generator=g).to(dtype).double()
+    ft = torch.randn(B, 8, S, S, S, generator=g).to(dtype).double()
+    target = _onehot(B, S, g)
+    if drop_class:  # class 3 absent from sample 1 -> skipped for the whole batch (criterions.py:157)
+        t1 = target[1]
+        t1[0] += t1[3]
+        t1[3] = 0
+    fr = fs.clone().requires_grad_(True)
+    loss, dist = _ref_proto(fr, ft, target)
+    (loss * torch.tensor([1.0, 2.0])).sum().backward()
+    fd = cl(fs).to(dev, dtype).requires_grad_(True)
+    lo, di = ops.proto_loss(fd, cl(ft).to(dev, dtype), ops.target_to_cl(target.to(dev)))
+    (lo[:, 0] * torch.tensor([1.0, 2.0], device=dev)).sum().backward()
+    tol = 1e-4 if dtype == torch.float32 else 3e-2
+    assert relerr(lo[:, 0].detach(), loss.detach()) < tol
+    assert relerr(di[:, 0].detach(), dist.detach()) < tol
+    assert relerr(nc(fd.grad.float()), fr.grad) < tol * 3
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("N", [8, 125, 256])
+def test_attention(N, dtype):
+    from passion_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(13)
+    B, Hh, Dh = 2, 8, 64
+    qkv = torch.randn(B, N, 3 * Hh * Dh, generator=g).to(dtype).double()
+    qr = qkv.clone().requires_grad_(True)
+    q, k, v = qr.reshape(B, N, 3, Hh, Dh).permute(2, 0, 3, 1, 4)
+    att = ((q @ k.transpose(-2, -1)) * Dh ** -0.5).softmax(-1)
+    outr = (att @ v).transpose(1, 2).reshape(B, N, Hh * Dh)
+    go = torch.randn(outr.shape, generator=g, dtype=torch.float64).to(dtype).double()
+    outr.backward(go)
+    qd = qkv.to(dev, dtype).requires_grad_(True)
+    out = ops.attention(qd, Hh, Dh ** -0.5)
+    out.backward(go.to(dev, dtype))
+    tol = TOL[dtype]
+    assert relerr(out.detach().float(), outr) < tol
+    assert relerr(qd.grad.float(), qr.grad) < tol * 3
+
+
+def test_layout_roundtrip():
+    from passion_amd import ops
+    dev = _dev()
+    x = torch.randn(2, 4, 3, 5, 7).to(dev)
+    assert torch.equal(ops.to_ncdhw(ops.to_channels_last(x)), x)
+    y = ops.to_channels_last(x, torch.bfloat16)
+    assert torch.equal(y, x.permute(0, 2, 3, 4, 1).contiguous().to(torch.bfloat16))
