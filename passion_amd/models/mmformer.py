@@ -1,0 +1,379 @@
+"""mmformer backbone + PASSION self-distillation losses on the MI355X HIP kernels.
+
+Drop-in for the reference's code/models/mmformer.py: `Model(num_cls=4)` with the plain attributes
+`mask_type`, `use_passion`, `is_training` set after construction (train.py:91-92,212) and
+`forward(x, mask, target=None, temp=1.0)` returning softmax(fuse) | (pred, prm_loss, sep_loss) |
+(pred, prm_loss, sep_loss, kl_loss, proto_loss, dist) exactly as mmformer.py:635,657,659.  The
+module tree, parameter names, shapes, registration order and initialisation (hence the RNG stream
+of torch.manual_seed) are the reference's, so its checkpoints load with strict=True.
+
+What differs is everything underneath: activations are channels-last (B,D,H,W,C) in f32 or bf16
+(`compute_dtype`), every conv / InstanceNorm / LeakyReLU / upsample / softmax / loss / attention
+core is a HIP kernel from libpassion_hip.so (passion_amd.ops), MaskModal + stack + cat never
+materialise (they are per-segment masks of the conv loader), InstanceNorm statistics of a tensor are
+computed once and shared by all its consumers (the five decoder_fuse passes re-use them).
+
+Module-level constants are read at construction time, as in the reference, so
+`mmformer.patch_size = S // 16` selects a crop edge S (the reference hard-codes 80 -> 5).
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import _lib as L
+from .. import ops
+from ..utils import criterions as crit
+from .blocks import Feat, fusion_prenorm, general_conv3d_prenorm, run_conv
+
+basic_dims = 8
+transformer_basic_dims = 512
+mlp_dim = 4096
+num_heads = 8
+depth = 1
+num_cls = 4
+num_modals = 4
+patch_size = 5
+H = W = Z = 80
+
+MODALS = ("flair", "t1ce", "t1", "t2")
+
+
+def _up2(f):
+    return Feat(ops.upsample(f.t, 2), f.mask, f.mask_col)
+
+
+class Encoder(nn.Module):
+    """five-level pre-norm residual encoder of one modality (reference mmformer.py:24-64)"""
+
+    def __init__(self):
+        super().__init__()
+        c = basic_dims
+        self.e1_c1 = nn.Conv3d(in_channels=1, out_channels=c, kernel_size=3, stride=1, padding=1,
+                               padding_mode="reflect", bias=True)
+        self.e1_c2 = general_conv3d_prenorm(c, c, pad_type="reflect")
+        self.e1_c3 = general_conv3d_prenorm(c, c, pad_type="reflect")
+        for lvl in range(2, 6):
+            ci, co = c * 2 ** (lvl - 2), c * 2 ** (lvl - 1)
+            setattr(self, f"e{lvl}_c1", general_conv3d_prenorm(ci, co, stride=2, pad_type="reflect"))
+            setattr(self, f"e{lvl}_c2", general_conv3d_prenorm(co, co, pad_type="reflect"))
+            setattr(self, f"e{lvl}_c3", general_conv3d_prenorm(co, co, pad_type="reflect"))
+
+    def forward(self, x, modal, mask, dtype):
+        """x: the whole (B,4,S,S,S) input; this encoder reads modality `modal` as a C=1 segment"""
+        B, K, D, Hh, Ww = x.shape
+        vol = D * Hh * Ww
+        seg = ops.SegIn(x, mask=mask, mask_col=modal, C=1, offset=modal * vol, bstride=K * vol)
+        cache = self.e1_c1.__dict__.setdefault("_passion_pack", {})
+        f = Feat(ops.conv_block([seg], self.e1_c1.weight, self.e1_c1.bias, D, Hh, Ww, ksize=3, stride=1,
+                                pad_mode=L.PAD_REFLECT, out_dtype=dtype, pack_cache=cache))
+        feats = []
+        for lvl in range(1, 6):
+            if lvl > 1:
+                f = getattr(self, f"e{lvl}_c1")(f)
+            f = getattr(self, f"e{lvl}_c3")(getattr(self, f"e{lvl}_c2")(f), residual=f.t)
+            feats.append(f)
+        return feats
+
+
+def _decoder_convs(mod):
+    c = basic_dims
+    for lvl in (4, 3, 2, 1):
+        co = c * 2 ** (lvl - 1)
+        setattr(mod, f"d{lvl}_c1", general_conv3d_prenorm(co * 2, co, pad_type="reflect"))
+        setattr(mod, f"d{lvl}_c2", general_conv3d_prenorm(co * 2, co, pad_type="reflect"))
+        setattr(mod, f"d{lvl}_out", general_conv3d_prenorm(co, co, k_size=1, padding=0, pad_type="reflect"))
+
+
+class Decoder_sep(nn.Module):
+    """per-modality U-Net decoder, shared weights (reference mmformer.py:66-114); returns softmax probs
+    (channels-last f32)"""
+
+    def __init__(self, num_cls=4):
+        super().__init__()
+        c = basic_dims
+        for lvl in (4, 3, 2, 1):
+            co = c * 2 ** (lvl - 1)
+            setattr(self, f"d{lvl}", nn.Upsample(scale_factor=2, mode="trilinear", align_corners=True))
+            setattr(self, f"d{lvl}_c1", general_conv3d_prenorm(co * 2, co, pad_type="reflect"))
+            setattr(self, f"d{lvl}_c2", general_conv3d_prenorm(co * 2, co, pad_type="reflect"))
+            setattr(self, f"d{lvl}_out", general_conv3d_prenorm(co, co, k_size=1, padding=0, pad_type="reflect"))
+        self.seg_layer = nn.Conv3d(in_channels=c, out_channels=num_cls, kernel_size=1, stride=1, padding=0, bias=True)
+        self.softmax = nn.Softmax(dim=1)
+
+    def forward(self, x1, x2, x3, x4, x5):
+        skips = (x1, x2, x3, x4)
+        h = self.d4_c1(_up2(x5))
+        for lvl in (4, 3, 2, 1):
+            h = getattr(self, f"d{lvl}_out")(getattr(self, f"d{lvl}_c2")([h, skips[lvl - 1]]))
+            if lvl > 1:
+                h = getattr(self, f"d{lvl - 1}_c1")(_up2(h))
+        logits = run_conv(self.seg_layer, h, norm=False, out_dtype=torch.float32).t
+        return ops.softmax_classes(logits, 1.0, "cl")
+
+
+class Decoder_fuse(nn.Module):
+    """fusion decoder with deep supervision (reference mmformer.py:116-189); returns channels-last
+    logits, the four deep-supervision logits and the five feature maps"""
+
+    def __init__(self, num_cls=4):
+        super().__init__()
+        c = basic_dims
+        _decoder_convs(self)
+        self.seg_d4 = nn.Conv3d(in_channels=c * 16, out_channels=num_cls, kernel_size=1, stride=1, padding=0, bias=True)
+        self.seg_d3 = nn.Conv3d(in_channels=c * 8, out_channels=num_cls, kernel_size=1, stride=1, padding=0, bias=True)
+        self.seg_d2 = nn.Conv3d(in_channels=c * 4, out_channels=num_cls, kernel_size=1, stride=1, padding=0, bias=True)
+        self.seg_d1 = nn.Conv3d(in_channels=c * 2, out_channels=num_cls, kernel_size=1, stride=1, padding=0, bias=True)
+        self.seg_layer = nn.Conv3d(in_channels=c, out_channels=num_cls, kernel_size=1, stride=1, padding=0, bias=True)
+        self.up2 = nn.Upsample(scale_factor=2, mode="trilinear", align_corners=True)
+        self.RFM5 = fusion_prenorm(in_channel=c * 16, num_cls=num_cls)
+        self.RFM4 = fusion_prenorm(in_channel=c * 8, num_cls=num_cls)
+        self.RFM3 = fusion_prenorm(in_channel=c * 4, num_cls=num_cls)
+        self.RFM2 = fusion_prenorm(in_channel=c * 2, num_cls=num_cls)
+        self.RFM1 = fusion_prenorm(in_channel=c * 1, num_cls=num_cls)
+
+    def forward(self, x1, x2, x3, x4, x5, mask=None):
+        """x1..x4: lists of the four modality Feats (already carrying their masks); x5: fused level-5 Feat"""
+        xs = (x1, x2, x3, x4)
+        feats, preds = {}, {}
+        feats[5] = self.RFM5([x5])
+        preds[4] = run_conv(self.seg_d4, feats[5], norm=False, out_dtype=torch.float32).t
+        h = self.d4_c1(_up2(feats[5]))
+        for lvl in (4, 3, 2, 1):
+            r = getattr(self, f"RFM{lvl}")(xs[lvl - 1])
+            f = getattr(self, f"d{lvl}_out")(getattr(self, f"d{lvl}_c2")([r, h]))
+            feats[lvl] = f
+            if lvl > 1:
+                preds[lvl - 1] = run_conv(getattr(self, f"seg_d{lvl - 1}"), f, norm=False, out_dtype=torch.float32).t
+                h = getattr(self, f"d{lvl - 1}_c1")(_up2(f))
+        logits = run_conv(self.seg_layer, feats[1], norm=False, out_dtype=torch.float32).t
+        return logits, (preds[1], preds[2], preds[3], preds[4]), tuple(feats[i].t for i in (1, 2, 3, 4, 5))
+
+
+class SelfAttention(nn.Module):
+    """reference mmformer.py:192-227; the softmax(QK^T)V core is the HIP attention op"""
+
+    def __init__(self, dim, heads=8, qkv_bias=False, qk_scale=None, dropout_rate=0.0):
+        super().__init__()
+        self.num_heads = heads
+        head_dim = dim // heads
+        self.scale = qk_scale or head_dim ** -0.5
+        self.qkv = nn.Linear(dim, dim * 3, bias=qkv_bias)
+        self.attn_drop = nn.Dropout(dropout_rate)
+        self.proj = nn.Linear(dim, dim)
+        self.proj_drop = nn.Dropout(dropout_rate)
+
+    def forward(self, x):
+        qkv = self.qkv(x)
+        p = self.attn_drop.p if self.training else 0.0
+        x = ops.attention(qkv, self.num_heads, self.scale, p)
+        return self.proj_drop(self.proj(x))
+
+
+class Residual(nn.Module):
+    def __init__(self, fn):
+        super().__init__()
+        self.fn = fn
+
+    def forward(self, x):
+        return self.fn(x) + x
+
+
+class PreNorm(nn.Module):
+    def __init__(self, dim, fn):
+        super().__init__()
+        self.norm = nn.LayerNorm(dim)
+        self.fn = fn
+
+    def forward(self, x):
+        return self.fn(self.norm(x))
+
+
+class PreNormDrop(nn.Module):
+    def __init__(self, dim, dropout_rate, fn):
+        super().__init__()
+        self.norm = nn.LayerNorm(dim)
+        self.dropout = nn.Dropout(p=dropout_rate)
+        self.fn = fn
+
+    def forward(self, x):
+        return self.dropout(self.fn(self.norm(x)))
+
+
+class GELU(nn.Module):
+    def forward(self, x):
+        return F.gelu(x)
+
+
+class FeedForward(nn.Module):
+    def __init__(self, dim, hidden_dim, dropout_rate):
+        super().__init__()
+        self.net = nn.Sequential(nn.Linear(dim, hidden_dim), GELU(), nn.Dropout(p=dropout_rate),
+                                 nn.Linear(hidden_dim, dim), nn.Dropout(p=dropout_rate))
+
+    def forward(self, x):
+        return self.net(x)
+
+
+class Transformer(nn.Module):
+    """reference mmformer.py:282-313 (token GEMMs / LayerNorm / GELU stay on torch = hipBLASLt)"""
+
+    def __init__(self, embedding_dim, depth, heads, mlp_dim, dropout_rate=0.1, n_levels=1, n_points=4):
+        super().__init__()
+        att, ffn = [], []
+        self.depth = depth
+        for _ in range(depth):
+            att.append(Residual(PreNormDrop(embedding_dim, dropout_rate,
+                                            SelfAttention(embedding_dim, heads=heads, dropout_rate=dropout_rate))))
+            ffn.append(Residual(PreNorm(embedding_dim, FeedForward(embedding_dim, mlp_dim, dropout_rate))))
+        self.cross_attention_list = nn.ModuleList(att)
+        self.cross_ffn_list = nn.ModuleList(ffn)
+
+    def forward(self, x, pos):
+        for j in range(self.depth):
+            x = x + pos
+            x = self.cross_attention_list[j](x)
+            x = self.cross_ffn_list[j](x)
+        return x
+
+
+class MaskModal(nn.Module):
+    """kept for tree/API fidelity (reference mmformer.py:316-325); the product forward never copies:
+    masks travel with the Feats into the conv loaders"""
+
+    def forward(self, x, mask):
+        B, K, C, Hh, Ww, Zz = x.size()
+        return (x * mask.view(B, K, 1, 1, 1, 1).to(x.dtype)).view(B, -1, Hh, Ww, Zz)
+
+
+class Model(nn.Module):
+    def __init__(self, num_cls=4):
+        super().__init__()
+        self.flair_encoder = Encoder()
+        self.t1ce_encoder = Encoder()
+        self.t1_encoder = Encoder()
+        self.t2_encoder = Encoder()
+
+        td = transformer_basic_dims
+        for m in MODALS:
+            setattr(self, f"{m}_encode_conv", nn.Conv3d(basic_dims * 16, td, kernel_size=1, stride=1, padding=0))
+        for m in MODALS:
+            setattr(self, f"{m}_pos", nn.Parameter(torch.zeros(1, patch_size ** 3, td)))
+        for m in MODALS:
+            setattr(self, f"{m}_transformer", Transformer(embedding_dim=td, depth=depth, heads=num_heads, mlp_dim=mlp_dim))
+        self.multimodal_transformer = Transformer(embedding_dim=td, depth=depth, heads=num_heads, mlp_dim=mlp_dim,
+                                                  n_levels=num_modals)
+        self.multimodal_decode_conv = nn.Conv3d(td * num_modals, basic_dims * 16 * num_modals, kernel_size=1, padding=0)
+
+        eye = np.eye(4, dtype=bool)
+        self.masks_mod0 = torch.from_numpy(eye[0:1].copy())
+        self.masks_mod1 = torch.from_numpy(eye[1:2].copy())
+        self.masks_mod2 = torch.from_numpy(eye[2:3].copy())
+        self.masks_mod3 = torch.from_numpy(eye[3:4].copy())
+
+        self.decoder_fuse = Decoder_fuse(num_cls=num_cls)
+        self.decoder_sep = Decoder_sep(num_cls=num_cls)
+
+        self.up2 = nn.Upsample(scale_factor=2, mode="trilinear", align_corners=True)
+        self.up4 = nn.Upsample(scale_factor=4, mode="trilinear", align_corners=True)
+        self.up8 = nn.Upsample(scale_factor=8, mode="trilinear", align_corners=True)
+        self.up16 = nn.Upsample(scale_factor=16, mode="trilinear", align_corners=True)
+        self.up_ops = nn.ModuleList([self.up2, self.up4, self.up8, self.up16])
+
+        self.masker = MaskModal()
+        self.mask_type = "idt"
+        self.use_passion = False
+        self.is_training = False
+        self.compute_dtype = torch.float32   # torch.bfloat16 = the bench's storage dtype (f32 accumulate)
+        self.num_cls = num_cls
+        self.token_dim = td
+
+        for m in self.modules():
+            if isinstance(m, nn.Conv3d):
+                torch.nn.init.kaiming_normal_(m.weight)
+
+    # ------------------------------------------------------------------------------------------
+    def _transformer(self, tr, tok, pos):
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=self.compute_dtype == torch.bfloat16):
+            return tr(tok, pos)
+
+    def _inter(self, intra, tok_mask, pos_cat, B, p):
+        """concat the (masked) intra tokens modality-major -> inter-modal transformer -> reinterpret
+        (B,4N,512) as a (B,p,p,p,2048) channels-last volume [the reference's .view, mmformer.py:444,
+        is this very reinterpretation] -> 1x1x1 decode conv"""
+        toks = intra if tok_mask is None else [t * tok_mask[:, i].view(B, 1, 1).to(t.dtype) for i, t in enumerate(intra)]
+        tok = self._transformer(self.multimodal_transformer, torch.cat(toks, 1), pos_cat)
+        vol = tok.to(self.compute_dtype).contiguous().view(B, p, p, p, self.token_dim * num_modals)
+        return run_conv(self.multimodal_decode_conv, Feat(vol), norm=False)
+
+    def forward(self, x, mask, target=None, temp=1.0):
+        L.require_gpu(x)
+        B, S = x.size(0), x.size(2)
+        dev = x.device
+        dt = self.compute_dtype
+        idt = self.mask_type != "pdt"
+        mask = mask.to(device=dev, dtype=torch.bool).contiguous()
+        xin = x.to(dt).contiguous()
+
+        # ---- encoders (idt: input and features of absent modalities are zero, mmformer.py:397-415)
+        encs = [getattr(self, f"{m}_encoder")(xin, i, mask if idt else None, dt) for i, m in enumerate(MODALS)]
+        p = encs[0][4].t.shape[1]
+
+        def modal_feats(lvl, msk):
+            return [encs[i][lvl].with_mask(msk, i) if msk is not None else encs[i][lvl] for i in range(4)]
+
+        own = [[(f.with_mask(mask, i) if idt else f) for f in encs[i]] for i in range(4)]  # what decoder_sep / tokens see
+        xs = [modal_feats(l, mask) for l in range(4)]
+
+        # ---- intra-modal transformers (mmformer.py:417-433)
+        pos = [getattr(self, f"{m}_pos") for m in MODALS]
+        intra = []
+        for i, m in enumerate(MODALS):
+            tok = run_conv(getattr(self, f"{m}_encode_conv"), own[i][4], norm=False).t.view(B, p ** 3, self.token_dim)
+            tok = self._transformer(getattr(self, f"{m}_transformer"), tok, pos[i])
+            intra.append(tok * mask[:, i].view(B, 1, 1).to(tok.dtype))
+        pos_cat = torch.cat(pos, 1)
+
+        fuse_pred, preds, de_f_avg = self.decoder_fuse(*xs, self._inter(intra, None, pos_cat, B, p))
+        pred = ops.softmax_classes(fuse_pred, 1.0, "ncdhw")
+        if not self.is_training:
+            return pred
+
+        tcl = ops.target_to_cl(target)
+        sep_preds = [self.decoder_sep(*own[i]) for i in range(4)]
+        eye = torch.eye(4, device=dev)
+        maskf = mask.float()
+        gates = [(maskf * eye[i]) if idt else eye[i].expand(B, 4) for i in range(4)]
+
+        prm_loss = torch.zeros(B, 1, device=dev)
+        for j, pp in enumerate(preds):   # deep supervision: softmax -> upsample -> WCE + Dice (mmformer.py:540-544)
+            pair = crit.seg_losses_cl(ops.softmax_classes(pp, 1.0, "cl"), tcl, 2 ** (j + 1))
+            prm_loss = prm_loss + 0.5 ** (j + 1) * pair.sum(1, keepdim=True)
+        sep_loss = torch.zeros(B, 4, device=dev)
+        for i in range(4):
+            sep_loss = sep_loss + gates[i] * ops.wce_dice(sep_preds[i], tcl, "cl").sum(1, keepdim=True)
+        if not self.use_passion:
+            return pred, prm_loss, sep_loss
+
+        # ---- PASSION: four uni-modal students through the shared fusion path (mmformer.py:468-531)
+        inv_t = 1.0 / temp
+        pt_full = ops.softmax_classes(fuse_pred.detach(), inv_t, "cl")
+        pt_deep = [ops.upsample(ops.softmax_classes(pp.detach(), inv_t, "cl"), 2 ** (j + 1)) for j, pp in enumerate(preds)]
+        f_teacher = de_f_avg[0].detach()
+        kl_loss, proto_loss, dist = (torch.zeros(B, 4, device=dev) for _ in range(3))
+        onehots = [getattr(self, f"masks_mod{i}").to(dev).expand(B, 4).contiguous() for i in range(4)]
+        for i in range(4):
+            xs_i = [modal_feats(l, onehots[i]) for l in range(4)]
+            if idt:  # absent-by-data modalities stay zero as well: the student sees mask AND one-hot
+                both = (mask & onehots[i]).contiguous()
+                xs_i = [modal_feats(l, both) for l in range(4)]
+            tok_mask = onehots[2] if i == 3 else onehots[i]          # reference quirk, mmformer.py:522
+            fuse_i, preds_i, de_f_i = self.decoder_fuse(*xs_i, self._inter(intra, tok_mask, pos_cat, B, p))
+            pl, d = ops.proto_loss(de_f_i[0], f_teacher, tcl)
+            proto_loss = proto_loss + gates[i] * pl
+            dist = dist + gates[i] * d
+            kl = crit.kl_cl(fuse_i, pt_full, temp)
+            for j, ps_ in enumerate(preds_i):
+                kl = kl + 0.5 ** (j + 1) * crit.kl_cl(ps_, pt_deep[j], temp, 2 ** (j + 1))
+            kl_loss = kl_loss + gates[i] * kl
+        return pred, prm_loss, sep_loss, kl_loss, proto_loss, dist
