@@ -1,0 +1,157 @@
+#!/usr/bin/env python
+"""bench.py -- headline metric of BASELINE.json on MI355X: train volumes/sec of the PASSION hot path
+(mmformer, 4-modality synthetic 128^3 volumes, batch 1 per GPU, bf16 storage / f32 accumulate).
+
+    python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run)
+
+One "step" = one full training iteration on one synthetic batch already resident in HBM:
+Model.forward (all losses are computed inside it) + train.py's loss assembly + backward +
+gradient all-reduce (N>1) + AdamW(amsgrad) step.  Ranks own independent volumes (weak scaling, no
+data-path collective).  Rank 0 prints ONE JSON line; besides the contract's fields it carries
+  roofline     : dominant kernel = the fused IN+LeakyReLU+3x3x3 conv forward, algorithmic bytes
+                 (in + out activations + weights) / average launch time, both taken live
+                 with hipEvents on the launch stream inside the timed region; peak = 8 TB/s HBM3E
+  cpu_baseline : the oracle (oracle/, a CPU restatement proven equal to the reference) timed on the
+                 host cores, rank 0, N=1 only, on one 64^3 training step (1/8 of a 128^3 volume).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured copy)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="mmformer128", choices=["mmformer128", "mmformer128_passion"],
+                    help="BASELINE.json configs[1] (default) / configs[2] (+ PASSION self-distillation)")
+    ap.add_argument("--size", type=int, default=128)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(passion):
+    """oracle training step (forward + loss assembly + backward + AdamW) on the host cores"""
+    from oracle import train_step_ref
+    from passion_amd.models import mmformer
+    S = 64
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    mmformer.patch_size = S // 16
+    torch.manual_seed(1037)
+    m = mmformer.Model(num_cls=4)       # parameter holder only (CPU); the forward below is the oracle's
+    mmformer.patch_size = 5
+    P = {k: v.detach().clone().requires_grad_(True) for k, v in m.state_dict().items()}
+    opt = torch.optim.AdamW(list(P.values()), lr=2e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-4, amsgrad=True)
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(1, 4, S, S, S, generator=g)
+    lab = torch.randint(0, 4, (1, S, S, S), generator=g)
+    target = torch.nn.functional.one_hot(lab, 4).permute(0, 4, 1, 2, 3).double()
+    mask = torch.ones(1, 4, dtype=torch.bool)
+    times = []
+    for it in range(2):                 # 1 warm-up + 1 timed
+        t0 = time.time()
+        loss, _, _ = train_step_ref.train_step(P, x, mask, target, 4.0, "idt", passion, drop_p=0.1)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        times.append(time.time() - t0)
+    t = times[-1]
+    return {"value": round((S / 128.0) ** 3 / t, 6), "unit": "volumes/s (128^3-equivalent)", "cores": cores,
+            "kind": "port", "sample": f"1 training step (fwd+loss+bwd+AdamW, dropout on) of the same model on one "
+            f"4x{S}^3 synthetic volume = 1/8 of a 128^3 volume by voxel count; {t:.2f} s on {cores} threads"}
+
+
+def main():
+    args = parse()
+    from passion_amd import ops, parallel
+    from passion_amd import train as ptrain
+    from passion_amd.models import mmformer
+
+    ctx = parallel.init()
+    assert torch.cuda.is_available(), "bench.py measures the HIP path: a GPU is required"
+    if ctx.world != args.gpus and ctx.rank == 0:
+        print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={ctx.world}", file=sys.stderr)
+    S = args.size
+    passion = args.workload.endswith("passion")
+    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+
+    mmformer.patch_size = S // 16
+    torch.manual_seed(1037)
+    model = mmformer.Model(num_cls=4).to(ctx.device)
+    model.mask_type, model.use_passion, model.compute_dtype = "idt", passion, dtype
+    model.train()                                   # dropout live, as in the reference's training loop
+    reducer = parallel.GradReducer(model, ctx)
+    opt = ptrain.make_optimizer(model)
+    state = ptrain.LossState(ctx.device)
+    x, target, mask = ptrain.synthetic_batch(1, S, ctx.device, seed=7 + ctx.rank)   # resident in HBM before timing
+
+    def step():
+        return ptrain.train_step(model, opt, x, mask, target, 4.0, state, reducer)
+
+    for _ in range(args.warmup):
+        step()
+    parallel.barrier(ctx)
+    torch.cuda.synchronize()
+    if not args.no_roofline:
+        ops.prof_enable(1)                          # bit 0: fused IN+LReLU+conv3x3x3 forward launches
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    parallel.barrier(ctx)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    ops.prof_enable(0)
+    dt = parallel.all_reduce_max(ctx, dt)
+
+    if ctx.rank != 0:
+        return
+    out = {
+        "metric": "train volumes/sec (4-modality 128^3, bs=1/GPU)", "value": round(ctx.world * args.steps / dt, 4),
+        "unit": "volumes/s", "n_gpus": ctx.world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "bf16" if dtype == torch.bfloat16 else "f32", "data": "synthetic",
+        "config": {"workload": f"mmformer{'+PASSION' if passion else ''} train step, 4x{S}^3 volume, batch 1/GPU, "
+                               f"mask_type idt, all modalities present, AdamW(amsgrad), dropout 0.1 "
+                               f"(BASELINE.json configs[{2 if passion else 1}])",
+                   "global_batch": ctx.world, "parallelism": f"dp{ctx.world} (RCCL grad all-reduce, sum)",
+                   "final_loss": round(float(loss), 5)},
+    }
+    if not args.no_roofline:
+        recs = [r for r in ops.prof_read() if r[0] == 0]
+        if recs:
+            ms = sum(r[1] for r in recs)
+            by = sum(r[2] for r in recs)
+            fl = sum(r[3] for r in recs)
+            ach = by / (ms * 1e-3) / 1e9
+            traffic = None
+            tpath = os.path.join(ROOT, "profiles", "traffic.json")
+            if os.path.exists(tpath):
+                traffic = json.load(open(tpath)).get("conv3_fwd_bytes_per_launch")
+            out["roofline"] = {"kernel": "conv_mfma_kernel<.., KS=3, fwd> (fused InstanceNorm+LeakyReLU+Conv3d 3x3x3)",
+                               "bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic,
+                               "launches": len(recs), "avg_launch_ms": round(ms / len(recs), 5),
+                               "algorithmic_bytes_per_launch": round(by / len(recs), 1),
+                               "tflops": round(fl / (ms * 1e-3) / 1e12, 3)}
+    if not args.no_cpu_baseline and ctx.world == 1:
+        out["cpu_baseline"] = cpu_baseline(passion)
+    print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -157,8 +157,8 @@ int passion_attn_scores_bwd(const float* probs, float* dprobs, const void* qkv, 
                             int N, int H, int Dh, float scale, void* dqkv, void* stream);
 
 /* ---- in-library kernel timing (bench.py roofline leg) ------------------------------------------
- * When enabled, conv3d launches are bracketed by hipEvents on their own stream and their
- * algorithmic bytes recorded.  passion_prof_read drains up to `cap` records:
+ * passion_prof_enable(mask): bit k of `mask` selects launches of kind k; selected conv3d launches are
+ * bracketed by hipEvents on their own stream and their algorithmic bytes / flops recorded.  passion_prof_read drains up to `cap` records:
  * rec[i] = {kind, ms, bytes, flops}. kind: 0 fwd k3, 1 fwd k1, 2 dgrad, 3 wgrad. */
 typedef struct { int32_t kind; float ms; double bytes; double flops; } passion_prof_rec_t;
 void passion_prof_enable(int on);

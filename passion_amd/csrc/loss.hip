@@ -220,19 +220,23 @@ __host__ __device__ inline int pw_sumt(int c, int ch) { return 4 + 4 * CF + c * 
 __host__ __device__ inline int pw_gp(int c, int ch) { return 4 + 8 * CF + c * CF + ch; }
 constexpr int PW_LOSS = 4 + 12 * CF, PW_DIST = PW_LOSS + 1;
 
-template <typename T> __device__ __forceinline__ void load8(const T* p, float* o) {
-    f32x4 a = load4(p), b = load4(p + 4);
+// features have cf = 4 or 8 channels; the arithmetic always runs on 8 lanes with the tail zero-filled
+// (zero channels change no dot product, norm or prototype)
+template <typename T> __device__ __forceinline__ void load8(const T* p, float* o, int cf) {
+    f32x4 a = load4(p), b = {0.f, 0.f, 0.f, 0.f};
+    if (cf == 8) b = load4(p + 4);
 #pragma unroll
     for (int j = 0; j < 4; ++j) { o[j] = a[j]; o[4 + j] = b[j]; }
 }
-template <typename T> __device__ __forceinline__ void store8(T* p, const float* o) {
+template <typename T> __device__ __forceinline__ void store8(T* p, const float* o, int cf) {
     f32x4 a = {o[0], o[1], o[2], o[3]}, b = {o[4], o[5], o[6], o[7]};
-    store4(p, a); store4(p + 4, b);
+    store4(p, a);
+    if (cf == 8) store4(p + 4, b);
 }
 
 template <typename T>
 __global__ __launch_bounds__(256) void proto_sums_kernel(const T* __restrict__ fs, const T* __restrict__ ft,
-                                                         const float* __restrict__ tg, long V, float* __restrict__ work) {
+                                                         const float* __restrict__ tg, long V, float* __restrict__ work, int cf) {
     __shared__ float red[4][4 + 8 * CF];
     const int b = blockIdx.y;
     float cnt[NC], ss[NC][CF], st[NC][CF];
@@ -244,8 +248,8 @@ __global__ __launch_bounds__(256) void proto_sums_kernel(const T* __restrict__ f
     }
     for (long v = (long)blockIdx.x * blockDim.x + threadIdx.x; v < V; v += (long)gridDim.x * blockDim.x) {
         float a[CF], e[CF];
-        load8(fs + ((long)b * V + v) * CF, a);
-        load8(ft + ((long)b * V + v) * CF, e);
+        load8(fs + ((long)b * V + v) * cf, a, cf);
+        load8(ft + ((long)b * V + v) * cf, e, cf);
         const f32x4 t = load4(tg + ((long)b * V + v) * 4);
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
@@ -312,7 +316,7 @@ __device__ __forceinline__ void load_protos(const float* __restrict__ work, int 
 
 template <typename T>
 __global__ __launch_bounds__(256) void proto_loss_kernel(const T* __restrict__ fs, const T* __restrict__ ft, long V,
-                                                         int B, float* __restrict__ work) {
+                                                         int B, float* __restrict__ work, int cf) {
     __shared__ float red[4][2];
     const int b = blockIdx.y;
     const float eps = 1e-5f;
@@ -321,8 +325,8 @@ __global__ __launch_bounds__(256) void proto_loss_kernel(const T* __restrict__ f
     float al = 0.f, ad = 0.f;
     for (long v = (long)blockIdx.x * blockDim.x + threadIdx.x; v < V; v += (long)gridDim.x * blockDim.x) {
         float a[CF], e[CF];
-        load8(fs + ((long)b * V + v) * CF, a);
-        load8(ft + ((long)b * V + v) * CF, e);
+        load8(fs + ((long)b * V + v) * cf, a, cf);
+        load8(ft + ((long)b * V + v) * cf, e, cf);
         float na = 0.f, ne = 0.f;
 #pragma unroll
         for (int h = 0; h < CF; ++h) { na += a[h] * a[h]; ne += e[h] * e[h]; }
@@ -360,7 +364,7 @@ __global__ void proto_out_kernel(const float* __restrict__ work, int B, float* _
 template <typename T>
 __global__ __launch_bounds__(256) void proto_bwd1_kernel(const T* __restrict__ fs, const T* __restrict__ ft,
                                                          const float* __restrict__ g, long V, int B,
-                                                         float* __restrict__ work, T* __restrict__ dfs) {
+                                                         float* __restrict__ work, T* __restrict__ dfs, int cf) {
     __shared__ float red[4][NC * CF];
     const int b = blockIdx.y;
     const float eps = 1e-5f;
@@ -374,8 +378,8 @@ __global__ __launch_bounds__(256) void proto_bwd1_kernel(const T* __restrict__ f
         for (int h = 0; h < CF; ++h) gp[c][h] = 0.f;
     for (long v = (long)blockIdx.x * blockDim.x + threadIdx.x; v < V; v += (long)gridDim.x * blockDim.x) {
         float a[CF], e[CF], da_[CF];
-        load8(fs + ((long)b * V + v) * CF, a);
-        load8(ft + ((long)b * V + v) * CF, e);
+        load8(fs + ((long)b * V + v) * cf, a, cf);
+        load8(ft + ((long)b * V + v) * cf, e, cf);
         float na = 0.f, ne = 0.f;
 #pragma unroll
         for (int h = 0; h < CF; ++h) { na += a[h] * a[h]; ne += e[h] * e[h]; da_[h] = 0.f; }
@@ -399,7 +403,7 @@ __global__ __launch_bounds__(256) void proto_bwd1_kernel(const T* __restrict__ f
                 gp[c][h] += gs * (a[h] * ia / Np - cp * P.ps[c][h]);
             }
         }
-        store8(dfs + ((long)b * V + v) * CF, da_);
+        store8(dfs + ((long)b * V + v) * cf, da_, cf);
     }
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
 #pragma unroll
@@ -419,7 +423,7 @@ __global__ __launch_bounds__(256) void proto_bwd1_kernel(const T* __restrict__ f
 // backward pass 2: prototypes are masked means of fs, so every voxel of class c receives Gp[c]/(count_c+eps)
 template <typename T>
 __global__ void proto_bwd2_kernel(const float* __restrict__ tg, long V, const float* __restrict__ work,
-                                  T* __restrict__ dfs) {
+                                  T* __restrict__ dfs, int cf) {
     const int b = blockIdx.y;
     const float eps = 1e-5f;
     float gpn[NC][CF];
@@ -429,13 +433,13 @@ __global__ void proto_bwd2_kernel(const float* __restrict__ tg, long V, const fl
         for (int h = 0; h < CF; ++h) gpn[c][h] = work[(long)b * PW + pw_gp(c, h)] / (work[(long)b * PW + c] + eps);
     for (long v = (long)blockIdx.x * blockDim.x + threadIdx.x; v < V; v += (long)gridDim.x * blockDim.x) {
         float d[CF];
-        load8(dfs + ((long)b * V + v) * CF, d);
+        load8(dfs + ((long)b * V + v) * cf, d, cf);
         const f32x4 t = load4(tg + ((long)b * V + v) * 4);
 #pragma unroll
         for (int c = 0; c < NC; ++c)
 #pragma unroll
             for (int h = 0; h < CF; ++h) d[h] += t[c] * gpn[c][h];
-        store8(dfs + ((long)b * V + v) * CF, d);
+        store8(dfs + ((long)b * V + v) * cf, d, cf);
     }
 }
 
@@ -541,23 +545,23 @@ extern "C" int64_t passion_proto_work_floats(int B, int Cf) { (void)Cf; return (
 
 extern "C" int passion_proto_fwd(const void* fs, const void* ft, int dtype, const float* target, int B, int64_t V,
                                  int Cf, float* work, float* out, void* stream) {
-    if (Cf != CF) return -1013;
+    if (Cf != 4 && Cf != 8) return -1013;
     hipStream_t st = (hipStream_t)stream;
     HIP_RET(hipMemsetAsync(work, 0, sizeof(float) * (size_t)passion_proto_work_floats(B, Cf), st));
     dim3 grid(vgrid_red(V), B);
     if (dtype == PASSION_F32)
-        hipLaunchKernelGGL(proto_sums_kernel<float>, grid, dim3(256), 0, st, (const float*)fs, (const float*)ft, target, (long)V, work);
+        hipLaunchKernelGGL(proto_sums_kernel<float>, grid, dim3(256), 0, st, (const float*)fs, (const float*)ft, target, (long)V, work, Cf);
     else if (dtype == PASSION_BF16)
-        hipLaunchKernelGGL(proto_sums_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)fs, (const bf16_t*)ft, target, (long)V, work);
+        hipLaunchKernelGGL(proto_sums_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)fs, (const bf16_t*)ft, target, (long)V, work, Cf);
     else
         return -1007;
     LAUNCH_RET();
     hipLaunchKernelGGL(proto_valid_kernel, dim3(1), dim3(64), 0, st, work, B);
     LAUNCH_RET();
     if (dtype == PASSION_F32)
-        hipLaunchKernelGGL(proto_loss_kernel<float>, grid, dim3(256), 0, st, (const float*)fs, (const float*)ft, (long)V, B, work);
+        hipLaunchKernelGGL(proto_loss_kernel<float>, grid, dim3(256), 0, st, (const float*)fs, (const float*)ft, (long)V, B, work, Cf);
     else
-        hipLaunchKernelGGL(proto_loss_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)fs, (const bf16_t*)ft, (long)V, B, work);
+        hipLaunchKernelGGL(proto_loss_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)fs, (const bf16_t*)ft, (long)V, B, work, Cf);
     LAUNCH_RET();
     hipLaunchKernelGGL(proto_out_kernel, dim3((B + 63) / 64), dim3(64), 0, st, work, B, out);
     LAUNCH_RET();
@@ -566,7 +570,7 @@ extern "C" int passion_proto_fwd(const void* fs, const void* ft, int dtype, cons
 
 extern "C" int passion_proto_bwd(const void* fs, const void* ft, int dtype, const float* target, const float* g, int B,
                                  int64_t V, int Cf, float* work, void* dfs, void* stream) {
-    if (Cf != CF) return -1013;
+    if (Cf != 4 && Cf != 8) return -1013;
     hipStream_t st = (hipStream_t)stream;
     // `work` still holds the forward's sums / validity; only the Gp block is re-zeroed
     for (int b = 0; b < B; ++b)
@@ -574,13 +578,13 @@ extern "C" int passion_proto_bwd(const void* fs, const void* ft, int dtype, cons
     dim3 grid(vgrid_red(V), B);
     dim3 grid2(vgrid(V), B);
     if (dtype == PASSION_F32) {
-        hipLaunchKernelGGL(proto_bwd1_kernel<float>, grid, dim3(256), 0, st, (const float*)fs, (const float*)ft, g, (long)V, B, work, (float*)dfs);
+        hipLaunchKernelGGL(proto_bwd1_kernel<float>, grid, dim3(256), 0, st, (const float*)fs, (const float*)ft, g, (long)V, B, work, (float*)dfs, Cf);
         LAUNCH_RET();
-        hipLaunchKernelGGL(proto_bwd2_kernel<float>, grid2, dim3(256), 0, st, target, (long)V, work, (float*)dfs);
+        hipLaunchKernelGGL(proto_bwd2_kernel<float>, grid2, dim3(256), 0, st, target, (long)V, work, (float*)dfs, Cf);
     } else if (dtype == PASSION_BF16) {
-        hipLaunchKernelGGL(proto_bwd1_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)fs, (const bf16_t*)ft, g, (long)V, B, work, (bf16_t*)dfs);
+        hipLaunchKernelGGL(proto_bwd1_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)fs, (const bf16_t*)ft, g, (long)V, B, work, (bf16_t*)dfs, Cf);
         LAUNCH_RET();
-        hipLaunchKernelGGL(proto_bwd2_kernel<bf16_t>, grid2, dim3(256), 0, st, target, (long)V, work, (bf16_t*)dfs);
+        hipLaunchKernelGGL(proto_bwd2_kernel<bf16_t>, grid2, dim3(256), 0, st, target, (long)V, work, (bf16_t*)dfs, Cf);
     } else
         return -1007;
     LAUNCH_RET();

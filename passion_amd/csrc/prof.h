@@ -3,10 +3,10 @@
 #include <hip/hip_runtime.h>
 void passion_prof_begin(int kind, double bytes, double flops, hipStream_t st);
 void passion_prof_end(hipStream_t st);
-extern int g_passion_prof_on;
+extern int g_passion_prof_on;  // bit k set: time launches of kind k
 struct ProfScope {
     hipStream_t st; bool on;
-    ProfScope(int kind, double bytes, double flops, hipStream_t s) : st(s), on(g_passion_prof_on != 0) {
+    ProfScope(int kind, double bytes, double flops, hipStream_t s) : st(s), on(((g_passion_prof_on >> kind) & 1) != 0) {
         if (on) passion_prof_begin(kind, bytes, flops, st);
     }
     ~ProfScope() { if (on) passion_prof_end(st); }

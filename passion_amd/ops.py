@@ -459,7 +459,9 @@ def attention(qkv, heads, scale, drop_p=0.0):
 # kernel timing hooks (bench.py)
 # ------------------------------------------------------------------------------------------------
 def prof_enable(on):
-    L.load().passion_prof_enable(1 if on else 0)
+    """on: False/0 = off, True = all conv kinds, or a bitmask (bit0 fwd k3, bit1 fwd k1, bit2 dgrad, bit3 wgrad)"""
+    mask = 0xF if on is True else int(on or 0)
+    L.load().passion_prof_enable(mask)
 
 
 def prof_read(cap=65536):

@@ -1,0 +1,164 @@
+"""Training step of the PASSION hot path on MI355X.
+
+Counterpart of the reference's code/train.py hot loop (:198-289 PASSION branch, :390-448 plain
+branch): model forward (losses are computed inside it), the per-iteration loss assembly with the
+relative-preference mask, backward, AdamW(amsgrad) step -- and of the epoch-level imbalance update
+(:325-335).  Differences that matter on a ~tens-of-ms GPU step:
+  * everything stays on the device: the reference's 36 `.item()/.cpu()` syncs per iteration
+    (train.py:291-321) are replaced by device-side accumulators read once per epoch;
+  * multi-GPU is one process per GPU with RCCL gradient all-reduce (passion_amd.parallel) instead of
+    single-process DataParallel (train.py:90).  Losses are SUMS over samples (train.py:229-231), so
+    gradients are summed -- not averaged -- across ranks, which equals DataParallel on the global batch.
+"""
+import os
+import time
+
+import numpy as np
+import torch
+
+from .utils import criterions
+
+
+class LossState:
+    """imb_beta / modal_weight and the per-epoch accumulators (reference train.py:163-175,185-195)"""
+
+    def __init__(self, device, modal_weight=None, eta=0.01, eta_ext=1.5):
+        self.imb_beta = torch.ones(4, device=device)
+        self.modal_weight = torch.ones(4, device=device) if modal_weight is None else modal_weight.to(device)
+        self.eta, self.eta_ext = eta, eta_ext
+        self.epoch_dist_m = torch.zeros(4, device=device)
+
+    def end_epoch(self, epoch, warmup=False):
+        """train.py:325-335: beta <- clamp(beta - eta*rp_epoch, .1, 4), renormalised to |beta|_2 = 2"""
+        avg = self.epoch_dist_m.sum() / 4.0
+        rp_epoch = (avg - self.epoch_dist_m) / avg
+        if not warmup:
+            if epoch % 100 == 0:
+                self.eta *= self.eta_ext
+            beta = torch.clamp(self.imb_beta - self.eta * rp_epoch, 0.1, 4.0)
+            self.imb_beta = 2 * beta / beta.pow(2).sum().sqrt()
+        self.epoch_dist_m.zero_()
+        return rp_epoch
+
+
+def assemble_loss(outs, target, mask, mask_type="idt", use_passion=True, state=None, warmup=False, modal_num=None):
+    """Per-iteration loss (train.py:228-280 / :413-440), no host synchronisation."""
+    pred = outs[0]
+    B = pred.shape[0]
+    dev = pred.device
+    fuse_loss = (criterions.softmax_weighted_loss_bs(pred, target, num_cls=4) +
+                 criterions.dice_loss_bs(pred, target, num_cls=4)).sum()
+    prm_loss = outs[1].sum()
+    idt = mask_type != "pdt"
+    mk = mask.to(device=dev, dtype=torch.float32)
+    red = (lambda t: (t * mk).sum(0)) if idt else (lambda t: t.sum(0))
+    sep_m = red(outs[2])
+    if not use_passion:
+        sep = sep_m.sum()
+        return (sep + 0.0 * (fuse_loss + prm_loss)) if warmup else (fuse_loss + sep + prm_loss)
+    beta = state.imb_beta if state is not None else torch.ones(4, device=dev)
+    w = (state.modal_weight if (state is not None and idt) else torch.ones(4, device=dev))
+    kl_m, proto_m, dist_bs = red(outs[3]), red(outs[4]), outs[5]
+    if idt:   # relative preference: per-sample dist / mean over that sample's present modalities - 1
+        rp = (mk * (dist_bs / (dist_bs.sum(1, keepdim=True) / mk.sum(1, keepdim=True)) - 1)).sum(0)
+    else:
+        rp = (dist_bs / dist_bs.mean(1, keepdim=True) - 1).sum(0)
+    rp_mask = (rp > 0).float()
+    kl = (beta * w * kl_m).sum()
+    proto = (rp_mask * w * proto_m).sum()
+    if state is not None:
+        dm = red(dist_bs).detach()
+        state.epoch_dist_m += dm / modal_num if (idt and modal_num is not None) else dm
+    if warmup:
+        return (beta * w * sep_m).sum() + 0.0 * (fuse_loss + prm_loss + kl + proto)
+    return fuse_loss + (rp_mask * beta * w * sep_m).sum() + prm_loss + 0.5 * kl + 0.1 * proto
+
+
+def make_optimizer(model, lr=2e-4, weight_decay=1e-4):
+    """AdamW(betas=(0.9,0.999), eps=1e-8, amsgrad=True) as train.py:95-96"""
+    params = [{"params": model.parameters(), "lr": lr, "weight_decay": weight_decay}]
+    return torch.optim.AdamW(params, betas=(0.9, 0.999), eps=1e-08, amsgrad=True)
+
+
+def poly_lr(base_lr, epoch, num_epochs, power=0.9):
+    """LR_Scheduler (utils/lr_scheduler.py:17,43)"""
+    return round(base_lr * np.power(1 - np.float32(epoch) / np.float32(num_epochs), power), 8)
+
+
+def train_step(model, optimizer, x, mask, target, temp=4.0, state=None, reducer=None, warmup=False, modal_num=None):
+    """one iteration: forward, loss assembly, backward, (gradient all-reduce,) optimizer step"""
+    net = model
+    net.is_training = True
+    outs = net(x, mask, target=target, temp=temp)
+    loss = assemble_loss(outs, target, mask, net.mask_type, net.use_passion, state, warmup, modal_num)
+    optimizer.zero_grad(set_to_none=False)
+    loss.backward()
+    if reducer is not None:
+        reducer.all_reduce_grads()
+    optimizer.step()
+    return loss.detach()
+
+
+def synthetic_batch(B, S, device, seed=7, mask=None):
+    """SURVEY 8d synthetic inputs: randn volumes, uniform random one-hot float64 targets"""
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(B, 4, S, S, S, generator=g)
+    lab = torch.randint(0, 4, (B, S, S, S), generator=g)
+    target = torch.nn.functional.one_hot(lab, 4).permute(0, 4, 1, 2, 3).double()
+    if mask is None:
+        mask = torch.ones(B, 4, dtype=torch.bool)
+    return x.to(device), target.to(device), mask.to(device)
+
+
+MASK_TABLE = [[True, False, False, False], [False, True, False, False], [False, False, True, False],
+              [False, False, False, True], [True, True, False, False], [True, False, True, False],
+              [True, False, False, True], [False, True, True, False], [False, True, False, True],
+              [False, False, True, True], [True, True, True, False], [True, True, False, True],
+              [True, False, True, True], [False, True, True, True], [True, True, True, True]]
+
+
+def main(argv=None):
+    """python -m passion_amd.train --synthetic --use_passion --patch 128 --dtype bf16 ...  (under torchrun
+    for several GPUs).  Real-data loading (code/data/*) is out of this round's scope."""
+    from . import parallel
+    from .models import mmformer
+    from .options import args_parser
+    args = args_parser(argv)
+    ctx = parallel.init()
+    torch.manual_seed(args.seed)
+    assert args.model == "mmformer", "rfnet is the next scope row (SURVEY 8a a16)"
+    mmformer.patch_size = args.patch // 16
+    model = mmformer.Model(num_cls=4).to(ctx.device)
+    model.mask_type, model.use_passion = args.mask_type, args.use_passion
+    model.compute_dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    model.train()
+    reducer = parallel.GradReducer(model, ctx)
+    optimizer = make_optimizer(model, args.lr, args.weight_decay)
+    state = LossState(ctx.device)
+    if not args.synthetic:
+        raise SystemExit("only --synthetic input is wired in this round (dataset loader: SURVEY 8f N3)")
+    iters = args.iters_per_epoch or 10
+    rng = np.random.RandomState(args.seed + ctx.rank)
+    for epoch in range(args.num_epochs):
+        lr = poly_lr(args.lr, epoch, args.num_epochs)
+        for g_ in optimizer.param_groups:
+            g_["lr"] = lr
+        t0 = time.time()
+        for it in range(iters):
+            mk = torch.tensor([MASK_TABLE[rng.randint(15)] for _ in range(args.batch_size)])
+            x, target, mk = synthetic_batch(args.batch_size, args.patch, ctx.device, seed=epoch * iters + it, mask=mk)
+            loss = train_step(model, optimizer, x, mk, target, args.temp, state, reducer,
+                              warmup=epoch < args.region_fusion_start_epoch)
+        torch.cuda.synchronize()
+        if args.use_passion:
+            state.end_epoch(epoch, epoch < args.region_fusion_start_epoch)
+        if ctx.rank == 0:
+            print(f"epoch {epoch + 1}/{args.num_epochs} lr {lr} loss {float(loss):.4f} "
+                  f"{iters * args.batch_size * ctx.world / (time.time() - t0):.3f} vol/s", flush=True)
+            os.makedirs(args.savepath, exist_ok=True)
+            torch.save({"epoch": epoch, "state_dict": {"module." + k: v for k, v in model.state_dict().items()},
+                        "optim_dict": optimizer.state_dict()}, os.path.join(args.savepath, "model_last.pth"))
+
+
+if __name__ == "__main__":
+    main()

@@ -250,13 +250,14 @@ def _ref_proto(fs, ft, target):
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("drop_class", [False, True])
-def test_proto(dtype, drop_class):
+@pytest.mark.parametrize("Cf", [8, 4])
+def test_proto(dtype, drop_class, Cf):
     from passion_amd import ops
     dev = _dev()
     g = torch.Generator().manual_seed(12)
     B, S = 2, 8
-    fs = torch.randn(B, 8, S, S, S, generator=g).to(dtype).double()
-    ft = torch.randn(B, 8, S, S, S, generator=g).to(dtype).double()
+    fs = torch.randn(B, Cf, S, S, S, generator=g).to(dtype).double()
+    ft = torch.randn(B, Cf, S, S, S, generator=g).to(dtype).double()
     target = _onehot(B, S, g)
     if drop_class:  # class 3 absent from sample 1 -> skipped for the whole batch (criterions.py:157)
         t1 = target[1]

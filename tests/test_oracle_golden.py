@@ -70,7 +70,7 @@ def test_small_model_matches_reference(tag):
         assert abs(gn[str(k)] - ref) < 2e-4 * ref + 1e-7, (k, gn[str(k)], ref)
     for key in g.files:
         if key.startswith("grad::"):
-            if np.abs(g[key]).max() < 1e-7:   # bias in front of an InstanceNorm: gradient is rounding noise around 0
+            if np.abs(g[key]).max() < 1e-6:   # bias in front of an InstanceNorm: gradient is rounding noise around 0
                 assert P[key[6:]].grad.abs().max() < 1e-6
                 continue
             assert rel(P[key[6:]].grad, g[key]) < 2e-3, key

@@ -1,0 +1,81 @@
+"""CPU, world_size 2 over gloo: the N>1 path of passion_amd.parallel (parameter broadcast + bucketed
+SUM all-reduce of gradients) equals single-process training on the global batch with summed
+per-sample losses -- the reference's DataParallel semantics (train.py:90,229-231)."""
+import os
+import socket
+import sys
+
+import torch
+import torch.multiprocessing as mp
+import torch.nn as nn
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _net(seed):
+    torch.manual_seed(seed)
+    return nn.Sequential(nn.Linear(6, 16), nn.Tanh(), nn.Linear(16, 3), nn.Tanh(), nn.Linear(3, 1))
+
+
+def _data():
+    g = torch.Generator().manual_seed(5)
+    return torch.randn(4, 6, generator=g), torch.randn(4, 1, generator=g)
+
+
+def _worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    from passion_amd import parallel
+    ctx = parallel.init(backend="gloo")
+    net = _net(100 + rank)                          # deliberately different init: broadcast must fix it
+    red = parallel.GradReducer(net, ctx, bucket_mb=0)   # 0 -> one bucket per parameter: exercises many buckets
+    x, y = _data()
+    xs, ys = x[rank * 2:(rank + 1) * 2], y[rank * 2:(rank + 1) * 2]    # weak scaling: each rank owns its samples
+    opt = torch.optim.SGD(net.parameters(), lr=0.1)
+    for _ in range(3):
+        opt.zero_grad()
+        ((net(xs) - ys) ** 2).sum().backward()     # per-sample losses are summed, never averaged
+        red.all_reduce_grads()
+        opt.step()
+    t = parallel.all_reduce_max(ctx, float(rank))
+    parallel.barrier(ctx)
+    if rank == 0:
+        torch.save({"sd": net.state_dict(), "max": t, "nb": len(red.buckets)}, out)
+    torch.distributed.destroy_process_group()
+
+
+def test_two_rank_gloo_equals_global_batch(tmp_path):
+    out = str(tmp_path / "r0.pt")
+    mp.spawn(_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    got = torch.load(out)
+    assert got["max"] == 1.0 and got["nb"] >= 6
+    net = _net(100)
+    x, y = _data()
+    opt = torch.optim.SGD(net.parameters(), lr=0.1)
+    for _ in range(3):
+        opt.zero_grad()
+        ((net(x) - y) ** 2).sum().backward()
+        opt.step()
+    for k, v in net.state_dict().items():
+        assert torch.allclose(v, got["sd"][k], atol=1e-6), k
+
+
+def test_single_process_reducer_is_a_noop():
+    sys.path.insert(0, ROOT)
+    from passion_amd import parallel
+    ctx = parallel.Ctx(0, 1, 0, torch.device("cpu"), "gloo")
+    net = _net(1)
+    red = parallel.GradReducer(net, ctx)
+    net(torch.randn(2, 6)).sum().backward()
+    g0 = [p.grad.clone() for p in net.parameters()]
+    red.all_reduce_grads()
+    assert all(torch.equal(a, p.grad) for a, p in zip(g0, net.parameters()))
