@@ -48,7 +48,7 @@ def cpu_baseline(passion):
     from oracle import train_step_ref
     from passion_amd.models import mmformer
     S = 64
-    cores = os.cpu_count() or 1
+    cores = min(os.cpu_count() or 1, 32)   # more threads than that only add contention on these op sizes
     torch.set_num_threads(cores)
     mmformer.patch_size = S // 16
     torch.manual_seed(1037)

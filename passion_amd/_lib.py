@@ -98,6 +98,8 @@ def load():
         raise PassionHipError(
             f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "or `make -C passion_amd/csrc`.  passion_amd has no CPU/eager fallback.")
+    import torch  # noqa: F401  -- torch's bundled libamdhip64 must be the HIP runtime this library binds to:
+    #                  loading ours first would pull a second runtime from /opt/rocm (kernels then fail with hipErrorNoDevice)
     lib = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)

@@ -1,5 +1,6 @@
 // Library-level entry points: ABI version and the optional hipEvent timing of conv launches.
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include <mutex>
 #include <vector>
 #include "passion_hip.h"
@@ -49,4 +50,11 @@ extern "C" int passion_prof_read(passion_prof_rec_t* rec, int cap) {
     }
     g_pending.erase(g_pending.begin(), g_pending.begin() + i);
     return n;
+}
+
+// A/B switch for debugging: PASSION_FORCE_F32_MFMA=1 routes bf16 tensors through the f32-MFMA conv kernels.
+extern int g_passion_force_f32_mfma;
+__attribute__((constructor)) static void passion_read_env() {
+    const char* e = getenv("PASSION_FORCE_F32_MFMA");
+    if (e && e[0] == '1') g_passion_force_f32_mfma = 1;
 }

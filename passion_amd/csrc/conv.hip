@@ -15,38 +15,14 @@
 // [tap][Cout][CinPad] image, plus "mirror taps" that implement the adjoint of reflect padding,
 // and an epilogue that goes back through LeakyReLU and accumulates the two InstanceNorm-backward
 // sums per (b, channel).
-#include "common.h"
-#include "passion_hip.h"
+#include "conv_common.h"
 #include "prof.h"
 
+using namespace pconv;
+
+int g_passion_force_f32_mfma = 0;   // debugging / A-B switch: route bf16 tensors through the f32-MFMA kernel
+
 namespace {
-
-constexpr int TD = 4, TH = 8, TW = 8;
-
-struct SegD {
-    const void* x;
-    const float* stats;
-    const uint8_t* mask;
-    void* dx;
-    long bstride;
-    int C, mask_col, mask_ld, cbase;
-};
-
-struct ConvK {
-    int B, Di, Hi, Wi, Do, Ho, Wo;
-    int pad_mode, nseg, Cin, Cout;
-    float slope;
-    SegD seg[PASSION_MAX_SEG];
-    const float* wpack;
-    int Mpad;
-    const float* bias;
-    const void* residual;
-    void* y;
-    const void* dy;
-    float* sums;
-    int tilesD, tilesH, tilesW;
-    int hi_t[3], hi_u[3];  // dgrad reflect: tap / source coordinate of the high-side mirror term per axis
-};
 
 template <int KS, int S, bool DG> struct Geo {
     static constexpr int HALO = (KS == 3) ? 1 : 0;
@@ -135,21 +111,6 @@ __device__ __forceinline__ void stage_tile(float* lds, const TI* __restrict__ sr
     }
 }
 
-// One axis of a tap entry.  a < KS: regular tap; a == KS: low-side mirror term; a == KS+1: high-side.
-template <int KS, int HALO, bool DG, int S>
-__device__ __forceinline__ void axis_tap(int a, int il, int i0, int Sin, int hi_t, int hi_u,
-                                         int& t, int& pos, bool& valid) {
-    if (a < KS) {
-        t = a; valid = true;
-        pos = DG ? (il + 2 * HALO - a) : (il * S + a);
-    } else if (a == KS) {   // padded coordinate -1 reflects onto input index 1: fwd (o = 0, t = 0)
-        t = 0; valid = (i0 + il == 1); pos = 1 - i0;
-    } else {                // padded coordinate Sin reflects onto Sin-2
-        t = hi_t; valid = (hi_t >= 0) && (i0 + il == Sin - 2); pos = hi_u - (i0 - HALO);
-    }
-    if (!valid) pos = 0;
-}
-
 template <typename TI, typename TO, int KS, int S, int MT, int MODE>
 __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvK p) {
     constexpr bool DG = (MODE == 1);
@@ -230,7 +191,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvK p) {
                         for (int nt = 0; nt < 4; ++nt)
                             axis_tap<KS, G::HALO, DG, S>(ah, lh[nt], o0h, Oh, p.hi_t[1], p.hi_u[1], thp, posh[nt], vh[nt]);
                         const int tap = (tdp * KS + thp) * KS + twp;
-                        const float* wrow = p.wpack + ((long)tap * Ktot + cbase + c0) * p.Mpad + (mg * MT) * 16 + n;
+                        const float* wrow = reinterpret_cast<const float*>(p.wpack) + ((long)tap * Ktot + cbase + c0) * p.Mpad + (mg * MT) * 16 + n;
                         int pos[4]; bool val[4];
 #pragma unroll
                         for (int nt = 0; nt < 4; ++nt) {
@@ -259,101 +220,9 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvK p) {
     }
 
     // ---------------- epilogue ----------------
-    const int od = o0d + ld_, ow = o0w + lw;
-    if (!DG) {
-        TO* y = reinterpret_cast<TO*>(p.y);
-        const TO* res = reinterpret_cast<const TO*>(p.residual);
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
-            const int oh = o0h + lh[nt];
-            if (od >= Od || oh >= Oh || ow >= Ow) continue;
-            const long vox = (((long)b * Od + od) * Oh + oh) * Ow + ow;
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                const int co = (mg * MT + mt) * 16 + kq * 4;
-                if (co >= p.Cout) continue;
-                f32x4 v = acc[mt][nt];
-                if (p.bias) {
-                    f32x4 bb = load4(p.bias + co);
-                    v += bb;
-                }
-                if (res) v += load4(res + vox * p.Cout + co);
-                store4(y + vox * p.Cout + co, v);
-            }
-        }
-    } else {
-        // rows are input channels of the forward conv; find the segment of each 4-channel group
-        const int nrows = MT * 16;
-        for (int i = tid; i < nrows * 2; i += 256) lsum[i] = 0.f;
-        __syncthreads();
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            const int cg = (mg * MT + mt) * 16 + kq * 4;  // global input channel of row 0 of this lane
-            int sg = -1;
-            if (cg < p.Cin) {
-#pragma unroll
-                for (int s2 = 0; s2 < PASSION_MAX_SEG; ++s2)
-                    if (s2 < p.nseg && cg >= p.seg[s2].cbase && cg < p.seg[s2].cbase + p.seg[s2].C) sg = s2;
-            }
-            float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2v[4] = {0.f, 0.f, 0.f, 0.f};
-            const bool seg_ok = (sg >= 0) && (p.seg[sg].dx != nullptr);
-            if (seg_ok) {
-                const SegD& sd = p.seg[sg];
-                const int cl = cg - sd.cbase;
-                float mval = 1.f;
-                if (sd.mask) mval = sd.mask[(long)b * sd.mask_ld + sd.mask_col] ? 1.f : 0.f;
-                f32x4 mean = {0.f, 0.f, 0.f, 0.f}, rstd = {1.f, 1.f, 1.f, 1.f};
-                if (sd.stats) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        mean[j] = sd.stats[((long)b * sd.C + cl + j) * 2 + 0];
-                        rstd[j] = sd.stats[((long)b * sd.C + cl + j) * 2 + 1];
-                    }
-                }
-                const TO* x = reinterpret_cast<const TO*>(sd.x) + (long)b * sd.bstride;
-                TO* dx = reinterpret_cast<TO*>(sd.dx) + (long)b * sd.bstride;
-#pragma unroll
-                for (int nt = 0; nt < 4; ++nt) {
-                    const int oh = o0h + lh[nt];
-                    if (od >= Od || oh >= Oh || ow >= Ow) continue;
-                    const long vox = (((long)od) * Oh + oh) * Ow + ow;
-                    f32x4 g = acc[mt][nt];
-                    if (sd.stats) {
-                        f32x4 xv = load4(x + vox * sd.C + cl);
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            float xh = (xv[j] - mean[j]) * rstd[j];
-                            float gg = g[j] * (xh > 0.f ? 1.f : p.slope) * mval;
-                            g[j] = gg;
-                            s1[j] += gg;
-                            s2v[j] += gg * xh;
-                        }
-                    } else {
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) g[j] *= mval;
-                    }
-                    store4(dx + vox * sd.C + cl, g);
-                }
-            }
-            // reduce the per-channel sums over the 16 voxel lanes, then over waves through LDS
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                float a1 = group16_sum(s1[j]), a2 = group16_sum(s2v[j]);
-                if (n == 0 && seg_ok && p.seg[sg].stats) {
-                    atomicAdd(&lsum[(mt * 16 + kq * 4 + j) * 2 + 0], a1);
-                    atomicAdd(&lsum[(mt * 16 + kq * 4 + j) * 2 + 1], a2);
-                }
-            }
-        }
-        __syncthreads();
-        for (int i = tid; i < nrows; i += 256) {
-            const int cg = mg * MT * 16 + i;
-            if (cg < p.Cin && (lsum[i * 2] != 0.f || lsum[i * 2 + 1] != 0.f)) {
-                atomicAdd(&p.sums[((long)b * p.Cin + cg) * 2 + 0], lsum[i * 2 + 0]);
-                atomicAdd(&p.sums[((long)b * p.Cin + cg) * 2 + 1], lsum[i * 2 + 1]);
-            }
-        }
-    }
+    const int oh4[4] = {o0h + lh[0], o0h + lh[1], o0h + lh[2], o0h + lh[3]};
+    if (!DG) epilogue_fwd<TO, MT>(p, acc, b, mg, o0d + ld_, o0w + lw, oh4, kq);
+    else epilogue_dgrad<TO, MT>(p, acc, lsum, b, mg, o0d + ld_, o0w + lw, oh4, kq, n, tid);
 }
 
 // InstanceNorm backward, second half:  dx = rstd * (g - mean(g) - xhat * mean(g * xhat))
@@ -550,8 +419,6 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, int Cin, int Cou
     }
 }
 
-inline int pad16(int c) { return (c + 15) / 16 * 16; }
-
 int fill_params(const passion_conv_desc_t* d, ConvK& k) {
     if (!d) return -1001;
     if (d->ksize != 1 && d->ksize != 3) return -1002;
@@ -639,6 +506,8 @@ int launch_wgrad_geo(ConvK& k, int ksize, int stride, float* dW, float* db, hipS
     return launch_wgrad_mt<TX, TY, 3, 2>(k, dW, db, st);
 }
 
+long f32_pack_floats(int Cin, int Cout, int nt) { return (long)nt * Cin * pad16(Cout) + (long)nt * Cout * pad16(Cin); }
+
 double conv_bytes(const ConvK& k, int xs, int ys) {
     const double vin = (double)k.B * k.Di * k.Hi * k.Wi, vout = (double)k.B * k.Do * k.Ho * k.Wo;
     return vin * k.Cin * xs + vout * k.Cout * ys;
@@ -648,18 +517,19 @@ double conv_bytes(const ConvK& k, int xs, int ys) {
 
 extern "C" int64_t passion_conv_pack_floats(int Cin, int Cout, int ksize) {
     const int64_t nt = (int64_t)ksize * ksize * ksize;
-    return nt * Cin * pad16(Cout) + nt * Cout * pad16(Cin);
+    // [f32 fwd image | f32 dgrad image | bf16 fwd + dgrad images]
+    return nt * Cin * pad16(Cout) + nt * Cout * pad16(Cin) + (bf16_pack_elems(Cin, Cout, (int)nt) + 1) / 2;
 }
 
 extern "C" int passion_conv_pack_weight(const float* weight, int Cin, int Cout, int ksize, float* packed, void* stream) {
     const int nt = ksize * ksize * ksize;
     const long nf = (long)nt * Cin * pad16(Cout);
-    const long total = passion_conv_pack_floats(Cin, Cout, ksize);
+    const long total = nf + (long)nt * Cout * pad16(Cin);   // f32 images; the bf16 images follow
     const int blocks = (int)hmin((total + 255) / 256, 1024);
     hipLaunchKernelGGL(pack_weight_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, weight, Cin, Cout, nt,
                        pad16(Cout), pad16(Cin), packed, packed + nf);
     LAUNCH_RET();
-    return 0;
+    return pack_weight_bf16(weight, Cin, Cout, nt, packed + total, (hipStream_t)stream);
 }
 
 extern "C" int passion_conv3d_fwd(const passion_conv_desc_t* d, const float* packed, const float* bias,
@@ -677,9 +547,12 @@ extern "C" int passion_conv3d_fwd(const passion_conv_desc_t* d, const float* pac
                    2.0 * k.B * k.Do * k.Ho * k.Wo * (double)k.Cout * k.Cin * nt, st);
     if (d->x_dtype == PASSION_F32 && d->y_dtype == PASSION_F32)
         rc = launch_conv_geo<float, float, 0>(k, d->ksize, d->stride, mtiles, st);
-    else if (d->x_dtype == PASSION_BF16 && d->y_dtype == PASSION_BF16)
-        rc = launch_conv_geo<bf16_t, bf16_t, 0>(k, d->ksize, d->stride, mtiles, st);
-    else if (d->x_dtype == PASSION_BF16 && d->y_dtype == PASSION_F32)
+    else if (d->x_dtype == PASSION_BF16 && d->y_dtype == PASSION_BF16) {
+        if (bf16_eligible(k, false) && !g_passion_force_f32_mfma)
+            rc = launch_conv_bf16(k, d->ksize, d->stride, false, packed + f32_pack_floats(k.Cin, k.Cout, nt), st);
+        else
+            rc = launch_conv_geo<bf16_t, bf16_t, 0>(k, d->ksize, d->stride, mtiles, st);
+    } else if (d->x_dtype == PASSION_BF16 && d->y_dtype == PASSION_F32)
         rc = launch_conv_geo<bf16_t, float, 0>(k, d->ksize, d->stride, mtiles, st);
     else
         rc = -1007;
@@ -704,7 +577,9 @@ extern "C" int passion_conv3d_bwd(const passion_conv_desc_t* d, const float* pac
         if (d->x_dtype == PASSION_F32 && d->y_dtype == PASSION_F32)
             rc = launch_wgrad_geo<float, float>(k, d->ksize, d->stride, dweight, dbias, st);
         else if (d->x_dtype == PASSION_BF16 && d->y_dtype == PASSION_BF16)
-            rc = launch_wgrad_geo<bf16_t, bf16_t>(k, d->ksize, d->stride, dweight, dbias, st);
+            rc = (bf16_eligible(k, false) && !g_passion_force_f32_mfma)
+                     ? launch_wgrad_bf16(k, d->ksize, d->stride, dweight, dbias, st)
+                     : launch_wgrad_geo<bf16_t, bf16_t>(k, d->ksize, d->stride, dweight, dbias, st);
         else if (d->x_dtype == PASSION_BF16 && d->y_dtype == PASSION_F32)
             rc = launch_wgrad_geo<bf16_t, float>(k, d->ksize, d->stride, dweight, dbias, st);
         else
@@ -734,8 +609,12 @@ extern "C" int passion_conv3d_bwd(const passion_conv_desc_t* d, const float* pac
         // TI = dy dtype, TO = x/dx dtype
         if (d->x_dtype == PASSION_F32 && d->y_dtype == PASSION_F32)
             rc = launch_conv_geo<float, float, 1>(k, d->ksize, d->stride, mtiles, st);
-        else if (d->x_dtype == PASSION_BF16 && d->y_dtype == PASSION_BF16)
-            rc = launch_conv_geo<bf16_t, bf16_t, 1>(k, d->ksize, d->stride, mtiles, st);
+        else if (d->x_dtype == PASSION_BF16 && d->y_dtype == PASSION_BF16) {
+            if (bf16_eligible(k, true) && !g_passion_force_f32_mfma)
+                rc = launch_conv_bf16(k, d->ksize, d->stride, true, packed + f32_pack_floats(k.Cin, k.Cout, nt), st);
+            else
+                rc = launch_conv_geo<bf16_t, bf16_t, 1>(k, d->ksize, d->stride, mtiles, st);
+        }
         else if (d->x_dtype == PASSION_BF16 && d->y_dtype == PASSION_F32)
             rc = launch_conv_geo<float, bf16_t, 1>(k, d->ksize, d->stride, mtiles, st);
         else

@@ -1,0 +1,541 @@
+// bf16 matrix-core version of the fused (InstanceNorm -> LeakyReLU ->) Conv3d forward / dgrad.
+// Same implicit GEMM as conv.hip (D[channel][voxel] += W[channel][K] * act[K][voxel], K = (tap, cin)),
+// but on v_mfma_f32_16x16x32_bf16: one MFMA eats K = 32 = four (tap, 8-channel block) pairs.
+//
+//  * LDS brick is voxel-major [voxel][CKB channels] bf16: the 8 consecutive k of a lane's B fragment are
+//    the 8 channels of one voxel at one tap = ONE ds_read_b128, no transposes anywhere.
+//  * lane group g = lane >> 4 owns pair q = 4*step + g -> (tap = q / (CKB/8), block = q % (CKB/8)); every
+//    lane computes its own tap offset (the LDS address is per-lane anyway), so a 3x3x3 conv over 8
+//    channels is 7 MFMA steps per column tile instead of 54 f32 steps.
+//  * weights stream from L2 as [tap][cin/8][coutPad][8] bf16: one 16-byte load per lane per step,
+//    1 KiB contiguous per wave, prefetched one step ahead.
+//  * the loader normalises / activates / masks / pads each input element once and writes it back to LDS
+//    with one ds_write_b128 per 8 channels.
+// The accumulator layout equals the f32 kernel's, so the epilogues (conv_common.h) are shared.
+#include "conv_common.h"
+
+using namespace pconv;
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+template <int KS, int S, bool DG, int CKB> struct GeoB {
+    static constexpr int HALO = (KS == 3) ? 1 : 0;
+    static constexpr int ID = DG ? TD + 2 * HALO : (TD - 1) * S + KS;
+    static constexpr int IH = DG ? TH + 2 * HALO : (TH - 1) * S + KS;
+    static constexpr int IW = DG ? TW + 2 * HALO : (TW - 1) * S + KS;
+    static constexpr int VOL = ID * IH * IW;
+    static constexpr int NC8 = CKB / 8;
+    static constexpr int VS = CKB * 2 + (CKB > 8 ? 16 : 0);  // bytes per voxel (padded: spreads 16-B slots over banks)
+    static constexpr int NTAP = KS * KS * KS;
+    static constexpr int Q = NTAP * NC8;
+    static constexpr int NSTEP = (Q + 3) / 4;
+};
+
+__device__ __forceinline__ bf16x8 zero8() {
+    bf16x8 z;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) z[j] = (__bf16)0.f;
+    return z;
+}
+
+// Stage channels [c0, c0+ck) of one brick into lds as [voxel][CKB] bf16 (zero beyond ck).
+template <int KS, int S, bool DG, int CKB>
+__device__ __forceinline__ void stage_tile_b(char* lds, const bf16_t* __restrict__ src, int C, int c0, int ck,
+                                             const float* __restrict__ stats, float slope, int pad_mode, int b,
+                                             int o0d, int o0h, int o0w, int Sd, int Sh, int Sw, int tid) {
+    using G = GeoB<KS, S, DG, CKB>;
+    const int j = tid % G::NC8;                 // 8-channel block of this thread (constant: NC8 divides 256)
+    const int cb = c0 + j * 8;
+    const int nch = min(8, max(0, min(ck - j * 8, C - cb)));
+    const bool has_norm = (stats != nullptr);
+    float mean[8], rstd[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        mean[c] = 0.f; rstd[c] = 1.f;
+        if (has_norm && c < nch) {
+            mean[c] = stats[((long)b * C + cb + c) * 2 + 0];
+            rstd[c] = stats[((long)b * C + cb + c) * 2 + 1];
+        }
+    }
+    for (int it = tid; it < G::VOL * G::NC8; it += 256) {
+        const int tv = it / G::NC8;
+        const int zw = tv % G::IW, zh = (tv / G::IW) % G::IH, zd = tv / (G::IW * G::IH);
+        int sd, sh, sw;
+        bool ok = true;
+        if (!DG) {
+            sd = o0d * S - G::HALO + zd; sh = o0h * S - G::HALO + zh; sw = o0w * S - G::HALO + zw;
+            if (pad_mode == PASSION_PAD_REFLECT) {
+                sd = reflect_idx(sd, Sd); sh = reflect_idx(sh, Sh); sw = reflect_idx(sw, Sw);
+                sd = min(max(sd, 0), Sd - 1); sh = min(max(sh, 0), Sh - 1); sw = min(max(sw, 0), Sw - 1);
+            } else {
+                ok = (sd >= 0 && sd < Sd && sh >= 0 && sh < Sh && sw >= 0 && sw < Sw);
+            }
+        } else {
+            const int ud = o0d - G::HALO + zd, uh = o0h - G::HALO + zh, uw = o0w - G::HALO + zw;
+            ok = (ud >= 0 && uh >= 0 && uw >= 0 && (ud % S) == 0 && (uh % S) == 0 && (uw % S) == 0);
+            sd = ud / S; sh = uh / S; sw = uw / S;
+            ok = ok && (sd < Sd && sh < Sh && sw < Sw);
+        }
+        float v[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) v[c] = 0.f;
+        if (ok && nch > 0) {
+            const bf16_t* ptr = src + (((long)sd * Sh + sh) * Sw + sw) * C + cb;
+            if (nch == 8) {
+                const f32x4 lo = load4(ptr), hi = load4(ptr + 4);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) { v[c] = lo[c]; v[4 + c] = hi[c]; }
+            } else {
+#pragma unroll
+                for (int c = 0; c < 8; ++c) if (c < nch) v[c] = to_f32(ptr[c]);
+            }
+            if (has_norm) {
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    float t = (v[c] - mean[c]) * rstd[c];
+                    t = t > 0.f ? t : t * slope;
+                    v[c] = (c < nch) ? t : 0.f;
+                }
+            }
+        }
+        bf16x8 o;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) o[c] = (__bf16)v[c];
+        *reinterpret_cast<bf16x8*>(lds + tv * G::VS + j * 16) = o;
+    }
+}
+
+template <int KS, int S, int MT, int MODE, int CKB>
+__global__ __launch_bounds__(256) void conv_bf16_kernel(ConvK p) {
+    constexpr bool DG = (MODE == 1);
+    using G = GeoB<KS, S, DG, CKB>;
+    __shared__ __attribute__((aligned(16))) char lds[G::VOL * G::VS];
+    __shared__ float lsum[DG ? MT * 16 * 2 : 1];
+
+    const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, n = lane & 15, g = lane >> 4;
+    int bid = blockIdx.x;
+    const int tw_ = bid % p.tilesW; bid /= p.tilesW;
+    const int th_ = bid % p.tilesH; bid /= p.tilesH;
+    const int td_ = bid % p.tilesD; bid /= p.tilesD;
+    const int b = bid;
+    const int o0d = td_ * TD, o0h = th_ * TH, o0w = tw_ * TW;
+    const int mg = blockIdx.y;
+
+    const int Od = DG ? p.Di : p.Do, Oh = DG ? p.Hi : p.Ho, Ow = DG ? p.Wi : p.Wo;
+    const int Sd = DG ? p.Do : p.Di, Sh = DG ? p.Ho : p.Hi, Sw = DG ? p.Wo : p.Wi;
+    const int K8 = DG ? pad8(p.Cout) / 8 : pad8(p.Cin) / 8;       // 8-channel blocks along K in the packed image
+    const bf16x8* wp = reinterpret_cast<const bf16x8*>(p.wpack);
+
+    f32x4 acc[MT][4];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int lh[4] = {0 + (n >> 3), 2 + (n >> 3), 4 + (n >> 3), 6 + (n >> 3)};
+    const int lw = n & 7, ld_ = wv;
+    // byte offset of this lane's four voxels (tap 0) inside the brick
+    int pos[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+        pos[nt] = DG ? ((ld_ * G::IH + lh[nt]) * G::IW + lw) * G::VS
+                     : (((ld_ * S) * G::IH + lh[nt] * S) * G::IW + lw * S) * G::VS;
+
+    const bool reflect_dg = DG && (KS == 3) && (p.pad_mode == PASSION_PAD_REFLECT);
+    const bool lowD = reflect_dg && (o0d == 0) && (Od >= 2), lowH = reflect_dg && (o0h == 0) && (Oh >= 2),
+               lowW = reflect_dg && (o0w == 0) && (Ow >= 2);
+    const bool hiD = reflect_dg && p.hi_t[0] >= 0 && (o0d <= Od - 2) && (Od - 2 < o0d + TD);
+    const bool hiH = reflect_dg && p.hi_t[1] >= 0 && (o0h <= Oh - 2) && (Oh - 2 < o0h + TH);
+    const bool hiW = reflect_dg && p.hi_t[2] >= 0 && (o0w <= Ow - 2) && (Ow - 2 < o0w + TW);
+    const bool any_mirror = lowD || lowH || lowW || hiD || hiH || hiW;
+
+    const int nseg = DG ? 1 : p.nseg;
+    for (int sg = 0; sg < nseg; ++sg) {
+        const int C = DG ? p.Cout : p.seg[sg].C;
+        const int cbase = DG ? 0 : p.seg[sg].cbase;
+        const bf16_t* src;
+        const float* stats = nullptr;
+        if (DG) {
+            src = reinterpret_cast<const bf16_t*>(p.dy) + (long)b * Sd * Sh * Sw * C;
+        } else {
+            src = reinterpret_cast<const bf16_t*>(p.seg[sg].x) + (long)b * p.seg[sg].bstride;
+            stats = p.seg[sg].stats;
+            if (p.seg[sg].mask && !p.seg[sg].mask[(long)b * p.seg[sg].mask_ld + p.seg[sg].mask_col]) continue;
+        }
+        for (int c0 = 0; c0 < C; c0 += CKB) {
+            const int ck = min(CKB, C - c0);
+            const int nblk = (ck + 7) / 8;               // valid 8-channel blocks in this chunk
+            const int cb8 = (cbase + c0) / 8;
+            __syncthreads();
+            stage_tile_b<KS, S, DG, CKB>(lds, src, C, c0, ck, stats, p.slope, p.pad_mode, b, o0d, o0h, o0w, Sd, Sh, Sw, tid);
+            __syncthreads();
+
+            // ---- regular taps: 4 (tap, block) pairs per MFMA step, one per lane group
+            auto decode = [&](int s, int& toff, long& wrow) -> bool {
+                const int q = 4 * s + g;
+                const int tap = q / G::NC8, blk = q % G::NC8;
+                const bool v = (q < G::Q) && (blk < nblk);
+                int td = 0, th = 0, tw = 0;
+                if (KS == 3) { td = tap / 9; th = (tap / 3) % 3; tw = tap % 3; }
+                if (DG && KS == 3) { td = 2 - td; th = 2 - th; tw = 2 - tw; }   // gather form: voxel i reads u = i + 1 - t
+                toff = v ? ((td * G::IH + th) * G::IW + tw) * G::VS + blk * 16 : 0;
+                wrow = ((long)(v ? tap : 0) * K8 + cb8 + (v ? blk : 0)) * p.Mpad + (mg * MT) * 16 + n;
+                return v;
+            };
+            int toff; long wrow;
+            bool v = decode(0, toff, wrow);
+            bf16x8 a[MT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) a[mt] = v ? wp[wrow + mt * 16] : zero8();
+            for (int s = 0; s < G::NSTEP; ++s) {
+                int toff_n = 0; long wrow_n = 0; bool v_n = false;
+                bf16x8 a_n[MT];
+                if (s + 1 < G::NSTEP) {
+                    v_n = decode(s + 1, toff_n, wrow_n);
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) a_n[mt] = v_n ? wp[wrow_n + mt * 16] : zero8();
+                }
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) {
+                    const bf16x8 bv = *reinterpret_cast<const bf16x8*>(lds + pos[nt] + toff);
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mt], bv, acc[mt][nt], 0, 0, 0);
+                }
+                toff = toff_n;
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) a[mt] = a_n[mt];
+            }
+
+            // ---- mirror taps (adjoint of reflect padding); only bricks touching planes 1 / Sin-2
+            if (any_mirror) {
+                for (int ad = 0; ad < KS + 2; ++ad) {
+                    if (ad == KS && !lowD) continue;
+                    if (ad == KS + 1 && !hiD) continue;
+                    int tdp, posd; bool vd;
+                    axis_tap<KS, G::HALO, DG, S>(ad, ld_, o0d, Od, p.hi_t[0], p.hi_u[0], tdp, posd, vd);
+                    for (int ah = 0; ah < KS + 2; ++ah) {
+                        if (ah == KS && !lowH) continue;
+                        if (ah == KS + 1 && !hiH) continue;
+                        for (int aw = 0; aw < KS + 2; ++aw) {
+                            if (aw == KS && !lowW) continue;
+                            if (aw == KS + 1 && !hiW) continue;
+                            if (ad < KS && ah < KS && aw < KS) continue;      // all-regular: done above
+                            int twp, posw; bool vw;
+                            axis_tap<KS, G::HALO, DG, S>(aw, lw, o0w, Ow, p.hi_t[2], p.hi_u[2], twp, posw, vw);
+                            int thp = 0, mpos[4]; bool mval[4];
+#pragma unroll
+                            for (int nt = 0; nt < 4; ++nt) {
+                                int ph; bool vh;
+                                axis_tap<KS, G::HALO, DG, S>(ah, lh[nt], o0h, Oh, p.hi_t[1], p.hi_u[1], thp, ph, vh);
+                                mval[nt] = vd && vh && vw;
+                                mpos[nt] = mval[nt] ? ((posd * G::IH + ph) * G::IW + posw) * G::VS : 0;
+                            }
+                            const int tap = (tdp * KS + thp) * KS + twp;
+                            for (int s2 = 0; s2 * 4 < nblk; ++s2) {
+                                const int blk = s2 * 4 + g;
+                                const bool bvld = blk < nblk;
+                                bf16x8 am[MT];
+#pragma unroll
+                                for (int mt = 0; mt < MT; ++mt)
+                                    am[mt] = bvld ? wp[((long)tap * K8 + cb8 + blk) * p.Mpad + (mg * MT + mt) * 16 + n] : zero8();
+#pragma unroll
+                                for (int nt = 0; nt < 4; ++nt) {
+                                    bf16x8 bv = zero8();
+                                    if (bvld && mval[nt]) bv = *reinterpret_cast<const bf16x8*>(lds + mpos[nt] + blk * 16);
+#pragma unroll
+                                    for (int mt = 0; mt < MT; ++mt)
+                                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am[mt], bv, acc[mt][nt], 0, 0, 0);
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+
+    const int oh4[4] = {o0h + lh[0], o0h + lh[1], o0h + lh[2], o0h + lh[3]};
+    if (!DG) epilogue_fwd<bf16_t, MT>(p, acc, b, mg, o0d + ld_, o0w + lw, oh4, g);
+    else epilogue_dgrad<bf16_t, MT>(p, acc, lsum, b, mg, o0d + ld_, o0w + lw, oh4, g, n, tid);
+}
+
+// ------------------------------------------------------------------------------------------------
+// wgrad on bf16 matrix cores:  dW[co][ci][tap] += sum_vox dY[vox][co] * act(x)[vox*s + tap][ci]
+// D[m = co][n = (tap, ci)] with K = 32 voxels per MFMA.  Both operands are k-strided in their voxel-major
+// LDS images ([vox][co] and [vox][ci]), so both fragments come from ds_read_b64_tr_b16: a 16-lane group
+// reads a block of 4 voxels x 16 columns and every lane receives ITS column for the 4 voxels; lane 4q+p of
+// the group supplies the address of (voxel q, columns 4p..4p+3), which lets one 16-column tile mix two taps
+// of an 8-channel chunk (columns 0-7: tap 2t, columns 8-15: tap 2t+1) with no copies.
+// A workgroup owns (a strided set of bricks) x (one 8-channel chunk of one segment) x (MT row tiles); partial
+// sums stay in registers across bricks and are flushed once with f32 atomics.
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ bf16x8 tr_read8(const char* p0, const char* p1) {
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p0));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p1));
+    const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+template <int KS, int S, int MT>
+__global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(ConvK p, float* __restrict__ dW, float* __restrict__ dbias,
+                                                              int tiles_per_b) {
+    constexpr int CKW = 8;
+    using G = GeoB<KS, S, false, CKW>;
+    constexpr int NTAP = G::NTAP;
+    constexpr int NTILES = (NTAP + 1) / 2;            // 16 columns = 2 taps x 8 channels
+    constexpr int KSPLIT = (NTILES >= 4) ? 1 : 4;     // few column tiles: waves split the voxels instead
+    constexpr int NTW = (KSPLIT == 1) ? (NTILES + 3) / 4 : NTILES;
+    constexpr int MC = MT * 16;
+    constexpr int DYS = MC * 2 + 16;                  // bytes per voxel row of the dY image
+    __shared__ __attribute__((aligned(16))) char lact[G::VOL * G::VS];
+    __shared__ __attribute__((aligned(16))) char ldy[TD * TH * TW * DYS];
+
+    const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, n = lane & 15, g = lane >> 4;
+    const int q = n >> 2, pq = n & 3;
+    const int mgroups = p.Mpad / 16 / MT;
+    const int mg = blockIdx.y % mgroups;
+    int chunk = blockIdx.y / mgroups;
+    int sg = 0, c0 = 0;
+    for (int s2 = 0; s2 < p.nseg; ++s2) {
+        const int nch = (p.seg[s2].C + CKW - 1) / CKW;
+        if (chunk < nch) { sg = s2; c0 = chunk * CKW; break; }
+        chunk -= nch;
+    }
+    const SegD& sd = p.seg[sg];
+    const int ck = min(CKW, sd.C - c0);
+
+    // per column tile of this wave: byte offset of this lane's (tap, channel quad) inside a voxel neighbourhood
+    int boff[NTW];
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) {
+        const int nt = (KSPLIT == 1) ? wv + 4 * j : j;
+        int tap = 2 * nt + (pq >> 1);
+        if (tap >= NTAP) tap = 0;                      // padded column: reads finite data, dropped at the flush
+        const int tw = tap % KS, th = (tap / KS) % KS, td = tap / (KS * KS);
+        boff[j] = ((td * G::IH + th) * G::IW + tw) * G::VS + (pq & 1) * 8;
+    }
+    f32x4 acc[MT][NTW], accb[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        accb[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) acc[mt][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    const bool bias_block = (dbias != nullptr) && (blockIdx.y / mgroups == 0);
+    const bool do_bias = bias_block && (KSPLIT == 4 || wv == 0);
+    bf16x8 ones;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ones[j] = (__bf16)1.0f;
+
+    const int total_tiles = p.B * tiles_per_b;
+    for (int tile = blockIdx.x; tile < total_tiles; tile += gridDim.x) {
+        int t2 = tile;
+        const int tw_ = t2 % p.tilesW; t2 /= p.tilesW;
+        const int th_ = t2 % p.tilesH; t2 /= p.tilesH;
+        const int td_ = t2 % p.tilesD; t2 /= p.tilesD;
+        const int b = t2;
+        const int o0d = td_ * TD, o0h = th_ * TH, o0w = tw_ * TW;
+        const bool present = sd.mask ? (sd.mask[(long)b * sd.mask_ld + sd.mask_col] != 0) : true;
+        if (!present && !bias_block) continue;
+        __syncthreads();
+        const bf16_t* src = reinterpret_cast<const bf16_t*>(sd.x) + (long)b * sd.bstride;
+        stage_tile_b<KS, S, false, CKW>(lact, src, sd.C, c0, present ? ck : 0, sd.stats, p.slope, p.pad_mode, b, o0d, o0h,
+                                        o0w, p.Di, p.Hi, p.Wi, tid);
+        const bf16_t* dy = reinterpret_cast<const bf16_t*>(p.dy) + (long)b * p.Do * p.Ho * p.Wo * p.Cout;
+        for (int i = tid; i < TD * TH * TW * (MC / 8); i += 256) {
+            const int c8 = i % (MC / 8), v = i / (MC / 8);
+            const int w = v % TW, h = (v / TW) % TH, d = v / (TW * TH);
+            const int od = o0d + d, oh = o0h + h, ow = o0w + w;
+            const int co = mg * MC + c8 * 8;
+            bf16x8 o = zero8();
+            if (od < p.Do && oh < p.Ho && ow < p.Wo && co < p.Cout) {
+                const bf16_t* ptr = dy + ((((long)od) * p.Ho + oh) * p.Wo + ow) * p.Cout + co;
+                if (co + 8 <= p.Cout) {
+                    o = *reinterpret_cast<const bf16x8*>(ptr);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) if (co + e < p.Cout) o[e] = ptr[e];
+                }
+            }
+            *reinterpret_cast<bf16x8*>(ldy + v * DYS + c8 * 16) = o;
+        }
+        __syncthreads();
+        // K loop: 32 voxels per MFMA = one (d, 4 h-rows) slab; lane group g owns h-row g, its two tr-reads
+        // cover w = 0..3 and 4..7
+        for (int ks = (KSPLIT == 4 ? wv : 0); ks < TD * TH * TW / 32; ks += KSPLIT) {
+            const int d = ks >> 1, h = (ks & 1) * 4 + g, w = q;
+            const int v = (d * TH + h) * TW + w;
+            const char* ap = ldy + v * DYS + pq * 8;
+            bf16x8 a[MT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) a[mt] = tr_read8(ap + mt * 32, ap + mt * 32 + 4 * DYS);
+            const char* bp = lact + (((d * S) * G::IH + h * S) * G::IW + w * S) * G::VS;
+#pragma unroll
+            for (int j = 0; j < NTW; ++j) {
+                const bf16x8 bv = tr_read8(bp + boff[j], bp + boff[j] + 4 * S * G::VS);
+                if (KSPLIT == 1 && wv + 4 * j >= NTILES) continue;   // wave-uniform
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+                    acc[mt][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mt], bv, acc[mt][j], 0, 0, 0);
+            }
+            if (do_bias) {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+                    accb[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mt], ones, accb[mt], 0, 0, 0);
+            }
+        }
+    }
+    if (dW) {
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) {
+            const int nt = (KSPLIT == 1) ? wv + 4 * j : j;
+            const int tap = 2 * nt + (n >> 3), c = n & 7;
+            if (nt >= NTILES || tap >= NTAP || c >= ck) continue;
+            const long ci = sd.cbase + c0 + c;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int co = (mg * MT + mt) * 16 + g * 4 + r;
+                    const float v = acc[mt][j][r];
+                    if (co < p.Cout && v != 0.f) atomicAdd(&dW[((long)co * p.Cin + ci) * NTAP + tap], v);
+                }
+        }
+    }
+    if (do_bias && n == 0) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int co = (mg * MT + mt) * 16 + g * 4 + r;
+                if (co < p.Cout) atomicAdd(&dbias[co], accb[mt][r]);
+            }
+    }
+}
+
+template <int KS, int S>
+int launch_wgrad_b(ConvK& k, float* dW, float* db, hipStream_t st) {
+    int chunks = 0;
+    for (int s = 0; s < k.nseg; ++s) chunks += (k.seg[s].C + 7) / 8;
+    const int mtiles = k.Mpad / 16;
+    const int MT = (mtiles % 2 == 0) ? 2 : 1;
+    const int tiles_per_b = k.tilesD * k.tilesH * k.tilesW;
+    const int total = k.B * tiles_per_b;
+    const int gy = chunks * (mtiles / MT);
+    int gx = total;
+    const int cap = (int)hmax(1, 2048 / gy);
+    if (gx > cap) gx = cap;
+    dim3 grid(gx, gy);
+    if (MT == 2) hipLaunchKernelGGL((conv_wgrad_bf16_kernel<KS, S, 2>), grid, dim3(256), 0, st, k, dW, db, tiles_per_b);
+    else hipLaunchKernelGGL((conv_wgrad_bf16_kernel<KS, S, 1>), grid, dim3(256), 0, st, k, dW, db, tiles_per_b);
+    LAUNCH_RET();
+    return 0;
+}
+
+// weight f32 [Cout][Cin][ntap] -> bf16 fwd image [tap][CinPad8/8][CoutPad16][8] and dgrad image
+// [tap][CoutPad8/8][CinPad16][8]
+__global__ void pack_weight_bf16_kernel(const float* __restrict__ w, int Cin, int Cout, int ntap, bf16_t* __restrict__ fwd,
+                                        bf16_t* __restrict__ dg) {
+    const int ci8 = pad8(Cin), co16 = pad16(Cout), co8 = pad8(Cout), ci16 = pad16(Cin);
+    const long nf = (long)ntap * ci8 * co16, nd = (long)ntap * co8 * ci16;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nf + nd; i += (long)gridDim.x * blockDim.x) {
+        if (i < nf) {
+            const int e = (int)(i % 8);
+            const int co = (int)((i / 8) % co16);
+            const int cb = (int)((i / (8L * co16)) % (ci8 / 8));
+            const int tap = (int)(i / (8L * co16 * (ci8 / 8)));
+            const int ci = cb * 8 + e;
+            fwd[i] = (bf16_t)((co < Cout && ci < Cin) ? w[((long)co * Cin + ci) * ntap + tap] : 0.f);
+        } else {
+            const long k = i - nf;
+            const int e = (int)(k % 8);
+            const int ci = (int)((k / 8) % ci16);
+            const int cb = (int)((k / (8L * ci16)) % (co8 / 8));
+            const int tap = (int)(k / (8L * ci16 * (co8 / 8)));
+            const int co = cb * 8 + e;
+            dg[k] = (bf16_t)((co < Cout && ci < Cin) ? w[((long)co * Cin + ci) * ntap + tap] : 0.f);
+        }
+    }
+}
+
+template <int KS, int S, int MODE, int CKB>
+int launch_mt(ConvK& k, int mtiles, hipStream_t st) {
+    const int tiles = k.B * k.tilesD * k.tilesH * k.tilesW;
+    int MT = mtiles >= 4 ? 4 : mtiles;
+    if (mtiles % MT) MT = (mtiles % 2 == 0) ? 2 : 1;
+    while (MT > 1 && (long)tiles * (mtiles / MT) < 512) MT >>= 1;
+    dim3 grid(tiles, mtiles / MT);
+    if (MT == 4) hipLaunchKernelGGL((conv_bf16_kernel<KS, S, 4, MODE, CKB>), grid, dim3(256), 0, st, k);
+    else if (MT == 2) hipLaunchKernelGGL((conv_bf16_kernel<KS, S, 2, MODE, CKB>), grid, dim3(256), 0, st, k);
+    else hipLaunchKernelGGL((conv_bf16_kernel<KS, S, 1, MODE, CKB>), grid, dim3(256), 0, st, k);
+    LAUNCH_RET();
+    return 0;
+}
+
+template <int MODE>
+int launch_geo(ConvK& k, int ksize, int stride, int cmax, int mtiles, hipStream_t st) {
+    const bool big = cmax >= 32;
+    if (ksize == 1) return big ? launch_mt<1, 1, MODE, 32>(k, mtiles, st) : launch_mt<1, 1, MODE, 8>(k, mtiles, st);
+    if (stride == 2) {
+        // forward stride-2 brick is 9x17x17 voxels: only the 8-channel chunk fits LDS; dgrad stages a zero-stuffed 6x10x10 brick
+        if constexpr (MODE == 0) return launch_mt<3, 2, MODE, 8>(k, mtiles, st);
+        else return big ? launch_mt<3, 2, MODE, 32>(k, mtiles, st) : launch_mt<3, 2, MODE, 8>(k, mtiles, st);
+    }
+    return big ? launch_mt<3, 1, MODE, 32>(k, mtiles, st) : launch_mt<3, 1, MODE, 8>(k, mtiles, st);
+}
+
+}  // namespace
+
+namespace pconv {
+
+long bf16_pack_elems(int Cin, int Cout, int ntap) {
+    return (long)ntap * pad8(Cin) * pad16(Cout) + (long)ntap * pad8(Cout) * pad16(Cin);
+}
+
+int pack_weight_bf16(const float* w, int Cin, int Cout, int ntap, void* out, hipStream_t st) {
+    const long nf = (long)ntap * pad8(Cin) * pad16(Cout);
+    const long total = bf16_pack_elems(Cin, Cout, ntap);
+    const int blocks = (int)hmin((total + 255) / 256, 1024);
+    hipLaunchKernelGGL(pack_weight_bf16_kernel, dim3(blocks), dim3(256), 0, st, w, Cin, Cout, ntap,
+                       reinterpret_cast<bf16_t*>(out), reinterpret_cast<bf16_t*>(out) + nf);
+    LAUNCH_RET();
+    return 0;
+}
+
+// All-bf16 launches only; every segment must have C % 8 == 0 unless it is the only one.
+bool bf16_eligible(const ConvK& k, bool dgrad) {
+    if (k.nseg == 1) return dgrad ? true : true;
+    for (int s = 0; s < k.nseg; ++s)
+        if (k.seg[s].C % 8) return false;
+    return true;
+}
+
+int launch_conv_bf16(ConvK& k, int ksize, int stride, bool dgrad, const void* packed_bf16, hipStream_t st) {
+    const int ntap = ksize * ksize * ksize;
+    int cmax = 0;
+    if (dgrad) {
+        cmax = k.Cout;
+        k.Mpad = pad16(k.Cin);
+        k.wpack = reinterpret_cast<const bf16_t*>(packed_bf16) + (long)ntap * pad8(k.Cin) * pad16(k.Cout);
+    } else {
+        for (int s = 0; s < k.nseg; ++s) cmax = k.seg[s].C > cmax ? k.seg[s].C : cmax;
+        k.Mpad = pad16(k.Cout);
+        k.wpack = packed_bf16;
+    }
+    const int mtiles = k.Mpad / 16;
+    return dgrad ? launch_geo<1>(k, ksize, stride, cmax, mtiles, st) : launch_geo<0>(k, ksize, stride, cmax, mtiles, st);
+}
+
+int launch_wgrad_bf16(ConvK& k, int ksize, int stride, float* dW, float* db, hipStream_t st) {
+    k.Mpad = pad16(k.Cout);
+    if (ksize == 1) return launch_wgrad_b<1, 1>(k, dW, db, st);
+    if (stride == 1) return launch_wgrad_b<3, 1>(k, dW, db, st);
+    return launch_wgrad_b<3, 2>(k, dW, db, st);
+}
+
+}  // namespace pconv

@@ -1,0 +1,168 @@
+// Shared between the f32-MFMA (conv.hip) and bf16-MFMA (conv_bf16.hip) implicit-GEMM conv kernels:
+// launch parameters, brick geometry, the reflect-adjoint tap decoding and the two epilogues
+// (forward: bias + residual + store; dgrad: back through LeakyReLU, InstanceNorm-backward sums).
+// Both kernels produce the same accumulator layout: D[row = channel][col = voxel] in 16x16 MFMA tiles,
+// lane l holds column n = l & 15 and rows 4 * (l >> 4) + r, r = 0..3.
+#pragma once
+#include "common.h"
+#include "passion_hip.h"
+
+namespace pconv {
+
+constexpr int TD = 4, TH = 8, TW = 8;   // output brick of one 256-thread workgroup (wave w = depth slice w)
+
+struct SegD {
+    const void* x;
+    const float* stats;
+    const uint8_t* mask;
+    void* dx;
+    long bstride;
+    int C, mask_col, mask_ld, cbase;
+};
+
+struct ConvK {
+    int B, Di, Hi, Wi, Do, Ho, Wo;
+    int pad_mode, nseg, Cin, Cout;
+    float slope;
+    SegD seg[PASSION_MAX_SEG];
+    const void* wpack;
+    int Mpad;
+    const float* bias;
+    const void* residual;
+    void* y;
+    const void* dy;
+    float* sums;
+    int tilesD, tilesH, tilesW;
+    int hi_t[3], hi_u[3];  // dgrad reflect: tap / source coordinate of the high-side mirror term per axis
+};
+
+__host__ __device__ inline int pad16(int c) { return (c + 15) / 16 * 16; }
+__host__ __device__ inline int pad8(int c) { return (c + 7) / 8 * 8; }
+
+// bf16 matrix-core path (conv_bf16.hip)
+long bf16_pack_elems(int Cin, int Cout, int ntap);
+int pack_weight_bf16(const float* w, int Cin, int Cout, int ntap, void* out, hipStream_t st);
+struct ConvK;
+bool bf16_eligible(const ConvK& k, bool dgrad);
+int launch_conv_bf16(ConvK& k, int ksize, int stride, bool dgrad, const void* packed_bf16, hipStream_t st);
+int launch_wgrad_bf16(ConvK& k, int ksize, int stride, float* dW, float* db, hipStream_t st);
+
+// One axis of a tap entry.  a < KS: regular tap; a == KS: low-side mirror term; a == KS+1: high-side.
+// Forward conv of stride S reads padded coordinate o*S + t - 1; 'reflect' maps -1 -> 1 and Sin -> Sin-2, so
+// input index 1 (resp. Sin-2) receives an extra gradient term from (o = 0, t = 0) (resp. the unique (o, t) with
+// o*S + t - 1 = Sin, precomputed on the host as hi_t / hi_u = o*S).
+template <int KS, int HALO, bool DG, int S>
+__device__ __forceinline__ void axis_tap(int a, int il, int i0, int Sin, int hi_t, int hi_u,
+                                         int& t, int& pos, bool& valid) {
+    if (a < KS) {
+        t = a; valid = true;
+        pos = DG ? (il + 2 * HALO - a) : (il * S + a);
+    } else if (a == KS) {
+        t = 0; valid = (i0 + il == 1); pos = 1 - i0;
+    } else {
+        t = hi_t; valid = (hi_t >= 0) && (i0 + il == Sin - 2); pos = hi_u - (i0 - HALO);
+    }
+    if (!valid) pos = 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+template <typename TO, int MT>
+__device__ __forceinline__ void epilogue_fwd(const ConvK& p, const f32x4 (&acc)[MT][4], int b, int mg,
+                                             int od, int ow, const int (&oh4)[4], int kq) {
+    TO* y = reinterpret_cast<TO*>(p.y);
+    const TO* res = reinterpret_cast<const TO*>(p.residual);
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        const int oh = oh4[nt];
+        if (od >= p.Do || oh >= p.Ho || ow >= p.Wo) continue;
+        const long vox = (((long)b * p.Do + od) * p.Ho + oh) * p.Wo + ow;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int co = (mg * MT + mt) * 16 + kq * 4;
+            if (co >= p.Cout) continue;
+            f32x4 v = acc[mt][nt];
+            if (p.bias) v += load4(p.bias + co);
+            if (res) v += load4(res + vox * p.Cout + co);
+            store4(y + vox * p.Cout + co, v);
+        }
+    }
+}
+
+// rows are input channels of the forward conv.  lsum: shared float[MT*16*2], zeroed here.
+template <typename TO, int MT>
+__device__ __forceinline__ void epilogue_dgrad(const ConvK& p, const f32x4 (&acc)[MT][4], float* lsum, int b, int mg,
+                                               int od, int ow, const int (&oh4)[4], int kq, int n, int tid) {
+    const int Od = p.Di, Oh = p.Hi, Ow = p.Wi;
+    const int nrows = MT * 16;
+    for (int i = tid; i < nrows * 2; i += 256) lsum[i] = 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int cg = (mg * MT + mt) * 16 + kq * 4;  // global input channel of row 0 of this lane
+        int sg = -1;
+        if (cg < p.Cin) {
+#pragma unroll
+            for (int s2 = 0; s2 < PASSION_MAX_SEG; ++s2)
+                if (s2 < p.nseg && cg >= p.seg[s2].cbase && cg < p.seg[s2].cbase + p.seg[s2].C) sg = s2;
+        }
+        float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2v[4] = {0.f, 0.f, 0.f, 0.f};
+        const bool seg_ok = (sg >= 0) && (p.seg[sg].dx != nullptr);
+        if (seg_ok) {
+            const SegD& sd = p.seg[sg];
+            const int cl = cg - sd.cbase;
+            float mval = 1.f;
+            if (sd.mask) mval = sd.mask[(long)b * sd.mask_ld + sd.mask_col] ? 1.f : 0.f;
+            f32x4 mean = {0.f, 0.f, 0.f, 0.f}, rstd = {1.f, 1.f, 1.f, 1.f};
+            if (sd.stats) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    mean[j] = sd.stats[((long)b * sd.C + cl + j) * 2 + 0];
+                    rstd[j] = sd.stats[((long)b * sd.C + cl + j) * 2 + 1];
+                }
+            }
+            const TO* x = reinterpret_cast<const TO*>(sd.x) + (long)b * sd.bstride;
+            TO* dx = reinterpret_cast<TO*>(sd.dx) + (long)b * sd.bstride;
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                const int oh = oh4[nt];
+                if (od >= Od || oh >= Oh || ow >= Ow) continue;
+                const long vox = (((long)od) * Oh + oh) * Ow + ow;
+                f32x4 g = acc[mt][nt];
+                if (sd.stats) {
+                    f32x4 xv = load4(x + vox * sd.C + cl);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        float xh = (xv[j] - mean[j]) * rstd[j];
+                        float gg = g[j] * (xh > 0.f ? 1.f : p.slope) * mval;
+                        g[j] = gg;
+                        s1[j] += gg;
+                        s2v[j] += gg * xh;
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) g[j] *= mval;
+                }
+                store4(dx + vox * sd.C + cl, g);
+            }
+        }
+        // reduce the per-channel sums over the 16 voxel lanes, then over waves through LDS
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float a1 = group16_sum(s1[j]), a2 = group16_sum(s2v[j]);
+            if (n == 0 && seg_ok && p.seg[sg].stats) {
+                atomicAdd(&lsum[(mt * 16 + kq * 4 + j) * 2 + 0], a1);
+                atomicAdd(&lsum[(mt * 16 + kq * 4 + j) * 2 + 1], a2);
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < nrows; i += 256) {
+        const int cg = mg * MT * 16 + i;
+        if (cg < p.Cin && (lsum[i * 2] != 0.f || lsum[i * 2 + 1] != 0.f)) {
+            atomicAdd(&p.sums[((long)b * p.Cin + cg) * 2 + 0], lsum[i * 2 + 0]);
+            atomicAdd(&p.sums[((long)b * p.Cin + cg) * 2 + 1], lsum[i * 2 + 1]);
+        }
+    }
+}
+
+}  // namespace pconv
