@@ -80,7 +80,8 @@ int passion_conv3d_fwd(const passion_conv_desc_t* d, const float* packed, const 
 /* Backward of the whole block.  dy: [B][Vout][Cout].
  *  dweight: f32 [Cout][Cin][k^3] and dbias f32 [Cout] are ACCUMULATED into (caller zeroes), either may be NULL.
  *  For every segment with dx != NULL the gradient wrt its raw x is written (through LeakyReLU and
- *  InstanceNorm when stats != NULL).  sums: f32 scratch [B][Cin][2]. */
+ *  InstanceNorm when stats != NULL).  sums: f32 scratch of passion_conv_bwd_scratch_floats(B, Cin) floats. */
+int64_t passion_conv_bwd_scratch_floats(int B, int Cin);
 int passion_conv3d_bwd(const passion_conv_desc_t* d, const float* packed, const void* dy,
                        float* dweight, float* dbias, float* sums, void* stream);
 

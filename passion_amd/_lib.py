@@ -40,6 +40,7 @@ SIGNATURES = {
     "passion_instnorm_stats": (c_int, [c_void_p, c_int, c_int, c_int64, c_int, c_int64, c_float,
                                        c_void_p, c_void_p, c_void_p]),
     "passion_conv_pack_floats": (c_int64, [c_int, c_int, c_int]),
+    "passion_conv_bwd_scratch_floats": (c_int64, [c_int, c_int]),
     "passion_conv_pack_weight": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "passion_conv3d_fwd": (c_int, [POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p,
                                    c_void_p]),

@@ -225,6 +225,15 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvK p) {
     else epilogue_dgrad<TO, MT>(p, acc, lsum, b, mg, o0d + ld_, o0w + lw, oh4, kq, n, tid);
 }
 
+// sums[0][i] = sum_r sums[r][i] in a fixed order
+__global__ void fold_replicas_kernel(float* __restrict__ sums, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float a = 0.f;
+    for (int r = 0; r < SUMS_REP; ++r) a += sums[(long)r * n + i];
+    sums[i] = a;
+}
+
 // InstanceNorm backward, second half:  dx = rstd * (g - mean(g) - xhat * mean(g * xhat))
 // where g = dL/dxhat (already written into dx by the dgrad epilogue) -- in place.
 template <typename T>
@@ -490,7 +499,7 @@ int launch_wgrad_mt(ConvK& k, float* dW, float* db, hipStream_t st) {
     const int total = k.B * tiles_per_b;
     const int gy = chunks * (mtiles / MT);
     int gx = total;
-    const int cap = (int)hmax(1, 2048 / gy);
+    const int cap = (int)hmax(1, 512 / gy);   // every block ends with an atomic flush into the same dW words: keep them few
     if (gx > cap) gx = cap;
     dim3 grid(gx, gy);
     if (MT == 2) hipLaunchKernelGGL((conv_wgrad_kernel<TX, TY, KS, S, 2>), grid, dim3(256), 0, st, k, dW, db, chunks, tiles_per_b);
@@ -514,6 +523,8 @@ double conv_bytes(const ConvK& k, int xs, int ys) {
 }
 
 }  // namespace
+
+extern "C" int64_t passion_conv_bwd_scratch_floats(int B, int Cin) { return (int64_t)2 * B * Cin * SUMS_REP; }
 
 extern "C" int64_t passion_conv_pack_floats(int Cin, int Cout, int ksize) {
     const int64_t nt = (int64_t)ksize * ksize * ksize;
@@ -596,7 +607,7 @@ extern "C" int passion_conv3d_bwd(const passion_conv_desc_t* d, const float* pac
     for (int s = 0; s < k.nseg; ++s) if (k.seg[s].C % 4) return -1008;
     if (need_norm) {
         if (!sums) return -1009;
-        HIP_RET(hipMemsetAsync(sums, 0, sizeof(float) * 2 * (size_t)k.B * k.Cin, st));
+        HIP_RET(hipMemsetAsync(sums, 0, sizeof(float) * 2 * (size_t)k.B * k.Cin * SUMS_REP, st));
     }
     k.sums = sums;
     k.Mpad = pad16(k.Cin);
@@ -620,6 +631,11 @@ extern "C" int passion_conv3d_bwd(const passion_conv_desc_t* d, const float* pac
         else
             rc = -1007;
         if (rc) return rc;
+    }
+    if (need_norm) {
+        const int nw = 2 * k.B * k.Cin;
+        hipLaunchKernelGGL(fold_replicas_kernel, dim3((nw + 255) / 256), dim3(256), 0, st, sums, nw);
+        LAUNCH_RET();
     }
     // ---- InstanceNorm backward finish (in place on dx) ----
     const long V = (long)k.Di * k.Hi * k.Wi;

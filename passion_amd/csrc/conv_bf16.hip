@@ -428,7 +428,7 @@ int launch_wgrad_b(ConvK& k, float* dW, float* db, hipStream_t st) {
     const int total = k.B * tiles_per_b;
     const int gy = chunks * (mtiles / MT);
     int gx = total;
-    const int cap = (int)hmax(1, 2048 / gy);
+    const int cap = (int)hmax(1, 512 / gy);   // every block ends with an atomic flush into the same dW words: keep them few
     if (gx > cap) gx = cap;
     dim3 grid(gx, gy);
     if (MT == 2) hipLaunchKernelGGL((conv_wgrad_bf16_kernel<KS, S, 2>), grid, dim3(256), 0, st, k, dW, db, tiles_per_b);

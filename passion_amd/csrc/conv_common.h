@@ -9,6 +9,7 @@
 
 namespace pconv {
 
+constexpr int SUMS_REP = 32;            // replicas of the InstanceNorm-backward sums (atomic contention)
 constexpr int TD = 4, TH = 8, TW = 8;   // output brick of one 256-thread workgroup (wave w = depth slice w)
 
 struct SegD {
@@ -159,8 +160,10 @@ __device__ __forceinline__ void epilogue_dgrad(const ConvK& p, const f32x4 (&acc
     for (int i = tid; i < nrows; i += 256) {
         const int cg = mg * MT * 16 + i;
         if (cg < p.Cin && (lsum[i * 2] != 0.f || lsum[i * 2 + 1] != 0.f)) {
-            atomicAdd(&p.sums[((long)b * p.Cin + cg) * 2 + 0], lsum[i * 2 + 0]);
-            atomicAdd(&p.sums[((long)b * p.Cin + cg) * 2 + 1], lsum[i * 2 + 1]);
+            // thousands of bricks add into the same 2*Cin words: spread them over SUMS_REP replicas (folded afterwards)
+            float* rs = p.sums + (long)(blockIdx.x % SUMS_REP) * p.B * p.Cin * 2;
+            atomicAdd(&rs[((long)b * p.Cin + cg) * 2 + 0], lsum[i * 2 + 0]);
+            atomicAdd(&rs[((long)b * p.Cin + cg) * 2 + 1], lsum[i * 2 + 1]);
         }
     }
 }

@@ -2,8 +2,9 @@
 // Replaces the reduction inside nn.InstanceNorm3d(affine=False) (reference code/models/blocks.py:18,
 // applied at blocks.py:313).  The normalisation itself is fused into the consuming conv's loader.
 // Channels-last input: a thread keeps one 4-channel vector lane for the whole sweep (coalesced 16 B
-// loads), block partials are combined with wavefront shuffles + LDS and leave the block as f64
-// atomics so that E[x^2] - E[x]^2 is evaluated without cancellation trouble.
+// loads, several in flight), lanes that share a channel vector are combined with wavefront shuffles,
+// the four waves through LDS, and a block leaves with ONE f64 atomic per (channel, moment) so that
+// E[x^2] - E[x]^2 is evaluated without cancellation trouble.
 #include "common.h"
 #include "passion_hip.h"
 
@@ -12,27 +13,52 @@ namespace {
 template <typename T>
 __global__ __launch_bounds__(256) void stats_partial_kernel(const T* __restrict__ x, long V, int C, long bstride,
                                                             double* __restrict__ scratch) {
-    __shared__ float red[256 * 8];
+    __shared__ float red[4 * 64 * 8];
     const int b = blockIdx.y;
-    const int cvn = C / 4;              // channel vectors per voxel; divides 256
-    const int tid = threadIdx.x;
+    const int cvn = C / 4;              // channel vectors per voxel; a power of two <= 256
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const long nvec = V * cvn;
     const T* xb = x + (long)b * bstride;
     float s[4] = {0.f, 0.f, 0.f, 0.f}, q[4] = {0.f, 0.f, 0.f, 0.f};
     // stride is a multiple of cvn, so a thread always sees the same 4 channels
-    for (long i = (long)blockIdx.x * 256 + tid; i < nvec; i += (long)gridDim.x * 256) {
-        f32x4 v = load4(xb + i * 4);
+    const long stride = (long)gridDim.x * 256;
+    long i = (long)blockIdx.x * 256 + tid;
+    for (; i + 3 * stride < nvec; i += 4 * stride) {   // four independent 16-byte loads in flight
+        const f32x4 v0 = load4(xb + i * 4), v1 = load4(xb + (i + stride) * 4), v2 = load4(xb + (i + 2 * stride) * 4),
+                    v3 = load4(xb + (i + 3 * stride) * 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            s[j] += (v0[j] + v1[j]) + (v2[j] + v3[j]);
+            q[j] += (v0[j] * v0[j] + v1[j] * v1[j]) + (v2[j] * v2[j] + v3[j] * v3[j]);
+        }
+    }
+    for (; i < nvec; i += stride) {
+        const f32x4 v = load4(xb + i * 4);
 #pragma unroll
         for (int j = 0; j < 4; ++j) { s[j] += v[j]; q[j] += v[j] * v[j]; }
     }
+    // lanes l and l ^ o share a channel vector whenever o is a multiple of cvn
+    const int w = cvn < 64 ? cvn : 64;   // distinct channel vectors inside one wave
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { red[tid * 8 + j] = s[j]; red[tid * 8 + 4 + j] = q[j]; }
+    for (int o = 32; o >= 1; o >>= 1) {
+        if (o >= w) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { s[j] += __shfl_xor(s[j], o, 64); q[j] += __shfl_xor(q[j], o, 64); }
+        }
+    }
+    if (lane < w) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { red[(wv * 64 + lane) * 8 + j] = s[j]; red[(wv * 64 + lane) * 8 + 4 + j] = q[j]; }
+    }
     __syncthreads();
+    // channel vector cv lives in (wave wv, lane l) with (wv*64 + l) % cvn == cv
     if (tid < cvn) {
         double ds[4] = {0, 0, 0, 0}, dq[4] = {0, 0, 0, 0};
-        for (int r = tid; r < 256; r += cvn) {
+        for (int t = tid; t < 256; t += cvn) {
+            const int l = t & 63;
+            if (l >= w) continue;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { ds[j] += (double)red[r * 8 + j]; dq[j] += (double)red[r * 8 + 4 + j]; }
+            for (int j = 0; j < 4; ++j) { ds[j] += (double)red[t * 8 + j]; dq[j] += (double)red[t * 8 + 4 + j]; }
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -61,7 +87,7 @@ extern "C" int passion_instnorm_stats(const void* x, int dtype, int B, int64_t V
     hipStream_t st = (hipStream_t)stream;
     HIP_RET(hipMemsetAsync(scratch, 0, sizeof(double) * 2 * (size_t)B * C, st));
     const long nvec = V * (C / 4);
-    int gx = (int)hmin((nvec + 256 * 8 - 1) / (256 * 8), 1024);
+    int gx = (int)hmin((nvec + 256 * 16 - 1) / (256 * 16), 512);
     if (gx < 1) gx = 1;
     dim3 grid(gx, B);
     if (dtype == PASSION_F32)

@@ -110,6 +110,54 @@ __global__ __launch_bounds__(256) void upsample_bwd_kernel(const T* __restrict__
     }
 }
 
+// k <= 2: one thread per (input voxel, 4-channel vector).  At most 5 output indices per axis can reference an
+// input index; their weights are evaluated once per axis (15 evaluations) instead of once per candidate triple.
+template <typename T>
+__global__ __launch_bounds__(256) void upsample_bwd_k2_kernel(const T* __restrict__ dy, T* __restrict__ dx, int B, int D,
+                                                              int H, int W, int C, int k) {
+    constexpr int NC = 6;
+    const int Do = D * k, Ho = H * k, Wo = W * k, cvn = C / 4;
+    const float sd = axis_scale(D, Do), sh = axis_scale(H, Ho), sw = axis_scale(W, Wo);
+    const long items = (long)B * D * H * W * cvn;
+    for (long it = (long)blockIdx.x * blockDim.x + threadIdx.x; it < items; it += (long)gridDim.x * blockDim.x) {
+        const int cv = (int)(it % cvn);
+        long v = it / cvn;
+        const int iw = (int)(v % W); v /= W;
+        const int ih = (int)(v % H); v /= H;
+        const int id = (int)(v % D);
+        const int b = (int)(v / D);
+        // outputs that can reference input i have src in (i-1, i+1), i.e. o in ((i-1)/scale, (i+1)/scale): a window of
+        // 2/scale ~ 4.03 indices for k = 2.  Slots o = lo + j, j < NC, with statically indexed weights (zero = skip).
+        const int dlo = max(0, (int)floorf((float)(id - 1) / sd)), hlo = max(0, (int)floorf((float)(ih - 1) / sh)),
+                  wlo = max(0, (int)floorf((float)(iw - 1) / sw));
+        float wd[NC], wh[NC], ww[NC];
+#pragma unroll
+        for (int j = 0; j < NC; ++j) {
+            wd[j] = (dlo + j < Do) ? axis_weight(dlo + j, id, sd, D) : 0.f;
+            wh[j] = (hlo + j < Ho) ? axis_weight(hlo + j, ih, sh, H) : 0.f;
+            ww[j] = (wlo + j < Wo) ? axis_weight(wlo + j, iw, sw, W) : 0.f;
+        }
+        const T* dyb = dy + (long)b * Do * Ho * Wo * C + cv * 4;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int a = 0; a < NC; ++a) {
+            if (wd[a] == 0.f) continue;
+#pragma unroll
+            for (int e = 0; e < NC; ++e) {
+                if (wh[e] == 0.f) continue;
+                const float wde = wd[a] * wh[e];
+                const T* row = dyb + (((long)(dlo + a)) * Ho + (hlo + e)) * Wo * C;
+#pragma unroll
+                for (int f = 0; f < NC; ++f) {
+                    if (ww[f] == 0.f) continue;
+                    acc += (wde * ww[f]) * load4(row + (long)(wlo + f) * C);
+                }
+            }
+        }
+        store4(dx + it * 4, acc);
+    }
+}
+
 }  // namespace
 
 extern "C" int passion_upsample_fwd(const void* x, void* y, int dtype, int B, int D, int H, int W, int C, int k,
@@ -133,12 +181,12 @@ extern "C" int passion_upsample_bwd(const void* dy, void* dx, int dtype, int B, 
     if (C % 4 || k < 1) return -1011;
     const long items = (long)B * D * H * W * (C / 4);
     hipStream_t st = (hipStream_t)stream;
-    if (k <= 2) {
+    if (k == 2 && D > 1 && H > 1 && W > 1) {
         const int blocks = (int)hmin((items + 255) / 256, 8192);
         if (dtype == PASSION_F32)
-            hipLaunchKernelGGL((upsample_bwd_kernel<float, 1>), dim3(blocks), dim3(256), 0, st, (const float*)dy, (float*)dx, B, D, H, W, C, k);
+            hipLaunchKernelGGL(upsample_bwd_k2_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)dy, (float*)dx, B, D, H, W, C, k);
         else if (dtype == PASSION_BF16)
-            hipLaunchKernelGGL((upsample_bwd_kernel<bf16_t, 1>), dim3(blocks), dim3(256), 0, st, (const bf16_t*)dy, (bf16_t*)dx, B, D, H, W, C, k);
+            hipLaunchKernelGGL(upsample_bwd_k2_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, (const bf16_t*)dy, (bf16_t*)dx, B, D, H, W, C, k);
         else
             return -1007;
     } else {

@@ -370,10 +370,17 @@ class Model(nn.Module):
             tok_mask = onehots[2] if i == 3 else onehots[i]          # reference quirk, mmformer.py:522
             fuse_i, preds_i, de_f_i = self.decoder_fuse(*xs_i, self._inter(intra, tok_mask, pos_cat, B, p))
             pl, d = ops.proto_loss(de_f_i[0], f_teacher, tcl)
-            proto_loss = proto_loss + gates[i] * pl
-            dist = dist + gates[i] * d
             kl = crit.kl_cl(fuse_i, pt_full, temp)
             for j, ps_ in enumerate(preds_i):
                 kl = kl + 0.5 ** (j + 1) * crit.kl_cl(ps_, pt_deep[j], temp, 2 ** (j + 1))
+            if i != 3:
+                # A sample whose only present modality is i feeds the student exactly what the teacher saw, so
+                # the reference (deterministic kernels) gets kl = proto = dist = 0 *exactly* -- and train.py:266-267
+                # then turns that 0/0 into an all-false rp_mask.  Our reductions use atomics (run-to-run rounding),
+                # so the identity is imposed instead of hoped for.  (Not for T2: its tokens are T1's, mmformer.py:522.)
+                differs = (~(mask == onehots[i]).all(1)).float().view(B, 1)
+                pl, d, kl = pl * differs, d * differs, kl * differs
+            proto_loss = proto_loss + gates[i] * pl
+            dist = dist + gates[i] * d
             kl_loss = kl_loss + gates[i] * kl
         return pred, prm_loss, sep_loss, kl_loss, proto_loss, dist

@@ -149,7 +149,7 @@ class ConvBlockFn(torch.autograd.Function):
         d = _fill_desc(cfg, xs, dxs)
         d.Cout = ctx.wshape[0]
         cin = sum(s.C for s in cfg.segs)
-        sums = torch.empty(cfg.B * cin * 2, dtype=torch.float32, device=dev)
+        sums = torch.empty(lib.passion_conv_bwd_scratch_floats(cfg.B, cin), dtype=torch.float32, device=dev)
         L.check(lib.passion_conv3d_bwd(byref(d), _p(ctx.packed), _p(dy), _p(dW), _p(db), _p(sums),
                                        L.stream_ptr()), "passion_conv3d_bwd")
         dres = dy if (ctx.has_res and ctx.needs_input_grad[3]) else None
