@@ -34,8 +34,10 @@ int passion_abi_version(void);
 /* ---- InstanceNorm statistics ------------------------------------------------------------
  * Replaces the reduction half of nn.InstanceNorm3d(affine=False) (code/models/blocks.py:18,
  * applied at blocks.py:313 / :368): per (b,c) mean and 1/sqrt(biased_var + eps) over D*H*W.
- * x: [B][V][C] (batch stride `bstride` elements); scratch: B*C*2 doubles (zeroed by the call);
+ * x: [B][V][C] (batch stride `bstride` elements); scratch: passion_instnorm_scratch_doubles(B,V,C) doubles
+ * (per-workgroup partial sums, folded in a fixed order: no atomics, bitwise reproducible);
  * stats out: [B][C][2] f32 = (mean, rstd).  C must be a multiple of 4. */
+int64_t passion_instnorm_scratch_doubles(int B, int64_t V, int C);
 int passion_instnorm_stats(const void* x, int dtype, int B, int64_t V, int C, int64_t bstride,
                            float eps, double* scratch, float* stats, void* stream);
 
@@ -78,12 +80,15 @@ int passion_conv_pack_weight(const float* weight, int Cin, int Cout, int ksize, 
 int passion_conv3d_fwd(const passion_conv_desc_t* d, const float* packed, const float* bias,
                        const void* residual, void* y, void* stream);
 /* Backward of the whole block.  dy: [B][Vout][Cout].
- *  dweight: f32 [Cout][Cin][k^3] and dbias f32 [Cout] are ACCUMULATED into (caller zeroes), either may be NULL.
+ *  dweight: f32 [Cout][Cin][k^3] and dbias f32 [Cout] are OVERWRITTEN (either may be NULL).  They are produced
+ *  without atomics: every workgroup stores its partial sums into its own slot of a slab inside `scratch`,
+ *  a second kernel folds the slots in a fixed order (bitwise reproducible).
  *  For every segment with dx != NULL the gradient wrt its raw x is written (through LeakyReLU and
- *  InstanceNorm when stats != NULL).  sums: f32 scratch of passion_conv_bwd_scratch_floats(B, Cin) floats. */
-int64_t passion_conv_bwd_scratch_floats(int B, int Cin);
+ *  InstanceNorm when stats != NULL).
+ *  scratch: f32 workspace of passion_conv_bwd_scratch_floats(d) floats (InstanceNorm-backward sums + slabs). */
+int64_t passion_conv_bwd_scratch_floats(const passion_conv_desc_t* d);
 int passion_conv3d_bwd(const passion_conv_desc_t* d, const float* packed, const void* dy,
-                       float* dweight, float* dbias, float* sums, void* stream);
+                       float* dweight, float* dbias, float* scratch, void* stream);
 
 /* ---- trilinear resampling, align_corners=True ---------------------------------------------
  * Replaces nn.Upsample(scale_factor=k, mode='trilinear', align_corners=True)

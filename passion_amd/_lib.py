@@ -37,10 +37,11 @@ class ProfRec(Structure):
 # (tests/test_abi.py cross-checks the header against this table and against the .so).
 SIGNATURES = {
     "passion_abi_version": (c_int, []),
+    "passion_instnorm_scratch_doubles": (c_int64, [c_int, c_int64, c_int]),
     "passion_instnorm_stats": (c_int, [c_void_p, c_int, c_int, c_int64, c_int, c_int64, c_float,
                                        c_void_p, c_void_p, c_void_p]),
     "passion_conv_pack_floats": (c_int64, [c_int, c_int, c_int]),
-    "passion_conv_bwd_scratch_floats": (c_int64, [c_int, c_int]),
+    "passion_conv_bwd_scratch_floats": (c_int64, [POINTER(ConvDesc)]),
     "passion_conv_pack_weight": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "passion_conv3d_fwd": (c_int, [POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p,
                                    c_void_p]),

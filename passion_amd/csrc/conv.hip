@@ -225,15 +225,6 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvK p) {
     else epilogue_dgrad<TO, MT>(p, acc, lsum, b, mg, o0d + ld_, o0w + lw, oh4, kq, n, tid);
 }
 
-// sums[0][i] = sum_r sums[r][i] in a fixed order
-__global__ void fold_replicas_kernel(float* __restrict__ sums, int n) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    float a = 0.f;
-    for (int r = 0; r < SUMS_REP; ++r) a += sums[(long)r * n + i];
-    sums[i] = a;
-}
-
 // InstanceNorm backward, second half:  dx = rstd * (g - mean(g) - xhat * mean(g * xhat))
 // where g = dL/dxhat (already written into dx by the dgrad epilogue) -- in place.
 template <typename T>
@@ -379,8 +370,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(ConvK p, float* __restr
             }
         }
     }
-    // flush: lane holds rows co = (mg*MT+mt)*16 + kq*4 + r, column n of each of its tiles
+    // flush: lane holds rows co = (mg*MT+mt)*16 + kq*4 + r, column n of each of its tiles.  Every workgroup owns
+    // slot blockIdx.x of the partial-sum slab (plain stores, no atomics); reduce_parts_kernel folds the slots.
     if (dW) {
+        dW += (long)blockIdx.x * p.Cout * p.Cin * NTAP;
 #pragma unroll
         for (int j = 0; j < WG_NTW; ++j) {
             if (!colok[j]) continue;
@@ -393,7 +386,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(ConvK p, float* __restr
                 for (int r = 0; r < 4; ++r) {
                     const int co = (mg * MT + mt) * 16 + kq * 4 + r;
                     const float v = acc[mt][j][r];
-                    if (co < p.Cout && v != 0.f) atomicAdd(&dW[((long)co * p.Cin + ci) * NTAP + tap], v);
+                    if (co < p.Cout) dW[((long)co * p.Cin + ci) * NTAP + tap] = v;
                 }
         }
     }
@@ -403,8 +396,27 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(ConvK p, float* __restr
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int co = (mg * MT + mt) * 16 + kq * 4 + r;
-                if (co < p.Cout) atomicAdd(&dbias[co], accb[mt][r]);
+                if (co < p.Cout) dbias[(long)blockIdx.x * p.Cout + co] = accb[mt][r];
             }
+    }
+}
+
+// out[i] = sum_{r < R} part[r * n + i], fixed summation order.  256 threads = 16 outputs x 16 slices of r.
+__global__ __launch_bounds__(256) void reduce_parts_kernel(const float* __restrict__ part, int R, long n,
+                                                           float* __restrict__ out) {
+    __shared__ float red[16][17];
+    const int li = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    const long i = (long)blockIdx.x * 16 + li;
+    float a = 0.f;
+    if (i < n)
+        for (int r = sl; r < R; r += 16) a += part[(long)r * n + i];
+    red[sl][li] = a;
+    __syncthreads();
+    if (sl == 0 && i < n) {
+        float t = 0.f;
+#pragma unroll
+        for (int k2 = 0; k2 < 16; ++k2) t += red[k2][li];
+        out[i] = t;
     }
 }
 
@@ -488,31 +500,39 @@ int launch_conv_geo(ConvK& k, int ksize, int stride, int mtiles, hipStream_t st)
     return launch_conv_mt<TI, TO, 3, 2, MODE>(k, mtiles, st);
 }
 
+struct WgPlan { bool bf16; int MT, chunks, gx, gy; };
+
+// grid of the wgrad launch: y = (8/16-channel chunk) x (row-tile group), x = bricks strided over <= 1024/gy workgroups
+WgPlan plan_wgrad(const ConvK& k, const passion_conv_desc_t* d) {
+    WgPlan w;
+    w.bf16 = d->x_dtype == PASSION_BF16 && d->y_dtype == PASSION_BF16 && bf16_eligible(k, false) && !g_passion_force_f32_mfma;
+    const int CK = w.bf16 ? 8 : (d->ksize == 1 ? 16 : (d->stride == 2 ? 4 : 8));
+    w.chunks = 0;
+    for (int s = 0; s < k.nseg; ++s) w.chunks += (k.seg[s].C + CK - 1) / CK;
+    const int mtiles = pad16(k.Cout) / 16;
+    w.MT = w.bf16 ? ((mtiles % 2 == 0) ? 2 : 1) : ((mtiles % 2 == 0 && d->stride == 1) ? 2 : 1);
+    w.gy = w.chunks * (mtiles / w.MT);
+    const long total = (long)k.B * cdiv(k.Do, TD) * cdiv(k.Ho, TH) * cdiv(k.Wo, TW);
+    w.gx = (int)hmin(total, hmax(1, 1024 / w.gy));
+    return w;
+}
+
 template <typename TX, typename TY, int KS, int S>
-int launch_wgrad_mt(ConvK& k, float* dW, float* db, hipStream_t st) {
-    constexpr int CK = Geo<KS, S, false>::CK;
-    int chunks = 0;
-    for (int s = 0; s < k.nseg; ++s) chunks += (k.seg[s].C + CK - 1) / CK;
-    const int mtiles = k.Mpad / 16;
-    const int MT = (mtiles % 2 == 0 && S == 1) ? 2 : 1;  // stride-2 input brick already fills the 64 KB static LDS
+int launch_wgrad_mt(ConvK& k, const WgPlan& w, float* dW, float* db, hipStream_t st) {
     const int tiles_per_b = k.tilesD * k.tilesH * k.tilesW;
-    const int total = k.B * tiles_per_b;
-    const int gy = chunks * (mtiles / MT);
-    int gx = total;
-    const int cap = (int)hmax(1, 512 / gy);   // every block ends with an atomic flush into the same dW words: keep them few
-    if (gx > cap) gx = cap;
-    dim3 grid(gx, gy);
-    if (MT == 2) hipLaunchKernelGGL((conv_wgrad_kernel<TX, TY, KS, S, 2>), grid, dim3(256), 0, st, k, dW, db, chunks, tiles_per_b);
-    else hipLaunchKernelGGL((conv_wgrad_kernel<TX, TY, KS, S, 1>), grid, dim3(256), 0, st, k, dW, db, chunks, tiles_per_b);
+    dim3 grid(w.gx, w.gy);
+    if (w.MT == 2) {
+        if constexpr (S == 1) hipLaunchKernelGGL((conv_wgrad_kernel<TX, TY, KS, S, 2>), grid, dim3(256), 0, st, k, dW, db, w.chunks, tiles_per_b);
+    } else hipLaunchKernelGGL((conv_wgrad_kernel<TX, TY, KS, S, 1>), grid, dim3(256), 0, st, k, dW, db, w.chunks, tiles_per_b);
     LAUNCH_RET();
     return 0;
 }
 
 template <typename TX, typename TY>
-int launch_wgrad_geo(ConvK& k, int ksize, int stride, float* dW, float* db, hipStream_t st) {
-    if (ksize == 1) return launch_wgrad_mt<TX, TY, 1, 1>(k, dW, db, st);
-    if (stride == 1) return launch_wgrad_mt<TX, TY, 3, 1>(k, dW, db, st);
-    return launch_wgrad_mt<TX, TY, 3, 2>(k, dW, db, st);
+int launch_wgrad_geo(ConvK& k, const WgPlan& w, int ksize, int stride, float* dW, float* db, hipStream_t st) {
+    if (ksize == 1) return launch_wgrad_mt<TX, TY, 1, 1>(k, w, dW, db, st);
+    if (stride == 1) return launch_wgrad_mt<TX, TY, 3, 1>(k, w, dW, db, st);
+    return launch_wgrad_mt<TX, TY, 3, 2>(k, w, dW, db, st);
 }
 
 long f32_pack_floats(int Cin, int Cout, int nt) { return (long)nt * Cin * pad16(Cout) + (long)nt * Cout * pad16(Cin); }
@@ -524,7 +544,13 @@ double conv_bytes(const ConvK& k, int xs, int ys) {
 
 }  // namespace
 
-extern "C" int64_t passion_conv_bwd_scratch_floats(int B, int Cin) { return (int64_t)2 * B * Cin * SUMS_REP; }
+extern "C" int64_t passion_conv_bwd_scratch_floats(const passion_conv_desc_t* d) {
+    ConvK k;
+    if (fill_params(d, k)) return -1;
+    const WgPlan w = plan_wgrad(k, d);
+    const int64_t nt = (int64_t)d->ksize * d->ksize * d->ksize;
+    return (int64_t)2 * k.B * k.Cin * SUMS_REP + (int64_t)w.gx * ((int64_t)k.Cout * k.Cin * nt + k.Cout);
+}
 
 extern "C" int64_t passion_conv_pack_floats(int Cin, int Cout, int ksize) {
     const int64_t nt = (int64_t)ksize * ksize * ksize;
@@ -580,22 +606,38 @@ extern "C" int passion_conv3d_bwd(const passion_conv_desc_t* d, const float* pac
     const int xs = d->x_dtype == PASSION_BF16 ? 2 : 4, ys = d->y_dtype == PASSION_BF16 ? 2 : 4;
     k.dy = dy;
     k.tilesD = cdiv(k.Do, TD); k.tilesH = cdiv(k.Ho, TH); k.tilesW = cdiv(k.Wo, TW);
-    // ---- wgrad (+ bias grad) ----
+    // ---- wgrad (+ bias grad): per-workgroup partial slabs, then a fixed-order fold (no atomics, deterministic) ----
     if (dweight || dbias) {
         k.Mpad = pad16(k.Cout);
-        ProfScope prof(3, conv_bytes(k, xs, ys) + (double)nt * k.Cin * k.Cout * 4,
-                       2.0 * k.B * k.Do * k.Ho * k.Wo * (double)k.Cout * k.Cin * nt, st);
-        if (d->x_dtype == PASSION_F32 && d->y_dtype == PASSION_F32)
-            rc = launch_wgrad_geo<float, float>(k, d->ksize, d->stride, dweight, dbias, st);
-        else if (d->x_dtype == PASSION_BF16 && d->y_dtype == PASSION_BF16)
-            rc = (bf16_eligible(k, false) && !g_passion_force_f32_mfma)
-                     ? launch_wgrad_bf16(k, d->ksize, d->stride, dweight, dbias, st)
-                     : launch_wgrad_geo<bf16_t, bf16_t>(k, d->ksize, d->stride, dweight, dbias, st);
-        else if (d->x_dtype == PASSION_BF16 && d->y_dtype == PASSION_F32)
-            rc = launch_wgrad_geo<bf16_t, float>(k, d->ksize, d->stride, dweight, dbias, st);
-        else
-            rc = -1007;
-        if (rc) return rc;
+        const WgPlan w = plan_wgrad(k, d);
+        const long nW = (long)k.Cout * k.Cin * nt;
+        float* wslab = sums + (long)2 * k.B * k.Cin * SUMS_REP;
+        float* bslab = wslab + (long)w.gx * nW;
+        {
+            ProfScope prof(3, conv_bytes(k, xs, ys) + (double)nt * k.Cin * k.Cout * 4,
+                           2.0 * k.B * k.Do * k.Ho * k.Wo * (double)k.Cout * k.Cin * nt, st);
+            float* dWs = dweight ? wslab : nullptr;
+            float* dbs = dbias ? bslab : nullptr;
+            if (w.bf16)
+                rc = launch_wgrad_bf16(k, d->ksize, d->stride, w.MT, w.gx, w.gy, dWs, dbs, st);
+            else if (d->x_dtype == PASSION_F32 && d->y_dtype == PASSION_F32)
+                rc = launch_wgrad_geo<float, float>(k, w, d->ksize, d->stride, dWs, dbs, st);
+            else if (d->x_dtype == PASSION_BF16 && d->y_dtype == PASSION_BF16)
+                rc = launch_wgrad_geo<bf16_t, bf16_t>(k, w, d->ksize, d->stride, dWs, dbs, st);
+            else if (d->x_dtype == PASSION_BF16 && d->y_dtype == PASSION_F32)
+                rc = launch_wgrad_geo<bf16_t, float>(k, w, d->ksize, d->stride, dWs, dbs, st);
+            else
+                rc = -1007;
+            if (rc) return rc;
+        }
+        if (dweight) {
+            hipLaunchKernelGGL(reduce_parts_kernel, dim3((unsigned)((nW + 15) / 16)), dim3(256), 0, st, wslab, w.gx, nW, dweight);
+            LAUNCH_RET();
+        }
+        if (dbias) {
+            hipLaunchKernelGGL(reduce_parts_kernel, dim3((k.Cout + 15) / 16), dim3(256), 0, st, bslab, w.gx, (long)k.Cout, dbias);
+            LAUNCH_RET();
+        }
     }
     // ---- dgrad ----
     bool need_dx = false, need_norm = false;
@@ -634,7 +676,7 @@ extern "C" int passion_conv3d_bwd(const passion_conv_desc_t* d, const float* pac
     }
     if (need_norm) {
         const int nw = 2 * k.B * k.Cin;
-        hipLaunchKernelGGL(fold_replicas_kernel, dim3((nw + 255) / 256), dim3(256), 0, st, sums, nw);
+        hipLaunchKernelGGL(reduce_parts_kernel, dim3((nw + 15) / 16), dim3(256), 0, st, sums, SUMS_REP, (long)nw, sums);
         LAUNCH_RET();
     }
     // ---- InstanceNorm backward finish (in place on dx) ----

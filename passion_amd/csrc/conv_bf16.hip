@@ -33,6 +33,15 @@ template <int KS, int S, bool DG, int CKB> struct GeoB {
     static constexpr int NSTEP = (Q + 3) / 4;
 };
 
+// weight fragments of one chunk in LDS: NSTEP * 4 lane groups * MT*16 rows * 16 B; kept when <= 56 KB
+__host__ __device__ constexpr bool wlds_fits(int ckb, int mt) { return ckb == 8 || mt <= 2; }
+template <int KS, int S, bool DG, int CKB> __host__ __device__ constexpr int brick_bytes() {
+    return (GeoB<KS, S, DG, CKB>::VOL * GeoB<KS, S, DG, CKB>::VS + 15) / 16 * 16;
+}
+template <int KS, int S, bool DG, int CKB, int MT> constexpr int conv_lds_bytes() {
+    return brick_bytes<KS, S, DG, CKB>() + (wlds_fits(CKB, MT) ? GeoB<KS, S, DG, CKB>::NSTEP * 4 * MT * 16 * 16 : 0);
+}
+
 __device__ __forceinline__ bf16x8 zero8() {
     bf16x8 z;
 #pragma unroll
@@ -111,8 +120,13 @@ template <int KS, int S, int MT, int MODE, int CKB>
 __global__ __launch_bounds__(256) void conv_bf16_kernel(ConvK p) {
     constexpr bool DG = (MODE == 1);
     using G = GeoB<KS, S, DG, CKB>;
-    __shared__ __attribute__((aligned(16))) char lds[G::VOL * G::VS];
-    __shared__ float lsum[DG ? MT * 16 * 2 : 1];
+    // dynamic LDS: [input brick | this chunk's weight fragments (when they fit: WLDS)]
+    extern __shared__ __attribute__((aligned(16))) char dyn_lds[];
+    char* lds = dyn_lds;
+    constexpr bool WLDS = wlds_fits(CKB, MT);
+    constexpr int WV = G::NSTEP * 4 * MT * 16;          // 16-byte weight vectors per chunk
+    bf16x8* wl = reinterpret_cast<bf16x8*>(dyn_lds + brick_bytes<KS, S, DG, CKB>());
+    __shared__ float lsum[DG ? MT * 16 * 2 : 4];
 
     const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, n = lane & 15, g = lane >> 4;
     int bid = blockIdx.x;
@@ -150,6 +164,27 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(ConvK p) {
     const bool hiH = reflect_dg && p.hi_t[1] >= 0 && (o0h <= Oh - 2) && (Oh - 2 < o0h + TH);
     const bool hiW = reflect_dg && p.hi_t[2] >= 0 && (o0w <= Ow - 2) && (Ow - 2 < o0w + TW);
     const bool any_mirror = lowD || lowH || lowW || hiD || hiH || hiW;
+    // list of this brick's mirror tap combos, in a fixed order (ballot + prefix count over waves 0 and 1)
+    __shared__ unsigned short mlist[128];
+    __shared__ int mcnt[4];
+    int nmirror = 0;
+    if (DG && KS == 3 && any_mirror) {       // workgroup-uniform
+        bool f = false;
+        int code = 0;
+        if (tid < 125) {
+            const int ad = tid / 25, ah = (tid / 5) % 5, aw = tid % 5;
+            f = !(ad < 3 && ah < 3 && aw < 3) && (ad != 3 || lowD) && (ad != 4 || hiD) && (ah != 3 || lowH) &&
+                (ah != 4 || hiH) && (aw != 3 || lowW) && (aw != 4 || hiW);
+            code = ad | (ah << 3) | (aw << 6);
+        }
+        const unsigned long long bal = __ballot(f);
+        const int prefix = __popcll(bal & ((1ull << lane) - 1ull));
+        if (lane == 0 && wv < 2) mcnt[wv] = __popcll(bal);
+        __syncthreads();
+        if (f) mlist[(wv == 1 ? mcnt[0] : 0) + prefix] = (unsigned short)code;
+        __syncthreads();
+        nmirror = mcnt[0] + mcnt[1];
+    }
 
     const int nseg = DG ? 1 : p.nseg;
     for (int sg = 0; sg < nseg; ++sg) {
@@ -170,6 +205,14 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(ConvK p) {
             const int cb8 = (cbase + c0) / 8;
             __syncthreads();
             stage_tile_b<KS, S, DG, CKB>(lds, src, C, c0, ck, stats, p.slope, p.pad_mode, b, o0d, o0h, o0w, Sd, Sh, Sw, tid);
+            if (WLDS) {
+                for (int v = tid; v < WV; v += 256) {
+                    const int row = v % (MT * 16), gg = (v / (MT * 16)) % 4, s = v / (MT * 16 * 4);
+                    const int q = 4 * s + gg, tap = q / G::NC8, blk = q % G::NC8;
+                    const bool ok = (q < G::Q) && (blk < nblk);
+                    wl[v] = ok ? wp[((long)tap * K8 + cb8 + blk) * p.Mpad + (mg * MT) * 16 + row] : zero8();
+                }
+            }
             __syncthreads();
 
             // ---- regular taps: 4 (tap, block) pairs per MFMA step, one per lane group
@@ -184,73 +227,83 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(ConvK p) {
                 wrow = ((long)(v ? tap : 0) * K8 + cb8 + (v ? blk : 0)) * p.Mpad + (mg * MT) * 16 + n;
                 return v;
             };
-            int toff; long wrow;
-            bool v = decode(0, toff, wrow);
-            bf16x8 a[MT];
+            if (WLDS) {
+                // A fragments come from LDS: the whole chunk's weights were fetched by all 256 threads at once
+                // (many loads in flight) instead of one dependent L2 round trip per MFMA step
+                for (int s = 0; s < G::NSTEP; ++s) {
+                    int toff; long wrow;
+                    decode(s, toff, wrow);
+                    bf16x8 a[MT];
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) a[mt] = v ? wp[wrow + mt * 16] : zero8();
-            for (int s = 0; s < G::NSTEP; ++s) {
-                int toff_n = 0; long wrow_n = 0; bool v_n = false;
-                bf16x8 a_n[MT];
-                if (s + 1 < G::NSTEP) {
-                    v_n = decode(s + 1, toff_n, wrow_n);
+                    for (int mt = 0; mt < MT; ++mt) a[mt] = wl[((s * 4 + g) * MT + mt) * 16 + n];
 #pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) a_n[mt] = v_n ? wp[wrow_n + mt * 16] : zero8();
+                    for (int nt = 0; nt < 4; ++nt) {
+                        const bf16x8 bv = *reinterpret_cast<const bf16x8*>(lds + pos[nt] + toff);
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt)
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mt], bv, acc[mt][nt], 0, 0, 0);
+                    }
                 }
+            } else {
+                int toff; long wrow;
+                bool v = decode(0, toff, wrow);
+                bf16x8 a[MT];
 #pragma unroll
-                for (int nt = 0; nt < 4; ++nt) {
-                    const bf16x8 bv = *reinterpret_cast<const bf16x8*>(lds + pos[nt] + toff);
+                for (int mt = 0; mt < MT; ++mt) a[mt] = v ? wp[wrow + mt * 16] : zero8();
+                for (int s = 0; s < G::NSTEP; ++s) {
+                    int toff_n = 0; long wrow_n = 0; bool v_n = false;
+                    bf16x8 a_n[MT];
+                    if (s + 1 < G::NSTEP) {
+                        v_n = decode(s + 1, toff_n, wrow_n);
 #pragma unroll
-                    for (int mt = 0; mt < MT; ++mt)
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mt], bv, acc[mt][nt], 0, 0, 0);
+                        for (int mt = 0; mt < MT; ++mt) a_n[mt] = v_n ? wp[wrow_n + mt * 16] : zero8();
+                    }
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt) {
+                        const bf16x8 bv = *reinterpret_cast<const bf16x8*>(lds + pos[nt] + toff);
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt)
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mt], bv, acc[mt][nt], 0, 0, 0);
+                    }
+                    toff = toff_n;
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) a[mt] = a_n[mt];
                 }
-                toff = toff_n;
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt) a[mt] = a_n[mt];
             }
 
-            // ---- mirror taps (adjoint of reflect padding); only bricks touching planes 1 / Sin-2
-            if (any_mirror) {
-                for (int ad = 0; ad < KS + 2; ++ad) {
-                    if (ad == KS && !lowD) continue;
-                    if (ad == KS + 1 && !hiD) continue;
-                    int tdp, posd; bool vd;
+            // ---- mirror taps (adjoint of reflect padding); only bricks touching planes 1 / Sin-2.  The brick's
+            // list of (tap, block) pairs is packed four per MFMA step exactly like the regular taps.
+            if (nmirror > 0) {
+                const int P = nmirror * nblk;
+                for (int s2 = 0; s2 * 4 < P; ++s2) {
+                    const int pr = s2 * 4 + g;
+                    const bool pv = pr < P;
+                    const int ent = pv ? pr / nblk : 0, blk = pv ? pr % nblk : 0;
+                    const int code = mlist[ent];
+                    const int ad = code & 7, ah = (code >> 3) & 7, aw = (code >> 6) & 7;
+                    int tdp, posd, twp, posw; bool vd, vw;
                     axis_tap<KS, G::HALO, DG, S>(ad, ld_, o0d, Od, p.hi_t[0], p.hi_u[0], tdp, posd, vd);
-                    for (int ah = 0; ah < KS + 2; ++ah) {
-                        if (ah == KS && !lowH) continue;
-                        if (ah == KS + 1 && !hiH) continue;
-                        for (int aw = 0; aw < KS + 2; ++aw) {
-                            if (aw == KS && !lowW) continue;
-                            if (aw == KS + 1 && !hiW) continue;
-                            if (ad < KS && ah < KS && aw < KS) continue;      // all-regular: done above
-                            int twp, posw; bool vw;
-                            axis_tap<KS, G::HALO, DG, S>(aw, lw, o0w, Ow, p.hi_t[2], p.hi_u[2], twp, posw, vw);
-                            int thp = 0, mpos[4]; bool mval[4];
+                    axis_tap<KS, G::HALO, DG, S>(aw, lw, o0w, Ow, p.hi_t[2], p.hi_u[2], twp, posw, vw);
+                    int thp = 0, mpos[4]; bool mval[4];
 #pragma unroll
-                            for (int nt = 0; nt < 4; ++nt) {
-                                int ph; bool vh;
-                                axis_tap<KS, G::HALO, DG, S>(ah, lh[nt], o0h, Oh, p.hi_t[1], p.hi_u[1], thp, ph, vh);
-                                mval[nt] = vd && vh && vw;
-                                mpos[nt] = mval[nt] ? ((posd * G::IH + ph) * G::IW + posw) * G::VS : 0;
-                            }
-                            const int tap = (tdp * KS + thp) * KS + twp;
-                            for (int s2 = 0; s2 * 4 < nblk; ++s2) {
-                                const int blk = s2 * 4 + g;
-                                const bool bvld = blk < nblk;
-                                bf16x8 am[MT];
+                    for (int nt = 0; nt < 4; ++nt) {
+                        int ph; bool vh;
+                        axis_tap<KS, G::HALO, DG, S>(ah, lh[nt], o0h, Oh, p.hi_t[1], p.hi_u[1], thp, ph, vh);
+                        mval[nt] = pv && vd && vh && vw;
+                        mpos[nt] = mval[nt] ? ((posd * G::IH + ph) * G::IW + posw) * G::VS + blk * 16 : 0;
+                    }
+                    const int tap = (tdp * KS + thp) * KS + twp;
+                    bf16x8 am[MT];
 #pragma unroll
-                                for (int mt = 0; mt < MT; ++mt)
-                                    am[mt] = bvld ? wp[((long)tap * K8 + cb8 + blk) * p.Mpad + (mg * MT + mt) * 16 + n] : zero8();
+                    for (int mt = 0; mt < MT; ++mt)
+                        am[mt] = pv ? wp[((long)tap * K8 + cb8 + blk) * p.Mpad + (mg * MT + mt) * 16 + n] : zero8();
 #pragma unroll
-                                for (int nt = 0; nt < 4; ++nt) {
-                                    bf16x8 bv = zero8();
-                                    if (bvld && mval[nt]) bv = *reinterpret_cast<const bf16x8*>(lds + mpos[nt] + blk * 16);
+                    for (int nt = 0; nt < 4; ++nt) {
+                        bf16x8 bv = zero8();
+                        if (mval[nt]) bv = *reinterpret_cast<const bf16x8*>(lds + mpos[nt]);
 #pragma unroll
-                                    for (int mt = 0; mt < MT; ++mt)
-                                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am[mt], bv, acc[mt][nt], 0, 0, 0);
-                                }
-                            }
-                        }
+                        for (int mt = 0; mt < MT; ++mt)
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am[mt], bv, acc[mt][nt], 0, 0, 0);
                     }
                 }
             }
@@ -390,7 +443,36 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(ConvK p, float* __
             }
         }
     }
+    if (KSPLIT == 4) {
+        // the four waves hold partial sums over disjoint voxels of the SAME outputs: combine through LDS (fixed order)
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(ldy);          // [4 waves][MT][NTW + 1][64 lanes][4]
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+            for (int j = 0; j < NTW; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) red[(((wv * MT + mt) * (NTW + 1) + j) * 64 + lane) * 4 + r] = acc[mt][j][r];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[(((wv * MT + mt) * (NTW + 1) + NTW) * 64 + lane) * 4 + r] = accb[mt][r];
+        }
+        __syncthreads();
+        if (wv != 0) return;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+            for (int j = 0; j <= NTW; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float t = 0.f;
+#pragma unroll
+                    for (int w2 = 0; w2 < 4; ++w2) t += red[(((w2 * MT + mt) * (NTW + 1) + j) * 64 + lane) * 4 + r];
+                    if (j < NTW) acc[mt][j][r] = t; else accb[mt][r] = t;
+                }
+        }
+    }
     if (dW) {
+        dW += (long)blockIdx.x * p.Cout * p.Cin * NTAP;      // this workgroup's slot of the partial-sum slab
 #pragma unroll
         for (int j = 0; j < NTW; ++j) {
             const int nt = (KSPLIT == 1) ? wv + 4 * j : j;
@@ -403,33 +485,24 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(ConvK p, float* __
                 for (int r = 0; r < 4; ++r) {
                     const int co = (mg * MT + mt) * 16 + g * 4 + r;
                     const float v = acc[mt][j][r];
-                    if (co < p.Cout && v != 0.f) atomicAdd(&dW[((long)co * p.Cin + ci) * NTAP + tap], v);
+                    if (co < p.Cout) dW[((long)co * p.Cin + ci) * NTAP + tap] = v;
                 }
         }
     }
-    if (do_bias && n == 0) {
+    if (bias_block && wv == 0 && n == 0) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int co = (mg * MT + mt) * 16 + g * 4 + r;
-                if (co < p.Cout) atomicAdd(&dbias[co], accb[mt][r]);
+                if (co < p.Cout) dbias[(long)blockIdx.x * p.Cout + co] = accb[mt][r];
             }
     }
 }
 
 template <int KS, int S>
-int launch_wgrad_b(ConvK& k, float* dW, float* db, hipStream_t st) {
-    int chunks = 0;
-    for (int s = 0; s < k.nseg; ++s) chunks += (k.seg[s].C + 7) / 8;
-    const int mtiles = k.Mpad / 16;
-    const int MT = (mtiles % 2 == 0) ? 2 : 1;
+int launch_wgrad_b(ConvK& k, int MT, int gx, int gy, float* dW, float* db, hipStream_t st) {
     const int tiles_per_b = k.tilesD * k.tilesH * k.tilesW;
-    const int total = k.B * tiles_per_b;
-    const int gy = chunks * (mtiles / MT);
-    int gx = total;
-    const int cap = (int)hmax(1, 512 / gy);   // every block ends with an atomic flush into the same dW words: keep them few
-    if (gx > cap) gx = cap;
     dim3 grid(gx, gy);
     if (MT == 2) hipLaunchKernelGGL((conv_wgrad_bf16_kernel<KS, S, 2>), grid, dim3(256), 0, st, k, dW, db, tiles_per_b);
     else hipLaunchKernelGGL((conv_wgrad_bf16_kernel<KS, S, 1>), grid, dim3(256), 0, st, k, dW, db, tiles_per_b);
@@ -463,6 +536,20 @@ __global__ void pack_weight_bf16_kernel(const float* __restrict__ w, int Cin, in
     }
 }
 
+template <int KS, int S, int MT, int MODE, int CKB>
+int launch_one(ConvK& k, dim3 grid, hipStream_t st) {
+    constexpr int bytes = conv_lds_bytes<KS, S, MODE == 1, CKB, MT>();
+    static bool attr_set = false;     // > 64 KB of dynamic LDS has to be granted once per kernel
+    if (!attr_set) {
+        HIP_RET(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16_kernel<KS, S, MT, MODE, CKB>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((conv_bf16_kernel<KS, S, MT, MODE, CKB>), grid, dim3(256), bytes, st, k);
+    LAUNCH_RET();
+    return 0;
+}
+
 template <int KS, int S, int MODE, int CKB>
 int launch_mt(ConvK& k, int mtiles, hipStream_t st) {
     const int tiles = k.B * k.tilesD * k.tilesH * k.tilesW;
@@ -470,11 +557,9 @@ int launch_mt(ConvK& k, int mtiles, hipStream_t st) {
     if (mtiles % MT) MT = (mtiles % 2 == 0) ? 2 : 1;
     while (MT > 1 && (long)tiles * (mtiles / MT) < 512) MT >>= 1;
     dim3 grid(tiles, mtiles / MT);
-    if (MT == 4) hipLaunchKernelGGL((conv_bf16_kernel<KS, S, 4, MODE, CKB>), grid, dim3(256), 0, st, k);
-    else if (MT == 2) hipLaunchKernelGGL((conv_bf16_kernel<KS, S, 2, MODE, CKB>), grid, dim3(256), 0, st, k);
-    else hipLaunchKernelGGL((conv_bf16_kernel<KS, S, 1, MODE, CKB>), grid, dim3(256), 0, st, k);
-    LAUNCH_RET();
-    return 0;
+    if (MT == 4) return launch_one<KS, S, 4, MODE, CKB>(k, grid, st);
+    if (MT == 2) return launch_one<KS, S, 2, MODE, CKB>(k, grid, st);
+    return launch_one<KS, S, 1, MODE, CKB>(k, grid, st);
 }
 
 template <int MODE>
@@ -531,11 +616,11 @@ int launch_conv_bf16(ConvK& k, int ksize, int stride, bool dgrad, const void* pa
     return dgrad ? launch_geo<1>(k, ksize, stride, cmax, mtiles, st) : launch_geo<0>(k, ksize, stride, cmax, mtiles, st);
 }
 
-int launch_wgrad_bf16(ConvK& k, int ksize, int stride, float* dW, float* db, hipStream_t st) {
+int launch_wgrad_bf16(ConvK& k, int ksize, int stride, int MT, int gx, int gy, float* dW, float* db, hipStream_t st) {
     k.Mpad = pad16(k.Cout);
-    if (ksize == 1) return launch_wgrad_b<1, 1>(k, dW, db, st);
-    if (stride == 1) return launch_wgrad_b<3, 1>(k, dW, db, st);
-    return launch_wgrad_b<3, 2>(k, dW, db, st);
+    if (ksize == 1) return launch_wgrad_b<1, 1>(k, MT, gx, gy, dW, db, st);
+    if (stride == 1) return launch_wgrad_b<3, 1>(k, MT, gx, gy, dW, db, st);
+    return launch_wgrad_b<3, 2>(k, MT, gx, gy, dW, db, st);
 }
 
 }  // namespace pconv

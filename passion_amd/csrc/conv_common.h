@@ -9,7 +9,7 @@
 
 namespace pconv {
 
-constexpr int SUMS_REP = 32;            // replicas of the InstanceNorm-backward sums (atomic contention)
+constexpr int SUMS_REP = 256;           // replicas of the InstanceNorm-backward sums (atomic contention)
 constexpr int TD = 4, TH = 8, TW = 8;   // output brick of one 256-thread workgroup (wave w = depth slice w)
 
 struct SegD {
@@ -46,7 +46,7 @@ int pack_weight_bf16(const float* w, int Cin, int Cout, int ntap, void* out, hip
 struct ConvK;
 bool bf16_eligible(const ConvK& k, bool dgrad);
 int launch_conv_bf16(ConvK& k, int ksize, int stride, bool dgrad, const void* packed_bf16, hipStream_t st);
-int launch_wgrad_bf16(ConvK& k, int ksize, int stride, float* dW, float* db, hipStream_t st);
+int launch_wgrad_bf16(ConvK& k, int ksize, int stride, int MT, int gx, int gy, float* dWslab, float* dbslab, hipStream_t st);
 
 // One axis of a tap entry.  a < KS: regular tap; a == KS: low-side mirror term; a == KS+1: high-side.
 // Forward conv of stride S reads padded coordinate o*S + t - 1; 'reflect' maps -1 -> 1 and Sin -> Sin-2, so

@@ -444,7 +444,9 @@ __global__ void proto_bwd2_kernel(const float* __restrict__ tg, long V, const fl
 }
 
 inline int vgrid(long V) { return (int)hmin((V + 255) / 256, 2048); }
-inline int vgrid_red(long V) { return (int)hmin((V + 256 * 4 - 1) / (256 * 4), 1024); }
+// reductions end with one atomic per block per scalar on a handful of addresses: same-address atomics serialise
+// (~50-100 ns each), so keep the block count low and give each block more voxels
+inline int vgrid_red(long V) { return (int)hmin((V + 256 * 4 - 1) / (256 * 4), 128); }
 
 }  // namespace
 

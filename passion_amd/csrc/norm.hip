@@ -61,34 +61,53 @@ __global__ __launch_bounds__(256) void stats_partial_kernel(const T* __restrict_
             for (int j = 0; j < 4; ++j) { ds[j] += (double)red[t * 8 + j]; dq[j] += (double)red[t * 8 + 4 + j]; }
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            atomicAdd(&scratch[((long)b * C + tid * 4 + j) * 2 + 0], ds[j]);
-            atomicAdd(&scratch[((long)b * C + tid * 4 + j) * 2 + 1], dq[j]);
+        for (int j = 0; j < 4; ++j) {   // this block's slot of the partial slab: no atomics, reproducible
+            scratch[(((long)blockIdx.x * gridDim.y + b) * C + tid * 4 + j) * 2 + 0] = ds[j];
+            scratch[(((long)blockIdx.x * gridDim.y + b) * C + tid * 4 + j) * 2 + 1] = dq[j];
         }
     }
 }
 
-__global__ void stats_finalize_kernel(const double* __restrict__ scratch, long V, int n, float eps,
-                                      float* __restrict__ stats) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const double mean = scratch[i * 2] / (double)V;
-    double var = scratch[i * 2 + 1] / (double)V - mean * mean;
-    if (var < 0) var = 0;
-    stats[i * 2 + 0] = (float)mean;
-    stats[i * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+// 256 threads = 16 (b, c) outputs x 16 slices of the R partial slots; fixed summation order
+__global__ __launch_bounds__(256) void stats_finalize_kernel(const double* __restrict__ part, int R, long V, int n, float eps,
+                                                             float* __restrict__ stats) {
+    __shared__ double rs[16][17], rq[16][17];
+    const int li = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    const int i = blockIdx.x * 16 + li;
+    double s = 0, q = 0;
+    if (i < n)
+        for (int r = sl; r < R; r += 16) { s += part[((long)r * n + i) * 2]; q += part[((long)r * n + i) * 2 + 1]; }
+    rs[sl][li] = s; rq[sl][li] = q;
+    __syncthreads();
+    if (sl == 0 && i < n) {
+        s = 0; q = 0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { s += rs[k][li]; q += rq[k][li]; }
+        const double mean = s / (double)V;
+        double var = q / (double)V - mean * mean;
+        if (var < 0) var = 0;
+        stats[i * 2 + 0] = (float)mean;
+        stats[i * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+}
+
+inline int stats_blocks(long V, int C) {
+    const long nvec = V * (C / 4);
+    long gx = (nvec + 256 * 16 - 1) / (256 * 16);
+    return (int)(gx < 1 ? 1 : (gx > 256 ? 256 : gx));
 }
 
 }  // namespace
+
+extern "C" int64_t passion_instnorm_scratch_doubles(int B, int64_t V, int C) {
+    return (int64_t)stats_blocks((long)V, C) * B * C * 2;
+}
 
 extern "C" int passion_instnorm_stats(const void* x, int dtype, int B, int64_t V, int C, int64_t bstride, float eps,
                                       double* scratch, float* stats, void* stream) {
     if (C % 4 || (256 % (C / 4)) != 0) return -1010;
     hipStream_t st = (hipStream_t)stream;
-    HIP_RET(hipMemsetAsync(scratch, 0, sizeof(double) * 2 * (size_t)B * C, st));
-    const long nvec = V * (C / 4);
-    int gx = (int)hmin((nvec + 256 * 16 - 1) / (256 * 16), 512);
-    if (gx < 1) gx = 1;
+    const int gx = stats_blocks((long)V, C);
     dim3 grid(gx, B);
     if (dtype == PASSION_F32)
         hipLaunchKernelGGL(stats_partial_kernel<float>, grid, dim3(256), 0, st, (const float*)x, (long)V, C, (long)bstride, scratch);
@@ -98,7 +117,7 @@ extern "C" int passion_instnorm_stats(const void* x, int dtype, int B, int64_t V
         return -1007;
     LAUNCH_RET();
     const int n = B * C;
-    hipLaunchKernelGGL(stats_finalize_kernel, dim3((n + 255) / 256), dim3(256), 0, st, scratch, (long)V, n, eps, stats);
+    hipLaunchKernelGGL(stats_finalize_kernel, dim3((n + 15) / 16), dim3(256), 0, st, scratch, gx, (long)V, n, eps, stats);
     LAUNCH_RET();
     return 0;
 }

@@ -30,9 +30,10 @@ def instnorm_stats(x, eps=1e-5):
     assert x.dim() == 5 and x.is_contiguous()
     B, D, H, W, C = x.shape
     V = D * H * W
-    scratch = torch.empty(B * C * 2, dtype=torch.float64, device=x.device)
+    lib = L.load()
+    scratch = torch.empty(lib.passion_instnorm_scratch_doubles(B, V, C), dtype=torch.float64, device=x.device)
     stats = torch.empty(B, C, 2, dtype=torch.float32, device=x.device)
-    rc = L.load().passion_instnorm_stats(_p(x), L.dtype_code(x.dtype), B, V, C, V * C, eps,
+    rc = lib.passion_instnorm_stats(_p(x), L.dtype_code(x.dtype), B, V, C, V * C, eps,
                                          _p(scratch), _p(stats), L.stream_ptr())
     L.check(rc, "passion_instnorm_stats")
     return stats
@@ -137,8 +138,8 @@ class ConvBlockFn(torch.autograd.Function):
         need_w = ctx.needs_input_grad[1]
         need_b = ctx.has_bias and ctx.needs_input_grad[2]
         dev = dy.device
-        dW = torch.zeros(ctx.wshape, dtype=torch.float32, device=dev) if need_w else None
-        db = torch.zeros(ctx.wshape[0], dtype=torch.float32, device=dev) if need_b else None
+        dW = torch.empty(ctx.wshape, dtype=torch.float32, device=dev) if need_w else None
+        db = torch.empty(ctx.wshape[0], dtype=torch.float32, device=dev) if need_b else None
         dxs = []
         for i, (s, x) in enumerate(zip(cfg.segs, xs)):
             if ctx.needs_input_grad[5 + i]:
@@ -148,8 +149,7 @@ class ConvBlockFn(torch.autograd.Function):
                 dxs.append(None)
         d = _fill_desc(cfg, xs, dxs)
         d.Cout = ctx.wshape[0]
-        cin = sum(s.C for s in cfg.segs)
-        sums = torch.empty(lib.passion_conv_bwd_scratch_floats(cfg.B, cin), dtype=torch.float32, device=dev)
+        sums = torch.empty(lib.passion_conv_bwd_scratch_floats(byref(d)), dtype=torch.float32, device=dev)
         L.check(lib.passion_conv3d_bwd(byref(d), _p(ctx.packed), _p(dy), _p(dW), _p(db), _p(sums),
                                        L.stream_ptr()), "passion_conv3d_bwd")
         dres = dy if (ctx.has_res and ctx.needs_input_grad[3]) else None

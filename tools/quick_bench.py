@@ -21,11 +21,13 @@ for i in range(5):
     m.is_training = True
     outs = m(x, mask, target=target, temp=4.0)
     loss = ptrain.assemble_loss(outs, target, mask, "idt", passion)
+    t1h = time.time()
     torch.cuda.synchronize(); t1 = time.time()
     opt.zero_grad(set_to_none=False); loss.backward()
+    t2h = time.time()
     torch.cuda.synchronize(); t2 = time.time()
     opt.step(); torch.cuda.synchronize(); t3 = time.time()
-    print(f"S={S} {dtype} passion={passion} it{i}: fwd {1e3*(t1-t0):.1f} ms bwd {1e3*(t2-t1):.1f} ms opt {1e3*(t3-t2):.1f} ms loss {float(loss):.4f} mem {torch.cuda.max_memory_allocated()/2**30:.1f} GiB", flush=True)
+    print(f"S={S} {dtype} passion={passion} it{i}: fwd {1e3*(t1-t0):.1f} ms bwd {1e3*(t2-t1):.1f} ms opt {1e3*(t3-t2):.1f} ms [host enqueue fwd {1e3*(t1h-t0):.1f} bwd {1e3*(t2h-t1):.1f}] loss {float(loss):.4f} mem {torch.cuda.max_memory_allocated()/2**30:.1f} GiB", flush=True)
 ops.prof_enable(True)
 m.is_training = True
 outs = m(x, mask, target=target, temp=4.0)
