@@ -34,8 +34,9 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="mmformer128", choices=["mmformer128", "mmformer128_passion"],
-                    help="BASELINE.json configs[1] (default) / configs[2] (+ PASSION self-distillation)")
+    ap.add_argument("--workload", default="mmformer128", choices=["mmformer128", "mmformer128_passion", "rfnet128_passion"],
+                    help="BASELINE.json configs[1] (default) / configs[2] (+ PASSION self-distillation) / "
+                         "configs[3] (RFNet + PASSION, batch 2 per GPU)")
     ap.add_argument("--size", type=int, default=128)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -89,15 +90,21 @@ def main():
     passion = args.workload.endswith("passion")
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
 
-    mmformer.patch_size = S // 16
+    is_rfnet = args.workload.startswith("rfnet")
+    batch = 2 if is_rfnet else 1
     torch.manual_seed(1037)
-    model = mmformer.Model(num_cls=4).to(ctx.device)
+    if is_rfnet:
+        from passion_amd.models import rfnet
+        model = rfnet.Model(num_cls=4).to(ctx.device)
+    else:
+        mmformer.patch_size = S // 16
+        model = mmformer.Model(num_cls=4).to(ctx.device)
     model.mask_type, model.use_passion, model.compute_dtype = "idt", passion, dtype
     model.train()                                   # dropout live, as in the reference's training loop
     reducer = parallel.GradReducer(model, ctx)
     opt = ptrain.make_optimizer(model)
     state = ptrain.LossState(ctx.device)
-    x, target, mask = ptrain.synthetic_batch(1, S, ctx.device, seed=7 + ctx.rank)   # resident in HBM before timing
+    x, target, mask = ptrain.synthetic_batch(batch, S, ctx.device, seed=7 + ctx.rank)   # resident in HBM before timing
 
     def step():
         return ptrain.train_step(model, opt, x, mask, target, 4.0, state, reducer)
@@ -121,14 +128,15 @@ def main():
     if ctx.rank != 0:
         return
     out = {
-        "metric": "train volumes/sec (4-modality 128^3, bs=1/GPU)", "value": round(ctx.world * args.steps / dt, 4),
+        "metric": "train volumes/sec (4-modality 128^3, bs=%d/GPU)" % batch, "value": round(batch * ctx.world * args.steps / dt, 4),
         "unit": "volumes/s", "n_gpus": ctx.world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "bf16" if dtype == torch.bfloat16 else "f32", "data": "synthetic",
-        "config": {"workload": f"mmformer{'+PASSION' if passion else ''} train step, 4x{S}^3 volume, batch 1/GPU, "
-                               f"mask_type idt, all modalities present, AdamW(amsgrad), dropout 0.1 "
-                               f"(BASELINE.json configs[{2 if passion else 1}])",
-                   "global_batch": ctx.world, "parallelism": f"dp{ctx.world} (RCCL grad all-reduce, sum)",
+        "config": {"workload": f"{'rfnet' if is_rfnet else 'mmformer'}{'+PASSION' if passion else ''} train step, 4x{S}^3 volume, "
+                               f"batch {batch}/GPU, mask_type idt, all modalities present, AdamW(amsgrad)"
+                               f"{'' if is_rfnet else ', dropout 0.1'} "
+                               f"(BASELINE.json configs[{3 if is_rfnet else (2 if passion else 1)}])",
+                   "global_batch": batch * ctx.world, "parallelism": f"dp{ctx.world} (RCCL grad all-reduce, sum)",
                    "final_loss": round(float(loss), 5)},
     }
     if not args.no_roofline:
@@ -148,7 +156,7 @@ def main():
                                "launches": len(recs), "avg_launch_ms": round(ms / len(recs), 5),
                                "algorithmic_bytes_per_launch": round(by / len(recs), 1),
                                "tflops": round(fl / (ms * 1e-3) / 1e12, 3)}
-    if not args.no_cpu_baseline and ctx.world == 1:
+    if not args.no_cpu_baseline and ctx.world == 1 and not is_rfnet:
         out["cpu_baseline"] = cpu_baseline(passion)
     print(json.dumps(out), flush=True)
 

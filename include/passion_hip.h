@@ -162,6 +162,35 @@ int passion_attn_pv_bwd(const float* probs, const void* qkv, const void* dout, i
 int passion_attn_scores_bwd(const float* probs, float* dprobs, const void* qkv, int dtype, int B,
                             int N, int H, int Dh, float scale, void* dqkv, void* stream);
 
+/* ---- RFNet (post-norm backbone) streaming ops -------------------------------------------------------
+ * norm_act: out[b][v][out_coff + c] = sum_k LeakyReLU((x_k - mean_k) * rstd_k), k = 1 or 2 inputs (x1 may be
+ * NULL).  Materialises general_conv3d's Conv->IN->LReLU output (code/models/blocks.py:366-370) where a
+ * non-conv consumer needs it: the encoder residual (code/models/rfnet.py:37,40,43,46), upsample inputs,
+ * prototype features.  out has `out_ld` channels per voxel (writes the slice [out_coff, out_coff + C)). */
+int passion_norm_act_fwd(const void* x0, const float* st0, const void* x1, const float* st1, void* out,
+                         int dtype, int B, int64_t V, int C, int out_ld, int out_coff, float slope,
+                         void* stream);
+int64_t passion_norm_act_scratch_floats(int B, int64_t V, int C);
+/* gradient wrt ONE input x (with its stats) given dout (same layout as out); call once per input */
+int passion_norm_act_bwd(const void* x, const float* stats, const void* dout, void* dx, int dtype, int B,
+                         int64_t V, int C, int out_ld, int out_coff, float slope, float* scratch,
+                         void* stream);
+/* region-aware modal fusion (code/models/blocks.py:495-517, 582-626).  y: 4 device pointers to the
+ * modality feature maps [B][V][C]; mask: [B][mask_ld] present flags (NULL: all); prob: [B][V][4] f32
+ * region probabilities (detached in the reference, rfnet.py:128).
+ * region_gap: sums[b][(i*4+m)*C + c] = sum_v y_m[c] prob_i, sums[b][16*C + i] = sum_v prob_i. */
+int64_t passion_region_scratch_floats(int B, int64_t V, int C);
+int passion_region_gap_fwd(const void* const* y, const uint8_t* mask, int mask_ld, const float* prob,
+                           int dtype, int B, int64_t V, int C, float* scratch, float* sums, void* stream);
+int passion_region_gap_bwd(void* const* dy, const uint8_t* mask, int mask_ld, const float* prob,
+                           const float* gS, int dtype, int B, int64_t V, int C, void* stream);
+/* region_mix: out[b][v][i*C + c] = prob_i(v) * sum_m w[b][i][m] * y_m[c](v);  w: [B][4][4] f32 */
+int passion_region_mix_fwd(const void* const* y, const uint8_t* mask, int mask_ld, const float* prob,
+                           const float* w, void* out, int dtype, int B, int64_t V, int C, void* stream);
+int passion_region_mix_bwd(const void* const* y, void* const* dy, const uint8_t* mask, int mask_ld,
+                           const float* prob, const float* w, const void* dR, int dtype, int B, int64_t V,
+                           int C, float* scratch, float* dw, void* stream);
+
 /* ---- in-library kernel timing (bench.py roofline leg) ------------------------------------------
  * passion_prof_enable(mask): bit k of `mask` selects launches of kind k; selected conv3d launches are
  * bracketed by hipEvents on their own stream and their algorithmic bytes / flops recorded.  passion_prof_read drains up to `cap` records:

@@ -275,7 +275,8 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(ConvK p) {
             // list of (tap, block) pairs is packed four per MFMA step exactly like the regular taps.
             if (nmirror > 0) {
                 const int P = nmirror * nblk;
-                for (int s2 = 0; s2 * 4 < P; ++s2) {
+                // decode pair 4*s2 + g -> (mirror combo, 8-channel block): weight fragment, per-voxel LDS offsets, validity
+                auto prep = [&](int s2, bf16x8 (&am)[MT], int (&mpos)[4], bool (&mval)[4]) {
                     const int pr = s2 * 4 + g;
                     const bool pv = pr < P;
                     const int ent = pv ? pr / nblk : 0, blk = pv ? pr % nblk : 0;
@@ -284,7 +285,7 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(ConvK p) {
                     int tdp, posd, twp, posw; bool vd, vw;
                     axis_tap<KS, G::HALO, DG, S>(ad, ld_, o0d, Od, p.hi_t[0], p.hi_u[0], tdp, posd, vd);
                     axis_tap<KS, G::HALO, DG, S>(aw, lw, o0w, Ow, p.hi_t[2], p.hi_u[2], twp, posw, vw);
-                    int thp = 0, mpos[4]; bool mval[4];
+                    int thp = 0;
 #pragma unroll
                     for (int nt = 0; nt < 4; ++nt) {
                         int ph; bool vh;
@@ -293,10 +294,16 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(ConvK p) {
                         mpos[nt] = mval[nt] ? ((posd * G::IH + ph) * G::IW + posw) * G::VS + blk * 16 : 0;
                     }
                     const int tap = (tdp * KS + thp) * KS + twp;
-                    bf16x8 am[MT];
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt)
                         am[mt] = pv ? wp[((long)tap * K8 + cb8 + blk) * p.Mpad + (mg * MT + mt) * 16 + n] : zero8();
+                };
+                bf16x8 am[MT]; int mpos[4]; bool mval[4];
+                prep(0, am, mpos, mval);
+                for (int s2 = 0; s2 * 4 < P; ++s2) {
+                    bf16x8 am_n[MT]; int mpos_n[4]; bool mval_n[4];
+                    const bool more = (s2 + 1) * 4 < P;
+                    if (more) prep(s2 + 1, am_n, mpos_n, mval_n);       // weight loads of the next step fly during these MFMAs
 #pragma unroll
                     for (int nt = 0; nt < 4; ++nt) {
                         bf16x8 bv = zero8();
@@ -304,6 +311,12 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(ConvK p) {
 #pragma unroll
                         for (int mt = 0; mt < MT; ++mt)
                             acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am[mt], bv, acc[mt][nt], 0, 0, 0);
+                    }
+                    if (more) {
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt) am[mt] = am_n[mt];
+#pragma unroll
+                        for (int nt = 0; nt < 4; ++nt) { mpos[nt] = mpos_n[nt]; mval[nt] = mval_n[nt]; }
                     }
                 }
             }
@@ -385,42 +398,121 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(ConvK p, float* __
 #pragma unroll
     for (int j = 0; j < 8; ++j) ones[j] = (__bf16)1.0f;
 
-    const int total_tiles = p.B * tiles_per_b;
-    for (int tile = blockIdx.x; tile < total_tiles; tile += gridDim.x) {
+    // Software pipeline over this workgroup's bricks: the global loads of brick t+1 (raw activations + dY) are issued
+    // into registers before the MFMA loop of brick t and only normalised / written to LDS after it, so the HBM
+    // round trip hides under the matrix work instead of serialising with it.
+    constexpr int AR = (G::VOL + 255) / 256;   // activation voxels per thread (one 16-byte block each)
+    constexpr int DR = MC / 8;                 // dY 16-byte blocks per thread
+    struct Regs { bf16x8 a[AR]; bf16x8 d[DR]; unsigned ok; int b; bool present; };
+    const int nch = min(8, ck);
+    const bool has_norm = (sd.stats != nullptr);
+    auto fetch = [&](int tile, Regs& R) {
         int t2 = tile;
         const int tw_ = t2 % p.tilesW; t2 /= p.tilesW;
         const int th_ = t2 % p.tilesH; t2 /= p.tilesH;
         const int td_ = t2 % p.tilesD; t2 /= p.tilesD;
         const int b = t2;
         const int o0d = td_ * TD, o0h = th_ * TH, o0w = tw_ * TW;
-        const bool present = sd.mask ? (sd.mask[(long)b * sd.mask_ld + sd.mask_col] != 0) : true;
-        if (!present && !bias_block) continue;
-        __syncthreads();
+        R.b = b;
+        R.present = sd.mask ? (sd.mask[(long)b * sd.mask_ld + sd.mask_col] != 0) : true;
+        R.ok = 0u;
         const bf16_t* src = reinterpret_cast<const bf16_t*>(sd.x) + (long)b * sd.bstride;
-        stage_tile_b<KS, S, false, CKW>(lact, src, sd.C, c0, present ? ck : 0, sd.stats, p.slope, p.pad_mode, b, o0d, o0h,
-                                        o0w, p.Di, p.Hi, p.Wi, tid);
+#pragma unroll
+        for (int r = 0; r < AR; ++r) {
+            const int tv = tid + 256 * r;
+            R.a[r] = zero8();
+            if (tv >= G::VOL || !R.present) continue;
+            const int zw = tv % G::IW, zh = (tv / G::IW) % G::IH, zd = tv / (G::IW * G::IH);
+            int s_d = o0d * S - G::HALO + zd, s_h = o0h * S - G::HALO + zh, s_w = o0w * S - G::HALO + zw;
+            bool ok = true;
+            if (p.pad_mode == PASSION_PAD_REFLECT) {
+                s_d = reflect_idx(s_d, p.Di); s_h = reflect_idx(s_h, p.Hi); s_w = reflect_idx(s_w, p.Wi);
+                s_d = min(max(s_d, 0), p.Di - 1); s_h = min(max(s_h, 0), p.Hi - 1); s_w = min(max(s_w, 0), p.Wi - 1);
+            } else {
+                ok = (s_d >= 0 && s_d < p.Di && s_h >= 0 && s_h < p.Hi && s_w >= 0 && s_w < p.Wi);
+            }
+            if (!ok) continue;
+            const bf16_t* ptr = src + (((long)s_d * p.Hi + s_h) * p.Wi + s_w) * sd.C + c0;
+            if (nch == 8) {
+                R.a[r] = *reinterpret_cast<const bf16x8*>(ptr);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) if (e < nch) R.a[r][e] = ptr[e];
+            }
+            R.ok |= (1u << r);
+        }
         const bf16_t* dy = reinterpret_cast<const bf16_t*>(p.dy) + (long)b * p.Do * p.Ho * p.Wo * p.Cout;
-        for (int i = tid; i < TD * TH * TW * (MC / 8); i += 256) {
-            const int c8 = i % (MC / 8), v = i / (MC / 8);
+#pragma unroll
+        for (int r = 0; r < DR; ++r) {
+            const int i = tid + 256 * r;
+            const int c8 = i % DR, v = i / DR;
             const int w = v % TW, h = (v / TW) % TH, d = v / (TW * TH);
             const int od = o0d + d, oh = o0h + h, ow = o0w + w;
             const int co = mg * MC + c8 * 8;
-            bf16x8 o = zero8();
+            R.d[r] = zero8();
             if (od < p.Do && oh < p.Ho && ow < p.Wo && co < p.Cout) {
                 const bf16_t* ptr = dy + ((((long)od) * p.Ho + oh) * p.Wo + ow) * p.Cout + co;
                 if (co + 8 <= p.Cout) {
-                    o = *reinterpret_cast<const bf16x8*>(ptr);
+                    R.d[r] = *reinterpret_cast<const bf16x8*>(ptr);
                 } else {
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) if (co + e < p.Cout) o[e] = ptr[e];
+                    for (int e = 0; e < 8; ++e) if (co + e < p.Cout) R.d[r][e] = ptr[e];
                 }
             }
-            *reinterpret_cast<bf16x8*>(ldy + v * DYS + c8 * 16) = o;
         }
+    };
+    auto commit = [&](const Regs& R) {
+        float mean[8], rstd[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            mean[c] = 0.f; rstd[c] = 1.f;
+            if (has_norm && c < nch) {
+                mean[c] = sd.stats[((long)R.b * sd.C + c0 + c) * 2 + 0];
+                rstd[c] = sd.stats[((long)R.b * sd.C + c0 + c) * 2 + 1];
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < AR; ++r) {
+            const int tv = tid + 256 * r;
+            if (tv >= G::VOL) continue;
+            bf16x8 o = zero8();
+            if ((R.ok >> r) & 1u) {
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    float t = (float)R.a[r][c];
+                    if (has_norm) {
+                        t = (t - mean[c]) * rstd[c];
+                        t = t > 0.f ? t : t * p.slope;
+                    }
+                    o[c] = (__bf16)((c < nch) ? t : 0.f);
+                }
+            }
+            *reinterpret_cast<bf16x8*>(lact + tv * G::VS) = o;
+        }
+#pragma unroll
+        for (int r = 0; r < DR; ++r) {
+            const int i = tid + 256 * r;
+            *reinterpret_cast<bf16x8*>(ldy + (i / DR) * DYS + (i % DR) * 16) = R.d[r];
+        }
+    };
+
+    const int total_tiles = p.B * tiles_per_b;
+    int tile = blockIdx.x;
+    bool have = tile < total_tiles;
+    Regs R;
+    if (have) fetch(tile, R);
+    while (have) {
         __syncthreads();
+        commit(R);
+        __syncthreads();
+        const bool work = R.present || bias_block;
+        const int next = tile + gridDim.x;
+        const bool have_n = next < total_tiles;
+        Regs Rn;
+        if (have_n) fetch(next, Rn);
         // K loop: 32 voxels per MFMA = one (d, 4 h-rows) slab; lane group g owns h-row g, its two tr-reads
         // cover w = 0..3 and 4..7
-        for (int ks = (KSPLIT == 4 ? wv : 0); ks < TD * TH * TW / 32; ks += KSPLIT) {
+        for (int ks = (KSPLIT == 4 ? wv : 0); work && ks < TD * TH * TW / 32; ks += KSPLIT) {
             const int d = ks >> 1, h = (ks & 1) * 4 + g, w = q;
             const int v = (d * TH + h) * TW + w;
             const char* ap = ldy + v * DYS + pq * 8;
@@ -442,6 +534,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(ConvK p, float* __
                     accb[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mt], ones, accb[mt], 0, 0, 0);
             }
         }
+        tile = next; have = have_n;
+        if (have_n) R = Rn;
     }
     if (KSPLIT == 4) {
         // the four waves hold partial sums over disjoint voxels of the SAME outputs: combine through LDS (fixed order)

@@ -97,3 +97,171 @@ class fusion_prenorm(nn.Module):
         h = self.fusion_layer[0](feats)
         h = self.fusion_layer[1](h)
         return self.fusion_layer[2](h)
+
+
+# ------------------------------------------------------------------------------------------------
+# RFNet (post-norm) blocks
+# ------------------------------------------------------------------------------------------------
+class PFeat(Feat):
+    """raw output of a post-norm general_conv3d: its VALUE is LeakyReLU(InstanceNorm(t)).  A consuming
+    conv applies that in its loader (same fused path as the pre-norm blocks); anything else calls
+    materialize()."""
+    __slots__ = ()
+
+
+def _seg_auto(f):
+    return f.seg(norm=isinstance(f, PFeat))
+
+
+def materialize(f):
+    """Feat whose tensor holds the activated values"""
+    if isinstance(f, PFeat):
+        return Feat(ops.norm_act(f.t, f.stats()), f.mask, f.mask_col)
+    return f
+
+
+def _pad_axis(t, dim, mult=4):
+    n = t.shape[dim]
+    if n % mult == 0:
+        return t
+    pad = [0, 0] * t.dim()
+    pad[2 * (t.dim() - 1 - dim) + 1] = mult - n % mult
+    return torch.nn.functional.pad(t, pad)
+
+
+def run_conv_auto(conv, feats, out_dtype=None, post=False):
+    """like run_conv, but every input decides by its own type whether the loader normalises it; channel
+    counts that are not multiples of 4 (RFNet's C//4 = 2 embedding at level 1) are zero-padded to 4:
+    the padded output channels are exactly 0 before and after InstanceNorm+LeakyReLU and meet zero
+    weights downstream, the weight gradient of the padding is sliced away by autograd."""
+    if not isinstance(feats, (list, tuple)):
+        feats = [feats]
+    D, H, W = feats[0].dims
+    cin_have = sum(f.t.shape[-1] for f in feats)
+    w, b = conv.weight, conv.bias
+    if w.shape[1] != cin_have:          # producer was padded: pad the matching input-channel axis
+        assert len(feats) == 1 and cin_have == (w.shape[1] + 3) // 4 * 4
+        w = _pad_axis(w, 1)
+    w = _pad_axis(w, 0)
+    b = _pad_axis(b, 0) if b is not None else None
+    padded = w is not conv.weight
+    cache = None if padded else conv.__dict__.setdefault("_passion_pack", {})
+    y = ops.conv_block([_seg_auto(f) for f in feats], w, b, D, H, W, ksize=conv.kernel_size[0], stride=conv.stride[0],
+                       pad_mode=PAD[conv.padding_mode], out_dtype=out_dtype, pack_cache=cache)
+    return PFeat(y) if post else Feat(y)
+
+
+class general_conv3d(nn.Module):
+    """Conv3d -> InstanceNorm -> LeakyReLU(0.2) (reference blocks.py:354-370).  The conv launches here; the
+    norm + activation happen in the loader of whichever conv consumes the returned PFeat."""
+
+    def __init__(self, in_ch, out_ch, k_size=3, stride=1, padding=1, pad_type="reflect", norm="in", is_training=True,
+                 act_type="lrelu", relufactor=0.2):
+        super().__init__()
+        self.conv = nn.Conv3d(in_channels=in_ch, out_channels=out_ch, kernel_size=k_size, stride=stride, padding=padding,
+                              padding_mode=pad_type, bias=True)
+        self.norm = normalization(out_ch, norm=norm)
+        self.activation = nn.LeakyReLU(negative_slope=relufactor, inplace=True) if act_type == "lrelu" else nn.ReLU(inplace=True)
+
+    def forward(self, feats):
+        return run_conv_auto(self.conv, feats, post=True)
+
+
+def _chain(seq, feats):
+    for layer in seq:
+        feats = layer(feats) if isinstance(layer, general_conv3d) else run_conv_auto(layer, feats, out_dtype=torch.float32)
+    return feats
+
+
+class prm_generator_laststage_pk(nn.Module):
+    """region probability logits of the deepest level (reference blocks.py:396-416)"""
+
+    def __init__(self, in_channel=64, norm="in", num_cls=4):
+        super().__init__()
+        q = int(in_channel // 4)
+        self.embedding_layer = nn.Sequential(general_conv3d(in_channel * 4, q, k_size=1, padding=0, stride=1),
+                                             general_conv3d(q, q, k_size=3, padding=1, stride=1),
+                                             general_conv3d(q, in_channel, k_size=1, padding=0, stride=1))
+        self.prm_layer = nn.Sequential(general_conv3d(in_channel, 16, k_size=1, stride=1, padding=0),
+                                       nn.Conv3d(16, num_cls, kernel_size=1, padding=0, stride=1, bias=True))
+
+    def forward(self, x, mask=None):
+        """x: the four (masked) modality Feats"""
+        return _chain(self.prm_layer, _chain(self.embedding_layer, x)).t
+
+
+class prm_generator_pk(nn.Module):
+    """reference blocks.py:443-464: prm_layer(cat(x1, embedding_layer(masked x2)))"""
+
+    def __init__(self, in_channel=64, norm="in", num_cls=4):
+        super().__init__()
+        q = int(in_channel // 4)
+        self.embedding_layer = nn.Sequential(general_conv3d(in_channel * 4, q, k_size=1, padding=0, stride=1),
+                                             general_conv3d(q, q, k_size=3, padding=1, stride=1),
+                                             general_conv3d(q, in_channel, k_size=1, padding=0, stride=1))
+        self.prm_layer = nn.Sequential(general_conv3d(in_channel * 2, 16, k_size=1, stride=1, padding=0),
+                                       nn.Conv3d(16, num_cls, kernel_size=1, padding=0, stride=1, bias=True))
+
+    def forward(self, x1, x2, mask=None):
+        return _chain(self.prm_layer, [x1, _chain(self.embedding_layer, x2)]).t
+
+
+class modal_fusion(nn.Module):
+    """per-region modality weights from global statistics (reference blocks.py:495-517); the tiny
+    (B, 4C+1) -> 128 -> 4 MLP stays on torch, the volume work is in region_gap / region_mix"""
+
+    def __init__(self, in_channel=64):
+        super().__init__()
+        self.weight_layer = nn.Sequential(nn.Conv3d(4 * in_channel + 1, 128, 1, padding=0, bias=True),
+                                          nn.LeakyReLU(negative_slope=0.2, inplace=True),
+                                          nn.Conv3d(128, 4, 1, padding=0, bias=True))
+        self.sigmoid = nn.Sigmoid()
+
+    def weights(self, feat_avg, prm_avg):
+        """feat_avg (B, 4*C), prm_avg (B, 1) -> sigmoid weights (B, 4)"""
+        w0, w2 = self.weight_layer[0], self.weight_layer[2]
+        h = torch.nn.functional.linear(torch.cat((feat_avg, prm_avg), 1), w0.weight.flatten(1), w0.bias)
+        h = torch.nn.functional.leaky_relu(h, 0.2)
+        return torch.sigmoid(torch.nn.functional.linear(h, w2.weight.flatten(1), w2.bias))
+
+
+class region_fusion(nn.Module):
+    """reference blocks.py:520-531"""
+
+    def __init__(self, in_channel=64, num_cls=4):
+        super().__init__()
+        self.fusion_layer = nn.Sequential(general_conv3d(in_channel * num_cls, in_channel, k_size=1, padding=0, stride=1),
+                                          general_conv3d(in_channel, in_channel, k_size=3, padding=1, stride=1),
+                                          general_conv3d(in_channel, in_channel // 2, k_size=1, padding=0, stride=1))
+
+    def forward(self, x):
+        return _chain(self.fusion_layer, x)
+
+
+class region_aware_modal_fusion(nn.Module):
+    """reference blocks.py:582-626.  x: the four modality Feats (carrying the mask), prm: (B,D,H,W,4) f32
+    region probabilities (already detached).  Returns the two halves of the channel concat
+    [region_fusion(...), short_cut(...)] as post-norm Feats."""
+
+    def __init__(self, in_channel=64, norm="in", num_cls=4):
+        super().__init__()
+        self.num_cls = num_cls
+        self.modal_fusion = nn.ModuleList([modal_fusion(in_channel=in_channel) for _ in range(num_cls)])
+        self.region_fusion = region_fusion(in_channel=in_channel, num_cls=num_cls)
+        self.short_cut = nn.Sequential(general_conv3d(in_channel * 4, in_channel, k_size=1, padding=0, stride=1),
+                                       general_conv3d(in_channel, in_channel, k_size=3, padding=1, stride=1),
+                                       general_conv3d(in_channel, in_channel // 2, k_size=1, padding=0, stride=1))
+        self.clsname_list = ['BG', 'NCR', 'ED', 'NET', 'ET']
+
+    def forward(self, x, prm, mask=None):
+        ys = [f.t for f in x]
+        msk = x[0].mask
+        B, D, H, W, C = ys[0].shape
+        V = D * H * W
+        S, P = ops.region_gap(prm, msk, ys)                       # (B,4,4,C) sums, (B,4) prob sums
+        prm_avg = P / V + 1e-7                                    # blocks.py:507
+        feat_avg = (S / V) / prm_avg.view(B, 4, 1, 1)             # blocks.py:508
+        w = torch.stack([self.modal_fusion[i].weights(feat_avg[:, i].reshape(B, 4 * C).float(), prm_avg[:, i:i + 1])
+                         for i in range(self.num_cls)], 1)        # (B, region, modality)
+        R = ops.region_mix(prm, msk, w, ys)
+        return [self.region_fusion(Feat(R)), _chain(self.short_cut, x)]

@@ -1,0 +1,238 @@
+"""RFNet backbone + PASSION self-distillation losses on the MI355X HIP kernels.
+
+Drop-in for the reference's code/models/rfnet.py (Model :176-403): same constructor, attributes
+(`mask_type`, `use_passion`, `is_training`), forward signature / return tuples and state-dict keys.
+Post-norm convs (general_conv3d = Conv -> IN -> LReLU) run on the same fused conv kernel as mmformer's
+pre-norm blocks: a conv returns its raw output, the consumer's loader normalises + activates it; the
+activated tensor is only materialised (ops.norm_act) for the encoder residuals, upsampling inputs and
+prototype features.  Region-aware modal fusion runs on region_gap / region_mix (blocks.py).
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import _lib as L
+from .. import ops
+from ..utils import criterions as crit
+from .blocks import (Feat, PFeat, general_conv3d, materialize, prm_generator_laststage_pk, prm_generator_pk,
+                     region_aware_modal_fusion, run_conv_auto)
+
+basic_dims = 8
+H = W = Z = 80
+num_cls = 4
+num_modals = 4
+MODALS = ("flair", "t1ce", "t1", "t2")
+
+
+def _up2_mat(feats):
+    """upsample x2 of the activated value of one Feat / the channel concat of several"""
+    if not isinstance(feats, (list, tuple)):
+        feats = [feats]
+    mats = [materialize(f) for f in feats]
+    t = mats[0].t if len(mats) == 1 else torch.cat([m.t for m in mats], -1)
+    return Feat(ops.upsample(t, 2), feats[0].mask, feats[0].mask_col)
+
+
+class Encoder(nn.Module):
+    """four-level post-norm residual encoder (reference rfnet.py:15-48)"""
+
+    def __init__(self):
+        super().__init__()
+        c = basic_dims
+        self.e1_c1 = general_conv3d(1, c, pad_type="reflect")
+        self.e1_c2 = general_conv3d(c, c, pad_type="reflect")
+        self.e1_c3 = general_conv3d(c, c, pad_type="reflect")
+        for lvl in range(2, 5):
+            ci, co = c * 2 ** (lvl - 2), c * 2 ** (lvl - 1)
+            setattr(self, f"e{lvl}_c1", general_conv3d(ci, co, stride=2, pad_type="reflect"))
+            setattr(self, f"e{lvl}_c2", general_conv3d(co, co, pad_type="reflect"))
+            setattr(self, f"e{lvl}_c3", general_conv3d(co, co, pad_type="reflect"))
+
+    def forward(self, x, modal, mask, dtype):
+        B, K, D, Hh, Ww = x.shape
+        vol = D * Hh * Ww
+        seg = ops.SegIn(x, mask=mask, mask_col=modal, C=1, offset=modal * vol, bstride=K * vol)
+        conv = self.e1_c1.conv
+        cache = conv.__dict__.setdefault("_passion_pack", {})
+        r1 = PFeat(ops.conv_block([seg], conv.weight, conv.bias, D, Hh, Ww, ksize=3, stride=1, pad_mode=L.PAD_REFLECT,
+                                  out_dtype=dtype, pack_cache=cache))
+        feats = []
+        for lvl in range(1, 5):
+            if lvl > 1:
+                r1 = getattr(self, f"e{lvl}_c1")(feats[-1])
+            r3 = getattr(self, f"e{lvl}_c3")(getattr(self, f"e{lvl}_c2")(r1))
+            feats.append(Feat(ops.norm_act(r1.t, r1.stats(), r3.t, r3.stats())))      # x + c3(c2(x)) on activated values
+        return feats
+
+
+class Decoder_sep(nn.Module):
+    """reference rfnet.py:50-89 -> softmax probabilities (channels-last f32)"""
+
+    def __init__(self, num_cls=4):
+        super().__init__()
+        c = basic_dims
+        for lvl in (3, 2, 1):
+            co = c * 2 ** (lvl - 1)
+            setattr(self, f"d{lvl}", nn.Upsample(scale_factor=2, mode="trilinear", align_corners=True))
+            setattr(self, f"d{lvl}_c1", general_conv3d(co * 2, co, pad_type="reflect"))
+            setattr(self, f"d{lvl}_c2", general_conv3d(co * 2, co, pad_type="reflect"))
+            setattr(self, f"d{lvl}_out", general_conv3d(co, co, k_size=1, padding=0, pad_type="reflect"))
+        self.seg_layer = nn.Conv3d(in_channels=c, out_channels=num_cls, kernel_size=1, stride=1, padding=0, bias=True)
+        self.softmax = nn.Softmax(dim=1)
+
+    def forward(self, x1, x2, x3, x4):
+        skips = (x1, x2, x3)
+        h = self.d3_c1(_up2_mat(x4))
+        for lvl in (3, 2, 1):
+            h = getattr(self, f"d{lvl}_out")(getattr(self, f"d{lvl}_c2")([h, skips[lvl - 1]]))
+            if lvl > 1:
+                h = getattr(self, f"d{lvl - 1}_c1")(_up2_mat(h))
+        logits = run_conv_auto(self.seg_layer, h, out_dtype=torch.float32).t
+        return ops.softmax_classes(logits, 1.0, "cl")
+
+
+class Decoder_fuse(nn.Module):
+    """reference rfnet.py:91-152"""
+
+    def __init__(self, num_cls=4):
+        super().__init__()
+        c = basic_dims
+        for lvl in (3, 2, 1):
+            co = c * 2 ** (lvl - 1)
+            setattr(self, f"d{lvl}_c1", general_conv3d(co * 2, co, pad_type="reflect"))
+            setattr(self, f"d{lvl}_c2", general_conv3d(co * 2, co, pad_type="reflect"))
+            setattr(self, f"d{lvl}_out", general_conv3d(co, co, k_size=1, padding=0, pad_type="reflect"))
+        self.seg_layer = nn.Conv3d(in_channels=c, out_channels=num_cls, kernel_size=1, stride=1, padding=0, bias=True)
+        self.softmax = nn.Softmax(dim=1)
+        self.up2 = nn.Upsample(scale_factor=2, mode="trilinear", align_corners=True)
+        self.up4 = nn.Upsample(scale_factor=4, mode="trilinear", align_corners=True)
+        self.up8 = nn.Upsample(scale_factor=8, mode="trilinear", align_corners=True)
+        self.RFM4 = region_aware_modal_fusion(in_channel=c * 8, num_cls=num_cls)
+        self.RFM3 = region_aware_modal_fusion(in_channel=c * 4, num_cls=num_cls)
+        self.RFM2 = region_aware_modal_fusion(in_channel=c * 2, num_cls=num_cls)
+        self.RFM1 = region_aware_modal_fusion(in_channel=c * 1, num_cls=num_cls)
+        self.prm_generator4 = prm_generator_laststage_pk(in_channel=c * 8, num_cls=num_cls)
+        self.prm_generator3 = prm_generator_pk(in_channel=c * 4, num_cls=num_cls)
+        self.prm_generator2 = prm_generator_pk(in_channel=c * 2, num_cls=num_cls)
+        self.prm_generator1 = prm_generator_pk(in_channel=c * 1, num_cls=num_cls)
+
+    def forward(self, x1, x2, x3, x4, mask=None):
+        """x1..x4: lists of the four modality Feats carrying the effective mask"""
+        xs = {1: x1, 2: x2, 3: x3, 4: x4}
+        prm4 = self.prm_generator4(x4)
+        prms = {4: prm4}
+        fused = self.RFM4(x4, ops.softmax_classes(prm4.detach(), 1.0, "cl"))
+        h = self.d3_c1(_up2_mat(fused))                                        # de_x4
+        feats = {4: h}
+        for lvl in (3, 2, 1):
+            prm = getattr(self, f"prm_generator{lvl}")(h, xs[lvl])
+            prms[lvl] = prm
+            fused = getattr(self, f"RFM{lvl}")(xs[lvl], ops.softmax_classes(prm.detach(), 1.0, "cl"))
+            h = getattr(self, f"d{lvl}_out")(getattr(self, f"d{lvl}_c2")(fused + [h]))
+            feats[lvl] = h
+            if lvl > 1:
+                h = getattr(self, f"d{lvl - 1}_c1")(_up2_mat(h))
+                feats[lvl] = feats[lvl]
+                nxt = h
+            # note: reference returns de_x{lvl} AFTER d{lvl-1}_c1(up2(.)) for lvl 3,2 (rfnet.py:135,141) -- keep that
+            if lvl > 1:
+                feats[lvl] = nxt
+        logits = run_conv_auto(self.seg_layer, feats[1], out_dtype=torch.float32).t
+        return logits, (prms[1], prms[2], prms[3], prms[4]), (feats[1], feats[2], feats[3], feats[4])
+
+
+class MaskModal(nn.Module):
+    def forward(self, x, mask):
+        B, K, C, Hh, Ww, Zz = x.size()
+        return (x * mask.view(B, K, 1, 1, 1, 1).to(x.dtype)).view(B, -1, Hh, Ww, Zz)
+
+
+class MaskModal_NoCat(nn.Module):
+    def forward(self, x, mask):
+        B, K = x.shape[:2]
+        return x * mask.view(B, K, 1, 1, 1, 1).to(x.dtype)
+
+
+class Model(nn.Module):
+    def __init__(self, num_cls=4):
+        super().__init__()
+        self.flair_encoder = Encoder()
+        self.t1ce_encoder = Encoder()
+        self.t1_encoder = Encoder()
+        self.t2_encoder = Encoder()
+        self.decoder_fuse = Decoder_fuse(num_cls=num_cls)
+        self.decoder_sep = Decoder_sep(num_cls=num_cls)
+        self.masker = MaskModal()
+        self.masker_nocat = MaskModal_NoCat()
+        self.is_training = False
+        self.use_passion = False
+        self.mask_type = "idt"
+        self.compute_dtype = torch.float32
+        eye = np.eye(4, dtype=bool)
+        for i in range(4):
+            setattr(self, f"masks_mod{i}", torch.from_numpy(eye[i:i + 1].copy()))
+        self.up1 = nn.Identity()
+        self.up2 = nn.Upsample(scale_factor=2, mode="trilinear", align_corners=True)
+        self.up4 = nn.Upsample(scale_factor=4, mode="trilinear", align_corners=True)
+        self.up8 = nn.Upsample(scale_factor=8, mode="trilinear", align_corners=True)
+        self.up_ops = nn.ModuleList([self.up1, self.up2, self.up4, self.up8])
+        for m in self.modules():
+            if isinstance(m, nn.Conv3d):
+                torch.nn.init.kaiming_normal_(m.weight)
+
+    def forward(self, x, mask, target=None, temp=1.0):
+        L.require_gpu(x)
+        B = x.size(0)
+        dev, dt = x.device, self.compute_dtype
+        idt = self.mask_type != "pdt"
+        mask = mask.to(device=dev, dtype=torch.bool).contiguous()
+        xin = x.to(dt).contiguous()
+        encs = [getattr(self, f"{m}_encoder")(xin, i, mask if idt else None, dt) for i, m in enumerate(MODALS)]
+
+        def modal_feats(lvl, msk):
+            return [encs[i][lvl].with_mask(msk, i) for i in range(4)]
+
+        # decoder_fuse always masks with the mask it is given (rfnet.py:126-144); in idt the features are masked too
+        fuse_pred, preds, de_f_avg = self.decoder_fuse(*[modal_feats(l, mask) for l in range(4)])
+        pred = ops.softmax_classes(fuse_pred, 1.0, "ncdhw")
+        if not self.is_training:
+            return pred
+
+        tcl = ops.target_to_cl(target)
+        own = [[(f.with_mask(mask, i) if idt else f) for f in encs[i]] for i in range(4)]
+        sep_preds = [self.decoder_sep(*own[i]) for i in range(4)]
+        eye = torch.eye(4, device=dev)
+        maskf = mask.float()
+        gates = [(maskf * eye[i]) if idt else eye[i].expand(B, 4) for i in range(4)]
+        ups = (1, 2, 4, 8)
+
+        prm_loss = torch.zeros(B, 1, device=dev)
+        for j, pp in enumerate(preds):
+            pair = crit.seg_losses_cl(ops.softmax_classes(pp, 1.0, "cl"), tcl, ups[j])
+            prm_loss = prm_loss + 0.5 ** (j + 1) * pair.sum(1, keepdim=True)
+        sep_loss = torch.zeros(B, 4, device=dev)
+        for i in range(4):
+            sep_loss = sep_loss + gates[i] * ops.wce_dice(sep_preds[i], tcl, "cl").sum(1, keepdim=True)
+        if not self.use_passion:
+            return pred, prm_loss, sep_loss
+
+        inv_t = 1.0 / temp
+        pt_full = ops.softmax_classes(fuse_pred.detach(), inv_t, "cl")
+        pt_deep = [ops.upsample(ops.softmax_classes(pp.detach(), inv_t, "cl"), ups[j]) for j, pp in enumerate(preds)]
+        f_teacher = materialize(de_f_avg[0]).t.detach()
+        kl_loss, proto_loss, dist = (torch.zeros(B, 4, device=dev) for _ in range(3))
+        onehots = [getattr(self, f"masks_mod{i}").to(dev).expand(B, 4).contiguous() for i in range(4)]
+        for i in range(4):
+            eff = (mask & onehots[i]).contiguous() if idt else onehots[i]
+            fuse_i, preds_i, de_f_i = self.decoder_fuse(*[modal_feats(l, eff) for l in range(4)])
+            pl, d = ops.proto_loss(materialize(de_f_i[0]).t, f_teacher, tcl)
+            kl = crit.kl_cl(fuse_i, pt_full, temp)
+            for j, ps_ in enumerate(preds_i):
+                kl = kl + 0.5 ** (j + 1) * crit.kl_cl(ps_, pt_deep[j], temp, ups[j])
+            # single-present-modality sample: student == teacher exactly (see mmformer.py for the rationale)
+            differs = (~(mask == onehots[i]).all(1)).float().view(B, 1)
+            pl, d, kl = pl * differs, d * differs, kl * differs
+            proto_loss = proto_loss + gates[i] * pl
+            dist = dist + gates[i] * d
+            kl_loss = kl_loss + gates[i] * kl
+        return pred, prm_loss, sep_loss, kl_loss, proto_loss, dist

@@ -456,6 +456,131 @@ def attention(qkv, heads, scale, drop_p=0.0):
 
 
 # ------------------------------------------------------------------------------------------------
+# RFNet ops: post-norm materialisation and region-aware modal fusion
+# ------------------------------------------------------------------------------------------------
+class NormActFn(torch.autograd.Function):
+    """sum_k LeakyReLU(InstanceNorm(x_k)) for 1 or 2 raw conv outputs -- the value a post-norm
+    general_conv3d (reference blocks.py:366-370) hands to a non-conv consumer."""
+
+    @staticmethod
+    def forward(ctx, slope, x0, st0, x1, st1):
+        L.require_gpu(x0)
+        x0 = x0.contiguous()
+        B, D, H, W, C = x0.shape
+        out = torch.empty_like(x0)
+        L.check(L.load().passion_norm_act_fwd(_p(x0), _p(st0), _p(x1), _p(st1), _p(out), L.dtype_code(x0.dtype), B,
+                                              D * H * W, C, C, 0, float(slope), L.stream_ptr()), "passion_norm_act_fwd")
+        ctx.slope = float(slope)
+        ctx.save_for_backward(x0, st0, x1, st1)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x0, st0, x1, st1 = ctx.saved_tensors
+        B, D, H, W, C = x0.shape
+        V = D * H * W
+        lib = L.load()
+        dout = dout.contiguous()
+        scratch = torch.empty(lib.passion_norm_act_scratch_floats(B, V, C), dtype=torch.float32, device=x0.device)
+        outs = []
+        for x, st in ((x0, st0), (x1, st1)):
+            if x is None:
+                outs.append(None)
+                continue
+            dx = torch.empty_like(x)
+            L.check(lib.passion_norm_act_bwd(_p(x), _p(st), _p(dout), _p(dx), L.dtype_code(x.dtype), B, V, C, C, 0,
+                                             ctx.slope, _p(scratch), L.stream_ptr()), "passion_norm_act_bwd")
+            outs.append(dx)
+        return None, outs[0], None, outs[1], None
+
+
+def norm_act(x0, st0, x1=None, st1=None, slope=0.2):
+    return NormActFn.apply(slope, x0, st0, x1, st1)
+
+
+def _ptr4(ts):
+    arr = (c_void_p * 4)()
+    for i, t in enumerate(ts):
+        arr[i] = t.data_ptr() if t is not None else None
+    return arr
+
+
+class RegionGapFn(torch.autograd.Function):
+    """S[b,i,m,c] = sum_v y_m[c] prob_i and P[b,i] = sum_v prob_i -- the global average pools of
+    modal_fusion (reference blocks.py:507-508) for all regions x modalities in one pass."""
+
+    @staticmethod
+    def forward(ctx, prob, mask, y0, y1, y2, y3):
+        ys = [t.contiguous() for t in (y0, y1, y2, y3)]
+        L.require_gpu(prob, *ys)
+        B, D, H, W, C = ys[0].shape
+        V = D * H * W
+        lib = L.load()
+        scratch = torch.empty(lib.passion_region_scratch_floats(B, V, C), dtype=torch.float32, device=prob.device)
+        sums = torch.empty(B, 16 * C + 4, dtype=torch.float32, device=prob.device)
+        L.check(lib.passion_region_gap_fwd(_ptr4(ys), _p(mask), mask.shape[1] if mask is not None else 0, _p(prob),
+                                           L.dtype_code(ys[0].dtype), B, V, C, _p(scratch), _p(sums), L.stream_ptr()),
+                "passion_region_gap_fwd")
+        ctx.save_for_backward(prob, mask)
+        ctx.meta = (B, V, C, ys[0].dtype, ys[0].shape)
+        S = sums[:, :16 * C].reshape(B, 4, 4, C)
+        P = sums[:, 16 * C:]
+        ctx.mark_non_differentiable(P)
+        return S, P
+
+    @staticmethod
+    def backward(ctx, gS, _gP):
+        prob, mask = ctx.saved_tensors
+        B, V, C, dt, shape = ctx.meta
+        gS = gS.contiguous().float()
+        dys = [torch.empty(shape, dtype=dt, device=prob.device) if ctx.needs_input_grad[2 + m] else None for m in range(4)]
+        L.check(L.load().passion_region_gap_bwd(_ptr4(dys), _p(mask), mask.shape[1] if mask is not None else 0, _p(prob),
+                                                _p(gS), L.dtype_code(dt), B, V, C, L.stream_ptr()), "passion_region_gap_bwd")
+        return (None, None, *dys)
+
+
+class RegionMixFn(torch.autograd.Function):
+    """R[b,v,i*C+c] = prob_i(v) * sum_m w[b,i,m] y_m[c](v): region split + weighted modality sum + reshape
+    (reference blocks.py:602-616, 516, 530) without the (B,4,4,C,D,H,W) intermediate."""
+
+    @staticmethod
+    def forward(ctx, prob, mask, w, y0, y1, y2, y3):
+        ys = [t.contiguous() for t in (y0, y1, y2, y3)]
+        B, D, H, W, C = ys[0].shape
+        V = D * H * W
+        w = w.contiguous().float()
+        out = torch.empty(B, D, H, W, 4 * C, dtype=ys[0].dtype, device=prob.device)
+        L.check(L.load().passion_region_mix_fwd(_ptr4(ys), _p(mask), mask.shape[1] if mask is not None else 0, _p(prob),
+                                                _p(w), _p(out), L.dtype_code(ys[0].dtype), B, V, C, L.stream_ptr()),
+                "passion_region_mix_fwd")
+        ctx.save_for_backward(prob, mask, w, *ys)
+        return out
+
+    @staticmethod
+    def backward(ctx, dR):
+        prob, mask, w, *ys = ctx.saved_tensors
+        B, D, H, W, C = ys[0].shape
+        V = D * H * W
+        lib = L.load()
+        dR = dR.contiguous()
+        dys = [torch.empty_like(ys[m]) if ctx.needs_input_grad[3 + m] else None for m in range(4)]
+        scratch = torch.empty(lib.passion_region_scratch_floats(B, V, C), dtype=torch.float32, device=prob.device)
+        dw = torch.empty(B, 4, 4, dtype=torch.float32, device=prob.device)
+        L.check(lib.passion_region_mix_bwd(_ptr4(ys), _ptr4(dys), _p(mask), mask.shape[1] if mask is not None else 0,
+                                           _p(prob), _p(w), _p(dR), L.dtype_code(ys[0].dtype), B, V, C, _p(scratch), _p(dw),
+                                           L.stream_ptr()), "passion_region_mix_bwd")
+        return (None, None, dw, *dys)
+
+
+def region_gap(prob, mask, ys):
+    return RegionGapFn.apply(prob, mask, *ys)
+
+
+def region_mix(prob, mask, w, ys):
+    return RegionMixFn.apply(prob, mask, w, *ys)
+
+
+# ------------------------------------------------------------------------------------------------
 # kernel timing hooks (bench.py)
 # ------------------------------------------------------------------------------------------------
 def prof_enable(on):

@@ -126,9 +126,14 @@ def main(argv=None):
     args = args_parser(argv)
     ctx = parallel.init()
     torch.manual_seed(args.seed)
-    assert args.model == "mmformer", "rfnet is the next scope row (SURVEY 8a a16)"
-    mmformer.patch_size = args.patch // 16
-    model = mmformer.Model(num_cls=4).to(ctx.device)
+    if args.model == "mmformer":
+        mmformer.patch_size = args.patch // 16
+        model = mmformer.Model(num_cls=4).to(ctx.device)
+    elif args.model == "rfnet":
+        from .models import rfnet
+        model = rfnet.Model(num_cls=4).to(ctx.device)
+    else:
+        raise SystemExit("m2ftrans is out of this build's scope (SURVEY.md 2.1 row 7)")
     model.mask_type, model.use_passion = args.mask_type, args.use_passion
     model.compute_dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     model.train()

@@ -172,10 +172,69 @@ def loss_cases(mmformer, criterions):
     print("wrote losses")
 
 
+def rfnet_case(rfnet, criterions, tag, S, B, mask, mask_type, passion, blobs, temp=4.0):
+    """rfnet.Model (reference code/models/rfnet.py) with float16-representable weights stored once"""
+    torch.manual_seed(1037)
+    model = rfnet.Model(num_cls=4)
+    with torch.no_grad():
+        for p_ in model.parameters():
+            p_.copy_(p_.half().float())
+    model.eval()
+    model.mask_type, model.use_passion, model.is_training = mask_type, passion, True
+    x, target = synth(B, S, blobs=blobs)
+    mask_t = torch.tensor(mask, dtype=torch.bool).view(B, 4)
+    outs = model(x, mask_t, target=target, temp=temp)
+    fuse_pred = outs[0]
+    fuse_loss_bs = criterions.softmax_weighted_loss_bs(fuse_pred, target, num_cls=4) + \
+        criterions.dice_loss_bs(fuse_pred, target, num_cls=4)
+    rec = {"S": S, "B": B, "mask": np.array(mask, dtype=bool).reshape(B, 4), "temp": temp, "mask_type": mask_type,
+           "passion": passion, "small": False, "blobs": blobs, "fuse_loss_bs": fuse_loss_bs.detach().numpy(),
+           "argmax": fuse_pred.argmax(1).numpy().astype(np.uint8), "pred_slice": fuse_pred[:, :, S // 2].detach().numpy(),
+           "pred_sum": fuse_pred.detach().double().sum((2, 3, 4)).numpy()}
+    for n, o in zip(["prm_loss", "sep_loss", "kl_loss", "proto_loss", "dist"], outs[1:]):
+        rec[n] = o.detach().numpy()
+    loss = fuse_loss_bs.sum() + outs[1].sum()
+    mk = mask_t.float() if mask_type != "pdt" else torch.ones(B, 4)
+    if passion:
+        sep_m, kl_m, proto_m = (outs[2] * mk).sum(0), (outs[3] * mk).sum(0), (outs[4] * mk).sum(0)
+        rp = torch.zeros(4)
+        for b in range(B):
+            rp += mk[b] * (outs[5][b] / (outs[5][b].sum() / mk[b].sum()) - 1)
+        rp_mask = (rp > 0).float()
+        rec["rp_mask"] = rp_mask.numpy()
+        loss = loss + (rp_mask * sep_m).sum() + 0.5 * kl_m.sum() + 0.1 * (rp_mask * proto_m).sum()
+    else:
+        loss = loss + (outs[2] * mk).sum()
+    rec["loss"] = float(loss)
+    model.zero_grad()
+    loss.backward()
+    gn = grad_norms(model)
+    rec["grad_keys"] = np.array(sorted(gn))
+    rec["grad_norms"] = np.array([gn[k] for k in sorted(gn)])
+    sd = dict(model.named_parameters())
+    for key in ("flair_encoder.e1_c1.conv.weight", "t1_encoder.e3_c2.conv.weight", "decoder_fuse.RFM1.modal_fusion.2.weight_layer.0.weight",
+                "decoder_fuse.prm_generator1.embedding_layer.1.conv.weight", "decoder_fuse.RFM3.region_fusion.fusion_layer.0.conv.weight",
+                "decoder_fuse.RFM2.short_cut.1.conv.weight", "decoder_fuse.prm_generator4.prm_layer.1.bias", "decoder_sep.d2_c1.conv.weight"):
+        if sd[key].grad is not None:
+            rec["grad::" + key] = sd[key].grad.numpy()
+    wpath = os.path.join(OUT, "weights_rfnet.npz")
+    if not os.path.exists(wpath):
+        np.savez_compressed(wpath, **{k: v.numpy().astype(np.float16) for k, v in model.state_dict().items()})
+    np.savez_compressed(os.path.join(OUT, f"rfnet_{tag}.npz"), **rec)
+    print("wrote rfnet", tag, rec["loss"])
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
     mmformer, criterions = import_reference()
+    if len(sys.argv) > 1 and sys.argv[1] == "rfnet":      # only (re)generate the RFNet fixtures
+        from models import rfnet
+        rfnet_case(rfnet, criterions, "idt_passion_1011", 32, 1, [[1, 0, 1, 1]], "idt", True, True)
+        rfnet_case(rfnet, criterions, "idt_passion_b2", 32, 2, [[1, 1, 1, 1], [0, 0, 1, 0]], "idt", True, True)
+        rfnet_case(rfnet, criterions, "idt_plain_1111", 32, 1, [[1, 1, 1, 1]], "idt", False, False)
+        rfnet_case(rfnet, criterions, "pdt_passion_1101", 32, 1, [[1, 1, 0, 1]], "pdt", True, True)
+        return
     loss_cases(mmformer, criterions)
     # small-constants models: full state_dict stored -> independent of RNG order
     model_case(mmformer, criterions, "small_idt_passion_1011", 32, 1, [[1, 0, 1, 1]], "idt", True, True, True)
@@ -185,6 +244,11 @@ def main():
     # full-size model (35.6 M parameters): weights reproduced from torch.manual_seed(1037) construction order
     model_case(mmformer, criterions, "full_idt_passion_1111", 32, 1, [[1, 1, 1, 1]], "idt", True, False, True)
     model_case(mmformer, criterions, "full_idt_plain_64", 64, 1, [[1, 1, 1, 1]], "idt", False, False, True, with_grads=False)
+    from models import rfnet
+    rfnet_case(rfnet, criterions, "idt_passion_1011", 32, 1, [[1, 0, 1, 1]], "idt", True, True)
+    rfnet_case(rfnet, criterions, "idt_passion_b2", 32, 2, [[1, 1, 1, 1], [0, 0, 1, 0]], "idt", True, True)
+    rfnet_case(rfnet, criterions, "idt_plain_1111", 32, 1, [[1, 1, 1, 1]], "idt", False, False)
+    rfnet_case(rfnet, criterions, "pdt_passion_1101", 32, 1, [[1, 1, 0, 1]], "pdt", True, True)
 
 
 if __name__ == "__main__":
