@@ -86,10 +86,119 @@ __global__ __launch_bounds__(256) void bgemm_kernel(GemmP p) {
             }
 }
 
+// ---- bf16 matrix-core version (used when the tensors are bf16: the bench dtype) --------------------------------
+// 64x64 tile, K chunk 32, v_mfma_f32_16x16x32_bf16.  Either operand may be contiguous along k (row image, fragment =
+// one ds_read_b128) or along m/n (k-major image, fragment = two ds_read_b64_tr_b16): no transposing copies, the six
+// attention products only differ in strides.  f32 inputs (the probabilities) are rounded to bf16 while staging.
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef short s16x4_t __attribute__((ext_vector_type(4)));
+typedef short s16x8_t __attribute__((ext_vector_type(8)));
+constexpr int BK = 32;
+constexpr int ROWS = BK * 2 + 16;      // bytes per row of a [64][32] row image (k contiguous)
+constexpr int ROWT = GT * 2 + 16;      // bytes per row of a [32][64] k-major image
+
+template <typename T>
+__device__ __forceinline__ bf16x8_t load_run8(const T* base, long off, long stride, int valid) {
+    // 8 elements base[off + i*stride], i < valid (others 0); vectorised when contiguous, aligned and complete
+    bf16x8_t r;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r[i] = (__bf16)0.f;
+    if (valid <= 0) return r;
+    const T* p = base + off;
+    if (stride == 1 && valid == 8 && ((reinterpret_cast<uintptr_t>(p) & 15) == 0)) {
+        if (sizeof(T) == 2) return *reinterpret_cast<const bf16x8_t*>(p);
+        const f32x4 lo = *reinterpret_cast<const f32x4*>(p), hi = *reinterpret_cast<const f32x4*>(p + 4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { r[i] = (__bf16)lo[i]; r[4 + i] = (__bf16)hi[i]; }
+        return r;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) if (i < valid) r[i] = (__bf16)to_f32(p[i * stride]);
+    return r;
+}
+
+__device__ __forceinline__ bf16x8_t tr8(const char* p0, const char* p1) {
+    const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(p0));
+    const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(p1));
+    return __builtin_bit_cast(bf16x8_t, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+}
+
+template <typename TA, typename TB, typename TC>
+__global__ __launch_bounds__(256) void bgemm_bf16_kernel(GemmP p) {
+    __shared__ __attribute__((aligned(16))) char As[GT * ROWS > BK * ROWT ? GT * ROWS : BK * ROWT];
+    __shared__ __attribute__((aligned(16))) char Bs[GT * ROWS > BK * ROWT ? GT * ROWS : BK * ROWT];
+    const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, n = lane & 15, g = lane >> 4, q = n >> 2, pq = n & 3;
+    const int batch = blockIdx.z, b1 = batch / p.nb2, b2 = batch % p.nb2;
+    const TA* A = reinterpret_cast<const TA*>(p.A) + b1 * p.a_b1 + b2 * p.a_b2;
+    const TB* Bm = reinterpret_cast<const TB*>(p.Bm) + b1 * p.b_b1 + b2 * p.b_b2;
+    TC* C = reinterpret_cast<TC*>(p.C) + b1 * p.c_b1 + b2 * p.c_b2;
+    const int m0 = blockIdx.y * GT, n0 = blockIdx.x * GT;
+    const int wm = (wv >> 1) * 32, wn = (wv & 1) * 32;
+    const bool a_row = (p.ak == 1), b_row = (p.bk == 1);     // operand contiguous along k -> row image
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int k0 = 0; k0 < p.K; k0 += BK) {
+        __syncthreads();
+        if (a_row) {            // thread: row m = tid/4, 8 consecutive k
+            const int m = tid >> 2, k8 = (tid & 3) * 8;
+            const int valid = (m0 + m < p.M) ? min(8, p.K - (k0 + k8)) : 0;
+            *reinterpret_cast<bf16x8_t*>(As + m * ROWS + k8 * 2) = load_run8(A, (long)(m0 + m) * p.am + (k0 + k8), 1, valid);
+        } else {                // thread: k = tid/8, 8 consecutive m (or strided when neither axis is contiguous)
+            const int k = tid >> 3, m8 = (tid & 7) * 8;
+            const int valid = (k0 + k < p.K) ? min(8, p.M - (m0 + m8)) : 0;
+            *reinterpret_cast<bf16x8_t*>(As + k * ROWT + m8 * 2) = load_run8(A, (long)(k0 + k) * p.ak + (long)(m0 + m8) * p.am, p.am, valid);
+        }
+        if (b_row) {
+            const int nn = tid >> 2, k8 = (tid & 3) * 8;
+            const int valid = (n0 + nn < p.N) ? min(8, p.K - (k0 + k8)) : 0;
+            *reinterpret_cast<bf16x8_t*>(Bs + nn * ROWS + k8 * 2) = load_run8(Bm, (long)(n0 + nn) * p.bn + (k0 + k8), 1, valid);
+        } else {
+            const int k = tid >> 3, n8 = (tid & 7) * 8;
+            const int valid = (k0 + k < p.K) ? min(8, p.N - (n0 + n8)) : 0;
+            *reinterpret_cast<bf16x8_t*>(Bs + k * ROWT + n8 * 2) = load_run8(Bm, (long)(k0 + k) * p.bk + (long)(n0 + n8) * p.bn, p.bn, valid);
+        }
+        __syncthreads();
+        bf16x8_t a[2], b[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            if (a_row) a[i] = *reinterpret_cast<const bf16x8_t*>(As + (wm + i * 16 + n) * ROWS + g * 16);
+            else a[i] = tr8(As + (8 * g + q) * ROWT + (wm + i * 16 + 4 * pq) * 2, As + (8 * g + 4 + q) * ROWT + (wm + i * 16 + 4 * pq) * 2);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            if (b_row) b[j] = *reinterpret_cast<const bf16x8_t*>(Bs + (wn + j * 16 + n) * ROWS + g * 16);
+            else b[j] = tr8(Bs + (8 * g + q) * ROWT + (wn + j * 16 + 4 * pq) * 2, Bs + (8 * g + 4 + q) * ROWT + (wn + j * 16 + 4 * pq) * 2);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = m0 + wm + i * 16 + g * 4 + r, col = n0 + wn + j * 16 + n;
+                if (row < p.M && col < p.N) C[(long)row * p.cm + (long)col * p.cn] = from_f32<TC>(p.alpha * acc[i][j][r]);
+            }
+}
+
+template <typename T> struct is_bf16 { static constexpr bool value = false; };
+template <> struct is_bf16<bf16_t> { static constexpr bool value = true; };
+
 template <typename TA, typename TB, typename TC>
 int launch_gemm(const GemmP& p, int nbatch, hipStream_t st) {
     dim3 grid(cdiv(p.N, GT), cdiv(p.M, GT), nbatch);
-    hipLaunchKernelGGL((bgemm_kernel<TA, TB, TC>), grid, dim3(256), 0, st, p);
+    // bf16 tensors (qkv / out / dqkv in bench mode) -> bf16 matrix cores; the all-f32 parity mode keeps the exact f32 MFMA
+    if (is_bf16<TA>::value || is_bf16<TB>::value || is_bf16<TC>::value)
+        hipLaunchKernelGGL((bgemm_bf16_kernel<TA, TB, TC>), grid, dim3(256), 0, st, p);
+    else
+        hipLaunchKernelGGL((bgemm_kernel<TA, TB, TC>), grid, dim3(256), 0, st, p);
     LAUNCH_RET();
     return 0;
 }

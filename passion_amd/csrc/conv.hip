@@ -162,7 +162,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvK p) {
         if (DG) {
             src = reinterpret_cast<const TI*>(p.dy) + (long)b * Sd * Sh * Sw * C;
         } else {
-            src = reinterpret_cast<const TI*>(p.seg[sg].x) + (long)b * p.seg[sg].bstride;
+            src = reinterpret_cast<const TI*>(p.seg[sg].x) + (long)p.seg[sg].bsrc(b) * p.seg[sg].bstride;
             stats = p.seg[sg].stats;
             if (p.seg[sg].mask) mval = p.seg[sg].mask[(long)b * p.seg[sg].mask_ld + p.seg[sg].mask_col] ? 1.f : 0.f;
         }
@@ -170,7 +170,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvK p) {
         for (int c0 = 0; c0 < C; c0 += CK) {
             const int ck = min(CK, C - c0);
             __syncthreads();
-            stage_tile<TI, KS, S, DG>(lds, src, 0, C, c0, ck, stats, mval, p.slope, p.pad_mode, b, o0d, o0h, o0w,
+            stage_tile<TI, KS, S, DG>(lds, src, 0, C, c0, ck, stats, mval, p.slope, p.pad_mode, DG ? b : p.seg[sg].bsrc(b), o0d, o0h, o0w,
                                       Sd, Sh, Sw, tid);
             __syncthreads();
             for (int ad = 0; ad < NOPT; ++ad) {
@@ -230,13 +230,14 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvK p) {
 template <typename T>
 __global__ void in_bwd_finish_kernel(T* __restrict__ dx, const T* __restrict__ x, const float* __restrict__ stats,
                                      const float* __restrict__ sums, const uint8_t* mask, int mask_col, int mask_ld,
-                                     long V, int C, long bstride, int Cin_tot, int cbase) {
+                                     long V, int C, long bstride, int Cin_tot, int cbase, int bmod) {
     const int b = blockIdx.y;
     const long nvec = V * C / 4;
     const float invV = 1.0f / (float)V;
     const bool present = mask ? (mask[(long)b * mask_ld + mask_col] != 0) : true;
+    const int bs = bmod > 0 ? b % bmod : b;       // x / stats sample (dx and the sums are per virtual sample b)
     T* dxb = dx + (long)b * bstride;
-    const T* xb = x + (long)b * bstride;
+    const T* xb = x + (long)bs * bstride;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (long)gridDim.x * blockDim.x) {
         const int c = (int)((i * 4) % C);
         f32x4 g = load4(dxb + i * 4);
@@ -246,7 +247,7 @@ __global__ void in_bwd_finish_kernel(T* __restrict__ dx, const T* __restrict__ x
             f32x4 xv = load4(xb + i * 4);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const float mean = stats[((long)b * C + c + j) * 2 + 0], rstd = stats[((long)b * C + c + j) * 2 + 1];
+                const float mean = stats[((long)bs * C + c + j) * 2 + 0], rstd = stats[((long)bs * C + c + j) * 2 + 1];
                 const float m1 = sums[((long)b * Cin_tot + cbase + c + j) * 2 + 0] * invV;
                 const float m2 = sums[((long)b * Cin_tot + cbase + c + j) * 2 + 1] * invV;
                 const float xh = (xv[j] - mean) * rstd;
@@ -330,8 +331,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(ConvK p, float* __restr
         if (sd.mask) mval = sd.mask[(long)b * sd.mask_ld + sd.mask_col] ? 1.f : 0.f;
         if (mval == 0.f && !bias_block) continue;  // absent modality: no weight gradient from this brick
         __syncthreads();
-        const TX* src = reinterpret_cast<const TX*>(sd.x) + (long)b * sd.bstride;
-        stage_tile<TX, KS, S, false>(lx, src, 0, sd.C, c0, ck, sd.stats, mval, p.slope, p.pad_mode, b, o0d, o0h, o0w,
+        const TX* src = reinterpret_cast<const TX*>(sd.x) + (long)sd.bsrc(b) * sd.bstride;
+        stage_tile<TX, KS, S, false>(lx, src, 0, sd.C, c0, ck, sd.stats, mval, p.slope, p.pad_mode, sd.bsrc(b), o0d, o0h, o0w,
                                      p.Di, p.Hi, p.Wi, tid);
         // dY brick [vox][MC] (zero outside the volume / beyond Cout)
         const TY* dy = reinterpret_cast<const TY*>(p.dy) + (long)b * p.Do * p.Ho * p.Wo * p.Cout;
@@ -460,10 +461,10 @@ int fill_params(const passion_conv_desc_t* d, ConvK& k) {
         if (s < d->nseg) {
             const passion_seg_t& i = d->seg[s];
             o.x = i.x; o.stats = i.stats; o.mask = i.mask; o.dx = i.dx; o.bstride = i.bstride; o.C = i.C;
-            o.mask_col = i.mask_col; o.mask_ld = i.mask_ld; o.cbase = cb;
+            o.mask_col = i.mask_col; o.mask_ld = i.mask_ld; o.cbase = cb; o.bmod = i.bmod;
             cb += i.C;
         } else {
-            o = SegD{nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0, 0};
+            o = SegD{nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0, 0, 0};
         }
     }
     k.Cin = cb;
@@ -506,9 +507,15 @@ struct WgPlan { bool bf16; int MT, chunks, gx, gy; };
 WgPlan plan_wgrad(const ConvK& k, const passion_conv_desc_t* d) {
     WgPlan w;
     w.bf16 = d->x_dtype == PASSION_BF16 && d->y_dtype == PASSION_BF16 && bf16_eligible(k, false) && !g_passion_force_f32_mfma;
-    const int CK = w.bf16 ? 8 : (d->ksize == 1 ? 16 : (d->stride == 2 ? 4 : 8));
+    const int CK = w.bf16 ? wgrad_bf16_chunk(k, d->ksize, d->stride) : (d->ksize == 1 ? 16 : (d->stride == 2 ? 4 : 8));
     w.chunks = 0;
-    for (int s = 0; s < k.nseg; ++s) w.chunks += (k.seg[s].C + CK - 1) / CK;
+    if (w.bf16) {   // chunks run over the 8-channel blocks of the whole virtual concat
+        int k8 = 0;
+        for (int s = 0; s < k.nseg; ++s) k8 += (k.seg[s].C + 7) / 8;
+        w.chunks = (k8 + CK / 8 - 1) / (CK / 8);
+    } else {
+        for (int s = 0; s < k.nseg; ++s) w.chunks += (k.seg[s].C + CK - 1) / CK;
+    }
     const int mtiles = pad16(k.Cout) / 16;
     w.MT = w.bf16 ? ((mtiles % 2 == 0) ? 2 : 1) : ((mtiles % 2 == 0 && d->stride == 1) ? 2 : 1);
     w.gy = w.chunks * (mtiles / w.MT);
@@ -688,11 +695,11 @@ extern "C" int passion_conv3d_bwd(const passion_conv_desc_t* d, const float* pac
         dim3 grid((unsigned)hmin((nvec + 255) / 256, 2048), k.B);
         if (d->x_dtype == PASSION_F32)
             hipLaunchKernelGGL(in_bwd_finish_kernel<float>, grid, dim3(256), 0, st, (float*)sg.dx, (const float*)sg.x,
-                               sg.stats, sums, sg.mask, sg.mask_col, sg.mask_ld, V, sg.C, sg.bstride, k.Cin, sg.cbase);
+                               sg.stats, sums, sg.mask, sg.mask_col, sg.mask_ld, V, sg.C, sg.bstride, k.Cin, sg.cbase, sg.bmod);
         else
             hipLaunchKernelGGL(in_bwd_finish_kernel<bf16_t>, grid, dim3(256), 0, st, (bf16_t*)sg.dx,
                                (const bf16_t*)sg.x, sg.stats, sums, sg.mask, sg.mask_col, sg.mask_ld, V, sg.C,
-                               sg.bstride, k.Cin, sg.cbase);
+                               sg.bstride, k.Cin, sg.cbase, sg.bmod);
         LAUNCH_RET();
     }
     return 0;

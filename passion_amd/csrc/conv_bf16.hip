@@ -14,6 +14,7 @@
 // The accumulator layout equals the f32 kernel's, so the epilogues (conv_common.h) are shared.
 #include "conv_common.h"
 
+namespace pconv { extern int g_conv_merge, g_wgrad_wide; }
 using namespace pconv;
 
 namespace {
@@ -49,15 +50,15 @@ __device__ __forceinline__ bf16x8 zero8() {
     return z;
 }
 
-// Stage channels [c0, c0+ck) of one brick into lds as [voxel][CKB] bf16 (zero beyond ck).
+// Stage one brick into lds as [voxel][CKB] bf16.  Thread t fills 8-channel block j = t % NC8 of every voxel it
+// visits; the caller says where that block comes from (tensor of the virtual concat, channel offset cb, how many
+// of the 8 channels exist, its InstanceNorm statistics) -- nch = 0 stages zeros (absent modality / past the end).
 template <int KS, int S, bool DG, int CKB>
-__device__ __forceinline__ void stage_tile_b(char* lds, const bf16_t* __restrict__ src, int C, int c0, int ck,
+__device__ __forceinline__ void stage_tile_b(char* lds, const bf16_t* __restrict__ src, int C, int cb, int nch,
                                              const float* __restrict__ stats, float slope, int pad_mode, int b,
                                              int o0d, int o0h, int o0w, int Sd, int Sh, int Sw, int tid) {
     using G = GeoB<KS, S, DG, CKB>;
     const int j = tid % G::NC8;                 // 8-channel block of this thread (constant: NC8 divides 256)
-    const int cb = c0 + j * 8;
-    const int nch = min(8, max(0, min(ck - j * 8, C - cb)));
     const bool has_norm = (stats != nullptr);
     float mean[8], rstd[8];
 #pragma unroll
@@ -139,7 +140,8 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(ConvK p) {
 
     const int Od = DG ? p.Di : p.Do, Oh = DG ? p.Hi : p.Ho, Ow = DG ? p.Wi : p.Wo;
     const int Sd = DG ? p.Do : p.Di, Sh = DG ? p.Ho : p.Hi, Sw = DG ? p.Wo : p.Wi;
-    const int K8 = DG ? pad8(p.Cout) / 8 : pad8(p.Cin) / 8;       // 8-channel blocks along K in the packed image
+    int K8 = pad8(p.Cout) / 8;                                      // 8-channel blocks along K in the packed image
+    if (!DG) { K8 = 0; for (int s2 = 0; s2 < p.nseg; ++s2) K8 += (p.seg[s2].C + 7) / 8; }
     const bf16x8* wp = reinterpret_cast<const bf16x8*>(p.wpack);
 
     f32x4 acc[MT][4];
@@ -167,8 +169,16 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(ConvK p) {
     // list of this brick's mirror tap combos, in a fixed order (ballot + prefix count over waves 0 and 1)
     __shared__ unsigned short mlist[128];
     __shared__ int mcnt[4];
+    __shared__ unsigned char mtab[3][5][8];   // [axis d,h,w][option][local coordinate] = tap | valid << 2 | brick position << 3
     int nmirror = 0;
     if (DG && KS == 3 && any_mirror) {       // workgroup-uniform
+        if (tid < 3 * 5 * 8) {
+            const int ax = tid / 40, a = (tid / 8) % 5, il = tid % 8;
+            const int i0 = ax == 0 ? o0d : (ax == 1 ? o0h : o0w), Sn = ax == 0 ? Od : (ax == 1 ? Oh : Ow);
+            int t, pos; bool v;
+            axis_tap<KS, G::HALO, DG, S>(a, il, i0, Sn, p.hi_t[ax], p.hi_u[ax], t, pos, v);
+            mtab[ax][a][il] = (unsigned char)((t & 3) | (v ? 4 : 0) | ((pos & 31) << 3));
+        }
         bool f = false;
         int code = 0;
         if (tid < 125) {
@@ -186,30 +196,46 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(ConvK p) {
         nmirror = mcnt[0] + mcnt[1];
     }
 
-    const int nseg = DG ? 1 : p.nseg;
-    for (int sg = 0; sg < nseg; ++sg) {
-        const int C = DG ? p.Cout : p.seg[sg].C;
-        const int cbase = DG ? 0 : p.seg[sg].cbase;
-        const bf16_t* src;
-        const float* stats = nullptr;
-        if (DG) {
-            src = reinterpret_cast<const bf16_t*>(p.dy) + (long)b * Sd * Sh * Sw * C;
-        } else {
-            src = reinterpret_cast<const bf16_t*>(p.seg[sg].x) + (long)b * p.seg[sg].bstride;
-            stats = p.seg[sg].stats;
-            if (p.seg[sg].mask && !p.seg[sg].mask[(long)b * p.seg[sg].mask_ld + p.seg[sg].mask_col]) continue;
+    // K runs over the 8-channel blocks of the virtual concat (dgrad: of dY); a chunk = NC8 consecutive blocks, which
+    // may come from different tensors (decoder skip concat [8|8], the four modality maps of a fusion conv [8|8|8|8])
+    auto locate = [&](int gb, int& sg, int& c0) -> bool {      // global block -> (segment, channel offset); false: past the end
+        if (DG) { sg = 0; c0 = gb * 8; return gb < K8; }
+        for (int s2 = 0; s2 < p.nseg; ++s2) {
+            const int nb = (p.seg[s2].C + 7) / 8;
+            if (gb < nb) { sg = s2; c0 = gb * 8; return true; }
+            gb -= nb;
         }
-        for (int c0 = 0; c0 < C; c0 += CKB) {
-            const int ck = min(CKB, C - c0);
-            const int nblk = (ck + 7) / 8;               // valid 8-channel blocks in this chunk
-            const int cb8 = (cbase + c0) / 8;
+        sg = 0; c0 = 0;
+        return false;
+    };
+    {
+        for (int gb0 = 0; gb0 < K8; gb0 += G::NC8) {
+            const int cb8 = gb0;
+            unsigned vmask = 0;                      // which of this chunk's blocks exist and are present
+#pragma unroll
+            for (int j2 = 0; j2 < G::NC8; ++j2) {
+                int sg2, c02;
+                bool ok = locate(gb0 + j2, sg2, c02);
+                if (ok && !DG && p.seg[sg2].mask && !p.seg[sg2].mask[(long)b * p.seg[sg2].mask_ld + p.seg[sg2].mask_col]) ok = false;
+                vmask |= (ok ? 1u : 0u) << j2;
+            }
+            if (vmask == 0) continue;               // e.g. an absent modality: contributes exactly zero
+            // this thread's source block
+            int sgj, c0j;
+            const int jj = tid % G::NC8;
+            const bool okj = locate(gb0 + jj, sgj, c0j) && ((vmask >> jj) & 1u);
+            const int Cj = DG ? p.Cout : p.seg[sgj].C;
+            const bf16_t* srcj = DG ? reinterpret_cast<const bf16_t*>(p.dy) + (long)b * Sd * Sh * Sw * Cj
+                                    : reinterpret_cast<const bf16_t*>(p.seg[sgj].x) + (long)p.seg[sgj].bsrc(b) * p.seg[sgj].bstride;
+            const float* statsj = DG ? nullptr : p.seg[sgj].stats;
+            const int nchj = okj ? min(8, Cj - c0j) : 0;
             __syncthreads();
-            stage_tile_b<KS, S, DG, CKB>(lds, src, C, c0, ck, stats, p.slope, p.pad_mode, b, o0d, o0h, o0w, Sd, Sh, Sw, tid);
+            stage_tile_b<KS, S, DG, CKB>(lds, srcj, Cj, c0j, nchj, statsj, p.slope, p.pad_mode, DG ? b : p.seg[sgj].bsrc(b), o0d, o0h, o0w, Sd, Sh, Sw, tid);
             if (WLDS) {
                 for (int v = tid; v < WV; v += 256) {
                     const int row = v % (MT * 16), gg = (v / (MT * 16)) % 4, s = v / (MT * 16 * 4);
                     const int q = 4 * s + gg, tap = q / G::NC8, blk = q % G::NC8;
-                    const bool ok = (q < G::Q) && (blk < nblk);
+                    const bool ok = (q < G::Q) && ((vmask >> blk) & 1u);
                     wl[v] = ok ? wp[((long)tap * K8 + cb8 + blk) * p.Mpad + (mg * MT) * 16 + row] : zero8();
                 }
             }
@@ -219,7 +245,7 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(ConvK p) {
             auto decode = [&](int s, int& toff, long& wrow) -> bool {
                 const int q = 4 * s + g;
                 const int tap = q / G::NC8, blk = q % G::NC8;
-                const bool v = (q < G::Q) && (blk < nblk);
+                const bool v = (q < G::Q) && ((vmask >> blk) & 1u);
                 int td = 0, th = 0, tw = 0;
                 if (KS == 3) { td = tap / 9; th = (tap / 3) % 3; tw = tap % 3; }
                 if (DG && KS == 3) { td = 2 - td; th = 2 - th; tw = 2 - tw; }   // gather form: voxel i reads u = i + 1 - t
@@ -274,29 +300,32 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(ConvK p) {
             // ---- mirror taps (adjoint of reflect padding); only bricks touching planes 1 / Sin-2.  The brick's
             // list of (tap, block) pairs is packed four per MFMA step exactly like the regular taps.
             if (nmirror > 0) {
-                const int P = nmirror * nblk;
+                const int P = nmirror * G::NC8;
                 // decode pair 4*s2 + g -> (mirror combo, 8-channel block): weight fragment, per-voxel LDS offsets, validity
                 auto prep = [&](int s2, bf16x8 (&am)[MT], int (&mpos)[4], bool (&mval)[4]) {
                     const int pr = s2 * 4 + g;
-                    const bool pv = pr < P;
-                    const int ent = pv ? pr / nblk : 0, blk = pv ? pr % nblk : 0;
-                    const int code = mlist[ent];
-                    const int ad = code & 7, ah = (code >> 3) & 7, aw = (code >> 6) & 7;
-                    int tdp, posd, twp, posw; bool vd, vw;
-                    axis_tap<KS, G::HALO, DG, S>(ad, ld_, o0d, Od, p.hi_t[0], p.hi_u[0], tdp, posd, vd);
-                    axis_tap<KS, G::HALO, DG, S>(aw, lw, o0w, Ow, p.hi_t[2], p.hi_u[2], twp, posw, vw);
+                    const int ent = pr / G::NC8, blk = pr % G::NC8;
+                    const bool pv = (ent < nmirror) && ((vmask >> blk) & 1u);
+                    const int code = mlist[pv ? ent : 0];
+                    // per-axis (tap, brick position, valid) come from the tables built once per workgroup
+                    const int cd = mtab[0][code & 7][ld_], cw = mtab[2][(code >> 6) & 7][lw];
+                    const int ah = (code >> 3) & 7;
                     int thp = 0;
 #pragma unroll
                     for (int nt = 0; nt < 4; ++nt) {
-                        int ph; bool vh;
-                        axis_tap<KS, G::HALO, DG, S>(ah, lh[nt], o0h, Oh, p.hi_t[1], p.hi_u[1], thp, ph, vh);
-                        mval[nt] = pv && vd && vh && vw;
-                        mpos[nt] = mval[nt] ? ((posd * G::IH + ph) * G::IW + posw) * G::VS + blk * 16 : 0;
+                        const int ch = mtab[1][ah][lh[nt]];
+                        thp = ch & 3;
+                        mval[nt] = pv && (cd & 4) && (ch & 4) && (cw & 4);
+                        mpos[nt] = mval[nt] ? (((cd >> 3) * G::IH + (ch >> 3)) * G::IW + (cw >> 3)) * G::VS + blk * 16 : 0;
                     }
-                    const int tap = (tdp * KS + thp) * KS + twp;
+                    const int tap = ((cd & 3) * KS + thp) * KS + (cw & 3);
+                    // the mirror terms reuse the weights of regular taps: with WLDS they are already in LDS
+                    // (pair q = tap * NC8 + blk sits at wl[(q * MT + mt) * 16 + row])
 #pragma unroll
-                    for (int mt = 0; mt < MT; ++mt)
-                        am[mt] = pv ? wp[((long)tap * K8 + cb8 + blk) * p.Mpad + (mg * MT + mt) * 16 + n] : zero8();
+                    for (int mt = 0; mt < MT; ++mt) {
+                        if (WLDS) am[mt] = pv ? wl[((tap * G::NC8 + blk) * MT + mt) * 16 + n] : zero8();
+                        else am[mt] = pv ? wp[((long)tap * K8 + cb8 + blk) * p.Mpad + (mg * MT + mt) * 16 + n] : zero8();
+                    }
                 };
                 bf16x8 am[MT]; int mpos[4]; bool mval[4];
                 prep(0, am, mpos, mval);
@@ -347,13 +376,15 @@ __device__ __forceinline__ bf16x8 tr_read8(const char* p0, const char* p1) {
     return __builtin_bit_cast(bf16x8, v);
 }
 
-template <int KS, int S, int MT>
+template <int KS, int S, int MT, int CKW>
 __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(ConvK p, float* __restrict__ dW, float* __restrict__ dbias,
                                                               int tiles_per_b) {
-    constexpr int CKW = 8;
     using G = GeoB<KS, S, false, CKW>;
+    constexpr int NC8 = CKW / 8;
     constexpr int NTAP = G::NTAP;
-    constexpr int NTILES = (NTAP + 1) / 2;            // 16 columns = 2 taps x 8 channels
+    // 16 columns = 2 taps x 8 channels (CKW 8) or 1 tap x 16 channels (CKW 16; the two 8-channel blocks of a
+    // chunk may belong to different tensors of the virtual concat, e.g. the decoder's [upsampled | skip] pair)
+    constexpr int NTILES = (CKW == 8) ? (NTAP + 1) / 2 : NTAP;
     constexpr int KSPLIT = (NTILES >= 4) ? 1 : 4;     // few column tiles: waves split the voxels instead
     constexpr int NTW = (KSPLIT == 1) ? (NTILES + 3) / 4 : NTILES;
     constexpr int MC = MT * 16;
@@ -365,25 +396,33 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(ConvK p, float* __
     const int q = n >> 2, pq = n & 3;
     const int mgroups = p.Mpad / 16 / MT;
     const int mg = blockIdx.y % mgroups;
-    int chunk = blockIdx.y / mgroups;
-    int sg = 0, c0 = 0;
-    for (int s2 = 0; s2 < p.nseg; ++s2) {
-        const int nch = (p.seg[s2].C + CKW - 1) / CKW;
-        if (chunk < nch) { sg = s2; c0 = chunk * CKW; break; }
-        chunk -= nch;
-    }
-    const SegD& sd = p.seg[sg];
-    const int ck = min(CKW, sd.C - c0);
+    const int gb0 = (blockIdx.y / mgroups) * NC8;     // first global 8-channel block of this workgroup's chunk
+    auto locate = [&](int gb, int& sg, int& c0) -> bool {
+        for (int s2 = 0; s2 < p.nseg; ++s2) {
+            const int nb = (p.seg[s2].C + 7) / 8;
+            if (gb < nb) { sg = s2; c0 = gb * 8; return true; }
+            gb -= nb;
+        }
+        sg = 0; c0 = 0;
+        return false;
+    };
+    // this thread stages block jj of every voxel it visits
+    const int jj = tid % NC8;
+    int sgj, c0j;
+    const bool existj = locate(gb0 + jj, sgj, c0j);
+    const SegD& sd = p.seg[sgj];
+    const int nch = existj ? min(8, sd.C - c0j) : 0;
+    const bool has_norm = existj && (sd.stats != nullptr);
 
     // per column tile of this wave: byte offset of this lane's (tap, channel quad) inside a voxel neighbourhood
     int boff[NTW];
 #pragma unroll
     for (int j = 0; j < NTW; ++j) {
         const int nt = (KSPLIT == 1) ? wv + 4 * j : j;
-        int tap = 2 * nt + (pq >> 1);
+        int tap = (CKW == 8) ? 2 * nt + (pq >> 1) : nt;
         if (tap >= NTAP) tap = 0;                      // padded column: reads finite data, dropped at the flush
         const int tw = tap % KS, th = (tap / KS) % KS, td = tap / (KS * KS);
-        boff[j] = ((td * G::IH + th) * G::IW + tw) * G::VS + (pq & 1) * 8;
+        boff[j] = ((td * G::IH + th) * G::IW + tw) * G::VS + ((CKW == 8) ? (pq & 1) : pq) * 8;
     }
     f32x4 acc[MT][NTW], accb[MT];
 #pragma unroll
@@ -401,11 +440,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(ConvK p, float* __
     // Software pipeline over this workgroup's bricks: the global loads of brick t+1 (raw activations + dY) are issued
     // into registers before the MFMA loop of brick t and only normalised / written to LDS after it, so the HBM
     // round trip hides under the matrix work instead of serialising with it.
-    constexpr int AR = (G::VOL + 255) / 256;   // activation voxels per thread (one 16-byte block each)
-    constexpr int DR = MC / 8;                 // dY 16-byte blocks per thread
+    constexpr int AR = (G::VOL * NC8 + 255) / 256;   // 16-byte activation blocks per thread
+    constexpr int DR = MC / 8;                       // dY 16-byte blocks per thread
     struct Regs { bf16x8 a[AR]; bf16x8 d[DR]; unsigned ok; int b; bool present; };
-    const int nch = min(8, ck);
-    const bool has_norm = (sd.stats != nullptr);
     auto fetch = [&](int tile, Regs& R) {
         int t2 = tile;
         const int tw_ = t2 % p.tilesW; t2 /= p.tilesW;
@@ -414,12 +451,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(ConvK p, float* __
         const int b = t2;
         const int o0d = td_ * TD, o0h = th_ * TH, o0w = tw_ * TW;
         R.b = b;
-        R.present = sd.mask ? (sd.mask[(long)b * sd.mask_ld + sd.mask_col] != 0) : true;
+        R.present = existj && (sd.mask ? (sd.mask[(long)b * sd.mask_ld + sd.mask_col] != 0) : true);
         R.ok = 0u;
-        const bf16_t* src = reinterpret_cast<const bf16_t*>(sd.x) + (long)b * sd.bstride;
+        const bf16_t* src = reinterpret_cast<const bf16_t*>(sd.x) + (long)sd.bsrc(b) * sd.bstride;
 #pragma unroll
         for (int r = 0; r < AR; ++r) {
-            const int tv = tid + 256 * r;
+            const int tv = (tid + 256 * r) / NC8;
             R.a[r] = zero8();
             if (tv >= G::VOL || !R.present) continue;
             const int zw = tv % G::IW, zh = (tv / G::IW) % G::IH, zd = tv / (G::IW * G::IH);
@@ -432,7 +469,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(ConvK p, float* __
                 ok = (s_d >= 0 && s_d < p.Di && s_h >= 0 && s_h < p.Hi && s_w >= 0 && s_w < p.Wi);
             }
             if (!ok) continue;
-            const bf16_t* ptr = src + (((long)s_d * p.Hi + s_h) * p.Wi + s_w) * sd.C + c0;
+            const bf16_t* ptr = src + (((long)s_d * p.Hi + s_h) * p.Wi + s_w) * sd.C + c0j;
             if (nch == 8) {
                 R.a[r] = *reinterpret_cast<const bf16x8*>(ptr);
             } else {
@@ -467,13 +504,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(ConvK p, float* __
         for (int c = 0; c < 8; ++c) {
             mean[c] = 0.f; rstd[c] = 1.f;
             if (has_norm && c < nch) {
-                mean[c] = sd.stats[((long)R.b * sd.C + c0 + c) * 2 + 0];
-                rstd[c] = sd.stats[((long)R.b * sd.C + c0 + c) * 2 + 1];
+                mean[c] = sd.stats[((long)sd.bsrc(R.b) * sd.C + c0j + c) * 2 + 0];
+                rstd[c] = sd.stats[((long)sd.bsrc(R.b) * sd.C + c0j + c) * 2 + 1];
             }
         }
 #pragma unroll
         for (int r = 0; r < AR; ++r) {
-            const int tv = tid + 256 * r;
+            const int tv = (tid + 256 * r) / NC8;
             if (tv >= G::VOL) continue;
             bf16x8 o = zero8();
             if ((R.ok >> r) & 1u) {
@@ -487,7 +524,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(ConvK p, float* __
                     o[c] = (__bf16)((c < nch) ? t : 0.f);
                 }
             }
-            *reinterpret_cast<bf16x8*>(lact + tv * G::VS) = o;
+            *reinterpret_cast<bf16x8*>(lact + tv * G::VS + jj * 16) = o;
         }
 #pragma unroll
         for (int r = 0; r < DR; ++r) {
@@ -505,7 +542,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(ConvK p, float* __
         __syncthreads();
         commit(R);
         __syncthreads();
-        const bool work = R.present || bias_block;
+        const bool work = true;   // absent blocks were staged as zeros: their columns flush zeros
         const int next = tile + gridDim.x;
         const bool have_n = next < total_tiles;
         Regs Rn;
@@ -570,9 +607,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(ConvK p, float* __
 #pragma unroll
         for (int j = 0; j < NTW; ++j) {
             const int nt = (KSPLIT == 1) ? wv + 4 * j : j;
-            const int tap = 2 * nt + (n >> 3), c = n & 7;
-            if (nt >= NTILES || tap >= NTAP || c >= ck) continue;
-            const long ci = sd.cbase + c0 + c;
+            const int tap = (CKW == 8) ? 2 * nt + (n >> 3) : nt;
+            const int blk = (CKW == 8) ? 0 : (n >> 3), c = n & 7;
+            int sgb, c0b;
+            if (nt >= NTILES || tap >= NTAP || !locate(gb0 + blk, sgb, c0b) || c0b + c >= p.seg[sgb].C) continue;
+            const long ci = p.seg[sgb].cbase + c0b + c;
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -594,12 +633,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(ConvK p, float* __
     }
 }
 
-template <int KS, int S>
+template <int KS, int S, int CKW>
 int launch_wgrad_b(ConvK& k, int MT, int gx, int gy, float* dW, float* db, hipStream_t st) {
     const int tiles_per_b = k.tilesD * k.tilesH * k.tilesW;
     dim3 grid(gx, gy);
-    if (MT == 2) hipLaunchKernelGGL((conv_wgrad_bf16_kernel<KS, S, 2>), grid, dim3(256), 0, st, k, dW, db, tiles_per_b);
-    else hipLaunchKernelGGL((conv_wgrad_bf16_kernel<KS, S, 1>), grid, dim3(256), 0, st, k, dW, db, tiles_per_b);
+    if (MT == 2) hipLaunchKernelGGL((conv_wgrad_bf16_kernel<KS, S, 2, CKW>), grid, dim3(256), 0, st, k, dW, db, tiles_per_b);
+    else hipLaunchKernelGGL((conv_wgrad_bf16_kernel<KS, S, 1, CKW>), grid, dim3(256), 0, st, k, dW, db, tiles_per_b);
     LAUNCH_RET();
     return 0;
 }
@@ -656,21 +695,32 @@ int launch_mt(ConvK& k, int mtiles, hipStream_t st) {
     return launch_one<KS, S, 1, MODE, CKB>(k, grid, st);
 }
 
+using pconv::g_conv_merge;
+
+template <int KS, int S, int MODE>
+int launch_ckb(ConvK& k, int ktot, int mtiles, hipStream_t st) {
+    // chunk width = as much of K as exists, up to 32 channels (one brick staging + one barrier pair per chunk)
+    if (ktot >= 32) return launch_mt<KS, S, MODE, 32>(k, mtiles, st);
+    if (ktot >= 16 && g_conv_merge) return launch_mt<KS, S, MODE, 16>(k, mtiles, st);
+    return launch_mt<KS, S, MODE, 8>(k, mtiles, st);
+}
+
 template <int MODE>
-int launch_geo(ConvK& k, int ksize, int stride, int cmax, int mtiles, hipStream_t st) {
-    const bool big = cmax >= 32;
-    if (ksize == 1) return big ? launch_mt<1, 1, MODE, 32>(k, mtiles, st) : launch_mt<1, 1, MODE, 8>(k, mtiles, st);
+int launch_geo(ConvK& k, int ksize, int stride, int ktot, int mtiles, hipStream_t st) {
+    if (ksize == 1) return launch_ckb<1, 1, MODE>(k, ktot, mtiles, st);
     if (stride == 2) {
         // forward stride-2 brick is 9x17x17 voxels: only the 8-channel chunk fits LDS; dgrad stages a zero-stuffed 6x10x10 brick
         if constexpr (MODE == 0) return launch_mt<3, 2, MODE, 8>(k, mtiles, st);
-        else return big ? launch_mt<3, 2, MODE, 32>(k, mtiles, st) : launch_mt<3, 2, MODE, 8>(k, mtiles, st);
+        else return launch_ckb<3, 2, MODE>(k, ktot, mtiles, st);
     }
-    return big ? launch_mt<3, 1, MODE, 32>(k, mtiles, st) : launch_mt<3, 1, MODE, 8>(k, mtiles, st);
+    return launch_ckb<3, 1, MODE>(k, ktot, mtiles, st);
 }
 
 }  // namespace
 
 namespace pconv {
+
+extern int g_conv_merge, g_wgrad_wide;
 
 long bf16_pack_elems(int Cin, int Cout, int ntap) {
     return (long)ntap * pad8(Cin) * pad16(Cout) + (long)ntap * pad8(Cout) * pad16(Cin);
@@ -702,7 +752,13 @@ int launch_conv_bf16(ConvK& k, int ksize, int stride, bool dgrad, const void* pa
         k.Mpad = pad16(k.Cin);
         k.wpack = reinterpret_cast<const bf16_t*>(packed_bf16) + (long)ntap * pad8(k.Cin) * pad16(k.Cout);
     } else {
-        for (int s = 0; s < k.nseg; ++s) cmax = k.seg[s].C > cmax ? k.seg[s].C : cmax;
+        // chunk width: measured on MI355X, merging several 8-channel tensors into one 16/32-channel chunk LOSES
+        // (3x the LDS per workgroup -> fewer resident workgroups -> less latency hiding: [8|8]->8 @128^3 86 -> 129 us),
+        // so the width follows the widest single tensor; PASSION_CONV_MERGE=1 switches to the total for A/B runs
+        for (int s = 0; s < k.nseg; ++s) {
+            if (g_conv_merge) cmax += pad8(k.seg[s].C);
+            else cmax = k.seg[s].C > cmax ? k.seg[s].C : cmax;
+        }
         k.Mpad = pad16(k.Cout);
         k.wpack = packed_bf16;
     }
@@ -710,11 +766,20 @@ int launch_conv_bf16(ConvK& k, int ksize, int stride, bool dgrad, const void* pa
     return dgrad ? launch_geo<1>(k, ksize, stride, cmax, mtiles, st) : launch_geo<0>(k, ksize, stride, cmax, mtiles, st);
 }
 
+int g_conv_merge = 0, g_wgrad_wide = 0;   // A/B switches (environment: PASSION_CONV_MERGE, PASSION_WGRAD_WIDE)
+
+int wgrad_bf16_chunk(const ConvK& k, int ksize, int stride) {
+    int ktot = 0;
+    for (int s = 0; s < k.nseg; ++s) ktot += pad8(k.seg[s].C);
+    return (g_wgrad_wide && ktot >= 16 && stride == 1) ? 16 : 8;     // stride-2 bricks (9x17x17) only fit LDS 8 channels at a time
+}
+
 int launch_wgrad_bf16(ConvK& k, int ksize, int stride, int MT, int gx, int gy, float* dW, float* db, hipStream_t st) {
     k.Mpad = pad16(k.Cout);
-    if (ksize == 1) return launch_wgrad_b<1, 1>(k, MT, gx, gy, dW, db, st);
-    if (stride == 1) return launch_wgrad_b<3, 1>(k, MT, gx, gy, dW, db, st);
-    return launch_wgrad_b<3, 2>(k, MT, gx, gy, dW, db, st);
+    const bool wide = wgrad_bf16_chunk(k, ksize, stride) == 16;
+    if (ksize == 1) return wide ? launch_wgrad_b<1, 1, 16>(k, MT, gx, gy, dW, db, st) : launch_wgrad_b<1, 1, 8>(k, MT, gx, gy, dW, db, st);
+    if (stride == 1) return wide ? launch_wgrad_b<3, 1, 16>(k, MT, gx, gy, dW, db, st) : launch_wgrad_b<3, 1, 8>(k, MT, gx, gy, dW, db, st);
+    return launch_wgrad_b<3, 2, 8>(k, MT, gx, gy, dW, db, st);
 }
 
 }  // namespace pconv

@@ -19,6 +19,9 @@ struct SegD {
     void* dx;
     long bstride;
     int C, mask_col, mask_ld, cbase;
+    int bmod;   // > 0: the tensor has only `bmod` samples and sample b reads x[b % bmod] (several masked passes over the same
+                // features batched into one launch); dx and the mask are still indexed by b
+    __host__ __device__ int bsrc(int b) const { return bmod > 0 ? b % bmod : b; }
 };
 
 struct ConvK {
@@ -47,6 +50,7 @@ struct ConvK;
 bool bf16_eligible(const ConvK& k, bool dgrad);
 int launch_conv_bf16(ConvK& k, int ksize, int stride, bool dgrad, const void* packed_bf16, hipStream_t st);
 int launch_wgrad_bf16(ConvK& k, int ksize, int stride, int MT, int gx, int gy, float* dWslab, float* dbslab, hipStream_t st);
+int wgrad_bf16_chunk(const ConvK& k, int ksize, int stride);
 
 // One axis of a tap entry.  a < KS: regular tap; a == KS: low-side mirror term; a == KS+1: high-side.
 // Forward conv of stride S reads padded coordinate o*S + t - 1; 'reflect' maps -1 -> 1 and Sin -> Sin-2, so
@@ -117,11 +121,11 @@ __device__ __forceinline__ void epilogue_dgrad(const ConvK& p, const f32x4 (&acc
             if (sd.stats) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    mean[j] = sd.stats[((long)b * sd.C + cl + j) * 2 + 0];
-                    rstd[j] = sd.stats[((long)b * sd.C + cl + j) * 2 + 1];
+                    mean[j] = sd.stats[((long)sd.bsrc(b) * sd.C + cl + j) * 2 + 0];
+                    rstd[j] = sd.stats[((long)sd.bsrc(b) * sd.C + cl + j) * 2 + 1];
                 }
             }
-            const TO* x = reinterpret_cast<const TO*>(sd.x) + (long)b * sd.bstride;
+            const TO* x = reinterpret_cast<const TO*>(sd.x) + (long)sd.bsrc(b) * sd.bstride;
             TO* dx = reinterpret_cast<TO*>(sd.dx) + (long)b * sd.bstride;
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) {
