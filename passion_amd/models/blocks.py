@@ -18,23 +18,28 @@ PAD = {"zeros": L.PAD_ZEROS, "reflect": L.PAD_REFLECT}
 
 class Feat:
     """A channels-last activation (B,D,H,W,C) plus its lazily computed InstanceNorm statistics and
-    an optional modality mask (mask tensor, column): consumers treat absent modalities as zeros."""
-    __slots__ = ("t", "_stats", "mask", "mask_col")
+    an optional modality mask (mask tensor, column): consumers treat absent modalities as zeros.
+    With `passes` > 1 the mask has passes*B rows and a consuming conv runs all the masked passes
+    (teacher + uni-modal students) over the same B samples in one launch (ops.SegIn.bmod).
+    `stats_out`: optional preallocated (B,C,2) slot the statistics are written into (one slice of the
+    statistics of a stacked buffer)."""
+    __slots__ = ("t", "_stats", "mask", "mask_col", "passes", "stats_out")
 
-    def __init__(self, t, mask=None, mask_col=0, _stats=None):
-        self.t, self.mask, self.mask_col = t, mask, mask_col
+    def __init__(self, t, mask=None, mask_col=0, _stats=None, passes=1, stats_out=None):
+        self.t, self.mask, self.mask_col, self.passes, self.stats_out = t, mask, mask_col, passes, stats_out
         self._stats = _stats if _stats is not None else [None]   # shared between masked views of one tensor
 
     def stats(self):
         if self._stats[0] is None:
-            self._stats[0] = ops.instnorm_stats(self.t.detach())
+            self._stats[0] = ops.instnorm_stats(self.t.detach(), out=self.stats_out)
         return self._stats[0]
 
-    def with_mask(self, mask, col):
-        return Feat(self.t, mask, col, self._stats)
+    def with_mask(self, mask, col, passes=1):
+        return Feat(self.t, mask, col, self._stats, passes, self.stats_out)
 
     def seg(self, norm=True):
-        return ops.SegIn(self.t, stats=self.stats() if norm else None, mask=self.mask, mask_col=self.mask_col)
+        return ops.SegIn(self.t, stats=self.stats() if norm else None, mask=self.mask, mask_col=self.mask_col,
+                         bmod=self.t.shape[0] if self.passes > 1 else 0)
 
     @property
     def dims(self):
@@ -52,7 +57,7 @@ def normalization(planes, norm="in"):
     raise ValueError(f"normalization type {norm} is not supported")
 
 
-def run_conv(conv, feats, norm, residual=None, out_dtype=None):
+def run_conv(conv, feats, norm, residual=None, out_dtype=None, out=None, stats_out=None):
     """Launch the fused conv for an nn.Conv3d parameter holder over the virtual concat of `feats`."""
     if not isinstance(feats, (list, tuple)):
         feats = [feats]
@@ -60,8 +65,8 @@ def run_conv(conv, feats, norm, residual=None, out_dtype=None):
     cache = conv.__dict__.setdefault("_passion_pack", {})
     y = ops.conv_block([f.seg(norm) for f in feats], conv.weight, conv.bias, D, H, W,
                        ksize=conv.kernel_size[0], stride=conv.stride[0], pad_mode=PAD[conv.padding_mode],
-                       residual=residual, out_dtype=out_dtype, pack_cache=cache)
-    return Feat(y)
+                       residual=residual, out_dtype=out_dtype, pack_cache=cache, out=out)
+    return Feat(y, stats_out=stats_out)
 
 
 class general_conv3d_prenorm(nn.Module):
@@ -77,8 +82,8 @@ class general_conv3d_prenorm(nn.Module):
         self.norm = normalization(out_ch, norm=norm)
         self.activation = nn.LeakyReLU(negative_slope=relufactor, inplace=True) if act_type == "lrelu" else nn.ReLU(inplace=True)
 
-    def forward(self, feats, residual=None):
-        return run_conv(self.conv, feats, norm=True, residual=residual)
+    def forward(self, feats, residual=None, out=None, stats_out=None):
+        return run_conv(self.conv, feats, norm=True, residual=residual, out=out, stats_out=stats_out)
 
 
 class fusion_prenorm(nn.Module):

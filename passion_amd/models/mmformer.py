@@ -59,8 +59,10 @@ class Encoder(nn.Module):
             setattr(self, f"e{lvl}_c2", general_conv3d_prenorm(co, co, pad_type="reflect"))
             setattr(self, f"e{lvl}_c3", general_conv3d_prenorm(co, co, pad_type="reflect"))
 
-    def forward(self, x, modal, mask, dtype):
-        """x: the whole (B,4,S,S,S) input; this encoder reads modality `modal` as a C=1 segment"""
+    def forward(self, x, modal, mask, dtype, outs=None, stats=None):
+        """x: the whole (B,4,S,S,S) input; this encoder reads modality `modal` as a C=1 segment.
+        outs / stats: optional per-level output slots (this modality's slice of the buffers that stack the
+        four modalities for decoder_sep) and the matching InstanceNorm-statistics slots."""
         B, K, D, Hh, Ww = x.shape
         vol = D * Hh * Ww
         seg = ops.SegIn(x, mask=mask, mask_col=modal, C=1, offset=modal * vol, bstride=K * vol)
@@ -71,7 +73,9 @@ class Encoder(nn.Module):
         for lvl in range(1, 6):
             if lvl > 1:
                 f = getattr(self, f"e{lvl}_c1")(f)
-            f = getattr(self, f"e{lvl}_c3")(getattr(self, f"e{lvl}_c2")(f), residual=f.t)
+            f = getattr(self, f"e{lvl}_c3")(getattr(self, f"e{lvl}_c2")(f), residual=f.t,
+                                            out=outs[lvl - 1] if outs is not None else None,
+                                            stats_out=stats[lvl - 1] if stats is not None else None)
             feats.append(f)
         return feats
 
@@ -297,13 +301,18 @@ class Model(nn.Module):
         with torch.autocast("cuda", dtype=torch.bfloat16, enabled=self.compute_dtype == torch.bfloat16):
             return tr(tok, pos)
 
-    def _inter(self, intra, tok_mask, pos_cat, B, p):
+    def _inter(self, intra, tok_mask, pos_cat, B, p, P=1):
         """concat the (masked) intra tokens modality-major -> inter-modal transformer -> reinterpret
         (B,4N,512) as a (B,p,p,p,2048) channels-last volume [the reference's .view, mmformer.py:444,
-        is this very reinterpretation] -> 1x1x1 decode conv"""
-        toks = intra if tok_mask is None else [t * tok_mask[:, i].view(B, 1, 1).to(t.dtype) for i, t in enumerate(intra)]
+        is this very reinterpretation] -> 1x1x1 decode conv.  With P passes (teacher + students) the token
+        sets of all passes go through the transformer as one batch of P*B: tok_mask is (P*B, 4)."""
+        if tok_mask is None:
+            toks = intra
+        else:
+            toks = [(t.unsqueeze(0) * tok_mask[:, i].view(P, B, 1, 1).to(t.dtype)).view(P * B, t.shape[1], t.shape[2])
+                    for i, t in enumerate(intra)]
         tok = self._transformer(self.multimodal_transformer, torch.cat(toks, 1), pos_cat)
-        vol = tok.to(self.compute_dtype).contiguous().view(B, p, p, p, self.token_dim * num_modals)
+        vol = tok.to(self.compute_dtype).contiguous().view(P * B, p, p, p, self.token_dim * num_modals)
         return run_conv(self.multimodal_decode_conv, Feat(vol), norm=False)
 
     def forward(self, x, mask, target=None, temp=1.0):
@@ -312,35 +321,70 @@ class Model(nn.Module):
         dev = x.device
         dt = self.compute_dtype
         idt = self.mask_type != "pdt"
+        training = self.is_training
+        passion = training and self.use_passion
         mask = mask.to(device=dev, dtype=torch.bool).contiguous()
         xin = x.to(dt).contiguous()
 
-        # ---- encoders (idt: input and features of absent modalities are zero, mmformer.py:397-415)
-        encs = [getattr(self, f"{m}_encoder")(xin, i, mask if idt else None, dt) for i, m in enumerate(MODALS)]
+        # ---- encoders (idt: input and features of absent modalities are zero, mmformer.py:397-415).
+        # When training, the level outputs of the four modalities land back to back in one buffer per level:
+        # decoder_sep (shared weights) then runs ONCE over the 4B stack instead of four times.
+        bufs = sbufs = None
+        if training:
+            c = self.flair_encoder.e1_c1.out_channels
+            bufs = [torch.empty(4, B, S >> l, S >> l, S >> l, c << l, dtype=dt, device=dev) for l in range(5)]
+            sbufs = [torch.empty(4, B, c << l, 2, dtype=torch.float32, device=dev) for l in range(5)]
+        encs = []
+        for i, m in enumerate(MODALS):
+            outs = [ops.alias_slice(b_, i) for b_ in bufs] if training else None
+            sts = [s_[i] for s_ in sbufs] if training else None
+            encs.append(getattr(self, f"{m}_encoder")(xin, i, mask if idt else None, dt, outs, sts))
         p = encs[0][4].t.shape[1]
 
-        def modal_feats(lvl, msk):
-            return [encs[i][lvl].with_mask(msk, i) if msk is not None else encs[i][lvl] for i in range(4)]
-
-        own = [[(f.with_mask(mask, i) if idt else f) for f in encs[i]] for i in range(4)]  # what decoder_sep / tokens see
-        xs = [modal_feats(l, mask) for l in range(4)]
+        # ---- the masks of every pass through the fusion path: teacher (+ the four uni-modal students,
+        # mmformer.py:468-531).  All P passes share the encoder features, so they run as ONE virtual batch of
+        # P*B: each conv that reads encoder features re-reads sample b % B under mask row b.
+        P = 1
+        masks_all, tok_mask = mask, None
+        if passion:
+            P = 5
+            onehots = [getattr(self, f"masks_mod{i}").to(dev).expand(B, 4) for i in range(4)]
+            # idt: absent-by-data modalities stay zero as well -- the student sees mask AND one-hot
+            studs = [(mask & onehots[i]) if idt else onehots[i] for i in range(4)]
+            masks_all = torch.cat([mask] + studs, 0).contiguous()
+            tok_mask = torch.cat([torch.ones_like(mask)] + [onehots[2 if i == 3 else i] for i in range(4)], 0)  # quirk :522
+        xs = [[encs[i][l].with_mask(masks_all, i, P) for i in range(4)] for l in range(4)]
+        own5 = [(encs[i][4].with_mask(mask, i) if idt else encs[i][4]) for i in range(4)]
 
         # ---- intra-modal transformers (mmformer.py:417-433)
         pos = [getattr(self, f"{m}_pos") for m in MODALS]
         intra = []
         for i, m in enumerate(MODALS):
-            tok = run_conv(getattr(self, f"{m}_encode_conv"), own[i][4], norm=False).t.view(B, p ** 3, self.token_dim)
+            tok = run_conv(getattr(self, f"{m}_encode_conv"), own5[i], norm=False).t.view(B, p ** 3, self.token_dim)
             tok = self._transformer(getattr(self, f"{m}_transformer"), tok, pos[i])
             intra.append(tok * mask[:, i].view(B, 1, 1).to(tok.dtype))
         pos_cat = torch.cat(pos, 1)
 
-        fuse_pred, preds, de_f_avg = self.decoder_fuse(*xs, self._inter(intra, None, pos_cat, B, p))
+        fuse_all, preds_all, feats_all = self.decoder_fuse(*xs, self._inter(intra, tok_mask, pos_cat, B, p, P))
+        if P == 1:
+            fuse_pred, preds = fuse_all, preds_all
+        else:
+            fuse_parts = fuse_all.split(B, 0)
+            preds_parts = [pp.split(B, 0) for pp in preds_all]
+            f1_parts = feats_all[0].split(B, 0)
+            fuse_pred, preds = fuse_parts[0], [pp[0] for pp in preds_parts]
         pred = ops.softmax_classes(fuse_pred, 1.0, "ncdhw")
-        if not self.is_training:
+        if not training:
             return pred
 
         tcl = ops.target_to_cl(target)
-        sep_preds = [self.decoder_sep(*own[i]) for i in range(4)]
+        sep_mask = mask.t().reshape(4 * B, 1).contiguous() if idt else None      # row i*B+b = mask[b, i]
+        stacked = []
+        for l in range(5):
+            t = ops.stack_slots(bufs[l], [encs[i][l].t for i in range(4)])
+            st = [sbufs[l].view(4 * B, -1, 2)] if l < 4 else None               # filled by the encoders' next-level convs
+            stacked.append(Feat(t, sep_mask, 0, _stats=st))
+        sep_preds = self.decoder_sep(*stacked).split(B, 0)
         eye = torch.eye(4, device=dev)
         maskf = mask.float()
         gates = [(maskf * eye[i]) if idt else eye[i].expand(B, 4) for i in range(4)]
@@ -352,32 +396,26 @@ class Model(nn.Module):
         sep_loss = torch.zeros(B, 4, device=dev)
         for i in range(4):
             sep_loss = sep_loss + gates[i] * ops.wce_dice(sep_preds[i], tcl, "cl").sum(1, keepdim=True)
-        if not self.use_passion:
+        if not passion:
             return pred, prm_loss, sep_loss
 
-        # ---- PASSION: four uni-modal students through the shared fusion path (mmformer.py:468-531)
+        # ---- PASSION losses of the four students against the (detached) teacher
         inv_t = 1.0 / temp
         pt_full = ops.softmax_classes(fuse_pred.detach(), inv_t, "cl")
         pt_deep = [ops.upsample(ops.softmax_classes(pp.detach(), inv_t, "cl"), 2 ** (j + 1)) for j, pp in enumerate(preds)]
-        f_teacher = de_f_avg[0].detach()
+        f_teacher = f1_parts[0].detach()
         kl_loss, proto_loss, dist = (torch.zeros(B, 4, device=dev) for _ in range(3))
-        onehots = [getattr(self, f"masks_mod{i}").to(dev).expand(B, 4).contiguous() for i in range(4)]
         for i in range(4):
-            xs_i = [modal_feats(l, onehots[i]) for l in range(4)]
-            if idt:  # absent-by-data modalities stay zero as well: the student sees mask AND one-hot
-                both = (mask & onehots[i]).contiguous()
-                xs_i = [modal_feats(l, both) for l in range(4)]
-            tok_mask = onehots[2] if i == 3 else onehots[i]          # reference quirk, mmformer.py:522
-            fuse_i, preds_i, de_f_i = self.decoder_fuse(*xs_i, self._inter(intra, tok_mask, pos_cat, B, p))
-            pl, d = ops.proto_loss(de_f_i[0], f_teacher, tcl)
-            kl = crit.kl_cl(fuse_i, pt_full, temp)
-            for j, ps_ in enumerate(preds_i):
-                kl = kl + 0.5 ** (j + 1) * crit.kl_cl(ps_, pt_deep[j], temp, 2 ** (j + 1))
+            pl, d = ops.proto_loss(f1_parts[i + 1], f_teacher, tcl)
+            kl = crit.kl_cl(fuse_parts[i + 1], pt_full, temp)
+            for j in range(4):
+                kl = kl + 0.5 ** (j + 1) * crit.kl_cl(preds_parts[j][i + 1], pt_deep[j], temp, 2 ** (j + 1))
             if i != 3:
                 # A sample whose only present modality is i feeds the student exactly what the teacher saw, so
                 # the reference (deterministic kernels) gets kl = proto = dist = 0 *exactly* -- and train.py:266-267
-                # then turns that 0/0 into an all-false rp_mask.  Our reductions use atomics (run-to-run rounding),
-                # so the identity is imposed instead of hoped for.  (Not for T2: its tokens are T1's, mmformer.py:522.)
+                # then turns that 0/0 into an all-false rp_mask.  Teacher and student are different rows of one
+                # batched launch here (GEMM rounding may differ per row), so the identity is imposed instead of
+                # hoped for.  (Not for T2: its tokens are T1's, mmformer.py:522.)
                 differs = (~(mask == onehots[i]).all(1)).float().view(B, 1)
                 pl, d, kl = pl * differs, d * differs, kl * differs
             proto_loss = proto_loss + gates[i] * pl

@@ -22,7 +22,7 @@ def _p_off(t, off_elems):
 # ------------------------------------------------------------------------------------------------
 # InstanceNorm statistics
 # ------------------------------------------------------------------------------------------------
-def instnorm_stats(x, eps=1e-5):
+def instnorm_stats(x, eps=1e-5, out=None):
     """(mean, rstd) per (b, c) of a channels-last (B,D,H,W,C) tensor -> f32 (B, C, 2).
     Statistics half of nn.InstanceNorm3d (reference blocks.py:18); not differentiated directly:
     the conv block's backward carries the InstanceNorm gradient analytically."""
@@ -32,7 +32,8 @@ def instnorm_stats(x, eps=1e-5):
     V = D * H * W
     lib = L.load()
     scratch = torch.empty(lib.passion_instnorm_scratch_doubles(B, V, C), dtype=torch.float64, device=x.device)
-    stats = torch.empty(B, C, 2, dtype=torch.float32, device=x.device)
+    stats = out if out is not None else torch.empty(B, C, 2, dtype=torch.float32, device=x.device)
+    assert stats.shape == (B, C, 2) and stats.is_contiguous()
     rc = lib.passion_instnorm_stats(_p(x), L.dtype_code(x.dtype), B, V, C, V * C, eps,
                                          _p(scratch), _p(stats), L.stream_ptr())
     L.check(rc, "passion_instnorm_stats")
@@ -49,17 +50,20 @@ class SegIn:
                explicitly (used for the raw NCDHW input, one modality = one C=1 segment).
     stats    : (B,C,2) from instnorm_stats -> loader applies InstanceNorm + LeakyReLU; None -> raw.
     mask     : (B,K) bool tensor of present modalities and the column to read; absent => zeros.
+    bmod     : > 0 -> the conv runs over a virtual batch of P*bmod samples (P masked passes over the
+               same bmod physical samples: teacher + uni-modal students); sample b reads x[b % bmod],
+               stats[b % bmod] and mask[b].  Its gradient is the sum over the P passes.
     """
 
-    def __init__(self, x, stats=None, mask=None, mask_col=0, C=None, offset=0, bstride=None):
-        self.x, self.stats, self.mask, self.mask_col = x, stats, mask, mask_col
+    def __init__(self, x, stats=None, mask=None, mask_col=0, C=None, offset=0, bstride=None, bmod=0):
+        self.x, self.stats, self.mask, self.mask_col, self.bmod = x, stats, mask, mask_col, bmod
         self.C = x.shape[-1] if C is None else C
         self.offset = offset
         self.bstride = (x[0].numel() if bstride is None else bstride)
 
 
 class _ConvCfg:
-    __slots__ = ("segs", "D", "H", "W", "ksize", "stride", "pad_mode", "slope", "out_dtype", "B")
+    __slots__ = ("segs", "D", "H", "W", "ksize", "stride", "pad_mode", "slope", "out_dtype", "B", "out")
 
 
 def pack_weight(weight, cache=None):
@@ -99,6 +103,7 @@ def _fill_desc(cfg, xs, dxs=None):
         sg.mask_ld = s.mask.shape[1] if s.mask is not None else 0
         sg.C = s.C
         sg.bstride = s.bstride
+        sg.bmod = s.bmod
         sg.dx = dxs[i].data_ptr() if (dxs is not None and dxs[i] is not None) else None
     return d
 
@@ -117,7 +122,10 @@ class ConvBlockFn(torch.autograd.Function):
         Do = (cfg.D + 2 * pad - cfg.ksize) // cfg.stride + 1
         Ho = (cfg.H + 2 * pad - cfg.ksize) // cfg.stride + 1
         Wo = (cfg.W + 2 * pad - cfg.ksize) // cfg.stride + 1
-        y = torch.empty(cfg.B, Do, Ho, Wo, Cout, dtype=cfg.out_dtype, device=weight.device)
+        y, cfg.out = cfg.out, None
+        if y is None:
+            y = torch.empty(cfg.B, Do, Ho, Wo, Cout, dtype=cfg.out_dtype, device=weight.device)
+        assert y.shape == (cfg.B, Do, Ho, Wo, Cout) and y.dtype == cfg.out_dtype and y.is_contiguous()
         d = _fill_desc(cfg, xs)
         d.Cout = Cout
         b32 = bias.detach().float() if bias is not None else None
@@ -144,7 +152,8 @@ class ConvBlockFn(torch.autograd.Function):
         for i, (s, x) in enumerate(zip(cfg.segs, xs)):
             if ctx.needs_input_grad[5 + i]:
                 assert s.offset == 0, "gradient wrt an offset view is not supported"
-                dxs.append(torch.empty_like(x))
+                dxs.append(torch.empty((cfg.B,) + tuple(x.shape[1:]), dtype=x.dtype, device=dev) if s.bmod
+                           else torch.empty_like(x))
             else:
                 dxs.append(None)
         d = _fill_desc(cfg, xs, dxs)
@@ -152,20 +161,57 @@ class ConvBlockFn(torch.autograd.Function):
         sums = torch.empty(lib.passion_conv_bwd_scratch_floats(byref(d)), dtype=torch.float32, device=dev)
         L.check(lib.passion_conv3d_bwd(byref(d), _p(ctx.packed), _p(dy), _p(dW), _p(db), _p(sums),
                                        L.stream_ptr()), "passion_conv3d_bwd")
+        for i, s in enumerate(cfg.segs):   # P passes over the same samples: their input gradients add up
+            if s.bmod and dxs[i] is not None:
+                dxs[i] = dxs[i].view(cfg.B // s.bmod, *xs[i].shape).sum(0)
         dres = dy if (ctx.has_res and ctx.needs_input_grad[3]) else None
         return (None, dW, db, dres, None, *dxs)
 
 
 def conv_block(segs, weight, bias, D, H, W, ksize=3, stride=1, pad_mode=L.PAD_REFLECT,
-               residual=None, out_dtype=None, slope=0.2, pack_cache=None):
+               residual=None, out_dtype=None, slope=0.2, pack_cache=None, out=None):
+    """`out`: optional preallocated output (a non-view alias into a larger buffer, see alias_slice)"""
     cfg = _ConvCfg()
     cfg.segs, cfg.D, cfg.H, cfg.W = segs, D, H, W
     cfg.ksize, cfg.stride, cfg.pad_mode, cfg.slope = ksize, stride, pad_mode, slope
-    cfg.B = segs[0].x.shape[0]
+    vb = [s.mask.shape[0] if s.bmod else s.x.shape[0] for s in segs]
+    assert min(vb) == max(vb), "segments disagree on the (virtual) batch size"
+    cfg.B, cfg.out = vb[0], out
     x0 = segs[0].x
     cfg.out_dtype = out_dtype if out_dtype is not None else (x0.dtype if x0.dtype != torch.float64 else torch.float32)
     packed = pack_weight(weight, pack_cache)
     return ConvBlockFn.apply(cfg, weight, bias, residual, packed, *[s.x for s in segs])
+
+
+def alias_slice(buf, i):
+    """buf[i] as a tensor that shares buf's storage but is NOT an autograd view of it, so that an op may
+    return it as its own output (autograd forbids custom-Function outputs that are views of a base which is
+    written elsewhere).  Used to let producers write straight into one slot of a stacked buffer."""
+    sub = buf[i]
+    return torch.empty(0, dtype=buf.dtype, device=buf.device).set_(buf.untyped_storage(), sub.storage_offset(),
+                                                                    sub.shape, sub.stride())
+
+
+class StackFn(torch.autograd.Function):
+    """torch.cat(parts, 0) where the parts already live back to back in `buf` (alias_slice): no copy forward,
+    the gradient is handed out in chunks backward."""
+
+    @staticmethod
+    def forward(ctx, holder, *parts):
+        buf = holder[0]
+        n, b = buf.shape[0], buf.shape[1]
+        assert len(parts) == n and all(p.data_ptr() == buf[i].data_ptr() for i, p in enumerate(parts))
+        ctx.n = n
+        return torch.empty(0, dtype=buf.dtype, device=buf.device).set_(
+            buf.untyped_storage(), buf.storage_offset(), (n * b,) + tuple(buf.shape[2:]), buf.stride()[1:])
+
+    @staticmethod
+    def backward(ctx, g):
+        return (None, *g.contiguous().chunk(ctx.n, 0))
+
+
+def stack_slots(buf, parts):
+    return StackFn.apply([buf], *parts)
 
 
 # ------------------------------------------------------------------------------------------------
