@@ -9,7 +9,7 @@ from ctypes import (POINTER, Structure, c_double, c_float, c_int, c_int32, c_int
                     c_void_p)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libpassion_hip.so")
+LIB_PATH = os.environ.get("PASSION_HIP_LIB") or os.path.join(_HERE, "lib", "libpassion_hip.so")   # env: A/B builds
 
 F32, BF16 = 0, 1
 PAD_ZEROS, PAD_REFLECT = 0, 1

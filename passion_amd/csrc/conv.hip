@@ -120,7 +120,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvK p) {
     __shared__ float lsum[DG ? MT * 16 * 2 : 1];
 
     const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, n = lane & 15, kq = lane >> 4;
-    int bid = blockIdx.x;
+    int bid = xcd_swizzle(blockIdx.x, gridDim.x);
     const int tw_ = bid % p.tilesW; bid /= p.tilesW;
     const int th_ = bid % p.tilesH; bid /= p.tilesH;
     const int td_ = bid % p.tilesD; bid /= p.tilesD;
@@ -320,7 +320,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(ConvK p, float* __restr
     const bool do_bias = bias_block && (wv == 0);
 
     const int total_tiles = p.B * tiles_per_b;
-    for (int tile = blockIdx.x; tile < total_tiles; tile += gridDim.x) {
+    for (int tile = xcd_swizzle(blockIdx.x, gridDim.x); tile < total_tiles; tile += gridDim.x) {
         int t2 = tile;
         const int tw_ = t2 % p.tilesW; t2 /= p.tilesW;
         const int th_ = t2 % p.tilesH; t2 /= p.tilesH;
@@ -443,6 +443,7 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, int Cin, int Cou
 
 int fill_params(const passion_conv_desc_t* d, ConvK& k) {
     if (!d) return -1001;
+    k.dbg = 0;
     if (d->ksize != 1 && d->ksize != 3) return -1002;
     if (d->stride != 1 && d->stride != 2) return -1003;
     if (d->ksize == 1 && d->stride != 1) return -1003;

@@ -14,7 +14,7 @@
 // The accumulator layout equals the f32 kernel's, so the epilogues (conv_common.h) are shared.
 #include "conv_common.h"
 
-namespace pconv { extern int g_conv_merge, g_wgrad_wide; }
+namespace pconv { extern int g_conv_merge, g_wgrad_wide, g_conv_lean; }
 using namespace pconv;
 
 namespace {
@@ -130,7 +130,7 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(ConvK p) {
     __shared__ float lsum[DG ? MT * 16 * 2 : 4];
 
     const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, n = lane & 15, g = lane >> 4;
-    int bid = blockIdx.x;
+    int bid = xcd_swizzle(blockIdx.x, gridDim.x);
     const int tw_ = bid % p.tilesW; bid /= p.tilesW;
     const int th_ = bid % p.tilesH; bid /= p.tilesH;
     const int td_ = bid % p.tilesD; bid /= p.tilesD;
@@ -534,7 +534,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(ConvK p, float* __
     };
 
     const int total_tiles = p.B * tiles_per_b;
-    int tile = blockIdx.x;
+    int tile = xcd_swizzle(blockIdx.x, gridDim.x);   // per round of gridDim.x bricks every XCD works on one contiguous run
     bool have = tile < total_tiles;
     Regs R;
     if (have) fetch(tile, R);
@@ -745,6 +745,10 @@ bool bf16_eligible(const ConvK& k, bool dgrad) {
 }
 
 int launch_conv_bf16(ConvK& k, int ksize, int stride, bool dgrad, const void* packed_bf16, hipStream_t st) {
+    if (g_conv_lean) {                       // lean persistent kernel for the stride-1, 8-channel-aligned shapes
+        const int rc = launch_conv_lean(k, ksize, stride, dgrad, packed_bf16, st);
+        if (rc <= 0) return rc;              // > 0: shape not covered, use the general kernel below
+    }
     const int ntap = ksize * ksize * ksize;
     int cmax = 0;
     if (dgrad) {
@@ -766,6 +770,9 @@ int launch_conv_bf16(ConvK& k, int ksize, int stride, bool dgrad, const void* pa
     return dgrad ? launch_geo<1>(k, ksize, stride, cmax, mtiles, st) : launch_geo<0>(k, ksize, stride, cmax, mtiles, st);
 }
 
+int g_conv_dbg = 0;       // developer timing switch (PASSION_CONV_DBG): bit0 skip staging, bit1 skip MFMA, bit2 skip epilogue
+int g_conv_target = 1024; // persistent conv workgroups aimed at per launch (PASSION_CONV_TARGET)
+int g_conv_lean = 1;      // PASSION_CONV_LEAN=0: general kernel everywhere (A/B)
 int g_conv_merge = 0, g_wgrad_wide = 0;   // A/B switches (environment: PASSION_CONV_MERGE, PASSION_WGRAD_WIDE)
 
 int wgrad_bf16_chunk(const ConvK& k, int ksize, int stride) {

@@ -38,6 +38,8 @@ struct ConvK {
     float* sums;
     int tilesD, tilesH, tilesW;
     int hi_t[3], hi_u[3];  // dgrad reflect: tap / source coordinate of the high-side mirror term per axis
+    int per, wres;         // bf16 kernel: bricks per (persistent) workgroup; all chunks' weight fragments resident in LDS
+    int dbg;               // developer timing switch (PASSION_CONV_DBG): bit0 skip staging, bit1 skip MFMA loop, bit2 skip epilogue
 };
 
 __host__ __device__ inline int pad16(int c) { return (c + 15) / 16 * 16; }
@@ -49,8 +51,19 @@ int pack_weight_bf16(const float* w, int Cin, int Cout, int ntap, void* out, hip
 struct ConvK;
 bool bf16_eligible(const ConvK& k, bool dgrad);
 int launch_conv_bf16(ConvK& k, int ksize, int stride, bool dgrad, const void* packed_bf16, hipStream_t st);
+int launch_conv_lean(ConvK& k, int ksize, int stride, bool dgrad, const void* packed_bf16, hipStream_t st);   // conv_lean.hip
 int launch_wgrad_bf16(ConvK& k, int ksize, int stride, int MT, int gx, int gy, float* dWslab, float* dbslab, hipStream_t st);
 int wgrad_bf16_chunk(const ConvK& k, int ksize, int stride);
+
+// Workgroups are dealt round-robin to the 8 XCDs, each with a private L2.  Neighbouring bricks share halo planes
+// and the 128-byte lines that straddle a brick edge, so consecutive brick indices must land on the SAME XCD:
+// workgroup i (XCD i % 8) takes brick (i % 8) * (n / 8) + i / 8, i.e. every XCD owns one contiguous run of bricks.
+// Measured on the level-1 forward conv: L2 fill traffic 5.6x the input (= 3 W-lines x 10/8 H x 6/4 D, no sharing
+// across XCDs at all) before the swizzle.
+__device__ __forceinline__ int xcd_swizzle(int i, int n) {
+    const int n8 = n & ~7;
+    return i < n8 ? (i & 7) * (n8 >> 3) + (i >> 3) : i;
+}
 
 // One axis of a tap entry.  a < KS: regular tap; a == KS: low-side mirror term; a == KS+1: high-side.
 // Forward conv of stride S reads padded coordinate o*S + t - 1; 'reflect' maps -1 -> 1 and Sin -> Sin-2, so

@@ -1,0 +1,634 @@
+// Lean persistent bf16 implicit-GEMM conv (forward and dgrad of the stride-1 convs, every tensor a multiple of
+// 8 channels wide) -- same math, operand layouts and epilogues as conv_bf16.hip, restructured around what the
+// counters said about that kernel on MI355X (level-1 8->8 conv, 128^3): it is VALU/SALU-issue bound, not memory
+// bound: per wavefront and brick 895 VALU + 508 SALU instructions against 28 MFMAs, 302 + 328 of them before the
+// first load is even issued (decoding the launch descriptor, the virtual-concat lookup, masks, weight staging,
+// index arithmetic with runtime divisors), 366 in the brick staging, 138 in the epilogue.  So here:
+//   * a workgroup is persistent over `per` consecutive bricks of ONE sample: descriptor decoding, the concat
+//     lookup, masks and InstanceNorm statistics are resolved once into a small LDS table (BlkDesc per 8-channel
+//     block), weights stay in LDS, brick coordinates advance incrementally (no runtime divisions per brick);
+//   * everything that does not depend on the brick is a per-lane constant computed once: source voxel offsets of
+//     the staging threads, LDS tap offsets of the MFMA lanes, output voxel offsets of the epilogue lanes;
+//   * interior bricks (no padding involved) take a branch-free addressing path: address = brick base + constant;
+//   * the next step's brick is fetched into registers while the matrix cores work on the current one.
+#include "conv_common.h"
+
+namespace pconv { extern int g_conv_target, g_conv_dbg; }
+using namespace pconv;
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+template <int KS, int CKB> struct GeoL {
+    static constexpr int HALO = (KS == 3) ? 1 : 0;
+    static constexpr int ID = TD + 2 * HALO, IH = TH + 2 * HALO, IW = TW + 2 * HALO;
+    static constexpr int VOL = ID * IH * IW;
+    static constexpr int NC8 = CKB / 8;
+    static constexpr int VS = CKB * 2 + (CKB > 8 ? 16 : 0);   // bytes per voxel in LDS (padded: spreads 16-B slots over banks)
+    static constexpr int NTAP = KS * KS * KS;
+    static constexpr int Q = NTAP * NC8;                      // (tap, 8-channel block) pairs per chunk
+    static constexpr int NSTEP = (Q + 3) / 4;                 // MFMA K-steps per chunk (4 pairs = K 32 each)
+    static constexpr int TOT = VOL * NC8, NIT = (TOT + 255) / 256;
+    static constexpr int BRICK = (VOL * VS + 15) / 16 * 16;
+};
+
+struct alignas(16) BlkDesc {     // one 8-channel block of the K axis, resolved for this workgroup's sample
+    const bf16_t* src;           // sample base + channel offset
+    int C, nch, has_norm, pad_;  // voxel stride (elements); 8 or 0 (absent modality); InstanceNorm + LeakyReLU in the loader
+    float mean[8], rstd[8];
+};
+static_assert(sizeof(BlkDesc) == 96, "BlkDesc layout");
+struct alignas(16) EpiDesc {     // dgrad epilogue: the four output rows (= forward input channels) of one lane group
+    const bf16_t* x;             // forward input of those channels (sample base + channel), for x_hat
+    bf16_t* dx;
+    int C, ok, has_stats;
+    float mval;                  // modality mask of the segment for this sample
+    float mean[4], rstd[4];
+};
+static_assert(sizeof(EpiDesc) == 64, "EpiDesc layout");
+constexpr int MAXBLK = 32;       // K <= 256 channels
+constexpr int DESC_BYTES = MAXBLK * (int)sizeof(BlkDesc);
+
+__device__ __forceinline__ bf16x8 zero8() {
+    bf16x8 z;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) z[j] = (__bf16)0.f;
+    return z;
+}
+
+template <int KS, int MT, int MODE, int CKB>
+__global__ __launch_bounds__(256) void conv_lean_kernel(ConvK p) {
+    constexpr bool DG = (MODE == 1);
+    using G = GeoL<KS, CKB>;
+    constexpr int NIT = G::NIT, NC8 = G::NC8, VS = G::VS;
+    constexpr int WV = G::NSTEP * 4 * MT * 16;            // 16-byte weight vectors per chunk
+    extern __shared__ __attribute__((aligned(16))) char dyn_lds[];
+    char* lds = dyn_lds;                                   // [brick | block descriptors | weight fragments]
+    BlkDesc* desc = reinterpret_cast<BlkDesc*>(dyn_lds + G::BRICK);
+    bf16x8* wl0 = reinterpret_cast<bf16x8*>(dyn_lds + G::BRICK + DESC_BYTES);
+    __shared__ float lsum[DG ? MT * 16 * 2 : 4];
+    __shared__ EpiDesc edesc[DG ? MT * 4 : 1];
+    __shared__ unsigned short mlist[128];
+    __shared__ int mcnt[4];
+    __shared__ unsigned char mtab[3][5][8];   // [axis d,h,w][option][local coordinate] = tap | valid << 2 | brick position << 3
+
+    const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, n = lane & 15, g = lane >> 4;
+    const int mg = blockIdx.y;
+    // stride 1: the GEMM's output volume (fwd: y, dgrad: dx) and its source volume (fwd: x, dgrad: dy) coincide
+    const int Sd = p.Di, Sh = p.Hi, Sw = p.Wi;
+    const int K8 = DG ? p.Cout / 8 : p.Cin / 8;
+    const int nchunk = (K8 + NC8 - 1) / NC8;
+    const bool wres = p.wres != 0;
+    const bf16x8* wp = reinterpret_cast<const bf16x8*>(p.wpack);
+
+    const int tiles_per_b = p.tilesD * p.tilesH * p.tilesW;
+    const int wgs_per_b = (tiles_per_b + p.per - 1) / p.per;
+    const int bx = xcd_swizzle(blockIdx.x, gridDim.x);
+    const int b = bx / wgs_per_b;
+    // Brick schedule of this workgroup.  Forward: `per` consecutive bricks (measured best: 46 vs 54 us on the level-1
+    // conv).  Dgrad: border bricks are several times more expensive (mirror taps), a workgroup that owns a whole border
+    // row would set the kernel's duration -- so round i of the sample's bricks is [i*W, (i+1)*W), W = workgroups per
+    // sample, and workgroup w takes slot (w + 17 i) mod W of it: within a round neighbouring workgroups (same XCD) work
+    // on neighbouring bricks, from round to round a workgroup drifts diagonally through the (h, w) tile grid
+    // (level-1 dgrad 118 -> 99 us).
+    __shared__ int bricktab[256];
+    const int wq = bx % wgs_per_b;
+    auto brick_of = [&](int i) { return DG ? (wq + 17 * i) % wgs_per_b + i * wgs_per_b : wq * p.per + i; };
+    if (tid < p.per) {
+        const int t = brick_of(tid);
+        int code = -1;
+        if (t < tiles_per_b) {
+            const int tw = t % p.tilesW, th = (t / p.tilesW) % p.tilesH, td = t / (p.tilesW * p.tilesH);
+            code = (td << 20) | (th << 10) | tw;
+        }
+        bricktab[tid] = code;
+    }
+    // valid bricks form a prefix of the table (dgrad: only the last round can be short)
+    const int nbricks = DG ? (brick_of(p.per - 1) < tiles_per_b ? p.per : p.per - 1)
+                           : max(0, min(p.per, tiles_per_b - wq * p.per));
+    if (nbricks <= 0) return;
+
+    // ---- once per workgroup: resolve the K axis into block descriptors
+    if (tid < K8) {
+        BlkDesc d;
+        d.pad_ = 0;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) { d.mean[c] = 0.f; d.rstd[c] = 1.f; }
+        if (DG) {
+            d.src = reinterpret_cast<const bf16_t*>(p.dy) + (long)b * Sd * Sh * Sw * p.Cout + tid * 8;
+            d.C = p.Cout; d.nch = 8; d.has_norm = 0;
+        } else {
+            int r = tid;
+            bool found = false;
+            d.src = nullptr; d.C = 8; d.nch = 0; d.has_norm = 0;
+#pragma unroll
+            for (int s2 = 0; s2 < PASSION_MAX_SEG; ++s2) {
+                if (s2 < p.nseg && !found) {
+                    const SegD& sd = p.seg[s2];
+                    const int nb = sd.C / 8;
+                    if (r < nb) {
+                        found = true;
+                        const int bs = sd.bsrc(b), c0 = r * 8;
+                        const bool on = !sd.mask || sd.mask[(long)b * sd.mask_ld + sd.mask_col] != 0;
+                        d.src = reinterpret_cast<const bf16_t*>(sd.x) + (long)bs * sd.bstride + c0;
+                        d.C = sd.C; d.nch = on ? 8 : 0; d.has_norm = sd.stats != nullptr;
+                        if (sd.stats) {
+#pragma unroll
+                            for (int c = 0; c < 8; ++c) {
+                                d.mean[c] = sd.stats[((long)bs * sd.C + c0 + c) * 2 + 0];
+                                d.rstd[c] = sd.stats[((long)bs * sd.C + c0 + c) * 2 + 1];
+                            }
+                        }
+                    }
+                    r -= nb;
+                }
+            }
+        }
+        desc[tid] = d;
+    }
+    if (DG && tid >= 64 && tid < 64 + MT * 4) {     // dgrad epilogue descriptors (second wave, concurrently with the above)
+        const int e = tid - 64, cg = (mg * MT + e / 4) * 16 + (e % 4) * 4;
+        EpiDesc d;
+        d.x = nullptr; d.dx = nullptr; d.C = 4; d.ok = 0; d.has_stats = 0; d.mval = 1.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { d.mean[j] = 0.f; d.rstd[j] = 1.f; }
+#pragma unroll
+        for (int s2 = 0; s2 < PASSION_MAX_SEG; ++s2) {
+            if (s2 < p.nseg && cg < p.Cin) {
+                const SegD& sd = p.seg[s2];
+                if (cg >= sd.cbase && cg < sd.cbase + sd.C && sd.dx != nullptr) {
+                    const int cl = cg - sd.cbase, bs = sd.bsrc(b);
+                    d.ok = 1; d.C = sd.C; d.has_stats = sd.stats != nullptr;
+                    d.x = reinterpret_cast<const bf16_t*>(sd.x) + (long)bs * sd.bstride + cl;
+                    d.dx = reinterpret_cast<bf16_t*>(sd.dx) + (long)b * sd.bstride + cl;
+                    if (sd.mask) d.mval = sd.mask[(long)b * sd.mask_ld + sd.mask_col] ? 1.f : 0.f;
+                    if (sd.stats) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            d.mean[j] = sd.stats[((long)bs * sd.C + cl + j) * 2 + 0];
+                            d.rstd[j] = sd.stats[((long)bs * sd.C + cl + j) * 2 + 1];
+                        }
+                    }
+                }
+            }
+        }
+        edesc[e] = d;
+    }
+    // weight fragments of chunk c -> LDS slot dst; padding pairs (q >= Q) and blocks past K8 are zero, so the MFMA
+    // loop never predicates (absent modalities are zeros on the ACTIVATION side: staged as zero blocks)
+    auto load_weights = [&](int c, bf16x8* dst) {
+        for (int v = tid; v < WV; v += 256) {
+            const int row = v % (MT * 16), gg = (v / (MT * 16)) % 4, s = v / (MT * 16 * 4);
+            const int q = 4 * s + gg, tap = q / NC8, blk = q % NC8;
+            const bool ok = (q < G::Q) && (c * NC8 + blk < K8);
+            dst[v] = ok ? wp[((long)tap * K8 + c * NC8 + blk) * p.Mpad + (mg * MT) * 16 + row] : zero8();
+        }
+    };
+    if (wres)
+        for (int c = 0; c < nchunk; ++c) load_weights(c, wl0 + c * WV);
+    __syncthreads();
+    unsigned chunk_live = 0u;                     // chunks with at least one present block
+    for (int gb = 0; gb < K8; ++gb)
+        if (desc[gb].nch > 0) chunk_live |= 1u << (gb / NC8);
+
+    // ---- per-lane constants
+    const int jj = tid % NC8;
+    int voxoff[NIT];                              // source voxel of staging iteration u relative to the brick's first voxel
+#pragma unroll
+    for (int u = 0; u < NIT; ++u) {
+        const int tv = (tid + 256 * u) / NC8;
+        const int zw = tv % G::IW, zh = (tv / G::IW) % G::IH, zd = tv / (G::IW * G::IH);
+        voxoff[u] = (zd * Sh + zh) * Sw + zw;
+    }
+    const int ldsoff0 = (tid / NC8) * VS + jj * 16;       // iteration u writes at ldsoff0 + u * (256 / NC8) * VS
+    const int lh0 = n >> 3, lw = n & 7, ld_ = wv;
+    const int lh[4] = {lh0, lh0 + 2, lh0 + 4, lh0 + 6};
+    // B fragments: this lane's voxel (row nt) at tap 0, plus its 8-channel block inside a 32-channel voxel
+    const int pos0 = ((ld_ * G::IH + lh0) * G::IW + lw) * VS + (NC8 == 4 ? g * 16 : 0);
+    int toffv[NC8 == 1 ? G::NSTEP : 1];           // CKB 8: lane group g owns tap 4s+g (per-lane offset); CKB 32: tap s for all
+    if (NC8 == 1) {
+#pragma unroll
+        for (int s = 0; s < G::NSTEP; ++s) {
+            const int tap = 4 * s + g;
+            int td = 0, th = 0, tw = 0;
+            if (KS == 3) { td = tap / 9; th = (tap / 3) % 3; tw = tap % 3; }
+            if (DG && KS == 3) { td = 2 - td; th = 2 - th; tw = 2 - tw; }   // gather form: voxel i reads u = i + 1 - t
+            toffv[s] = (tap < G::NTAP) ? ((td * G::IH + th) * G::IW + tw) * VS : 0;
+        }
+    }
+    const int wlane = (g * MT * 16 + n) * 16;     // A fragment of step s, row tile mt: wl + wlane + s*4*MT*256 + mt*256
+    const int lanevox0 = (ld_ * Sh + lh0) * Sw + lw;      // output voxel of row nt: + nt * 2 * Sw
+    f32x4 biasv[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int co = (mg * MT + mt) * 16 + g * 4;
+        biasv[mt] = (!DG && p.bias && co < p.Cout) ? load4(p.bias + co) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    const bool reflect_dg = DG && (KS == 3) && (p.pad_mode == PASSION_PAD_REFLECT);
+
+    // ---- staging: FETCH (global -> registers) / COMMIT (registers -> normalise -> LDS)
+    u32x4 raw[NIT];
+    unsigned okbits = 0u;
+    auto fetch = [&](int chunk, int o0d, int o0h, int o0w) {
+        const BlkDesc* dp = desc + chunk * NC8 + jj;
+        const bf16_t* src = dp->src;
+        const int C = dp->C;
+        const bool have = dp->nch > 0 && chunk * NC8 + jj < K8;
+        okbits = 0u;
+        const bool interior = o0d >= G::HALO && o0h >= G::HALO && o0w >= G::HALO && o0d + TD + G::HALO <= Sd &&
+                              o0h + TH + G::HALO <= Sh && o0w + TW + G::HALO <= Sw;
+        if (interior) {                           // workgroup-uniform: no padding anywhere in this brick
+            const int basevox = ((o0d - G::HALO) * Sh + (o0h - G::HALO)) * Sw + (o0w - G::HALO);
+#pragma unroll
+            for (int u = 0; u < NIT; ++u) {
+                raw[u] = (u32x4){0u, 0u, 0u, 0u};
+                if (have && (tid + 256 * u < G::TOT)) {
+                    raw[u] = *reinterpret_cast<const u32x4*>(src + (long)(basevox + voxoff[u]) * C);
+                    okbits |= 1u << u;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < NIT; ++u) {
+                const int tv = (tid + 256 * u) / NC8;
+                const int zw = tv % G::IW, zh = (tv / G::IW) % G::IH, zd = tv / (G::IW * G::IH);
+                int sd = o0d - G::HALO + zd, sh = o0h - G::HALO + zh, sw = o0w - G::HALO + zw;
+                bool ok = have && (tid + 256 * u < G::TOT);
+                if (!DG && p.pad_mode == PASSION_PAD_REFLECT) {
+                    sd = reflect_idx(sd, Sd); sh = reflect_idx(sh, Sh); sw = reflect_idx(sw, Sw);
+                    sd = min(max(sd, 0), Sd - 1); sh = min(max(sh, 0), Sh - 1); sw = min(max(sw, 0), Sw - 1);
+                } else {
+                    ok = ok && (sd >= 0 && sd < Sd && sh >= 0 && sh < Sh && sw >= 0 && sw < Sw);
+                }
+                raw[u] = (u32x4){0u, 0u, 0u, 0u};
+                if (ok) {
+                    raw[u] = *reinterpret_cast<const u32x4*>(src + (((long)sd * Sh + sh) * Sw + sw) * C);
+                    okbits |= 1u << u;
+                }
+            }
+        }
+    };
+    auto commit = [&](int chunk) {
+        const BlkDesc* dp = desc + chunk * NC8 + jj;
+        const bool norm = dp->has_norm != 0 && okbits != 0u;
+        float mean[8], rstd[8];
+        if (norm) {
+#pragma unroll
+            for (int c = 0; c < 8; ++c) { mean[c] = dp->mean[c]; rstd[c] = dp->rstd[c]; }
+        }
+#pragma unroll
+        for (int u = 0; u < NIT; ++u) {
+            if (tid + 256 * u >= G::TOT) continue;
+            u32x4 o = raw[u];
+            if (norm && ((okbits >> u) & 1u)) {
+                bf16x8 ob;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {      // bf16 pairs -> f32: low half = even channel
+                    const float v0 = __uint_as_float(raw[u][c] << 16), v1 = __uint_as_float(raw[u][c] & 0xffff0000u);
+                    float t0_ = (v0 - mean[2 * c]) * rstd[2 * c], t1_ = (v1 - mean[2 * c + 1]) * rstd[2 * c + 1];
+                    t0_ = t0_ > 0.f ? t0_ : t0_ * p.slope;
+                    t1_ = t1_ > 0.f ? t1_ : t1_ * p.slope;
+                    ob[2 * c] = (__bf16)t0_; ob[2 * c + 1] = (__bf16)t1_;
+                }
+                o = __builtin_bit_cast(u32x4, ob);
+            }
+            *reinterpret_cast<u32x4*>(lds + ldsoff0 + u * (256 / NC8) * VS) = o;
+        }
+    };
+
+    // ---- walk the flattened (brick, chunk) steps
+    int brick_i = 0;
+    int tw_ = bricktab[0] & 1023, th_ = (bricktab[0] >> 10) & 1023, td_ = bricktab[0] >> 20;
+    int chunk = 0;
+    const int nsteps = nbricks * nchunk;
+    const bool nostage = (p.dbg & 1) != 0;
+    if (((chunk_live >> 0) & 1u) && !nostage) fetch(0, td_ * TD, th_ * TH, tw_ * TW);
+    f32x4 acc[MT][4];
+    int nmirror = 0;
+    // dgrad: InstanceNorm-backward sums (sum g, sum g * x_hat) stay in registers over all bricks of the workgroup
+    float s1[DG ? MT : 1][4], s2v[DG ? MT : 1][4];
+#pragma unroll
+    for (int mt = 0; mt < (DG ? MT : 1); ++mt)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { s1[mt][j] = 0.f; s2v[mt][j] = 0.f; }
+    uint2 xpre[4];                                // MT == 1: x of the four output voxels, fetched ahead of the MFMA loop
+
+    for (int step = 0; step < nsteps; ++step) {
+        const int o0d = td_ * TD, o0h = th_ * TH, o0w = tw_ * TW;
+        const int cb8 = chunk * NC8;
+        const bf16x8* wl = wres ? wl0 + chunk * WV : wl0;
+        const bool live = (chunk_live >> chunk) & 1u;
+        __syncthreads();                              // everybody is done reading the previous step's brick / tables
+        if (chunk == 0) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            nmirror = 0;
+            if (reflect_dg) {                         // mirror-tap bookkeeping of this brick (adjoint of reflect padding)
+                const bool lowD = (o0d == 0) && (Sd >= 2), lowH = (o0h == 0) && (Sh >= 2), lowW = (o0w == 0) && (Sw >= 2);
+                const bool hiD = p.hi_t[0] >= 0 && (o0d <= Sd - 2) && (Sd - 2 < o0d + TD);
+                const bool hiH = p.hi_t[1] >= 0 && (o0h <= Sh - 2) && (Sh - 2 < o0h + TH);
+                const bool hiW = p.hi_t[2] >= 0 && (o0w <= Sw - 2) && (Sw - 2 < o0w + TW);
+                if (lowD || lowH || lowW || hiD || hiH || hiW) {       // workgroup-uniform
+                    if (tid < 3 * 5 * 8) {
+                        const int ax = tid / 40, a = (tid / 8) % 5, il = tid % 8;
+                        const int i0 = ax == 0 ? o0d : (ax == 1 ? o0h : o0w), Sn = ax == 0 ? Sd : (ax == 1 ? Sh : Sw);
+                        int t, pos2; bool v;
+                        axis_tap<KS, G::HALO, DG, 1>(a, il, i0, Sn, p.hi_t[ax], p.hi_u[ax], t, pos2, v);
+                        mtab[ax][a][il] = (unsigned char)((t & 3) | (v ? 4 : 0) | ((pos2 & 31) << 3));
+                    }
+                    bool f = false;
+                    int code = 0;
+                    if (tid < 125) {
+                        const int ad = tid / 25, ah = (tid / 5) % 5, aw = tid % 5;
+                        f = !(ad < 3 && ah < 3 && aw < 3) && (ad != 3 || lowD) && (ad != 4 || hiD) && (ah != 3 || lowH) &&
+                            (ah != 4 || hiH) && (aw != 3 || lowW) && (aw != 4 || hiW);
+                        code = ad | (ah << 3) | (aw << 6);
+                    }
+                    const unsigned long long bal = __ballot(f);
+                    const int prefix = __popcll(bal & ((1ull << lane) - 1ull));
+                    if (lane == 0 && wv < 2) mcnt[wv] = __popcll(bal);
+                    __syncthreads();
+                    if (f) mlist[(wv == 1 ? mcnt[0] : 0) + prefix] = (unsigned short)code;
+                    __syncthreads();
+                    nmirror = mcnt[0] + mcnt[1];
+                }
+            }
+        }
+        if (live && !nostage) commit(chunk);
+        if (!wres && live) load_weights(chunk, wl0);
+        __syncthreads();
+
+        // ---- next step: advance the brick coordinates incrementally, get its loads in flight
+        int n_chunk = chunk + 1, n_tw = tw_, n_th = th_, n_td = td_;
+        if (n_chunk == nchunk) {
+            n_chunk = 0;
+            if (++brick_i < nbricks) {
+                const int code = bricktab[brick_i];
+                n_tw = code & 1023; n_th = (code >> 10) & 1023; n_td = code >> 20;
+            }
+        }
+        if (step + 1 < nsteps && ((chunk_live >> n_chunk) & 1u) && !nostage) fetch(n_chunk, n_td * TD, n_th * TH, n_tw * TW);
+
+        if (DG && MT == 1 && chunk == nchunk - 1) {
+            const EpiDesc& e = edesc[g];
+            if (e.ok && e.has_stats) {
+                const int vox0 = ((o0d + ld_) * Sh + o0h + lh0) * Sw + o0w + lw;
+                const bool inw = (o0d + ld_ < Sd) && (o0w + lw < Sw);
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) {
+                    xpre[nt] = make_uint2(0u, 0u);
+                    if (inw && o0h + lh[nt] < Sh) xpre[nt] = *reinterpret_cast<const uint2*>(e.x + (long)(vox0 + nt * 2 * Sw) * e.C);
+                }
+            }
+        }
+        if (live && !(p.dbg & 2)) {
+            const char* bbase = lds + pos0;
+            const char* abase = reinterpret_cast<const char*>(wl) + wlane;
+#pragma unroll
+            for (int s = 0; s < G::NSTEP; ++s) {
+                int toff;
+                if (NC8 == 1) {
+                    toff = toffv[s];
+                } else {                              // tap s, block g (already in pos0): a compile-time offset
+                    int td = 0, th = 0, tw = 0;
+                    if (KS == 3) { td = s / 9; th = (s / 3) % 3; tw = s % 3; }
+                    if (DG && KS == 3) { td = 2 - td; th = 2 - th; tw = 2 - tw; }
+                    toff = ((td * G::IH + th) * G::IW + tw) * VS;
+                }
+                bf16x8 a[MT];
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+                    a[mt] = *reinterpret_cast<const bf16x8*>(abase + s * (4 * MT * 256) + mt * 256);
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) {
+                    const bf16x8 bv = *reinterpret_cast<const bf16x8*>(bbase + toff + nt * (2 * G::IW * VS));
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mt], bv, acc[mt][nt], 0, 0, 0);
+                }
+            }
+
+            // ---- mirror taps (adjoint of reflect padding); only bricks touching planes 1 / Sin-2.  The brick's
+            // list of (tap, block) pairs is packed four per MFMA step exactly like the regular taps.
+            if (nmirror > 0) {
+                const int P = nmirror * NC8;
+                auto prep = [&](int s2, bf16x8 (&am)[MT], int (&mpos)[4], bool (&mval)[4]) {
+                    const int pr = s2 * 4 + g;
+                    const int ent = pr / NC8, blk = pr % NC8;
+                    const bool pv = (ent < nmirror) && (cb8 + blk < K8);
+                    const int code = mlist[pv ? ent : 0];
+                    const int cd = mtab[0][code & 7][ld_], cw = mtab[2][(code >> 6) & 7][lw];
+                    const int ah = (code >> 3) & 7;
+                    int thp = 0;
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt) {
+                        const int ch = mtab[1][ah][lh[nt]];
+                        thp = ch & 3;
+                        mval[nt] = pv && (cd & 4) && (ch & 4) && (cw & 4);
+                        mpos[nt] = mval[nt] ? (((cd >> 3) * G::IH + (ch >> 3)) * G::IW + (cw >> 3)) * VS + blk * 16 : 0;
+                    }
+                    const int tap = ((cd & 3) * KS + thp) * KS + (cw & 3);
+                    // the mirror terms reuse the weights of regular taps, already in LDS:
+                    // pair q = tap * NC8 + blk sits at wl[(q * MT + mt) * 16 + row]
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) am[mt] = pv ? wl[((tap * NC8 + blk) * MT + mt) * 16 + n] : zero8();
+                };
+                bf16x8 am[MT]; int mpos[4]; bool mval[4];
+                prep(0, am, mpos, mval);
+                for (int s2 = 0; s2 * 4 < P; ++s2) {
+                    bf16x8 am_n[MT]; int mpos_n[4]; bool mval_n[4];
+                    const bool more_m = (s2 + 1) * 4 < P;
+                    if (more_m) prep(s2 + 1, am_n, mpos_n, mval_n);
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt) {
+                        bf16x8 bv = zero8();
+                        if (mval[nt]) bv = *reinterpret_cast<const bf16x8*>(lds + mpos[nt]);
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt)
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am[mt], bv, acc[mt][nt], 0, 0, 0);
+                    }
+                    if (more_m) {
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt) am[mt] = am_n[mt];
+#pragma unroll
+                        for (int nt = 0; nt < 4; ++nt) { mpos[nt] = mpos_n[nt]; mval[nt] = mval_n[nt]; }
+                    }
+                }
+            }
+        }
+
+        if (chunk == nchunk - 1 && !(p.dbg & 4)) {
+            const int oh4[4] = {o0h + lh[0], o0h + lh[1], o0h + lh[2], o0h + lh[3]};
+            if (DG) {
+                // back through LeakyReLU / mask; the InstanceNorm-backward sums accumulate in registers
+                const int vox0 = ((o0d + ld_) * Sh + o0h + lh0) * Sw + o0w + lw;
+                const bool inw = (o0d + ld_ < Sd) && (o0w + lw < Sw);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    const EpiDesc& e = edesc[mt * 4 + g];
+                    if (!e.ok) continue;
+                    f32x4 mean, rstd;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { mean[j] = e.mean[j]; rstd[j] = e.rstd[j]; }
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt) {
+                        if (!(inw && oh4[nt] < Sh)) continue;
+                        const long off = (long)(vox0 + nt * 2 * Sw) * e.C;
+                        f32x4 gv = acc[mt][nt];
+                        if (e.has_stats) {
+                            uint2 xr;
+                            if (MT == 1) xr = xpre[nt];
+                            else xr = *reinterpret_cast<const uint2*>(e.x + off);
+                            const float xv[4] = {__uint_as_float(xr.x << 16), __uint_as_float(xr.x & 0xffff0000u),
+                                                 __uint_as_float(xr.y << 16), __uint_as_float(xr.y & 0xffff0000u)};
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                const float xh = (xv[j] - mean[j]) * rstd[j];
+                                const float gg = gv[j] * (xh > 0.f ? 1.f : p.slope) * e.mval;
+                                gv[j] = gg;
+                                s1[mt][j] += gg;
+                                s2v[mt][j] += gg * xh;
+                            }
+                        } else {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) gv[j] *= e.mval;
+                        }
+                        store4(e.dx + off, gv);
+                    }
+                }
+            } else if (o0d + TD <= Sd && o0h + TH <= Sh && o0w + TW <= Sw) {       // whole brick inside: no per-lane bounds
+                bf16_t* y = reinterpret_cast<bf16_t*>(p.y);
+                const bf16_t* res = reinterpret_cast<const bf16_t*>(p.residual);
+                const long basevox = (((long)b * Sd + o0d) * Sh + o0h) * Sw + o0w + lanevox0;
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    const int co = (mg * MT + mt) * 16 + g * 4;
+                    if (co >= p.Cout) continue;
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt) {
+                        const long e = (basevox + nt * 2 * Sw) * p.Cout + co;
+                        f32x4 v = acc[mt][nt] + biasv[mt];
+                        if (res) v += load4(res + e);
+                        store4(y + e, v);
+                    }
+                }
+            } else {
+                epilogue_fwd<bf16_t, MT>(p, acc, b, mg, o0d + ld_, o0w + lw, oh4, g);
+            }
+        }
+        chunk = n_chunk; tw_ = n_tw; th_ = n_th; td_ = n_td;
+    }
+
+    if (DG) {
+        // one reduction per workgroup: 16 voxel lanes (shuffles) -> 4 waves (LDS) -> one replica of the global sums
+        __syncthreads();
+        for (int i = tid; i < MT * 16 * 2; i += 256) lsum[i] = 0.f;
+        __syncthreads();
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const bool st = edesc[mt * 4 + g].ok && edesc[mt * 4 + g].has_stats;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float a1 = group16_sum(s1[mt][j]), a2 = group16_sum(s2v[mt][j]);
+                if (n == 0 && st) {
+                    atomicAdd(&lsum[(mt * 16 + g * 4 + j) * 2 + 0], a1);
+                    atomicAdd(&lsum[(mt * 16 + g * 4 + j) * 2 + 1], a2);
+                }
+            }
+        }
+        __syncthreads();
+        for (int i = tid; i < MT * 16; i += 256) {
+            const int cg = mg * MT * 16 + i;
+            if (cg < p.Cin && (lsum[i * 2] != 0.f || lsum[i * 2 + 1] != 0.f)) {
+                float* rs = p.sums + (long)(blockIdx.x % SUMS_REP) * p.B * p.Cin * 2;
+                atomicAdd(&rs[((long)b * p.Cin + cg) * 2 + 0], lsum[i * 2 + 0]);
+                atomicAdd(&rs[((long)b * p.Cin + cg) * 2 + 1], lsum[i * 2 + 1]);
+            }
+        }
+    }
+}
+
+template <int KS, int MT, int MODE, int CKB>
+int launch_lean_one(ConvK& k, int K8, int gy, hipStream_t st) {
+    using G = GeoL<KS, CKB>;
+    constexpr int wchunk = G::NSTEP * 4 * MT * 16 * 16;
+    const int nchunk = (K8 + G::NC8 - 1) / G::NC8;
+    const int fixed = G::BRICK + DESC_BYTES;
+    k.wres = (nchunk == 1 || fixed + nchunk * wchunk <= 48 * 1024) ? 1 : 0;
+    const int bytes = fixed + (k.wres ? nchunk : 1) * wchunk;
+    // persistent workgroups: about g_conv_target of them per launch, each walking `per` consecutive bricks of one sample
+    const int tiles_per_b = k.tilesD * k.tilesH * k.tilesW;
+    const long tiles = (long)k.B * tiles_per_b;
+    int per = (int)hmax(1, (tiles * gy + g_conv_target - 1) / g_conv_target);
+    per = (int)hmin(hmin(per, tiles_per_b), 256);      // 256 = entries of the workgroup's brick table
+    k.per = per;
+    const int gx = k.B * ((tiles_per_b + per - 1) / per);
+    static int attr_bytes = 0;        // > 64 KB of dynamic LDS has to be granted per kernel
+    if (bytes > attr_bytes) {
+        HIP_RET(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_lean_kernel<KS, MT, MODE, CKB>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+        attr_bytes = bytes;
+    }
+    hipLaunchKernelGGL((conv_lean_kernel<KS, MT, MODE, CKB>), dim3(gx, gy), dim3(256), bytes, st, k);
+    LAUNCH_RET();
+    return 0;
+}
+
+template <int KS, int MODE>
+int launch_lean_geo(ConvK& k, int K8, int cmax, int mtiles, hipStream_t st) {
+    const long tiles = (long)k.B * k.tilesD * k.tilesH * k.tilesW;
+    if (cmax >= 32) {                 // 32-channel chunks; weight fragments of a chunk fit LDS up to two row tiles
+        int MT = (mtiles % 2 == 0) ? 2 : 1;
+        while (MT > 1 && tiles * (mtiles / MT) < 512) MT >>= 1;
+        if (MT == 2) return launch_lean_one<KS, 2, MODE, 32>(k, K8, mtiles / 2, st);
+        return launch_lean_one<KS, 1, MODE, 32>(k, K8, mtiles, st);
+    }
+    int MT = mtiles >= 4 ? 4 : mtiles;
+    if (mtiles % MT) MT = (mtiles % 2 == 0) ? 2 : 1;
+    while (MT > 1 && tiles * (mtiles / MT) < 512) MT >>= 1;
+    if (MT == 4) return launch_lean_one<KS, 4, MODE, 8>(k, K8, mtiles / 4, st);
+    if (MT == 2) return launch_lean_one<KS, 2, MODE, 8>(k, K8, mtiles / 2, st);
+    return launch_lean_one<KS, 1, MODE, 8>(k, K8, mtiles, st);
+}
+
+}  // namespace
+
+namespace pconv {
+
+// returns 0 = launched, < 0 = HIP error, 1 = shape not covered (caller falls back to the general kernel)
+int launch_conv_lean(ConvK& k, int ksize, int stride, bool dgrad, const void* packed_bf16, hipStream_t st) {
+    if (stride != 1) return 1;
+    const int ntap = ksize * ksize * ksize;
+    int K8, cmax = 0;
+    if (dgrad) {
+        if (k.Cout % 8) return 1;
+        K8 = k.Cout / 8;
+        cmax = k.Cout;
+    } else {
+        K8 = 0;
+        for (int s = 0; s < k.nseg; ++s) {
+            if (k.seg[s].C % 8) return 1;
+            K8 += k.seg[s].C / 8;
+            cmax = k.seg[s].C > cmax ? k.seg[s].C : cmax;
+        }
+        if (K8 * 8 != k.Cin) return 1;
+    }
+    if (K8 > MAXBLK) return 1;
+    if (dgrad) {
+        k.Mpad = pad16(k.Cin);
+        k.wpack = reinterpret_cast<const bf16_t*>(packed_bf16) + (long)ntap * pad8(k.Cin) * pad16(k.Cout);
+    } else {
+        k.Mpad = pad16(k.Cout);
+        k.wpack = packed_bf16;
+    }
+    k.dbg = g_conv_dbg;
+    const int mtiles = k.Mpad / 16;
+    if (ksize == 1) return dgrad ? launch_lean_geo<1, 1>(k, K8, cmax, mtiles, st) : launch_lean_geo<1, 0>(k, K8, cmax, mtiles, st);
+    return dgrad ? launch_lean_geo<3, 1>(k, K8, cmax, mtiles, st) : launch_lean_geo<3, 0>(k, K8, cmax, mtiles, st);
+}
+
+}  // namespace pconv
