@@ -77,6 +77,9 @@ int64_t passion_conv_pack_floats(int Cin, int Cout, int ksize);
 /* weight: f32 [Cout][Cin][k][k][k] (the reference nn.Conv3d layout) -> packed workspace. */
 int passion_conv_pack_weight(const float* weight, int Cin, int Cout, int ksize, float* packed,
                              void* stream);
+/* the same for n weights in one launch (all conv weights are re-packed once per optimizer step) */
+int passion_conv_pack_weights(int n, const float* const* weights, const int* Cin, const int* Cout,
+                              const int* ksize, float* const* packed, void* stream);
 /* y[b][vo][co] = bias[co] + residual + sum_{tap,ci} W * act(x_padded).  residual may be NULL. */
 int passion_conv3d_fwd(const passion_conv_desc_t* d, const float* packed, const float* bias,
                        const void* residual, void* y, void* stream);
@@ -96,8 +99,11 @@ int passion_conv3d_bwd(const passion_conv_desc_t* d, const float* packed, const 
  * (code/models/mmformer.py:70,143,366-370).  x: [B][D][H][W][C] -> y: [B][kD][kH][kW][C]. */
 int passion_upsample_fwd(const void* x, void* y, int dtype, int B, int D, int H, int W, int C,
                          int k, void* stream);
+/* backward: k <= 2 one gather pass (scratch unused, may be NULL); k > 2 three separable passes through
+ * `scratch` (passion_upsample_bwd_scratch_floats floats; NULL falls back to the one-pass gather). */
+int64_t passion_upsample_bwd_scratch_floats(int B, int D, int H, int W, int C, int k);
 int passion_upsample_bwd(const void* dy, void* dx, int dtype, int B, int D, int H, int W, int C,
-                         int k, void* stream);
+                         int k, float* scratch, void* stream);
 
 /* ---- layout / softmax -----------------------------------------------------------------------
  * softmax over the class axis (nn.Softmax(dim=1), mmformer.py:91,543,635; criterions.py:93-94

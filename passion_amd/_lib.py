@@ -43,14 +43,16 @@ SIGNATURES = {
     "passion_conv_pack_floats": (c_int64, [c_int, c_int, c_int]),
     "passion_conv_bwd_scratch_floats": (c_int64, [POINTER(ConvDesc)]),
     "passion_conv_pack_weight": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "passion_conv_pack_weights": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "passion_conv3d_fwd": (c_int, [POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p,
                                    c_void_p]),
     "passion_conv3d_bwd": (c_int, [POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p,
                                    c_void_p, c_void_p]),
     "passion_upsample_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
                                      c_int, c_void_p]),
+    "passion_upsample_bwd_scratch_floats": (c_int64, [c_int, c_int, c_int, c_int, c_int, c_int]),
     "passion_upsample_bwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
-                                     c_int, c_void_p]),
+                                     c_int, c_void_p, c_void_p]),
     "passion_softmax_fwd": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int64,
                                     c_int64, c_int64, c_int, c_int64, c_int, c_float, c_void_p]),
     "passion_softmax_bwd": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int64,

@@ -230,8 +230,16 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvK p) {
 template <typename T>
 __global__ void in_bwd_finish_kernel(T* __restrict__ dx, const T* __restrict__ x, const float* __restrict__ stats,
                                      const float* __restrict__ sums, const uint8_t* mask, int mask_col, int mask_ld,
-                                     long V, int C, long bstride, int Cin_tot, int cbase, int bmod) {
+                                     long V, int C, long bstride, int Cin_tot, int cbase, int bmod, int rep, long rep_stride) {
+    // the dgrad kernel left `rep` replicas of (sum g, sum g*xhat); fold this segment's channels once per block
+    __shared__ float fs[512];
     const int b = blockIdx.y;
+    for (int i = threadIdx.x; i < 2 * C && i < 512; i += blockDim.x) {
+        float a = 0.f;
+        for (int r = 0; r < rep; ++r) a += sums[(long)r * rep_stride + ((long)b * Cin_tot + cbase) * 2 + i];
+        fs[i] = a;
+    }
+    __syncthreads();
     const long nvec = V * C / 4;
     const float invV = 1.0f / (float)V;
     const bool present = mask ? (mask[(long)b * mask_ld + mask_col] != 0) : true;
@@ -248,8 +256,9 @@ __global__ void in_bwd_finish_kernel(T* __restrict__ dx, const T* __restrict__ x
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const float mean = stats[((long)bs * C + c + j) * 2 + 0], rstd = stats[((long)bs * C + c + j) * 2 + 1];
-                const float m1 = sums[((long)b * Cin_tot + cbase + c + j) * 2 + 0] * invV;
-                const float m2 = sums[((long)b * Cin_tot + cbase + c + j) * 2 + 1] * invV;
+                const int ci = (c + j) * 2;           // channels >= 256 (host pre-folded them: rep == 1) come from global
+                const float m1 = (ci < 512 ? fs[ci] : sums[((long)b * Cin_tot + cbase) * 2 + ci]) * invV;
+                const float m2 = (ci < 512 ? fs[ci + 1] : sums[((long)b * Cin_tot + cbase) * 2 + ci + 1]) * invV;
                 const float xh = (xv[j] - mean) * rstd;
                 g[j] = rstd * (g[j] - m1 - xh * m2);
             }
@@ -374,7 +383,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(ConvK p, float* __restr
     // flush: lane holds rows co = (mg*MT+mt)*16 + kq*4 + r, column n of each of its tiles.  Every workgroup owns
     // slot blockIdx.x of the partial-sum slab (plain stores, no atomics); reduce_parts_kernel folds the slots.
     if (dW) {
-        dW += (long)blockIdx.x * p.Cout * p.Cin * NTAP;
+        dW += (long)blockIdx.x * p.wslot;
 #pragma unroll
         for (int j = 0; j < WG_NTW; ++j) {
             if (!colok[j]) continue;
@@ -397,20 +406,20 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(ConvK p, float* __restr
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int co = (mg * MT + mt) * 16 + kq * 4 + r;
-                if (co < p.Cout) dbias[(long)blockIdx.x * p.Cout + co] = accb[mt][r];
+                if (co < p.Cout) dbias[(long)blockIdx.x * p.wslot + co] = accb[mt][r];
             }
     }
 }
 
-// out[i] = sum_{r < R} part[r * n + i], fixed summation order.  256 threads = 16 outputs x 16 slices of r.
-__global__ __launch_bounds__(256) void reduce_parts_kernel(const float* __restrict__ part, int R, long n,
+// out[i] = sum_{r < R} part[r * stride + i], fixed summation order.  256 threads = 16 outputs x 16 slices of r.
+__global__ __launch_bounds__(256) void reduce_parts_kernel(const float* __restrict__ part, int R, long n, long stride,
                                                            float* __restrict__ out) {
     __shared__ float red[16][17];
     const int li = threadIdx.x & 15, sl = threadIdx.x >> 4;
     const long i = (long)blockIdx.x * 16 + li;
     float a = 0.f;
     if (i < n)
-        for (int r = sl; r < R; r += 16) a += part[(long)r * n + i];
+        for (int r = sl; r < R; r += 16) a += part[(long)r * stride + i];
     red[sl][li] = a;
     __syncthreads();
     if (sl == 0 && i < n) {
@@ -567,14 +576,75 @@ extern "C" int64_t passion_conv_pack_floats(int Cin, int Cout, int ksize) {
 }
 
 extern "C" int passion_conv_pack_weight(const float* weight, int Cin, int Cout, int ksize, float* packed, void* stream) {
-    const int nt = ksize * ksize * ksize;
-    const long nf = (long)nt * Cin * pad16(Cout);
-    const long total = nf + (long)nt * Cout * pad16(Cin);   // f32 images; the bf16 images follow
-    const int blocks = (int)hmin((total + 255) / 256, 1024);
-    hipLaunchKernelGGL(pack_weight_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, weight, Cin, Cout, nt,
-                       pad16(Cout), pad16(Cin), packed, packed + nf);
-    LAUNCH_RET();
-    return pack_weight_bf16(weight, Cin, Cout, nt, packed + total, (hipStream_t)stream);
+    const float* ws[1] = {weight};
+    float* outs[1] = {packed};
+    return passion_conv_pack_weights(1, ws, &Cin, &Cout, &ksize, outs, stream);
+}
+
+// Every conv weight is re-packed once per optimizer step: ~110 tensors, a few microseconds of work each -- as
+// separate launches that is 220 dispatches per step, so up to PACK_MAX weights share one launch (blockIdx.y = weight).
+constexpr int PACK_MAX = 48;
+struct PackEnt { const float* w; float* out; int Cin, Cout, ntap, pad_; };
+struct PackTable { PackEnt e[PACK_MAX]; };
+
+__global__ __launch_bounds__(256) void pack_multi_kernel(PackTable t) {
+    const PackEnt& q = t.e[blockIdx.y];
+    const int Cin = q.Cin, Cout = q.Cout, ntap = q.ntap;
+    const int CoutPad = pad16(Cout), CinPad = pad16(Cin);
+    const long nf = (long)ntap * Cin * CoutPad, nd = (long)ntap * Cout * CinPad;        // f32 images
+    const int ci8 = pad8(Cin), co8 = pad8(Cout);
+    const long bf = (long)ntap * ci8 * CoutPad, bd = (long)ntap * co8 * CinPad;         // bf16 images (follow the f32 ones)
+    float* fwd = q.out;
+    float* dg = q.out + nf;
+    bf16_t* bfwd = reinterpret_cast<bf16_t*>(q.out + nf + nd);
+    bf16_t* bdg = bfwd + bf;
+    const float* w = q.w;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nf + nd + bf + bd; i += (long)gridDim.x * blockDim.x) {
+        if (i < nf) {                       // [tap][Cin][CoutPad]
+            const int co = (int)(i % CoutPad);
+            const int ci = (int)((i / CoutPad) % Cin);
+            const int tap = (int)(i / ((long)CoutPad * Cin));
+            fwd[i] = (co < Cout) ? w[((long)co * Cin + ci) * ntap + tap] : 0.f;
+        } else if (i < nf + nd) {           // [tap][Cout][CinPad]
+            const long k = i - nf;
+            const int ci = (int)(k % CinPad);
+            const int co = (int)((k / CinPad) % Cout);
+            const int tap = (int)(k / ((long)CinPad * Cout));
+            dg[k] = (ci < Cin) ? w[((long)co * Cin + ci) * ntap + tap] : 0.f;
+        } else if (i < nf + nd + bf) {      // bf16 [tap][CinPad8/8][CoutPad16][8]
+            const long k = i - nf - nd;
+            const int e = (int)(k % 8);
+            const int co = (int)((k / 8) % CoutPad);
+            const int cb = (int)((k / (8L * CoutPad)) % (ci8 / 8));
+            const int tap = (int)(k / (8L * CoutPad * (ci8 / 8)));
+            const int ci = cb * 8 + e;
+            bfwd[k] = (bf16_t)((co < Cout && ci < Cin) ? w[((long)co * Cin + ci) * ntap + tap] : 0.f);
+        } else {                            // bf16 [tap][CoutPad8/8][CinPad16][8]
+            const long k = i - nf - nd - bf;
+            const int e = (int)(k % 8);
+            const int ci = (int)((k / 8) % CinPad);
+            const int cb = (int)((k / (8L * CinPad)) % (co8 / 8));
+            const int tap = (int)(k / (8L * CinPad * (co8 / 8)));
+            const int co = cb * 8 + e;
+            bdg[k] = (bf16_t)((co < Cout && ci < Cin) ? w[((long)co * Cin + ci) * ntap + tap] : 0.f);
+        }
+    }
+}
+
+extern "C" int passion_conv_pack_weights(int n, const float* const* weights, const int* Cin, const int* Cout, const int* ksize,
+                                         float* const* packed, void* stream) {
+    for (int i0 = 0; i0 < n; i0 += PACK_MAX) {
+        PackTable t;
+        const int m = (n - i0 < PACK_MAX) ? n - i0 : PACK_MAX;
+        for (int i = 0; i < m; ++i) {
+            const int ks = ksize[i0 + i];
+            if (ks != 1 && ks != 3) return -1002;
+            t.e[i] = PackEnt{weights[i0 + i], packed[i0 + i], Cin[i0 + i], Cout[i0 + i], ks * ks * ks, 0};
+        }
+        hipLaunchKernelGGL(pack_multi_kernel, dim3(32, m), dim3(256), 0, (hipStream_t)stream, t);
+        LAUNCH_RET();
+    }
+    return 0;
 }
 
 extern "C" int passion_conv3d_fwd(const passion_conv_desc_t* d, const float* packed, const float* bias,
@@ -619,8 +689,9 @@ extern "C" int passion_conv3d_bwd(const passion_conv_desc_t* d, const float* pac
         k.Mpad = pad16(k.Cout);
         const WgPlan w = plan_wgrad(k, d);
         const long nW = (long)k.Cout * k.Cin * nt;
+        k.wslot = nW + k.Cout;                       // one slot = [dW | dbias] of one workgroup
         float* wslab = sums + (long)2 * k.B * k.Cin * SUMS_REP;
-        float* bslab = wslab + (long)w.gx * nW;
+        float* bslab = wslab + nW;
         {
             ProfScope prof(3, conv_bytes(k, xs, ys) + (double)nt * k.Cin * k.Cout * 4,
                            2.0 * k.B * k.Do * k.Ho * k.Wo * (double)k.Cout * k.Cin * nt, st);
@@ -638,13 +709,19 @@ extern "C" int passion_conv3d_bwd(const passion_conv_desc_t* d, const float* pac
                 rc = -1007;
             if (rc) return rc;
         }
-        if (dweight) {
-            hipLaunchKernelGGL(reduce_parts_kernel, dim3((unsigned)((nW + 15) / 16)), dim3(256), 0, st, wslab, w.gx, nW, dweight);
+        if (dweight && dbias == dweight + nW) {      // caller keeps [dW | dbias] in one buffer: one fold for both
+            hipLaunchKernelGGL(reduce_parts_kernel, dim3((unsigned)((k.wslot + 15) / 16)), dim3(256), 0, st, wslab, w.gx, k.wslot,
+                               k.wslot, dweight);
             LAUNCH_RET();
-        }
-        if (dbias) {
-            hipLaunchKernelGGL(reduce_parts_kernel, dim3((k.Cout + 15) / 16), dim3(256), 0, st, bslab, w.gx, (long)k.Cout, dbias);
-            LAUNCH_RET();
+        } else {
+            if (dweight) {
+                hipLaunchKernelGGL(reduce_parts_kernel, dim3((unsigned)((nW + 15) / 16)), dim3(256), 0, st, wslab, w.gx, nW, k.wslot, dweight);
+                LAUNCH_RET();
+            }
+            if (dbias) {
+                hipLaunchKernelGGL(reduce_parts_kernel, dim3((k.Cout + 15) / 16), dim3(256), 0, st, bslab, w.gx, (long)k.Cout, k.wslot, dbias);
+                LAUNCH_RET();
+            }
         }
     }
     // ---- dgrad ----
@@ -660,6 +737,7 @@ extern "C" int passion_conv3d_bwd(const passion_conv_desc_t* d, const float* pac
         HIP_RET(hipMemsetAsync(sums, 0, sizeof(float) * 2 * (size_t)k.B * k.Cin * SUMS_REP, st));
     }
     k.sums = sums;
+    k.sums_rep = SUMS_REP;                           // the lean launcher lowers it
     k.Mpad = pad16(k.Cin);
     k.wpack = packed + (long)nt * k.Cin * pad16(k.Cout);
     k.tilesD = cdiv(k.Di, TD); k.tilesH = cdiv(k.Hi, TH); k.tilesW = cdiv(k.Wi, TW);
@@ -682,10 +760,13 @@ extern "C" int passion_conv3d_bwd(const passion_conv_desc_t* d, const float* pac
             rc = -1007;
         if (rc) return rc;
     }
-    if (need_norm) {
+    int rep = k.sums_rep;
+    for (int s = 0; s < k.nseg; ++s) if (k.seg[s].C > 256) rep = SUMS_REP;   // finish kernel folds in LDS: 2 * C floats
+    if (need_norm && rep > SUMS_REP_LEAN) {          // many replicas: fold them first (in place, replica 0)
         const int nw = 2 * k.B * k.Cin;
-        hipLaunchKernelGGL(reduce_parts_kernel, dim3((nw + 15) / 16), dim3(256), 0, st, sums, SUMS_REP, (long)nw, sums);
+        hipLaunchKernelGGL(reduce_parts_kernel, dim3((nw + 15) / 16), dim3(256), 0, st, sums, k.sums_rep, (long)nw, (long)nw, sums);
         LAUNCH_RET();
+        rep = 1;
     }
     // ---- InstanceNorm backward finish (in place on dx) ----
     const long V = (long)k.Di * k.Hi * k.Wi;
@@ -696,11 +777,12 @@ extern "C" int passion_conv3d_bwd(const passion_conv_desc_t* d, const float* pac
         dim3 grid((unsigned)hmin((nvec + 255) / 256, 2048), k.B);
         if (d->x_dtype == PASSION_F32)
             hipLaunchKernelGGL(in_bwd_finish_kernel<float>, grid, dim3(256), 0, st, (float*)sg.dx, (const float*)sg.x,
-                               sg.stats, sums, sg.mask, sg.mask_col, sg.mask_ld, V, sg.C, sg.bstride, k.Cin, sg.cbase, sg.bmod);
+                               sg.stats, sums, sg.mask, sg.mask_col, sg.mask_ld, V, sg.C, sg.bstride, k.Cin, sg.cbase, sg.bmod,
+                               rep, (long)2 * k.B * k.Cin);
         else
             hipLaunchKernelGGL(in_bwd_finish_kernel<bf16_t>, grid, dim3(256), 0, st, (bf16_t*)sg.dx,
                                (const bf16_t*)sg.x, sg.stats, sums, sg.mask, sg.mask_col, sg.mask_ld, V, sg.C,
-                               sg.bstride, k.Cin, sg.cbase, sg.bmod);
+                               sg.bstride, k.Cin, sg.cbase, sg.bmod, rep, (long)2 * k.B * k.Cin);
         LAUNCH_RET();
     }
     return 0;

@@ -603,7 +603,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(ConvK p, float* __
         }
     }
     if (dW) {
-        dW += (long)blockIdx.x * p.Cout * p.Cin * NTAP;      // this workgroup's slot of the partial-sum slab
+        dW += (long)blockIdx.x * p.wslot;                    // this workgroup's slot of the partial-sum slab
 #pragma unroll
         for (int j = 0; j < NTW; ++j) {
             const int nt = (KSPLIT == 1) ? wv + 4 * j : j;
@@ -628,7 +628,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(ConvK p, float* __
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int co = (mg * MT + mt) * 16 + g * 4 + r;
-                if (co < p.Cout) dbias[(long)blockIdx.x * p.Cout + co] = accb[mt][r];
+                if (co < p.Cout) dbias[(long)blockIdx.x * p.wslot + co] = accb[mt][r];
             }
     }
 }

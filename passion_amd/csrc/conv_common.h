@@ -9,7 +9,8 @@
 
 namespace pconv {
 
-constexpr int SUMS_REP = 256;           // replicas of the InstanceNorm-backward sums (atomic contention)
+constexpr int SUMS_REP = 256;           // replicas of the InstanceNorm-backward sums (atomic contention): one-brick-per-workgroup kernels
+constexpr int SUMS_REP_LEAN = 16;       // persistent kernels add once per workgroup: few replicas, folded by the finish kernel itself
 constexpr int TD = 4, TH = 8, TW = 8;   // output brick of one 256-thread workgroup (wave w = depth slice w)
 
 struct SegD {
@@ -38,6 +39,8 @@ struct ConvK {
     float* sums;
     int tilesD, tilesH, tilesW;
     int hi_t[3], hi_u[3];  // dgrad reflect: tap / source coordinate of the high-side mirror term per axis
+    long wslot;            // wgrad: floats per workgroup slot of the partial slab ([dW | dbias])
+    int sums_rep;          // dgrad: replicas of the InstanceNorm-backward sums this launch spreads its atomics over
     int per, wres;         // bf16 kernel: bricks per (persistent) workgroup; all chunks' weight fragments resident in LDS
     int dbg;               // developer timing switch (PASSION_CONV_DBG): bit0 skip staging, bit1 skip MFMA loop, bit2 skip epilogue
 };
@@ -178,7 +181,7 @@ __device__ __forceinline__ void epilogue_dgrad(const ConvK& p, const f32x4 (&acc
         const int cg = mg * MT * 16 + i;
         if (cg < p.Cin && (lsum[i * 2] != 0.f || lsum[i * 2 + 1] != 0.f)) {
             // thousands of bricks add into the same 2*Cin words: spread them over SUMS_REP replicas (folded afterwards)
-            float* rs = p.sums + (long)(blockIdx.x % SUMS_REP) * p.B * p.Cin * 2;
+            float* rs = p.sums + (long)(blockIdx.x % p.sums_rep) * p.B * p.Cin * 2;
             atomicAdd(&rs[((long)b * p.Cin + cg) * 2 + 0], lsum[i * 2 + 0]);
             atomicAdd(&rs[((long)b * p.Cin + cg) * 2 + 1], lsum[i * 2 + 1]);
         }

@@ -544,7 +544,7 @@ __global__ __launch_bounds__(256) void conv_lean_kernel(ConvK p) {
         for (int i = tid; i < MT * 16; i += 256) {
             const int cg = mg * MT * 16 + i;
             if (cg < p.Cin && (lsum[i * 2] != 0.f || lsum[i * 2 + 1] != 0.f)) {
-                float* rs = p.sums + (long)(blockIdx.x % SUMS_REP) * p.B * p.Cin * 2;
+                float* rs = p.sums + (long)(blockIdx.x % p.sums_rep) * p.B * p.Cin * 2;
                 atomicAdd(&rs[((long)b * p.Cin + cg) * 2 + 0], lsum[i * 2 + 0]);
                 atomicAdd(&rs[((long)b * p.Cin + cg) * 2 + 1], lsum[i * 2 + 1]);
             }
@@ -626,6 +626,7 @@ int launch_conv_lean(ConvK& k, int ksize, int stride, bool dgrad, const void* pa
         k.wpack = packed_bf16;
     }
     k.dbg = g_conv_dbg;
+    k.sums_rep = SUMS_REP_LEAN;
     const int mtiles = k.Mpad / 16;
     if (ksize == 1) return dgrad ? launch_lean_geo<1, 1>(k, K8, cmax, mtiles, st) : launch_lean_geo<1, 0>(k, K8, cmax, mtiles, st);
     return dgrad ? launch_lean_geo<3, 1>(k, K8, cmax, mtiles, st) : launch_lean_geo<3, 0>(k, K8, cmax, mtiles, st);

@@ -110,6 +110,53 @@ __global__ __launch_bounds__(256) void upsample_bwd_kernel(const T* __restrict__
     }
 }
 
+// k > 2: the adjoint is separable (A_d x A_h x A_w), so it is applied one axis at a time, W first (the contiguous and
+// largest reduction): [outer][No][inner] -> [outer][Ni][inner], one thread per output (4-channel vector), which sums
+// the ~2k inputs along the axis that reference it.  Three passes read dy once and 1/k, 1/k^2 of it again -- the
+// one-pass gather over the (2k+3)^3 candidate window took 250-500 us for the k = 4/8/16 deep-supervision maps.
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void upsample_bwd_axis_kernel(const TI* __restrict__ in, TO* __restrict__ out, long outer,
+                                                                int Ni, int No, long inner) {
+    const float sc = axis_scale(Ni, No);
+    const long total = outer * Ni * inner;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const long iv = idx % inner;
+        const int i = (int)((idx / inner) % Ni);
+        const long o_ = idx / (inner * Ni);
+        int lo, hi;
+        axis_range(i, sc, No, lo, hi);
+        const TI* base = in + ((o_ * No) * inner + iv) * 4;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int o = lo; o <= hi; ++o) {
+            const float w = axis_weight(o, i, sc, Ni);
+            if (w != 0.f) acc += w * load4(base + (long)o * inner * 4);
+        }
+        store4(out + idx * 4, acc);
+    }
+}
+
+template <typename TI, typename TO>
+int launch_axis(const TI* in, TO* out, long outer, int Ni, int No, long inner, hipStream_t st) {
+    const long total = outer * Ni * inner;
+    const int blocks = (int)hmin((total + 255) / 256, 16384);
+    hipLaunchKernelGGL((upsample_bwd_axis_kernel<TI, TO>), dim3(blocks), dim3(256), 0, st, in, out, outer, Ni, No, inner);
+    LAUNCH_RET();
+    return 0;
+}
+
+template <typename T>
+int upsample_bwd_separable(const T* dy, T* dx, int B, int D, int H, int W, int C, int k, float* scratch, hipStream_t st) {
+    const int Do = D * k, Ho = H * k, Wo = W * k;
+    const long cv = C / 4;
+    float* t1 = scratch;                                   // [B][Do][Ho][W][C]
+    float* t2 = scratch + (long)B * Do * Ho * W * C;       // [B][Do][H][W][C]
+    int rc = launch_axis<T, float>(dy, t1, (long)B * Do * Ho, W, Wo, cv, st);
+    if (rc) return rc;
+    rc = launch_axis<float, float>(t1, t2, (long)B * Do, H, Ho, (long)W * cv, st);
+    if (rc) return rc;
+    return launch_axis<float, T>(t2, dx, (long)B, D, Do, (long)H * W * cv, st);
+}
+
 // k <= 2: one thread per (input voxel, 4-channel vector).  At most 5 output indices per axis can reference an
 // input index; their weights are evaluated once per axis (15 evaluations) instead of once per candidate triple.
 template <typename T>
@@ -176,9 +223,20 @@ extern "C" int passion_upsample_fwd(const void* x, void* y, int dtype, int B, in
     return 0;
 }
 
+extern "C" int64_t passion_upsample_bwd_scratch_floats(int B, int D, int H, int W, int C, int k) {
+    if (k <= 2) return 0;
+    return (int64_t)B * D * k * H * k * W * C + (int64_t)B * D * k * H * W * C;
+}
+
 extern "C" int passion_upsample_bwd(const void* dy, void* dx, int dtype, int B, int D, int H, int W, int C, int k,
-                                    void* stream) {
+                                    float* scratch, void* stream) {
     if (C % 4 || k < 1) return -1011;
+    if (k > 2 && scratch) {
+        hipStream_t st2 = (hipStream_t)stream;
+        if (dtype == PASSION_F32) return upsample_bwd_separable<float>((const float*)dy, (float*)dx, B, D, H, W, C, k, scratch, st2);
+        if (dtype == PASSION_BF16) return upsample_bwd_separable<bf16_t>((const bf16_t*)dy, (bf16_t*)dx, B, D, H, W, C, k, scratch, st2);
+        return -1007;
+    }
     const long items = (long)B * D * H * W * (C / 4);
     hipStream_t st = (hipStream_t)stream;
     if (k == 2 && D > 1 && H > 1 && W > 1) {

@@ -317,6 +317,7 @@ class Model(nn.Module):
 
     def forward(self, x, mask, target=None, temp=1.0):
         L.require_gpu(x)
+        ops.repack_stale()       # all conv weights the optimizer touched, one launch
         B, S = x.size(0), x.size(2)
         dev = x.device
         dt = self.compute_dtype

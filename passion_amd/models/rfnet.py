@@ -182,6 +182,7 @@ class Model(nn.Module):
 
     def forward(self, x, mask, target=None, temp=1.0):
         L.require_gpu(x)
+        ops.repack_stale()       # all conv weights the optimizer touched, one launch
         B = x.size(0)
         dev, dt = x.device, self.compute_dtype
         idt = self.mask_type != "pdt"

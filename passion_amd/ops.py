@@ -66,6 +66,37 @@ class _ConvCfg:
     __slots__ = ("segs", "D", "H", "W", "ksize", "stride", "pad_mode", "slope", "out_dtype", "B", "out")
 
 
+_PACK_REGISTRY = {}     # id(cache dict) -> (weakref to the weight parameter, cache dict)
+
+
+def repack_stale():
+    """Re-pack, in ONE launch, every registered conv weight whose version moved since it was packed (i.e. all of
+    them after an optimizer step) into its existing buffer.  Called at the top of Model.forward: the per-conv
+    pack_weight() calls below then all hit their caches."""
+    stale = []
+    for key in list(_PACK_REGISTRY):
+        ref, cache = _PACK_REGISTRY[key]
+        w = ref()
+        if w is None:
+            del _PACK_REGISTRY[key]
+            continue
+        if cache.get("key") != (w.data_ptr(), w._version) and w.is_cuda and w.dtype == torch.float32 and w.is_contiguous():
+            stale.append((w, cache))
+    if not stale:
+        return 0
+    n = len(stale)
+    from ctypes import c_int as _ci
+    ptrs, outs = (c_void_p * n)(), (c_void_p * n)()
+    cin, cout, ks = (_ci * n)(), (_ci * n)(), (_ci * n)()
+    for i, (w, cache) in enumerate(stale):
+        ptrs[i], outs[i] = w.data_ptr(), cache["packed"].data_ptr()
+        cout[i], cin[i], ks[i] = w.shape[0], w.shape[1], w.shape[2]
+    L.check(L.load().passion_conv_pack_weights(n, ptrs, cin, cout, ks, outs, L.stream_ptr()), "passion_conv_pack_weights")
+    for w, cache in stale:
+        cache["key"] = (w.data_ptr(), w._version)
+    return n
+
+
 def pack_weight(weight, cache=None):
     """f32 (Cout,Cin,k,k,k) -> packed MFMA operand images (fwd + dgrad); cached per weight version."""
     key = (weight.data_ptr(), weight._version)
@@ -83,6 +114,9 @@ def pack_weight(weight, cache=None):
             "passion_conv_pack_weight")
     if cache is not None:
         cache["key"], cache["packed"] = key, packed
+        if weight.is_leaf and id(cache) not in _PACK_REGISTRY:
+            import weakref
+            _PACK_REGISTRY[id(cache)] = (weakref.ref(weight), cache)
     return packed
 
 
@@ -146,8 +180,15 @@ class ConvBlockFn(torch.autograd.Function):
         need_w = ctx.needs_input_grad[1]
         need_b = ctx.has_bias and ctx.needs_input_grad[2]
         dev = dy.device
-        dW = torch.empty(ctx.wshape, dtype=torch.float32, device=dev) if need_w else None
-        db = torch.empty(ctx.wshape[0], dtype=torch.float32, device=dev) if need_b else None
+        dW = db = None
+        if need_w and need_b:      # one buffer [dW | db]: the library folds both partial slabs in one launch
+            nW = ctx.wshape.numel()
+            buf = torch.empty(nW + ctx.wshape[0], dtype=torch.float32, device=dev)
+            dW, db = buf[:nW].view(ctx.wshape), buf[nW:]
+        elif need_w:
+            dW = torch.empty(ctx.wshape, dtype=torch.float32, device=dev)
+        elif need_b:
+            db = torch.empty(ctx.wshape[0], dtype=torch.float32, device=dev)
         dxs = []
         for i, (s, x) in enumerate(zip(cfg.segs, xs)):
             if ctx.needs_input_grad[5 + i]:
@@ -236,8 +277,11 @@ class UpsampleFn(torch.autograd.Function):
         B, D, H, W, C = ctx.shape
         dy = dy.contiguous()
         dx = torch.empty(B, D, H, W, C, dtype=dy.dtype, device=dy.device)
-        L.check(L.load().passion_upsample_bwd(_p(dy), _p(dx), L.dtype_code(dy.dtype), B, D, H, W, C,
-                                              ctx.k, L.stream_ptr()), "passion_upsample_bwd")
+        lib = L.load()
+        ns = lib.passion_upsample_bwd_scratch_floats(B, D, H, W, C, ctx.k)
+        scratch = torch.empty(ns, dtype=torch.float32, device=dy.device) if ns else None
+        L.check(lib.passion_upsample_bwd(_p(dy), _p(dx), L.dtype_code(dy.dtype), B, D, H, W, C,
+                                         ctx.k, _p(scratch), L.stream_ptr()), "passion_upsample_bwd")
         return dx, None
 
 
