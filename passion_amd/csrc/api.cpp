@@ -54,7 +54,7 @@ extern "C" int passion_prof_read(passion_prof_rec_t* rec, int cap) {
 
 // A/B switch for debugging: PASSION_FORCE_F32_MFMA=1 routes bf16 tensors through the f32-MFMA conv kernels.
 extern int g_passion_force_f32_mfma;
-namespace pconv { extern int g_conv_merge, g_wgrad_wide, g_conv_dbg, g_conv_target, g_conv_lean; }
+namespace pconv { extern int g_conv_merge, g_wgrad_wide, g_conv_dbg, g_conv_target, g_conv_lean, g_conv_padout; }
 __attribute__((constructor)) static void passion_read_env() {
     const char* e = getenv("PASSION_FORCE_F32_MFMA");
     if (e && e[0] == '1') g_passion_force_f32_mfma = 1;
@@ -64,6 +64,8 @@ __attribute__((constructor)) static void passion_read_env() {
     if (e) pconv::g_conv_dbg = atoi(e);
     e = getenv("PASSION_CONV_LEAN");
     if (e && e[0] == '0') pconv::g_conv_lean = 0;
+    e = getenv("PASSION_CONV_PADOUT");
+    if (e && e[0] == '0') pconv::g_conv_padout = 0;
     e = getenv("PASSION_CONV_TARGET");
     if (e && atoi(e) > 0) pconv::g_conv_target = atoi(e);
     e = getenv("PASSION_WGRAD_WIDE");

@@ -267,6 +267,62 @@ __global__ void in_bwd_finish_kernel(T* __restrict__ dx, const T* __restrict__ x
     }
 }
 
+// The same finish for a dgrad that ran over the padded domain (conv_lean.hip MODE 2): dxp is [B][D+2][H+2][W+2][Cin_tot]
+// with the gradient of padded position op-1 at coordinate op; the reflect adjoint folds the halo planes back:
+// plane 1 also receives plane -1, plane S-2 also receives plane S (per axis, so up to 8 terms at the corners).
+template <typename T>
+__global__ void in_bwd_finish_pad_kernel(T* __restrict__ dx, const T* __restrict__ x, const T* __restrict__ dxp,
+                                         const float* __restrict__ stats, const float* __restrict__ sums, const uint8_t* mask,
+                                         int mask_col, int mask_ld, int D, int H, int W, int C, long bstride, int Cin_tot,
+                                         int cbase, int bmod, int rep, long rep_stride) {
+    __shared__ float fs[512];
+    const int b = blockIdx.y;
+    for (int i = threadIdx.x; i < 2 * C && i < 512; i += blockDim.x) {
+        float a = 0.f;
+        for (int r = 0; r < rep; ++r) a += sums[(long)r * rep_stride + ((long)b * Cin_tot + cbase) * 2 + i];
+        fs[i] = a;
+    }
+    __syncthreads();
+    const long V = (long)D * H * W;
+    const long nvec = V * C / 4;
+    const int cvn = C / 4;
+    const float invV = 1.0f / (float)V;
+    const bool present = mask ? (mask[(long)b * mask_ld + mask_col] != 0) : true;
+    const int bs = bmod > 0 ? b % bmod : b;
+    T* dxb = dx + (long)b * bstride;
+    const T* xb = x + (long)bs * bstride;
+    const T* pb = dxp + (long)b * (D + 2) * (H + 2) * (W + 2) * Cin_tot + cbase;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % cvn) * 4;
+        long v = i / cvn;
+        const int w = (int)(v % W); v /= W;
+        const int h = (int)(v % H);
+        const int d = (int)(v / H);
+        f32x4 g = {0.f, 0.f, 0.f, 0.f};
+        if (present) {
+            int dl[3], hl[3], wl[3], nd = 0, nh = 0, nw = 0;
+            dl[nd++] = d + 1; if (d == 1) dl[nd++] = 0; if (d == D - 2) dl[nd++] = D + 1;
+            hl[nh++] = h + 1; if (h == 1) hl[nh++] = 0; if (h == H - 2) hl[nh++] = H + 1;
+            wl[nw++] = w + 1; if (w == 1) wl[nw++] = 0; if (w == W - 2) wl[nw++] = W + 1;
+            for (int a = 0; a < nd; ++a)
+                for (int e = 0; e < nh; ++e)
+                    for (int f = 0; f < nw; ++f)
+                        g += load4(pb + ((((long)dl[a]) * (H + 2) + hl[e]) * (W + 2) + wl[f]) * Cin_tot + c);
+            const f32x4 xv = load4(xb + i * 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float mean = stats[((long)bs * C + c + j) * 2 + 0], rstd = stats[((long)bs * C + c + j) * 2 + 1];
+                const int ci = (c + j) * 2;
+                const float m1 = (ci < 512 ? fs[ci] : sums[((long)b * Cin_tot + cbase) * 2 + ci]) * invV;
+                const float m2 = (ci < 512 ? fs[ci + 1] : sums[((long)b * Cin_tot + cbase) * 2 + ci + 1]) * invV;
+                const float xh = (xv[j] - mean) * rstd;
+                g[j] = rstd * (g[j] - m1 - xh * m2);
+            }
+        }
+        store4(dxb + i * 4, g);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // wgrad:  dW[co][ci][tap] += sum_vox dY[vox][co] * act(x)[vox*s + tap][ci]
 // GEMM with M = out-channel, N = (ci, tap) (tap fastest: the reference weight layout), K = voxels.
@@ -561,12 +617,31 @@ double conv_bytes(const ConvK& k, int xs, int ys) {
 
 }  // namespace
 
+namespace pconv { int g_conv_padout = 1; }   // PASSION_CONV_PADOUT=0: reflect adjoint through mirror taps everywhere (A/B)
+
+// dgrad over the padded domain (conv_lean.hip MODE 2) + folding finish kernel: 3x3x3 stride-1 reflect-padded bf16 convs
+// whose every differentiated input is normalised in the loader (so the finish pass exists anyway)
+static bool use_padout(const ConvK& k, const passion_conv_desc_t* d) {
+    if (!pconv::g_conv_lean || !pconv::g_conv_padout || g_passion_force_f32_mfma) return false;
+    if (d->ksize != 3 || d->stride != 1 || d->pad_mode != PASSION_PAD_REFLECT) return false;
+    if (d->x_dtype != PASSION_BF16 || d->y_dtype != PASSION_BF16) return false;
+    if (k.Di < 2 || k.Hi < 2 || k.Wi < 2 || k.Cin % 4 || !pconv::lean_covers(k, 1, true)) return false;
+    bool any = false;
+    for (int s = 0; s < k.nseg; ++s)
+        if (k.seg[s].dx) { if (!k.seg[s].stats) return false; any = true; }
+    return any;
+}
+static long padout_floats(const ConvK& k) {     // bf16 [B][D+2][H+2][W+2][Cin]
+    return ((long)k.B * (k.Di + 2) * (k.Hi + 2) * (k.Wi + 2) * k.Cin + 1) / 2 + 4;
+}
+
 extern "C" int64_t passion_conv_bwd_scratch_floats(const passion_conv_desc_t* d) {
     ConvK k;
     if (fill_params(d, k)) return -1;
     const WgPlan w = plan_wgrad(k, d);
     const int64_t nt = (int64_t)d->ksize * d->ksize * d->ksize;
-    return (int64_t)2 * k.B * k.Cin * SUMS_REP + (int64_t)w.gx * ((int64_t)k.Cout * k.Cin * nt + k.Cout);
+    return (int64_t)2 * k.B * k.Cin * SUMS_REP + (int64_t)w.gx * ((int64_t)k.Cout * k.Cin * nt + k.Cout) +
+           (use_padout(k, d) ? padout_floats(k) : 0);
 }
 
 extern "C" int64_t passion_conv_pack_floats(int Cin, int Cout, int ksize) {
@@ -742,11 +817,26 @@ extern "C" int passion_conv3d_bwd(const passion_conv_desc_t* d, const float* pac
     k.wpack = packed + (long)nt * k.Cin * pad16(k.Cout);
     k.tilesD = cdiv(k.Di, TD); k.tilesH = cdiv(k.Hi, TH); k.tilesW = cdiv(k.Wi, TW);
     const int mtiles = k.Mpad / 16;
+    bool padout = use_padout(k, d);
+    void* dxp = nullptr;
     {
         ProfScope prof(2, conv_bytes(k, xs, ys) + (double)nt * k.Cin * k.Cout * 4,
                        2.0 * k.B * k.Do * k.Ho * k.Wo * (double)k.Cout * k.Cin * nt, st);
+        if (padout) {
+            const WgPlan w = plan_wgrad(k, d);
+            dxp = sums + (long)2 * k.B * k.Cin * SUMS_REP + (long)w.gx * ((long)k.Cout * k.Cin * nt + k.Cout);
+            k.tilesD = cdiv(k.Di + 2, TD); k.tilesH = cdiv(k.Hi + 2, TH); k.tilesW = cdiv(k.Wi + 2, TW);
+            k.y = dxp;
+            rc = launch_conv_lean(k, d->ksize, d->stride, 2, packed + f32_pack_floats(k.Cin, k.Cout, nt), st);
+            if (rc < 0) return rc;
+            if (rc > 0) {
+                padout = false;
+                k.tilesD = cdiv(k.Di, TD); k.tilesH = cdiv(k.Hi, TH); k.tilesW = cdiv(k.Wi, TW);
+            }
+        }
         // TI = dy dtype, TO = x/dx dtype
-        if (d->x_dtype == PASSION_F32 && d->y_dtype == PASSION_F32)
+        if (padout) rc = 0;
+        else if (d->x_dtype == PASSION_F32 && d->y_dtype == PASSION_F32)
             rc = launch_conv_geo<float, float, 1>(k, d->ksize, d->stride, mtiles, st);
         else if (d->x_dtype == PASSION_BF16 && d->y_dtype == PASSION_BF16) {
             if (bf16_eligible(k, true) && !g_passion_force_f32_mfma)
@@ -775,7 +865,11 @@ extern "C" int passion_conv3d_bwd(const passion_conv_desc_t* d, const float* pac
         if (!sg.dx || !sg.stats) continue;
         const long nvec = V * sg.C / 4;
         dim3 grid((unsigned)hmin((nvec + 255) / 256, 2048), k.B);
-        if (d->x_dtype == PASSION_F32)
+        if (padout) {
+            hipLaunchKernelGGL(in_bwd_finish_pad_kernel<bf16_t>, grid, dim3(256), 0, st, (bf16_t*)sg.dx, (const bf16_t*)sg.x,
+                               (const bf16_t*)dxp, sg.stats, sums, sg.mask, sg.mask_col, sg.mask_ld, k.Di, k.Hi, k.Wi, sg.C,
+                               sg.bstride, k.Cin, sg.cbase, sg.bmod, rep, (long)2 * k.B * k.Cin);
+        } else if (d->x_dtype == PASSION_F32)
             hipLaunchKernelGGL(in_bwd_finish_kernel<float>, grid, dim3(256), 0, st, (float*)sg.dx, (const float*)sg.x,
                                sg.stats, sums, sg.mask, sg.mask_col, sg.mask_ld, V, sg.C, sg.bstride, k.Cin, sg.cbase, sg.bmod,
                                rep, (long)2 * k.B * k.Cin);

@@ -746,7 +746,7 @@ bool bf16_eligible(const ConvK& k, bool dgrad) {
 
 int launch_conv_bf16(ConvK& k, int ksize, int stride, bool dgrad, const void* packed_bf16, hipStream_t st) {
     if (g_conv_lean) {                       // lean persistent kernel for the stride-1, 8-channel-aligned shapes
-        const int rc = launch_conv_lean(k, ksize, stride, dgrad, packed_bf16, st);
+        const int rc = launch_conv_lean(k, ksize, stride, dgrad ? 1 : 0, packed_bf16, st);
         if (rc <= 0) return rc;              // > 0: shape not covered, use the general kernel below
     }
     const int ntap = ksize * ksize * ksize;

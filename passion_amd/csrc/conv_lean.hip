@@ -60,7 +60,12 @@ __device__ __forceinline__ bf16x8 zero8() {
 
 template <int KS, int MT, int MODE, int CKB>
 __global__ __launch_bounds__(256) void conv_lean_kernel(ConvK p) {
-    constexpr bool DG = (MODE == 1);
+    constexpr bool DG = (MODE >= 1);
+    // MODE 2: dgrad of a reflect-padded conv computed over the PADDED input domain (output coordinate op <-> input
+    // position op - 1, from -1 to S): every brick costs the same 27 taps, no mirror-tap bookkeeping at all; the halo
+    // planes are folded onto planes 1 / S-2 by the InstanceNorm-backward finish kernel, which reads dx anyway.
+    // (Mirror taps made every brick of the small deep levels a 'border' brick: 8^3 x 128 channels took 230 us.)
+    constexpr bool PADOUT = (MODE == 2);
     using G = GeoL<KS, CKB>;
     constexpr int NIT = G::NIT, NC8 = G::NC8, VS = G::VS;
     constexpr int WV = G::NSTEP * 4 * MT * 16;            // 16-byte weight vectors per chunk
@@ -95,7 +100,8 @@ __global__ __launch_bounds__(256) void conv_lean_kernel(ConvK p) {
     // (level-1 dgrad 118 -> 99 us).
     __shared__ int bricktab[256];
     const int wq = bx % wgs_per_b;
-    auto brick_of = [&](int i) { return DG ? (wq + 17 * i) % wgs_per_b + i * wgs_per_b : wq * p.per + i; };
+    constexpr bool DIAG = DG && !PADOUT;
+    auto brick_of = [&](int i) { return DIAG ? (wq + 17 * i) % wgs_per_b + i * wgs_per_b : wq * p.per + i; };
     if (tid < p.per) {
         const int t = brick_of(tid);
         int code = -1;
@@ -106,7 +112,7 @@ __global__ __launch_bounds__(256) void conv_lean_kernel(ConvK p) {
         bricktab[tid] = code;
     }
     // valid bricks form a prefix of the table (dgrad: only the last round can be short)
-    const int nbricks = DG ? (brick_of(p.per - 1) < tiles_per_b ? p.per : p.per - 1)
+    const int nbricks = DIAG ? (brick_of(p.per - 1) < tiles_per_b ? p.per : p.per - 1)
                            : max(0, min(p.per, tiles_per_b - wq * p.per));
     if (nbricks <= 0) return;
 
@@ -162,7 +168,8 @@ __global__ __launch_bounds__(256) void conv_lean_kernel(ConvK p) {
                     const int cl = cg - sd.cbase, bs = sd.bsrc(b);
                     d.ok = 1; d.C = sd.C; d.has_stats = sd.stats != nullptr;
                     d.x = reinterpret_cast<const bf16_t*>(sd.x) + (long)bs * sd.bstride + cl;
-                    d.dx = reinterpret_cast<bf16_t*>(sd.dx) + (long)b * sd.bstride + cl;
+                    d.dx = PADOUT ? reinterpret_cast<bf16_t*>(p.y) + (long)b * (Sd + 2) * (Sh + 2) * (Sw + 2) * p.Cin + cg
+                                  : reinterpret_cast<bf16_t*>(sd.dx) + (long)b * sd.bstride + cl;
                     if (sd.mask) d.mval = sd.mask[(long)b * sd.mask_ld + sd.mask_col] ? 1.f : 0.f;
                     if (sd.stats) {
 #pragma unroll
@@ -226,7 +233,8 @@ __global__ __launch_bounds__(256) void conv_lean_kernel(ConvK p) {
         const int co = (mg * MT + mt) * 16 + g * 4;
         biasv[mt] = (!DG && p.bias && co < p.Cout) ? load4(p.bias + co) : (f32x4){0.f, 0.f, 0.f, 0.f};
     }
-    const bool reflect_dg = DG && (KS == 3) && (p.pad_mode == PASSION_PAD_REFLECT);
+    const bool reflect_dg = DG && !PADOUT && (KS == 3) && (p.pad_mode == PASSION_PAD_REFLECT);
+    constexpr int SHIFT = PADOUT ? 1 : 0;        // padded output coordinate -> position
 
     // ---- staging: FETCH (global -> registers) / COMMIT (registers -> normalise -> LDS)
     u32x4 raw[NIT];
@@ -304,7 +312,7 @@ __global__ __launch_bounds__(256) void conv_lean_kernel(ConvK p) {
     int chunk = 0;
     const int nsteps = nbricks * nchunk;
     const bool nostage = (p.dbg & 1) != 0;
-    if (((chunk_live >> 0) & 1u) && !nostage) fetch(0, td_ * TD, th_ * TH, tw_ * TW);
+    if (((chunk_live >> 0) & 1u) && !nostage) fetch(0, td_ * TD - SHIFT, th_ * TH - SHIFT, tw_ * TW - SHIFT);
     f32x4 acc[MT][4];
     int nmirror = 0;
     // dgrad: InstanceNorm-backward sums (sum g, sum g * x_hat) stay in registers over all bricks of the workgroup
@@ -371,17 +379,36 @@ __global__ __launch_bounds__(256) void conv_lean_kernel(ConvK p) {
                 n_tw = code & 1023; n_th = (code >> 10) & 1023; n_td = code >> 20;
             }
         }
-        if (step + 1 < nsteps && ((chunk_live >> n_chunk) & 1u) && !nostage) fetch(n_chunk, n_td * TD, n_th * TH, n_tw * TW);
+        if (step + 1 < nsteps && ((chunk_live >> n_chunk) & 1u) && !nostage)
+            fetch(n_chunk, n_td * TD - SHIFT, n_th * TH - SHIFT, n_tw * TW - SHIFT);
 
+        // dgrad epilogue geometry of this lane's output voxel of row nt: voxel index in x (x_hat source; PADOUT: the
+        // reflected position) and in the dx target (PADOUT: the padded scratch volume), or -1 outside the volume
+        auto dg_vox = [&](int nt, int& xv, int& dv) {
+            const int od = o0d + ld_, oh = o0h + lh[nt], ow = o0w + lw;
+            if (PADOUT) {
+                const bool in = od < Sd + 2 && oh < Sh + 2 && ow < Sw + 2;
+                int rd = od - 1, rh = oh - 1, rw = ow - 1;
+                rd = rd < 0 ? -rd : (rd >= Sd ? 2 * Sd - 2 - rd : rd);
+                rh = rh < 0 ? -rh : (rh >= Sh ? 2 * Sh - 2 - rh : rh);
+                rw = rw < 0 ? -rw : (rw >= Sw ? 2 * Sw - 2 - rw : rw);
+                xv = in ? (rd * Sh + rh) * Sw + rw : -1;
+                dv = (od * (Sh + 2) + oh) * (Sw + 2) + ow;
+            } else {
+                const bool in = od < Sd && oh < Sh && ow < Sw;
+                xv = in ? (od * Sh + oh) * Sw + ow : -1;
+                dv = xv;
+            }
+        };
         if (DG && MT == 1 && chunk == nchunk - 1) {
             const EpiDesc& e = edesc[g];
             if (e.ok && e.has_stats) {
-                const int vox0 = ((o0d + ld_) * Sh + o0h + lh0) * Sw + o0w + lw;
-                const bool inw = (o0d + ld_ < Sd) && (o0w + lw < Sw);
 #pragma unroll
                 for (int nt = 0; nt < 4; ++nt) {
+                    int xv, dv;
+                    dg_vox(nt, xv, dv);
                     xpre[nt] = make_uint2(0u, 0u);
-                    if (inw && o0h + lh[nt] < Sh) xpre[nt] = *reinterpret_cast<const uint2*>(e.x + (long)(vox0 + nt * 2 * Sw) * e.C);
+                    if (xv >= 0) xpre[nt] = *reinterpret_cast<const uint2*>(e.x + (long)xv * e.C);
                 }
             }
         }
@@ -465,8 +492,7 @@ __global__ __launch_bounds__(256) void conv_lean_kernel(ConvK p) {
             const int oh4[4] = {o0h + lh[0], o0h + lh[1], o0h + lh[2], o0h + lh[3]};
             if (DG) {
                 // back through LeakyReLU / mask; the InstanceNorm-backward sums accumulate in registers
-                const int vox0 = ((o0d + ld_) * Sh + o0h + lh0) * Sw + o0w + lw;
-                const bool inw = (o0d + ld_ < Sd) && (o0w + lw < Sw);
+                const int dxC = PADOUT ? p.Cin : 0;
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) {
                     const EpiDesc& e = edesc[mt * 4 + g];
@@ -476,13 +502,14 @@ __global__ __launch_bounds__(256) void conv_lean_kernel(ConvK p) {
                     for (int j = 0; j < 4; ++j) { mean[j] = e.mean[j]; rstd[j] = e.rstd[j]; }
 #pragma unroll
                     for (int nt = 0; nt < 4; ++nt) {
-                        if (!(inw && oh4[nt] < Sh)) continue;
-                        const long off = (long)(vox0 + nt * 2 * Sw) * e.C;
+                        int xvox, dvox;
+                        dg_vox(nt, xvox, dvox);
+                        if (xvox < 0) continue;
                         f32x4 gv = acc[mt][nt];
                         if (e.has_stats) {
                             uint2 xr;
                             if (MT == 1) xr = xpre[nt];
-                            else xr = *reinterpret_cast<const uint2*>(e.x + off);
+                            else xr = *reinterpret_cast<const uint2*>(e.x + (long)xvox * e.C);
                             const float xv[4] = {__uint_as_float(xr.x << 16), __uint_as_float(xr.x & 0xffff0000u),
                                                  __uint_as_float(xr.y << 16), __uint_as_float(xr.y & 0xffff0000u)};
 #pragma unroll
@@ -497,7 +524,7 @@ __global__ __launch_bounds__(256) void conv_lean_kernel(ConvK p) {
 #pragma unroll
                             for (int j = 0; j < 4; ++j) gv[j] *= e.mval;
                         }
-                        store4(e.dx + off, gv);
+                        store4(e.dx + (long)dvox * (PADOUT ? dxC : e.C), gv);
                     }
                 }
             } else if (o0d + TD <= Sd && o0h + TH <= Sh && o0w + TW <= Sw) {       // whole brick inside: no per-lane bounds
@@ -599,9 +626,23 @@ int launch_lean_geo(ConvK& k, int K8, int cmax, int mtiles, hipStream_t st) {
 
 namespace pconv {
 
+// mode 0 forward, 1 dgrad, 2 dgrad over the padded domain (see PADOUT; k.tiles* cover (S+2)^3, k.y = padded scratch)
 // returns 0 = launched, < 0 = HIP error, 1 = shape not covered (caller falls back to the general kernel)
-int launch_conv_lean(ConvK& k, int ksize, int stride, bool dgrad, const void* packed_bf16, hipStream_t st) {
+bool lean_covers(const ConvK& k, int stride, bool dgrad) {
+    if (stride != 1) return false;
+    if (dgrad) return k.Cout % 8 == 0 && k.Cout / 8 <= MAXBLK;
+    int K8 = 0;
+    for (int s = 0; s < k.nseg; ++s) {
+        if (k.seg[s].C % 8) return false;
+        K8 += k.seg[s].C / 8;
+    }
+    return K8 * 8 == k.Cin && K8 <= MAXBLK;
+}
+
+int launch_conv_lean(ConvK& k, int ksize, int stride, int mode, const void* packed_bf16, hipStream_t st) {
+    const bool dgrad = mode >= 1;
     if (stride != 1) return 1;
+    if (mode == 2 && ksize != 3) return 1;
     const int ntap = ksize * ksize * ksize;
     int K8, cmax = 0;
     if (dgrad) {
@@ -629,6 +670,7 @@ int launch_conv_lean(ConvK& k, int ksize, int stride, bool dgrad, const void* pa
     k.sums_rep = SUMS_REP_LEAN;
     const int mtiles = k.Mpad / 16;
     if (ksize == 1) return dgrad ? launch_lean_geo<1, 1>(k, K8, cmax, mtiles, st) : launch_lean_geo<1, 0>(k, K8, cmax, mtiles, st);
+    if (mode == 2) return launch_lean_geo<3, 2>(k, K8, cmax, mtiles, st);
     return dgrad ? launch_lean_geo<3, 1>(k, K8, cmax, mtiles, st) : launch_lean_geo<3, 0>(k, K8, cmax, mtiles, st);
 }
 
