@@ -784,6 +784,10 @@ int wgrad_bf16_chunk(const ConvK& k, int ksize, int stride) {
 int launch_wgrad_bf16(ConvK& k, int ksize, int stride, int MT, int gx, int gy, float* dW, float* db, hipStream_t st) {
     k.Mpad = pad16(k.Cout);
     const bool wide = wgrad_bf16_chunk(k, ksize, stride) == 16;
+    if (g_conv_lean && !wide) {
+        const int rc = launch_wgrad_lean(k, ksize, stride, MT, gx, gy, dW, db, st);
+        if (rc <= 0) return rc;
+    }
     if (ksize == 1) return wide ? launch_wgrad_b<1, 1, 16>(k, MT, gx, gy, dW, db, st) : launch_wgrad_b<1, 1, 8>(k, MT, gx, gy, dW, db, st);
     if (stride == 1) return wide ? launch_wgrad_b<3, 1, 16>(k, MT, gx, gy, dW, db, st) : launch_wgrad_b<3, 1, 8>(k, MT, gx, gy, dW, db, st);
     return launch_wgrad_b<3, 2, 8>(k, MT, gx, gy, dW, db, st);

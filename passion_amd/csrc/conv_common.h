@@ -56,6 +56,7 @@ bool bf16_eligible(const ConvK& k, bool dgrad);
 int launch_conv_bf16(ConvK& k, int ksize, int stride, bool dgrad, const void* packed_bf16, hipStream_t st);
 int launch_conv_lean(ConvK& k, int ksize, int stride, int mode, const void* packed_bf16, hipStream_t st);   // conv_lean.hip
 bool lean_covers(const ConvK& k, int stride, bool dgrad);
+int launch_wgrad_lean(ConvK& k, int ksize, int stride, int MT, int gx, int gy, float* dWslab, float* dbslab, hipStream_t st);   // conv_wgrad_lean.hip
 extern int g_conv_lean;
 int launch_wgrad_bf16(ConvK& k, int ksize, int stride, int MT, int gx, int gy, float* dWslab, float* dbslab, hipStream_t st);
 int wgrad_bf16_chunk(const ConvK& k, int ksize, int stride);

@@ -1,0 +1,343 @@
+// Lean bf16 wgrad for the stride-1 convs with 8-channel-aligned tensors:
+//   dW[co][ci][tap] = sum_vox dY[vox][co] * act(x)[vox + tap][ci]      (+ dbias[co] = sum_vox dY[vox][co])
+// Same decomposition, operand layouts and deterministic slab flush as conv_wgrad_bf16_kernel (conv_bf16.hip):
+// D[m = co][n = (tap, ci)] with K = 32 voxels per v_mfma_f32_16x16x32_bf16, both operands k-strided in their
+// voxel-major LDS images and read with ds_read_b64_tr_b16; a workgroup owns (a run of bricks of ONE sample) x (one
+// 8-channel block of the virtual concat) x (MT row tiles) and keeps its partial sums in registers across bricks.
+// What changed is the instruction diet -- the counters of the general kernel on the level-1 conv (128^3, 8 -> 8):
+// 1620 VALU + 490 SALU instructions per wavefront and brick against 40 MFMAs.  Here the concat lookup, mask and
+// InstanceNorm statistics are resolved once per workgroup, the source / dY / LDS offsets of every thread are
+// brick-invariant constants (interior bricks: address = brick base + constant), the MFMA loop is fully unrolled
+// over immediates, and brick coordinates advance incrementally.
+#include "conv_common.h"
+
+using namespace pconv;
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ bf16x8 tr_read8(const char* p0, const char* p1) {
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p0));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p1));
+    const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+template <int KS, int MT>
+__global__ __launch_bounds__(256) void wgrad_lean_kernel(ConvK p, float* __restrict__ dW, float* __restrict__ dbias) {
+    constexpr int HALO = (KS == 3) ? 1 : 0;
+    constexpr int ID = TD + 2 * HALO, IH = TH + 2 * HALO, IW = TW + 2 * HALO, VOL = ID * IH * IW;
+    constexpr int VS = 16;                            // bytes per voxel of the activation image (8 channels)
+    constexpr int NTAP = KS * KS * KS;
+    constexpr int NTILES = (NTAP + 1) / 2;            // 16 columns = 2 taps x 8 channels
+    constexpr int KSPLIT = (NTILES >= 4) ? 1 : 4;     // few column tiles: the waves split the voxels instead
+    constexpr int NTW = (KSPLIT == 1) ? (NTILES + 3) / 4 : NTILES;
+    constexpr int MC = MT * 16;
+    constexpr int DYS = MC * 2 + 16;                  // bytes per voxel row of the dY image
+    constexpr int AR = (VOL + 255) / 256;             // activation voxels per thread
+    constexpr int DR = MC / 8;                        // dY 16-byte blocks per thread
+    constexpr int NKS = TD * TH * TW / 32;            // K steps per brick
+    __shared__ __attribute__((aligned(16))) char lact[VOL * VS];
+    __shared__ __attribute__((aligned(16))) char ldy[TD * TH * TW * DYS];
+
+    const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, n = lane & 15, g = lane >> 4;
+    const int q = n >> 2, pq = n & 3;
+    const int mgroups = p.Mpad / 16 / MT;
+    const int mg = blockIdx.y % mgroups;
+    const int gb0 = blockIdx.y / mgroups;             // this workgroup's 8-channel block of the virtual concat
+    const int Sd = p.Di, Sh = p.Hi, Sw = p.Wi;        // stride 1: input and output volumes coincide
+
+    const int tiles_per_b = p.tilesD * p.tilesH * p.tilesW;
+    const int wgs_per_b = (tiles_per_b + p.per - 1) / p.per;
+    const int bx = xcd_swizzle(blockIdx.x, gridDim.x);
+    const int b = bx / wgs_per_b;                     // >= B: spare workgroup, flushes a zero slot
+    const int t0 = (bx % wgs_per_b) * p.per;
+    const int nbricks = (b < p.B) ? max(0, min(p.per, tiles_per_b - t0)) : 0;
+
+    // ---- once per workgroup: which tensor / channels, mask, statistics
+    int sg = 0, c0 = 0, C = 8, cbase = 0;
+    bool exist = false;
+    {
+        int r = gb0;
+#pragma unroll
+        for (int s2 = 0; s2 < PASSION_MAX_SEG; ++s2) {
+            if (s2 < p.nseg && !exist) {
+                const int nb = p.seg[s2].C / 8;
+                if (r < nb) { exist = true; sg = s2; c0 = r * 8; C = p.seg[s2].C; cbase = p.seg[s2].cbase; }
+                r -= nb;
+            }
+        }
+    }
+    const bf16_t* src = nullptr;
+    bool present = false, has_norm = false;
+    float mean[8], rstd[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) { mean[c] = 0.f; rstd[c] = 1.f; }
+    if (exist && nbricks > 0) {
+#pragma unroll
+        for (int s2 = 0; s2 < PASSION_MAX_SEG; ++s2) {
+            if (s2 == sg) {
+                const SegD& sd = p.seg[s2];
+                const int bs = sd.bsrc(b);
+                present = !sd.mask || sd.mask[(long)b * sd.mask_ld + sd.mask_col] != 0;
+                src = reinterpret_cast<const bf16_t*>(sd.x) + (long)bs * sd.bstride + c0;
+                has_norm = sd.stats != nullptr;
+                if (sd.stats) {
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) {
+                        mean[c] = sd.stats[((long)bs * sd.C + c0 + c) * 2 + 0];
+                        rstd[c] = sd.stats[((long)bs * sd.C + c0 + c) * 2 + 1];
+                    }
+                }
+            }
+        }
+    }
+    const bf16_t* dyb = reinterpret_cast<const bf16_t*>(p.dy) + (long)(b < p.B ? b : 0) * Sd * Sh * Sw * p.Cout;
+
+    // ---- per-thread constants of the staging
+    int voxoff[AR];                                   // activation voxel of iteration r relative to the brick's first voxel
+#pragma unroll
+    for (int r = 0; r < AR; ++r) {
+        const int tv = tid + 256 * r;
+        const int zw = tv % IW, zh = (tv / IW) % IH, zd = tv / (IW * IH);
+        voxoff[r] = (zd * Sh + zh) * Sw + zw;
+    }
+    int dvoff[DR], dco[DR], dlds[DR];                 // dY: voxel offset, channel offset, LDS byte offset
+#pragma unroll
+    for (int r = 0; r < DR; ++r) {
+        const int i = tid + 256 * r;
+        const int c8 = i % DR, v = i / DR;
+        const int w = v % TW, h = (v / TW) % TH, d = v / (TW * TH);
+        dvoff[r] = (d * Sh + h) * Sw + w;
+        dco[r] = mg * MC + c8 * 8;
+        dlds[r] = v * DYS + c8 * 16;
+    }
+    // ---- per-lane constants of the MFMA loop (K step ks: voxels d = ks >> 1, h = (ks & 1) * 4 + g, w = 4 * half + q)
+    const int alane = (g * TW + q) * DYS + pq * 8;
+    const int blane = (g * IW + q) * VS;
+    int boff[NTW];                                    // column tile j: this lane's (tap, channel quad) inside a neighbourhood
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) {
+        const int nt = (KSPLIT == 1) ? wv + 4 * j : j;
+        int tap = 2 * nt + (pq >> 1);
+        if (tap >= NTAP) tap = 0;                      // padded column: reads finite data, dropped at the flush
+        const int tw = tap % KS, th = (tap / KS) % KS, td = tap / (KS * KS);
+        boff[j] = blane + ((td * IH + th) * IW + tw) * VS + (pq & 1) * 8;
+    }
+    f32x4 acc[MT][NTW], accb[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        accb[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) acc[mt][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    const bool bias_block = (dbias != nullptr) && (gb0 == 0);
+    const bool do_bias = bias_block && (KSPLIT == 4 || wv == 0);
+    bf16x8 ones;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ones[j] = (__bf16)1.0f;
+
+    // ---- staging: FETCH (global -> registers) / COMMIT (normalise -> LDS)
+    u32x4 ra[AR], rd[DR];
+    unsigned okbits = 0u;
+    auto fetch = [&](int o0d, int o0h, int o0w) {
+        okbits = 0u;
+        const bool interior = o0d >= HALO && o0h >= HALO && o0w >= HALO && o0d + TD + HALO <= Sd && o0h + TH + HALO <= Sh &&
+                              o0w + TW + HALO <= Sw;
+        if (interior) {                               // workgroup-uniform: no padding, no partial brick
+            const int basevox = ((o0d - HALO) * Sh + (o0h - HALO)) * Sw + (o0w - HALO);
+#pragma unroll
+            for (int r = 0; r < AR; ++r) {
+                ra[r] = (u32x4){0u, 0u, 0u, 0u};
+                if (present && tid + 256 * r < VOL) {
+                    ra[r] = *reinterpret_cast<const u32x4*>(src + (long)(basevox + voxoff[r]) * C);
+                    okbits |= 1u << r;
+                }
+            }
+            const int baseo = (o0d * Sh + o0h) * Sw + o0w;
+#pragma unroll
+            for (int r = 0; r < DR; ++r) {
+                rd[r] = (u32x4){0u, 0u, 0u, 0u};
+                if (dco[r] < p.Cout) rd[r] = *reinterpret_cast<const u32x4*>(dyb + (long)(baseo + dvoff[r]) * p.Cout + dco[r]);
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < AR; ++r) {
+                const int tv = tid + 256 * r;
+                const int zw = tv % IW, zh = (tv / IW) % IH, zd = tv / (IW * IH);
+                int s_d = o0d - HALO + zd, s_h = o0h - HALO + zh, s_w = o0w - HALO + zw;
+                bool ok = present && tv < VOL;
+                if (p.pad_mode == PASSION_PAD_REFLECT) {
+                    s_d = reflect_idx(s_d, Sd); s_h = reflect_idx(s_h, Sh); s_w = reflect_idx(s_w, Sw);
+                    s_d = min(max(s_d, 0), Sd - 1); s_h = min(max(s_h, 0), Sh - 1); s_w = min(max(s_w, 0), Sw - 1);
+                } else {
+                    ok = ok && (s_d >= 0 && s_d < Sd && s_h >= 0 && s_h < Sh && s_w >= 0 && s_w < Sw);
+                }
+                ra[r] = (u32x4){0u, 0u, 0u, 0u};
+                if (ok) {
+                    ra[r] = *reinterpret_cast<const u32x4*>(src + (((long)s_d * Sh + s_h) * Sw + s_w) * C);
+                    okbits |= 1u << r;
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < DR; ++r) {
+                const int v = (tid + 256 * r) / DR;
+                const int w = v % TW, h = (v / TW) % TH, d = v / (TW * TH);
+                const int od = o0d + d, oh = o0h + h, ow = o0w + w;
+                rd[r] = (u32x4){0u, 0u, 0u, 0u};
+                if (od < Sd && oh < Sh && ow < Sw && dco[r] < p.Cout)
+                    rd[r] = *reinterpret_cast<const u32x4*>(dyb + (((long)od * Sh + oh) * Sw + ow) * p.Cout + dco[r]);
+            }
+        }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int r = 0; r < AR; ++r) {
+            if (tid + 256 * r >= VOL) continue;
+            u32x4 o = ra[r];
+            if (has_norm && ((okbits >> r) & 1u)) {
+                bf16x8 ob;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {      // bf16 pairs -> f32: low half = even channel
+                    const float v0 = __uint_as_float(ra[r][c] << 16), v1 = __uint_as_float(ra[r][c] & 0xffff0000u);
+                    float t0_ = (v0 - mean[2 * c]) * rstd[2 * c], t1_ = (v1 - mean[2 * c + 1]) * rstd[2 * c + 1];
+                    t0_ = t0_ > 0.f ? t0_ : t0_ * p.slope;
+                    t1_ = t1_ > 0.f ? t1_ : t1_ * p.slope;
+                    ob[2 * c] = (__bf16)t0_; ob[2 * c + 1] = (__bf16)t1_;
+                }
+                o = __builtin_bit_cast(u32x4, ob);
+            }
+            *reinterpret_cast<u32x4*>(lact + (tid + 256 * r) * VS) = o;
+        }
+#pragma unroll
+        for (int r = 0; r < DR; ++r) *reinterpret_cast<u32x4*>(ldy + dlds[r]) = rd[r];
+    };
+
+    // ---- bricks t0 .. t0 + nbricks - 1 of sample b, coordinates advanced incrementally
+    int tw_ = t0 % p.tilesW, th_ = (t0 / p.tilesW) % p.tilesH, td_ = t0 / (p.tilesW * p.tilesH);
+    if (nbricks > 0) fetch(td_ * TD, th_ * TH, tw_ * TW);
+    for (int i = 0; i < nbricks; ++i) {
+        __syncthreads();
+        commit();
+        __syncthreads();
+        if (++tw_ == p.tilesW) { tw_ = 0; if (++th_ == p.tilesH) { th_ = 0; ++td_; } }
+        if (i + 1 < nbricks) fetch(td_ * TD, th_ * TH, tw_ * TW);    // loads of the next brick fly during the MFMAs below
+#pragma unroll
+        for (int kk = 0; kk < NKS / KSPLIT; ++kk) {
+            // KSPLIT 1: ks = kk (compile-time offsets); KSPLIT 4: ks = wv + 4 kk (per-wave offsets)
+            const int ks = (KSPLIT == 1) ? kk : wv + 4 * kk;
+            const int kd = ks >> 1, kh = (ks & 1) * 4;
+            const char* ap = ldy + alane + ((kd * TH + kh) * TW) * DYS;
+            bf16x8 a[MT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) a[mt] = tr_read8(ap + mt * 32, ap + mt * 32 + 4 * DYS);
+            const char* bp = lact + ((kd * IH + kh) * IW) * VS;
+#pragma unroll
+            for (int j = 0; j < NTW; ++j) {
+                const bf16x8 bv = tr_read8(bp + boff[j], bp + boff[j] + 4 * VS);
+                if (KSPLIT == 1 && wv + 4 * j >= NTILES) continue;   // wave-uniform
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+                    acc[mt][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mt], bv, acc[mt][j], 0, 0, 0);
+            }
+            if (do_bias) {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+                    accb[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mt], ones, accb[mt], 0, 0, 0);
+            }
+        }
+    }
+
+    if (KSPLIT == 4) {
+        // the four waves hold partial sums over disjoint voxels of the SAME outputs: combine through LDS (fixed order)
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(ldy);          // [4 waves][MT][NTW + 1][64 lanes][4]
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+            for (int j = 0; j < NTW; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) red[(((wv * MT + mt) * (NTW + 1) + j) * 64 + lane) * 4 + r] = acc[mt][j][r];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[(((wv * MT + mt) * (NTW + 1) + NTW) * 64 + lane) * 4 + r] = accb[mt][r];
+        }
+        __syncthreads();
+        if (wv != 0) return;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+            for (int j = 0; j <= NTW; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float t = 0.f;
+#pragma unroll
+                    for (int w2 = 0; w2 < 4; ++w2) t += red[(((w2 * MT + mt) * (NTW + 1) + j) * 64 + lane) * 4 + r];
+                    if (j < NTW) acc[mt][j][r] = t; else accb[mt][r] = t;
+                }
+        }
+    }
+    // ---- this workgroup's slot of the partial-sum slab (plain stores; reduce_parts_kernel folds the slots)
+    if (dW && exist) {
+        float* slot = dW + (long)blockIdx.x * p.wslot;
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) {
+            const int nt = (KSPLIT == 1) ? wv + 4 * j : j;
+            const int tap = 2 * nt + (n >> 3), c = n & 7;
+            if (nt >= NTILES || tap >= NTAP) continue;
+            const long ci = cbase + c0 + c;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int co = (mg * MT + mt) * 16 + g * 4 + r;
+                    if (co < p.Cout) slot[((long)co * p.Cin + ci) * NTAP + tap] = acc[mt][j][r];
+                }
+        }
+    }
+    if (bias_block && wv == 0 && n == 0) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int co = (mg * MT + mt) * 16 + g * 4 + r;
+                if (co < p.Cout) dbias[(long)blockIdx.x * p.wslot + co] = accb[mt][r];
+            }
+    }
+}
+
+template <int KS>
+int launch_wl(ConvK& k, int MT, int gx, int gy, float* dW, float* db, hipStream_t st) {
+    dim3 grid(gx, gy);
+    if (MT == 2) hipLaunchKernelGGL((wgrad_lean_kernel<KS, 2>), grid, dim3(256), 0, st, k, dW, db);
+    else hipLaunchKernelGGL((wgrad_lean_kernel<KS, 1>), grid, dim3(256), 0, st, k, dW, db);
+    LAUNCH_RET();
+    return 0;
+}
+
+}  // namespace
+
+namespace pconv {
+
+// returns 0 = launched, < 0 = HIP error, 1 = shape not covered (caller uses conv_wgrad_bf16_kernel).
+// gx = slots of the partial slab = workgroups in x (spare ones flush zeros), gy = (8-channel blocks) x (row-tile groups)
+int launch_wgrad_lean(ConvK& k, int ksize, int stride, int MT, int gx, int gy, float* dW, float* db, hipStream_t st) {
+    if (stride != 1 || k.Cout % 8 || gx < k.B) return 1;
+    int K8 = 0;
+    for (int s = 0; s < k.nseg; ++s) {
+        if (k.seg[s].C % 8) return 1;
+        K8 += k.seg[s].C / 8;
+    }
+    k.Mpad = pad16(k.Cout);
+    if (K8 * (k.Mpad / 16 / MT) != gy) return 1;       // the plan was made for a different chunking
+    const int tiles_per_b = k.tilesD * k.tilesH * k.tilesW;
+    const int wgs = gx / k.B;                          // workgroups per sample
+    k.per = (tiles_per_b + wgs - 1) / wgs;
+    if (ksize == 1) return launch_wl<1>(k, MT, gx, gy, dW, db, st);
+    return launch_wl<3>(k, MT, gx, gy, dW, db, st);
+}
+
+}  // namespace pconv
