@@ -468,9 +468,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(ConvK p, float* __restr
 }
 
 // out[i] = sum_{r < R} part[r * stride + i], fixed summation order.  256 threads = 16 outputs x 16 slices of r.
+// Optionally also clears zero_n floats at zero_ptr (the replicas the following dgrad launch adds into): saves a memset
+// dispatch per conv backward.
 __global__ __launch_bounds__(256) void reduce_parts_kernel(const float* __restrict__ part, int R, long n, long stride,
-                                                           float* __restrict__ out) {
+                                                           float* __restrict__ out, float* __restrict__ zero_ptr = nullptr,
+                                                           long zero_n = 0) {
     __shared__ float red[16][17];
+    for (long z = (long)blockIdx.x * 256 + threadIdx.x; z < zero_n; z += (long)gridDim.x * 256) zero_ptr[z] = 0.f;
     const int li = threadIdx.x & 15, sl = threadIdx.x >> 4;
     const long i = (long)blockIdx.x * 16 + li;
     float a = 0.f;
@@ -716,7 +720,7 @@ extern "C" int passion_conv_pack_weights(int n, const float* const* weights, con
             if (ks != 1 && ks != 3) return -1002;
             t.e[i] = PackEnt{weights[i0 + i], packed[i0 + i], Cin[i0 + i], Cout[i0 + i], ks * ks * ks, 0};
         }
-        hipLaunchKernelGGL(pack_multi_kernel, dim3(32, m), dim3(256), 0, (hipStream_t)stream, t);
+        hipLaunchKernelGGL(pack_multi_kernel, dim3(192, m), dim3(256), 0, (hipStream_t)stream, t);
         LAUNCH_RET();
     }
     return 0;
@@ -759,6 +763,12 @@ extern "C" int passion_conv3d_bwd(const passion_conv_desc_t* d, const float* pac
     const int xs = d->x_dtype == PASSION_BF16 ? 2 : 4, ys = d->y_dtype == PASSION_BF16 ? 2 : 4;
     k.dy = dy;
     k.tilesD = cdiv(k.Do, TD); k.tilesH = cdiv(k.Ho, TH); k.tilesW = cdiv(k.Wo, TW);
+    bool need_dx = false, need_norm = false, sums_cleared = false;
+    for (int s = 0; s < k.nseg; ++s) {
+        if (k.seg[s].dx) { need_dx = true; if (k.seg[s].stats) need_norm = true; }
+    }
+    float* zsums = (need_norm && sums) ? sums : nullptr;              // cleared by the weight-gradient fold when there is one
+    const long zn = zsums ? (long)2 * k.B * k.Cin * SUMS_REP : 0;
     // ---- wgrad (+ bias grad): per-workgroup partial slabs, then a fixed-order fold (no atomics, deterministic) ----
     if (dweight || dbias) {
         k.Mpad = pad16(k.Cout);
@@ -786,12 +796,15 @@ extern "C" int passion_conv3d_bwd(const passion_conv_desc_t* d, const float* pac
         }
         if (dweight && dbias == dweight + nW) {      // caller keeps [dW | dbias] in one buffer: one fold for both
             hipLaunchKernelGGL(reduce_parts_kernel, dim3((unsigned)((k.wslot + 15) / 16)), dim3(256), 0, st, wslab, w.gx, k.wslot,
-                               k.wslot, dweight);
+                               k.wslot, dweight, zsums, zn);
             LAUNCH_RET();
+            sums_cleared = zsums != nullptr;
         } else {
             if (dweight) {
-                hipLaunchKernelGGL(reduce_parts_kernel, dim3((unsigned)((nW + 15) / 16)), dim3(256), 0, st, wslab, w.gx, nW, k.wslot, dweight);
+                hipLaunchKernelGGL(reduce_parts_kernel, dim3((unsigned)((nW + 15) / 16)), dim3(256), 0, st, wslab, w.gx, nW, k.wslot, dweight,
+                                   zsums, zn);
                 LAUNCH_RET();
+                sums_cleared = zsums != nullptr;
             }
             if (dbias) {
                 hipLaunchKernelGGL(reduce_parts_kernel, dim3((k.Cout + 15) / 16), dim3(256), 0, st, bslab, w.gx, (long)k.Cout, k.wslot, dbias);
@@ -800,16 +813,12 @@ extern "C" int passion_conv3d_bwd(const passion_conv_desc_t* d, const float* pac
         }
     }
     // ---- dgrad ----
-    bool need_dx = false, need_norm = false;
-    for (int s = 0; s < k.nseg; ++s) {
-        if (k.seg[s].dx) { need_dx = true; if (k.seg[s].stats) need_norm = true; }
-    }
     if (!need_dx) return 0;
     if (k.Cin % 4) return -1008;
     for (int s = 0; s < k.nseg; ++s) if (k.seg[s].C % 4) return -1008;
     if (need_norm) {
         if (!sums) return -1009;
-        HIP_RET(hipMemsetAsync(sums, 0, sizeof(float) * 2 * (size_t)k.B * k.Cin * SUMS_REP, st));
+        if (!sums_cleared) HIP_RET(hipMemsetAsync(sums, 0, sizeof(float) * 2 * (size_t)k.B * k.Cin * SUMS_REP, st));
     }
     k.sums = sums;
     k.sums_rep = SUMS_REP;                           // the lean launcher lowers it

@@ -73,6 +73,7 @@ def repack_stale():
     """Re-pack, in ONE launch, every registered conv weight whose version moved since it was packed (i.e. all of
     them after an optimizer step) into its existing buffer.  Called at the top of Model.forward: the per-conv
     pack_weight() calls below then all hit their caches."""
+    capturing = torch.cuda.is_current_stream_capturing()   # a graph replays after optimizer steps: record all of them
     stale = []
     for key in list(_PACK_REGISTRY):
         ref, cache = _PACK_REGISTRY[key]
@@ -80,7 +81,8 @@ def repack_stale():
         if w is None:
             del _PACK_REGISTRY[key]
             continue
-        if cache.get("key") != (w.data_ptr(), w._version) and w.is_cuda and w.dtype == torch.float32 and w.is_contiguous():
+        if (capturing or cache.get("key") != (w.data_ptr(), w._version)) and w.is_cuda and w.dtype == torch.float32 \
+                and w.is_contiguous():
             stale.append((w, cache))
     if not stale:
         return 0
@@ -348,7 +350,7 @@ def target_to_cl(target):
     """one-hot target (B,4,D,H,W) f64/f32 (datasets_nii.py:151-153) -> f32 channels-last (B,D,H,W,4)"""
     L.require_gpu(target)
     cached = getattr(target, "_passion_cl", None)
-    if cached is not None and cached[0] == target._version:
+    if cached is not None and cached[0] == target._version and not torch.cuda.is_current_stream_capturing():
         return cached[1]
     t = target.contiguous()
     B, C, D, H, W = t.shape

@@ -74,10 +74,11 @@ def assemble_loss(outs, target, mask, mask_type="idt", use_passion=True, state=N
     return fuse_loss + (rp_mask * beta * w * sep_m).sum() + prm_loss + 0.5 * kl + 0.1 * proto
 
 
-def make_optimizer(model, lr=2e-4, weight_decay=1e-4):
-    """AdamW(betas=(0.9,0.999), eps=1e-8, amsgrad=True) as train.py:95-96"""
+def make_optimizer(model, lr=2e-4, weight_decay=1e-4, capturable=False):
+    """AdamW(betas=(0.9,0.999), eps=1e-8, amsgrad=True) as train.py:95-96; capturable=True keeps the step counter on
+    the device so that the step can be recorded in a HIP graph (passion_amd.graph)"""
     params = [{"params": model.parameters(), "lr": lr, "weight_decay": weight_decay}]
-    return torch.optim.AdamW(params, betas=(0.9, 0.999), eps=1e-08, amsgrad=True)
+    return torch.optim.AdamW(params, betas=(0.9, 0.999), eps=1e-08, amsgrad=True, capturable=capturable)
 
 
 def poly_lr(base_lr, epoch, num_epochs, power=0.9):
@@ -91,7 +92,7 @@ def train_step(model, optimizer, x, mask, target, temp=4.0, state=None, reducer=
     net.is_training = True
     outs = net(x, mask, target=target, temp=temp)
     loss = assemble_loss(outs, target, mask, net.mask_type, net.use_passion, state, warmup, modal_num)
-    optimizer.zero_grad(set_to_none=False)
+    optimizer.zero_grad()            # set_to_none: no 288 fill launches, backward assigns the fresh gradients
     loss.backward()
     if reducer is not None:
         reducer.all_reduce_grads()

@@ -23,7 +23,7 @@ for i in range(5):
     loss = ptrain.assemble_loss(outs, target, mask, "idt", passion)
     t1h = time.time()
     torch.cuda.synchronize(); t1 = time.time()
-    opt.zero_grad(set_to_none=False); loss.backward()
+    opt.zero_grad(); loss.backward()
     t2h = time.time()
     torch.cuda.synchronize(); t2 = time.time()
     opt.step(); torch.cuda.synchronize(); t3 = time.time()
