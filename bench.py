@@ -8,9 +8,11 @@ One "step" = one full training iteration on one synthetic batch already resident
 Model.forward (all losses are computed inside it) + train.py's loss assembly + backward +
 gradient all-reduce (N>1) + AdamW(amsgrad) step.  Ranks own independent volumes (weak scaling, no
 data-path collective).  Rank 0 prints ONE JSON line; besides the contract's fields it carries
-  roofline     : dominant kernel = the fused IN+LeakyReLU+3x3x3 conv forward, algorithmic bytes
-                 (in + out activations + weights) / average launch time, both taken live
-                 with hipEvents on the launch stream inside the timed region; peak = 8 TB/s HBM3E
+  roofline     : the conv kernel family with the largest total time in the step (forward 3x3x3 / forward 1x1x1 /
+                 dgrad / wgrad): algorithmic bytes (activations in + out + weights) / average launch time,
+                 taken live with hipEvents on the launch stream inside the timed region; peak = 8 TB/s HBM3E.
+                 (--graph replays the step as one HIP graph; hipEventElapsedTime cannot time event nodes of a graph, so
+                 there the event pairs come from eager iterations of the same step right after the timed region.)
   cpu_baseline : the oracle (oracle/, a CPU restatement proven equal to the reference) timed on the
                  host cores, rank 0, N=1 only, on one 64^3 training step (1/8 of a 128^3 volume).
 """
@@ -41,6 +43,10 @@ def parse():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--graph", action="store_true",
+                    help="EXPERIMENTAL: replay the whole step as one HIP graph (N=1; ~6%% faster, but on ROCm 7.2 / torch 2.10 "
+                         "replays were observed to corrupt gradients intermittently -- DESIGN.md, so it is not the default)")
+    ap.add_argument("--no-graph", action="store_true", help=argparse.SUPPRESS)
     return ap.parse_args()
 
 
@@ -102,28 +108,54 @@ def main():
     model.mask_type, model.use_passion, model.compute_dtype = "idt", passion, dtype
     model.train()                                   # dropout live, as in the reference's training loop
     reducer = parallel.GradReducer(model, ctx)
-    opt = ptrain.make_optimizer(model)
+    use_graph = ctx.world == 1 and args.graph and not args.no_graph
+    opt = ptrain.make_optimizer(model, capturable=use_graph)
     state = ptrain.LossState(ctx.device)
     x, target, mask = ptrain.synthetic_batch(batch, S, ctx.device, seed=7 + ctx.rank)   # resident in HBM before timing
 
-    def step():
+    def eager_step():
         return ptrain.train_step(model, opt, x, mask, target, 4.0, state, reducer)
 
+    step = eager_step
+    if use_graph:           # the whole iteration (weight packing, forward, losses, backward, AdamW) as one HIP graph
+        from passion_amd import graph as pgraph
+        try:
+            gstep = pgraph.GraphedTrainStep(model, opt, x, mask, target, temp=4.0, state=state)
+            step = lambda: gstep(x, mask, target)   # the batch is copied into the graph's static buffers every step
+        except Exception as e:  # noqa: BLE001
+            print(f"[bench] HIP-graph capture failed ({type(e).__name__}: {e}); eager steps", file=sys.stderr)
+            use_graph = False
+
     for _ in range(args.warmup):
-        step()
+        wl = step()
+        if os.environ.get("BENCH_DEBUG") == "2":
+            print(f"[bench] warmup loss {float(wl):.5f}", file=sys.stderr)
     parallel.barrier(ctx)
     torch.cuda.synchronize()
-    if not args.no_roofline:
-        ops.prof_enable(1)                          # bit 0: fused IN+LReLU+conv3x3x3 forward launches
+    live_events = not args.no_roofline and not use_graph
+    if live_events:
+        ops.prof_enable(0xF)                        # hipEvent pairs around every conv launch (fwd k3, fwd k1, dgrad, wgrad)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
+        if os.environ.get("BENCH_DEBUG"):
+            print(f"[bench] loss {float(loss):.5f}", file=sys.stderr)
     torch.cuda.synchronize()
     parallel.barrier(ctx)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     ops.prof_enable(0)
     dt = parallel.all_reduce_max(ctx, dt)
+    final_loss = float(loss)
+    prof_steps = args.steps
+    if not args.no_roofline and use_graph and ctx.rank == 0:
+        prof_steps = min(args.steps, 3)             # same step, eager, with the event pairs (see the module docstring)
+        ops.prof_read()
+        ops.prof_enable(0xF)
+        for _ in range(prof_steps):
+            eager_step()
+        torch.cuda.synchronize()
+        ops.prof_enable(0)
 
     if ctx.rank != 0:
         return
@@ -137,25 +169,33 @@ def main():
                                f"{'' if is_rfnet else ', dropout 0.1'} "
                                f"(BASELINE.json configs[{3 if is_rfnet else (2 if passion else 1)}])",
                    "global_batch": batch * ctx.world, "parallelism": f"dp{ctx.world} (RCCL grad all-reduce, sum)",
-                   "final_loss": round(float(loss), 5)},
+                   "final_loss": round(final_loss, 5),
+                   "launch": "one HIP graph per step" if use_graph else "eager"},
     }
     if not args.no_roofline:
-        recs = [r for r in ops.prof_read() if r[0] == 0]
-        if recs:
-            ms = sum(r[1] for r in recs)
-            by = sum(r[2] for r in recs)
-            fl = sum(r[3] for r in recs)
+        recs = ops.prof_read()
+        kinds = {0: ("fwd3", "conv_lean_kernel<3,MT,0,CKB> (fused InstanceNorm+LeakyReLU+Conv3d 3x3x3 forward)"),
+                 1: ("fwd1", "conv_lean_kernel<1,MT,0,CKB> (fused InstanceNorm+LeakyReLU+Conv3d 1x1x1 forward)"),
+                 2: ("dgrad", "conv_lean_kernel<3,MT,2,CKB> / <.,.,1,.> (conv input gradient + LeakyReLU/InstanceNorm backward sums)"),
+                 3: ("wgrad", "wgrad_lean_kernel<KS,MT> (conv weight + bias gradient, InstanceNorm+LeakyReLU recomputed in the loader)")}
+        tot = {k: sum(r[1] for r in recs if r[0] == k) for k in kinds}
+        if recs and max(tot.values()) > 0:
+            dom = max(tot, key=tot.get)
+            rk = [r for r in recs if r[0] == dom]
+            ms, by, fl = sum(r[1] for r in rk), sum(r[2] for r in rk), sum(r[3] for r in rk)
             ach = by / (ms * 1e-3) / 1e9
             traffic = None
             tpath = os.path.join(ROOT, "profiles", "traffic.json")
             if os.path.exists(tpath):
-                traffic = json.load(open(tpath)).get("conv3_fwd_bytes_per_launch")
-            out["roofline"] = {"kernel": "conv_mfma_kernel<.., KS=3, fwd> (fused InstanceNorm+LeakyReLU+Conv3d 3x3x3)",
-                               "bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic,
-                               "launches": len(recs), "avg_launch_ms": round(ms / len(recs), 5),
-                               "algorithmic_bytes_per_launch": round(by / len(recs), 1),
-                               "tflops": round(fl / (ms * 1e-3) / 1e12, 3)}
+                traffic = json.load(open(tpath)).get("bytes_per_launch", {}).get(kinds[dom][0])
+            out["roofline"] = {"kernel": kinds[dom][1], "bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS,
+                               "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic,
+                               "launches_per_step": len(rk) // prof_steps, "avg_launch_ms": round(ms / len(rk), 5),
+                               "algorithmic_bytes_per_launch": round(by / len(rk), 1),
+                               "tflops": round(fl / (ms * 1e-3) / 1e12, 3),
+                               "events": "live, inside the timed region" if live_events else
+                                         f"{prof_steps} eager iterations of the same step after the timed graph replays",
+                               "ms_per_step_by_family": {kinds[k][0]: round(tot[k] / prof_steps, 3) for k in kinds}}
     if not args.no_cpu_baseline and ctx.world == 1 and not is_rfnet:
         out["cpu_baseline"] = cpu_baseline(passion)
     print(json.dumps(out), flush=True)

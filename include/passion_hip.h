@@ -205,6 +205,10 @@ int passion_region_mix_bwd(const void* const* y, void* const* dy, const uint8_t*
 typedef struct { int32_t kind; float ms; double bytes; double flops; } passion_prof_rec_t;
 void passion_prof_enable(int on);
 int passion_prof_read(passion_prof_rec_t* rec, int cap);
+/* like passion_prof_read but leaves the records (and their events) in place: for launches recorded inside a HIP
+ * graph capture, whose event pairs are re-recorded by every replay; ms = latest replay, -1 if it cannot be timed
+ * (ROCm 7.2: hipEventElapsedTime refuses event nodes of a graph, so this returns -1 there) */
+int passion_prof_peek(passion_prof_rec_t* rec, int cap);
 
 #ifdef __cplusplus
 }

@@ -98,6 +98,7 @@ SIGNATURES = {
                                        c_void_p, c_int, c_int, c_int64, c_int, c_void_p, c_void_p, c_void_p]),
     "passion_prof_enable": (None, [c_int]),
     "passion_prof_read": (c_int, [POINTER(ProfRec), c_int]),
+    "passion_prof_peek": (c_int, [POINTER(ProfRec), c_int]),
 }
 
 _lib = None

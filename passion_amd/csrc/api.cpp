@@ -52,6 +52,24 @@ extern "C" int passion_prof_read(passion_prof_rec_t* rec, int cap) {
     return n;
 }
 
+// The same without consuming the records: event pairs that were recorded while a stream capture was running are nodes
+// of that HIP graph and are re-recorded by every replay, so they must stay alive; ms is the elapsed time of the latest
+// replay (or -1 when the runtime cannot time them).
+extern "C" int passion_prof_peek(passion_prof_rec_t* rec, int cap) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    int n = 0;
+    for (size_t i = 0; i < g_pending.size() && n < cap; ++i) {
+        Pending& p = g_pending[i];
+        if (!p.closed) break;
+        float ms = -1.f;
+        if (hipEventSynchronize(p.e1) != hipSuccess || hipEventElapsedTime(&ms, p.e0, p.e1) != hipSuccess) ms = -1.f;
+        rec[n].kind = p.kind; rec[n].ms = ms; rec[n].bytes = p.bytes; rec[n].flops = p.flops;
+        ++n;
+    }
+    (void)hipGetLastError();
+    return n;
+}
+
 // A/B switch for debugging: PASSION_FORCE_F32_MFMA=1 routes bf16 tensors through the f32-MFMA conv kernels.
 extern int g_passion_force_f32_mfma;
 namespace pconv { extern int g_conv_merge, g_wgrad_wide, g_conv_dbg, g_conv_target, g_conv_lean, g_conv_padout; }

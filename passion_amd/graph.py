@@ -19,7 +19,7 @@ from . import train as _train
 
 class GraphedTrainStep:
     def __init__(self, model, optimizer, x, mask, target, temp=4.0, state=None, warmup=False, modal_num=None,
-                 warmup_iters=3):
+                 warmup_iters=3, prof_mask=0):
         assert x.is_cuda, "GraphedTrainStep needs the batch on the GPU"
         self.model, self.optimizer, self.state = model, optimizer, state
         self.temp, self.warmup, self.modal_num = temp, warmup, modal_num
@@ -37,10 +37,20 @@ class GraphedTrainStep:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
-        optimizer.zero_grad(set_to_none=True)
+        # Gradients live OUTSIDE the graph's memory pool: they are the tensors the warm-up steps left in .grad, cleared by
+        # a (captured) foreach-zero at the top of every replay and accumulated into in place.  Letting the capture allocate
+        # them (zero_grad(set_to_none=True) before the capture, the usual recipe) was measured to corrupt four Linear bias
+        # gradients from the third replay on (ROCm 7.2 / torch 2.10: their pool blocks get re-used).
+        if prof_mask:            # hipEvent pairs around the conv launches become event-record nodes of the graph:
+            from . import ops    # ops.prof_read(keep=True) after a replay returns that replay's kernel durations
+            ops.prof_read()
+            ops.prof_enable(prof_mask)
         with torch.cuda.graph(self.graph):
+            optimizer.zero_grad(set_to_none=False)
             self.loss = self._fwd_bwd()
             optimizer.step()
+        if prof_mask:
+            ops.prof_enable(0)
         torch.cuda.synchronize()
 
     def _fwd_bwd(self):

@@ -681,7 +681,10 @@ def prof_enable(on):
     L.load().passion_prof_enable(mask)
 
 
-def prof_read(cap=65536):
+def prof_read(cap=65536, keep=False):
+    """(kind, ms, algorithmic bytes, flops) per timed launch.  keep=True leaves the records in place: the event pairs
+    recorded during a HIP-graph capture are re-timed by every replay."""
     recs = (L.ProfRec * cap)()
-    n = L.load().passion_prof_read(recs, cap)
+    lib = L.load()
+    n = (lib.passion_prof_peek if keep else lib.passion_prof_read)(recs, cap)
     return [(recs[i].kind, recs[i].ms, recs[i].bytes, recs[i].flops) for i in range(n)]
