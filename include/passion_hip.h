@@ -30,6 +30,11 @@ extern "C" {
 #define PASSION_MAX_SEG 4
 
 int passion_abi_version(void);
+/* developer A/B switches, also read from the environment at load time (PASSION_CONV_LEAN, PASSION_CONV_PADOUT,
+ * PASSION_FORCE_F32_MFMA, ...): "conv_lean", "conv_padout", "force_f32_mfma", "conv_target", "conv_merge",
+ * "wgrad_wide", "conv_dbg".  Returns the previous value, -1 for an unknown name.  The parity tests use it to run the
+ * same conv through the general and the lean kernels. */
+int passion_set_option(const char* name, int value);
 
 /* ---- InstanceNorm statistics ------------------------------------------------------------
  * Replaces the reduction half of nn.InstanceNorm3d(affine=False) (code/models/blocks.py:18,

@@ -5,7 +5,7 @@ asked to run on a non-GPU tensor, this module raises.
 """
 import ctypes
 import os
-from ctypes import (POINTER, Structure, c_double, c_float, c_int, c_int32, c_int64, c_uint8,
+from ctypes import (POINTER, Structure, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_uint8,
                     c_void_p)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -96,6 +96,7 @@ SIGNATURES = {
                                        c_int64, c_int, c_void_p]),
     "passion_region_mix_bwd": (c_int, [POINTER(c_void_p), POINTER(c_void_p), c_void_p, c_int, c_void_p, c_void_p,
                                        c_void_p, c_int, c_int, c_int64, c_int, c_void_p, c_void_p, c_void_p]),
+    "passion_set_option": (c_int, [c_char_p, c_int]),
     "passion_prof_enable": (None, [c_int]),
     "passion_prof_read": (c_int, [POINTER(ProfRec), c_int]),
     "passion_prof_peek": (c_int, [POINTER(ProfRec), c_int]),

@@ -31,6 +31,22 @@ void passion_prof_end(hipStream_t st) {
 
 extern "C" int passion_abi_version(void) { return 1; }
 
+// run-time A/B switches (the same ones the environment sets at load time); returns the previous value, -1 = unknown name
+extern int g_passion_force_f32_mfma;
+namespace pconv { extern int g_conv_merge, g_wgrad_wide, g_conv_dbg, g_conv_target, g_conv_lean, g_conv_padout; }
+extern "C" int passion_set_option(const char* name, int value) {
+    struct { const char* n; int* p; } opts[] = {
+        {"force_f32_mfma", &g_passion_force_f32_mfma}, {"conv_lean", &pconv::g_conv_lean}, {"conv_padout", &pconv::g_conv_padout},
+        {"conv_target", &pconv::g_conv_target}, {"conv_merge", &pconv::g_conv_merge}, {"wgrad_wide", &pconv::g_wgrad_wide},
+        {"conv_dbg", &pconv::g_conv_dbg}};
+    for (auto& o : opts) {
+        const char *a = o.n, *b = name;
+        while (*a && *a == *b) { ++a; ++b; }
+        if (!*a && !*b) { const int old = *o.p; *o.p = value; return old; }
+    }
+    return -1;
+}
+
 extern "C" void passion_prof_enable(int on) { g_passion_prof_on = on; }
 
 // Drains finished records (synchronises on their events: call outside the timed region).

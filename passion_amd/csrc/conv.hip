@@ -277,10 +277,12 @@ __global__ void in_bwd_finish_pad_kernel(T* __restrict__ dx, const T* __restrict
                                          int cbase, int bmod, int rep, long rep_stride) {
     __shared__ float fs[512];
     const int b = blockIdx.y;
-    for (int i = threadIdx.x; i < 2 * C && i < 512; i += blockDim.x) {
-        float a = 0.f;
-        for (int r = 0; r < rep; ++r) a += sums[(long)r * rep_stride + ((long)b * Cin_tot + cbase) * 2 + i];
-        fs[i] = a;
+    if (stats) {
+        for (int i = threadIdx.x; i < 2 * C && i < 512; i += blockDim.x) {
+            float a = 0.f;
+            for (int r = 0; r < rep; ++r) a += sums[(long)r * rep_stride + ((long)b * Cin_tot + cbase) * 2 + i];
+            fs[i] = a;
+        }
     }
     __syncthreads();
     const long V = (long)D * H * W;
@@ -308,6 +310,7 @@ __global__ void in_bwd_finish_pad_kernel(T* __restrict__ dx, const T* __restrict
                 for (int e = 0; e < nh; ++e)
                     for (int f = 0; f < nw; ++f)
                         g += load4(pb + ((((long)dl[a]) * (H + 2) + hl[e]) * (W + 2) + wl[f]) * Cin_tot + c);
+            if (!stats) { store4(dxb + i * 4, g); continue; }      // input was not normalised in the loader: fold only
             const f32x4 xv = load4(xb + i * 4);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -624,7 +627,7 @@ double conv_bytes(const ConvK& k, int xs, int ys) {
 namespace pconv { int g_conv_padout = 1; }   // PASSION_CONV_PADOUT=0: reflect adjoint through mirror taps everywhere (A/B)
 
 // dgrad over the padded domain (conv_lean.hip MODE 2) + folding finish kernel: 3x3x3 stride-1 reflect-padded bf16 convs
-// whose every differentiated input is normalised in the loader (so the finish pass exists anyway)
+// (the finish kernel folds the halo planes; for inputs normalised in the loader it also completes InstanceNorm backward)
 static bool use_padout(const ConvK& k, const passion_conv_desc_t* d) {
     if (!pconv::g_conv_lean || !pconv::g_conv_padout || g_passion_force_f32_mfma) return false;
     if (d->ksize != 3 || d->stride != 1 || d->pad_mode != PASSION_PAD_REFLECT) return false;
@@ -632,7 +635,7 @@ static bool use_padout(const ConvK& k, const passion_conv_desc_t* d) {
     if (k.Di < 2 || k.Hi < 2 || k.Wi < 2 || k.Cin % 4 || !pconv::lean_covers(k, 1, true)) return false;
     bool any = false;
     for (int s = 0; s < k.nseg; ++s)
-        if (k.seg[s].dx) { if (!k.seg[s].stats) return false; any = true; }
+        if (k.seg[s].dx) any = true;
     return any;
 }
 static long padout_floats(const ConvK& k) {     // bf16 [B][D+2][H+2][W+2][Cin]
@@ -871,7 +874,7 @@ extern "C" int passion_conv3d_bwd(const passion_conv_desc_t* d, const float* pac
     const long V = (long)k.Di * k.Hi * k.Wi;
     for (int s = 0; s < k.nseg; ++s) {
         const SegD& sg = k.seg[s];
-        if (!sg.dx || !sg.stats) continue;
+        if (!sg.dx || (!sg.stats && !padout)) continue;
         const long nvec = V * sg.C / 4;
         dim3 grid((unsigned)hmin((nvec + 255) / 256, 2048), k.B);
         if (padout) {

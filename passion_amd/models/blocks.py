@@ -14,6 +14,8 @@ from .. import _lib as L
 from .. import ops
 
 PAD = {"zeros": L.PAD_ZEROS, "reflect": L.PAD_REFLECT}
+import os as _os
+MATERIALIZE = _os.environ.get("PASSION_MATERIALIZE", "0") == "1"   # experiment: activations normalised once per tensor
 
 
 class Feat:
@@ -23,11 +25,12 @@ class Feat:
     (teacher + uni-modal students) over the same B samples in one launch (ops.SegIn.bmod).
     `stats_out`: optional preallocated (B,C,2) slot the statistics are written into (one slice of the
     statistics of a stacked buffer)."""
-    __slots__ = ("t", "_stats", "mask", "mask_col", "passes", "stats_out")
+    __slots__ = ("t", "_stats", "mask", "mask_col", "passes", "stats_out", "_act")
 
-    def __init__(self, t, mask=None, mask_col=0, _stats=None, passes=1, stats_out=None):
+    def __init__(self, t, mask=None, mask_col=0, _stats=None, passes=1, stats_out=None, _act=None):
         self.t, self.mask, self.mask_col, self.passes, self.stats_out = t, mask, mask_col, passes, stats_out
         self._stats = _stats if _stats is not None else [None]   # shared between masked views of one tensor
+        self._act = _act if _act is not None else [None]         # LeakyReLU(InstanceNorm(t)) when materialised
 
     def stats(self):
         if self._stats[0] is None:
@@ -35,11 +38,18 @@ class Feat:
         return self._stats[0]
 
     def with_mask(self, mask, col, passes=1):
-        return Feat(self.t, mask, col, self._stats, passes, self.stats_out)
+        return Feat(self.t, mask, col, self._stats, passes, self.stats_out, self._act)
+
+    def act(self):
+        if self._act[0] is None:
+            self._act[0] = ops.norm_act(self.t, self.stats())
+        return self._act[0]
 
     def seg(self, norm=True):
-        return ops.SegIn(self.t, stats=self.stats() if norm else None, mask=self.mask, mask_col=self.mask_col,
-                         bmod=self.t.shape[0] if self.passes > 1 else 0)
+        bmod = self.t.shape[0] if self.passes > 1 else 0
+        if norm and MATERIALIZE:      # the conv loaders then copy instead of normalising every halo voxel again
+            return ops.SegIn(self.act(), stats=None, mask=self.mask, mask_col=self.mask_col, bmod=bmod)
+        return ops.SegIn(self.t, stats=self.stats() if norm else None, mask=self.mask, mask_col=self.mask_col, bmod=bmod)
 
     @property
     def dims(self):

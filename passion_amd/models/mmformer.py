@@ -315,6 +315,13 @@ class Model(nn.Module):
         vol = tok.to(self.compute_dtype).contiguous().view(P * B, p, p, p, self.token_dim * num_modals)
         return run_conv(self.multimodal_decode_conv, Feat(vol), norm=False)
 
+    def _onehots_on(self, dev):
+        """masks_mod0..3 (plain CPU attributes, as in the reference) copied to the device once, not per forward"""
+        cache = self.__dict__.setdefault("_onehots_dev", {})
+        if dev not in cache:
+            cache[dev] = [getattr(self, f"masks_mod{i}").to(dev) for i in range(4)]
+        return cache[dev]
+
     def forward(self, x, mask, target=None, temp=1.0):
         L.require_gpu(x)
         ops.repack_stale()       # all conv weights the optimizer touched, one launch
@@ -349,7 +356,7 @@ class Model(nn.Module):
         masks_all, tok_mask = mask, None
         if passion:
             P = 5
-            onehots = [getattr(self, f"masks_mod{i}").to(dev).expand(B, 4) for i in range(4)]
+            onehots = [t.expand(B, 4) for t in self._onehots_on(dev)]
             # idt: absent-by-data modalities stay zero as well -- the student sees mask AND one-hot
             studs = [(mask & onehots[i]) if idt else onehots[i] for i in range(4)]
             masks_all = torch.cat([mask] + studs, 0).contiguous()

@@ -180,6 +180,13 @@ class Model(nn.Module):
             if isinstance(m, nn.Conv3d):
                 torch.nn.init.kaiming_normal_(m.weight)
 
+    def _onehots_on(self, dev):
+        """masks_mod0..3 (plain CPU attributes, as in the reference) copied to the device once, not per forward"""
+        cache = self.__dict__.setdefault("_onehots_dev", {})
+        if dev not in cache:
+            cache[dev] = [getattr(self, f"masks_mod{i}").to(dev) for i in range(4)]
+        return cache[dev]
+
     def forward(self, x, mask, target=None, temp=1.0):
         L.require_gpu(x)
         ops.repack_stale()       # all conv weights the optimizer touched, one launch
@@ -222,7 +229,7 @@ class Model(nn.Module):
         pt_deep = [ops.upsample(ops.softmax_classes(pp.detach(), inv_t, "cl"), ups[j]) for j, pp in enumerate(preds)]
         f_teacher = materialize(de_f_avg[0]).t.detach()
         kl_loss, proto_loss, dist = (torch.zeros(B, 4, device=dev) for _ in range(3))
-        onehots = [getattr(self, f"masks_mod{i}").to(dev).expand(B, 4).contiguous() for i in range(4)]
+        onehots = [t.expand(B, 4).contiguous() for t in self._onehots_on(dev)]
         for i in range(4):
             eff = (mask & onehots[i]).contiguous() if idt else onehots[i]
             fuse_i, preds_i, de_f_i = self.decoder_fuse(*[modal_feats(l, eff) for l in range(4)])

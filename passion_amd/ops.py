@@ -675,6 +675,14 @@ def region_mix(prob, mask, w, ys):
 # ------------------------------------------------------------------------------------------------
 # kernel timing hooks (bench.py)
 # ------------------------------------------------------------------------------------------------
+def set_option(name, value):
+    """run-time A/B switch of the library (see passion_set_option in include/passion_hip.h); returns the old value"""
+    old = L.load().passion_set_option(name.encode(), int(value))
+    if old < 0:
+        raise ValueError(f"unknown libpassion_hip option {name!r}")
+    return old
+
+
 def prof_enable(on):
     """on: False/0 = off, True = all conv kinds, or a bitmask (bit0 fwd k3, bit1 fwd k1, bit2 dgrad, bit3 wgrad)"""
     mask = 0xF if on is True else int(on or 0)

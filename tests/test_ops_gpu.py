@@ -111,6 +111,72 @@ def test_conv_block_fwd_bwd(case, dtype):
         assert e < tol * 3, f"dx[{i}] {e}"
 
 
+PATH_CASES = [
+    # bigger volumes: several bricks per persistent workgroup, interior + border + partial bricks
+    ([8], 8, 3, 1, 1, (12, 24, 40), True, False, True),
+    ([8, 8], 16, 3, 1, 1, (9, 20, 28), True, True, False),
+    ([32], 32, 3, 1, 1, (8, 16, 24), True, False, False),
+    ([8, 8, 8, 8], 8, 1, 1, 0, (12, 16, 24), True, True, False),
+    ([16], 16, 3, 1, 0, (8, 24, 24), True, False, False),
+    ([8], 8, 3, 1, 1, (12, 16, 24), False, False, False),      # reflect pad, input NOT normalised (fold-only finish)
+]
+PATHS = {"lean": {}, "lean_mirror_taps": {"conv_padout": 0}, "general": {"conv_lean": 0}, "few_workgroups": {"conv_target": 8}}
+
+
+@pytest.mark.parametrize("path", list(PATHS))
+@pytest.mark.parametrize("case", PATH_CASES, ids=[str(i) for i in range(len(PATH_CASES))])
+def test_conv_kernel_paths(case, path):
+    """the same bf16 conv through the lean persistent kernels (default), the lean dgrad with mirror taps instead of the
+    padded domain, the general one-brick-per-workgroup kernels, and with so few persistent workgroups that each walks
+    many bricks -- all against the f64 reference"""
+    from passion_amd import ops
+    dev = _dev()
+    old = {k: ops.set_option(k, v) for k, v in PATHS[path].items()}
+    try:
+        test_conv_block_fwd_bwd(case, torch.bfloat16)
+    finally:
+        for k, v in old.items():
+            ops.set_option(k, v)
+
+
+def test_conv_batched_passes():
+    """SegIn.bmod: P masked passes over the same B samples in one launch == P separate launches, gradients summed"""
+    from passion_amd import ops
+    dev = _dev()
+    B, P, C, Cout, D, H, W = 2, 3, 8, 8, 8, 8, 16
+    g = torch.Generator().manual_seed(5)
+    xs = [(torch.randn(B, D, H, W, C, generator=g) * 1.3).to(dev, torch.bfloat16) for _ in range(2)]
+    w = (torch.randn(Cout, 2 * C, 3, 3, 3, generator=g) / (2 * C * 27) ** 0.5).to(dev)
+    b = torch.randn(Cout, generator=g).to(dev)
+    masks = torch.tensor([[1, 1], [1, 0], [1, 1], [0, 1], [0, 0], [1, 1]], dtype=torch.bool, device=dev)   # (P*B, 2)
+    gy = torch.randn(P * B, D, H, W, Cout, generator=g).to(dev, torch.bfloat16)
+    stats = [ops.instnorm_stats(x) for x in xs]
+
+    def run(batched):
+        xl = [x.clone().requires_grad_(True) for x in xs]
+        wl, bl = w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+        if batched:
+            segs = [ops.SegIn(x, stats=st, mask=masks, mask_col=i, bmod=B) for i, (x, st) in enumerate(zip(xl, stats))]
+            y = ops.conv_block(segs, wl, bl, D, H, W)
+            y.backward(gy)
+        else:
+            ys = []
+            for p_ in range(P):
+                mk = masks[p_ * B:(p_ + 1) * B].contiguous()
+                segs = [ops.SegIn(x, stats=st, mask=mk, mask_col=i) for i, (x, st) in enumerate(zip(xl, stats))]
+                ys.append(ops.conv_block(segs, wl, bl, D, H, W))
+            y = torch.cat(ys, 0)
+            y.backward(gy)
+        return y.detach().float(), [x.grad.float() for x in xl], wl.grad, bl.grad
+
+    ya, dxa, dwa, dba = run(True)
+    yb, dxb, dwb, dbb = run(False)
+    assert torch.equal(ya, yb)
+    assert relerr(dwa, dwb) < 2e-3 and relerr(dba, dbb) < 2e-3
+    for a, c in zip(dxa, dxb):
+        assert relerr(a, c) < 2e-2     # bf16 per-pass gradients are summed in a different order
+
+
 def test_conv_raw_input_segments():
     """first encoder conv: one modality of the NCDHW input = one C=1 segment, masked per sample"""
     from passion_amd import ops
