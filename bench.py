@@ -173,29 +173,34 @@ def main():
                    "launch": "one HIP graph per step" if use_graph else "eager"},
     }
     if not args.no_roofline:
-        recs = ops.prof_read()
-        kinds = {0: ("fwd3", "conv_lean_kernel<3,MT,0,CKB> (fused InstanceNorm+LeakyReLU+Conv3d 3x3x3 forward)"),
-                 1: ("fwd1", "conv_lean_kernel<1,MT,0,CKB> (fused InstanceNorm+LeakyReLU+Conv3d 1x1x1 forward)"),
-                 2: ("dgrad", "conv_lean_kernel<3,MT,2,CKB> / <.,.,1,.> (conv input gradient + LeakyReLU/InstanceNorm backward sums)"),
-                 3: ("wgrad", "wgrad_lean_kernel<KS,MT> (conv weight + bias gradient, InstanceNorm+LeakyReLU recomputed in the loader)")}
-        tot = {k: sum(r[1] for r in recs if r[0] == k) for k in kinds}
-        if recs and max(tot.values()) > 0:
-            dom = max(tot, key=tot.get)
-            rk = [r for r in recs if r[0] == dom]
+        recs = [r for r in ops.prof_read() if r[1] >= 0]
+        fam = {0: "fwd3", 1: "fwd1", 2: "dgrad", 3: "wgrad"}
+        what = {0: "fused InstanceNorm+LeakyReLU+Conv3d 3x3x3 forward", 1: "fused InstanceNorm+LeakyReLU+Conv3d 1x1x1 forward",
+                2: "conv input gradient + LeakyReLU'/mask + InstanceNorm-backward sums",
+                3: "conv weight + bias gradient (InstanceNorm+LeakyReLU recomputed in the loader)"}
+        tot = {}
+        for r in recs:                              # per kernel instantiation, as rocprofv3 names it
+            tot[r[4]] = tot.get(r[4], 0.0) + r[1]
+        if tot:
+            dom = max(tot, key=tot.get)             # the kernel with the largest total time in the timed region
+            rk = [r for r in recs if r[4] == dom]
             ms, by, fl = sum(r[1] for r in rk), sum(r[2] for r in rk), sum(r[3] for r in rk)
             ach = by / (ms * 1e-3) / 1e9
             traffic = None
             tpath = os.path.join(ROOT, "profiles", "traffic.json")
             if os.path.exists(tpath):
-                traffic = json.load(open(tpath)).get("bytes_per_launch", {}).get(kinds[dom][0])
-            out["roofline"] = {"kernel": kinds[dom][1], "bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS,
-                               "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic,
+                traffic = json.load(open(tpath)).get("bytes_per_launch", {}).get(dom)
+            fam_ms = {}
+            for r in recs:
+                fam_ms[fam[r[0]]] = fam_ms.get(fam[r[0]], 0.0) + r[1]
+            out["roofline"] = {"kernel": f"{dom} ({what[rk[0][0]]})", "bound": "hbm", "achieved": round(ach, 2),
+                               "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic,
                                "launches_per_step": len(rk) // prof_steps, "avg_launch_ms": round(ms / len(rk), 5),
                                "algorithmic_bytes_per_launch": round(by / len(rk), 1),
                                "tflops": round(fl / (ms * 1e-3) / 1e12, 3),
                                "events": "live, inside the timed region" if live_events else
                                          f"{prof_steps} eager iterations of the same step after the timed graph replays",
-                               "ms_per_step_by_family": {kinds[k][0]: round(tot[k] / prof_steps, 3) for k in kinds}}
+                               "ms_per_step_by_family": {k: round(v / prof_steps, 3) for k, v in sorted(fam_ms.items())}}
     if not args.no_cpu_baseline and ctx.world == 1 and not is_rfnet:
         out["cpu_baseline"] = cpu_baseline(passion)
     print(json.dumps(out), flush=True)

@@ -206,8 +206,9 @@ int passion_region_mix_bwd(const void* const* y, void* const* dy, const uint8_t*
 /* ---- in-library kernel timing (bench.py roofline leg) ------------------------------------------
  * passion_prof_enable(mask): bit k of `mask` selects launches of kind k; selected conv3d launches are
  * bracketed by hipEvents on their own stream and their algorithmic bytes / flops recorded.  passion_prof_read drains up to `cap` records:
- * rec[i] = {kind, ms, bytes, flops}. kind: 0 fwd k3, 1 fwd k1, 2 dgrad, 3 wgrad. */
-typedef struct { int32_t kind; float ms; double bytes; double flops; } passion_prof_rec_t;
+ * rec[i] = {kind, ms, bytes, flops, name}. kind: 0 fwd k3, 1 fwd k1, 2 dgrad, 3 wgrad; name = the kernel instantiation
+ * that ran, spelled as rocprofv3 prints it (e.g. "wgrad_lean_kernel<3, 1>"). */
+typedef struct { int32_t kind; float ms; double bytes; double flops; char name[64]; } passion_prof_rec_t;
 void passion_prof_enable(int on);
 int passion_prof_read(passion_prof_rec_t* rec, int cap);
 /* like passion_prof_read but leaves the records (and their events) in place: for launches recorded inside a HIP

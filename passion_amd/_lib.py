@@ -5,7 +5,7 @@ asked to run on a non-GPU tensor, this module raises.
 """
 import ctypes
 import os
-from ctypes import (POINTER, Structure, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_uint8,
+from ctypes import (POINTER, Structure, c_char, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_uint8,
                     c_void_p)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -30,7 +30,7 @@ class ConvDesc(Structure):
 
 
 class ProfRec(Structure):
-    _fields_ = [("kind", c_int32), ("ms", c_float), ("bytes", c_double), ("flops", c_double)]
+    _fields_ = [("kind", c_int32), ("ms", c_float), ("bytes", c_double), ("flops", c_double), ("name", c_char * 64)]
 
 
 # name -> (restype, argtypes).  Must list every symbol include/passion_hip.h declares

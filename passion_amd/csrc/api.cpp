@@ -1,5 +1,7 @@
 // Library-level entry points: ABI version and the optional hipEvent timing of conv launches.
 #include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdio>
 #include <cstdlib>
 #include <mutex>
 #include <vector>
@@ -9,13 +11,15 @@
 int g_passion_prof_on = 0;
 
 namespace {
-struct Pending { int kind; double bytes, flops; hipEvent_t e0, e1; bool closed; };
+struct Pending { int kind; double bytes, flops; hipEvent_t e0, e1; bool closed; char name[64]; };
+thread_local char g_tag[64] = "";
 std::mutex g_mu;
 std::vector<Pending> g_pending;
 }  // namespace
 
 void passion_prof_begin(int kind, double bytes, double flops, hipStream_t st) {
-    Pending p{kind, bytes, flops, nullptr, nullptr, false};
+    Pending p{kind, bytes, flops, nullptr, nullptr, false, ""};
+    g_tag[0] = 0;
     if (hipEventCreate(&p.e0) != hipSuccess || hipEventCreate(&p.e1) != hipSuccess) return;
     hipEventRecord(p.e0, st);
     std::lock_guard<std::mutex> lk(g_mu);
@@ -25,8 +29,21 @@ void passion_prof_begin(int kind, double bytes, double flops, hipStream_t st) {
 void passion_prof_end(hipStream_t st) {
     std::lock_guard<std::mutex> lk(g_mu);
     for (size_t i = g_pending.size(); i-- > 0;) {
-        if (!g_pending[i].closed) { hipEventRecord(g_pending[i].e1, st); g_pending[i].closed = true; break; }
+        if (!g_pending[i].closed) {
+            hipEventRecord(g_pending[i].e1, st);
+            g_pending[i].closed = true;
+            snprintf(g_pending[i].name, sizeof(g_pending[i].name), "%s", g_tag);
+            break;
+        }
     }
+}
+
+void passion_prof_tag(const char* fmt, ...) {
+    if (!g_passion_prof_on) return;
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_tag, sizeof(g_tag), fmt, ap);
+    va_end(ap);
 }
 
 extern "C" int passion_abi_version(void) { return 1; }
@@ -62,6 +79,7 @@ extern "C" int passion_prof_read(passion_prof_rec_t* rec, int cap) {
         hipEventElapsedTime(&ms, p.e0, p.e1);
         hipEventDestroy(p.e0); hipEventDestroy(p.e1);
         rec[n].kind = p.kind; rec[n].ms = ms; rec[n].bytes = p.bytes; rec[n].flops = p.flops;
+        snprintf(rec[n].name, sizeof(rec[n].name), "%s", p.name);
         ++n;
     }
     g_pending.erase(g_pending.begin(), g_pending.begin() + i);
@@ -80,6 +98,7 @@ extern "C" int passion_prof_peek(passion_prof_rec_t* rec, int cap) {
         float ms = -1.f;
         if (hipEventSynchronize(p.e1) != hipSuccess || hipEventElapsedTime(&ms, p.e0, p.e1) != hipSuccess) ms = -1.f;
         rec[n].kind = p.kind; rec[n].ms = ms; rec[n].bytes = p.bytes; rec[n].flops = p.flops;
+        snprintf(rec[n].name, sizeof(rec[n].name), "%s", p.name);
         ++n;
     }
     (void)hipGetLastError();

@@ -13,6 +13,7 @@
 //    with one ds_write_b128 per 8 channels.
 // The accumulator layout equals the f32 kernel's, so the epilogues (conv_common.h) are shared.
 #include "conv_common.h"
+#include "prof.h"
 
 namespace pconv { extern int g_conv_merge, g_wgrad_wide, g_conv_lean; }
 using namespace pconv;
@@ -637,6 +638,7 @@ template <int KS, int S, int CKW>
 int launch_wgrad_b(ConvK& k, int MT, int gx, int gy, float* dW, float* db, hipStream_t st) {
     const int tiles_per_b = k.tilesD * k.tilesH * k.tilesW;
     dim3 grid(gx, gy);
+    passion_prof_tag("conv_wgrad_bf16_kernel<%d, %d, %d, %d>", KS, S, MT == 2 ? 2 : 1, CKW);
     if (MT == 2) hipLaunchKernelGGL((conv_wgrad_bf16_kernel<KS, S, 2, CKW>), grid, dim3(256), 0, st, k, dW, db, tiles_per_b);
     else hipLaunchKernelGGL((conv_wgrad_bf16_kernel<KS, S, 1, CKW>), grid, dim3(256), 0, st, k, dW, db, tiles_per_b);
     LAUNCH_RET();
@@ -678,6 +680,7 @@ int launch_one(ConvK& k, dim3 grid, hipStream_t st) {
                                     hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
         attr_set = true;
     }
+    passion_prof_tag("conv_bf16_kernel<%d, %d, %d, %d, %d>", KS, S, MT, MODE, CKB);
     hipLaunchKernelGGL((conv_bf16_kernel<KS, S, MT, MODE, CKB>), grid, dim3(256), bytes, st, k);
     LAUNCH_RET();
     return 0;

@@ -12,6 +12,7 @@
 //   * interior bricks (no padding involved) take a branch-free addressing path: address = brick base + constant;
 //   * the next step's brick is fetched into registers while the matrix cores work on the current one.
 #include "conv_common.h"
+#include "prof.h"
 
 namespace pconv { extern int g_conv_target, g_conv_dbg; }
 using namespace pconv;
@@ -600,6 +601,7 @@ int launch_lean_one(ConvK& k, int K8, int gy, hipStream_t st) {
                                     hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
         attr_bytes = bytes;
     }
+    passion_prof_tag("conv_lean_kernel<%d, %d, %d, %d>", KS, MT, MODE, CKB);
     hipLaunchKernelGGL((conv_lean_kernel<KS, MT, MODE, CKB>), dim3(gx, gy), dim3(256), bytes, st, k);
     LAUNCH_RET();
     return 0;

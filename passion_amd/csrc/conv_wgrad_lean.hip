@@ -10,6 +10,7 @@
 // brick-invariant constants (interior bricks: address = brick base + constant), the MFMA loop is fully unrolled
 // over immediates, and brick coordinates advance incrementally.
 #include "conv_common.h"
+#include "prof.h"
 
 using namespace pconv;
 
@@ -312,6 +313,7 @@ __global__ __launch_bounds__(256) void wgrad_lean_kernel(ConvK p, float* __restr
 template <int KS>
 int launch_wl(ConvK& k, int MT, int gx, int gy, float* dW, float* db, hipStream_t st) {
     dim3 grid(gx, gy);
+    passion_prof_tag("wgrad_lean_kernel<%d, %d>", KS, MT == 2 ? 2 : 1);
     if (MT == 2) hipLaunchKernelGGL((wgrad_lean_kernel<KS, 2>), grid, dim3(256), 0, st, k, dW, db);
     else hipLaunchKernelGGL((wgrad_lean_kernel<KS, 1>), grid, dim3(256), 0, st, k, dW, db);
     LAUNCH_RET();

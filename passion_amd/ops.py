@@ -690,9 +690,9 @@ def prof_enable(on):
 
 
 def prof_read(cap=65536, keep=False):
-    """(kind, ms, algorithmic bytes, flops) per timed launch.  keep=True leaves the records in place: the event pairs
+    """(kind, ms, algorithmic bytes, flops, kernel name) per timed launch.  keep=True leaves the records in place: the event pairs
     recorded during a HIP-graph capture are re-timed by every replay."""
     recs = (L.ProfRec * cap)()
     lib = L.load()
     n = (lib.passion_prof_peek if keep else lib.passion_prof_read)(recs, cap)
-    return [(recs[i].kind, recs[i].ms, recs[i].bytes, recs[i].flops) for i in range(n)]
+    return [(recs[i].kind, recs[i].ms, recs[i].bytes, recs[i].flops, recs[i].name.decode()) for i in range(n)]

@@ -43,7 +43,7 @@ def test_struct_layout_matches_header():
     # passion_seg_t: 4 pointers + int64 + 4 int32 = 56 bytes; conv desc: 12 x 4-byte fields + 4 segments
     assert ctypes.sizeof(_lib.Seg) == 56
     assert ctypes.sizeof(_lib.ConvDesc) == 48 + 4 * 56
-    assert ctypes.sizeof(_lib.ProfRec) == 24
+    assert ctypes.sizeof(_lib.ProfRec) == 24 + 64      # {kind, ms, bytes, flops, char name[64]}
 
 
 def test_product_path_has_no_cpu_fallback():

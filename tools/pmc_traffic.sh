@@ -13,22 +13,15 @@ cd $R
 python3 - "$OUT" <<'PY'
 import csv, glob, collections, json, re, sys
 fam = collections.defaultdict(lambda: collections.defaultdict(list))
-def family(k):
-    m = re.search(r"conv_lean_kernel<(\d), (\d), (\d), (\d+)>", k)
-    if m:
-        return {"0": "fwd3" if m.group(1) == "3" else "fwd1"}.get(m.group(3), "dgrad")
-    if "wgrad_lean_kernel" in k or "conv_wgrad" in k:
-        return "wgrad"
-    m = re.search(r"conv_bf16_kernel<(\d), (\d), (\d), (\d), (\d+)>", k)
-    if m:
-        return "dgrad" if m.group(4) == "1" else ("fwd3" if m.group(1) == "3" else "fwd1")
-    return None
+def family(k):                      # kernel instantiation, spelled like the names bench.py gets from the library
+    m = re.search(r"((conv_lean_kernel|wgrad_lean_kernel|conv_bf16_kernel|conv_wgrad_bf16_kernel)<[0-9, ]+>)", k)
+    return m.group(1) if m else None
 for f in glob.glob("gpurun_out/pmc_traffic/*/*/*counter_collection.csv"):
     for r in csv.DictReader(open(f)):
         fm = family(r["Kernel_Name"])
         if fm:
             fam[fm][r["Counter_Name"]].append(float(r["Counter_Value"]))
-out = {"unit": "bytes per launch, averaged over the family's launches in one training step",
+out = {"unit": "bytes per launch, averaged over that kernel's launches in the traced training steps",
        "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; KiB -> bytes; FETCH_SIZE x2 (gfx950)",
        "bytes_per_launch": {}, "fetch_bytes": {}, "write_bytes": {}, "launches": {}}
 for fm, d in fam.items():
