@@ -569,6 +569,8 @@ int launch_conv_mt(ConvK& k, int mtiles, hipStream_t st) {
 
 template <typename TI, typename TO, int MODE>
 int launch_conv_geo(ConvK& k, int ksize, int stride, int mtiles, hipStream_t st) {
+    passion_prof_tag("conv_mfma_kernel<%s, %s, KS=%d, S=%d, MODE=%d>", sizeof(TI) == 4 ? "float" : "bf16", sizeof(TO) == 4 ? "float" : "bf16",
+                     ksize, stride, MODE);
     if (ksize == 1) return launch_conv_mt<TI, TO, 1, 1, MODE>(k, mtiles, st);
     if (stride == 1) return launch_conv_mt<TI, TO, 3, 1, MODE>(k, mtiles, st);
     return launch_conv_mt<TI, TO, 3, 2, MODE>(k, mtiles, st);
@@ -601,6 +603,7 @@ template <typename TX, typename TY, int KS, int S>
 int launch_wgrad_mt(ConvK& k, const WgPlan& w, float* dW, float* db, hipStream_t st) {
     const int tiles_per_b = k.tilesD * k.tilesH * k.tilesW;
     dim3 grid(w.gx, w.gy);
+    passion_prof_tag("conv_wgrad_kernel<%s, %s, %d, %d, %d>", sizeof(TX) == 4 ? "float" : "bf16", sizeof(TY) == 4 ? "float" : "bf16", KS, S, w.MT);
     if (w.MT == 2) {
         if constexpr (S == 1) hipLaunchKernelGGL((conv_wgrad_kernel<TX, TY, KS, S, 2>), grid, dim3(256), 0, st, k, dW, db, w.chunks, tiles_per_b);
     } else hipLaunchKernelGGL((conv_wgrad_kernel<TX, TY, KS, S, 1>), grid, dim3(256), 0, st, k, dW, db, w.chunks, tiles_per_b);
