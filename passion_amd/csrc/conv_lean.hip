@@ -52,6 +52,16 @@ static_assert(sizeof(EpiDesc) == 64, "EpiDesc layout");
 constexpr int MAXBLK = 32;       // K <= 256 channels
 constexpr int DESC_BYTES = MAXBLK * (int)sizeof(BlkDesc);
 
+// Values that are the same in every lane but arrive through LDS or per-thread arithmetic look divergent to the compiler:
+// branches on them become exec-masked regions (with copies of every live accumulator) and their address arithmetic runs
+// on the vector ALU.  readfirstlane moves them to scalar registers.
+__device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
+template <typename T> __device__ __forceinline__ T* rfl_ptr(T* p) {
+    const unsigned long long v = reinterpret_cast<unsigned long long>(p);
+    const unsigned lo = (unsigned)rfl((int)(unsigned)v), hi = (unsigned)rfl((int)(unsigned)(v >> 32));
+    return reinterpret_cast<T*>(((unsigned long long)hi << 32) | lo);
+}
+
 __device__ __forceinline__ bf16x8 zero8() {
     bf16x8 z;
 #pragma unroll
@@ -80,7 +90,8 @@ __global__ __launch_bounds__(256) void conv_lean_kernel(ConvK p) {
     __shared__ int mcnt[4];
     __shared__ unsigned char mtab[3][5][8];   // [axis d,h,w][option][local coordinate] = tap | valid << 2 | brick position << 3
 
-    const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, n = lane & 15, g = lane >> 4;
+    const int tid = threadIdx.x, lane = tid & 63, n = lane & 15, g = lane >> 4;
+    const int wv = rfl(tid >> 6);
     const int mg = blockIdx.y;
     // stride 1: the GEMM's output volume (fwd: y, dgrad: dx) and its source volume (fwd: x, dgrad: dy) coincide
     const int Sd = p.Di, Sh = p.Hi, Sw = p.Wi;
@@ -200,6 +211,7 @@ __global__ __launch_bounds__(256) void conv_lean_kernel(ConvK p) {
     unsigned chunk_live = 0u;                     // chunks with at least one present block
     for (int gb = 0; gb < K8; ++gb)
         if (desc[gb].nch > 0) chunk_live |= 1u << (gb / NC8);
+    chunk_live = (unsigned)rfl((int)chunk_live);
 
     // ---- per-lane constants
     const int jj = tid % NC8;
@@ -243,8 +255,11 @@ __global__ __launch_bounds__(256) void conv_lean_kernel(ConvK p) {
     auto fetch = [&](int chunk, int o0d, int o0h, int o0w) {
         const BlkDesc* dp = desc + chunk * NC8 + jj;
         const bf16_t* src = dp->src;
-        const int C = dp->C;
-        const bool have = dp->nch > 0 && chunk * NC8 + jj < K8;
+        int C = dp->C;
+        bool have = dp->nch > 0 && chunk * NC8 + jj < K8;
+        if (NC8 == 1) {                               // one block per chunk: the descriptor is the same for every thread
+            src = rfl_ptr(src); C = rfl(C); have = rfl(have ? 1 : 0) != 0;
+        }
         okbits = 0u;
         const bool interior = o0d >= G::HALO && o0h >= G::HALO && o0w >= G::HALO && o0d + TD + G::HALO <= Sd &&
                               o0h + TH + G::HALO <= Sh && o0w + TW + G::HALO <= Sw;
@@ -281,7 +296,8 @@ __global__ __launch_bounds__(256) void conv_lean_kernel(ConvK p) {
     };
     auto commit = [&](int chunk) {
         const BlkDesc* dp = desc + chunk * NC8 + jj;
-        const bool norm = dp->has_norm != 0 && okbits != 0u;
+        const bool hn = (NC8 == 1) ? rfl(dp->has_norm) != 0 : dp->has_norm != 0;
+        const bool norm = hn && okbits != 0u;
         float mean[8], rstd[8];
         if (norm) {
 #pragma unroll
@@ -309,7 +325,8 @@ __global__ __launch_bounds__(256) void conv_lean_kernel(ConvK p) {
 
     // ---- walk the flattened (brick, chunk) steps
     int brick_i = 0;
-    int tw_ = bricktab[0] & 1023, th_ = (bricktab[0] >> 10) & 1023, td_ = bricktab[0] >> 20;
+    const int code0 = rfl(bricktab[0]);
+    int tw_ = code0 & 1023, th_ = (code0 >> 10) & 1023, td_ = code0 >> 20;
     int chunk = 0;
     const int nsteps = nbricks * nchunk;
     const bool nostage = (p.dbg & 1) != 0;
@@ -376,7 +393,7 @@ __global__ __launch_bounds__(256) void conv_lean_kernel(ConvK p) {
         if (n_chunk == nchunk) {
             n_chunk = 0;
             if (++brick_i < nbricks) {
-                const int code = bricktab[brick_i];
+                const int code = rfl(bricktab[brick_i]);
                 n_tw = code & 1023; n_th = (code >> 10) & 1023; n_td = code >> 20;
             }
         }

@@ -45,7 +45,8 @@ __global__ __launch_bounds__(256) void wgrad_lean_kernel(ConvK p, float* __restr
     __shared__ __attribute__((aligned(16))) char lact[VOL * VS];
     __shared__ __attribute__((aligned(16))) char ldy[TD * TH * TW * DYS];
 
-    const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, n = lane & 15, g = lane >> 4;
+    const int tid = threadIdx.x, lane = tid & 63, n = lane & 15, g = lane >> 4;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform: branches on it stay scalar
     const int q = n >> 2, pq = n & 3;
     const int mgroups = p.Mpad / 16 / MT;
     const int mg = blockIdx.y % mgroups;
@@ -129,15 +130,18 @@ __global__ __launch_bounds__(256) void wgrad_lean_kernel(ConvK p, float* __restr
         const int tw = tap % KS, th = (tap / KS) % KS, td = tap / (KS * KS);
         boff[j] = blane + ((td * IH + th) * IW + tw) * VS + (pq & 1) * 8;
     }
-    f32x4 acc[MT][NTW], accb[MT];
+    f32x4 acc[MT][NTW];
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-        accb[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int j = 0; j < NTW; ++j) acc[mt][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    }
+    // dbias[co] = sum_vox dY[vox][co] rides along for free: NTAP is odd, so columns 8..15 of the last column tile are
+    // padding -- their B operand is set to ones and the accumulator columns 8..15 of that tile come out as the bias sums.
+    static_assert(NTAP % 2 == 1, "bias trick needs a padding half-tile");
+    constexpr int JB = (KSPLIT == 1) ? (NTILES - 1) / 4 : NTILES - 1;   // tile slot and ...
+    constexpr int WB = (KSPLIT == 1) ? (NTILES - 1) % 4 : -1;           // ... wave that own the last tile (-1: every wave)
     const bool bias_block = (dbias != nullptr) && (gb0 == 0);
-    const bool do_bias = bias_block && (KSPLIT == 4 || wv == 0);
+    const bool bias_wave = (WB < 0 || wv == WB);
     bf16x8 ones;
 #pragma unroll
     for (int j = 0; j < 8; ++j) ones[j] = (__bf16)1.0f;
@@ -239,16 +243,12 @@ __global__ __launch_bounds__(256) void wgrad_lean_kernel(ConvK p, float* __restr
             const char* bp = lact + ((kd * IH + kh) * IW) * VS;
 #pragma unroll
             for (int j = 0; j < NTW; ++j) {
-                const bf16x8 bv = tr_read8(bp + boff[j], bp + boff[j] + 4 * VS);
-                if (KSPLIT == 1 && wv + 4 * j >= NTILES) continue;   // wave-uniform
+                bf16x8 bv = tr_read8(bp + boff[j], bp + boff[j] + 4 * VS);
+                if (j == JB && bias_wave && n >= 8) bv = ones;        // padding half of the last tile (the lane RECEIVES column n)
+                // (tiles past NTILES on waves 2/3 are computed and dropped at the flush: no branch around an MFMA)
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt)
                     acc[mt][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mt], bv, acc[mt][j], 0, 0, 0);
-            }
-            if (do_bias) {
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
-                    accb[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mt], ones, accb[mt], 0, 0, 0);
             }
         }
     }
@@ -256,28 +256,26 @@ __global__ __launch_bounds__(256) void wgrad_lean_kernel(ConvK p, float* __restr
     if (KSPLIT == 4) {
         // the four waves hold partial sums over disjoint voxels of the SAME outputs: combine through LDS (fixed order)
         __syncthreads();
-        float* red = reinterpret_cast<float*>(ldy);          // [4 waves][MT][NTW + 1][64 lanes][4]
+        float* red = reinterpret_cast<float*>(ldy);          // [4 waves][MT][NTW][64 lanes][4]
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
             for (int j = 0; j < NTW; ++j)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) red[(((wv * MT + mt) * (NTW + 1) + j) * 64 + lane) * 4 + r] = acc[mt][j][r];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) red[(((wv * MT + mt) * (NTW + 1) + NTW) * 64 + lane) * 4 + r] = accb[mt][r];
+                for (int r = 0; r < 4; ++r) red[(((wv * MT + mt) * NTW + j) * 64 + lane) * 4 + r] = acc[mt][j][r];
         }
         __syncthreads();
         if (wv != 0) return;
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
-            for (int j = 0; j <= NTW; ++j)
+            for (int j = 0; j < NTW; ++j)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     float t = 0.f;
 #pragma unroll
-                    for (int w2 = 0; w2 < 4; ++w2) t += red[(((w2 * MT + mt) * (NTW + 1) + j) * 64 + lane) * 4 + r];
-                    if (j < NTW) acc[mt][j][r] = t; else accb[mt][r] = t;
+                    for (int w2 = 0; w2 < 4; ++w2) t += red[(((w2 * MT + mt) * NTW + j) * 64 + lane) * 4 + r];
+                    acc[mt][j][r] = t;
                 }
         }
     }
@@ -299,13 +297,13 @@ __global__ __launch_bounds__(256) void wgrad_lean_kernel(ConvK p, float* __restr
                 }
         }
     }
-    if (bias_block && wv == 0 && n == 0) {
+    if (bias_block && (KSPLIT == 4 || wv == WB) && n == 8) {       // column 8 of the last tile = bias sums
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int co = (mg * MT + mt) * 16 + g * 4 + r;
-                if (co < p.Cout) dbias[(long)blockIdx.x * p.wslot + co] = accb[mt][r];
+                if (co < p.Cout) dbias[(long)blockIdx.x * p.wslot + co] = acc[mt][JB][r];
             }
     }
 }
