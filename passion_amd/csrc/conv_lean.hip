@@ -400,33 +400,48 @@ __global__ __launch_bounds__(256) void conv_lean_kernel(ConvK p) {
         if (step + 1 < nsteps && ((chunk_live >> n_chunk) & 1u) && !nostage)
             fetch(n_chunk, n_td * TD - SHIFT, n_th * TH - SHIFT, n_tw * TW - SHIFT);
 
-        // dgrad epilogue geometry of this lane's output voxel of row nt: voxel index in x (x_hat source; PADOUT: the
-        // reflected position) and in the dx target (PADOUT: the padded scratch volume), or -1 outside the volume
-        auto dg_vox = [&](int nt, int& xv, int& dv) {
-            const int od = o0d + ld_, oh = o0h + lh[nt], ow = o0w + lw;
+        // dgrad epilogue geometry of this lane's four output voxels, once per brick: voxel index in x (x_hat source;
+        // PADOUT: the reflected position) and in the dx target (PADOUT: the padded scratch volume), -1 outside the volume.
+        // Bricks that touch no border (workgroup-uniform test) are brick base + per-lane constant.
+        int xvv[4], dvv[4];
+        if (DG && chunk == nchunk - 1) {
             if (PADOUT) {
-                const bool in = od < Sd + 2 && oh < Sh + 2 && ow < Sw + 2;
-                int rd = od - 1, rh = oh - 1, rw = ow - 1;
-                rd = rd < 0 ? -rd : (rd >= Sd ? 2 * Sd - 2 - rd : rd);
-                rh = rh < 0 ? -rh : (rh >= Sh ? 2 * Sh - 2 - rh : rh);
-                rw = rw < 0 ? -rw : (rw >= Sw ? 2 * Sw - 2 - rw : rw);
-                xv = in ? (rd * Sh + rh) * Sw + rw : -1;
-                dv = (od * (Sh + 2) + oh) * (Sw + 2) + ow;
+                const bool inner = o0d >= 1 && o0h >= 1 && o0w >= 1 && o0d + TD <= Sd + 1 && o0h + TH <= Sh + 1 && o0w + TW <= Sw + 1;
+                if (inner) {
+                    const int xb = ((o0d - 1 + ld_) * Sh + (o0h - 1 + lh0)) * Sw + (o0w - 1 + lw);
+                    const int db = ((o0d + ld_) * (Sh + 2) + (o0h + lh0)) * (Sw + 2) + (o0w + lw);
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt) { xvv[nt] = xb + nt * 2 * Sw; dvv[nt] = db + nt * 2 * (Sw + 2); }
+                } else {
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt) {
+                        const int od = o0d + ld_, oh = o0h + lh[nt], ow = o0w + lw;
+                        const bool in = od < Sd + 2 && oh < Sh + 2 && ow < Sw + 2;
+                        int rd = od - 1, rh = oh - 1, rw = ow - 1;
+                        rd = rd < 0 ? -rd : (rd >= Sd ? 2 * Sd - 2 - rd : rd);
+                        rh = rh < 0 ? -rh : (rh >= Sh ? 2 * Sh - 2 - rh : rh);
+                        rw = rw < 0 ? -rw : (rw >= Sw ? 2 * Sw - 2 - rw : rw);
+                        xvv[nt] = in ? (rd * Sh + rh) * Sw + rw : -1;
+                        dvv[nt] = (od * (Sh + 2) + oh) * (Sw + 2) + ow;
+                    }
+                }
             } else {
-                const bool in = od < Sd && oh < Sh && ow < Sw;
-                xv = in ? (od * Sh + oh) * Sw + ow : -1;
-                dv = xv;
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) {
+                    const int od = o0d + ld_, oh = o0h + lh[nt], ow = o0w + lw;
+                    const bool in = od < Sd && oh < Sh && ow < Sw;
+                    xvv[nt] = in ? (od * Sh + oh) * Sw + ow : -1;
+                    dvv[nt] = xvv[nt];
+                }
             }
-        };
+        }
         if (DG && MT == 1 && chunk == nchunk - 1) {
             const EpiDesc& e = edesc[g];
             if (e.ok && e.has_stats) {
 #pragma unroll
                 for (int nt = 0; nt < 4; ++nt) {
-                    int xv, dv;
-                    dg_vox(nt, xv, dv);
                     xpre[nt] = make_uint2(0u, 0u);
-                    if (xv >= 0) xpre[nt] = *reinterpret_cast<const uint2*>(e.x + (long)xv * e.C);
+                    if (xvv[nt] >= 0) xpre[nt] = *reinterpret_cast<const uint2*>(e.x + (long)xvv[nt] * e.C);
                 }
             }
         }
@@ -509,40 +524,39 @@ __global__ __launch_bounds__(256) void conv_lean_kernel(ConvK p) {
         if (chunk == nchunk - 1 && !(p.dbg & 4)) {
             const int oh4[4] = {o0h + lh[0], o0h + lh[1], o0h + lh[2], o0h + lh[3]};
             if (DG) {
-                // back through LeakyReLU / mask; the InstanceNorm-backward sums accumulate in registers
+                // back through LeakyReLU / mask; the InstanceNorm-backward sums accumulate in registers.  Written without
+                // divergent branches (only the load / store are predicated): `continue`s on per-lane conditions turn the
+                // unrolled loops into exec-masked regions with copies of the live registers.
                 const int dxC = PADOUT ? p.Cin : 0;
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) {
                     const EpiDesc& e = edesc[mt * 4 + g];
-                    if (!e.ok) continue;
+                    const bool ok = e.ok != 0, hs = e.has_stats != 0;
                     f32x4 mean, rstd;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) { mean[j] = e.mean[j]; rstd[j] = e.rstd[j]; }
+                    for (int j = 0; j < 4; ++j) { mean[j] = e.mean[j]; rstd[j] = e.rstd[j]; }     // (0, 1) without statistics
+                    const float f_pos = e.mval, f_neg = hs ? e.mval * p.slope : e.mval;     // LeakyReLU' x modality mask
+                    const int xC = e.C, dC = PADOUT ? dxC : e.C;
 #pragma unroll
                     for (int nt = 0; nt < 4; ++nt) {
-                        int xvox, dvox;
-                        dg_vox(nt, xvox, dvox);
-                        if (xvox < 0) continue;
+                        const bool valid = ok && xvv[nt] >= 0;
+                        uint2 xr = make_uint2(0u, 0u);
+                        if (MT == 1) xr = xpre[nt];
+                        else if (valid && hs) xr = *reinterpret_cast<const uint2*>(e.x + (long)xvv[nt] * xC);
+                        const float xv[4] = {__uint_as_float(xr.x << 16), __uint_as_float(xr.x & 0xffff0000u),
+                                             __uint_as_float(xr.y << 16), __uint_as_float(xr.y & 0xffff0000u)};
+                        const float vf = (valid && hs) ? 1.f : 0.f;
                         f32x4 gv = acc[mt][nt];
-                        if (e.has_stats) {
-                            uint2 xr;
-                            if (MT == 1) xr = xpre[nt];
-                            else xr = *reinterpret_cast<const uint2*>(e.x + (long)xvox * e.C);
-                            const float xv[4] = {__uint_as_float(xr.x << 16), __uint_as_float(xr.x & 0xffff0000u),
-                                                 __uint_as_float(xr.y << 16), __uint_as_float(xr.y & 0xffff0000u)};
 #pragma unroll
-                            for (int j = 0; j < 4; ++j) {
-                                const float xh = (xv[j] - mean[j]) * rstd[j];
-                                const float gg = gv[j] * (xh > 0.f ? 1.f : p.slope) * e.mval;
-                                gv[j] = gg;
-                                s1[mt][j] += gg;
-                                s2v[mt][j] += gg * xh;
-                            }
-                        } else {
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) gv[j] *= e.mval;
+                        for (int j = 0; j < 4; ++j) {
+                            const float xh = (xv[j] - mean[j]) * rstd[j];
+                            const float gg = gv[j] * (xh > 0.f ? f_pos : f_neg);
+                            gv[j] = gg;
+                            const float gs = gg * vf;
+                            s1[mt][j] += gs;
+                            s2v[mt][j] = __builtin_fmaf(gs, xh, s2v[mt][j]);
                         }
-                        store4(e.dx + (long)dvox * (PADOUT ? dxC : e.C), gv);
+                        if (valid) store4(e.dx + (long)dvv[nt] * dC, gv);
                     }
                 }
             } else if (o0d + TD <= Sd && o0h + TH <= Sh && o0w + TW <= Sw) {       // whole brick inside: no per-lane bounds
