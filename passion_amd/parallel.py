@@ -47,14 +47,20 @@ def init(backend=None):
 
 
 class GradReducer:
-    """Bucketed SUM all-reduce of parameter gradients + initial parameter broadcast from rank 0."""
+    """Bucketed SUM all-reduce of parameter gradients + initial parameter broadcast from rank 0.
 
-    def __init__(self, model, ctx, bucket_mb=64):
+    overlap=True (default): every parameter gets a post-accumulate-grad hook; as soon as the last gradient of a bucket
+    has been written during backward the bucket is packed and its all_reduce is issued (async, RCCL's own stream), so
+    the collectives of the late layers run under the backward kernels of the early ones.  all_reduce_grads() then only
+    launches the buckets that never completed (parameters without gradient in this step), waits and unpacks.
+    Buckets are filled in reverse registration order ~ the order in which backward produces gradients."""
+
+    def __init__(self, model, ctx, bucket_mb=32, overlap=True):
         self.ctx = ctx
         self.params = [p for p in model.parameters() if p.requires_grad]
         self.buckets = []
         cur, cur_bytes = [], 0
-        for p in reversed(self.params):            # reverse order ~ order in which backward produces them
+        for p in reversed(self.params):
             cur.append(p)
             cur_bytes += p.numel() * 4
             if cur_bytes >= bucket_mb * (1 << 20):
@@ -64,26 +70,46 @@ class GradReducer:
             self.buckets.append(cur)
         self.flat = [torch.zeros(sum(p.numel() for p in b), dtype=torch.float32, device=self.params[0].device)
                      for b in self.buckets]
+        self.overlap = overlap and ctx.world > 1 and hasattr(torch.Tensor, "register_post_accumulate_grad_hook")
+        self._pending = [len(b) for b in self.buckets]       # gradients still missing per bucket in this backward
+        self._works = [None] * len(self.buckets)
         if ctx.world > 1:
             for p in model.parameters():
                 dist.broadcast(p.data, src=0)
+        if self.overlap:
+            for bi, bucket in enumerate(self.buckets):
+                for p in bucket:
+                    p.register_post_accumulate_grad_hook(self._make_hook(bi))
+
+    def _make_hook(self, bi):
+        def hook(_param):
+            self._pending[bi] -= 1
+            if self._pending[bi] == 0:
+                self._launch(bi)
+        return hook
+
+    def _launch(self, bi):
+        bucket, flat = self.buckets[bi], self.flat[bi]
+        grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in bucket]
+        torch._foreach_copy_(list(flat.split([g.numel() for g in grads])), [g.reshape(-1) for g in grads])
+        self._works[bi] = dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True)
 
     def all_reduce_grads(self):
         if self.ctx.world == 1:
             return
-        works = []
-        for bucket, flat in zip(self.buckets, self.flat):
-            grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in bucket]
-            torch._foreach_copy_(list(flat.split([g.numel() for g in grads])), [g.reshape(-1) for g in grads])
-            works.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True))
-        for w, bucket, flat in zip(works, self.buckets, self.flat):
-            w.wait()
+        for bi in range(len(self.buckets)):
+            if self._works[bi] is None:                  # not (completely) produced by this backward, or overlap off
+                self._launch(bi)
+        for bi, (bucket, flat) in enumerate(zip(self.buckets, self.flat)):
+            self._works[bi].wait()
             views = flat.split([p.numel() for p in bucket])
             for p, v in zip(bucket, views):
                 if p.grad is None:
                     p.grad = v.view_as(p).clone()
                 else:
                     p.grad.copy_(v.view_as(p))
+        self._pending = [len(b) for b in self.buckets]
+        self._works = [None] * len(self.buckets)
 
 
 def barrier(ctx):
