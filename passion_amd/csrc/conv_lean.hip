@@ -313,8 +313,8 @@ __global__ __launch_bounds__(256) void conv_lean_kernel(ConvK p) {
                 for (int c = 0; c < 4; ++c) {      // bf16 pairs -> f32: low half = even channel
                     const float v0 = __uint_as_float(raw[u][c] << 16), v1 = __uint_as_float(raw[u][c] & 0xffff0000u);
                     float t0_ = (v0 - mean[2 * c]) * rstd[2 * c], t1_ = (v1 - mean[2 * c + 1]) * rstd[2 * c + 1];
-                    t0_ = t0_ > 0.f ? t0_ : t0_ * p.slope;
-                    t1_ = t1_ > 0.f ? t1_ : t1_ * p.slope;
+                    t0_ = fmaxf(t0_, t0_ * p.slope);      // LeakyReLU for 0 <= slope <= 1: one max instead of compare + select
+                    t1_ = fmaxf(t1_, t1_ * p.slope);
                     ob[2 * c] = (__bf16)t0_; ob[2 * c + 1] = (__bf16)t1_;
                 }
                 o = __builtin_bit_cast(u32x4, ob);
@@ -675,6 +675,7 @@ bool lean_covers(const ConvK& k, int stride, bool dgrad) {
 int launch_conv_lean(ConvK& k, int ksize, int stride, int mode, const void* packed_bf16, hipStream_t st) {
     const bool dgrad = mode >= 1;
     if (stride != 1) return 1;
+    if (!(k.slope >= 0.f && k.slope <= 1.f)) return 1;      // the loader's LeakyReLU is max(t, slope * t)
     if (mode == 2 && ksize != 3) return 1;
     const int ntap = ksize * ksize * ksize;
     int K8, cmax = 0;

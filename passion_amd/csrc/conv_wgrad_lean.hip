@@ -210,8 +210,8 @@ __global__ __launch_bounds__(256) void wgrad_lean_kernel(ConvK p, float* __restr
                 for (int c = 0; c < 4; ++c) {      // bf16 pairs -> f32: low half = even channel
                     const float v0 = __uint_as_float(ra[r][c] << 16), v1 = __uint_as_float(ra[r][c] & 0xffff0000u);
                     float t0_ = (v0 - mean[2 * c]) * rstd[2 * c], t1_ = (v1 - mean[2 * c + 1]) * rstd[2 * c + 1];
-                    t0_ = t0_ > 0.f ? t0_ : t0_ * p.slope;
-                    t1_ = t1_ > 0.f ? t1_ : t1_ * p.slope;
+                    t0_ = fmaxf(t0_, t0_ * p.slope);      // LeakyReLU for 0 <= slope <= 1: one max instead of compare + select
+                    t1_ = fmaxf(t1_, t1_ * p.slope);
                     ob[2 * c] = (__bf16)t0_; ob[2 * c + 1] = (__bf16)t1_;
                 }
                 o = __builtin_bit_cast(u32x4, ob);
@@ -326,6 +326,7 @@ namespace pconv {
 // gx = slots of the partial slab = workgroups in x (spare ones flush zeros), gy = (8-channel blocks) x (row-tile groups)
 int launch_wgrad_lean(ConvK& k, int ksize, int stride, int MT, int gx, int gy, float* dW, float* db, hipStream_t st) {
     if (stride != 1 || k.Cout % 8 || gx < k.B) return 1;
+    if (!(k.slope >= 0.f && k.slope <= 1.f)) return 1;      // the loader's LeakyReLU is max(t, slope * t)
     int K8 = 0;
     for (int s = 0; s < k.nseg; ++s) {
         if (k.seg[s].C % 8) return 1;
