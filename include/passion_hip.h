@@ -193,15 +193,17 @@ int passion_norm_act_bwd(const void* x, const float* stats, const void* dout, vo
  * region_gap: sums[b][(i*4+m)*C + c] = sum_v y_m[c] prob_i, sums[b][16*C + i] = sum_v prob_i. */
 int64_t passion_region_scratch_floats(int B, int64_t V, int C);
 int passion_region_gap_fwd(const void* const* y, const uint8_t* mask, int mask_ld, const float* prob,
-                           int dtype, int B, int64_t V, int C, float* scratch, float* sums, void* stream);
+                           int dtype, int B, int64_t V, int C, int bmod, float* scratch, float* sums, void* stream);
 int passion_region_gap_bwd(void* const* dy, const uint8_t* mask, int mask_ld, const float* prob,
                            const float* gS, int dtype, int B, int64_t V, int C, void* stream);
 /* region_mix: out[b][v][i*C + c] = prob_i(v) * sum_m w[b][i][m] * y_m[c](v);  w: [B][4][4] f32 */
 int passion_region_mix_fwd(const void* const* y, const uint8_t* mask, int mask_ld, const float* prob,
-                           const float* w, void* out, int dtype, int B, int64_t V, int C, void* stream);
+                           const float* w, void* out, int dtype, int B, int64_t V, int C, int bmod, void* stream);
 int passion_region_mix_bwd(const void* const* y, void* const* dy, const uint8_t* mask, int mask_ld,
                            const float* prob, const float* w, const void* dR, int dtype, int B, int64_t V,
-                           int C, float* scratch, float* dw, void* stream);
+                           int C, int bmod, float* scratch, float* dw, void* stream);
+/* bmod > 0: y holds only bmod samples and (virtual) sample b of the B given reads y[b % bmod] -- the masked passes of the
+ * PASSION students over the same features in one launch; mask, prob, w, out, dy stay indexed by b. */
 
 /* ---- in-library kernel timing (bench.py roofline leg) ------------------------------------------
  * passion_prof_enable(mask): bit k of `mask` selects launches of kind k; selected conv3d launches are

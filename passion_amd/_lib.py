@@ -89,13 +89,13 @@ SIGNATURES = {
                                      c_int, c_float, c_void_p, c_void_p]),
     "passion_region_scratch_floats": (c_int64, [c_int, c_int64, c_int]),
     "passion_region_gap_fwd": (c_int, [POINTER(c_void_p), c_void_p, c_int, c_void_p, c_int, c_int, c_int64, c_int,
-                                       c_void_p, c_void_p, c_void_p]),
+                                       c_int, c_void_p, c_void_p, c_void_p]),
     "passion_region_gap_bwd": (c_int, [POINTER(c_void_p), c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int64,
                                        c_int, c_void_p]),
     "passion_region_mix_fwd": (c_int, [POINTER(c_void_p), c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int,
-                                       c_int64, c_int, c_void_p]),
+                                       c_int64, c_int, c_int, c_void_p]),
     "passion_region_mix_bwd": (c_int, [POINTER(c_void_p), POINTER(c_void_p), c_void_p, c_int, c_void_p, c_void_p,
-                                       c_void_p, c_int, c_int, c_int64, c_int, c_void_p, c_void_p, c_void_p]),
+                                       c_void_p, c_int, c_int, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "passion_set_option": (c_int, [c_char_p, c_int]),
     "passion_prof_enable": (None, [c_int]),
     "passion_prof_read": (c_int, [POINTER(ProfRec), c_int]),

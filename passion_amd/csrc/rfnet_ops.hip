@@ -21,6 +21,8 @@ struct Mod4 {
     void* dy[4];
     const uint8_t* mask;   // device [B][mask_ld] modality-present flags (NULL: all present)
     int mask_ld;
+    int bmod;              // > 0: y holds bmod samples, virtual sample b reads y[b % bmod] (several masked passes in one launch)
+    __device__ __forceinline__ int ysrc(int b) const { return bmod > 0 ? b % bmod : b; }
     __device__ __forceinline__ bool present(int m, int b) const { return mask ? mask[(long)b * mask_ld + m] != 0 : true; }
 };
 
@@ -159,7 +161,7 @@ __global__ __launch_bounds__(256) void region_gap_kernel(Mod4 md, const float* _
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
             if (!md.present(m, b)) continue;
-            const f32x4 y = load4(reinterpret_cast<const T*>(md.y[m]) + ((long)b * V + v) * C + c);
+            const f32x4 y = load4(reinterpret_cast<const T*>(md.y[m]) + ((long)md.ysrc(b) * V + v) * C + c);
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -236,7 +238,7 @@ __global__ void region_mix_fwd_kernel(Mod4 md, const float* __restrict__ prob, c
         f32x4 y[4];
 #pragma unroll
         for (int m = 0; m < 4; ++m)
-            y[m] = md.present(m, b) ? load4(reinterpret_cast<const T*>(md.y[m]) + ((long)b * V + v) * C + c) : (f32x4){0.f, 0.f, 0.f, 0.f};
+            y[m] = md.present(m, b) ? load4(reinterpret_cast<const T*>(md.y[m]) + ((long)md.ysrc(b) * V + v) * C + c) : (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const f32x4 r = pr[i] * (wl[i][0] * y[0] + wl[i][1] * y[1] + wl[i][2] * y[2] + wl[i][3] * y[3]);
@@ -270,7 +272,7 @@ __global__ __launch_bounds__(256) void region_mix_bwd_kernel(Mod4 md, const floa
                 if (md.dy[m]) store4(reinterpret_cast<T*>(md.dy[m]) + ((long)b * V + v) * C + c, (f32x4){0.f, 0.f, 0.f, 0.f});
                 continue;
             }
-            const f32x4 y = load4(reinterpret_cast<const T*>(md.y[m]) + ((long)b * V + v) * C + c);
+            const f32x4 y = load4(reinterpret_cast<const T*>(md.y[m]) + ((long)md.ysrc(b) * V + v) * C + c);
 #pragma unroll
             for (int i = 0; i < 4; ++i) dw[i][m] += g[i][0] * y[0] + g[i][1] * y[1] + g[i][2] * y[2] + g[i][3] * y[3];
             if (md.dy[m]) {
@@ -294,12 +296,12 @@ __global__ __launch_bounds__(256) void region_mix_bwd_kernel(Mod4 md, const floa
 inline int egrid(long n) { return (int)hmin((n + 255) / 256, 4096); }
 inline int rgrid(long nvec) { long g = (nvec + 256 * 16 - 1) / (256 * 16); return (int)(g < 1 ? 1 : (g > 256 ? 256 : g)); }
 
-int fill_mod(Mod4& md, const void* const* y, void* const* dy, const uint8_t* mask, int mask_ld) {
+int fill_mod(Mod4& md, const void* const* y, void* const* dy, const uint8_t* mask, int mask_ld, int bmod = 0) {
     for (int m = 0; m < 4; ++m) {
         md.y[m] = y ? y[m] : nullptr;
         md.dy[m] = dy ? dy[m] : nullptr;
     }
-    md.mask = mask; md.mask_ld = mask_ld;
+    md.mask = mask; md.mask_ld = mask_ld; md.bmod = bmod;
     return 0;
 }
 
@@ -354,10 +356,10 @@ extern "C" int64_t passion_region_scratch_floats(int B, int64_t V, int C) {
 
 // sums: [B][16*C + 4] = S[b][i][m][c] then P[b][i]
 extern "C" int passion_region_gap_fwd(const void* const* y, const uint8_t* mask, int mask_ld, const float* prob, int dtype, int B,
-                                      int64_t V, int C, float* scratch, float* sums, void* stream) {
+                                      int64_t V, int C, int bmod, float* scratch, float* sums, void* stream) {
     if (C % 4 || (256 % (C / 4)) != 0) return -1021;
     Mod4 md;
-    int rc = fill_mod(md, y, nullptr, mask, mask_ld);
+    int rc = fill_mod(md, y, nullptr, mask, mask_ld, bmod);
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
     const int gx = rgrid((long)V * (C / 4));
@@ -390,10 +392,10 @@ extern "C" int passion_region_gap_bwd(void* const* dy, const uint8_t* mask, int 
 
 // w: [B][4 regions][4 modalities]; out: [B][V][4*C]
 extern "C" int passion_region_mix_fwd(const void* const* y, const uint8_t* mask, int mask_ld, const float* prob, const float* w, void* out,
-                                      int dtype, int B, int64_t V, int C, void* stream) {
+                                      int dtype, int B, int64_t V, int C, int bmod, void* stream) {
     if (C % 4) return -1021;
     Mod4 md;
-    int rc = fill_mod(md, y, nullptr, mask, mask_ld);
+    int rc = fill_mod(md, y, nullptr, mask, mask_ld, bmod);
     if (rc) return rc;
     dim3 grid(egrid(V * (C / 4)), B);
     hipStream_t st = (hipStream_t)stream;
@@ -406,11 +408,11 @@ extern "C" int passion_region_mix_fwd(const void* const* y, const uint8_t* mask,
 
 // dR: [B][V][4*C]; writes dy[m] (skipped when NULL) and dw [B][4][4]; scratch: passion_region_scratch_floats
 extern "C" int passion_region_mix_bwd(const void* const* y, void* const* dy, const uint8_t* mask, int mask_ld, const float* prob,
-                                      const float* w, const void* dR, int dtype, int B, int64_t V, int C, float* scratch,
+                                      const float* w, const void* dR, int dtype, int B, int64_t V, int C, int bmod, float* scratch,
                                       float* dw, void* stream) {
     if (C % 4) return -1021;
     Mod4 md;
-    int rc = fill_mod(md, y, dy, mask, mask_ld);
+    int rc = fill_mod(md, y, dy, mask, mask_ld, bmod);
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
     const int gx = rgrid((long)V * (C / 4));

@@ -284,7 +284,8 @@ class region_aware_modal_fusion(nn.Module):
     def forward(self, x, prm, mask=None):
         ys = [f.t for f in x]
         msk = x[0].mask
-        B, D, H, W, C = ys[0].shape
+        _, D, H, W, C = ys[0].shape
+        B = prm.shape[0]                                          # virtual batch: P passes x physical samples of ys
         V = D * H * W
         S, P = ops.region_gap(prm, msk, ys)                       # (B,4,4,C) sums, (B,4) prob sums
         prm_avg = P / V + 1e-7                                    # blocks.py:507

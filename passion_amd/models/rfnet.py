@@ -196,19 +196,35 @@ class Model(nn.Module):
         mask = mask.to(device=dev, dtype=torch.bool).contiguous()
         xin = x.to(dt).contiguous()
         encs = [getattr(self, f"{m}_encoder")(xin, i, mask if idt else None, dt) for i, m in enumerate(MODALS)]
+        training = self.is_training
+        passion = training and self.use_passion
 
-        def modal_feats(lvl, msk):
-            return [encs[i][lvl].with_mask(msk, i) for i in range(4)]
-
-        # decoder_fuse always masks with the mask it is given (rfnet.py:126-144); in idt the features are masked too
-        fuse_pred, preds, de_f_avg = self.decoder_fuse(*[modal_feats(l, mask) for l in range(4)])
+        # decoder_fuse always masks with the mask it is given (rfnet.py:126-144); in idt the features are masked too.
+        # PASSION: teacher + four uni-modal students (rfnet.py:269-275) share the encoder features -> ONE virtual batch
+        # of 5*B through the fusion path (conv segments, region_gap / region_mix re-read sample b % B under mask row b).
+        P, masks_all = 1, mask
+        if passion:
+            P = 5
+            onehots = [t.expand(B, 4).contiguous() for t in self._onehots_on(dev)]
+            effs = [(mask & onehots[i]) if idt else onehots[i] for i in range(4)]
+            masks_all = torch.cat([mask] + effs, 0).contiguous()
+        fuse_all, preds_all, de_f_all = self.decoder_fuse(*[[encs[i][l].with_mask(masks_all, i, P) for i in range(4)]
+                                                            for l in range(4)])
+        if P == 1:
+            fuse_pred, preds = fuse_all, preds_all
+        else:
+            fuse_parts = fuse_all.split(B, 0)
+            preds_parts = [pp.split(B, 0) for pp in preds_all]
+            fuse_pred, preds = fuse_parts[0], [pp[0] for pp in preds_parts]
         pred = ops.softmax_classes(fuse_pred, 1.0, "ncdhw")
-        if not self.is_training:
+        if not training:
             return pred
 
         tcl = ops.target_to_cl(target)
-        own = [[(f.with_mask(mask, i) if idt else f) for f in encs[i]] for i in range(4)]
-        sep_preds = [self.decoder_sep(*own[i]) for i in range(4)]
+        # decoder_sep (shared weights) once over the four modalities stacked along the batch axis
+        sep_mask = mask.t().reshape(4 * B, 1).contiguous() if idt else None       # row i*B+b = mask[b, i]
+        stacked = [Feat(torch.cat([encs[i][l].t for i in range(4)], 0), sep_mask, 0) for l in range(4)]
+        sep_preds = self.decoder_sep(*stacked).split(B, 0)
         eye = torch.eye(4, device=dev)
         maskf = mask.float()
         gates = [(maskf * eye[i]) if idt else eye[i].expand(B, 4) for i in range(4)]
@@ -221,22 +237,20 @@ class Model(nn.Module):
         sep_loss = torch.zeros(B, 4, device=dev)
         for i in range(4):
             sep_loss = sep_loss + gates[i] * ops.wce_dice(sep_preds[i], tcl, "cl").sum(1, keepdim=True)
-        if not self.use_passion:
+        if not passion:
             return pred, prm_loss, sep_loss
 
         inv_t = 1.0 / temp
         pt_full = ops.softmax_classes(fuse_pred.detach(), inv_t, "cl")
         pt_deep = [ops.upsample(ops.softmax_classes(pp.detach(), inv_t, "cl"), ups[j]) for j, pp in enumerate(preds)]
-        f_teacher = materialize(de_f_avg[0]).t.detach()
+        f1_parts = materialize(de_f_all[0]).t.split(B, 0)
+        f_teacher = f1_parts[0].detach()
         kl_loss, proto_loss, dist = (torch.zeros(B, 4, device=dev) for _ in range(3))
-        onehots = [t.expand(B, 4).contiguous() for t in self._onehots_on(dev)]
         for i in range(4):
-            eff = (mask & onehots[i]).contiguous() if idt else onehots[i]
-            fuse_i, preds_i, de_f_i = self.decoder_fuse(*[modal_feats(l, eff) for l in range(4)])
-            pl, d = ops.proto_loss(materialize(de_f_i[0]).t, f_teacher, tcl)
-            kl = crit.kl_cl(fuse_i, pt_full, temp)
-            for j, ps_ in enumerate(preds_i):
-                kl = kl + 0.5 ** (j + 1) * crit.kl_cl(ps_, pt_deep[j], temp, ups[j])
+            pl, d = ops.proto_loss(f1_parts[i + 1], f_teacher, tcl)
+            kl = crit.kl_cl(fuse_parts[i + 1], pt_full, temp)
+            for j in range(4):
+                kl = kl + 0.5 ** (j + 1) * crit.kl_cl(preds_parts[j][i + 1], pt_deep[j], temp, ups[j])
             # single-present-modality sample: student == teacher exactly (see mmformer.py for the rationale)
             differs = (~(mask == onehots[i]).all(1)).float().view(B, 1)
             pl, d, kl = pl * differs, d * differs, kl * differs

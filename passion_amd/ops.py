@@ -599,23 +599,26 @@ def _ptr4(ts):
 
 class RegionGapFn(torch.autograd.Function):
     """S[b,i,m,c] = sum_v y_m[c] prob_i and P[b,i] = sum_v prob_i -- the global average pools of
-    modal_fusion (reference blocks.py:507-508) for all regions x modalities in one pass."""
+    modal_fusion (reference blocks.py:507-508) for all regions x modalities in one pass.
+    prob / mask may hold P*B rows (P masked passes over the same B samples of y, see SegIn.bmod)."""
 
     @staticmethod
     def forward(ctx, prob, mask, y0, y1, y2, y3):
         ys = [t.contiguous() for t in (y0, y1, y2, y3)]
         L.require_gpu(prob, *ys)
-        B, D, H, W, C = ys[0].shape
+        Bp, D, H, W, C = ys[0].shape
+        Bv = prob.shape[0]
+        bmod = Bp if Bv != Bp else 0
         V = D * H * W
         lib = L.load()
-        scratch = torch.empty(lib.passion_region_scratch_floats(B, V, C), dtype=torch.float32, device=prob.device)
-        sums = torch.empty(B, 16 * C + 4, dtype=torch.float32, device=prob.device)
+        scratch = torch.empty(lib.passion_region_scratch_floats(Bv, V, C), dtype=torch.float32, device=prob.device)
+        sums = torch.empty(Bv, 16 * C + 4, dtype=torch.float32, device=prob.device)
         L.check(lib.passion_region_gap_fwd(_ptr4(ys), _p(mask), mask.shape[1] if mask is not None else 0, _p(prob),
-                                           L.dtype_code(ys[0].dtype), B, V, C, _p(scratch), _p(sums), L.stream_ptr()),
+                                           L.dtype_code(ys[0].dtype), Bv, V, C, bmod, _p(scratch), _p(sums), L.stream_ptr()),
                 "passion_region_gap_fwd")
         ctx.save_for_backward(prob, mask)
-        ctx.meta = (B, V, C, ys[0].dtype, ys[0].shape)
-        S = sums[:, :16 * C].reshape(B, 4, 4, C)
+        ctx.meta = (Bv, V, C, ys[0].dtype, ys[0].shape, bmod)
+        S = sums[:, :16 * C].reshape(Bv, 4, 4, C)
         P = sums[:, 16 * C:]
         ctx.mark_non_differentiable(P)
         return S, P
@@ -623,11 +626,14 @@ class RegionGapFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gS, _gP):
         prob, mask = ctx.saved_tensors
-        B, V, C, dt, shape = ctx.meta
+        Bv, V, C, dt, shape, bmod = ctx.meta
         gS = gS.contiguous().float()
-        dys = [torch.empty(shape, dtype=dt, device=prob.device) if ctx.needs_input_grad[2 + m] else None for m in range(4)]
+        vshape = (Bv,) + tuple(shape[1:])
+        dys = [torch.empty(vshape, dtype=dt, device=prob.device) if ctx.needs_input_grad[2 + m] else None for m in range(4)]
         L.check(L.load().passion_region_gap_bwd(_ptr4(dys), _p(mask), mask.shape[1] if mask is not None else 0, _p(prob),
-                                                _p(gS), L.dtype_code(dt), B, V, C, L.stream_ptr()), "passion_region_gap_bwd")
+                                                _p(gS), L.dtype_code(dt), Bv, V, C, L.stream_ptr()), "passion_region_gap_bwd")
+        if bmod:       # the passes' gradients add up
+            dys = [d.view(Bv // bmod, *shape).sum(0) if d is not None else None for d in dys]
         return (None, None, *dys)
 
 
@@ -638,29 +644,37 @@ class RegionMixFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, prob, mask, w, y0, y1, y2, y3):
         ys = [t.contiguous() for t in (y0, y1, y2, y3)]
-        B, D, H, W, C = ys[0].shape
+        Bp, D, H, W, C = ys[0].shape
+        Bv = prob.shape[0]
+        bmod = Bp if Bv != Bp else 0
         V = D * H * W
         w = w.contiguous().float()
-        out = torch.empty(B, D, H, W, 4 * C, dtype=ys[0].dtype, device=prob.device)
+        out = torch.empty(Bv, D, H, W, 4 * C, dtype=ys[0].dtype, device=prob.device)
         L.check(L.load().passion_region_mix_fwd(_ptr4(ys), _p(mask), mask.shape[1] if mask is not None else 0, _p(prob),
-                                                _p(w), _p(out), L.dtype_code(ys[0].dtype), B, V, C, L.stream_ptr()),
+                                                _p(w), _p(out), L.dtype_code(ys[0].dtype), Bv, V, C, bmod, L.stream_ptr()),
                 "passion_region_mix_fwd")
         ctx.save_for_backward(prob, mask, w, *ys)
+        ctx.bmod = bmod
         return out
 
     @staticmethod
     def backward(ctx, dR):
         prob, mask, w, *ys = ctx.saved_tensors
-        B, D, H, W, C = ys[0].shape
+        Bp, D, H, W, C = ys[0].shape
+        Bv, bmod = prob.shape[0], ctx.bmod
         V = D * H * W
         lib = L.load()
         dR = dR.contiguous()
-        dys = [torch.empty_like(ys[m]) if ctx.needs_input_grad[3 + m] else None for m in range(4)]
-        scratch = torch.empty(lib.passion_region_scratch_floats(B, V, C), dtype=torch.float32, device=prob.device)
-        dw = torch.empty(B, 4, 4, dtype=torch.float32, device=prob.device)
+        vshape = (Bv, D, H, W, C)
+        dys = [torch.empty(vshape, dtype=ys[m].dtype, device=prob.device) if ctx.needs_input_grad[3 + m] else None
+               for m in range(4)]
+        scratch = torch.empty(lib.passion_region_scratch_floats(Bv, V, C), dtype=torch.float32, device=prob.device)
+        dw = torch.empty(Bv, 4, 4, dtype=torch.float32, device=prob.device)
         L.check(lib.passion_region_mix_bwd(_ptr4(ys), _ptr4(dys), _p(mask), mask.shape[1] if mask is not None else 0,
-                                           _p(prob), _p(w), _p(dR), L.dtype_code(ys[0].dtype), B, V, C, _p(scratch), _p(dw),
-                                           L.stream_ptr()), "passion_region_mix_bwd")
+                                           _p(prob), _p(w), _p(dR), L.dtype_code(ys[0].dtype), Bv, V, C, bmod, _p(scratch),
+                                           _p(dw), L.stream_ptr()), "passion_region_mix_bwd")
+        if bmod:
+            dys = [d.view(Bv // bmod, Bp, D, H, W, C).sum(0) if d is not None else None for d in dys]
         return (None, None, dw, *dys)
 
 
