@@ -205,6 +205,13 @@ int passion_region_mix_bwd(const void* const* y, void* const* dy, const uint8_t*
 /* bmod > 0: y holds only bmod samples and (virtual) sample b of the B given reads y[b % bmod] -- the masked passes of the
  * PASSION students over the same features in one launch; mask, prob, w, out, dy stay indexed by b. */
 
+/* ---- optimizer: torch.optim.AdamW(betas, eps, weight_decay, amsgrad) (code/train.py:95-96) for n f32 parameter
+ * tensors in ceil(n/40) launches.  Host arrays of device pointers; `step` is the 1-based step count after increment. */
+int passion_adamw_step(int n, float* const* params, const float* const* grads, float* const* exp_avg,
+                       float* const* exp_avg_sq, float* const* max_exp_avg_sq, const int64_t* numel, double lr,
+                       double beta1, double beta2, double eps, double weight_decay, int64_t step, int amsgrad,
+                       void* stream);
+
 /* ---- in-library kernel timing (bench.py roofline leg) ------------------------------------------
  * passion_prof_enable(mask): bit k of `mask` selects launches of kind k; selected conv3d launches are
  * bracketed by hipEvents on their own stream and their algorithmic bytes / flops recorded.  passion_prof_read drains up to `cap` records:

@@ -592,3 +592,75 @@ extern "C" int passion_proto_bwd(const void* fs, const void* ft, int dtype, cons
     LAUNCH_RET();
     return 0;
 }
+
+// ------------------------------------------------------------------------------------------------
+// AdamW (amsgrad) over many parameter tensors in one launch per <= ADAM_MAX tensors -- torch.optim.AdamW semantics
+// (reference code/train.py:95-96: betas (0.9, 0.999), eps 1e-8, amsgrad=True, decoupled weight decay):
+//   p *= 1 - lr*wd;  m = b1 m + (1-b1) g;  v = b2 v + (1-b2) g^2;  vmax = max(vmax, v);
+//   p -= (lr / (1 - b1^t)) * m / (sqrt(vmax) / sqrt(1 - b2^t) + eps)
+// The foreach implementation of torch takes ~1.4 ms for the 288 tensors / 35.6 M parameters of mmformer; this streams
+// the 36 bytes per parameter once.
+namespace {
+constexpr int ADAM_MAX = 40;
+struct AdamEnt { float* p; const float* g; float* m; float* v; float* vmax; long n; };
+struct AdamTable { AdamEnt e[ADAM_MAX]; };
+
+__global__ __launch_bounds__(256) void adamw_multi_kernel(AdamTable t, float lr_wd, float omb1, float b2, float omb2, float step_size,
+                                                          float inv_bc2_sqrt, float eps, int amsgrad) {
+    const AdamEnt& q = t.e[blockIdx.y];
+    const long n4 = q.n / 4;
+    const bool vec = ((((size_t)q.p | (size_t)q.g | (size_t)q.m | (size_t)q.v | (size_t)q.vmax) & 15) == 0);
+    auto upd = [&](float& p, float g, float& m, float& v, float& vm) {
+        p = p * (1.f - lr_wd);
+        m = m + (g - m) * omb1;              // lerp, as torch (omb = 1 - beta, rounded from double on the host)
+        v = b2 * v + omb2 * g * g;
+        float d = v;
+        if (amsgrad) { vm = fmaxf(vm, v); d = vm; }
+        p = p - step_size * (m / (sqrtf(d) * inv_bc2_sqrt + eps));
+    };
+    if (vec) {
+        for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+            f32x4 p = reinterpret_cast<f32x4*>(q.p)[i], m = reinterpret_cast<f32x4*>(q.m)[i], v = reinterpret_cast<f32x4*>(q.v)[i];
+            const f32x4 g = reinterpret_cast<const f32x4*>(q.g)[i];
+            f32x4 vm = amsgrad ? reinterpret_cast<f32x4*>(q.vmax)[i] : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float pj = p[j], mj = m[j], vj = v[j], vmj = vm[j];
+                upd(pj, g[j], mj, vj, vmj);
+                p[j] = pj; m[j] = mj; v[j] = vj; vm[j] = vmj;
+            }
+            reinterpret_cast<f32x4*>(q.p)[i] = p; reinterpret_cast<f32x4*>(q.m)[i] = m; reinterpret_cast<f32x4*>(q.v)[i] = v;
+            if (amsgrad) reinterpret_cast<f32x4*>(q.vmax)[i] = vm;
+        }
+    }
+    for (long i = (vec ? n4 * 4 : 0) + (long)blockIdx.x * 256 + threadIdx.x; i < q.n; i += (long)gridDim.x * 256) {
+        float vm = amsgrad ? q.vmax[i] : 0.f;
+        upd(q.p[i], q.g[i], q.m[i], q.v[i], vm);
+        if (amsgrad) q.vmax[i] = vm;
+    }
+}
+}  // namespace
+
+extern "C" int passion_adamw_step(int n, float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
+                                  float* const* max_exp_avg_sq, const int64_t* numel, double lr, double beta1d, double beta2d, double eps,
+                                  double weight_decay, int64_t step, int amsgrad, void* stream) {
+    if (step < 1) return -1031;
+    const float beta2 = (float)beta2d;
+    const double bc1 = 1.0 - pow(beta1d, (double)step), bc2 = 1.0 - pow(beta2d, (double)step);
+    const float step_size = (float)(lr / bc1), inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
+    for (int i0 = 0; i0 < n; i0 += ADAM_MAX) {
+        AdamTable t;
+        const int m = (n - i0 < ADAM_MAX) ? n - i0 : ADAM_MAX;
+        long nmax = 0;
+        for (int i = 0; i < m; ++i) {
+            t.e[i] = AdamEnt{params[i0 + i], grads[i0 + i], exp_avg[i0 + i], exp_avg_sq[i0 + i],
+                             amsgrad ? max_exp_avg_sq[i0 + i] : nullptr, (long)numel[i0 + i]};
+            nmax = numel[i0 + i] > nmax ? numel[i0 + i] : nmax;
+        }
+        const int gx = (int)hmax(1, hmin(256, (nmax / 4 + 255) / 256));
+        hipLaunchKernelGGL(adamw_multi_kernel, dim3(gx, m), dim3(256), 0, (hipStream_t)stream, t, (float)(lr * weight_decay),
+                           (float)(1.0 - (double)beta1d), beta2, (float)(1.0 - (double)beta2d), step_size, inv_bc2_sqrt, (float)eps, amsgrad);
+        LAUNCH_RET();
+    }
+    return 0;
+}

@@ -77,7 +77,11 @@ def assemble_loss(outs, target, mask, mask_type="idt", use_passion=True, state=N
 def make_optimizer(model, lr=2e-4, weight_decay=1e-4, capturable=False):
     """AdamW(betas=(0.9,0.999), eps=1e-8, amsgrad=True) as train.py:95-96; capturable=True keeps the step counter on
     the device so that the step can be recorded in a HIP graph (passion_amd.graph)"""
-    params = [{"params": model.parameters(), "lr": lr, "weight_decay": weight_decay}]
+    params = [{"params": list(model.parameters()), "lr": lr, "weight_decay": weight_decay}]
+    on_gpu = all(p.is_cuda and p.dtype == torch.float32 for p in params[0]["params"])
+    if on_gpu and not capturable:      # same math and state layout, all parameters updated in a handful of launches
+        from .optim import FusedAdamW
+        return FusedAdamW(params, betas=(0.9, 0.999), eps=1e-08, amsgrad=True)
     return torch.optim.AdamW(params, betas=(0.9, 0.999), eps=1e-08, amsgrad=True, capturable=capturable)
 
 

@@ -370,3 +370,29 @@ def test_layout_roundtrip():
     assert torch.equal(ops.to_ncdhw(ops.to_channels_last(x)), x)
     y = ops.to_channels_last(x, torch.bfloat16)
     assert torch.equal(y, x.permute(0, 2, 3, 4, 1).contiguous().to(torch.bfloat16))
+
+
+@pytest.mark.parametrize("amsgrad", [True, False])
+def test_fused_adamw_matches_torch(amsgrad):
+    """passion_amd.optim.FusedAdamW == torch.optim.AdamW (same state layout, interchangeable state_dict)"""
+    from passion_amd.optim import FusedAdamW
+    dev = _dev()
+    g = torch.Generator().manual_seed(21)
+    shapes = [(8, 1, 3, 3, 3), (8,), (128, 128, 3, 3, 3), (1, 125, 512), (4097,), (3,), (512, 2048, 1, 1, 1)]
+    pa = [torch.randn(s_, generator=g).to(dev).requires_grad_(True) for s_ in shapes]
+    pb = [p.detach().clone().requires_grad_(True) for p in pa]
+    oa = FusedAdamW(pa, lr=2e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-4, amsgrad=amsgrad)
+    ob = torch.optim.AdamW(pb, lr=2e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-4, amsgrad=amsgrad)
+    for it in range(4):
+        for a, b in zip(pa, pb):
+            gr = torch.randn(a.shape, generator=g).to(dev) * (10.0 ** (it - 2))
+            a.grad, b.grad = gr.clone(), gr.clone()
+        oa.step(); ob.step()
+    for a, b in zip(pa, pb):
+        assert relerr(a.detach(), b.detach()) < 2e-6
+    sa, sb = oa.state_dict(), ob.state_dict()
+    assert sa["state"].keys() == sb["state"].keys()
+    for k in sa["state"]:
+        assert set(sa["state"][k]) == set(sb["state"][k])
+        assert relerr(sa["state"][k]["exp_avg_sq"], sb["state"][k]["exp_avg_sq"]) < 2e-6
+    ob.load_state_dict(sa)      # interchangeable
