@@ -226,103 +226,132 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvK p) {
 }
 
 // InstanceNorm backward, second half:  dx = rstd * (g - mean(g) - xhat * mean(g * xhat))
-// where g = dL/dxhat (already written into dx by the dgrad epilogue) -- in place.
-template <typename T>
-__global__ void in_bwd_finish_kernel(T* __restrict__ dx, const T* __restrict__ x, const float* __restrict__ stats,
-                                     const float* __restrict__ sums, const uint8_t* mask, int mask_col, int mask_ld,
-                                     long V, int C, long bstride, int Cin_tot, int cbase, int bmod, int rep, long rep_stride) {
-    // the dgrad kernel left `rep` replicas of (sum g, sum g*xhat); fold this segment's channels once per block
-    __shared__ float fs[512];
-    const int b = blockIdx.y;
-    for (int i = threadIdx.x; i < 2 * C && i < 512; i += blockDim.x) {
-        float a = 0.f;
-        for (int r = 0; r < rep; ++r) a += sums[(long)r * rep_stride + ((long)b * Cin_tot + cbase) * 2 + i];
-        fs[i] = a;
+// where g = dL/dxhat (already written into dx by the dgrad epilogue) -- in place.  Per channel this is an affine map of
+// (g, x): dx = a g + b x + c0 with a = rstd, b = -rstd^2 m2, c0 = rstd^2 m2 mean - rstd m1; the block folds the `rep`
+// replicas of the sums and tabulates (a, b, c0) in LDS once, the sweep is then two FMAs per element on VEC-channel
+// vectors (16-byte accesses for bf16 when C % 8 == 0).
+template <typename T, int VEC> struct VecIO;
+template <typename T> struct VecIO<T, 4> {
+    static __device__ __forceinline__ void load(const T* p, float (&v)[4]) { const f32x4 t = load4(p); for (int j = 0; j < 4; ++j) v[j] = t[j]; }
+    static __device__ __forceinline__ void store(T* p, const float (&v)[4]) { store4(p, (f32x4){v[0], v[1], v[2], v[3]}); }
+};
+template <> struct VecIO<bf16_t, 8> {
+    static __device__ __forceinline__ void load(const bf16_t* p, float (&v)[8]) {
+        const uint4 u = *reinterpret_cast<const uint4*>(p);
+        const unsigned w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { v[2 * j] = __uint_as_float(w[j] << 16); v[2 * j + 1] = __uint_as_float(w[j] & 0xffff0000u); }
     }
-    __syncthreads();
-    const long nvec = V * C / 4;
-    const float invV = 1.0f / (float)V;
-    const bool present = mask ? (mask[(long)b * mask_ld + mask_col] != 0) : true;
+    static __device__ __forceinline__ void store(bf16_t* p, const float (&v)[8]) {
+        union { bf16_t h[8]; uint4 u; } t;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) t.h[j] = (bf16_t)v[j];
+        *reinterpret_cast<uint4*>(p) = t.u;
+    }
+};
+
+// coef[c] = (a, b, c0) for the C <= FIN_MAXC channels of this block's sample; folds the rep replicas of the sums
+constexpr int FIN_MAXC = 512;
+__device__ __forceinline__ void finish_coefs(float (*coef)[3], const float* stats, const float* sums, int b, int bs, int C, int Cin_tot,
+                                             int cbase, int rep, long rep_stride, float invV) {
+    for (int c = threadIdx.x; c < C && c < FIN_MAXC; c += blockDim.x) {
+        float s1 = 0.f, s2 = 0.f;
+        for (int r = 0; r < rep; ++r) {
+            s1 += sums[(long)r * rep_stride + ((long)b * Cin_tot + cbase + c) * 2 + 0];
+            s2 += sums[(long)r * rep_stride + ((long)b * Cin_tot + cbase + c) * 2 + 1];
+        }
+        const float mean = stats[((long)bs * C + c) * 2 + 0], rstd = stats[((long)bs * C + c) * 2 + 1];
+        const float m1 = s1 * invV, m2 = s2 * invV;
+        coef[c][0] = rstd;
+        coef[c][1] = -rstd * rstd * m2;
+        coef[c][2] = rstd * rstd * m2 * mean - rstd * m1;
+    }
+}
+
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void in_bwd_finish_kernel(T* __restrict__ dx, const T* __restrict__ x, const float* __restrict__ stats,
+                                                            const float* __restrict__ sums, const uint8_t* mask, int mask_col, int mask_ld,
+                                                            long V, int C, long bstride, int Cin_tot, int cbase, int bmod, int rep,
+                                                            long rep_stride) {
+    __shared__ float coef[FIN_MAXC][3];
+    const int b = blockIdx.y;
     const int bs = bmod > 0 ? b % bmod : b;       // x / stats sample (dx and the sums are per virtual sample b)
+    finish_coefs(coef, stats, sums, b, bs, C, Cin_tot, cbase, rep, rep_stride, 1.0f / (float)V);
+    __syncthreads();
+    const long nvec = V * C / VEC;
+    const int cvn = C / VEC;
+    const bool present = mask ? (mask[(long)b * mask_ld + mask_col] != 0) : true;
     T* dxb = dx + (long)b * bstride;
     const T* xb = x + (long)bs * bstride;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (long)gridDim.x * blockDim.x) {
-        const int c = (int)((i * 4) % C);
-        f32x4 g = load4(dxb + i * 4);
-        if (!present) {
-            g = (f32x4){0.f, 0.f, 0.f, 0.f};
-        } else {
-            f32x4 xv = load4(xb + i * 4);
+        const int c = (int)(i % cvn) * VEC;
+        float g[VEC], xv[VEC];
+        VecIO<T, VEC>::load(dxb + i * VEC, g);
+        VecIO<T, VEC>::load(xb + i * VEC, xv);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float mean = stats[((long)bs * C + c + j) * 2 + 0], rstd = stats[((long)bs * C + c + j) * 2 + 1];
-                const int ci = (c + j) * 2;           // channels >= 256 (host pre-folded them: rep == 1) come from global
-                const float m1 = (ci < 512 ? fs[ci] : sums[((long)b * Cin_tot + cbase) * 2 + ci]) * invV;
-                const float m2 = (ci < 512 ? fs[ci + 1] : sums[((long)b * Cin_tot + cbase) * 2 + ci + 1]) * invV;
-                const float xh = (xv[j] - mean) * rstd;
-                g[j] = rstd * (g[j] - m1 - xh * m2);
-            }
-        }
-        store4(dxb + i * 4, g);
+        for (int j = 0; j < VEC; ++j)
+            g[j] = present ? __builtin_fmaf(coef[c + j][0], g[j], __builtin_fmaf(coef[c + j][1], xv[j], coef[c + j][2])) : 0.f;
+        VecIO<T, VEC>::store(dxb + i * VEC, g);
     }
 }
 
 // The same finish for a dgrad that ran over the padded domain (conv_lean.hip MODE 2): dxp is [B][D+2][H+2][W+2][Cin_tot]
 // with the gradient of padded position op-1 at coordinate op; the reflect adjoint folds the halo planes back:
 // plane 1 also receives plane -1, plane S-2 also receives plane S (per axis, so up to 8 terms at the corners).
-template <typename T>
-__global__ void in_bwd_finish_pad_kernel(T* __restrict__ dx, const T* __restrict__ x, const T* __restrict__ dxp,
-                                         const float* __restrict__ stats, const float* __restrict__ sums, const uint8_t* mask,
-                                         int mask_col, int mask_ld, int D, int H, int W, int C, long bstride, int Cin_tot,
-                                         int cbase, int bmod, int rep, long rep_stride) {
-    __shared__ float fs[512];
+// One (d, h) row of W voxels per loop trip: the row's source planes are resolved once (workgroup-uniform), only the
+// two W positions 1 and W-2 gather an extra column.
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void in_bwd_finish_pad_kernel(T* __restrict__ dx, const T* __restrict__ x, const T* __restrict__ dxp,
+                                                                const float* __restrict__ stats, const float* __restrict__ sums,
+                                                                const uint8_t* mask, int mask_col, int mask_ld, int D, int H, int W, int C,
+                                                                long bstride, int Cin_tot, int cbase, int bmod, int rep, long rep_stride) {
+    __shared__ float coef[FIN_MAXC][3];
     const int b = blockIdx.y;
-    if (stats) {
-        for (int i = threadIdx.x; i < 2 * C && i < 512; i += blockDim.x) {
-            float a = 0.f;
-            for (int r = 0; r < rep; ++r) a += sums[(long)r * rep_stride + ((long)b * Cin_tot + cbase) * 2 + i];
-            fs[i] = a;
-        }
-    }
-    __syncthreads();
-    const long V = (long)D * H * W;
-    const long nvec = V * C / 4;
-    const int cvn = C / 4;
-    const float invV = 1.0f / (float)V;
-    const bool present = mask ? (mask[(long)b * mask_ld + mask_col] != 0) : true;
     const int bs = bmod > 0 ? b % bmod : b;
+    const long V = (long)D * H * W;
+    if (stats) finish_coefs(coef, stats, sums, b, bs, C, Cin_tot, cbase, rep, rep_stride, 1.0f / (float)V);
+    __syncthreads();
+    const int cvn = C / VEC, rowv = W * cvn;
+    const bool present = mask ? (mask[(long)b * mask_ld + mask_col] != 0) : true;
     T* dxb = dx + (long)b * bstride;
     const T* xb = x + (long)bs * bstride;
     const T* pb = dxp + (long)b * (D + 2) * (H + 2) * (W + 2) * Cin_tot + cbase;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (long)gridDim.x * blockDim.x) {
-        const int c = (int)(i % cvn) * 4;
-        long v = i / cvn;
-        const int w = (int)(v % W); v /= W;
-        const int h = (int)(v % H);
-        const int d = (int)(v / H);
-        f32x4 g = {0.f, 0.f, 0.f, 0.f};
-        if (present) {
-            int dl[3], hl[3], wl[3], nd = 0, nh = 0, nw = 0;
-            dl[nd++] = d + 1; if (d == 1) dl[nd++] = 0; if (d == D - 2) dl[nd++] = D + 1;
-            hl[nh++] = h + 1; if (h == 1) hl[nh++] = 0; if (h == H - 2) hl[nh++] = H + 1;
-            wl[nw++] = w + 1; if (w == 1) wl[nw++] = 0; if (w == W - 2) wl[nw++] = W + 1;
-            for (int a = 0; a < nd; ++a)
-                for (int e = 0; e < nh; ++e)
-                    for (int f = 0; f < nw; ++f)
-                        g += load4(pb + ((((long)dl[a]) * (H + 2) + hl[e]) * (W + 2) + wl[f]) * Cin_tot + c);
-            if (!stats) { store4(dxb + i * 4, g); continue; }      // input was not normalised in the loader: fold only
-            const f32x4 xv = load4(xb + i * 4);
+    const int tpr = rowv < 256 ? rowv : 256;              // threads that work on one row; 256 / tpr rows in flight per block
+    const int rpb = 256 / tpr, rsub = threadIdx.x / tpr, tin = threadIdx.x % tpr;
+    for (int r0 = blockIdx.x * rpb; r0 < D * H; r0 += gridDim.x * rpb) {
+        const int r = r0 + rsub;
+        if (r >= D * H || rsub >= rpb) continue;
+        const int d = r / H, h = r % H;
+        int dl[3], hl[3], nd = 0, nh = 0;
+        dl[nd++] = d + 1; if (d == 1) dl[nd++] = 0; if (d == D - 2) dl[nd++] = D + 1;
+        hl[nh++] = h + 1; if (h == 1) hl[nh++] = 0; if (h == H - 2) hl[nh++] = H + 1;
+        for (int i = tin; i < rowv; i += tpr) {
+            const int w = i / cvn, c = (i % cvn) * VEC;
+            const long e = ((long)r * W + w) * C + c;
+            float g[VEC];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float mean = stats[((long)bs * C + c + j) * 2 + 0], rstd = stats[((long)bs * C + c + j) * 2 + 1];
-                const int ci = (c + j) * 2;
-                const float m1 = (ci < 512 ? fs[ci] : sums[((long)b * Cin_tot + cbase) * 2 + ci]) * invV;
-                const float m2 = (ci < 512 ? fs[ci + 1] : sums[((long)b * Cin_tot + cbase) * 2 + ci + 1]) * invV;
-                const float xh = (xv[j] - mean) * rstd;
-                g[j] = rstd * (g[j] - m1 - xh * m2);
+            for (int j = 0; j < VEC; ++j) g[j] = 0.f;
+            if (present) {
+                int wl[3], nw = 0;
+                wl[nw++] = w + 1; if (w == 1) wl[nw++] = 0; if (w == W - 2) wl[nw++] = W + 1;
+                for (int a = 0; a < nd; ++a)
+                    for (int e2 = 0; e2 < nh; ++e2)
+                        for (int f = 0; f < nw; ++f) {
+                            float t[VEC];
+                            VecIO<T, VEC>::load(pb + ((((long)dl[a]) * (H + 2) + hl[e2]) * (W + 2) + wl[f]) * Cin_tot + c, t);
+#pragma unroll
+                            for (int j = 0; j < VEC; ++j) g[j] += t[j];
+                        }
+                if (stats) {                               // else: input was not normalised in the loader, fold only
+                    float xv[VEC];
+                    VecIO<T, VEC>::load(xb + e, xv);
+#pragma unroll
+                    for (int j = 0; j < VEC; ++j)
+                        g[j] = __builtin_fmaf(coef[c + j][0], g[j], __builtin_fmaf(coef[c + j][1], xv[j], coef[c + j][2]));
+                }
             }
+            VecIO<T, VEC>::store(dxb + e, g);
         }
-        store4(dxb + i * 4, g);
     }
 }
 
@@ -866,7 +895,6 @@ extern "C" int passion_conv3d_bwd(const passion_conv_desc_t* d, const float* pac
         if (rc) return rc;
     }
     int rep = k.sums_rep;
-    for (int s = 0; s < k.nseg; ++s) if (k.seg[s].C > 256) rep = SUMS_REP;   // finish kernel folds in LDS: 2 * C floats
     if (need_norm && rep > SUMS_REP_LEAN) {          // many replicas: fold them first (in place, replica 0)
         const int nw = 2 * k.B * k.Cin;
         hipLaunchKernelGGL(reduce_parts_kernel, dim3((nw + 15) / 16), dim3(256), 0, st, sums, k.sums_rep, (long)nw, (long)nw, sums);
@@ -878,20 +906,32 @@ extern "C" int passion_conv3d_bwd(const passion_conv_desc_t* d, const float* pac
     for (int s = 0; s < k.nseg; ++s) {
         const SegD& sg = k.seg[s];
         if (!sg.dx || (!sg.stats && !padout)) continue;
-        const long nvec = V * sg.C / 4;
+        if (sg.C > FIN_MAXC) return -1013;            // coefficient table of the finish kernels
+        const bool v8 = d->x_dtype == PASSION_BF16 && sg.C % 8 == 0 && k.Cin % 8 == 0 && sg.cbase % 8 == 0;
+        const long nvec = V * sg.C / (v8 ? 8 : 4);
         dim3 grid((unsigned)hmin((nvec + 255) / 256, 2048), k.B);
+        const long rs = (long)2 * k.B * k.Cin;
         if (padout) {
-            hipLaunchKernelGGL(in_bwd_finish_pad_kernel<bf16_t>, grid, dim3(256), 0, st, (bf16_t*)sg.dx, (const bf16_t*)sg.x,
-                               (const bf16_t*)dxp, sg.stats, sums, sg.mask, sg.mask_col, sg.mask_ld, k.Di, k.Hi, k.Wi, sg.C,
-                               sg.bstride, k.Cin, sg.cbase, sg.bmod, rep, (long)2 * k.B * k.Cin);
+            const int rowv = k.Wi * sg.C / (v8 ? 8 : 4);
+            const int rpb = 256 / (rowv < 256 ? rowv : 256);
+            dim3 pg((unsigned)hmin(((long)k.Di * k.Hi + rpb - 1) / rpb, 4096), k.B);
+            if (v8)
+                hipLaunchKernelGGL((in_bwd_finish_pad_kernel<bf16_t, 8>), pg, dim3(256), 0, st, (bf16_t*)sg.dx, (const bf16_t*)sg.x,
+                                   (const bf16_t*)dxp, sg.stats, sums, sg.mask, sg.mask_col, sg.mask_ld, k.Di, k.Hi, k.Wi, sg.C,
+                                   sg.bstride, k.Cin, sg.cbase, sg.bmod, rep, rs);
+            else
+                hipLaunchKernelGGL((in_bwd_finish_pad_kernel<bf16_t, 4>), pg, dim3(256), 0, st, (bf16_t*)sg.dx, (const bf16_t*)sg.x,
+                                   (const bf16_t*)dxp, sg.stats, sums, sg.mask, sg.mask_col, sg.mask_ld, k.Di, k.Hi, k.Wi, sg.C,
+                                   sg.bstride, k.Cin, sg.cbase, sg.bmod, rep, rs);
         } else if (d->x_dtype == PASSION_F32)
-            hipLaunchKernelGGL(in_bwd_finish_kernel<float>, grid, dim3(256), 0, st, (float*)sg.dx, (const float*)sg.x,
-                               sg.stats, sums, sg.mask, sg.mask_col, sg.mask_ld, V, sg.C, sg.bstride, k.Cin, sg.cbase, sg.bmod,
-                               rep, (long)2 * k.B * k.Cin);
+            hipLaunchKernelGGL((in_bwd_finish_kernel<float, 4>), grid, dim3(256), 0, st, (float*)sg.dx, (const float*)sg.x,
+                               sg.stats, sums, sg.mask, sg.mask_col, sg.mask_ld, V, sg.C, sg.bstride, k.Cin, sg.cbase, sg.bmod, rep, rs);
+        else if (v8)
+            hipLaunchKernelGGL((in_bwd_finish_kernel<bf16_t, 8>), grid, dim3(256), 0, st, (bf16_t*)sg.dx, (const bf16_t*)sg.x,
+                               sg.stats, sums, sg.mask, sg.mask_col, sg.mask_ld, V, sg.C, sg.bstride, k.Cin, sg.cbase, sg.bmod, rep, rs);
         else
-            hipLaunchKernelGGL(in_bwd_finish_kernel<bf16_t>, grid, dim3(256), 0, st, (bf16_t*)sg.dx,
-                               (const bf16_t*)sg.x, sg.stats, sums, sg.mask, sg.mask_col, sg.mask_ld, V, sg.C,
-                               sg.bstride, k.Cin, sg.cbase, sg.bmod, rep, (long)2 * k.B * k.Cin);
+            hipLaunchKernelGGL((in_bwd_finish_kernel<bf16_t, 4>), grid, dim3(256), 0, st, (bf16_t*)sg.dx, (const bf16_t*)sg.x,
+                               sg.stats, sums, sg.mask, sg.mask_col, sg.mask_ld, V, sg.C, sg.bstride, k.Cin, sg.cbase, sg.bmod, rep, rs);
         LAUNCH_RET();
     }
     return 0;
