@@ -42,6 +42,32 @@ __device__ __forceinline__ void store4(bf16_t* p, f32x4 v) {
     *reinterpret_cast<uint2*>(p) = t.u;
 }
 
+// VEC consecutive channel values <-> float[VEC].  VEC = 8 on bf16 is one 16-byte access per lane, the width the memory
+// system wants from a streaming kernel (pointer must be VEC-element aligned).
+template <typename T, int VEC> struct VecIO;
+template <typename T> struct VecIO<T, 4> {
+    static __device__ __forceinline__ void load(const T* p, float (&v)[4]) {
+        const f32x4 t = load4(p);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = t[j];
+    }
+    static __device__ __forceinline__ void store(T* p, const float (&v)[4]) { store4(p, (f32x4){v[0], v[1], v[2], v[3]}); }
+};
+template <> struct VecIO<bf16_t, 8> {
+    static __device__ __forceinline__ void load(const bf16_t* p, float (&v)[8]) {
+        const uint4 u = *reinterpret_cast<const uint4*>(p);
+        const unsigned w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { v[2 * j] = __uint_as_float(w[j] << 16); v[2 * j + 1] = __uint_as_float(w[j] & 0xffff0000u); }
+    }
+    static __device__ __forceinline__ void store(bf16_t* p, const float (&v)[8]) {
+        union { bf16_t h[8]; uint4 u; } t;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) t.h[j] = (bf16_t)v[j];
+        *reinterpret_cast<uint4*>(p) = t.u;
+    }
+};
+
 // Sum over the 64 lanes of a wavefront (result valid in every lane).
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

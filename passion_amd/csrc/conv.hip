@@ -230,26 +230,6 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvK p) {
 // (g, x): dx = a g + b x + c0 with a = rstd, b = -rstd^2 m2, c0 = rstd^2 m2 mean - rstd m1; the block folds the `rep`
 // replicas of the sums and tabulates (a, b, c0) in LDS once, the sweep is then two FMAs per element on VEC-channel
 // vectors (16-byte accesses for bf16 when C % 8 == 0).
-template <typename T, int VEC> struct VecIO;
-template <typename T> struct VecIO<T, 4> {
-    static __device__ __forceinline__ void load(const T* p, float (&v)[4]) { const f32x4 t = load4(p); for (int j = 0; j < 4; ++j) v[j] = t[j]; }
-    static __device__ __forceinline__ void store(T* p, const float (&v)[4]) { store4(p, (f32x4){v[0], v[1], v[2], v[3]}); }
-};
-template <> struct VecIO<bf16_t, 8> {
-    static __device__ __forceinline__ void load(const bf16_t* p, float (&v)[8]) {
-        const uint4 u = *reinterpret_cast<const uint4*>(p);
-        const unsigned w[4] = {u.x, u.y, u.z, u.w};
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { v[2 * j] = __uint_as_float(w[j] << 16); v[2 * j + 1] = __uint_as_float(w[j] & 0xffff0000u); }
-    }
-    static __device__ __forceinline__ void store(bf16_t* p, const float (&v)[8]) {
-        union { bf16_t h[8]; uint4 u; } t;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) t.h[j] = (bf16_t)v[j];
-        *reinterpret_cast<uint4*>(p) = t.u;
-    }
-};
-
 // coef[c] = (a, b, c0) for the C <= FIN_MAXC channels of this block's sample; folds the rep replicas of the sums
 constexpr int FIN_MAXC = 512;
 __device__ __forceinline__ void finish_coefs(float (*coef)[3], const float* stats, const float* sums, int b, int bs, int C, int Cin_tot,

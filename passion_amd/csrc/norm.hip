@@ -10,32 +10,36 @@
 
 namespace {
 
-template <typename T>
+template <typename T, int VEC>
 __global__ __launch_bounds__(256) void stats_partial_kernel(const T* __restrict__ x, long V, int C, long bstride,
                                                             double* __restrict__ scratch) {
-    __shared__ float red[4 * 64 * 8];
+    __shared__ float red[4 * 64 * 2 * VEC];
     const int b = blockIdx.y;
-    const int cvn = C / 4;              // channel vectors per voxel; a power of two <= 256
+    const int cvn = C / VEC;            // channel vectors per voxel; a power of two <= 256
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const long nvec = V * cvn;
     const T* xb = x + (long)b * bstride;
-    float s[4] = {0.f, 0.f, 0.f, 0.f}, q[4] = {0.f, 0.f, 0.f, 0.f};
-    // stride is a multiple of cvn, so a thread always sees the same 4 channels
+    float s[VEC], q[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) { s[j] = 0.f; q[j] = 0.f; }
+    // stride is a multiple of cvn, so a thread always sees the same VEC channels
     const long stride = (long)gridDim.x * 256;
     long i = (long)blockIdx.x * 256 + tid;
-    for (; i + 3 * stride < nvec; i += 4 * stride) {   // four independent 16-byte loads in flight
-        const f32x4 v0 = load4(xb + i * 4), v1 = load4(xb + (i + stride) * 4), v2 = load4(xb + (i + 2 * stride) * 4),
-                    v3 = load4(xb + (i + 3 * stride) * 4);
+    for (; i + 3 * stride < nvec; i += 4 * stride) {   // four independent vector loads in flight
+        float v0[VEC], v1[VEC], v2[VEC], v3[VEC];
+        VecIO<T, VEC>::load(xb + i * VEC, v0); VecIO<T, VEC>::load(xb + (i + stride) * VEC, v1);
+        VecIO<T, VEC>::load(xb + (i + 2 * stride) * VEC, v2); VecIO<T, VEC>::load(xb + (i + 3 * stride) * VEC, v3);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < VEC; ++j) {
             s[j] += (v0[j] + v1[j]) + (v2[j] + v3[j]);
             q[j] += (v0[j] * v0[j] + v1[j] * v1[j]) + (v2[j] * v2[j] + v3[j] * v3[j]);
         }
     }
     for (; i < nvec; i += stride) {
-        const f32x4 v = load4(xb + i * 4);
+        float v[VEC];
+        VecIO<T, VEC>::load(xb + i * VEC, v);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { s[j] += v[j]; q[j] += v[j] * v[j]; }
+        for (int j = 0; j < VEC; ++j) { s[j] += v[j]; q[j] += v[j] * v[j]; }
     }
     // lanes l and l ^ o share a channel vector whenever o is a multiple of cvn
     const int w = cvn < 64 ? cvn : 64;   // distinct channel vectors inside one wave
@@ -43,27 +47,29 @@ __global__ __launch_bounds__(256) void stats_partial_kernel(const T* __restrict_
     for (int o = 32; o >= 1; o >>= 1) {
         if (o >= w) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { s[j] += __shfl_xor(s[j], o, 64); q[j] += __shfl_xor(q[j], o, 64); }
+            for (int j = 0; j < VEC; ++j) { s[j] += __shfl_xor(s[j], o, 64); q[j] += __shfl_xor(q[j], o, 64); }
         }
     }
     if (lane < w) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { red[(wv * 64 + lane) * 8 + j] = s[j]; red[(wv * 64 + lane) * 8 + 4 + j] = q[j]; }
+        for (int j = 0; j < VEC; ++j) { red[(wv * 64 + lane) * 2 * VEC + j] = s[j]; red[(wv * 64 + lane) * 2 * VEC + VEC + j] = q[j]; }
     }
     __syncthreads();
     // channel vector cv lives in (wave wv, lane l) with (wv*64 + l) % cvn == cv
     if (tid < cvn) {
-        double ds[4] = {0, 0, 0, 0}, dq[4] = {0, 0, 0, 0};
+        double ds[VEC], dq[VEC];
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) { ds[j] = 0; dq[j] = 0; }
         for (int t = tid; t < 256; t += cvn) {
             const int l = t & 63;
             if (l >= w) continue;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { ds[j] += (double)red[t * 8 + j]; dq[j] += (double)red[t * 8 + 4 + j]; }
+            for (int j = 0; j < VEC; ++j) { ds[j] += (double)red[t * 2 * VEC + j]; dq[j] += (double)red[t * 2 * VEC + VEC + j]; }
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {   // this block's slot of the partial slab: no atomics, reproducible
-            scratch[(((long)blockIdx.x * gridDim.y + b) * C + tid * 4 + j) * 2 + 0] = ds[j];
-            scratch[(((long)blockIdx.x * gridDim.y + b) * C + tid * 4 + j) * 2 + 1] = dq[j];
+        for (int j = 0; j < VEC; ++j) {   // this block's slot of the partial slab: no atomics, reproducible
+            scratch[(((long)blockIdx.x * gridDim.y + b) * C + tid * VEC + j) * 2 + 0] = ds[j];
+            scratch[(((long)blockIdx.x * gridDim.y + b) * C + tid * VEC + j) * 2 + 1] = dq[j];
         }
     }
 }
@@ -110,9 +116,11 @@ extern "C" int passion_instnorm_stats(const void* x, int dtype, int B, int64_t V
     const int gx = stats_blocks((long)V, C);
     dim3 grid(gx, B);
     if (dtype == PASSION_F32)
-        hipLaunchKernelGGL(stats_partial_kernel<float>, grid, dim3(256), 0, st, (const float*)x, (long)V, C, (long)bstride, scratch);
+        hipLaunchKernelGGL((stats_partial_kernel<float, 4>), grid, dim3(256), 0, st, (const float*)x, (long)V, C, (long)bstride, scratch);
+    else if (dtype == PASSION_BF16 && C % 8 == 0 && bstride % 8 == 0)
+        hipLaunchKernelGGL((stats_partial_kernel<bf16_t, 8>), grid, dim3(256), 0, st, (const bf16_t*)x, (long)V, C, (long)bstride, scratch);
     else if (dtype == PASSION_BF16)
-        hipLaunchKernelGGL(stats_partial_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)x, (long)V, C, (long)bstride, scratch);
+        hipLaunchKernelGGL((stats_partial_kernel<bf16_t, 4>), grid, dim3(256), 0, st, (const bf16_t*)x, (long)V, C, (long)bstride, scratch);
     else
         return -1007;
     LAUNCH_RET();

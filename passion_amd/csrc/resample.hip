@@ -25,10 +25,10 @@ __device__ __forceinline__ Src src_index(int o, float scale, int in) {
 
 __host__ __device__ inline float axis_scale(int in, int out) { return out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f; }
 
-template <typename T>
+template <typename T, int VEC>
 __global__ __launch_bounds__(256) void upsample_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int B, int D,
                                                            int H, int W, int C, int k) {
-    const int Do = D * k, Ho = H * k, Wo = W * k, cvn = C / 4;
+    const int Do = D * k, Ho = H * k, Wo = W * k, cvn = C / VEC;
     const float sd = axis_scale(D, Do), sh = axis_scale(H, Ho), sw = axis_scale(W, Wo);
     const long total = (long)B * Do * Ho * Wo * cvn;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -39,14 +39,30 @@ __global__ __launch_bounds__(256) void upsample_fwd_kernel(const T* __restrict__
         const int od = (int)(v % Do);
         const int b = (int)(v / Do);
         const Src a = src_index(od, sd, D), e = src_index(oh, sh, H), f = src_index(ow, sw, W);
-        const T* xb = x + (long)b * D * H * W * C + cv * 4;
-#define AT(dd, hh, ww) load4(xb + ((((long)(dd)) * H + (hh)) * W + (ww)) * C)
-        f32x4 r = a.l0 * (e.l0 * (f.l0 * AT(a.i0, e.i0, f.i0) + f.l1 * AT(a.i0, e.i0, f.i1)) +
-                          e.l1 * (f.l0 * AT(a.i0, e.i1, f.i0) + f.l1 * AT(a.i0, e.i1, f.i1))) +
-                  a.l1 * (e.l0 * (f.l0 * AT(a.i1, e.i0, f.i0) + f.l1 * AT(a.i1, e.i0, f.i1)) +
-                          e.l1 * (f.l0 * AT(a.i1, e.i1, f.i0) + f.l1 * AT(a.i1, e.i1, f.i1)));
-#undef AT
-        store4(y + i * 4, r);
+        const T* xb = x + (long)b * D * H * W * C + cv * VEC;
+        float r[VEC];
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) r[j] = 0.f;
+        // same association as ATen: ((w-blend) h-blend) d-blend, weights applied innermost first
+        const int di[2] = {a.i0, a.i1}, hi[2] = {e.i0, e.i1}, wi[2] = {f.i0, f.i1};
+        const float dl[2] = {a.l0, a.l1}, hl[2] = {e.l0, e.l1}, wl[2] = {f.l0, f.l1};
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            float rh[VEC];
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) rh[j] = 0.f;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                float t0[VEC], t1[VEC];
+                VecIO<T, VEC>::load(xb + ((((long)di[p]) * H + hi[q]) * W + wi[0]) * C, t0);
+                VecIO<T, VEC>::load(xb + ((((long)di[p]) * H + hi[q]) * W + wi[1]) * C, t1);
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) rh[j] += hl[q] * (wl[0] * t0[j] + wl[1] * t1[j]);
+            }
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) r[j] += dl[p] * rh[j];
+        }
+        VecIO<T, VEC>::store(y + i * VEC, r);
     }
 }
 
@@ -159,11 +175,11 @@ int upsample_bwd_separable(const T* dy, T* dx, int B, int D, int H, int W, int C
 
 // k <= 2: one thread per (input voxel, 4-channel vector).  At most 5 output indices per axis can reference an
 // input index; their weights are evaluated once per axis (15 evaluations) instead of once per candidate triple.
-template <typename T>
+template <typename T, int VEC>
 __global__ __launch_bounds__(256) void upsample_bwd_k2_kernel(const T* __restrict__ dy, T* __restrict__ dx, int B, int D,
                                                               int H, int W, int C, int k) {
     constexpr int NC = 6;
-    const int Do = D * k, Ho = H * k, Wo = W * k, cvn = C / 4;
+    const int Do = D * k, Ho = H * k, Wo = W * k, cvn = C / VEC;
     const float sd = axis_scale(D, Do), sh = axis_scale(H, Ho), sw = axis_scale(W, Wo);
     const long items = (long)B * D * H * W * cvn;
     for (long it = (long)blockIdx.x * blockDim.x + threadIdx.x; it < items; it += (long)gridDim.x * blockDim.x) {
@@ -184,8 +200,10 @@ __global__ __launch_bounds__(256) void upsample_bwd_k2_kernel(const T* __restric
             wh[j] = (hlo + j < Ho) ? axis_weight(hlo + j, ih, sh, H) : 0.f;
             ww[j] = (wlo + j < Wo) ? axis_weight(wlo + j, iw, sw, W) : 0.f;
         }
-        const T* dyb = dy + (long)b * Do * Ho * Wo * C + cv * 4;
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        const T* dyb = dy + (long)b * Do * Ho * Wo * C + cv * VEC;
+        float acc[VEC];
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) acc[j] = 0.f;
 #pragma unroll
         for (int a = 0; a < NC; ++a) {
             if (wd[a] == 0.f) continue;
@@ -197,11 +215,15 @@ __global__ __launch_bounds__(256) void upsample_bwd_k2_kernel(const T* __restric
 #pragma unroll
                 for (int f = 0; f < NC; ++f) {
                     if (ww[f] == 0.f) continue;
-                    acc += (wde * ww[f]) * load4(row + (long)(wlo + f) * C);
+                    float t[VEC];
+                    VecIO<T, VEC>::load(row + (long)(wlo + f) * C, t);
+                    const float wt = wde * ww[f];
+#pragma unroll
+                    for (int j = 0; j < VEC; ++j) acc[j] += wt * t[j];
                 }
             }
         }
-        store4(dx + it * 4, acc);
+        VecIO<T, VEC>::store(dx + it * VEC, acc);
     }
 }
 
@@ -210,13 +232,16 @@ __global__ __launch_bounds__(256) void upsample_bwd_k2_kernel(const T* __restric
 extern "C" int passion_upsample_fwd(const void* x, void* y, int dtype, int B, int D, int H, int W, int C, int k,
                                     void* stream) {
     if (C % 4 || k < 1) return -1011;
-    const long total = (long)B * D * k * H * k * W * k * (C / 4);
-    const int blocks = (int)hmin((total + 255) / 256, 8192);
+    const bool v8 = dtype == PASSION_BF16 && C % 8 == 0;
+    const long total = (long)B * D * k * H * k * W * k * (C / (v8 ? 8 : 4));
+    const int blocks = (int)hmin((total + 255) / 256, 16384);
     hipStream_t st = (hipStream_t)stream;
     if (dtype == PASSION_F32)
-        hipLaunchKernelGGL(upsample_fwd_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)x, (float*)y, B, D, H, W, C, k);
+        hipLaunchKernelGGL((upsample_fwd_kernel<float, 4>), dim3(blocks), dim3(256), 0, st, (const float*)x, (float*)y, B, D, H, W, C, k);
+    else if (v8)
+        hipLaunchKernelGGL((upsample_fwd_kernel<bf16_t, 8>), dim3(blocks), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y, B, D, H, W, C, k);
     else if (dtype == PASSION_BF16)
-        hipLaunchKernelGGL(upsample_fwd_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y, B, D, H, W, C, k);
+        hipLaunchKernelGGL((upsample_fwd_kernel<bf16_t, 4>), dim3(blocks), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y, B, D, H, W, C, k);
     else
         return -1007;
     LAUNCH_RET();
@@ -240,11 +265,14 @@ extern "C" int passion_upsample_bwd(const void* dy, void* dx, int dtype, int B, 
     const long items = (long)B * D * H * W * (C / 4);
     hipStream_t st = (hipStream_t)stream;
     if (k == 2 && D > 1 && H > 1 && W > 1) {
-        const int blocks = (int)hmin((items + 255) / 256, 8192);
+        const bool v8 = dtype == PASSION_BF16 && C % 8 == 0;
+        const int blocks = (int)hmin(((v8 ? items / 2 : items) + 255) / 256, 16384);
         if (dtype == PASSION_F32)
-            hipLaunchKernelGGL(upsample_bwd_k2_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)dy, (float*)dx, B, D, H, W, C, k);
+            hipLaunchKernelGGL((upsample_bwd_k2_kernel<float, 4>), dim3(blocks), dim3(256), 0, st, (const float*)dy, (float*)dx, B, D, H, W, C, k);
+        else if (v8)
+            hipLaunchKernelGGL((upsample_bwd_k2_kernel<bf16_t, 8>), dim3(blocks), dim3(256), 0, st, (const bf16_t*)dy, (bf16_t*)dx, B, D, H, W, C, k);
         else if (dtype == PASSION_BF16)
-            hipLaunchKernelGGL(upsample_bwd_k2_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, (const bf16_t*)dy, (bf16_t*)dx, B, D, H, W, C, k);
+            hipLaunchKernelGGL((upsample_bwd_k2_kernel<bf16_t, 4>), dim3(blocks), dim3(256), 0, st, (const bf16_t*)dy, (bf16_t*)dx, B, D, H, W, C, k);
         else
             return -1007;
     } else {
