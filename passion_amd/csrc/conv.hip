@@ -525,6 +525,7 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, int Cin, int Cou
 int fill_params(const passion_conv_desc_t* d, ConvK& k) {
     if (!d) return -1001;
     k.dbg = 0;
+    k.y_f32 = 0;
     if (d->ksize != 1 && d->ksize != 3) return -1002;
     if (d->stride != 1 && d->stride != 2) return -1003;
     if (d->ksize == 1 && d->stride != 1) return -1003;
@@ -588,9 +589,19 @@ int launch_conv_geo(ConvK& k, int ksize, int stride, int mtiles, hipStream_t st)
 struct WgPlan { bool bf16; int MT, chunks, gx, gy; };
 
 // grid of the wgrad launch: y = (8/16-channel chunk) x (row-tile group), x = bricks strided over <= 1024/gy workgroups
+// the 4-class logit heads: bf16 activations in, f32 logits out (Cout <= 8), 1x1x1 or 3x3x3 stride 1
+static bool lean_f32_head(const ConvK& k, const passion_conv_desc_t* d) {
+    if (!pconv::g_conv_lean || g_passion_force_f32_mfma) return false;
+    if (d->x_dtype != PASSION_BF16 || d->y_dtype != PASSION_F32 || d->stride != 1 || k.Cout > 8 || k.Cout % 4) return false;
+    int K8 = 0;
+    for (int s = 0; s < k.nseg; ++s) { if (k.seg[s].C % 8) return false; K8 += k.seg[s].C / 8; }
+    return K8 * 8 == k.Cin && K8 <= 32;
+}
+
 WgPlan plan_wgrad(const ConvK& k, const passion_conv_desc_t* d) {
     WgPlan w;
-    w.bf16 = d->x_dtype == PASSION_BF16 && d->y_dtype == PASSION_BF16 && bf16_eligible(k, false) && !g_passion_force_f32_mfma;
+    w.bf16 = (d->x_dtype == PASSION_BF16 && d->y_dtype == PASSION_BF16 && bf16_eligible(k, false) && !g_passion_force_f32_mfma) ||
+             lean_f32_head(k, d);
     const int CK = w.bf16 ? wgrad_bf16_chunk(k, d->ksize, d->stride) : (d->ksize == 1 ? 16 : (d->stride == 2 ? 4 : 8));
     w.chunks = 0;
     if (w.bf16) {   // chunks run over the 8-channel blocks of the whole virtual concat
@@ -761,8 +772,15 @@ extern "C" int passion_conv3d_fwd(const passion_conv_desc_t* d, const float* pac
             rc = launch_conv_bf16(k, d->ksize, d->stride, false, packed + f32_pack_floats(k.Cin, k.Cout, nt), st);
         else
             rc = launch_conv_geo<bf16_t, bf16_t, 0>(k, d->ksize, d->stride, mtiles, st);
-    } else if (d->x_dtype == PASSION_BF16 && d->y_dtype == PASSION_F32)
-        rc = launch_conv_geo<bf16_t, float, 0>(k, d->ksize, d->stride, mtiles, st);
+    } else if (d->x_dtype == PASSION_BF16 && d->y_dtype == PASSION_F32) {
+        rc = 1;
+        if (lean_f32_head(k, d) && !residual) {
+            k.y_f32 = 1;
+            rc = launch_conv_lean(k, d->ksize, d->stride, 0, packed + f32_pack_floats(k.Cin, k.Cout, nt), st);
+            if (rc > 0) k.y_f32 = 0;
+        }
+        if (rc > 0) rc = launch_conv_geo<bf16_t, float, 0>(k, d->ksize, d->stride, mtiles, st);
+    }
     else
         rc = -1007;
     return rc;
@@ -797,7 +815,12 @@ extern "C" int passion_conv3d_bwd(const passion_conv_desc_t* d, const float* pac
                            2.0 * k.B * k.Do * k.Ho * k.Wo * (double)k.Cout * k.Cin * nt, st);
             float* dWs = dweight ? wslab : nullptr;
             float* dbs = dbias ? bslab : nullptr;
-            if (w.bf16)
+            if (w.bf16 && d->y_dtype == PASSION_F32) {
+                k.y_f32 = 1;
+                rc = launch_wgrad_lean(k, d->ksize, d->stride, w.MT, w.gx, w.gy, dWs, dbs, st);
+                k.y_f32 = 0;
+                if (rc > 0) rc = -1014;              // planned for the lean kernel: must be covered
+            } else if (w.bf16)
                 rc = launch_wgrad_bf16(k, d->ksize, d->stride, w.MT, w.gx, w.gy, dWs, dbs, st);
             else if (d->x_dtype == PASSION_F32 && d->y_dtype == PASSION_F32)
                 rc = launch_wgrad_geo<float, float>(k, w, d->ksize, d->stride, dWs, dbs, st);
@@ -868,8 +891,15 @@ extern "C" int passion_conv3d_bwd(const passion_conv_desc_t* d, const float* pac
             else
                 rc = launch_conv_geo<bf16_t, bf16_t, 1>(k, d->ksize, d->stride, mtiles, st);
         }
-        else if (d->x_dtype == PASSION_BF16 && d->y_dtype == PASSION_F32)
-            rc = launch_conv_geo<float, bf16_t, 1>(k, d->ksize, d->stride, mtiles, st);
+        else if (d->x_dtype == PASSION_BF16 && d->y_dtype == PASSION_F32) {
+            rc = 1;
+            if (lean_f32_head(k, d) && d->ksize == 1) {
+                k.y_f32 = 1;
+                rc = launch_conv_lean(k, d->ksize, d->stride, 1, packed + f32_pack_floats(k.Cin, k.Cout, nt), st);
+                k.y_f32 = 0;
+            }
+            if (rc > 0) rc = launch_conv_geo<float, bf16_t, 1>(k, d->ksize, d->stride, mtiles, st);
+        }
         else
             rc = -1007;
         if (rc) return rc;

@@ -39,6 +39,7 @@ struct ConvK {
     float* sums;
     int tilesD, tilesH, tilesW;
     int hi_t[3], hi_u[3];  // dgrad reflect: tap / source coordinate of the high-side mirror term per axis
+    int y_f32;             // lean kernels: y (forward) / dy (backward) is f32 with Cout <= 8 -- the 4-class logit heads
     long wslot;            // wgrad: floats per workgroup slot of the partial slab ([dW | dbias])
     int sums_rep;          // dgrad: replicas of the InstanceNorm-backward sums this launch spreads its atomics over
     int per, wres;         // bf16 kernel: bricks per (persistent) workgroup; all chunks' weight fragments resident in LDS

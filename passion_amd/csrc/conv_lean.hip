@@ -95,7 +95,7 @@ __global__ __launch_bounds__(256) void conv_lean_kernel(ConvK p) {
     const int mg = blockIdx.y;
     // stride 1: the GEMM's output volume (fwd: y, dgrad: dx) and its source volume (fwd: x, dgrad: dy) coincide
     const int Sd = p.Di, Sh = p.Hi, Sw = p.Wi;
-    const int K8 = DG ? p.Cout / 8 : p.Cin / 8;
+    const int K8 = DG ? (p.Cout + 7) / 8 : p.Cin / 8;
     const int nchunk = (K8 + NC8 - 1) / NC8;
     const bool wres = p.wres != 0;
     const bf16x8* wp = reinterpret_cast<const bf16x8*>(p.wpack);
@@ -134,7 +134,10 @@ __global__ __launch_bounds__(256) void conv_lean_kernel(ConvK p) {
         d.pad_ = 0;
 #pragma unroll
         for (int c = 0; c < 8; ++c) { d.mean[c] = 0.f; d.rstd[c] = 1.f; }
-        if (DG) {
+        if (DG && p.y_f32) {        // f32 dY of a logit head: one block of Cout <= 8 channels, converted while staging
+            d.src = reinterpret_cast<const bf16_t*>(reinterpret_cast<const float*>(p.dy) + (long)b * Sd * Sh * Sw * p.Cout);
+            d.C = p.Cout; d.nch = 8; d.has_norm = 0;
+        } else if (DG) {
             d.src = reinterpret_cast<const bf16_t*>(p.dy) + (long)b * Sd * Sh * Sw * p.Cout + tid * 8;
             d.C = p.Cout; d.nch = 8; d.has_norm = 0;
         } else {
@@ -252,6 +255,20 @@ __global__ __launch_bounds__(256) void conv_lean_kernel(ConvK p) {
     // ---- staging: FETCH (global -> registers) / COMMIT (registers -> normalise -> LDS)
     u32x4 raw[NIT];
     unsigned okbits = 0u;
+    // f32 dY (DG && p.y_f32): C = Cout floats per voxel -> 8 bf16 (upper channels zero)
+    auto load_vox = [&](const bf16_t* src, long vox, int C) -> u32x4 {
+        if (DG && p.y_f32) {
+            const float* f = reinterpret_cast<const float*>(src) + vox * C;
+            const f32x4 lo = *reinterpret_cast<const f32x4*>(f);
+            f32x4 hi = {0.f, 0.f, 0.f, 0.f};
+            if (C == 8) hi = *reinterpret_cast<const f32x4*>(f + 4);
+            bf16x8 o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { o[j] = (__bf16)lo[j]; o[4 + j] = (__bf16)hi[j]; }
+            return __builtin_bit_cast(u32x4, o);
+        }
+        return *reinterpret_cast<const u32x4*>(src + vox * C);
+    };
     auto fetch = [&](int chunk, int o0d, int o0h, int o0w) {
         const BlkDesc* dp = desc + chunk * NC8 + jj;
         const bf16_t* src = dp->src;
@@ -269,7 +286,7 @@ __global__ __launch_bounds__(256) void conv_lean_kernel(ConvK p) {
             for (int u = 0; u < NIT; ++u) {
                 raw[u] = (u32x4){0u, 0u, 0u, 0u};
                 if (have && (tid + 256 * u < G::TOT)) {
-                    raw[u] = *reinterpret_cast<const u32x4*>(src + (long)(basevox + voxoff[u]) * C);
+                    raw[u] = load_vox(src, (long)(basevox + voxoff[u]), C);
                     okbits |= 1u << u;
                 }
             }
@@ -288,7 +305,7 @@ __global__ __launch_bounds__(256) void conv_lean_kernel(ConvK p) {
                 }
                 raw[u] = (u32x4){0u, 0u, 0u, 0u};
                 if (ok) {
-                    raw[u] = *reinterpret_cast<const u32x4*>(src + (((long)sd * Sh + sh) * Sw + sw) * C);
+                    raw[u] = load_vox(src, ((long)sd * Sh + sh) * Sw + sw, C);
                     okbits |= 1u << u;
                 }
             }
@@ -571,10 +588,13 @@ __global__ __launch_bounds__(256) void conv_lean_kernel(ConvK p) {
                     for (int nt = 0; nt < 4; ++nt) {
                         const long e = (basevox + nt * 2 * Sw) * p.Cout + co;
                         f32x4 v = acc[mt][nt] + biasv[mt];
+                        if (p.y_f32) { *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.y) + e) = v; continue; }   // logit head
                         if (res) v += load4(res + e);
                         store4(y + e, v);
                     }
                 }
+            } else if (p.y_f32) {
+                epilogue_fwd<float, MT>(p, acc, b, mg, o0d + ld_, o0w + lw, oh4, g);
             } else {
                 epilogue_fwd<bf16_t, MT>(p, acc, b, mg, o0d + ld_, o0w + lw, oh4, g);
             }
@@ -663,7 +683,7 @@ namespace pconv {
 // returns 0 = launched, < 0 = HIP error, 1 = shape not covered (caller falls back to the general kernel)
 bool lean_covers(const ConvK& k, int stride, bool dgrad) {
     if (stride != 1) return false;
-    if (dgrad) return k.Cout % 8 == 0 && k.Cout / 8 <= MAXBLK;
+    if (dgrad) return (k.Cout % 8 == 0 || k.y_f32) && (k.Cout + 7) / 8 <= MAXBLK;
     int K8 = 0;
     for (int s = 0; s < k.nseg; ++s) {
         if (k.seg[s].C % 8) return false;
@@ -680,8 +700,8 @@ int launch_conv_lean(ConvK& k, int ksize, int stride, int mode, const void* pack
     const int ntap = ksize * ksize * ksize;
     int K8, cmax = 0;
     if (dgrad) {
-        if (k.Cout % 8) return 1;
-        K8 = k.Cout / 8;
+        if (k.Cout % 8 && !k.y_f32) return 1;
+        K8 = (k.Cout + 7) / 8;
         cmax = k.Cout;
     } else {
         K8 = 0;

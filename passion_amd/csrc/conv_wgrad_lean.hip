@@ -99,6 +99,21 @@ __global__ __launch_bounds__(256) void wgrad_lean_kernel(ConvK p, float* __restr
         }
     }
     const bf16_t* dyb = reinterpret_cast<const bf16_t*>(p.dy) + (long)(b < p.B ? b : 0) * Sd * Sh * Sw * p.Cout;
+    const float* dyf = reinterpret_cast<const float*>(p.dy) + (long)(b < p.B ? b : 0) * Sd * Sh * Sw * p.Cout;   // p.y_f32
+    // dY block of 8 channels at (voxel, co): bf16 16-byte load, or (f32 logit heads, Cout <= 8) converted on the fly
+    auto load_dy = [&](long vox, int co) -> u32x4 {
+        if (p.y_f32) {
+            const float* f = dyf + vox * p.Cout + co;
+            const f32x4 lo = *reinterpret_cast<const f32x4*>(f);
+            f32x4 hi = {0.f, 0.f, 0.f, 0.f};
+            if (co + 8 <= p.Cout) hi = *reinterpret_cast<const f32x4*>(f + 4);
+            bf16x8 o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { o[j] = (__bf16)lo[j]; o[4 + j] = (__bf16)hi[j]; }
+            return __builtin_bit_cast(u32x4, o);
+        }
+        return *reinterpret_cast<const u32x4*>(dyb + vox * p.Cout + co);
+    };
 
     // ---- per-thread constants of the staging
     int voxoff[AR];                                   // activation voxel of iteration r relative to the brick's first voxel
@@ -167,7 +182,7 @@ __global__ __launch_bounds__(256) void wgrad_lean_kernel(ConvK p, float* __restr
 #pragma unroll
             for (int r = 0; r < DR; ++r) {
                 rd[r] = (u32x4){0u, 0u, 0u, 0u};
-                if (dco[r] < p.Cout) rd[r] = *reinterpret_cast<const u32x4*>(dyb + (long)(baseo + dvoff[r]) * p.Cout + dco[r]);
+                if (dco[r] < p.Cout) rd[r] = load_dy((long)(baseo + dvoff[r]), dco[r]);
             }
         } else {
 #pragma unroll
@@ -195,7 +210,7 @@ __global__ __launch_bounds__(256) void wgrad_lean_kernel(ConvK p, float* __restr
                 const int od = o0d + d, oh = o0h + h, ow = o0w + w;
                 rd[r] = (u32x4){0u, 0u, 0u, 0u};
                 if (od < Sd && oh < Sh && ow < Sw && dco[r] < p.Cout)
-                    rd[r] = *reinterpret_cast<const u32x4*>(dyb + (((long)od * Sh + oh) * Sw + ow) * p.Cout + dco[r]);
+                    rd[r] = load_dy(((long)od * Sh + oh) * Sw + ow, dco[r]);
             }
         }
     };
@@ -325,7 +340,7 @@ namespace pconv {
 // returns 0 = launched, < 0 = HIP error, 1 = shape not covered (caller uses conv_wgrad_bf16_kernel).
 // gx = slots of the partial slab = workgroups in x (spare ones flush zeros), gy = (8-channel blocks) x (row-tile groups)
 int launch_wgrad_lean(ConvK& k, int ksize, int stride, int MT, int gx, int gy, float* dW, float* db, hipStream_t st) {
-    if (stride != 1 || k.Cout % 8 || gx < k.B) return 1;
+    if (stride != 1 || (k.Cout % 8 && !(k.y_f32 && k.Cout % 4 == 0 && k.Cout <= 8)) || gx < k.B) return 1;
     if (!(k.slope >= 0.f && k.slope <= 1.f)) return 1;      // the loader's LeakyReLU is max(t, slope * t)
     int K8 = 0;
     for (int s = 0; s < k.nseg; ++s) {

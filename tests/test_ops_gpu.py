@@ -139,6 +139,35 @@ def test_conv_kernel_paths(case, path):
             ops.set_option(k, v)
 
 
+@pytest.mark.parametrize("segC,Cout,k,norm", [([16], 4, 1, False), ([8, 8], 4, 1, True), ([8], 4, 3, True), ([32], 8, 1, False)])
+def test_conv_f32_logit_head(segC, Cout, k, norm):
+    """bf16 activations -> f32 logits (segmentation / region-probability heads): forward, dgrad with f32 dY, wgrad"""
+    from passion_amd import ops
+    dev = _dev()
+    B, D, H, W = 2, 8, 16, 24
+    g = torch.Generator().manual_seed(13)
+    xs = [(torch.randn(B, c, D, H, W, generator=g, dtype=torch.float64) * 1.2 + 0.2).to(torch.bfloat16).double() for c in segC]
+    cin = sum(segC)
+    w = torch.randn(Cout, cin, k, k, k, generator=g, dtype=torch.float64) / (cin * k ** 3) ** 0.5
+    b = torch.randn(Cout, generator=g, dtype=torch.float64)
+    gy = torch.randn(B, Cout, D, H, W, generator=g, dtype=torch.float64).float().double()
+    xr = [x.clone().requires_grad_(True) for x in xs]
+    wr, br = w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    yr = ref_conv_block(xr, [norm] * len(segC), [None] * len(segC), wr, br, k, 1, 1, None)
+    yr.backward(gy)
+    xd = [cl(x).to(dev, torch.bfloat16).requires_grad_(True) for x in xs]
+    wd, bd = w.float().to(dev).requires_grad_(True), b.float().to(dev).requires_grad_(True)
+    segs = [ops.SegIn(x, stats=ops.instnorm_stats(x.detach()) if norm else None) for x in xd]
+    y = ops.conv_block(segs, wd, bd, D, H, W, ksize=k, stride=1, pad_mode=1, out_dtype=torch.float32)
+    assert y.dtype == torch.float32
+    y.backward(cl(gy).to(dev, torch.float32))
+    tol = TOL[torch.bfloat16]
+    assert relerr(nc(y.detach()), yr) < tol
+    assert relerr(wd.grad, wr.grad) < tol * 2 and relerr(bd.grad, br.grad) < tol * 2
+    for i in range(len(segC)):
+        assert relerr(nc(xd[i].grad.float()), xr[i].grad) < tol * 3
+
+
 def test_conv_batched_passes():
     """SegIn.bmod: P masked passes over the same B samples in one launch == P separate launches, gradients summed"""
     from passion_amd import ops

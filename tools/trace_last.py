@@ -4,7 +4,7 @@ import csv, sys, re, collections
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 top = int(sys.argv[2]) if len(sys.argv) > 2 else 40
-opt = [i for i, r in enumerate(rows) if "multi_tensor_apply" in r["Kernel_Name"]]
+opt = [i for i, r in enumerate(rows) if "multi_tensor_apply" in r["Kernel_Name"] or "adamw_multi_kernel" in r["Kernel_Name"]]
 # group optimizer launches into steps: a gap of > 200 dispatches separates steps
 ends = [i for j, i in enumerate(opt) if j + 1 == len(opt) or opt[j + 1] - i > 200]
 if len(ends) >= 2:
