@@ -56,4 +56,7 @@ class FusedAdamW(torch.optim.Optimizer):
                                            1 if group["amsgrad"] else 0, L.stream_ptr()), "passion_adamw_step")
             for p in ps:
                 self.state[p]["step"] += 1
+                # the kernel wrote the parameters behind autograd's back: bump their version counters, the packed-weight
+                # caches (ops.pack_weight / repack_stale) and any saved-tensor checks key on them
+                torch.autograd.graph.increment_version(p)
         return loss

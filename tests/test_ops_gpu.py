@@ -411,6 +411,7 @@ def test_fused_adamw_matches_torch(amsgrad):
     pa = [torch.randn(s_, generator=g).to(dev).requires_grad_(True) for s_ in shapes]
     pb = [p.detach().clone().requires_grad_(True) for p in pa]
     oa = FusedAdamW(pa, lr=2e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-4, amsgrad=amsgrad)
+    v0 = [p._version for p in pa]
     ob = torch.optim.AdamW(pb, lr=2e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-4, amsgrad=amsgrad)
     for it in range(4):
         for a, b in zip(pa, pb):
@@ -419,6 +420,7 @@ def test_fused_adamw_matches_torch(amsgrad):
         oa.step(); ob.step()
     for a, b in zip(pa, pb):
         assert relerr(a.detach(), b.detach()) < 2e-6
+    assert all(p._version > v for p, v in zip(pa, v0)), "in-place update must bump the version (packed-weight caches key on it)"
     sa, sb = oa.state_dict(), ob.state_dict()
     assert sa["state"].keys() == sb["state"].keys()
     for k in sa["state"]:
