@@ -69,8 +69,11 @@ __device__ __forceinline__ bf16x8 zero8() {
     return z;
 }
 
-template <int KS, int MT, int MODE, int CKB>
+// S: stride of the forward conv; only MODE 2 (dgrad over the padded domain) runs with S = 2: dY is staged zero-stuffed
+// (position u of the fine grid holds dy[u / 2] for even u, zero otherwise) and the 27 flipped taps gather as for S = 1.
+template <int KS, int MT, int MODE, int CKB, int S = 1>
 __global__ __launch_bounds__(256) void conv_lean_kernel(ConvK p) {
+    static_assert(S == 1 || MODE == 2, "stride 2 only for the padded-domain dgrad");
     constexpr bool DG = (MODE >= 1);
     // MODE 2: dgrad of a reflect-padded conv computed over the PADDED input domain (output coordinate op <-> input
     // position op - 1, from -1 to S): every brick costs the same 27 taps, no mirror-tap bookkeeping at all; the halo
@@ -95,6 +98,7 @@ __global__ __launch_bounds__(256) void conv_lean_kernel(ConvK p) {
     const int mg = blockIdx.y;
     // stride 1: the GEMM's output volume (fwd: y, dgrad: dx) and its source volume (fwd: x, dgrad: dy) coincide
     const int Sd = p.Di, Sh = p.Hi, Sw = p.Wi;
+    const int Qd = (S == 2) ? p.Do : Sd, Qh = (S == 2) ? p.Ho : Sh, Qw = (S == 2) ? p.Wo : Sw;   // source volume (dgrad: dY)
     const int K8 = DG ? (p.Cout + 7) / 8 : p.Cin / 8;
     const int nchunk = (K8 + NC8 - 1) / NC8;
     const bool wres = p.wres != 0;
@@ -135,10 +139,10 @@ __global__ __launch_bounds__(256) void conv_lean_kernel(ConvK p) {
 #pragma unroll
         for (int c = 0; c < 8; ++c) { d.mean[c] = 0.f; d.rstd[c] = 1.f; }
         if (DG && p.y_f32) {        // f32 dY of a logit head: one block of Cout <= 8 channels, converted while staging
-            d.src = reinterpret_cast<const bf16_t*>(reinterpret_cast<const float*>(p.dy) + (long)b * Sd * Sh * Sw * p.Cout);
+            d.src = reinterpret_cast<const bf16_t*>(reinterpret_cast<const float*>(p.dy) + (long)b * Qd * Qh * Qw * p.Cout);
             d.C = p.Cout; d.nch = 8; d.has_norm = 0;
         } else if (DG) {
-            d.src = reinterpret_cast<const bf16_t*>(p.dy) + (long)b * Sd * Sh * Sw * p.Cout + tid * 8;
+            d.src = reinterpret_cast<const bf16_t*>(p.dy) + (long)b * Qd * Qh * Qw * p.Cout + tid * 8;
             d.C = p.Cout; d.nch = 8; d.has_norm = 0;
         } else {
             int r = tid;
@@ -223,7 +227,10 @@ __global__ __launch_bounds__(256) void conv_lean_kernel(ConvK p) {
     for (int u = 0; u < NIT; ++u) {
         const int tv = (tid + 256 * u) / NC8;
         const int zw = tv % G::IW, zh = (tv / G::IW) % G::IH, zd = tv / (G::IW * G::IH);
-        voxoff[u] = (zd * Sh + zh) * Sw + zw;
+        // S == 2 (zero-stuffed dY): brick origins are even, so the parity of a staged position is the parity of its
+        // brick-local coordinate -- a per-thread constant; only the all-even ones carry data (source voxel = half)
+        voxoff[u] = (S == 2) ? ((zd >> 1) * Qh + (zh >> 1)) * Qw + (zw >> 1) : (zd * Qh + zh) * Qw + zw;
+        if (S == 2 && ((zd | zh | zw) & 1)) voxoff[u] = -1;
     }
     const int ldsoff0 = (tid / NC8) * VS + jj * 16;       // iteration u writes at ldsoff0 + u * (256 / NC8) * VS
     const int lh0 = n >> 3, lw = n & 7, ld_ = wv;
@@ -278,14 +285,14 @@ __global__ __launch_bounds__(256) void conv_lean_kernel(ConvK p) {
             src = rfl_ptr(src); C = rfl(C); have = rfl(have ? 1 : 0) != 0;
         }
         okbits = 0u;
-        const bool interior = o0d >= G::HALO && o0h >= G::HALO && o0w >= G::HALO && o0d + TD + G::HALO <= Sd &&
-                              o0h + TH + G::HALO <= Sh && o0w + TW + G::HALO <= Sw;
+        const bool interior = o0d >= G::HALO && o0h >= G::HALO && o0w >= G::HALO && o0d + TD + G::HALO <= S * Qd &&
+                              o0h + TH + G::HALO <= S * Qh && o0w + TW + G::HALO <= S * Qw;
         if (interior) {                           // workgroup-uniform: no padding anywhere in this brick
-            const int basevox = ((o0d - G::HALO) * Sh + (o0h - G::HALO)) * Sw + (o0w - G::HALO);
+            const int basevox = (((o0d - G::HALO) / S) * Qh + (o0h - G::HALO) / S) * Qw + (o0w - G::HALO) / S;
 #pragma unroll
             for (int u = 0; u < NIT; ++u) {
                 raw[u] = (u32x4){0u, 0u, 0u, 0u};
-                if (have && (tid + 256 * u < G::TOT)) {
+                if (have && (tid + 256 * u < G::TOT) && (S == 1 || voxoff[u] >= 0)) {
                     raw[u] = load_vox(src, (long)(basevox + voxoff[u]), C);
                     okbits |= 1u << u;
                 }
@@ -301,11 +308,15 @@ __global__ __launch_bounds__(256) void conv_lean_kernel(ConvK p) {
                     sd = reflect_idx(sd, Sd); sh = reflect_idx(sh, Sh); sw = reflect_idx(sw, Sw);
                     sd = min(max(sd, 0), Sd - 1); sh = min(max(sh, 0), Sh - 1); sw = min(max(sw, 0), Sw - 1);
                 } else {
-                    ok = ok && (sd >= 0 && sd < Sd && sh >= 0 && sh < Sh && sw >= 0 && sw < Sw);
+                    if (S == 2) {                             // zero-stuffed dY: only even fine-grid positions carry data
+                        ok = ok && sd >= 0 && sh >= 0 && sw >= 0 && !((sd | sh | sw) & 1);
+                        sd >>= 1; sh >>= 1; sw >>= 1;
+                    }
+                    ok = ok && (sd >= 0 && sd < Qd && sh >= 0 && sh < Qh && sw >= 0 && sw < Qw);
                 }
                 raw[u] = (u32x4){0u, 0u, 0u, 0u};
                 if (ok) {
-                    raw[u] = load_vox(src, ((long)sd * Sh + sh) * Sw + sw, C);
+                    raw[u] = load_vox(src, ((long)sd * Qh + sh) * Qw + sw, C);
                     okbits |= 1u << u;
                 }
             }
@@ -631,7 +642,7 @@ __global__ __launch_bounds__(256) void conv_lean_kernel(ConvK p) {
     }
 }
 
-template <int KS, int MT, int MODE, int CKB>
+template <int KS, int MT, int MODE, int CKB, int S = 1>
 int launch_lean_one(ConvK& k, int K8, int gy, hipStream_t st) {
     using G = GeoL<KS, CKB>;
     constexpr int wchunk = G::NSTEP * 4 * MT * 16 * 16;
@@ -648,31 +659,32 @@ int launch_lean_one(ConvK& k, int K8, int gy, hipStream_t st) {
     const int gx = k.B * ((tiles_per_b + per - 1) / per);
     static int attr_bytes = 0;        // > 64 KB of dynamic LDS has to be granted per kernel
     if (bytes > attr_bytes) {
-        HIP_RET(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_lean_kernel<KS, MT, MODE, CKB>),
+        HIP_RET(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_lean_kernel<KS, MT, MODE, CKB, S>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
         attr_bytes = bytes;
     }
-    passion_prof_tag("conv_lean_kernel<%d, %d, %d, %d>", KS, MT, MODE, CKB);
-    hipLaunchKernelGGL((conv_lean_kernel<KS, MT, MODE, CKB>), dim3(gx, gy), dim3(256), bytes, st, k);
+    if (S == 1) passion_prof_tag("conv_lean_kernel<%d, %d, %d, %d, 1>", KS, MT, MODE, CKB);
+    else passion_prof_tag("conv_lean_kernel<%d, %d, %d, %d, %d>", KS, MT, MODE, CKB, S);
+    hipLaunchKernelGGL((conv_lean_kernel<KS, MT, MODE, CKB, S>), dim3(gx, gy), dim3(256), bytes, st, k);
     LAUNCH_RET();
     return 0;
 }
 
-template <int KS, int MODE>
+template <int KS, int MODE, int S = 1>
 int launch_lean_geo(ConvK& k, int K8, int cmax, int mtiles, hipStream_t st) {
     const long tiles = (long)k.B * k.tilesD * k.tilesH * k.tilesW;
     if (cmax >= 32) {                 // 32-channel chunks; weight fragments of a chunk fit LDS up to two row tiles
         int MT = (mtiles % 2 == 0) ? 2 : 1;
         while (MT > 1 && tiles * (mtiles / MT) < 512) MT >>= 1;
-        if (MT == 2) return launch_lean_one<KS, 2, MODE, 32>(k, K8, mtiles / 2, st);
-        return launch_lean_one<KS, 1, MODE, 32>(k, K8, mtiles, st);
+        if (MT == 2) return launch_lean_one<KS, 2, MODE, 32, S>(k, K8, mtiles / 2, st);
+        return launch_lean_one<KS, 1, MODE, 32, S>(k, K8, mtiles, st);
     }
     int MT = mtiles >= 4 ? 4 : mtiles;
     if (mtiles % MT) MT = (mtiles % 2 == 0) ? 2 : 1;
     while (MT > 1 && tiles * (mtiles / MT) < 512) MT >>= 1;
-    if (MT == 4) return launch_lean_one<KS, 4, MODE, 8>(k, K8, mtiles / 4, st);
-    if (MT == 2) return launch_lean_one<KS, 2, MODE, 8>(k, K8, mtiles / 2, st);
-    return launch_lean_one<KS, 1, MODE, 8>(k, K8, mtiles, st);
+    if (MT == 4) return launch_lean_one<KS, 4, MODE, 8, S>(k, K8, mtiles / 4, st);
+    if (MT == 2) return launch_lean_one<KS, 2, MODE, 8, S>(k, K8, mtiles / 2, st);
+    return launch_lean_one<KS, 1, MODE, 8, S>(k, K8, mtiles, st);
 }
 
 }  // namespace
@@ -682,7 +694,7 @@ namespace pconv {
 // mode 0 forward, 1 dgrad, 2 dgrad over the padded domain (see PADOUT; k.tiles* cover (S+2)^3, k.y = padded scratch)
 // returns 0 = launched, < 0 = HIP error, 1 = shape not covered (caller falls back to the general kernel)
 bool lean_covers(const ConvK& k, int stride, bool dgrad) {
-    if (stride != 1) return false;
+    if (stride != 1 && !(stride == 2 && dgrad)) return false;     // stride 2: only the padded-domain dgrad (mode 2)
     if (dgrad) return (k.Cout % 8 == 0 || k.y_f32) && (k.Cout + 7) / 8 <= MAXBLK;
     int K8 = 0;
     for (int s = 0; s < k.nseg; ++s) {
@@ -694,7 +706,7 @@ bool lean_covers(const ConvK& k, int stride, bool dgrad) {
 
 int launch_conv_lean(ConvK& k, int ksize, int stride, int mode, const void* packed_bf16, hipStream_t st) {
     const bool dgrad = mode >= 1;
-    if (stride != 1) return 1;
+    if (stride != 1 && !(stride == 2 && mode == 2)) return 1;
     if (!(k.slope >= 0.f && k.slope <= 1.f)) return 1;      // the loader's LeakyReLU is max(t, slope * t)
     if (mode == 2 && ksize != 3) return 1;
     const int ntap = ksize * ksize * ksize;
@@ -724,6 +736,7 @@ int launch_conv_lean(ConvK& k, int ksize, int stride, int mode, const void* pack
     k.sums_rep = SUMS_REP_LEAN;
     const int mtiles = k.Mpad / 16;
     if (ksize == 1) return dgrad ? launch_lean_geo<1, 1>(k, K8, cmax, mtiles, st) : launch_lean_geo<1, 0>(k, K8, cmax, mtiles, st);
+    if (mode == 2 && stride == 2) return launch_lean_geo<3, 2, 2>(k, K8, cmax, mtiles, st);
     if (mode == 2) return launch_lean_geo<3, 2>(k, K8, cmax, mtiles, st);
     return dgrad ? launch_lean_geo<3, 1>(k, K8, cmax, mtiles, st) : launch_lean_geo<3, 0>(k, K8, cmax, mtiles, st);
 }
