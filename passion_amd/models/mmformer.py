@@ -37,6 +37,8 @@ patch_size = 5
 H = W = Z = 80
 
 MODALS = ("flair", "t1ce", "t1", "t2")
+import os as _os
+ENC_STREAMS = _os.environ.get("PASSION_ENC_STREAMS", "1") != "0"
 
 
 def _up2(f):
@@ -315,6 +317,12 @@ class Model(nn.Module):
         vol = tok.to(self.compute_dtype).contiguous().view(P * B, p, p, p, self.token_dim * num_modals)
         return run_conv(self.multimodal_decode_conv, Feat(vol), norm=False)
 
+    def _enc_streams(self, dev):
+        cache = self.__dict__.setdefault("_streams_dev", {})
+        if dev not in cache:
+            cache[dev] = [torch.cuda.Stream(device=dev) for _ in range(4)]
+        return cache[dev]
+
     def _onehots_on(self, dev):
         """masks_mod0..3 (plain CPU attributes, as in the reference) copied to the device once, not per forward"""
         cache = self.__dict__.setdefault("_onehots_dev", {})
@@ -342,11 +350,28 @@ class Model(nn.Module):
             c = self.flair_encoder.e1_c1.out_channels
             bufs = [torch.empty(4, B, S >> l, S >> l, S >> l, c << l, dtype=dt, device=dev) for l in range(5)]
             sbufs = [torch.empty(4, B, c << l, 2, dtype=torch.float32, device=dev) for l in range(5)]
-        encs = []
+        # The four encoders are independent until the fusion: each runs on its own HIP stream (forward, and -- autograd
+        # replays every node on the stream of its forward -- backward too), so the small deep-level launches of one
+        # modality fill the CUs the others leave idle.  PASSION_ENC_STREAMS=0 keeps everything on one stream.
+        streams = self._enc_streams(dev) if ENC_STREAMS and x.is_cuda else None
+        main = torch.cuda.current_stream(dev) if streams else None
+        encs = [None] * 4
         for i, m in enumerate(MODALS):
             outs = [ops.alias_slice(b_, i) for b_ in bufs] if training else None
             sts = [s_[i] for s_ in sbufs] if training else None
-            encs.append(getattr(self, f"{m}_encoder")(xin, i, mask if idt else None, dt, outs, sts))
+            if streams:
+                streams[i].wait_stream(main)
+                with torch.cuda.stream(streams[i]):
+                    encs[i] = getattr(self, f"{m}_encoder")(xin, i, mask if idt else None, dt, outs, sts)
+                    for f in encs[i]:                    # consumed by work on the main stream: tell the allocator, or the
+                        f.t.record_stream(main)          # block could be handed out again on this side stream too early
+                        if f._stats[0] is not None:
+                            f._stats[0].record_stream(main)
+            else:
+                encs[i] = getattr(self, f"{m}_encoder")(xin, i, mask if idt else None, dt, outs, sts)
+        if streams:
+            for s_ in streams:
+                main.wait_stream(s_)
         p = encs[0][4].t.shape[1]
 
         # ---- the masks of every pass through the fusion path: teacher (+ the four uni-modal students,
