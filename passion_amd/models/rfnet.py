@@ -180,6 +180,12 @@ class Model(nn.Module):
             if isinstance(m, nn.Conv3d):
                 torch.nn.init.kaiming_normal_(m.weight)
 
+    def _enc_streams(self, dev):
+        cache = self.__dict__.setdefault("_streams_dev", {})
+        if dev not in cache:
+            cache[dev] = [torch.cuda.Stream(device=dev) for _ in range(4)]
+        return cache[dev]
+
     def _onehots_on(self, dev):
         """masks_mod0..3 (plain CPU attributes, as in the reference) copied to the device once, not per forward"""
         cache = self.__dict__.setdefault("_onehots_dev", {})
@@ -195,7 +201,25 @@ class Model(nn.Module):
         idt = self.mask_type != "pdt"
         mask = mask.to(device=dev, dtype=torch.bool).contiguous()
         xin = x.to(dt).contiguous()
-        encs = [getattr(self, f"{m}_encoder")(xin, i, mask if idt else None, dt) for i, m in enumerate(MODALS)]
+        # the four encoders are independent: one HIP stream each (forward and, through autograd, backward), see mmformer.py
+        from .mmformer import ENC_STREAMS
+        streams = self._enc_streams(dev) if ENC_STREAMS else None
+        main = torch.cuda.current_stream(dev) if streams else None
+        encs = [None] * 4
+        for i, m in enumerate(MODALS):
+            if streams:
+                streams[i].wait_stream(main)
+                with torch.cuda.stream(streams[i]):
+                    encs[i] = getattr(self, f"{m}_encoder")(xin, i, mask if idt else None, dt)
+                    for f in encs[i]:
+                        f.t.record_stream(main)
+                        if f._stats[0] is not None:
+                            f._stats[0].record_stream(main)
+            else:
+                encs[i] = getattr(self, f"{m}_encoder")(xin, i, mask if idt else None, dt)
+        if streams:
+            for s_ in streams:
+                main.wait_stream(s_)
         training = self.is_training
         passion = training and self.use_passion
 
