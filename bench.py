@@ -34,8 +34,12 @@ HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s s
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--prime", type=int, default=6,
+                    help="untimed set-up iterations before the W warm-up steps: the caching allocator keeps one pool per HIP "
+                         "stream (the four encoder branches run on their own streams) and needs a few iterations to stop "
+                         "calling hipMalloc; part of building the step, like compiling a graph would be")
     ap.add_argument("--workload", default="mmformer128", choices=["mmformer128", "mmformer128_passion", "rfnet128_passion"],
                     help="BASELINE.json configs[1] (default) / configs[2] (+ PASSION self-distillation) / "
                          "configs[3] (RFNet + PASSION, batch 2 per GPU)")
@@ -129,6 +133,8 @@ def main():
     # warm-up; with the roofline leg on, its event pairs bracket EVERY conv launch so that the kernel family that
     # dominates the step is known before the timed region starts -- there only that family keeps its event pairs
     # (326 event pairs per step cost ~5 % of throughput, one family ~1.5 %)
+    for _ in range(args.prime):
+        step()
     want_events = not args.no_roofline and not use_graph
     if want_events:
         ops.prof_read()

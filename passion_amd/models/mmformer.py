@@ -398,6 +398,24 @@ class Model(nn.Module):
             intra.append(tok * mask[:, i].view(B, 1, 1).to(tok.dtype))
         pos_cat = torch.cat(pos, 1)
 
+        # decoder_sep (per-modality decoders, shared weights: ONE pass over the stacked modalities) depends on the encoders
+        # only, like the fusion path: it goes to a side stream and overlaps with the transformers + decoder_fuse below
+        sep_all = None
+        if training:
+            sep_mask = mask.t().reshape(4 * B, 1).contiguous() if idt else None      # row i*B+b = mask[b, i]
+            stacked = []
+            for l in range(5):
+                t = ops.stack_slots(bufs[l], [encs[i][l].t for i in range(4)])
+                st = [sbufs[l].view(4 * B, -1, 2)] if l < 4 else None               # filled by the encoders' next-level convs
+                stacked.append(Feat(t, sep_mask, 0, _stats=st))
+            if streams:
+                streams[0].wait_stream(main)
+                with torch.cuda.stream(streams[0]):
+                    sep_all = self.decoder_sep(*stacked)
+                    sep_all.record_stream(main)
+            else:
+                sep_all = self.decoder_sep(*stacked)
+
         fuse_all, preds_all, feats_all = self.decoder_fuse(*xs, self._inter(intra, tok_mask, pos_cat, B, p, P))
         if P == 1:
             fuse_pred, preds = fuse_all, preds_all
@@ -411,13 +429,9 @@ class Model(nn.Module):
             return pred
 
         tcl = ops.target_to_cl(target)
-        sep_mask = mask.t().reshape(4 * B, 1).contiguous() if idt else None      # row i*B+b = mask[b, i]
-        stacked = []
-        for l in range(5):
-            t = ops.stack_slots(bufs[l], [encs[i][l].t for i in range(4)])
-            st = [sbufs[l].view(4 * B, -1, 2)] if l < 4 else None               # filled by the encoders' next-level convs
-            stacked.append(Feat(t, sep_mask, 0, _stats=st))
-        sep_preds = self.decoder_sep(*stacked).split(B, 0)
+        if streams:
+            main.wait_stream(streams[0])
+        sep_preds = sep_all.split(B, 0)
         eye = torch.eye(4, device=dev)
         maskf = mask.float()
         gates = [(maskf * eye[i]) if idt else eye[i].expand(B, 4) for i in range(4)]
