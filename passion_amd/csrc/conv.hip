@@ -15,6 +15,8 @@
 // [tap][Cout][CinPad] image, plus "mirror taps" that implement the adjoint of reflect padding,
 // and an epilogue that goes back through LeakyReLU and accumulates the two InstanceNorm-backward
 // sums per (b, channel).
+#include <mutex>
+#include <vector>
 #include "conv_common.h"
 #include "prof.h"
 
@@ -787,6 +789,29 @@ extern "C" int passion_conv3d_fwd(const passion_conv_desc_t* d, const float* pac
     return rc;
 }
 
+// wgrad and dgrad of one conv only share their inputs (x, dY): the weight-gradient kernels + fold go to a companion stream
+// of the caller's stream and run under the dgrad + InstanceNorm-finish kernels; the caller's stream waits for them before
+// the call returns, so nothing changes for the caller (ordering, buffer lifetimes).  Experimental: PASSION_WGRAD_FORK=1 /
+// option "wgrad_fork".
+namespace pconv { int g_wgrad_fork = 0; }   // measured: no gain on the 128^3 step (42.6 vs 42.4 vol/s) -> off by default
+namespace {
+struct Companion { hipStream_t caller, side; hipEvent_t fork, done; };
+std::vector<Companion> g_comp;
+std::mutex g_comp_mu;
+Companion* companion(hipStream_t caller) {
+    std::lock_guard<std::mutex> lk(g_comp_mu);
+    for (auto& c : g_comp) if (c.caller == caller) return &c;
+    if (g_comp.size() >= 16) return nullptr;
+    Companion c{caller, nullptr, nullptr, nullptr};
+    if (hipStreamCreateWithFlags(&c.side, hipStreamNonBlocking) != hipSuccess) return nullptr;
+    if (hipEventCreateWithFlags(&c.fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c.done, hipEventDisableTiming) != hipSuccess) return nullptr;
+    g_comp.reserve(16);
+    g_comp.push_back(c);
+    return &g_comp.back();
+}
+}  // namespace
+
 extern "C" int passion_conv3d_bwd(const passion_conv_desc_t* d, const float* packed, const void* dy, float* dweight,
                                   float* dbias, float* sums, void* stream) {
     ConvK k;
@@ -801,7 +826,15 @@ extern "C" int passion_conv3d_bwd(const passion_conv_desc_t* d, const float* pac
     for (int s = 0; s < k.nseg; ++s) {
         if (k.seg[s].dx) { need_dx = true; if (k.seg[s].stats) need_norm = true; }
     }
-    float* zsums = (need_norm && sums) ? sums : nullptr;              // cleared by the weight-gradient fold when there is one
+    Companion* comp = (pconv::g_wgrad_fork && need_dx && (dweight || dbias)) ? companion(st) : nullptr;
+    hipStream_t caller_st = st;
+    if (comp) {                                      // fork: the weight-gradient work below goes to the companion stream
+        HIP_RET(hipEventRecord(comp->fork, caller_st));
+        HIP_RET(hipStreamWaitEvent(comp->side, comp->fork, 0));
+        st = comp->side;
+    }
+    // cleared by the weight-gradient fold when that runs on the same stream as the dgrad
+    float* zsums = (need_norm && sums && !comp) ? sums : nullptr;
     const long zn = zsums ? (long)2 * k.B * k.Cin * SUMS_REP : 0;
     // ---- wgrad (+ bias grad): per-workgroup partial slabs, then a fixed-order fold (no atomics, deterministic) ----
     if (dweight || dbias) {
@@ -850,6 +883,10 @@ extern "C" int passion_conv3d_bwd(const passion_conv_desc_t* d, const float* pac
                 LAUNCH_RET();
             }
         }
+    }
+    if (comp) {
+        HIP_RET(hipEventRecord(comp->done, comp->side));
+        st = caller_st;
     }
     // ---- dgrad ----
     if (!need_dx) return 0;
@@ -945,5 +982,6 @@ extern "C" int passion_conv3d_bwd(const passion_conv_desc_t* d, const float* pac
                                sg.stats, sums, sg.mask, sg.mask_col, sg.mask_ld, V, sg.C, sg.bstride, k.Cin, sg.cbase, sg.bmod, rep, rs);
         LAUNCH_RET();
     }
+    if (comp) HIP_RET(hipStreamWaitEvent(caller_st, comp->done, 0));     // join
     return 0;
 }
