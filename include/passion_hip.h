@@ -61,7 +61,8 @@ typedef struct {
     int32_t mask_col;
     int32_t mask_ld;
     int32_t bmod;         /* > 0: x (and stats) hold only bmod samples; sample b reads x[b % bmod] -- several masked passes over
-                             the same features batched into one launch.  mask, dx stay indexed by b.  0: plain batch */
+                             the same features batched into one launch.  mask stays indexed by b; dx has bmod samples too and
+                             receives the SUM of the passes' gradients.  0: plain batch */
 } passion_seg_t;
 
 typedef struct {

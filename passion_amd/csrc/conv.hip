@@ -236,7 +236,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvK p) {
 constexpr int FIN_MAXC = 512;
 __device__ __forceinline__ void finish_coefs(float (*coef)[3], const float* stats, const float* sums, int b, int bs, int C, int Cin_tot,
                                              int cbase, int rep, long rep_stride, float invV) {
-    for (int c = threadIdx.x; c < C && c < FIN_MAXC; c += blockDim.x) {
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
         float s1 = 0.f, s2 = 0.f;
         for (int r = 0; r < rep; ++r) {
             s1 += sums[(long)r * rep_stride + ((long)b * Cin_tot + cbase + c) * 2 + 0];
@@ -250,30 +250,46 @@ __device__ __forceinline__ void finish_coefs(float (*coef)[3], const float* stat
     }
 }
 
+// `passes` > 1 (SegD.bmod: P masked passes over the same bmod samples in one launch): g holds P*bmod per-pass gradients,
+// dx the bmod physical samples; the kernel finishes every pass with its own sums / mask and writes their SUM -- what
+// autograd would otherwise do with P full-size tensors and a reduction.  passes == 1: in place (g == dx).
+constexpr int FIN_TAB = 1024;                     // passes * C entries of (a, b, c0)
 template <typename T, int VEC>
-__global__ __launch_bounds__(256) void in_bwd_finish_kernel(T* __restrict__ dx, const T* __restrict__ x, const float* __restrict__ stats,
-                                                            const float* __restrict__ sums, const uint8_t* mask, int mask_col, int mask_ld,
-                                                            long V, int C, long bstride, int Cin_tot, int cbase, int bmod, int rep,
-                                                            long rep_stride) {
-    __shared__ float coef[FIN_MAXC][3];
-    const int b = blockIdx.y;
-    const int bs = bmod > 0 ? b % bmod : b;       // x / stats sample (dx and the sums are per virtual sample b)
-    finish_coefs(coef, stats, sums, b, bs, C, Cin_tot, cbase, rep, rep_stride, 1.0f / (float)V);
+__global__ __launch_bounds__(256) void in_bwd_finish_kernel(const T* __restrict__ g_in, T* __restrict__ dx, const T* __restrict__ x,
+                                                            const float* __restrict__ stats, const float* __restrict__ sums,
+                                                            const uint8_t* mask, int mask_col, int mask_ld, long V, int C, long bstride,
+                                                            int Cin_tot, int cbase, int bmod, int passes, int rep, long rep_stride) {
+    __shared__ float coef[FIN_TAB][3];
+    __shared__ int pres[16];
+    const int bp = blockIdx.y;                     // physical sample (x, stats, dx when passes > 1) or the plain batch index
+    const int bs = (passes == 1 && bmod > 0) ? bp % bmod : bp;
+    for (int p = 0; p < passes; ++p) {
+        const int b = p * (passes > 1 ? bmod : 0) + bp;        // virtual sample of pass p
+        if (stats) finish_coefs(coef + p * C, stats, sums, b, bs, C, Cin_tot, cbase, rep, rep_stride, 1.0f / (float)V);
+        if (threadIdx.x == 0) pres[p] = mask ? (mask[(long)b * mask_ld + mask_col] != 0) : 1;
+    }
     __syncthreads();
     const long nvec = V * C / VEC;
     const int cvn = C / VEC;
-    const bool present = mask ? (mask[(long)b * mask_ld + mask_col] != 0) : true;
-    T* dxb = dx + (long)b * bstride;
+    T* dxb = dx + (long)bp * bstride;
     const T* xb = x + (long)bs * bstride;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (long)gridDim.x * blockDim.x) {
         const int c = (int)(i % cvn) * VEC;
-        float g[VEC], xv[VEC];
-        VecIO<T, VEC>::load(dxb + i * VEC, g);
-        VecIO<T, VEC>::load(xb + i * VEC, xv);
+        float acc[VEC], xv[VEC];
 #pragma unroll
-        for (int j = 0; j < VEC; ++j)
-            g[j] = present ? __builtin_fmaf(coef[c + j][0], g[j], __builtin_fmaf(coef[c + j][1], xv[j], coef[c + j][2])) : 0.f;
-        VecIO<T, VEC>::store(dxb + i * VEC, g);
+        for (int j = 0; j < VEC; ++j) { acc[j] = 0.f; xv[j] = 0.f; }
+        if (stats) VecIO<T, VEC>::load(xb + i * VEC, xv);
+        for (int p = 0; p < passes; ++p) {
+            if (!pres[p]) continue;                                   // workgroup-uniform
+            const long b = (long)p * (passes > 1 ? bmod : 0) + bp;
+            float g[VEC];
+            VecIO<T, VEC>::load(g_in + b * bstride + i * VEC, g);
+            const float (*cf)[3] = coef + p * C + c;
+#pragma unroll
+            for (int j = 0; j < VEC; ++j)
+                acc[j] += stats ? __builtin_fmaf(cf[j][0], g[j], __builtin_fmaf(cf[j][1], xv[j], cf[j][2])) : g[j];
+        }
+        VecIO<T, VEC>::store(dxb + i * VEC, acc);
     }
 }
 
@@ -661,8 +677,16 @@ static bool use_padout(const ConvK& k, const passion_conv_desc_t* d) {
     if (d->stride == 2 && ((k.Di | k.Hi | k.Wi) & 1)) return false;      // even input sizes: Do = Di / 2 exactly
     bool any = false;
     for (int s = 0; s < k.nseg; ++s)
-        if (k.seg[s].dx) any = true;
+        if (k.seg[s].dx) { any = true; if (k.seg[s].bmod > 0) return false; }    // batched passes: summed by the plain finish kernel
     return any;
+}
+// per-pass gradients of the batched-pass segments (SegD.bmod): [B virtual][V][C] each, summed over the passes by the finish
+static long pass_scratch_floats(const ConvK& k, const passion_conv_desc_t* d) {
+    const long es = d->x_dtype == PASSION_BF16 ? 2 : 4;
+    long bytes = 0;
+    for (int s = 0; s < k.nseg; ++s)
+        if (k.seg[s].dx && k.seg[s].bmod > 0) bytes += ((long)k.B * k.Di * k.Hi * k.Wi * k.seg[s].C * es + 15) / 16 * 16;
+    return bytes / 4;
 }
 static long padout_floats(const ConvK& k) {     // bf16 [B][D+2][H+2][W+2][Cin]
     return ((long)k.B * (k.Di + 2) * (k.Hi + 2) * (k.Wi + 2) * k.Cin + 1) / 2 + 4;
@@ -674,7 +698,7 @@ extern "C" int64_t passion_conv_bwd_scratch_floats(const passion_conv_desc_t* d)
     const WgPlan w = plan_wgrad(k, d);
     const int64_t nt = (int64_t)d->ksize * d->ksize * d->ksize;
     return (int64_t)2 * k.B * k.Cin * SUMS_REP + (int64_t)w.gx * ((int64_t)k.Cout * k.Cin * nt + k.Cout) +
-           (use_padout(k, d) ? padout_floats(k) : 0);
+           (use_padout(k, d) ? padout_floats(k) : 0) + pass_scratch_floats(k, d);
 }
 
 extern "C" int64_t passion_conv_pack_floats(int Cin, int Cout, int ksize) {
@@ -904,6 +928,22 @@ extern "C" int passion_conv3d_bwd(const passion_conv_desc_t* d, const float* pac
     const int mtiles = k.Mpad / 16;
     bool padout = use_padout(k, d);
     void* dxp = nullptr;
+    // batched-pass segments: the dgrad writes the per-pass gradients into scratch, the finish kernel sums them into dx
+    void* real_dx[PASSION_MAX_SEG] = {nullptr, nullptr, nullptr, nullptr};
+    {
+        const WgPlan w0 = plan_wgrad(k, d);
+        char* gp = reinterpret_cast<char*>(sums + (long)2 * k.B * k.Cin * SUMS_REP + (long)w0.gx * ((long)k.Cout * k.Cin * nt + k.Cout) +
+                                           (padout ? padout_floats(k) : 0));
+        const long es = d->x_dtype == PASSION_BF16 ? 2 : 4;
+        for (int s = 0; s < k.nseg; ++s) {
+            if (k.seg[s].dx && k.seg[s].bmod > 0) {
+                if ((long)(k.B / k.seg[s].bmod) * k.seg[s].C > FIN_TAB || k.B / k.seg[s].bmod > 16) return -1015;
+                real_dx[s] = k.seg[s].dx;
+                k.seg[s].dx = gp;
+                gp += ((long)k.B * k.Di * k.Hi * k.Wi * k.seg[s].C * es + 15) / 16 * 16;
+            }
+        }
+    }
     {
         ProfScope prof(2, conv_bytes(k, xs, ys) + (double)nt * k.Cin * k.Cout * 4,
                        2.0 * k.B * k.Do * k.Ho * k.Wo * (double)k.Cout * k.Cin * nt, st);
@@ -953,12 +993,15 @@ extern "C" int passion_conv3d_bwd(const passion_conv_desc_t* d, const float* pac
     const long V = (long)k.Di * k.Hi * k.Wi;
     for (int s = 0; s < k.nseg; ++s) {
         const SegD& sg = k.seg[s];
-        if (!sg.dx || (!sg.stats && !padout)) continue;
+        const bool sum_passes = real_dx[s] != nullptr;
+        if (!sg.dx || (!sg.stats && !padout && !sum_passes)) continue;
         if (sg.C > FIN_MAXC) return -1013;            // coefficient table of the finish kernels
         const bool v8 = d->x_dtype == PASSION_BF16 && sg.C % 8 == 0 && k.Cin % 8 == 0 && sg.cbase % 8 == 0;
         const long nvec = V * sg.C / (v8 ? 8 : 4);
-        dim3 grid((unsigned)hmin((nvec + 255) / 256, 2048), k.B);
+        const int passes = sum_passes ? k.B / sg.bmod : 1;
+        dim3 grid((unsigned)hmin((nvec + 255) / 256, 2048), sum_passes ? sg.bmod : k.B);
         const long rs = (long)2 * k.B * k.Cin;
+        void* out = sum_passes ? real_dx[s] : sg.dx;
         if (padout) {
             const int rowv = k.Wi * sg.C / (v8 ? 8 : 4);
             const int rpb = 256 / (rowv < 256 ? rowv : 256);
@@ -972,14 +1015,14 @@ extern "C" int passion_conv3d_bwd(const passion_conv_desc_t* d, const float* pac
                                    (const bf16_t*)dxp, sg.stats, sums, sg.mask, sg.mask_col, sg.mask_ld, k.Di, k.Hi, k.Wi, sg.C,
                                    sg.bstride, k.Cin, sg.cbase, sg.bmod, rep, rs);
         } else if (d->x_dtype == PASSION_F32)
-            hipLaunchKernelGGL((in_bwd_finish_kernel<float, 4>), grid, dim3(256), 0, st, (float*)sg.dx, (const float*)sg.x,
-                               sg.stats, sums, sg.mask, sg.mask_col, sg.mask_ld, V, sg.C, sg.bstride, k.Cin, sg.cbase, sg.bmod, rep, rs);
+            hipLaunchKernelGGL((in_bwd_finish_kernel<float, 4>), grid, dim3(256), 0, st, (const float*)sg.dx, (float*)out, (const float*)sg.x,
+                               sg.stats, sums, sg.mask, sg.mask_col, sg.mask_ld, V, sg.C, sg.bstride, k.Cin, sg.cbase, sg.bmod, passes, rep, rs);
         else if (v8)
-            hipLaunchKernelGGL((in_bwd_finish_kernel<bf16_t, 8>), grid, dim3(256), 0, st, (bf16_t*)sg.dx, (const bf16_t*)sg.x,
-                               sg.stats, sums, sg.mask, sg.mask_col, sg.mask_ld, V, sg.C, sg.bstride, k.Cin, sg.cbase, sg.bmod, rep, rs);
+            hipLaunchKernelGGL((in_bwd_finish_kernel<bf16_t, 8>), grid, dim3(256), 0, st, (const bf16_t*)sg.dx, (bf16_t*)out, (const bf16_t*)sg.x,
+                               sg.stats, sums, sg.mask, sg.mask_col, sg.mask_ld, V, sg.C, sg.bstride, k.Cin, sg.cbase, sg.bmod, passes, rep, rs);
         else
-            hipLaunchKernelGGL((in_bwd_finish_kernel<bf16_t, 4>), grid, dim3(256), 0, st, (bf16_t*)sg.dx, (const bf16_t*)sg.x,
-                               sg.stats, sums, sg.mask, sg.mask_col, sg.mask_ld, V, sg.C, sg.bstride, k.Cin, sg.cbase, sg.bmod, rep, rs);
+            hipLaunchKernelGGL((in_bwd_finish_kernel<bf16_t, 4>), grid, dim3(256), 0, st, (const bf16_t*)sg.dx, (bf16_t*)out, (const bf16_t*)sg.x,
+                               sg.stats, sums, sg.mask, sg.mask_col, sg.mask_ld, V, sg.C, sg.bstride, k.Cin, sg.cbase, sg.bmod, passes, rep, rs);
         LAUNCH_RET();
     }
     if (comp) HIP_RET(hipStreamWaitEvent(caller_st, comp->done, 0));     // join

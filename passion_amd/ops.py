@@ -195,8 +195,7 @@ class ConvBlockFn(torch.autograd.Function):
         for i, (s, x) in enumerate(zip(cfg.segs, xs)):
             if ctx.needs_input_grad[5 + i]:
                 assert s.offset == 0, "gradient wrt an offset view is not supported"
-                dxs.append(torch.empty((cfg.B,) + tuple(x.shape[1:]), dtype=x.dtype, device=dev) if s.bmod
-                           else torch.empty_like(x))
+                dxs.append(torch.empty_like(x))     # bmod segments: the library sums the passes into the physical samples
             else:
                 dxs.append(None)
         d = _fill_desc(cfg, xs, dxs)
@@ -204,9 +203,6 @@ class ConvBlockFn(torch.autograd.Function):
         sums = torch.empty(lib.passion_conv_bwd_scratch_floats(byref(d)), dtype=torch.float32, device=dev)
         L.check(lib.passion_conv3d_bwd(byref(d), _p(ctx.packed), _p(dy), _p(dW), _p(db), _p(sums),
                                        L.stream_ptr()), "passion_conv3d_bwd")
-        for i, s in enumerate(cfg.segs):   # P passes over the same samples: their input gradients add up
-            if s.bmod and dxs[i] is not None:
-                dxs[i] = dxs[i].view(cfg.B // s.bmod, *xs[i].shape).sum(0)
         dres = dy if (ctx.has_res and ctx.needs_input_grad[3]) else None
         return (None, dW, db, dres, None, *dxs)
 
