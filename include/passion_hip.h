@@ -213,6 +213,20 @@ int passion_adamw_step(int n, float* const* params, const float* const* grads, f
                        double beta1, double beta2, double eps, double weight_decay, int64_t step, int amsgrad,
                        void* stream);
 
+/* ---- training input pipeline on the GPU -------------------------------------------------
+ * One sample: crop [S0][S1][S2][C] f32 (the RandCrop3D window, code/data/transforms.py:217-230) and its labels
+ * seg [S0][S1][S2] int32  ->  x [C][S0][S1][S2] f32 and the one-hot target y_onehot [num_cls][S0][S1][S2] f64
+ * (datasets_nii.py:143-153; y_cl = the same as f32 channels-last, either may be NULL) after
+ * RandomRotion (transforms.py:86-120: scipy.ndimage.rotate order 0, cval -1, in the plane of sorted axes
+ * (rot_a0, rot_a1) of [H,W,D]; rot6 = HOST array {m00, m01, m10, m11, off0, off1} of scipy's affine map, NULL = none),
+ * seg_cval = label of a rotated-out voxel: scipy casts cval -1 to the label dtype (0 for the uint8 volumes of
+ * preprocess_brats.py:78, -1 = np.eye(4)[-1] = class 3 for signed types);
+ * RandomIntensityChange (:233-250: x * scale[h][c] + shift[h][c], device arrays [S0][C] f64) and RandomFlip (:133-155). */
+int passion_augment(const float* crop, const int32_t* seg, int S0, int S1, int S2, int C, int num_cls,
+                    int rot_a0, int rot_a1, const double* rot6, int seg_cval, int flip0, int flip1, int flip2,
+                    const double* scale, const double* shift, float* x, double* y_onehot, float* y_cl,
+                    void* stream);
+
 /* ---- in-library kernel timing (bench.py roofline leg) ------------------------------------------
  * passion_prof_enable(mask): bit k of `mask` selects launches of kind k; selected conv3d launches are
  * bracketed by hipEvents on their own stream and their algorithmic bytes / flops recorded.  passion_prof_read drains up to `cap` records:

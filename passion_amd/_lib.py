@@ -96,6 +96,8 @@ SIGNATURES = {
                                        c_int64, c_int, c_int, c_void_p]),
     "passion_region_mix_bwd": (c_int, [POINTER(c_void_p), POINTER(c_void_p), c_void_p, c_int, c_void_p, c_void_p,
                                        c_void_p, c_int, c_int, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "passion_augment": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int,
+                                c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "passion_adamw_step": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_double, c_double,
                                    c_double, c_double, c_double, c_int64, c_int, c_void_p]),
     "passion_set_option": (c_int, [c_char_p, c_int]),

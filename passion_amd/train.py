@@ -123,8 +123,8 @@ MASK_TABLE = [[True, False, False, False], [False, True, False, False], [False, 
 
 
 def main(argv=None):
-    """python -m passion_amd.train --synthetic --use_passion --patch 128 --dtype bf16 ...  (under torchrun
-    for several GPUs).  Real-data loading (code/data/*) is out of this round's scope."""
+    """python -m passion_amd.train [--synthetic] --use_passion --patch 128 --dtype bf16 ...  (under torchrun for several
+    GPUs).  Without --synthetic the npy dataset of the reference is read through passion_amd.data (GPU input pipeline)."""
     from . import parallel
     from .models import mmformer
     from .options import args_parser
@@ -145,9 +145,20 @@ def main(argv=None):
     reducer = parallel.GradReducer(model, ctx)
     optimizer = make_optimizer(model, args.lr, args.weight_decay)
     state = LossState(ctx.device)
-    if not args.synthetic:
-        raise SystemExit("only --synthetic input is wired in this round (dataset loader: SURVEY 8f N3)")
-    iters = args.iters_per_epoch or 10
+    data = None
+    if not args.synthetic:      # the reference's npy dataset through the GPU input pipeline (train.py:112-131)
+        from .data.datasets_nii import Brats_loadall_train_nii_idt
+        csv = os.path.join(args.datarootPath, args.imbmrpath)
+        data = Brats_loadall_train_nii_idt(transforms=args.train_transforms, root=args.datasetPath, num_cls=4,
+                                           mask_type=args.mask_type, train_file=csv, device=ctx.device)
+        order = np.random.RandomState(args.seed).permutation(len(data))[ctx.rank::ctx.world]     # each rank its own subjects
+    iters = args.iters_per_epoch or (10 if data is None else max(1, len(order) // args.batch_size))
+    modal_num = None
+    if data is not None:        # initial imbalance weights (train.py:163-171): iterations per epoch / subjects that have the modality
+        modal_num = torch.zeros(4, device=ctx.device)
+        for sample_mask in data.samples_masks:
+            modal_num += torch.tensor(eval(sample_mask), dtype=torch.float32, device=ctx.device)
+        state.modal_weight = (len(data) // args.batch_size) / modal_num
     rng = np.random.RandomState(args.seed + ctx.rank)
     for epoch in range(args.num_epochs):
         lr = poly_lr(args.lr, epoch, args.num_epochs)
@@ -155,10 +166,16 @@ def main(argv=None):
             g_["lr"] = lr
         t0 = time.time()
         for it in range(iters):
-            mk = torch.tensor([MASK_TABLE[rng.randint(15)] for _ in range(args.batch_size)])
-            x, target, mk = synthetic_batch(args.batch_size, args.patch, ctx.device, seed=epoch * iters + it, mask=mk)
+            if data is None:
+                mk = torch.tensor([MASK_TABLE[rng.randint(15)] for _ in range(args.batch_size)])
+                x, target, mk = synthetic_batch(args.batch_size, args.patch, ctx.device, seed=epoch * iters + it, mask=mk)
+            else:
+                samples = [data[int(order[(it * args.batch_size + j) % len(order)])] for j in range(args.batch_size)]
+                x = torch.stack([s_[0] for s_ in samples])
+                target = torch.stack([s_[1] for s_ in samples])
+                mk = torch.stack([s_[2] for s_ in samples])
             loss = train_step(model, optimizer, x, mk, target, args.temp, state, reducer,
-                              warmup=epoch < args.region_fusion_start_epoch)
+                              warmup=epoch < args.region_fusion_start_epoch, modal_num=modal_num)
         torch.cuda.synchronize()
         if args.use_passion:
             state.end_epoch(epoch, epoch < args.region_fusion_start_epoch)

@@ -224,9 +224,45 @@ def rfnet_case(rfnet, criterions, tag, S, B, mask, mask_type, passion, blobs, te
     print("wrote rfnet", tag, rec["loss"])
 
 
+def aug_cases():
+    """input pipeline: the reference's own train transform chain (options.py:50) run on small synthetic
+    volumes under fixed seeds; stores inputs' seeds, the sampled parameters and the outputs
+    (x float32 (C,H,W,D), one-hot float64 (4,H,W,D) as datasets_nii.py:143-153 builds them)."""
+    import collections
+    import collections.abc
+    import random
+    collections.Sequence = collections.abc.Sequence          # transforms.py:28 predates python 3.10
+    sys.path.insert(0, REF)
+    from data import transforms as T
+    out = {}
+    for ci, (shape, size, seed) in enumerate([((40, 36, 30), (24, 24, 24), 3), ((33, 41, 37), (32, 24, 16), 11),
+                                              ((24, 24, 24), (24, 24, 24), 5), ((48, 40, 44), (16, 32, 24), 29)]):
+        rs = np.random.RandomState(1000 + seed)
+        vol = rs.randn(*shape, 4).astype(np.float32)
+        seg = rs.randint(0, 4, shape).astype(np.uint8)
+        random.seed(seed); np.random.seed(seed)
+        tf = T.Compose([T.RandCrop3D(size), T.RandomRotion(10), T.RandomIntensityChange((0.1, 0.1)), T.RandomFlip(0),
+                        T.NumpyType((np.float32, np.int64))])
+        x, y = tf([vol[None].copy(), seg[None].copy()])
+        x = np.ascontiguousarray(x.transpose(0, 4, 1, 2, 3))
+        _, H, W, Z = y.shape
+        yo = np.eye(4)[y.reshape(-1)].reshape(1, H, W, Z, -1)
+        yo = np.ascontiguousarray(yo.transpose(0, 4, 1, 2, 3))
+        out[f"c{ci}_shape"], out[f"c{ci}_size"], out[f"c{ci}_seed"] = np.array(shape), np.array(size), np.array(seed)
+        out[f"c{ci}_x"], out[f"c{ci}_label"] = x[0], yo[0].argmax(0).astype(np.uint8)
+        out[f"c{ci}_onehot_sum"] = yo[0].sum((1, 2, 3))
+        assert (np.eye(4)[out[f"c{ci}_label"]].transpose(3, 0, 1, 2) == yo[0]).all()
+    out["ncases"] = np.array(4)
+    np.savez_compressed(os.path.join(OUT, "augment.npz"), **out)
+    print("augment.npz written")
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
+    if len(sys.argv) > 1 and sys.argv[1] == "aug":        # only the input-pipeline fixtures
+        aug_cases()
+        return
     mmformer, criterions = import_reference()
     if len(sys.argv) > 1 and sys.argv[1] == "rfnet":      # only (re)generate the RFNet fixtures
         from models import rfnet
@@ -249,6 +285,7 @@ def main():
     rfnet_case(rfnet, criterions, "idt_passion_b2", 32, 2, [[1, 1, 1, 1], [0, 0, 1, 0]], "idt", True, True)
     rfnet_case(rfnet, criterions, "idt_plain_1111", 32, 1, [[1, 1, 1, 1]], "idt", False, False)
     rfnet_case(rfnet, criterions, "pdt_passion_1101", 32, 1, [[1, 1, 0, 1]], "pdt", True, True)
+    aug_cases()
 
 
 if __name__ == "__main__":
