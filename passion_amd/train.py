@@ -161,7 +161,7 @@ def main(argv=None):
         state.modal_weight = (len(data) // args.batch_size) / modal_num
     rng = np.random.RandomState(args.seed + ctx.rank)
     for epoch in range(args.num_epochs):
-        lr = poly_lr(args.lr, epoch, args.num_epochs)
+        lr = float(poly_lr(args.lr, epoch, args.num_epochs))     # python float: keeps the checkpoint weights_only-loadable
         for g_ in optimizer.param_groups:
             g_["lr"] = lr
         t0 = time.time()

@@ -129,3 +129,26 @@ def test_dataset_class_on_disk(tmp_path):
     random.seed(9); np.random.seed(9)
     xr, yr = R.apply(vol, seg, R.sample_params(vol.shape[:3], (32, 32, 32)))
     assert np.array_equal(x.cpu().numpy(), xr) and np.array_equal(yo.cpu().numpy(), yr)
+
+
+@pytest.mark.gpu
+def test_train_main_reads_npy_dataset(tmp_path):
+    """python -m passion_amd.train without --synthetic: one short epoch from an on-disk dataset in the reference's format"""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from passion_amd import train as ptrain
+    root = tmp_path / "data"
+    (root / "vol").mkdir(parents=True); (root / "seg").mkdir()
+    rows = []
+    for i in range(2):
+        vol, seg = _inputs((40, 40, 40), 70 + i)
+        n = f"BraTS20_{i:03d}"
+        np.save(root / "vol" / f"{n}_vol.npy", vol); np.save(root / "seg" / f"{n}_seg.npy", seg)
+        rows.append(f"{n},{[14, 6][i]},\"[True, True, True, True]\",\"[14]\"" if i == 0 else f"{n},6,\"[True, False, True, False]\",\"[6]\"")
+    csv = tmp_path / "split.csv"
+    csv.write_text("data_name,mask_id,mask,pos_mask_ids\n" + "\n".join(rows) + "\n")
+    out = tmp_path / "out"
+    ptrain.main(["--model", "mmformer", "--use_passion", "--num_epochs", "1", "--patch", "32", "--dtype", "bf16",
+                 "--datapath", str(root), "--imbmrpath", str(csv), "--savepath", str(out)])
+    ck = torch.load(out / "model_last.pth", map_location="cpu")
+    assert ck["epoch"] == 0 and any(k.startswith("module.") for k in ck["state_dict"])
