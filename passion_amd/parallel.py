@@ -31,15 +31,18 @@ def init(backend=None):
     local = int(os.environ.get("LOCAL_RANK", "0"))
     use_gpu = torch.cuda.is_available()
     if use_gpu:
-        torch.cuda.set_device(local)
-        device = torch.device("cuda", local)
+        # PASSION_DEVICE_INDEX: rehearsal of the N > 1 path on a box with fewer GPUs than ranks (every rank on that
+        # device; RCCL refuses two ranks per GPU, so combine with PASSION_DIST_BACKEND=gloo)
+        local_dev = int(os.environ.get("PASSION_DEVICE_INDEX", local))
+        torch.cuda.set_device(local_dev)
+        device = torch.device("cuda", local_dev)
     else:
         device = torch.device("cpu")
-    backend = backend or ("nccl" if use_gpu else "gloo")
+    backend = backend or os.environ.get("PASSION_DIST_BACKEND") or ("nccl" if use_gpu else "gloo")
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        if use_gpu:
+        if use_gpu and backend == "nccl":
             dist.init_process_group(backend, rank=rank, world_size=world, device_id=device)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
@@ -53,7 +56,13 @@ class GradReducer:
     has been written during backward the bucket is packed and its all_reduce is issued (async, RCCL's own stream), so
     the collectives of the late layers run under the backward kernels of the early ones.  all_reduce_grads() then only
     launches the buckets that never completed (parameters without gradient in this step), waits and unpacks.
-    Buckets are filled in reverse registration order ~ the order in which backward produces gradients."""
+    Buckets are filled in reverse registration order ~ the order in which backward produces gradients.
+
+    Streams: the models run their modality encoders on side streams and autograd replays each backward node on its
+    forward's stream, so the gradients of one bucket may be written on several streams while the hook that completes the
+    bucket runs on only one of them.  Every hook notes the stream it ran on; the launch makes its own stream wait for an
+    event recorded on each of the others (all their gradient kernels are already enqueued by then, hooks fire in host
+    order) before it packs the bucket."""
 
     def __init__(self, model, ctx, bucket_mb=32, overlap=True):
         self.ctx = ctx
@@ -73,6 +82,8 @@ class GradReducer:
         self.overlap = overlap and ctx.world > 1 and hasattr(torch.Tensor, "register_post_accumulate_grad_hook")
         self._pending = [len(b) for b in self.buckets]       # gradients still missing per bucket in this backward
         self._works = [None] * len(self.buckets)
+        self._streams = [set() for _ in self.buckets]        # streams that produced gradients of the bucket in this backward
+        self._on_gpu = self.params[0].is_cuda
         if ctx.world > 1:
             for p in model.parameters():
                 dist.broadcast(p.data, src=0)
@@ -83,6 +94,8 @@ class GradReducer:
 
     def _make_hook(self, bi):
         def hook(_param):
+            if self._on_gpu:
+                self._streams[bi].add(torch.cuda.current_stream())
             self._pending[bi] -= 1
             if self._pending[bi] == 0:
                 self._launch(bi)
@@ -90,6 +103,14 @@ class GradReducer:
 
     def _launch(self, bi):
         bucket, flat = self.buckets[bi], self.flat[bi]
+        if self._on_gpu:
+            cur = torch.cuda.current_stream()
+            for st in self._streams[bi]:
+                if st != cur:
+                    ev = torch.cuda.Event()
+                    ev.record(st)
+                    cur.wait_event(ev)
+            self._streams[bi].clear()
         grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in bucket]
         torch._foreach_copy_(list(flat.split([g.numel() for g in grads])), [g.reshape(-1) for g in grads])
         self._works[bi] = dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True)

@@ -1,0 +1,92 @@
+"""GPU, world_size 2: the product models under passion_amd.parallel.GradReducer with the overlapped bucket launches.  The
+box has ONE GPU and RCCL refuses two ranks per device, so the two ranks share cuda:0 and talk over gloo
+(PASSION_DEVICE_INDEX / PASSION_DIST_BACKEND): what is covered is everything above the transport -- hooks firing on the
+encoders' side streams, bucket packing across streams, unpacking into .grad -- against the sum of the two ranks' gradients
+computed one after the other in a single process (DataParallel semantics of the reference, train.py:90,229-231)."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _model(dev):
+    from passion_amd.models import mmformer
+    old = (mmformer.basic_dims, mmformer.patch_size)
+    mmformer.basic_dims, mmformer.patch_size = 8, 2
+    try:
+        torch.manual_seed(5)
+        m = mmformer.Model(num_cls=4).to(dev)
+    finally:
+        mmformer.basic_dims, mmformer.patch_size = old
+    # f32 arithmetic: run-to-run noise of the gradients is ~4e-6 (order of the f32 atomics); in bf16 one flipped rounding
+    # of a dx voxel moves transformer gradients by percents between two runs of the SAME process, which would hide a race
+    m.mask_type, m.use_passion, m.compute_dtype = "idt", True, torch.float32
+    m.eval()                     # dropout off: the comparison run must see the same network
+    return m
+
+
+def _grads(m, rank, dev):
+    from passion_amd import train as ptrain
+    x, target, mask = ptrain.synthetic_batch(1, 32, dev, seed=7 + rank)
+    m.is_training = True
+    outs = m(x, mask, target=target, temp=4.0)
+    loss = ptrain.assemble_loss(outs, target, mask, "idt", True)
+    for p in m.parameters():
+        p.grad = None
+    loss.backward()
+    return loss
+
+
+def _worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port), PASSION_DEVICE_INDEX="0", PASSION_DIST_BACKEND="gloo")
+    from passion_amd import parallel
+    ctx = parallel.init()
+    m = _model(ctx.device)
+    red = parallel.GradReducer(m, ctx, bucket_mb=1)      # small buckets: many launches from inside backward
+    for _ in range(2):                                   # second round: the per-step bookkeeping was reset
+        _grads(m, rank, ctx.device)
+        red.all_reduce_grads()
+    torch.cuda.synchronize()
+    if rank == 0:
+        torch.save({"g": {k: p.grad.cpu() for k, p in m.named_parameters() if p.grad is not None},
+                    "nb": len(red.buckets), "overlap": red.overlap}, out)
+    parallel.barrier(ctx)
+    torch.distributed.destroy_process_group()
+
+
+def test_two_ranks_sum_gradients_across_side_streams(tmp_path):
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    out = str(tmp_path / "r0.pt")
+    mp.spawn(_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    got = torch.load(out)
+    assert got["overlap"] and got["nb"] >= 3
+    dev = torch.device("cuda:0")
+    m = _model(dev)
+    want = {}
+    for rank in range(2):
+        _grads(m, rank, dev)
+        for k, p in m.named_parameters():
+            if p.grad is not None:
+                want[k] = want.get(k, 0) + p.grad.detach().float().cpu()
+    assert set(want) == set(got["g"])
+    for k, w in want.items():
+        g = got["g"][k].float()
+        tol = 2e-4 * float(w.abs().max()) + 1e-6        # f32 atomics order differs from run to run
+        assert float((g - w).abs().max()) <= tol, (k, float((g - w).abs().max()), tol)
