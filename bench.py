@@ -162,10 +162,13 @@ def main():
         loss = step()
         if os.environ.get("BENCH_DEBUG"):
             print(f"[bench] loss {float(loss):.5f}", file=sys.stderr)
+    t_host = time.perf_counter() - t0                # all K steps enqueued; the GPU may still be working
     torch.cuda.synchronize()
     parallel.barrier(ctx)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    if os.environ.get("BENCH_HOST") and ctx.rank == 0:
+        print(f"[bench] host enqueue {1e3 * t_host / args.steps:.2f} ms/step, wall {1e3 * dt / args.steps:.2f} ms/step", file=sys.stderr)
     ops.prof_enable(0)
     dt = parallel.all_reduce_max(ctx, dt)
     final_loss = float(loss)

@@ -138,6 +138,35 @@ def check(rc, what):
         raise PassionHipError(f"{what} failed with code {rc}")
 
 
+HOST_EXT_PATH = os.path.join(_HERE, "lib", "_passion_host.so")
+_host = None
+
+
+def host():
+    """The C++ host extension (csrc/host_ext.cpp: autograd nodes of the conv block and the InstanceNorm statistics), bound
+    to the entry points of the library load() returned.  PASSION_HOST_EXT=0 selects the Python autograd.Functions in ops.py
+    instead (same C ABI underneath; kept for A/B timing of the host path)."""
+    global _host
+    if _host is not None:
+        return _host or None
+    if os.environ.get("PASSION_HOST_EXT", "1") == "0":
+        _host = False
+        return None
+    lib = load()
+    if not os.path.exists(HOST_EXT_PATH):
+        raise PassionHipError(f"{HOST_EXT_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                              "or `make -C passion_amd/csrc`")
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("_passion_host", HOST_EXT_PATH)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    addr = lambda name: ctypes.cast(getattr(lib, name), c_void_p).value
+    mod.bind(addr("passion_conv3d_fwd"), addr("passion_conv3d_bwd"), addr("passion_conv_bwd_scratch_floats"),
+             addr("passion_instnorm_stats"), addr("passion_instnorm_scratch_doubles"))
+    _host = mod
+    return mod
+
+
 def dtype_code(t):
     import torch
     if t == torch.float32:
@@ -154,6 +183,14 @@ def require_gpu(*tensors):
                                   f"{t.device} tensor")
 
 
+_raw_stream = _cur_dev = None
+
+
 def stream_ptr():
-    import torch
-    return c_void_p(torch.cuda.current_stream().cuda_stream)
+    """raw hipStream_t of torch's current stream.  (torch.cuda.current_stream() builds a Stream object through several
+    Python layers: 10 us a call, 250 calls a step -- the step is host-bound, so that was 10 % of it.)"""
+    global _raw_stream, _cur_dev
+    if _raw_stream is None:
+        import torch
+        _raw_stream, _cur_dev = torch._C._cuda_getCurrentRawStream, torch._C._cuda_getDevice
+    return c_void_p(_raw_stream(_cur_dev()))

@@ -1,0 +1,217 @@
+// Host side of the two hottest ops as C++ autograd nodes: the fused conv block (forward + backward) and the
+// InstanceNorm statistics.  A training step issues ~110 conv blocks and ~95 statistics calls in each direction; as Python
+// autograd.Functions over ctypes the step was HOST-bound on MI355X (19 ms of interpreter + binding time against < 19 ms of
+// kernels): descriptor filling, output / scratch allocation and the backward nodes (which the autograd engine otherwise
+// runs under the GIL) live here instead.  The kernels are reached through the same C ABI as everything else
+// (include/passion_hip.h); the entry points are handed over as addresses by passion_amd/_lib.py (bind()), so the library
+// that ctypes loaded -- and nothing else -- is what runs.
+//
+// Mirrors passion_amd/ops.py: ConvBlockFn (reference general_conv3d_prenorm, code/models/blocks.py:300-316) and
+// instnorm_stats (nn.InstanceNorm3d statistics, blocks.py:18).
+#include <torch/extension.h>
+#include <c10/hip/HIPStream.h>
+
+#include "passion_hip.h"
+
+namespace {
+
+using torch::autograd::AutogradContext;
+using torch::autograd::variable_list;
+using OptT = std::optional<at::Tensor>;
+
+struct Abi {
+    decltype(&passion_conv3d_fwd) conv_fwd = nullptr;
+    decltype(&passion_conv3d_bwd) conv_bwd = nullptr;
+    decltype(&passion_conv_bwd_scratch_floats) conv_bwd_scratch = nullptr;
+    decltype(&passion_instnorm_stats) stats = nullptr;
+    decltype(&passion_instnorm_scratch_doubles) stats_scratch = nullptr;
+} g;
+
+inline void* cur_stream() { return reinterpret_cast<void*>(c10::hip::getCurrentHIPStream().stream()); }
+
+inline int dtype_code(at::ScalarType t) {
+    if (t == at::kFloat) return PASSION_F32;
+    if (t == at::kBFloat16) return PASSION_BF16;
+    TORCH_CHECK(false, "passion_amd: unsupported activation dtype ", t);
+}
+
+inline void check(int rc, const char* what) { TORCH_CHECK(rc == 0, what, " failed with code ", rc); }
+
+inline void need_gpu(const at::Tensor& t) {
+    TORCH_CHECK(t.is_cuda(), "passion_amd kernels need GPU tensors (no CPU fallback); got a ", t.device(), " tensor");
+}
+
+// per segment: C, offset (elements), bstride (elements), bmod, mask_col
+constexpr int SEG_INTS = 5;
+// geo: B, D, H, W, ksize, stride, pad_mode, out dtype code
+constexpr int GEO_INTS = 8;
+
+struct ConvCfg {
+    std::vector<int64_t> geo, seg;
+    double slope;
+    std::vector<OptT> stats, masks;
+    at::Tensor packed;
+    OptT out;
+};
+
+void fill_desc(passion_conv_desc_t& d, const std::vector<int64_t>& geo, const std::vector<int64_t>& seg, double slope,
+               const std::vector<OptT>& stats, const std::vector<OptT>& masks, at::TensorList xs, const std::vector<at::Tensor>* dxs,
+               int64_t Cout) {
+    const int n = (int)xs.size();
+    TORCH_CHECK(n >= 1 && n <= PASSION_MAX_SEG && (int)seg.size() == n * SEG_INTS && (int)geo.size() == GEO_INTS, "conv descriptor");
+    d.x_dtype = xs[0].scalar_type() == at::kDouble ? PASSION_F32 : dtype_code(xs[0].scalar_type());
+    d.y_dtype = (int)geo[7];
+    d.B = (int)geo[0]; d.D = (int)geo[1]; d.H = (int)geo[2]; d.W = (int)geo[3];
+    d.ksize = (int)geo[4]; d.stride = (int)geo[5]; d.pad_mode = (int)geo[6];
+    d.nseg = n;
+    d.Cout = (int)Cout;
+    d.lrelu_slope = (float)slope;
+    for (int i = 0; i < n; ++i) {
+        passion_seg_t& sg = d.seg[i];
+        const at::Tensor& x = xs[i];
+        sg.x = static_cast<const char*>(x.data_ptr()) + seg[i * SEG_INTS + 1] * x.element_size();
+        sg.stats = stats[i] ? stats[i]->data_ptr<float>() : nullptr;
+        sg.mask = masks[i] ? static_cast<const uint8_t*>(masks[i]->data_ptr()) : nullptr;
+        sg.mask_col = (int)seg[i * SEG_INTS + 4];
+        sg.mask_ld = masks[i] ? (int)masks[i]->size(1) : 0;
+        sg.C = (int)seg[i * SEG_INTS + 0];
+        sg.bstride = seg[i * SEG_INTS + 2];
+        sg.bmod = (int)seg[i * SEG_INTS + 3];
+        sg.dx = (dxs && (*dxs)[i].defined()) ? (*dxs)[i].data_ptr() : nullptr;
+    }
+}
+
+c10::List<OptT> to_list(const std::vector<OptT>& v) {
+    c10::List<OptT> l;
+    for (const auto& t : v) l.push_back(t);
+    return l;
+}
+std::vector<OptT> from_list(const c10::IValue& iv) {
+    std::vector<OptT> v;
+    for (const c10::IValue& e : iv.toListRef()) v.push_back(e.isNone() ? OptT() : OptT(e.toTensor()));
+    return v;
+}
+
+struct ConvBlockNode : public torch::autograd::Function<ConvBlockNode> {
+    static at::Tensor forward(AutogradContext* ctx, const at::Tensor& weight, const OptT& bias, const OptT& residual,
+                              at::TensorList xs, ConvCfg cfg) {
+        need_gpu(weight);
+        for (const at::Tensor& x : xs) need_gpu(x);
+        const int64_t Cout = weight.size(0), ks = cfg.geo[4], stride = cfg.geo[5], pad = ks / 2;
+        const int64_t B = cfg.geo[0];
+        const int64_t Do = (cfg.geo[1] + 2 * pad - ks) / stride + 1, Ho = (cfg.geo[2] + 2 * pad - ks) / stride + 1,
+                      Wo = (cfg.geo[3] + 2 * pad - ks) / stride + 1;
+        const at::ScalarType odt = cfg.geo[7] == PASSION_BF16 ? at::kBFloat16 : at::kFloat;
+        at::Tensor y = cfg.out ? *cfg.out : at::empty({B, Do, Ho, Wo, Cout}, weight.options().dtype(odt));
+        TORCH_CHECK(y.sizes() == at::IntArrayRef({B, Do, Ho, Wo, Cout}) && y.scalar_type() == odt && y.is_contiguous(),
+                    "conv_block: `out` has the wrong shape / dtype / layout");
+        if (residual)
+            TORCH_CHECK(residual->sizes() == y.sizes() && residual->scalar_type() == odt && residual->is_contiguous(), "conv_block: residual");
+        if (bias) TORCH_CHECK(bias->scalar_type() == at::kFloat && bias->is_contiguous(), "conv_block: bias must be f32");
+        passion_conv_desc_t d;
+        fill_desc(d, cfg.geo, cfg.seg, cfg.slope, cfg.stats, cfg.masks, xs, nullptr, Cout);
+        check(g.conv_fwd(&d, cfg.packed.data_ptr<float>(), bias ? bias->data_ptr<float>() : nullptr,
+                         residual ? residual->data_ptr() : nullptr, y.data_ptr(), cur_stream()),
+              "passion_conv3d_fwd");
+        ctx->save_for_backward(xs.vec());
+        ctx->saved_data["geo"] = cfg.geo;
+        ctx->saved_data["seg"] = cfg.seg;
+        ctx->saved_data["slope"] = cfg.slope;
+        ctx->saved_data["stats"] = to_list(cfg.stats);
+        ctx->saved_data["masks"] = to_list(cfg.masks);
+        ctx->saved_data["packed"] = cfg.packed;
+        ctx->saved_data["wshape"] = weight.sizes().vec();
+        ctx->saved_data["flags"] = std::vector<int64_t>{bias.has_value(), residual.has_value()};
+        return y;
+    }
+
+    static variable_list backward(AutogradContext* ctx, variable_list grads) {
+        const variable_list xs = ctx->get_saved_variables();
+        const int n = (int)xs.size();
+        const std::vector<int64_t> geo = ctx->saved_data["geo"].toIntVector(), seg = ctx->saved_data["seg"].toIntVector(),
+                                   wshape = ctx->saved_data["wshape"].toIntVector(), flags = ctx->saved_data["flags"].toIntVector();
+        const std::vector<OptT> stats = from_list(ctx->saved_data["stats"]), masks = from_list(ctx->saved_data["masks"]);
+        const at::Tensor packed = ctx->saved_data["packed"].toTensor();
+        const bool has_bias = flags[0] != 0, has_res = flags[1] != 0;
+        // autograd edges exist for the tensor arguments only: weight, [bias], [residual], xs...
+        size_t e = 0;
+        const bool need_w = ctx->needs_input_grad(e++);
+        const bool need_b = has_bias && ctx->needs_input_grad(e);
+        if (has_bias) ++e;
+        const bool need_res = has_res && ctx->needs_input_grad(e);
+        if (has_res) ++e;
+        const at::Tensor dy = grads[0].contiguous();
+        const auto f32 = dy.options().dtype(at::kFloat);
+        at::Tensor dW, db;
+        int64_t nW = 1;
+        for (int64_t s : wshape) nW *= s;
+        if (need_w && need_b) {      // one buffer [dW | db]: the library folds both partial slabs in one launch
+            at::Tensor buf = at::empty({nW + wshape[0]}, f32);
+            dW = buf.narrow(0, 0, nW).view(wshape);
+            db = buf.narrow(0, nW, wshape[0]);
+        } else if (need_w) {
+            dW = at::empty(wshape, f32);
+        } else if (need_b) {
+            db = at::empty({wshape[0]}, f32);
+        }
+        std::vector<at::Tensor> dxs(n);
+        for (int i = 0; i < n; ++i) {
+            if (ctx->needs_input_grad(e + i)) {
+                TORCH_CHECK(seg[i * SEG_INTS + 1] == 0, "gradient wrt an offset view is not supported");
+                dxs[i] = at::empty_like(xs[i]);      // bmod segments: the library sums the passes into the physical samples
+            }
+        }
+        passion_conv_desc_t d;
+        fill_desc(d, geo, seg, ctx->saved_data["slope"].toDouble(), stats, masks, xs, &dxs, wshape[0]);
+        at::Tensor scratch = at::empty({g.conv_bwd_scratch(&d)}, f32);
+        check(g.conv_bwd(&d, packed.data_ptr<float>(), dy.data_ptr(), dW.defined() ? dW.data_ptr<float>() : nullptr,
+                         db.defined() ? db.data_ptr<float>() : nullptr, scratch.data_ptr<float>(), cur_stream()),
+              "passion_conv3d_bwd");
+        variable_list out;
+        out.reserve(4 + n);
+        out.push_back(dW);
+        out.push_back(db);
+        out.push_back(need_res ? dy : at::Tensor());
+        for (int i = 0; i < n; ++i) out.push_back(dxs[i]);
+        out.push_back(at::Tensor());     // cfg
+        return out;
+    }
+};
+
+at::Tensor conv_block(const at::Tensor& weight, const OptT& bias, const OptT& residual, const std::vector<at::Tensor>& xs,
+                      std::vector<OptT> stats, std::vector<OptT> masks, std::vector<int64_t> seg, std::vector<int64_t> geo,
+                      double slope, const at::Tensor& packed, const OptT& out) {
+    TORCH_CHECK(g.conv_fwd, "passion_amd host extension is not bound to libpassion_hip.so");
+    ConvCfg cfg{std::move(geo), std::move(seg), slope, std::move(stats), std::move(masks), packed, out};
+    return ConvBlockNode::apply(weight, bias, residual, at::TensorList(xs), std::move(cfg));
+}
+
+at::Tensor instnorm_stats(const at::Tensor& x, double eps, const OptT& out) {
+    TORCH_CHECK(g.stats, "passion_amd host extension is not bound to libpassion_hip.so");
+    need_gpu(x);
+    TORCH_CHECK(x.dim() == 5 && x.is_contiguous(), "instnorm_stats: channels-last (B,D,H,W,C) contiguous tensor expected");
+    const int64_t B = x.size(0), V = x.size(1) * x.size(2) * x.size(3), C = x.size(4);
+    at::Tensor scratch = at::empty({g.stats_scratch((int)B, V, (int)C)}, x.options().dtype(at::kDouble));
+    at::Tensor stats = out ? *out : at::empty({B, C, 2}, x.options().dtype(at::kFloat));
+    TORCH_CHECK(stats.sizes() == at::IntArrayRef({B, C, 2}) && stats.is_contiguous() && stats.scalar_type() == at::kFloat, "instnorm_stats: out");
+    check(g.stats(x.data_ptr(), dtype_code(x.scalar_type()), (int)B, V, (int)C, V * C, (float)eps, scratch.data_ptr<double>(),
+                  stats.data_ptr<float>(), cur_stream()),
+          "passion_instnorm_stats");
+    return stats;
+}
+
+void bind(uint64_t conv_fwd, uint64_t conv_bwd, uint64_t conv_bwd_scratch, uint64_t stats, uint64_t stats_scratch) {
+    g.conv_fwd = reinterpret_cast<decltype(g.conv_fwd)>(conv_fwd);
+    g.conv_bwd = reinterpret_cast<decltype(g.conv_bwd)>(conv_bwd);
+    g.conv_bwd_scratch = reinterpret_cast<decltype(g.conv_bwd_scratch)>(conv_bwd_scratch);
+    g.stats = reinterpret_cast<decltype(g.stats)>(stats);
+    g.stats_scratch = reinterpret_cast<decltype(g.stats_scratch)>(stats_scratch);
+}
+
+}  // namespace
+
+PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
+    m.def("bind", &bind, "addresses of the C-ABI entry points (from the ctypes handle of libpassion_hip.so)");
+    m.def("conv_block", &conv_block);
+    m.def("instnorm_stats", &instnorm_stats);
+}

@@ -26,6 +26,9 @@ def instnorm_stats(x, eps=1e-5, out=None):
     """(mean, rstd) per (b, c) of a channels-last (B,D,H,W,C) tensor -> f32 (B, C, 2).
     Statistics half of nn.InstanceNorm3d (reference blocks.py:18); not differentiated directly:
     the conv block's backward carries the InstanceNorm gradient analytically."""
+    h = L.host()
+    if h is not None:
+        return h.instnorm_stats(x, eps, out)
     L.require_gpu(x)
     assert x.dim() == 5 and x.is_contiguous()
     B, D, H, W, C = x.shape
@@ -219,6 +222,13 @@ def conv_block(segs, weight, bias, D, H, W, ksize=3, stride=1, pad_mode=L.PAD_RE
     x0 = segs[0].x
     cfg.out_dtype = out_dtype if out_dtype is not None else (x0.dtype if x0.dtype != torch.float64 else torch.float32)
     packed = pack_weight(weight, pack_cache)
+    h = L.host()
+    if h is not None:            # C++ autograd node (csrc/host_ext.cpp): same descriptor, same C-ABI calls
+        seg_ints = []
+        for s in segs:
+            seg_ints += (s.C, s.offset, s.bstride, s.bmod, s.mask_col)
+        return h.conv_block(weight, bias, residual, [s.x for s in segs], [s.stats for s in segs], [s.mask for s in segs], seg_ints,
+                            (cfg.B, D, H, W, ksize, stride, pad_mode, L.dtype_code(cfg.out_dtype)), slope, packed, out)
     return ConvBlockFn.apply(cfg, weight, bias, residual, packed, *[s.x for s in segs])
 
 

@@ -15,6 +15,10 @@ import torch
 import torch.distributed as dist
 
 
+def _raw_stream():
+    return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
+
+
 @dataclass
 class Ctx:
     rank: int
@@ -95,7 +99,7 @@ class GradReducer:
     def _make_hook(self, bi):
         def hook(_param):
             if self._on_gpu:
-                self._streams[bi].add(torch.cuda.current_stream())
+                self._streams[bi].add(_raw_stream())     # raw handle: a Stream object costs 10 us to build, per parameter
             self._pending[bi] -= 1
             if self._pending[bi] == 0:
                 self._launch(bi)
@@ -105,10 +109,10 @@ class GradReducer:
         bucket, flat = self.buckets[bi], self.flat[bi]
         if self._on_gpu:
             cur = torch.cuda.current_stream()
-            for st in self._streams[bi]:
-                if st != cur:
+            for raw in self._streams[bi]:
+                if raw != cur.cuda_stream:
                     ev = torch.cuda.Event()
-                    ev.record(st)
+                    ev.record(torch.cuda.ExternalStream(raw))
                     cur.wait_event(ev)
             self._streams[bi].clear()
         grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in bucket]
