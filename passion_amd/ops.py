@@ -26,10 +26,10 @@ def instnorm_stats(x, eps=1e-5, out=None):
     """(mean, rstd) per (b, c) of a channels-last (B,D,H,W,C) tensor -> f32 (B, C, 2).
     Statistics half of nn.InstanceNorm3d (reference blocks.py:18); not differentiated directly:
     the conv block's backward carries the InstanceNorm gradient analytically."""
+    L.require_gpu(x)
     h = L.host()
     if h is not None:
         return h.instnorm_stats(x, eps, out)
-    L.require_gpu(x)
     assert x.dim() == 5 and x.is_contiguous()
     B, D, H, W, C = x.shape
     V = D * H * W
@@ -224,6 +224,7 @@ def conv_block(segs, weight, bias, D, H, W, ksize=3, stride=1, pad_mode=L.PAD_RE
     packed = pack_weight(weight, pack_cache)
     h = L.host()
     if h is not None:            # C++ autograd node (csrc/host_ext.cpp): same descriptor, same C-ABI calls
+        L.require_gpu(weight, x0)
         seg_ints = []
         for s in segs:
             seg_ints += (s.C, s.offset, s.bstride, s.bmod, s.mask_col)
