@@ -120,7 +120,7 @@ __attribute__((constructor)) static void passion_read_env() {
     e = getenv("PASSION_WGRAD_FORK");
     if (e && e[0] == '1') pconv::g_wgrad_fork = 1;
     e = getenv("PASSION_CONV_PADOUT");
-    if (e && e[0] == '0') pconv::g_conv_padout = 0;
+    if (e) pconv::g_conv_padout = atoi(e);          // 0 never, 1 always, N > 1: only for volumes with depth < N
     e = getenv("PASSION_CONV_TARGET");
     if (e && atoi(e) > 0) pconv::g_conv_target = atoi(e);
     e = getenv("PASSION_WGRAD_WIDE");

@@ -672,6 +672,7 @@ namespace pconv { int g_conv_padout = 1; }   // PASSION_CONV_PADOUT=0: reflect a
 static bool use_padout(const ConvK& k, const passion_conv_desc_t* d) {
     if (!pconv::g_conv_lean || !pconv::g_conv_padout || g_passion_force_f32_mfma) return false;
     if (d->ksize != 3 || d->pad_mode != PASSION_PAD_REFLECT) return false;
+    if (pconv::g_conv_padout > 1 && k.Di >= pconv::g_conv_padout) return false;
     if (d->x_dtype != PASSION_BF16 || d->y_dtype != PASSION_BF16) return false;
     if (k.Di < 2 || k.Hi < 2 || k.Wi < 2 || k.Cin % 4 || !pconv::lean_covers(k, d->stride, true)) return false;
     if (d->stride == 2 && ((k.Di | k.Hi | k.Wi) & 1)) return false;      // even input sizes: Do = Di / 2 exactly

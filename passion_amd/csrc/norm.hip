@@ -97,6 +97,67 @@ __global__ __launch_bounds__(256) void stats_finalize_kernel(const double* __res
     }
 }
 
+// Small tensors (the deep levels: 8^3 ... 32^3): every conv there is a short dependent chain conv -> partial -> finalize
+// -> conv of launches that are pure latency, so the statistics take ONE launch: a block owns `cvb` channel vectors of one
+// sample over all voxels -- nothing to combine across blocks, the block finalises its own channels.
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void stats_small_kernel(const T* __restrict__ x, long V, int C, long bstride, int cvb, float eps,
+                                                          float* __restrict__ stats) {
+    __shared__ float red[256 * 2 * VEC];
+    const int b = blockIdx.y, tid = threadIdx.x;
+    const int cvn = C / VEC;                 // channel vectors per voxel
+    const int j = tid % cvb, lane = tid / cvb, nlane = 256 / cvb;      // cvb is a power of two <= 64
+    const int cv = blockIdx.x * cvb + j;
+    const T* xb = x + (long)b * bstride + (long)cv * VEC;
+    float s[VEC], q[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) { s[i] = 0.f; q[i] = 0.f; }
+    long v = lane;
+    for (; v + 3 * nlane < V; v += 4 * nlane) {          // four independent vector loads in flight
+        float v0[VEC], v1[VEC], v2[VEC], v3[VEC];
+        VecIO<T, VEC>::load(xb + v * C, v0); VecIO<T, VEC>::load(xb + (v + nlane) * C, v1);
+        VecIO<T, VEC>::load(xb + (v + 2 * nlane) * C, v2); VecIO<T, VEC>::load(xb + (v + 3 * nlane) * C, v3);
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+            s[i] += (v0[i] + v1[i]) + (v2[i] + v3[i]);
+            q[i] += (v0[i] * v0[i] + v1[i] * v1[i]) + (v2[i] * v2[i] + v3[i] * v3[i]);
+        }
+    }
+    for (; v < V; v += nlane) {
+        float t[VEC];
+        VecIO<T, VEC>::load(xb + v * C, t);
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) { s[i] += t[i]; q[i] += t[i] * t[i]; }
+    }
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) { red[tid * 2 * VEC + i] = s[i]; red[tid * 2 * VEC + VEC + i] = q[i]; }
+    __syncthreads();
+    // thread (j, i): channel i of vector j, summed over the nlane voxel lanes in a fixed order, in double
+    for (int o = tid; o < cvb * VEC; o += 256) {
+        const int jj = o / VEC, i = o % VEC;
+        double ds = 0, dq = 0;
+        for (int l = 0; l < nlane; ++l) {
+            ds += (double)red[(l * cvb + jj) * 2 * VEC + i];
+            dq += (double)red[(l * cvb + jj) * 2 * VEC + VEC + i];
+        }
+        const double mean = ds / (double)V;
+        double var = dq / (double)V - mean * mean;
+        if (var < 0) var = 0;
+        const int c = (blockIdx.x * cvb + jj) * VEC + i;
+        stats[((long)b * C + c) * 2 + 0] = (float)mean;
+        stats[((long)b * C + c) * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+}
+
+// blocks per sample for the one-launch path (0: tensor too large, use partial + finalize)
+inline int small_blocks(long V, int cvn) {
+    const long vecs = V * cvn;
+    if (vecs > 4 * 32768) return 0;
+    int nb = 1;
+    while (nb < cvn && (vecs / nb > 32768 || cvn / nb > 64)) nb *= 2;
+    return (vecs / nb <= 32768 && cvn % nb == 0 && cvn / nb <= 64) ? nb : 0;
+}
+
 inline int stats_blocks(long V, int C) {
     const long nvec = V * (C / 4);
     long gx = (nvec + 256 * 16 - 1) / (256 * 16);
@@ -113,6 +174,22 @@ extern "C" int passion_instnorm_stats(const void* x, int dtype, int B, int64_t V
                                       double* scratch, float* stats, void* stream) {
     if (C % 4 || (256 % (C / 4)) != 0) return -1010;
     hipStream_t st = (hipStream_t)stream;
+    {
+        const bool v8 = dtype == PASSION_BF16 && C % 8 == 0 && bstride % 8 == 0;
+        const int cvn = C / (v8 ? 8 : 4);
+        const int nb = (dtype == PASSION_F32 || dtype == PASSION_BF16) ? small_blocks((long)V, cvn) : 0;
+        if (nb > 0) {
+            dim3 grid(nb, B);
+            if (dtype == PASSION_F32)
+                hipLaunchKernelGGL((stats_small_kernel<float, 4>), grid, dim3(256), 0, st, (const float*)x, (long)V, C, (long)bstride, cvn / nb, eps, stats);
+            else if (v8)
+                hipLaunchKernelGGL((stats_small_kernel<bf16_t, 8>), grid, dim3(256), 0, st, (const bf16_t*)x, (long)V, C, (long)bstride, cvn / nb, eps, stats);
+            else
+                hipLaunchKernelGGL((stats_small_kernel<bf16_t, 4>), grid, dim3(256), 0, st, (const bf16_t*)x, (long)V, C, (long)bstride, cvn / nb, eps, stats);
+            LAUNCH_RET();
+            return 0;
+        }
+    }
     const int gx = stats_blocks((long)V, C);
     dim3 grid(gx, B);
     if (dtype == PASSION_F32)

@@ -228,14 +228,19 @@ def test_conv_raw_input_segments():
     assert wd.grad is not None and torch.isfinite(wd.grad).all()
 
 
+# one-launch path (small tensors, 1..4 blocks per sample) and the partial + finalize path (large ones)
+@pytest.mark.parametrize("shape", [(2, 6, 10, 12, 16), (1, 8, 8, 8, 128), (2, 16, 16, 16, 64), (1, 32, 32, 32, 32), (1, 3, 5, 7, 4),
+                                   (1, 64, 64, 48, 16), (2, 40, 40, 40, 8), (1, 4, 4, 4, 512)])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-def test_instnorm_stats(dtype):
+def test_instnorm_stats(dtype, shape):
     from passion_amd import ops
     dev = _dev()
-    x = torch.randn(2, 6, 10, 12, 16, generator=torch.Generator().manual_seed(0)) * 3 + 5
+    C = shape[-1]
+    x = torch.randn(*shape, generator=torch.Generator().manual_seed(0)) * 3 + 5
+    x = x + 0.05 * torch.arange(C).float()   # channels differ: a channel mix-up cannot hide
     x = x.to(dtype)
     st = ops.instnorm_stats(x.to(dev)).cpu().double()
-    xf = x.double().reshape(2, -1, 16)
+    xf = x.double().reshape(shape[0], -1, C)
     mean, var = xf.mean(1), xf.var(1, unbiased=False)
     assert relerr(st[..., 0], mean) < 1e-5
     assert relerr(st[..., 1], 1 / torch.sqrt(var + 1e-5)) < 1e-5
