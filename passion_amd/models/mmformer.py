@@ -156,6 +156,15 @@ class Decoder_fuse(nn.Module):
         return logits, (preds[1], preds[2], preds[3], preds[4]), tuple(feats[i].t for i in (1, 2, 3, 4, 5))
 
 
+class Linear(nn.Linear):
+    """nn.Linear whose bf16 operand images are kept across calls (ops.bf16_param) when it runs under bf16 autocast"""
+
+    def forward(self, x):
+        if self.weight.is_cuda and torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") == torch.bfloat16:
+            return F.linear(x, ops.bf16_param(self.weight), ops.bf16_param(self.bias) if self.bias is not None else None)
+        return F.linear(x, self.weight, self.bias)
+
+
 class SelfAttention(nn.Module):
     """reference mmformer.py:192-227; the softmax(QK^T)V core is the HIP attention op"""
 
@@ -164,9 +173,9 @@ class SelfAttention(nn.Module):
         self.num_heads = heads
         head_dim = dim // heads
         self.scale = qk_scale or head_dim ** -0.5
-        self.qkv = nn.Linear(dim, dim * 3, bias=qkv_bias)
+        self.qkv = Linear(dim, dim * 3, bias=qkv_bias)
         self.attn_drop = nn.Dropout(dropout_rate)
-        self.proj = nn.Linear(dim, dim)
+        self.proj = Linear(dim, dim)
         self.proj_drop = nn.Dropout(dropout_rate)
 
     def forward(self, x):
@@ -214,8 +223,8 @@ class GELU(nn.Module):
 class FeedForward(nn.Module):
     def __init__(self, dim, hidden_dim, dropout_rate):
         super().__init__()
-        self.net = nn.Sequential(nn.Linear(dim, hidden_dim), GELU(), nn.Dropout(p=dropout_rate),
-                                 nn.Linear(hidden_dim, dim), nn.Dropout(p=dropout_rate))
+        self.net = nn.Sequential(Linear(dim, hidden_dim), GELU(), nn.Dropout(p=dropout_rate),
+                                 Linear(hidden_dim, dim), nn.Dropout(p=dropout_rate))
 
     def forward(self, x):
         return self.net(x)
@@ -333,6 +342,7 @@ class Model(nn.Module):
     def forward(self, x, mask, target=None, temp=1.0):
         L.require_gpu(x)
         ops.repack_stale()       # all conv weights the optimizer touched, one launch
+        ops.recast_stale()       # ... and the bf16 images of the token-GEMM parameters, one more
         B, S = x.size(0), x.size(2)
         dev = x.device
         dt = self.compute_dtype

@@ -102,6 +102,60 @@ def repack_stale():
     return n
 
 
+# ------------------------------------------------------------------------------------------------
+# bf16 images of the token-GEMM (nn.Linear) parameters
+# ------------------------------------------------------------------------------------------------
+_CAST_REGISTRY = {}     # id(param) -> [weakref to the f32 parameter, bf16 image or None, (data_ptr, version) of the image]
+
+
+class _CastGradFn(torch.autograd.Function):
+    """the cached bf16 image of an f32 parameter as a differentiable function of it (gradient: cast back to f32)"""
+
+    @staticmethod
+    def forward(ctx, param, image):
+        return image.detach()
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.float(), None
+
+
+def recast_stale():
+    """Refresh, in one multi-tensor launch, the bf16 image of every registered Linear parameter the optimizer touched.
+    Under autocast every F.linear casts its f32 weight and bias again on every call (40 tiny launches per step for the five
+    transformers); a bf16 operand passes through autocast untouched."""
+    capturing = torch.cuda.is_current_stream_capturing()
+    src, dst = [], []
+    for key in list(_CAST_REGISTRY):
+        ent = _CAST_REGISTRY[key]
+        p = ent[0]()
+        if p is None:
+            del _CAST_REGISTRY[key]
+            continue
+        if not p.is_cuda:
+            continue
+        if ent[1] is None or ent[1].device != p.device:
+            ent[1], ent[2] = torch.empty_like(p, dtype=torch.bfloat16), None
+        if capturing or ent[2] != (p.data_ptr(), p._version):
+            src.append(p.detach())
+            dst.append(ent[1])
+            ent[2] = (p.data_ptr(), p._version)
+    if src:
+        torch._foreach_copy_(dst, src)
+    return len(src)
+
+
+def bf16_param(p):
+    """bf16 image of the f32 parameter `p` (registered on first use; refreshed by recast_stale at the top of forward)"""
+    ent = _CAST_REGISTRY.get(id(p))
+    if ent is None or ent[0]() is not p:
+        import weakref
+        ent = _CAST_REGISTRY[id(p)] = [weakref.ref(p), None, None]
+    if ent[1] is None or ent[2] != (p.data_ptr(), p._version):
+        recast_stale()
+    return _CastGradFn.apply(p, ent[1])
+
+
 def pack_weight(weight, cache=None):
     """f32 (Cout,Cin,k,k,k) -> packed MFMA operand images (fwd + dgrad); cached per weight version."""
     key = (weight.data_ptr(), weight._version)

@@ -16,6 +16,7 @@ class FusedAdamW(torch.optim.Optimizer):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, amsgrad=False):
         defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=amsgrad)
         super().__init__(params, defaults)
+        self._tables = {}
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -24,39 +25,66 @@ class FusedAdamW(torch.optim.Optimizer):
             with torch.enable_grad():
                 loss = closure()
         lib = L.load()
-        for group in self.param_groups:
+        for gi, group in enumerate(self.param_groups):
             ps = [p for p in group["params"] if p.grad is not None]
             if not ps:
                 continue
-            for p in ps:
-                st = self.state[p]
-                if len(st) == 0:
-                    st["step"] = torch.tensor(0.0)
-                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                    if group["amsgrad"]:
-                        st["max_exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-            ok = all(p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() and p.grad.dtype == torch.float32
-                     for p in ps)
-            if not ok:
-                raise L.PassionHipError("FusedAdamW needs contiguous f32 CUDA parameters and gradients")
-            steps = {int(self.state[p]["step"]) for p in ps}
-            assert len(steps) == 1, "parameters of one group must share the step count"
-            step = steps.pop() + 1
+            # everything that does not change from step to step (validation, pointer tables of the parameters and their
+            # moments) is built once per set of live parameters: the step is host-bound, 288 parameters x a few dict
+            # lookups and CPU-tensor increments were 1.2 ms of it
+            key = tuple(id(p) for p in ps)
+            cache = self._tables.get(gi)
+            if cache is None or cache["key"] != key or any(p.data_ptr() != q for p, q in zip(ps, cache["pptr"])):
+                for p in ps:
+                    st = self.state[p]
+                    if len(st) == 0:
+                        st["step"] = torch.tensor(0.0)
+                        st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                        st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                        if group["amsgrad"]:
+                            st["max_exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                if not all(p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() for p in ps):
+                    raise L.PassionHipError("FusedAdamW needs contiguous f32 CUDA parameters and gradients")
+                steps = {int(self.state[p]["step"]) for p in ps}
+                assert len(steps) == 1, "parameters of one group must share the step count"
+                n = len(ps)
+                arr = lambda ts: (c_void_p * n)(*[t.data_ptr() for t in ts])     # noqa: E731
+                ms = [self.state[p]["exp_avg"] for p in ps]
+                vs = [self.state[p]["exp_avg_sq"] for p in ps]
+                vm = [self.state[p]["max_exp_avg_sq"] for p in ps] if group["amsgrad"] else ms
+                cache = {"key": key, "pptr": [p.data_ptr() for p in ps], "p": arr(ps), "m": arr(ms), "v": arr(vs), "vm": arr(vm),
+                         "numel": (c_int64 * n)(*[p.numel() for p in ps]), "g": (c_void_p * n)(), "step": steps.pop(),
+                         "step_tensors": [self.state[p]["step"] for p in ps]}
+                self._tables[gi] = cache
             n = len(ps)
-            arr = lambda ts: (c_void_p * n)(*[t.data_ptr() for t in ts])     # noqa: E731
-            grads = [p.grad if p.grad.is_contiguous() else p.grad.contiguous() for p in ps]
-            ms = [self.state[p]["exp_avg"] for p in ps]
-            vs = [self.state[p]["exp_avg_sq"] for p in ps]
-            vm = [self.state[p]["max_exp_avg_sq"] for p in ps] if group["amsgrad"] else ms
-            numel = (c_int64 * n)(*[p.numel() for p in ps])
+            garr = cache["g"]
+            for i, p in enumerate(ps):
+                g = p.grad
+                if g.dtype != torch.float32 or not g.is_cuda:
+                    raise L.PassionHipError("FusedAdamW needs contiguous f32 CUDA parameters and gradients")
+                if not g.is_contiguous():
+                    g = p.grad = g.contiguous()
+                garr[i] = g.data_ptr()
+            cache["step"] += 1
             b1, b2 = group["betas"]
-            L.check(lib.passion_adamw_step(n, arr(ps), arr(grads), arr(ms), arr(vs), arr(vm), numel, float(group["lr"]), float(b1),
-                                           float(b2), float(group["eps"]), float(group["weight_decay"]), step,
+            L.check(lib.passion_adamw_step(n, cache["p"], garr, cache["m"], cache["v"], cache["vm"], cache["numel"], float(group["lr"]),
+                                           float(b1), float(b2), float(group["eps"]), float(group["weight_decay"]), cache["step"],
                                            1 if group["amsgrad"] else 0, L.stream_ptr()), "passion_adamw_step")
-            for p in ps:
-                self.state[p]["step"] += 1
-                # the kernel wrote the parameters behind autograd's back: bump their version counters, the packed-weight
-                # caches (ops.pack_weight / repack_stale) and any saved-tensor checks key on them
-                torch.autograd.graph.increment_version(p)
+            # the kernel wrote the parameters behind autograd's back: bump their version counters, the packed-weight
+            # caches (ops.pack_weight / repack_stale) and any saved-tensor checks key on them
+            torch.autograd.graph.increment_version(ps)
         return loss
+
+    def _sync_steps(self):
+        """the per-parameter 'step' tensors of torch's state layout, brought up to date (they are only read by state_dict)"""
+        for cache in self._tables.values():
+            for t in cache["step_tensors"]:
+                t.fill_(float(cache["step"]))
+
+    def state_dict(self):
+        self._sync_steps()
+        return super().state_dict()
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        self._tables = {}

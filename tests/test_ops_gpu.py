@@ -431,4 +431,5 @@ def test_fused_adamw_matches_torch(amsgrad):
     for k in sa["state"]:
         assert set(sa["state"][k]) == set(sb["state"][k])
         assert relerr(sa["state"][k]["exp_avg_sq"], sb["state"][k]["exp_avg_sq"]) < 2e-6
+        assert float(sa["state"][k]["step"]) == float(sb["state"][k]["step"])
     ob.load_state_dict(sa)      # interchangeable
