@@ -296,8 +296,8 @@ __global__ __launch_bounds__(256) void in_bwd_finish_kernel(const T* __restrict_
 // The same finish for a dgrad that ran over the padded domain (conv_lean.hip MODE 2): dxp is [B][D+2][H+2][W+2][Cin_tot]
 // with the gradient of padded position op-1 at coordinate op; the reflect adjoint folds the halo planes back:
 // plane 1 also receives plane -1, plane S-2 also receives plane S (per axis, so up to 8 terms at the corners).
-// One (d, h) row of W voxels per loop trip: the row's source planes are resolved once (workgroup-uniform), only the
-// two W positions 1 and W-2 gather an extra column.
+// One (d, h) row of W voxels per loop trip: the row's halo planes are resolved once (wave-uniform flags, no indexed
+// local arrays -- those live in scratch memory), only the two W positions 1 and W-2 gather an extra column.
 template <typename T, int VEC>
 __global__ __launch_bounds__(256) void in_bwd_finish_pad_kernel(T* __restrict__ dx, const T* __restrict__ x, const T* __restrict__ dxp,
                                                                 const float* __restrict__ stats, const float* __restrict__ sums,
@@ -316,33 +316,47 @@ __global__ __launch_bounds__(256) void in_bwd_finish_pad_kernel(T* __restrict__ 
     const T* pb = dxp + (long)b * (D + 2) * (H + 2) * (W + 2) * Cin_tot + cbase;
     const int tpr = rowv < 256 ? rowv : 256;              // threads that work on one row; 256 / tpr rows in flight per block
     const int rpb = 256 / tpr, rsub = threadIdx.x / tpr, tin = threadIdx.x % tpr;
+    const long prow = (long)(W + 2) * Cin_tot, pplane = (long)(H + 2) * prow;
     for (int r0 = blockIdx.x * rpb; r0 < D * H; r0 += gridDim.x * rpb) {
         const int r = r0 + rsub;
         if (r >= D * H || rsub >= rpb) continue;
         const int d = r / H, h = r % H;
-        int dl[3], hl[3], nd = 0, nh = 0;
-        dl[nd++] = d + 1; if (d == 1) dl[nd++] = 0; if (d == D - 2) dl[nd++] = D + 1;
-        hl[nh++] = h + 1; if (h == 1) hl[nh++] = 0; if (h == H - 2) hl[nh++] = H + 1;
+        // source planes of this row: the own one, plus the halo plane folded onto planes 1 / S-2 (reflect adjoint)
+        const int dsrc[3] = {d + 1, 0, D + 1}, hsrc[3] = {h + 1, 0, H + 1};
+        const bool dok[3] = {true, d == 1, d == D - 2}, hok[3] = {true, h == 1, h == H - 2};
         for (int i = tin; i < rowv; i += tpr) {
             const int w = i / cvn, c = (i % cvn) * VEC;
             const long e = ((long)r * W + w) * C + c;
-            float g[VEC];
+            float g[VEC], xv[VEC];
 #pragma unroll
-            for (int j = 0; j < VEC; ++j) g[j] = 0.f;
+            for (int j = 0; j < VEC; ++j) { g[j] = 0.f; xv[j] = 0.f; }
             if (present) {
-                int wl[3], nw = 0;
-                wl[nw++] = w + 1; if (w == 1) wl[nw++] = 0; if (w == W - 2) wl[nw++] = W + 1;
-                for (int a = 0; a < nd; ++a)
-                    for (int e2 = 0; e2 < nh; ++e2)
-                        for (int f = 0; f < nw; ++f) {
-                            float t[VEC];
-                            VecIO<T, VEC>::load(pb + ((((long)dl[a]) * (H + 2) + hl[e2]) * (W + 2) + wl[f]) * Cin_tot + c, t);
+                if (stats) VecIO<T, VEC>::load(xb + e, xv);
+                const bool wlo = (w == 1), whi = (w == W - 2);
+#pragma unroll
+                for (int a = 0; a < 3; ++a) {
+                    if (!dok[a]) continue;
+#pragma unroll
+                    for (int e2 = 0; e2 < 3; ++e2) {
+                        if (!hok[e2]) continue;
+                        const T* rowp = pb + dsrc[a] * pplane + hsrc[e2] * prow + c;
+                        float t[VEC];
+                        VecIO<T, VEC>::load(rowp + (long)(w + 1) * Cin_tot, t);
+#pragma unroll
+                        for (int j = 0; j < VEC; ++j) g[j] += t[j];
+                        if (wlo) {
+                            VecIO<T, VEC>::load(rowp, t);
 #pragma unroll
                             for (int j = 0; j < VEC; ++j) g[j] += t[j];
                         }
+                        if (whi) {
+                            VecIO<T, VEC>::load(rowp + (long)(W + 1) * Cin_tot, t);
+#pragma unroll
+                            for (int j = 0; j < VEC; ++j) g[j] += t[j];
+                        }
+                    }
+                }
                 if (stats) {                               // else: input was not normalised in the loader, fold only
-                    float xv[VEC];
-                    VecIO<T, VEC>::load(xb + e, xv);
 #pragma unroll
                     for (int j = 0; j < VEC; ++j)
                         g[j] = __builtin_fmaf(coef[c + j][0], g[j], __builtin_fmaf(coef[c + j][1], xv[j], coef[c + j][2]));

@@ -21,6 +21,7 @@ namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 template <int KS, int CKB> struct GeoL {
     static constexpr int HALO = (KS == 3) ? 1 : 0;
@@ -38,7 +39,7 @@ template <int KS, int CKB> struct GeoL {
 struct alignas(16) BlkDesc {     // one 8-channel block of the K axis, resolved for this workgroup's sample
     const bf16_t* src;           // sample base + channel offset
     int C, nch, has_norm, pad_;  // voxel stride (elements); 8 or 0 (absent modality); InstanceNorm + LeakyReLU in the loader
-    float mean[8], rstd[8];
+    float shift[8], rstd[8];     // normalised value = x * rstd + shift  (shift = -mean * rstd: one FMA per element)
 };
 static_assert(sizeof(BlkDesc) == 96, "BlkDesc layout");
 struct alignas(16) EpiDesc {     // dgrad epilogue: the four output rows (= forward input channels) of one lane group
@@ -137,7 +138,7 @@ __global__ __launch_bounds__(256) void conv_lean_kernel(ConvK p) {
         BlkDesc d;
         d.pad_ = 0;
 #pragma unroll
-        for (int c = 0; c < 8; ++c) { d.mean[c] = 0.f; d.rstd[c] = 1.f; }
+        for (int c = 0; c < 8; ++c) { d.shift[c] = 0.f; d.rstd[c] = 1.f; }
         if (DG && p.y_f32) {        // f32 dY of a logit head: one block of Cout <= 8 channels, converted while staging
             d.src = reinterpret_cast<const bf16_t*>(reinterpret_cast<const float*>(p.dy) + (long)b * Qd * Qh * Qw * p.Cout);
             d.C = p.Cout; d.nch = 8; d.has_norm = 0;
@@ -162,8 +163,9 @@ __global__ __launch_bounds__(256) void conv_lean_kernel(ConvK p) {
                         if (sd.stats) {
 #pragma unroll
                             for (int c = 0; c < 8; ++c) {
-                                d.mean[c] = sd.stats[((long)bs * sd.C + c0 + c) * 2 + 0];
+                                const float mean = sd.stats[((long)bs * sd.C + c0 + c) * 2 + 0];
                                 d.rstd[c] = sd.stats[((long)bs * sd.C + c0 + c) * 2 + 1];
+                                d.shift[c] = -mean * d.rstd[c];
                             }
                         }
                     }
@@ -287,7 +289,21 @@ __global__ __launch_bounds__(256) void conv_lean_kernel(ConvK p) {
         okbits = 0u;
         const bool interior = o0d >= G::HALO && o0h >= G::HALO && o0w >= G::HALO && o0d + TD + G::HALO <= S * Qd &&
                               o0h + TH + G::HALO <= S * Qh && o0w + TW + G::HALO <= S * Qw;
-        if (interior) {                           // workgroup-uniform: no padding anywhere in this brick
+        if (interior && !(DG && p.y_f32)) {       // workgroup-uniform: no padding anywhere in this brick
+            // 32-bit element offsets from the sample base (a sample has < 2^31 elements; voxoff and C are < 2^24):
+            // one 24-bit multiply and one add per load instead of a 64-bit multiply-add chain
+            const int basevox = (((o0d - G::HALO) / S) * Qh + (o0h - G::HALO) / S) * Qw + (o0w - G::HALO) / S;
+            const unsigned base_el = (unsigned)basevox * (unsigned)C;
+#pragma unroll
+            for (int u = 0; u < NIT; ++u) {
+                raw[u] = (u32x4){0u, 0u, 0u, 0u};
+                if (have && (tid + 256 * u < G::TOT) && (S == 1 || voxoff[u] >= 0)) {
+                    const unsigned el = base_el + __umul24((unsigned)voxoff[u], (unsigned)C);
+                    raw[u] = *reinterpret_cast<const u32x4*>(src + el);
+                    okbits |= 1u << u;
+                }
+            }
+        } else if (interior) {
             const int basevox = (((o0d - G::HALO) / S) * Qh + (o0h - G::HALO) / S) * Qw + (o0w - G::HALO) / S;
 #pragma unroll
             for (int u = 0; u < NIT; ++u) {
@@ -326,11 +342,16 @@ __global__ __launch_bounds__(256) void conv_lean_kernel(ConvK p) {
         const BlkDesc* dp = desc + chunk * NC8 + jj;
         const bool hn = (NC8 == 1) ? rfl(dp->has_norm) != 0 : dp->has_norm != 0;
         const bool norm = hn && okbits != 0u;
-        float mean[8], rstd[8];
+        // channel pairs as 2-vectors: v_pk_fma_f32 / v_pk_mul_f32 work on two channels per instruction
+        f32x2 sc[4], sh[4];
         if (norm) {
 #pragma unroll
-            for (int c = 0; c < 8; ++c) { mean[c] = dp->mean[c]; rstd[c] = dp->rstd[c]; }
+            for (int c = 0; c < 4; ++c) {
+                sc[c] = (f32x2){dp->rstd[2 * c], dp->rstd[2 * c + 1]};
+                sh[c] = (f32x2){dp->shift[2 * c], dp->shift[2 * c + 1]};
+            }
         }
+        const f32x2 slope2 = {p.slope, p.slope};
 #pragma unroll
         for (int u = 0; u < NIT; ++u) {
             if (tid + 256 * u >= G::TOT) continue;
@@ -339,11 +360,12 @@ __global__ __launch_bounds__(256) void conv_lean_kernel(ConvK p) {
                 bf16x8 ob;
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {      // bf16 pairs -> f32: low half = even channel
-                    const float v0 = __uint_as_float(raw[u][c] << 16), v1 = __uint_as_float(raw[u][c] & 0xffff0000u);
-                    float t0_ = (v0 - mean[2 * c]) * rstd[2 * c], t1_ = (v1 - mean[2 * c + 1]) * rstd[2 * c + 1];
-                    t0_ = fmaxf(t0_, t0_ * p.slope);      // LeakyReLU for 0 <= slope <= 1: one max instead of compare + select
-                    t1_ = fmaxf(t1_, t1_ * p.slope);
-                    ob[2 * c] = (__bf16)t0_; ob[2 * c + 1] = (__bf16)t1_;
+                    const f32x2 v = {__uint_as_float(raw[u][c] << 16), __uint_as_float(raw[u][c] & 0xffff0000u)};
+                    f32x2 t = __builtin_elementwise_fma(v, sc[c], sh[c]);
+                    const f32x2 ts = t * slope2;
+                    t.x = fmaxf(t.x, ts.x);               // LeakyReLU for 0 <= slope <= 1: one max instead of compare + select
+                    t.y = fmaxf(t.y, ts.y);
+                    ob[2 * c] = (__bf16)t.x; ob[2 * c + 1] = (__bf16)t.y;
                 }
                 o = __builtin_bit_cast(u32x4, ob);
             }
@@ -469,7 +491,7 @@ __global__ __launch_bounds__(256) void conv_lean_kernel(ConvK p) {
 #pragma unroll
                 for (int nt = 0; nt < 4; ++nt) {
                     xpre[nt] = make_uint2(0u, 0u);
-                    if (xvv[nt] >= 0) xpre[nt] = *reinterpret_cast<const uint2*>(e.x + (long)xvv[nt] * e.C);
+                    if (xvv[nt] >= 0) xpre[nt] = *reinterpret_cast<const uint2*>(e.x + (unsigned)xvv[nt] * (unsigned)e.C);      // < 2^32 elements per sample
                 }
             }
         }
@@ -570,7 +592,7 @@ __global__ __launch_bounds__(256) void conv_lean_kernel(ConvK p) {
                         const bool valid = ok && xvv[nt] >= 0;
                         uint2 xr = make_uint2(0u, 0u);
                         if (MT == 1) xr = xpre[nt];
-                        else if (valid && hs) xr = *reinterpret_cast<const uint2*>(e.x + (long)xvv[nt] * xC);
+                        else if (valid && hs) xr = *reinterpret_cast<const uint2*>(e.x + (unsigned)xvv[nt] * (unsigned)xC);
                         const float xv[4] = {__uint_as_float(xr.x << 16), __uint_as_float(xr.x & 0xffff0000u),
                                              __uint_as_float(xr.y << 16), __uint_as_float(xr.y & 0xffff0000u)};
                         const float vf = (valid && hs) ? 1.f : 0.f;
@@ -584,22 +606,27 @@ __global__ __launch_bounds__(256) void conv_lean_kernel(ConvK p) {
                             s1[mt][j] += gs;
                             s2v[mt][j] = __builtin_fmaf(gs, xh, s2v[mt][j]);
                         }
-                        if (valid) store4(e.dx + (long)dvv[nt] * dC, gv);
+                        if (valid) store4(e.dx + (unsigned)dvv[nt] * (unsigned)dC, gv);
                     }
                 }
             } else if (o0d + TD <= Sd && o0h + TH <= Sh && o0w + TW <= Sw) {       // whole brick inside: no per-lane bounds
-                bf16_t* y = reinterpret_cast<bf16_t*>(p.y);
-                const bf16_t* res = reinterpret_cast<const bf16_t*>(p.residual);
-                const long basevox = (((long)b * Sd + o0d) * Sh + o0h) * Sw + o0w + lanevox0;
+                // sample base (64-bit, uniform) + 32-bit element offsets: brick (uniform) + lane constant + row tile
+                const long sample_el = (long)b * Sd * Sh * Sw * p.Cout;
+                bf16_t* y = reinterpret_cast<bf16_t*>(p.y) + sample_el;
+                float* yf = reinterpret_cast<float*>(p.y) + sample_el;
+                const bf16_t* res = p.residual ? reinterpret_cast<const bf16_t*>(p.residual) + sample_el : nullptr;
+                const unsigned brick_el = (unsigned)((o0d * Sh + o0h) * Sw + o0w) * (unsigned)p.Cout;
+                const unsigned nt_el = (unsigned)(2 * Sw) * (unsigned)p.Cout;
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) {
                     const int co = (mg * MT + mt) * 16 + g * 4;
                     if (co >= p.Cout) continue;
+                    const unsigned lane_el = brick_el + (unsigned)lanevox0 * (unsigned)p.Cout + (unsigned)co;
 #pragma unroll
                     for (int nt = 0; nt < 4; ++nt) {
-                        const long e = (basevox + nt * 2 * Sw) * p.Cout + co;
+                        const unsigned e = lane_el + nt * nt_el;
                         f32x4 v = acc[mt][nt] + biasv[mt];
-                        if (p.y_f32) { *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.y) + e) = v; continue; }   // logit head
+                        if (p.y_f32) { *reinterpret_cast<f32x4*>(yf + e) = v; continue; }   // logit head
                         if (res) v += load4(res + e);
                         store4(y + e, v);
                     }

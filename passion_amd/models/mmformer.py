@@ -39,6 +39,7 @@ H = W = Z = 80
 MODALS = ("flair", "t1ce", "t1", "t2")
 import os as _os
 ENC_STREAMS = _os.environ.get("PASSION_ENC_STREAMS", "1") != "0"
+INTRA_STREAMS = _os.environ.get("PASSION_INTRA_STREAMS", "1") != "0"   # intra-modal transformers stay on their encoder's stream
 
 
 def _up2(f):
@@ -366,6 +367,19 @@ class Model(nn.Module):
         streams = self._enc_streams(dev) if ENC_STREAMS and x.is_cuda else None
         main = torch.cuda.current_stream(dev) if streams else None
         encs = [None] * 4
+        intra = [None] * 4
+        pos = [getattr(self, f"{m}_pos") for m in MODALS]
+
+        def intra_tokens(i):
+            """token conv + intra-modal transformer of modality i (mmformer.py:417-433): a chain of ~30 tiny launches that
+            depends on encoder i only, so it stays on that encoder's stream"""
+            m = MODALS[i]
+            own5 = encs[i][4].with_mask(mask, i) if idt else encs[i][4]
+            pp = own5.t.shape[1]
+            tok = run_conv(getattr(self, f"{m}_encode_conv"), own5, norm=False).t.view(B, pp ** 3, self.token_dim)
+            tok = self._transformer(getattr(self, f"{m}_transformer"), tok, pos[i])
+            return tok * mask[:, i].view(B, 1, 1).to(tok.dtype)
+
         for i, m in enumerate(MODALS):
             outs = [ops.alias_slice(b_, i) for b_ in bufs] if training else None
             sts = [s_[i] for s_ in sbufs] if training else None
@@ -377,6 +391,9 @@ class Model(nn.Module):
                         f.t.record_stream(main)          # block could be handed out again on this side stream too early
                         if f._stats[0] is not None:
                             f._stats[0].record_stream(main)
+                    if INTRA_STREAMS:
+                        intra[i] = intra_tokens(i)
+                        intra[i].record_stream(main)
             else:
                 encs[i] = getattr(self, f"{m}_encoder")(xin, i, mask if idt else None, dt, outs, sts)
         if streams:
@@ -397,15 +414,11 @@ class Model(nn.Module):
             masks_all = torch.cat([mask] + studs, 0).contiguous()
             tok_mask = torch.cat([torch.ones_like(mask)] + [onehots[2 if i == 3 else i] for i in range(4)], 0)  # quirk :522
         xs = [[encs[i][l].with_mask(masks_all, i, P) for i in range(4)] for l in range(4)]
-        own5 = [(encs[i][4].with_mask(mask, i) if idt else encs[i][4]) for i in range(4)]
 
-        # ---- intra-modal transformers (mmformer.py:417-433)
-        pos = [getattr(self, f"{m}_pos") for m in MODALS]
-        intra = []
-        for i, m in enumerate(MODALS):
-            tok = run_conv(getattr(self, f"{m}_encode_conv"), own5[i], norm=False).t.view(B, p ** 3, self.token_dim)
-            tok = self._transformer(getattr(self, f"{m}_transformer"), tok, pos[i])
-            intra.append(tok * mask[:, i].view(B, 1, 1).to(tok.dtype))
+        # ---- intra-modal transformers (mmformer.py:417-433), unless they already ran on the encoder streams
+        for i in range(4):
+            if intra[i] is None:
+                intra[i] = intra_tokens(i)
         pos_cat = torch.cat(pos, 1)
 
         # decoder_sep (per-modality decoders, shared weights: ONE pass over the stacked modalities) depends on the encoders
