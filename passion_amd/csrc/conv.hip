@@ -893,8 +893,11 @@ extern "C" int passion_conv3d_bwd(const passion_conv_desc_t* d, const float* pac
                 rc = launch_wgrad_lean(k, d->ksize, d->stride, w.MT, w.gx, w.gy, dWs, dbs, st);
                 k.y_f32 = 0;
                 if (rc > 0) rc = -1014;              // planned for the lean kernel: must be covered
-            } else if (w.bf16)
-                rc = launch_wgrad_bf16(k, d->ksize, d->stride, w.MT, w.gx, w.gy, dWs, dbs, st);
+            } else if (w.bf16) {
+                rc = (pconv::g_conv_lean && d->x_dtype == PASSION_BF16 && d->y_dtype == PASSION_BF16)
+                         ? launch_wgrad_c1(k, d->ksize, d->stride, w.gx, w.gy, dWs, dbs, st) : 1;
+                if (rc > 0) rc = launch_wgrad_bf16(k, d->ksize, d->stride, w.MT, w.gx, w.gy, dWs, dbs, st);
+            }
             else if (d->x_dtype == PASSION_F32 && d->y_dtype == PASSION_F32)
                 rc = launch_wgrad_geo<float, float>(k, w, d->ksize, d->stride, dWs, dbs, st);
             else if (d->x_dtype == PASSION_BF16 && d->y_dtype == PASSION_BF16)

@@ -58,6 +58,7 @@ int launch_conv_bf16(ConvK& k, int ksize, int stride, bool dgrad, const void* pa
 int launch_conv_lean(ConvK& k, int ksize, int stride, int mode, const void* packed_bf16, hipStream_t st);   // conv_lean.hip
 bool lean_covers(const ConvK& k, int stride, bool dgrad);
 int launch_wgrad_lean(ConvK& k, int ksize, int stride, int MT, int gx, int gy, float* dWslab, float* dbslab, hipStream_t st);   // conv_wgrad_lean.hip
+int launch_wgrad_c1(ConvK& k, int ksize, int stride, int gx, int gy, float* dWslab, float* dbslab, hipStream_t st);   // first layer, Cin = 1
 extern int g_conv_lean;
 int launch_wgrad_bf16(ConvK& k, int ksize, int stride, int MT, int gx, int gy, float* dWslab, float* dbslab, hipStream_t st);
 int wgrad_bf16_chunk(const ConvK& k, int ksize, int stride);

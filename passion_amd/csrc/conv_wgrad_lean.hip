@@ -323,6 +323,135 @@ __global__ __launch_bounds__(256) void wgrad_lean_kernel(ConvK p, float* __restr
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// First-layer weight gradient (reference nn.Conv3d(1, 8, 3, padding_mode='reflect'), mmformer.py:28): Cin = 1 -- one raw
+// modality volume, no InstanceNorm in front -- and Cout = 8.  As an MFMA GEMM this is a 16 x 32 tile with 8 x 27 useful
+// entries and a K axis (voxels) whose B operand would have to be gathered element by element; the generic bf16 wgrad
+// kernel spent 136 us per launch on it.  Here a thread owns voxels, keeps the 9 x 8 partial sums of one depth tap (+ 8 bias sums) in
+// registers as channel pairs (v_pk_fma_f32: two channels per instruction), and the workgroup folds them once at the end
+// into its slot of the partial slab ([co][tap] | dbias, the same layout the other wgrad kernels fill).
+__global__ __launch_bounds__(256) void wgrad_c1_kernel(ConvK p, float* __restrict__ dW, float* __restrict__ dbias) {
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    __shared__ float red[256 * 33];
+    __shared__ float red2[8][32];
+    const SegD& sd = p.seg[0];
+    const int D = p.Di, H = p.Hi, W = p.Wi, tid = threadIdx.x;
+    const int td = blockIdx.y;            // depth tap of this workgroup: 9 taps x 8 channels of partial sums per thread, so that
+                                          // several waves fit a SIMD (all 27 taps = 260 registers = one wave, latency-bound)
+    const unsigned V = (unsigned)D * H * W, total = (unsigned)p.B * V;        // < 2^31 (checked by the launcher)
+    const bool reflect = p.pad_mode == PASSION_PAD_REFLECT;
+    const bool pow2 = !(W & (W - 1)) && !(H & (H - 1)) && !(V & (V - 1));
+    const int lw = __builtin_ctz(W), lh = __builtin_ctz(H), lv = __builtin_ctz(V);
+    const bf16_t* dy = reinterpret_cast<const bf16_t*>(p.dy);
+    f32x2 acc[9][4], bacc[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        bacc[c] = (f32x2){0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < 9; ++t) acc[t][c] = (f32x2){0.f, 0.f};
+    }
+    // Software pipeline: the 9 neighbour loads + the dY vector of the next two voxels are issued before the packed FMAs
+    // of the current two.
+    struct Vox { unsigned short x[9]; uint4 dy; unsigned okbits; };
+    auto fetch = [&](unsigned i, Vox& o) {
+        o.okbits = 0u;
+        o.dy = make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+        for (int t = 0; t < 9; ++t) o.x[t] = 0;
+        if (i >= total) return;
+        unsigned b, v, w, h, d;
+        if (pow2) { b = i >> lv; v = i & (V - 1); w = v & (W - 1); h = (v >> lw) & (H - 1); d = v >> (lw + lh); }
+        else { b = i / V; v = i - b * V; const unsigned r = v / W; w = v - r * W; d = r / H; h = r - d * H; }
+        o.dy = *reinterpret_cast<const uint4*>(dy + (long)i * 8);
+        const bool present = !sd.mask || sd.mask[(long)b * sd.mask_ld + sd.mask_col];      // absent modality: its input is zero
+        const unsigned short* xb = reinterpret_cast<const unsigned short*>(sd.x) + (long)sd.bsrc((int)b) * sd.bstride;
+        int cd = (int)d + td - 1;
+        const bool okd = reflect || (cd >= 0 && cd < D);
+        cd = cd < 0 ? -cd : (cd >= D ? 2 * D - 2 - cd : cd);
+        cd = min(max(cd, 0), D - 1);
+        int ih[3], iw[3];
+        unsigned okh = 0, okw = 0;
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            int ch = (int)h + t - 1, cw = (int)w + t - 1;
+            if (reflect || (ch >= 0 && ch < H)) okh |= 1u << t;
+            if (reflect || (cw >= 0 && cw < W)) okw |= 1u << t;
+            ch = ch < 0 ? -ch : (ch >= H ? 2 * H - 2 - ch : ch);
+            cw = cw < 0 ? -cw : (cw >= W ? 2 * W - 2 - cw : cw);
+            ih[t] = min(max(ch, 0), H - 1); iw[t] = min(max(cw, 0), W - 1);
+        }
+#pragma unroll
+        for (int th = 0; th < 3; ++th) {
+            const unsigned short* row = xb + ((long)cd * H + ih[th]) * W;
+#pragma unroll
+            for (int tw = 0; tw < 3; ++tw) {
+                o.x[th * 3 + tw] = row[iw[tw]];
+                if (present && okd && ((okh >> th) & (okw >> tw) & 1u)) o.okbits |= 1u << (th * 3 + tw);
+            }
+        }
+    };
+    auto accumulate = [&](const Vox& q) {
+        const unsigned dw[4] = {q.dy.x, q.dy.y, q.dy.z, q.dy.w};
+        f32x2 dy2[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {      // bf16 pairs -> f32: low half = even channel
+            dy2[c] = (f32x2){__uint_as_float(dw[c] << 16), __uint_as_float(dw[c] & 0xffff0000u)};
+            bacc[c] += dy2[c];
+        }
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            float xv = __uint_as_float((unsigned)q.x[t] << 16);
+            if (!((q.okbits >> t) & 1u)) xv = 0.f;
+            const f32x2 x2 = {xv, xv};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[t][c] = __builtin_elementwise_fma(x2, dy2[c], acc[t][c]);
+        }
+    };
+    const unsigned stride = gridDim.x * 256u;
+    unsigned i = blockIdx.x * 256u + tid;
+    Vox n0, n1;
+    fetch(i, n0);
+    fetch(i + stride, n1);
+    for (; i < total; i += 2 * stride) {
+        const Vox c0 = n0, c1 = n1;
+        fetch(i + 2 * stride, n0);
+        fetch(i + 3 * stride, n1);
+        accumulate(c0);
+        accumulate(c1);
+    }
+    // fold over the 256 threads, 32 values at a time: value k = t * 8 + co (k < 72, t = th * 3 + tw), 72 + co = bias sums
+    float* slot = dW ? dW + (long)blockIdx.x * p.wslot : nullptr;
+#pragma unroll
+    for (int ck = 0; ck < 3; ++ck) {
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 32; ++j) {
+            const int k = ck * 32 + j;
+            float val = 0.f;
+            if (k < 72) val = acc[k / 8][(k % 8) / 2][k % 2];
+            else if (k < 80) val = bacc[(k - 72) / 2][(k - 72) % 2];
+            red[tid * 33 + j] = val;
+        }
+        __syncthreads();
+        {
+            const int j = tid & 31, part = tid >> 5;
+            float sacc = 0.f;
+            for (int t = part * 32; t < part * 32 + 32; ++t) sacc += red[t * 33 + j];
+            red2[part][j] = sacc;
+        }
+        __syncthreads();
+        if (tid < 32) {
+            float sacc = 0.f;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) sacc += red2[q][tid];
+            const int k = ck * 32 + tid;
+            if (k < 72) { if (slot) slot[(k % 8) * 27 + td * 9 + k / 8] = sacc; }
+            else if (k < 80 && dbias && td == 0) dbias[(long)blockIdx.x * p.wslot + (k - 72)] = sacc;
+        }
+    }
+}
+
 template <int KS>
 int launch_wl(ConvK& k, int MT, int gx, int gy, float* dW, float* db, hipStream_t st) {
     dim3 grid(gx, gy);
@@ -354,6 +483,16 @@ int launch_wgrad_lean(ConvK& k, int ksize, int stride, int MT, int gx, int gy, f
     k.per = (tiles_per_b + wgs - 1) / wgs;
     if (ksize == 1) return launch_wl<1>(k, MT, gx, gy, dW, db, st);
     return launch_wl<3>(k, MT, gx, gy, dW, db, st);
+}
+
+// Cin = 1, Cout = 8, 3x3x3, stride 1, bf16 x and dY, no InstanceNorm in the loader: 0 = launched, 1 = not this shape
+int launch_wgrad_c1(ConvK& k, int ksize, int stride, int gx, int gy, float* dW, float* db, hipStream_t st) {
+    if (ksize != 3 || stride != 1 || k.nseg != 1 || k.Cin != 1 || k.seg[0].C != 1 || k.Cout != 8 || k.seg[0].stats || gy != 1 || k.y_f32) return 1;
+    if ((long)k.B * k.Di * k.Hi * k.Wi >= (1L << 31)) return 1;
+    passion_prof_tag("wgrad_c1_kernel");
+    hipLaunchKernelGGL(wgrad_c1_kernel, dim3(gx, 3), dim3(256), 0, st, k, dW, db);
+    LAUNCH_RET();
+    return 0;
 }
 
 }  // namespace pconv

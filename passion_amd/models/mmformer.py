@@ -330,7 +330,9 @@ class Model(nn.Module):
     def _enc_streams(self, dev):
         cache = self.__dict__.setdefault("_streams_dev", {})
         if dev not in cache:
-            cache[dev] = [torch.cuda.Stream(device=dev) for _ in range(4)]
+            n = max(1, min(4, int(_os.environ.get("PASSION_SIDE_STREAMS", "4"))))     # < 4: encoders share side streams
+            pool = [torch.cuda.Stream(device=dev) for _ in range(n)]
+            cache[dev] = [pool[i % n] for i in range(4)]
         return cache[dev]
 
     def _onehots_on(self, dev):

@@ -49,8 +49,13 @@ for label in ("pipelined", "pipelined, gc disabled"):
         gc.disable()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    delay = float(os.environ.get("HOST_DELAY_MS", "0")) * 1e-3
     for _ in range(30):
         ptrain.train_step(m, opt, x, mask, target, 4.0, state, None)
+        if delay:                                   # is the step host-bound?  burn host time and watch the wall clock
+            te = time.perf_counter() + delay
+            while time.perf_counter() < te:
+                pass
     t1 = time.perf_counter()
     torch.cuda.synchronize()
     t2 = time.perf_counter()
