@@ -48,7 +48,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--graph", action="store_true",
-                    help="EXPERIMENTAL: replay the whole step as one HIP graph (N=1; ~6%% faster, but on ROCm 7.2 / torch 2.10 "
+                    help="EXPERIMENTAL: replay the whole step as one HIP graph (N=1; slower than eager on ROCm 7.2 (30 vs 19.5 ms), and on ROCm 7.2 / torch 2.10 "
                          "replays were observed to corrupt gradients intermittently -- DESIGN.md, so it is not the default)")
     ap.add_argument("--no-graph", action="store_true", help=argparse.SUPPRESS)
     return ap.parse_args()
@@ -154,8 +154,8 @@ def main():
             if r[1] >= 0:
                 tot_w[(r[0], r[4])] = tot_w.get((r[0], r[4]), 0.0) + r[1]
                 fam_warm[r[0]] = fam_warm.get(r[0], 0.0) + r[1]
-        if tot_w:
-            dom_kind = max(tot_w, key=tot_w.get)[0]
+        if fam_warm:          # the family (fwd3 / fwd1 / dgrad / wgrad) with the largest total; its top kernel is reported
+            dom_kind = max(fam_warm, key=fam_warm.get)
         ops.prof_enable(1 << dom_kind)
     t0 = time.perf_counter()
     for _ in range(args.steps):

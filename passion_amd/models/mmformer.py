@@ -39,6 +39,11 @@ H = W = Z = 80
 MODALS = ("flair", "t1ce", "t1", "t2")
 import os as _os
 ENC_STREAMS = _os.environ.get("PASSION_ENC_STREAMS", "1") != "0"
+# Parameters that are first touched on a side stream (encoders, intra-modal transformers) get their AccumulateGrad node on
+# that stream while e.g. the position embeddings also receive a gradient from the main stream: autograd synchronises the
+# two correctly and says so in a warning; the mismatch is intended.
+if hasattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch"):
+    torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
 INTRA_STREAMS = _os.environ.get("PASSION_INTRA_STREAMS", "1") != "0"   # intra-modal transformers stay on their encoder's stream
 
 

@@ -60,3 +60,12 @@ def test_product_does_not_import_oracle():
             if f.endswith(".py"):
                 text = open(os.path.join(dirpath, f)).read()
                 assert "oracle" not in text.replace("# oracle", ""), f"{f} mentions the oracle"
+
+
+def test_host_extension_loads_and_binds():
+    """the C++ autograd nodes (csrc/host_ext.cpp) import on a CPU-only box and get the kernel entry points from ctypes"""
+    from passion_amd import _lib
+    h = _lib.host()
+    assert h is not None
+    for name in ("bind", "conv_block", "instnorm_stats"):
+        assert callable(getattr(h, name))
