@@ -23,6 +23,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
+constexpr bool LDS_ROW_PAD = false;   // see GeoL::RS: superseded by the row pairing of the N tiles (rows h and h + 4)
 template <int KS, int CKB> struct GeoL {
     static constexpr int HALO = (KS == 3) ? 1 : 0;
     static constexpr int ID = TD + 2 * HALO, IH = TH + 2 * HALO, IW = TW + 2 * HALO;
@@ -33,7 +34,12 @@ template <int KS, int CKB> struct GeoL {
     static constexpr int Q = NTAP * NC8;                      // (tap, 8-channel block) pairs per chunk
     static constexpr int NSTEP = (Q + 3) / 4;                 // MFMA K-steps per chunk (4 pairs = K 32 each)
     static constexpr int TOT = VOL * NC8, NIT = (TOT + 255) / 256;
-    static constexpr int BRICK = (VOL * VS + 15) / 16 * 16;
+    // LDS layout of the staged brick: voxel (zd, zh, zw) at zd * PS + zh * RS + zw * VS.  A B-fragment read covers, per 16
+    // lanes, 8 voxels of row h and 8 of row h + 1: with 8-channel voxels (16 B) and dense rows (160 B) the two runs overlap
+    // in two of the sixteen 16-byte bank groups; a row stride of 384 B puts the second run exactly 128 B (mod 256) further.
+    static constexpr int RS = (KS == 3 && CKB == 8 && LDS_ROW_PAD) ? 384 : IW * VS;
+    static constexpr int PS = IH * RS;
+    static constexpr int BRICK = (ID * PS + 15) / 16 * 16;
 };
 
 struct alignas(16) BlkDesc {     // one 8-channel block of the K axis, resolved for this workgroup's sample
@@ -234,11 +240,15 @@ __global__ __launch_bounds__(256) void conv_lean_kernel(ConvK p) {
         voxoff[u] = (S == 2) ? ((zd >> 1) * Qh + (zh >> 1)) * Qw + (zw >> 1) : (zd * Qh + zh) * Qw + zw;
         if (S == 2 && ((zd | zh | zw) & 1)) voxoff[u] = -1;
     }
+    static_assert(G::RS == G::IW * VS, "dense rows: the staged brick is linear in the staging index");
     const int ldsoff0 = (tid / NC8) * VS + jj * 16;       // iteration u writes at ldsoff0 + u * (256 / NC8) * VS
-    const int lh0 = n >> 3, lw = n & 7, ld_ = wv;
-    const int lh[4] = {lh0, lh0 + 2, lh0 + 4, lh0 + 6};
+    // N tile nt of a wave = rows nt and nt + 4 of its depth slice, 8 voxels of W each.  Rows four apart (not neighbours):
+    // with 8-channel voxels a staged row is 10 x 16 B, so rows h and h + 4 start 640 B = 128 B (mod 256) apart and the two
+    // 128-byte runs of a B-fragment read fall into disjoint LDS bank groups (neighbouring rows overlapped in two of sixteen).
+    const int lh0 = 4 * (n >> 3), lw = n & 7, ld_ = wv;
+    const int lh[4] = {lh0, lh0 + 1, lh0 + 2, lh0 + 3};
     // B fragments: this lane's voxel (row nt) at tap 0, plus its 8-channel block inside a 32-channel voxel
-    const int pos0 = ((ld_ * G::IH + lh0) * G::IW + lw) * VS + (NC8 == 4 ? g * 16 : 0);
+    const int pos0 = ld_ * G::PS + lh0 * G::RS + lw * VS + (NC8 == 4 ? g * 16 : 0);
     int toffv[NC8 == 1 ? G::NSTEP : 1];           // CKB 8: lane group g owns tap 4s+g (per-lane offset); CKB 32: tap s for all
     if (NC8 == 1) {
 #pragma unroll
@@ -247,11 +257,11 @@ __global__ __launch_bounds__(256) void conv_lean_kernel(ConvK p) {
             int td = 0, th = 0, tw = 0;
             if (KS == 3) { td = tap / 9; th = (tap / 3) % 3; tw = tap % 3; }
             if (DG && KS == 3) { td = 2 - td; th = 2 - th; tw = 2 - tw; }   // gather form: voxel i reads u = i + 1 - t
-            toffv[s] = (tap < G::NTAP) ? ((td * G::IH + th) * G::IW + tw) * VS : 0;
+            toffv[s] = (tap < G::NTAP) ? td * G::PS + th * G::RS + tw * VS : 0;
         }
     }
     const int wlane = (g * MT * 16 + n) * 16;     // A fragment of step s, row tile mt: wl + wlane + s*4*MT*256 + mt*256
-    const int lanevox0 = (ld_ * Sh + lh0) * Sw + lw;      // output voxel of row nt: + nt * 2 * Sw
+    const int lanevox0 = (ld_ * Sh + lh0) * Sw + lw;      // output voxel of row nt: + nt * Sw
     f32x4 biasv[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
@@ -461,7 +471,7 @@ __global__ __launch_bounds__(256) void conv_lean_kernel(ConvK p) {
                     const int xb = ((o0d - 1 + ld_) * Sh + (o0h - 1 + lh0)) * Sw + (o0w - 1 + lw);
                     const int db = ((o0d + ld_) * (Sh + 2) + (o0h + lh0)) * (Sw + 2) + (o0w + lw);
 #pragma unroll
-                    for (int nt = 0; nt < 4; ++nt) { xvv[nt] = xb + nt * 2 * Sw; dvv[nt] = db + nt * 2 * (Sw + 2); }
+                    for (int nt = 0; nt < 4; ++nt) { xvv[nt] = xb + nt * Sw; dvv[nt] = db + nt * (Sw + 2); }
                 } else {
 #pragma unroll
                     for (int nt = 0; nt < 4; ++nt) {
@@ -507,7 +517,7 @@ __global__ __launch_bounds__(256) void conv_lean_kernel(ConvK p) {
                     int td = 0, th = 0, tw = 0;
                     if (KS == 3) { td = s / 9; th = (s / 3) % 3; tw = s % 3; }
                     if (DG && KS == 3) { td = 2 - td; th = 2 - th; tw = 2 - tw; }
-                    toff = ((td * G::IH + th) * G::IW + tw) * VS;
+                    toff = td * G::PS + th * G::RS + tw * VS;
                 }
                 bf16x8 a[MT];
 #pragma unroll
@@ -515,7 +525,7 @@ __global__ __launch_bounds__(256) void conv_lean_kernel(ConvK p) {
                     a[mt] = *reinterpret_cast<const bf16x8*>(abase + s * (4 * MT * 256) + mt * 256);
 #pragma unroll
                 for (int nt = 0; nt < 4; ++nt) {
-                    const bf16x8 bv = *reinterpret_cast<const bf16x8*>(bbase + toff + nt * (2 * G::IW * VS));
+                    const bf16x8 bv = *reinterpret_cast<const bf16x8*>(bbase + toff + nt * G::RS);
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt)
                         acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mt], bv, acc[mt][nt], 0, 0, 0);
@@ -539,7 +549,7 @@ __global__ __launch_bounds__(256) void conv_lean_kernel(ConvK p) {
                         const int ch = mtab[1][ah][lh[nt]];
                         thp = ch & 3;
                         mval[nt] = pv && (cd & 4) && (ch & 4) && (cw & 4);
-                        mpos[nt] = mval[nt] ? (((cd >> 3) * G::IH + (ch >> 3)) * G::IW + (cw >> 3)) * VS + blk * 16 : 0;
+                        mpos[nt] = mval[nt] ? (cd >> 3) * G::PS + (ch >> 3) * G::RS + (cw >> 3) * VS + blk * 16 : 0;
                     }
                     const int tap = ((cd & 3) * KS + thp) * KS + (cw & 3);
                     // the mirror terms reuse the weights of regular taps, already in LDS:
@@ -616,7 +626,7 @@ __global__ __launch_bounds__(256) void conv_lean_kernel(ConvK p) {
                 float* yf = reinterpret_cast<float*>(p.y) + sample_el;
                 const bf16_t* res = p.residual ? reinterpret_cast<const bf16_t*>(p.residual) + sample_el : nullptr;
                 const unsigned brick_el = (unsigned)((o0d * Sh + o0h) * Sw + o0w) * (unsigned)p.Cout;
-                const unsigned nt_el = (unsigned)(2 * Sw) * (unsigned)p.Cout;
+                const unsigned nt_el = (unsigned)Sw * (unsigned)p.Cout;
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) {
                     const int co = (mg * MT + mt) * 16 + g * 4;
