@@ -86,6 +86,21 @@ def cpu_baseline(passion):
             f"4x{S}^3 synthetic volume = 1/8 of a 128^3 volume by voxel count; {t:.2f} s on {cores} threads"}
 
 
+def measured_copy_gbs(device):
+    """device-to-device copy of 1 GiB (read + write counted), the 'measured peak' SURVEY 8(d) asks for beside the nominal one"""
+    a = torch.empty(1 << 29, dtype=torch.bfloat16, device=device)
+    b = torch.empty_like(a)
+    for _ in range(2):
+        b.copy_(a)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(5):
+        b.copy_(a)
+    e1.record()
+    torch.cuda.synchronize()
+    return 5 * 2 * a.numel() * 2 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+
+
 def main():
     args = parse()
     from passion_amd import ops, parallel
@@ -218,8 +233,10 @@ def main():
             fam_ms = {}
             for r in recs:
                 fam_ms[fam[r[0]]] = fam_ms.get(fam[r[0]], 0.0) + r[1]
+            copy_gbs = measured_copy_gbs(ctx.device)
             out["roofline"] = {"kernel": f"{dom} ({what[rk[0][0]]})", "bound": "hbm", "achieved": round(ach, 2),
                                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic,
+                               "measured_copy_peak": round(copy_gbs, 1), "frac_of_measured_copy": round(ach / copy_gbs, 5),
                                "launches_per_step": len(rk) // prof_steps, "avg_launch_ms": round(ms / len(rk), 5),
                                "algorithmic_bytes_per_launch": round(by / len(rk), 1),
                                "tflops": round(fl / (ms * 1e-3) / 1e12, 3),

@@ -137,6 +137,15 @@ class GradReducer:
         self._works = [None] * len(self.buckets)
 
 
+def all_reduce_sum_(t):
+    """in-place SUM of a (small, detached) tensor over all ranks; a no-op in a single process.  Used for the two places where
+    the reference's loss assembly couples the samples of the GLOBAL batch (DataParallel gathers the per-sample outputs before
+    train.py:266-270 forms rp_iter, and :325 sums epoch_dist_m over every sample of the epoch)."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t
+
+
 def barrier(ctx):
     if ctx.world > 1:
         dist.barrier()

@@ -30,6 +30,8 @@ class LossState:
 
     def end_epoch(self, epoch, warmup=False):
         """train.py:325-335: beta <- clamp(beta - eta*rp_epoch, .1, 4), renormalised to |beta|_2 = 2"""
+        from .parallel import all_reduce_sum_
+        all_reduce_sum_(self.epoch_dist_m)           # every rank saw its own samples only; the reference sums over all of them
         avg = self.epoch_dist_m.sum() / 4.0
         rp_epoch = (avg - self.epoch_dist_m) / avg
         if not warmup:
@@ -59,11 +61,7 @@ def assemble_loss(outs, target, mask, mask_type="idt", use_passion=True, state=N
     beta = state.imb_beta if state is not None else torch.ones(4, device=dev)
     w = (state.modal_weight if (state is not None and idt) else torch.ones(4, device=dev))
     kl_m, proto_m, dist_bs = red(outs[3]), red(outs[4]), outs[5]
-    if idt:   # relative preference: per-sample dist / mean over that sample's present modalities - 1
-        rp = (mk * (dist_bs / (dist_bs.sum(1, keepdim=True) / mk.sum(1, keepdim=True)) - 1)).sum(0)
-    else:
-        rp = (dist_bs / dist_bs.mean(1, keepdim=True) - 1).sum(0)
-    rp_mask = (rp > 0).float()
+    rp_mask = relative_preference(dist_bs, mk, idt)
     kl = (beta * w * kl_m).sum()
     proto = (rp_mask * w * proto_m).sum()
     if state is not None:
@@ -72,6 +70,19 @@ def assemble_loss(outs, target, mask, mask_type="idt", use_passion=True, state=N
     if warmup:
         return (beta * w * sep_m).sum() + 0.0 * (fuse_loss + prm_loss + kl + proto)
     return fuse_loss + (rp_mask * beta * w * sep_m).sum() + prm_loss + 0.5 * kl + 0.1 * proto
+
+
+def relative_preference(dist_bs, mk, idt=True):
+    """rp_mask of train.py:266-270: per sample, dist / (mean over that sample's present modalities) - 1, summed over the
+    samples of the GLOBAL batch (the reference forms it on the outputs DataParallel gathered from all devices: with one
+    process per GPU that is a 4-float all-reduce), thresholded at 0.  No gradient flows through it."""
+    from .parallel import all_reduce_sum_
+    d = dist_bs.detach()
+    if idt:
+        rp = (mk * (d / (d.sum(1, keepdim=True) / mk.sum(1, keepdim=True)) - 1)).sum(0)
+    else:
+        rp = (d / d.mean(1, keepdim=True) - 1).sum(0)
+    return (all_reduce_sum_(rp.contiguous()) > 0).float()
 
 
 def make_optimizer(model, lr=2e-4, weight_decay=1e-4, capturable=False):

@@ -69,6 +69,47 @@ def test_two_rank_gloo_equals_global_batch(tmp_path):
         assert torch.allclose(v, got["sd"][k], atol=1e-6), k
 
 
+def _rp_worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    from passion_amd import parallel
+    from passion_amd import train as ptrain
+    parallel.init(backend="gloo")
+    d, mk = _rp_data()
+    rp = ptrain.relative_preference(d[rank:rank + 1], mk[rank:rank + 1], idt=True)      # one sample per rank
+    st = ptrain.LossState(torch.device("cpu"))
+    st.epoch_dist_m += (d[rank:rank + 1] * mk[rank:rank + 1]).sum(0)
+    rp_epoch = st.end_epoch(1)
+    if rank == 0:
+        torch.save({"rp": rp, "rp_epoch": rp_epoch, "beta": st.imb_beta}, out)
+    torch.distributed.destroy_process_group()
+
+
+def _rp_data():
+    d = torch.tensor([[0.9, 0.1, 0.4, 0.2], [0.05, 0.6, 0.5, 0.3]])
+    mk = torch.tensor([[1.0, 1.0, 0.0, 1.0], [1.0, 1.0, 1.0, 1.0]])
+    return d, mk
+
+
+def test_relative_preference_and_epoch_update_span_the_global_batch(tmp_path):
+    """train.py:266-270 / :325-335 couple the samples of the whole (DataParallel-gathered) batch: two ranks with one sample
+    each must get the rp_mask / imb_beta of one process holding both"""
+    sys.path.insert(0, ROOT)
+    from passion_amd import train as ptrain
+    out = str(tmp_path / "rp.pt")
+    mp.spawn(_rp_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    got = torch.load(out)
+    d, mk = _rp_data()
+    want = ptrain.relative_preference(d, mk, idt=True)
+    assert torch.equal(got["rp"], want)
+    solo = ptrain.relative_preference(d[:1], mk[:1], idt=True)
+    assert not torch.equal(solo, want)                  # the fixture does distinguish local from global
+    st = ptrain.LossState(torch.device("cpu"))
+    st.epoch_dist_m += (d * mk).sum(0)
+    assert torch.allclose(st.end_epoch(1), got["rp_epoch"]) and torch.allclose(st.imb_beta, got["beta"])
+
+
 def test_single_process_reducer_is_a_noop():
     sys.path.insert(0, ROOT)
     from passion_amd import parallel
