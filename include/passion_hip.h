@@ -175,6 +175,11 @@ int passion_attn_pv_bwd(const float* probs, const void* qkv, const void* dout, i
 int passion_attn_scores_bwd(const float* probs, float* dprobs, const void* qkv, int dtype, int B,
                             int N, int H, int Dh, float scale, void* dqkv, void* stream);
 
+/* Attention dropout (nn.Dropout on the attention probabilities, code/models/mmformer.py:222) in one pass and without a
+ * stored mask: y[i] = keep(i) ? x[i] / (1 - p) : 0 with keep(i) ~ Bernoulli(1 - p) drawn from a counter-based hash of
+ * (seed, i).  The same (seed, p) reproduces the mask, which is how the backward applies it to dprobs.  y may alias x. */
+int passion_dropout(const float* x, float* y, int64_t n, float p, uint64_t seed, void* stream);
+
 /* ---- RFNet (post-norm backbone) streaming ops -------------------------------------------------------
  * norm_act: out[b][v][out_coff + c] = sum_k LeakyReLU((x_k - mean_k) * rstd_k), k = 1 or 2 inputs (x1 may be
  * NULL).  Materialises general_conv3d's Conv->IN->LReLU output (code/models/blocks.py:366-370) where a

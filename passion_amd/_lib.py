@@ -80,6 +80,7 @@ SIGNATURES = {
                                     c_void_p, c_void_p]),
     "passion_attn_pv_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                     c_int, c_void_p, c_void_p, c_void_p]),
+    "passion_dropout": (c_int, [c_void_p, c_void_p, c_int64, ctypes.c_float, ctypes.c_uint64, c_void_p]),
     "passion_attn_scores_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                         c_int, c_float, c_void_p, c_void_p]),
     "passion_norm_act_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64, c_int,

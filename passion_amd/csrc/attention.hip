@@ -334,3 +334,43 @@ extern "C" int passion_attn_scores_bwd(const float* probs, float* dprobs, const 
     if (dtype == PASSION_BF16) return attn_scores_bwd<bf16_t>(probs, dprobs, qkv, B, N, H, Dh, scale, dqkv, (hipStream_t)stream);
     return -1007;
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Attention dropout, mask regenerated from (seed, index): torch's rand_like / >= / two multiplies were four passes over
+// the (B, H, N, N) f32 probabilities forward (168 M elements for the inter-modal transformer with the five PASSION
+// passes) plus a stored mask; this is one pass each way.  splitmix64 of (seed, index / 4) yields four 16-bit uniforms.
+namespace {
+__global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ x, float* __restrict__ y, long n4, long n, unsigned thr,
+                                                      float inv_keep, unsigned long long seed) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        unsigned long long z = (unsigned long long)i + seed * 0x9E3779B97F4A7C15ull;
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        z ^= z >> 31;
+        const long e = i * 4;
+        if (e + 3 < n) {
+            f32x4 v = *reinterpret_cast<const f32x4*>(x + e);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = (((unsigned)(z >> (16 * j)) & 0xffffu) >= thr) ? v[j] * inv_keep : 0.f;
+            *reinterpret_cast<f32x4*>(y + e) = v;
+        } else {
+            for (int j = 0; j < 4 && e + j < n; ++j)
+                y[e + j] = (((unsigned)(z >> (16 * j)) & 0xffffu) >= thr) ? x[e + j] * inv_keep : 0.f;
+        }
+    }
+}
+}  // namespace
+
+extern "C" int passion_dropout(const float* x, float* y, int64_t n, float p, uint64_t seed, void* stream) {
+    if (!(p >= 0.f && p < 1.f) || n < 0) return -1003;
+    if (n == 0) return 0;
+    if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) return -1005;
+    const long n4 = (n + 3) / 4;
+    const unsigned thr = (unsigned)(p * 65536.0f + 0.5f);          // keep when the 16-bit uniform >= p * 2^16
+    long gx = (n4 + 255) / 256;
+    if (gx > 65536) gx = 65536;
+    hipLaunchKernelGGL(dropout_kernel, dim3((unsigned)gx), dim3(256), 0, (hipStream_t)stream, x, y, n4, (long)n, thr, 1.0f / (1.0f - p),
+                       (unsigned long long)seed);
+    LAUNCH_RET();
+    return 0;
+}

@@ -572,21 +572,22 @@ class AttentionFn(torch.autograd.Function):
         probs = torch.empty(B, heads, N, N, dtype=torch.float32, device=qkv.device)
         L.check(lib.passion_attn_scores_fwd(_p(qkv), dt, B, N, heads, Dh, float(scale), _p(probs), L.stream_ptr()),
                 "passion_attn_scores_fwd")
-        keep = None
-        pd = probs
-        if drop_p > 0.0:
-            keep = (torch.rand_like(probs) >= drop_p)
-            pd = probs * keep * (1.0 / (1.0 - drop_p))
+        pd, seed = probs, 0
+        if drop_p > 0.0:     # one pass, mask regenerated from the seed in backward (no rand / compare / mask tensors)
+            seed = int(torch.empty((), dtype=torch.int64).random_().item())      # CPU generator: follows torch.manual_seed
+            pd = torch.empty_like(probs)
+            L.check(lib.passion_dropout(_p(probs), _p(pd), probs.numel(), float(drop_p), seed & (2 ** 64 - 1), L.stream_ptr()),
+                    "passion_dropout")
         out = torch.empty(B, N, heads * Dh, dtype=qkv.dtype, device=qkv.device)
         L.check(lib.passion_attn_pv_fwd(_p(pd), _p(qkv), dt, B, N, heads, Dh, _p(out), L.stream_ptr()),
                 "passion_attn_pv_fwd")
-        ctx.heads, ctx.scale, ctx.drop_p = heads, float(scale), drop_p
-        ctx.save_for_backward(qkv, probs, pd if keep is not None else None, keep)
+        ctx.heads, ctx.scale, ctx.drop_p, ctx.seed = heads, float(scale), drop_p, seed
+        ctx.save_for_backward(qkv, probs, pd if drop_p > 0.0 else None)
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        qkv, probs, pd, keep = ctx.saved_tensors
+        qkv, probs, pd = ctx.saved_tensors
         B, N, C3 = qkv.shape
         H = ctx.heads
         Dh = C3 // 3 // H
@@ -597,8 +598,9 @@ class AttentionFn(torch.autograd.Function):
         dprobs = torch.empty_like(probs)
         L.check(lib.passion_attn_pv_bwd(_p(pd if pd is not None else probs), _p(qkv), _p(dout), dt, B, N, H, Dh,
                                         _p(dprobs), _p(dqkv), L.stream_ptr()), "passion_attn_pv_bwd")
-        if keep is not None:
-            dprobs = dprobs * keep * (1.0 / (1.0 - ctx.drop_p))
+        if pd is not None:           # the same mask, in place
+            L.check(lib.passion_dropout(_p(dprobs), _p(dprobs), dprobs.numel(), float(ctx.drop_p), ctx.seed & (2 ** 64 - 1),
+                                        L.stream_ptr()), "passion_dropout")
         L.check(lib.passion_attn_scores_bwd(_p(probs), _p(dprobs), _p(qkv), dt, B, N, H, Dh, ctx.scale, _p(dqkv),
                                             L.stream_ptr()), "passion_attn_scores_bwd")
         return dqkv, None, None, None

@@ -433,3 +433,54 @@ def test_fused_adamw_matches_torch(amsgrad):
         assert relerr(sa["state"][k]["exp_avg_sq"], sb["state"][k]["exp_avg_sq"]) < 2e-6
         assert float(sa["state"][k]["step"]) == float(sb["state"][k]["step"])
     ob.load_state_dict(sa)      # interchangeable
+
+
+def test_dropout_mask_is_bernoulli_and_reproducible():
+    """passion_dropout: keep rate 1 - p, survivors scaled by 1 / (1 - p), the mask is a pure function of (seed, index)
+    -- the backward of the attention op applies it again to dprobs -- and different seeds give independent masks"""
+    from ctypes import c_void_p
+    from passion_amd import _lib as L
+    dev = _dev()
+    lib = L.load()
+    n, p = 1_000_003, 0.1
+    x = torch.rand(n, device=dev) + 0.5
+
+    def run(src, seed):
+        y = torch.empty_like(src)
+        L.check(lib.passion_dropout(c_void_p(src.data_ptr()), c_void_p(y.data_ptr()), n, p, seed, L.stream_ptr()), "passion_dropout")
+        return y
+
+    y1, y2, y3 = run(x, 12345), run(x, 12345), run(x, 999)
+    assert torch.equal(y1, y2)
+    keep = y1 != 0
+    assert abs(float(keep.float().mean()) - (1 - p)) < 3e-3
+    assert torch.allclose(y1[keep], x[keep] / (1 - p), rtol=1e-6)
+    both = float((keep & (y3 != 0)).float().mean())
+    assert abs(both - (1 - p) ** 2) < 3e-3                      # independent masks
+    g = run(torch.ones_like(x), 12345)                          # what backward multiplies dprobs with
+    assert torch.equal(g != 0, keep)
+    # no structure along the index: neighbouring elements (which share one hash value) are uncorrelated
+    k = keep.float()
+    c = float(((k[:-1] - (1 - p)) * (k[1:] - (1 - p))).mean()) / (p * (1 - p))
+    assert abs(c) < 5e-3
+
+
+def test_attention_dropout_backward_uses_the_forward_mask():
+    from passion_amd import ops
+    dev = _dev()
+    torch.manual_seed(3)
+    B, N, H, Dh = 1, 64, 2, 16
+    qkv = torch.randn(B, N, 3 * H * Dh, device=dev, requires_grad=True)
+    torch.manual_seed(11)
+    out = ops.attention(qkv, H, Dh ** -0.5, 0.5)
+    (g,) = torch.autograd.grad(out.sum(), qkv)
+    # finite differences along a random direction see the same (fixed-seed) mask
+    d = torch.randn_like(qkv) * 1e-3
+
+    def f(t):
+        torch.manual_seed(11)
+        return float(ops.attention(t, H, Dh ** -0.5, 0.5).double().sum())
+
+    num = (f(qkv.detach() + d) - f(qkv.detach() - d)) / 2
+    ana = float((g * d).double().sum())
+    assert abs(num - ana) < 2e-2 * max(abs(num), abs(ana), 1e-3)
