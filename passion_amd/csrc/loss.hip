@@ -5,6 +5,7 @@
 //   proto                           <- prototype_passion_loss_bs                   (criterions.py:144-180)
 // All are HBM-bound streaming reductions over D*H*W: one pass, 16-byte loads per voxel, per-thread
 // register partials, wavefront shuffle reduction, one atomic per workgroup per scalar.
+#include <cstdlib>
 #include "common.h"
 #include "passion_hip.h"
 
@@ -443,10 +444,13 @@ __global__ void proto_bwd2_kernel(const float* __restrict__ tg, long V, const fl
     }
 }
 
+int g_red_blocks = []() { const char* e = getenv("PASSION_RED_BLOCKS"); return e && atoi(e) > 0 ? atoi(e) : 512; }();
 inline int vgrid(long V) { return (int)hmin((V + 255) / 256, 2048); }
 // reductions end with one atomic per block per scalar on a handful of addresses: same-address atomics serialise
-// (~50-100 ns each), so keep the block count low and give each block more voxels
-inline int vgrid_red(long V) { return (int)hmin((V + 256 * 4 - 1) / (256 * 4), 128); }
+// (~50-100 ns each), which argues for few blocks -- but 128 blocks left half of the 256 CUs idle and one workgroup per CU
+// cannot hide its load latency (kl_fwd 46 us, proto_bwd1 231 us per launch at 128^3): 512 blocks measured +5 % on the whole
+// PASSION step, 1024 the same (PASSION_RED_BLOCKS to override)
+inline int vgrid_red(long V) { return (int)hmin((V + 256 * 4 - 1) / (256 * 4), g_red_blocks); }
 
 }  // namespace
 
