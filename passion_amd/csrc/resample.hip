@@ -25,19 +25,22 @@ __device__ __forceinline__ Src src_index(int o, float scale, int in) {
 
 __host__ __device__ inline float axis_scale(int in, int out) { return out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f; }
 
-template <typename T, int VEC>
+// IT: index type of the flattened (b, d, h, w, channel vector) index.  `unsigned` whenever the tensor has < 2^32 vectors:
+// the five div/mod pairs per element are then 32-bit (a 64-bit division by a run-time value is ~100 instructions each
+// and made this gather VALU-bound).
+template <typename T, int VEC, typename IT>
 __global__ __launch_bounds__(256) void upsample_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int B, int D,
                                                            int H, int W, int C, int k) {
     const int Do = D * k, Ho = H * k, Wo = W * k, cvn = C / VEC;
     const float sd = axis_scale(D, Do), sh = axis_scale(H, Ho), sw = axis_scale(W, Wo);
-    const long total = (long)B * Do * Ho * Wo * cvn;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int cv = (int)(i % cvn);
-        long v = i / cvn;
-        const int ow = (int)(v % Wo); v /= Wo;
-        const int oh = (int)(v % Ho); v /= Ho;
-        const int od = (int)(v % Do);
-        const int b = (int)(v / Do);
+    const IT total = (IT)B * Do * Ho * Wo * cvn;
+    for (IT i = (IT)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (IT)gridDim.x * blockDim.x) {
+        const int cv = (int)(i % (IT)cvn);
+        IT v = i / (IT)cvn;
+        const int ow = (int)(v % (IT)Wo); v /= (IT)Wo;
+        const int oh = (int)(v % (IT)Ho); v /= (IT)Ho;
+        const int od = (int)(v % (IT)Do);
+        const int b = (int)(v / (IT)Do);
         const Src a = src_index(od, sd, D), e = src_index(oh, sh, H), f = src_index(ow, sw, W);
         const T* xb = x + (long)b * D * H * W * C + cv * VEC;
         float r[VEC];
@@ -62,7 +65,7 @@ __global__ __launch_bounds__(256) void upsample_fwd_kernel(const T* __restrict__
 #pragma unroll
             for (int j = 0; j < VEC; ++j) r[j] += dl[p] * rh[j];
         }
-        VecIO<T, VEC>::store(y + i * VEC, r);
+        VecIO<T, VEC>::store(y + (long)i * VEC, r);
     }
 }
 
@@ -175,20 +178,20 @@ int upsample_bwd_separable(const T* dy, T* dx, int B, int D, int H, int W, int C
 
 // k <= 2: one thread per (input voxel, 4-channel vector).  At most 5 output indices per axis can reference an
 // input index; their weights are evaluated once per axis (15 evaluations) instead of once per candidate triple.
-template <typename T, int VEC>
+template <typename T, int VEC, typename IT>
 __global__ __launch_bounds__(256) void upsample_bwd_k2_kernel(const T* __restrict__ dy, T* __restrict__ dx, int B, int D,
                                                               int H, int W, int C, int k) {
     constexpr int NC = 6;
     const int Do = D * k, Ho = H * k, Wo = W * k, cvn = C / VEC;
     const float sd = axis_scale(D, Do), sh = axis_scale(H, Ho), sw = axis_scale(W, Wo);
-    const long items = (long)B * D * H * W * cvn;
-    for (long it = (long)blockIdx.x * blockDim.x + threadIdx.x; it < items; it += (long)gridDim.x * blockDim.x) {
-        const int cv = (int)(it % cvn);
-        long v = it / cvn;
-        const int iw = (int)(v % W); v /= W;
-        const int ih = (int)(v % H); v /= H;
-        const int id = (int)(v % D);
-        const int b = (int)(v / D);
+    const IT items = (IT)B * D * H * W * cvn;
+    for (IT it = (IT)blockIdx.x * blockDim.x + threadIdx.x; it < items; it += (IT)gridDim.x * blockDim.x) {
+        const int cv = (int)(it % (IT)cvn);
+        IT v = it / (IT)cvn;
+        const int iw = (int)(v % (IT)W); v /= (IT)W;
+        const int ih = (int)(v % (IT)H); v /= (IT)H;
+        const int id = (int)(v % (IT)D);
+        const int b = (int)(v / (IT)D);
         // outputs that can reference input i have src in (i-1, i+1), i.e. o in ((i-1)/scale, (i+1)/scale): a window of
         // 2/scale ~ 4.03 indices for k = 2.  Slots o = lo + j, j < NC, with statically indexed weights (zero = skip).
         const int dlo = max(0, (int)floorf((float)(id - 1) / sd)), hlo = max(0, (int)floorf((float)(ih - 1) / sh)),
@@ -223,11 +226,27 @@ __global__ __launch_bounds__(256) void upsample_bwd_k2_kernel(const T* __restric
                 }
             }
         }
-        VecIO<T, VEC>::store(dx + it * VEC, acc);
+        VecIO<T, VEC>::store(dx + (long)it * VEC, acc);
     }
 }
 
 }  // namespace
+
+// 32-bit index arithmetic unless the tensor (or the grid-stride overshoot) would overflow it
+#define FWD_LAUNCH(T, VEC, xin, yout)                                                                                              \
+    do {                                                                                                                           \
+        if (total < (1L << 31))                                                                                                    \
+            hipLaunchKernelGGL((upsample_fwd_kernel<T, VEC, unsigned>), dim3(blocks), dim3(256), 0, st, xin, yout, B, D, H, W, C, k); \
+        else                                                                                                                       \
+            hipLaunchKernelGGL((upsample_fwd_kernel<T, VEC, long>), dim3(blocks), dim3(256), 0, st, xin, yout, B, D, H, W, C, k);   \
+    } while (0)
+#define K2_LAUNCH(T, VEC, dyin, dxout)                                                                                               \
+    do {                                                                                                                             \
+        if (items < (1L << 31))                                                                                                      \
+            hipLaunchKernelGGL((upsample_bwd_k2_kernel<T, VEC, unsigned>), dim3(blocks), dim3(256), 0, st, dyin, dxout, B, D, H, W, C, k); \
+        else                                                                                                                         \
+            hipLaunchKernelGGL((upsample_bwd_k2_kernel<T, VEC, long>), dim3(blocks), dim3(256), 0, st, dyin, dxout, B, D, H, W, C, k);   \
+    } while (0)
 
 extern "C" int passion_upsample_fwd(const void* x, void* y, int dtype, int B, int D, int H, int W, int C, int k,
                                     void* stream) {
@@ -237,11 +256,11 @@ extern "C" int passion_upsample_fwd(const void* x, void* y, int dtype, int B, in
     const int blocks = (int)hmin((total + 255) / 256, 16384);
     hipStream_t st = (hipStream_t)stream;
     if (dtype == PASSION_F32)
-        hipLaunchKernelGGL((upsample_fwd_kernel<float, 4>), dim3(blocks), dim3(256), 0, st, (const float*)x, (float*)y, B, D, H, W, C, k);
+        FWD_LAUNCH(float, 4, (const float*)x, (float*)y);
     else if (v8)
-        hipLaunchKernelGGL((upsample_fwd_kernel<bf16_t, 8>), dim3(blocks), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y, B, D, H, W, C, k);
+        FWD_LAUNCH(bf16_t, 8, (const bf16_t*)x, (bf16_t*)y);
     else if (dtype == PASSION_BF16)
-        hipLaunchKernelGGL((upsample_fwd_kernel<bf16_t, 4>), dim3(blocks), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y, B, D, H, W, C, k);
+        FWD_LAUNCH(bf16_t, 4, (const bf16_t*)x, (bf16_t*)y);
     else
         return -1007;
     LAUNCH_RET();
@@ -268,11 +287,11 @@ extern "C" int passion_upsample_bwd(const void* dy, void* dx, int dtype, int B, 
         const bool v8 = dtype == PASSION_BF16 && C % 8 == 0;
         const int blocks = (int)hmin(((v8 ? items / 2 : items) + 255) / 256, 16384);
         if (dtype == PASSION_F32)
-            hipLaunchKernelGGL((upsample_bwd_k2_kernel<float, 4>), dim3(blocks), dim3(256), 0, st, (const float*)dy, (float*)dx, B, D, H, W, C, k);
+            K2_LAUNCH(float, 4, (const float*)dy, (float*)dx);
         else if (v8)
-            hipLaunchKernelGGL((upsample_bwd_k2_kernel<bf16_t, 8>), dim3(blocks), dim3(256), 0, st, (const bf16_t*)dy, (bf16_t*)dx, B, D, H, W, C, k);
+            K2_LAUNCH(bf16_t, 8, (const bf16_t*)dy, (bf16_t*)dx);
         else if (dtype == PASSION_BF16)
-            hipLaunchKernelGGL((upsample_bwd_k2_kernel<bf16_t, 4>), dim3(blocks), dim3(256), 0, st, (const bf16_t*)dy, (bf16_t*)dx, B, D, H, W, C, k);
+            K2_LAUNCH(bf16_t, 4, (const bf16_t*)dy, (bf16_t*)dx);
         else
             return -1007;
     } else {
