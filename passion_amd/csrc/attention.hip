@@ -203,7 +203,61 @@ int launch_gemm(const GemmP& p, int nbatch, hipStream_t st) {
     return 0;
 }
 
-// one wavefront per row, in place
+// one wavefront per row, in place, the row held in registers: one read and one write of the (B, H, N, N) scores instead of
+// three reads and two writes (N = 512 intra-modal, 2048 inter-modal: NV = N / 256 float4 per lane)
+template <int NV>
+__global__ __launch_bounds__(256) void row_softmax_reg_kernel(float* __restrict__ s, long rows) {
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    f32x4* r = reinterpret_cast<f32x4*>(s + row * (NV * 256)) + lane;
+    f32x4 v[NV];
+    float m = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        v[j] = r[j * 64];
+        m = fmaxf(m, fmaxf(fmaxf(v[j][0], v[j][1]), fmaxf(v[j][2], v[j][3])));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < NV; ++j)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { v[j][c] = expf(v[j][c] - m); sum += v[j][c]; }
+    sum = wave_sum(sum);
+    const float inv = 1.f / sum;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) r[j * 64] = v[j] * inv;
+}
+
+template <int NV>
+__global__ __launch_bounds__(256) void row_softmax_bwd_reg_kernel(const float* __restrict__ pr, float* __restrict__ dp, long rows,
+                                                                  float scale) {
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const f32x4* p = reinterpret_cast<const f32x4*>(pr + row * (NV * 256)) + lane;
+    f32x4* g = reinterpret_cast<f32x4*>(dp + row * (NV * 256)) + lane;
+    f32x4 pv[NV], gv[NV];
+    float dot = 0.f;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        pv[j] = p[j * 64]; gv[j] = g[j * 64];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) dot += pv[j][c] * gv[j][c];
+    }
+    dot = wave_sum(dot);
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        f32x4 o;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) o[c] = scale * pv[j][c] * (gv[j][c] - dot);
+        g[j * 64] = o;
+    }
+}
+
+// any row length: three passes through memory
 __global__ __launch_bounds__(256) void row_softmax_kernel(float* __restrict__ s, long rows, int n) {
     const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -246,7 +300,12 @@ int attn_scores(const void* qkv, int B, int N, int H, int Dh, float scale, float
     int rc = launch_gemm<T, T, float>(p, B * H, st);
     if (rc) return rc;
     const long rows = (long)B * H * N;
-    hipLaunchKernelGGL(row_softmax_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, probs, rows, N);
+    const dim3 grid((unsigned)((rows + 3) / 4));
+    if (N == 2048) hipLaunchKernelGGL(row_softmax_reg_kernel<8>, grid, dim3(256), 0, st, probs, rows);
+    else if (N == 1024) hipLaunchKernelGGL(row_softmax_reg_kernel<4>, grid, dim3(256), 0, st, probs, rows);
+    else if (N == 512) hipLaunchKernelGGL(row_softmax_reg_kernel<2>, grid, dim3(256), 0, st, probs, rows);
+    else if (N == 256) hipLaunchKernelGGL(row_softmax_reg_kernel<1>, grid, dim3(256), 0, st, probs, rows);
+    else hipLaunchKernelGGL(row_softmax_kernel, grid, dim3(256), 0, st, probs, rows, N);
     LAUNCH_RET();
     return 0;
 }
@@ -290,8 +349,12 @@ int attn_scores_bwd(const float* probs, float* dprobs, const void* qkv, int B, i
                     void* dqkv, hipStream_t st) {
     const long rs = 3L * H * Dh;
     const long rows = (long)B * H * N;
-    hipLaunchKernelGGL(row_softmax_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, probs, dprobs, rows,
-                       N, scale);
+    const dim3 sgrid((unsigned)((rows + 3) / 4));
+    if (N == 2048) hipLaunchKernelGGL(row_softmax_bwd_reg_kernel<8>, sgrid, dim3(256), 0, st, probs, dprobs, rows, scale);
+    else if (N == 1024) hipLaunchKernelGGL(row_softmax_bwd_reg_kernel<4>, sgrid, dim3(256), 0, st, probs, dprobs, rows, scale);
+    else if (N == 512) hipLaunchKernelGGL(row_softmax_bwd_reg_kernel<2>, sgrid, dim3(256), 0, st, probs, dprobs, rows, scale);
+    else if (N == 256) hipLaunchKernelGGL(row_softmax_bwd_reg_kernel<1>, sgrid, dim3(256), 0, st, probs, dprobs, rows, scale);
+    else hipLaunchKernelGGL(row_softmax_bwd_kernel, sgrid, dim3(256), 0, st, probs, dprobs, rows, N, scale);
     LAUNCH_RET();
     GemmP p;
     // dQ[q][d] = sum_key dS[q][key] K[key][d]

@@ -376,7 +376,7 @@ def test_proto(dtype, drop_class, Cf):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("N", [8, 125, 256])
+@pytest.mark.parametrize("N", [8, 125, 256, 512, 2048])      # 256 / 512 / 1024 / 2048: register-resident softmax rows
 def test_attention(N, dtype):
     from passion_amd import ops
     dev = _dev()
