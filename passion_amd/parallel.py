@@ -86,6 +86,7 @@ class GradReducer:
         self.overlap = overlap and ctx.world > 1 and hasattr(torch.Tensor, "register_post_accumulate_grad_hook")
         self._pending = [len(b) for b in self.buckets]       # gradients still missing per bucket in this backward
         self._works = [None] * len(self.buckets)
+        self._next = 0                                       # first bucket that has not been launched in this backward
         self._streams = [set() for _ in self.buckets]        # streams that produced gradients of the bucket in this backward
         self._on_gpu = self.params[0].is_cuda
         if ctx.world > 1:
@@ -101,8 +102,12 @@ class GradReducer:
             if self._on_gpu:
                 self._streams[bi].add(_raw_stream())     # raw handle: a Stream object costs 10 us to build, per parameter
             self._pending[bi] -= 1
-            if self._pending[bi] == 0:
-                self._launch(bi)
+            # Collectives must be issued in the same order on every rank.  Readiness order can differ between ranks (a
+            # parameter that got no gradient on one of them), so buckets are launched strictly by index: bucket k goes out
+            # once it is complete AND every bucket before it has gone out; the rest follows in all_reduce_grads().
+            while self._next < len(self.buckets) and self._pending[self._next] == 0:
+                self._launch(self._next)
+                self._next += 1
         return hook
 
     def _launch(self, bi):
@@ -122,9 +127,8 @@ class GradReducer:
     def all_reduce_grads(self):
         if self.ctx.world == 1:
             return
-        for bi in range(len(self.buckets)):
-            if self._works[bi] is None:                  # not (completely) produced by this backward, or overlap off
-                self._launch(bi)
+        for bi in range(self._next, len(self.buckets)):  # not (completely) produced by this backward, or overlap off
+            self._launch(bi)
         for bi, (bucket, flat) in enumerate(zip(self.buckets, self.flat)):
             self._works[bi].wait()
             views = flat.split([p.numel() for p in bucket])
@@ -135,6 +139,7 @@ class GradReducer:
                     p.grad.copy_(v.view_as(p))
         self._pending = [len(b) for b in self.buckets]
         self._works = [None] * len(self.buckets)
+        self._next = 0
 
 
 def all_reduce_sum_(t):

@@ -110,6 +110,52 @@ def test_relative_preference_and_epoch_update_span_the_global_batch(tmp_path):
     assert torch.allclose(st.end_epoch(1), got["rp_epoch"]) and torch.allclose(st.imb_beta, got["beta"])
 
 
+def _skip_worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    from passion_amd import parallel
+    ctx = parallel.init(backend="gloo")
+    torch.manual_seed(3)
+    l1, l2, l3 = nn.Linear(6, 6), nn.Linear(6, 6), nn.Linear(6, 6)
+    net = nn.ModuleList([l1, l2, l3])
+    red = parallel.GradReducer(net, ctx, bucket_mb=0)
+    x = torch.ones(2, 6) * (rank + 1)
+    h = l1(x)
+    if rank == 0:
+        h = l2(h)                  # rank 1 never touches l2: its buckets complete only in all_reduce_grads()
+    l3(h).sum().backward()
+    red.all_reduce_grads()
+    if rank == 0:
+        torch.save({k: p.grad.clone() for k, p in net.named_parameters()}, out)
+    torch.distributed.destroy_process_group()
+
+
+def test_buckets_go_out_in_the_same_order_on_every_rank(tmp_path):
+    """a parameter without gradient on ONE rank must not reorder that rank's collectives (they would pair up with the wrong
+    buckets of the other rank): launches are strictly by bucket index"""
+    out = str(tmp_path / "skip.pt")
+    mp.spawn(_skip_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    got = torch.load(out)
+    torch.manual_seed(3)
+    l1, l2, l3 = nn.Linear(6, 6), nn.Linear(6, 6), nn.Linear(6, 6)
+    want = {}
+    for rank in range(2):
+        for m in (l1, l2, l3):
+            m.zero_grad()
+        x = torch.ones(2, 6) * (rank + 1)
+        h = l1(x)
+        if rank == 0:
+            h = l2(h)
+        l3(h).sum().backward()
+        for i, m in enumerate((l1, l2, l3)):
+            for n, p in m.named_parameters():
+                if p.grad is not None:
+                    want[f"{i}.{n}"] = want.get(f"{i}.{n}", 0) + p.grad.clone()
+    for k, w in want.items():
+        assert torch.allclose(got[k], w, atol=1e-6), k
+
+
 def test_single_process_reducer_is_a_noop():
     sys.path.insert(0, ROOT)
     from passion_amd import parallel
