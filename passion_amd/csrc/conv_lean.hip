@@ -11,6 +11,7 @@
 //     the staging threads, LDS tap offsets of the MFMA lanes, output voxel offsets of the epilogue lanes;
 //   * interior bricks (no padding involved) take a branch-free addressing path: address = brick base + constant;
 //   * the next step's brick is fetched into registers while the matrix cores work on the current one.
+#include <cstdlib>
 #include "conv_common.h"
 #include "prof.h"
 
@@ -686,7 +687,8 @@ int launch_lean_one(ConvK& k, int K8, int gy, hipStream_t st) {
     const int nchunk = (K8 + G::NC8 - 1) / G::NC8;
     const int fixed = G::BRICK + DESC_BYTES;
     k.wres = (nchunk == 1 || fixed + nchunk * wchunk <= 48 * 1024) ? 1 : 0;
-    const int bytes = fixed + (k.wres ? nchunk : 1) * wchunk;
+    static const int lds_pad = []() { const char* e = getenv("PASSION_LDS_PAD_KB"); return e ? atoi(e) * 1024 : 0; }();   // occupancy experiments
+    const int bytes = fixed + (k.wres ? nchunk : 1) * wchunk + lds_pad;
     // persistent workgroups: about g_conv_target of them per launch, each walking `per` consecutive bricks of one sample
     const int tiles_per_b = k.tilesD * k.tilesH * k.tilesW;
     const long tiles = (long)k.B * tiles_per_b;
