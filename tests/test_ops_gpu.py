@@ -168,16 +168,20 @@ def test_conv_f32_logit_head(segC, Cout, k, norm):
         assert relerr(nc(xd[i].grad.float()), xr[i].grad) < tol * 3
 
 
-def test_conv_batched_passes():
+# 3x3x3 over two segments, and the shape of the fusion blocks' first conv (blocks.py:536): 1x1x1 over four modality segments
+@pytest.mark.parametrize("ks,nseg,C", [(3, 2, 8), (1, 4, 8), (1, 4, 16)])
+def test_conv_batched_passes(ks, nseg, C):
     """SegIn.bmod: P masked passes over the same B samples in one launch == P separate launches, gradients summed"""
     from passion_amd import ops
     dev = _dev()
-    B, P, C, Cout, D, H, W = 2, 3, 8, 8, 8, 8, 16
+    B, P, Cout, D, H, W = 2, 3, C, 8, 8, 16
     g = torch.Generator().manual_seed(5)
-    xs = [(torch.randn(B, D, H, W, C, generator=g) * 1.3).to(dev, torch.bfloat16) for _ in range(2)]
-    w = (torch.randn(Cout, 2 * C, 3, 3, 3, generator=g) / (2 * C * 27) ** 0.5).to(dev)
+    xs = [(torch.randn(B, D, H, W, C, generator=g) * 1.3).to(dev, torch.bfloat16) for _ in range(nseg)]
+    w = (torch.randn(Cout, nseg * C, ks, ks, ks, generator=g) / (nseg * C * ks ** 3) ** 0.5).to(dev)
     b = torch.randn(Cout, generator=g).to(dev)
-    masks = torch.tensor([[1, 1], [1, 0], [1, 1], [0, 1], [0, 0], [1, 1]], dtype=torch.bool, device=dev)   # (P*B, 2)
+    masks = (torch.rand(P * B, nseg, generator=g) > 0.35).to(dev)   # (P*B, nseg)
+    masks[0] = True
+    masks[4] = False
     gy = torch.randn(P * B, D, H, W, Cout, generator=g).to(dev, torch.bfloat16)
     stats = [ops.instnorm_stats(x) for x in xs]
 
@@ -186,14 +190,14 @@ def test_conv_batched_passes():
         wl, bl = w.clone().requires_grad_(True), b.clone().requires_grad_(True)
         if batched:
             segs = [ops.SegIn(x, stats=st, mask=masks, mask_col=i, bmod=B) for i, (x, st) in enumerate(zip(xl, stats))]
-            y = ops.conv_block(segs, wl, bl, D, H, W)
+            y = ops.conv_block(segs, wl, bl, D, H, W, ksize=ks)
             y.backward(gy)
         else:
             ys = []
             for p_ in range(P):
                 mk = masks[p_ * B:(p_ + 1) * B].contiguous()
                 segs = [ops.SegIn(x, stats=st, mask=mk, mask_col=i) for i, (x, st) in enumerate(zip(xl, stats))]
-                ys.append(ops.conv_block(segs, wl, bl, D, H, W))
+                ys.append(ops.conv_block(segs, wl, bl, D, H, W, ksize=ks))
             y = torch.cat(ys, 0)
             y.backward(gy)
         return y.detach().float(), [x.grad.float() for x in xl], wl.grad, bl.grad
