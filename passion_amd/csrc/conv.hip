@@ -557,6 +557,7 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, int Cin, int Cou
 int fill_params(const passion_conv_desc_t* d, ConvK& k) {
     if (!d) return -1001;
     k.dbg = 0;
+    k.bd_rows = 0; k.bd_k8 = 0;
     k.y_f32 = 0;
     if (d->ksize != 1 && d->ksize != 3) return -1002;
     if (d->stride != 1 && d->stride != 2) return -1003;
@@ -695,8 +696,61 @@ static bool use_padout(const ConvK& k, const passion_conv_desc_t* d) {
         if (k.seg[s].dx) { any = true; if (k.seg[s].bmod > 0) return false; }    // batched passes: summed by the plain finish kernel
     return any;
 }
+// Batched passes through a 1x1x1 conv (the fusion blocks' first conv, reference blocks.py:536, run as teacher + four
+// students): InstanceNorm backward and the conv transpose are linear in dY and the only per-pass quantity is the 0/1
+// modality mask, so  sum_p dX_p[segment i] = Backward_i( sum_p mask[p][i] dY_p ).  The P masked sums (one per segment) are
+// laid side by side as a [bmod][V][nseg * Cout] tensor and ONE dgrad runs over the physical samples with block-diagonal
+// weights (segment i's rows see only its own Cout-block): dX is written once instead of P times and re-read P times.
+namespace pconv { int g_conv_blockdiag = 1; }    // PASSION_CONV_BLOCKDIAG=0: per-pass gradients + summing finish (A/B)
+static bool use_blockdiag(const ConvK& k, const passion_conv_desc_t* d) {
+    if (!pconv::g_conv_lean || !pconv::g_conv_blockdiag || g_passion_force_f32_mfma) return false;
+    if (d->ksize != 1 || d->x_dtype != PASSION_BF16 || d->y_dtype != PASSION_BF16 || k.Cout % 8) return false;
+    const int bm = k.seg[0].bmod, cs = k.seg[0].C;
+    if (bm <= 0 || k.B % bm || k.B / bm < 2 || cs % 8) return false;
+    for (int s = 0; s < k.nseg; ++s)
+        if (!k.seg[s].dx || k.seg[s].bmod != bm || k.seg[s].C != cs || k.seg[s].cbase != s * cs) return false;
+    return (long)k.nseg * k.Cout / 8 <= 32;
+}
+static long blockdiag_bytes(const ConvK& k) {     // bf16 [bmod][V][nseg * Cout]
+    return ((long)k.seg[0].bmod * k.Di * k.Hi * k.Wi * k.nseg * k.Cout * 2 + 15) / 16 * 16;
+}
+struct PassSumArgs { const uint8_t* mask[PASSION_MAX_SEG]; int col[PASSION_MAX_SEG], ld[PASSION_MAX_SEG]; };
+// one thread per (sample b, voxel v, 8-channel vector c8 of Cout): out[b][v][i * Cout + c8 * 8 ..] = sum_p mask[p*bm+b][i] dy[p*bm+b][v][..]
+__global__ __launch_bounds__(256) void pass_sum_kernel(const bf16_t* __restrict__ dy, bf16_t* __restrict__ out, PassSumArgs a, int P, int bm,
+                                                       long V, int Cout, int nseg) {
+    const int c8n = Cout / 8;
+    const long total = (long)bm * V * c8n;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int c8 = (int)(i % c8n);
+        const long bv = i / c8n;
+        const int b = (int)(bv / V);
+        float acc[PASSION_MAX_SEG][8];
+#pragma unroll
+        for (int s2 = 0; s2 < PASSION_MAX_SEG; ++s2)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[s2][j] = 0.f;
+        for (int p = 0; p < P; ++p) {
+            float v[8];
+            VecIO<bf16_t, 8>::load(dy + (((long)p * bm) * V + bv) * Cout + c8 * 8, v);
+#pragma unroll
+            for (int s2 = 0; s2 < PASSION_MAX_SEG; ++s2) {
+                if (s2 >= nseg) continue;
+                const bool on = !a.mask[s2] || a.mask[s2][((long)p * bm + b) * a.ld[s2] + a.col[s2]] != 0;
+                if (on) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc[s2][j] += v[j];
+                }
+            }
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < PASSION_MAX_SEG; ++s2)
+            if (s2 < nseg) VecIO<bf16_t, 8>::store(out + (bv * nseg + s2) * Cout + c8 * 8, acc[s2]);
+    }
+}
+
 // per-pass gradients of the batched-pass segments (SegD.bmod): [B virtual][V][C] each, summed over the passes by the finish
 static long pass_scratch_floats(const ConvK& k, const passion_conv_desc_t* d) {
+    if (use_blockdiag(k, d)) return blockdiag_bytes(k) / 4;
     const long es = d->x_dtype == PASSION_BF16 ? 2 : 4;
     long bytes = 0;
     for (int s = 0; s < k.nseg; ++s)
@@ -948,7 +1002,31 @@ extern "C" int passion_conv3d_bwd(const passion_conv_desc_t* d, const float* pac
     void* dxp = nullptr;
     // batched-pass segments: the dgrad writes the per-pass gradients into scratch, the finish kernel sums them into dx
     void* real_dx[PASSION_MAX_SEG] = {nullptr, nullptr, nullptr, nullptr};
-    {
+    const bool blockdiag = use_blockdiag(k, d);
+    if (blockdiag) {         // passes summed first (per segment, masked), one dgrad over the physical samples
+        const WgPlan w0 = plan_wgrad(k, d);
+        bf16_t* dycat = reinterpret_cast<bf16_t*>(sums + (long)2 * k.B * k.Cin * SUMS_REP +
+                                                  (long)w0.gx * ((long)k.Cout * k.Cin * nt + k.Cout) + (padout ? padout_floats(k) : 0));
+        const int bm = k.seg[0].bmod, P = k.B / bm;
+        const long V = (long)k.Di * k.Hi * k.Wi;
+        PassSumArgs pa;
+        for (int s = 0; s < PASSION_MAX_SEG; ++s) {
+            pa.mask[s] = s < k.nseg ? k.seg[s].mask : nullptr;
+            pa.col[s] = s < k.nseg ? k.seg[s].mask_col : 0;
+            pa.ld[s] = s < k.nseg ? k.seg[s].mask_ld : 0;
+        }
+        const long items = (long)bm * V * (k.Cout / 8);
+        hipLaunchKernelGGL(pass_sum_kernel, dim3((unsigned)hmin((items + 255) / 256, 8192)), dim3(256), 0, st,
+                           reinterpret_cast<const bf16_t*>(dy), dycat, pa, P, bm, V, k.Cout, k.nseg);
+        LAUNCH_RET();
+        k.bd_rows = k.seg[0].C;
+        k.bd_k8 = k.Cout / 8;
+        k.Cout = k.nseg * k.Cout;                    // K axis of the dgrad GEMM: one Cout-block per segment
+        k.B = bm;
+        k.dy = dycat;
+        for (int s = 0; s < k.nseg; ++s) { k.seg[s].mask = nullptr; k.seg[s].bmod = 0; }
+        k.tilesD = cdiv(k.Di, TD); k.tilesH = cdiv(k.Hi, TH); k.tilesW = cdiv(k.Wi, TW);
+    } else {
         const WgPlan w0 = plan_wgrad(k, d);
         char* gp = reinterpret_cast<char*>(sums + (long)2 * k.B * k.Cin * SUMS_REP + (long)w0.gx * ((long)k.Cout * k.Cin * nt + k.Cout) +
                                            (padout ? padout_floats(k) : 0));
@@ -981,6 +1059,10 @@ extern "C" int passion_conv3d_bwd(const passion_conv_desc_t* d, const float* pac
         if (padout) rc = 0;
         else if (d->x_dtype == PASSION_F32 && d->y_dtype == PASSION_F32)
             rc = launch_conv_geo<float, float, 1>(k, d->ksize, d->stride, mtiles, st);
+        else if (blockdiag) {
+            rc = launch_conv_lean(k, d->ksize, d->stride, 1, packed + f32_pack_floats(k.Cin, k.bd_k8 * 8, nt), st);
+            if (rc > 0) rc = -1018;              // planned for the lean kernel: must be covered
+        }
         else if (d->x_dtype == PASSION_BF16 && d->y_dtype == PASSION_BF16) {
             if (bf16_eligible(k, true) && !g_passion_force_f32_mfma)
                 rc = launch_conv_bf16(k, d->ksize, d->stride, true, packed + f32_pack_floats(k.Cin, k.Cout, nt), st);

@@ -43,6 +43,8 @@ struct ConvK {
     long wslot;            // wgrad: floats per workgroup slot of the partial slab ([dW | dbias])
     int sums_rep;          // dgrad: replicas of the InstanceNorm-backward sums this launch spreads its atomics over
     int per, wres;         // bf16 kernel: bricks per (persistent) workgroup; all chunks' weight fragments resident in LDS
+    int bd_rows, bd_k8;    // lean dgrad with block-diagonal weights (batched passes summed first, conv.hip): K block gb = (segment
+                           // gb / bd_k8, block gb % bd_k8 of the real Cout); rows of another segment (bd_rows each) read zero weights
     int dbg;               // developer timing switch (PASSION_CONV_DBG): bit0 skip staging, bit1 skip MFMA loop, bit2 skip epilogue
 };
 

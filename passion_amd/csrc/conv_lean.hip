@@ -217,8 +217,14 @@ __global__ __launch_bounds__(256) void conv_lean_kernel(ConvK p) {
         for (int v = tid; v < WV; v += 256) {
             const int row = v % (MT * 16), gg = (v / (MT * 16)) % 4, s = v / (MT * 16 * 4);
             const int q = 4 * s + gg, tap = q / NC8, blk = q % NC8;
-            const bool ok = (q < G::Q) && (c * NC8 + blk < K8);
-            dst[v] = ok ? wp[((long)tap * K8 + c * NC8 + blk) * p.Mpad + (mg * MT) * 16 + row] : zero8();
+            const int gb = c * NC8 + blk, rowg = (mg * MT) * 16 + row;
+            bool ok = (q < G::Q) && (gb < K8);
+            long src = ((long)tap * K8 + gb) * p.Mpad + rowg;
+            if (DG && p.bd_rows) {               // block-diagonal: K block gb = (segment, block of the real Cout); see conv.hip
+                ok = ok && (rowg / p.bd_rows == gb / p.bd_k8);
+                src = ((long)tap * p.bd_k8 + gb % p.bd_k8) * p.Mpad + rowg;
+            }
+            dst[v] = ok ? wp[src] : zero8();
         }
     };
     if (wres)
@@ -766,7 +772,8 @@ int launch_conv_lean(ConvK& k, int ksize, int stride, int mode, const void* pack
     if (K8 > MAXBLK) return 1;
     if (dgrad) {
         k.Mpad = pad16(k.Cin);
-        k.wpack = reinterpret_cast<const bf16_t*>(packed_bf16) + (long)ntap * pad8(k.Cin) * pad16(k.Cout);
+        const int cout_w = k.bd_rows ? k.bd_k8 * 8 : k.Cout;      // the packed images are those of the real weight
+        k.wpack = reinterpret_cast<const bf16_t*>(packed_bf16) + (long)ntap * pad8(k.Cin) * pad16(cout_w);
     } else {
         k.Mpad = pad16(k.Cout);
         k.wpack = packed_bf16;
