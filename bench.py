@@ -11,6 +11,8 @@ data-path collective).  Rank 0 prints ONE JSON line; besides the contract's fiel
   roofline     : the conv kernel family with the largest total time in the step (forward 3x3x3 / forward 1x1x1 /
                  dgrad / wgrad): algorithmic bytes (activations in + out + weights) / average launch time,
                  taken live with hipEvents on the launch stream inside the timed region; peak = 8 TB/s HBM3E.
+                 `avg_launch_ms_single_stream` / `frac_single_stream`: the same kernel in three extra steps with all work
+                 on one stream (no other stream's launches sharing the CUs) -- the figure a rocprofv3 summary shows.
                  (--graph replays the step as one HIP graph; hipEventElapsedTime cannot time event nodes of a graph, so
                  there the event pairs come from eager iterations of the same step right after the timed region.)
   cpu_baseline : the oracle (oracle/, a CPU restatement proven equal to the reference) timed on the
@@ -197,6 +199,23 @@ def main():
         torch.cuda.synchronize()
         ops.prof_enable(0)
 
+    # The same kernel without stream overlap: three more steps (every rank, the gradient all-reduce is collective) with the
+    # modality encoders / decoder_sep on the main stream.  Inside the timed region the launches of five streams share the CUs and
+    # stretch each other; rocprofv3 (whose interception makes the step host-bound) sees nearly stand-alone launches.  Reporting
+    # both lets the live number be checked against profiles/*kernel_stats.csv.
+    timed_recs = ops.prof_read() if not args.no_roofline else []
+    alone_recs = []
+    if want_events and live_events:
+        was = mmformer.ENC_STREAMS
+        mmformer.ENC_STREAMS = False
+        ops.prof_enable(1 << dom_kind)
+        for _ in range(3):
+            eager_step()
+        torch.cuda.synchronize()
+        ops.prof_enable(0)
+        mmformer.ENC_STREAMS = was
+        alone_recs = [r for r in ops.prof_read() if r[1] >= 0]
+
     if ctx.rank != 0:
         return
     out = {
@@ -213,7 +232,7 @@ def main():
                    "launch": "one HIP graph per step" if use_graph else "eager"},
     }
     if not args.no_roofline:
-        recs = [r for r in ops.prof_read() if r[1] >= 0]
+        recs = [r for r in timed_recs if r[1] >= 0]
         fam = {0: "fwd3", 1: "fwd1", 2: "dgrad", 3: "wgrad"}
         what = {0: "fused InstanceNorm+LeakyReLU+Conv3d 3x3x3 forward", 1: "fused InstanceNorm+LeakyReLU+Conv3d 1x1x1 forward",
                 2: "conv input gradient + LeakyReLU'/mask + InstanceNorm-backward sums",
@@ -234,9 +253,14 @@ def main():
             for r in recs:
                 fam_ms[fam[r[0]]] = fam_ms.get(fam[r[0]], 0.0) + r[1]
             copy_gbs = measured_copy_gbs(ctx.device)
+            ak = [r for r in alone_recs if r[4] == dom]
+            alone_ms = sum(r[1] for r in ak) / len(ak) if ak else None
+            alone_ach = (sum(r[2] for r in ak) / (sum(r[1] for r in ak) * 1e-3) / 1e9) if ak else None
             out["roofline"] = {"kernel": f"{dom} ({what[rk[0][0]]})", "bound": "hbm", "achieved": round(ach, 2),
                                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic,
                                "measured_copy_peak": round(copy_gbs, 1), "frac_of_measured_copy": round(ach / copy_gbs, 5),
+                               "avg_launch_ms_single_stream": round(alone_ms, 5) if alone_ms else None,
+                               "frac_single_stream": round(alone_ach / HBM_PEAK_GBS, 5) if alone_ach else None,
                                "launches_per_step": len(rk) // prof_steps, "avg_launch_ms": round(ms / len(rk), 5),
                                "algorithmic_bytes_per_launch": round(by / len(rk), 1),
                                "tflops": round(fl / (ms * 1e-3) / 1e12, 3),
