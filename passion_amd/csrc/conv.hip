@@ -313,10 +313,11 @@ __global__ __launch_bounds__(256) void in_bwd_finish_pad_kernel(T* __restrict__ 
     const bool present = mask ? (mask[(long)b * mask_ld + mask_col] != 0) : true;
     T* dxb = dx + (long)b * bstride;
     const T* xb = x + (long)bs * bstride;
-    const T* pb = dxp + (long)b * (D + 2) * (H + 2) * (W + 2) * Cin_tot + cbase;
+    const int Wp = pconv::pad8(W + 2);                     // row pitch of the padded scratch (conv_lean.hip MODE 2)
+    const T* pb = dxp + (long)b * (D + 2) * (H + 2) * Wp * Cin_tot + cbase;
     const int tpr = rowv < 256 ? rowv : 256;              // threads that work on one row; 256 / tpr rows in flight per block
     const int rpb = 256 / tpr, rsub = threadIdx.x / tpr, tin = threadIdx.x % tpr;
-    const long prow = (long)(W + 2) * Cin_tot, pplane = (long)(H + 2) * prow;
+    const long prow = (long)Wp * Cin_tot, pplane = (long)(H + 2) * prow;
     for (int r0 = blockIdx.x * rpb; r0 < D * H; r0 += gridDim.x * rpb) {
         const int r = r0 + rsub;
         if (r >= D * H || rsub >= rpb) continue;
@@ -757,8 +758,14 @@ static long pass_scratch_floats(const ConvK& k, const passion_conv_desc_t* d) {
         if (k.seg[s].dx && k.seg[s].bmod > 0) bytes += ((long)k.B * k.Di * k.Hi * k.Wi * k.seg[s].C * es + 15) / 16 * 16;
     return bytes / 4;
 }
+// scratch layout (floats): [InstanceNorm-backward sums | wgrad slab] then, from a 128-byte boundary, [padded-domain gradient]
+// [per-pass gradients or the masked pass sums]
+static long slab_end_floats(const ConvK& k, int gx, int nt) {
+    const long n = (long)2 * k.B * k.Cin * SUMS_REP + (long)gx * ((long)k.Cout * k.Cin * nt + k.Cout);
+    return (n + 31) / 32 * 32;
+}
 static long padout_floats(const ConvK& k) {     // bf16 [B][D+2][H+2][W+2][Cin]
-    return ((long)k.B * (k.Di + 2) * (k.Hi + 2) * (k.Wi + 2) * k.Cin + 1) / 2 + 4;
+    return (((long)k.B * (k.Di + 2) * (k.Hi + 2) * pad8(k.Wi + 2) * k.Cin + 1) / 2 + 4 + 31) / 32 * 32;      // rows padded to 8 voxels
 }
 
 extern "C" int64_t passion_conv_bwd_scratch_floats(const passion_conv_desc_t* d) {
@@ -766,8 +773,7 @@ extern "C" int64_t passion_conv_bwd_scratch_floats(const passion_conv_desc_t* d)
     if (fill_params(d, k)) return -1;
     const WgPlan w = plan_wgrad(k, d);
     const int64_t nt = (int64_t)d->ksize * d->ksize * d->ksize;
-    return (int64_t)2 * k.B * k.Cin * SUMS_REP + (int64_t)w.gx * ((int64_t)k.Cout * k.Cin * nt + k.Cout) +
-           (use_padout(k, d) ? padout_floats(k) : 0) + pass_scratch_floats(k, d);
+    return slab_end_floats(k, w.gx, (int)nt) + (use_padout(k, d) ? padout_floats(k) : 0) + pass_scratch_floats(k, d);
 }
 
 extern "C" int64_t passion_conv_pack_floats(int Cin, int Cout, int ksize) {
@@ -1005,8 +1011,7 @@ extern "C" int passion_conv3d_bwd(const passion_conv_desc_t* d, const float* pac
     const bool blockdiag = use_blockdiag(k, d);
     if (blockdiag) {         // passes summed first (per segment, masked), one dgrad over the physical samples
         const WgPlan w0 = plan_wgrad(k, d);
-        bf16_t* dycat = reinterpret_cast<bf16_t*>(sums + (long)2 * k.B * k.Cin * SUMS_REP +
-                                                  (long)w0.gx * ((long)k.Cout * k.Cin * nt + k.Cout) + (padout ? padout_floats(k) : 0));
+        bf16_t* dycat = reinterpret_cast<bf16_t*>(sums + slab_end_floats(k, w0.gx, nt) + (padout ? padout_floats(k) : 0));
         const int bm = k.seg[0].bmod, P = k.B / bm;
         const long V = (long)k.Di * k.Hi * k.Wi;
         PassSumArgs pa;
@@ -1028,8 +1033,7 @@ extern "C" int passion_conv3d_bwd(const passion_conv_desc_t* d, const float* pac
         k.tilesD = cdiv(k.Di, TD); k.tilesH = cdiv(k.Hi, TH); k.tilesW = cdiv(k.Wi, TW);
     } else {
         const WgPlan w0 = plan_wgrad(k, d);
-        char* gp = reinterpret_cast<char*>(sums + (long)2 * k.B * k.Cin * SUMS_REP + (long)w0.gx * ((long)k.Cout * k.Cin * nt + k.Cout) +
-                                           (padout ? padout_floats(k) : 0));
+        char* gp = reinterpret_cast<char*>(sums + slab_end_floats(k, w0.gx, nt) + (padout ? padout_floats(k) : 0));
         const long es = d->x_dtype == PASSION_BF16 ? 2 : 4;
         for (int s = 0; s < k.nseg; ++s) {
             if (k.seg[s].dx && k.seg[s].bmod > 0) {
@@ -1045,7 +1049,7 @@ extern "C" int passion_conv3d_bwd(const passion_conv_desc_t* d, const float* pac
                        2.0 * k.B * k.Do * k.Ho * k.Wo * (double)k.Cout * k.Cin * nt, st);
         if (padout) {
             const WgPlan w = plan_wgrad(k, d);
-            dxp = sums + (long)2 * k.B * k.Cin * SUMS_REP + (long)w.gx * ((long)k.Cout * k.Cin * nt + k.Cout);
+            dxp = sums + slab_end_floats(k, w.gx, nt);
             k.tilesD = cdiv(k.Di + 2, TD); k.tilesH = cdiv(k.Hi + 2, TH); k.tilesW = cdiv(k.Wi + 2, TW);
             k.y = dxp;
             rc = launch_conv_lean(k, d->ksize, d->stride, 2, packed + f32_pack_floats(k.Cin, k.Cout, nt), st);

@@ -106,6 +106,7 @@ __global__ __launch_bounds__(256) void conv_lean_kernel(ConvK p) {
     const int mg = blockIdx.y;
     // stride 1: the GEMM's output volume (fwd: y, dgrad: dx) and its source volume (fwd: x, dgrad: dy) coincide
     const int Sd = p.Di, Sh = p.Hi, Sw = p.Wi;
+    const int Wp = pad8(Sw + 2);      // row pitch of the padded gradient scratch (MODE 2): rows start on 128-byte lines for 8-channel tensors
     const int Qd = (S == 2) ? p.Do : Sd, Qh = (S == 2) ? p.Ho : Sh, Qw = (S == 2) ? p.Wo : Sw;   // source volume (dgrad: dY)
     const int K8 = DG ? (p.Cout + 7) / 8 : p.Cin / 8;
     const int nchunk = (K8 + NC8 - 1) / NC8;
@@ -196,7 +197,7 @@ __global__ __launch_bounds__(256) void conv_lean_kernel(ConvK p) {
                     const int cl = cg - sd.cbase, bs = sd.bsrc(b);
                     d.ok = 1; d.C = sd.C; d.has_stats = sd.stats != nullptr;
                     d.x = reinterpret_cast<const bf16_t*>(sd.x) + (long)bs * sd.bstride + cl;
-                    d.dx = PADOUT ? reinterpret_cast<bf16_t*>(p.y) + (long)b * (Sd + 2) * (Sh + 2) * (Sw + 2) * p.Cin + cg
+                    d.dx = PADOUT ? reinterpret_cast<bf16_t*>(p.y) + (long)b * (Sd + 2) * (Sh + 2) * pad8(Sw + 2) * p.Cin + cg
                                   : reinterpret_cast<bf16_t*>(sd.dx) + (long)b * sd.bstride + cl;
                     if (sd.mask) d.mval = sd.mask[(long)b * sd.mask_ld + sd.mask_col] ? 1.f : 0.f;
                     if (sd.stats) {
@@ -476,9 +477,9 @@ __global__ __launch_bounds__(256) void conv_lean_kernel(ConvK p) {
                 const bool inner = o0d >= 1 && o0h >= 1 && o0w >= 1 && o0d + TD <= Sd + 1 && o0h + TH <= Sh + 1 && o0w + TW <= Sw + 1;
                 if (inner) {
                     const int xb = ((o0d - 1 + ld_) * Sh + (o0h - 1 + lh0)) * Sw + (o0w - 1 + lw);
-                    const int db = ((o0d + ld_) * (Sh + 2) + (o0h + lh0)) * (Sw + 2) + (o0w + lw);
+                    const int db = ((o0d + ld_) * (Sh + 2) + (o0h + lh0)) * Wp + (o0w + lw);
 #pragma unroll
-                    for (int nt = 0; nt < 4; ++nt) { xvv[nt] = xb + nt * Sw; dvv[nt] = db + nt * (Sw + 2); }
+                    for (int nt = 0; nt < 4; ++nt) { xvv[nt] = xb + nt * Sw; dvv[nt] = db + nt * Wp; }
                 } else {
 #pragma unroll
                     for (int nt = 0; nt < 4; ++nt) {
@@ -489,7 +490,7 @@ __global__ __launch_bounds__(256) void conv_lean_kernel(ConvK p) {
                         rh = rh < 0 ? -rh : (rh >= Sh ? 2 * Sh - 2 - rh : rh);
                         rw = rw < 0 ? -rw : (rw >= Sw ? 2 * Sw - 2 - rw : rw);
                         xvv[nt] = in ? (rd * Sh + rh) * Sw + rw : -1;
-                        dvv[nt] = (od * (Sh + 2) + oh) * (Sw + 2) + ow;
+                        dvv[nt] = (od * (Sh + 2) + oh) * Wp + ow;
                     }
                 }
             } else {
