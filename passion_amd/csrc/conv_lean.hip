@@ -80,7 +80,7 @@ __device__ __forceinline__ bf16x8 zero8() {
 // S: stride of the forward conv; only MODE 2 (dgrad over the padded domain) runs with S = 2: dY is staged zero-stuffed
 // (position u of the fine grid holds dy[u / 2] for even u, zero otherwise) and the 27 flipped taps gather as for S = 1.
 template <int KS, int MT, int MODE, int CKB, int S = 1>
-__global__ __launch_bounds__(256) void conv_lean_kernel(ConvK p) {
+__device__ __forceinline__ void conv_lean_body(const ConvK& p) {
     static_assert(S == 1 || MODE == 2, "stride 2 only for the padded-domain dgrad");
     constexpr bool DG = (MODE >= 1);
     // MODE 2: dgrad of a reflect-padded conv computed over the PADDED input domain (output coordinate op <-> input
@@ -688,6 +688,17 @@ __global__ __launch_bounds__(256) void conv_lean_kernel(ConvK p) {
 }
 
 template <int KS, int MT, int MODE, int CKB, int S = 1>
+__global__ __launch_bounds__(256) void conv_lean_kernel(ConvK p) {
+    conv_lean_body<KS, MT, MODE, CKB, S>(p);
+}
+// the same body held to 128 registers = four waves per SIMD (experiment, PASSION_CONV_OCC4=1): the padded-domain dgrad of
+// the 8-channel levels needs 160 and runs three
+template <int KS, int MT, int MODE, int CKB, int S = 1>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void conv_lean_kernel_occ4(ConvK p) {
+    conv_lean_body<KS, MT, MODE, CKB, S>(p);
+}
+
+template <int KS, int MT, int MODE, int CKB, int S = 1>
 int launch_lean_one(ConvK& k, int K8, int gy, hipStream_t st) {
     using G = GeoL<KS, CKB>;
     constexpr int wchunk = G::NSTEP * 4 * MT * 16 * 16;
@@ -709,9 +720,24 @@ int launch_lean_one(ConvK& k, int K8, int gy, hipStream_t st) {
                                     hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
         attr_bytes = bytes;
     }
-    if (S == 1) passion_prof_tag("conv_lean_kernel<%d, %d, %d, %d, 1>", KS, MT, MODE, CKB);
+    // measured on the level-1 dgrad (8 -> 8 channels, 128^3): 75.7 -> 61.6 us with the fourth wave (15 dwords spilled to scratch);
+    // with two K chunks (16 -> 16 at 64^3) the spills cost more than the wave brings (24.3 -> 27.0 us): single-chunk launches only
+    // Opt-in (PASSION_CONV_OCC4=1): alone the kernel gains 19 %, inside the training step nothing measurable (its launches share
+    // the chip with the side streams), and the spills show up as scratch traffic: FETCH+WRITE per launch 1.9x -> 2.8x algorithmic.
+    static const bool occ4 = []() { const char* e = getenv("PASSION_CONV_OCC4"); return e && e[0] == '1'; }();
+    const bool use_occ4 = occ4 && MODE == 2 && CKB == 8 && MT == 1 && S == 1 && KS == 3 && K8 == 1;
+    if (S == 1) passion_prof_tag(use_occ4 ? "conv_lean_kernel_occ4<%d, %d, %d, %d, 1>" : "conv_lean_kernel<%d, %d, %d, %d, 1>", KS, MT, MODE, CKB);
     else passion_prof_tag("conv_lean_kernel<%d, %d, %d, %d, %d>", KS, MT, MODE, CKB, S);
-    hipLaunchKernelGGL((conv_lean_kernel<KS, MT, MODE, CKB, S>), dim3(gx, gy), dim3(256), bytes, st, k);
+    if (use_occ4) {
+        static int attr2 = 0;
+        if (bytes > attr2) {
+            HIP_RET(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_lean_kernel_occ4<KS, MT, MODE, CKB, S>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+            attr2 = bytes;
+        }
+        hipLaunchKernelGGL((conv_lean_kernel_occ4<KS, MT, MODE, CKB, S>), dim3(gx, gy), dim3(256), bytes, st, k);
+    } else
+        hipLaunchKernelGGL((conv_lean_kernel<KS, MT, MODE, CKB, S>), dim3(gx, gy), dim3(256), bytes, st, k);
     LAUNCH_RET();
     return 0;
 }
