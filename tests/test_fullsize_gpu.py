@@ -1,0 +1,137 @@
+"""BASELINE.json's full size (4 x 128^3, bf16 storage -- the bench configuration), where the CPU oracle takes minutes per
+step: properties of the reference's computation that do not depend on the size, checked on the product path.
+
+  * an absent modality's voxels are never looked at (idt: `x[mask==0]` is zeroed, mmformer.py:397-415; MaskModal :316-325):
+    changing them changes nothing, bit for bit;
+  * InstanceNorm has no batch statistics and every loss is per sample (`_bs`): a sample's outputs do not depend on its
+    batch mates;
+  * the PASSION teacher IS the plain forward (mmformer.py:468-531 runs it first with the full mask): `pred`, `prm_loss`,
+    `sep_loss` of the PASSION step equal those of the plain step;
+  * softmax output: probabilities of every voxel sum to one;
+  * the training step is linear in the loss scale: gradients of 2 * loss are 2 * gradients (f32 atomics: to rounding).
+"""
+import os
+import sys
+
+import pytest
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from _util import build_product_model, synth  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+S = 128
+
+
+def _dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def model():
+    dev = _dev()
+    m = build_product_model(S, small=False).to(dev)
+    m.mask_type, m.compute_dtype = "idt", torch.bfloat16
+    m.eval()                                    # dropout off: the comparisons below are between separate forwards
+    return m
+
+
+def test_absent_modality_is_never_read(model):
+    dev = _dev()
+    x, _ = synth(1, S)
+    x = x.to(dev)
+    mask = torch.tensor([[True, False, True, True]], device=dev)
+    model.is_training, model.use_passion = False, False
+    with torch.no_grad():
+        a = model(x, mask)
+        x2 = x.clone()
+        x2[:, 1] = torch.randn_like(x2[:, 1]) * 50 + 7
+        b = model(x2, mask)
+    assert torch.equal(a, b)
+    s = a.sum(1)
+    assert float((s - 1).abs().max()) < 1e-5 and bool(torch.isfinite(a).all())
+
+
+def test_samples_of_a_batch_are_independent(model):
+    dev = _dev()
+    x, t = synth(2, S)
+    x, t = x.to(dev), t.to(dev)
+    mask = torch.tensor([[True, True, True, True], [True, False, False, True]], device=dev)
+    model.is_training, model.use_passion = True, False
+    with torch.no_grad():
+        both = model(x, mask, target=t, temp=4.0)
+        one = model(x[1:], mask[1:], target=t[1:], temp=4.0)
+    assert torch.equal(both[0][1:], one[0])                   # probabilities: bit for bit
+    for u, v in zip(both[1:], one[1:]):                       # loss sums end in f32 atomics: equal to rounding
+        assert torch.allclose(u[1:], v, rtol=2e-5, atol=1e-6)
+
+
+def test_passion_teacher_is_the_plain_forward(model):
+    dev = _dev()
+    x, t = synth(1, S, blobs=True)
+    x, t = x.to(dev), t.to(dev)
+    mask = torch.tensor([[True, True, False, True]], device=dev)
+    model.is_training = True
+    with torch.no_grad():
+        model.use_passion = False
+        plain = model(x, mask, target=t, temp=4.0)
+        model.use_passion = True
+        full = model(x, mask, target=t, temp=4.0)
+    model.use_passion = False
+    assert len(plain) == 3 and len(full) == 6
+    assert torch.equal(plain[0], full[0])
+    for u, v in zip(plain[1:], full[1:3]):
+        assert torch.allclose(u, v, rtol=2e-5, atol=1e-6)
+    kl, proto, dist = full[3:]
+    assert bool(torch.isfinite(kl).all() and torch.isfinite(proto).all() and torch.isfinite(dist).all())
+
+
+def test_gradients_are_linear_in_the_loss_scale(model):
+    dev = _dev()
+    from passion_amd import train as ptrain
+    x, t = synth(1, S)
+    x, t = x.to(dev), t.to(dev)
+    mask = torch.ones(1, 4, dtype=torch.bool, device=dev)
+    model.is_training, model.use_passion = True, False
+    names = ["flair_encoder.e1_c2.conv.weight", "decoder_fuse.d1_c2.conv.weight", "decoder_sep.d2_c1.conv.weight",
+             "multimodal_transformer.cross_attention_list.0.fn.fn.qkv.weight"]
+    params = dict(model.named_parameters())
+    grads = []
+    for scale in (1.0, 2.0):
+        outs = model(x, mask, target=t, temp=4.0)
+        loss = ptrain.assemble_loss(outs, t, mask, "idt", False) * scale
+        gs = torch.autograd.grad(loss, [params[n] for n in names])
+        grads.append([g.float() for g in gs])
+    for n, g1, g2 in zip(names, *grads):
+        denom = float(g1.abs().max())
+        assert denom > 0
+        # bf16 activations + f32 atomics: two runs of the SAME step differ by percents on individual entries;
+        # the scale must come through on the bulk of the tensor
+        rel = float((g2 - 2 * g1).abs().mean()) / float((2 * g1).abs().mean())
+        assert rel < 5e-2, (n, rel)
+
+
+def test_rfnet_absent_modality_and_batch_independence():
+    """the same two invariances for the RFNet backbone (rfnet.py:217-403) at 128^3, batch 2 (BASELINE.json configs[3])"""
+    dev = _dev()
+    from passion_amd.models import rfnet
+    torch.manual_seed(1037)
+    m = rfnet.Model(num_cls=4).to(dev)
+    m.mask_type, m.compute_dtype, m.use_passion = "idt", torch.bfloat16, False
+    m.eval()
+    x, t = synth(2, S)
+    x, t = x.to(dev), t.to(dev)
+    mask = torch.tensor([[True, True, False, True], [False, True, True, True]], device=dev)
+    m.is_training = False
+    with torch.no_grad():
+        a = m(x, mask)
+        x2 = x.clone()
+        x2[0, 2] = 123.0
+        x2[1, 0] = torch.randn_like(x2[1, 0]) * 9
+        b = m(x2, mask)
+        c = m(x[:1], mask[:1])
+    assert torch.equal(a, b)
+    assert torch.equal(a[:1], c)
+    assert float((a.sum(1) - 1).abs().max()) < 1e-5
