@@ -153,8 +153,8 @@ __global__ __launch_bounds__(256) void stats_small_kernel(const T* __restrict__ 
 inline int small_blocks(long V, int cvn) {
     const long vecs = V * cvn;
     if (vecs > 4 * 32768) return 0;
-    int nb = 1;
-    while (nb < cvn && (vecs / nb > 32768 || cvn / nb > 64)) nb *= 2;
+    int nb = 1;                                   // as many blocks as the channel vectors allow until a block has <= 4096 vectors:
+    while (nb < cvn && (vecs / nb > 4096 || cvn / nb > 64)) nb *= 2;      // a single block is a 128-deep serial chain at 16^3 x 64
     return (vecs / nb <= 32768 && cvn % nb == 0 && cvn / nb <= 64) ? nb : 0;
 }
 
