@@ -35,6 +35,7 @@ class FusedAdamW(torch.optim.Optimizer):
             key = tuple(id(p) for p in ps)
             cache = self._tables.get(gi)
             if cache is None or cache["key"] != key or any(p.data_ptr() != q for p, q in zip(ps, cache["pptr"])):
+                self._sync_steps()      # the live counts are in the old table: bring the per-parameter tensors up to date first
                 for p in ps:
                     st = self.state[p]
                     if len(st) == 0:
@@ -45,31 +46,40 @@ class FusedAdamW(torch.optim.Optimizer):
                             st["max_exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                 if not all(p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() for p in ps):
                     raise L.PassionHipError("FusedAdamW needs contiguous f32 CUDA parameters and gradients")
-                steps = {int(self.state[p]["step"]) for p in ps}
-                assert len(steps) == 1, "parameters of one group must share the step count"
-                n = len(ps)
-                arr = lambda ts: (c_void_p * n)(*[t.data_ptr() for t in ts])     # noqa: E731
-                ms = [self.state[p]["exp_avg"] for p in ps]
-                vs = [self.state[p]["exp_avg_sq"] for p in ps]
-                vm = [self.state[p]["max_exp_avg_sq"] for p in ps] if group["amsgrad"] else ms
-                cache = {"key": key, "pptr": [p.data_ptr() for p in ps], "p": arr(ps), "m": arr(ms), "v": arr(vs), "vm": arr(vm),
-                         "numel": (c_int64 * n)(*[p.numel() for p in ps]), "g": (c_void_p * n)(), "step": steps.pop(),
-                         "step_tensors": [self.state[p]["step"] for p in ps]}
+                # torch keeps one step count per parameter (bias correction): parameters whose first gradient arrived late
+                # form their own sub-table with their own count -- one launch per distinct count (normally one)
+                by_step = {}
+                for i, p in enumerate(ps):
+                    by_step.setdefault(int(self.state[p]["step"]), []).append(i)
+                subs = []
+                for step0, idx in sorted(by_step.items()):
+                    sp = [ps[i] for i in idx]
+                    n = len(sp)
+                    arr = lambda ts: (c_void_p * n)(*[t.data_ptr() for t in ts])     # noqa: E731
+                    ms = [self.state[p]["exp_avg"] for p in sp]
+                    vs = [self.state[p]["exp_avg_sq"] for p in sp]
+                    vm = [self.state[p]["max_exp_avg_sq"] for p in sp] if group["amsgrad"] else ms
+                    subs.append({"idx": idx, "p": arr(sp), "m": arr(ms), "v": arr(vs), "vm": arr(vm),
+                                 "numel": (c_int64 * n)(*[p.numel() for p in sp]), "g": (c_void_p * n)(), "step": step0,
+                                 "step_tensors": [self.state[p]["step"] for p in sp]})
+                cache = {"key": key, "pptr": [p.data_ptr() for p in ps], "subs": subs}
                 self._tables[gi] = cache
-            n = len(ps)
-            garr = cache["g"]
-            for i, p in enumerate(ps):
-                g = p.grad
-                if g.dtype != torch.float32 or not g.is_cuda:
-                    raise L.PassionHipError("FusedAdamW needs contiguous f32 CUDA parameters and gradients")
-                if not g.is_contiguous():
-                    g = p.grad = g.contiguous()
-                garr[i] = g.data_ptr()
-            cache["step"] += 1
             b1, b2 = group["betas"]
-            L.check(lib.passion_adamw_step(n, cache["p"], garr, cache["m"], cache["v"], cache["vm"], cache["numel"], float(group["lr"]),
-                                           float(b1), float(b2), float(group["eps"]), float(group["weight_decay"]), cache["step"],
-                                           1 if group["amsgrad"] else 0, L.stream_ptr()), "passion_adamw_step")
+            for sub in cache["subs"]:
+                garr = sub["g"]
+                for j, i in enumerate(sub["idx"]):
+                    p = ps[i]
+                    g = p.grad
+                    if g.dtype != torch.float32 or not g.is_cuda:
+                        raise L.PassionHipError("FusedAdamW needs contiguous f32 CUDA parameters and gradients")
+                    if not g.is_contiguous():
+                        g = p.grad = g.contiguous()
+                    garr[j] = g.data_ptr()
+                sub["step"] += 1
+                L.check(lib.passion_adamw_step(len(sub["idx"]), sub["p"], garr, sub["m"], sub["v"], sub["vm"], sub["numel"],
+                                               float(group["lr"]), float(b1), float(b2), float(group["eps"]),
+                                               float(group["weight_decay"]), sub["step"], 1 if group["amsgrad"] else 0,
+                                               L.stream_ptr()), "passion_adamw_step")
             # the kernel wrote the parameters behind autograd's back: bump their version counters, the packed-weight
             # caches (ops.pack_weight / repack_stale) and any saved-tensor checks key on them
             torch.autograd.graph.increment_version(ps)
@@ -78,8 +88,9 @@ class FusedAdamW(torch.optim.Optimizer):
     def _sync_steps(self):
         """the per-parameter 'step' tensors of torch's state layout, brought up to date (they are only read by state_dict)"""
         for cache in self._tables.values():
-            for t in cache["step_tensors"]:
-                t.fill_(float(cache["step"]))
+            for sub in cache["subs"]:
+                for t in sub["step_tensors"]:
+                    t.fill_(float(sub["step"]))
 
     def state_dict(self):
         self._sync_steps()

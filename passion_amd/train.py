@@ -43,13 +43,15 @@ class LossState:
         return rp_epoch
 
 
-def assemble_loss(outs, target, mask, mask_type="idt", use_passion=True, state=None, warmup=False, modal_num=None):
-    """Per-iteration loss (train.py:228-280 / :413-440), no host synchronisation."""
+def assemble_loss(outs, target, mask, mask_type="idt", use_passion=True, state=None, warmup=False, modal_num=None,
+                  iter_per_epoch=None):
+    """Per-iteration loss (train.py:228-280 / :413-440), no host synchronisation.  `modal_num` / `iter_per_epoch`: the
+    normaliser of the epoch accumulators (train.py:295-304: / modal_num for mask_type 'idt', / iter_per_epoch otherwise)."""
     pred = outs[0]
     B = pred.shape[0]
     dev = pred.device
-    fuse_loss = (criterions.softmax_weighted_loss_bs(pred, target, num_cls=4) +
-                 criterions.dice_loss_bs(pred, target, num_cls=4)).sum()
+    # softmax_weighted_loss_bs + dice_loss_bs (train.py:228): both columns of ONE pass over the prediction
+    fuse_loss = criterions.seg_pair_bs(pred, target).sum()
     prm_loss = outs[1].sum()
     idt = mask_type != "pdt"
     mk = mask.to(device=dev, dtype=torch.float32)
@@ -66,7 +68,11 @@ def assemble_loss(outs, target, mask, mask_type="idt", use_passion=True, state=N
     proto = (rp_mask * w * proto_m).sum()
     if state is not None:
         dm = red(dist_bs).detach()
-        state.epoch_dist_m += dm / modal_num if (idt and modal_num is not None) else dm
+        if mask_type == "idt" and modal_num is not None:
+            dm = dm / modal_num
+        elif mask_type != "idt" and iter_per_epoch:
+            dm = dm / iter_per_epoch
+        state.epoch_dist_m += dm
     if warmup:
         return (beta * w * sep_m).sum() + 0.0 * (fuse_loss + prm_loss + kl + proto)
     return fuse_loss + (rp_mask * beta * w * sep_m).sum() + prm_loss + 0.5 * kl + 0.1 * proto
@@ -101,12 +107,13 @@ def poly_lr(base_lr, epoch, num_epochs, power=0.9):
     return round(base_lr * np.power(1 - np.float32(epoch) / np.float32(num_epochs), power), 8)
 
 
-def train_step(model, optimizer, x, mask, target, temp=4.0, state=None, reducer=None, warmup=False, modal_num=None):
+def train_step(model, optimizer, x, mask, target, temp=4.0, state=None, reducer=None, warmup=False, modal_num=None,
+               iter_per_epoch=None):
     """one iteration: forward, loss assembly, backward, (gradient all-reduce,) optimizer step"""
     net = model
     net.is_training = True
     outs = net(x, mask, target=target, temp=temp)
-    loss = assemble_loss(outs, target, mask, net.mask_type, net.use_passion, state, warmup, modal_num)
+    loss = assemble_loss(outs, target, mask, net.mask_type, net.use_passion, state, warmup, modal_num, iter_per_epoch)
     optimizer.zero_grad()            # set_to_none: no 288 fill launches, backward assigns the fresh gradients
     loss.backward()
     if reducer is not None:
@@ -126,11 +133,39 @@ def synthetic_batch(B, S, device, seed=7, mask=None):
     return x.to(device), target.to(device), mask.to(device)
 
 
-MASK_TABLE = [[True, False, False, False], [False, True, False, False], [False, False, True, False],
-              [False, False, False, True], [True, True, False, False], [True, False, True, False],
-              [True, False, False, True], [False, True, True, False], [False, True, False, True],
-              [False, False, True, True], [True, True, True, False], [True, True, False, True],
-              [True, False, True, True], [False, True, True, True], [True, True, True, True]]
+# mask_id -> present modalities [flair, t1ce, t1, t2] (reference data/datasets_nii.py:27-30) and the empirical mask_id histogram
+# of datasets/BraTS/brats_split/Brats2020_imb_split_mr2468.csv (the --imbmrpath default; 219 subjects, modalities present
+# [90, 135, 184, 43]): what BASELINE.json configs[2] ("imbalanced missing-rate masks (brats_split)") samples from
+MASK_TABLE = [[False, False, False, True], [False, True, False, False], [False, False, True, False], [True, False, False, False],
+              [False, True, False, True], [False, True, True, False], [True, False, True, False], [False, False, True, True],
+              [True, False, False, True], [True, True, False, False], [True, True, True, False], [True, False, True, True],
+              [True, True, False, True], [False, True, True, True], [True, True, True, True]]
+SPLIT_MR2468_HIST = [2, 12, 38, 6, 3, 53, 23, 9, 1, 9, 35, 5, 2, 12, 9]
+
+
+def split_modal_weight(batch_size=1, world=1):
+    """modal_weight = iter_per_epoch / modal_num of the mr2468 split (train.py:163-171)"""
+    hist = np.asarray(SPLIT_MR2468_HIST, dtype=np.float64)
+    modal_num = (hist[:, None] * np.asarray(MASK_TABLE, dtype=np.float64)).sum(0)
+    return torch.tensor((int(hist.sum()) // (batch_size * world)) / modal_num, dtype=torch.float32)
+
+
+def sample_split_masks(rng, n):
+    """n masks drawn i.i.d. from the split's empirical mask_id distribution (rng: numpy RandomState)"""
+    hist = np.asarray(SPLIT_MR2468_HIST, dtype=np.float64)
+    ids = rng.choice(15, size=n, p=hist / hist.sum())
+    return torch.tensor([MASK_TABLE[i] for i in ids], dtype=torch.bool)
+
+
+def epoch_order(n, epoch, seed, world, rank, batch_size, iters):
+    """(iters, batch_size) subject indices of this rank for one epoch: shuffle=True of the reference's DataLoader (train.py:124)
+    as a fresh permutation per epoch, identical on every rank, cut to iters * batch_size * world subjects and dealt so that
+    global batch `it` = the ranks' rows `it` side by side.  Every rank gets exactly `iters` rows: each step issues collectives."""
+    perm = np.random.RandomState(seed + epoch).permutation(n)
+    gb = batch_size * world
+    if n < gb:                      # fewer subjects than one global batch: wrap around
+        perm = np.resize(perm, gb * max(1, iters))
+    return perm[:iters * gb].reshape(iters, world, batch_size)[:, rank]
 
 
 def main(argv=None):
@@ -153,46 +188,62 @@ def main(argv=None):
     model.mask_type, model.use_passion = args.mask_type, args.use_passion
     model.compute_dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     model.train()
+    start_epoch = 0
+    ckpt = None
+    if args.resume is not None:         # train.py:143-152 (--use_pretrain: weights only) / checkpoint layout of :358-364
+        ckpt = torch.load(args.resume, map_location="cpu", weights_only=True)
+        sd = {k[7:] if k.startswith("module.") else k: v for k, v in ckpt["state_dict"].items()}
+        own = model.state_dict()
+        own.update({k: v for k, v in sd.items() if k in own})
+        model.load_state_dict(own)
     reducer = parallel.GradReducer(model, ctx)
     optimizer = make_optimizer(model, args.lr, args.weight_decay)
+    if ckpt is not None and not args.use_pretrain:      # continue the run: optimizer moments and the epoch counter too
+        optimizer.load_state_dict(ckpt["optim_dict"])
+        start_epoch = int(ckpt["epoch"]) + 1
     state = LossState(ctx.device)
     data = None
+    gb = args.batch_size * ctx.world                    # global batch: one DataParallel batch of the reference = all ranks' samples
     if not args.synthetic:      # the reference's npy dataset through the GPU input pipeline (train.py:112-131)
         from .data.datasets_nii import Brats_loadall_train_nii_idt
         csv = os.path.join(args.datarootPath, args.imbmrpath)
         data = Brats_loadall_train_nii_idt(transforms=args.train_transforms, root=args.datasetPath, num_cls=4,
                                            mask_type=args.mask_type, train_file=csv, device=ctx.device)
-        order = np.random.RandomState(args.seed).permutation(len(data))[ctx.rank::ctx.world]     # each rank its own subjects
-    iters = args.iters_per_epoch or (10 if data is None else max(1, len(order) // args.batch_size))
+    # iterations per epoch from a RANK-INDEPENDENT quantity: every step issues collectives (rp_mask, gradient buckets), so all
+    # ranks must run the same number of steps; the len(data) % gb left-over subjects of an epoch's permutation are dropped
+    iters = args.iters_per_epoch or (10 if data is None else max(1, len(data) // gb))
     modal_num = None
     if data is not None:        # initial imbalance weights (train.py:163-171): iterations per epoch / subjects that have the modality
         modal_num = torch.zeros(4, device=ctx.device)
         for sample_mask in data.samples_masks:
             modal_num += torch.tensor(eval(sample_mask), dtype=torch.float32, device=ctx.device)
-        state.modal_weight = (len(data) // args.batch_size) / modal_num
+        state.modal_weight = iters / modal_num
     rng = np.random.RandomState(args.seed + ctx.rank)
-    for epoch in range(args.num_epochs):
+    loss = torch.zeros((), device=ctx.device)
+    for epoch in range(start_epoch, args.num_epochs):
         lr = float(poly_lr(args.lr, epoch, args.num_epochs))     # python float: keeps the checkpoint weights_only-loadable
         for g_ in optimizer.param_groups:
             g_["lr"] = lr
+        if data is not None:
+            order = epoch_order(len(data), epoch, args.seed, ctx.world, ctx.rank, args.batch_size, iters)
         t0 = time.time()
         for it in range(iters):
             if data is None:
-                mk = torch.tensor([MASK_TABLE[rng.randint(15)] for _ in range(args.batch_size)])
+                mk = sample_split_masks(rng, args.batch_size)
                 x, target, mk = synthetic_batch(args.batch_size, args.patch, ctx.device, seed=epoch * iters + it, mask=mk)
             else:
-                samples = [data[int(order[(it * args.batch_size + j) % len(order)])] for j in range(args.batch_size)]
+                samples = [data[int(j)] for j in order[it]]
                 x = torch.stack([s_[0] for s_ in samples])
                 target = torch.stack([s_[1] for s_ in samples])
                 mk = torch.stack([s_[2] for s_ in samples])
             loss = train_step(model, optimizer, x, mk, target, args.temp, state, reducer,
-                              warmup=epoch < args.region_fusion_start_epoch, modal_num=modal_num)
+                              warmup=epoch < args.region_fusion_start_epoch, modal_num=modal_num, iter_per_epoch=iters)
         torch.cuda.synchronize()
         if args.use_passion:
             state.end_epoch(epoch, epoch < args.region_fusion_start_epoch)
         if ctx.rank == 0:
             print(f"epoch {epoch + 1}/{args.num_epochs} lr {lr} loss {float(loss):.4f} "
-                  f"{iters * args.batch_size * ctx.world / (time.time() - t0):.3f} vol/s", flush=True)
+                  f"{iters * gb / (time.time() - t0):.3f} vol/s", flush=True)
             os.makedirs(args.savepath, exist_ok=True)
             torch.save({"epoch": epoch, "state_dict": {"module." + k: v for k, v in model.state_dict().items()},
                         "optim_dict": optimizer.state_dict()}, os.path.join(args.savepath, "model_last.pth"))

@@ -48,6 +48,11 @@ class _NcdhwToCl(torch.autograd.Function):
         return ops.to_ncdhw(g.contiguous())
 
 
+def seg_pair_bs(output, target, up_op=None):
+    """softmax_weighted_loss_bs + dice_loss_bs in one pass -> (B,1) (the sum train.py:228 forms)"""
+    return _seg_pair(output, target, up_op).sum(1, keepdim=True)
+
+
 def softmax_weighted_loss_bs(output, target, num_cls=4, up_op=None):
     assert num_cls == 4 and output.shape[1] == 4
     return _seg_pair(output, target, up_op)[:, 0:1]

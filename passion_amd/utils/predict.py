@@ -36,18 +36,19 @@ def coverage_count(shape, patch, device):
 def sliding_window_predict(model, x, mask, patch, windows_per_batch=4, ctx=None):
     """x (B,4,H,W,Z), mask (B,4) -> (prob (B,num_cls,H,W,Z) averaged over windows, argmax (B,H,W,Z) int64)"""
     B, _, H, W, Z = x.shape
-    was = model.is_training
+    was, was_mode = model.is_training, getattr(model, "training", None)
     model.is_training = False
+    if was_mode is not None:
+        model.eval()                   # dropout off, as test_dice_hd95_softmax does (reference predict.py:154, restored :251)
     starts = [(h, w, z) for h in window_starts(H, patch) for w in window_starts(W, patch) for z in window_starts(Z, patch)]
     if ctx is not None and ctx.world > 1:
         starts = starts[ctx.rank::ctx.world]
-    pred = None
+    # allocated up front: a rank that was dealt no window (more ranks than windows) still joins the all-reduce below
+    pred = torch.zeros(B, getattr(model, "num_cls", 4), H, W, Z, device=x.device, dtype=torch.float32)
     for i in range(0, len(starts), windows_per_batch):
         grp = starts[i:i + windows_per_batch]
         xin = torch.cat([x[:, :, h:h + patch, w:w + patch, z:z + patch] for h, w, z in grp], 0).contiguous()
         out = model(xin, mask.repeat(len(grp), 1))
-        if pred is None:
-            pred = torch.zeros(B, out.shape[1], H, W, Z, device=x.device, dtype=out.dtype)
         for j, (h, w, z) in enumerate(grp):
             pred[:, :, h:h + patch, w:w + patch, z:z + patch] += out[j * B:(j + 1) * B]
     if ctx is not None and ctx.world > 1:
@@ -55,6 +56,8 @@ def sliding_window_predict(model, x, mask, patch, windows_per_batch=4, ctx=None)
         dist.all_reduce(pred, op=dist.ReduceOp.SUM)
     pred = pred / coverage_count((H, W, Z), patch, x.device)
     model.is_training = was
+    if was_mode is not None:
+        model.train(was_mode)
     return pred, torch.argmax(pred, dim=1)
 
 

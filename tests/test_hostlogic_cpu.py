@@ -1,0 +1,76 @@
+"""CPU tests of host-side logic that needs no kernel: the per-epoch subject order of train.main (every rank runs the same number
+of steps), the brats_split mask distribution of BASELINE.json configs[2], bench.py's N > 1 self-launch, the 128^3 fixtures' own
+consistency."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+from _util import gold
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_every_rank_gets_the_same_number_of_iterations_on_an_odd_dataset():
+    from passion_amd import train as ptrain
+    n, world, bs = 219, 8, 1                 # BraTS2020 split: 219 subjects on 8 GPUs (27 full global batches, 3 left over)
+    iters = n // (bs * world)
+    rows = [ptrain.epoch_order(n, 0, 1037, world, r, bs, iters) for r in range(world)]
+    assert all(o.shape == (iters, bs) for o in rows)
+    flat = np.concatenate([o.reshape(-1) for o in rows])
+    assert len(set(flat.tolist())) == len(flat) == iters * bs * world      # disjoint subjects, nobody runs an extra step
+    other = ptrain.epoch_order(n, 1, 1037, world, 0, bs, iters)
+    assert not np.array_equal(rows[0], other)                                # reshuffled per epoch (DataLoader shuffle=True)
+    tiny = ptrain.epoch_order(3, 0, 1037, 2, 1, 2, 1)
+    assert tiny.shape == (1, 2)
+
+
+def test_split_masks_follow_the_reference_csv():
+    from passion_amd import train as ptrain
+    g = gold("brats_split_mr2468.npz")
+    assert g["mask_array"].tolist() == ptrain.MASK_TABLE                      # id -> mask table of datasets_nii.py:27-30
+    assert np.bincount(g["mask_id"], minlength=15).tolist() == ptrain.SPLIT_MR2468_HIST
+    assert g["modal_num"].tolist() == [90, 135, 184, 43]
+    w = ptrain.split_modal_weight(1, 1)
+    assert torch.allclose(w, torch.tensor([219 / 90, 219 / 135, 219 / 184, 219 / 43]))
+    rng = np.random.RandomState(0)
+    m = ptrain.sample_split_masks(rng, 20000).float().mean(0)
+    assert torch.allclose(m, torch.tensor([90, 135, 184, 43.]) / 219, atol=0.02)
+    g2 = gold("model_full128_idt_passion_split.npz")
+    assert np.allclose(g2["modal_weight"], w.numpy(), rtol=1e-6) and abs(float((g2["imb_beta"] ** 2).sum()) - 4) < 1e-5
+    assert g2["mask"].tolist()[0] in ptrain.MASK_TABLE and 2 <= g2["mask"].sum() < 4
+
+
+def test_bench_self_launch_spawns_torchrun_before_touching_the_gpu(monkeypatch):
+    sys.path.insert(0, ROOT)
+    import subprocess
+    import bench
+    seen = {}
+
+    def fake_call(cmd, env=None):
+        seen["cmd"], seen["env"] = cmd, env
+        return 7
+
+    monkeypatch.setattr(subprocess, "call", fake_call)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3", "--warmup", "1"])
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    try:
+        bench.main()
+        raise AssertionError("self_launch must exit")
+    except SystemExit as e:
+        assert e.code == 7                                                    # the children's exit code is relayed
+    cmd = seen["cmd"]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-6:] == ["--gpus", "4", "--steps", "3", "--warmup", "1"]
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    assert not torch.cuda.is_initialized()
+
+
+def test_fixture_argmax_packing_roundtrip():
+    g = gold("model_full128_idt_plain_1111.npz")
+    p = g["argmax_packed"]
+    assert p.size * 4 == 128 ** 3
+    lab = np.stack([(p >> (2 * j)) & 3 for j in range(4)], 1).reshape(-1)
+    import hashlib
+    assert hashlib.sha1(lab.astype(np.uint8).tobytes()).hexdigest() == str(g["argmax_sha1"])

@@ -120,3 +120,27 @@ def test_full_volume_mean_dice_vs_oracle_on_gpu():
     _, ev_t = predict.softmax_output_dice_class4(a, tgt.to(dev))
     _, ev_r = predict_ref.softmax_output_dice_class4(a_ref, tgt)
     assert torch.allclose(ev_t.cpu(), ev_r, atol=2e-4)
+
+
+def test_predict_runs_in_eval_mode_and_restores_the_mode():
+    """reference predict.py:154/:251 wraps inference in model.eval() ... model.train(): dropout must be off inside"""
+    from passion_amd.utils import predict
+
+    class Drop(torch.nn.Module):
+        is_training, num_cls = True, 4
+
+        def __init__(self):
+            super().__init__()
+            self.toy, self.drop, self.modes = Toy(), torch.nn.Dropout(0.5), []
+
+        def forward(self, x, mask):
+            self.modes.append(self.training)
+            return self.drop(self.toy(x, mask))
+
+    x, _ = _vol((24, 20, 16))
+    mask = torch.ones(1, 4, dtype=torch.bool)
+    m = Drop().train()
+    p, _ = predict.sliding_window_predict(m, x, mask, 16)
+    p_ref, _ = predict_ref.test_volume_softmax(m.toy, x, mask, 16)
+    assert m.modes and not any(m.modes) and m.training and m.is_training
+    assert torch.allclose(p, p_ref, atol=1e-6)
