@@ -175,6 +175,19 @@ int passion_attn_pv_bwd(const float* probs, const void* qkv, const void* dout, i
 int passion_attn_scores_bwd(const float* probs, float* dprobs, const void* qkv, int dtype, int B,
                             int N, int H, int Dh, float scale, void* dqkv, void* stream);
 
+/* Fused attention (flash-style), bf16 tensors with Dh = 64 -- replaces SelfAttention.forward's
+ * `attn = (q @ k.transpose(-2, -1)) * self.scale; attn = attn.softmax(dim=-1); attn = self.attn_drop(attn); x = attn @ v`
+ * (code/models/mmformer.py:220-224) and its autograd backward without any [N][N] tensor in memory.
+ *   fwd: out [B][N][H][64] bf16, lse [B][H][N] f32 (log2 of the row sum of exp2(scale*log2(e)*s); kept for the backward).
+ *   bwd: dqkv [B][N][3][H][64] bf16 (all three slots written); delta: scratch of B*H*N floats.  Bitwise reproducible (no atomics).
+ * drop_p > 0: attention dropout with keep bits = a counter-based hash of (seed, b, h, query, key); the backward must be given the
+ * forward's (drop_p, seed).  Returns -1003 for any other head width (passion_flash_attn_supported tells). */
+int passion_flash_attn_supported(int dtype, int Dh);
+int passion_flash_attn_fwd(const void* qkv, int B, int N, int H, int Dh, float scale, float drop_p, uint64_t seed,
+                           void* out, float* lse, void* stream);
+int passion_flash_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse, int B, int N, int H, int Dh,
+                           float scale, float drop_p, uint64_t seed, float* delta, void* dqkv, void* stream);
+
 /* Attention dropout (nn.Dropout on the attention probabilities, code/models/mmformer.py:222) in one pass and without a
  * stored mask: y[i] = keep(i) ? x[i] / (1 - p) : 0 with keep(i) ~ Bernoulli(1 - p) drawn from a counter-based hash of
  * (seed, i).  The same (seed, p) reproduces the mask, which is how the backward applies it to dprobs.  y may alias x. */

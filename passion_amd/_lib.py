@@ -80,6 +80,11 @@ SIGNATURES = {
                                     c_void_p, c_void_p]),
     "passion_attn_pv_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                     c_int, c_void_p, c_void_p, c_void_p]),
+    "passion_flash_attn_supported": (c_int, [c_int, c_int]),
+    "passion_flash_attn_fwd": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_float, c_float, ctypes.c_uint64, c_void_p, c_void_p,
+                                       c_void_p]),
+    "passion_flash_attn_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_float,
+                                       ctypes.c_uint64, c_void_p, c_void_p, c_void_p]),
     "passion_dropout": (c_int, [c_void_p, c_void_p, c_int64, ctypes.c_float, ctypes.c_uint64, c_void_p]),
     "passion_attn_scores_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                         c_int, c_float, c_void_p, c_void_p]),

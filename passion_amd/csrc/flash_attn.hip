@@ -1,0 +1,618 @@
+// Fused multi-head self-attention for bf16 tensors with 64-wide heads (reference code/models/mmformer.py:192-227:
+// softmax(q k^T * scale) -> attention dropout -> @ v, call sites :422-425 intra-modal N = (S/16)^3, :437-443 inter-modal 4N).
+// No N x N tensor ever reaches HBM: forward keeps only the row log-sum-exp, backward recomputes the probabilities.
+//
+// gfx950 mapping (MI355X guide, "accumulator tile as the next MFMA's operand"):
+//   * v_mfma_f32_32x32x16_bf16 everywhere.  The score tile is computed TRANSPOSED, S^T[key][q] = K . Q^T, so a lane owns one query
+//     (column l & 31) and 16 of a tile's 32 keys in registers (rows (r & 3) + 8 (r >> 2) + 4 (l >> 5)): row max / row sum are
+//     in-register plus ONE exchange with lane l ^ 32, and the probabilities -- converted to bf16 in place -- ARE the B operand
+//     of the next product (O^T = V^T . P^T, dQ^T = K^T . dS^T), whose A operand comes out of the [key][d] LDS image through
+//     ds_read_b64_tr_b16 in the matching k order.  The key-major backward kernel is the mirror image (S[q][key] = Q . K^T, a
+//     lane owns one key): there P and dS are the B operands of dV^T = dO^T . P and dK^T = Q^T . dS.
+//   * backward = two kernels, both free of atomics and cross-workgroup sums (bitwise reproducible): a query-major one for dQ and
+//     a key-major one for dK, dV.  S and dP are recomputed in both: 7 MFMA products instead of 5, no dQ reduction.
+//   * online softmax with a lazy rescale: the running reference only moves when a block exceeds it by 2^8 (bf16 / f32 have the
+//     exponent range; the row sum uses the same reference, so nothing is approximated).
+//   * attention dropout: a counter-based mask, bit (b, h, q, key) = 16 bits of a two-round 24-bit-multiply hash of
+//     (seed, ((b H + h) N + q) ceil(N / 2) + key / 2): v_mad_u32_u24 is full rate (v_mul_lo_u32 is quarter rate), a query-major
+//     lane gets two keys per hash; the backward regenerates the same bits.  The 1 / (1 - p) factor is folded into the final row
+//     normalisation.  tests/test_ops_gpu.py restates the hash in numpy.
+#include "common.h"
+#include "passion_hip.h"
+#include "prof.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int DH = 64;          // head width
+constexpr int BLK = 64;         // keys (query-major kernels) / queries (key-major kernel) staged per step
+constexpr int RS = 144;         // bytes per row of a [64][64] bf16 LDS image: 16 lanes reading 16 rows at one column hit 16
+                                // different 4-bank groups (ds_read_b128 row reads); transposed reads of the same image see a
+                                // 2-way conflict on half of their lanes
+constexpr int TS = 192;         // ... of an image that is only read transposed (ds_read_b64_tr_b16: 4 consecutive rows x 64 B
+                                // land in disjoint 16-bank windows)
+constexpr float LAZY = 8.0f;    // log2 units
+
+struct FlashP {
+    const bf16_t* qkv;          // [B][N][3][H][64]
+    bf16_t* out;                // [B][N][H][64]
+    float* lse;                 // [B][H][N], log2 domain: log2 sum_key exp2(c * s)
+    const bf16_t* dout;         // backward
+    float* delta;               // [B][H][N] rowsum(dO o O)
+    bf16_t* dqkv;
+    int B, N, H;
+    float c;                    // scale * log2(e)
+    float scale;
+    unsigned thr;               // keep when the 16-bit uniform >= thr; 0 = no dropout
+    float inv_keep;
+    unsigned s0, s1;            // seed halves
+};
+
+// two rounds of (24-bit multiply-add, xorshift): every instruction is full rate on the vector ALU
+__device__ __forceinline__ unsigned drop_hash(unsigned pair, unsigned s0, unsigned s1) {
+    unsigned x = pair ^ s0;
+    x = __umul24(x, 0xB5297Au) + (x >> 9);
+    x ^= x >> 15;
+    x += s1;
+    x = __umul24(x, 0x68E31Du) + (x >> 11);
+    x ^= x >> 14;
+    return x;
+}
+
+__device__ __forceinline__ bf16x8 zero8() {
+    bf16x8 z;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) z[j] = (__bf16)0.f;
+    return z;
+}
+
+__device__ __forceinline__ f32x16 zero16() {
+    f32x16 z;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) z[j] = 0.f;
+    return z;
+}
+
+// registers 8s .. 8s+7 of a 32x32 accumulator as the bf16 B fragment of k-step s of the next product
+__device__ __forceinline__ bf16x8 pack8(const f32x16& a, int s) {
+    bf16x8 r;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r[j] = (__bf16)a[8 * s + j];
+    return r;
+}
+
+// A fragment of a product that sums over the ROWS (r0 .. r0+15) of a [row][64] LDS image (row stride `stride` bytes) and whose
+// output rows are the image's COLUMNS c0 .. c0+31, in the k order of pack8(): lane (column c0 + 16 * ((l >> 4) & 1) + (l & 15),
+// half h = l >> 5), element j <-> image row r0 + 8 (j >> 2) + 4 h + (j & 3).
+__device__ __forceinline__ bf16x8 tr_frag(const char* img, int stride, int r0, int c0, int lane) {
+    const int n = lane & 15, g = lane >> 4, h = g >> 1, q4 = n >> 2, pq = n & 3;
+    const char* p0 = img + (r0 + 4 * h + q4) * stride + (c0 + 16 * (g & 1) + 4 * pq) * 2;
+    const char* p1 = p0 + 8 * stride;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p0));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p1));
+    return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+}
+
+// row fragment: lane (row r0 + (l & 31), half h), 8 consecutive columns 16 s + 8 h of a [row][64] image
+__device__ __forceinline__ bf16x8 row_frag(const char* img, int stride, int r0, int s, int lane) {
+    return *reinterpret_cast<const bf16x8*>(img + (r0 + (lane & 31)) * stride + (16 * s + 8 * (lane >> 5)) * 2);
+}
+
+// 64 rows x 64 columns of one head's q / k / v (or dout) slice -> registers (NT threads, 512 16-byte chunks), zero past N
+template <int NT>
+__device__ __forceinline__ void fetch_tile(u32x4 (&r)[512 / NT], const bf16_t* base, long rowstride, int row0, int N, int tid) {
+#pragma unroll
+    for (int i = 0; i < 512 / NT; ++i) {
+        const int ci = i * NT + tid, row = ci >> 3, c8 = ci & 7;
+        r[i] = (u32x4){0u, 0u, 0u, 0u};
+        if (row0 + row < N) r[i] = *reinterpret_cast<const u32x4*>(base + (long)(row0 + row) * rowstride + c8 * 8);
+    }
+}
+template <int NT>
+__device__ __forceinline__ void commit_tile(const u32x4 (&r)[512 / NT], char* img, int stride, int tid) {
+#pragma unroll
+    for (int i = 0; i < 512 / NT; ++i) {
+        const int ci = i * NT + tid, row = ci >> 3, c8 = ci & 7;
+        *reinterpret_cast<u32x4*>(img + row * stride + c8 * 16) = r[i];
+    }
+}
+
+// max / sum of a value over the two lanes l, l ^ 32 that share a query: v_permlane32_swap leaves [lo, lo] and [hi, hi]
+__device__ __forceinline__ float half_max(float v) {
+    const unsigned u = __float_as_uint(v);
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float half_sum(float v) {
+    const unsigned u = __float_as_uint(v);
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
+#define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
+
+// --------------------------------------------------------------------------------------------------------------
+// query-major kernels: MODE 0 = forward (out, lse), MODE 1 = backward dQ
+// grid (ceil(N / (32 NW)), H, B), block 64 NW: wave w owns queries q0 .. q0+31
+template <int NW, int MODE>
+__global__ __launch_bounds__(64 * NW) void flash_q_kernel(FlashP p) {
+    constexpr int NT = 64 * NW;
+    constexpr int KIMG = BLK * RS, VIMG = (MODE == 0) ? BLK * TS : BLK * RS;
+    extern __shared__ __attribute__((aligned(16))) char lds[];      // [2][K image | V image]
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, h = lane >> 5;
+    const int hh = blockIdx.y, b = blockIdx.z, N = p.N;
+    const long rs = 3L * p.H * DH;
+    const bf16_t* qb = p.qkv + (long)b * N * rs + hh * DH;
+    const bf16_t* kbase = qb + (long)p.H * DH;
+    const bf16_t* vbase = qb + 2L * p.H * DH;
+    const int q0 = (blockIdx.x * NW + wv) * 32, q = q0 + (lane & 31);
+    const bool qok = q < N;
+    const int nblk = (N + BLK - 1) / BLK;
+
+    // B operands held for the whole kernel: Q^T (and dO^T) of this wave's 32 queries
+    bf16x8 qf[4], dof[MODE == 1 ? 4 : 1];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        qf[s] = zero8();
+        if (qok) qf[s] = *reinterpret_cast<const bf16x8*>(qb + (long)q * rs + 16 * s + 8 * h);
+        if (MODE == 1) {
+            dof[s] = zero8();
+            if (qok) dof[s] = *reinterpret_cast<const bf16x8*>(p.dout + ((long)b * N + q) * (p.H * DH) + hh * DH + 16 * s + 8 * h);
+        }
+    }
+    float lse2 = 0.f, dlt = 0.f;
+    if (MODE == 1 && qok) {
+        lse2 = p.lse[((long)b * p.H + hh) * N + q];
+        dlt = p.delta[((long)b * p.H + hh) * N + q];
+    }
+    const unsigned npair = (unsigned)(N + 1) >> 1;
+    const unsigned rowpair = ((unsigned)(b * p.H + hh) * (unsigned)N + (unsigned)q) * npair;
+
+    f32x16 o[2] = {zero16(), zero16()};          // forward: O^T[d][q]; backward: dQ^T[d][q]
+    float m_run = -INFINITY, l_run = 0.f;
+
+    u32x4 kr[512 / NT], vr[512 / NT];
+    fetch_tile<NT>(kr, kbase, rs, 0, N, tid);
+    fetch_tile<NT>(vr, vbase, rs, 0, N, tid);
+    commit_tile<NT>(kr, lds, RS, tid);
+    commit_tile<NT>(vr, lds + KIMG, MODE == 0 ? TS : RS, tid);
+    __syncthreads();
+
+    for (int kb = 0; kb < nblk; ++kb) {
+        const char* kimg = lds + (kb & 1) * (KIMG + VIMG);
+        const char* vimg = kimg + KIMG;
+        if (kb + 1 < nblk) {
+            fetch_tile<NT>(kr, kbase, rs, (kb + 1) * BLK, N, tid);
+            fetch_tile<NT>(vr, vbase, rs, (kb + 1) * BLK, N, tid);
+        }
+        // ---- S^T = K . Q^T (and dP^T = V . dO^T): two 32-key tiles.  All A fragments of the step are requested before the first
+        // MFMA (the compiler otherwise alternates read / wait / MFMA on two registers and every LDS latency is exposed)
+        f32x16 st[2], dp[MODE == 1 ? 2 : 1];
+        {
+            bf16x8 kfr[2][4];
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int s = 0; s < 4; ++s) kfr[kt][s] = row_frag(kimg, RS, kt * 32, s, lane);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt) {
+                st[kt] = zero16();
+#pragma unroll
+                for (int s = 0; s < 4; ++s) st[kt] = MFMA32(kfr[kt][s], qf[s], st[kt]);
+            }
+            if (MODE == 1) {
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) kfr[kt][s] = row_frag(vimg, RS, kt * 32, s, lane);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt) {
+                    dp[kt] = zero16();
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) dp[kt] = MFMA32(kfr[kt][s], dof[s], dp[kt]);
+                }
+            }
+        }
+        // transposed fragments of the second product: requested now, consumed after the softmax arithmetic
+        const char* timg = (MODE == 0) ? vimg : kimg;
+        constexpr int tstride = (MODE == 0) ? TS : RS;
+        bf16x8 tfr[2][2][2];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) tfr[kt][s][dt] = tr_frag(timg, tstride, kt * 32 + 16 * s, dt * 32, lane);
+        const int key0 = kb * BLK;
+        const bool ragged = key0 + BLK > N;
+        if (ragged) {
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (key0 + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h >= N) st[kt][r] = -INFINITY;
+        }
+        if (MODE == 0) {
+            // ---- online softmax, lazy reference
+            float mx = -INFINITY;
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[kt][r]);
+            mx = half_max(mx) * p.c;
+            const bool move = mx > m_run + LAZY;
+            if (__any(move)) {
+                const float m_new = move ? mx : m_run;
+                const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);     // first block: exp2(-inf) = 0
+                m_run = m_new;
+                l_run *= alpha;
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+            }
+            float psum = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(st[kt][r], p.c, -m_run));
+                    st[kt][r] = e;
+                    psum += e;
+                }
+            l_run += psum;
+        } else {
+            // ---- P^T from the saved log-sum-exp; dS^T = P^T o (dP^T_dropped - delta)
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) st[kt][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(st[kt][r], p.c, -lse2));
+        }
+        if (p.thr) {           // dropout bits of this lane's 32 (query, key) elements: two keys per hash
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {
+                    const unsigned key = (unsigned)(key0 + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h);
+                    const unsigned u = drop_hash(rowpair + (key >> 1), p.s0, p.s1);
+                    const bool k0 = (u & 0xffffu) >= p.thr, k1 = (u >> 16) >= p.thr;
+                    if (MODE == 0) {
+                        st[kt][r] = k0 ? st[kt][r] : 0.f;
+                        st[kt][r + 1] = k1 ? st[kt][r + 1] : 0.f;
+                    } else {
+                        dp[kt][r] = k0 ? dp[kt][r] * p.inv_keep : 0.f;
+                        dp[kt][r + 1] = k1 ? dp[kt][r + 1] * p.inv_keep : 0.f;
+                    }
+                }
+        }
+        if (MODE == 1) {
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) st[kt][r] *= (dp[kt][r] - dlt);
+        }
+        // ---- O^T += V^T . P^T   /   dQ^T += K^T . dS^T
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const bf16x8 pf = pack8(st[kt], s);
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) o[dt] = MFMA32(tfr[kt][s][dt], pf, o[dt]);
+            }
+        if (kb + 1 < nblk) {
+            char* nk = lds + ((kb + 1) & 1) * (KIMG + VIMG);
+            commit_tile<NT>(kr, nk, RS, tid);
+            commit_tile<NT>(vr, nk + KIMG, MODE == 0 ? TS : RS, tid);
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: scale, transpose through LDS (the tile buffers are free after the last barrier), whole 128-byte rows out
+    float f;
+    if (MODE == 0) {
+        const float l_tot = half_sum(l_run);
+        f = p.inv_keep / l_tot;
+        if (qok && h == 0) p.lse[((long)b * p.H + hh) * N + q] = m_run + __builtin_amdgcn_logf(l_tot);
+    } else {
+        f = p.scale;
+    }
+    char* obuf = lds + wv * (32 * RS);            // [32 queries][64 d] bf16 per wave
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            union { bf16_t hv[4]; uint2 u; } t;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) t.hv[j] = (bf16_t)(o[dt][4 * g4 + j] * f);
+            *reinterpret_cast<uint2*>(obuf + (lane & 31) * RS + (dt * 32 + 8 * g4 + 4 * h) * 2) = t.u;
+        }
+    __syncthreads();
+    bf16_t* dst = (MODE == 0) ? p.out + (long)b * N * (p.H * DH) + hh * DH : p.dqkv + (long)b * N * rs + hh * DH;
+    const long drs = (MODE == 0) ? (long)p.H * DH : rs;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int ci = i * 64 + lane, row = ci >> 3, c8 = ci & 7;
+        if (q0 + row < N)
+            *reinterpret_cast<u32x4*>(dst + (long)(q0 + row) * drs + c8 * 8) = *reinterpret_cast<const u32x4*>(obuf + row * RS + c8 * 16);
+    }
+}
+
+// --------------------------------------------------------------------------------------------------------------
+// key-major backward kernel: dK, dV.  grid (ceil(N / (32 NW)), H, B); wave w owns keys k0 .. k0+31 and walks the queries in
+// steps of 64 (Q and dO staged in LDS, read by rows for S / dP and transposed for dK^T / dV^T; lse, delta beside them)
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void flash_k_kernel(FlashP p) {
+    constexpr int NT = 64 * NW;
+    constexpr int IMG = BLK * RS, BUF = 2 * IMG + 2 * BLK * 4;
+    extern __shared__ __attribute__((aligned(16))) char lds[];      // [2][Q image | dO image | lse[64] | delta[64]]
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, h = lane >> 5;
+    const int hh = blockIdx.y, b = blockIdx.z, N = p.N;
+    const long rs = 3L * p.H * DH, os = (long)p.H * DH;
+    const bf16_t* qb = p.qkv + (long)b * N * rs + hh * DH;
+    const bf16_t* dob = p.dout + (long)b * N * os + hh * DH;
+    const float* lseb = p.lse + ((long)b * p.H + hh) * N;
+    const float* dltb = p.delta + ((long)b * p.H + hh) * N;
+    const int k0 = (blockIdx.x * NW + wv) * 32, key = k0 + (lane & 31);
+    const bool kok = key < N;
+    const int nblk = (N + BLK - 1) / BLK;
+
+    bf16x8 kf[4], vf[4];                                  // B operands: K^T, V^T of this wave's 32 keys
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        kf[s] = zero8(); vf[s] = zero8();
+        if (kok) {
+            kf[s] = *reinterpret_cast<const bf16x8*>(qb + (long)key * rs + p.H * DH + 16 * s + 8 * h);
+            vf[s] = *reinterpret_cast<const bf16x8*>(qb + (long)key * rs + 2 * p.H * DH + 16 * s + 8 * h);
+        }
+    }
+    const unsigned npair = (unsigned)(N + 1) >> 1;
+    const unsigned bhrow = (unsigned)(b * p.H + hh) * (unsigned)N;
+    const unsigned kpair = (unsigned)key >> 1;
+    const int khalf = key & 1;
+
+    f32x16 dk[2] = {zero16(), zero16()}, dv[2] = {zero16(), zero16()};       // dK^T[d][key], dV^T[d][key]
+    u32x4 qr[512 / NT], dr[512 / NT];
+    float lr = 0.f, tr = 0.f;                             // thread tid < 64: lse / delta of query q0 + tid
+    auto fetch_rows = [&](int q0) {
+        fetch_tile<NT>(qr, qb, rs, q0, N, tid);
+        fetch_tile<NT>(dr, dob, os, q0, N, tid);
+        if (tid < BLK) {
+            const bool ok = q0 + tid < N;
+            lr = ok ? lseb[q0 + tid] : INFINITY;           // exp2(. - inf) = 0: queries past N contribute nothing
+            tr = ok ? dltb[q0 + tid] : 0.f;
+        }
+    };
+    auto commit_rows = [&](char* buf) {
+        commit_tile<NT>(qr, buf, RS, tid);
+        commit_tile<NT>(dr, buf + IMG, RS, tid);
+        if (tid < BLK) {
+            reinterpret_cast<float*>(buf + 2 * IMG)[tid] = lr;
+            reinterpret_cast<float*>(buf + 2 * IMG + BLK * 4)[tid] = tr;
+        }
+    };
+    fetch_rows(0);
+    commit_rows(lds);
+    __syncthreads();
+
+    for (int qbk = 0; qbk < nblk; ++qbk) {
+        const char* qimg = lds + (qbk & 1) * BUF;
+        const char* dimg = qimg + IMG;
+        const float* lsev = reinterpret_cast<const float*>(qimg + 2 * IMG);
+        const float* dltv = lsev + BLK;
+        if (qbk + 1 < nblk) fetch_rows((qbk + 1) * BLK);
+        const int q0 = qbk * BLK;
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+            // ---- S[q][key] = Q . K^T, dP[q][key] = dO . V^T for 32 queries (rows) x this lane's key
+            f32x16 sa = zero16(), da = zero16();
+            {
+                bf16x8 qfr[4], dfr[4];
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    qfr[s] = row_frag(qimg, RS, qt * 32, s, lane);
+                    dfr[s] = row_frag(dimg, RS, qt * 32, s, lane);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    sa = MFMA32(qfr[s], kf[s], sa);
+                    da = MFMA32(dfr[s], vf[s], da);
+                }
+            }
+            bf16x8 tq[2][2], td[2][2];                       // transposed fragments of the two gradient products, requested early
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) {
+                    td[s][dt] = tr_frag(dimg, RS, qt * 32 + 16 * s, dt * 32, lane);
+                    tq[s][dt] = tr_frag(qimg, RS, qt * 32 + 16 * s, dt * 32, lane);
+                }
+            // row constants of the 16 queries this lane holds: rows 8 g4 + 4 h + j
+            f32x16 pd;                                        // dropped probabilities (B operand of dV^T)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const f32x4 l4 = *reinterpret_cast<const f32x4*>(lsev + qt * 32 + 8 * g4 + 4 * h);
+                const f32x4 d4 = *reinterpret_cast<const f32x4*>(dltv + qt * 32 + 8 * g4 + 4 * h);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int r = 4 * g4 + j;
+                    float pr = kok ? __builtin_amdgcn_exp2f(__builtin_fmaf(sa[r], p.c, -l4[j])) : 0.f;
+                    float dpv = da[r], pdv = pr;
+                    if (p.thr) {
+                        const unsigned qq = (unsigned)(q0 + qt * 32 + 8 * g4 + 4 * h + j);
+                        const unsigned u = drop_hash((bhrow + qq) * npair + kpair, p.s0, p.s1);
+                        const bool keep = ((khalf ? (u >> 16) : (u & 0xffffu)) >= p.thr);
+                        dpv = keep ? dpv * p.inv_keep : 0.f;
+                        pdv = keep ? pr * p.inv_keep : 0.f;
+                    }
+                    pd[r] = pdv;
+                    sa[r] = pr * (dpv - d4[j]);               // dS
+                }
+            }
+            // ---- dV^T += dO^T . P_dropped,  dK^T += Q^T . dS   (sum over the 32 queries = rows of the accumulators)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const bf16x8 pf = pack8(pd, s), sf = pack8(sa, s);
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) {
+                    dv[dt] = MFMA32(td[s][dt], pf, dv[dt]);
+                    dk[dt] = MFMA32(tq[s][dt], sf, dk[dt]);
+                }
+            }
+        }
+        if (qbk + 1 < nblk) commit_rows(lds + ((qbk + 1) & 1) * BUF);
+        __syncthreads();
+    }
+
+    // ---- epilogue: dK = scale * dK^T^T, dV through LDS, whole rows out
+    char* obuf = lds + wv * (2 * 32 * RS);
+#pragma unroll
+    for (int which = 0; which < 2; ++which) {
+        const float f = which == 0 ? p.scale : 1.f;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                union { bf16_t hv[4]; uint2 u; } t;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) t.hv[j] = (bf16_t)((which == 0 ? dk[dt][4 * g4 + j] : dv[dt][4 * g4 + j]) * f);
+                *reinterpret_cast<uint2*>(obuf + which * 32 * RS + (lane & 31) * RS + (dt * 32 + 8 * g4 + 4 * h) * 2) = t.u;
+            }
+    }
+    __syncthreads();
+    bf16_t* dst = p.dqkv + (long)b * N * rs + hh * DH;
+#pragma unroll
+    for (int which = 0; which < 2; ++which)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int ci = i * 64 + lane, row = ci >> 3, c8 = ci & 7;
+            if (k0 + row < N)
+                *reinterpret_cast<u32x4*>(dst + (long)(k0 + row) * rs + (which + 1) * p.H * DH + c8 * 8) =
+                    *reinterpret_cast<const u32x4*>(obuf + which * 32 * RS + row * RS + c8 * 16);
+        }
+}
+
+// delta[b][h][q] = sum_d dO[b][q][h][d] * O[b][q][h][d]: 8 lanes per (b, q, h) row of 64
+__global__ __launch_bounds__(256) void flash_delta_kernel(const bf16_t* __restrict__ o, const bf16_t* __restrict__ dout, float* __restrict__ delta,
+                                                          int B, int N, int H) {
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;
+    const long row = t >> 3;                      // (b * N + q) * H + h
+    const int c8 = (int)(t & 7);
+    float s = 0.f;
+    if (row < (long)B * N * H) {
+        float a[8], g[8];
+        VecIO<bf16_t, 8>::load(o + row * DH + c8 * 8, a);
+        VecIO<bf16_t, 8>::load(dout + row * DH + c8 * 8, g);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s = __builtin_fmaf(a[j], g[j], s);
+    }
+    s += __shfl_xor(s, 1, 64);
+    s += __shfl_xor(s, 2, 64);
+    s += __shfl_xor(s, 4, 64);
+    if (c8 == 0 && row < (long)B * N * H) {
+        const long bq = row / H;
+        const int h = (int)(row % H);
+        const long b = bq / N, q = bq % N;
+        delta[(b * H + h) * N + q] = s;
+    }
+}
+
+int set_dropout(FlashP& p, float drop_p, uint64_t seed) {
+    if (!(drop_p >= 0.f && drop_p < 1.f)) return -1003;
+    p.thr = (unsigned)(drop_p * 65536.0f + 0.5f);
+    p.inv_keep = p.thr ? 1.0f / (1.0f - (float)p.thr / 65536.0f) : 1.0f;
+    p.s0 = (unsigned)(seed & 0xffffffffu);
+    p.s1 = (unsigned)(seed >> 32);
+    return 0;
+}
+
+template <typename K>
+int grant_lds(K kern, int bytes) {
+    HIP_RET(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    return 0;
+}
+
+// waves per workgroup: 4 when that still gives the chip >= 2 workgroups per CU, else fewer
+int pick_nw(int B, int N, int H) {
+    const long tiles = (long)((N + 31) / 32) * H * B;
+    return tiles >= 4 * 512 ? 4 : (tiles >= 2 * 256 ? 2 : 1);
+}
+
+}  // namespace
+
+extern "C" int passion_flash_attn_supported(int dtype, int Dh) { return dtype == PASSION_BF16 && Dh == DH; }
+
+extern "C" int passion_flash_attn_fwd(const void* qkv, int B, int N, int H, int Dh, float scale, float drop_p, uint64_t seed,
+                                      void* out, float* lse, void* stream) {
+    if (Dh != DH || B <= 0 || N <= 0 || H <= 0) return -1003;
+    if ((reinterpret_cast<uintptr_t>(qkv) | reinterpret_cast<uintptr_t>(out)) & 15) return -1005;
+    FlashP p{};
+    p.qkv = (const bf16_t*)qkv; p.out = (bf16_t*)out; p.lse = lse;
+    p.B = B; p.N = N; p.H = H; p.scale = scale; p.c = scale * 1.4426950408889634f;
+    int rc = set_dropout(p, drop_p, seed);
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    const int nw = pick_nw(B, N, H);
+    const dim3 grid((N + 32 * nw - 1) / (32 * nw), H, B);
+    const int bytes = 2 * (BLK * RS + BLK * TS);
+    ProfScope prof(4, 2.0 * B * N * H * Dh * 2 * 2, 4.0 * B * H * (double)N * N * Dh, st);
+    passion_prof_tag("flash_q_kernel<%d, 0>", nw);
+    static bool granted = false;
+    if (!granted) {
+        if ((rc = grant_lds(flash_q_kernel<4, 0>, bytes)) || (rc = grant_lds(flash_q_kernel<2, 0>, bytes)) || (rc = grant_lds(flash_q_kernel<1, 0>, bytes))) return rc;
+        granted = true;
+    }
+    if (nw == 4) hipLaunchKernelGGL((flash_q_kernel<4, 0>), grid, dim3(256), bytes, st, p);
+    else if (nw == 2) hipLaunchKernelGGL((flash_q_kernel<2, 0>), grid, dim3(128), bytes, st, p);
+    else hipLaunchKernelGGL((flash_q_kernel<1, 0>), grid, dim3(64), bytes, st, p);
+    LAUNCH_RET();
+    return 0;
+}
+
+extern "C" int passion_flash_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse, int B, int N, int H, int Dh,
+                                      float scale, float drop_p, uint64_t seed, float* delta, void* dqkv, void* stream) {
+    if (Dh != DH || B <= 0 || N <= 0 || H <= 0) return -1003;
+    if ((reinterpret_cast<uintptr_t>(qkv) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(dout) | reinterpret_cast<uintptr_t>(dqkv)) & 15) return -1005;
+    FlashP p{};
+    p.qkv = (const bf16_t*)qkv; p.out = nullptr; p.lse = const_cast<float*>(lse); p.dout = (const bf16_t*)dout; p.delta = delta; p.dqkv = (bf16_t*)dqkv;
+    p.B = B; p.N = N; p.H = H; p.scale = scale; p.c = scale * 1.4426950408889634f;
+    int rc = set_dropout(p, drop_p, seed);
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    ProfScope prof(5, 2.0 * B * N * H * Dh * 2 * 4, 10.0 * B * H * (double)N * N * Dh, st);      // backward = 2.5 x forward FLOPs
+    const long rows8 = (long)B * N * H * 8;
+    hipLaunchKernelGGL(flash_delta_kernel, dim3((unsigned)((rows8 + 255) / 256)), dim3(256), 0, st, (const bf16_t*)out, (const bf16_t*)dout, delta, B, N, H);
+    LAUNCH_RET();
+    const int nw = pick_nw(B, N, H);
+    const dim3 grid((N + 32 * nw - 1) / (32 * nw), H, B);
+    const int qbytes = 2 * (2 * BLK * RS);
+    const int kbytes_min = 2 * (2 * BLK * RS + 2 * BLK * 4);
+    passion_prof_tag("flash_q_kernel<%d, 1> + flash_k_kernel<%d>", nw, nw);
+    static bool granted = false;
+    if (!granted) {
+        const int kb4 = kbytes_min > 4 * 2 * 32 * RS ? kbytes_min : 4 * 2 * 32 * RS;
+        if ((rc = grant_lds(flash_q_kernel<4, 1>, qbytes)) || (rc = grant_lds(flash_q_kernel<2, 1>, qbytes)) || (rc = grant_lds(flash_q_kernel<1, 1>, qbytes)) ||
+            (rc = grant_lds(flash_k_kernel<4>, kb4)) || (rc = grant_lds(flash_k_kernel<2>, kb4)) || (rc = grant_lds(flash_k_kernel<1>, kb4))) return rc;
+        granted = true;
+    }
+    const int kbytes = kbytes_min > nw * 2 * 32 * RS ? kbytes_min : nw * 2 * 32 * RS;      // the epilogue stages 2 x [32][64] per wave
+    if (nw == 4) {
+        hipLaunchKernelGGL((flash_q_kernel<4, 1>), grid, dim3(256), qbytes, st, p);
+        hipLaunchKernelGGL((flash_k_kernel<4>), grid, dim3(256), kbytes, st, p);
+    } else if (nw == 2) {
+        hipLaunchKernelGGL((flash_q_kernel<2, 1>), grid, dim3(128), qbytes, st, p);
+        hipLaunchKernelGGL((flash_k_kernel<2>), grid, dim3(128), kbytes, st, p);
+    } else {
+        hipLaunchKernelGGL((flash_q_kernel<1, 1>), grid, dim3(64), qbytes, st, p);
+        hipLaunchKernelGGL((flash_k_kernel<1>), grid, dim3(64), kbytes, st, p);
+    }
+    LAUNCH_RET();
+    return 0;
+}

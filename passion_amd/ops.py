@@ -557,8 +557,46 @@ def proto_loss(fs, ft, target_cl):
 # ------------------------------------------------------------------------------------------------
 # attention
 # ------------------------------------------------------------------------------------------------
+def _draw_seed():
+    """64-bit seed of an attention-dropout mask from torch's CPU generator (follows torch.manual_seed; no device sync)"""
+    return int(torch.empty((), dtype=torch.int64).random_().item()) & (2 ** 64 - 1)
+
+
+class FlashAttentionFn(torch.autograd.Function):
+    """fused attention for bf16, 64-wide heads (csrc/flash_attn.hip): no (B,H,N,N) tensor, backward recomputes from the row
+    log-sum-exp; attention dropout is a counter-based mask regenerated in the backward from the forward's seed"""
+
+    @staticmethod
+    def forward(ctx, qkv, heads, scale, drop_p):
+        L.require_gpu(qkv)
+        qkv = qkv.contiguous()
+        B, N, C3 = qkv.shape
+        Dh = C3 // 3 // heads
+        seed = _draw_seed() if drop_p > 0.0 else 0
+        out = torch.empty(B, N, heads * Dh, dtype=qkv.dtype, device=qkv.device)
+        lse = torch.empty(B, heads, N, dtype=torch.float32, device=qkv.device)
+        L.check(L.load().passion_flash_attn_fwd(_p(qkv), B, N, heads, Dh, float(scale), float(drop_p), seed, _p(out), _p(lse),
+                                                L.stream_ptr()), "passion_flash_attn_fwd")
+        ctx.heads, ctx.scale, ctx.drop_p, ctx.seed = heads, float(scale), float(drop_p), seed
+        ctx.save_for_backward(qkv, out, lse)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        qkv, out, lse = ctx.saved_tensors
+        B, N, C3 = qkv.shape
+        H = ctx.heads
+        dout = dout.contiguous()
+        dqkv = torch.empty_like(qkv)
+        delta = torch.empty(B, H, N, dtype=torch.float32, device=qkv.device)
+        L.check(L.load().passion_flash_attn_bwd(_p(qkv), _p(out), _p(dout), _p(lse), B, N, H, C3 // 3 // H, ctx.scale, ctx.drop_p,
+                                                ctx.seed, _p(delta), _p(dqkv), L.stream_ptr()), "passion_flash_attn_bwd")
+        return dqkv, None, None, None
+
+
 class AttentionFn(torch.autograd.Function):
-    """softmax(q k^T * scale) v for qkv (B,N,3,H,Dh) -> (B,N,H*Dh)  (reference mmformer.py:220-224).
+    """softmax(q k^T * scale) v for qkv (B,N,3,H,Dh) -> (B,N,H*Dh)  (reference mmformer.py:220-224), general path: f32 parity
+    mode (exact f32 MFMA) and head widths other than 64; the scores are materialised.
     `drop_p` > 0 applies attention dropout to the probabilities (mmformer.py:222)."""
 
     @staticmethod
@@ -574,9 +612,9 @@ class AttentionFn(torch.autograd.Function):
                 "passion_attn_scores_fwd")
         pd, seed = probs, 0
         if drop_p > 0.0:     # one pass, mask regenerated from the seed in backward (no rand / compare / mask tensors)
-            seed = int(torch.empty((), dtype=torch.int64).random_().item())      # CPU generator: follows torch.manual_seed
+            seed = _draw_seed()
             pd = torch.empty_like(probs)
-            L.check(lib.passion_dropout(_p(probs), _p(pd), probs.numel(), float(drop_p), seed & (2 ** 64 - 1), L.stream_ptr()),
+            L.check(lib.passion_dropout(_p(probs), _p(pd), probs.numel(), float(drop_p), seed, L.stream_ptr()),
                     "passion_dropout")
         out = torch.empty(B, N, heads * Dh, dtype=qkv.dtype, device=qkv.device)
         L.check(lib.passion_attn_pv_fwd(_p(pd), _p(qkv), dt, B, N, heads, Dh, _p(out), L.stream_ptr()),
@@ -599,14 +637,19 @@ class AttentionFn(torch.autograd.Function):
         L.check(lib.passion_attn_pv_bwd(_p(pd if pd is not None else probs), _p(qkv), _p(dout), dt, B, N, H, Dh,
                                         _p(dprobs), _p(dqkv), L.stream_ptr()), "passion_attn_pv_bwd")
         if pd is not None:           # the same mask, in place
-            L.check(lib.passion_dropout(_p(dprobs), _p(dprobs), dprobs.numel(), float(ctx.drop_p), ctx.seed & (2 ** 64 - 1),
+            L.check(lib.passion_dropout(_p(dprobs), _p(dprobs), dprobs.numel(), float(ctx.drop_p), ctx.seed,
                                         L.stream_ptr()), "passion_dropout")
         L.check(lib.passion_attn_scores_bwd(_p(probs), _p(dprobs), _p(qkv), dt, B, N, H, Dh, ctx.scale, _p(dqkv),
                                             L.stream_ptr()), "passion_attn_scores_bwd")
         return dqkv, None, None, None
 
 
+FLASH = True      # A/B switch (tests compare the two paths)
+
+
 def attention(qkv, heads, scale, drop_p=0.0):
+    if FLASH and qkv.dtype == torch.bfloat16 and qkv.shape[-1] // 3 // heads == 64:
+        return FlashAttentionFn.apply(qkv, heads, scale, drop_p)
     return AttentionFn.apply(qkv, heads, scale, drop_p)
 
 

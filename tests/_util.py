@@ -72,3 +72,22 @@ def rel(a, b):
     a = torch.as_tensor(np.asarray(a)).double().cpu() if not torch.is_tensor(a) else a.detach().double().cpu()
     b = torch.as_tensor(np.asarray(b)).double().cpu() if not torch.is_tensor(b) else b.detach().double().cpu()
     return ((a - b).abs().max() / (b.abs().max() + 1e-12)).item()
+
+
+def flash_keep_mask(B, N, p, seed, H=8):
+    """numpy restatement of drop_hash (flash_attn.hip): keep[b, h, q, key]"""
+    thr = int(p * 65536.0 + 0.5)
+    s0, s1 = np.uint64(seed & 0xffffffff), np.uint64(seed >> 32)
+    m32, m24 = np.uint64(0xffffffff), np.uint64(0xffffff)
+    npair = (N + 1) // 2
+    rows = np.arange(B * H * N, dtype=np.uint64)[:, None] * np.uint64(npair)
+    pair = ((rows + np.arange(npair, dtype=np.uint64)[None, :]) & m32)
+    x = (pair ^ s0) & m32
+    x = ((x & m24) * np.uint64(0xB5297A) + (x >> np.uint64(9))) & m32
+    x ^= x >> np.uint64(15)
+    x = (x + s1) & m32
+    x = ((x & m24) * np.uint64(0x68E31D) + (x >> np.uint64(11))) & m32
+    x ^= x >> np.uint64(14)
+    u = np.stack([x & np.uint64(0xffff), x >> np.uint64(16)], -1).reshape(B * H * N, 2 * npair)[:, :N]
+    keep = (u >= thr).reshape(B, H, N, N)
+    return torch.from_numpy(keep), 1.0 / (1.0 - thr / 65536.0)

@@ -17,7 +17,9 @@ from _util import build_product_model, gold, grad_norms, rel, synth
 pytestmark = pytest.mark.gpu
 
 # bf16 storage / f32 accumulate vs the f32 reference, 128^3, ~130 conv layers deep (measured on MI355X, x ~2 headroom)
-BF16_TOL = {"pred": 4e-2, "loss_terms": 4e-2, "loss": 2e-2, "grad_norm": 8e-2, "mask_agree": 0.97}
+# first measurement (r02, cfg1): pred max 1.0e-1 (a handful of voxels; rms below), loss terms 1.6e-4, loss 1.1e-4, grad norms 6.8e-3,
+# mask agreement 0.9835 (random-init logits are near-ties almost everywhere: 477 voxels tie below 1e-4 even in f32)
+BF16_TOL = {"pred_max": 2e-1, "pred_rms": 2e-2, "loss_terms": 5e-3, "loss": 2e-3, "grad_norm": 3e-2, "mask_agree": 0.97}
 
 
 def _unpack2(packed, n):
@@ -94,7 +96,10 @@ def _check_bf16(g, m, outs, loss, tag):
     S = int(g["S"])
     pred = outs[0]
     t = BF16_TOL
-    obs = {"pred": max(rel(pred[:, :, S // 2], g["pred_slice"]), rel(pred.double().sum((2, 3, 4)), g["pred_sum"]))}
+    ref_slice = torch.from_numpy(g["pred_slice"]).double()
+    obs = {"pred_max": rel(pred[:, :, S // 2], g["pred_slice"]),
+           "pred_rms": float((pred[:, :, S // 2].double().cpu() - ref_slice).pow(2).mean().sqrt() / ref_slice.pow(2).mean().sqrt()),
+           "pred_sum": rel(pred.double().sum((2, 3, 4)), g["pred_sum"])}
     obs["loss_terms"] = max(rel(o, g[n]) for n, o in zip(["prm_loss", "sep_loss", "kl_loss", "proto_loss"], outs[1:5]))
     obs["loss"] = abs(float(loss) - float(g["loss"])) / abs(float(g["loss"]))
     gn = grad_norms((k, p.grad) for k, p in m.named_parameters())
@@ -102,6 +107,7 @@ def _check_bf16(g, m, outs, loss, tag):
     diff = _mask_report(g, pred, tag)
     agree = 1.0 - len(diff) / S ** 3
     print(f"[{tag}] bf16 vs f32 reference: " + ", ".join(f"{k} {v:.3e}" for k, v in obs.items()) + f", mask agreement {agree:.5f}")
+    t = dict(t, pred_sum=t["loss"])
     for k, v in obs.items():
         assert v < t[k], (k, v, t[k])
     assert agree > t["mask_agree"]

@@ -7,7 +7,7 @@ import sys
 import numpy as np
 import torch
 
-from _util import gold
+from _util import flash_keep_mask, gold
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -74,3 +74,17 @@ def test_fixture_argmax_packing_roundtrip():
     lab = np.stack([(p >> (2 * j)) & 3 for j in range(4)], 1).reshape(-1)
     import hashlib
     assert hashlib.sha1(lab.astype(np.uint8).tobytes()).hexdigest() == str(g["argmax_sha1"])
+
+
+def test_dropout_hash_statistics():
+    """CPU-side property of the mask generator itself (keep rate, independence of neighbours / rows / seeds)"""
+    keep, _ = flash_keep_mask(1, 1024, 0.1, 0x123456789abcdef)
+    k = keep.float().reshape(-1, 1024)
+    assert abs(float(k.mean()) - 0.9) < 2e-3
+    kc = k - k.mean()
+    for lag in (1, 2, 3, 16, 64):
+        assert abs(float((kc[:, :-lag] * kc[:, lag:]).mean() / kc.var())) < 5e-3
+    assert abs(float((kc[:-1] * kc[1:]).mean() / kc.var())) < 5e-3
+    keep2, _ = flash_keep_mask(1, 1024, 0.1, 0x123456789abcdf0)
+    k2 = keep2.float().reshape(-1, 1024)
+    assert abs(float(((k2 - k2.mean()) * kc).mean() / kc.var())) < 5e-3
