@@ -761,7 +761,7 @@ static long pass_scratch_floats(const ConvK& k, const passion_conv_desc_t* d) {
 // scratch layout (floats): [InstanceNorm-backward sums | wgrad slab] then, from a 128-byte boundary, [padded-domain gradient]
 // [per-pass gradients or the masked pass sums]
 static long slab_end_floats(const ConvK& k, int gx, int nt) {
-    const long n = (long)2 * k.B * k.Cin * SUMS_REP + (long)gx * ((long)k.Cout * k.Cin * nt + k.Cout);
+    const long n = (long)2 * k.B * k.Cin * SUMS_SLOTS + (long)gx * ((long)k.Cout * k.Cin * nt + k.Cout);
     return (n + 31) / 32 * 32;
 }
 static long padout_floats(const ConvK& k) {     // bf16 [B][D+2][H+2][W+2][Cin]
@@ -941,7 +941,7 @@ extern "C" int passion_conv3d_bwd(const passion_conv_desc_t* d, const float* pac
         const WgPlan w = plan_wgrad(k, d);
         const long nW = (long)k.Cout * k.Cin * nt;
         k.wslot = nW + k.Cout;                       // one slot = [dW | dbias] of one workgroup
-        float* wslab = sums + (long)2 * k.B * k.Cin * SUMS_REP;
+        float* wslab = sums + (long)2 * k.B * k.Cin * SUMS_SLOTS;
         float* bslab = wslab + nW;
         {
             ProfScope prof(3, conv_bytes(k, xs, ys) + (double)nt * k.Cin * k.Cout * 4,

@@ -10,6 +10,7 @@
 namespace pconv {
 
 constexpr int SUMS_REP = 256;           // replicas of the InstanceNorm-backward sums (atomic contention): one-brick-per-workgroup kernels
+constexpr int SUMS_SLOTS = 1024;         // capacity of the sums region in replicas: the marching dgrad (conv_march.hip) gives every workgroup of a sample its own slot
 constexpr int SUMS_REP_LEAN = 16;       // persistent kernels add once per workgroup: few replicas, folded by the finish kernel itself
 constexpr int TD = 4, TH = 8, TW = 8;   // output brick of one 256-thread workgroup (wave w = depth slice w)
 
@@ -59,6 +60,8 @@ bool bf16_eligible(const ConvK& k, bool dgrad);
 int launch_conv_bf16(ConvK& k, int ksize, int stride, bool dgrad, const void* packed_bf16, hipStream_t st);
 int launch_conv_lean(ConvK& k, int ksize, int stride, int mode, const void* packed_bf16, hipStream_t st);   // conv_lean.hip
 bool lean_covers(const ConvK& k, int stride, bool dgrad);
+int launch_conv_march(ConvK& k, int ksize, int stride, int mode, const void* packed_bf16, hipStream_t st);   // conv_march.hip
+extern int g_conv_march;
 int launch_wgrad_lean(ConvK& k, int ksize, int stride, int MT, int gx, int gy, float* dWslab, float* dbslab, hipStream_t st);   // conv_wgrad_lean.hip
 int launch_wgrad_c1(ConvK& k, int ksize, int stride, int gx, int gy, float* dWslab, float* dbslab, hipStream_t st);   // first layer, Cin = 1
 extern int g_conv_lean;

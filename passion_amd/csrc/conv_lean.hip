@@ -777,6 +777,10 @@ bool lean_covers(const ConvK& k, int stride, bool dgrad) {
 }
 
 int launch_conv_lean(ConvK& k, int ksize, int stride, int mode, const void* packed_bf16, hipStream_t st) {
+    {   // the two finest levels: marching kernel (conv_march.hip); > 0 = not covered, go on
+        const int rc = launch_conv_march(k, ksize, stride, mode, packed_bf16, st);
+        if (rc <= 0) return rc;
+    }
     const bool dgrad = mode >= 1;
     if (stride != 1 && !(stride == 2 && mode == 2)) return 1;
     if (!(k.slope >= 0.f && k.slope <= 1.f)) return 1;      // the loader's LeakyReLU is max(t, slope * t)

@@ -1,0 +1,570 @@
+// Marching bf16 implicit-GEMM conv for the two finest levels (3x3x3, stride 1, <= 32 input and <= 16 output channels: the
+// 128^3 / 64^3 layers that hold ~3/4 of the conv bytes of a step) -- forward (MODE 0) and the padded-domain dgrad (MODE 2) of
+// general_conv3d_prenorm (reference code/models/blocks.py:300-316).  Same math, operand images, descriptors and epilogue
+// semantics as conv_lean.hip; a different schedule, designed from what the counters said about that kernel: it is
+// bound by instruction issue and by the latency of ONE brick of prefetch per workgroup, not by HBM.
+//   * a workgroup owns one (8 x TW) tile of the (H, W) plane and MARCHES along D: every input plane is fetched once per tile
+//     (halo overhead 10/8 x 34/32 = 1.33 instead of 6/4 x 10/8 x 10/8 = 2.34 per brick), the three planes a 3x3x3 tap needs
+//     live in a 4-slot LDS ring, one barrier per plane;
+//   * the tile is fixed for the workgroup's lifetime, so ALL index arithmetic (reflect / zero padding, halo, concat lookup, masks,
+//     InstanceNorm statistics, LDS offsets) is done once: per plane a staging thread adds one plane offset to a constant;
+//   * planes are fetched FOUR steps ahead into registers (4 x the bytes in flight of the one-brick prefetch) and normalised
+//     (InstanceNorm + LeakyReLU, packed f32) on their way into LDS;
+//   * weights of the whole K axis stay in registers as MFMA A fragments (<= 16 channels) -- the inner loop is one ds_read_b128
+//     per v_mfma_f32_16x16x32_bf16;
+//   * MODE 2 covers the reflect-padding adjoint without ragged tiles: tiles are aligned to the volume, the halo outputs
+//     (position -1 and S of every axis) are extra column tiles of the edge workgroups, read through a zero guard ring around
+//     the staged plane; the InstanceNorm-backward sums leave the workgroup as ONE plain store into its own slot (no atomics:
+//     the fold in conv.hip is fixed-order, so the gradients are bitwise reproducible).
+#include <cstdlib>
+#include "conv_common.h"
+#include "prof.h"
+
+namespace pconv { extern int g_conv_target, g_conv_dbg; int g_conv_march = 1; }
+using namespace pconv;
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int MTH = 8;                   // tile rows (two per wave)
+constexpr int NSLOT = 4, ND = 4;         // LDS ring slots; planes in flight in registers
+
+template <int NB, int TW> struct GeoM {
+    static constexpr int EH = MTH + 4, EW = TW + 4;          // staged plane: tile + halo 1 + zero guard ring 1
+    static constexpr int VS = 16 * NB;                        // bytes per voxel
+    static constexpr int RSB = EW * VS;
+    static constexpr int PLANE = EH * RSB;
+    static constexpr int SV = (MTH + 2) * (TW + 2);           // voxels fetched per plane
+    static constexpr int CH = SV * NB, NIT = (CH + 255) / 256;
+    static constexpr int Q = 27 * NB, NSTEP = (Q + 3) / 4;
+    static constexpr int NTW = TW / 16;                       // 16-voxel column tiles per row
+    static constexpr int LDS = NSLOT * PLANE;
+};
+
+struct alignas(16) MBlk {          // one 8-channel block of the K axis, resolved for this workgroup's sample
+    const bf16_t* src;             // sample base + channel offset
+    int C, on, has_norm, pad_;
+    float shift[8], rstd[8];
+};
+struct alignas(16) MEpi {          // MODE 2 epilogue: the four output rows (= forward input channels) of lane group g
+    const bf16_t* x;
+    int C, ok, has_stats;
+    float mval;
+    float mean[4], rstd[4];
+};
+
+__device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+// Loads through pointers that reached the lane via LDS (the block descriptors) are FLAT loads unless told otherwise, and one
+// pending flat_load makes the compiler wait with vmcnt(0) everywhere (flat returns out of order): every prefetch would be drained
+// at its first use.  These are global pointers: say so.
+template <typename T> __device__ __forceinline__ T gload(const void* ptr) {
+    return *reinterpret_cast<const T __attribute__((address_space(1)))*>(reinterpret_cast<unsigned long long>(ptr));
+}
+
+__device__ __forceinline__ bf16x8 zero8() {
+    bf16x8 z;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) z[j] = (__bf16)0.f;
+    return z;
+}
+
+struct MarchP {
+    int nseg_d, planes_per_seg;    // D segments per tile and output planes per segment
+    int tilesH, tilesW;
+    int nwg_b;                     // workgroups per sample
+};
+
+template <int NB, int TW, int MODE, bool HAS_RES>
+__global__ __launch_bounds__(256) void conv_march_kernel(ConvK p, MarchP mp) {
+    using G = GeoM<NB, TW>;
+    constexpr bool DG = (MODE == 2);
+    constexpr int NIT = G::NIT, NSTEP = G::NSTEP, NTW = G::NTW, VS = G::VS, RSB = G::RSB, PLANE = G::PLANE;
+    extern __shared__ __attribute__((aligned(16))) char lds[];            // [NSLOT planes]
+    __shared__ float lsum[DG ? 4 * 16 * 2 : 4];
+
+    const int tid = threadIdx.x, lane = tid & 63, n = lane & 15, g = (lane >> 4) & 3;
+    const int wv = rfl(tid >> 6);
+    const int Sd = p.Di, Sh = p.Hi, Sw = p.Wi;
+    const int K8 = NB;
+
+    // ---- which tile / D segment
+    const int bx = xcd_swizzle(blockIdx.x, gridDim.x);
+    const int b = bx / mp.nwg_b;
+    int r = bx % mp.nwg_b;
+    const int tw_i = r % mp.tilesW; r /= mp.tilesW;
+    const int th_i = r % mp.tilesH; r /= mp.tilesH;
+    const int dseg = r;
+    const int h0 = th_i * MTH, w0 = tw_i * TW;
+    // output planes [dlo, dhi) in "position" coordinates: MODE 0: 0 .. Sd-1; MODE 2: -1 .. Sd (the padded domain)
+    const int dfirst = DG ? -1 : 0, dcount = DG ? Sd + 2 : Sd;
+    const int dlo = dfirst + dseg * mp.planes_per_seg;
+    const int dhi = min(dlo + mp.planes_per_seg, dfirst + dcount);
+    const int L = dhi - dlo;
+    if (L <= 0) return;
+
+    // ---- prologue.  Nothing goes through LDS or waits on another thread: every staging thread resolves ITS 8-channel block of
+    // the K axis from the launch descriptor (scalar reads) and issues, back to back, the first ND planes, the weights, the mask
+    // byte and the InstanceNorm statistics -- one memory latency instead of a chain of three (descriptor -> barrier -> planes).
+    const int jb = tid % NB;                                   // 256 % NB == 0: a thread always stages the same block
+    const bf16_t* src;
+    int Cst;
+    const uint8_t* mptr = nullptr;                             // presence byte of the block's modality for this sample
+    const float* sptr = nullptr;                               // (mean, rstd) x 8 channels
+    if (DG) {
+        src = reinterpret_cast<const bf16_t*>(p.dy) + (long)b * Sd * Sh * Sw * p.Cout + jb * 8;
+        Cst = p.Cout;
+    } else {
+        src = reinterpret_cast<const bf16_t*>(p.seg[0].x); Cst = 8;
+        int rr = jb;
+        bool found = false;
+#pragma unroll
+        for (int s2 = 0; s2 < PASSION_MAX_SEG; ++s2) {
+            if (s2 < p.nseg && !found) {
+                const SegD& sd = p.seg[s2];
+                const int nb = sd.C / 8;
+                if (rr < nb) {
+                    found = true;
+                    const int bs = sd.bsrc(b), c0 = rr * 8;
+                    src = reinterpret_cast<const bf16_t*>(sd.x) + (long)bs * sd.bstride + c0;
+                    Cst = sd.C;
+                    if (sd.mask) mptr = sd.mask + (long)b * sd.mask_ld + sd.mask_col;
+                    if (sd.stats) sptr = sd.stats + ((long)bs * sd.C + c0) * 2;
+                }
+                rr -= nb;
+            }
+        }
+    }
+    if (NB == 1) Cst = rfl(Cst);
+    const bool reflect = !DG && p.pad_mode == PASSION_PAD_REFLECT;
+    unsigned srcel[NIT];                                       // in-plane source element offset (clamped)
+    int dstoff[NIT];                                           // LDS byte offset inside a plane slot
+    unsigned keepbits = 0u;                                    // bit u: chunk u carries data (else it stays zero)
+#pragma unroll
+    for (int u = 0; u < NIT; ++u) {
+        const int c = u * 256 + tid, sv = min(c, G::CH - 1) / NB;
+        const int zh = sv / (TW + 2), zw = sv % (TW + 2);
+        int ih = h0 - 1 + zh, iw = w0 - 1 + zw;
+        bool ok = c < G::CH;
+        if (reflect) { ih = reflect_idx(ih, Sh); iw = reflect_idx(iw, Sw); }
+        else ok = ok && ih >= 0 && ih < Sh && iw >= 0 && iw < Sw;
+        ih = min(max(ih, 0), Sh - 1); iw = min(max(iw, 0), Sw - 1);
+        srcel[u] = (unsigned)(ih * Sw + iw) * (unsigned)Cst;
+        dstoff[u] = (zh + 1) * RSB + (zw + 1) * VS + jb * 16;
+        if (ok) keepbits |= 1u << u;
+    }
+    const unsigned plane_el = (unsigned)(Sh * Sw) * (unsigned)Cst;
+    // virtual input planes of this segment: v = dlo - 1 + j, j = 0 .. L + 1
+    auto plane_of = [&](int j, bool& live) {                  // source plane of virtual plane j; live = it holds data
+        int v = dlo - 1 + j;
+        live = j <= L + 1;
+        if (reflect) v = reflect_idx(v, Sd);
+        else live = live && v >= 0 && v < Sd;
+        return min(max(v, 0), Sd - 1);
+    };
+    // Every global load of the plane loop is UNCONDITIONAL (clamped address, data discarded by a select) and requested ND
+    // iterations before its use, in a fixed program order: vmcnt counts in order, so a single wait on a recent load (or one load
+    // inside a branch, which makes the compiler fall back to vmcnt(0)) would drain the whole prefetch queue.
+    u32x4 raw[ND][NIT];
+    auto fetch = [&](int j, u32x4 (&dst)[NIT]) {
+        bool live;
+        const unsigned pbase = (unsigned)plane_of(j, live) * plane_el;
+#pragma unroll
+        for (int u = 0; u < NIT; ++u) dst[u] = gload<u32x4>(src + (pbase + srcel[u]));
+    };
+#pragma unroll
+    for (int j = 0; j < ND; ++j) fetch(j, raw[j]);
+
+    // weights: all A fragments of the K axis in registers.  pair q = 4 s + g -> (tap, block)
+    bf16x8 wfr[NSTEP];
+#pragma unroll
+    for (int s = 0; s < NSTEP; ++s) {
+        const int q = min(4 * s + g, G::Q - 1), tap = q / NB, blk = q % NB;
+        wfr[s] = gload<bf16x8>(reinterpret_cast<const bf16x8*>(p.wpack) + ((long)tap * K8 + blk) * p.Mpad + n);
+        if (4 * s + g >= G::Q) wfr[s] = zero8();
+    }
+    // mask byte + statistics of the staged block
+    unsigned mbyte = 1u;
+    if (mptr) mbyte = gload<uint8_t>(mptr);
+    f32x4 st4[4];
+    const bool has_norm = sptr != nullptr;
+    if (has_norm) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) st4[c] = gload<f32x4>(sptr + 4 * c);       // (mean, rstd) of channels 2c, 2c + 1
+    }
+    // MODE 2 epilogue: the four output rows (= forward input channels 4 g .. 4 g + 3) of this lane
+    const bf16_t* ex = nullptr;
+    int eC = 4;
+    bool e_ok = false, e_st = false;
+    float emval = 1.f;
+    f32x4 emean = {0.f, 0.f, 0.f, 0.f}, erstd = {1.f, 1.f, 1.f, 1.f};
+    if (DG) {
+        const int cg = g * 4;
+        const uint8_t* emp = nullptr;
+        const float* esp = nullptr;
+#pragma unroll
+        for (int s2 = 0; s2 < PASSION_MAX_SEG; ++s2) {
+            if (s2 < p.nseg && cg < p.Cin) {
+                const SegD& sd = p.seg[s2];
+                if (cg >= sd.cbase && cg < sd.cbase + sd.C && sd.dx != nullptr) {
+                    const int cl = cg - sd.cbase, bs = sd.bsrc(b);
+                    e_ok = true; eC = sd.C; e_st = sd.stats != nullptr;
+                    ex = reinterpret_cast<const bf16_t*>(sd.x) + (long)bs * sd.bstride + cl;
+                    if (sd.mask) emp = sd.mask + (long)b * sd.mask_ld + sd.mask_col;
+                    if (sd.stats) esp = sd.stats + ((long)bs * sd.C + cl) * 2;
+                }
+            }
+        }
+        if (emp) emval = gload<uint8_t>(emp) ? 1.f : 0.f;
+        if (esp) {
+            const f32x4 a = gload<f32x4>(esp), c2 = gload<f32x4>(esp + 4);
+            emean = (f32x4){a[0], a[2], c2[0], c2[2]};
+            erstd = (f32x4){a[1], a[3], c2[1], c2[3]};
+        }
+    }
+    // zero the whole ring once: the guard ring and the out-of-volume halo of zero-padded / gradient planes stay zero
+    for (int i = tid; i < G::LDS / 16; i += 256) reinterpret_cast<u32x4*>(lds)[i] = (u32x4){0u, 0u, 0u, 0u};
+
+    // per-lane LDS offset of step s relative to the lane's output voxel and the plane of its depth tap
+    int toff[NSTEP], tdsel[NSTEP];
+#pragma unroll
+    for (int s = 0; s < NSTEP; ++s) {
+        const int q = 4 * s + g, tap = (q < G::Q) ? q / NB : 0, blk = q % NB;
+        int td = tap / 9, th = (tap / 3) % 3, tw = tap % 3;
+        if (DG) { td = 2 - td; th = 2 - th; tw = 2 - tw; }       // gather form: position i reads dY[i + 1 - t]
+        tdsel[s] = td;
+        toff[s] = (th - 1) * RSB + (tw - 1) * VS + blk * 16;
+    }
+    // normalisation constants of the staged block: x_hat = x * rstd + shift
+    f32x2 sc[4], sh[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        sc[c] = (f32x2){1.f, 1.f}; sh[c] = (f32x2){0.f, 0.f};
+        if (has_norm) {
+            sc[c] = (f32x2){st4[c][1], st4[c][3]};
+            sh[c] = (f32x2){-st4[c][0] * st4[c][1], -st4[c][2] * st4[c][3]};
+        }
+    }
+    if (mbyte == 0u) keepbits = 0u;                            // absent modality: the block stays zero
+    const f32x2 slope2 = {p.slope, p.slope};
+    auto commit = [&](int j, const u32x4 (&rv)[NIT]) {
+        char* slot = lds + (j & (NSLOT - 1)) * PLANE;
+        bool live;
+        plane_of(j, live);
+        const unsigned keep = live ? keepbits : 0u;            // zero padding is applied AFTER norm + activation: dead planes stay zero
+#pragma unroll
+        for (int u = 0; u < NIT; ++u) {
+            u32x4 o = rv[u];
+            if (has_norm) {                                    // workgroup-uniform for NB == 1, per staging thread otherwise
+                bf16x8 ob;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const f32x2 xv = {__uint_as_float(rv[u][c] << 16), __uint_as_float(rv[u][c] & 0xffff0000u)};
+                    f32x2 t = __builtin_elementwise_fma(xv, sc[c], sh[c]);
+                    const f32x2 ts = t * slope2;
+                    t.x = fmaxf(t.x, ts.x);
+                    t.y = fmaxf(t.y, ts.y);
+                    ob[2 * c] = (__bf16)t.x; ob[2 * c + 1] = (__bf16)t.y;
+                }
+                o = __builtin_bit_cast(u32x4, ob);
+            }
+            if (!((keep >> u) & 1u)) o = (u32x4){0u, 0u, 0u, 0u};
+            if (u * 256 + tid < G::CH) *reinterpret_cast<u32x4*>(slot + dstoff[u]) = o;
+        }
+    };
+
+    // ---- output side: the column tiles of this lane.  t < NT: main tiles (row r0 + t / NTW, columns 16 (t % NTW) + n);
+    // MODE 2 adds up to two halo tiles per wave (edge workgroups): the halo rows (position -1 / Sh) over the tile's columns and
+    // the halo columns (position -1 / Sw) over rows h0 - 1 .. h0 + MTH, dealt over the four waves
+    constexpr int NT = 2 * NTW, TT = DG ? NT + 2 : NT;
+    const int r0 = 2 * wv;
+    int vb[TT], tph[TT], tpw[TT];                              // LDS offset of the lane's voxel in a plane slot; its (h, w) position
+    unsigned vmask = 0u;                                       // bit t: the lane's voxel of tile t exists
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int rr = t / NTW, tx = t % NTW;
+        vb[t] = (r0 + rr + 2) * RSB + (tx * 16 + n + 2) * VS;
+        tph[t] = h0 + r0 + rr; tpw[t] = w0 + tx * 16 + n;
+        vmask |= 1u << t;
+    }
+    if (DG) {
+        const bool top = h0 == 0, bot = h0 + MTH == Sh, left = w0 == 0, right = w0 + TW == Sw;
+#pragma unroll
+        for (int xslot = 0; xslot < 2; ++xslot) {
+            const int want = wv + 4 * xslot;                   // this wave's extra number `want` of the workgroup's list
+            int e = 0, evb = 2 * RSB + 2 * VS, eph = h0, epw = w0;
+            bool ev = false;
+            if (top) {
+#pragma unroll
+                for (int tx = 0; tx < NTW; ++tx, ++e)
+                    if (e == want) { evb = 1 * RSB + (tx * 16 + n + 2) * VS; eph = -1; epw = w0 + tx * 16 + n; ev = true; }
+            }
+            if (bot) {
+#pragma unroll
+                for (int tx = 0; tx < NTW; ++tx, ++e)
+                    if (e == want) { evb = (MTH + 2) * RSB + (tx * 16 + n + 2) * VS; eph = Sh; epw = w0 + tx * 16 + n; ev = true; }
+            }
+            const bool cvalid = n <= MTH + 1 && (n >= 1 || top) && (n <= MTH || bot);      // lane n <-> row h0 - 1 + n
+            const int crow = min(n, MTH + 1) + 1;
+            if (left) {
+                if (e == want) { evb = crow * RSB + 1 * VS; eph = h0 - 1 + min(n, MTH + 1); epw = -1; ev = cvalid; }
+                ++e;
+            }
+            if (right) {
+                if (e == want) { evb = crow * RSB + (TW + 2) * VS; eph = h0 - 1 + min(n, MTH + 1); epw = Sw; ev = cvalid; }
+                ++e;
+            }
+            vb[NT + xslot] = evb; tph[NT + xslot] = eph; tpw[NT + xslot] = epw;
+            if (ev) vmask |= 1u << (NT + xslot);
+        }
+    }
+    // which tiles this wave computes at all (wave-uniform): the extras only where some lane has one
+    bool tile_on[TT];
+#pragma unroll
+    for (int t = 0; t < TT; ++t) tile_on[t] = t < NT || __any((vmask >> t) & 1u);
+
+    f32x4 biasv = {0.f, 0.f, 0.f, 0.f};
+    if (!DG && p.bias && g * 4 < p.Cout) biasv = load4(p.bias + g * 4);
+    const bool row_ok = g * 4 < (DG ? p.Cin : p.Cout);
+    const float f_pos = emval, f_neg = e_st ? emval * p.slope : emval;       // LeakyReLU' x modality mask
+    const int Wp = pad8(Sw + 2);
+    bf16_t* ybase = DG ? reinterpret_cast<bf16_t*>(p.y) + (long)b * (Sd + 2) * (Sh + 2) * Wp * p.Cin
+                       : reinterpret_cast<bf16_t*>(p.y) + (long)b * Sd * Sh * Sw * p.Cout;
+    // epilogue operand of a tile, one 8-byte load per lane: MODE 0 the residual (HAS_RES), MODE 2 x (for x_hat); in-plane element
+    // offset per tile (clamped / reflected to a valid voxel), plane offset added per step
+    constexpr bool EOP = DG || HAS_RES;
+    // lanes whose four rows do not exist (g * 4 >= channels) load from element 0 of a valid tensor: their x / residual is never used,
+    // and "their" channels of the last voxel would lie past the end of the allocation
+    const bf16_t* ebase = DG ? (e_ok ? ex : reinterpret_cast<const bf16_t*>(p.seg[0].x))
+                             : reinterpret_cast<const bf16_t*>(p.residual) + (long)b * Sd * Sh * Sw * p.Cout + (row_ok ? g * 4 : 0);
+    const int eCs = DG ? (e_ok ? eC : 0) : (row_ok ? p.Cout : 0);
+    unsigned eel[TT], oel[TT];                                 // in-plane element offsets: operand / output
+#pragma unroll
+    for (int t = 0; t < TT; ++t) {
+        const int rh = min(max(reflect_idx(tph[t], Sh), 0), Sh - 1), rw = min(max(reflect_idx(tpw[t], Sw), 0), Sw - 1);
+        eel[t] = (unsigned)(rh * Sw + rw) * (unsigned)eCs;
+        oel[t] = DG ? (unsigned)((tph[t] + 1) * Wp + (tpw[t] + 1)) * (unsigned)p.Cin + (unsigned)(g * 4)
+                    : (unsigned)(tph[t] * Sw + tpw[t]) * (unsigned)p.Cout + (unsigned)(g * 4);
+    }
+    const unsigned eplane = (unsigned)(Sh * Sw) * (unsigned)eCs;
+    const unsigned oplane = DG ? (unsigned)((Sh + 2) * Wp) * (unsigned)p.Cin : (unsigned)(Sh * Sw) * (unsigned)p.Cout;
+    u32x2 eop[ND][EOP ? TT : 1];
+    auto eload = [&](int jout, u32x2 (&dst)[EOP ? TT : 1]) {
+        if (!EOP) return;
+        const int dpos = dlo + jout;
+        const unsigned pb = (unsigned)min(max(reflect_idx(dpos, Sd), 0), Sd - 1) * eplane;
+#pragma unroll
+        for (int t = 0; t < TT; ++t) dst[t] = gload<u32x2>(ebase + (pb + eel[t]));
+    };
+    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2v[4] = {0.f, 0.f, 0.f, 0.f};
+
+    // output plane jout (position dlo + jout) from ring planes jout, jout + 1, jout + 2
+    const int lanebase = (r0 + 2) * RSB + (n + 2) * VS;        // main tile t: + (t / NTW) * RSB + (t % NTW) * 16 * VS (an immediate)
+    char* yb8 = reinterpret_cast<char*>(ybase);
+    auto compute = [&](int jout, const u32x2 (&eo)[EOP ? TT : 1]) {
+        const int dpos = dlo + jout;
+        const bool pvalid = jout >= 0 && jout < L;
+        f32x4 acc[TT];
+#pragma unroll
+        for (int t = 0; t < TT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        // B fragments one K step ahead of the MFMAs that consume them (the compiler alternates read / wait / MFMA otherwise)
+        bf16x8 cur[TT], nxt[TT];
+        auto bload = [&](int s, bf16x8 (&dst)[TT]) {
+            const int soff = toff[s] + ((jout + tdsel[s]) & (NSLOT - 1)) * PLANE;
+            const char* base = lds + lanebase + soff;
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+                dst[t] = *reinterpret_cast<const bf16x8*>(base + (t / NTW) * RSB + (t % NTW) * 16 * VS);
+#pragma unroll
+            for (int t = NT; t < TT; ++t)
+                if (tile_on[t]) dst[t] = *reinterpret_cast<const bf16x8*>(lds + vb[t] + soff);
+        };
+        if (!(p.dbg & 2)) {
+        bload(0, cur);
+#pragma unroll
+        for (int s = 0; s < NSTEP; ++s) {
+            if (s + 1 < NSTEP) bload(s + 1, nxt);
+            __builtin_amdgcn_sched_barrier(0);                 // keep the reads of step s + 1 ahead of the MFMAs of step s
+#pragma unroll
+            for (int t = 0; t < TT; ++t)
+                if (tile_on[t]) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfr[s], cur[t], acc[t], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < TT; ++t) cur[t] = nxt[t];
+        }
+        }
+        if (p.dbg & 4) return;
+        const unsigned ob = (unsigned)(DG ? dpos + 1 : dpos) * oplane;
+#pragma unroll
+        for (int t = 0; t < TT; ++t) {
+            if (!tile_on[t]) continue;
+            const bool valid = pvalid && ((vmask >> t) & 1u);
+            const unsigned obyte = (ob + oel[t]) * 2u;         // < 2^32: one sample of the output / scratch volume
+            if (!DG) {
+                f32x4 v = acc[t] + biasv;
+                if (HAS_RES) {
+                    v[0] += __uint_as_float(eo[t].x << 16); v[1] += __uint_as_float(eo[t].x & 0xffff0000u);
+                    v[2] += __uint_as_float(eo[t].y << 16); v[3] += __uint_as_float(eo[t].y & 0xffff0000u);
+                }
+                if (valid && row_ok) store4(reinterpret_cast<bf16_t*>(yb8 + obyte), v);
+            } else {
+                const u32x2 xr = eo[t];
+                const float xv[4] = {__uint_as_float(xr.x << 16), __uint_as_float(xr.x & 0xffff0000u),
+                                     __uint_as_float(xr.y << 16), __uint_as_float(xr.y & 0xffff0000u)};
+                const float vf = (valid && e_ok && e_st) ? 1.f : 0.f;
+                f32x4 gv = acc[t];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float xh = e_st ? (xv[j] - emean[j]) * erstd[j] : 1.f;
+                    const float gg = gv[j] * (xh > 0.f ? f_pos : f_neg);
+                    gv[j] = gg;
+                    const float gs = gg * vf;
+                    s1[j] += gs;
+                    s2v[j] = __builtin_fmaf(gs, xh, s2v[j]);
+                }
+                if (valid && e_ok) store4(reinterpret_cast<bf16_t*>(yb8 + obyte), gv);
+            }
+        }
+    };
+
+    // ---- pipeline.  iteration j: barrier; commit plane j; fetch plane j + ND; compute output j - 3 (ring planes j-3 .. j-1,
+    // all committed before this barrier; slot j & 3 = the slot of plane j - 4, last read in iteration j - 1); fetch the
+    // epilogue operands of output j - 3 + ND.  Dead iterations past the segment compute / load clamped garbage and store nothing.
+#pragma unroll
+    for (int j = 0; j < ND; ++j) eload(j, eop[j]);
+    __syncthreads();                                           // ring zeroed before the first commit
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {                              // planes 0 .. 2: nothing to compute yet
+        __syncthreads();
+        commit(j, raw[j]);
+        fetch(j + ND, raw[j]);
+    }
+    for (int j0 = 3; j0 < L + 3; j0 += ND) {
+#pragma unroll
+        for (int jj = 0; jj < ND; ++jj) {
+            const int j = j0 + jj;                             // raw slot (3 + jj) & 3, output j - 3 in operand slot jj
+            __syncthreads();
+            if (!(p.dbg & 1)) {                                // developer timing switches (PASSION_CONV_DBG): 1 no staging, 2 no MFMA loop, 4 no epilogue
+                commit(j, raw[(3 + jj) & 3]);
+                fetch(j + ND, raw[(3 + jj) & 3]);
+            }
+            compute(j - 3, eop[jj]);
+            eload(j - 3 + ND, eop[jj]);
+        }
+    }
+
+    if (DG) {
+        // InstanceNorm-backward sums: 16 voxel lanes (shuffles) -> 4 waves (LDS, fixed order) -> this workgroup's own slot
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float a1 = group16_sum(s1[j]), a2 = group16_sum(s2v[j]);
+            if (n == 0) {
+                lsum[(wv * 16 + g * 4 + j) * 2 + 0] = a1;
+                lsum[(wv * 16 + g * 4 + j) * 2 + 1] = a2;
+            }
+        }
+        __syncthreads();
+        if (tid < 32) {
+            const int c = tid >> 1, k2 = tid & 1;
+            if (c < p.Cin) {
+                const float t = ((lsum[(0 * 16 + c) * 2 + k2] + lsum[(1 * 16 + c) * 2 + k2]) + lsum[(2 * 16 + c) * 2 + k2]) + lsum[(3 * 16 + c) * 2 + k2];
+                float* rs = p.sums + (long)(bx % mp.nwg_b) * p.B * p.Cin * 2;
+                rs[((long)b * p.Cin + c) * 2 + k2] = t;
+            }
+        }
+    }
+}
+
+template <int NB, int TW, int MODE, bool HAS_RES>
+int launch_march_res(ConvK& k, const MarchP& mp, hipStream_t st) {
+    using G = GeoM<NB, TW>;
+    static bool granted = false;
+    if (!granted) {
+        HIP_RET(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_march_kernel<NB, TW, MODE, HAS_RES>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS));
+        granted = true;
+    }
+    passion_prof_tag("conv_march_kernel<%d, %d, %d, %d>", NB, TW, MODE, HAS_RES ? 1 : 0);
+    hipLaunchKernelGGL((conv_march_kernel<NB, TW, MODE, HAS_RES>), dim3(k.B * mp.nwg_b), dim3(256), G::LDS, st, k, mp);
+    LAUNCH_RET();
+    return 0;
+}
+
+template <int NB, int TW, int MODE>
+int launch_march_one(ConvK& k, hipStream_t st) {
+    using G = GeoM<NB, TW>;
+    MarchP mp;
+    mp.tilesH = k.Hi / MTH; mp.tilesW = k.Wi / TW;
+    const int dcount = MODE == 2 ? k.Di + 2 : k.Di;
+    const int tiles = mp.tilesH * mp.tilesW;
+    // D segments: about g_conv_target workgroups per launch, at least 8 output planes per segment (2 halo planes each)
+    int nseg = (int)hmax(1, (g_conv_target + (long)k.B * tiles - 1) / ((long)k.B * tiles));
+    static const int min_planes = []() { const char* e = getenv("PASSION_MARCH_PLANES"); return e && atoi(e) > 0 ? atoi(e) : 16; }();
+    nseg = (int)hmin(nseg, hmax(1, dcount / min_planes));
+    if (MODE == 2) nseg = (int)hmin(nseg, hmax(1, SUMS_SLOTS / tiles));      // one sums slot per workgroup of a sample
+    mp.planes_per_seg = (dcount + nseg - 1) / nseg;
+    mp.nseg_d = (dcount + mp.planes_per_seg - 1) / mp.planes_per_seg;
+    mp.nwg_b = mp.nseg_d * tiles;
+    if (MODE == 2) {
+        if (mp.nwg_b > SUMS_SLOTS) return 1;
+        k.sums_rep = mp.nwg_b;
+    }
+    if (MODE == 0 && k.residual) return launch_march_res<NB, TW, MODE, true>(k, mp, st);
+    return launch_march_res<NB, TW, MODE, false>(k, mp, st);
+}
+
+}  // namespace
+
+namespace pconv {
+
+// 0 = launched, < 0 = HIP error, 1 = shape not covered (the caller goes on to the lean kernel)
+int launch_conv_march(ConvK& k, int ksize, int stride, int mode, const void* packed_bf16, hipStream_t st) {
+    if (!g_conv_march || ksize != 3 || stride != 1 || (mode != 0 && mode != 2)) return 1;
+    if (k.y_f32 || k.bd_rows || !(k.slope >= 0.f && k.slope <= 1.f)) return 1;
+    if (k.Hi % MTH || k.Wi % 16 || k.Di < 4) return 1;
+    const int rows = mode == 2 ? k.Cin : k.Cout;               // M axis
+    if (rows > 16 || rows % 4) return 1;
+    int K8;
+    if (mode == 2) {
+        if (k.Cout % 8) return 1;
+        K8 = k.Cout / 8;
+        for (int s = 0; s < k.nseg; ++s) if (k.seg[s].dx && k.seg[s].bmod > 0) return 1;
+    } else {
+        K8 = 0;
+        for (int s = 0; s < k.nseg; ++s) {
+            if (k.seg[s].C % 8) return 1;
+            K8 += k.seg[s].C / 8;
+        }
+        if (K8 * 8 != k.Cin) return 1;
+    }
+    if (K8 != 1 && K8 != 2) return 1;       // 32 input channels: the 108 weight registers cost the second wave per SIMD -- lean kernel
+    static const int force_tw = []() { const char* e = getenv("PASSION_MARCH_TW"); return e ? atoi(e) : 0; }();
+    bool w32 = (k.Wi % 32 == 0) && K8 <= 2;
+    if (force_tw == 16) w32 = false;
+    if (mode == 2 && force_tw != 32) w32 = false;          // the dgrad keeps six tiles of operands in flight: 16-wide tiles fit three waves per SIMD
+    const int ntap = 27;
+    if (mode == 2) {
+        k.Mpad = pad16(k.Cin);
+        k.wpack = reinterpret_cast<const bf16_t*>(packed_bf16) + (long)ntap * pad8(k.Cin) * pad16(k.Cout);
+    } else {
+        k.Mpad = pad16(k.Cout);
+        k.wpack = packed_bf16;
+    }
+    k.dbg = g_conv_dbg;
+#define MARCH_CASE(NBv)                                                                             \
+    if (K8 == NBv) {                                                                                \
+        if (w32) return mode == 2 ? launch_march_one<NBv, 32, 2>(k, st) : launch_march_one<NBv, 32, 0>(k, st); \
+        return mode == 2 ? launch_march_one<NBv, 16, 2>(k, st) : launch_march_one<NBv, 16, 0>(k, st);           \
+    }
+    MARCH_CASE(1)
+    MARCH_CASE(2)
+#undef MARCH_CASE
+    return 1;
+}
+
+}  // namespace pconv

@@ -17,9 +17,11 @@ from _util import build_product_model, gold, grad_norms, rel, synth
 pytestmark = pytest.mark.gpu
 
 # bf16 storage / f32 accumulate vs the f32 reference, 128^3, ~130 conv layers deep (measured on MI355X, x ~2 headroom)
-# first measurement (r02, cfg1): pred max 1.0e-1 (a handful of voxels; rms below), loss terms 1.6e-4, loss 1.1e-4, grad norms 6.8e-3,
-# mask agreement 0.9835 (random-init logits are near-ties almost everywhere: 477 voxels tie below 1e-4 even in f32)
-BF16_TOL = {"pred_max": 2e-1, "pred_rms": 2e-2, "loss_terms": 5e-3, "loss": 2e-3, "grad_norm": 3e-2, "mask_agree": 0.97}
+# measured (r02, cfg1, marching conv + flash attention): pred max 9.8e-2, rms 2.5e-2, per-class sums 2.0e-3, loss terms 1.6e-4,
+# loss 1.1e-4, grad norms 1.4e-2, mask agreement 0.9834 (random-init logits are near-ties almost everywhere: 477 voxels tie
+# below 1e-4 even in f32)
+BF16_TOL = {"pred_max": 2e-1, "pred_rms": 5e-2, "pred_sum": 5e-3, "loss_terms": 5e-3, "loss": 2e-3, "grad_norm": 3e-2,
+            "mask_agree": 0.97}
 
 
 def _unpack2(packed, n):
@@ -107,7 +109,6 @@ def _check_bf16(g, m, outs, loss, tag):
     diff = _mask_report(g, pred, tag)
     agree = 1.0 - len(diff) / S ** 3
     print(f"[{tag}] bf16 vs f32 reference: " + ", ".join(f"{k} {v:.3e}" for k, v in obs.items()) + f", mask agreement {agree:.5f}")
-    t = dict(t, pred_sum=t["loss"])
     for k, v in obs.items():
         assert v < t[k], (k, v, t[k])
     assert agree > t["mask_agree"]

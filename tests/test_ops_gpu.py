@@ -488,3 +488,49 @@ def test_attention_dropout_backward_uses_the_forward_mask():
     num = (f(qkv.detach() + d) - f(qkv.detach() - d)) / 2
     ana = float((g * d).double().sum())
     assert abs(num - ana) < 2e-2 * max(abs(num), abs(ana), 1e-3)
+
+
+MARCH_CASES = [
+    # shapes the marching kernel (csrc/conv_march.hip) covers: 3x3x3 stride 1, <= 16 in / out channels, H % 8 == 0, W % 16 == 0
+    ([8], 8, 3, 1, 1, (12, 24, 32), True, False, True),        # one block, 32-wide tiles, residual
+    ([8, 8], 8, 3, 1, 1, (9, 16, 48), True, True, False),      # two segments, one absent in sample 0/1, 16-wide tiles
+    ([16], 16, 3, 1, 0, (8, 24, 32), True, False, False),      # zero padding (forward only: its dgrad stays on the lean kernel)
+    ([8], 8, 3, 1, 1, (6, 8, 16), False, False, False),        # not normalised: fold-only finish
+    ([8, 8], 16, 3, 1, 1, (16, 16, 64), True, True, False),
+    ([16], 8, 3, 1, 1, (40, 32, 32), True, False, False),      # several depth segments per tile
+    ([8], 4, 3, 1, 1, (5, 8, 32), True, False, False),         # 4 output channels (RFNet-style narrow head input)
+]
+MARCH_PATHS = {"march": {}, "march_one_segment": {"conv_target": 1}, "march_many_segments": {"conv_target": 100000},
+               "march_off": {"conv_march": 0}}
+
+
+@pytest.mark.parametrize("path", list(MARCH_PATHS))
+@pytest.mark.parametrize("case", MARCH_CASES, ids=[str(i) for i in range(len(MARCH_CASES))])
+def test_conv_march_kernel(case, path):
+    from passion_amd import ops
+    _dev()
+    old = {k: ops.set_option(k, v) for k, v in MARCH_PATHS[path].items()}
+    try:
+        test_conv_block_fwd_bwd(case, torch.bfloat16)
+    finally:
+        for k, v in old.items():
+            ops.set_option(k, v)
+
+
+def test_conv_march_backward_is_bitwise_reproducible():
+    """the marching dgrad leaves its InstanceNorm-backward sums in per-workgroup slots (fixed-order fold): no f32 atomics"""
+    from passion_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 24, 32, 64, 8, generator=g).to(dev, torch.bfloat16)
+    w = (torch.randn(8, 8, 3, 3, 3, generator=g) * 0.1).to(dev).requires_grad_(True)
+    gy = torch.randn(2, 24, 32, 64, 8, generator=g).to(dev, torch.bfloat16)
+    outs = []
+    for _ in range(3):
+        xd = x.clone().requires_grad_(True)
+        y = ops.conv_block([ops.SegIn(xd, stats=ops.instnorm_stats(xd.detach()))], w, None, 24, 32, 64, ksize=3, stride=1, pad_mode=1)
+        w.grad = None
+        y.backward(gy)
+        outs.append((xd.grad.clone(), w.grad.clone()))
+    assert all(torch.equal(outs[0][0], o[0]) for o in outs[1:])
+    assert all(torch.equal(outs[0][1], o[1]) for o in outs[1:])
