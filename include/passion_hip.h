@@ -99,6 +99,14 @@ int passion_conv3d_fwd(const passion_conv_desc_t* d, const float* packed, const 
 int64_t passion_conv_bwd_scratch_floats(const passion_conv_desc_t* d);
 int passion_conv3d_bwd(const passion_conv_desc_t* d, const float* packed, const void* dy,
                        float* dweight, float* dbias, float* scratch, void* stream);
+/* The same backward in two phases, for a volume that is split along D over the ranks (BASELINE.json configs[4]): InstanceNorm
+ * backward needs sum(g) and sum(g * x_hat) over the WHOLE volume.  phase 1: weight / bias gradient and the dgrad; on return
+ * scratch[0 .. 2 * B * Cin) holds this rank's sums (b-major, (sum g, sum g x_hat) per input channel) -- the caller all-reduces
+ * them in place.  phase 2: the finish with 1 / V multiplied by vscale (= V_local / V_global) and the mean-subtraction terms
+ * applied to the depth planes [dwin_lo, dwin_hi) only (the halo planes of an extended slab belong to the neighbours).
+ * Same arguments and scratch in both calls.  Batched-pass segments (bmod) are not supported here (-1019). */
+int passion_conv3d_bwd_phase(const passion_conv_desc_t* d, const float* packed, const void* dy, float* dweight, float* dbias,
+                             float* scratch, int phase, float vscale, int dwin_lo, int dwin_hi, void* stream);
 
 /* ---- trilinear resampling, align_corners=True ---------------------------------------------
  * Replaces nn.Upsample(scale_factor=k, mode='trilinear', align_corners=True)
@@ -110,6 +118,20 @@ int passion_upsample_fwd(const void* x, void* y, int dtype, int B, int D, int H,
 int64_t passion_upsample_bwd_scratch_floats(int B, int D, int H, int W, int C, int k);
 int passion_upsample_bwd(const void* dy, void* dx, int dtype, int B, int D, int H, int W, int C,
                          int k, float* scratch, void* stream);
+
+/* ---- depth sharding (BASELINE.json configs[4]: one volume split along D over the ranks; SURVEY 8b "halo_pack/unpack", 8e row 2).
+ * halo_pack: plane d of every sample of a (B, D, P) tensor -> contiguous (B, P) send buffer (P elements per plane, P*sizeof % 16 == 0);
+ * halo_unpack: a received (B, P) buffer -> plane d of y, overwriting (forward: the halo planes of the extended slab) or
+ * accumulating (backward: the neighbour's gradient of our boundary plane).  The exchange itself is torch.distributed (RCCL). */
+int passion_halo_pack(const void* x, void* buf, int dtype, int B, int D, int64_t P, int d, void* stream);
+int passion_halo_unpack(const void* buf, void* y, int dtype, int B, int D, int64_t P, int d, int accumulate, void* stream);
+/* trilinear x k (align_corners=True) where the D axis is one window of a larger volume: the rank holds input planes
+ * [id0, id0 + Dl_in) of Dg and produces output planes [od0, od0 + Dl_out) of k*Dg with GLOBAL source coordinates;
+ * bwd = the adjoint restricted to those outputs, gradient of every local input plane (halo planes included). */
+int passion_upsample_window_fwd(const void* x, void* y, int dtype, int B, int Dl_in, int id0, int Dg, int Dl_out, int od0,
+                                int H, int W, int C, int k, void* stream);
+int passion_upsample_window_bwd(const void* dy, void* dx, int dtype, int B, int Dl_in, int id0, int Dg, int Dl_out, int od0,
+                                int H, int W, int C, int k, void* stream);
 
 /* ---- layout / softmax -----------------------------------------------------------------------
  * softmax over the class axis (nn.Softmax(dim=1), mmformer.py:91,543,635; criterions.py:93-94

@@ -48,6 +48,14 @@ SIGNATURES = {
                                    c_void_p]),
     "passion_conv3d_bwd": (c_int, [POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p,
                                    c_void_p, c_void_p]),
+    "passion_conv3d_bwd_phase": (c_int, [POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float,
+                                         c_int, c_int, c_void_p]),
+    "passion_halo_pack": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int64, c_int, c_void_p]),
+    "passion_halo_unpack": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int64, c_int, c_int, c_void_p]),
+    "passion_upsample_window_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                                            c_int, c_void_p]),
+    "passion_upsample_window_bwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                                            c_int, c_void_p]),
     "passion_upsample_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
                                      c_int, c_void_p]),
     "passion_upsample_bwd_scratch_floats": (c_int64, [c_int, c_int, c_int, c_int, c_int, c_int]),

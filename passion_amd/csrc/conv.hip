@@ -258,14 +258,15 @@ template <typename T, int VEC>
 __global__ __launch_bounds__(256) void in_bwd_finish_kernel(const T* __restrict__ g_in, T* __restrict__ dx, const T* __restrict__ x,
                                                             const float* __restrict__ stats, const float* __restrict__ sums,
                                                             const uint8_t* mask, int mask_col, int mask_ld, long V, int C, long bstride,
-                                                            int Cin_tot, int cbase, int bmod, int passes, int rep, long rep_stride) {
+                                                            int Cin_tot, int cbase, int bmod, int passes, int rep, long rep_stride,
+                                                            float vscale, long win_lo, long win_hi) {
     __shared__ float coef[FIN_TAB][3];
     __shared__ int pres[16];
     const int bp = blockIdx.y;                     // physical sample (x, stats, dx when passes > 1) or the plain batch index
     const int bs = (passes == 1 && bmod > 0) ? bp % bmod : bp;
     for (int p = 0; p < passes; ++p) {
         const int b = p * (passes > 1 ? bmod : 0) + bp;        // virtual sample of pass p
-        if (stats) finish_coefs(coef + p * C, stats, sums, b, bs, C, Cin_tot, cbase, rep, rep_stride, 1.0f / (float)V);
+        if (stats) finish_coefs(coef + p * C, stats, sums, b, bs, C, Cin_tot, cbase, rep, rep_stride, vscale / (float)V);
         if (threadIdx.x == 0) pres[p] = mask ? (mask[(long)b * mask_ld + mask_col] != 0) : 1;
     }
     __syncthreads();
@@ -285,9 +286,11 @@ __global__ __launch_bounds__(256) void in_bwd_finish_kernel(const T* __restrict_
             float g[VEC];
             VecIO<T, VEC>::load(g_in + b * bstride + i * VEC, g);
             const float (*cf)[3] = coef + p * C + c;
+            // voxels outside [win_lo, win_hi) are another rank's (depth-sharded halo planes): only the rstd * g term is ours
+            const bool own = (i * VEC) / C >= win_lo && (i * VEC) / C < win_hi;
 #pragma unroll
             for (int j = 0; j < VEC; ++j)
-                acc[j] += stats ? __builtin_fmaf(cf[j][0], g[j], __builtin_fmaf(cf[j][1], xv[j], cf[j][2])) : g[j];
+                acc[j] += stats ? (own ? __builtin_fmaf(cf[j][0], g[j], __builtin_fmaf(cf[j][1], xv[j], cf[j][2])) : cf[j][0] * g[j]) : g[j];
         }
         VecIO<T, VEC>::store(dxb + i * VEC, acc);
     }
@@ -302,12 +305,13 @@ template <typename T, int VEC>
 __global__ __launch_bounds__(256) void in_bwd_finish_pad_kernel(T* __restrict__ dx, const T* __restrict__ x, const T* __restrict__ dxp,
                                                                 const float* __restrict__ stats, const float* __restrict__ sums,
                                                                 const uint8_t* mask, int mask_col, int mask_ld, int D, int H, int W, int C,
-                                                                long bstride, int Cin_tot, int cbase, int bmod, int rep, long rep_stride) {
+                                                                long bstride, int Cin_tot, int cbase, int bmod, int rep, long rep_stride,
+                                                                float vscale, int dwin_lo, int dwin_hi) {
     __shared__ float coef[FIN_MAXC][3];
     const int b = blockIdx.y;
     const int bs = bmod > 0 ? b % bmod : b;
     const long V = (long)D * H * W;
-    if (stats) finish_coefs(coef, stats, sums, b, bs, C, Cin_tot, cbase, rep, rep_stride, 1.0f / (float)V);
+    if (stats) finish_coefs(coef, stats, sums, b, bs, C, Cin_tot, cbase, rep, rep_stride, vscale / (float)V);
     __syncthreads();
     const int cvn = C / VEC, rowv = W * cvn;
     const bool present = mask ? (mask[(long)b * mask_ld + mask_col] != 0) : true;
@@ -358,9 +362,10 @@ __global__ __launch_bounds__(256) void in_bwd_finish_pad_kernel(T* __restrict__ 
                     }
                 }
                 if (stats) {                               // else: input was not normalised in the loader, fold only
+                    const bool own = d >= dwin_lo && d < dwin_hi;      // depth-sharded halo planes: only the rstd * g term is ours
 #pragma unroll
                     for (int j = 0; j < VEC; ++j)
-                        g[j] = __builtin_fmaf(coef[c + j][0], g[j], __builtin_fmaf(coef[c + j][1], xv[j], coef[c + j][2]));
+                        g[j] = own ? __builtin_fmaf(coef[c + j][0], g[j], __builtin_fmaf(coef[c + j][1], xv[j], coef[c + j][2])) : coef[c + j][0] * g[j];
                 }
             }
             VecIO<T, VEC>::store(dxb + e, g);
@@ -911,11 +916,18 @@ Companion* companion(hipStream_t caller) {
 }
 }  // namespace
 
-extern "C" int passion_conv3d_bwd(const passion_conv_desc_t* d, const float* packed, const void* dy, float* dweight,
-                                  float* dbias, float* sums, void* stream) {
+// phase 0: the whole backward.  Depth-sharded volumes (one volume split along D over the ranks) need the InstanceNorm-backward
+// sums of ALL ranks before the gradient can be finished: phase 1 stops after the dgrad with the sums folded into
+// sums[0 .. 2 B Cin) (the caller all-reduces them), phase 2 runs only the finish with 1 / V scaled by vscale = V_local / V_global
+// and the mean-subtraction terms restricted to the depth planes [dwin_lo, dwin_hi) the rank owns.
+static int conv3d_bwd_impl(const passion_conv_desc_t* d, const float* packed, const void* dy, float* dweight,
+                           float* dbias, float* sums, void* stream, int phase, float vscale, int dwin_lo, int dwin_hi) {
     ConvK k;
     int rc = fill_params(d, k);
     if (rc) return rc;
+    if (phase != 0) {
+        for (int s = 0; s < k.nseg; ++s) if (k.seg[s].bmod > 0) return -1019;       // batched passes are not sharded
+    }
     hipStream_t st = (hipStream_t)stream;
     const int nt = d->ksize * d->ksize * d->ksize;
     const int xs = d->x_dtype == PASSION_BF16 ? 2 : 4, ys = d->y_dtype == PASSION_BF16 ? 2 : 4;
@@ -925,7 +937,7 @@ extern "C" int passion_conv3d_bwd(const passion_conv_desc_t* d, const float* pac
     for (int s = 0; s < k.nseg; ++s) {
         if (k.seg[s].dx) { need_dx = true; if (k.seg[s].stats) need_norm = true; }
     }
-    Companion* comp = (pconv::g_wgrad_fork && need_dx && (dweight || dbias)) ? companion(st) : nullptr;
+    Companion* comp = (phase == 0 && pconv::g_wgrad_fork && need_dx && (dweight || dbias)) ? companion(st) : nullptr;
     hipStream_t caller_st = st;
     if (comp) {                                      // fork: the weight-gradient work below goes to the companion stream
         HIP_RET(hipEventRecord(comp->fork, caller_st));
@@ -936,7 +948,7 @@ extern "C" int passion_conv3d_bwd(const passion_conv_desc_t* d, const float* pac
     float* zsums = (need_norm && sums && !comp) ? sums : nullptr;
     const long zn = zsums ? (long)2 * k.B * k.Cin * SUMS_REP : 0;
     // ---- wgrad (+ bias grad): per-workgroup partial slabs, then a fixed-order fold (no atomics, deterministic) ----
-    if (dweight || dbias) {
+    if (phase != 2 && (dweight || dbias)) {
         k.Mpad = pad16(k.Cout);
         const WgPlan w = plan_wgrad(k, d);
         const long nW = (long)k.Cout * k.Cin * nt;
@@ -996,7 +1008,7 @@ extern "C" int passion_conv3d_bwd(const passion_conv_desc_t* d, const float* pac
     for (int s = 0; s < k.nseg; ++s) if (k.seg[s].C % 4) return -1008;
     if (need_norm) {
         if (!sums) return -1009;
-        if (!sums_cleared) HIP_RET(hipMemsetAsync(sums, 0, sizeof(float) * 2 * (size_t)k.B * k.Cin * SUMS_REP, st));
+        if (phase != 2 && !sums_cleared) HIP_RET(hipMemsetAsync(sums, 0, sizeof(float) * 2 * (size_t)k.B * k.Cin * SUMS_REP, st));
     }
     k.sums = sums;
     k.sums_rep = SUMS_REP;                           // the lean launcher lowers it
@@ -1009,6 +1021,9 @@ extern "C" int passion_conv3d_bwd(const passion_conv_desc_t* d, const float* pac
     // batched-pass segments: the dgrad writes the per-pass gradients into scratch, the finish kernel sums them into dx
     void* real_dx[PASSION_MAX_SEG] = {nullptr, nullptr, nullptr, nullptr};
     const bool blockdiag = use_blockdiag(k, d);
+    if (phase == 2) {
+        if (padout) dxp = sums + slab_end_floats(k, plan_wgrad(k, d).gx, nt);
+    } else
     if (blockdiag) {         // passes summed first (per segment, masked), one dgrad over the physical samples
         const WgPlan w0 = plan_wgrad(k, d);
         bf16_t* dycat = reinterpret_cast<bf16_t*>(sums + slab_end_floats(k, w0.gx, nt) + (padout ? padout_floats(k) : 0));
@@ -1044,7 +1059,7 @@ extern "C" int passion_conv3d_bwd(const passion_conv_desc_t* d, const float* pac
             }
         }
     }
-    {
+    if (phase != 2) {
         ProfScope prof(2, conv_bytes(k, xs, ys) + (double)nt * k.Cin * k.Cout * 4,
                        2.0 * k.B * k.Do * k.Ho * k.Wo * (double)k.Cout * k.Cin * nt, st);
         if (padout) {
@@ -1086,13 +1101,16 @@ extern "C" int passion_conv3d_bwd(const passion_conv_desc_t* d, const float* pac
             rc = -1007;
         if (rc) return rc;
     }
-    int rep = k.sums_rep;
-    if (need_norm && rep > SUMS_REP_LEAN) {          // many replicas: fold them first (in place, replica 0)
+    int rep = phase == 2 ? 1 : k.sums_rep;
+    if (phase != 2 && need_norm && (rep > SUMS_REP_LEAN || phase == 1)) {          // many replicas: fold them first (in place, replica 0)
         const int nw = 2 * k.B * k.Cin;
         hipLaunchKernelGGL(reduce_parts_kernel, dim3((nw + 15) / 16), dim3(256), 0, st, sums, k.sums_rep, (long)nw, (long)nw, sums);
         LAUNCH_RET();
         rep = 1;
     }
+    if (phase == 1) return 0;
+    const long hw = (long)k.Hi * k.Wi;
+    const long win_lo = (long)dwin_lo * hw, win_hi = (long)dwin_hi * hw;
     // ---- InstanceNorm backward finish (in place on dx) ----
     const long V = (long)k.Di * k.Hi * k.Wi;
     for (int s = 0; s < k.nseg; ++s) {
@@ -1113,22 +1131,33 @@ extern "C" int passion_conv3d_bwd(const passion_conv_desc_t* d, const float* pac
             if (v8)
                 hipLaunchKernelGGL((in_bwd_finish_pad_kernel<bf16_t, 8>), pg, dim3(256), 0, st, (bf16_t*)sg.dx, (const bf16_t*)sg.x,
                                    (const bf16_t*)dxp, sg.stats, sums, sg.mask, sg.mask_col, sg.mask_ld, k.Di, k.Hi, k.Wi, sg.C,
-                                   sg.bstride, k.Cin, sg.cbase, sg.bmod, rep, rs);
+                                   sg.bstride, k.Cin, sg.cbase, sg.bmod, rep, rs, vscale, dwin_lo, dwin_hi);
             else
                 hipLaunchKernelGGL((in_bwd_finish_pad_kernel<bf16_t, 4>), pg, dim3(256), 0, st, (bf16_t*)sg.dx, (const bf16_t*)sg.x,
                                    (const bf16_t*)dxp, sg.stats, sums, sg.mask, sg.mask_col, sg.mask_ld, k.Di, k.Hi, k.Wi, sg.C,
-                                   sg.bstride, k.Cin, sg.cbase, sg.bmod, rep, rs);
+                                   sg.bstride, k.Cin, sg.cbase, sg.bmod, rep, rs, vscale, dwin_lo, dwin_hi);
         } else if (d->x_dtype == PASSION_F32)
             hipLaunchKernelGGL((in_bwd_finish_kernel<float, 4>), grid, dim3(256), 0, st, (const float*)sg.dx, (float*)out, (const float*)sg.x,
-                               sg.stats, sums, sg.mask, sg.mask_col, sg.mask_ld, V, sg.C, sg.bstride, k.Cin, sg.cbase, sg.bmod, passes, rep, rs);
+                               sg.stats, sums, sg.mask, sg.mask_col, sg.mask_ld, V, sg.C, sg.bstride, k.Cin, sg.cbase, sg.bmod, passes, rep, rs, vscale, win_lo, win_hi);
         else if (v8)
             hipLaunchKernelGGL((in_bwd_finish_kernel<bf16_t, 8>), grid, dim3(256), 0, st, (const bf16_t*)sg.dx, (bf16_t*)out, (const bf16_t*)sg.x,
-                               sg.stats, sums, sg.mask, sg.mask_col, sg.mask_ld, V, sg.C, sg.bstride, k.Cin, sg.cbase, sg.bmod, passes, rep, rs);
+                               sg.stats, sums, sg.mask, sg.mask_col, sg.mask_ld, V, sg.C, sg.bstride, k.Cin, sg.cbase, sg.bmod, passes, rep, rs, vscale, win_lo, win_hi);
         else
             hipLaunchKernelGGL((in_bwd_finish_kernel<bf16_t, 4>), grid, dim3(256), 0, st, (const bf16_t*)sg.dx, (bf16_t*)out, (const bf16_t*)sg.x,
-                               sg.stats, sums, sg.mask, sg.mask_col, sg.mask_ld, V, sg.C, sg.bstride, k.Cin, sg.cbase, sg.bmod, passes, rep, rs);
+                               sg.stats, sums, sg.mask, sg.mask_col, sg.mask_ld, V, sg.C, sg.bstride, k.Cin, sg.cbase, sg.bmod, passes, rep, rs, vscale, win_lo, win_hi);
         LAUNCH_RET();
     }
     if (comp) HIP_RET(hipStreamWaitEvent(caller_st, comp->done, 0));     // join
     return 0;
+}
+
+extern "C" int passion_conv3d_bwd(const passion_conv_desc_t* d, const float* packed, const void* dy, float* dweight,
+                                  float* dbias, float* sums, void* stream) {
+    return conv3d_bwd_impl(d, packed, dy, dweight, dbias, sums, stream, 0, 1.0f, 0, d ? d->D : 0);
+}
+
+extern "C" int passion_conv3d_bwd_phase(const passion_conv_desc_t* d, const float* packed, const void* dy, float* dweight,
+                                        float* dbias, float* sums, int phase, float vscale, int dwin_lo, int dwin_hi, void* stream) {
+    if (phase != 1 && phase != 2) return -1003;
+    return conv3d_bwd_impl(d, packed, dy, dweight, dbias, sums, stream, phase, vscale, dwin_lo, dwin_hi);
 }

@@ -230,6 +230,104 @@ __global__ __launch_bounds__(256) void upsample_bwd_k2_kernel(const T* __restric
     }
 }
 
+
+// ---- depth-sharded variant (BASELINE.json configs[4]: one volume split along D over the ranks).
+// A rank holds input planes [id0, id0 + Dl_in) of a volume of Dg planes (its slab plus one halo plane from each neighbour)
+// and produces output planes [od0, od0 + Dl_out) of the k Dg output planes: the D axis uses GLOBAL align_corners coordinates,
+// H and W are whole.  Backward = exact adjoint restricted to the local outputs, written as a gather over the local inputs
+// (the halo planes' gradients go back to the neighbours).
+template <typename T>
+__global__ __launch_bounds__(256) void upsample_window_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int B, int Dl_in, int id0,
+                                                                  int Dg, int Dl_out, int od0, int H, int W, int C, int k) {
+    const int Ho = H * k, Wo = W * k, cvn = C / 4;
+    const float sd = axis_scale(Dg, Dg * k), sh = axis_scale(H, Ho), sw = axis_scale(W, Wo);
+    const long total = (long)B * Dl_out * Ho * Wo * cvn;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int cv = (int)(i % cvn);
+        long v = i / cvn;
+        const int ow = (int)(v % Wo); v /= Wo;
+        const int oh = (int)(v % Ho); v /= Ho;
+        const int od = (int)(v % Dl_out);
+        const int b = (int)(v / Dl_out);
+        const Src a = src_index(od0 + od, sd, Dg), e = src_index(oh, sh, H), f = src_index(ow, sw, W);
+        const T* xb = x + (long)b * Dl_in * H * W * C + cv * 4;
+        const int di[2] = {min(max(a.i0 - id0, 0), Dl_in - 1), min(max(a.i1 - id0, 0), Dl_in - 1)}, hi[2] = {e.i0, e.i1}, wi[2] = {f.i0, f.i1};
+        const float dl[2] = {a.l0, a.l1}, hl[2] = {e.l0, e.l1}, wl[2] = {f.l0, f.l1};
+        f32x4 r = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            f32x4 rh = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const f32x4 t0 = load4(xb + ((((long)di[p]) * H + hi[q]) * W + wi[0]) * C);
+                const f32x4 t1 = load4(xb + ((((long)di[p]) * H + hi[q]) * W + wi[1]) * C);
+                rh += hl[q] * (wl[0] * t0 + wl[1] * t1);
+            }
+            r += dl[p] * rh;
+        }
+        store4(y + i * 4, r);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void upsample_window_bwd_kernel(const T* __restrict__ dy, T* __restrict__ dx, int B, int Dl_in, int id0,
+                                                                  int Dg, int Dl_out, int od0, int H, int W, int C, int k) {
+    const int Ho = H * k, Wo = W * k, cvn = C / 4;
+    const float sd = axis_scale(Dg, Dg * k), sh = axis_scale(H, Ho), sw = axis_scale(W, Wo);
+    const long items = (long)B * Dl_in * H * W * cvn;
+    for (long it = (long)blockIdx.x * blockDim.x + threadIdx.x; it < items; it += (long)gridDim.x * blockDim.x) {
+        const int cv = (int)(it % cvn);
+        long v = it / cvn;
+        const int iw = (int)(v % W); v /= W;
+        const int ih = (int)(v % H); v /= H;
+        const int idl = (int)(v % Dl_in);
+        const int b = (int)(v / Dl_in);
+        const int gi = id0 + idl;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        if (gi >= 0 && gi < Dg) {
+            int dlo, dhi, hlo, hhi, wlo, whi;
+            axis_range(gi, sd, Dg * k, dlo, dhi);
+            axis_range(ih, sh, Ho, hlo, hhi);
+            axis_range(iw, sw, Wo, wlo, whi);
+            dlo = max(dlo, od0); dhi = min(dhi, od0 + Dl_out - 1);
+            const T* dyb = dy + (long)b * Dl_out * Ho * Wo * C + cv * 4;
+            for (int go = dlo; go <= dhi; ++go) {
+                const float wd = axis_weight(go, gi, sd, Dg);
+                if (wd == 0.f) continue;
+                for (int oh = hlo; oh <= hhi; ++oh) {
+                    const float wh = axis_weight(oh, ih, sh, H);
+                    if (wh == 0.f) continue;
+                    for (int ow = wlo; ow <= whi; ++ow) {
+                        const float ww = axis_weight(ow, iw, sw, W);
+                        if (ww == 0.f) continue;
+                        acc += (wd * wh * ww) * load4(dyb + ((((long)(go - od0)) * Ho + oh) * Wo + ow) * C);
+                    }
+                }
+            }
+        }
+        store4(dx + it * 4, acc);
+    }
+}
+
+// plane d of every sample of a (B, D, P) tensor <-> a contiguous (B, P) buffer: the halo planes a rank sends / receives
+template <typename T>
+__global__ __launch_bounds__(256) void halo_pack_kernel(const T* __restrict__ x, T* __restrict__ buf, int B, int D, long P8, int d) {
+    const long total = (long)B * P8;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long b = i / P8, e = i % P8;
+        reinterpret_cast<uint4*>(buf)[i] = reinterpret_cast<const uint4*>(x)[(b * D + d) * P8 + e];
+    }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void halo_unpack_kernel(const T* __restrict__ buf, T* __restrict__ y, int B, int D, long P, int d, int accumulate) {
+    const long total = (long)B * P;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long b = i / P, e = i % P;
+        const long o = (b * D + d) * P + e;
+        y[o] = accumulate ? from_f32<T>(to_f32(y[o]) + to_f32(buf[i])) : buf[i];
+    }
+}
+
 }  // namespace
 
 // 32-bit index arithmetic unless the tensor (or the grid-stride overshoot) would overflow it
@@ -303,6 +401,65 @@ extern "C" int passion_upsample_bwd(const void* dy, void* dx, int dtype, int B, 
         else
             return -1007;
     }
+    LAUNCH_RET();
+    return 0;
+}
+
+
+extern "C" int passion_upsample_window_fwd(const void* x, void* y, int dtype, int B, int Dl_in, int id0, int Dg, int Dl_out, int od0,
+                                           int H, int W, int C, int k, void* stream) {
+    if (C % 4 || k < 1 || Dl_in < 1 || Dl_out < 1 || Dg < 1) return -1011;
+    const long total = (long)B * Dl_out * H * k * W * k * (C / 4);
+    const int blocks = (int)hmin((total + 255) / 256, 16384);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == PASSION_F32)
+        hipLaunchKernelGGL(upsample_window_fwd_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)x, (float*)y, B, Dl_in, id0, Dg, Dl_out, od0, H, W, C, k);
+    else if (dtype == PASSION_BF16)
+        hipLaunchKernelGGL(upsample_window_fwd_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y, B, Dl_in, id0, Dg, Dl_out, od0, H, W, C, k);
+    else
+        return -1007;
+    LAUNCH_RET();
+    return 0;
+}
+
+extern "C" int passion_upsample_window_bwd(const void* dy, void* dx, int dtype, int B, int Dl_in, int id0, int Dg, int Dl_out, int od0,
+                                           int H, int W, int C, int k, void* stream) {
+    if (C % 4 || k < 1 || Dl_in < 1 || Dl_out < 1 || Dg < 1) return -1011;
+    const long items = (long)B * Dl_in * H * W * (C / 4);
+    const int blocks = (int)hmin((items + 255) / 256, 16384);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == PASSION_F32)
+        hipLaunchKernelGGL(upsample_window_bwd_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)dy, (float*)dx, B, Dl_in, id0, Dg, Dl_out, od0, H, W, C, k);
+    else if (dtype == PASSION_BF16)
+        hipLaunchKernelGGL(upsample_window_bwd_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, (const bf16_t*)dy, (bf16_t*)dx, B, Dl_in, id0, Dg, Dl_out, od0, H, W, C, k);
+    else
+        return -1007;
+    LAUNCH_RET();
+    return 0;
+}
+
+extern "C" int passion_halo_pack(const void* x, void* buf, int dtype, int B, int D, int64_t P, int d, void* stream) {
+    const int es = dtype == PASSION_BF16 ? 2 : 4;
+    if (B < 1 || D < 1 || d < 0 || d >= D || (P * es) % 16) return -1011;
+    if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(buf)) & 15) return -1005;
+    const long P8 = P * es / 16, total = (long)B * P8;
+    const int blocks = (int)hmin((total + 255) / 256, 8192);
+    hipLaunchKernelGGL(halo_pack_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float*)x, (float*)buf, B, D, P8, d);
+    LAUNCH_RET();
+    return 0;
+}
+
+extern "C" int passion_halo_unpack(const void* buf, void* y, int dtype, int B, int D, int64_t P, int d, int accumulate, void* stream) {
+    if (B < 1 || D < 1 || d < 0 || d >= D || P < 1) return -1011;
+    const long total = (long)B * P;
+    const int blocks = (int)hmin((total + 255) / 256, 8192);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == PASSION_F32)
+        hipLaunchKernelGGL(halo_unpack_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)buf, (float*)y, B, D, (long)P, d, accumulate);
+    else if (dtype == PASSION_BF16)
+        hipLaunchKernelGGL(halo_unpack_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, (const bf16_t*)buf, (bf16_t*)y, B, D, (long)P, d, accumulate);
+    else
+        return -1007;
     LAUNCH_RET();
     return 0;
 }

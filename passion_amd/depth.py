@@ -1,0 +1,469 @@
+"""Depth (slab) sharding of ONE volume over the ranks -- BASELINE.json configs[4], SURVEY.md 8(e) row 2.
+
+The reference has no counterpart (a full 240x240x155 forward is not defined by it): this is the multi-GPU mode the
+north_star asks for, held to "sharded == unsharded" on the same volume.  Every rank owns a contiguous slab of D planes of every
+activation (dim 1 of the channels-last tensors) at every level; what couples the slabs:
+
+  3x3x3 conv (stride 1)   one halo plane from each neighbour (HaloExtendFn: passion_halo_pack / unpack + point-to-point over
+                          RCCL), reflect / zero only at the global ends; the conv runs over the extended slab and the two outer
+                          output planes are dropped.  Backward: the halo planes' gradients go back and are added.
+  3x3x3 conv (stride 2)   one plane from the low neighbour only
+  InstanceNorm            statistics: the ranks' (sum x, sum x^2) all-reduced once per tensor (global_stats); backward: the conv
+                          backward stops after its dgrad (passion_conv3d_bwd_phase 1), the (sum g, sum g x_hat) are all-reduced,
+                          the finish runs with 1 / V_global (phase 2); halo planes get only the rstd * g term (their owner adds
+                          the mean-subtraction terms)
+  trilinear x k           global align_corners coordinates along D (passion_upsample_window_fwd / bwd) on the extended slab
+  transformers            level-5 token volumes are all-gathered along D and the token path runs replicated (8 planes at 128^3:
+                          one per GPU); its output is sliced back.  Backward of the gather = all-reduce + slice
+  losses                  per-class partial sums all-reduced before the loss is formed (one (B,16) all-reduce per loss term)
+  weight gradients        every rank's dW covers its slab: summed over the ranks by parallel.GradReducer like data parallel
+
+`sharded_step_loss` is the plain (non-PASSION) mmformer training forward in this mode; tests/test_depth_*.py hold it against the
+unsharded model (world 2, gloo rehearsal transport on one GPU).  Unmeasured on multi-GPU hardware.
+"""
+from ctypes import byref, c_void_p
+
+import torch
+import torch.distributed as dist
+
+from . import _lib as L
+from . import ops
+from .ops import _p
+
+
+class DepthCtx:
+    """rank r of `world` owns planes [r * D / world, (r + 1) * D / world) of every level (D divisible by world at every level it
+    is split; below that the caller gathers)"""
+
+    def __init__(self, rank=None, world=None, group=None):
+        self.group = group
+        self.rank = dist.get_rank(group) if rank is None else rank
+        self.world = dist.get_world_size(group) if world is None else world
+        self.backend = dist.get_backend(group) if dist.is_initialized() else "none"
+
+    @property
+    def lo(self):
+        return self.rank - 1 if self.rank > 0 else None
+
+    @property
+    def hi(self):
+        return self.rank + 1 if self.rank < self.world - 1 else None
+
+    def all_reduce(self, t):
+        if self.world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        return t
+
+    def exchange(self, to_lo, to_hi):
+        """send `to_lo` / `to_hi` to the neighbours, return what they sent (None at the global ends).  Point-to-point; the gloo
+        rehearsal transport cannot move device tensors, so there the planes travel through host memory."""
+        if self.world == 1:
+            return None, None
+        via_host = self.backend == "gloo" and to_lo.is_cuda
+        dev = to_lo.device
+        s_lo, s_hi = (to_lo.cpu(), to_hi.cpu()) if via_host else (to_lo, to_hi)
+        r_lo = torch.empty_like(s_hi) if self.lo is not None else None
+        r_hi = torch.empty_like(s_lo) if self.hi is not None else None
+        reqs = []
+        if self.lo is not None:
+            reqs += [dist.P2POp(dist.isend, s_lo, self.lo, self.group), dist.P2POp(dist.irecv, r_lo, self.lo, self.group)]
+        if self.hi is not None:
+            reqs += [dist.P2POp(dist.isend, s_hi, self.hi, self.group), dist.P2POp(dist.irecv, r_hi, self.hi, self.group)]
+        for w in dist.batch_isend_irecv(reqs):
+            w.wait()
+        if via_host:
+            r_lo = r_lo.to(dev) if r_lo is not None else None
+            r_hi = r_hi.to(dev) if r_hi is not None else None
+        return r_lo, r_hi
+
+
+def _plane(x, d):
+    """plane d of every sample of a (B', D, ...) tensor as a contiguous (B', P) buffer (passion_halo_pack)"""
+    Bp, D = x.shape[0], x.shape[1]
+    P = x[0, 0].numel()
+    buf = torch.empty(Bp, P, dtype=x.dtype, device=x.device)
+    if x.is_cuda:
+        L.check(L.load().passion_halo_pack(_p(x), _p(buf), L.dtype_code(x.dtype), Bp, D, P, d, L.stream_ptr()), "passion_halo_pack")
+    else:                       # CPU rehearsal of the exchange logic (tests/test_depth_cpu.py)
+        buf.copy_(x[:, d].reshape(Bp, P))
+    return buf
+
+
+def _put_plane(buf, y, d, accumulate):
+    Bp, D = y.shape[0], y.shape[1]
+    P = y[0, 0].numel()
+    if y.is_cuda:
+        L.check(L.load().passion_halo_unpack(_p(buf), _p(y), L.dtype_code(y.dtype), Bp, D, P, d, 1 if accumulate else 0, L.stream_ptr()),
+                "passion_halo_unpack")
+    elif accumulate:
+        y[:, d] += buf.view(y[:, d].shape)
+    else:
+        y[:, d] = buf.view(y[:, d].shape)
+
+
+class HaloExtendFn(torch.autograd.Function):
+    """(B', Dl, ...) slab -> (B', n_lo + Dl + n_hi, ...): n_hi in {0, 1} planes from the high neighbour, n_lo in {0, 1, 2} from the
+    low one (2 = one zero plane in front of the halo plane: the stride-2 convs read planes 2j-1 .. 2j+1; 0 / n_hi = 0 at a global
+    end of a ZERO-padded pre-norm conv: its padding is zero AFTER norm + activation, so there the conv's own padding is used and
+    no plane is added).  At the global ends of the other ops the halo plane is reflect (plane 1 / Dl-2) or zeros.
+    hi_used: the op reads a high halo at all (stride-1 convs, upsampling) -- tells the backward whether the low neighbour sent a
+    gradient for my first plane."""
+
+    @staticmethod
+    def forward(ctx, x, shard, reflect, n_lo, n_hi, hi_used=True):
+        x = x.contiguous()
+        Dl = x.shape[1]
+        ext = torch.zeros((x.shape[0], n_lo + Dl + n_hi) + tuple(x.shape[2:]), dtype=x.dtype, device=x.device)
+        ext[:, n_lo:n_lo + Dl].copy_(x)
+        r_lo, r_hi = shard.exchange(_plane(x, 0), _plane(x, Dl - 1))       # my first plane goes down, my last plane goes up
+        # reflect at a global end mirrors plane 1 (resp. D-2) of the VOLUME: with one plane per rank (level 5 of a 128^3 volume on
+        # 8 GPUs) that is the neighbour's plane, i.e. the halo plane received from the other side
+        if n_lo:
+            if r_lo is not None:
+                _put_plane(r_lo, ext, n_lo - 1, False)
+            elif reflect:
+                _put_plane(_plane(x, 1) if Dl > 1 else r_hi, ext, n_lo - 1, False)
+        if n_hi:
+            if r_hi is not None:
+                _put_plane(r_hi, ext, n_lo + Dl, False)
+            elif reflect:
+                _put_plane(_plane(x, Dl - 2) if Dl > 1 else r_lo, ext, n_lo + Dl, False)
+        ctx.shard, ctx.reflect, ctx.n_lo, ctx.n_hi, ctx.Dl, ctx.hi_used = shard, reflect, n_lo, n_hi, Dl, hi_used
+        return ext
+
+    @staticmethod
+    def backward(ctx, g):
+        shard, n_lo, n_hi, Dl = ctx.shard, ctx.n_lo, ctx.n_hi, ctx.Dl
+        g = g.contiguous()
+        gx = g[:, n_lo:n_lo + Dl].contiguous()
+        # gradient of the halo planes: back to their owners (the low halo is the low neighbour's LAST plane)
+        zero = torch.zeros(g.shape[0], g[0, 0].numel(), dtype=g.dtype, device=g.device)
+        g_lo = _plane(g, n_lo - 1) if n_lo else zero
+        g_hi = _plane(g, n_lo + Dl) if n_hi else zero
+        if ctx.reflect and Dl == 1:               # the mirrored plane was the neighbour's (see forward): its gradient travels with the halo's
+            if shard.lo is None and n_lo:
+                g_hi = g_hi + g_lo
+            if shard.hi is None and n_hi:
+                g_lo = g_lo + g_hi
+        r_lo, r_hi = shard.exchange(g_lo, g_hi)
+        if r_hi is not None:                      # the high neighbour's low halo was my last plane
+            _put_plane(r_hi, gx, Dl - 1, True)
+        if r_lo is not None and ctx.hi_used:      # the low neighbour's high halo was my first plane
+            _put_plane(r_lo, gx, 0, True)
+        if ctx.reflect and Dl > 1:
+            if shard.lo is None and n_lo:
+                _put_plane(g_lo, gx, 1, True)
+            if shard.hi is None and n_hi:
+                _put_plane(g_hi, gx, Dl - 2, True)
+        return gx, None, None, None, None, None
+
+
+class GatherDFn(torch.autograd.Function):
+    """all-gather along dim 1 (D); backward: the ranks' gradients of the gathered tensor summed, own slab returned"""
+
+    @staticmethod
+    def forward(ctx, x, shard):
+        ctx.shard, ctx.Dl = shard, x.shape[1]
+        if shard.world == 1:
+            return x
+        parts = [torch.empty_like(x) for _ in range(shard.world)]
+        dist.all_gather(parts, x.contiguous(), group=shard.group)
+        return torch.cat(parts, 1)
+
+    @staticmethod
+    def backward(ctx, g):
+        if ctx.shard.world == 1:
+            return g, None
+        g = ctx.shard.all_reduce(g.contiguous().clone())
+        return g[:, ctx.shard.rank * ctx.Dl:(ctx.shard.rank + 1) * ctx.Dl].contiguous(), None
+
+
+def global_stats(x, shard, eps=1e-5):
+    """InstanceNorm (mean, rstd) per (b, c) over the WHOLE volume from the ranks' slabs: local statistics kernel, then one
+    all-reduce of (sum x, sum x^2) -- SURVEY 8e "per IN: all-reduce of (sum x, sum x^2) * C floats" """
+    st = ops.instnorm_stats(x.detach(), eps).double()                       # (B, C, 2) = mean, rstd of the slab
+    V = float(x[0, ..., 0].numel())
+    mean, var = st[..., 0], st[..., 1].pow(-2) - eps
+    sums = torch.stack([mean * V, (var + mean * mean) * V], -1).contiguous()
+    shard.all_reduce(sums)
+    Vg = V * shard.world
+    gm = sums[..., 0] / Vg
+    gv = (sums[..., 1] / Vg - gm * gm).clamp_min(0)
+    return torch.stack([gm, (gv + eps).rsqrt()], -1).float().contiguous()
+
+
+class ShardedConvFn(torch.autograd.Function):
+    """ops.ConvBlockFn over (extended) slabs: same forward launch; the backward is split around the all-reduce of the
+    InstanceNorm-backward sums (passion_conv3d_bwd_phase)"""
+
+    @staticmethod
+    def forward(ctx, cfg, shard, win, Dg, weight, bias, packed, *xs):
+        L.require_gpu(weight, *xs)
+        lib = L.load()
+        Cout = weight.shape[0]
+        pad = cfg.ksize // 2
+        Do = (cfg.D + 2 * pad - cfg.ksize) // cfg.stride + 1
+        Ho = (cfg.H + 2 * pad - cfg.ksize) // cfg.stride + 1
+        Wo = (cfg.W + 2 * pad - cfg.ksize) // cfg.stride + 1
+        y = torch.empty(cfg.B, Do, Ho, Wo, Cout, dtype=cfg.out_dtype, device=weight.device)
+        d = ops._fill_desc(cfg, xs)
+        d.Cout = Cout
+        b32 = bias.detach().float() if bias is not None else None
+        L.check(lib.passion_conv3d_fwd(byref(d), _p(packed), _p(b32), c_void_p(0), _p(y), L.stream_ptr()), "passion_conv3d_fwd")
+        ctx.cfg, ctx.packed, ctx.has_bias, ctx.wshape = cfg, packed, bias is not None, weight.shape
+        ctx.shard, ctx.win, ctx.Dg = shard, win, Dg
+        ctx.save_for_backward(*xs)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        cfg, xs, shard = ctx.cfg, ctx.saved_tensors, ctx.shard
+        lib = L.load()
+        dy = dy.contiguous()
+        dev = dy.device
+        nW = ctx.wshape.numel()
+        buf = torch.empty(nW + ctx.wshape[0], dtype=torch.float32, device=dev)
+        dW, db = buf[:nW].view(ctx.wshape), buf[nW:]
+        dxs = [torch.empty_like(x) if ctx.needs_input_grad[7 + i] else None for i, x in enumerate(xs)]
+        d = ops._fill_desc(cfg, xs, dxs)
+        d.Cout = ctx.wshape[0]
+        Cin = sum(s.C for s in cfg.segs)
+        scratch = torch.empty(lib.passion_conv_bwd_scratch_floats(byref(d)), dtype=torch.float32, device=dev)
+        vscale = float(cfg.D) / float(ctx.Dg)                 # V of the (extended) slab / V of the whole volume
+        args = (byref(d), _p(ctx.packed), _p(dy), _p(dW), _p(db) if ctx.has_bias else c_void_p(0), _p(scratch))
+        L.check(lib.passion_conv3d_bwd_phase(*args, 1, vscale, ctx.win[0], ctx.win[1], L.stream_ptr()), "passion_conv3d_bwd_phase 1")
+        if any(dx is not None for dx in dxs):
+            shard.all_reduce(scratch[:2 * cfg.B * Cin])       # (sum g, sum g x_hat) of every rank's slab
+            L.check(lib.passion_conv3d_bwd_phase(*args, 2, vscale, ctx.win[0], ctx.win[1], L.stream_ptr()), "passion_conv3d_bwd_phase 2")
+        return (None, None, None, None, dW, db if ctx.has_bias else None, None, *dxs)
+
+
+class WindowUpsampleFn(torch.autograd.Function):
+    """trilinear x k (align_corners=True) of an extended slab (planes [id0, id0 + Dl_in) of Dg) onto output planes
+    [od0, od0 + Dl_out) of k * Dg"""
+
+    @staticmethod
+    def forward(ctx, x, k, id0, Dg, Dl_out, od0):
+        x = x.contiguous()
+        B, Dl_in, H, W, C = x.shape
+        y = torch.empty(B, Dl_out, H * k, W * k, C, dtype=x.dtype, device=x.device)
+        L.check(L.load().passion_upsample_window_fwd(_p(x), _p(y), L.dtype_code(x.dtype), B, Dl_in, id0, Dg, Dl_out, od0, H, W, C, k,
+                                                     L.stream_ptr()), "passion_upsample_window_fwd")
+        ctx.meta = (x.shape, k, id0, Dg, Dl_out, od0)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (B, Dl_in, H, W, C), k, id0, Dg, Dl_out, od0 = ctx.meta
+        dy = dy.contiguous()
+        dx = torch.empty(B, Dl_in, H, W, C, dtype=dy.dtype, device=dy.device)
+        L.check(L.load().passion_upsample_window_bwd(_p(dy), _p(dx), L.dtype_code(dy.dtype), B, Dl_in, id0, Dg, Dl_out, od0, H, W, C, k,
+                                                     L.stream_ptr()), "passion_upsample_window_bwd")
+        return dx, None, None, None, None, None
+
+
+class ShardedWceDiceFn(torch.autograd.Function):
+    """softmax_weighted_loss_bs + dice_loss_bs (criterions.py:59-76, 25-38) of a slab of probabilities: the sixteen per-class sums
+    of the loss kernel are all-reduced before the two scalars are formed; the backward kernel takes the global sums"""
+
+    @staticmethod
+    def forward(ctx, probs, target_cl, shard, layout):
+        probs = probs.contiguous()
+        B, V, C, ps = ops._strides(probs, layout)
+        sums = torch.empty(B, 16, dtype=torch.float32, device=probs.device)
+        out = torch.empty(B, 2, dtype=torch.float32, device=probs.device)
+        L.check(L.load().passion_wce_dice_fwd(_p(probs), *ps, _p(target_cl), B, V, C, _p(sums), _p(out), L.stream_ptr()), "passion_wce_dice_fwd")
+        shard.all_reduce(sums)
+        Vg = float(V * shard.world)
+        s = sums.double()
+        rt = s[:, 8:12].sum(1, keepdim=True)
+        w = 1.0 - s[:, 8:12] / rt
+        ce = (-(w * s[:, 12:16]).sum(1)) / Vg                                   # wce_dice_final_kernel with the global sums
+        dice = 1.0 - (2.0 * s[:, 0:4] / (s[:, 4:8] + s[:, 8:12] + 1e-7)).sum(1) / 4.0
+        ctx.layout, ctx.scale = layout, 1.0 / shard.world                        # the kernel divides by the local V
+        ctx.save_for_backward(probs, target_cl, sums)
+        return torch.stack([ce, dice], 1).float()
+
+    @staticmethod
+    def backward(ctx, g):
+        probs, target_cl, sums = ctx.saved_tensors
+        B, V, C, ps = ops._strides(probs, ctx.layout)
+        g = g.contiguous().float().clone()
+        g[:, 0] *= ctx.scale
+        dp = torch.empty_like(probs)
+        L.check(L.load().passion_wce_dice_bwd(_p(probs), *ps, _p(target_cl), _p(sums), _p(g), _p(dp), B, V, C, L.stream_ptr()),
+                "passion_wce_dice_bwd")
+        return dp, None, None, None
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# the plain mmformer training forward on slabs
+# ------------------------------------------------------------------------------------------------------------------
+class Slab:
+    """a slab (B, Dl, H, W, C) + its global InstanceNorm statistics (computed once, shared by the consumers) + modality mask"""
+
+    def __init__(self, t, shard, mask=None, col=0):
+        self.t, self.shard, self.mask, self.col, self._st = t, shard, mask, col, None
+
+    def stats(self):
+        if self._st is None:
+            self._st = global_stats(self.t, self.shard)
+        return self._st
+
+    def with_mask(self, mask, col):
+        s = Slab(self.t, self.shard, mask, col)
+        s._st = self.stats()
+        return s
+
+
+def conv(mod, feats, shard, Dg, norm=True, residual=None, out_dtype=None):
+    """one conv layer (nn.Conv3d holder `mod`) over the virtual concat of the slabs `feats`; Dg = depth of the whole volume at
+    the conv's INPUT level"""
+    if not isinstance(feats, (list, tuple)):
+        feats = [feats]
+    from .models.blocks import PAD
+    k, stride = mod.kernel_size[0], mod.stride[0]
+    reflect = mod.padding_mode == "reflect"
+    Dl = feats[0].t.shape[1]
+    n_lo, n_hi = (0, 0) if k == 1 else ((2, 0) if stride == 2 else (1, 1))
+    if k == 3 and not reflect:                                # zero padding of a pre-norm conv: the conv's own, at the global ends
+        assert stride == 1
+        n_lo, n_hi = (0 if shard.lo is None else 1), (0 if shard.hi is None else 1)
+    segs = []
+    for f in feats:
+        t = HaloExtendFn.apply(f.t, shard, reflect, n_lo, n_hi, stride == 1) if k == 3 else f.t
+        segs.append(ops.SegIn(t, stats=f.stats() if norm else None, mask=f.mask, mask_col=f.col))
+    cfg = ops._ConvCfg()
+    x0 = segs[0].x
+    cfg.segs, cfg.D, cfg.H, cfg.W = segs, x0.shape[1], x0.shape[2], x0.shape[3]
+    cfg.ksize, cfg.stride, cfg.pad_mode, cfg.slope = k, stride, PAD[mod.padding_mode], 0.2
+    cfg.B, cfg.out = x0.shape[0], None
+    cfg.out_dtype = out_dtype if out_dtype is not None else x0.dtype
+    cache = mod.__dict__.setdefault("_passion_pack", {})
+    packed = ops.pack_weight(mod.weight, cache)
+    win = (n_lo, n_lo + Dl)                                   # the planes of the extended slab this rank owns
+    Dg_ext = Dg                                               # 1 / V_global = (D_ext / Dg) / V_ext
+    y = ShardedConvFn.apply(cfg, shard, win, Dg_ext, mod.weight, mod.bias, packed, *[s.x for s in segs])
+    if k == 3:
+        o0 = 1 if stride == 2 else n_lo
+        y = y[:, o0:o0 + (Dl // stride)]                      # drop the output planes that belong to the neighbours
+    y = y.contiguous()
+    if residual is not None:
+        y = y + residual
+    return Slab(y, shard)
+
+
+def up(f, k, shard, Dg):
+    """trilinear x k of a slab whose whole volume has Dg planes"""
+    Dl = f.t.shape[1]
+    ext = HaloExtendFn.apply(f.t, shard, False, 1, 1)
+    d0 = shard.rank * Dl
+    return Slab(WindowUpsampleFn.apply(ext, k, d0 - 1, Dg, Dl * k, d0 * k), shard, f.mask, f.col)
+
+
+def seg_pair(probs_cl, target_cl, shard):
+    return ShardedWceDiceFn.apply(probs_cl, target_cl, shard, "cl")
+
+
+def sharded_step_loss(model, shard, x, mask, target, Dg):
+    """mmformer.Model.forward (training, no self-distillation: reference mmformer.py:381-465,533-561,637-657) + train.py's plain
+    loss assembly (:413-440) for ONE volume whose D axis is split over the ranks.
+    x (B, 4, Dl, H, W), target (B, 4, Dl, H, W): this rank's slabs; Dg: depth of the whole volume.
+    -> (loss, pred_local (B, 4, Dl, H, W), prm_loss (B, 1), sep_loss (B, 4)); the losses are global (equal on every rank)"""
+    from .models.mmformer import MODALS
+    B, _, Dl, H, W = x.shape
+    dt = model.compute_dtype
+    idt = model.mask_type != "pdt"
+    mask = mask.to(device=x.device, dtype=torch.bool).contiguous()
+    ops.repack_stale()
+    ops.recast_stale()
+    xin = x.to(dt).contiguous()
+    xe = HaloExtendFn.apply(xin.view(B * 4, Dl, H, W), shard, True, 1, 1).view(B, 4, Dl + 2, H, W)
+    vol = (Dl + 2) * H * W
+    encs = []
+    for i, m in enumerate(MODALS):
+        enc = getattr(model, f"{m}_encoder")
+        seg = ops.SegIn(xe, mask=mask if idt else None, mask_col=i, C=1, offset=i * vol, bstride=4 * vol)
+        cache = enc.e1_c1.__dict__.setdefault("_passion_pack", {})
+        y = ops.conv_block([seg], enc.e1_c1.weight, enc.e1_c1.bias, Dl + 2, H, W, ksize=3, stride=1, pad_mode=L.PAD_REFLECT,
+                           out_dtype=dt, pack_cache=cache)
+        f = Slab(y[:, 1:1 + Dl].contiguous(), shard)
+        feats = []
+        dg = Dg
+        for lvl in range(1, 6):
+            if lvl > 1:
+                f = conv(getattr(enc, f"e{lvl}_c1").conv, f, shard, dg)
+                dg //= 2
+            h = conv(getattr(enc, f"e{lvl}_c2").conv, f, shard, dg)
+            f = conv(getattr(enc, f"e{lvl}_c3").conv, h, shard, dg, residual=f.t)
+            feats.append(f)
+        encs.append(feats)
+    dg5 = Dg // 16
+    # ---- token path: gathered along D, replicated
+    pos = [getattr(model, f"{m}_pos") for m in MODALS]
+    intra = []
+    for i, m in enumerate(MODALS):
+        own5 = encs[i][4].with_mask(mask, i) if idt else encs[i][4]
+        tokv = conv(getattr(model, f"{m}_encode_conv"), own5, shard, dg5, norm=False).t
+        tok = GatherDFn.apply(tokv, shard)
+        p = tok.shape[2]
+        tok = tok.reshape(B, -1, model.token_dim)
+        tok = model._transformer(getattr(model, f"{m}_transformer"), tok, pos[i])
+        intra.append(tok * mask[:, i].view(B, 1, 1).to(tok.dtype))
+    tok = model._transformer(model.multimodal_transformer, torch.cat(intra, 1), torch.cat(pos, 1))
+    volf = tok.to(dt).contiguous().view(B, dg5, p, p, model.token_dim * 4)
+    Dl5 = encs[0][4].t.shape[1]
+    mine = volf[:, shard.rank * Dl5:(shard.rank + 1) * Dl5].contiguous()
+    x5 = conv(model.multimodal_decode_conv, Slab(mine, shard), shard, dg5, norm=False)
+
+    xs = [[encs[i][l].with_mask(mask, i) if idt else encs[i][l] for i in range(4)] for l in range(4)]
+    dgs = [Dg, Dg // 2, Dg // 4, Dg // 8, Dg // 16]
+    df = model.decoder_fuse
+
+    def rfm(mod, feats, dg):
+        h = conv(mod.fusion_layer[0].conv, feats, shard, dg)
+        h = conv(mod.fusion_layer[1].conv, h, shard, dg)
+        return conv(mod.fusion_layer[2].conv, h, shard, dg)
+
+    f5 = rfm(df.RFM5, [x5], dgs[4])
+    preds = {4: conv(df.seg_d4, f5, shard, dgs[4], norm=False, out_dtype=torch.float32).t}
+    h = conv(df.d4_c1.conv, up(f5, 2, shard, dgs[4]), shard, dgs[3])
+    f1 = None
+    for lvl in (4, 3, 2, 1):
+        r = rfm(getattr(df, f"RFM{lvl}"), xs[lvl - 1], dgs[lvl - 1])
+        f = conv(getattr(df, f"d{lvl}_out").conv, conv(getattr(df, f"d{lvl}_c2").conv, [r, h], shard, dgs[lvl - 1]), shard, dgs[lvl - 1])
+        if lvl > 1:
+            preds[lvl - 1] = conv(getattr(df, f"seg_d{lvl - 1}"), f, shard, dgs[lvl - 1], norm=False, out_dtype=torch.float32).t
+            h = conv(getattr(df, f"d{lvl - 1}_c1").conv, up(f, 2, shard, dgs[lvl - 1]), shard, dgs[lvl - 2])
+        else:
+            f1 = f
+    logits = conv(df.seg_layer, f1, shard, Dg, norm=False, out_dtype=torch.float32).t
+    pred_cl = ops.softmax_classes(logits, 1.0, "cl")
+
+    tcl = ops.target_to_cl(target)
+    # ---- per-modality decoders (shared weights, reference mmformer.py:66-114)
+    ds = model.decoder_sep
+    sep_loss = torch.zeros(B, 4, device=x.device)
+    eye = torch.eye(4, device=x.device)
+    maskf = mask.float()
+    for i in range(4):
+        e = [encs[i][l].with_mask(mask, i) if idt else encs[i][l] for l in range(5)]
+        hh = conv(ds.d4_c1.conv, up(e[4], 2, shard, dgs[4]), shard, dgs[3])
+        for lvl in (4, 3, 2, 1):
+            hh = conv(getattr(ds, f"d{lvl}_out").conv, conv(getattr(ds, f"d{lvl}_c2").conv, [hh, e[lvl - 1]], shard, dgs[lvl - 1]),
+                      shard, dgs[lvl - 1])
+            if lvl > 1:
+                hh = conv(getattr(ds, f"d{lvl - 1}_c1").conv, up(hh, 2, shard, dgs[lvl - 1]), shard, dgs[lvl - 2])
+        sp = ops.softmax_classes(conv(ds.seg_layer, hh, shard, Dg, norm=False, out_dtype=torch.float32).t, 1.0, "cl")
+        gate = (maskf * eye[i]) if idt else eye[i].expand(B, 4)
+        sep_loss = sep_loss + gate * seg_pair(sp, tcl, shard).sum(1, keepdim=True)
+    # ---- deep supervision (mmformer.py:540-544): softmax -> x 2^(j+1) -> WCE + Dice, weights 1/2, 1/4, 1/8, 1/16
+    prm_loss = torch.zeros(B, 1, device=x.device)
+    for j in range(4):
+        pj = Slab(ops.softmax_classes(preds[j + 1], 1.0, "cl"), shard)
+        prm_loss = prm_loss + 0.5 ** (j + 1) * seg_pair(up(pj, 2 ** (j + 1), shard, dgs[j + 1]).t, tcl, shard).sum(1, keepdim=True)
+    fuse = seg_pair(pred_cl, tcl, shard).sum()
+    mk = maskf if idt else torch.ones_like(maskf)
+    loss = fuse + (sep_loss * mk).sum() + prm_loss.sum()
+    pred = ops.to_ncdhw(pred_cl.detach())
+    return loss, pred, prm_loss, sep_loss
