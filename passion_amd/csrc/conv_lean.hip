@@ -70,6 +70,23 @@ template <typename T> __device__ __forceinline__ T* rfl_ptr(T* p) {
     return reinterpret_cast<T*>(((unsigned long long)hi << 32) | lo);
 }
 
+// Pointers that reached a lane through the LDS descriptor tables are generic to the compiler: their loads become flat_load, and
+// one pending flat access turns every later wait into vmcnt(0) (flat returns out of order) -- the brick prefetch was drained at
+// its first use.  They are global pointers: say so.
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+template <typename T> __device__ __forceinline__ T gload(const void* ptr) {
+    return *reinterpret_cast<const T __attribute__((address_space(1)))*>(reinterpret_cast<unsigned long long>(ptr));
+}
+__device__ __forceinline__ uint2 gload2(const void* ptr) {
+    const u32x2 v = gload<u32x2>(ptr);
+    return make_uint2(v.x, v.y);
+}
+__device__ __forceinline__ void gstore4(bf16_t* ptr, f32x4 v) {
+    union { bf16_t h[4]; u32x2 u; } t;
+    t.h[0] = (bf16_t)v[0]; t.h[1] = (bf16_t)v[1]; t.h[2] = (bf16_t)v[2]; t.h[3] = (bf16_t)v[3];
+    *reinterpret_cast<u32x2 __attribute__((address_space(1)))*>(reinterpret_cast<unsigned long long>(ptr)) = t.u;
+}
+
 __device__ __forceinline__ bf16x8 zero8() {
     bf16x8 z;
 #pragma unroll
@@ -286,15 +303,15 @@ __device__ __forceinline__ void conv_lean_body(const ConvK& p) {
     auto load_vox = [&](const bf16_t* src, long vox, int C) -> u32x4 {
         if (DG && p.y_f32) {
             const float* f = reinterpret_cast<const float*>(src) + vox * C;
-            const f32x4 lo = *reinterpret_cast<const f32x4*>(f);
+            const f32x4 lo = gload<f32x4>(f);
             f32x4 hi = {0.f, 0.f, 0.f, 0.f};
-            if (C == 8) hi = *reinterpret_cast<const f32x4*>(f + 4);
+            if (C == 8) hi = gload<f32x4>(f + 4);
             bf16x8 o;
 #pragma unroll
             for (int j = 0; j < 4; ++j) { o[j] = (__bf16)lo[j]; o[4 + j] = (__bf16)hi[j]; }
             return __builtin_bit_cast(u32x4, o);
         }
-        return *reinterpret_cast<const u32x4*>(src + vox * C);
+        return gload<u32x4>(src + vox * C);
     };
     auto fetch = [&](int chunk, int o0d, int o0h, int o0w) {
         const BlkDesc* dp = desc + chunk * NC8 + jj;
@@ -317,7 +334,7 @@ __device__ __forceinline__ void conv_lean_body(const ConvK& p) {
                 raw[u] = (u32x4){0u, 0u, 0u, 0u};
                 if (have && (tid + 256 * u < G::TOT) && (S == 1 || voxoff[u] >= 0)) {
                     const unsigned el = base_el + __umul24((unsigned)voxoff[u], (unsigned)C);
-                    raw[u] = *reinterpret_cast<const u32x4*>(src + el);
+                    raw[u] = gload<u32x4>(src + el);
                     okbits |= 1u << u;
                 }
             }
@@ -509,7 +526,7 @@ __device__ __forceinline__ void conv_lean_body(const ConvK& p) {
 #pragma unroll
                 for (int nt = 0; nt < 4; ++nt) {
                     xpre[nt] = make_uint2(0u, 0u);
-                    if (xvv[nt] >= 0) xpre[nt] = *reinterpret_cast<const uint2*>(e.x + (unsigned)xvv[nt] * (unsigned)e.C);      // < 2^32 elements per sample
+                    if (xvv[nt] >= 0) xpre[nt] = gload2(e.x + (unsigned)xvv[nt] * (unsigned)e.C);      // < 2^32 elements per sample
                 }
             }
         }
@@ -610,7 +627,7 @@ __device__ __forceinline__ void conv_lean_body(const ConvK& p) {
                         const bool valid = ok && xvv[nt] >= 0;
                         uint2 xr = make_uint2(0u, 0u);
                         if (MT == 1) xr = xpre[nt];
-                        else if (valid && hs) xr = *reinterpret_cast<const uint2*>(e.x + (unsigned)xvv[nt] * (unsigned)xC);
+                        else if (valid && hs) xr = gload2(e.x + (unsigned)xvv[nt] * (unsigned)xC);
                         const float xv[4] = {__uint_as_float(xr.x << 16), __uint_as_float(xr.x & 0xffff0000u),
                                              __uint_as_float(xr.y << 16), __uint_as_float(xr.y & 0xffff0000u)};
                         const float vf = (valid && hs) ? 1.f : 0.f;
@@ -624,7 +641,7 @@ __device__ __forceinline__ void conv_lean_body(const ConvK& p) {
                             s1[mt][j] += gs;
                             s2v[mt][j] = __builtin_fmaf(gs, xh, s2v[mt][j]);
                         }
-                        if (valid) store4(e.dx + (unsigned)dvv[nt] * (unsigned)dC, gv);
+                        if (valid) gstore4(e.dx + (unsigned)dvv[nt] * (unsigned)dC, gv);
                     }
                 }
             } else if (o0d + TD <= Sd && o0h + TH <= Sh && o0w + TW <= Sw) {       // whole brick inside: no per-lane bounds
