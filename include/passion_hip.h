@@ -154,8 +154,11 @@ int passion_copy_strided(const void* src, int sdtype, int64_t ssb, int64_t ssv, 
 /* ---- segmentation losses --------------------------------------------------------------------
  * softmax_weighted_loss_bs + dice_loss_bs (code/utils/criterions.py:59-76, 25-38) on
  * probabilities.  probs strided as above; target f32 channels-last [B][V][C], C = 4.
- * sums: f32 scratch [B][4*C] (num, l, r, celog per class; zeroed by the call).
+ * sums: f32 scratch of passion_wce_dice_sums_floats(B) floats; its first [B][4*C] hold (num, l, r, celog per class) after the
+ * call -- the backward (and the depth-sharded all-reduce) read those -- the rest is the reduction's per-block slots: the sums
+ * are added in a fixed order, so the result repeats bit for bit run to run.
  * out: [B][2] = (weighted CE, Dice loss). */
+int64_t passion_wce_dice_sums_floats(int B);
 int passion_wce_dice_fwd(const float* probs, int64_t psb, int64_t psv, int64_t psc,
                          const float* target, int B, int64_t V, int C, float* sums, float* out,
                          void* stream);
@@ -164,9 +167,11 @@ int passion_wce_dice_bwd(const float* probs, int64_t psb, int64_t psv, int64_t p
                          const float* target, const float* sums, const float* g, float* dprobs,
                          int B, int64_t V, int C, void* stream);
 /* temp_kl_loss_bs (criterions.py:92-103) on already softmaxed(/T) [and upsampled] probabilities.
- * out[b] = T^2 * mean_{c,v} pt*(log pt - log ps) with both clamped to [0.005,1]. */
+ * out[b] = T^2 * mean_{c,v} pt*(log pt - log ps) with both clamped to [0.005,1].
+ * work: f32 scratch of passion_kl_work_floats(B) floats (fixed-order reduction slots). */
+int64_t passion_kl_work_floats(int B);
 int passion_kl_fwd(const float* ps, const float* pt, int B, int64_t V, int C, float temp,
-                   float* out, void* stream);
+                   float* out, float* work, void* stream);
 int passion_kl_bwd(const float* ps, const float* pt, const float* g, float* dps, int B, int64_t V,
                    int C, float temp, void* stream);
 /* prototype_passion_loss_bs (criterions.py:144-180).  fs, ft: [B][V][Cf] features (dtype),
@@ -270,7 +275,8 @@ int passion_augment(const float* crop, const int32_t* seg, int S0, int S1, int S
 /* ---- in-library kernel timing (bench.py roofline leg) ------------------------------------------
  * passion_prof_enable(mask): bit k of `mask` selects launches of kind k; selected conv3d launches are
  * bracketed by hipEvents on their own stream and their algorithmic bytes / flops recorded.  passion_prof_read drains up to `cap` records:
- * rec[i] = {kind, ms, bytes, flops, name}. kind: 0 fwd k3, 1 fwd k1, 2 dgrad, 3 wgrad; name = the kernel instantiation
+ * rec[i] = {kind, ms, bytes, flops, name}. kind: 0 fwd k3, 1 fwd k1, 2 dgrad, 3 wgrad, 4 / 5 fused attention forward / backward, 6 the sums fold + finish kernels that
+ * complete a dgrad (name "finish of <dgrad kernel>", bytes = the dgrad's); name = the kernel instantiation
  * that ran, spelled as rocprofv3 prints it (e.g. "wgrad_lean_kernel<3, 1>"). */
 typedef struct { int32_t kind; float ms; double bytes; double flops; char name[64]; } passion_prof_rec_t;
 void passion_prof_enable(int on);

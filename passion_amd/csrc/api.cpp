@@ -38,6 +38,8 @@ void passion_prof_end(hipStream_t st) {
     }
 }
 
+const char* passion_prof_last_tag() { return g_tag; }
+
 void passion_prof_tag(const char* fmt, ...) {
     if (!g_passion_prof_on) return;
     va_list ap;

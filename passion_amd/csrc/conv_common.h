@@ -43,6 +43,8 @@ struct ConvK {
     int y_f32;             // lean kernels: y (forward) / dy (backward) is f32 with Cout <= 8 -- the 4-class logit heads
     long wslot;            // wgrad: floats per workgroup slot of the partial slab ([dW | dbias])
     int sums_rep;          // dgrad: replicas of the InstanceNorm-backward sums this launch spreads its atomics over
+    int sums_fixed;        // the replicas hold 64-bit fixed-point (2^-40) integers instead of floats (lean dgrad: order-independent atomics)
+    int sums_float_only;   // caller needs float sums (two-phase backward of the depth-sharded path all-reduces them)
     int per, wres;         // bf16 kernel: bricks per (persistent) workgroup; all chunks' weight fragments resident in LDS
     int bd_rows, bd_k8;    // lean dgrad with block-diagonal weights (batched passes summed first, conv.hip): K block gb = (segment
                            // gb / bd_k8, block gb % bd_k8 of the real Cout); rows of another segment (bd_rows each) read zero weights

@@ -112,7 +112,7 @@ __device__ __forceinline__ void conv_lean_body(const ConvK& p) {
     char* lds = dyn_lds;                                   // [brick | block descriptors | weight fragments]
     BlkDesc* desc = reinterpret_cast<BlkDesc*>(dyn_lds + G::BRICK);
     bf16x8* wl0 = reinterpret_cast<bf16x8*>(dyn_lds + G::BRICK + DESC_BYTES);
-    __shared__ float lsum[DG ? MT * 16 * 2 : 4];
+    __shared__ float lsum[DG ? 4 * MT * 16 * 2 : 4];        // [wave][row][2]
     __shared__ EpiDesc edesc[DG ? MT * 4 : 1];
     __shared__ unsigned short mlist[128];
     __shared__ int mcnt[4];
@@ -676,9 +676,10 @@ __device__ __forceinline__ void conv_lean_body(const ConvK& p) {
     }
 
     if (DG) {
-        // one reduction per workgroup: 16 voxel lanes (shuffles) -> 4 waves (LDS) -> one replica of the global sums
-        __syncthreads();
-        for (int i = tid; i < MT * 16 * 2; i += 256) lsum[i] = 0.f;
+        // one reduction per workgroup: 16 voxel lanes (shuffles) -> 4 waves (LDS slots, summed in a fixed order) -> one replica of
+        // the global sums.  The global add is a 64-bit INTEGER atomic on a 2^-40 fixed-point image of the partial sum (sums_fixed):
+        // integer addition is associative, so the result does not depend on the order in which the workgroups arrive and the
+        // gradients repeat bit for bit (f32 atomics made bf16 gradients differ from run to run by percents downstream).
         __syncthreads();
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
@@ -686,19 +687,27 @@ __device__ __forceinline__ void conv_lean_body(const ConvK& p) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const float a1 = group16_sum(s1[mt][j]), a2 = group16_sum(s2v[mt][j]);
-                if (n == 0 && st) {
-                    atomicAdd(&lsum[(mt * 16 + g * 4 + j) * 2 + 0], a1);
-                    atomicAdd(&lsum[(mt * 16 + g * 4 + j) * 2 + 1], a2);
+                if (n == 0) {
+                    lsum[((wv * MT + mt) * 16 + g * 4 + j) * 2 + 0] = st ? a1 : 0.f;
+                    lsum[((wv * MT + mt) * 16 + g * 4 + j) * 2 + 1] = st ? a2 : 0.f;
                 }
             }
         }
         __syncthreads();
-        for (int i = tid; i < MT * 16; i += 256) {
-            const int cg = mg * MT * 16 + i;
-            if (cg < p.Cin && (lsum[i * 2] != 0.f || lsum[i * 2 + 1] != 0.f)) {
-                float* rs = p.sums + (long)(blockIdx.x % p.sums_rep) * p.B * p.Cin * 2;
-                atomicAdd(&rs[((long)b * p.Cin + cg) * 2 + 0], lsum[i * 2 + 0]);
-                atomicAdd(&rs[((long)b * p.Cin + cg) * 2 + 1], lsum[i * 2 + 1]);
+        for (int i = tid; i < MT * 16 * 2; i += 256) {
+            const int row = i >> 1, k2 = i & 1;
+            const int cg = mg * MT * 16 + row;
+            const float t = ((lsum[(0 * MT * 16 + row) * 2 + k2] + lsum[(1 * MT * 16 + row) * 2 + k2]) + lsum[(2 * MT * 16 + row) * 2 + k2]) +
+                            lsum[(3 * MT * 16 + row) * 2 + k2];
+            if (cg < p.Cin && t != 0.f) {
+                const long idx = (long)(blockIdx.x % p.sums_rep) * p.B * p.Cin * 2 + ((long)b * p.Cin + cg) * 2 + k2;
+                if (p.sums_fixed) {
+                    double v = (double)t * 1099511627776.0;                      // 2^40
+                    v = fmin(fmax(v, -9.0e18), 9.0e18);
+                    atomicAdd(reinterpret_cast<unsigned long long*>(p.sums) + idx, (unsigned long long)(long long)llrint(v));
+                } else {
+                    atomicAdd(&p.sums[idx], t);
+                }
             }
         }
     }
@@ -828,6 +837,7 @@ int launch_conv_lean(ConvK& k, int ksize, int stride, int mode, const void* pack
     }
     k.dbg = g_conv_dbg;
     k.sums_rep = SUMS_REP_LEAN;
+    k.sums_fixed = k.sums_float_only ? 0 : 1;
     const int mtiles = k.Mpad / 16;
     if (ksize == 1) return dgrad ? launch_lean_geo<1, 1>(k, K8, cmax, mtiles, st) : launch_lean_geo<1, 0>(k, K8, cmax, mtiles, st);
     if (mode == 2 && stride == 2) return launch_lean_geo<3, 2, 2>(k, K8, cmax, mtiles, st);

@@ -88,11 +88,44 @@ __global__ void copy_strided_kernel(const TS* __restrict__ s, long ssb, long ssv
     }
 }
 
+// ---------------------------------------------------------------- deterministic grid reductions
+// The per-sample sums of the loss kernels used to end with one float atomicAdd per block: the order of those adds changes run
+// to run, the sums differ in their last bit, and a bf16 rounding downstream then flips -- gradients did not repeat.  Now every
+// block stores its J partial sums in its own slot (`part`: [gridDim.y][gridDim.x][J] floats), takes a ticket from a device
+// counter, and the block that arrives LAST adds the slots in block order: the same additions in the same order every run.
+// Returns true in that last block only, with column j's total in thread j (j < J <= 256).  `red` is LDS for 4*J floats
+// (the caller's own reduction buffer, reused); the counter is left at zero again for the next launch on the stream.
+template <int J>
+__device__ __forceinline__ bool fold_blocks(float s, float* __restrict__ part, unsigned* __restrict__ counter,
+                                            float* __restrict__ red, float& total) {
+    __shared__ int last;
+    const int nb = gridDim.x, b = blockIdx.y, tid = threadIdx.x;
+    __syncthreads();                                        // everyone is done reading `red`
+    if (tid < J) part[((long)b * nb + blockIdx.x) * J + tid] = s;
+    __threadfence();                                        // release: the slot is visible device-wide before the ticket
+    __syncthreads();
+    if (tid == 0) last = atomicAdd(&counter[b], 1u) == (unsigned)(nb - 1);
+    __syncthreads();
+    if (!last) return false;
+    __threadfence();                                        // acquire: see the other blocks' slots
+    for (int j = tid & 63; j < J; j += 64) {
+        float a = 0.f;
+        for (int r = tid >> 6; r < nb; r += 4) a += part[((long)b * nb + r) * J + j];
+        red[(tid >> 6) * J + j] = a;
+    }
+    __syncthreads();
+    total = tid < J ? (red[tid] + red[J + tid]) + (red[2 * J + tid] + red[3 * J + tid]) : 0.f;
+    if (tid == 0) counter[b] = 0u;
+    return true;
+}
+constexpr int RED_BLOCKS_MAX = 1024;
+
 // ---------------------------------------------------------------- weighted CE + Dice
 // sums[b][0..3]=num_c, [4..7]=l_c (sum p), [8..11]=r_c (sum t), [12..15]=sum t_c*log(clamp p_c)
 __global__ __launch_bounds__(256) void wce_dice_sums_kernel(const float* __restrict__ pr, long psb, long psv, long psc,
                                                             const float* __restrict__ tg, long V,
-                                                            float* __restrict__ sums) {
+                                                            float* __restrict__ sums, float* __restrict__ part,
+                                                            unsigned* __restrict__ counter, float* __restrict__ out) {
     __shared__ float red[4][16];
     const int b = blockIdx.y;
     float a[16];
@@ -124,16 +157,14 @@ __global__ __launch_bounds__(256) void wce_dice_sums_kernel(const float* __restr
         if (lane == 0) red[wv][j] = s;
     }
     __syncthreads();
-    if (threadIdx.x < 16) {
-        const float s = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
-        atomicAdd(&sums[b * 16 + threadIdx.x], s);
-    }
-}
-
-__global__ void wce_dice_final_kernel(const float* __restrict__ sums, int B, long V, float* __restrict__ out) {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= B) return;
-    const float* s = sums + b * 16;
+    float s_blk = 0.f, tot;
+    if (threadIdx.x < 16) s_blk = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+    if (!fold_blocks<16>(s_blk, part, counter, &red[0][0], tot)) return;
+    // last block: the sixteen totals (kept for the backward / the depth-sharded all-reduce) and the two loss scalars
+    if (threadIdx.x < 16) { sums[b * 16 + threadIdx.x] = tot; red[0][threadIdx.x] = tot; }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    const float* s = &red[0][0];
     const float rt = s[8] + s[9] + s[10] + s[11];
     float ce = 0.f, dice = 0.f;
 #pragma unroll
@@ -176,7 +207,8 @@ __global__ void wce_dice_bwd_kernel(const float* __restrict__ pr, long psb, long
 
 // ---------------------------------------------------------------- temperature KL
 __global__ __launch_bounds__(256) void kl_fwd_kernel(const float* __restrict__ ps, const float* __restrict__ pt, long V,
-                                                     float k, float* __restrict__ out) {
+                                                     float k, float* __restrict__ out, float* __restrict__ part,
+                                                     unsigned* __restrict__ counter) {
     __shared__ float red[4];
     const int b = blockIdx.y;
     float a = 0.f;
@@ -191,7 +223,9 @@ __global__ __launch_bounds__(256) void kl_fwd_kernel(const float* __restrict__ p
     a = wave_sum(a);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a;
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(&out[b], k * (red[0] + red[1] + red[2] + red[3]));
+    float s_blk = 0.f, tot;
+    if (threadIdx.x == 0) s_blk = red[0] + red[1] + red[2] + red[3];
+    if (fold_blocks<1>(s_blk, part, counter, red, tot) && threadIdx.x == 0) out[b] = k * tot;
 }
 
 __global__ void kl_bwd_kernel(const float* __restrict__ ps, const float* __restrict__ pt, const float* __restrict__ g,
@@ -237,7 +271,8 @@ template <typename T> __device__ __forceinline__ void store8(T* p, const float* 
 
 template <typename T>
 __global__ __launch_bounds__(256) void proto_sums_kernel(const T* __restrict__ fs, const T* __restrict__ ft,
-                                                         const float* __restrict__ tg, long V, float* __restrict__ work, int cf) {
+                                                         const float* __restrict__ tg, long V, float* __restrict__ work, int cf,
+                                                         float* __restrict__ part, unsigned* __restrict__ counter) {
     __shared__ float red[4][4 + 8 * CF];
     const int b = blockIdx.y;
     float cnt[NC], ss[NC][CF], st[NC][CF];
@@ -273,10 +308,10 @@ __global__ __launch_bounds__(256) void proto_sums_kernel(const T* __restrict__ f
         }
     }
     __syncthreads();
-    if (threadIdx.x < 4 + 8 * CF) {
-        const int j = threadIdx.x;
-        atomicAdd(&work[(long)b * PW + j], red[0][j] + red[1][j] + red[2][j] + red[3][j]);
-    }
+    const int j = threadIdx.x;
+    float s_blk = 0.f, tot;
+    if (j < 4 + 8 * CF) s_blk = red[0][j] + red[1][j] + red[2][j] + red[3][j];
+    if (fold_blocks<4 + 8 * CF>(s_blk, part, counter, &red[0][0], tot) && j < 4 + 8 * CF) work[(long)b * PW + j] = tot;
 }
 
 // class c counts only if every sample of the (local) batch contains it (criterions.py:157)
@@ -317,7 +352,8 @@ __device__ __forceinline__ void load_protos(const float* __restrict__ work, int 
 
 template <typename T>
 __global__ __launch_bounds__(256) void proto_loss_kernel(const T* __restrict__ fs, const T* __restrict__ ft, long V,
-                                                         int B, float* __restrict__ work, int cf) {
+                                                         int B, float* __restrict__ work, int cf,
+                                                         float* __restrict__ part, unsigned* __restrict__ counter) {
     __shared__ float red[4][2];
     const int b = blockIdx.y;
     const float eps = 1e-5f;
@@ -347,11 +383,10 @@ __global__ __launch_bounds__(256) void proto_loss_kernel(const T* __restrict__ f
     al = wave_sum(al); ad = wave_sum(ad);
     if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6][0] = al; red[threadIdx.x >> 6][1] = ad; }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        const float k = 1.0f / (P.nvalid * (float)V);
-        atomicAdd(&work[(long)b * PW + PW_LOSS], k * (red[0][0] + red[1][0] + red[2][0] + red[3][0]));
-        atomicAdd(&work[(long)b * PW + PW_DIST], k * (red[0][1] + red[1][1] + red[2][1] + red[3][1]));
-    }
+    float s_blk = 0.f, tot;
+    if (threadIdx.x < 2) s_blk = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+    if (fold_blocks<2>(s_blk, part, counter, &red[0][0], tot) && threadIdx.x < 2)
+        work[(long)b * PW + PW_LOSS + threadIdx.x] = tot / (P.nvalid * (float)V);
 }
 
 __global__ void proto_out_kernel(const float* __restrict__ work, int B, float* __restrict__ out) {
@@ -365,7 +400,8 @@ __global__ void proto_out_kernel(const float* __restrict__ work, int B, float* _
 template <typename T>
 __global__ __launch_bounds__(256) void proto_bwd1_kernel(const T* __restrict__ fs, const T* __restrict__ ft,
                                                          const float* __restrict__ g, long V, int B,
-                                                         float* __restrict__ work, T* __restrict__ dfs, int cf) {
+                                                         float* __restrict__ work, T* __restrict__ dfs, int cf,
+                                                         float* __restrict__ part, unsigned* __restrict__ counter) {
     __shared__ float red[4][NC * CF];
     const int b = blockIdx.y;
     const float eps = 1e-5f;
@@ -415,10 +451,10 @@ __global__ __launch_bounds__(256) void proto_bwd1_kernel(const T* __restrict__ f
             if (lane == 0) red[wv][c * CF + h] = s;
         }
     __syncthreads();
-    if (threadIdx.x < NC * CF) {
-        const int j = threadIdx.x;
-        atomicAdd(&work[(long)b * PW + 4 + 8 * CF + j], red[0][j] + red[1][j] + red[2][j] + red[3][j]);
-    }
+    const int j = threadIdx.x;
+    float s_blk = 0.f, tot;
+    if (j < NC * CF) s_blk = red[0][j] + red[1][j] + red[2][j] + red[3][j];
+    if (fold_blocks<NC * CF>(s_blk, part, counter, &red[0][0], tot) && j < NC * CF) work[(long)b * PW + 4 + 8 * CF + j] = tot;
 }
 
 // backward pass 2: prototypes are masked means of fs, so every voxel of class c receives Gp[c]/(count_c+eps)
@@ -450,7 +486,9 @@ inline int vgrid(long V) { return (int)hmin((V + 255) / 256, 2048); }
 // (~50-100 ns each), which argues for few blocks -- but 128 blocks left half of the 256 CUs idle and one workgroup per CU
 // cannot hide its load latency (kl_fwd 46 us, proto_bwd1 231 us per launch at 128^3): 512 blocks measured +5 % on the whole
 // PASSION step, 1024 the same (PASSION_RED_BLOCKS to override)
-inline int vgrid_red(long V) { return (int)hmin((V + 256 * 4 - 1) / (256 * 4), g_red_blocks); }
+inline int vgrid_red(long V) { return (int)hmin((V + 256 * 4 - 1) / (256 * 4), hmin((long)g_red_blocks, (long)RED_BLOCKS_MAX)); }
+// scratch behind a reduction's own floats: B ticket counters (+ padding to 4), then B * RED_BLOCKS_MAX * J partial-sum slots
+inline long red_extra_floats(int B, int J) { return (long)((B + 3) & ~3) + (long)B * RED_BLOCKS_MAX * J; }
 
 }  // namespace
 
@@ -508,14 +546,16 @@ extern "C" int passion_wce_dice_fwd(const float* probs, int64_t psb, int64_t psv
                                     int B, int64_t V, int C, float* sums, float* out, void* stream) {
     if (C != NC) return -1012;
     hipStream_t st = (hipStream_t)stream;
-    HIP_RET(hipMemsetAsync(sums, 0, sizeof(float) * 16 * (size_t)B, st));
+    unsigned* counter = (unsigned*)(sums + 16 * (size_t)B);
+    float* part = sums + 16 * (size_t)B + ((B + 3) & ~3);
+    HIP_RET(hipMemsetAsync(counter, 0, sizeof(unsigned) * (size_t)B, st));
     hipLaunchKernelGGL(wce_dice_sums_kernel, dim3(vgrid_red(V), B), dim3(256), 0, st, probs, (long)psb, (long)psv,
-                       (long)psc, target, (long)V, sums);
-    LAUNCH_RET();
-    hipLaunchKernelGGL(wce_dice_final_kernel, dim3((B + 63) / 64), dim3(64), 0, st, sums, B, (long)V, out);
+                       (long)psc, target, (long)V, sums, part, counter, out);
     LAUNCH_RET();
     return 0;
 }
+extern "C" int64_t passion_wce_dice_sums_floats(int B) { return 16 * (int64_t)B + red_extra_floats(B, 16); }
+extern "C" int64_t passion_kl_work_floats(int B) { return red_extra_floats(B, 1); }
 
 extern "C" int passion_wce_dice_bwd(const float* probs, int64_t psb, int64_t psv, int64_t psc, const float* target,
                                     const float* sums, const float* g, float* dprobs, int B, int64_t V, int C,
@@ -528,12 +568,14 @@ extern "C" int passion_wce_dice_bwd(const float* probs, int64_t psb, int64_t psv
 }
 
 extern "C" int passion_kl_fwd(const float* ps, const float* pt, int B, int64_t V, int C, float temp, float* out,
-                              void* stream) {
+                              float* work, void* stream) {
     if (C != NC) return -1012;
     hipStream_t st = (hipStream_t)stream;
-    HIP_RET(hipMemsetAsync(out, 0, sizeof(float) * (size_t)B, st));
+    unsigned* counter = (unsigned*)work;
+    HIP_RET(hipMemsetAsync(counter, 0, sizeof(unsigned) * (size_t)B, st));
     const float k = temp * temp / ((float)NC * (float)V);
-    hipLaunchKernelGGL(kl_fwd_kernel, dim3(vgrid_red(V), B), dim3(256), 0, st, ps, pt, (long)V, k, out);
+    hipLaunchKernelGGL(kl_fwd_kernel, dim3(vgrid_red(V), B), dim3(256), 0, st, ps, pt, (long)V, k, out,
+                       work + ((B + 3) & ~3), counter);
     LAUNCH_RET();
     return 0;
 }
@@ -547,27 +589,29 @@ extern "C" int passion_kl_bwd(const float* ps, const float* pt, const float* g, 
     return 0;
 }
 
-extern "C" int64_t passion_proto_work_floats(int B, int Cf) { (void)Cf; return (int64_t)B * PW + 8; }
+extern "C" int64_t passion_proto_work_floats(int B, int Cf) { (void)Cf; return (int64_t)B * PW + 8 + red_extra_floats(B, 4 + 8 * CF); }
 
 extern "C" int passion_proto_fwd(const void* fs, const void* ft, int dtype, const float* target, int B, int64_t V,
                                  int Cf, float* work, float* out, void* stream) {
     if (Cf != 4 && Cf != 8) return -1013;
     hipStream_t st = (hipStream_t)stream;
-    HIP_RET(hipMemsetAsync(work, 0, sizeof(float) * (size_t)passion_proto_work_floats(B, Cf), st));
+    unsigned* counter = (unsigned*)(work + (long)B * PW + 8);
+    float* part = work + (long)B * PW + 8 + ((B + 3) & ~3);
+    HIP_RET(hipMemsetAsync(work, 0, sizeof(float) * ((size_t)B * PW + 8 + ((B + 3) & ~3)), st));
     dim3 grid(vgrid_red(V), B);
     if (dtype == PASSION_F32)
-        hipLaunchKernelGGL(proto_sums_kernel<float>, grid, dim3(256), 0, st, (const float*)fs, (const float*)ft, target, (long)V, work, Cf);
+        hipLaunchKernelGGL(proto_sums_kernel<float>, grid, dim3(256), 0, st, (const float*)fs, (const float*)ft, target, (long)V, work, Cf, part, counter);
     else if (dtype == PASSION_BF16)
-        hipLaunchKernelGGL(proto_sums_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)fs, (const bf16_t*)ft, target, (long)V, work, Cf);
+        hipLaunchKernelGGL(proto_sums_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)fs, (const bf16_t*)ft, target, (long)V, work, Cf, part, counter);
     else
         return -1007;
     LAUNCH_RET();
     hipLaunchKernelGGL(proto_valid_kernel, dim3(1), dim3(64), 0, st, work, B);
     LAUNCH_RET();
     if (dtype == PASSION_F32)
-        hipLaunchKernelGGL(proto_loss_kernel<float>, grid, dim3(256), 0, st, (const float*)fs, (const float*)ft, (long)V, B, work, Cf);
+        hipLaunchKernelGGL(proto_loss_kernel<float>, grid, dim3(256), 0, st, (const float*)fs, (const float*)ft, (long)V, B, work, Cf, part, counter);
     else
-        hipLaunchKernelGGL(proto_loss_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)fs, (const bf16_t*)ft, (long)V, B, work, Cf);
+        hipLaunchKernelGGL(proto_loss_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)fs, (const bf16_t*)ft, (long)V, B, work, Cf, part, counter);
     LAUNCH_RET();
     hipLaunchKernelGGL(proto_out_kernel, dim3((B + 63) / 64), dim3(64), 0, st, work, B, out);
     LAUNCH_RET();
@@ -578,17 +622,18 @@ extern "C" int passion_proto_bwd(const void* fs, const void* ft, int dtype, cons
                                  int64_t V, int Cf, float* work, void* dfs, void* stream) {
     if (Cf != 4 && Cf != 8) return -1013;
     hipStream_t st = (hipStream_t)stream;
-    // `work` still holds the forward's sums / validity; only the Gp block is re-zeroed
-    for (int b = 0; b < B; ++b)
-        HIP_RET(hipMemsetAsync(work + (long)b * PW + 4 + 8 * CF, 0, sizeof(float) * 4 * CF, st));
+    // `work` still holds the forward's sums / validity; the Gp block is overwritten by the last block of bwd1; the ticket
+    // counters were left at zero by the forward's reductions
+    unsigned* counter = (unsigned*)(work + (long)B * PW + 8);
+    float* part = work + (long)B * PW + 8 + ((B + 3) & ~3);
     dim3 grid(vgrid_red(V), B);
     dim3 grid2(vgrid(V), B);
     if (dtype == PASSION_F32) {
-        hipLaunchKernelGGL(proto_bwd1_kernel<float>, grid, dim3(256), 0, st, (const float*)fs, (const float*)ft, g, (long)V, B, work, (float*)dfs, Cf);
+        hipLaunchKernelGGL(proto_bwd1_kernel<float>, grid, dim3(256), 0, st, (const float*)fs, (const float*)ft, g, (long)V, B, work, (float*)dfs, Cf, part, counter);
         LAUNCH_RET();
         hipLaunchKernelGGL(proto_bwd2_kernel<float>, grid2, dim3(256), 0, st, target, (long)V, work, (float*)dfs, Cf);
     } else if (dtype == PASSION_BF16) {
-        hipLaunchKernelGGL(proto_bwd1_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)fs, (const bf16_t*)ft, g, (long)V, B, work, (bf16_t*)dfs, Cf);
+        hipLaunchKernelGGL(proto_bwd1_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)fs, (const bf16_t*)ft, g, (long)V, B, work, (bf16_t*)dfs, Cf, part, counter);
         LAUNCH_RET();
         hipLaunchKernelGGL(proto_bwd2_kernel<bf16_t>, grid2, dim3(256), 0, st, target, (long)V, work, (bf16_t*)dfs, Cf);
     } else

@@ -3,7 +3,8 @@
 #include <hip/hip_runtime.h>
 void passion_prof_begin(int kind, double bytes, double flops, hipStream_t st);
 void passion_prof_end(hipStream_t st);
-void passion_prof_tag(const char* fmt, ...);   // name of the kernel instantiation launched inside the open scope
+void passion_prof_tag(const char* fmt, ...);
+const char* passion_prof_last_tag();            // the tag of the scope that closed last on this thread   // name of the kernel instantiation launched inside the open scope
 extern int g_passion_prof_on;  // bit k set: time launches of kind k
 struct ProfScope {
     hipStream_t st; bool on;

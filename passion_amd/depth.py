@@ -270,9 +270,11 @@ class ShardedWceDiceFn(torch.autograd.Function):
     def forward(ctx, probs, target_cl, shard, layout):
         probs = probs.contiguous()
         B, V, C, ps = ops._strides(probs, layout)
-        sums = torch.empty(B, 16, dtype=torch.float32, device=probs.device)
+        lib = L.load()
+        scratch = torch.empty(lib.passion_wce_dice_sums_floats(B), dtype=torch.float32, device=probs.device)
         out = torch.empty(B, 2, dtype=torch.float32, device=probs.device)
-        L.check(L.load().passion_wce_dice_fwd(_p(probs), *ps, _p(target_cl), B, V, C, _p(sums), _p(out), L.stream_ptr()), "passion_wce_dice_fwd")
+        L.check(lib.passion_wce_dice_fwd(_p(probs), *ps, _p(target_cl), B, V, C, _p(scratch), _p(out), L.stream_ptr()), "passion_wce_dice_fwd")
+        sums = scratch[:B * 16].view(B, 16).clone()    # the sixteen sums; the rest of the scratch is per-block reduction slots
         shard.all_reduce(sums)
         Vg = float(V * shard.world)
         s = sums.double()

@@ -465,10 +465,12 @@ class WceDiceFn(torch.autograd.Function):
         probs = probs.contiguous()
         assert probs.dtype == torch.float32 and target_cl.dtype == torch.float32
         B, V, C, ps = _strides(probs, layout)
-        sums = torch.empty(B, 16, dtype=torch.float32, device=probs.device)
+        lib = L.load()
+        scratch = torch.empty(lib.passion_wce_dice_sums_floats(B), dtype=torch.float32, device=probs.device)
+        sums = scratch[:B * 16].view(B, 16)            # the rest: the reduction's per-block slots (fixed-order sums)
         out = torch.empty(B, 2, dtype=torch.float32, device=probs.device)
-        L.check(L.load().passion_wce_dice_fwd(_p(probs), *ps, _p(target_cl), B, V, C, _p(sums), _p(out),
-                                              L.stream_ptr()), "passion_wce_dice_fwd")
+        L.check(lib.passion_wce_dice_fwd(_p(probs), *ps, _p(target_cl), B, V, C, _p(scratch), _p(out),
+                                         L.stream_ptr()), "passion_wce_dice_fwd")
         ctx.layout = layout
         ctx.save_for_backward(probs, target_cl, sums)
         return out
@@ -499,7 +501,9 @@ class KLFn(torch.autograd.Function):
         ps, pt = ps.contiguous(), pt.contiguous()
         B, D, H, W, C = ps.shape
         out = torch.empty(B, dtype=torch.float32, device=ps.device)
-        L.check(L.load().passion_kl_fwd(_p(ps), _p(pt), B, D * H * W, C, float(temp), _p(out), L.stream_ptr()),
+        lib = L.load()
+        work = torch.empty(lib.passion_kl_work_floats(B), dtype=torch.float32, device=ps.device)
+        L.check(lib.passion_kl_fwd(_p(ps), _p(pt), B, D * H * W, C, float(temp), _p(out), _p(work), L.stream_ptr()),
                 "passion_kl_fwd")
         ctx.temp = float(temp)
         ctx.save_for_backward(ps, pt)

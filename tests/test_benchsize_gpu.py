@@ -19,8 +19,9 @@ pytestmark = pytest.mark.gpu
 # bf16 storage / f32 accumulate vs the f32 reference, 128^3, ~130 conv layers deep (measured on MI355X, x ~2 headroom)
 # measured (r02, cfg1, marching conv + flash attention): pred max 9.8e-2, rms 2.5e-2, per-class sums 2.0e-3, loss terms 1.6e-4,
 # loss 1.1e-4, grad norms 1.4e-2, mask agreement 0.9834 (random-init logits are near-ties almost everywhere: 477 voxels tie
-# below 1e-4 even in f32)
-BF16_TOL = {"pred_max": 2e-1, "pred_rms": 5e-2, "pred_sum": 5e-3, "loss_terms": 5e-3, "loss": 2e-3, "grad_norm": 3e-2,
+# below 1e-4 even in f32); cfg3 (RFNet 96^3, PASSION): pred max 1.2e-1, rms 2.5e-2, sums 6e-4, loss terms 1.2e-2 (the
+# prototype term: a difference of two cosine maps that nearly cancel), loss 1.2e-4, grad norms 4.5e-3, agreement 0.9746
+BF16_TOL = {"pred_max": 2e-1, "pred_rms": 5e-2, "pred_sum": 5e-3, "loss_terms": 3e-2, "loss": 2e-3, "grad_norm": 3e-2,
             "mask_agree": 0.97}
 
 

@@ -23,7 +23,7 @@ def _free_port():
     return p
 
 
-def _model(dev):
+def _model(dev, dtype=torch.float32):
     from passion_amd.models import mmformer
     old = (mmformer.basic_dims, mmformer.patch_size)
     mmformer.basic_dims, mmformer.patch_size = 8, 2
@@ -32,9 +32,11 @@ def _model(dev):
         m = mmformer.Model(num_cls=4).to(dev)
     finally:
         mmformer.basic_dims, mmformer.patch_size = old
-    # f32 arithmetic: run-to-run noise of the gradients is ~4e-6 (order of the f32 atomics); in bf16 one flipped rounding
-    # of a dx voxel moves transformer gradients by percents between two runs of the SAME process, which would hide a race
-    m.mask_type, m.use_passion, m.compute_dtype = "idt", True, torch.float32
+    # f32 arithmetic (bf16x3 kernels): the InstanceNorm-backward sums of the general conv kernel are f32 atomics, run-to-run
+    # noise ~4e-6.  bf16 (the product configuration): every sum on the path is added in a fixed order or in integers, the
+    # gradients repeat bit for bit -- one flipped bf16 rounding would move transformer gradients by percents, so a race in
+    # the bucket launches cannot hide behind a tolerance there
+    m.mask_type, m.use_passion, m.compute_dtype = "idt", True, dtype
     m.eval()                     # dropout off: the comparison run must see the same network
     return m
 
@@ -51,13 +53,13 @@ def _grads(m, rank, dev):
     return loss
 
 
-def _worker(rank, world, port, out):
+def _worker(rank, world, port, out, dtype):
     sys.path.insert(0, ROOT)
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
                       MASTER_PORT=str(port), PASSION_DEVICE_INDEX="0", PASSION_DIST_BACKEND="gloo")
     from passion_amd import parallel
     ctx = parallel.init()
-    m = _model(ctx.device)
+    m = _model(ctx.device, dtype)
     red = parallel.GradReducer(m, ctx, bucket_mb=1)      # small buckets: many launches from inside backward
     for _ in range(2):                                   # second round: the per-step bookkeeping was reset
         _grads(m, rank, ctx.device)
@@ -70,15 +72,16 @@ def _worker(rank, world, port, out):
     torch.distributed.destroy_process_group()
 
 
-def test_two_ranks_sum_gradients_across_side_streams(tmp_path):
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+def test_two_ranks_sum_gradients_across_side_streams(tmp_path, dtype):
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
     out = str(tmp_path / "r0.pt")
-    mp.spawn(_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, _free_port(), out, dtype), nprocs=2, join=True)
     got = torch.load(out)
     assert got["overlap"] and got["nb"] >= 3
     dev = torch.device("cuda:0")
-    m = _model(dev)
+    m = _model(dev, dtype)
     want = {}
     for rank in range(2):
         _grads(m, rank, dev)
@@ -88,5 +91,6 @@ def test_two_ranks_sum_gradients_across_side_streams(tmp_path):
     assert set(want) == set(got["g"])
     for k, w in want.items():
         g = got["g"][k].float()
-        tol = 2e-4 * float(w.abs().max()) + 1e-6        # f32 atomics order differs from run to run
+        # f32: the atomics' order differs from run to run; bf16: bit for bit (a + b of two f32 gradients commutes)
+        tol = 2e-4 * float(w.abs().max()) + 1e-6 if dtype == torch.float32 else 0.0
         assert float((g - w).abs().max()) <= tol, (k, float((g - w).abs().max()), tol)
