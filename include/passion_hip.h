@@ -251,6 +251,12 @@ int passion_region_mix_bwd(const void* const* y, void* const* dy, const uint8_t*
 /* bmod > 0: y holds only bmod samples and (virtual) sample b of the B given reads y[b % bmod] -- the masked passes of the
  * PASSION students over the same features in one launch; mask, prob, w, out, dy stay indexed by b. */
 
+/* ---- bias gradient of the token GEMMs (nn.Linear of code/models/mmformer.py:196-199, 254-262): out[c] = sum_r g[r][c],
+ * g [R][C] row-major (dtype), out f32 [C], C even.  Fixed summation order (bit-reproducible, also next to other streams).
+ * work: f32 scratch of passion_colsum_work_floats(C) floats. */
+int64_t passion_colsum_work_floats(int C);
+int passion_colsum(const void* g, int dtype, int64_t R, int C, float* out, float* work, void* stream);
+
 /* ---- optimizer: torch.optim.AdamW(betas, eps, weight_decay, amsgrad) (code/train.py:95-96) for n f32 parameter
  * tensors in ceil(n/40) launches.  Host arrays of device pointers; `step` is the 1-based step count after increment. */
 int passion_adamw_step(int n, float* const* params, const float* const* grads, float* const* exp_avg,

@@ -480,6 +480,62 @@ __global__ void proto_bwd2_kernel(const float* __restrict__ tg, long V, const fl
     }
 }
 
+
+// ---------------------------------------------------------------- column sums (bias gradient of the token GEMMs)
+// out[c] = sum_r g[r][c], g: [R][C] row-major (bf16 or f32), out f32.  Stands in for torch's `grad.sum(0)`: that reduce kernel
+// (global reduce through a staging buffer) was measured NOT reproducible on this stack while a second stream keeps the GPU
+// busy -- 20 % of 1000 column sums of a 1280 x 4096 bf16 matrix differed from the first, by up to the size of the sum itself
+// (tools/linear_bias_determinism.py) -- and the encoders run on side streams next to the transformers' backward.
+// One block: 128 columns (a wave reads 256 B of a bf16 row), its four waves take rows r = 4*by + w, + 4*gridDim.y, ...; the
+// row slices of gridDim.y blocks are folded by the last block in slice order (same ticket scheme as fold_blocks).
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ g, long R, int C, float* __restrict__ out,
+                                                     float* __restrict__ part, unsigned* __restrict__ counter) {
+    __shared__ float red[4][128];
+    __shared__ int last;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int col = blockIdx.x * 128 + lane * 2;
+    float a0 = 0.f, a1 = 0.f;
+    if (col < C) {
+        const long step = 4L * gridDim.y;
+        long r = 4L * blockIdx.y + w;
+        for (; r + 3 * step < R; r += 4 * step) {            // four rows in flight
+            float v[4][2];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const T* q = g + (r + u * step) * C + col;
+                v[u][0] = to_f32(q[0]); v[u][1] = to_f32(q[1]);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { a0 += v[u][0]; a1 += v[u][1]; }
+        }
+        for (; r < R; r += step) { a0 += to_f32(g[r * C + col]); a1 += to_f32(g[r * C + col + 1]); }
+    }
+    red[w][lane * 2] = a0; red[w][lane * 2 + 1] = a1;
+    __syncthreads();
+    const int t = threadIdx.x, c = blockIdx.x * 128 + t;
+    float s = 0.f;
+    if (t < 128) s = (red[0][t] + red[1][t]) + (red[2][t] + red[3][t]);
+    if (gridDim.y == 1) {
+        if (t < 128 && c < C) out[c] = s;
+        return;
+    }
+    if (t < 128 && c < C) part[(long)blockIdx.y * C + c] = s;
+    __threadfence();
+    __syncthreads();
+    if (t == 0) last = atomicAdd(&counter[blockIdx.x], 1u) == gridDim.y - 1;
+    __syncthreads();
+    if (!last) return;
+    __threadfence();
+    if (t < 128 && c < C) {
+        float tot = 0.f;
+        for (int y = 0; y < (int)gridDim.y; ++y) tot += part[(long)y * C + c];
+        out[c] = tot;
+    }
+    if (t == 0) counter[blockIdx.x] = 0u;
+}
+constexpr int COLSUM_SLICES = 16;
+
 int g_red_blocks = []() { const char* e = getenv("PASSION_RED_BLOCKS"); return e && atoi(e) > 0 ? atoi(e) : 512; }();
 inline int vgrid(long V) { return (int)hmin((V + 255) / 256, 2048); }
 // reductions end with one atomic per block per scalar on a handful of addresses: same-address atomics serialise
@@ -637,6 +693,27 @@ extern "C" int passion_proto_bwd(const void* fs, const void* ft, int dtype, cons
         LAUNCH_RET();
         hipLaunchKernelGGL(proto_bwd2_kernel<bf16_t>, grid2, dim3(256), 0, st, target, (long)V, work, (bf16_t*)dfs, Cf);
     } else
+        return -1007;
+    LAUNCH_RET();
+    return 0;
+}
+
+
+extern "C" int64_t passion_colsum_work_floats(int C) { return (int64_t)((C + 127) / 128 + 3) / 4 * 4 + (int64_t)COLSUM_SLICES * C; }
+extern "C" int passion_colsum(const void* g, int dtype, int64_t R, int C, float* out, float* work, void* stream) {
+    if (C <= 0 || (C & 1)) return -1014;
+    hipStream_t st = (hipStream_t)stream;
+    const int nbx = (C + 127) / 128;
+    // enough row slices to put ~2 blocks on every CU, at least 16 rows per wave
+    int ny = (int)hmin((long)COLSUM_SLICES, hmax(1L, hmin((long)(512 + nbx - 1) / nbx, R / 64)));
+    unsigned* counter = (unsigned*)work;
+    float* part = work + (nbx + 3) / 4 * 4;
+    if (ny > 1) HIP_RET(hipMemsetAsync(counter, 0, sizeof(unsigned) * (size_t)nbx, st));
+    if (dtype == PASSION_BF16)
+        hipLaunchKernelGGL(colsum_kernel<bf16_t>, dim3(nbx, ny), dim3(256), 0, st, (const bf16_t*)g, (long)R, C, out, part, counter);
+    else if (dtype == PASSION_F32)
+        hipLaunchKernelGGL(colsum_kernel<float>, dim3(nbx, ny), dim3(256), 0, st, (const float*)g, (long)R, C, out, part, counter);
+    else
         return -1007;
     LAUNCH_RET();
     return 0;

@@ -163,12 +163,16 @@ class Decoder_fuse(nn.Module):
 
 
 class Linear(nn.Linear):
-    """nn.Linear whose bf16 operand images are kept across calls (ops.bf16_param) when it runs under bf16 autocast"""
+    """nn.Linear of the token GEMMs: bf16 operand images kept across calls (ops.bf16_param) under bf16 autocast, and the bias
+    gradient from the library's fixed-order column sum (ops.LinearFn) in either precision"""
 
     def forward(self, x):
-        if self.weight.is_cuda and torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") == torch.bfloat16:
-            return F.linear(x, ops.bf16_param(self.weight), ops.bf16_param(self.bias) if self.bias is not None else None)
-        return F.linear(x, self.weight, self.bias)
+        if not self.weight.is_cuda:
+            return F.linear(x, self.weight, self.bias)
+        bf16 = torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") == torch.bfloat16
+        if bf16 and x.dtype != torch.bfloat16:
+            x = x.to(torch.bfloat16)
+        return ops.linear(x, self.weight, self.bias, bf16)
 
 
 class SelfAttention(nn.Module):
@@ -392,6 +396,9 @@ class Model(nn.Module):
             sts = [s_[i] for s_ in sbufs] if training else None
             if streams:
                 streams[i].wait_stream(main)
+                if training and _os.environ.get("PASSION_DBG_NOREC") is None:
+                    for b_ in bufs + sbufs:              # allocated on the main stream, written and (backward) read on this one
+                        b_.record_stream(streams[i])
                 with torch.cuda.stream(streams[i]):
                     encs[i] = getattr(self, f"{m}_encoder")(xin, i, mask if idt else None, dt, outs, sts)
                     for f in encs[i]:                    # consumed by work on the main stream: tell the allocator, or the

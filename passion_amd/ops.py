@@ -7,6 +7,7 @@ hand-written HIP kernel, and raises if the library or a GPU tensor is missing.
 from ctypes import byref, c_void_p
 
 import torch
+import torch.nn.functional as F
 
 from . import _lib as L
 
@@ -154,6 +155,53 @@ def bf16_param(p):
     if ent[1] is None or ent[2] != (p.data_ptr(), p._version):
         recast_stale()
     return _CastGradFn.apply(p, ent[1])
+
+
+class LinearFn(torch.autograd.Function):
+    """y = x W^T + b for the token GEMMs (reference mmformer.py nn.Linear): the GEMMs stay on torch (hipBLASLt),
+    the bias gradient is the library's fixed-order column sum (passion_colsum) instead of torch's `grad.sum(0)`, whose reduce
+    kernel does not repeat -- and drops contributions -- while the encoders' side streams keep the GPU busy
+    (tools/linear_bias_determinism.py).  w / b are the operands in the compute dtype (bf16 images or the f32 parameters);
+    the bias gradient comes back in f32."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, bias_param):
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = b is not None
+        return F.linear(x, w, b)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        g2 = g.reshape(-1, g.shape[-1])
+        if not g2.is_contiguous():
+            g2 = g2.contiguous()
+        x2 = x.reshape(-1, x.shape[-1])
+        dx = torch.mm(g2, w).view(x.shape) if ctx.needs_input_grad[0] else None
+        dw = torch.mm(g2.t(), x2) if ctx.needs_input_grad[1] else None
+        db = colsum(g2) if ctx.has_bias and ctx.needs_input_grad[3] else None
+        return dx, dw, None, db
+
+
+def colsum(g2):
+    """f32 column sums of a contiguous [R][C] f32 / bf16 matrix, fixed summation order"""
+    L.require_gpu(g2)
+    R, C = g2.shape
+    lib = L.load()
+    out = torch.empty(C, dtype=torch.float32, device=g2.device)
+    work = torch.empty(lib.passion_colsum_work_floats(C), dtype=torch.float32, device=g2.device)
+    L.check(lib.passion_colsum(_p(g2), L.dtype_code(g2.dtype), R, C, _p(out), _p(work), L.stream_ptr()), "passion_colsum")
+    return out
+
+
+def linear(x, weight, bias, bf16):
+    """nn.Linear forward for a token GEMM: bf16 -> the kept bf16 operand images (bf16_param), else the f32 parameters"""
+    if bf16:
+        w = bf16_param(weight)
+        b = bf16_param(bias).detach() if bias is not None else None
+    else:
+        w, b = weight, (bias.detach() if bias is not None else None)
+    return LinearFn.apply(x, w, b, bias)
 
 
 def pack_weight(weight, cache=None):

@@ -534,3 +534,42 @@ def test_conv_march_backward_is_bitwise_reproducible():
         outs.append((xd.grad.clone(), w.grad.clone()))
     assert all(torch.equal(outs[0][0], o[0]) for o in outs[1:])
     assert all(torch.equal(outs[0][1], o[1]) for o in outs[1:])
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32], ids=["bf16", "f32"])
+@pytest.mark.parametrize("R,C", [(1280, 4096), (256, 512), (67, 130), (5, 2), (2560, 1536)])
+def test_colsum_bias_gradient(R, C, dtype):
+    """passion_colsum (the bias gradient of the token GEMMs) against a float64 column sum, and bit-identical over repeats
+    while a second stream keeps the GPU busy (torch's own sum is not, on this stack: tools/linear_bias_determinism.py)"""
+    dev = torch.device("cuda:0")
+    g = (torch.randn(R, C, device=dev, generator=torch.Generator(dev).manual_seed(R + C)) * 0.1).to(dtype)
+    want = g.double().sum(0)
+    got = ops.colsum(g)
+    assert got.dtype == torch.float32 and got.shape == (C,)
+    assert float((got.double() - want).abs().max()) <= 2e-6 * float(g.double().abs().sum(0).max()) + 1e-9
+    side = torch.cuda.Stream()
+    a = torch.randn(1024, 1024, device=dev, dtype=torch.bfloat16)
+    for it in range(50):
+        if it % 4 == 0:
+            with torch.cuda.stream(side):
+                a @ a
+        assert torch.equal(ops.colsum(g), got)
+    torch.cuda.synchronize()
+
+
+def test_linear_fn_matches_torch_linear():
+    """ops.linear (hipBLASLt GEMMs + passion_colsum bias gradient) against torch's F.linear autograd, f32"""
+    dev = torch.device("cuda:0")
+    gen = torch.Generator(dev).manual_seed(3)
+    x = torch.randn(3, 40, 64, device=dev, generator=gen, requires_grad=True)
+    w = (torch.randn(96, 64, device=dev, generator=gen) * 0.1).requires_grad_(True)
+    b = torch.randn(96, device=dev, generator=gen).requires_grad_(True)
+    gy = torch.randn(3, 40, 96, device=dev, generator=gen)
+    y = ops.linear(x, w, b, False)
+    y.backward(gy)
+    got = (y.detach().clone(), x.grad.clone(), w.grad.clone(), b.grad.clone())
+    x.grad = w.grad = b.grad = None
+    y2 = torch.nn.functional.linear(x, w, b)
+    y2.backward(gy)
+    for a_, b_ in zip(got, (y2.detach(), x.grad, w.grad, b.grad)):
+        assert float((a_ - b_).abs().max()) <= 1e-4 * float(b_.abs().max())
