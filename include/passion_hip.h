@@ -89,6 +89,13 @@ int passion_conv_pack_weights(int n, const float* const* weights, const int* Cin
 /* y[b][vo][co] = bias[co] + residual + sum_{tap,ci} W * act(x_padded).  residual may be NULL. */
 int passion_conv3d_fwd(const passion_conv_desc_t* d, const float* packed, const float* bias,
                        const void* residual, void* y, void* stream);
+/* The same, and the InstanceNorm statistics of y as well (the nn.InstanceNorm3d of the NEXT general_conv3d_prenorm,
+ * code/models/blocks.py:313, 18): stats f32 [B][Cout][2] = (mean, 1/sqrt(biased var + eps)) over the output volume, as
+ * passion_instnorm_stats(y) would give.  The bf16 stride-1 kernels accumulate the sums in their epilogue (no extra pass over
+ * y, no extra launch); every other case runs the statistics kernels after the conv.  Scratch comes from the library's
+ * per-stream region. */
+int passion_conv3d_fwd_stats(const passion_conv_desc_t* d, const float* packed, const float* bias,
+                             const void* residual, void* y, float* stats, float eps, void* stream);
 /* Backward of the whole block.  dy: [B][Vout][Cout].
  *  dweight: f32 [Cout][Cin][k^3] and dbias f32 [Cout] are OVERWRITTEN (either may be NULL).  They are produced
  *  without atomics: every workgroup stores its partial sums into its own slot of a slab inside `scratch`,

@@ -46,6 +46,8 @@ SIGNATURES = {
     "passion_conv_pack_weights": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "passion_conv3d_fwd": (c_int, [POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p,
                                    c_void_p]),
+    "passion_conv3d_fwd_stats": (c_int, [POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p,
+                                         c_void_p, c_float, c_void_p]),
     "passion_conv3d_bwd": (c_int, [POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p,
                                    c_void_p, c_void_p]),
     "passion_conv3d_bwd_phase": (c_int, [POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float,
@@ -180,7 +182,7 @@ def host():
     spec.loader.exec_module(mod)
     addr = lambda name: ctypes.cast(getattr(lib, name), c_void_p).value
     mod.bind(addr("passion_conv3d_fwd"), addr("passion_conv3d_bwd"), addr("passion_conv_bwd_scratch_floats"),
-             addr("passion_instnorm_stats"), addr("passion_instnorm_scratch_doubles"))
+             addr("passion_instnorm_stats"), addr("passion_instnorm_scratch_doubles"), addr("passion_conv3d_fwd_stats"))
     _host = mod
     return mod
 

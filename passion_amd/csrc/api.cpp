@@ -50,6 +50,61 @@ void passion_prof_tag(const char* fmt, ...) {
 
 extern "C" int passion_abi_version(void) { return 1; }
 
+// ---- per-stream scratch (conv_common.h): tickets (kept zero by the kernels that use them) + uninitialised slots
+#include "conv_common.h"
+namespace {
+struct StreamScratch { hipStream_t st; int dev; char *zero, *plain; size_t zero_sz, plain_sz; };
+std::vector<StreamScratch> g_scratch;
+std::mutex g_scratch_mu;
+}  // namespace
+namespace pconv {
+int stream_scratch(hipStream_t st, size_t zero_bytes, size_t plain_bytes, void** zero, void** plain) {
+    std::lock_guard<std::mutex> lk(g_scratch_mu);
+    int dev = 0;
+    HIP_RET(hipGetDevice(&dev));
+    StreamScratch* s = nullptr;
+    for (auto& e : g_scratch) if (e.st == st && e.dev == dev) { s = &e; break; }
+    if (!s) {
+        g_scratch.push_back(StreamScratch{st, dev, nullptr, nullptr, 0, 0});
+        s = &g_scratch.back();
+    }
+    if (zero_bytes > s->zero_sz) {
+        const size_t want = zero_bytes < (64u << 10) ? (64u << 10) : zero_bytes * 2;
+        if (s->zero) { HIP_RET(hipStreamSynchronize(st)); HIP_RET(hipFree(s->zero)); s->zero = nullptr; s->zero_sz = 0; }
+        HIP_RET(hipMalloc(reinterpret_cast<void**>(&s->zero), want));
+        HIP_RET(hipMemsetAsync(s->zero, 0, want, st));      // ordered before the first kernel that uses it
+        s->zero_sz = want;
+    }
+    if (plain_bytes > s->plain_sz) {
+        const size_t want = plain_bytes < (4u << 20) ? (4u << 20) : plain_bytes * 2;
+        if (s->plain) { HIP_RET(hipStreamSynchronize(st)); HIP_RET(hipFree(s->plain)); s->plain = nullptr; s->plain_sz = 0; }
+        HIP_RET(hipMalloc(reinterpret_cast<void**>(&s->plain), want));
+        s->plain_sz = want;
+    }
+    if (zero) *zero = s->zero;
+    if (plain) *plain = s->plain;
+    return 0;
+}
+
+int fwd_stats_setup(ConvK& k, int nwg, int ny, hipStream_t st) {
+    FwdStats& f = k.fst;
+    f.nwg = nwg; f.ny = ny; f.ngroup = (nwg + STATS_GROUP - 1) / STATS_GROUP;
+    const size_t nv = (size_t)k.Cout * 2;
+    const size_t slots = (size_t)k.B * nwg * nv * sizeof(float), gsl = (size_t)k.B * f.ngroup * nv * sizeof(double);
+    const size_t gs_off = (slots + 255) / 256 * 256;
+    void *zero = nullptr, *plain = nullptr;
+    const int rc = stream_scratch(st, (size_t)k.B * (f.ngroup + 1) * sizeof(unsigned), gs_off + gsl, &zero, &plain);
+    if (rc) return rc;
+    f.tickets = static_cast<unsigned*>(zero);
+    f.slots = static_cast<float*>(plain);
+    f.gslots = reinterpret_cast<double*>(static_cast<char*>(plain) + gs_off);
+    f.eps = k.fst_eps;
+    f.inv_v = 1.0 / ((double)k.Do * k.Ho * k.Wo);
+    f.stats = k.fst_want;
+    return 0;
+}
+}  // namespace pconv
+
 // run-time A/B switches (the same ones the environment sets at load time); returns the previous value, -1 = unknown name
 extern int g_passion_force_f32_mfma;
 namespace pconv { extern int g_conv_merge, g_wgrad_wide, g_conv_dbg, g_conv_target, g_conv_lean, g_conv_padout, g_wgrad_fork, g_conv_blockdiag, g_conv_march; }

@@ -86,6 +86,15 @@ __device__ __forceinline__ float group16_sum(float v) {
     return v;
 }
 
+// Hand-over of a few words between workgroups of one kernel (per-workgroup partial sums -> the workgroup that arrives last):
+// RELAXED ATOMIC stores / loads at agent scope (sc1: coherent across the XCDs' L2s) + a ticket counter, ordered by the
+// s_waitcnt of __syncthreads().  NOT __threadfence(): an agent-scope release fence writes back every dirty line of the XCD's L2
+// (buffer_wbl2) -- at the end of a conv that just stored its output that cost 50 us per launch (128^3, 8 channels).
+__device__ __forceinline__ void st_agent(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_agent(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float ld_agent(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ double ld_agent(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
 __device__ __forceinline__ int reflect_idx(int p, int n) {
     // torch 'reflect' padding (no edge repeat); valid for |overshoot| < n.
     if (p < 0) p = -p;

@@ -575,6 +575,8 @@ int fill_params(const passion_conv_desc_t* d, ConvK& k) {
     if (!d) return -1001;
     k.dbg = 0;
     k.sums_fixed = 0; k.sums_float_only = 0;
+    k.fst = FwdStats{nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0.f, 0.0};
+    k.fst_want = nullptr; k.fst_eps = 0.f;
     k.bd_rows = 0; k.bd_k8 = 0;
     k.y_f32 = 0;
     if (d->ksize != 1 && d->ksize != 3) return -1002;
@@ -871,38 +873,59 @@ extern "C" int passion_conv_pack_weights(int n, const float* const* weights, con
     return 0;
 }
 
-extern "C" int passion_conv3d_fwd(const passion_conv_desc_t* d, const float* packed, const float* bias,
-                                  const void* residual, void* y, void* stream) {
+static int conv3d_fwd_impl(const passion_conv_desc_t* d, const float* packed, const float* bias, const void* residual, void* y,
+                           float* stats_out, float eps, void* stream) {
     ConvK k;
     int rc = fill_params(d, k);
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
     k.wpack = packed; k.Mpad = pad16(k.Cout); k.bias = bias; k.residual = residual; k.y = y;
+    k.fst_want = stats_out; k.fst_eps = eps;
     k.tilesD = cdiv(k.Do, TD); k.tilesH = cdiv(k.Ho, TH); k.tilesW = cdiv(k.Wo, TW);
     const int mtiles = k.Mpad / 16;
     const int xs = d->x_dtype == PASSION_BF16 ? 2 : 4, ys = d->y_dtype == PASSION_BF16 ? 2 : 4;
     const int nt = d->ksize * d->ksize * d->ksize;
-    ProfScope prof(d->ksize == 3 ? 0 : 1, conv_bytes(k, xs, ys) + (double)nt * k.Cin * k.Cout * 4,
-                   2.0 * k.B * k.Do * k.Ho * k.Wo * (double)k.Cout * k.Cin * nt, st);
-    if (d->x_dtype == PASSION_F32 && d->y_dtype == PASSION_F32)
-        rc = launch_conv_geo<float, float, 0>(k, d->ksize, d->stride, mtiles, st);
-    else if (d->x_dtype == PASSION_BF16 && d->y_dtype == PASSION_BF16) {
-        if (bf16_eligible(k, false) && !g_passion_force_f32_mfma)
-            rc = launch_conv_bf16(k, d->ksize, d->stride, false, packed + f32_pack_floats(k.Cin, k.Cout, nt), st);
-        else
-            rc = launch_conv_geo<bf16_t, bf16_t, 0>(k, d->ksize, d->stride, mtiles, st);
-    } else if (d->x_dtype == PASSION_BF16 && d->y_dtype == PASSION_F32) {
-        rc = 1;
-        if (lean_f32_head(k, d) && !residual) {
-            k.y_f32 = 1;
-            rc = launch_conv_lean(k, d->ksize, d->stride, 0, packed + f32_pack_floats(k.Cin, k.Cout, nt), st);
-            if (rc > 0) k.y_f32 = 0;
+    {
+        ProfScope prof(d->ksize == 3 ? 0 : 1, conv_bytes(k, xs, ys) + (double)nt * k.Cin * k.Cout * 4,
+                       2.0 * k.B * k.Do * k.Ho * k.Wo * (double)k.Cout * k.Cin * nt, st);
+        if (d->x_dtype == PASSION_F32 && d->y_dtype == PASSION_F32)
+            rc = launch_conv_geo<float, float, 0>(k, d->ksize, d->stride, mtiles, st);
+        else if (d->x_dtype == PASSION_BF16 && d->y_dtype == PASSION_BF16) {
+            if (bf16_eligible(k, false) && !g_passion_force_f32_mfma)
+                rc = launch_conv_bf16(k, d->ksize, d->stride, false, packed + f32_pack_floats(k.Cin, k.Cout, nt), st);
+            else
+                rc = launch_conv_geo<bf16_t, bf16_t, 0>(k, d->ksize, d->stride, mtiles, st);
+        } else if (d->x_dtype == PASSION_BF16 && d->y_dtype == PASSION_F32) {
+            rc = 1;
+            if (lean_f32_head(k, d) && !residual) {
+                k.y_f32 = 1;
+                rc = launch_conv_lean(k, d->ksize, d->stride, 0, packed + f32_pack_floats(k.Cin, k.Cout, nt), st);
+                if (rc > 0) k.y_f32 = 0;
+            }
+            if (rc > 0) rc = launch_conv_geo<bf16_t, float, 0>(k, d->ksize, d->stride, mtiles, st);
         }
-        if (rc > 0) rc = launch_conv_geo<bf16_t, float, 0>(k, d->ksize, d->stride, mtiles, st);
+        else
+            rc = -1007;
     }
-    else
-        rc = -1007;
-    return rc;
+    if (rc || !stats_out || k.fst.stats) return rc;      // k.fst.stats: the conv kernel itself left the statistics
+    // kernels without the fused epilogue (f32 storage, stride 2, ragged bricks, the general bf16 kernel): the statistics
+    // kernels of norm.hip over y, scratch from the stream's region
+    const int64_t V = (int64_t)k.Do * k.Ho * k.Wo;
+    void* plain = nullptr;
+    rc = stream_scratch(st, 0, (size_t)passion_instnorm_scratch_doubles(k.B, V, k.Cout) * sizeof(double), nullptr, &plain);
+    if (rc) return rc;
+    return passion_instnorm_stats(y, d->y_dtype, k.B, V, k.Cout, V * k.Cout, eps, static_cast<double*>(plain), stats_out, stream);
+}
+
+extern "C" int passion_conv3d_fwd(const passion_conv_desc_t* d, const float* packed, const float* bias,
+                                  const void* residual, void* y, void* stream) {
+    return conv3d_fwd_impl(d, packed, bias, residual, y, nullptr, 0.f, stream);
+}
+
+extern "C" int passion_conv3d_fwd_stats(const passion_conv_desc_t* d, const float* packed, const float* bias,
+                                        const void* residual, void* y, float* stats, float eps, void* stream) {
+    if (!stats) return -1015;
+    return conv3d_fwd_impl(d, packed, bias, residual, y, stats, eps, stream);
 }
 
 // wgrad and dgrad of one conv only share their inputs (x, dY): the weight-gradient kernels + fold go to a companion stream

@@ -26,6 +26,22 @@ struct SegD {
     __host__ __device__ int bsrc(int b) const { return bmod > 0 ? b % bmod : b; }
 };
 
+// InstanceNorm statistics of the conv's OUTPUT produced by the forward kernel itself (marching / lean bf16 kernels): every
+// workgroup leaves the (sum, sum of squares) of the bf16 values it stored in its own slot, groups of STATS_GROUP workgroups
+// are folded by whichever of them arrives last (ticket), the group sums by the group that arrives last -- fixed order both
+// times, so the statistics repeat bit for bit -- and that workgroup writes (mean, rstd).  Replaces the separate statistics
+// launches (one or two per conv) and their pass over y.
+constexpr int STATS_GROUP = 16;
+struct FwdStats {
+    float* stats;          // [B][Cout][2] (mean, rstd); nullptr: not requested / not fused
+    float* slots;          // [B][nwg][Cout][2] f32, plain stores (scratch)
+    double* gslots;        // [B][ngroup][Cout][2] (scratch)
+    unsigned* tickets;     // [B][ngroup + 1]: zero before the launch, left at zero
+    int nwg, ngroup, ny;   // workgroups per sample along x, groups of STATS_GROUP, workgroups per x position (row-tile groups)
+    float eps;
+    double inv_v;
+};
+
 struct ConvK {
     int B, Di, Hi, Wi, Do, Ho, Wo;
     int pad_mode, nseg, Cin, Cout;
@@ -49,7 +65,17 @@ struct ConvK {
     int bd_rows, bd_k8;    // lean dgrad with block-diagonal weights (batched passes summed first, conv.hip): K block gb = (segment
                            // gb / bd_k8, block gb % bd_k8 of the real Cout); rows of another segment (bd_rows each) read zero weights
     int dbg;               // developer timing switch (PASSION_CONV_DBG): bit0 skip staging, bit1 skip MFMA loop, bit2 skip epilogue
+    FwdStats fst;          // forward: statistics of y from the kernel's epilogue (fst.stats != nullptr)
+    float* fst_want;       // forward: the caller wants statistics of y here (a launcher that fuses them moves it to fst.stats)
+    float fst_eps;
 };
+
+// per-stream scratch of the library (api.cpp): `zero` bytes that are zero at every kernel start (kernels that use them leave
+// them zero: tickets), `plain` bytes of uninitialised scratch.  Kernels of one stream run one after the other, so one region
+// per stream is enough; it grows on demand (synchronising that stream once).
+int stream_scratch(hipStream_t st, size_t zero_bytes, size_t plain_bytes, void** zero, void** plain);
+// sets up k.fst for a launch of nwg x ny workgroups per sample (0 = ok)
+int fwd_stats_setup(ConvK& k, int nwg, int ny, hipStream_t st);
 
 __host__ __device__ inline int pad16(int c) { return (c + 15) / 16 * 16; }
 __host__ __device__ inline int pad8(int c) { return (c + 7) / 8 * 8; }
@@ -96,6 +122,75 @@ __device__ __forceinline__ void axis_tap(int a, int il, int i0, int Sin, int hi_
         t = hi_t; valid = (hi_t >= 0) && (i0 + il == Sin - 2); pos = hi_u - (i0 - HALO);
     }
     if (!valid) pos = 0;
+}
+
+
+// End of a forward kernel with fused statistics.  wsum: LDS, [rows][2] partial sums of this workgroup for channels
+// row0 .. row0 + rows - 1 of sample b (already combined over the workgroup's threads); wq: workgroup index inside the sample.
+__device__ __forceinline__ void fwd_stats_commit(const FwdStats& fs, int Cout, int b, int wq, int row0, int rows,
+                                                 const float* wsum, int tid) {
+    __shared__ int fst_flag;
+    const int NV = Cout * 2;
+    float* slot = fs.slots + ((long)b * fs.nwg + wq) * NV;
+    for (int i = tid; i < rows * 2; i += 256) {
+        const int c = row0 + (i >> 1);
+        if (c < Cout) st_agent(&slot[c * 2 + (i & 1)], wsum[i]);
+    }
+    __syncthreads();                                           // waits for the stores (vmcnt 0) of every thread: slot before ticket
+    const int grp = wq / STATS_GROUP, gsz = min(STATS_GROUP, fs.nwg - grp * STATS_GROUP);
+    unsigned* tk = fs.tickets + (long)b * (fs.ngroup + 1);
+    if (tid == 0) fst_flag = atomicAdd(&tk[grp], 1u) == (unsigned)(gsz * fs.ny - 1);
+    __syncthreads();
+    if (!fst_flag) return;
+    double* gs = fs.gslots + ((long)b * fs.ngroup + grp) * NV;
+    for (int i = tid; i < NV; i += 256) {
+        const float* s0 = fs.slots + ((long)b * fs.nwg + (long)grp * STATS_GROUP) * NV + i;
+        float v[STATS_GROUP];
+#pragma unroll
+        for (int u = 0; u < STATS_GROUP; ++u) v[u] = u < gsz ? ld_agent(&s0[(long)u * NV]) : 0.f;
+        double a = 0.0;
+#pragma unroll
+        for (int u = 0; u < STATS_GROUP; ++u) a += (double)v[u];
+        st_agent(&gs[i], a);
+    }
+    if (tid == 0) __hip_atomic_store(&tk[grp], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (tid == 0) fst_flag = atomicAdd(&tk[fs.ngroup], 1u) == (unsigned)(fs.ngroup - 1);
+    __syncthreads();
+    if (!fst_flag) return;
+    // the group sums: value v = (channel, moment) x SL slices of the groups per thread, slices combined through LDS in order
+    __shared__ double fst_part[256];
+    const int SL = NV <= 256 ? 256 / NV : 1;
+    for (int v0 = 0; v0 < NV; v0 += 256) {                     // one pass unless Cout > 128
+        const int v = v0 + tid % min(NV, 256), sl = tid / min(NV, 256);
+        double a = 0.0;
+        if (v < NV && sl < SL) {
+            const double* g0 = fs.gslots + (long)b * fs.ngroup * NV + v;
+            for (int gi = sl; gi < fs.ngroup; gi += SL) a += ld_agent(&g0[(long)gi * NV]);
+        }
+        __syncthreads();
+        fst_part[tid] = a;
+        __syncthreads();
+        const int c = (v0 >> 1) + tid;                         // thread c: both moments of channel c
+        if (tid < min(NV, 256) / 2 && c < Cout) {
+            double sm = 0.0, sq = 0.0;
+            for (int q = 0; q < SL; ++q) { sm += fst_part[q * min(NV, 256) + 2 * tid]; sq += fst_part[q * min(NV, 256) + 2 * tid + 1]; }
+            const double mean = sm * fs.inv_v;
+            double var = sq * fs.inv_v - mean * mean;
+            if (var < 0) var = 0;
+            fs.stats[((long)b * Cout + c) * 2 + 0] = (float)mean;
+            fs.stats[((long)b * Cout + c) * 2 + 1] = (float)(1.0 / sqrt(var + (double)fs.eps));
+        }
+    }
+    if (tid == 0) __hip_atomic_store(&tk[fs.ngroup], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// v -> the four bf16 values that get stored (packed) and what they read back as
+__device__ __forceinline__ void round4_bf16(const f32x4& v, unsigned (&packed)[2], float (&r)[4]) {
+    union { bf16_t h[4]; unsigned u[2]; } t;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { t.h[j] = (bf16_t)v[j]; r[j] = (float)t.h[j]; }
+    packed[0] = t.u[0]; packed[1] = t.u[1];
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -112,7 +112,7 @@ __device__ __forceinline__ void conv_lean_body(const ConvK& p) {
     char* lds = dyn_lds;                                   // [brick | block descriptors | weight fragments]
     BlkDesc* desc = reinterpret_cast<BlkDesc*>(dyn_lds + G::BRICK);
     bf16x8* wl0 = reinterpret_cast<bf16x8*>(dyn_lds + G::BRICK + DESC_BYTES);
-    __shared__ float lsum[DG ? 4 * MT * 16 * 2 : 4];        // [wave][row][2]
+    __shared__ float lsum[4 * MT * 16 * 2 + (DG ? 0 : MT * 16 * 2)];        // [wave][row][2] (+ forward: the workgroup's totals)
     __shared__ EpiDesc edesc[DG ? MT * 4 : 1];
     __shared__ unsigned short mlist[128];
     __shared__ int mcnt[4];
@@ -419,11 +419,13 @@ __device__ __forceinline__ void conv_lean_body(const ConvK& p) {
     f32x4 acc[MT][4];
     int nmirror = 0;
     // dgrad: InstanceNorm-backward sums (sum g, sum g * x_hat) stay in registers over all bricks of the workgroup
-    float s1[DG ? MT : 1][4], s2v[DG ? MT : 1][4];
+    // forward with fused statistics (p.fst.stats): (sum y, sum y^2) of the stored bf16 values, likewise
+    float s1[MT][4], s2v[MT][4];
 #pragma unroll
-    for (int mt = 0; mt < (DG ? MT : 1); ++mt)
+    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int j = 0; j < 4; ++j) { s1[mt][j] = 0.f; s2v[mt][j] = 0.f; }
+    const bool fstats = !DG && p.fst.stats != nullptr;     // the launcher grants it only when every brick is whole
     uint2 xpre[4];                                // MT == 1: x of the four output voxels, fetched ahead of the MFMA loop
 
     for (int step = 0; step < nsteps; ++step) {
@@ -663,7 +665,16 @@ __device__ __forceinline__ void conv_lean_body(const ConvK& p) {
                         f32x4 v = acc[mt][nt] + biasv[mt];
                         if (p.y_f32) { *reinterpret_cast<f32x4*>(yf + e) = v; continue; }   // logit head
                         if (res) v += load4(res + e);
-                        store4(y + e, v);
+                        if (fstats) {                       // workgroup-uniform
+                            unsigned pk[2];
+                            float rb[4];
+                            round4_bf16(v, pk, rb);
+                            *reinterpret_cast<u32x2*>(y + e) = (u32x2){pk[0], pk[1]};
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) { s1[mt][j] += rb[j]; s2v[mt][j] = __builtin_fmaf(rb[j], rb[j], s2v[mt][j]); }
+                        } else {
+                            store4(y + e, v);
+                        }
                     }
                 }
             } else if (p.y_f32) {
@@ -675,6 +686,30 @@ __device__ __forceinline__ void conv_lean_body(const ConvK& p) {
         chunk = n_chunk; tw_ = n_tw; th_ = n_th; td_ = n_td;
     }
 
+    if (fstats) {
+        // statistics of y: 16 voxel lanes (shuffles) -> 4 waves (LDS, fixed order) -> the workgroup's slot -> ticket fold
+        __syncthreads();
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float a1 = group16_sum(s1[mt][j]), a2 = group16_sum(s2v[mt][j]);
+                if (n == 0) {
+                    lsum[((wv * MT + mt) * 16 + g * 4 + j) * 2 + 0] = a1;
+                    lsum[((wv * MT + mt) * 16 + g * 4 + j) * 2 + 1] = a2;
+                }
+            }
+        }
+        __syncthreads();
+        float* wsum = lsum + 4 * MT * 16 * 2;
+        for (int i = tid; i < MT * 16 * 2; i += 256) {
+            const int row = i >> 1, k2 = i & 1;
+            wsum[i] = ((lsum[(0 * MT * 16 + row) * 2 + k2] + lsum[(1 * MT * 16 + row) * 2 + k2]) + lsum[(2 * MT * 16 + row) * 2 + k2]) +
+                      lsum[(3 * MT * 16 + row) * 2 + k2];
+        }
+        __syncthreads();
+        fwd_stats_commit(p.fst, p.Cout, b, wq, mg * MT * 16, MT * 16, wsum, tid);
+    }
     if (DG) {
         // one reduction per workgroup: 16 voxel lanes (shuffles) -> 4 waves (LDS slots, summed in a fixed order) -> one replica of
         // the global sums.  The global add is a 64-bit INTEGER atomic on a 2^-40 fixed-point image of the partial sum (sums_fixed):
@@ -740,6 +775,11 @@ int launch_lean_one(ConvK& k, int K8, int gy, hipStream_t st) {
     per = (int)hmin(hmin(per, tiles_per_b), 256);      // 256 = entries of the workgroup's brick table
     k.per = per;
     const int gx = k.B * ((tiles_per_b + per - 1) / per);
+    k.fst.stats = nullptr;
+    if (MODE == 0 && k.fst_want && !k.y_f32 && k.Do % TD == 0 && k.Ho % TH == 0 && k.Wo % TW == 0) {
+        const int rc = fwd_stats_setup(k, (tiles_per_b + per - 1) / per, gy, st);      // whole bricks only: the ragged epilogue does not count
+        if (rc) return rc < 0 ? rc : -rc;
+    }
     static int attr_bytes = 0;        // > 64 KB of dynamic LDS has to be granted per kernel
     if (bytes > attr_bytes) {
         HIP_RET(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_lean_kernel<KS, MT, MODE, CKB, S>),

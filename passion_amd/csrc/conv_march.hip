@@ -85,7 +85,7 @@ __global__ __launch_bounds__(256) void conv_march_kernel(ConvK p, MarchP mp) {
     constexpr bool DG = (MODE == 2);
     constexpr int NIT = G::NIT, NSTEP = G::NSTEP, NTW = G::NTW, VS = G::VS, RSB = G::RSB, PLANE = G::PLANE;
     extern __shared__ __attribute__((aligned(16))) char lds[];            // [NSLOT planes]
-    __shared__ float lsum[DG ? 4 * 16 * 2 : 4];
+    __shared__ float lsum[4 * 16 * 2 + 32];               // [wave][row][2] partial sums, then the workgroup's 16 x 2 totals
 
     const int tid = threadIdx.x, lane = tid & 63, n = lane & 15, g = (lane >> 4) & 3;
     const int wv = rfl(tid >> 6);
@@ -361,6 +361,7 @@ __global__ __launch_bounds__(256) void conv_march_kernel(ConvK p, MarchP mp) {
         for (int t = 0; t < TT; ++t) dst[t] = gload<u32x2>(ebase + (pb + eel[t]));
     };
     float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2v[4] = {0.f, 0.f, 0.f, 0.f};
+    const bool fstats = !DG && p.fst.stats != nullptr;
 
     // output plane jout (position dlo + jout) from ring planes jout, jout + 1, jout + 2
     const int lanebase = (r0 + 2) * RSB + (n + 2) * VS;        // main tile t: + (t / NTW) * RSB + (t % NTW) * 16 * VS (an immediate)
@@ -410,7 +411,19 @@ __global__ __launch_bounds__(256) void conv_march_kernel(ConvK p, MarchP mp) {
                     v[0] += __uint_as_float(eo[t].x << 16); v[1] += __uint_as_float(eo[t].x & 0xffff0000u);
                     v[2] += __uint_as_float(eo[t].y << 16); v[3] += __uint_as_float(eo[t].y & 0xffff0000u);
                 }
-                if (valid && row_ok) store4(reinterpret_cast<bf16_t*>(yb8 + obyte), v);
+                unsigned pk[2];
+                float rb[4];
+                round4_bf16(v, pk, rb);
+                if (valid && row_ok) *reinterpret_cast<u32x2*>(yb8 + obyte) = (u32x2){pk[0], pk[1]};
+                if (fstats) {                                  // statistics of what was stored (workgroup-uniform branch)
+                    const float vf = valid ? 1.f : 0.f;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float r = rb[j] * vf;
+                        s1[j] += r;
+                        s2v[j] = __builtin_fmaf(r, r, s2v[j]);
+                    }
+                }
             } else {
                 const u32x2 xr = eo[t];
                 const float xv[4] = {__uint_as_float(xr.x << 16), __uint_as_float(xr.x & 0xffff0000u),
@@ -457,8 +470,9 @@ __global__ __launch_bounds__(256) void conv_march_kernel(ConvK p, MarchP mp) {
         }
     }
 
-    if (DG) {
-        // InstanceNorm-backward sums: 16 voxel lanes (shuffles) -> 4 waves (LDS, fixed order) -> this workgroup's own slot
+    if (DG || fstats) {
+        // InstanceNorm-backward sums (MODE 2) / statistics of y (MODE 0): 16 voxel lanes (shuffles) -> 4 waves (LDS, fixed
+        // order) -> this workgroup's own slot
         __syncthreads();
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -471,11 +485,19 @@ __global__ __launch_bounds__(256) void conv_march_kernel(ConvK p, MarchP mp) {
         __syncthreads();
         if (tid < 32) {
             const int c = tid >> 1, k2 = tid & 1;
-            if (c < p.Cin) {
-                const float t = ((lsum[(0 * 16 + c) * 2 + k2] + lsum[(1 * 16 + c) * 2 + k2]) + lsum[(2 * 16 + c) * 2 + k2]) + lsum[(3 * 16 + c) * 2 + k2];
-                float* rs = p.sums + (long)(bx % mp.nwg_b) * p.B * p.Cin * 2;
-                rs[((long)b * p.Cin + c) * 2 + k2] = t;
+            const float t = ((lsum[(0 * 16 + c) * 2 + k2] + lsum[(1 * 16 + c) * 2 + k2]) + lsum[(2 * 16 + c) * 2 + k2]) + lsum[(3 * 16 + c) * 2 + k2];
+            if (DG) {
+                if (c < p.Cin) {
+                    float* rs = p.sums + (long)(bx % mp.nwg_b) * p.B * p.Cin * 2;
+                    rs[((long)b * p.Cin + c) * 2 + k2] = t;
+                }
+            } else {
+                lsum[4 * 16 * 2 + tid] = t;
             }
+        }
+        if (!DG) {
+            __syncthreads();
+            fwd_stats_commit(p.fst, p.Cout, b, bx % mp.nwg_b, 0, 16, lsum + 4 * 16 * 2, tid);
         }
     }
 }
@@ -513,6 +535,10 @@ int launch_march_one(ConvK& k, hipStream_t st) {
     if (MODE == 2) {
         if (mp.nwg_b > SUMS_SLOTS) return 1;
         k.sums_rep = mp.nwg_b;
+    }
+    if (MODE == 0 && k.fst_want) {
+        const int rc = fwd_stats_setup(k, mp.nwg_b, 1, st);
+        if (rc) return rc < 0 ? rc : -rc;
     }
     if (MODE == 0 && k.residual) return launch_march_res<NB, TW, MODE, true>(k, mp, st);
     return launch_march_res<NB, TW, MODE, false>(k, mp, st);

@@ -21,6 +21,7 @@ using OptT = std::optional<at::Tensor>;
 
 struct Abi {
     decltype(&passion_conv3d_fwd) conv_fwd = nullptr;
+    decltype(&passion_conv3d_fwd_stats) conv_fwd_stats = nullptr;
     decltype(&passion_conv3d_bwd) conv_bwd = nullptr;
     decltype(&passion_conv_bwd_scratch_floats) conv_bwd_scratch = nullptr;
     decltype(&passion_instnorm_stats) stats = nullptr;
@@ -52,6 +53,9 @@ struct ConvCfg {
     std::vector<OptT> stats, masks;
     at::Tensor packed;
     OptT out;
+    bool want_stats = false;     // also return the InstanceNorm statistics of y (fused into the conv kernel where it can be)
+    OptT stats_out;              // ... written into this preallocated (B, Cout, 2) f32 slot
+    double eps = 1e-5;
 };
 
 void fill_desc(passion_conv_desc_t& d, const std::vector<int64_t>& geo, const std::vector<int64_t>& seg, double slope,
@@ -93,8 +97,8 @@ std::vector<OptT> from_list(const c10::IValue& iv) {
 }
 
 struct ConvBlockNode : public torch::autograd::Function<ConvBlockNode> {
-    static at::Tensor forward(AutogradContext* ctx, const at::Tensor& weight, const OptT& bias, const OptT& residual,
-                              at::TensorList xs, ConvCfg cfg) {
+    static variable_list forward(AutogradContext* ctx, const at::Tensor& weight, const OptT& bias, const OptT& residual,
+                                 at::TensorList xs, ConvCfg cfg) {
         need_gpu(weight);
         for (const at::Tensor& x : xs) need_gpu(x);
         const int64_t Cout = weight.size(0), ks = cfg.geo[4], stride = cfg.geo[5], pad = ks / 2;
@@ -110,9 +114,19 @@ struct ConvBlockNode : public torch::autograd::Function<ConvBlockNode> {
         if (bias) TORCH_CHECK(bias->scalar_type() == at::kFloat && bias->is_contiguous(), "conv_block: bias must be f32");
         passion_conv_desc_t d;
         fill_desc(d, cfg.geo, cfg.seg, cfg.slope, cfg.stats, cfg.masks, xs, nullptr, Cout);
-        check(g.conv_fwd(&d, cfg.packed.data_ptr<float>(), bias ? bias->data_ptr<float>() : nullptr,
-                         residual ? residual->data_ptr() : nullptr, y.data_ptr(), cur_stream()),
-              "passion_conv3d_fwd");
+        at::Tensor st;
+        if (cfg.want_stats) {
+            st = cfg.stats_out ? *cfg.stats_out : at::empty({B, Cout, 2}, weight.options().dtype(at::kFloat));
+            TORCH_CHECK(st.sizes() == at::IntArrayRef({B, Cout, 2}) && st.is_contiguous() && st.scalar_type() == at::kFloat, "conv_block: stats_out");
+            check(g.conv_fwd_stats(&d, cfg.packed.data_ptr<float>(), bias ? bias->data_ptr<float>() : nullptr,
+                                   residual ? residual->data_ptr() : nullptr, y.data_ptr(), st.data_ptr<float>(), (float)cfg.eps,
+                                   cur_stream()),
+                  "passion_conv3d_fwd_stats");
+        } else {
+            check(g.conv_fwd(&d, cfg.packed.data_ptr<float>(), bias ? bias->data_ptr<float>() : nullptr,
+                             residual ? residual->data_ptr() : nullptr, y.data_ptr(), cur_stream()),
+                  "passion_conv3d_fwd");
+        }
         ctx->save_for_backward(xs.vec());
         ctx->saved_data["geo"] = cfg.geo;
         ctx->saved_data["seg"] = cfg.seg;
@@ -122,7 +136,9 @@ struct ConvBlockNode : public torch::autograd::Function<ConvBlockNode> {
         ctx->saved_data["packed"] = cfg.packed;
         ctx->saved_data["wshape"] = weight.sizes().vec();
         ctx->saved_data["flags"] = std::vector<int64_t>{bias.has_value(), residual.has_value()};
-        return y;
+        if (!cfg.want_stats) return {y};
+        ctx->mark_non_differentiable({st});
+        return {y, st};
     }
 
     static variable_list backward(AutogradContext* ctx, variable_list grads) {
@@ -178,11 +194,13 @@ struct ConvBlockNode : public torch::autograd::Function<ConvBlockNode> {
     }
 };
 
-at::Tensor conv_block(const at::Tensor& weight, const OptT& bias, const OptT& residual, const std::vector<at::Tensor>& xs,
-                      std::vector<OptT> stats, std::vector<OptT> masks, std::vector<int64_t> seg, std::vector<int64_t> geo,
-                      double slope, const at::Tensor& packed, const OptT& out) {
-    TORCH_CHECK(g.conv_fwd, "passion_amd host extension is not bound to libpassion_hip.so");
-    ConvCfg cfg{std::move(geo), std::move(seg), slope, std::move(stats), std::move(masks), packed, out};
+// -> [y] or [y, stats of y]
+std::vector<at::Tensor> conv_block(const at::Tensor& weight, const OptT& bias, const OptT& residual, const std::vector<at::Tensor>& xs,
+                                   std::vector<OptT> stats, std::vector<OptT> masks, std::vector<int64_t> seg, std::vector<int64_t> geo,
+                                   double slope, const at::Tensor& packed, const OptT& out, bool want_stats, const OptT& stats_out,
+                                   double eps) {
+    TORCH_CHECK(g.conv_fwd && g.conv_fwd_stats, "passion_amd host extension is not bound to libpassion_hip.so");
+    ConvCfg cfg{std::move(geo), std::move(seg), slope, std::move(stats), std::move(masks), packed, out, want_stats, stats_out, eps};
     return ConvBlockNode::apply(weight, bias, residual, at::TensorList(xs), std::move(cfg));
 }
 
@@ -200,8 +218,9 @@ at::Tensor instnorm_stats(const at::Tensor& x, double eps, const OptT& out) {
     return stats;
 }
 
-void bind(uint64_t conv_fwd, uint64_t conv_bwd, uint64_t conv_bwd_scratch, uint64_t stats, uint64_t stats_scratch) {
+void bind(uint64_t conv_fwd, uint64_t conv_bwd, uint64_t conv_bwd_scratch, uint64_t stats, uint64_t stats_scratch, uint64_t conv_fwd_stats) {
     g.conv_fwd = reinterpret_cast<decltype(g.conv_fwd)>(conv_fwd);
+    g.conv_fwd_stats = reinterpret_cast<decltype(g.conv_fwd_stats)>(conv_fwd_stats);
     g.conv_bwd = reinterpret_cast<decltype(g.conv_bwd)>(conv_bwd);
     g.conv_bwd_scratch = reinterpret_cast<decltype(g.conv_bwd_scratch)>(conv_bwd_scratch);
     g.stats = reinterpret_cast<decltype(g.stats)>(stats);

@@ -93,29 +93,46 @@ __global__ void copy_strided_kernel(const TS* __restrict__ s, long ssb, long ssv
 // to run, the sums differ in their last bit, and a bf16 rounding downstream then flips -- gradients did not repeat.  Now every
 // block stores its J partial sums in its own slot (`part`: [gridDim.y][gridDim.x][J] floats), takes a ticket from a device
 // counter, and the block that arrives LAST adds the slots in block order: the same additions in the same order every run.
-// Returns true in that last block only, with column j's total in thread j (j < J <= 256).  `red` is LDS for 4*J floats
-// (the caller's own reduction buffer, reused); the counter is left at zero again for the next launch on the stream.
+// Returns true in that last block only, with column j's total in thread j (j < J <= 128): all 256 threads of the last block
+// share the slots (column j x slot group) with eight loads in flight each -- a serial walk over 512 slots would cost more than
+// the reduction itself.  The counter is left at zero again for the next launch on the stream.
 template <int J>
 __device__ __forceinline__ bool fold_blocks(float s, float* __restrict__ part, unsigned* __restrict__ counter,
-                                            float* __restrict__ red, float& total) {
+                                            float* __restrict__ /*red*/, float& total) {
+    constexpr int JP = J <= 1 ? 1 : J <= 2 ? 2 : J <= 4 ? 4 : J <= 8 ? 8 : J <= 16 ? 16 : J <= 32 ? 32 : J <= 64 ? 64 : 128;
+    constexpr int G = 256 / JP;                             // slot groups: thread (gq, j) adds slots gq, gq + G, ... of column j
+    static_assert(J <= 128, "fold_blocks: at most 128 columns");
     __shared__ int last;
+    __shared__ float fred[G * JP];
     const int nb = gridDim.x, b = blockIdx.y, tid = threadIdx.x;
-    __syncthreads();                                        // everyone is done reading `red`
-    if (tid < J) part[((long)b * nb + blockIdx.x) * J + tid] = s;
-    __threadfence();                                        // release: the slot is visible device-wide before the ticket
-    __syncthreads();
+    if (tid < J) st_agent(&part[((long)b * nb + blockIdx.x) * J + tid], s);      // agent-scope atomics, no fence: see common.h
+    __syncthreads();                                        // the slot is stored (vmcnt 0) before the ticket is taken
     if (tid == 0) last = atomicAdd(&counter[b], 1u) == (unsigned)(nb - 1);
     __syncthreads();
     if (!last) return false;
-    __threadfence();                                        // acquire: see the other blocks' slots
-    for (int j = tid & 63; j < J; j += 64) {
-        float a = 0.f;
-        for (int r = tid >> 6; r < nb; r += 4) a += part[((long)b * nb + r) * J + j];
-        red[(tid >> 6) * J + j] = a;
+    const int j = tid % JP, gq = tid / JP;
+    float a = 0.f;
+    if (j < J) {
+        const float* col = part + (long)b * nb * J + j;
+        int r = gq;
+        constexpr int U = JP >= 64 ? 16 : 8;                // independent loads in flight, added in slot order
+        for (; r + (U - 1) * G < nb; r += U * G) {
+            float v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) v[u] = ld_agent(&col[(long)(r + u * G) * J]);
+#pragma unroll
+            for (int u = 0; u < U; ++u) a += v[u];
+        }
+        for (; r < nb; r += G) a += ld_agent(&col[(long)r * J]);
     }
+    fred[gq * JP + j] = a;
     __syncthreads();
-    total = tid < J ? (red[tid] + red[J + tid]) + (red[2 * J + tid] + red[3 * J + tid]) : 0.f;
-    if (tid == 0) counter[b] = 0u;
+    total = 0.f;
+    if (tid < J) {
+#pragma unroll 8
+        for (int q = 0; q < G; ++q) total += fred[q * JP + tid];
+    }
+    if (tid == 0) __hip_atomic_store(&counter[b], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return true;
 }
 constexpr int RED_BLOCKS_MAX = 1024;
@@ -520,21 +537,27 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ g, lo
         if (t < 128 && c < C) out[c] = s;
         return;
     }
-    if (t < 128 && c < C) part[(long)blockIdx.y * C + c] = s;
-    __threadfence();
+    if (t < 128 && c < C) st_agent(&part[(long)blockIdx.y * C + c], s);
     __syncthreads();
     if (t == 0) last = atomicAdd(&counter[blockIdx.x], 1u) == gridDim.y - 1;
     __syncthreads();
     if (!last) return;
-    __threadfence();
     if (t < 128 && c < C) {
         float tot = 0.f;
-        for (int y = 0; y < (int)gridDim.y; ++y) tot += part[(long)y * C + c];
+        int y = 0;
+        for (; y + 8 <= (int)gridDim.y; y += 8) {           // eight loads in flight, added in slice order
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = ld_agent(&part[(long)(y + u) * C + c]);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) tot += v[u];
+        }
+        for (; y < (int)gridDim.y; ++y) tot += ld_agent(&part[(long)y * C + c]);
         out[c] = tot;
     }
-    if (t == 0) counter[blockIdx.x] = 0u;
+    if (t == 0) __hip_atomic_store(&counter[blockIdx.x], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-constexpr int COLSUM_SLICES = 16;
+constexpr int COLSUM_SLICES = 32;
 
 int g_red_blocks = []() { const char* e = getenv("PASSION_RED_BLOCKS"); return e && atoi(e) > 0 ? atoi(e) : 512; }();
 inline int vgrid(long V) { return (int)hmin((V + 255) / 256, 2048); }
@@ -704,8 +727,8 @@ extern "C" int passion_colsum(const void* g, int dtype, int64_t R, int C, float*
     if (C <= 0 || (C & 1)) return -1014;
     hipStream_t st = (hipStream_t)stream;
     const int nbx = (C + 127) / 128;
-    // enough row slices to put ~2 blocks on every CU, at least 16 rows per wave
-    int ny = (int)hmin((long)COLSUM_SLICES, hmax(1L, hmin((long)(512 + nbx - 1) / nbx, R / 64)));
+    // enough row slices to put ~2 blocks on every CU, at least 8 rows per wave (two batches of four loads)
+    int ny = (int)hmin((long)COLSUM_SLICES, hmax(1L, hmin((long)(512 + nbx - 1) / nbx, R / 32)));
     unsigned* counter = (unsigned*)work;
     float* part = work + (nbx + 3) / 4 * 4;
     if (ny > 1) HIP_RET(hipMemsetAsync(counter, 0, sizeof(unsigned) * (size_t)nbx, st));

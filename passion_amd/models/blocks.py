@@ -68,15 +68,24 @@ def normalization(planes, norm="in"):
     raise ValueError(f"normalization type {norm} is not supported")
 
 
-def run_conv(conv, feats, norm, residual=None, out_dtype=None, out=None, stats_out=None):
-    """Launch the fused conv for an nn.Conv3d parameter holder over the virtual concat of `feats`."""
+FUSE_STATS = _os.environ.get("PASSION_FUSE_STATS", "1") != "0"   # A/B: 0 = statistics by their own launches, on first use
+
+
+def run_conv(conv, feats, norm, residual=None, out_dtype=None, out=None, stats_out=None, want_stats=False):
+    """Launch the fused conv for an nn.Conv3d parameter holder over the virtual concat of `feats`.
+    want_stats: the output goes on into a pre-norm conv -- have this conv leave the InstanceNorm statistics of its output too
+    (from its own epilogue where the kernel can, ops.conv_block) instead of a separate pass on first use."""
     if not isinstance(feats, (list, tuple)):
         feats = [feats]
     D, H, W = feats[0].dims
     cache = conv.__dict__.setdefault("_passion_pack", {})
+    want_stats = want_stats and FUSE_STATS and not MATERIALIZE
     y = ops.conv_block([f.seg(norm) for f in feats], conv.weight, conv.bias, D, H, W,
                        ksize=conv.kernel_size[0], stride=conv.stride[0], pad_mode=PAD[conv.padding_mode],
-                       residual=residual, out_dtype=out_dtype, pack_cache=cache, out=out)
+                       residual=residual, out_dtype=out_dtype, pack_cache=cache, out=out, want_stats=want_stats,
+                       stats_out=stats_out)
+    if want_stats:
+        return Feat(y[0], _stats=[y[1]], stats_out=stats_out)
     return Feat(y, stats_out=stats_out)
 
 
@@ -93,8 +102,9 @@ class general_conv3d_prenorm(nn.Module):
         self.norm = normalization(out_ch, norm=norm)
         self.activation = nn.LeakyReLU(negative_slope=relufactor, inplace=True) if act_type == "lrelu" else nn.ReLU(inplace=True)
 
-    def forward(self, feats, residual=None, out=None, stats_out=None):
-        return run_conv(self.conv, feats, norm=True, residual=residual, out=out, stats_out=stats_out)
+    def forward(self, feats, residual=None, out=None, stats_out=None, want_stats=True):
+        """want_stats=False: nobody normalises this output (it only feeds an upsampling / a logit head / the token conv)"""
+        return run_conv(self.conv, feats, norm=True, residual=residual, out=out, stats_out=stats_out, want_stats=want_stats)
 
 
 class fusion_prenorm(nn.Module):
@@ -109,10 +119,10 @@ class fusion_prenorm(nn.Module):
             general_conv3d_prenorm(in_channel, in_channel, k_size=3, padding=1, stride=1),
             general_conv3d_prenorm(in_channel, in_channel, k_size=1, padding=0, stride=1))
 
-    def forward(self, feats):
+    def forward(self, feats, want_stats=True):
         h = self.fusion_layer[0](feats)
         h = self.fusion_layer[1](h)
-        return self.fusion_layer[2](h)
+        return self.fusion_layer[2](h, want_stats=want_stats)
 
 
 # ------------------------------------------------------------------------------------------------

@@ -75,15 +75,22 @@ class Encoder(nn.Module):
         vol = D * Hh * Ww
         seg = ops.SegIn(x, mask=mask, mask_col=modal, C=1, offset=modal * vol, bstride=K * vol)
         cache = self.e1_c1.__dict__.setdefault("_passion_pack", {})
-        f = Feat(ops.conv_block([seg], self.e1_c1.weight, self.e1_c1.bias, D, Hh, Ww, ksize=3, stride=1,
-                                pad_mode=L.PAD_REFLECT, out_dtype=dtype, pack_cache=cache))
+        from .blocks import FUSE_STATS
+        if FUSE_STATS:
+            y0, st0 = ops.conv_block([seg], self.e1_c1.weight, self.e1_c1.bias, D, Hh, Ww, ksize=3, stride=1,
+                                     pad_mode=L.PAD_REFLECT, out_dtype=dtype, pack_cache=cache, want_stats=True)
+            f = Feat(y0, _stats=[st0])
+        else:
+            f = Feat(ops.conv_block([seg], self.e1_c1.weight, self.e1_c1.bias, D, Hh, Ww, ksize=3, stride=1,
+                                    pad_mode=L.PAD_REFLECT, out_dtype=dtype, pack_cache=cache))
         feats = []
         for lvl in range(1, 6):
             if lvl > 1:
                 f = getattr(self, f"e{lvl}_c1")(f)
             f = getattr(self, f"e{lvl}_c3")(getattr(self, f"e{lvl}_c2")(f), residual=f.t,
                                             out=outs[lvl - 1] if outs is not None else None,
-                                            stats_out=stats[lvl - 1] if stats is not None else None)
+                                            stats_out=stats[lvl - 1] if stats is not None else None,
+                                            want_stats=lvl < 5)      # level 5 feeds the token conv / an upsampling only
             feats.append(f)
         return feats
 
@@ -117,7 +124,7 @@ class Decoder_sep(nn.Module):
         skips = (x1, x2, x3, x4)
         h = self.d4_c1(_up2(x5))
         for lvl in (4, 3, 2, 1):
-            h = getattr(self, f"d{lvl}_out")(getattr(self, f"d{lvl}_c2")([h, skips[lvl - 1]]))
+            h = getattr(self, f"d{lvl}_out")(getattr(self, f"d{lvl}_c2")([h, skips[lvl - 1]]), want_stats=False)
             if lvl > 1:
                 h = getattr(self, f"d{lvl - 1}_c1")(_up2(h))
         logits = run_conv(self.seg_layer, h, norm=False, out_dtype=torch.float32).t
@@ -148,12 +155,12 @@ class Decoder_fuse(nn.Module):
         """x1..x4: lists of the four modality Feats (already carrying their masks); x5: fused level-5 Feat"""
         xs = (x1, x2, x3, x4)
         feats, preds = {}, {}
-        feats[5] = self.RFM5([x5])
+        feats[5] = self.RFM5([x5], want_stats=False)        # feeds a logit head and an upsampling only
         preds[4] = run_conv(self.seg_d4, feats[5], norm=False, out_dtype=torch.float32).t
         h = self.d4_c1(_up2(feats[5]))
         for lvl in (4, 3, 2, 1):
             r = getattr(self, f"RFM{lvl}")(xs[lvl - 1])
-            f = getattr(self, f"d{lvl}_out")(getattr(self, f"d{lvl}_c2")([r, h]))
+            f = getattr(self, f"d{lvl}_out")(getattr(self, f"d{lvl}_c2")([r, h]), want_stats=False)
             feats[lvl] = f
             if lvl > 1:
                 preds[lvl - 1] = run_conv(getattr(self, f"seg_d{lvl - 1}"), f, norm=False, out_dtype=torch.float32).t
@@ -334,7 +341,7 @@ class Model(nn.Module):
                     for i, t in enumerate(intra)]
         tok = self._transformer(self.multimodal_transformer, torch.cat(toks, 1), pos_cat)
         vol = tok.to(self.compute_dtype).contiguous().view(P * B, p, p, p, self.token_dim * num_modals)
-        return run_conv(self.multimodal_decode_conv, Feat(vol), norm=False)
+        return run_conv(self.multimodal_decode_conv, Feat(vol), norm=False, want_stats=True)
 
     def _enc_streams(self, dev):
         cache = self.__dict__.setdefault("_streams_dev", {})

@@ -313,8 +313,10 @@ class ConvBlockFn(torch.autograd.Function):
 
 
 def conv_block(segs, weight, bias, D, H, W, ksize=3, stride=1, pad_mode=L.PAD_REFLECT,
-               residual=None, out_dtype=None, slope=0.2, pack_cache=None, out=None):
-    """`out`: optional preallocated output (a non-view alias into a larger buffer, see alias_slice)"""
+               residual=None, out_dtype=None, slope=0.2, pack_cache=None, out=None, want_stats=False, stats_out=None, eps=1e-5):
+    """`out`: optional preallocated output (a non-view alias into a larger buffer, see alias_slice).
+    want_stats: return (y, InstanceNorm statistics of y) -- the statistics the NEXT pre-norm conv applies in its loader, left
+    by this conv's own epilogue where the kernel can (passion_conv3d_fwd_stats); `stats_out`: preallocated (B,Cout,2) slot."""
     cfg = _ConvCfg()
     cfg.segs, cfg.D, cfg.H, cfg.W = segs, D, H, W
     cfg.ksize, cfg.stride, cfg.pad_mode, cfg.slope = ksize, stride, pad_mode, slope
@@ -330,9 +332,12 @@ def conv_block(segs, weight, bias, D, H, W, ksize=3, stride=1, pad_mode=L.PAD_RE
         seg_ints = []
         for s in segs:
             seg_ints += (s.C, s.offset, s.bstride, s.bmod, s.mask_col)
-        return h.conv_block(weight, bias, residual, [s.x for s in segs], [s.stats for s in segs], [s.mask for s in segs], seg_ints,
-                            (cfg.B, D, H, W, ksize, stride, pad_mode, L.dtype_code(cfg.out_dtype)), slope, packed, out)
-    return ConvBlockFn.apply(cfg, weight, bias, residual, packed, *[s.x for s in segs])
+        r = h.conv_block(weight, bias, residual, [s.x for s in segs], [s.stats for s in segs], [s.mask for s in segs], seg_ints,
+                         (cfg.B, D, H, W, ksize, stride, pad_mode, L.dtype_code(cfg.out_dtype)), slope, packed, out,
+                         want_stats, stats_out, eps)
+        return (r[0], r[1]) if want_stats else r[0]
+    y = ConvBlockFn.apply(cfg, weight, bias, residual, packed, *[s.x for s in segs])
+    return (y, instnorm_stats(y.detach(), eps, out=stats_out)) if want_stats else y
 
 
 def alias_slice(buf, i):

@@ -539,6 +539,7 @@ def test_conv_march_backward_is_bitwise_reproducible():
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32], ids=["bf16", "f32"])
 @pytest.mark.parametrize("R,C", [(1280, 4096), (256, 512), (67, 130), (5, 2), (2560, 1536)])
 def test_colsum_bias_gradient(R, C, dtype):
+    from passion_amd import ops
     """passion_colsum (the bias gradient of the token GEMMs) against a float64 column sum, and bit-identical over repeats
     while a second stream keeps the GPU busy (torch's own sum is not, on this stack: tools/linear_bias_determinism.py)"""
     dev = torch.device("cuda:0")
@@ -558,6 +559,7 @@ def test_colsum_bias_gradient(R, C, dtype):
 
 
 def test_linear_fn_matches_torch_linear():
+    from passion_amd import ops
     """ops.linear (hipBLASLt GEMMs + passion_colsum bias gradient) against torch's F.linear autograd, f32"""
     dev = torch.device("cuda:0")
     gen = torch.Generator(dev).manual_seed(3)
@@ -573,3 +575,56 @@ def test_linear_fn_matches_torch_linear():
     y2.backward(gy)
     for a_, b_ in zip(got, (y2.detach(), x.grad, w.grad, b.grad)):
         assert float((a_ - b_).abs().max()) <= 1e-4 * float(b_.abs().max())
+
+
+FUSED_STATS_CASES = [
+    # (segment channels, Cout, ksize, stride, pad, (D, H, W), dtype, residual, path the forward takes)
+    ([8], 8, 3, 1, 1, (24, 32, 64), torch.bfloat16, True, "marching kernel epilogue"),
+    ([8, 8], 16, 3, 1, 1, (16, 16, 32), torch.bfloat16, False, "marching kernel epilogue, two segments"),
+    ([16], 16, 3, 1, 0, (40, 32, 32), torch.bfloat16, False, "marching kernel, several depth segments"),
+    ([32], 32, 3, 1, 1, (16, 16, 16), torch.bfloat16, True, "lean kernel epilogue"),
+    ([64], 64, 3, 1, 1, (8, 8, 8), torch.bfloat16, False, "lean kernel epilogue, 8^3"),
+    ([32, 32], 32, 1, 1, 0, (16, 16, 16), torch.bfloat16, False, "lean 1x1x1"),
+    ([128], 128, 3, 1, 1, (8, 8, 8), torch.bfloat16, False, "lean, several row-tile groups"),
+    ([8], 16, 3, 2, 1, (16, 16, 16), torch.bfloat16, False, "stride 2: statistics kernels after the conv"),
+    ([8], 8, 3, 1, 1, (10, 12, 20), torch.bfloat16, False, "ragged bricks: statistics kernels after the conv"),
+    ([8], 8, 3, 1, 1, (8, 8, 16), torch.float32, False, "f32 storage: statistics kernels after the conv"),
+]
+
+
+@pytest.mark.parametrize("case", FUSED_STATS_CASES, ids=[c[-1] for c in FUSED_STATS_CASES])
+def test_conv_forward_leaves_the_statistics_of_its_output(case):
+    """passion_conv3d_fwd_stats: y bit-identical to passion_conv3d_fwd, statistics = passion_instnorm_stats(y) (the fused
+    epilogue sums the stored bf16 values in f32 per workgroup, the separate kernels per thread: agreement to f32 rounding),
+    bit-identical over repeats, also into a preallocated slot and for a batch of 3"""
+    from passion_amd import ops
+    dev = _dev()
+    segc, Cout, ks, stride, pad, (D, H, W), dtype, with_res, _ = case
+    B = 3
+    g = torch.Generator().manual_seed(sum(segc) + Cout + D)
+    xs = [(torch.randn(B, D, H, W, c, generator=g) * 2 + 0.7).to(dev, dtype) for c in segc]
+    w = (torch.randn(Cout, sum(segc), ks, ks, ks, generator=g) * 0.2).to(dev)
+    bias = torch.randn(Cout, generator=g).to(dev)
+    Do, Ho, Wo = [(s + 2 * (ks // 2) - ks) // stride + 1 for s in (D, H, W)]
+    res = (torch.randn(B, Do, Ho, Wo, Cout, generator=g).to(dev, dtype)) if with_res else None
+    segs = lambda: [ops.SegIn(x, stats=ops.instnorm_stats(x)) for x in xs]
+    kw = dict(ksize=ks, stride=stride, pad_mode=pad, residual=res)
+    y0 = ops.conv_block(segs(), w, bias, D, H, W, **kw)
+    y1, st1 = ops.conv_block(segs(), w, bias, D, H, W, want_stats=True, **kw)
+    assert torch.equal(y0, y1)
+    want = ops.instnorm_stats(y0)
+    assert st1.shape == (B, Cout, 2) and st1.dtype == torch.float32
+    std = 1.0 / want[..., 1]
+    assert float(((st1[..., 0] - want[..., 0]).abs() / (std + want[..., 0].abs())).max()) < 2e-5
+    assert float(((st1[..., 1] - want[..., 1]).abs() / want[..., 1]).max()) < 1e-4
+    slot = torch.full((2, B, Cout, 2), -7.0, device=dev)
+    for _ in range(3):
+        y2, st2 = ops.conv_block(segs(), w, bias, D, H, W, want_stats=True, stats_out=slot[1], **kw)
+        assert st2.data_ptr() == slot[1].data_ptr() and torch.equal(st2, st1) and torch.equal(y2, y0)
+    assert float(slot[0].min()) == -7.0 and float(slot[0].max()) == -7.0
+    # the statistics are plain data for autograd: the backward of y is unchanged
+    xg = [x.clone().requires_grad_(True) for x in xs]
+    wg = w.clone().requires_grad_(True)
+    y3, _ = ops.conv_block([ops.SegIn(x, stats=ops.instnorm_stats(x.detach())) for x in xg], wg, bias, D, H, W, want_stats=True, **kw)
+    y3.float().square().sum().backward()
+    assert wg.grad is not None and all(x.grad is not None for x in xg)
