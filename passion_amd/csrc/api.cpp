@@ -98,6 +98,7 @@ int fwd_stats_setup(ConvK& k, int nwg, int ny, hipStream_t st) {
     f.tickets = static_cast<unsigned*>(zero);
     f.slots = static_cast<float*>(plain);
     f.gslots = reinterpret_cast<double*>(static_cast<char*>(plain) + gs_off);
+    f.direct = ((long)nwg * (long)nv <= 16384 && nv <= 256) ? 1 : 0;
     f.eps = k.fst_eps;
     f.inv_v = 1.0 / ((double)k.Do * k.Ho * k.Wo);
     f.stats = k.fst_want;

@@ -575,7 +575,7 @@ int fill_params(const passion_conv_desc_t* d, ConvK& k) {
     if (!d) return -1001;
     k.dbg = 0;
     k.sums_fixed = 0; k.sums_float_only = 0;
-    k.fst = FwdStats{nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0.f, 0.0};
+    k.fst = FwdStats{nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0, 0.f, 0.0};
     k.fst_want = nullptr; k.fst_eps = 0.f;
     k.bd_rows = 0; k.bd_k8 = 0;
     k.y_f32 = 0;

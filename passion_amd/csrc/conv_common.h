@@ -38,6 +38,7 @@ struct FwdStats {
     double* gslots;        // [B][ngroup][Cout][2] (scratch)
     unsigned* tickets;     // [B][ngroup + 1]: zero before the launch, left at zero
     int nwg, ngroup, ny;   // workgroups per sample along x, groups of STATS_GROUP, workgroups per x position (row-tile groups)
+    int direct;            // few slots: one fold by the last workgroup of the sample instead of groups + final
     float eps;
     double inv_v;
 };
@@ -137,8 +138,43 @@ __device__ __forceinline__ void fwd_stats_commit(const FwdStats& fs, int Cout, i
         if (c < Cout) st_agent(&slot[c * 2 + (i & 1)], wsum[i]);
     }
     __syncthreads();                                           // waits for the stores (vmcnt 0) of every thread: slot before ticket
-    const int grp = wq / STATS_GROUP, gsz = min(STATS_GROUP, fs.nwg - grp * STATS_GROUP);
     unsigned* tk = fs.tickets + (long)b * (fs.ngroup + 1);
+    __shared__ double fst_part[256];
+    if (fs.direct) {
+        // few enough slots (nwg * NV <= 16384): the workgroup that arrives last adds all of them, value v x SL slot slices per
+        // thread (batches of eight loads), slices combined through LDS in order -- one hand-over instead of two
+        if (tid == 0) fst_flag = atomicAdd(&tk[fs.ngroup], 1u) == (unsigned)(fs.nwg * fs.ny - 1);
+        __syncthreads();
+        if (!fst_flag) return;
+        const int SLd = 256 / NV, v = tid % NV, sl = tid / NV;      // NV <= 256 here
+        double a = 0.0;
+        if (sl < SLd) {
+            const float* s0 = fs.slots + (long)b * fs.nwg * NV + v;
+            int r = sl;
+            for (; r + 7 * SLd < fs.nwg; r += 8 * SLd) {
+                float t[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) t[u] = ld_agent(&s0[(long)(r + u * SLd) * NV]);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) a += (double)t[u];
+            }
+            for (; r < fs.nwg; r += SLd) a += (double)ld_agent(&s0[(long)r * NV]);
+        }
+        fst_part[tid] = a;
+        __syncthreads();
+        if (tid < NV / 2) {
+            double sm = 0.0, sq = 0.0;
+            for (int q = 0; q < SLd; ++q) { sm += fst_part[q * NV + 2 * tid]; sq += fst_part[q * NV + 2 * tid + 1]; }
+            const double mean = sm * fs.inv_v;
+            double var = sq * fs.inv_v - mean * mean;
+            if (var < 0) var = 0;
+            fs.stats[((long)b * Cout + tid) * 2 + 0] = (float)mean;
+            fs.stats[((long)b * Cout + tid) * 2 + 1] = (float)(1.0 / sqrt(var + (double)fs.eps));
+        }
+        if (tid == 0) __hip_atomic_store(&tk[fs.ngroup], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
+    const int grp = wq / STATS_GROUP, gsz = min(STATS_GROUP, fs.nwg - grp * STATS_GROUP);
     if (tid == 0) fst_flag = atomicAdd(&tk[grp], 1u) == (unsigned)(gsz * fs.ny - 1);
     __syncthreads();
     if (!fst_flag) return;
@@ -159,7 +195,6 @@ __device__ __forceinline__ void fwd_stats_commit(const FwdStats& fs, int Cout, i
     __syncthreads();
     if (!fst_flag) return;
     // the group sums: value v = (channel, moment) x SL slices of the groups per thread, slices combined through LDS in order
-    __shared__ double fst_part[256];
     const int SL = NV <= 256 ? 256 / NV : 1;
     for (int v0 = 0; v0 < NV; v0 += 256) {                     // one pass unless Cout > 128
         const int v = v0 + tid % min(NV, 256), sl = tid / min(NV, 256);

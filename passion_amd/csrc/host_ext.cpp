@@ -138,6 +138,7 @@ struct ConvBlockNode : public torch::autograd::Function<ConvBlockNode> {
         ctx->saved_data["flags"] = std::vector<int64_t>{bias.has_value(), residual.has_value()};
         if (!cfg.want_stats) return {y};
         ctx->mark_non_differentiable({st});
+        ctx->set_materialize_grads(false);       // no zeros_like(stats) (a fill launch) per backward call for the gradient nobody has
         return {y, st};
     }
 
@@ -156,6 +157,7 @@ struct ConvBlockNode : public torch::autograd::Function<ConvBlockNode> {
         if (has_bias) ++e;
         const bool need_res = has_res && ctx->needs_input_grad(e);
         if (has_res) ++e;
+        if (!grads[0].defined()) return variable_list(4 + n);      // y was not used (set_materialize_grads(false))
         const at::Tensor dy = grads[0].contiguous();
         const auto f32 = dy.options().dtype(at::kFloat);
         at::Tensor dW, db;
