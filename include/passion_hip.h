@@ -120,6 +120,10 @@ int passion_conv3d_bwd_phase(const passion_conv_desc_t* d, const float* packed, 
  * (code/models/mmformer.py:70,143,366-370).  x: [B][D][H][W][C] -> y: [B][kD][kH][kW][C]. */
 int passion_upsample_fwd(const void* x, void* y, int dtype, int B, int D, int H, int W, int C,
                          int k, void* stream);
+/* ... and the InstanceNorm statistics of y ([B][C][2] f32 = mean, 1/sqrt(var + eps)) from the same pass (the decoders'
+ * d*_c1 convs normalise the upsampled tensor, code/models/mmformer.py:98-101). */
+int passion_upsample_fwd_stats(const void* x, void* y, int dtype, int B, int D, int H, int W, int C,
+                               int k, float* stats, float eps, void* stream);
 /* backward: k <= 2 one gather pass (scratch unused, may be NULL); k > 2 three separable passes through
  * `scratch` (passion_upsample_bwd_scratch_floats floats; NULL falls back to the one-pass gather). */
 int64_t passion_upsample_bwd_scratch_floats(int B, int D, int H, int W, int C, int k);

@@ -60,6 +60,8 @@ SIGNATURES = {
                                             c_int, c_void_p]),
     "passion_upsample_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
                                      c_int, c_void_p]),
+    "passion_upsample_fwd_stats": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
+                                           c_int, c_void_p, c_float, c_void_p]),
     "passion_upsample_bwd_scratch_floats": (c_int64, [c_int, c_int, c_int, c_int, c_int, c_int]),
     "passion_upsample_bwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
                                      c_int, c_void_p, c_void_p]),

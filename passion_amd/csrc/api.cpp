@@ -86,23 +86,26 @@ int stream_scratch(hipStream_t st, size_t zero_bytes, size_t plain_bytes, void**
     return 0;
 }
 
-int fwd_stats_setup(ConvK& k, int nwg, int ny, hipStream_t st) {
-    FwdStats& f = k.fst;
+int fwd_stats_setup_raw(FwdStats& f, int B, int C, int nwg, int ny, double inv_v, float eps, float* stats, hipStream_t st) {
     f.nwg = nwg; f.ny = ny; f.ngroup = (nwg + STATS_GROUP - 1) / STATS_GROUP;
-    const size_t nv = (size_t)k.Cout * 2;
-    const size_t slots = (size_t)k.B * nwg * nv * sizeof(float), gsl = (size_t)k.B * f.ngroup * nv * sizeof(double);
+    const size_t nv = (size_t)C * 2;
+    const size_t slots = (size_t)B * nwg * nv * sizeof(float), gsl = (size_t)B * f.ngroup * nv * sizeof(double);
     const size_t gs_off = (slots + 255) / 256 * 256;
     void *zero = nullptr, *plain = nullptr;
-    const int rc = stream_scratch(st, (size_t)k.B * (f.ngroup + 1) * sizeof(unsigned), gs_off + gsl, &zero, &plain);
+    const int rc = stream_scratch(st, (size_t)B * (f.ngroup + 1) * sizeof(unsigned), gs_off + gsl, &zero, &plain);
     if (rc) return rc;
     f.tickets = static_cast<unsigned*>(zero);
     f.slots = static_cast<float*>(plain);
     f.gslots = reinterpret_cast<double*>(static_cast<char*>(plain) + gs_off);
     f.direct = ((long)nwg * (long)nv <= 16384 && nv <= 256) ? 1 : 0;
-    f.eps = k.fst_eps;
-    f.inv_v = 1.0 / ((double)k.Do * k.Ho * k.Wo);
-    f.stats = k.fst_want;
+    f.eps = eps;
+    f.inv_v = inv_v;
+    f.stats = stats;
     return 0;
+}
+
+int fwd_stats_setup(ConvK& k, int nwg, int ny, hipStream_t st) {
+    return fwd_stats_setup_raw(k.fst, k.B, k.Cout, nwg, ny, 1.0 / ((double)k.Do * k.Ho * k.Wo), k.fst_eps, k.fst_want, st);
 }
 }  // namespace pconv
 

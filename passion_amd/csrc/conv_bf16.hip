@@ -128,7 +128,7 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(ConvK p) {
     constexpr bool WLDS = wlds_fits(CKB, MT);
     constexpr int WV = G::NSTEP * 4 * MT * 16;          // 16-byte weight vectors per chunk
     bf16x8* wl = reinterpret_cast<bf16x8*>(dyn_lds + brick_bytes<KS, S, DG, CKB>());
-    __shared__ float lsum[DG ? MT * 16 * 2 : 4];
+    __shared__ float lsum[DG ? MT * 16 * 2 : 5 * MT * 16 * 2];     // forward: [wave][row][2] + the workgroup's totals (fused statistics)
 
     const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, n = lane & 15, g = lane >> 4;
     int bid = xcd_swizzle(blockIdx.x, gridDim.x);
@@ -354,8 +354,14 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(ConvK p) {
     }
 
     const int oh4[4] = {o0h + lh[0], o0h + lh[1], o0h + lh[2], o0h + lh[3]};
-    if (!DG) epilogue_fwd<bf16_t, MT>(p, acc, b, mg, o0d + ld_, o0w + lw, oh4, g);
-    else epilogue_dgrad<bf16_t, MT>(p, acc, lsum, b, mg, o0d + ld_, o0w + lw, oh4, g, n, tid);
+    if (!DG) {
+        if (p.fst.stats) {        // workgroup-uniform: statistics of y from this epilogue (one brick = one slot)
+            __syncthreads();
+            epilogue_fwd_stats<MT>(p, acc, lsum, b, (td_ * p.tilesH + th_) * p.tilesW + tw_, mg, o0d + ld_, o0w + lw, oh4, g, n, wv, tid);
+        } else {
+            epilogue_fwd<bf16_t, MT>(p, acc, b, mg, o0d + ld_, o0w + lw, oh4, g);
+        }
+    } else epilogue_dgrad<bf16_t, MT>(p, acc, lsum, b, mg, o0d + ld_, o0w + lw, oh4, g, n, tid);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -681,6 +687,11 @@ int launch_one(ConvK& k, dim3 grid, hipStream_t st) {
         attr_set = true;
     }
     passion_prof_tag("conv_bf16_kernel<%d, %d, %d, %d, %d>", KS, S, MT, MODE, CKB);
+    k.fst.stats = nullptr;
+    if (MODE == 0 && k.fst_want) {          // one brick per workgroup: tiles per sample slots, grid.y row-tile groups
+        const int rc = fwd_stats_setup(k, k.tilesD * k.tilesH * k.tilesW, (int)grid.y, st);
+        if (rc) return rc < 0 ? rc : -rc;
+    }
     hipLaunchKernelGGL((conv_bf16_kernel<KS, S, MT, MODE, CKB>), grid, dim3(256), bytes, st, k);
     LAUNCH_RET();
     return 0;

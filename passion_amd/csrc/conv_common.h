@@ -77,6 +77,7 @@ struct ConvK {
 int stream_scratch(hipStream_t st, size_t zero_bytes, size_t plain_bytes, void** zero, void** plain);
 // sets up k.fst for a launch of nwg x ny workgroups per sample (0 = ok)
 int fwd_stats_setup(ConvK& k, int nwg, int ny, hipStream_t st);
+int fwd_stats_setup_raw(FwdStats& f, int B, int C, int nwg, int ny, double inv_v, float eps, float* stats, hipStream_t st);
 
 __host__ __device__ inline int pad16(int c) { return (c + 15) / 16 * 16; }
 __host__ __device__ inline int pad8(int c) { return (c + 7) / 8 * 8; }
@@ -201,7 +202,15 @@ __device__ __forceinline__ void fwd_stats_commit(const FwdStats& fs, int Cout, i
         double a = 0.0;
         if (v < NV && sl < SL) {
             const double* g0 = fs.gslots + (long)b * fs.ngroup * NV + v;
-            for (int gi = sl; gi < fs.ngroup; gi += SL) a += ld_agent(&g0[(long)gi * NV]);
+            int gi = sl;
+            for (; gi + 7 * SL < fs.ngroup; gi += 8 * SL) {     // eight loads in flight, added in group order
+                double t[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) t[u] = ld_agent(&g0[(long)(gi + u * SL) * NV]);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) a += t[u];
+            }
+            for (; gi < fs.ngroup; gi += SL) a += ld_agent(&g0[(long)gi * NV]);
         }
         __syncthreads();
         fst_part[tid] = a;
@@ -249,6 +258,60 @@ __device__ __forceinline__ void epilogue_fwd(const ConvK& p, const f32x4 (&acc)[
             store4(y + vox * p.Cout + co, v);
         }
     }
+}
+
+
+// The same with the statistics of the stored values: per-lane sums over the lane's voxels, 16 voxel lanes by shuffles, four
+// waves through LDS (fixed order), then the slot / ticket fold.  lsum: LDS float[4 * MT * 16 * 2 + MT * 16 * 2].
+template <int MT>
+__device__ __forceinline__ void epilogue_fwd_stats(const ConvK& p, const f32x4 (&acc)[MT][4], float* lsum, int b, int wq, int mg,
+                                                   int od, int ow, const int (&oh4)[4], int kq, int n, int wv, int tid) {
+    bf16_t* y = reinterpret_cast<bf16_t*>(p.y);
+    const bf16_t* res = reinterpret_cast<const bf16_t*>(p.residual);
+    float s1[MT][4], s2[MT][4];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { s1[mt][j] = 0.f; s2[mt][j] = 0.f; }
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        const int oh = oh4[nt];
+        if (od >= p.Do || oh >= p.Ho || ow >= p.Wo) continue;
+        const long vox = (((long)b * p.Do + od) * p.Ho + oh) * p.Wo + ow;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int co = (mg * MT + mt) * 16 + kq * 4;
+            if (co >= p.Cout) continue;
+            f32x4 v = acc[mt][nt];
+            if (p.bias) v += load4(p.bias + co);
+            if (res) v += load4(res + vox * p.Cout + co);
+            unsigned pk[2];
+            float rb[4];
+            round4_bf16(v, pk, rb);
+            *reinterpret_cast<uint2*>(y + vox * p.Cout + co) = make_uint2(pk[0], pk[1]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { s1[mt][j] += rb[j]; s2[mt][j] = __builtin_fmaf(rb[j], rb[j], s2[mt][j]); }
+        }
+    }
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float a1 = group16_sum(s1[mt][j]), a2 = group16_sum(s2[mt][j]);
+            if (n == 0) {
+                lsum[((wv * MT + mt) * 16 + kq * 4 + j) * 2 + 0] = a1;
+                lsum[((wv * MT + mt) * 16 + kq * 4 + j) * 2 + 1] = a2;
+            }
+        }
+    __syncthreads();
+    float* wsum = lsum + 4 * MT * 16 * 2;
+    for (int i = tid; i < MT * 16 * 2; i += 256) {
+        const int row = i >> 1, k2 = i & 1;
+        wsum[i] = ((lsum[(0 * MT * 16 + row) * 2 + k2] + lsum[(1 * MT * 16 + row) * 2 + k2]) + lsum[(2 * MT * 16 + row) * 2 + k2]) +
+                  lsum[(3 * MT * 16 + row) * 2 + k2];
+    }
+    __syncthreads();
+    fwd_stats_commit(p.fst, p.Cout, b, wq, mg * MT * 16, MT * 16, wsum, tid);
 }
 
 // rows are input channels of the forward conv.  lsum: shared float[MT*16*2], zeroed here.

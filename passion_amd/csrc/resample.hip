@@ -6,6 +6,7 @@
 // voxel sums the output voxels that referenced it), so there are no atomics and the result is
 // deterministic.  For large k a whole wavefront shares one input voxel and reduces with shuffles.
 #include "common.h"
+#include "conv_common.h"
 #include "passion_hip.h"
 
 namespace {
@@ -67,6 +68,76 @@ __global__ __launch_bounds__(256) void upsample_fwd_kernel(const T* __restrict__
         }
         VecIO<T, VEC>::store(y + (long)i * VEC, r);
     }
+}
+
+
+// The same gather with the InstanceNorm statistics of the OUTPUT as a by-product (the decoder's d*_c1 convs normalise the
+// upsampled tensor, reference mmformer.py:98-101 / blocks.py:313): grid (blocks, B), a thread keeps its channel vector, the
+// (sum, sum of squares) of the stored values leave the block through the slot / ticket fold of conv_common.h -- no second
+// pass over y, no statistics launches.
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void upsample_fwd_stats_kernel(const T* __restrict__ x, T* __restrict__ y, int D, int H, int W,
+                                                                 int C, int k, pconv::FwdStats fs) {
+    __shared__ float red[256 * 2 * VEC];
+    __shared__ float wsum[512];
+    const int Do = D * k, Ho = H * k, Wo = W * k, cvn = C / VEC;
+    const int b = blockIdx.y, tid = threadIdx.x;
+    const float sd = axis_scale(D, Do), sh = axis_scale(H, Ho), sw = axis_scale(W, Wo);
+    const unsigned total = (unsigned)Do * Ho * Wo * cvn;                   // per sample, < 2^32 (checked by the launcher)
+    const T* xs = x + (long)b * D * H * W * C;
+    T* ys = y + (long)b * Do * Ho * Wo * C;
+    float s[VEC], q[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) { s[j] = 0.f; q[j] = 0.f; }
+    for (unsigned i = blockIdx.x * 256u + tid; i < total; i += gridDim.x * 256u) {      // stride % cvn == 0: same channels every time
+        const int cv = (int)(i % (unsigned)cvn);
+        unsigned v = i / (unsigned)cvn;
+        const int ow = (int)(v % (unsigned)Wo); v /= (unsigned)Wo;
+        const int oh = (int)(v % (unsigned)Ho);
+        const int od = (int)(v / (unsigned)Ho);
+        const Src a = src_index(od, sd, D), e = src_index(oh, sh, H), f = src_index(ow, sw, W);
+        const T* xb = xs + cv * VEC;
+        float r[VEC];
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) r[j] = 0.f;
+        const int di[2] = {a.i0, a.i1}, hi[2] = {e.i0, e.i1}, wi[2] = {f.i0, f.i1};
+        const float dl[2] = {a.l0, a.l1}, hl[2] = {e.l0, e.l1}, wl[2] = {f.l0, f.l1};
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            float rh[VEC];
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) rh[j] = 0.f;
+#pragma unroll
+            for (int qq = 0; qq < 2; ++qq) {
+                float t0[VEC], t1[VEC];
+                VecIO<T, VEC>::load(xb + ((((long)di[p]) * H + hi[qq]) * W + wi[0]) * C, t0);
+                VecIO<T, VEC>::load(xb + ((((long)di[p]) * H + hi[qq]) * W + wi[1]) * C, t1);
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) rh[j] += hl[qq] * (wl[0] * t0[j] + wl[1] * t1[j]);
+            }
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) r[j] += dl[p] * rh[j];
+        }
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {                                     // what gets stored
+            r[j] = to_f32(from_f32<T>(r[j]));
+            s[j] += r[j];
+            q[j] = __builtin_fmaf(r[j], r[j], q[j]);
+        }
+        VecIO<T, VEC>::store(ys + (long)i * VEC, r);
+    }
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) { red[tid * 2 * VEC + j] = s[j]; red[tid * 2 * VEC + VEC + j] = q[j]; }
+    __syncthreads();
+    // thread tid holds channel vector tid % cvn: channel c = cv * VEC + j, summed over the 256 / cvn threads in a fixed order
+    for (int o = tid; o < C * 2; o += 256) {
+        const int c = o >> 1, k2 = o & 1, cv = c / VEC, j = c % VEC;
+        float t = 0.f;
+        for (int l = cv; l < 256; l += cvn) t += red[l * 2 * VEC + k2 * VEC + j];
+        wsum[o] = t;
+    }
+    __syncthreads();
+    pconv::fwd_stats_commit(fs, C, b, blockIdx.x, 0, C, wsum, tid);
 }
 
 // weight with which output index o reads input index i along one axis
@@ -361,6 +432,38 @@ extern "C" int passion_upsample_fwd(const void* x, void* y, int dtype, int B, in
         FWD_LAUNCH(bf16_t, 4, (const bf16_t*)x, (bf16_t*)y);
     else
         return -1007;
+    LAUNCH_RET();
+    return 0;
+}
+
+
+extern "C" int passion_upsample_fwd_stats(const void* x, void* y, int dtype, int B, int D, int H, int W, int C, int k,
+                                          float* stats, float eps, void* stream) {
+    if (C % 4 || k < 1 || !stats) return -1011;
+    hipStream_t st = (hipStream_t)stream;
+    const bool v8 = dtype == PASSION_BF16 && C % 8 == 0;
+    const int cvn = C / (v8 ? 8 : 4);
+    const long total = (long)D * k * H * k * W * k * cvn;                  // per sample
+    if (C > 256 || 256 % cvn || total >= (1L << 32) || (dtype != PASSION_F32 && dtype != PASSION_BF16)) {
+        // shapes the fused kernel does not take: the plain gather, then the statistics kernels over y
+        int rc = passion_upsample_fwd(x, y, dtype, B, D, H, W, C, k, stream);
+        if (rc) return rc;
+        const int64_t V = (int64_t)D * k * H * k * W * k;
+        void* plain = nullptr;
+        rc = pconv::stream_scratch(st, 0, (size_t)passion_instnorm_scratch_doubles(B, V, C) * sizeof(double), nullptr, &plain);
+        if (rc) return rc;
+        return passion_instnorm_stats(y, dtype, B, V, C, V * C, eps, static_cast<double*>(plain), stats, stream);
+    }
+    const int blocks = (int)hmin((total + 255) / 256, 1024);                // <= 1024 slots per sample for the fold
+    pconv::FwdStats fs;
+    const int rc = pconv::fwd_stats_setup_raw(fs, B, C, blocks, 1, 1.0 / ((double)D * k * H * k * W * k), eps, stats, st);
+    if (rc) return rc;
+    if (dtype == PASSION_F32)
+        hipLaunchKernelGGL((upsample_fwd_stats_kernel<float, 4>), dim3(blocks, B), dim3(256), 0, st, (const float*)x, (float*)y, D, H, W, C, k, fs);
+    else if (v8)
+        hipLaunchKernelGGL((upsample_fwd_stats_kernel<bf16_t, 8>), dim3(blocks, B), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y, D, H, W, C, k, fs);
+    else
+        hipLaunchKernelGGL((upsample_fwd_stats_kernel<bf16_t, 4>), dim3(blocks, B), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y, D, H, W, C, k, fs);
     LAUNCH_RET();
     return 0;
 }

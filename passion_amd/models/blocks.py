@@ -89,6 +89,22 @@ def run_conv(conv, feats, norm, residual=None, out_dtype=None, out=None, stats_o
     return Feat(y, stats_out=stats_out)
 
 
+GEMM_1X1 = _os.environ.get("PASSION_GEMM_1X1", "1") != "0"
+
+
+def run_pointwise(conv, feat):
+    """A 1x1x1 conv WITHOUT a normalisation in front (the token convs *_encode_conv and multimodal_decode_conv, reference
+    mmformer.py:213-214, 243) is a plain GEMM over the voxels of a channels-last tensor: it goes to hipBLASLt like the other
+    token GEMMs (ops.linear; a 2048 -> 512 conv over 512 voxels took 180 us per direction in the general conv kernel).  The
+    modality mask of `feat` is not applied: both call sites multiply the result's consumers by that mask anyway."""
+    t = feat.t
+    if not (GEMM_1X1 and t.is_cuda and conv.kernel_size[0] == 1 and conv.stride[0] == 1):
+        return run_conv(conv, feat, norm=False)
+    B, D, H, W, C = t.shape
+    y = ops.linear(t.view(B, D * H * W, C), conv.weight, conv.bias, t.dtype == torch.bfloat16)
+    return Feat(y.view(B, D, H, W, conv.out_channels))
+
+
 class general_conv3d_prenorm(nn.Module):
     """InstanceNorm -> LeakyReLU(0.2) -> Conv3d, one fused kernel (reference blocks.py:300-316).
     Note the reference builds InstanceNorm3d(out_ch) but applies it to the in_ch input; with

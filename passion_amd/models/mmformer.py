@@ -24,7 +24,7 @@ import torch.nn.functional as F
 from .. import _lib as L
 from .. import ops
 from ..utils import criterions as crit
-from .blocks import Feat, fusion_prenorm, general_conv3d_prenorm, run_conv
+from .blocks import Feat, fusion_prenorm, general_conv3d_prenorm, run_conv, run_pointwise
 
 basic_dims = 8
 transformer_basic_dims = 512
@@ -48,6 +48,11 @@ INTRA_STREAMS = _os.environ.get("PASSION_INTRA_STREAMS", "1") != "0"   # intra-m
 
 
 def _up2(f):
+    """x2 trilinear; the result goes into a pre-norm conv, so the statistics come along (one pass, ops.upsample_with_stats)"""
+    from .blocks import FUSE_STATS
+    if FUSE_STATS and f.t.is_cuda:
+        y, st = ops.upsample_with_stats(f.t, 2)
+        return Feat(y, f.mask, f.mask_col, _stats=[st])
     return Feat(ops.upsample(f.t, 2), f.mask, f.mask_col)
 
 
@@ -341,7 +346,7 @@ class Model(nn.Module):
                     for i, t in enumerate(intra)]
         tok = self._transformer(self.multimodal_transformer, torch.cat(toks, 1), pos_cat)
         vol = tok.to(self.compute_dtype).contiguous().view(P * B, p, p, p, self.token_dim * num_modals)
-        return run_conv(self.multimodal_decode_conv, Feat(vol), norm=False, want_stats=True)
+        return run_pointwise(self.multimodal_decode_conv, Feat(vol))
 
     def _enc_streams(self, dev):
         cache = self.__dict__.setdefault("_streams_dev", {})
@@ -394,7 +399,7 @@ class Model(nn.Module):
             m = MODALS[i]
             own5 = encs[i][4].with_mask(mask, i) if idt else encs[i][4]
             pp = own5.t.shape[1]
-            tok = run_conv(getattr(self, f"{m}_encode_conv"), own5, norm=False).t.view(B, pp ** 3, self.token_dim)
+            tok = run_pointwise(getattr(self, f"{m}_encode_conv"), own5).t.view(B, pp ** 3, self.token_dim)
             tok = self._transformer(getattr(self, f"{m}_transformer"), tok, pos[i])
             return tok * mask[:, i].view(B, 1, 1).to(tok.dtype)
 

@@ -201,6 +201,8 @@ def linear(x, weight, bias, bf16):
         b = bf16_param(bias).detach() if bias is not None else None
     else:
         w, b = weight, (bias.detach() if bias is not None else None)
+    if w.dim() > 2:              # the (Cout, Cin, 1, 1, 1) weight of a 1x1x1 conv run as a token GEMM
+        w = w.view(w.shape[0], -1)
     return LinearFn.apply(x, w, b, bias)
 
 
@@ -378,18 +380,27 @@ class UpsampleFn(torch.autograd.Function):
     """nn.Upsample(scale_factor=k, mode='trilinear', align_corners=True) on (B,D,H,W,C)."""
 
     @staticmethod
-    def forward(ctx, x, k):
+    def forward(ctx, x, k, want_stats=False, eps=1e-5):
         L.require_gpu(x)
         x = x.contiguous()
         B, D, H, W, C = x.shape
         y = torch.empty(B, D * k, H * k, W * k, C, dtype=x.dtype, device=x.device)
+        ctx.k, ctx.shape = k, (B, D, H, W, C)
+        if want_stats:       # the InstanceNorm statistics of y from the same pass (the next conv normalises y in its loader)
+            st = torch.empty(B, C, 2, dtype=torch.float32, device=x.device)
+            L.check(L.load().passion_upsample_fwd_stats(_p(x), _p(y), L.dtype_code(x.dtype), B, D, H, W, C, k, _p(st), eps,
+                                                        L.stream_ptr()), "passion_upsample_fwd_stats")
+            ctx.mark_non_differentiable(st)
+            ctx.set_materialize_grads(False)
+            return y, st
         L.check(L.load().passion_upsample_fwd(_p(x), _p(y), L.dtype_code(x.dtype), B, D, H, W, C, k,
                                               L.stream_ptr()), "passion_upsample_fwd")
-        ctx.k, ctx.shape = k, (B, D, H, W, C)
         return y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, _dst=None):
+        if dy is None:
+            return None, None, None, None
         B, D, H, W, C = ctx.shape
         dy = dy.contiguous()
         dx = torch.empty(B, D, H, W, C, dtype=dy.dtype, device=dy.device)
@@ -398,11 +409,16 @@ class UpsampleFn(torch.autograd.Function):
         scratch = torch.empty(ns, dtype=torch.float32, device=dy.device) if ns else None
         L.check(lib.passion_upsample_bwd(_p(dy), _p(dx), L.dtype_code(dy.dtype), B, D, H, W, C,
                                          ctx.k, _p(scratch), L.stream_ptr()), "passion_upsample_bwd")
-        return dx, None
+        return dx, None, None, None
 
 
 def upsample(x, k):
     return x if k == 1 else UpsampleFn.apply(x, k)
+
+
+def upsample_with_stats(x, k, eps=1e-5):
+    """-> (upsampled tensor, its InstanceNorm statistics (B,C,2))"""
+    return UpsampleFn.apply(x, k, True, eps)
 
 
 # ------------------------------------------------------------------------------------------------

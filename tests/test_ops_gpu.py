@@ -586,7 +586,9 @@ FUSED_STATS_CASES = [
     ([64], 64, 3, 1, 1, (8, 8, 8), torch.bfloat16, False, "lean kernel epilogue, 8^3"),
     ([32, 32], 32, 1, 1, 0, (16, 16, 16), torch.bfloat16, False, "lean 1x1x1"),
     ([128], 128, 3, 1, 1, (8, 8, 8), torch.bfloat16, False, "lean, several row-tile groups"),
-    ([8], 16, 3, 2, 1, (16, 16, 16), torch.bfloat16, False, "stride 2: statistics kernels after the conv"),
+    ([8], 16, 3, 2, 1, (16, 16, 16), torch.bfloat16, False, "stride 2: general bf16 kernel epilogue"),
+    ([16], 32, 3, 2, 1, (64, 64, 64), torch.bfloat16, False, "stride 2, 1024 bricks per sample: two-level fold"),
+    ([8], 8, 3, 2, 1, (10, 12, 20), torch.bfloat16, False, "stride 2, ragged bricks"),
     ([8], 8, 3, 1, 1, (10, 12, 20), torch.bfloat16, False, "ragged bricks: statistics kernels after the conv"),
     ([8], 8, 3, 1, 1, (8, 8, 16), torch.float32, False, "f32 storage: statistics kernels after the conv"),
 ]
@@ -628,3 +630,29 @@ def test_conv_forward_leaves_the_statistics_of_its_output(case):
     y3, _ = ops.conv_block([ops.SegIn(x, stats=ops.instnorm_stats(x.detach())) for x in xg], wg, bias, D, H, W, want_stats=True, **kw)
     y3.float().square().sum().backward()
     assert wg.grad is not None and all(x.grad is not None for x in xg)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32], ids=["bf16", "f32"])
+@pytest.mark.parametrize("shape", [(2, 8, 8, 8, 16), (1, 16, 16, 16, 8), (3, 4, 6, 5, 64), (1, 32, 32, 32, 16), (2, 3, 3, 3, 4)])
+def test_upsample_forward_leaves_the_statistics_of_its_output(shape, dtype):
+    """passion_upsample_fwd_stats: y bit-identical to passion_upsample_fwd, statistics = passion_instnorm_stats(y), repeatable"""
+    from passion_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(sum(shape))
+    x = (torch.randn(*shape, generator=g) * 1.5 - 0.4).to(dev, dtype)
+    y0 = ops.upsample(x, 2)
+    y1, st = ops.upsample_with_stats(x, 2)
+    assert torch.equal(y0, y1)
+    want = ops.instnorm_stats(y0)
+    std = 1.0 / want[..., 1]
+    assert float(((st[..., 0] - want[..., 0]).abs() / (std + want[..., 0].abs())).max()) < 2e-5
+    assert float(((st[..., 1] - want[..., 1]).abs() / want[..., 1]).max()) < 1e-4
+    for _ in range(3):
+        y2, st2 = ops.upsample_with_stats(x, 2)
+        assert torch.equal(st2, st) and torch.equal(y2, y0)
+    xg = x.clone().requires_grad_(True)
+    y3, _ = ops.upsample_with_stats(xg, 2)
+    y3.float().sum().backward()
+    xr = x.clone().requires_grad_(True)
+    ops.upsample(xr, 2).float().sum().backward()
+    assert torch.equal(xg.grad, xr.grad)

@@ -7,7 +7,9 @@ REPS=${REPS:-3}
 for r in $(seq 1 $REPS); do
   for c in "${cfgs[@]}"; do
     label=${c%%:*}; envs=${c#*:}
-    v=$(env $envs timeout 900 python bench.py --no-cpu-baseline --no-roofline --steps ${STEPS:-150} "$@" 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'])")
-    echo "$label rep$r: $v"
+    env $envs timeout 900 python bench.py --no-cpu-baseline --no-roofline --steps ${STEPS:-150} "$@" > /tmp/ab_out.txt 2> /tmp/ab_err.txt
+    v=$(tail -1 /tmp/ab_out.txt | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'])")
+    h=$(grep "host enqueue" /tmp/ab_err.txt | tail -1 | sed 's/\[bench\] //')
+    echo "$label rep$r: $v | $h"
   done
 done
