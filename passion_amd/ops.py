@@ -146,6 +146,17 @@ def recast_stale():
     return len(src)
 
 
+def bf16_image(p):
+    """the (detached) bf16 image of the f32 parameter `p`, registered on first use and refreshed by recast_stale"""
+    ent = _CAST_REGISTRY.get(id(p))
+    if ent is None or ent[0]() is not p:
+        import weakref
+        ent = _CAST_REGISTRY[id(p)] = [weakref.ref(p), None, None]
+    if ent[1] is None or ent[2] != (p.data_ptr(), p._version):
+        recast_stale()
+    return ent[1]
+
+
 def bf16_param(p):
     """bf16 image of the f32 parameter `p` (registered on first use; refreshed by recast_stale at the top of forward)"""
     ent = _CAST_REGISTRY.get(id(p))
@@ -161,13 +172,14 @@ class LinearFn(torch.autograd.Function):
     """y = x W^T + b for the token GEMMs (reference mmformer.py nn.Linear): the GEMMs stay on torch (hipBLASLt),
     the bias gradient is the library's fixed-order column sum (passion_colsum) instead of torch's `grad.sum(0)`, whose reduce
     kernel does not repeat -- and drops contributions -- while the encoders' side streams keep the GPU busy
-    (tools/linear_bias_determinism.py).  w / b are the operands in the compute dtype (bf16 images or the f32 parameters);
-    the bias gradient comes back in f32."""
+    (tools/linear_bias_determinism.py).  weight / bias are the f32 parameters (they receive f32 gradients: the weight
+    gradient GEMM writes f32 directly where torch can, no bf16 rounding + cast pass); w / b the operands in the compute
+    dtype (their kept bf16 images, or the parameters themselves)."""
 
     @staticmethod
-    def forward(ctx, x, w, b, bias_param):
+    def forward(ctx, x, weight, bias, w, b):
         ctx.save_for_backward(x, w)
-        ctx.has_bias = b is not None
+        ctx.wshape = weight.shape
         return F.linear(x, w, b)
 
     @staticmethod
@@ -178,9 +190,29 @@ class LinearFn(torch.autograd.Function):
             g2 = g2.contiguous()
         x2 = x.reshape(-1, x.shape[-1])
         dx = torch.mm(g2, w).view(x.shape) if ctx.needs_input_grad[0] else None
-        dw = torch.mm(g2.t(), x2) if ctx.needs_input_grad[1] else None
-        db = colsum(g2) if ctx.has_bias and ctx.needs_input_grad[3] else None
-        return dx, dw, None, db
+        dw = None
+        if ctx.needs_input_grad[1]:
+            dw = _mm_f32(g2.t(), x2).view(ctx.wshape)
+        db = colsum(g2) if ctx.needs_input_grad[2] else None
+        return dx, dw, db, None, None
+
+
+_MM_F32 = [None]      # torch.mm(bf16, bf16, out_dtype=f32) exists on this build?
+
+
+def _mm_f32(a, b):
+    """a @ b with an f32 result (the weight gradient of a token GEMM)"""
+    if a.dtype == torch.float32:
+        return torch.mm(a, b)
+    if _MM_F32[0] is None:
+        try:
+            torch.mm(a[:, :8].contiguous()[:8], b[:8], out_dtype=torch.float32)
+            _MM_F32[0] = True
+        except Exception:
+            _MM_F32[0] = False
+    if _MM_F32[0]:
+        return torch.mm(a, b, out_dtype=torch.float32)
+    return torch.mm(a, b).float()
 
 
 def colsum(g2):
@@ -195,15 +227,15 @@ def colsum(g2):
 
 
 def linear(x, weight, bias, bf16):
-    """nn.Linear forward for a token GEMM: bf16 -> the kept bf16 operand images (bf16_param), else the f32 parameters"""
+    """nn.Linear forward for a token GEMM: bf16 -> the kept bf16 operand images (refreshed by recast_stale), else the f32
+    parameters"""
     if bf16:
-        w = bf16_param(weight)
-        b = bf16_param(bias).detach() if bias is not None else None
+        w, b = bf16_image(weight), (bf16_image(bias) if bias is not None else None)
     else:
-        w, b = weight, (bias.detach() if bias is not None else None)
+        w, b = weight.detach(), (bias.detach() if bias is not None else None)
     if w.dim() > 2:              # the (Cout, Cin, 1, 1, 1) weight of a 1x1x1 conv run as a token GEMM
         w = w.view(w.shape[0], -1)
-    return LinearFn.apply(x, w, b, bias)
+    return LinearFn.apply(x, weight, bias, w, b)
 
 
 def pack_weight(weight, cache=None):
