@@ -96,6 +96,17 @@ int passion_conv3d_fwd(const passion_conv_desc_t* d, const float* packed, const 
  * per-stream region. */
 int passion_conv3d_fwd_stats(const passion_conv_desc_t* d, const float* packed, const float* bias,
                              const void* residual, void* y, float* stats, float eps, void* stream);
+/* Grouped launches along the batch: G <= 4 weight sets, sample b uses set b / (B / G) -- the four modality encoders of
+ * mmformer (code/models/mmformer.py:385-388: four Encoder() instances of identical shape, one per modality) as ONE launch
+ * per layer over the stacked batch [flair | t1ce | t1 | t2].  packed[g] / bias[g]: the sets' packed workspaces / biases
+ * (bias may be NULL); one launch needs the workspaces equally spaced (packed[g + 1] - packed[g] constant, a multiple of 4
+ * floats) and bf16 tensors -- anything else runs set by set.  Segments must not be batched passes (bmod = 0).
+ * Backward: dW[g] receives [dweight | dbias] of set g (Cout*Cin*k^3 + Cout floats, overwritten); NULL = no weight gradients. */
+int passion_conv3d_fwd_grouped(const passion_conv_desc_t* d, int G, const float* const* packed,
+                               const float* const* bias, const void* residual, void* y, float* stats, float eps,
+                               void* stream);
+int passion_conv3d_bwd_grouped(const passion_conv_desc_t* d, int G, const float* const* packed, const void* dy,
+                               float* const* dW, float* sums, void* stream);
 /* Backward of the whole block.  dy: [B][Vout][Cout].
  *  dweight: f32 [Cout][Cin][k^3] and dbias f32 [Cout] are OVERWRITTEN (either may be NULL).  They are produced
  *  without atomics: every workgroup stores its partial sums into its own slot of a slab inside `scratch`,

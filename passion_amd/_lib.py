@@ -50,6 +50,10 @@ SIGNATURES = {
                                          c_void_p, c_float, c_void_p]),
     "passion_conv3d_bwd": (c_int, [POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p,
                                    c_void_p, c_void_p]),
+    "passion_conv3d_fwd_grouped": (c_int, [POINTER(ConvDesc), c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                           c_void_p, c_float, c_void_p]),
+    "passion_conv3d_bwd_grouped": (c_int, [POINTER(ConvDesc), c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                           c_void_p]),
     "passion_conv3d_bwd_phase": (c_int, [POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float,
                                          c_int, c_int, c_void_p]),
     "passion_halo_pack": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int64, c_int, c_void_p]),
@@ -184,7 +188,8 @@ def host():
     spec.loader.exec_module(mod)
     addr = lambda name: ctypes.cast(getattr(lib, name), c_void_p).value
     mod.bind(addr("passion_conv3d_fwd"), addr("passion_conv3d_bwd"), addr("passion_conv_bwd_scratch_floats"),
-             addr("passion_instnorm_stats"), addr("passion_instnorm_scratch_doubles"), addr("passion_conv3d_fwd_stats"))
+             addr("passion_instnorm_stats"), addr("passion_instnorm_scratch_doubles"), addr("passion_conv3d_fwd_stats"),
+             addr("passion_conv3d_fwd_grouped"), addr("passion_conv3d_bwd_grouped"))
     _host = mod
     return mod
 

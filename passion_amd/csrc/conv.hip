@@ -551,6 +551,30 @@ __global__ __launch_bounds__(256) void reduce_parts_kernel(const float* __restri
     }
 }
 
+// The same fold for a grouped launch (blockIdx.y = weight set): group g's slots are the Rg consecutive ones from g * Rg on, its
+// result goes to outs.p[g].
+struct RedOuts { float* p[PASSION_MAX_GROUPS]; };
+__global__ __launch_bounds__(256) void reduce_parts_grouped_kernel(const float* __restrict__ part, int Rg, long n, long stride, RedOuts outs,
+                                                                   float* __restrict__ zero_ptr = nullptr, long zero_n = 0) {
+    __shared__ float red[16][17];
+    if (blockIdx.y == 0)
+        for (long z = (long)blockIdx.x * 256 + threadIdx.x; z < zero_n; z += (long)gridDim.x * 256) zero_ptr[z] = 0.f;
+    const int li = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    const long i = (long)blockIdx.x * 16 + li;
+    const float* pg = part + (long)blockIdx.y * Rg * stride;
+    float a = 0.f;
+    if (i < n)
+        for (int r = sl; r < Rg; r += 16) a += pg[(long)r * stride + i];
+    red[sl][li] = a;
+    __syncthreads();
+    if (sl == 0 && i < n) {
+        float t = 0.f;
+#pragma unroll
+        for (int k2 = 0; k2 < 16; ++k2) t += red[k2][li];
+        outs.p[blockIdx.y][i] = t;
+    }
+}
+
 // weight [Cout][Cin][ntap] -> fwd image [tap][Cin][CoutPad] and dgrad image [tap][Cout][CinPad]
 __global__ void pack_weight_kernel(const float* __restrict__ w, int Cin, int Cout, int ntap, int CoutPad, int CinPad,
                                    float* __restrict__ fwd, float* __restrict__ dg) {
@@ -577,6 +601,8 @@ int fill_params(const passion_conv_desc_t* d, ConvK& k) {
     k.sums_fixed = 0; k.sums_float_only = 0;
     k.fst = FwdStats{nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0, 0.f, 0.0};
     k.fst_want = nullptr; k.fst_eps = 0.f;
+    k.bgroup = 0; k.wg_vec = 0;
+    for (int g = 0; g < PASSION_MAX_GROUPS; ++g) k.biasg[g] = nullptr;
     k.bd_rows = 0; k.bd_k8 = 0;
     k.y_f32 = 0;
     if (d->ksize != 1 && d->ksize != 3) return -1002;
@@ -873,12 +899,24 @@ extern "C" int passion_conv_pack_weights(int n, const float* const* weights, con
     return 0;
 }
 
+// A grouped launch (include/passion_hip.h, passion_conv3d_fwd_grouped): G weight sets, sample b uses set b / (B / G).  `stride`
+// = floats between the packed workspaces of consecutive sets; bias[g] / dW[g] = that set's bias / [dW | dbias] output.
+struct GroupArgs { int G; long stride; const float* const* bias; float* const* dW; };
+
+static void set_groups(ConvK& k, const GroupArgs* ga) {
+    if (!ga) return;
+    k.bgroup = k.B / ga->G;
+    k.wg_vec = ga->stride / 4;                     // floats -> 16-byte vectors of the bf16 images
+    for (int g = 0; g < ga->G; ++g) k.biasg[g] = ga->bias ? ga->bias[g] : nullptr;
+}
+
 static int conv3d_fwd_impl(const passion_conv_desc_t* d, const float* packed, const float* bias, const void* residual, void* y,
-                           float* stats_out, float eps, void* stream) {
+                           float* stats_out, float eps, void* stream, const GroupArgs* ga = nullptr) {
     ConvK k;
     int rc = fill_params(d, k);
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
+    set_groups(k, ga);
     k.wpack = packed; k.Mpad = pad16(k.Cout); k.bias = bias; k.residual = residual; k.y = y;
     k.fst_want = stats_out; k.fst_eps = eps;
     k.tilesD = cdiv(k.Do, TD); k.tilesH = cdiv(k.Ho, TH); k.tilesW = cdiv(k.Wo, TW);
@@ -955,11 +993,15 @@ Companion* companion(hipStream_t caller) {
 // sums of ALL ranks before the gradient can be finished: phase 1 stops after the dgrad with the sums folded into
 // sums[0 .. 2 B Cin) (the caller all-reduces them), phase 2 runs only the finish with 1 / V scaled by vscale = V_local / V_global
 // and the mean-subtraction terms restricted to the depth planes [dwin_lo, dwin_hi) the rank owns.
+// ga / parts: grouped launches (passion_conv3d_bwd_grouped).  parts bit 0: weight (+ bias) gradient, bit 1: input gradient.
 static int conv3d_bwd_impl(const passion_conv_desc_t* d, const float* packed, const void* dy, float* dweight,
-                           float* dbias, float* sums, void* stream, int phase, float vscale, int dwin_lo, int dwin_hi) {
+                           float* dbias, float* sums, void* stream, int phase, float vscale, int dwin_lo, int dwin_hi,
+                           const GroupArgs* ga = nullptr, int parts = 3) {
     ConvK k;
     int rc = fill_params(d, k);
     if (rc) return rc;
+    set_groups(k, ga);
+    if (ga) { dweight = ga->dW ? ga->dW[0] : nullptr; dbias = dweight ? dweight + (long)k.Cout * k.Cin * d->ksize * d->ksize * d->ksize : nullptr; }
     if (phase != 0) {
         for (int s = 0; s < k.nseg; ++s) if (k.seg[s].bmod > 0) return -1019;       // batched passes are not sharded
     }
@@ -983,7 +1025,7 @@ static int conv3d_bwd_impl(const passion_conv_desc_t* d, const float* packed, co
     float* zsums = (need_norm && sums && !comp) ? sums : nullptr;
     const long zn = zsums ? (long)2 * k.B * k.Cin * SUMS_REP : 0;
     // ---- wgrad (+ bias grad): per-workgroup partial slabs, then a fixed-order fold (no atomics, deterministic) ----
-    if (phase != 2 && (dweight || dbias)) {
+    if (phase != 2 && (dweight || dbias) && (parts & 1)) {
         k.Mpad = pad16(k.Cout);
         const WgPlan w = plan_wgrad(k, d);
         const long nW = (long)k.Cout * k.Cin * nt;
@@ -995,7 +1037,10 @@ static int conv3d_bwd_impl(const passion_conv_desc_t* d, const float* packed, co
                            2.0 * k.B * k.Do * k.Ho * k.Wo * (double)k.Cout * k.Cin * nt, st);
             float* dWs = dweight ? wslab : nullptr;
             float* dbs = dbias ? bslab : nullptr;
-            if (w.bf16 && d->y_dtype == PASSION_F32) {
+            if (ga) {                                // grouped: the lean kernel (slots in sample order), checked by the caller
+                rc = launch_wgrad_lean(k, d->ksize, d->stride, w.MT, w.gx, w.gy, dWs, dbs, st);
+                if (rc > 0) rc = -1014;
+            } else if (w.bf16 && d->y_dtype == PASSION_F32) {
                 k.y_f32 = 1;
                 rc = launch_wgrad_lean(k, d->ksize, d->stride, w.MT, w.gx, w.gy, dWs, dbs, st);
                 k.y_f32 = 0;
@@ -1015,6 +1060,16 @@ static int conv3d_bwd_impl(const passion_conv_desc_t* d, const float* packed, co
                 rc = -1007;
             if (rc) return rc;
         }
+        if (ga) {                                    // one fold per weight set: Rg = its samples x workgroups per sample
+            const int tiles_per_b = k.tilesD * k.tilesH * k.tilesW;
+            const int wgs_per_b = (tiles_per_b + k.per - 1) / k.per;
+            RedOuts ro;
+            for (int g = 0; g < PASSION_MAX_GROUPS; ++g) ro.p[g] = g < ga->G ? ga->dW[g] : nullptr;
+            hipLaunchKernelGGL(reduce_parts_grouped_kernel, dim3((unsigned)((k.wslot + 15) / 16), ga->G), dim3(256), 0, st, wslab,
+                               k.bgroup * wgs_per_b, k.wslot, k.wslot, ro, zsums, zn);
+            LAUNCH_RET();
+            sums_cleared = zsums != nullptr;
+        } else
         if (dweight && dbias == dweight + nW) {      // caller keeps [dW | dbias] in one buffer: one fold for both
             hipLaunchKernelGGL(reduce_parts_kernel, dim3((unsigned)((k.wslot + 15) / 16)), dim3(256), 0, st, wslab, w.gx, k.wslot,
                                k.wslot, dweight, zsums, zn);
@@ -1038,7 +1093,7 @@ static int conv3d_bwd_impl(const passion_conv_desc_t* d, const float* packed, co
         st = caller_st;
     }
     // ---- dgrad ----
-    if (!need_dx) return 0;
+    if (!need_dx || !(parts & 2)) return 0;
     if (k.Cin % 4) return -1008;
     for (int s = 0; s < k.nseg; ++s) if (k.seg[s].C % 4) return -1008;
     if (need_norm) {
@@ -1192,6 +1247,106 @@ static int conv3d_bwd_impl(const passion_conv_desc_t* d, const float* packed, co
         LAUNCH_RET();
     }
     if (comp) HIP_RET(hipStreamWaitEvent(caller_st, comp->done, 0));     // join
+    return 0;
+}
+
+
+// ---- grouped launches: G weight sets over one batch (samples b / (B / G) -> set) ------------------------------------------
+namespace {
+// the descriptor of group g's samples alone (the per-group fallback of the kernels that take one weight set per launch)
+passion_conv_desc_t sub_desc(const passion_conv_desc_t* d, int g, int bg) {
+    passion_conv_desc_t s = *d;
+    s.B = bg;
+    const long es = d->x_dtype == PASSION_BF16 ? 2 : 4;
+    for (int i = 0; i < d->nseg; ++i) {
+        passion_seg_t& sg = s.seg[i];
+        const long off = (long)g * bg;
+        sg.x = static_cast<const char*>(sg.x) + off * sg.bstride * es;
+        if (sg.stats) sg.stats += off * sg.C * 2;
+        if (sg.mask) sg.mask += off * sg.mask_ld;
+        if (sg.dx) sg.dx = static_cast<char*>(sg.dx) + off * sg.bstride * es;
+    }
+    return s;
+}
+int check_groups(const passion_conv_desc_t* d, int G) {
+    if (!d || G < 1 || G > PASSION_MAX_GROUPS || d->B % G) return -1016;
+    for (int i = 0; i < d->nseg; ++i) if (d->seg[i].bmod > 0) return -1016;      // batched passes are not grouped
+    return 0;
+}
+bool uniform_stride(const float* const* packed, int G, long& stride) {
+    stride = G > 1 ? packed[1] - packed[0] : 0;
+    for (int g = 1; g < G; ++g) if (packed[g] - packed[g - 1] != stride) return false;
+    return G == 1 || (stride > 0 && stride % 4 == 0);
+}
+}  // namespace
+
+extern "C" int passion_conv3d_fwd_grouped(const passion_conv_desc_t* d, int G, const float* const* packed, const float* const* bias,
+                                          const void* residual, void* y, float* stats, float eps, void* stream) {
+    int rc = check_groups(d, G);
+    if (rc) return rc;
+    if (G == 1) return conv3d_fwd_impl(d, packed[0], bias ? bias[0] : nullptr, residual, y, stats, eps, stream);
+    ConvK k;
+    rc = fill_params(d, k);
+    if (rc) return rc;
+    long stride = 0;
+    const bool native = d->x_dtype == PASSION_BF16 && d->y_dtype == PASSION_BF16 && bf16_eligible(k, false) && !g_passion_force_f32_mfma &&
+                        uniform_stride(packed, G, stride);
+    if (native) {
+        GroupArgs ga{G, stride, bias, nullptr};
+        return conv3d_fwd_impl(d, packed[0], bias ? bias[0] : nullptr, residual, y, stats, eps, stream, &ga);
+    }
+    const int bg = d->B / G;
+    const long ys = d->y_dtype == PASSION_BF16 ? 2 : 4;
+    const long vout = (long)k.Do * k.Ho * k.Wo * k.Cout;
+    for (int g = 0; g < G; ++g) {
+        const passion_conv_desc_t s = sub_desc(d, g, bg);
+        const long off = (long)g * bg * vout;
+        rc = conv3d_fwd_impl(&s, packed[g], bias ? bias[g] : nullptr, residual ? static_cast<const char*>(residual) + off * ys : nullptr,
+                             static_cast<char*>(y) + off * ys, stats ? stats + (long)g * bg * k.Cout * 2 : nullptr, eps, stream);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+extern "C" int passion_conv3d_bwd_grouped(const passion_conv_desc_t* d, int G, const float* const* packed, const void* dy,
+                                          float* const* dW, float* sums, void* stream) {
+    int rc = check_groups(d, G);
+    if (rc) return rc;
+    ConvK k;
+    rc = fill_params(d, k);
+    if (rc) return rc;
+    const int nt = d->ksize * d->ksize * d->ksize;
+    const long nW = (long)k.Cout * k.Cin * nt;
+    if (G == 1) return conv3d_bwd_impl(d, packed[0], dy, dW ? dW[0] : nullptr, dW ? dW[0] + nW : nullptr, sums, stream, 0, 1.0f, 0, d->D);
+    long stride = 0;
+    const bool bf16 = d->x_dtype == PASSION_BF16 && d->y_dtype == PASSION_BF16 && !g_passion_force_f32_mfma && uniform_stride(packed, G, stride);
+    const bool native_dgrad = bf16 && bf16_eligible(k, true);
+    k.tilesD = cdiv(k.Do, TD); k.tilesH = cdiv(k.Ho, TH); k.tilesW = cdiv(k.Wo, TW);
+    const WgPlan w = plan_wgrad(k, d);
+    const bool native_wgrad = bf16 && dW && w.bf16 && pconv::g_conv_lean && wgrad_bf16_chunk(k, d->ksize, d->stride) != 16 &&
+                              !(k.Cin == 1) && wgrad_lean_covers(k, d->ksize, d->stride, w.MT, w.gx, w.gy);
+    GroupArgs ga{G, stride, nullptr, dW};
+    const int bg = d->B / G;
+    const long ys = d->y_dtype == PASSION_BF16 ? 2 : 4;
+    const long vout = (long)k.Do * k.Ho * k.Wo * k.Cout;
+    if (native_dgrad) {
+        if (native_wgrad || !dW) return conv3d_bwd_impl(d, packed[0], dy, nullptr, nullptr, sums, stream, 0, 1.0f, 0, d->D, &ga, dW ? 3 : 2);
+        for (int g = 0; g < G; ++g) {                 // weight gradients set by set (general kernels), then ONE input-gradient pass
+            passion_conv_desc_t s = sub_desc(d, g, bg);
+            for (int i = 0; i < s.nseg; ++i) s.seg[i].dx = nullptr;
+            rc = conv3d_bwd_impl(&s, packed[g], static_cast<const char*>(dy) + (long)g * bg * vout * ys, dW[g], dW[g] + nW, sums, stream, 0, 1.0f,
+                                 0, d->D, nullptr, 1);
+            if (rc) return rc;
+        }
+        GroupArgs gd{G, stride, nullptr, nullptr};
+        return conv3d_bwd_impl(d, packed[0], dy, nullptr, nullptr, sums, stream, 0, 1.0f, 0, d->D, &gd, 2);
+    }
+    for (int g = 0; g < G; ++g) {
+        const passion_conv_desc_t s = sub_desc(d, g, bg);
+        rc = conv3d_bwd_impl(&s, packed[g], static_cast<const char*>(dy) + (long)g * bg * vout * ys, dW ? dW[g] : nullptr,
+                             dW ? dW[g] + nW : nullptr, sums, stream, 0, 1.0f, 0, d->D);
+        if (rc) return rc;
+    }
     return 0;
 }
 

@@ -143,7 +143,7 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(ConvK p) {
     const int Sd = DG ? p.Do : p.Di, Sh = DG ? p.Ho : p.Hi, Sw = DG ? p.Wo : p.Wi;
     int K8 = pad8(p.Cout) / 8;                                      // 8-channel blocks along K in the packed image
     if (!DG) { K8 = 0; for (int s2 = 0; s2 < p.nseg; ++s2) K8 += (p.seg[s2].C + 7) / 8; }
-    const bf16x8* wp = reinterpret_cast<const bf16x8*>(p.wpack);
+    const bf16x8* wp = reinterpret_cast<const bf16x8*>(p.wpack) + wvec_of(p, b);      // grouped launch: this sample's weight set
 
     f32x4 acc[MT][4];
 #pragma unroll

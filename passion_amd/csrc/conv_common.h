@@ -9,6 +9,7 @@
 
 namespace pconv {
 
+constexpr int PASSION_MAX_GROUPS = 4;
 constexpr int SUMS_REP = 256;           // replicas of the InstanceNorm-backward sums (atomic contention): one-brick-per-workgroup kernels
 constexpr int SUMS_SLOTS = 1024;         // capacity of the sums region in replicas: the marching dgrad (conv_march.hip) gives every workgroup of a sample its own slot
 constexpr int SUMS_REP_LEAN = 16;       // persistent kernels add once per workgroup: few replicas, folded by the finish kernel itself
@@ -66,6 +67,12 @@ struct ConvK {
     int bd_rows, bd_k8;    // lean dgrad with block-diagonal weights (batched passes summed first, conv.hip): K block gb = (segment
                            // gb / bd_k8, block gb % bd_k8 of the real Cout); rows of another segment (bd_rows each) read zero weights
     int dbg;               // developer timing switch (PASSION_CONV_DBG): bit0 skip staging, bit1 skip MFMA loop, bit2 skip epilogue
+    // Grouped launch along the batch (the four modality encoders of mmformer as ONE launch per layer): samples b with the same
+    // b / bgroup share a weight set; group g's packed bf16 images start wg_vec 16-byte vectors after group g - 1's, its bias is
+    // biasg[g].  0 = one weight set for the whole batch.
+    int bgroup;
+    long wg_vec;
+    const float* biasg[PASSION_MAX_GROUPS];
     FwdStats fst;          // forward: statistics of y from the kernel's epilogue (fst.stats != nullptr)
     float* fst_want;       // forward: the caller wants statistics of y here (a launcher that fuses them moves it to fst.stats)
     float fst_eps;
@@ -93,6 +100,7 @@ bool lean_covers(const ConvK& k, int stride, bool dgrad);
 int launch_conv_march(ConvK& k, int ksize, int stride, int mode, const void* packed_bf16, hipStream_t st);   // conv_march.hip
 extern int g_conv_march;
 int launch_wgrad_lean(ConvK& k, int ksize, int stride, int MT, int gx, int gy, float* dWslab, float* dbslab, hipStream_t st);   // conv_wgrad_lean.hip
+bool wgrad_lean_covers(const ConvK& k, int ksize, int stride, int MT, int gx, int gy);
 int launch_wgrad_c1(ConvK& k, int ksize, int stride, int gx, int gy, float* dWslab, float* dbslab, hipStream_t st);   // first layer, Cin = 1
 extern int g_conv_lean;
 int launch_wgrad_bf16(ConvK& k, int ksize, int stride, int MT, int gx, int gy, float* dWslab, float* dbslab, hipStream_t st);
@@ -107,6 +115,9 @@ __device__ __forceinline__ int xcd_swizzle(int i, int n) {
     const int n8 = n & ~7;
     return i < n8 ? (i & 7) * (n8 >> 3) + (i >> 3) : i;
 }
+
+struct ConvK;
+__device__ __forceinline__ const float* bias_of(const ConvK& p, int b);
 
 // One axis of a tap entry.  a < KS: regular tap; a == KS: low-side mirror term; a == KS+1: high-side.
 // Forward conv of stride S reads padded coordinate o*S + t - 1; 'reflect' maps -1 -> 1 and Sin -> Sin-2, so
@@ -126,6 +137,9 @@ __device__ __forceinline__ void axis_tap(int a, int il, int i0, int Sin, int hi_
     if (!valid) pos = 0;
 }
 
+
+__device__ __forceinline__ const float* bias_of(const ConvK& p, int b) { return p.bgroup ? p.biasg[b / p.bgroup] : p.bias; }
+__device__ __forceinline__ long wvec_of(const ConvK& p, int b) { return p.bgroup ? (long)(b / p.bgroup) * p.wg_vec : 0; }
 
 // End of a forward kernel with fused statistics.  wsum: LDS, [rows][2] partial sums of this workgroup for channels
 // row0 .. row0 + rows - 1 of sample b (already combined over the workgroup's threads); wq: workgroup index inside the sample.
@@ -243,6 +257,7 @@ __device__ __forceinline__ void epilogue_fwd(const ConvK& p, const f32x4 (&acc)[
                                              int od, int ow, const int (&oh4)[4], int kq) {
     TO* y = reinterpret_cast<TO*>(p.y);
     const TO* res = reinterpret_cast<const TO*>(p.residual);
+    const float* bias = bias_of(p, b);
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) {
         const int oh = oh4[nt];
@@ -253,7 +268,7 @@ __device__ __forceinline__ void epilogue_fwd(const ConvK& p, const f32x4 (&acc)[
             const int co = (mg * MT + mt) * 16 + kq * 4;
             if (co >= p.Cout) continue;
             f32x4 v = acc[mt][nt];
-            if (p.bias) v += load4(p.bias + co);
+            if (bias) v += load4(bias + co);
             if (res) v += load4(res + vox * p.Cout + co);
             store4(y + vox * p.Cout + co, v);
         }
@@ -268,6 +283,7 @@ __device__ __forceinline__ void epilogue_fwd_stats(const ConvK& p, const f32x4 (
                                                    int od, int ow, const int (&oh4)[4], int kq, int n, int wv, int tid) {
     bf16_t* y = reinterpret_cast<bf16_t*>(p.y);
     const bf16_t* res = reinterpret_cast<const bf16_t*>(p.residual);
+    const float* bias = bias_of(p, b);
     float s1[MT][4], s2[MT][4];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
@@ -283,7 +299,7 @@ __device__ __forceinline__ void epilogue_fwd_stats(const ConvK& p, const f32x4 (
             const int co = (mg * MT + mt) * 16 + kq * 4;
             if (co >= p.Cout) continue;
             f32x4 v = acc[mt][nt];
-            if (p.bias) v += load4(p.bias + co);
+            if (bias) v += load4(bias + co);
             if (res) v += load4(res + vox * p.Cout + co);
             unsigned pk[2];
             float rb[4];

@@ -128,12 +128,13 @@ __device__ __forceinline__ void conv_lean_body(const ConvK& p) {
     const int K8 = DG ? (p.Cout + 7) / 8 : p.Cin / 8;
     const int nchunk = (K8 + NC8 - 1) / NC8;
     const bool wres = p.wres != 0;
-    const bf16x8* wp = reinterpret_cast<const bf16x8*>(p.wpack);
+    const bf16x8* wp0 = reinterpret_cast<const bf16x8*>(p.wpack);
 
     const int tiles_per_b = p.tilesD * p.tilesH * p.tilesW;
     const int wgs_per_b = (tiles_per_b + p.per - 1) / p.per;
     const int bx = xcd_swizzle(blockIdx.x, gridDim.x);
     const int b = bx / wgs_per_b;
+    const bf16x8* wp = wp0 + wvec_of(p, b);                 // grouped launch: this sample's weight set
     // Brick schedule of this workgroup.  Forward: `per` consecutive bricks (measured best: 46 vs 54 us on the level-1
     // conv).  Dgrad: border bricks are several times more expensive (mirror taps), a workgroup that owns a whole border
     // row would set the kernel's duration -- so round i of the sample's bricks is [i*W, (i+1)*W), W = workgroups per
@@ -291,7 +292,7 @@ __device__ __forceinline__ void conv_lean_body(const ConvK& p) {
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
         const int co = (mg * MT + mt) * 16 + g * 4;
-        biasv[mt] = (!DG && p.bias && co < p.Cout) ? load4(p.bias + co) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        biasv[mt] = (!DG && bias_of(p, b) && co < p.Cout) ? load4(bias_of(p, b) + co) : (f32x4){0.f, 0.f, 0.f, 0.f};
     }
     const bool reflect_dg = DG && !PADOUT && (KS == 3) && (p.pad_mode == PASSION_PAD_REFLECT);
     constexpr int SHIFT = PADOUT ? 1 : 0;        // padded output coordinate -> position

@@ -184,7 +184,7 @@ __global__ __launch_bounds__(256) void conv_march_kernel(ConvK p, MarchP mp) {
 #pragma unroll
     for (int s = 0; s < NSTEP; ++s) {
         const int q = min(4 * s + g, G::Q - 1), tap = q / NB, blk = q % NB;
-        wfr[s] = gload<bf16x8>(reinterpret_cast<const bf16x8*>(p.wpack) + ((long)tap * K8 + blk) * p.Mpad + n);
+        wfr[s] = gload<bf16x8>(reinterpret_cast<const bf16x8*>(p.wpack) + wvec_of(p, b) + ((long)tap * K8 + blk) * p.Mpad + n);
         if (4 * s + g >= G::Q) wfr[s] = zero8();
     }
     // mask byte + statistics of the staged block
@@ -328,7 +328,7 @@ __global__ __launch_bounds__(256) void conv_march_kernel(ConvK p, MarchP mp) {
     for (int t = 0; t < TT; ++t) tile_on[t] = t < NT || __any((vmask >> t) & 1u);
 
     f32x4 biasv = {0.f, 0.f, 0.f, 0.f};
-    if (!DG && p.bias && g * 4 < p.Cout) biasv = load4(p.bias + g * 4);
+    if (!DG && bias_of(p, b) && g * 4 < p.Cout) biasv = load4(bias_of(p, b) + g * 4);
     const bool row_ok = g * 4 < (DG ? p.Cin : p.Cout);
     const float f_pos = emval, f_neg = e_st ? emval * p.slope : emval;       // LeakyReLU' x modality mask
     const int Wp = pad8(Sw + 2);

@@ -296,7 +296,7 @@ __global__ __launch_bounds__(256) void wgrad_lean_kernel(ConvK p, float* __restr
     }
     // ---- this workgroup's slot of the partial-sum slab (plain stores; reduce_parts_kernel folds the slots)
     if (dW && exist) {
-        float* slot = dW + (long)blockIdx.x * p.wslot;
+        float* slot = dW + (long)bx * p.wslot;          // slots in sample order (a grouped launch folds them per weight set)
 #pragma unroll
         for (int j = 0; j < NTW; ++j) {
             const int nt = (KSPLIT == 1) ? wv + 4 * j : j;
@@ -318,7 +318,7 @@ __global__ __launch_bounds__(256) void wgrad_lean_kernel(ConvK p, float* __restr
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int co = (mg * MT + mt) * 16 + g * 4 + r;
-                if (co < p.Cout) dbias[(long)blockIdx.x * p.wslot + co] = acc[mt][JB][r];
+                if (co < p.Cout) dbias[(long)bx * p.wslot + co] = acc[mt][JB][r];
             }
     }
 }
@@ -468,16 +468,20 @@ namespace pconv {
 
 // returns 0 = launched, < 0 = HIP error, 1 = shape not covered (caller uses conv_wgrad_bf16_kernel).
 // gx = slots of the partial slab = workgroups in x (spare ones flush zeros), gy = (8-channel blocks) x (row-tile groups)
-int launch_wgrad_lean(ConvK& k, int ksize, int stride, int MT, int gx, int gy, float* dW, float* db, hipStream_t st) {
-    if (stride != 1 || (k.Cout % 8 && !(k.y_f32 && k.Cout % 4 == 0 && k.Cout <= 8)) || gx < k.B) return 1;
-    if (!(k.slope >= 0.f && k.slope <= 1.f)) return 1;      // the loader's LeakyReLU is max(t, slope * t)
+bool wgrad_lean_covers(const ConvK& k, int ksize, int stride, int MT, int gx, int gy) {
+    if (stride != 1 || (k.Cout % 8 && !(k.y_f32 && k.Cout % 4 == 0 && k.Cout <= 8)) || gx < k.B) return false;
+    if (!(k.slope >= 0.f && k.slope <= 1.f)) return false;      // the loader's LeakyReLU is max(t, slope * t)
     int K8 = 0;
     for (int s = 0; s < k.nseg; ++s) {
-        if (k.seg[s].C % 8) return 1;
+        if (k.seg[s].C % 8) return false;
         K8 += k.seg[s].C / 8;
     }
+    return K8 * (pad16(k.Cout) / 16 / MT) == gy;       // else the plan was made for a different chunking
+}
+
+int launch_wgrad_lean(ConvK& k, int ksize, int stride, int MT, int gx, int gy, float* dW, float* db, hipStream_t st) {
+    if (!wgrad_lean_covers(k, ksize, stride, MT, gx, gy)) return 1;
     k.Mpad = pad16(k.Cout);
-    if (K8 * (k.Mpad / 16 / MT) != gy) return 1;       // the plan was made for a different chunking
     const int tiles_per_b = k.tilesD * k.tilesH * k.tilesW;
     const int wgs = gx / k.B;                          // workgroups per sample
     k.per = (tiles_per_b + wgs - 1) / wgs;

@@ -22,6 +22,8 @@ using OptT = std::optional<at::Tensor>;
 struct Abi {
     decltype(&passion_conv3d_fwd) conv_fwd = nullptr;
     decltype(&passion_conv3d_fwd_stats) conv_fwd_stats = nullptr;
+    decltype(&passion_conv3d_fwd_grouped) conv_fwd_grouped = nullptr;
+    decltype(&passion_conv3d_bwd_grouped) conv_bwd_grouped = nullptr;
     decltype(&passion_conv3d_bwd) conv_bwd = nullptr;
     decltype(&passion_conv_bwd_scratch_floats) conv_bwd_scratch = nullptr;
     decltype(&passion_instnorm_stats) stats = nullptr;
@@ -206,6 +208,129 @@ std::vector<at::Tensor> conv_block(const at::Tensor& weight, const OptT& bias, c
     return ConvBlockNode::apply(weight, bias, residual, at::TensorList(xs), std::move(cfg));
 }
 
+
+// The same block for G weight sets over one stacked batch (passion_conv3d_fwd_grouped: the four modality encoders as one launch
+// per layer).  weights / biases: G tensors each (biases may be empty); cfg.packed: the G packed workspaces back to back in ONE
+// tensor (equal spacing = one launch).
+struct GroupedConvNode : public torch::autograd::Function<GroupedConvNode> {
+    static variable_list forward(AutogradContext* ctx, at::TensorList weights, at::TensorList biases, const OptT& residual,
+                                 at::TensorList xs, ConvCfg cfg) {
+        const int G = (int)weights.size();
+        TORCH_CHECK(G >= 1 && G <= 4 && (biases.empty() || (int)biases.size() == G), "grouped conv: 1..4 weight sets");
+        for (const at::Tensor& w : weights) { need_gpu(w); TORCH_CHECK(w.sizes() == weights[0].sizes(), "grouped conv: weight shapes differ"); }
+        for (const at::Tensor& x : xs) need_gpu(x);
+        const at::Tensor& weight = weights[0];
+        const int64_t Cout = weight.size(0), ks = cfg.geo[4], stride = cfg.geo[5], pad = ks / 2;
+        const int64_t B = cfg.geo[0];
+        const int64_t Do = (cfg.geo[1] + 2 * pad - ks) / stride + 1, Ho = (cfg.geo[2] + 2 * pad - ks) / stride + 1,
+                      Wo = (cfg.geo[3] + 2 * pad - ks) / stride + 1;
+        const at::ScalarType odt = cfg.geo[7] == PASSION_BF16 ? at::kBFloat16 : at::kFloat;
+        at::Tensor y = cfg.out ? *cfg.out : at::empty({B, Do, Ho, Wo, Cout}, weight.options().dtype(odt));
+        TORCH_CHECK(y.sizes() == at::IntArrayRef({B, Do, Ho, Wo, Cout}) && y.scalar_type() == odt && y.is_contiguous(),
+                    "conv_block: `out` has the wrong shape / dtype / layout");
+        if (residual)
+            TORCH_CHECK(residual->sizes() == y.sizes() && residual->scalar_type() == odt && residual->is_contiguous(), "conv_block: residual");
+        TORCH_CHECK(cfg.packed.numel() % G == 0, "grouped conv: packed workspace");
+        const int64_t pstride = cfg.packed.numel() / G;
+        const float* packed[4];
+        const float* bias[4];
+        for (int g = 0; g < G; ++g) {
+            packed[g] = cfg.packed.data_ptr<float>() + g * pstride;
+            if (!biases.empty()) {
+                TORCH_CHECK(biases[g].scalar_type() == at::kFloat && biases[g].is_contiguous(), "conv_block: bias must be f32");
+                bias[g] = biases[g].data_ptr<float>();
+            }
+        }
+        passion_conv_desc_t d;
+        fill_desc(d, cfg.geo, cfg.seg, cfg.slope, cfg.stats, cfg.masks, xs, nullptr, Cout);
+        at::Tensor st;
+        if (cfg.want_stats) {
+            st = cfg.stats_out ? *cfg.stats_out : at::empty({B, Cout, 2}, weight.options().dtype(at::kFloat));
+            TORCH_CHECK(st.sizes() == at::IntArrayRef({B, Cout, 2}) && st.is_contiguous() && st.scalar_type() == at::kFloat, "conv_block: stats_out");
+        }
+        check(g.conv_fwd_grouped(&d, G, packed, biases.empty() ? nullptr : bias, residual ? residual->data_ptr() : nullptr, y.data_ptr(),
+                                 cfg.want_stats ? st.data_ptr<float>() : nullptr, (float)cfg.eps, cur_stream()),
+              "passion_conv3d_fwd_grouped");
+        ctx->save_for_backward(xs.vec());
+        ctx->saved_data["geo"] = cfg.geo;
+        ctx->saved_data["seg"] = cfg.seg;
+        ctx->saved_data["slope"] = cfg.slope;
+        ctx->saved_data["stats"] = to_list(cfg.stats);
+        ctx->saved_data["masks"] = to_list(cfg.masks);
+        ctx->saved_data["packed"] = cfg.packed;
+        ctx->saved_data["wshape"] = weight.sizes().vec();
+        ctx->saved_data["flags"] = std::vector<int64_t>{G, biases.empty() ? 0 : 1, residual.has_value()};
+        ctx->set_materialize_grads(false);
+        if (!cfg.want_stats) return {y};
+        ctx->mark_non_differentiable({st});
+        return {y, st};
+    }
+
+    static variable_list backward(AutogradContext* ctx, variable_list grads) {
+        const variable_list xs = ctx->get_saved_variables();
+        const int n = (int)xs.size();
+        const std::vector<int64_t> geo = ctx->saved_data["geo"].toIntVector(), seg = ctx->saved_data["seg"].toIntVector(),
+                                   wshape = ctx->saved_data["wshape"].toIntVector(), flags = ctx->saved_data["flags"].toIntVector();
+        const int G = (int)flags[0];
+        const bool has_bias = flags[1] != 0, has_res = flags[2] != 0;
+        const int nout = G + (has_bias ? G : 0) + 1 + n + 1;      // one per forward argument: weights, biases, residual (even absent), xs, cfg
+        if (!grads[0].defined()) return variable_list(nout);
+        const std::vector<OptT> stats = from_list(ctx->saved_data["stats"]), masks = from_list(ctx->saved_data["masks"]);
+        const at::Tensor packed = ctx->saved_data["packed"].toTensor();
+        size_t e = 0;
+        bool need_w = false;
+        for (int g2 = 0; g2 < G; ++g2) need_w = need_w || ctx->needs_input_grad(e + g2);
+        e += G;
+        if (has_bias) { for (int g2 = 0; g2 < G; ++g2) need_w = need_w || ctx->needs_input_grad(e + g2); e += G; }
+        const bool need_res = has_res && ctx->needs_input_grad(e);
+        if (has_res) ++e;
+        const at::Tensor dy = grads[0].contiguous();
+        const auto f32 = dy.options().dtype(at::kFloat);
+        int64_t nW = 1;
+        for (int64_t s : wshape) nW *= s;
+        const int64_t Cout = wshape[0];
+        at::Tensor wbuf;
+        float* dWp[4] = {nullptr, nullptr, nullptr, nullptr};
+        if (need_w) {
+            wbuf = at::empty({G, nW + Cout}, f32);          // [dW | dbias] per weight set
+            for (int g2 = 0; g2 < G; ++g2) dWp[g2] = wbuf.data_ptr<float>() + g2 * (nW + Cout);
+        }
+        std::vector<at::Tensor> dxs(n);
+        for (int i = 0; i < n; ++i) {
+            if (ctx->needs_input_grad(e + i)) {
+                TORCH_CHECK(seg[i * SEG_INTS + 1] == 0, "gradient wrt an offset view is not supported");
+                dxs[i] = at::empty_like(xs[i]);
+            }
+        }
+        passion_conv_desc_t d;
+        fill_desc(d, geo, seg, ctx->saved_data["slope"].toDouble(), stats, masks, xs, &dxs, Cout);
+        at::Tensor scratch = at::empty({g.conv_bwd_scratch(&d)}, f32);
+        const int64_t pstride = packed.numel() / G;
+        const float* pk[4];
+        for (int g2 = 0; g2 < G; ++g2) pk[g2] = packed.data_ptr<float>() + g2 * pstride;
+        check(g.conv_bwd_grouped(&d, G, pk, dy.data_ptr(), need_w ? dWp : nullptr, scratch.data_ptr<float>(), cur_stream()),
+              "passion_conv3d_bwd_grouped");
+        variable_list out;
+        out.reserve(nout);
+        for (int g2 = 0; g2 < G; ++g2) out.push_back(need_w ? wbuf[g2].narrow(0, 0, nW).view(wshape) : at::Tensor());
+        if (has_bias)
+            for (int g2 = 0; g2 < G; ++g2) out.push_back(need_w ? wbuf[g2].narrow(0, nW, Cout) : at::Tensor());
+        out.push_back(need_res ? dy : at::Tensor());
+        for (int i = 0; i < n; ++i) out.push_back(dxs[i]);
+        out.push_back(at::Tensor());     // cfg
+        return out;
+    }
+};
+
+std::vector<at::Tensor> conv_block_grouped(const std::vector<at::Tensor>& weights, const std::vector<at::Tensor>& biases, const OptT& residual,
+                                           const std::vector<at::Tensor>& xs, std::vector<OptT> stats, std::vector<OptT> masks,
+                                           std::vector<int64_t> seg, std::vector<int64_t> geo, double slope, const at::Tensor& packed,
+                                           const OptT& out, bool want_stats, const OptT& stats_out, double eps) {
+    TORCH_CHECK(g.conv_fwd_grouped && g.conv_bwd_grouped, "passion_amd host extension is not bound to libpassion_hip.so");
+    ConvCfg cfg{std::move(geo), std::move(seg), slope, std::move(stats), std::move(masks), packed, out, want_stats, stats_out, eps};
+    return GroupedConvNode::apply(at::TensorList(weights), at::TensorList(biases), residual, at::TensorList(xs), std::move(cfg));
+}
+
 at::Tensor instnorm_stats(const at::Tensor& x, double eps, const OptT& out) {
     TORCH_CHECK(g.stats, "passion_amd host extension is not bound to libpassion_hip.so");
     need_gpu(x);
@@ -220,7 +345,10 @@ at::Tensor instnorm_stats(const at::Tensor& x, double eps, const OptT& out) {
     return stats;
 }
 
-void bind(uint64_t conv_fwd, uint64_t conv_bwd, uint64_t conv_bwd_scratch, uint64_t stats, uint64_t stats_scratch, uint64_t conv_fwd_stats) {
+void bind(uint64_t conv_fwd, uint64_t conv_bwd, uint64_t conv_bwd_scratch, uint64_t stats, uint64_t stats_scratch, uint64_t conv_fwd_stats,
+          uint64_t conv_fwd_grouped, uint64_t conv_bwd_grouped) {
+    g.conv_fwd_grouped = reinterpret_cast<decltype(g.conv_fwd_grouped)>(conv_fwd_grouped);
+    g.conv_bwd_grouped = reinterpret_cast<decltype(g.conv_bwd_grouped)>(conv_bwd_grouped);
     g.conv_fwd = reinterpret_cast<decltype(g.conv_fwd)>(conv_fwd);
     g.conv_fwd_stats = reinterpret_cast<decltype(g.conv_fwd_stats)>(conv_fwd_stats);
     g.conv_bwd = reinterpret_cast<decltype(g.conv_bwd)>(conv_bwd);
@@ -234,5 +362,6 @@ void bind(uint64_t conv_fwd, uint64_t conv_bwd, uint64_t conv_bwd_scratch, uint6
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     m.def("bind", &bind, "addresses of the C-ABI entry points (from the ctypes handle of libpassion_hip.so)");
     m.def("conv_block", &conv_block);
+    m.def("conv_block_grouped", &conv_block_grouped);
     m.def("instnorm_stats", &instnorm_stats);
 }

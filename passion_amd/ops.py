@@ -374,6 +374,59 @@ def conv_block(segs, weight, bias, D, H, W, ksize=3, stride=1, pad_mode=L.PAD_RE
     return (y, instnorm_stats(y.detach(), eps, out=stats_out)) if want_stats else y
 
 
+_GROUP_PACKS = {}     # ids of the G weights -> packed workspace of the group (the G images back to back)
+
+
+def _group_pack(weights):
+    """one workspace holding the packed images of the G weights at equal spacing; each weight's own pack cache points into it, so
+    repack_stale() refreshes the group with everything else"""
+    key = tuple(id(w) for w in weights)
+    ent = _GROUP_PACKS.get(key)
+    w0 = weights[0]
+    if ent is not None and ent[0].device == w0.device and all(r() is w for r, w in zip(ent[1], weights)):
+        if any(c.get("key") != (w.data_ptr(), w._version) for c, w in zip(ent[2], weights)):
+            repack_stale()
+        return ent[0]
+    import weakref
+    lib = L.load()
+    Cout, Cin, k = w0.shape[0], w0.shape[1], w0.shape[2]
+    n = lib.passion_conv_pack_floats(Cin, Cout, k)
+    n4 = (n + 3) // 4 * 4
+    buf = torch.empty(len(weights) * n4, dtype=torch.float32, device=w0.device)
+    caches = []
+    for g, w in enumerate(weights):
+        cache = {"packed": buf[g * n4:g * n4 + n]}
+        wd = w.detach()
+        L.check(lib.passion_conv_pack_weight(_p(wd), Cin, Cout, k, _p(cache["packed"]), L.stream_ptr()), "passion_conv_pack_weight")
+        cache["key"] = (w.data_ptr(), w._version)
+        if w.is_leaf:
+            _PACK_REGISTRY[id(cache)] = (weakref.ref(w), cache)
+        caches.append(cache)
+    _GROUP_PACKS[key] = (buf, [weakref.ref(w) for w in weights], caches)
+    return buf
+
+
+def conv_block_grouped(segs, weights, biases, D, H, W, ksize=3, stride=1, pad_mode=L.PAD_REFLECT, residual=None, out_dtype=None,
+                       slope=0.2, out=None, want_stats=False, stats_out=None, eps=1e-5):
+    """conv_block for G weight sets over one stacked batch: sample b of the (B,...) segments uses weights[b // (B // G)] -- the
+    four modality encoders of mmformer as one launch per layer (passion_conv3d_fwd_grouped / _bwd_grouped)."""
+    h = L.host()
+    assert h is not None, "grouped conv blocks need the C++ host extension"
+    x0 = segs[0].x
+    L.require_gpu(weights[0], x0)
+    B = x0.shape[0]
+    assert B % len(weights) == 0 and all(s.bmod == 0 for s in segs)
+    odt = out_dtype if out_dtype is not None else (x0.dtype if x0.dtype != torch.float64 else torch.float32)
+    packed = _group_pack(weights)
+    seg_ints = []
+    for s in segs:
+        seg_ints += (s.C, s.offset, s.bstride, s.bmod, s.mask_col)
+    r = h.conv_block_grouped(list(weights), list(biases) if biases is not None else [], residual, [s.x for s in segs],
+                             [s.stats for s in segs], [s.mask for s in segs], seg_ints,
+                             (B, D, H, W, ksize, stride, pad_mode, L.dtype_code(odt)), slope, packed, out, want_stats, stats_out, eps)
+    return (r[0], r[1]) if want_stats else r[0]
+
+
 def alias_slice(buf, i):
     """buf[i] as a tensor that shares buf's storage but is NOT an autograd view of it, so that an op may
     return it as its own output (autograd forbids custom-Function outputs that are views of a base which is

@@ -656,3 +656,75 @@ def test_upsample_forward_leaves_the_statistics_of_its_output(shape, dtype):
     xr = x.clone().requires_grad_(True)
     ops.upsample(xr, 2).float().sum().backward()
     assert torch.equal(xg.grad, xr.grad)
+
+
+GROUPED_CASES = [
+    # (segment channels, Cout, ksize, stride, pad, (D, H, W), dtype, residual, normalised input, per-sample modality mask)
+    ([8], 8, 3, 1, 1, (16, 16, 32), torch.bfloat16, True, True, True),        # marching kernels
+    ([16], 16, 3, 1, 1, (12, 24, 16), torch.bfloat16, False, True, False),
+    ([32], 32, 3, 1, 1, (8, 16, 16), torch.bfloat16, True, True, True),       # lean kernels
+    ([64], 64, 3, 1, 1, (8, 8, 8), torch.bfloat16, False, True, False),
+    ([8], 16, 3, 2, 1, (16, 16, 16), torch.bfloat16, False, True, True),      # stride 2: general forward / wgrad, lean dgrad
+    ([1], 8, 3, 1, 1, (8, 16, 16), torch.bfloat16, False, False, True),       # the first conv of an encoder (Cin = 1)
+    ([16, 16], 16, 3, 1, 1, (8, 8, 16), torch.bfloat16, False, True, False),  # two segments
+    ([8], 8, 3, 1, 1, (8, 8, 16), torch.float32, True, True, True),           # f32 storage: set by set
+]
+
+
+@pytest.mark.parametrize("bg", [1, 2], ids=["one_sample_per_set", "two_samples_per_set"])
+@pytest.mark.parametrize("case", GROUPED_CASES, ids=[str(i) for i in range(len(GROUPED_CASES))])
+def test_grouped_conv_equals_the_four_convs(case, bg):
+    """ops.conv_block_grouped (four weight sets over one stacked batch, one launch per kernel) against four ops.conv_block
+    calls on the four slices: outputs, statistics and input gradients bit for bit (the same kernels, the same order of sums);
+    weight gradients to f32 rounding (the grouped fold adds the same slots but in sample order)"""
+    from passion_amd import ops
+    dev = _dev()
+    segc, Cout, ks, stride, pad, (D, H, W), dtype, with_res, norm, with_mask = case
+    G, B = 4, 4 * bg
+    g = torch.Generator().manual_seed(11 + sum(segc) + Cout + D + bg)
+    xs = [(torch.randn(B, D, H, W, c, generator=g) * 1.5 + 0.3).to(dev, dtype) for c in segc]
+    ws = [(torch.randn(Cout, sum(segc), ks, ks, ks, generator=g) * 0.2).to(dev).requires_grad_(True) for _ in range(G)]
+    bs = [torch.randn(Cout, generator=g).to(dev).requires_grad_(True) for _ in range(G)]
+    Do, Ho, Wo = [(s + 2 * (ks // 2) - ks) // stride + 1 for s in (D, H, W)]
+    res = torch.randn(B, Do, Ho, Wo, Cout, generator=g).to(dev, dtype) if with_res else None
+    mask = (torch.rand(B, 1, generator=g) > 0.3).to(dev) if with_mask else None
+    gy = torch.randn(B, Do, Ho, Wo, Cout, generator=g).to(dev, dtype)
+    kw = dict(ksize=ks, stride=stride, pad_mode=pad)
+
+    def run(grouped):
+        xg = [x.clone().requires_grad_(sum(segc) % 4 == 0) for x in xs]      # the raw input volume (Cin = 1) takes no gradient
+        rg = res.clone().requires_grad_(True) if with_res else None
+        for t in ws + bs:
+            t.grad = None
+        sts = [ops.instnorm_stats(x.detach()) if norm else None for x in xg]
+        if grouped:
+            segs = [ops.SegIn(x, stats=s, mask=mask, mask_col=0) for x, s in zip(xg, sts)]
+            y, st = ops.conv_block_grouped(segs, ws, bs, D, H, W, residual=rg, want_stats=True, **kw)
+        else:
+            ys, stl = [], []
+            for q in range(G):
+                sl = slice(q * bg, (q + 1) * bg)
+                segs = [ops.SegIn(x[sl], stats=None if s is None else s[sl], mask=None if mask is None else mask[sl], mask_col=0)
+                        for x, s in zip(xg, sts)]
+                yq, sq = ops.conv_block(segs, ws[q], bs[q], D, H, W, residual=None if rg is None else rg[sl], want_stats=True, **kw)
+                ys.append(yq)
+                stl.append(sq)
+            y, st = torch.cat(ys, 0), torch.cat(stl, 0)
+        y.backward(gy)
+        return (y.detach(), st, [x.grad for x in xg], None if rg is None else rg.grad, [w.grad.clone() for w in ws], [b.grad.clone() for b in bs])
+
+    yg, stg, dxg, drg, dwg, dbg = run(True)
+    yr, str_, dxr, drr, dwr, dbr = run(False)
+    assert torch.equal(yg, yr)
+    assert torch.equal(stg, str_)
+    for a, b in zip(dxg, dxr):
+        if b is None:
+            assert a is None or float(a.abs().max()) == 0.0
+        elif dtype == torch.float32:     # the f32 kernels add the InstanceNorm-backward sums with f32 atomics: order-dependent
+            assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max())
+        else:
+            assert torch.equal(a, b)
+    if with_res:
+        assert torch.equal(drg, drr)
+    for a, b in zip(dwg + dbg, dwr + dbr):
+        assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max()) + 1e-6
