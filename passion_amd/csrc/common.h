@@ -90,6 +90,13 @@ __device__ __forceinline__ float group16_sum(float v) {
 // RELAXED ATOMIC stores / loads at agent scope (sc1: coherent across the XCDs' L2s) + a ticket counter, ordered by the
 // s_waitcnt of __syncthreads().  NOT __threadfence(): an agent-scope release fence writes back every dirty line of the XCD's L2
 // (buffer_wbl2) -- at the end of a conv that just stored its output that cost 50 us per launch (128^3, 8 channels).
+// ... and, in the workgroup that won the ticket, an ACQUIRE fence before it reads the others' slots (buffer_inv sc1: drops the
+// lines its own L2 may still hold from the buffer's previous use -- one stale 128-byte line in ~3000 launches without it;
+// an invalidate writes nothing back, so it is cheap where the release fence is not).
+__device__ __forceinline__ void acquire_agent() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); }
+// every vector-memory operation of this wave (the sc1 slot stores) acknowledged at its scope before anything that follows (the
+// barrier in front of the ticket): spelled out rather than left to what __syncthreads() happens to wait for
+__device__ __forceinline__ void stores_done() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 __device__ __forceinline__ void st_agent(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void st_agent(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ float ld_agent(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }

@@ -152,6 +152,7 @@ __device__ __forceinline__ void fwd_stats_commit(const FwdStats& fs, int Cout, i
         const int c = row0 + (i >> 1);
         if (c < Cout) st_agent(&slot[c * 2 + (i & 1)], wsum[i]);
     }
+    stores_done();
     __syncthreads();                                           // waits for the stores (vmcnt 0) of every thread: slot before ticket
     unsigned* tk = fs.tickets + (long)b * (fs.ngroup + 1);
     __shared__ double fst_part[256];
@@ -161,6 +162,7 @@ __device__ __forceinline__ void fwd_stats_commit(const FwdStats& fs, int Cout, i
         if (tid == 0) fst_flag = atomicAdd(&tk[fs.ngroup], 1u) == (unsigned)(fs.nwg * fs.ny - 1);
         __syncthreads();
         if (!fst_flag) return;
+        acquire_agent();
         const int SLd = 256 / NV, v = tid % NV, sl = tid / NV;      // NV <= 256 here
         double a = 0.0;
         if (sl < SLd) {
@@ -193,6 +195,7 @@ __device__ __forceinline__ void fwd_stats_commit(const FwdStats& fs, int Cout, i
     if (tid == 0) fst_flag = atomicAdd(&tk[grp], 1u) == (unsigned)(gsz * fs.ny - 1);
     __syncthreads();
     if (!fst_flag) return;
+    acquire_agent();
     double* gs = fs.gslots + ((long)b * fs.ngroup + grp) * NV;
     for (int i = tid; i < NV; i += 256) {
         const float* s0 = fs.slots + ((long)b * fs.nwg + (long)grp * STATS_GROUP) * NV + i;
@@ -205,10 +208,12 @@ __device__ __forceinline__ void fwd_stats_commit(const FwdStats& fs, int Cout, i
         st_agent(&gs[i], a);
     }
     if (tid == 0) __hip_atomic_store(&tk[grp], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    stores_done();
     __syncthreads();
     if (tid == 0) fst_flag = atomicAdd(&tk[fs.ngroup], 1u) == (unsigned)(fs.ngroup - 1);
     __syncthreads();
     if (!fst_flag) return;
+    acquire_agent();
     // the group sums: value v = (channel, moment) x SL slices of the groups per thread, slices combined through LDS in order
     const int SL = NV <= 256 ? 256 / NV : 1;
     for (int v0 = 0; v0 < NV; v0 += 256) {                     // one pass unless Cout > 128

@@ -175,6 +175,21 @@ struct ConvBlockNode : public torch::autograd::Function<ConvBlockNode> {
             db = at::empty({wshape[0]}, f32);
         }
         std::vector<at::Tensor> dxs(n);
+        // segments that are adjacent slices of one stacked tensor (the four modalities of a grouped encoder level feeding a fusion
+        // conv, ops.UnstackFn) get their gradients as adjacent slices of ONE buffer: the unstack node hands that on without a copy
+        bool joint = n >= 2;
+        for (int i = 0; i < n && joint; ++i) {
+            joint = ctx->needs_input_grad(e + i) && xs[i].is_contiguous() && xs[i].sizes() == xs[0].sizes() &&
+                    xs[i].scalar_type() == xs[0].scalar_type() && seg[i * SEG_INTS + 1] == 0 &&
+                    (i == 0 || static_cast<const char*>(xs[i].data_ptr()) == static_cast<const char*>(xs[i - 1].data_ptr()) + xs[i - 1].nbytes());
+        }
+        if (joint) {
+            std::vector<int64_t> shp = xs[0].sizes().vec();
+            const int64_t b0 = shp[0];
+            shp[0] = b0 * n;
+            at::Tensor all = at::empty(shp, xs[0].options());
+            for (int i = 0; i < n; ++i) dxs[i] = all.narrow(0, i * b0, b0);
+        } else
         for (int i = 0; i < n; ++i) {
             if (ctx->needs_input_grad(e + i)) {
                 TORCH_CHECK(seg[i * SEG_INTS + 1] == 0, "gradient wrt an offset view is not supported");

@@ -106,10 +106,12 @@ __device__ __forceinline__ bool fold_blocks(float s, float* __restrict__ part, u
     __shared__ float fred[G * JP];
     const int nb = gridDim.x, b = blockIdx.y, tid = threadIdx.x;
     if (tid < J) st_agent(&part[((long)b * nb + blockIdx.x) * J + tid], s);      // agent-scope atomics, no fence: see common.h
+    stores_done();
     __syncthreads();                                        // the slot is stored (vmcnt 0) before the ticket is taken
     if (tid == 0) last = atomicAdd(&counter[b], 1u) == (unsigned)(nb - 1);
     __syncthreads();
     if (!last) return false;
+    acquire_agent();
     const int j = tid % JP, gq = tid / JP;
     float a = 0.f;
     if (j < J) {
@@ -538,10 +540,12 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ g, lo
         return;
     }
     if (t < 128 && c < C) st_agent(&part[(long)blockIdx.y * C + c], s);
+    stores_done();
     __syncthreads();
     if (t == 0) last = atomicAdd(&counter[blockIdx.x], 1u) == gridDim.y - 1;
     __syncthreads();
     if (!last) return;
+    acquire_agent();
     if (t < 128 && c < C) {
         float tot = 0.f;
         int y = 0;

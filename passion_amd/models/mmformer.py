@@ -100,6 +100,41 @@ class Encoder(nn.Module):
         return feats
 
 
+GROUPED_ENC = _os.environ.get("PASSION_GROUPED_ENC", "1") != "0"   # the four modality encoders as one grouped launch per layer
+
+
+def encoders_grouped(encs, x, mask, dtype):
+    """The four modality encoders (reference mmformer.py:385-388, 397-415: four Encoder() instances of identical shape) over the
+    stacked batch [flair | t1ce | t1 | t2] (4B samples): every layer is ONE grouped launch (ops.conv_block_grouped: sample s
+    uses the weights of encoder s // B) instead of four launches on four streams -- a quarter of the launches, and deep-level
+    kernels four times the size.  x: (B,4,D,H,W); mask: (B,4) bool or None (idt: absent modalities read as zeros).
+    -> five Feats of shape (4B, D_l, H_l, W_l, C_l) with their statistics."""
+    B, K, D, H, W = x.shape
+    xs = torch.empty(K, B, D, H, W, 1, dtype=dtype, device=x.device)
+    xs.view(K, B, D, H, W).copy_(x.transpose(0, 1))             # cast + modality-major restack in one pass
+    xs = xs.view(K * B, D, H, W, 1)
+    gmask = mask.t().reshape(K * B, 1).contiguous() if mask is not None else None      # row m * B + b = mask[b, m]
+
+    def gconv(name, f, residual=None, want_stats=True, first=False):
+        convs = [getattr(e, name) if first else getattr(e, name).conv for e in encs]
+        c0 = convs[0]
+        d, h, w = f.t.shape[1:4]
+        seg = ops.SegIn(f.t, mask=gmask, mask_col=0) if first else f.seg(True)
+        r = ops.conv_block_grouped([seg], [c.weight for c in convs], [c.bias for c in convs], d, h, w, ksize=c0.kernel_size[0],
+                                   stride=c0.stride[0], pad_mode=L.PAD_REFLECT, residual=residual, out_dtype=dtype,
+                                   want_stats=want_stats)
+        return Feat(r[0], _stats=[r[1]]) if want_stats else Feat(r)
+
+    f = gconv("e1_c1", Feat(xs), first=True)
+    feats = []
+    for lvl in range(1, 6):
+        if lvl > 1:
+            f = gconv(f"e{lvl}_c1", f)
+        f = gconv(f"e{lvl}_c3", gconv(f"e{lvl}_c2", f), residual=f.t, want_stats=lvl < 5)
+        feats.append(f)
+    return feats
+
+
 def _decoder_convs(mod):
     c = basic_dims
     for lvl in (4, 3, 2, 1):
@@ -374,24 +409,16 @@ class Model(nn.Module):
         training = self.is_training
         passion = training and self.use_passion
         mask = mask.to(device=dev, dtype=torch.bool).contiguous()
-        xin = x.to(dt).contiguous()
-
-        # ---- encoders (idt: input and features of absent modalities are zero, mmformer.py:397-415).
-        # When training, the level outputs of the four modalities land back to back in one buffer per level:
-        # decoder_sep (shared weights) then runs ONCE over the 4B stack instead of four times.
-        bufs = sbufs = None
-        if training:
-            c = self.flair_encoder.e1_c1.out_channels
-            bufs = [torch.empty(4, B, S >> l, S >> l, S >> l, c << l, dtype=dt, device=dev) for l in range(5)]
-            sbufs = [torch.empty(4, B, c << l, 2, dtype=torch.float32, device=dev) for l in range(5)]
-        # The four encoders are independent until the fusion: each runs on its own HIP stream (forward, and -- autograd
-        # replays every node on the stream of its forward -- backward too), so the small deep-level launches of one
-        # modality fill the CUs the others leave idle.  PASSION_ENC_STREAMS=0 keeps everything on one stream.
+        grouped = GROUPED_ENC and x.is_cuda and L.host() is not None
         streams = self._enc_streams(dev) if ENC_STREAMS and x.is_cuda else None
         main = torch.cuda.current_stream(dev) if streams else None
+        if streams:
+            for s_ in streams:                           # (possibly a fresh copy made on the main stream) read on every side stream
+                mask.record_stream(s_)
         encs = [None] * 4
         intra = [None] * 4
         pos = [getattr(self, f"{m}_pos") for m in MODALS]
+        stacked_feats = None
 
         def intra_tokens(i):
             """token conv + intra-modal transformer of modality i (mmformer.py:417-433): a chain of ~30 tiny launches that
@@ -403,25 +430,56 @@ class Model(nn.Module):
             tok = self._transformer(getattr(self, f"{m}_transformer"), tok, pos[i])
             return tok * mask[:, i].view(B, 1, 1).to(tok.dtype)
 
-        for i, m in enumerate(MODALS):
-            outs = [ops.alias_slice(b_, i) for b_ in bufs] if training else None
-            sts = [s_[i] for s_ in sbufs] if training else None
-            if streams:
-                streams[i].wait_stream(main)
-                if training and _os.environ.get("PASSION_DBG_NOREC") is None:
-                    for b_ in bufs + sbufs:              # allocated on the main stream, written and (backward) read on this one
-                        b_.record_stream(streams[i])
-                with torch.cuda.stream(streams[i]):
-                    encs[i] = getattr(self, f"{m}_encoder")(xin, i, mask if idt else None, dt, outs, sts)
-                    for f in encs[i]:                    # consumed by work on the main stream: tell the allocator, or the
-                        f.t.record_stream(main)          # block could be handed out again on this side stream too early
-                        if f._stats[0] is not None:
-                            f._stats[0].record_stream(main)
-                    if INTRA_STREAMS:
+        if grouped:
+            # ---- the four encoders as grouped launches over the stacked batch (encoders_grouped); the per-modality tensors the
+            # fusion path reads are the four batch slices of every level (ops.unstack: shared storage, no copy either way)
+            stacked_feats = encoders_grouped([getattr(self, f"{m}_encoder") for m in MODALS], x, mask if idt else None, dt)
+            per_level = []
+            for l, f in enumerate(stacked_feats):
+                ts = ops.unstack(f.t, 4)
+                st = f._stats[0].view(4, B, -1, 2) if f._stats[0] is not None else None
+                per_level.append([Feat(ts[i], _stats=[st[i]] if st is not None else None) for i in range(4)])
+            encs = [[per_level[l][i] for l in range(5)] for i in range(4)]
+            if streams and INTRA_STREAMS:                # the four intra-modal transformers are independent: side streams
+                for i in range(4):
+                    streams[i].wait_stream(main)
+                    encs[i][4].t.record_stream(streams[i])
+                    with torch.cuda.stream(streams[i]):
                         intra[i] = intra_tokens(i)
                         intra[i].record_stream(main)
-            else:
-                encs[i] = getattr(self, f"{m}_encoder")(xin, i, mask if idt else None, dt, outs, sts)
+        else:
+            xin = x.to(dt).contiguous()
+            # ---- encoders (idt: input and features of absent modalities are zero, mmformer.py:397-415).
+            # When training, the level outputs of the four modalities land back to back in one buffer per level:
+            # decoder_sep (shared weights) then runs ONCE over the 4B stack instead of four times.
+            bufs = sbufs = None
+            if training:
+                c = self.flair_encoder.e1_c1.out_channels
+                bufs = [torch.empty(4, B, S >> l, S >> l, S >> l, c << l, dtype=dt, device=dev) for l in range(5)]
+                sbufs = [torch.empty(4, B, c << l, 2, dtype=torch.float32, device=dev) for l in range(5)]
+            # The four encoders are independent until the fusion: each runs on its own HIP stream (forward, and -- autograd
+            # replays every node on the stream of its forward -- backward too), so the small deep-level launches of one
+            # modality fill the CUs the others leave idle.  PASSION_ENC_STREAMS=0 keeps everything on one stream.
+
+            for i, m in enumerate(MODALS):
+                outs = [ops.alias_slice(b_, i) for b_ in bufs] if training else None
+                sts = [s_[i] for s_ in sbufs] if training else None
+                if streams:
+                    streams[i].wait_stream(main)
+                    if training and _os.environ.get("PASSION_DBG_NOREC") is None:
+                        for b_ in bufs + sbufs:              # allocated on the main stream, written and (backward) read on this one
+                            b_.record_stream(streams[i])
+                    with torch.cuda.stream(streams[i]):
+                        encs[i] = getattr(self, f"{m}_encoder")(xin, i, mask if idt else None, dt, outs, sts)
+                        for f in encs[i]:                    # consumed by work on the main stream: tell the allocator, or the
+                            f.t.record_stream(main)          # block could be handed out again on this side stream too early
+                            if f._stats[0] is not None:
+                                f._stats[0].record_stream(main)
+                        if INTRA_STREAMS:
+                            intra[i] = intra_tokens(i)
+                            intra[i].record_stream(main)
+                else:
+                    encs[i] = getattr(self, f"{m}_encoder")(xin, i, mask if idt else None, dt, outs, sts)
         if streams:
             for s_ in streams:
                 main.wait_stream(s_)
@@ -454,11 +512,22 @@ class Model(nn.Module):
             sep_mask = mask.t().reshape(4 * B, 1).contiguous() if idt else None      # row i*B+b = mask[b, i]
             stacked = []
             for l in range(5):
+                if grouped:                              # the grouped encoders' outputs ARE the stack
+                    f = stacked_feats[l]
+                    stacked.append(Feat(f.t, sep_mask, 0, _stats=f._stats))
+                    continue
                 t = ops.stack_slots(bufs[l], [encs[i][l].t for i in range(4)])
                 st = [sbufs[l].view(4 * B, -1, 2)] if l < 4 else None               # filled by the encoders' next-level convs
                 stacked.append(Feat(t, sep_mask, 0, _stats=st))
             if streams:
                 streams[0].wait_stream(main)
+                if sep_mask is not None:
+                    sep_mask.record_stream(streams[0])  # made on the main stream a moment ago, read by every conv of decoder_sep
+                if grouped:                              # allocated on the main stream, read (forward and backward) on this one
+                    for f in stacked:
+                        f.t.record_stream(streams[0])
+                        if f._stats[0] is not None:
+                            f._stats[0].record_stream(streams[0])
                 with torch.cuda.stream(streams[0]):
                     sep_all = self.decoder_sep(*stacked)
                     sep_all.record_stream(main)

@@ -454,6 +454,41 @@ class StackFn(torch.autograd.Function):
         return (None, *g.contiguous().chunk(ctx.n, 0))
 
 
+class UnstackFn(torch.autograd.Function):
+    """The n equal batch slices of a stacked (n*B, ...) tensor as tensors that share its storage without being autograd views of
+    it (the four modalities of a grouped encoder level, read as four segments by the fusion convs).  Backward: when the n
+    gradients are adjacent slices of one buffer (the conv backward allocates them that way, csrc/host_ext.cpp) the buffer IS
+    the gradient of the stack; otherwise they are concatenated."""
+
+    @staticmethod
+    def forward(ctx, t, n):
+        assert t.is_contiguous() and t.shape[0] % n == 0
+        B = t.shape[0] // n
+        ctx.n, ctx.shape, ctx.dtype = n, t.shape, t.dtype
+        ctx.set_materialize_grads(False)
+        return tuple(torch.empty(0, dtype=t.dtype, device=t.device).set_(
+            t.untyped_storage(), t.storage_offset() + i * B * t.stride(0), (B,) + tuple(t.shape[1:]), t.stride()) for i in range(n))
+
+    @staticmethod
+    def backward(ctx, *gs):
+        n = ctx.n
+        if all(g is None for g in gs):
+            return None, None
+        g0 = gs[0]
+        if g0 is not None and all(g is not None and g.is_contiguous() and g.shape == g0.shape and g.dtype == g0.dtype for g in gs) and \
+                all(gs[i].data_ptr() == g0.data_ptr() + i * g0.numel() * g0.element_size() for i in range(n)) and \
+                g0.untyped_storage().nbytes() - g0.storage_offset() * g0.element_size() >= n * g0.numel() * g0.element_size():
+            return torch.empty(0, dtype=g0.dtype, device=g0.device).set_(g0.untyped_storage(), g0.storage_offset(), ctx.shape), None
+        B = ctx.shape[0] // n
+        ref = next(g for g in gs if g is not None)
+        parts = [g if g is not None else torch.zeros((B,) + tuple(ctx.shape[1:]), dtype=ref.dtype, device=ref.device) for g in gs]
+        return torch.cat(parts, 0), None
+
+
+def unstack(t, n):
+    return UnstackFn.apply(t, n)
+
+
 def stack_slots(buf, parts):
     return StackFn.apply([buf], *parts)
 

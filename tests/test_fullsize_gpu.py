@@ -21,6 +21,14 @@ from _util import build_product_model, synth  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 S = 128
+# bf16 at 128^3: what a sample's batch mates (or the four student passes batched with the teacher) can change is how the
+# workgroups split the volume, i.e. the ROUNDING of the per-workgroup partial sums behind the InstanceNorm statistics the conv
+# epilogues produce (f32 sums folded in double, ~1e-7 relative) -- which flips a bf16 rounding here and there, and this
+# random-init network amplifies a flipped rounding like it amplifies bf16 itself (tests/test_benchsize_gpu.py: bf16 vs f32 max
+# 1e-1).  Measured: mean |dp| 3.0e-3, max 1.0e-1.  A statistic shared between samples would move every voxel by O(0.1).
+# The f32 model (statistics from their own kernels, one fixed split per sample) keeps both properties to f32 rounding (1e-4 on
+# the probabilities; the token GEMMs' kernel choice depends on the row count): checked at 64^3.
+MEAN_TOL, MAX_TOL = 1e-2, 2.5e-1
 
 
 def _dev():
@@ -35,6 +43,15 @@ def model():
     m = build_product_model(S, small=False).to(dev)
     m.mask_type, m.compute_dtype = "idt", torch.bfloat16
     m.eval()                                    # dropout off: the comparisons below are between separate forwards
+    return m
+
+
+@pytest.fixture(scope="module")
+def model_f32():
+    dev = _dev()
+    m = build_product_model(64, small=False).to(dev)
+    m.mask_type, m.compute_dtype = "idt", torch.float32
+    m.eval()
     return m
 
 
@@ -63,9 +80,32 @@ def test_samples_of_a_batch_are_independent(model):
     with torch.no_grad():
         both = model(x, mask, target=t, temp=4.0)
         one = model(x[1:], mask[1:], target=t[1:], temp=4.0)
-    assert torch.equal(both[0][1:], one[0])                   # probabilities: bit for bit
-    for u, v in zip(both[1:], one[1:]):                       # loss sums end in f32 atomics: equal to rounding
-        assert torch.allclose(u[1:], v, rtol=2e-5, atol=1e-6)
+    # No batch statistics anywhere: what a sample's batch mates can change is only how the workgroups split the volume, i.e. the
+    # ROUNDING of the per-workgroup partial sums behind its InstanceNorm statistics (f32 sums folded in double: ~1e-7 relative)
+    # -- which moves a bf16 rounding here and there.  (Until the statistics moved into the conv epilogues, round 2, this was bit
+    # for bit; a statistic shared between samples would move the probabilities by O(0.1) everywhere.)
+    d = (both[0][1:] - one[0]).abs()
+    print(f"sample 1 alone vs in a batch of two: max |dp| {float(d.max()):.2e}, mean |dp| {float(d.mean()):.2e}")
+    assert float(d.mean()) < MEAN_TOL and float(d.max()) < MAX_TOL, (float(d.mean()), float(d.max()))
+    for u, v in zip(both[1:], one[1:]):
+        assert torch.allclose(u[1:], v, rtol=2e-2, atol=1e-4)
+
+
+def test_samples_of_a_batch_are_independent_f32(model_f32):
+    dev = _dev()
+    x, t = synth(2, 64)
+    x, t = x.to(dev), t.to(dev)
+    mask = torch.tensor([[True, True, True, True], [True, False, False, True]], device=dev)
+    model_f32.is_training, model_f32.use_passion = True, False
+    with torch.no_grad():
+        both = model_f32(x, mask, target=t, temp=4.0)
+        one = model_f32(x[1:], mask[1:], target=t[1:], temp=4.0)
+    # the conv path is bit for bit here; the token GEMMs (hipBLASLt picks its kernel by the row count) are not: f32 rounding
+    d = (both[0][1:] - one[0]).abs()
+    print(f"f32, sample 1 alone vs in a batch of two: max |dp| {float(d.max()):.2e}")
+    assert float(d.max()) < 1e-4
+    for u, v in zip(both[1:], one[1:]):
+        assert torch.allclose(u[1:], v, rtol=1e-4, atol=1e-6)
 
 
 def test_passion_teacher_is_the_plain_forward(model):
@@ -81,11 +121,32 @@ def test_passion_teacher_is_the_plain_forward(model):
         full = model(x, mask, target=t, temp=4.0)
     model.use_passion = False
     assert len(plain) == 3 and len(full) == 6
-    assert torch.equal(plain[0], full[0])
+    d = (plain[0] - full[0]).abs()
+    print(f"PASSION teacher vs plain forward: max |dp| {float(d.max()):.2e}, mean |dp| {float(d.mean()):.2e}")
+    assert float(d.mean()) < MEAN_TOL and float(d.max()) < MAX_TOL, (float(d.mean()), float(d.max()))
     for u, v in zip(plain[1:], full[1:3]):
-        assert torch.allclose(u, v, rtol=2e-5, atol=1e-6)
+        assert torch.allclose(u, v, rtol=2e-2, atol=1e-4)
     kl, proto, dist = full[3:]
     assert bool(torch.isfinite(kl).all() and torch.isfinite(proto).all() and torch.isfinite(dist).all())
+
+
+def test_passion_teacher_is_the_plain_forward_f32(model_f32):
+    dev = _dev()
+    x, t = synth(1, 64, blobs=True)
+    x, t = x.to(dev), t.to(dev)
+    mask = torch.tensor([[True, True, False, True]], device=dev)
+    model_f32.is_training = True
+    with torch.no_grad():
+        model_f32.use_passion = False
+        plain = model_f32(x, mask, target=t, temp=4.0)
+        model_f32.use_passion = True
+        full = model_f32(x, mask, target=t, temp=4.0)
+    model_f32.use_passion = False
+    d = (plain[0] - full[0]).abs()
+    print(f"f32, PASSION teacher vs plain forward: max |dp| {float(d.max()):.2e}")
+    assert float(d.max()) < 1e-4                     # token GEMMs over 5 passes x B rows vs B rows: f32 rounding
+    for u, v in zip(plain[1:], full[1:3]):
+        assert torch.allclose(u, v, rtol=1e-4, atol=1e-6)
 
 
 def test_gradients_are_linear_in_the_loss_scale(model):
@@ -107,8 +168,9 @@ def test_gradients_are_linear_in_the_loss_scale(model):
     for n, g1, g2 in zip(names, *grads):
         denom = float(g1.abs().max())
         assert denom > 0
-        # bf16 activations + f32 atomics: two runs of the SAME step differ by percents on individual entries;
-        # the scale must come through on the bulk of the tensor
+        # two runs of the same step repeat bit for bit (round 2), but 2 x loss is not the same step: the fixed-point (2^-40)
+        # InstanceNorm-backward sums round differently and bf16 roundings flip downstream; the scale must come through on the
+        # bulk of the tensor
         rel = float((g2 - 2 * g1).abs().mean()) / float((2 * g1).abs().mean())
         assert rel < 5e-2, (n, rel)
 
