@@ -360,6 +360,25 @@ at::Tensor instnorm_stats(const at::Tensor& x, double eps, const OptT& out) {
     return stats;
 }
 
+// Optimizer bookkeeping over a few hundred parameters per step, out of the interpreter (the step is host-bound on a busy box):
+// (data_ptr of p, data_ptr of p.grad or 0) for every parameter; gradients are checked (f32, GPU) and made contiguous.
+std::pair<std::vector<int64_t>, std::vector<int64_t>> param_grad_ptrs(const std::vector<at::Tensor>& params) {
+    std::vector<int64_t> pp(params.size()), gp(params.size(), 0);
+    for (size_t i = 0; i < params.size(); ++i) {
+        const at::Tensor& p = params[i];
+        pp[i] = reinterpret_cast<int64_t>(p.data_ptr());
+        at::Tensor& g = const_cast<at::Tensor&>(p).mutable_grad();
+        if (!g.defined()) continue;
+        TORCH_CHECK(g.is_cuda() && g.scalar_type() == at::kFloat, "FusedAdamW needs f32 GPU gradients");
+        if (!g.is_contiguous()) g = g.contiguous();
+        gp[i] = reinterpret_cast<int64_t>(g.data_ptr());
+    }
+    return {pp, gp};
+}
+void drop_grads(const std::vector<at::Tensor>& params) {
+    for (const at::Tensor& p : params) const_cast<at::Tensor&>(p).mutable_grad().reset();
+}
+
 void bind(uint64_t conv_fwd, uint64_t conv_bwd, uint64_t conv_bwd_scratch, uint64_t stats, uint64_t stats_scratch, uint64_t conv_fwd_stats,
           uint64_t conv_fwd_grouped, uint64_t conv_bwd_grouped) {
     g.conv_fwd_grouped = reinterpret_cast<decltype(g.conv_fwd_grouped)>(conv_fwd_grouped);
@@ -378,5 +397,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     m.def("bind", &bind, "addresses of the C-ABI entry points (from the ctypes handle of libpassion_hip.so)");
     m.def("conv_block", &conv_block);
     m.def("conv_block_grouped", &conv_block_grouped);
+    m.def("param_grad_ptrs", &param_grad_ptrs);
+    m.def("drop_grads", &drop_grads);
     m.def("instnorm_stats", &instnorm_stats);
 }

@@ -71,6 +71,7 @@ class _ConvCfg:
 
 
 _PACK_REGISTRY = {}     # id(cache dict) -> (weakref to the weight parameter, cache dict)
+_PACK_TABLE = {}        # the pointer tables of the last multi-weight re-pack
 
 
 def repack_stale():
@@ -92,11 +93,16 @@ def repack_stale():
         return 0
     n = len(stale)
     from ctypes import c_int as _ci
-    ptrs, outs = (c_void_p * n)(), (c_void_p * n)()
-    cin, cout, ks = (_ci * n)(), (_ci * n)(), (_ci * n)()
-    for i, (w, cache) in enumerate(stale):
-        ptrs[i], outs[i] = w.data_ptr(), cache["packed"].data_ptr()
-        cout[i], cin[i], ks[i] = w.shape[0], w.shape[1], w.shape[2]
+    sig = tuple((w.data_ptr(), cache["packed"].data_ptr()) for w, cache in stale)
+    tab = _PACK_TABLE.get("tab")
+    if tab is None or tab[0] != sig:         # the same few hundred pointers every step: build the tables once
+        ptrs, outs = (c_void_p * n)(), (c_void_p * n)()
+        cin, cout, ks = (_ci * n)(), (_ci * n)(), (_ci * n)()
+        for i, (w, cache) in enumerate(stale):
+            ptrs[i], outs[i] = w.data_ptr(), cache["packed"].data_ptr()
+            cout[i], cin[i], ks[i] = w.shape[0], w.shape[1], w.shape[2]
+        tab = _PACK_TABLE["tab"] = (sig, ptrs, cin, cout, ks, outs)
+    _, ptrs, cin, cout, ks, outs = tab
     L.check(L.load().passion_conv_pack_weights(n, ptrs, cin, cout, ks, outs, L.stream_ptr()), "passion_conv_pack_weights")
     for w, cache in stale:
         cache["key"] = (w.data_ptr(), w._version)

@@ -25,16 +25,25 @@ class FusedAdamW(torch.optim.Optimizer):
             with torch.enable_grad():
                 loss = closure()
         lib = L.load()
+        host = L.host() if all(p.is_cuda for g in self.param_groups for p in g["params"]) else None
         for gi, group in enumerate(self.param_groups):
-            ps = [p for p in group["params"] if p.grad is not None]
+            allp = group["params"]
+            if host is not None:         # one C++ pass over the parameters instead of a few hundred attribute reads
+                pptr, gptr = host.param_grad_ptrs(allp)
+                live = [i for i, q in enumerate(gptr) if q]
+                ps = [allp[i] for i in live]
+            else:
+                ps = [p for p in allp if p.grad is not None]
+                live, pptr, gptr = None, None, None
             if not ps:
                 continue
             # everything that does not change from step to step (validation, pointer tables of the parameters and their
             # moments) is built once per set of live parameters: the step is host-bound, 288 parameters x a few dict
             # lookups and CPU-tensor increments were 1.2 ms of it
-            key = tuple(id(p) for p in ps)
+            key = tuple(live) if live is not None else tuple(id(p) for p in ps)
             cache = self._tables.get(gi)
-            if cache is None or cache["key"] != key or any(p.data_ptr() != q for p, q in zip(ps, cache["pptr"])):
+            cur_pptr = [pptr[i] for i in live] if live is not None else [p.data_ptr() for p in ps]
+            if cache is None or cache["key"] != key or cache["pptr"] != cur_pptr:
                 self._sync_steps()      # the live counts are in the old table: bring the per-parameter tensors up to date first
                 for p in ps:
                     st = self.state[p]
@@ -62,19 +71,22 @@ class FusedAdamW(torch.optim.Optimizer):
                     subs.append({"idx": idx, "p": arr(sp), "m": arr(ms), "v": arr(vs), "vm": arr(vm),
                                  "numel": (c_int64 * n)(*[p.numel() for p in sp]), "g": (c_void_p * n)(), "step": step0,
                                  "step_tensors": [self.state[p]["step"] for p in sp]})
-                cache = {"key": key, "pptr": [p.data_ptr() for p in ps], "subs": subs}
+                cache = {"key": key, "pptr": cur_pptr, "subs": subs}
                 self._tables[gi] = cache
             b1, b2 = group["betas"]
             for sub in cache["subs"]:
                 garr = sub["g"]
-                for j, i in enumerate(sub["idx"]):
-                    p = ps[i]
-                    g = p.grad
-                    if g.dtype != torch.float32 or not g.is_cuda:
-                        raise L.PassionHipError("FusedAdamW needs contiguous f32 CUDA parameters and gradients")
-                    if not g.is_contiguous():
-                        g = p.grad = g.contiguous()
-                    garr[j] = g.data_ptr()
+                if live is not None:         # checked and made contiguous by param_grad_ptrs
+                    garr[:] = [gptr[live[i]] for i in sub["idx"]]
+                else:
+                    for j, i in enumerate(sub["idx"]):
+                        p = ps[i]
+                        g = p.grad
+                        if g.dtype != torch.float32 or not g.is_cuda:
+                            raise L.PassionHipError("FusedAdamW needs contiguous f32 CUDA parameters and gradients")
+                        if not g.is_contiguous():
+                            g = p.grad = g.contiguous()
+                        garr[j] = g.data_ptr()
                 sub["step"] += 1
                 L.check(lib.passion_adamw_step(len(sub["idx"]), sub["p"], garr, sub["m"], sub["v"], sub["vm"], sub["numel"],
                                                float(group["lr"]), float(b1), float(b2), float(group["eps"]),
@@ -84,6 +96,13 @@ class FusedAdamW(torch.optim.Optimizer):
             # caches (ops.pack_weight / repack_stale) and any saved-tensor checks key on them
             torch.autograd.graph.increment_version(ps)
         return loss
+
+    def zero_grad(self, set_to_none=True):
+        host = L.host() if set_to_none and all(p.is_cuda for g in self.param_groups for p in g["params"]) else None
+        if host is None:
+            return super().zero_grad(set_to_none)
+        for group in self.param_groups:
+            host.drop_grads(group["params"])
 
     def _sync_steps(self):
         """the per-parameter 'step' tensors of torch's state layout, brought up to date (they are only read by state_dict)"""
