@@ -304,7 +304,11 @@ def main():
             traffic = None
             tpath = os.path.join(ROOT, "profiles", "traffic.json")
             if os.path.exists(tpath):
-                traffic = json.load(open(tpath)).get("bytes_per_launch", {}).get(dom)
+                tj = json.load(open(tpath)).get("bytes_per_launch", {})
+                # rocprofv3 spells a bool template argument true / false, the library's tag 1 / 0
+                import re as _re
+                alt = _re.sub(r", (0|1)>$", lambda m: ", false>" if m.group(1) == "0" else ", true>", dom)
+                traffic = tj.get(dom, tj.get(alt))
             copy_gbs = measured_copy_gbs(ctx.device)
             ak = [r for r in alone_recs if r[4] == dom]
             alone_ms = sum(r[1] for r in ak) / len(ak) if ak else None
