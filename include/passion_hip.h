@@ -278,6 +278,8 @@ int passion_region_mix_bwd(const void* const* y, void* const* dy, const uint8_t*
  * work: f32 scratch of passion_colsum_work_floats(C) floats. */
 int64_t passion_colsum_work_floats(int C);
 int passion_colsum(const void* g, int dtype, int64_t R, int C, float* out, float* work, void* stream);
+/* the same for G matrices [G][R][C] -> out [G][C] in one launch (work: G x passion_colsum_work_floats(C) floats) */
+int passion_colsum_batched(const void* g, int dtype, int G, int64_t R, int C, float* out, float* work, void* stream);
 
 /* ---- optimizer: torch.optim.AdamW(betas, eps, weight_decay, amsgrad) (code/train.py:95-96) for n f32 parameter
  * tensors in ceil(n/40) launches.  Host arrays of device pointers; `step` is the 1-based step count after increment. */

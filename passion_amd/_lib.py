@@ -83,6 +83,7 @@ SIGNATURES = {
                                      c_void_p, c_void_p, c_int, c_int64, c_int, c_void_p]),
     "passion_colsum_work_floats": (c_int64, [c_int]),
     "passion_colsum": (c_int, [c_void_p, c_int, c_int64, c_int, c_void_p, c_void_p, c_void_p]),
+    "passion_colsum_batched": (c_int, [c_void_p, c_int, c_int, c_int64, c_int, c_void_p, c_void_p, c_void_p]),
     "passion_wce_dice_sums_floats": (c_int64, [c_int]),
     "passion_kl_work_floats": (c_int64, [c_int]),
     "passion_kl_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int, c_float, c_void_p,

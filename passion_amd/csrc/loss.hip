@@ -512,6 +512,9 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ g, lo
                                                      float* __restrict__ part, unsigned* __restrict__ counter) {
     __shared__ float red[4][128];
     __shared__ int last;
+    // blockIdx.z: matrix of a batch (the grouped token GEMMs: one bias gradient per weight set)
+    g += (long)blockIdx.z * R * C; out += (long)blockIdx.z * C;
+    part += (long)blockIdx.z * gridDim.y * C; counter += blockIdx.z * gridDim.x;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int col = blockIdx.x * 128 + lane * 2;
     float a0 = 0.f, a1 = 0.f;
@@ -727,19 +730,24 @@ extern "C" int passion_proto_bwd(const void* fs, const void* ft, int dtype, cons
 
 
 extern "C" int64_t passion_colsum_work_floats(int C) { return (int64_t)((C + 127) / 128 + 3) / 4 * 4 + (int64_t)COLSUM_SLICES * C; }
+extern "C" int passion_colsum_batched(const void* g, int dtype, int G, int64_t R, int C, float* out, float* work, void* stream);
 extern "C" int passion_colsum(const void* g, int dtype, int64_t R, int C, float* out, float* work, void* stream) {
-    if (C <= 0 || (C & 1)) return -1014;
+    return passion_colsum_batched(g, dtype, 1, R, C, out, work, stream);
+}
+// G matrices [G][R][C] -> out [G][C]; work: G x passion_colsum_work_floats(C) floats
+extern "C" int passion_colsum_batched(const void* g, int dtype, int G, int64_t R, int C, float* out, float* work, void* stream) {
+    if (C <= 0 || (C & 1) || G < 1) return -1014;
     hipStream_t st = (hipStream_t)stream;
     const int nbx = (C + 127) / 128;
     // enough row slices to put ~2 blocks on every CU, at least 8 rows per wave (two batches of four loads)
     int ny = (int)hmin((long)COLSUM_SLICES, hmax(1L, hmin((long)(512 + nbx - 1) / nbx, R / 32)));
-    unsigned* counter = (unsigned*)work;
-    float* part = work + (nbx + 3) / 4 * 4;
-    if (ny > 1) HIP_RET(hipMemsetAsync(counter, 0, sizeof(unsigned) * (size_t)nbx, st));
+    unsigned* counter = (unsigned*)work;                       // [G][nbx] tickets, then [G][ny][C] partial sums
+    float* part = work + ((long)G * nbx + 3) / 4 * 4;
+    if (ny > 1) HIP_RET(hipMemsetAsync(counter, 0, sizeof(unsigned) * (size_t)nbx * G, st));
     if (dtype == PASSION_BF16)
-        hipLaunchKernelGGL(colsum_kernel<bf16_t>, dim3(nbx, ny), dim3(256), 0, st, (const bf16_t*)g, (long)R, C, out, part, counter);
+        hipLaunchKernelGGL(colsum_kernel<bf16_t>, dim3(nbx, ny, G), dim3(256), 0, st, (const bf16_t*)g, (long)R, C, out, part, counter);
     else if (dtype == PASSION_F32)
-        hipLaunchKernelGGL(colsum_kernel<float>, dim3(nbx, ny), dim3(256), 0, st, (const float*)g, (long)R, C, out, part, counter);
+        hipLaunchKernelGGL(colsum_kernel<float>, dim3(nbx, ny, G), dim3(256), 0, st, (const float*)g, (long)R, C, out, part, counter);
     else
         return -1007;
     LAUNCH_RET();

@@ -244,6 +244,92 @@ def linear(x, weight, bias, bf16):
     return LinearFn.apply(x, weight, bias, w, b)
 
 
+def colsum_batched(g3):
+    """f32 column sums of each matrix of a contiguous [G][R][C] tensor -> [G][C], one launch, fixed summation order"""
+    L.require_gpu(g3)
+    G, R, C = g3.shape
+    lib = L.load()
+    out = torch.empty(G, C, dtype=torch.float32, device=g3.device)
+    work = torch.empty(G * lib.passion_colsum_work_floats(C), dtype=torch.float32, device=g3.device)
+    L.check(lib.passion_colsum_batched(_p(g3), L.dtype_code(g3.dtype), G, R, C, _p(out), _p(work), L.stream_ptr()), "passion_colsum_batched")
+    return out
+
+
+_GROUP_IMAGES = {}     # ids of the G parameters -> [G, *shape] bf16 buffer whose slices are the parameters' registered images
+
+
+def bf16_group_image(params):
+    """the bf16 images of G same-shaped f32 parameters back to back in one (G, *shape) tensor: each parameter's registered image
+    (bf16_image / recast_stale) IS its slice, so one multi-tensor refresh keeps the stack current"""
+    key = tuple(id(p) for p in params)
+    ent = _GROUP_IMAGES.get(key)
+    p0 = params[0]
+    if ent is None or ent[0].device != p0.device or any(r() is not p for r, p in zip(ent[1], params)):
+        import weakref
+        buf = torch.empty((len(params),) + tuple(p0.shape), dtype=torch.bfloat16, device=p0.device)
+        for g, p in enumerate(params):
+            _CAST_REGISTRY[id(p)] = [weakref.ref(p), buf[g], None]
+        ent = _GROUP_IMAGES[key] = (buf, [weakref.ref(p) for p in params])
+    if any(_CAST_REGISTRY[id(p)][2] != (p.data_ptr(), p._version) for p in params):
+        recast_stale()
+    return ent[0]
+
+
+class GroupedLinearFn(torch.autograd.Function):
+    """G token GEMMs with G weight sets in one batched GEMM: y[g] = x[g] W[g]^T + b[g] (the four intra-modal transformers of
+    mmformer share every shape, reference mmformer.py:390-393).  x: (G, R, Cin); w: (G, Cout, Cin) / b: (G, Cout) operands in the
+    compute dtype; the 2G parameters are the autograd inputs that receive f32 gradients (bias: fixed-order column sums)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, n, *params):
+        ctx.save_for_backward(x, w)
+        ctx.n, ctx.has_bias, ctx.wshape = n, b is not None, params[0].shape
+        if b is None:
+            return torch.bmm(x, w.transpose(1, 2))
+        return torch.baddbmm(b.unsqueeze(1), x, w.transpose(1, 2))
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        n = ctx.n
+        g = g.contiguous()
+        dx = torch.bmm(g, w) if ctx.needs_input_grad[0] else None
+        if g.dtype == torch.float32:
+            dw = torch.bmm(g.transpose(1, 2), x)
+        elif _mm_f32_ok(g):
+            dw = torch.bmm(g.transpose(1, 2), x, out_dtype=torch.float32)
+        else:
+            dw = torch.bmm(g.transpose(1, 2), x).float()
+        grads = [dw[i].view(ctx.wshape) for i in range(n)]
+        if ctx.has_bias:
+            db = colsum_batched(g)
+            grads += [db[i] for i in range(n)]
+        return (dx, None, None, None, *grads)
+
+
+def _mm_f32_ok(t):
+    if _MM_F32[0] is None:
+        _mm_f32(t.reshape(-1, t.shape[-1])[:8].t().contiguous(), t.reshape(-1, t.shape[-1])[:8].contiguous())
+    return bool(_MM_F32[0])
+
+
+def linear_grouped(x, weights, biases, bf16):
+    """x: (G, R, Cin) -> (G, R, Cout) with weight set g for matrix g; weights / biases: lists of G parameters (biases may be None)"""
+    n = len(weights)
+    if bf16:
+        w = bf16_group_image(weights)
+        b = bf16_group_image(biases) if biases is not None else None
+        if x.dtype != torch.bfloat16:
+            x = x.to(torch.bfloat16)
+    else:
+        w = torch.stack([p.detach() for p in weights])
+        b = torch.stack([p.detach() for p in biases]) if biases is not None else None
+    if w.dim() > 3:              # (G, Cout, Cin, 1, 1, 1) weights of 1x1x1 convs run as token GEMMs
+        w = w.view(n, w.shape[1], -1)
+    params = list(weights) + (list(biases) if biases is not None else [])
+    return GroupedLinearFn.apply(x, w, b, n, *params)
+
+
 def pack_weight(weight, cache=None):
     """f32 (Cout,Cin,k,k,k) -> packed MFMA operand images (fwd + dgrad); cached per weight version."""
     key = (weight.data_ptr(), weight._version)
