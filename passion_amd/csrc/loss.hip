@@ -7,6 +7,7 @@
 // register partials, wavefront shuffle reduction, one atomic per workgroup per scalar.
 #include <cstdlib>
 #include "common.h"
+#include "conv_common.h"
 #include "passion_hip.h"
 
 namespace {
@@ -578,6 +579,16 @@ inline long red_extra_floats(int B, int J) { return (long)((B + 3) & ~3) + (long
 
 }  // namespace
 
+
+// ticket counters of the fold kernels: n zeroed words of the stream's library scratch (api.cpp); the winner leaves them at zero,
+// kernels of one stream run one after the other -- no memset launch per call
+static int tickets(hipStream_t st, size_t n, unsigned** out) {
+    void* z = nullptr;
+    const int rc = pconv::stream_scratch(st, n * sizeof(unsigned), 0, &z, nullptr);
+    *out = static_cast<unsigned*>(z);
+    return rc;
+}
+
 extern "C" int passion_softmax_fwd(const float* logits, int64_t lsb, int64_t lsv, int64_t lsc, float* probs, int64_t psb,
                                    int64_t psv, int64_t psc, int B, int64_t V, int C, float inv_temp, void* stream) {
     if (C != NC) return -1012;
@@ -632,9 +643,9 @@ extern "C" int passion_wce_dice_fwd(const float* probs, int64_t psb, int64_t psv
                                     int B, int64_t V, int C, float* sums, float* out, void* stream) {
     if (C != NC) return -1012;
     hipStream_t st = (hipStream_t)stream;
-    unsigned* counter = (unsigned*)(sums + 16 * (size_t)B);
+    unsigned* counter = nullptr;
     float* part = sums + 16 * (size_t)B + ((B + 3) & ~3);
-    HIP_RET(hipMemsetAsync(counter, 0, sizeof(unsigned) * (size_t)B, st));
+    { const int rc_ = tickets(st, B, &counter); if (rc_) return rc_; }
     hipLaunchKernelGGL(wce_dice_sums_kernel, dim3(vgrid_red(V), B), dim3(256), 0, st, probs, (long)psb, (long)psv,
                        (long)psc, target, (long)V, sums, part, counter, out);
     LAUNCH_RET();
@@ -657,8 +668,8 @@ extern "C" int passion_kl_fwd(const float* ps, const float* pt, int B, int64_t V
                               float* work, void* stream) {
     if (C != NC) return -1012;
     hipStream_t st = (hipStream_t)stream;
-    unsigned* counter = (unsigned*)work;
-    HIP_RET(hipMemsetAsync(counter, 0, sizeof(unsigned) * (size_t)B, st));
+    unsigned* counter = nullptr;
+    { const int rc_ = tickets(st, B, &counter); if (rc_) return rc_; }
     const float k = temp * temp / ((float)NC * (float)V);
     hipLaunchKernelGGL(kl_fwd_kernel, dim3(vgrid_red(V), B), dim3(256), 0, st, ps, pt, (long)V, k, out,
                        work + ((B + 3) & ~3), counter);
@@ -681,9 +692,9 @@ extern "C" int passion_proto_fwd(const void* fs, const void* ft, int dtype, cons
                                  int Cf, float* work, float* out, void* stream) {
     if (Cf != 4 && Cf != 8) return -1013;
     hipStream_t st = (hipStream_t)stream;
-    unsigned* counter = (unsigned*)(work + (long)B * PW + 8);
+    unsigned* counter = nullptr;                     // every word of `work` that is read is written first by these kernels
     float* part = work + (long)B * PW + 8 + ((B + 3) & ~3);
-    HIP_RET(hipMemsetAsync(work, 0, sizeof(float) * ((size_t)B * PW + 8 + ((B + 3) & ~3)), st));
+    { const int rc_ = tickets(st, B, &counter); if (rc_) return rc_; }
     dim3 grid(vgrid_red(V), B);
     if (dtype == PASSION_F32)
         hipLaunchKernelGGL(proto_sums_kernel<float>, grid, dim3(256), 0, st, (const float*)fs, (const float*)ft, target, (long)V, work, Cf, part, counter);
@@ -710,8 +721,9 @@ extern "C" int passion_proto_bwd(const void* fs, const void* ft, int dtype, cons
     hipStream_t st = (hipStream_t)stream;
     // `work` still holds the forward's sums / validity; the Gp block is overwritten by the last block of bwd1; the ticket
     // counters were left at zero by the forward's reductions
-    unsigned* counter = (unsigned*)(work + (long)B * PW + 8);
+    unsigned* counter = nullptr;
     float* part = work + (long)B * PW + 8 + ((B + 3) & ~3);
+    { const int rc_ = tickets(st, B, &counter); if (rc_) return rc_; }
     dim3 grid(vgrid_red(V), B);
     dim3 grid2(vgrid(V), B);
     if (dtype == PASSION_F32) {
@@ -741,9 +753,9 @@ extern "C" int passion_colsum_batched(const void* g, int dtype, int G, int64_t R
     const int nbx = (C + 127) / 128;
     // enough row slices to put ~2 blocks on every CU, at least 8 rows per wave (two batches of four loads)
     int ny = (int)hmin((long)COLSUM_SLICES, hmax(1L, hmin((long)(512 + nbx - 1) / nbx, R / 32)));
-    unsigned* counter = (unsigned*)work;                       // [G][nbx] tickets, then [G][ny][C] partial sums
+    unsigned* counter = nullptr;                               // [G][nbx] tickets (library scratch); work: [G][ny][C] partial sums
     float* part = work + ((long)G * nbx + 3) / 4 * 4;
-    if (ny > 1) HIP_RET(hipMemsetAsync(counter, 0, sizeof(unsigned) * (size_t)nbx * G, st));
+    { const int rc_ = tickets(st, (size_t)nbx * G, &counter); if (rc_) return rc_; }
     if (dtype == PASSION_BF16)
         hipLaunchKernelGGL(colsum_kernel<bf16_t>, dim3(nbx, ny, G), dim3(256), 0, st, (const bf16_t*)g, (long)R, C, out, part, counter);
     else if (dtype == PASSION_F32)
