@@ -190,20 +190,23 @@ int passion_wce_dice_bwd(const float* probs, int64_t psb, int64_t psv, int64_t p
                          int B, int64_t V, int C, void* stream);
 /* temp_kl_loss_bs (criterions.py:92-103) on already softmaxed(/T) [and upsampled] probabilities.
  * out[b] = T^2 * mean_{c,v} pt*(log pt - log ps) with both clamped to [0.005,1].
- * work: f32 scratch of passion_kl_work_floats(B) floats (fixed-order reduction slots). */
+ * work: f32 scratch of passion_kl_work_floats(B) floats (fixed-order reduction slots).
+ * Bt: samples of the teacher tensor pt ([Bt][V][C]); student sample b is held against teacher sample b % Bt -- the four
+ * uni-modal PASSION students (code/models/mmformer.py:468-531) batched against the one teacher.  0 = B. */
 int64_t passion_kl_work_floats(int B);
-int passion_kl_fwd(const float* ps, const float* pt, int B, int64_t V, int C, float temp,
+int passion_kl_fwd(const float* ps, const float* pt, int B, int Bt, int64_t V, int C, float temp,
                    float* out, float* work, void* stream);
-int passion_kl_bwd(const float* ps, const float* pt, const float* g, float* dps, int B, int64_t V,
+int passion_kl_bwd(const float* ps, const float* pt, const float* g, float* dps, int B, int Bt, int64_t V,
                    int C, float temp, void* stream);
 /* prototype_passion_loss_bs (criterions.py:144-180).  fs, ft: [B][V][Cf] features (dtype),
  * target [B][V][4] f32.  work: f32 scratch of passion_proto_work_floats(B,Cf) floats.
- * out: [B][2] = (proto_loss, dist).  Backward writes dfs (dtype) given g[b] = dL/dproto_loss[b]. */
+ * out: [B][2] = (proto_loss, dist).  Backward writes dfs (dtype) given g[b] = dL/dproto_loss[b].
+ * Bt as above: ft [Bt][V][Cf] and target [Bt][V][4] belong to sample b % Bt (0 = B). */
 int64_t passion_proto_work_floats(int B, int Cf);
-int passion_proto_fwd(const void* fs, const void* ft, int dtype, const float* target, int B,
+int passion_proto_fwd(const void* fs, const void* ft, int dtype, const float* target, int B, int Bt,
                       int64_t V, int Cf, float* work, float* out, void* stream);
 int passion_proto_bwd(const void* fs, const void* ft, int dtype, const float* target,
-                      const float* g, int B, int64_t V, int Cf, float* work, void* dfs,
+                      const float* g, int B, int Bt, int64_t V, int Cf, float* work, void* dfs,
                       void* stream);
 
 /* ---- attention ------------------------------------------------------------------------------

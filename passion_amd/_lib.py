@@ -86,14 +86,14 @@ SIGNATURES = {
     "passion_colsum_batched": (c_int, [c_void_p, c_int, c_int, c_int64, c_int, c_void_p, c_void_p, c_void_p]),
     "passion_wce_dice_sums_floats": (c_int64, [c_int]),
     "passion_kl_work_floats": (c_int64, [c_int]),
-    "passion_kl_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int, c_float, c_void_p,
+    "passion_kl_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int64, c_int, c_float, c_void_p,
                                c_void_p, c_void_p]),
-    "passion_kl_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int,
+    "passion_kl_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64, c_int,
                                c_float, c_void_p]),
     "passion_proto_work_floats": (c_int64, [c_int, c_int]),
-    "passion_proto_fwd": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int64, c_int,
+    "passion_proto_fwd": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int64, c_int,
                                   c_void_p, c_void_p, c_void_p]),
-    "passion_proto_bwd": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int64,
+    "passion_proto_bwd": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int64,
                                   c_int, c_void_p, c_void_p, c_void_p]),
     "passion_attn_scores_fwd": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_float,
                                         c_void_p, c_void_p]),

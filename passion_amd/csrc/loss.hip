@@ -226,14 +226,16 @@ __global__ void wce_dice_bwd_kernel(const float* __restrict__ pr, long psb, long
 }
 
 // ---------------------------------------------------------------- temperature KL
+// Bt: samples of the teacher tensor; student sample b is held against teacher sample b % Bt (the four PASSION students batched
+// against one teacher)
 __global__ __launch_bounds__(256) void kl_fwd_kernel(const float* __restrict__ ps, const float* __restrict__ pt, long V,
                                                      float k, float* __restrict__ out, float* __restrict__ part,
-                                                     unsigned* __restrict__ counter) {
+                                                     unsigned* __restrict__ counter, int Bt) {
     __shared__ float red[4];
-    const int b = blockIdx.y;
+    const int b = blockIdx.y, bt = b % Bt;
     float a = 0.f;
     for (long v = (long)blockIdx.x * blockDim.x + threadIdx.x; v < V; v += (long)gridDim.x * blockDim.x) {
-        const f32x4 s = load4(ps + ((long)b * V + v) * 4), t = load4(pt + ((long)b * V + v) * 4);
+        const f32x4 s = load4(ps + ((long)b * V + v) * 4), t = load4(pt + ((long)bt * V + v) * 4);
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
             const float sc = fminf(fmaxf(s[c], 0.005f), 1.0f), tc = fminf(fmaxf(t[c], 0.005f), 1.0f);
@@ -249,11 +251,11 @@ __global__ __launch_bounds__(256) void kl_fwd_kernel(const float* __restrict__ p
 }
 
 __global__ void kl_bwd_kernel(const float* __restrict__ ps, const float* __restrict__ pt, const float* __restrict__ g,
-                              float* __restrict__ dps, long V, float k) {
-    const int b = blockIdx.y;
+                              float* __restrict__ dps, long V, float k, int Bt) {
+    const int b = blockIdx.y, bt = b % Bt;
     const float gk = g[b] * k;
     for (long v = (long)blockIdx.x * blockDim.x + threadIdx.x; v < V; v += (long)gridDim.x * blockDim.x) {
-        const f32x4 s = load4(ps + ((long)b * V + v) * 4), t = load4(pt + ((long)b * V + v) * 4);
+        const f32x4 s = load4(ps + ((long)b * V + v) * 4), t = load4(pt + ((long)bt * V + v) * 4);
         f32x4 d;
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
@@ -292,9 +294,9 @@ template <typename T> __device__ __forceinline__ void store8(T* p, const float* 
 template <typename T>
 __global__ __launch_bounds__(256) void proto_sums_kernel(const T* __restrict__ fs, const T* __restrict__ ft,
                                                          const float* __restrict__ tg, long V, float* __restrict__ work, int cf,
-                                                         float* __restrict__ part, unsigned* __restrict__ counter) {
+                                                         float* __restrict__ part, unsigned* __restrict__ counter, int Bt) {
     __shared__ float red[4][4 + 8 * CF];
-    const int b = blockIdx.y;
+    const int b = blockIdx.y, bt = b % Bt;      // teacher features / target of student sample b
     float cnt[NC], ss[NC][CF], st[NC][CF];
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
@@ -305,8 +307,8 @@ __global__ __launch_bounds__(256) void proto_sums_kernel(const T* __restrict__ f
     for (long v = (long)blockIdx.x * blockDim.x + threadIdx.x; v < V; v += (long)gridDim.x * blockDim.x) {
         float a[CF], e[CF];
         load8(fs + ((long)b * V + v) * cf, a, cf);
-        load8(ft + ((long)b * V + v) * cf, e, cf);
-        const f32x4 t = load4(tg + ((long)b * V + v) * 4);
+        load8(ft + ((long)bt * V + v) * cf, e, cf);
+        const f32x4 t = load4(tg + ((long)bt * V + v) * 4);
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
             cnt[c] += t[c];
@@ -373,9 +375,9 @@ __device__ __forceinline__ void load_protos(const float* __restrict__ work, int 
 template <typename T>
 __global__ __launch_bounds__(256) void proto_loss_kernel(const T* __restrict__ fs, const T* __restrict__ ft, long V,
                                                          int B, float* __restrict__ work, int cf,
-                                                         float* __restrict__ part, unsigned* __restrict__ counter) {
+                                                         float* __restrict__ part, unsigned* __restrict__ counter, int Bt) {
     __shared__ float red[4][2];
-    const int b = blockIdx.y;
+    const int b = blockIdx.y, bt = b % Bt;      // teacher features / target of student sample b
     const float eps = 1e-5f;
     Protos P;
     load_protos(work, b, B, P);
@@ -383,7 +385,7 @@ __global__ __launch_bounds__(256) void proto_loss_kernel(const T* __restrict__ f
     for (long v = (long)blockIdx.x * blockDim.x + threadIdx.x; v < V; v += (long)gridDim.x * blockDim.x) {
         float a[CF], e[CF];
         load8(fs + ((long)b * V + v) * cf, a, cf);
-        load8(ft + ((long)b * V + v) * cf, e, cf);
+        load8(ft + ((long)bt * V + v) * cf, e, cf);
         float na = 0.f, ne = 0.f;
 #pragma unroll
         for (int h = 0; h < CF; ++h) { na += a[h] * a[h]; ne += e[h] * e[h]; }
@@ -421,9 +423,9 @@ template <typename T>
 __global__ __launch_bounds__(256) void proto_bwd1_kernel(const T* __restrict__ fs, const T* __restrict__ ft,
                                                          const float* __restrict__ g, long V, int B,
                                                          float* __restrict__ work, T* __restrict__ dfs, int cf,
-                                                         float* __restrict__ part, unsigned* __restrict__ counter) {
+                                                         float* __restrict__ part, unsigned* __restrict__ counter, int Bt) {
     __shared__ float red[4][NC * CF];
-    const int b = blockIdx.y;
+    const int b = blockIdx.y, bt = b % Bt;      // teacher features / target of student sample b
     const float eps = 1e-5f;
     Protos P;
     load_protos(work, b, B, P);
@@ -436,7 +438,7 @@ __global__ __launch_bounds__(256) void proto_bwd1_kernel(const T* __restrict__ f
     for (long v = (long)blockIdx.x * blockDim.x + threadIdx.x; v < V; v += (long)gridDim.x * blockDim.x) {
         float a[CF], e[CF], da_[CF];
         load8(fs + ((long)b * V + v) * cf, a, cf);
-        load8(ft + ((long)b * V + v) * cf, e, cf);
+        load8(ft + ((long)bt * V + v) * cf, e, cf);
         float na = 0.f, ne = 0.f;
 #pragma unroll
         for (int h = 0; h < CF; ++h) { na += a[h] * a[h]; ne += e[h] * e[h]; da_[h] = 0.f; }
@@ -480,8 +482,8 @@ __global__ __launch_bounds__(256) void proto_bwd1_kernel(const T* __restrict__ f
 // backward pass 2: prototypes are masked means of fs, so every voxel of class c receives Gp[c]/(count_c+eps)
 template <typename T>
 __global__ void proto_bwd2_kernel(const float* __restrict__ tg, long V, const float* __restrict__ work,
-                                  T* __restrict__ dfs, int cf) {
-    const int b = blockIdx.y;
+                                  T* __restrict__ dfs, int cf, int Bt) {
+    const int b = blockIdx.y, bt = b % Bt;      // teacher features / target of student sample b
     const float eps = 1e-5f;
     float gpn[NC][CF];
 #pragma unroll
@@ -491,7 +493,7 @@ __global__ void proto_bwd2_kernel(const float* __restrict__ tg, long V, const fl
     for (long v = (long)blockIdx.x * blockDim.x + threadIdx.x; v < V; v += (long)gridDim.x * blockDim.x) {
         float d[CF];
         load8(dfs + ((long)b * V + v) * cf, d, cf);
-        const f32x4 t = load4(tg + ((long)b * V + v) * 4);
+        const f32x4 t = load4(tg + ((long)bt * V + v) * 4);
 #pragma unroll
         for (int c = 0; c < NC; ++c)
 #pragma unroll
@@ -664,60 +666,68 @@ extern "C" int passion_wce_dice_bwd(const float* probs, int64_t psb, int64_t psv
     return 0;
 }
 
-extern "C" int passion_kl_fwd(const float* ps, const float* pt, int B, int64_t V, int C, float temp, float* out,
+extern "C" int passion_kl_fwd(const float* ps, const float* pt, int B, int Bt, int64_t V, int C, float temp, float* out,
                               float* work, void* stream) {
     if (C != NC) return -1012;
+    if (Bt <= 0) Bt = B;
+    if (B % Bt) return -1017;
     hipStream_t st = (hipStream_t)stream;
     unsigned* counter = nullptr;
     { const int rc_ = tickets(st, B, &counter); if (rc_) return rc_; }
     const float k = temp * temp / ((float)NC * (float)V);
     hipLaunchKernelGGL(kl_fwd_kernel, dim3(vgrid_red(V), B), dim3(256), 0, st, ps, pt, (long)V, k, out,
-                       work + ((B + 3) & ~3), counter);
+                       work + ((B + 3) & ~3), counter, Bt);
     LAUNCH_RET();
     return 0;
 }
 
-extern "C" int passion_kl_bwd(const float* ps, const float* pt, const float* g, float* dps, int B, int64_t V, int C,
+extern "C" int passion_kl_bwd(const float* ps, const float* pt, const float* g, float* dps, int B, int Bt, int64_t V, int C,
                               float temp, void* stream) {
     if (C != NC) return -1012;
+    if (Bt <= 0) Bt = B;
+    if (B % Bt) return -1017;
     const float k = temp * temp / ((float)NC * (float)V);
-    hipLaunchKernelGGL(kl_bwd_kernel, dim3(vgrid(V), B), dim3(256), 0, (hipStream_t)stream, ps, pt, g, dps, (long)V, k);
+    hipLaunchKernelGGL(kl_bwd_kernel, dim3(vgrid(V), B), dim3(256), 0, (hipStream_t)stream, ps, pt, g, dps, (long)V, k, Bt);
     LAUNCH_RET();
     return 0;
 }
 
 extern "C" int64_t passion_proto_work_floats(int B, int Cf) { (void)Cf; return (int64_t)B * PW + 8 + red_extra_floats(B, 4 + 8 * CF); }
 
-extern "C" int passion_proto_fwd(const void* fs, const void* ft, int dtype, const float* target, int B, int64_t V,
+extern "C" int passion_proto_fwd(const void* fs, const void* ft, int dtype, const float* target, int B, int Bt, int64_t V,
                                  int Cf, float* work, float* out, void* stream) {
     if (Cf != 4 && Cf != 8) return -1013;
+    if (Bt <= 0) Bt = B;
+    if (B % Bt) return -1017;
     hipStream_t st = (hipStream_t)stream;
     unsigned* counter = nullptr;                     // every word of `work` that is read is written first by these kernels
     float* part = work + (long)B * PW + 8 + ((B + 3) & ~3);
     { const int rc_ = tickets(st, B, &counter); if (rc_) return rc_; }
     dim3 grid(vgrid_red(V), B);
     if (dtype == PASSION_F32)
-        hipLaunchKernelGGL(proto_sums_kernel<float>, grid, dim3(256), 0, st, (const float*)fs, (const float*)ft, target, (long)V, work, Cf, part, counter);
+        hipLaunchKernelGGL(proto_sums_kernel<float>, grid, dim3(256), 0, st, (const float*)fs, (const float*)ft, target, (long)V, work, Cf, part, counter, Bt);
     else if (dtype == PASSION_BF16)
-        hipLaunchKernelGGL(proto_sums_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)fs, (const bf16_t*)ft, target, (long)V, work, Cf, part, counter);
+        hipLaunchKernelGGL(proto_sums_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)fs, (const bf16_t*)ft, target, (long)V, work, Cf, part, counter, Bt);
     else
         return -1007;
     LAUNCH_RET();
     hipLaunchKernelGGL(proto_valid_kernel, dim3(1), dim3(64), 0, st, work, B);
     LAUNCH_RET();
     if (dtype == PASSION_F32)
-        hipLaunchKernelGGL(proto_loss_kernel<float>, grid, dim3(256), 0, st, (const float*)fs, (const float*)ft, (long)V, B, work, Cf, part, counter);
+        hipLaunchKernelGGL(proto_loss_kernel<float>, grid, dim3(256), 0, st, (const float*)fs, (const float*)ft, (long)V, B, work, Cf, part, counter, Bt);
     else
-        hipLaunchKernelGGL(proto_loss_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)fs, (const bf16_t*)ft, (long)V, B, work, Cf, part, counter);
+        hipLaunchKernelGGL(proto_loss_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)fs, (const bf16_t*)ft, (long)V, B, work, Cf, part, counter, Bt);
     LAUNCH_RET();
     hipLaunchKernelGGL(proto_out_kernel, dim3((B + 63) / 64), dim3(64), 0, st, work, B, out);
     LAUNCH_RET();
     return 0;
 }
 
-extern "C" int passion_proto_bwd(const void* fs, const void* ft, int dtype, const float* target, const float* g, int B,
+extern "C" int passion_proto_bwd(const void* fs, const void* ft, int dtype, const float* target, const float* g, int B, int Bt,
                                  int64_t V, int Cf, float* work, void* dfs, void* stream) {
     if (Cf != 4 && Cf != 8) return -1013;
+    if (Bt <= 0) Bt = B;
+    if (B % Bt) return -1017;
     hipStream_t st = (hipStream_t)stream;
     // `work` still holds the forward's sums / validity; the Gp block is overwritten by the last block of bwd1; the ticket
     // counters were left at zero by the forward's reductions
@@ -727,13 +737,13 @@ extern "C" int passion_proto_bwd(const void* fs, const void* ft, int dtype, cons
     dim3 grid(vgrid_red(V), B);
     dim3 grid2(vgrid(V), B);
     if (dtype == PASSION_F32) {
-        hipLaunchKernelGGL(proto_bwd1_kernel<float>, grid, dim3(256), 0, st, (const float*)fs, (const float*)ft, g, (long)V, B, work, (float*)dfs, Cf, part, counter);
+        hipLaunchKernelGGL(proto_bwd1_kernel<float>, grid, dim3(256), 0, st, (const float*)fs, (const float*)ft, g, (long)V, B, work, (float*)dfs, Cf, part, counter, Bt);
         LAUNCH_RET();
-        hipLaunchKernelGGL(proto_bwd2_kernel<float>, grid2, dim3(256), 0, st, target, (long)V, work, (float*)dfs, Cf);
+        hipLaunchKernelGGL(proto_bwd2_kernel<float>, grid2, dim3(256), 0, st, target, (long)V, work, (float*)dfs, Cf, Bt);
     } else if (dtype == PASSION_BF16) {
-        hipLaunchKernelGGL(proto_bwd1_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)fs, (const bf16_t*)ft, g, (long)V, B, work, (bf16_t*)dfs, Cf, part, counter);
+        hipLaunchKernelGGL(proto_bwd1_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)fs, (const bf16_t*)ft, g, (long)V, B, work, (bf16_t*)dfs, Cf, part, counter, Bt);
         LAUNCH_RET();
-        hipLaunchKernelGGL(proto_bwd2_kernel<bf16_t>, grid2, dim3(256), 0, st, target, (long)V, work, (bf16_t*)dfs, Cf);
+        hipLaunchKernelGGL(proto_bwd2_kernel<bf16_t>, grid2, dim3(256), 0, st, target, (long)V, work, (bf16_t*)dfs, Cf, Bt);
     } else
         return -1007;
     LAUNCH_RET();

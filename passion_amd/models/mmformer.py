@@ -594,10 +594,11 @@ class Model(nn.Module):
         if P == 1:
             fuse_pred, preds = fuse_all, preds_all
         else:
-            fuse_parts = fuse_all.split(B, 0)
-            preds_parts = [pp.split(B, 0) for pp in preds_all]
-            f1_parts = feats_all[0].split(B, 0)
-            fuse_pred, preds = fuse_parts[0], [pp[0] for pp in preds_parts]
+            # rows [0, B): the teacher; rows [B, 5B): the four uni-modal students, student-major
+            fuse_pred, fuse_stud = fuse_all.split([B, 4 * B], 0)
+            preds_ts = [pp.split([B, 4 * B], 0) for pp in preds_all]
+            preds, preds_stud = [t[0] for t in preds_ts], [t[1] for t in preds_ts]
+            f1_teacher, f1_stud = feats_all[0].split([B, 4 * B], 0)
         pred = ops.softmax_classes(fuse_pred, 1.0, "ncdhw")
         if not training:
             return pred
@@ -624,13 +625,17 @@ class Model(nn.Module):
         inv_t = 1.0 / temp
         pt_full = ops.softmax_classes(fuse_pred.detach(), inv_t, "cl")
         pt_deep = [ops.upsample(ops.softmax_classes(pp.detach(), inv_t, "cl"), 2 ** (j + 1)) for j, pp in enumerate(preds)]
-        f_teacher = f1_parts[0].detach()
+        f_teacher = f1_teacher.detach()
+        # The four students are rows of ONE batch: every loss runs once over 4B samples against the B teacher samples (the kernels
+        # index teacher / target with b % B) instead of four times -- a quarter of the ~190 loss-chain launches of a PASSION step
+        pl_all, d_all = ops.proto_loss(f1_stud, f_teacher, tcl)                       # (4B, 1) each, student-major
+        kl_all = crit.kl_cl(fuse_stud, pt_full, temp)
+        for j in range(4):
+            kl_all = kl_all + 0.5 ** (j + 1) * crit.kl_cl(preds_stud[j], pt_deep[j], temp, 2 ** (j + 1))
+        pl_all, d_all, kl_all = pl_all.view(4, B, 1), d_all.view(4, B, 1), kl_all.view(4, B, 1)
         kl_loss, proto_loss, dist = (torch.zeros(B, 4, device=dev) for _ in range(3))
         for i in range(4):
-            pl, d = ops.proto_loss(f1_parts[i + 1], f_teacher, tcl)
-            kl = crit.kl_cl(fuse_parts[i + 1], pt_full, temp)
-            for j in range(4):
-                kl = kl + 0.5 ** (j + 1) * crit.kl_cl(preds_parts[j][i + 1], pt_deep[j], temp, 2 ** (j + 1))
+            pl, d, kl = pl_all[i], d_all[i], kl_all[i]
             if i != 3:
                 # A sample whose only present modality is i feeds the student exactly what the teacher saw, so
                 # the reference (deterministic kernels) gets kl = proto = dist = 0 *exactly* -- and train.py:266-267

@@ -781,10 +781,12 @@ class KLFn(torch.autograd.Function):
         L.require_gpu(ps, pt)
         ps, pt = ps.contiguous(), pt.contiguous()
         B, D, H, W, C = ps.shape
+        Bt = pt.shape[0]                 # fewer teacher samples than students: student b is held against teacher b % Bt
+        assert B % Bt == 0 and pt.shape[1:] == ps.shape[1:]
         out = torch.empty(B, dtype=torch.float32, device=ps.device)
         lib = L.load()
         work = torch.empty(lib.passion_kl_work_floats(B), dtype=torch.float32, device=ps.device)
-        L.check(lib.passion_kl_fwd(_p(ps), _p(pt), B, D * H * W, C, float(temp), _p(out), _p(work), L.stream_ptr()),
+        L.check(lib.passion_kl_fwd(_p(ps), _p(pt), B, Bt, D * H * W, C, float(temp), _p(out), _p(work), L.stream_ptr()),
                 "passion_kl_fwd")
         ctx.temp = float(temp)
         ctx.save_for_backward(ps, pt)
@@ -796,7 +798,7 @@ class KLFn(torch.autograd.Function):
         B, D, H, W, C = ps.shape
         g = g.contiguous().float().view(-1)
         dps = torch.empty_like(ps)
-        L.check(L.load().passion_kl_bwd(_p(ps), _p(pt), _p(g), _p(dps), B, D * H * W, C, ctx.temp, L.stream_ptr()),
+        L.check(L.load().passion_kl_bwd(_p(ps), _p(pt), _p(g), _p(dps), B, pt.shape[0], D * H * W, C, ctx.temp, L.stream_ptr()),
                 "passion_kl_bwd")
         return dps, None, None
 
@@ -817,7 +819,9 @@ class ProtoFn(torch.autograd.Function):
         lib = L.load()
         work = torch.empty(lib.passion_proto_work_floats(B, Cf), dtype=torch.float32, device=fs.device)
         out = torch.empty(B, 2, dtype=torch.float32, device=fs.device)
-        L.check(lib.passion_proto_fwd(_p(fs), _p(ft), L.dtype_code(fs.dtype), _p(target_cl), B, D * H * W, Cf,
+        Bt = ft.shape[0]                 # the four students batched against one teacher: sample b uses ft / target of b % Bt
+        assert B % Bt == 0 and target_cl.shape[0] == Bt
+        L.check(lib.passion_proto_fwd(_p(fs), _p(ft), L.dtype_code(fs.dtype), _p(target_cl), B, Bt, D * H * W, Cf,
                                       _p(work), _p(out), L.stream_ptr()), "passion_proto_fwd")
         ctx.save_for_backward(fs, ft, target_cl, work)
         loss, dist = out[:, 0:1].clone(), out[:, 1:2].clone()
@@ -830,7 +834,7 @@ class ProtoFn(torch.autograd.Function):
         B, D, H, W, Cf = fs.shape
         g = g.contiguous().float().view(-1)
         dfs = torch.empty_like(fs)
-        L.check(L.load().passion_proto_bwd(_p(fs), _p(ft), L.dtype_code(fs.dtype), _p(target_cl), _p(g), B,
+        L.check(L.load().passion_proto_bwd(_p(fs), _p(ft), L.dtype_code(fs.dtype), _p(target_cl), _p(g), B, ft.shape[0],
                                            D * H * W, Cf, _p(work), _p(dfs), L.stream_ptr()), "passion_proto_bwd")
         return dfs, None, None
 

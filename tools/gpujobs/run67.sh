@@ -1,0 +1,3 @@
+cd $GRAFT_REPO_ROOT
+timeout 1500 python -m pytest tests/test_model_gpu.py tests/test_benchsize_gpu.py tests/test_ops_gpu.py tests/test_fullsize_gpu.py tests/test_rfnet_gpu.py -x -q -m gpu 2>&1 | tail -4
+REPS=2 STEPS=60 bash tools/ab_bench.sh "passion:X=1" -- --workload mmformer128_passion
