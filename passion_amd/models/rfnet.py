@@ -237,9 +237,10 @@ class Model(nn.Module):
         if P == 1:
             fuse_pred, preds = fuse_all, preds_all
         else:
-            fuse_parts = fuse_all.split(B, 0)
-            preds_parts = [pp.split(B, 0) for pp in preds_all]
-            fuse_pred, preds = fuse_parts[0], [pp[0] for pp in preds_parts]
+            # rows [0, B): the teacher; rows [B, 5B): the four uni-modal students, student-major
+            fuse_pred, fuse_stud = fuse_all.split([B, 4 * B], 0)
+            preds_ts = [pp.split([B, 4 * B], 0) for pp in preds_all]
+            preds, preds_stud = [t[0] for t in preds_ts], [t[1] for t in preds_ts]
         pred = ops.softmax_classes(fuse_pred, 1.0, "ncdhw")
         if not training:
             return pred
@@ -267,14 +268,17 @@ class Model(nn.Module):
         inv_t = 1.0 / temp
         pt_full = ops.softmax_classes(fuse_pred.detach(), inv_t, "cl")
         pt_deep = [ops.upsample(ops.softmax_classes(pp.detach(), inv_t, "cl"), ups[j]) for j, pp in enumerate(preds)]
-        f1_parts = materialize(de_f_all[0]).t.split(B, 0)
-        f_teacher = f1_parts[0].detach()
+        f1_teacher, f1_stud = materialize(de_f_all[0]).t.split([B, 4 * B], 0)
+        f_teacher = f1_teacher.detach()
+        # the four students as one batch of 4B against the B teacher samples (kernels index teacher / target with b % B)
+        pl_all, d_all = ops.proto_loss(f1_stud, f_teacher, tcl)
+        kl_all = crit.kl_cl(fuse_stud, pt_full, temp)
+        for j in range(4):
+            kl_all = kl_all + 0.5 ** (j + 1) * crit.kl_cl(preds_stud[j], pt_deep[j], temp, ups[j])
+        pl_all, d_all, kl_all = pl_all.view(4, B, 1), d_all.view(4, B, 1), kl_all.view(4, B, 1)
         kl_loss, proto_loss, dist = (torch.zeros(B, 4, device=dev) for _ in range(3))
         for i in range(4):
-            pl, d = ops.proto_loss(f1_parts[i + 1], f_teacher, tcl)
-            kl = crit.kl_cl(fuse_parts[i + 1], pt_full, temp)
-            for j in range(4):
-                kl = kl + 0.5 ** (j + 1) * crit.kl_cl(preds_parts[j][i + 1], pt_deep[j], temp, ups[j])
+            pl, d, kl = pl_all[i], d_all[i], kl_all[i]
             # single-present-modality sample: student == teacher exactly (see mmformer.py for the rationale)
             differs = (~(mask == onehots[i]).all(1)).float().view(B, 1)
             pl, d, kl = pl * differs, d * differs, kl * differs
