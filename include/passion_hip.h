@@ -181,13 +181,15 @@ int passion_copy_strided(const void* src, int sdtype, int64_t ssb, int64_t ssv, 
  * are added in a fixed order, so the result repeats bit for bit run to run.
  * out: [B][2] = (weighted CE, Dice loss). */
 int64_t passion_wce_dice_sums_floats(int B);
+/* Bt: samples of `target` ([Bt][V][C]); prediction b is scored against target b % Bt (the four per-modality predictions of
+ * decoder_sep against the one label volume, code/models/mmformer.py:546-549).  0 = B. */
 int passion_wce_dice_fwd(const float* probs, int64_t psb, int64_t psv, int64_t psc,
-                         const float* target, int B, int64_t V, int C, float* sums, float* out,
+                         const float* target, int B, int Bt, int64_t V, int C, float* sums, float* out,
                          void* stream);
 /* dprobs (same strides as probs) = g[b][0]*dCE/dp + g[b][1]*dDice/dp ; g: [B][2] */
 int passion_wce_dice_bwd(const float* probs, int64_t psb, int64_t psv, int64_t psc,
                          const float* target, const float* sums, const float* g, float* dprobs,
-                         int B, int64_t V, int C, void* stream);
+                         int B, int Bt, int64_t V, int C, void* stream);
 /* temp_kl_loss_bs (criterions.py:92-103) on already softmaxed(/T) [and upsampled] probabilities.
  * out[b] = T^2 * mean_{c,v} pt*(log pt - log ps) with both clamped to [0.005,1].
  * work: f32 scratch of passion_kl_work_floats(B) floats (fixed-order reduction slots).

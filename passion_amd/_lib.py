@@ -77,10 +77,10 @@ SIGNATURES = {
     "passion_target_to_cl": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int64, c_int, c_void_p]),
     "passion_copy_strided": (c_int, [c_void_p, c_int, c_int64, c_int64, c_int64, c_void_p, c_int,
                                      c_int64, c_int64, c_int64, c_int, c_int64, c_int, c_void_p]),
-    "passion_wce_dice_fwd": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int,
+    "passion_wce_dice_fwd": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int, c_int,
                                      c_int64, c_int, c_void_p, c_void_p, c_void_p]),
     "passion_wce_dice_bwd": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p,
-                                     c_void_p, c_void_p, c_int, c_int64, c_int, c_void_p]),
+                                     c_void_p, c_void_p, c_int, c_int, c_int64, c_int, c_void_p]),
     "passion_colsum_work_floats": (c_int64, [c_int]),
     "passion_colsum": (c_int, [c_void_p, c_int, c_int64, c_int, c_void_p, c_void_p, c_void_p]),
     "passion_colsum_batched": (c_int, [c_void_p, c_int, c_int, c_int64, c_int, c_void_p, c_void_p, c_void_p]),

@@ -145,9 +145,9 @@ constexpr int RED_BLOCKS_MAX = 1024;
 __global__ __launch_bounds__(256) void wce_dice_sums_kernel(const float* __restrict__ pr, long psb, long psv, long psc,
                                                             const float* __restrict__ tg, long V,
                                                             float* __restrict__ sums, float* __restrict__ part,
-                                                            unsigned* __restrict__ counter, float* __restrict__ out) {
+                                                            unsigned* __restrict__ counter, float* __restrict__ out, int Bt) {
     __shared__ float red[4][16];
-    const int b = blockIdx.y;
+    const int b = blockIdx.y, bt = b % Bt;              // target of sample b (several predictions per target: Bt < B)
     float a[16];
 #pragma unroll
     for (int j = 0; j < 16; ++j) a[j] = 0.f;
@@ -161,7 +161,7 @@ __global__ __launch_bounds__(256) void wce_dice_sums_kernel(const float* __restr
 #pragma unroll
             for (int c = 0; c < NC; ++c) p[c] = pr[b * psb + v * psv + c * psc];
         }
-        const f32x4 t = load4(tg + ((long)b * V + v) * 4);
+        const f32x4 t = load4(tg + ((long)bt * V + v) * 4);
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
             a[c] += p[c] * t[c];
@@ -199,8 +199,8 @@ __global__ __launch_bounds__(256) void wce_dice_sums_kernel(const float* __restr
 
 __global__ void wce_dice_bwd_kernel(const float* __restrict__ pr, long psb, long psv, long psc,
                                     const float* __restrict__ tg, const float* __restrict__ sums,
-                                    const float* __restrict__ g, float* __restrict__ dp, long V) {
-    const int b = blockIdx.y;
+                                    const float* __restrict__ g, float* __restrict__ dp, long V, int Bt) {
+    const int b = blockIdx.y, bt = b % Bt;
     const float* s = sums + b * 16;
     const float rt = s[8] + s[9] + s[10] + s[11];
     const float g_ce = g[b * 2 + 0], g_dice = g[b * 2 + 1];
@@ -214,7 +214,7 @@ __global__ void wce_dice_bwd_kernel(const float* __restrict__ pr, long psb, long
         kd2[c] = g_dice * 2.0f * s[c] / ((float)NC * den * den);
     }
     for (long v = (long)blockIdx.x * blockDim.x + threadIdx.x; v < V; v += (long)gridDim.x * blockDim.x) {
-        const f32x4 t = load4(tg + ((long)b * V + v) * 4);
+        const f32x4 t = load4(tg + ((long)bt * V + v) * 4);
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
             const float p = pr[b * psb + v * psv + c * psc];
@@ -642,14 +642,16 @@ extern "C" int passion_copy_strided(const void* src, int sdtype, int64_t ssb, in
 }
 
 extern "C" int passion_wce_dice_fwd(const float* probs, int64_t psb, int64_t psv, int64_t psc, const float* target,
-                                    int B, int64_t V, int C, float* sums, float* out, void* stream) {
+                                    int B, int Bt, int64_t V, int C, float* sums, float* out, void* stream) {
     if (C != NC) return -1012;
+    if (Bt <= 0) Bt = B;
+    if (B % Bt) return -1017;
     hipStream_t st = (hipStream_t)stream;
     unsigned* counter = nullptr;
     float* part = sums + 16 * (size_t)B + ((B + 3) & ~3);
     { const int rc_ = tickets(st, B, &counter); if (rc_) return rc_; }
     hipLaunchKernelGGL(wce_dice_sums_kernel, dim3(vgrid_red(V), B), dim3(256), 0, st, probs, (long)psb, (long)psv,
-                       (long)psc, target, (long)V, sums, part, counter, out);
+                       (long)psc, target, (long)V, sums, part, counter, out, Bt);
     LAUNCH_RET();
     return 0;
 }
@@ -657,11 +659,13 @@ extern "C" int64_t passion_wce_dice_sums_floats(int B) { return 16 * (int64_t)B 
 extern "C" int64_t passion_kl_work_floats(int B) { return red_extra_floats(B, 1); }
 
 extern "C" int passion_wce_dice_bwd(const float* probs, int64_t psb, int64_t psv, int64_t psc, const float* target,
-                                    const float* sums, const float* g, float* dprobs, int B, int64_t V, int C,
+                                    const float* sums, const float* g, float* dprobs, int B, int Bt, int64_t V, int C,
                                     void* stream) {
     if (C != NC) return -1012;
+    if (Bt <= 0) Bt = B;
+    if (B % Bt) return -1017;
     hipLaunchKernelGGL(wce_dice_bwd_kernel, dim3(vgrid(V), B), dim3(256), 0, (hipStream_t)stream, probs, (long)psb,
-                       (long)psv, (long)psc, target, sums, g, dprobs, (long)V);
+                       (long)psv, (long)psc, target, sums, g, dprobs, (long)V, Bt);
     LAUNCH_RET();
     return 0;
 }

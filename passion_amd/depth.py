@@ -273,7 +273,7 @@ class ShardedWceDiceFn(torch.autograd.Function):
         lib = L.load()
         scratch = torch.empty(lib.passion_wce_dice_sums_floats(B), dtype=torch.float32, device=probs.device)
         out = torch.empty(B, 2, dtype=torch.float32, device=probs.device)
-        L.check(lib.passion_wce_dice_fwd(_p(probs), *ps, _p(target_cl), B, V, C, _p(scratch), _p(out), L.stream_ptr()), "passion_wce_dice_fwd")
+        L.check(lib.passion_wce_dice_fwd(_p(probs), *ps, _p(target_cl), B, target_cl.shape[0], V, C, _p(scratch), _p(out), L.stream_ptr()), "passion_wce_dice_fwd")
         sums = scratch[:B * 16].view(B, 16).clone()    # the sixteen sums; the rest of the scratch is per-block reduction slots
         shard.all_reduce(sums)
         Vg = float(V * shard.world)
@@ -293,7 +293,7 @@ class ShardedWceDiceFn(torch.autograd.Function):
         g = g.contiguous().float().clone()
         g[:, 0] *= ctx.scale
         dp = torch.empty_like(probs)
-        L.check(L.load().passion_wce_dice_bwd(_p(probs), *ps, _p(target_cl), _p(sums), _p(g), _p(dp), B, V, C, L.stream_ptr()),
+        L.check(L.load().passion_wce_dice_bwd(_p(probs), *ps, _p(target_cl), _p(sums), _p(g), _p(dp), B, target_cl.shape[0], V, C, L.stream_ptr()),
                 "passion_wce_dice_bwd")
         return dp, None, None, None
 

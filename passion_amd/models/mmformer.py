@@ -606,7 +606,6 @@ class Model(nn.Module):
         tcl = ops.target_to_cl(target)
         if streams:
             main.wait_stream(streams[0])
-        sep_preds = sep_all.split(B, 0)
         eye = torch.eye(4, device=dev)
         maskf = mask.float()
         gates = [(maskf * eye[i]) if idt else eye[i].expand(B, 4) for i in range(4)]
@@ -615,9 +614,11 @@ class Model(nn.Module):
         for j, pp in enumerate(preds):   # deep supervision: softmax -> upsample -> WCE + Dice (mmformer.py:540-544)
             pair = crit.seg_losses_cl(ops.softmax_classes(pp, 1.0, "cl"), tcl, 2 ** (j + 1))
             prm_loss = prm_loss + 0.5 ** (j + 1) * pair.sum(1, keepdim=True)
+        # the four per-modality predictions (4B samples, modality-major) against the B label volumes in one launch
+        sep_pair = ops.wce_dice(sep_all, tcl, "cl").sum(1, keepdim=True).view(4, B, 1)
         sep_loss = torch.zeros(B, 4, device=dev)
         for i in range(4):
-            sep_loss = sep_loss + gates[i] * ops.wce_dice(sep_preds[i], tcl, "cl").sum(1, keepdim=True)
+            sep_loss = sep_loss + gates[i] * sep_pair[i]
         if not passion:
             return pred, prm_loss, sep_loss
 

@@ -249,7 +249,7 @@ class Model(nn.Module):
         # decoder_sep (shared weights) once over the four modalities stacked along the batch axis
         sep_mask = mask.t().reshape(4 * B, 1).contiguous() if idt else None       # row i*B+b = mask[b, i]
         stacked = [Feat(torch.cat([encs[i][l].t for i in range(4)], 0), sep_mask, 0) for l in range(4)]
-        sep_preds = self.decoder_sep(*stacked).split(B, 0)
+        sep_all = self.decoder_sep(*stacked)
         eye = torch.eye(4, device=dev)
         maskf = mask.float()
         gates = [(maskf * eye[i]) if idt else eye[i].expand(B, 4) for i in range(4)]
@@ -259,9 +259,10 @@ class Model(nn.Module):
         for j, pp in enumerate(preds):
             pair = crit.seg_losses_cl(ops.softmax_classes(pp, 1.0, "cl"), tcl, ups[j])
             prm_loss = prm_loss + 0.5 ** (j + 1) * pair.sum(1, keepdim=True)
+        sep_pair = ops.wce_dice(sep_all, tcl, "cl").sum(1, keepdim=True).view(4, B, 1)      # 4B predictions against the B label volumes
         sep_loss = torch.zeros(B, 4, device=dev)
         for i in range(4):
-            sep_loss = sep_loss + gates[i] * ops.wce_dice(sep_preds[i], tcl, "cl").sum(1, keepdim=True)
+            sep_loss = sep_loss + gates[i] * sep_pair[i]
         if not passion:
             return pred, prm_loss, sep_loss
 

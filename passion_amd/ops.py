@@ -750,7 +750,7 @@ class WceDiceFn(torch.autograd.Function):
         scratch = torch.empty(lib.passion_wce_dice_sums_floats(B), dtype=torch.float32, device=probs.device)
         sums = scratch[:B * 16].view(B, 16)            # the rest: the reduction's per-block slots (fixed-order sums)
         out = torch.empty(B, 2, dtype=torch.float32, device=probs.device)
-        L.check(lib.passion_wce_dice_fwd(_p(probs), *ps, _p(target_cl), B, V, C, _p(scratch), _p(out),
+        L.check(lib.passion_wce_dice_fwd(_p(probs), *ps, _p(target_cl), B, target_cl.shape[0], V, C, _p(scratch), _p(out),
                                          L.stream_ptr()), "passion_wce_dice_fwd")
         ctx.layout = layout
         ctx.save_for_backward(probs, target_cl, sums)
@@ -762,7 +762,7 @@ class WceDiceFn(torch.autograd.Function):
         B, V, C, ps = _strides(probs, ctx.layout)
         g = g.contiguous().float()
         dp = torch.empty_like(probs)
-        L.check(L.load().passion_wce_dice_bwd(_p(probs), *ps, _p(target_cl), _p(sums), _p(g), _p(dp), B, V, C,
+        L.check(L.load().passion_wce_dice_bwd(_p(probs), *ps, _p(target_cl), _p(sums), _p(g), _p(dp), B, target_cl.shape[0], V, C,
                                               L.stream_ptr()), "passion_wce_dice_bwd")
         return dp, None, None
 

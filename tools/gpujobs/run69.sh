@@ -1,0 +1,3 @@
+cd $GRAFT_REPO_ROOT
+timeout 1500 python -m pytest tests/test_model_gpu.py tests/test_benchsize_gpu.py tests/test_ops_gpu.py tests/test_rfnet_gpu.py tests/test_depth_gpu.py -x -q -m gpu 2>&1 | tail -3
+REPS=2 STEPS=100 bash tools/ab_bench.sh "now:X=1"
