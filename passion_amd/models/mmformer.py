@@ -444,6 +444,12 @@ class Model(nn.Module):
             cache[dev] = [pool[i % n] for i in range(4)]
         return cache[dev]
 
+    def _deep_weights_on(self, dev):
+        cache = self.__dict__.setdefault("_deep_w_dev", {})
+        if dev not in cache:
+            cache[dev] = torch.tensor([0.5, 0.25, 0.125, 0.0625], device=dev).view(4, 1, 1)
+        return cache[dev]
+
     def _onehots_on(self, dev):
         """masks_mod0..3 (plain CPU attributes, as in the reference) copied to the device once, not per forward"""
         cache = self.__dict__.setdefault("_onehots_dev", {})
@@ -606,19 +612,16 @@ class Model(nn.Module):
         tcl = ops.target_to_cl(target)
         if streams:
             main.wait_stream(streams[0])
-        eye = torch.eye(4, device=dev)
-        maskf = mask.float()
-        gates = [(maskf * eye[i]) if idt else eye[i].expand(B, 4) for i in range(4)]
+        # Loss glue with as few tiny launches as possible (each is ~4 us of dependent latency on the main stream between forward and
+        # backward, and twice that in host work): (B, 4) matrices instead of per-modality loops.  gate[b, i] = 1 if modality i of
+        # sample b takes part (idt: present in the data; pdt: always) -- the reference's `* mask` / one-hot selection.
+        gate = mask.float() if idt else torch.ones(B, 4, device=dev)
 
-        prm_loss = torch.zeros(B, 1, device=dev)
-        for j, pp in enumerate(preds):   # deep supervision: softmax -> upsample -> WCE + Dice (mmformer.py:540-544)
-            pair = crit.seg_losses_cl(ops.softmax_classes(pp, 1.0, "cl"), tcl, 2 ** (j + 1))
-            prm_loss = prm_loss + 0.5 ** (j + 1) * pair.sum(1, keepdim=True)
+        # deep supervision: softmax -> upsample -> WCE + Dice (mmformer.py:540-544), weights 1/2, 1/4, 1/8, 1/16
+        pairs = [crit.seg_losses_cl(ops.softmax_classes(pp, 1.0, "cl"), tcl, 2 ** (j + 1)) for j, pp in enumerate(preds)]
+        prm_loss = (torch.stack(pairs, 0) * self._deep_weights_on(dev)).sum((0, 2)).view(B, 1)
         # the four per-modality predictions (4B samples, modality-major) against the B label volumes in one launch
-        sep_pair = ops.wce_dice(sep_all, tcl, "cl").sum(1, keepdim=True).view(4, B, 1)
-        sep_loss = torch.zeros(B, 4, device=dev)
-        for i in range(4):
-            sep_loss = sep_loss + gates[i] * sep_pair[i]
+        sep_loss = gate * ops.wce_dice(sep_all, tcl, "cl").sum(1).view(4, B).t()
         if not passion:
             return pred, prm_loss, sep_loss
 
@@ -633,19 +636,15 @@ class Model(nn.Module):
         kl_all = crit.kl_cl(fuse_stud, pt_full, temp)
         for j in range(4):
             kl_all = kl_all + 0.5 ** (j + 1) * crit.kl_cl(preds_stud[j], pt_deep[j], temp, 2 ** (j + 1))
-        pl_all, d_all, kl_all = pl_all.view(4, B, 1), d_all.view(4, B, 1), kl_all.view(4, B, 1)
-        kl_loss, proto_loss, dist = (torch.zeros(B, 4, device=dev) for _ in range(3))
-        for i in range(4):
-            pl, d, kl = pl_all[i], d_all[i], kl_all[i]
-            if i != 3:
-                # A sample whose only present modality is i feeds the student exactly what the teacher saw, so
-                # the reference (deterministic kernels) gets kl = proto = dist = 0 *exactly* -- and train.py:266-267
-                # then turns that 0/0 into an all-false rp_mask.  Teacher and student are different rows of one
-                # batched launch here (GEMM rounding may differ per row), so the identity is imposed instead of
-                # hoped for.  (Not for T2: its tokens are T1's, mmformer.py:522.)
-                differs = (~(mask == onehots[i]).all(1)).float().view(B, 1)
-                pl, d, kl = pl * differs, d * differs, kl * differs
-            proto_loss = proto_loss + gates[i] * pl
-            dist = dist + gates[i] * d
-            kl_loss = kl_loss + gates[i] * kl
+        # A sample whose only present modality is i feeds student i exactly what the teacher saw, so the reference (deterministic
+        # kernels) gets kl = proto = dist = 0 *exactly* -- and train.py:266-267 then turns that 0/0 into an all-false rp_mask.
+        # Teacher and student are different rows of one batched launch here (GEMM rounding may differ per row), so the identity
+        # is imposed instead of hoped for.  (Not for T2: its tokens are T1's, mmformer.py:522.)
+        only = mask & (mask.sum(1, keepdim=True) == 1)                                # [b, i]: i is sample b's only modality
+        differs = (~only).float()
+        differs[:, 3] = 1.0
+        gd = gate * differs
+        kl_loss = gd * kl_all.view(4, B).t()
+        proto_loss = gd * pl_all.view(4, B).t()
+        dist = gd * d_all.view(4, B).t()
         return pred, prm_loss, sep_loss, kl_loss, proto_loss, dist
