@@ -315,6 +315,8 @@ int passion_augment(const float* crop, const int32_t* seg, int S0, int S1, int S
  * that ran, spelled as rocprofv3 prints it (e.g. "wgrad_lean_kernel<3, 1>"). */
 typedef struct { int32_t kind; float ms; double bytes; double flops; char name[64]; } passion_prof_rec_t;
 void passion_prof_enable(int on);
+/* ... restricted to launches whose algorithmic bytes lie in [lo, hi] (0, 1e300 = all) */
+void passion_prof_filter(double lo, double hi);
 int passion_prof_read(passion_prof_rec_t* rec, int cap);
 /* like passion_prof_read but leaves the records (and their events) in place: for launches recorded inside a HIP
  * graph capture, whose event pairs are re-recorded by every replay; ms = latest replay, -1 if it cannot be timed

@@ -129,6 +129,7 @@ SIGNATURES = {
                                    c_double, c_double, c_double, c_int64, c_int, c_void_p]),
     "passion_set_option": (c_int, [c_char_p, c_int]),
     "passion_prof_enable": (None, [c_int]),
+    "passion_prof_filter": (None, [c_double, c_double]),
     "passion_prof_read": (c_int, [POINTER(ProfRec), c_int]),
     "passion_prof_peek": (c_int, [POINTER(ProfRec), c_int]),
 }

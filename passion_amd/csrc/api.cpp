@@ -9,6 +9,7 @@
 #include "prof.h"
 
 int g_passion_prof_on = 0;
+double g_passion_prof_lo = 0.0, g_passion_prof_hi = 1e300;
 
 namespace {
 struct Pending { int kind; double bytes, flops; hipEvent_t e0, e1; bool closed; char name[64]; };
@@ -134,6 +135,9 @@ extern "C" int passion_set_option(const char* name, int value) {
 }
 
 extern "C" void passion_prof_enable(int on) { g_passion_prof_on = on; }
+// only launches whose algorithmic bytes lie in [lo, hi] keep their event pair (bench.py: the launches of ONE kernel family inside the
+// timed region -- every pair costs the step ~10 us); (0, 1e300) = all
+extern "C" void passion_prof_filter(double lo, double hi) { g_passion_prof_lo = lo; g_passion_prof_hi = hi; }
 
 // Drains finished records (synchronises on their events: call outside the timed region).
 extern "C" int passion_prof_read(passion_prof_rec_t* rec, int cap) {

@@ -1098,6 +1098,11 @@ def prof_enable(on):
     L.load().passion_prof_enable(mask)
 
 
+def prof_filter(lo=0.0, hi=1e300):
+    """keep event pairs only for launches whose algorithmic bytes lie in [lo, hi] (default: all)"""
+    L.load().passion_prof_filter(float(lo), float(hi))
+
+
 def prof_read(cap=65536, keep=False):
     """(kind, ms, algorithmic bytes, flops, kernel name) per timed launch.  keep=True leaves the records in place: the event pairs
     recorded during a HIP-graph capture are re-timed by every replay."""
