@@ -135,6 +135,7 @@ def encoders_grouped(encs, x, mask, dtype):
     return feats
 
 
+FUSE_STREAM = _os.environ.get("PASSION_FUSE_STREAM", "1") != "0"       # fusion blocks of levels 4..1 on a side stream
 GROUPED_INTRA = _os.environ.get("PASSION_GROUPED_INTRA", "1") != "0"   # the four intra-modal transformers as batched GEMMs
 
 
@@ -244,15 +245,24 @@ class Decoder_fuse(nn.Module):
         self.RFM2 = fusion_prenorm(in_channel=c * 2, num_cls=num_cls)
         self.RFM1 = fusion_prenorm(in_channel=c * 1, num_cls=num_cls)
 
-    def forward(self, x1, x2, x3, x4, x5, mask=None):
-        """x1..x4: lists of the four modality Feats (already carrying their masks); x5: fused level-5 Feat"""
+    def fuse_levels(self, x1, x2, x3, x4):
+        """the fusion blocks of levels 4..1 (reference mmformer.py:159-176: RFM4..RFM1 on the four modality features): they depend
+        on the encoders only, so Model.forward may run them on a side stream while the transformers occupy the main one"""
+        xs = (x1, x2, x3, x4)
+        return {lvl: getattr(self, f"RFM{lvl}")(xs[lvl - 1]) for lvl in (4, 3, 2, 1)}
+
+    def forward(self, x1, x2, x3, x4, x5, mask=None, fused=None, wait=None):
+        """x1..x4: lists of the four modality Feats (already carrying their masks); x5: fused level-5 Feat.
+        fused: fuse_levels(x1..x4) computed beforehand (on another stream: `wait()` is called before their first use)"""
         xs = (x1, x2, x3, x4)
         feats, preds = {}, {}
         feats[5] = self.RFM5([x5], want_stats=False)        # feeds a logit head and an upsampling only
         preds[4] = run_conv(self.seg_d4, feats[5], norm=False, out_dtype=torch.float32).t
         h = self.d4_c1(_up2(feats[5]))
+        if wait is not None:
+            wait()
         for lvl in (4, 3, 2, 1):
-            r = getattr(self, f"RFM{lvl}")(xs[lvl - 1])
+            r = fused[lvl] if fused is not None else getattr(self, f"RFM{lvl}")(xs[lvl - 1])
             f = getattr(self, f"d{lvl}_out")(getattr(self, f"d{lvl}_c2")([r, h]), want_stats=False)
             feats[lvl] = f
             if lvl > 1:
@@ -596,7 +606,26 @@ class Model(nn.Module):
             else:
                 sep_all = self.decoder_sep(*stacked)
 
-        fuse_all, preds_all, feats_all = self.decoder_fuse(*xs, self._inter(intra, tok_mask, pos_cat, B, p, P))
+        # The fusion blocks of levels 4..1 read encoder features only: on a side stream they run under the transformers' chain of
+        # tiny launches (forward) and under the decoder's own backward chain (autograd replays them on that stream)
+        fused = wait = None
+        if streams and FUSE_STREAM:
+            s1 = streams[1]
+            s1.wait_stream(main)
+            masks_all.record_stream(s1)
+            for lv in xs:
+                for f in lv:                              # made on the main stream, read (forward and backward) on this one
+                    f.t.record_stream(s1)
+                    if f._stats[0] is not None:
+                        f._stats[0].record_stream(s1)
+            with torch.cuda.stream(s1):
+                fused = self.decoder_fuse.fuse_levels(*xs)
+                for f in fused.values():
+                    f.t.record_stream(main)
+                    if f._stats[0] is not None:
+                        f._stats[0].record_stream(main)
+            wait = lambda: main.wait_stream(s1)           # noqa: E731
+        fuse_all, preds_all, feats_all = self.decoder_fuse(*xs, self._inter(intra, tok_mask, pos_cat, B, p, P), fused=fused, wait=wait)
         if P == 1:
             fuse_pred, preds = fuse_all, preds_all
         else:
