@@ -53,6 +53,9 @@ def init(backend=None):
     return Ctx(rank, world, local, device, backend)
 
 
+_DDP_DEBUG = os.environ.get("PASSION_DDP_DEBUG") == "1"
+
+
 class GradReducer:
     """Bucketed SUM all-reduce of parameter gradients + initial parameter broadcast from rank 0.
 
@@ -70,6 +73,8 @@ class GradReducer:
 
     def __init__(self, model, ctx, bucket_mb=32, overlap=True):
         self.ctx = ctx
+        self._names = {id(p): k for k, p in model.named_parameters()}
+        self._stream_objs = {}
         self.params = [p for p in model.parameters() if p.requires_grad]
         self.buckets = []
         cur, cur_bytes = [], 0
@@ -101,6 +106,8 @@ class GradReducer:
         def hook(_param):
             if self._on_gpu:
                 self._streams[bi].add(_raw_stream())     # raw handle: a Stream object costs 10 us to build, per parameter
+                if _DDP_DEBUG and self.ctx.rank == 0:
+                    print(f"[ddp] hook bucket {bi} param {self._names.get(id(_param))} stream {_raw_stream():#x} pending {self._pending[bi] - 1}", flush=True)
             self._pending[bi] -= 1
             # Collectives must be issued in the same order on every rank.  Readiness order can differ between ranks (a
             # parameter that got no gradient on one of them), so buckets are launched strictly by index: bucket k goes out
@@ -110,14 +117,29 @@ class GradReducer:
                 self._next += 1
         return hook
 
+    def _stream_of(self, raw):
+        """torch Stream for a raw handle noted by a hook.  The default stream reports handle 0, but an event recorded on
+        torch.cuda.ExternalStream(0) does NOT wait for the default stream's pending work on this stack (152 of 200 trials in
+        tools/null_stream_event.py ran ahead): that was the stale-bucket race behind the flaky 2-rank test.  Handle 0 maps back to
+        torch.cuda.default_stream(); the side streams' handles are real pointers and wrap fine."""
+        st = self._stream_objs.get(raw)
+        if st is None:
+            d = torch.cuda.default_stream(self.params[0].device)
+            st = d if raw == d.cuda_stream else torch.cuda.ExternalStream(raw)
+            self._stream_objs[raw] = st
+        return st
+
     def _launch(self, bi):
         bucket, flat = self.buckets[bi], self.flat[bi]
         if self._on_gpu:
             cur = torch.cuda.current_stream()
+            if _DDP_DEBUG and self.ctx.rank == 0:
+                print(f"[ddp] launch bucket {bi} on {cur.cuda_stream:#x}, noted {[hex(r) for r in self._streams[bi]]}, "
+                      f"missing grads {[self._names.get(id(p)) for p in bucket if p.grad is None]}", flush=True)
             for raw in self._streams[bi]:
                 if raw != cur.cuda_stream:
                     ev = torch.cuda.Event()
-                    ev.record(torch.cuda.ExternalStream(raw))
+                    ev.record(self._stream_of(raw))
                     cur.wait_event(ev)
             self._streams[bi].clear()
         grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in bucket]
