@@ -135,6 +135,7 @@ def encoders_grouped(encs, x, mask, dtype):
     return feats
 
 
+LOSS_STREAMS = _os.environ.get("PASSION_LOSS_STREAMS", "1") != "0"     # deep-supervision / decoder_sep losses on side streams
 FUSE_STREAM = _os.environ.get("PASSION_FUSE_STREAM", "1") != "0"       # fusion blocks of levels 4..1 on a side stream
 GROUPED_INTRA = _os.environ.get("PASSION_GROUPED_INTRA", "1") != "0"   # the four intra-modal transformers as batched GEMMs
 
@@ -639,18 +640,43 @@ class Model(nn.Module):
             return pred
 
         tcl = ops.target_to_cl(target)
-        if streams:
-            main.wait_stream(streams[0])
         # Loss glue with as few tiny launches as possible (each is ~4 us of dependent latency on the main stream between forward and
         # backward, and twice that in host work): (B, 4) matrices instead of per-modality loops.  gate[b, i] = 1 if modality i of
         # sample b takes part (idt: present in the data; pdt: always) -- the reference's `* mask` / one-hot selection.
         gate = mask.float() if idt else torch.ones(B, 4, device=dev)
 
-        # deep supervision: softmax -> upsample -> WCE + Dice (mmformer.py:540-544), weights 1/2, 1/4, 1/8, 1/16
-        pairs = [crit.seg_losses_cl(ops.softmax_classes(pp, 1.0, "cl"), tcl, 2 ** (j + 1)) for j, pp in enumerate(preds)]
-        prm_loss = (torch.stack(pairs, 0) * self._deep_weights_on(dev)).sum((0, 2)).view(B, 1)
-        # the four per-modality predictions (4B samples, modality-major) against the B label volumes in one launch
-        sep_loss = gate * ops.wce_dice(sep_all, tcl, "cl").sum(1).view(4, B).t()
+        def deep_supervision():
+            # softmax -> upsample -> WCE + Dice (mmformer.py:540-544), weights 1/2, 1/4, 1/8, 1/16
+            pairs = [crit.seg_losses_cl(ops.softmax_classes(pp, 1.0, "cl"), tcl, 2 ** (j + 1)) for j, pp in enumerate(preds)]
+            return (torch.stack(pairs, 0) * self._deep_weights_on(dev)).sum((0, 2)).view(B, 1)
+
+        def sep_losses():
+            # the four per-modality predictions (4B samples, modality-major) against the B label volumes in one launch
+            return gate * ops.wce_dice(sep_all, tcl, "cl").sum(1).view(4, B).t()
+
+        if streams and LOSS_STREAMS:
+            # Both are side branches of the graph: on side streams their backward (softmax / upsample / loss gradients) runs under
+            # the start of the fusion decoder's backward chain instead of in front of it.  decoder_sep's loss stays on decoder_sep's
+            # stream, the deep-supervision branch gets its own.
+            s0, s2 = streams[0], streams[2]
+            for s_ in (s0, s2):
+                s_.wait_stream(main)
+                tcl.record_stream(s_)
+            gate.record_stream(s0)
+            for pp in preds:
+                pp.record_stream(s2)
+            with torch.cuda.stream(s2):
+                prm_loss = deep_supervision()
+                prm_loss.record_stream(main)
+            with torch.cuda.stream(s0):
+                sep_loss = sep_losses()
+                sep_loss.record_stream(main)
+            main.wait_stream(s0)
+            main.wait_stream(s2)
+        else:
+            if streams:
+                main.wait_stream(streams[0])
+            prm_loss, sep_loss = deep_supervision(), sep_losses()
         if not passion:
             return pred, prm_loss, sep_loss
 
