@@ -229,28 +229,45 @@ def main():
     parallel.barrier(ctx)
     torch.cuda.synchronize()
     fam_warm = {}
-    dom_kind = 2
-    warm_recs = []
-    flt = (0.0, 1e300)
+    dom, dom_kind = None, 2
+    warm_recs, alone_recs = [], []
     if want_events:
         ops.prof_enable(0)
         warm_recs = [r for r in ops.prof_read() if r[1] >= 0]
         for r in warm_recs:
             fam_warm[r[0]] = fam_warm.get(r[0], 0.0) + r[1]
-        conv_fam = {k: v for k, v in fam_warm.items() if k < 4}
-        if conv_fam:          # the family (fwd3 / fwd1 / dgrad / wgrad) with the largest total; its top kernel is reported
-            dom_kind = max(conv_fam, key=conv_fam.get)
-        # Inside the timed region only the launches of that family's top kernel keep their event pairs -- selected by their
-        # algorithmic bytes, the one thing the library knows before it launches (every pair costs the step ~10 us of host work and
-        # a marker packet: all dgrad + finish + attention launches, ~130 pairs per step, took 3 % off the figure being measured).
-        # Attention and the finish kernels are reported from the warm-up steps (live, all five streams), which time everything.
-        by_name = {}
-        for r in warm_recs:
-            if r[0] == dom_kind:
-                by_name.setdefault(r[4], []).append(r)
-        if by_name:
-            top = max(by_name.values(), key=lambda rs: sum(r[1] for r in rs))
+        # Which kernel is the dominant one: three more untimed steps (every rank, the gradient all-reduce is collective) with
+        # the whole step on ONE stream.  Live, the launches of up to five streams share the CUs and stretch each other, so a
+        # live total says who waited longest beside the others, not who needs the most machine time; rocprofv3 (whose
+        # interception makes the step host-bound) sees nearly stand-alone launches, and these steps reproduce its ranking.  The
+        # conv kernel (any of fwd3 / fwd1 / dgrad / wgrad) with the largest single-stream total is the one reported; both its
+        # live and its single-stream duration are given so the live one can be checked against profiles/*kernel_stats.csv.
+        was = mmformer.ENC_STREAMS
+        mmformer.ENC_STREAMS = False
+        ops.prof_enable(CONV_KINDS | ATTN_KINDS | FINISH_KIND)
+        for _ in range(3):
+            eager_step()
+        torch.cuda.synchronize()
+        ops.prof_enable(0)
+        mmformer.ENC_STREAMS = was
+        alone_recs = [r for r in ops.prof_read() if r[1] >= 0]
+        tot = {}
+        for r in alone_recs:                        # per kernel instantiation, as rocprofv3 names it
+            if r[0] < 4:
+                tot[r[4]] = tot.get(r[4], 0.0) + r[1]
+        flt = (0.0, 1e300)
+        if tot:
+            dom = max(tot, key=tot.get)
+            top = [r for r in alone_recs if r[4] == dom]
+            dom_kind = top[0][0]
+            # Inside the timed region only that kernel's launches keep their event pairs -- selected by kind and by their
+            # algorithmic bytes, the one thing the library knows before it launches (every pair costs the step ~10 us of host
+            # work and a marker packet: all dgrad + finish + attention launches, ~130 pairs per step, took 3 % off the figure
+            # being measured).  Attention and the finish kernels are reported from the warm-up steps (live, all streams).
             flt = (min(r[2] for r in top) * 0.999, max(r[2] for r in top) * 1.001)
+        eager_step()                                # back on the side streams before the clock starts
+        parallel.barrier(ctx)
+        torch.cuda.synchronize()
         ops.prof_filter(*flt)
         ops.prof_enable(1 << dom_kind)
     t0 = time.perf_counter()
@@ -270,22 +287,7 @@ def main():
     dt = parallel.all_reduce_max(ctx, dt)
     final_loss = float(loss)
 
-    # The same kernel without stream overlap: three more steps (every rank, the gradient all-reduce is collective) with the
-    # modality encoders / decoder_sep on the main stream.  Inside the timed region the launches of five streams share the CUs and
-    # stretch each other; rocprofv3 (whose interception makes the step host-bound) sees nearly stand-alone launches.  Reporting
-    # both lets the live number be checked against profiles/*kernel_stats.csv.
     timed_recs = ops.prof_read() if want_events else []
-    alone_recs = []
-    if want_events:
-        was = mmformer.ENC_STREAMS
-        mmformer.ENC_STREAMS = False
-        ops.prof_enable((1 << dom_kind) | ATTN_KINDS | (FINISH_KIND if dom_kind == 2 else 0))
-        for _ in range(3):
-            eager_step()
-        torch.cuda.synchronize()
-        ops.prof_enable(0)
-        mmformer.ENC_STREAMS = was
-        alone_recs = [r for r in ops.prof_read() if r[1] >= 0]
 
     if ctx.rank != 0:
         return
@@ -308,12 +310,7 @@ def main():
     if want_events:
         recs = [r for r in timed_recs if r[1] >= 0]
         live_all = warm_recs                        # every conv / finish / attention launch of the warm-up steps, all streams live
-        tot = {}
-        for r in recs:                              # per kernel instantiation, as rocprofv3 names it
-            if r[0] < 4:
-                tot[r[4]] = tot.get(r[4], 0.0) + r[1]
-        if tot:
-            dom = max(tot, key=tot.get)             # the kernel with the largest total time in the timed region
+        if dom and any(r[4] == dom for r in recs):
             rk = [r for r in recs if r[4] == dom]
             ms, by, fl = sum(r[1] for r in rk), sum(r[2] for r in rk), sum(r[3] for r in rk)
             ach = by / (ms * 1e-3) / 1e9
