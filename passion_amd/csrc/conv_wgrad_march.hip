@@ -1,0 +1,363 @@
+// Marching bf16 weight gradient of the 3x3x3 stride-1 convs with EIGHT output channels (the 128^3 level of every encoder /
+// decoder of the reference, code/models/mmformer.py:24-64,66-189 via general_conv3d_prenorm, blocks.py:300-316):
+//   dW[co][ci][tap] = sum_vox dY[vox][co] * act(x)[vox + tap][ci]      (+ dbias[co] = sum_vox dY[vox][co])
+// Same operand images, descriptors, slab layout and fixed-order fold as wgrad_lean_kernel (conv_wgrad_lean.hip), which this
+// kernel replaces where it applies.  What the counters and the arithmetic said about that kernel at Cout = 8: it is bound by
+// LDS reads and MFMA issue, not by HBM -- a 16-row MFMA tile holds 8 useful rows, a 4x8x8 brick re-stages 2.34x its voxels
+// as halo, and every K step re-reads both operands through ds_read_b64_tr_b16.  Two changes:
+//   * the idle half of the M tile carries a SECOND depth tap.  Rows 0..7 are dY[v][co], rows 8..15 are dY[v - e_d][co] (the
+//     previous plane, a per-lane address, no extra bytes); the columns are X[v + t'][ci] for the 18 taps t' with depth
+//     offset -1 and 0.  Row block 0 yields the depth taps -1 and 0, row block 1 yields 0 (dropped) and +1: 9 column tiles
+//     of 16 instead of 14, 27/36 of the MFMA work useful instead of 27/56;
+//   * a workgroup owns an 8 x 16 tile of the (H, W) plane and MARCHES along D (as conv_march.hip does for forward / dgrad): each
+//     input plane is fetched once per tile (halo 10/8 x 18/16 = 1.41 instead of 2.34), planes live in a 4-slot LDS ring, one
+//     barrier per plane, four planes of loads in flight in registers, all index arithmetic (padding, concat lookup, mask,
+//     statistics) done once per tile.  Each wave owns two tile rows = one K step of 32 voxels per plane and all 9 column
+//     tiles; the four waves' partial sums meet in LDS once, in fixed order, before the slot is written.
+// The bias gradient is summed by the threads that stage dY (packed f32 adds), folded in fixed order at the end.
+#include "conv_common.h"
+#include "prof.h"
+
+namespace pconv { int g_wgrad_march = 1; extern int g_conv_dbg; }
+using namespace pconv;
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+template <typename T> __device__ __forceinline__ T gload(const void* ptr) {      // a GLOBAL load, whatever the pointer's history
+    return *reinterpret_cast<const T __attribute__((address_space(1)))*>(reinterpret_cast<unsigned long long>(ptr));
+}
+
+__device__ __host__ constexpr int tapoff(int hw) { return ((hw / 3) * 20 + hw % 3) * 16; }     // staged-plane byte offset of in-plane tap hw
+
+__device__ __forceinline__ float uniform(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v)));
+}
+
+__device__ __forceinline__ bf16x8 tr_read8(const char* p0, const char* p1) {
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p0));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p1));
+    const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+constexpr int WTH = 8, WTW = 16;                  // tile of the (H, W) plane
+constexpr int XRW = 20;                           // voxels per staged row: 18 used; 320 bytes = 64 mod 256, so the three rows a
+                                                  // tap column touches start in different bank quarters
+constexpr int XVOX = (WTH + 2) * (WTW + 2);       // 180 voxels fetched per plane
+constexpr int XSLOT = (WTH + 2) * XRW * 16;       // 3200 bytes
+constexpr int YSLOT = WTH * WTW * 16 + 64;        // 2112: the previous plane's rows sit 64 bytes off in bank space
+constexpr int NSL = 4;                            // ring slots = planes in flight in registers
+constexpr int NT = 9;                             // column tiles: 18 taps x 8 channels
+constexpr int XBYTES = NSL * XSLOT, YBYTES = NSL * YSLOT;
+constexpr int RED_BYTES = 4 * NT * 64 * 16;       // [wave][tile][lane] f32x4
+constexpr int LDS_BYTES = (XBYTES + YBYTES > RED_BYTES) ? XBYTES + YBYTES : RED_BYTES;
+
+struct WMarchP {
+    int wgs_per_b;                 // workgroups (= slots of the partial slab) per sample
+    int ncols, tilesW;             // (H, W) tiles per sample
+    int nseg_d, planes_per_seg;    // D segments per tile; a unit = (tile, segment), dealt round-robin to the sample's workgroups
+};
+
+template <int DBG>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void wgrad_march_kernel(ConvK p, WMarchP mp, float* __restrict__ dW, float* __restrict__ dbias) {
+    __shared__ __attribute__((aligned(16))) char lds[LDS_BYTES];
+    char* const lx = lds;
+    char* const ly = lds + XBYTES;
+
+    const int tid = threadIdx.x, lane = tid & 63, n = lane & 15, g = lane >> 4;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int q = n >> 2, pq = n & 3;
+    const int gb0 = blockIdx.y;                       // this workgroup's 8-channel block of the virtual concat
+    const int Sd = p.Di, Sh = p.Hi, Sw = p.Wi;
+
+    const int bx = xcd_swizzle(blockIdx.x, gridDim.x);
+    const int b = bx / mp.wgs_per_b;                  // >= B: spare workgroup, flushes a zero slot
+    const int i0 = bx % mp.wgs_per_b;
+    const int nunits = (b < p.B) ? mp.ncols * mp.nseg_d : 0;
+
+    // ---- once per workgroup: which tensor / channels, mask, statistics
+    int sg = 0, c0 = 0, C = 8, cbase = 0;
+    bool exist = false;
+    {
+        int r = gb0;
+#pragma unroll
+        for (int s2 = 0; s2 < PASSION_MAX_SEG; ++s2) {
+            if (s2 < p.nseg && !exist) {
+                const int nb = p.seg[s2].C / 8;
+                if (r < nb) { exist = true; sg = s2; c0 = r * 8; C = p.seg[s2].C; cbase = p.seg[s2].cbase; }
+                r -= nb;
+            }
+        }
+    }
+    const bf16_t* src = nullptr;
+    bool present = false, has_norm = false;
+    f32x2 sc[4], sh[4];                                // x_hat = x * rstd + shift, channel pairs (the forward marching kernel's form)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { sc[c] = (f32x2){1.f, 1.f}; sh[c] = (f32x2){0.f, 0.f}; }
+    if (exist && i0 < nunits) {
+#pragma unroll
+        for (int s2 = 0; s2 < PASSION_MAX_SEG; ++s2) {
+            if (s2 == sg) {
+                const SegD& sd = p.seg[s2];
+                const int bs = sd.bsrc(b);
+                present = !sd.mask || sd.mask[(long)b * sd.mask_ld + sd.mask_col] != 0;
+                src = reinterpret_cast<const bf16_t*>(sd.x) + (long)bs * sd.bstride + c0;
+                has_norm = sd.stats != nullptr;
+                if (sd.stats) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const f32x4 st4 = *reinterpret_cast<const f32x4*>(sd.stats + ((long)bs * sd.C + c0 + 2 * c) * 2);   // mean, rstd, mean, rstd
+                        sc[c] = (f32x2){st4[1], st4[3]};
+                        sh[c] = (f32x2){uniform(-st4[0] * st4[1]), uniform(-st4[2] * st4[3])};      // workgroup-uniform: keep them scalar
+                    }
+                }
+            }
+        }
+    }
+    const bf16_t* dyb = reinterpret_cast<const bf16_t*>(p.dy) + (long)(b < p.B ? b : 0) * Sd * Sh * Sw * 8;      // Cout == 8
+
+    // ---- per-lane constants of the MFMA loop.  Wave wv owns tile rows 2 wv, 2 wv + 1; K index g * 8 + e of its step is the
+    // voxel (row 2 wv + (g >> 1), column (g & 1) * 8 + e); a transposing read hands lane n channel n of four voxels, so the lane
+    // LOADS 8 bytes of voxel q (+ 4 in the second read): A = channels (pq & 1) * 4.. of dY, current plane for pq < 2 (rows 0..7),
+    // previous plane for pq >= 2 (rows 8..15); B = channels (pq & 1) * 4.. of tap 2 j + (pq >> 1) of column tile j.
+    const int row = 2 * wv + (g >> 1), col = (g & 1) * 8 + q;
+    const int yoff = (row * WTW + col) * 16 + (pq & 1) * 8;
+    const bool yprev = pq >= 2;
+    // Column tile j = two taps (lane half h = pq >> 1 picks one) whose staged voxels differ by a CONSTANT, so that three lane
+    // bases + instruction immediates address all nine tiles: in-plane tap pairs (0,1) (3,4) (6,7) are one voxel apart, (2,5) one
+    // row; tap 8 of plane P - 1 pairs with tap 8 of plane P (tile 4).  Tiles 0..3 read plane P - 1, tiles 5..8 plane P.
+    const int h = pq >> 1;
+    const int xlane = (row * XRW + col) * 16 + (pq & 1) * 8;
+    const int xlaneA = xlane + h * 16, xlaneB = xlane + h * (XRW * 16);
+    f32x4 acc[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const bool bias_block = (dbias != nullptr) && (gb0 == 0);
+    f32x2 bsum[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) bsum[c] = (f32x2){0.f, 0.f};
+    const f32x2 slope2 = {p.slope, p.slope};
+
+    // ---- staging roles: threads 0..179 one voxel of the X plane (tile + halo), threads 128..255 one voxel of the dY plane
+    const bool xthr = tid < XVOX, ythr = tid >= 128;
+    const int zh = tid / (WTW + 2), zw = tid % (WTW + 2);
+    const int xlds = (zh * XRW + zw) * 16;
+    const int yv = tid - 128, vh = yv >> 4, vw = yv & 15;
+    const int ylds = yv * 16;
+    const bool reflect = p.pad_mode == PASSION_PAD_REFLECT;
+    const long plane_vox = (long)Sh * Sw;
+
+    for (int unit = i0; unit < nunits; unit += mp.wgs_per_b) {
+        const int colidx = unit % mp.ncols, dseg = unit / mp.ncols;
+        const int h0 = (colidx / mp.tilesW) * WTH, w0 = (colidx % mp.tilesW) * WTW;
+        const int dlo = dseg * mp.planes_per_seg, dhi = min(dlo + mp.planes_per_seg, Sd);
+        const int L = dhi - dlo;
+        if (L <= 0) continue;
+        const int nstage = L + 2;                     // stage j = plane dlo - 1 + j of X and of dY (zero outside [dlo, dhi))
+        // this thread's source voxel inside a plane, padding resolved once per tile.  Every global load of the plane loop is
+        // UNCONDITIONAL (clamped address, data dropped at commit time) and issued NSL iterations before its use: one load inside
+        // a branch makes the compiler wait with vmcnt(0) and drains the whole prefetch queue (conv_march.hip).  Threads without
+        // a voxel of their own (X: 180.., dY: ..127) re-read one fixed voxel -- a single cache line per wave instruction.
+        bool xok = xthr && present;
+        unsigned xel, yel;
+        {
+            int s_h = h0 - 1 + (xthr ? zh : 1), s_w = w0 - 1 + (xthr ? zw : 1);
+            if (reflect) { s_h = reflect_idx(s_h, Sh); s_w = reflect_idx(s_w, Sw); }
+            else xok = xok && s_h >= 0 && s_h < Sh && s_w >= 0 && s_w < Sw;
+            s_h = min(max(s_h, 0), Sh - 1); s_w = min(max(s_w, 0), Sw - 1);
+            xel = (unsigned)(s_h * Sw + s_w) * (unsigned)C;
+            yel = (unsigned)((h0 + (ythr ? vh : 0)) * Sw + w0 + (ythr ? vw : 0)) * 8u;
+        }
+        const unsigned xplane_el = (unsigned)(Sh * Sw) * (unsigned)C, yplane_el = (unsigned)(Sh * Sw) * 8u;
+        u32x4 ra[NSL], rd[NSL];
+        auto fetch = [&](int u, int j) {
+            if (DBG & 1) return;                      // developer timing builds (PASSION_CONV_DBG): 1 no loads, 2 no MFMA loop,
+                                                      // 8 one B read per plane, 16 reads but no MFMAs, 32 no commit
+            const int pl = dlo - 1 + j;
+            int xp = reflect ? reflect_idx(pl, Sd) : pl;
+            xp = min(max(xp, 0), Sd - 1);
+            const int yp = min(max(pl, dlo), dhi - 1);
+            ra[u] = gload<u32x4>(src + ((unsigned)xp * xplane_el + xel));
+            rd[u] = gload<u32x4>(dyb + ((unsigned)yp * yplane_el + yel));
+        };
+        auto commit = [&](int u, int j) {
+            const int pl = dlo - 1 + j;
+            const bool okd = reflect || (pl >= 0 && pl < Sd);
+            const bool yin = pl >= dlo && pl < dhi;       // (stages past the unit's end are never committed)
+            if (xthr) {
+                u32x4 o = (u32x4){0u, 0u, 0u, 0u};    // zero padding is applied AFTER norm + activation
+                if (xok && okd) {
+                    o = ra[u];
+                    if (has_norm) {
+                        bf16x8 ob;
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {      // bf16 pairs -> f32: low half = even channel
+                            const f32x2 xv = {__uint_as_float(ra[u][c] << 16), __uint_as_float(ra[u][c] & 0xffff0000u)};
+                            f32x2 t = __builtin_elementwise_fma(xv, sc[c], sh[c]);
+                            const f32x2 ts = t * slope2;   // LeakyReLU for 0 <= slope <= 1: max(t, slope t)
+                            t.x = fmaxf(t.x, ts.x);
+                            t.y = fmaxf(t.y, ts.y);
+                            ob[2 * c] = (__bf16)t.x; ob[2 * c + 1] = (__bf16)t.y;
+                        }
+                        o = __builtin_bit_cast(u32x4, ob);
+                    }
+                }
+                *reinterpret_cast<u32x4*>(lx + u * XSLOT + xlds) = o;
+            }
+            if (ythr) {
+                const u32x4 o = yin ? rd[u] : (u32x4){0u, 0u, 0u, 0u};
+                *reinterpret_cast<u32x4*>(ly + u * YSLOT + ylds) = o;
+                if (bias_block && yin) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        bsum[c] += (f32x2){__uint_as_float(o[c] << 16), __uint_as_float(o[c] & 0xffff0000u)};
+                }
+            }
+        };
+        auto compute = [&](int sp, int scur) {           // ring slots of plane P - 1 and of plane P
+            const char* ya = ly + yoff + (yprev ? sp : scur) * YSLOT;
+            const bf16x8 a = tr_read8(ya, ya + 64);
+            const int x4 = xlane + tapoff(8) + (h ? scur : sp) * XSLOT;
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const int pb = (j < 4 ? sp : scur) * XSLOT;
+                const int jj = j < 4 ? j : j - 5;
+                const char* bp = (j == 4) ? lx + x4 : (jj < 3 ? lx + xlaneA + pb + tapoff(3 * jj) : lx + xlaneB + pb + tapoff(2));
+                if ((DBG & 8) && j > 0) bp = lx + xlaneA + sp * XSLOT;
+                const bf16x8 bv = tr_read8(bp, bp + 64);
+                if (DBG & 16) acc[j][0] += (float)bv[0] + (float)a[0];
+                else acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bv, acc[j], 0, 0, 0);
+            }
+        };
+
+        // ---- pipeline.  iteration j: barrier; commit stage j; fetch stage j + NSL; compute K plane c = j - 2 from stages j - 2 and
+        // j - 1, both committed before this barrier (slot j & 3 held stage j - 4, last read in iteration j - 2).  The body has no
+        // branch around a load or an MFMA: dead iterations past the unit load clamped planes, commit ZERO dY planes and so add
+        // nothing.
+        __syncthreads();                              // the previous unit's last readers are done with the ring
+#pragma unroll
+        for (int u = 0; u < NSL; ++u) fetch(u, u);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {                 // stages 0, 1: nothing to compute yet
+            __syncthreads();
+            if (!(DBG & 32)) commit(j, j);
+            fetch(j, j + NSL);
+        }
+        for (int j0 = 2; j0 <= nstage; j0 += NSL) {
+#pragma unroll
+            for (int jj = 0; jj < NSL; ++jj) {
+                const int j = j0 + jj, u = (2 + jj) % NSL;
+                __syncthreads();
+                if (!(DBG & 32)) commit(u, j);
+                fetch(u, j + NSL);
+                if (!(DBG & 2)) compute((u + 2) % NSL, (u + 3) % NSL);
+            }
+        }
+    }
+
+    // ---- the four waves hold partial sums over disjoint voxels of the SAME outputs: combine through LDS in fixed order, and
+    // write this workgroup's slot of the partial-sum slab (plain stores; reduce_parts_kernel folds the slots)
+    __syncthreads();
+    f32x4* red = reinterpret_cast<f32x4*>(lds);
+#pragma unroll
+    for (int j = 0; j < NT; ++j) red[(wv * NT + j) * 64 + lane] = acc[j];
+    __syncthreads();
+    if (dW && exist) {
+        float* slot = dW + (long)bx * p.wslot;
+        for (int e = tid; e < NT * 64; e += 256) {
+            const int j = e >> 6, l2 = e & 63, n2 = l2 & 15, g2 = l2 >> 4;
+            f32x4 v = red[e];
+#pragma unroll
+            for (int w2 = 1; w2 < 4; ++w2) {
+                const f32x4 o = red[w2 * NT * 64 + e];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] += o[r];
+            }
+            const int h2 = n2 >> 3, ci = n2 & 7, jj = j < 4 ? j : j - 5;
+            const int dsel = (j == 4) ? h2 : (j > 4 ? 1 : 0), s = g2 >> 1;
+            const int hw = (j == 4) ? 8 : (jj < 3 ? 3 * jj + h2 : 2 + 3 * h2);
+            if (s == 1 && dsel == 0) continue;        // depth tap 0 a second time
+            const int tap = (dsel + s) * 9 + hw;
+            const long cig = cbase + c0 + ci;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int co = (g2 & 1) * 4 + r;
+                slot[((long)co * p.Cin + cig) * 27 + tap] = v[r];
+            }
+        }
+    }
+    if (bias_block) {
+        __syncthreads();
+        float* bred = reinterpret_cast<float*>(lds);              // [128][9], then [8][8]
+        float* bred2 = bred + 128 * 9;
+        if (ythr) {
+#pragma unroll
+            for (int c = 0; c < 8; ++c) bred[yv * 9 + c] = bsum[c >> 1][c & 1];
+        }
+        __syncthreads();
+        if (tid < 64) {
+            const int c = tid & 7, part = tid >> 3;
+            float sacc = 0.f;
+            for (int t = part * 16; t < part * 16 + 16; ++t) sacc += bred[t * 9 + c];
+            bred2[part * 8 + c] = sacc;
+        }
+        __syncthreads();
+        if (tid < 8) {
+            float sacc = 0.f;
+#pragma unroll
+            for (int part = 0; part < 8; ++part) sacc += bred2[part * 8 + tid];
+            dbias[(long)bx * p.wslot + tid] = sacc;
+        }
+    }
+}
+
+}  // namespace
+
+namespace pconv {
+
+// 0 = launched, < 0 = HIP error, 1 = shape not covered (the caller goes on to wgrad_lean_kernel).  Same slab plan as the lean
+// kernel: gx slots in sample order, gy = 8-channel blocks of the virtual concat; k.per is set so that the grouped fold
+// (conv.hip) derives the same workgroups-per-sample from it.
+int launch_wgrad_march(ConvK& k, int ksize, int stride, int MT, int gx, int gy, float* dW, float* db, hipStream_t st) {
+    if (!g_wgrad_march || ksize != 3 || stride != 1 || k.Cout != 8 || k.y_f32 || MT != 1) return 1;
+    if (!wgrad_lean_covers(k, ksize, stride, MT, gx, gy)) return 1;
+    if (k.Hi % WTH || k.Wi % WTW || k.Di < 8) return 1;
+    k.Mpad = pad16(k.Cout);
+    const int tiles_per_b = k.tilesD * k.tilesH * k.tilesW;
+    const int wgs = gx / k.B;
+    k.per = (tiles_per_b + wgs - 1) / wgs;
+    WMarchP mp;
+    mp.wgs_per_b = (tiles_per_b + k.per - 1) / k.per;
+    mp.tilesW = k.Wi / WTW;
+    mp.ncols = (k.Hi / WTH) * mp.tilesW;
+    // D segments: the split that keeps most of the sample's workgroups busy in every round; ties go to the longer march
+    int best = 1;
+    double best_eff = -1.0;
+    for (int ns = 1; ns <= 64; ns *= 2) {
+        const int pps = (k.Di + ns - 1) / ns;
+        if (ns > 1 && pps < 8) break;
+        const long units = (long)mp.ncols * ((k.Di + pps - 1) / pps);
+        const long rounds = (units + mp.wgs_per_b - 1) / mp.wgs_per_b;
+        const double eff = (double)units / (double)(rounds * mp.wgs_per_b);
+        if (eff > best_eff + 0.02) { best_eff = eff; best = ns; }
+    }
+    mp.planes_per_seg = (k.Di + best - 1) / best;
+    mp.nseg_d = (k.Di + mp.planes_per_seg - 1) / mp.planes_per_seg;
+    passion_prof_tag("wgrad_march_kernel");
+    switch (g_conv_dbg) {          // developer timing builds; 0 is the product
+#define WM_CASE(D) case D: hipLaunchKernelGGL(wgrad_march_kernel<D>, dim3(gx, gy), dim3(256), 0, st, k, mp, dW, db); break;
+        WM_CASE(1) WM_CASE(2) WM_CASE(8) WM_CASE(16) WM_CASE(32) WM_CASE(33) WM_CASE(3) WM_CASE(34)
+#undef WM_CASE
+        default: hipLaunchKernelGGL(wgrad_march_kernel<0>, dim3(gx, gy), dim3(256), 0, st, k, mp, dW, db);
+    }
+    LAUNCH_RET();
+    return 0;
+}
+
+}  // namespace pconv

@@ -728,3 +728,53 @@ def test_grouped_conv_equals_the_four_convs(case, bg):
         assert torch.equal(drg, drr)
     for a, b in zip(dwg + dbg, dwr + dbr):
         assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max()) + 1e-6
+
+
+WGRAD_MARCH_CASES = [
+    # 3x3x3 stride 1 with 8 output channels on (H % 8, W % 16) == 0 volumes: the marching weight-gradient kernel
+    ([8], 8, 3, 1, 1, (12, 16, 32), True, False, False),
+    ([8, 8], 8, 3, 1, 0, (9, 8, 16), True, True, False),        # zero padding, masked segments, ragged D split
+    ([16], 8, 3, 1, 1, (20, 24, 48), False, False, False),      # raw input (no InstanceNorm in the loader)
+    ([8], 8, 3, 1, 1, (40, 16, 16), True, False, True),         # several D segments per tile
+    ([32], 8, 3, 1, 0, (8, 128, 256), True, False, False),      # fewer workgroups per sample than tiles: two units per workgroup
+]
+
+
+@pytest.mark.parametrize("case", WGRAD_MARCH_CASES, ids=[str(i) for i in range(len(WGRAD_MARCH_CASES))])
+def test_wgrad_march(case):
+    """conv_wgrad_march.hip against the f64 reference (forward / dgrad ride along), and that it is the kernel that ran"""
+    from passion_amd import ops
+    ops.prof_read()
+    ops.prof_enable(1 << 3)
+    try:
+        test_conv_block_fwd_bwd(case, torch.bfloat16)
+    finally:
+        ops.prof_enable(0)
+    names = {r[4] for r in ops.prof_read()}
+    assert "wgrad_march_kernel" in names, names
+
+
+def test_wgrad_march_equals_lean_kernel_sums():
+    """same launch through wgrad_lean_kernel and wgrad_march_kernel: both sum the same bf16 products in f32, only the order differs"""
+    from passion_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(5)
+    B, C, D, H, W = 2, 8, 16, 32, 32
+    x = torch.randn(B, D, H, W, C, generator=g).to(dev, torch.bfloat16)
+    gy = torch.randn(B, D, H, W, 8, generator=g).to(dev, torch.bfloat16)
+    w0 = (torch.randn(8, C, 3, 3, 3, generator=g) / 15).to(dev)
+    b0 = torch.randn(8, generator=g).to(dev)
+    out = {}
+    for march in (1, 0):
+        old = ops.set_option("wgrad_march", march)
+        try:
+            xd = x.clone().requires_grad_(True)
+            wd, bd = w0.clone().requires_grad_(True), b0.clone().requires_grad_(True)
+            y = ops.conv_block([ops.SegIn(xd, stats=ops.instnorm_stats(xd.detach()))], wd, bd, D, H, W, ksize=3, stride=1, pad_mode=1)
+            y.backward(gy)
+            torch.cuda.synchronize()
+            out[march] = (wd.grad.clone(), bd.grad.clone())
+        finally:
+            ops.set_option("wgrad_march", old)
+    assert relerr(out[1][0], out[0][0].double()) < 1e-5
+    assert relerr(out[1][1], out[0][1].double()) < 1e-5

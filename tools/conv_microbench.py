@@ -12,7 +12,8 @@ iters = int(sys.argv[7]) if len(sys.argv) > 7 else 50
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
 segs_c = [8] * (cin // 8) if cin > 8 and cin <= 32 else [cin]
-xs = [torch.randn(1, S, S, S, c, device=dev).to(torch.bfloat16).requires_grad_(mode == "bwd") for c in segs_c]
+NB = int(os.environ.get('MB_BATCH', '1'))
+xs = [torch.randn(NB, S, S, S, c, device=dev).to(torch.bfloat16).requires_grad_(mode == "bwd") for c in segs_c]
 w = (torch.randn(cout, cin, k, k, k, device=dev) / (cin * k ** 3) ** 0.5).requires_grad_(True)
 b = torch.zeros(cout, device=dev, requires_grad=True)
 stats = [ops.instnorm_stats(x.detach()) for x in xs]
@@ -29,7 +30,7 @@ for _ in range(3):
     if mode == "bwd":
         y.backward(gy)
 torch.cuda.synchronize()
-ops.prof_enable(True)
+ops.prof_enable(15)
 t0 = time.time()
 for _ in range(iters):
     y = run()
@@ -37,11 +38,11 @@ for _ in range(iters):
         y.backward(gy)
 torch.cuda.synchronize()
 dt = (time.time() - t0) / iters
-ops.prof_enable(False)
+ops.prof_enable(0)
 recs = ops.prof_read()
 names = {0: "fwd_k3", 1: "fwd_k1", 2: "dgrad", 3: "wgrad"}
 So = S // stride
-alg = (cin * S ** 3 + cout * So ** 3) * 2
+alg = NB * (cin * S ** 3 + cout * So ** 3) * 2
 print(f"{mode} cin={cin} (segments {segs_c}) cout={cout} S={S} k={k} stride={stride}: wall {dt*1e6:.1f} us/iter, algorithmic {alg/1e6:.1f} MB")
 for kind in range(4):
     r = [x for x in recs if x[0] == kind]
