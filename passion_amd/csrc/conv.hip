@@ -261,6 +261,40 @@ __device__ __forceinline__ void finish_coefs(float (*coef)[3], const float* stat
     }
 }
 
+// The fold of a weight gradient's partial slab (out[i] = sum_r part[r * stride + i], fixed order) riding in a finish launch: the
+// finish kernels are the last launch of a conv backward and do not depend on the weight gradient, so the blocks x >= main_x of
+// their grid do the fold that used to be a launch of its own between the wgrad and the dgrad kernel (73 launches of ~10 us on
+// the critical stream of a training step, each with its dependent-launch gap).  G > 1: group g's R slots follow group g - 1's.
+struct FoldJob {
+    const float* part;
+    float* out[PASSION_MAX_GROUPS];
+    long n, stride;
+    int R, G, main_x;              // main_x == 0: no job, the whole grid is the finish kernel's
+};
+__device__ __forceinline__ void fold_block(const FoldJob& fj, long id) {
+    __shared__ float red[16][17];
+    const long nb16 = (fj.n + 15) / 16;
+    if (id >= nb16 * fj.G) return;                 // block-uniform
+    const int g = (int)(id / nb16);
+    const int li = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    const long i = (id % nb16) * 16 + li;
+    const float* pg = fj.part + (long)g * fj.R * fj.stride;
+    float a = 0.f;
+    if (i < fj.n)
+        for (int r = sl; r < fj.R; r += 16) a += pg[(long)r * fj.stride + i];
+    red[sl][li] = a;
+    __syncthreads();
+    if (sl == 0 && i < fj.n) {
+        float t = 0.f;
+#pragma unroll
+        for (int k2 = 0; k2 < 16; ++k2) t += red[k2][li];
+        float* o = fj.out[0];
+#pragma unroll
+        for (int g2 = 1; g2 < PASSION_MAX_GROUPS; ++g2) if (g == g2) o = fj.out[g2];
+        o[i] = t;
+    }
+}
+
 // `passes` > 1 (SegD.bmod: P masked passes over the same bmod samples in one launch): g holds P*bmod per-pass gradients,
 // dx the bmod physical samples; the kernel finishes every pass with its own sums / mask and writes their SUM -- what
 // autograd would otherwise do with P full-size tensors and a reduction.  passes == 1: in place (g == dx).
@@ -270,7 +304,9 @@ __global__ __launch_bounds__(256) void in_bwd_finish_kernel(const T* __restrict_
                                                             const float* __restrict__ stats, const float* __restrict__ sums,
                                                             const uint8_t* mask, int mask_col, int mask_ld, long V, int C, long bstride,
                                                             int Cin_tot, int cbase, int bmod, int passes, int rep, long rep_stride,
-                                                            float vscale, long win_lo, long win_hi) {
+                                                            float vscale, long win_lo, long win_hi, FoldJob fj) {
+    if (fj.main_x && (int)blockIdx.x >= fj.main_x) { fold_block(fj, (long)(blockIdx.x - fj.main_x) * gridDim.y + blockIdx.y); return; }
+    const long gdx = fj.main_x ? fj.main_x : gridDim.x;
     __shared__ float coef[FIN_TAB][3];
     __shared__ int pres[16];
     const int bp = blockIdx.y;                     // physical sample (x, stats, dx when passes > 1) or the plain batch index
@@ -285,7 +321,7 @@ __global__ __launch_bounds__(256) void in_bwd_finish_kernel(const T* __restrict_
     const int cvn = C / VEC;
     T* dxb = dx + (long)bp * bstride;
     const T* xb = x + (long)bs * bstride;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (long)gridDim.x * blockDim.x) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += gdx * blockDim.x) {
         const int c = (int)(i % cvn) * VEC;
         float acc[VEC], xv[VEC];
 #pragma unroll
@@ -317,7 +353,9 @@ __global__ __launch_bounds__(256) void in_bwd_finish_pad_kernel(T* __restrict__ 
                                                                 const float* __restrict__ stats, const float* __restrict__ sums,
                                                                 const uint8_t* mask, int mask_col, int mask_ld, int D, int H, int W, int C,
                                                                 long bstride, int Cin_tot, int cbase, int bmod, int rep, long rep_stride,
-                                                                float vscale, int dwin_lo, int dwin_hi) {
+                                                                float vscale, int dwin_lo, int dwin_hi, FoldJob fj) {
+    if (fj.main_x && (int)blockIdx.x >= fj.main_x) { fold_block(fj, (long)(blockIdx.x - fj.main_x) * gridDim.y + blockIdx.y); return; }
+    const int gdx = fj.main_x ? fj.main_x : (int)gridDim.x;
     __shared__ float coef[FIN_MAXC][3];
     const int b = blockIdx.y;
     const int bs = bmod > 0 ? b % bmod : b;
@@ -333,7 +371,7 @@ __global__ __launch_bounds__(256) void in_bwd_finish_pad_kernel(T* __restrict__ 
     const int tpr = rowv < 256 ? rowv : 256;              // threads that work on one row; 256 / tpr rows in flight per block
     const int rpb = 256 / tpr, rsub = threadIdx.x / tpr, tin = threadIdx.x % tpr;
     const long prow = (long)Wp * Cin_tot, pplane = (long)(H + 2) * prow;
-    for (int r0 = blockIdx.x * rpb; r0 < D * H; r0 += gridDim.x * rpb) {
+    for (int r0 = blockIdx.x * rpb; r0 < D * H; r0 += gdx * rpb) {
         const int r = r0 + rsub;
         if (r >= D * H || rsub >= rpb) continue;
         const int d = r / H, h = r % H;
@@ -395,6 +433,7 @@ constexpr int WG_NTW = 7;  // column tiles per wave (4 waves * 7 * 16 >= 27 taps
 template <typename TX, typename TY, int KS, int S, int MT>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(ConvK p, float* __restrict__ dW, float* __restrict__ dbias,
                                                          int chunks_total, int tiles_per_b) {
+    wgrad_clear(p);
     using G = Geo<KS, S, false>;
     constexpr int CK = (KS == 1) ? 16 : ((S == 2) ? 4 : 8);
     static_assert(CK == G::CK, "chunk");
@@ -599,6 +638,7 @@ int fill_params(const passion_conv_desc_t* d, ConvK& k) {
     if (!d) return -1001;
     k.dbg = 0;
     k.sums_fixed = 0; k.sums_float_only = 0;
+    k.zero_ptr = nullptr; k.zero_n = 0;
     k.fst = FwdStats{nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0, 0.f, 0.0};
     k.fst_want = nullptr; k.fst_eps = 0.f;
     k.bgroup = 0; k.wg_vec = 0;
@@ -1023,6 +1063,8 @@ static int conv3d_bwd_impl(const passion_conv_desc_t* d, const float* packed, co
     }
     // cleared by the weight-gradient fold when that runs on the same stream as the dgrad
     float* zsums = (need_norm && sums && !comp) ? sums : nullptr;
+    bool defer_fold = false;
+    FoldJob fj{nullptr, {nullptr, nullptr, nullptr, nullptr}, 0, 0, 0, 0, 0};
     const long zn = zsums ? (long)2 * k.B * k.Cin * SUMS_REP : 0;
     // ---- wgrad (+ bias grad): per-workgroup partial slabs, then a fixed-order fold (no atomics, deterministic) ----
     if (phase != 2 && (dweight || dbias) && (parts & 1)) {
@@ -1032,6 +1074,10 @@ static int conv3d_bwd_impl(const passion_conv_desc_t* d, const float* packed, co
         k.wslot = nW + k.Cout;                       // one slot = [dW | dbias] of one workgroup
         float* wslab = sums + (long)2 * k.B * k.Cin * SUMS_SLOTS;
         float* bslab = wslab + nW;
+        // the fold of the slab rides in the finish launch at the end of this call when one follows (FoldJob); the wgrad kernel then
+        // clears the InstanceNorm-backward sums itself
+        defer_fold = !comp && phase == 0 && (parts & 2) && need_dx && (ga || (dweight && dbias == dweight + nW));
+        if (defer_fold && zsums) { k.zero_ptr = zsums; k.zero_n = zn; }
         {
             ProfScope prof(3, conv_bytes(k, xs, ys) + (double)nt * k.Cin * k.Cout * 4,
                            2.0 * k.B * k.Do * k.Ho * k.Wo * (double)k.Cout * k.Cin * nt, st);
@@ -1060,6 +1106,18 @@ static int conv3d_bwd_impl(const passion_conv_desc_t* d, const float* packed, co
                 rc = -1007;
             if (rc) return rc;
         }
+        k.zero_ptr = nullptr; k.zero_n = 0;
+        if (defer_fold) {
+            fj.part = wslab; fj.n = k.wslot; fj.stride = k.wslot; fj.R = w.gx; fj.G = 1;
+            fj.out[0] = dweight;
+            if (ga) {                                // one fold per weight set: R = its samples x workgroups per sample
+                const int tiles_per_b = k.tilesD * k.tilesH * k.tilesW;
+                fj.R = k.bgroup * ((tiles_per_b + k.per - 1) / k.per);
+                fj.G = ga->G;
+                for (int g = 0; g < ga->G; ++g) fj.out[g] = ga->dW[g];
+            }
+            sums_cleared = zsums != nullptr;
+        } else
         if (ga) {                                    // one fold per weight set: Rg = its samples x workgroups per sample
             const int tiles_per_b = k.tilesD * k.tilesH * k.tilesW;
             const int wgs_per_b = (tiles_per_b + k.per - 1) / k.per;
@@ -1223,27 +1281,41 @@ static int conv3d_bwd_impl(const passion_conv_desc_t* d, const float* packed, co
         dim3 grid((unsigned)hmin((nvec + 255) / 256, 2048), sum_passes ? sg.bmod : k.B);
         const long rs = (long)2 * k.B * k.Cin;
         void* out = sum_passes ? real_dx[s] : sg.dx;
+        FoldJob fjl = fj;                             // the pending fold goes with the first finish launch
+        fjl.main_x = 0;
+        const long fold_blocks = defer_fold ? ((fj.n + 15) / 16) * fj.G : 0;
         if (padout) {
             const int rowv = k.Wi * sg.C / (v8 ? 8 : 4);
             const int rpb = 256 / (rowv < 256 ? rowv : 256);
             dim3 pg((unsigned)hmin(((long)k.Di * k.Hi + rpb - 1) / rpb, 4096), k.B);
+            if (defer_fold) { fjl.main_x = (int)pg.x; pg.x += (unsigned)((fold_blocks + pg.y - 1) / pg.y); }
             if (v8)
                 hipLaunchKernelGGL((in_bwd_finish_pad_kernel<bf16_t, 8>), pg, dim3(256), 0, st, (bf16_t*)sg.dx, (const bf16_t*)sg.x,
                                    (const bf16_t*)dxp, sg.stats, sums, sg.mask, sg.mask_col, sg.mask_ld, k.Di, k.Hi, k.Wi, sg.C,
-                                   sg.bstride, k.Cin, sg.cbase, sg.bmod, rep, rs, vscale, dwin_lo, dwin_hi);
+                                   sg.bstride, k.Cin, sg.cbase, sg.bmod, rep, rs, vscale, dwin_lo, dwin_hi, fjl);
             else
                 hipLaunchKernelGGL((in_bwd_finish_pad_kernel<bf16_t, 4>), pg, dim3(256), 0, st, (bf16_t*)sg.dx, (const bf16_t*)sg.x,
                                    (const bf16_t*)dxp, sg.stats, sums, sg.mask, sg.mask_col, sg.mask_ld, k.Di, k.Hi, k.Wi, sg.C,
-                                   sg.bstride, k.Cin, sg.cbase, sg.bmod, rep, rs, vscale, dwin_lo, dwin_hi);
-        } else if (d->x_dtype == PASSION_F32)
+                                   sg.bstride, k.Cin, sg.cbase, sg.bmod, rep, rs, vscale, dwin_lo, dwin_hi, fjl);
+        } else if (defer_fold) { fjl.main_x = (int)grid.x; grid.x += (unsigned)((fold_blocks + grid.y - 1) / grid.y); }
+        if (padout) {}
+        else if (d->x_dtype == PASSION_F32)
             hipLaunchKernelGGL((in_bwd_finish_kernel<float, 4>), grid, dim3(256), 0, st, (const float*)sg.dx, (float*)out, (const float*)sg.x,
-                               sg.stats, sums, sg.mask, sg.mask_col, sg.mask_ld, V, sg.C, sg.bstride, k.Cin, sg.cbase, sg.bmod, passes, rep, rs, vscale, win_lo, win_hi);
+                               sg.stats, sums, sg.mask, sg.mask_col, sg.mask_ld, V, sg.C, sg.bstride, k.Cin, sg.cbase, sg.bmod, passes, rep, rs, vscale, win_lo, win_hi, fjl);
         else if (v8)
             hipLaunchKernelGGL((in_bwd_finish_kernel<bf16_t, 8>), grid, dim3(256), 0, st, (const bf16_t*)sg.dx, (bf16_t*)out, (const bf16_t*)sg.x,
-                               sg.stats, sums, sg.mask, sg.mask_col, sg.mask_ld, V, sg.C, sg.bstride, k.Cin, sg.cbase, sg.bmod, passes, rep, rs, vscale, win_lo, win_hi);
+                               sg.stats, sums, sg.mask, sg.mask_col, sg.mask_ld, V, sg.C, sg.bstride, k.Cin, sg.cbase, sg.bmod, passes, rep, rs, vscale, win_lo, win_hi, fjl);
         else
             hipLaunchKernelGGL((in_bwd_finish_kernel<bf16_t, 4>), grid, dim3(256), 0, st, (const bf16_t*)sg.dx, (bf16_t*)out, (const bf16_t*)sg.x,
-                               sg.stats, sums, sg.mask, sg.mask_col, sg.mask_ld, V, sg.C, sg.bstride, k.Cin, sg.cbase, sg.bmod, passes, rep, rs, vscale, win_lo, win_hi);
+                               sg.stats, sums, sg.mask, sg.mask_col, sg.mask_ld, V, sg.C, sg.bstride, k.Cin, sg.cbase, sg.bmod, passes, rep, rs, vscale, win_lo, win_hi, fjl);
+        LAUNCH_RET();
+        defer_fold = false;
+    }
+    if (defer_fold) {                                 // no finish kernel ran (raw input, no padded domain): the fold on its own
+        RedOuts ro;
+        for (int g = 0; g < PASSION_MAX_GROUPS; ++g) ro.p[g] = fj.out[g];
+        hipLaunchKernelGGL(reduce_parts_grouped_kernel, dim3((unsigned)((fj.n + 15) / 16), fj.G), dim3(256), 0, st, fj.part, fj.R, fj.n, fj.stride, ro,
+                           (float*)nullptr, 0L);
         LAUNCH_RET();
     }
     if (comp) HIP_RET(hipStreamWaitEvent(caller_st, comp->done, 0));     // join

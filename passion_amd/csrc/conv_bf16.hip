@@ -386,6 +386,7 @@ __device__ __forceinline__ bf16x8 tr_read8(const char* p0, const char* p1) {
 template <int KS, int S, int MT, int CKW>
 __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(ConvK p, float* __restrict__ dW, float* __restrict__ dbias,
                                                               int tiles_per_b) {
+    wgrad_clear(p);
     using G = GeoB<KS, S, false, CKW>;
     constexpr int NC8 = CKW / 8;
     constexpr int NTAP = G::NTAP;

@@ -73,10 +73,22 @@ struct ConvK {
     int bgroup;
     long wg_vec;
     const float* biasg[PASSION_MAX_GROUPS];
+    float* zero_ptr;       // wgrad kernels: zero_n floats every launch clears before anything else (the InstanceNorm-backward sum
+    long zero_n;           // replicas the following dgrad adds into; the fold that used to clear them now rides in the finish launch)
     FwdStats fst;          // forward: statistics of y from the kernel's epilogue (fst.stats != nullptr)
     float* fst_want;       // forward: the caller wants statistics of y here (a launcher that fuses them moves it to fst.stats)
     float fst_eps;
 };
+
+#if defined(__HIPCC__)
+// first thing in every weight-gradient kernel (conv.hip: why)
+__device__ __forceinline__ void wgrad_clear(const ConvK& p) {
+    if (p.zero_n <= 0) return;
+    const long nb = (long)gridDim.x * gridDim.y, id = (long)blockIdx.y * gridDim.x + blockIdx.x;
+    for (long z = id * blockDim.x + threadIdx.x; z < p.zero_n; z += nb * blockDim.x) p.zero_ptr[z] = 0.f;
+}
+#endif
+
 
 // per-stream scratch of the library (api.cpp): `zero` bytes that are zero at every kernel start (kernels that use them leave
 // them zero: tickets), `plain` bytes of uninitialised scratch.  Kernels of one stream run one after the other, so one region

@@ -30,6 +30,7 @@ __device__ __forceinline__ bf16x8 tr_read8(const char* p0, const char* p1) {
 
 template <int KS, int MT>
 __global__ __launch_bounds__(256) void wgrad_lean_kernel(ConvK p, float* __restrict__ dW, float* __restrict__ dbias) {
+    wgrad_clear(p);
     constexpr int HALO = (KS == 3) ? 1 : 0;
     constexpr int ID = TD + 2 * HALO, IH = TH + 2 * HALO, IW = TW + 2 * HALO, VOL = ID * IH * IW;
     constexpr int VS = 16;                            // bytes per voxel of the activation image (8 channels)
@@ -332,6 +333,7 @@ __global__ __launch_bounds__(256) void wgrad_lean_kernel(ConvK p, float* __restr
 // registers as channel pairs (v_pk_fma_f32: two channels per instruction), and the workgroup folds them once at the end
 // into its slot of the partial slab ([co][tap] | dbias, the same layout the other wgrad kernels fill).
 __global__ __launch_bounds__(256) void wgrad_c1_kernel(ConvK p, float* __restrict__ dW, float* __restrict__ dbias) {
+    wgrad_clear(p);
     typedef float f32x2 __attribute__((ext_vector_type(2)));
     __shared__ float red[256 * 33];
     __shared__ float red2[8][32];

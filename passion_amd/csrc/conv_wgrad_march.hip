@@ -66,6 +66,7 @@ struct WMarchP {
 
 template <int DBG>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void wgrad_march_kernel(ConvK p, WMarchP mp, float* __restrict__ dW, float* __restrict__ dbias) {
+    wgrad_clear(p);
     __shared__ __attribute__((aligned(16))) char lds[LDS_BYTES];
     char* const lx = lds;
     char* const ly = lds + XBYTES;
