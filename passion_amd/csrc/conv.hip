@@ -262,14 +262,15 @@ __device__ __forceinline__ void finish_coefs(float (*coef)[3], const float* stat
 }
 
 // The fold of a weight gradient's partial slab (out[i] = sum_r part[r * stride + i], fixed order) riding in a finish launch: the
-// finish kernels are the last launch of a conv backward and do not depend on the weight gradient, so the blocks x >= main_x of
-// their grid do the fold that used to be a launch of its own between the wgrad and the dgrad kernel (73 launches of ~10 us on
+// finish kernels are the last launch of a conv backward and do not depend on the weight gradient, so the last fold_x blocks of
+// every row of their grid do the fold that used to be a launch of its own between the wgrad and the dgrad kernel (73 launches of ~10 us on
 // the critical stream of a training step, each with its dependent-launch gap).  G > 1: group g's R slots follow group g - 1's.
 struct FoldJob {
     const float* part;
     float* out[PASSION_MAX_GROUPS];
     long n, stride;
-    int R, G, main_x;              // main_x == 0: no job, the whole grid is the finish kernel's
+    int R, G, main_x;              // main_x == 0: no job, the whole grid is the finish kernel's; else the finish kernel's share of x
+    int fold_x;                    // blocks x >= main_x fold (fold blocks FIRST in every row was measured: 3 us slower per finish launch)
 };
 __device__ __forceinline__ void fold_block(const FoldJob& fj, long id) {
     __shared__ float red[16][17];
@@ -280,8 +281,18 @@ __device__ __forceinline__ void fold_block(const FoldJob& fj, long id) {
     const long i = (id % nb16) * 16 + li;
     const float* pg = fj.part + (long)g * fj.R * fj.stride;
     float a = 0.f;
-    if (i < fj.n)
-        for (int r = sl; r < fj.R; r += 16) a += pg[(long)r * fj.stride + i];
+    if (i < fj.n) {                                // four loads in flight per thread; the order of the adds is fixed all the same
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        int r = sl;
+        for (; r + 48 < fj.R; r += 64) {
+            a0 += pg[(long)r * fj.stride + i];
+            a1 += pg[(long)(r + 16) * fj.stride + i];
+            a2 += pg[(long)(r + 32) * fj.stride + i];
+            a3 += pg[(long)(r + 48) * fj.stride + i];
+        }
+        for (; r < fj.R; r += 16) a0 += pg[(long)r * fj.stride + i];
+        a = (a0 + a1) + (a2 + a3);
+    }
     red[sl][li] = a;
     __syncthreads();
     if (sl == 0 && i < fj.n) {
@@ -307,6 +318,7 @@ __global__ __launch_bounds__(256) void in_bwd_finish_kernel(const T* __restrict_
                                                             float vscale, long win_lo, long win_hi, FoldJob fj) {
     if (fj.main_x && (int)blockIdx.x >= fj.main_x) { fold_block(fj, (long)(blockIdx.x - fj.main_x) * gridDim.y + blockIdx.y); return; }
     const long gdx = fj.main_x ? fj.main_x : gridDim.x;
+    const long bix = blockIdx.x;
     __shared__ float coef[FIN_TAB][3];
     __shared__ int pres[16];
     const int bp = blockIdx.y;                     // physical sample (x, stats, dx when passes > 1) or the plain batch index
@@ -321,7 +333,7 @@ __global__ __launch_bounds__(256) void in_bwd_finish_kernel(const T* __restrict_
     const int cvn = C / VEC;
     T* dxb = dx + (long)bp * bstride;
     const T* xb = x + (long)bs * bstride;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += gdx * blockDim.x) {
+    for (long i = bix * blockDim.x + threadIdx.x; i < nvec; i += gdx * blockDim.x) {
         const int c = (int)(i % cvn) * VEC;
         float acc[VEC], xv[VEC];
 #pragma unroll
@@ -356,6 +368,7 @@ __global__ __launch_bounds__(256) void in_bwd_finish_pad_kernel(T* __restrict__ 
                                                                 float vscale, int dwin_lo, int dwin_hi, FoldJob fj) {
     if (fj.main_x && (int)blockIdx.x >= fj.main_x) { fold_block(fj, (long)(blockIdx.x - fj.main_x) * gridDim.y + blockIdx.y); return; }
     const int gdx = fj.main_x ? fj.main_x : (int)gridDim.x;
+    const int bix = (int)blockIdx.x;
     __shared__ float coef[FIN_MAXC][3];
     const int b = blockIdx.y;
     const int bs = bmod > 0 ? b % bmod : b;
@@ -371,7 +384,7 @@ __global__ __launch_bounds__(256) void in_bwd_finish_pad_kernel(T* __restrict__ 
     const int tpr = rowv < 256 ? rowv : 256;              // threads that work on one row; 256 / tpr rows in flight per block
     const int rpb = 256 / tpr, rsub = threadIdx.x / tpr, tin = threadIdx.x % tpr;
     const long prow = (long)Wp * Cin_tot, pplane = (long)(H + 2) * prow;
-    for (int r0 = blockIdx.x * rpb; r0 < D * H; r0 += gdx * rpb) {
+    for (int r0 = bix * rpb; r0 < D * H; r0 += gdx * rpb) {
         const int r = r0 + rsub;
         if (r >= D * H || rsub >= rpb) continue;
         const int d = r / H, h = r % H;
@@ -1064,7 +1077,7 @@ static int conv3d_bwd_impl(const passion_conv_desc_t* d, const float* packed, co
     // cleared by the weight-gradient fold when that runs on the same stream as the dgrad
     float* zsums = (need_norm && sums && !comp) ? sums : nullptr;
     bool defer_fold = false;
-    FoldJob fj{nullptr, {nullptr, nullptr, nullptr, nullptr}, 0, 0, 0, 0, 0};
+    FoldJob fj{nullptr, {nullptr, nullptr, nullptr, nullptr}, 0, 0, 0, 0, 0, 0};
     const long zn = zsums ? (long)2 * k.B * k.Cin * SUMS_REP : 0;
     // ---- wgrad (+ bias grad): per-workgroup partial slabs, then a fixed-order fold (no atomics, deterministic) ----
     if (phase != 2 && (dweight || dbias) && (parts & 1)) {
@@ -1282,13 +1295,13 @@ static int conv3d_bwd_impl(const passion_conv_desc_t* d, const float* packed, co
         const long rs = (long)2 * k.B * k.Cin;
         void* out = sum_passes ? real_dx[s] : sg.dx;
         FoldJob fjl = fj;                             // the pending fold goes with the first finish launch
-        fjl.main_x = 0;
+        fjl.main_x = 0; fjl.fold_x = 0;
         const long fold_blocks = defer_fold ? ((fj.n + 15) / 16) * fj.G : 0;
         if (padout) {
             const int rowv = k.Wi * sg.C / (v8 ? 8 : 4);
             const int rpb = 256 / (rowv < 256 ? rowv : 256);
             dim3 pg((unsigned)hmin(((long)k.Di * k.Hi + rpb - 1) / rpb, 4096), k.B);
-            if (defer_fold) { fjl.main_x = (int)pg.x; pg.x += (unsigned)((fold_blocks + pg.y - 1) / pg.y); }
+            if (defer_fold) { fjl.main_x = (int)pg.x; fjl.fold_x = (int)((fold_blocks + pg.y - 1) / pg.y); pg.x += (unsigned)fjl.fold_x; }
             if (v8)
                 hipLaunchKernelGGL((in_bwd_finish_pad_kernel<bf16_t, 8>), pg, dim3(256), 0, st, (bf16_t*)sg.dx, (const bf16_t*)sg.x,
                                    (const bf16_t*)dxp, sg.stats, sums, sg.mask, sg.mask_col, sg.mask_ld, k.Di, k.Hi, k.Wi, sg.C,
@@ -1297,7 +1310,7 @@ static int conv3d_bwd_impl(const passion_conv_desc_t* d, const float* packed, co
                 hipLaunchKernelGGL((in_bwd_finish_pad_kernel<bf16_t, 4>), pg, dim3(256), 0, st, (bf16_t*)sg.dx, (const bf16_t*)sg.x,
                                    (const bf16_t*)dxp, sg.stats, sums, sg.mask, sg.mask_col, sg.mask_ld, k.Di, k.Hi, k.Wi, sg.C,
                                    sg.bstride, k.Cin, sg.cbase, sg.bmod, rep, rs, vscale, dwin_lo, dwin_hi, fjl);
-        } else if (defer_fold) { fjl.main_x = (int)grid.x; grid.x += (unsigned)((fold_blocks + grid.y - 1) / grid.y); }
+        } else if (defer_fold) { fjl.main_x = (int)grid.x; fjl.fold_x = (int)((fold_blocks + grid.y - 1) / grid.y); grid.x += (unsigned)fjl.fold_x; }
         if (padout) {}
         else if (d->x_dtype == PASSION_F32)
             hipLaunchKernelGGL((in_bwd_finish_kernel<float, 4>), grid, dim3(256), 0, st, (const float*)sg.dx, (float*)out, (const float*)sg.x,
