@@ -140,6 +140,95 @@ __global__ __launch_bounds__(256) void upsample_fwd_stats_kernel(const T* __rest
     pconv::fwd_stats_commit(fs, C, b, blockIdx.x, 0, C, wsum, tid);
 }
 
+// The same result, bit for bit in y, from a row-wise schedule: the flat-index version above spends ~160 VALU instructions per
+// 16-byte output on three run-time divisions and three source-coordinate evaluations and ~250 on scalar f32 blending -- the
+// gather was VALU-bound at 1.4 TB/s (302 MB in 221 us for the sep decoder's 4 x 64^3 x 16 -> 128^3).  Here a block walks output
+// rows (od, oh): the D / H source planes and weights are workgroup-uniform, a thread keeps ITS W source columns and weights
+// for the whole launch (<= ROWV vectors of the row), and the blend runs on channel PAIRS (v_pk_mul_f32 / v_pk_add_f32) in the
+// same order of operations as before: ((w-blend) h-blend) d-blend, weights applied innermost first, no contraction.
+typedef float f32x2_r __attribute__((ext_vector_type(2)));
+template <typename T, int VEC, int ROWV>
+__global__ __launch_bounds__(256) void upsample_rows_fwd_stats_kernel(const T* __restrict__ x, T* __restrict__ y, int D, int H, int W,
+                                                                      int C, int k, pconv::FwdStats fs) {
+    __shared__ float red[256 * 2 * VEC];
+    __shared__ float wsum[512];
+    constexpr int NP = VEC / 2;
+    const int Do = D * k, Ho = H * k, Wo = W * k, cvn = C / VEC;
+    const int b = blockIdx.y, tid = threadIdx.x;
+    const float sd = axis_scale(D, Do), sh = axis_scale(H, Ho), sw = axis_scale(W, Wo);
+    const int rowvec = Wo * cvn;                                           // <= 256 * ROWV (checked by the launcher)
+    const T* xs = x + (long)b * D * H * W * C;
+    T* ys = y + (long)b * Do * Ho * Wo * C;
+    int off0[ROWV], off1[ROWV];
+    f32x2_r wl0[ROWV], wl1[ROWV];
+    bool valid[ROWV];
+#pragma unroll
+    for (int v = 0; v < ROWV; ++v) {
+        const int t = tid + 256 * v;
+        valid[v] = t < rowvec;
+        const int tc = valid[v] ? t : 0, ow = tc / cvn, cv = tc % cvn;     // 256 % cvn == 0: the same channel vector for every v
+        const Src f = src_index(ow, sw, W);
+        off0[v] = f.i0 * C + cv * VEC; off1[v] = f.i1 * C + cv * VEC;
+        wl0[v] = (f32x2_r){f.l0, f.l0}; wl1[v] = (f32x2_r){f.l1, f.l1};
+    }
+    f32x2_r s[NP], q[NP];
+#pragma unroll
+    for (int j = 0; j < NP; ++j) { s[j] = (f32x2_r){0.f, 0.f}; q[j] = (f32x2_r){0.f, 0.f}; }
+    const int nrows = Do * Ho;
+    for (int r = blockIdx.x; r < nrows; r += gridDim.x) {
+        const int od = r / Ho, oh = r - od * Ho;                            // workgroup-uniform
+        const Src a = src_index(od, sd, D), e = src_index(oh, sh, H);
+        const T* rowp[2][2] = {{xs + ((long)a.i0 * H + e.i0) * W * C, xs + ((long)a.i0 * H + e.i1) * W * C},
+                               {xs + ((long)a.i1 * H + e.i0) * W * C, xs + ((long)a.i1 * H + e.i1) * W * C}};
+        const f32x2_r dl[2] = {{a.l0, a.l0}, {a.l1, a.l1}}, hl[2] = {{e.l0, e.l0}, {e.l1, e.l1}};
+        T* yr = ys + (long)r * Wo * C;
+#pragma unroll
+        for (int v = 0; v < ROWV; ++v) {
+            if (!valid[v]) continue;
+            float t0[2][2][VEC], t1[2][2][VEC];
+#pragma unroll
+            for (int p = 0; p < 2; ++p)
+#pragma unroll
+                for (int qq = 0; qq < 2; ++qq) {                            // all eight loads first
+                    VecIO<T, VEC>::load(rowp[p][qq] + off0[v], t0[p][qq]);
+                    VecIO<T, VEC>::load(rowp[p][qq] + off1[v], t1[p][qq]);
+                }
+            float out[VEC];
+#pragma unroll
+            for (int j = 0; j < NP; ++j) {
+                f32x2_r rr = {0.f, 0.f};
+#pragma unroll
+                for (int p = 0; p < 2; ++p) {
+                    f32x2_r rh = {0.f, 0.f};
+#pragma unroll
+                    for (int qq = 0; qq < 2; ++qq) {
+                        const f32x2_r a0 = {t0[p][qq][2 * j], t0[p][qq][2 * j + 1]}, a1 = {t1[p][qq][2 * j], t1[p][qq][2 * j + 1]};
+                        rh = rh + hl[qq] * (wl0[v] * a0 + wl1[v] * a1);
+                    }
+                    rr = rr + dl[p] * rh;
+                }
+                const f32x2_r st = {to_f32(from_f32<T>(rr.x)), to_f32(from_f32<T>(rr.y))};      // what gets stored
+                s[j] = s[j] + st;
+                q[j] = __builtin_elementwise_fma(st, st, q[j]);
+                out[2 * j] = st.x; out[2 * j + 1] = st.y;
+            }
+            VecIO<T, VEC>::store(yr + (long)(tid + 256 * v) * VEC, out);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) { red[tid * 2 * VEC + j] = s[j >> 1][j & 1]; red[tid * 2 * VEC + VEC + j] = q[j >> 1][j & 1]; }
+    __syncthreads();
+    // thread tid holds channel vector tid % cvn: channel c = cv * VEC + j, summed over the 256 / cvn threads in a fixed order
+    for (int o = tid; o < C * 2; o += 256) {
+        const int c = o >> 1, k2 = o & 1, cv = c / VEC, j = c % VEC;
+        float t = 0.f;
+        for (int l = cv; l < 256; l += cvn) t += red[l * 2 * VEC + k2 * VEC + j];
+        wsum[o] = t;
+    }
+    __syncthreads();
+    pconv::fwd_stats_commit(fs, C, b, blockIdx.x, 0, C, wsum, tid);
+}
+
 // weight with which output index o reads input index i along one axis
 __device__ __forceinline__ float axis_weight(int o, int i, float scale, int in) {
     const Src s = src_index(o, scale, in);
@@ -454,16 +543,31 @@ extern "C" int passion_upsample_fwd_stats(const void* x, void* y, int dtype, int
         if (rc) return rc;
         return passion_instnorm_stats(y, dtype, B, V, C, V * C, eps, static_cast<double*>(plain), stats, stream);
     }
-    const int blocks = (int)hmin((total + 255) / 256, 1024);                // <= 1024 slots per sample for the fold
+    const long rowvec = (long)W * k * cvn, nrows = (long)D * k * H * k;
+    const bool rows = rowvec <= 512;                                        // row-wise schedule: a thread owns <= 2 vectors of a row
+    const int blocks = (int)hmin(rows ? nrows : (total + 255) / 256, 1024);    // <= 1024 slots per sample for the fold
     pconv::FwdStats fs;
     const int rc = pconv::fwd_stats_setup_raw(fs, B, C, blocks, 1, 1.0 / ((double)D * k * H * k * W * k), eps, stats, st);
     if (rc) return rc;
+#define ROWS_LAUNCH(T, VEC)                                                                                                             \
+    do {                                                                                                                                \
+        if (rowvec <= 256)                                                                                                              \
+            hipLaunchKernelGGL((upsample_rows_fwd_stats_kernel<T, VEC, 1>), dim3(blocks, B), dim3(256), 0, st, (const T*)x, (T*)y, D, H, W, C, k, fs); \
+        else                                                                                                                            \
+            hipLaunchKernelGGL((upsample_rows_fwd_stats_kernel<T, VEC, 2>), dim3(blocks, B), dim3(256), 0, st, (const T*)x, (T*)y, D, H, W, C, k, fs); \
+    } while (0)
+    if (rows) {
+        if (dtype == PASSION_F32) ROWS_LAUNCH(float, 4);
+        else if (v8) ROWS_LAUNCH(bf16_t, 8);
+        else ROWS_LAUNCH(bf16_t, 4);
+    } else
     if (dtype == PASSION_F32)
         hipLaunchKernelGGL((upsample_fwd_stats_kernel<float, 4>), dim3(blocks, B), dim3(256), 0, st, (const float*)x, (float*)y, D, H, W, C, k, fs);
     else if (v8)
         hipLaunchKernelGGL((upsample_fwd_stats_kernel<bf16_t, 8>), dim3(blocks, B), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y, D, H, W, C, k, fs);
     else
         hipLaunchKernelGGL((upsample_fwd_stats_kernel<bf16_t, 4>), dim3(blocks, B), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y, D, H, W, C, k, fs);
+#undef ROWS_LAUNCH
     LAUNCH_RET();
     return 0;
 }
