@@ -350,7 +350,7 @@ int launch_wgrad_march(ConvK& k, int ksize, int stride, int MT, int gx, int gy, 
     }
     mp.planes_per_seg = (k.Di + best - 1) / best;
     mp.nseg_d = (k.Di + mp.planes_per_seg - 1) / mp.planes_per_seg;
-    passion_prof_tag("wgrad_march_kernel");
+    passion_prof_tag("wgrad_march_kernel<0>");
     switch (g_conv_dbg) {          // developer timing builds; 0 is the product
 #define WM_CASE(D) case D: hipLaunchKernelGGL(wgrad_march_kernel<D>, dim3(gx, gy), dim3(256), 0, st, k, mp, dW, db); break;
         WM_CASE(1) WM_CASE(2) WM_CASE(8) WM_CASE(16) WM_CASE(32) WM_CASE(33) WM_CASE(3) WM_CASE(34)

@@ -751,7 +751,7 @@ def test_wgrad_march(case):
     finally:
         ops.prof_enable(0)
     names = {r[4] for r in ops.prof_read()}
-    assert "wgrad_march_kernel" in names, names
+    assert "wgrad_march_kernel<0>" in names, names
 
 
 def test_wgrad_march_equals_lean_kernel_sums():
