@@ -229,6 +229,115 @@ __global__ __launch_bounds__(256) void upsample_rows_fwd_stats_kernel(const T* _
     pconv::fwd_stats_commit(fs, C, b, blockIdx.x, 0, C, wsum, tid);
 }
 
+// Row-wise with the D/H blend SHARED along W (PASSION_UPSAMPLE_SHARED, default on): the blended source row
+//   u[iw][c] = dl0 (hl0 x[d0][h0][iw][c] + hl1 x[d0][h1][iw][c]) + dl1 (hl0 x[d1][h0][iw][c] + hl1 x[d1][h1][iw][c])
+// is formed once per output row (W vectors, f32, in LDS) and every output of the row blends two of its entries along W -- each
+// source vector is unpacked and weighted once instead of once per output that touches it (2k outputs): ~90 VALU instructions
+// per 16-byte output instead of ~220, the gather is no longer VALU-bound.  The order of the f32 operations differs from the
+// flat kernels (they blend W first, as ATen does): results agree to f32 rounding, not bit for bit -- so only bf16 tensors take
+// this path (their store rounds at 2^-8; the f32 parity mode keeps ATen's order: one 96^3 RFNet gradient moved from under to
+// just over its 5e-3 bound against the reference fixture otherwise).  passion_upsample_fwd and passion_upsample_fwd_stats both
+// take it for the same shapes, so they still agree with each other exactly.
+// fs.stats == nullptr: no statistics.
+template <typename T, int VEC, int ROWV>
+__global__ __launch_bounds__(256) void upsample_shared_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int D, int H, int W,
+                                                                  int C, int k, pconv::FwdStats fs) {
+    __shared__ float red[256 * 2 * VEC];
+    __shared__ float wsum[512];
+    extern __shared__ __attribute__((aligned(16))) float urow[];          // [2][W * C]
+    constexpr int NP = VEC / 2;
+    const int Do = D * k, Ho = H * k, Wo = W * k, cvn = C / VEC;
+    const int b = blockIdx.y, tid = threadIdx.x;
+    const float sd = axis_scale(D, Do), sh = axis_scale(H, Ho), sw = axis_scale(W, Wo);
+    const int rowvec = Wo * cvn, srcvec = W * cvn;                        // rowvec <= 256 * ROWV, srcvec <= 256 (launcher)
+    const T* xs = x + (long)b * D * H * W * C;
+    T* ys = y + (long)b * Do * Ho * Wo * C;
+    int off0[ROWV], off1[ROWV];
+    f32x2_r wl0[ROWV], wl1[ROWV];
+    bool valid[ROWV];
+#pragma unroll
+    for (int v = 0; v < ROWV; ++v) {
+        const int t = tid + 256 * v;
+        valid[v] = t < rowvec;
+        const int tc = valid[v] ? t : 0, ow = tc / cvn, cv = tc % cvn;     // 256 % cvn == 0: the same channel vector for every v
+        const Src f = src_index(ow, sw, W);
+        off0[v] = f.i0 * C + cv * VEC; off1[v] = f.i1 * C + cv * VEC;      // float offsets into the blended row
+        wl0[v] = (f32x2_r){f.l0, f.l0}; wl1[v] = (f32x2_r){f.l1, f.l1};
+    }
+    f32x2_r s[NP], q[NP];
+#pragma unroll
+    for (int j = 0; j < NP; ++j) { s[j] = (f32x2_r){0.f, 0.f}; q[j] = (f32x2_r){0.f, 0.f}; }
+    const int nrows = Do * Ho;
+    int buf = 0;
+    for (int r = blockIdx.x; r < nrows; r += gridDim.x, buf ^= 1) {
+        const int od = r / Ho, oh = r - od * Ho;                            // workgroup-uniform
+        const Src a = src_index(od, sd, D), e = src_index(oh, sh, H);
+        float* u = urow + buf * (W * C);
+        if (tid < srcvec) {
+            const f32x2_r dl0 = {a.l0, a.l0}, dl1 = {a.l1, a.l1}, hl0 = {e.l0, e.l0}, hl1 = {e.l1, e.l1};
+            float t00[VEC], t01[VEC], t10[VEC], t11[VEC];
+            const long o = (long)tid * VEC;
+            VecIO<T, VEC>::load(xs + ((long)a.i0 * H + e.i0) * W * C + o, t00);
+            VecIO<T, VEC>::load(xs + ((long)a.i0 * H + e.i1) * W * C + o, t01);
+            VecIO<T, VEC>::load(xs + ((long)a.i1 * H + e.i0) * W * C + o, t10);
+            VecIO<T, VEC>::load(xs + ((long)a.i1 * H + e.i1) * W * C + o, t11);
+#pragma unroll
+            for (int j = 0; j < NP; ++j) {
+                const f32x2_r x00 = {t00[2 * j], t00[2 * j + 1]}, x01 = {t01[2 * j], t01[2 * j + 1]};
+                const f32x2_r x10 = {t10[2 * j], t10[2 * j + 1]}, x11 = {t11[2 * j], t11[2 * j + 1]};
+                const f32x2_r uu = dl0 * (hl0 * x00 + hl1 * x01) + dl1 * (hl0 * x10 + hl1 * x11);
+                *reinterpret_cast<f32x2_r*>(u + o + 2 * j) = uu;
+            }
+        }
+        __syncthreads();                                                   // (double-buffered: one barrier per row)
+        T* yr = ys + (long)r * Wo * C;
+#pragma unroll
+        for (int v = 0; v < ROWV; ++v) {
+            if (!valid[v]) continue;
+            float out[VEC];
+#pragma unroll
+            for (int j = 0; j < NP; ++j) {
+                const f32x2_r u0 = *reinterpret_cast<const f32x2_r*>(u + off0[v] + 2 * j);
+                const f32x2_r u1 = *reinterpret_cast<const f32x2_r*>(u + off1[v] + 2 * j);
+                const f32x2_r rr = wl0[v] * u0 + wl1[v] * u1;
+                const f32x2_r st = {to_f32(from_f32<T>(rr.x)), to_f32(from_f32<T>(rr.y))};      // what gets stored
+                s[j] = s[j] + st;
+                q[j] = __builtin_elementwise_fma(st, st, q[j]);
+                out[2 * j] = st.x; out[2 * j + 1] = st.y;
+            }
+            VecIO<T, VEC>::store(yr + (long)(tid + 256 * v) * VEC, out);
+        }
+    }
+    if (!fs.stats) return;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) { red[tid * 2 * VEC + j] = s[j >> 1][j & 1]; red[tid * 2 * VEC + VEC + j] = q[j >> 1][j & 1]; }
+    __syncthreads();
+    for (int o = tid; o < C * 2; o += 256) {
+        const int c = o >> 1, k2 = o & 1, cv = c / VEC, j = c % VEC;
+        float t = 0.f;
+        for (int l = cv; l < 256; l += cvn) t += red[l * 2 * VEC + k2 * VEC + j];
+        wsum[o] = t;
+    }
+    __syncthreads();
+    pconv::fwd_stats_commit(fs, C, b, blockIdx.x, 0, C, wsum, tid);
+}
+
+// shapes the shared-row kernel takes (both entry points ask the same question, so their outputs agree bit for bit)
+static int g_upsample_shared = -1;
+static bool shared_rows_ok(int D, int H, int W, int C, int k, int cvn) {
+    if (g_upsample_shared < 0) { const char* e = getenv("PASSION_UPSAMPLE_SHARED"); g_upsample_shared = !(e && e[0] == '0'); }
+    return g_upsample_shared && (long)W * k * cvn <= 512 && (long)W * cvn <= 256 && 256 % cvn == 0 && C <= 256 &&
+           (long)D * k * H * k * W * k * cvn < (1L << 31);
+}
+template <typename T, int VEC>
+static void launch_shared(const void* x, void* y, int B, int D, int H, int W, int C, int k, int blocks, const pconv::FwdStats& fs, hipStream_t st) {
+    const size_t dyn = (size_t)2 * W * C * sizeof(float);
+    if ((long)W * k * (C / VEC) <= 256)
+        hipLaunchKernelGGL((upsample_shared_fwd_kernel<T, VEC, 1>), dim3(blocks, B), dim3(256), dyn, st, (const T*)x, (T*)y, D, H, W, C, k, fs);
+    else
+        hipLaunchKernelGGL((upsample_shared_fwd_kernel<T, VEC, 2>), dim3(blocks, B), dim3(256), dyn, st, (const T*)x, (T*)y, D, H, W, C, k, fs);
+}
+
 // weight with which output index o reads input index i along one axis
 __device__ __forceinline__ float axis_weight(int o, int i, float scale, int in) {
     const Src s = src_index(o, scale, in);
@@ -513,6 +622,15 @@ extern "C" int passion_upsample_fwd(const void* x, void* y, int dtype, int B, in
     const long total = (long)B * D * k * H * k * W * k * (C / (v8 ? 8 : 4));
     const int blocks = (int)hmin((total + 255) / 256, 16384);
     hipStream_t st = (hipStream_t)stream;
+    if (dtype == PASSION_BF16 && shared_rows_ok(D, H, W, C, k, C / (v8 ? 8 : 4))) {       // f32 tensors keep ATen's order of operations
+        pconv::FwdStats none{nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0, 0.f, 0.0};
+        const int rb = (int)hmin((long)D * k * H * k, 4096);
+        if (dtype == PASSION_F32) launch_shared<float, 4>(x, y, B, D, H, W, C, k, rb, none, st);
+        else if (v8) launch_shared<bf16_t, 8>(x, y, B, D, H, W, C, k, rb, none, st);
+        else launch_shared<bf16_t, 4>(x, y, B, D, H, W, C, k, rb, none, st);
+        LAUNCH_RET();
+        return 0;
+    }
     if (dtype == PASSION_F32)
         FWD_LAUNCH(float, 4, (const float*)x, (float*)y);
     else if (v8)
@@ -556,6 +674,11 @@ extern "C" int passion_upsample_fwd_stats(const void* x, void* y, int dtype, int
         else                                                                                                                            \
             hipLaunchKernelGGL((upsample_rows_fwd_stats_kernel<T, VEC, 2>), dim3(blocks, B), dim3(256), 0, st, (const T*)x, (T*)y, D, H, W, C, k, fs); \
     } while (0)
+    if (rows && dtype == PASSION_BF16 && shared_rows_ok(D, H, W, C, k, cvn)) {
+        if (dtype == PASSION_F32) launch_shared<float, 4>(x, y, B, D, H, W, C, k, blocks, fs, st);
+        else if (v8) launch_shared<bf16_t, 8>(x, y, B, D, H, W, C, k, blocks, fs, st);
+        else launch_shared<bf16_t, 4>(x, y, B, D, H, W, C, k, blocks, fs, st);
+    } else
     if (rows) {
         if (dtype == PASSION_F32) ROWS_LAUNCH(float, 4);
         else if (v8) ROWS_LAUNCH(bf16_t, 8);

@@ -1,0 +1,5 @@
+cd $GRAFT_REPO_ROOT
+timeout 900 python -m pytest tests/test_ops_gpu.py -x -q -m gpu -k "upsample" 2>&1 | tail -3
+python tools/upsample_bench.py 2>&1 | grep -v Warn
+PASSION_UPSAMPLE_SHARED=0 python tools/upsample_bench.py 2>&1 | grep -v Warn | head -3
+timeout 2400 python -m pytest tests -x -q -m gpu 2>&1 | tail -4
