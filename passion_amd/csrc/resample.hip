@@ -500,6 +500,101 @@ __global__ __launch_bounds__(256) void upsample_bwd_k2_kernel(const T* __restric
 }
 
 
+// Row-wise x2 backward for bf16 tensors (the adjoint of upsample_shared_fwd_kernel's schedule).  upsample_bwd_k2_kernel gathers
+// up to 6 x 6 x 6 candidate outputs per input vector, evaluates 18 axis weights per thread and unpacks 64 vectors: VALU-bound
+// at 1.2 TB/s (268 MB of dY in 240 us for 4 x 64^3 x 16).  Here a block walks INPUT rows (id, ih): the <= 6 x 6 dY rows that
+// reach it and their weights wd * wh are workgroup-uniform (twelve threads evaluate them one row ahead, through LDS); every
+// thread sums ITS vector of those rows -- v[ow][c] = sum wd wh dY[od][oh][ow][c], the D/H part of the adjoint, once per output
+// column instead of once per input that touches it -- into an f32 row in LDS, and the threads that own an input vector gather
+// their <= 6 W taps (constant per thread for the whole launch) from that row.  f32 tensors keep the flat kernel (same sums in
+// another order).
+template <typename T, int VEC, int ROWV>
+__global__ __launch_bounds__(256) void upsample_shared_bwd_kernel(const T* __restrict__ dy, T* __restrict__ dx, int D, int H, int W,
+                                                                  int C, int k) {
+    constexpr int NC = 6, NP = VEC / 2;
+    extern __shared__ __attribute__((aligned(16))) float vrow[];          // [2][Wo * C]
+    __shared__ float wts[2][2][NC];                                        // [buffer][axis d / h][candidate]
+    __shared__ int los[2][2];
+    const int Do = D * k, Ho = H * k, Wo = W * k, cvn = C / VEC;
+    const int b = blockIdx.y, tid = threadIdx.x;
+    const float sd = axis_scale(D, Do), sh = axis_scale(H, Ho), sw = axis_scale(W, Wo);
+    const int rowvec = Wo * cvn, srcvec = W * cvn;
+    const T* dys = dy + (long)b * Do * Ho * Wo * C;
+    T* dxs = dx + (long)b * D * H * W * C;
+    // input role: the W taps of this thread's input vector
+    const bool in_thr = tid < srcvec;
+    const int iw = in_thr ? tid / cvn : 0, cvi = tid % cvn;
+    const int wlo = max(0, (int)floorf((float)(iw - 1) / sw));
+    float ww[NC];
+#pragma unroll
+    for (int f = 0; f < NC; ++f) ww[f] = (in_thr && wlo + f < Wo) ? axis_weight(wlo + f, iw, sw, W) : 0.f;
+    const int voff = wlo * C + cvi * VEC;
+    const int nrows = D * H;
+    auto row_weights = [&](int r, int bufw) {                              // threads 0 .. 2 NC - 1: one candidate each
+        if (tid < 2 * NC && r < nrows) {
+            const int ax = tid / NC, a = tid % NC, id = r / H, ih = r - id * H;
+            const int i = ax ? ih : id, in = ax ? H : D, out = ax ? Ho : Do;
+            const float sc = ax ? sh : sd;
+            const int lo = max(0, (int)floorf((float)(i - 1) / sc));
+            wts[bufw][ax][a] = (lo + a < out) ? axis_weight(lo + a, i, sc, in) : 0.f;
+            if (a == 0) los[bufw][ax] = lo;
+        }
+    };
+    row_weights(blockIdx.x, 0);
+    __syncthreads();
+    int buf = 0;
+    for (int r = blockIdx.x; r < nrows; r += gridDim.x, buf ^= 1) {
+        row_weights(r + gridDim.x, buf ^ 1);                               // visible after this iteration's barrier
+        float* v = vrow + buf * (Wo * C);
+        const int dlo = los[buf][0], hlo = los[buf][1];
+        float wd[NC], wh[NC];
+#pragma unroll
+        for (int a = 0; a < NC; ++a) { wd[a] = wts[buf][0][a]; wh[a] = wts[buf][1][a]; }
+#pragma unroll
+        for (int u = 0; u < ROWV; ++u) {
+            const int t = tid + 256 * u;
+            if (t >= rowvec) continue;
+            f32x2_r acc[NP];
+#pragma unroll
+            for (int j = 0; j < NP; ++j) acc[j] = (f32x2_r){0.f, 0.f};
+#pragma unroll
+            for (int a = 0; a < NC; ++a) {
+                if (wd[a] == 0.f) continue;                                // workgroup-uniform
+#pragma unroll
+                for (int e = 0; e < NC; ++e) {
+                    if (wh[e] == 0.f) continue;
+                    const float wde = wd[a] * wh[e];
+                    const f32x2_r w2 = {wde, wde};
+                    float tv[VEC];
+                    VecIO<T, VEC>::load(dys + (((long)(dlo + a)) * Ho + (hlo + e)) * Wo * C + (long)t * VEC, tv);
+#pragma unroll
+                    for (int j = 0; j < NP; ++j) acc[j] = __builtin_elementwise_fma(w2, (f32x2_r){tv[2 * j], tv[2 * j + 1]}, acc[j]);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < NP; ++j) *reinterpret_cast<f32x2_r*>(v + t * VEC + 2 * j) = acc[j];
+        }
+        __syncthreads();
+        if (in_thr) {
+            f32x2_r o[NP];
+#pragma unroll
+            for (int j = 0; j < NP; ++j) o[j] = (f32x2_r){0.f, 0.f};
+#pragma unroll
+            for (int f = 0; f < NC; ++f) {
+                if (ww[f] == 0.f) continue;                                // (also keeps the reads inside the row)
+                const f32x2_r w2 = {ww[f], ww[f]};
+#pragma unroll
+                for (int j = 0; j < NP; ++j)
+                    o[j] = __builtin_elementwise_fma(w2, *reinterpret_cast<const f32x2_r*>(v + voff + f * C + 2 * j), o[j]);
+            }
+            float out[VEC];
+#pragma unroll
+            for (int j = 0; j < NP; ++j) { out[2 * j] = o[j].x; out[2 * j + 1] = o[j].y; }
+            VecIO<T, VEC>::store(dxs + ((long)r * W + iw) * C + cvi * VEC, out);
+        }
+    }
+}
+
 // ---- depth-sharded variant (BASELINE.json configs[4]: one volume split along D over the ranks).
 // A rank holds input planes [id0, id0 + Dl_in) of a volume of Dg planes (its slab plus one halo plane from each neighbour)
 // and produces output planes [od0, od0 + Dl_out) of the k Dg output planes: the D axis uses GLOBAL align_corners coordinates,
@@ -711,6 +806,20 @@ extern "C" int passion_upsample_bwd(const void* dy, void* dx, int dtype, int B, 
     }
     const long items = (long)B * D * H * W * (C / 4);
     hipStream_t st = (hipStream_t)stream;
+    if (k == 2 && D > 1 && H > 1 && W > 1 && dtype == PASSION_BF16 && shared_rows_ok(D, H, W, C, k, C / (C % 8 == 0 ? 8 : 4))) {
+        const int rb = (int)hmin((long)D * H, 2048);
+        const size_t dyn = (size_t)2 * W * k * C * sizeof(float);
+        const bool one = (long)W * k * (C / (C % 8 == 0 ? 8 : 4)) <= 256;
+        const bf16_t* g = (const bf16_t*)dy;
+        bf16_t* o = (bf16_t*)dx;
+        if (C % 8 == 0) {
+            if (one) hipLaunchKernelGGL((upsample_shared_bwd_kernel<bf16_t, 8, 1>), dim3(rb, B), dim3(256), dyn, st, g, o, D, H, W, C, k);
+            else hipLaunchKernelGGL((upsample_shared_bwd_kernel<bf16_t, 8, 2>), dim3(rb, B), dim3(256), dyn, st, g, o, D, H, W, C, k);
+        } else {
+            if (one) hipLaunchKernelGGL((upsample_shared_bwd_kernel<bf16_t, 4, 1>), dim3(rb, B), dim3(256), dyn, st, g, o, D, H, W, C, k);
+            else hipLaunchKernelGGL((upsample_shared_bwd_kernel<bf16_t, 4, 2>), dim3(rb, B), dim3(256), dyn, st, g, o, D, H, W, C, k);
+        }
+    } else
     if (k == 2 && D > 1 && H > 1 && W > 1) {
         const bool v8 = dtype == PASSION_BF16 && C % 8 == 0;
         const int blocks = (int)hmin(((v8 ? items / 2 : items) + 255) / 256, 16384);

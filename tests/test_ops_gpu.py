@@ -252,7 +252,7 @@ def test_instnorm_stats(dtype, shape):
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("k,C,shape", [(2, 8, (4, 6, 8)), (2, 128, (2, 2, 2)), (4, 4, (4, 4, 4)), (8, 4, (2, 4, 2)),
-                                       (16, 4, (2, 2, 2))])
+                                       (16, 4, (2, 2, 2)), (2, 32, (3, 4, 40)), (2, 16, (5, 3, 24))])   # last two: two / one vector per thread and row
 def test_upsample(k, C, shape, dtype):
     from passion_amd import ops
     dev = _dev()
