@@ -115,6 +115,8 @@ int launch_wgrad_lean(ConvK& k, int ksize, int stride, int MT, int gx, int gy, f
 bool wgrad_lean_covers(const ConvK& k, int ksize, int stride, int MT, int gx, int gy);
 int launch_wgrad_march(ConvK& k, int ksize, int stride, int MT, int gx, int gy, float* dWslab, float* dbslab, hipStream_t st);   // conv_wgrad_march.hip: Cout = 8
 extern int g_wgrad_march;
+int launch_conv_c1_fwd(ConvK& k, int ksize, int stride, const void* packed_bf16, hipStream_t st);   // conv_c1_fwd.hip: Cin = 1, Cout = 8
+extern int g_conv_c1;
 int launch_wgrad_c1(ConvK& k, int ksize, int stride, int gx, int gy, float* dWslab, float* dbslab, hipStream_t st);   // first layer, Cin = 1
 extern int g_conv_lean;
 int launch_wgrad_bf16(ConvK& k, int ksize, int stride, int MT, int gx, int gy, float* dWslab, float* dbslab, hipStream_t st);

@@ -778,3 +778,58 @@ def test_wgrad_march_equals_lean_kernel_sums():
             ops.set_option("wgrad_march", old)
     assert relerr(out[1][0], out[0][0].double()) < 1e-5
     assert relerr(out[1][1], out[0][1].double()) < 1e-5
+
+
+@pytest.mark.parametrize("pad_mode", [1, 0], ids=["reflect", "zeros"])
+@pytest.mark.parametrize("shape", [(20, 16, 32), (5, 32, 16)])
+def test_first_layer_forward_kernel(shape, pad_mode):
+    """conv_c1_fwd.hip (one raw input channel -> 8, bf16): against the f64 reference, against the general kernel, statistics of
+    the output from the same launch, masked samples, plain and grouped (four weight sets over one stacked batch)"""
+    from passion_amd import ops
+    dev = _dev()
+    D, H, W = shape
+    B = 4
+    g = torch.Generator().manual_seed(9)
+    x = (torch.randn(B, D, H, W, 1, generator=g) * 1.3 + 0.2).to(torch.bfloat16)
+    ws = [(torch.randn(8, 1, 3, 3, 3, generator=g) / 4) for _ in range(4)]
+    bs = [torch.randn(8, generator=g) for _ in range(4)]
+    mask = torch.tensor([[True], [False], [True], [True]])
+    xd, md = x.to(dev), mask.to(dev)
+
+    def ref(wi, bi, samples):
+        xm = (x[samples].double() * mask[samples].view(-1, 1, 1, 1, 1)).permute(0, 4, 1, 2, 3)
+        xm = F.pad(xm, (1,) * 6, mode="reflect" if pad_mode == 1 else "constant")
+        return F.conv3d(xm, wi.to(torch.bfloat16).double(), bi.double())
+
+    ops.prof_read()
+    ops.prof_enable(1)
+    try:
+        wd, bd = ws[0].to(dev).requires_grad_(True), bs[0].to(dev).requires_grad_(True)
+        y, st = ops.conv_block([ops.SegIn(xd, mask=md, mask_col=0)], wd, bd, D, H, W, ksize=3, stride=1, pad_mode=pad_mode, want_stats=True)
+        wg = [w.to(dev).requires_grad_(True) for w in ws]
+        bg = [b.to(dev).requires_grad_(True) for b in bs]
+        yg, stg = ops.conv_block_grouped([ops.SegIn(xd, mask=md, mask_col=0)], wg, bg, D, H, W, ksize=3, stride=1, pad_mode=pad_mode,
+                                         want_stats=True)
+        torch.cuda.synchronize()
+    finally:
+        ops.prof_enable(0)
+    names = [r[4] for r in ops.prof_read()]
+    assert names.count("conv_c1_fwd_kernel") == 2, names
+    assert relerr(nc(y.detach().float()), ref(ws[0], bs[0], slice(0, B))) < 1e-2
+    for gi in range(4):
+        assert relerr(nc(yg[gi:gi + 1].detach().float()), ref(ws[gi], bs[gi], slice(gi, gi + 1))) < 1e-2
+    for yy, ss in ((y, st), (yg, stg)):
+        want = ops.instnorm_stats(yy.detach())
+        std = 1.0 / want[..., 1]
+        assert float(((ss[..., 0] - want[..., 0]).abs() / (std + want[..., 0].abs())).max()) < 2e-5
+        assert float(((ss[..., 1] - want[..., 1]).abs() / want[..., 1]).max()) < 1e-4
+    old = ops.set_option("conv_c1", 0)
+    try:
+        y0 = ops.conv_block([ops.SegIn(xd, mask=md, mask_col=0)], wd, bd, D, H, W, ksize=3, stride=1, pad_mode=pad_mode)
+    finally:
+        ops.set_option("conv_c1", old)
+    # same bf16 products, f32 sums in another order: at most one bf16 ulp apart
+    assert relerr(y.detach().float(), y0.detach().float().double()) < 1e-2
+    assert float((y.detach().float() - y0.detach().float()).abs().mean()) < 1e-3
+    y.float().sum().backward()
+    assert torch.isfinite(wd.grad).all()
