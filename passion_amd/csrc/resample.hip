@@ -402,24 +402,37 @@ __global__ __launch_bounds__(256) void upsample_bwd_kernel(const T* __restrict__
 // largest reduction): [outer][No][inner] -> [outer][Ni][inner], one thread per output (4-channel vector), which sums
 // the ~2k inputs along the axis that reference it.  Three passes read dy once and 1/k, 1/k^2 of it again -- the
 // one-pass gather over the (2k+3)^3 candidate window took 250-500 us for the k = 4/8/16 deep-supervision maps.
-template <typename TI, typename TO>
+// Four candidates per trip: their weights first, then four UNCONDITIONAL loads (clamped index, weight 0 past the window), then the
+// sums in the same ascending order as before -- a load behind `if (w != 0)` serialised one memory latency per candidate (12-36 of
+// them per output), which is what these launches spent their time on.  IT: 32-bit index arithmetic whenever the tensor allows.
+template <typename TI, typename TO, typename IT>
 __global__ __launch_bounds__(256) void upsample_bwd_axis_kernel(const TI* __restrict__ in, TO* __restrict__ out, long outer,
-                                                                int Ni, int No, long inner) {
+                                                                int Ni, int No, long inner_) {
     const float sc = axis_scale(Ni, No);
-    const long total = outer * Ni * inner;
-    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-        const long iv = idx % inner;
-        const int i = (int)((idx / inner) % Ni);
-        const long o_ = idx / (inner * Ni);
+    const IT inner = (IT)inner_;
+    const IT total = (IT)outer * (IT)Ni * inner;
+    for (IT idx = (IT)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (IT)gridDim.x * blockDim.x) {
+        const IT iv = idx % inner;
+        const int i = (int)((idx / inner) % (IT)Ni);
+        const IT o_ = idx / (inner * (IT)Ni);
         int lo, hi;
         axis_range(i, sc, No, lo, hi);
-        const TI* base = in + ((o_ * No) * inner + iv) * 4;
+        const TI* base = in + ((long)(o_ * (IT)No) * inner_ + (long)iv) * 4;
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        for (int o = lo; o <= hi; ++o) {
-            const float w = axis_weight(o, i, sc, Ni);
-            if (w != 0.f) acc += w * load4(base + (long)o * inner * 4);
+        for (int o = lo; o <= hi; o += 4) {
+            float w[4];
+            f32x4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int oo = min(o + u, hi);
+                w[u] = (o + u <= hi) ? axis_weight(oo, i, sc, Ni) : 0.f;
+                v[u] = load4(base + (long)oo * inner_ * 4);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (w[u] != 0.f) acc += w[u] * v[u];          // (a select, not a branch around a load: same sums as before, bit for bit)
         }
-        store4(out + idx * 4, acc);
+        store4(out + (long)idx * 4, acc);
     }
 }
 
@@ -427,7 +440,10 @@ template <typename TI, typename TO>
 int launch_axis(const TI* in, TO* out, long outer, int Ni, int No, long inner, hipStream_t st) {
     const long total = outer * Ni * inner;
     const int blocks = (int)hmin((total + 255) / 256, 16384);
-    hipLaunchKernelGGL((upsample_bwd_axis_kernel<TI, TO>), dim3(blocks), dim3(256), 0, st, in, out, outer, Ni, No, inner);
+    if (total + 16384L * 256 < (1L << 31) && outer * No * inner < (1L << 29))
+        hipLaunchKernelGGL((upsample_bwd_axis_kernel<TI, TO, unsigned>), dim3(blocks), dim3(256), 0, st, in, out, outer, Ni, No, inner);
+    else
+        hipLaunchKernelGGL((upsample_bwd_axis_kernel<TI, TO, long>), dim3(blocks), dim3(256), 0, st, in, out, outer, Ni, No, inner);
     LAUNCH_RET();
     return 0;
 }
