@@ -1,0 +1,3 @@
+cd $GRAFT_REPO_ROOT
+timeout 2400 python -m pytest tests -x -q -m gpu 2>&1 | tail -3
+bash tools/gpujobs/run92.sh
