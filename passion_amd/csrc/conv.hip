@@ -365,7 +365,7 @@ __global__ __launch_bounds__(256) void in_bwd_finish_pad_kernel(T* __restrict__ 
                                                                 const float* __restrict__ stats, const float* __restrict__ sums,
                                                                 const uint8_t* mask, int mask_col, int mask_ld, int D, int H, int W, int C,
                                                                 long bstride, int Cin_tot, int cbase, int bmod, int rep, long rep_stride,
-                                                                float vscale, int dwin_lo, int dwin_hi, FoldJob fj) {
+                                                                float vscale, int dwin_lo, int dwin_hi, FoldJob fj, int fold) {
     if (fj.main_x && (int)blockIdx.x >= fj.main_x) { fold_block(fj, (long)(blockIdx.x - fj.main_x) * gridDim.y + blockIdx.y); return; }
     const int gdx = fj.main_x ? fj.main_x : (int)gridDim.x;
     const int bix = (int)blockIdx.x;
@@ -390,7 +390,7 @@ __global__ __launch_bounds__(256) void in_bwd_finish_pad_kernel(T* __restrict__ 
         const int d = r / H, h = r % H;
         // source planes of this row: the own one, plus the halo plane folded onto planes 1 / S-2 (reflect adjoint)
         const int dsrc[3] = {d + 1, 0, D + 1}, hsrc[3] = {h + 1, 0, H + 1};
-        const bool dok[3] = {true, d == 1, d == D - 2}, hok[3] = {true, h == 1, h == H - 2};
+        const bool dok[3] = {true, fold && d == 1, fold && d == D - 2}, hok[3] = {true, fold && h == 1, fold && h == H - 2};   // fold = 0: zero-padded conv
         for (int i = tin; i < rowv; i += tpr) {
             const int w = i / cvn, c = (i % cvn) * VEC;
             const long e = ((long)r * W + w) * C + c;
@@ -399,7 +399,7 @@ __global__ __launch_bounds__(256) void in_bwd_finish_pad_kernel(T* __restrict__ 
             for (int j = 0; j < VEC; ++j) { g[j] = 0.f; xv[j] = 0.f; }
             if (present) {
                 if (stats) VecIO<T, VEC>::load(xb + e, xv);
-                const bool wlo = (w == 1), whi = (w == W - 2);
+                const bool wlo = fold && (w == 1), whi = fold && (w == W - 2);
 #pragma unroll
                 for (int a = 0; a < 3; ++a) {
                     if (!dok[a]) continue;
@@ -785,9 +785,14 @@ namespace pconv { int g_conv_padout = 1; }   // PASSION_CONV_PADOUT=0: reflect a
 // (the finish kernel folds the halo planes; for inputs normalised in the loader it also completes InstanceNorm backward)
 static bool use_padout(const ConvK& k, const passion_conv_desc_t* d) {
     if (!pconv::g_conv_lean || !pconv::g_conv_padout || g_passion_force_f32_mfma) return false;
-    if (d->ksize != 3 || d->pad_mode != PASSION_PAD_REFLECT) return false;
+    if (d->ksize != 3) return false;
     if (pconv::g_conv_padout > 1 && k.Di >= pconv::g_conv_padout) return false;
     if (d->x_dtype != PASSION_BF16 || d->y_dtype != PASSION_BF16) return false;
+    if (d->pad_mode != PASSION_PAD_REFLECT) {
+        // zero padding: only where the marching kernel runs the padded-domain dgrad (it skips the halo outputs; the lean MODE 2
+        // kernel would count them in the InstanceNorm-backward sums) -- the fusion blocks' 3x3x3 convs at the two finest levels
+        if (d->pad_mode != PASSION_PAD_ZEROS || !pconv::conv_march_covers(k, d->ksize, d->stride, 2, nullptr)) return false;
+    }
     if (k.Di < 2 || k.Hi < 2 || k.Wi < 2 || k.Cin % 4 || !pconv::lean_covers(k, d->stride, true)) return false;
     if (d->stride == 2 && ((k.Di | k.Hi | k.Wi) & 1)) return false;      // even input sizes: Do = Di / 2 exactly
     bool any = false;
@@ -1230,7 +1235,9 @@ static int conv3d_bwd_impl(const passion_conv_desc_t* d, const float* packed, co
             dxp = sums + slab_end_floats(k, w.gx, nt);
             k.tilesD = cdiv(k.Di + 2, TD); k.tilesH = cdiv(k.Hi + 2, TH); k.tilesW = cdiv(k.Wi + 2, TW);
             k.y = dxp;
-            rc = launch_conv_lean(k, d->ksize, d->stride, 2, packed + f32_pack_floats(k.Cin, k.Cout, nt), st);
+            rc = d->pad_mode == PASSION_PAD_REFLECT
+                     ? launch_conv_lean(k, d->ksize, d->stride, 2, packed + f32_pack_floats(k.Cin, k.Cout, nt), st)
+                     : launch_conv_march(k, d->ksize, d->stride, 2, packed + f32_pack_floats(k.Cin, k.Cout, nt), st);    // zero padding: marching kernel or not at all
             if (rc < 0) return rc;
             if (rc > 0) {
                 padout = false;
@@ -1305,11 +1312,11 @@ static int conv3d_bwd_impl(const passion_conv_desc_t* d, const float* packed, co
             if (v8)
                 hipLaunchKernelGGL((in_bwd_finish_pad_kernel<bf16_t, 8>), pg, dim3(256), 0, st, (bf16_t*)sg.dx, (const bf16_t*)sg.x,
                                    (const bf16_t*)dxp, sg.stats, sums, sg.mask, sg.mask_col, sg.mask_ld, k.Di, k.Hi, k.Wi, sg.C,
-                                   sg.bstride, k.Cin, sg.cbase, sg.bmod, rep, rs, vscale, dwin_lo, dwin_hi, fjl);
+                                   sg.bstride, k.Cin, sg.cbase, sg.bmod, rep, rs, vscale, dwin_lo, dwin_hi, fjl, d->pad_mode == PASSION_PAD_REFLECT ? 1 : 0);
             else
                 hipLaunchKernelGGL((in_bwd_finish_pad_kernel<bf16_t, 4>), pg, dim3(256), 0, st, (bf16_t*)sg.dx, (const bf16_t*)sg.x,
                                    (const bf16_t*)dxp, sg.stats, sums, sg.mask, sg.mask_col, sg.mask_ld, k.Di, k.Hi, k.Wi, sg.C,
-                                   sg.bstride, k.Cin, sg.cbase, sg.bmod, rep, rs, vscale, dwin_lo, dwin_hi, fjl);
+                                   sg.bstride, k.Cin, sg.cbase, sg.bmod, rep, rs, vscale, dwin_lo, dwin_hi, fjl, d->pad_mode == PASSION_PAD_REFLECT ? 1 : 0);
         } else if (defer_fold) { fjl.main_x = (int)grid.x; fjl.fold_x = (int)((fold_blocks + grid.y - 1) / grid.y); grid.x += (unsigned)fjl.fold_x; }
         if (padout) {}
         else if (d->x_dtype == PASSION_F32)

@@ -291,6 +291,9 @@ __global__ __launch_bounds__(256) void conv_march_kernel(ConvK p, MarchP mp) {
         tph[t] = h0 + r0 + rr; tpw[t] = w0 + tx * 16 + n;
         vmask |= 1u << t;
     }
+    // zero-padded convs (the fusion blocks' 3x3x3 conv): the adjoint has no halo outputs -- positions -1 and S of every axis
+    // are neither computed nor counted; the finish kernel then reads the interior of the padded scratch only (fold = 0)
+    const bool nohalo = DG && p.pad_mode != PASSION_PAD_REFLECT;
     if (DG) {
         const bool top = h0 == 0, bot = h0 + MTH == Sh, left = w0 == 0, right = w0 + TW == Sw;
 #pragma unroll
@@ -319,7 +322,7 @@ __global__ __launch_bounds__(256) void conv_march_kernel(ConvK p, MarchP mp) {
                 ++e;
             }
             vb[NT + xslot] = evb; tph[NT + xslot] = eph; tpw[NT + xslot] = epw;
-            if (ev) vmask |= 1u << (NT + xslot);
+            if (ev && !nohalo) vmask |= 1u << (NT + xslot);
         }
     }
     // which tiles this wave computes at all (wave-uniform): the extras only where some lane has one
@@ -368,7 +371,7 @@ __global__ __launch_bounds__(256) void conv_march_kernel(ConvK p, MarchP mp) {
     char* yb8 = reinterpret_cast<char*>(ybase);
     auto compute = [&](int jout, const u32x2 (&eo)[EOP ? TT : 1]) {
         const int dpos = dlo + jout;
-        const bool pvalid = jout >= 0 && jout < L;
+        const bool pvalid = jout >= 0 && jout < L && !(nohalo && (dpos < 0 || dpos >= Sd));
         f32x4 acc[TT];
 #pragma unroll
         for (int t = 0; t < TT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -549,26 +552,34 @@ int launch_march_one(ConvK& k, hipStream_t st) {
 namespace pconv {
 
 // 0 = launched, < 0 = HIP error, 1 = shape not covered (the caller goes on to the lean kernel)
-int launch_conv_march(ConvK& k, int ksize, int stride, int mode, const void* packed_bf16, hipStream_t st) {
-    if (!g_conv_march || ksize != 3 || stride != 1 || (mode != 0 && mode != 2)) return 1;
-    if (k.y_f32 || k.bd_rows || !(k.slope >= 0.f && k.slope <= 1.f)) return 1;
-    if (k.Hi % MTH || k.Wi % 16 || k.Di < 4) return 1;
+// the shapes the marching kernel takes; K8 = 8-channel blocks of its K axis
+bool conv_march_covers(const ConvK& k, int ksize, int stride, int mode, int* K8out) {
+    if (!g_conv_march || ksize != 3 || stride != 1 || (mode != 0 && mode != 2)) return false;
+    if (k.y_f32 || k.bd_rows || !(k.slope >= 0.f && k.slope <= 1.f)) return false;
+    if (k.Hi % MTH || k.Wi % 16 || k.Di < 4) return false;
     const int rows = mode == 2 ? k.Cin : k.Cout;               // M axis
-    if (rows > 16 || rows % 4) return 1;
+    if (rows > 16 || rows % 4) return false;
     int K8;
     if (mode == 2) {
-        if (k.Cout % 8) return 1;
+        if (k.Cout % 8) return false;
         K8 = k.Cout / 8;
-        for (int s = 0; s < k.nseg; ++s) if (k.seg[s].dx && k.seg[s].bmod > 0) return 1;
+        for (int s = 0; s < k.nseg; ++s) if (k.seg[s].dx && k.seg[s].bmod > 0) return false;
     } else {
         K8 = 0;
         for (int s = 0; s < k.nseg; ++s) {
-            if (k.seg[s].C % 8) return 1;
+            if (k.seg[s].C % 8) return false;
             K8 += k.seg[s].C / 8;
         }
-        if (K8 * 8 != k.Cin) return 1;
+        if (K8 * 8 != k.Cin) return false;
     }
-    if (K8 != 1 && K8 != 2) return 1;       // 32 input channels: the 108 weight registers cost the second wave per SIMD -- lean kernel
+    if (K8 != 1 && K8 != 2) return false;   // 32 input channels: the 108 weight registers cost the second wave per SIMD -- lean kernel
+    if (K8out) *K8out = K8;
+    return true;
+}
+
+int launch_conv_march(ConvK& k, int ksize, int stride, int mode, const void* packed_bf16, hipStream_t st) {
+    int K8 = 0;
+    if (!conv_march_covers(k, ksize, stride, mode, &K8)) return 1;
     static const int force_tw = []() { const char* e = getenv("PASSION_MARCH_TW"); return e ? atoi(e) : 0; }();
     bool w32 = (k.Wi % 32 == 0) && K8 <= 2;
     if (force_tw == 16) w32 = false;

@@ -120,6 +120,27 @@ PATH_CASES = [
     ([16], 16, 3, 1, 0, (8, 24, 24), True, False, False),
     ([8], 8, 3, 1, 1, (12, 16, 24), False, False, False),      # reflect pad, input NOT normalised (fold-only finish)
 ]
+ZERO_PAD_MARCH_CASES = [
+    # zero-padded 3x3x3 convs on volumes the marching kernel takes: padded-domain dgrad without halo outputs, finish without fold
+    ([8], 8, 3, 1, 0, (12, 16, 32), True, False, False),
+    ([8, 8], 16, 3, 1, 0, (9, 24, 16), True, True, True),
+    ([16], 8, 3, 1, 0, (6, 8, 48), True, False, False),
+]
+
+
+@pytest.mark.parametrize("case", ZERO_PAD_MARCH_CASES, ids=[str(i) for i in range(len(ZERO_PAD_MARCH_CASES))])
+def test_zero_padded_dgrad_on_the_marching_kernel(case):
+    from passion_amd import ops
+    ops.prof_read()
+    ops.prof_enable(1 << 2)
+    try:
+        test_conv_block_fwd_bwd(case, torch.bfloat16)
+    finally:
+        ops.prof_enable(0)
+    names = {r[4] for r in ops.prof_read()}
+    assert any(n.startswith("conv_march_kernel") for n in names), names
+
+
 PATHS = {"lean": {}, "lean_mirror_taps": {"conv_padout": 0}, "general": {"conv_lean": 0}, "few_workgroups": {"conv_target": 8}}
 
 
