@@ -1,7 +1,10 @@
 """ORACLE (test infrastructure only).  Serial restatement of the reference's sliding-window inference loop and Dice
 (code/utils/predict.py:182-218, 78-124) around any `model(x_window, mask) -> softmax probabilities` callable.
-predict.py itself cannot be imported here (medpy / nibabel / scipy.misc are absent), so this file is pinned
-by construction against the source lines it cites and by tests that run it around the pinned model oracle."""
+predict.py itself cannot be imported here (medpy / nibabel / scipy.misc are absent).  PINNED (round 3) by
+tests/golden/predict.npz (tools/make_golden_predict.py): the Dice function against the reference's OWN
+softmax_output_dice_class4, taken out of the reference file's syntax tree and executed in the build container; the window loop
+against the imported reference mmformer.Model driven through this restatement (the loop itself sits inside a function that
+calls medpy's hd95 per subject and cannot run here: it stays a restatement of the cited lines)."""
 import numpy as np
 import torch
 

@@ -144,3 +144,69 @@ def test_predict_runs_in_eval_mode_and_restores_the_mode():
     p_ref, _ = predict_ref.test_volume_softmax(m.toy, x, mask, 16)
     assert m.modes and not any(m.modes) and m.training and m.is_training
     assert torch.allclose(p, p_ref, atol=1e-6)
+
+
+# ---- pins from the reference itself (tools/make_golden_predict.py -> tests/golden/predict.npz) ---------------------------------
+def test_dice_matches_the_references_own_function():
+    """softmax_output_dice_class4 (predict.py:78-124) executed from the reference file in the build container: oracle and product
+    restatements against its outputs, incl. the < 500-voxel post-processing branch (499 / 500 / 1200 voxels) and an absent class"""
+    from _util import gold
+    from passion_amd.utils import predict
+    g = gold("predict.npz")
+    for i in range(int(g["n_dice"])):
+        out, tgt = torch.from_numpy(g[f"dice{i}_out"]).long(), torch.from_numpy(g[f"dice{i}_tgt"]).long()
+        for fn in (predict_ref.softmax_output_dice_class4, predict.softmax_output_dice_class4):
+            sep, ev = fn(out, tgt)
+            assert np.allclose(np.asarray(sep), g[f"dice{i}_sep"], rtol=1e-6, atol=1e-7), (i, fn.__module__)
+            assert np.allclose(np.asarray(ev), g[f"dice{i}_ev"], rtol=1e-6, atol=1e-7), (i, fn.__module__)
+
+
+def _golden_volume(g):
+    gen = torch.Generator().manual_seed(int(g["vol_seed"]))
+    shape = tuple(int(v) for v in g["vol_shape"])
+    x = torch.randn(1, 4, *shape, generator=gen)
+    tgt = torch.randint(0, 4, (1, *shape), generator=gen)
+    return x, tgt, torch.from_numpy(g["vol_mask"]), shape, int(g["vol_patch"])
+
+
+def _check_volume(g, p, a, tol):
+    shape = tuple(int(v) for v in g["vol_shape"])
+    p, a = p.cpu(), a.cpu()
+    assert float((p[:, :, shape[0] // 2] - torch.from_numpy(g["vol_pred_slice"])).abs().max()) < tol
+    assert np.allclose(p.double().sum((2, 3, 4)).numpy(), g["vol_pred_sum"], rtol=tol)
+    diff = np.nonzero(a.reshape(-1).numpy().astype(np.uint8) != g["vol_argmax"].reshape(-1))[0]
+    assert np.isin(diff, g["vol_close_idx"]).all(), f"{len(diff)} voxels differ, not all of them reference-side ties < 1e-4"
+    return diff
+
+
+def test_oracle_window_loop_around_the_oracle_model_matches_the_reference_model():
+    """oracle/predict_ref.py + oracle/mmformer_ref.py against the imported reference Model inside the same window loop"""
+    from _util import gold
+    g = gold("predict.npz")
+    x, tgt, mask, shape, S = _golden_volume(g)
+    P = small_weights()
+    with torch.no_grad():
+        p, a = predict_ref.test_volume_softmax(lambda xw, mk: mmformer_ref.forward(P, xw, mk, None, 1.0, "idt", False, False), x, mask, S)
+    diff = _check_volume(g, p, a, 1e-5)
+    assert len(diff) == 0
+    _, ev = predict_ref.softmax_output_dice_class4(a, tgt)
+    assert np.allclose(np.asarray(ev), g["vol_ev"], atol=1e-6)
+
+
+@pytest.mark.gpu
+def test_product_sliding_window_matches_the_reference_model_fixture():
+    """the product's batched sliding-window predictor (HIP kernels, f32) against the fixture the imported reference Model
+    produced: probabilities 1e-3, argmax bit-exact up to reference-side ties, Dice vs the label volume"""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from _util import gold
+    from passion_amd.utils import predict
+    g = gold("predict.npz")
+    dev = torch.device("cuda:0")
+    x, tgt, mask, shape, S = _golden_volume(g)
+    m = build_product_model(S, small=True).to(dev)
+    p, a = predict.sliding_window_predict(m, x.to(dev), mask.to(dev), S, windows_per_batch=4)
+    diff = _check_volume(g, p, a, 1e-3)
+    print(f"product vs reference sliding-window mask: {len(diff)} of {a.numel()} voxels differ (all reference-side ties)")
+    _, ev = predict.softmax_output_dice_class4(a, tgt.to(dev))
+    assert np.allclose(ev.cpu().numpy(), g["vol_ev"], atol=2e-4)

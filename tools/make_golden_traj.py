@@ -1,0 +1,100 @@
+#!/usr/bin/env python
+"""Multi-step golden fixtures: the IMPORTED reference (/root/reference/code, build container only) takes K AdamW(amsgrad)
+steps -- forward (losses inside, mmformer.py:381-659), the loss assembly of train.py:228-280 / :413-440, backward,
+`optimizer.step()` as constructed at train.py:95-96 -- on one synthetic volume whose intensities carry the label (so the
+network LEARNS and its prediction acquires margins: a random-init prediction is a near tie almost everywhere and cannot tell
+bf16 rounding from a small kernel bug).  Committed: the loss trajectory, the per-step voxel accuracy, the final
+argmax mask (2-bit packed), the voxels the reference itself decides by less than 1e-3, a probability slice and a few small
+final weights.  The product replays the same K steps from the same seed (tests/test_trajectory_gpu.py; bench.py's
+`dice_vs_ref` replays the 128^3 one in bf16).
+
+    python tools/make_golden_traj.py 64 30 plain      -> tests/golden/traj_plain_64.npz      (~3 min on 8 cores)
+    python tools/make_golden_traj.py 32 20 passion    -> tests/golden/traj_passion_32.npz
+    python tools/make_golden_traj.py 128 16 plain     -> tests/golden/traj_plain_128.npz     (~57 s per step)
+"""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import make_golden as mg  # noqa: E402
+
+LR = 1e-3          # options.py:11 default is 2e-4; the fixture uses a larger step so that K steps move the prediction
+MEANS = [[0., 1.5, -1.0, 2.0], [0., -1.0, 1.5, 1.0], [0., 1.0, 1.0, -1.5], [0., -1.5, 0.5, 1.5]]   # [modality][class]
+
+
+def signal_volume(S, seed=7):
+    """blob labels (make_golden.synth) and x = 0.5 * noise + a class-dependent mean per modality"""
+    x, target = mg.synth(1, S, seed=seed, blobs=True)
+    lab = target.argmax(1)
+    x = 0.5 * x + torch.tensor(MEANS)[:, lab[0]].unsqueeze(0)
+    return x, target
+
+
+def pack2(a):
+    a = np.asarray(a, dtype=np.uint8).reshape(-1)
+    pad = (-len(a)) % 4
+    a = np.concatenate([a, np.zeros(pad, np.uint8)]).reshape(-1, 4)
+    return (a[:, 0] | (a[:, 1] << 2) | (a[:, 2] << 4) | (a[:, 3] << 6)).astype(np.uint8)
+
+
+def main():
+    S, K, mode = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3]
+    passion = mode == "passion"
+    torch.set_num_threads(int(os.environ.get("TRAJ_THREADS", "8")))
+    mmformer, crit = mg.import_reference()
+    m = mg.build(mmformer, S, small=False)            # eval(): dropout off; weights by torch.manual_seed(1037) construction order
+    m.mask_type, m.use_passion, m.is_training = "idt", passion, True
+    x, target = signal_volume(S)
+    mask = torch.tensor([[True, True, False, True]])
+    mk = mask.float()
+    opt = torch.optim.AdamW([{"params": m.parameters(), "lr": LR, "weight_decay": 1e-4}], betas=(0.9, 0.999), eps=1e-08,
+                            amsgrad=True)            # train.py:95-96
+    losses, accs = [], []
+    lab = target.argmax(1)
+    for it in range(K + 1):
+        t0 = time.time()
+        outs = m(x, mask, target=target, temp=4.0)
+        pred = outs[0]
+        fuse = crit.softmax_weighted_loss_bs(pred, target, num_cls=4) + crit.dice_loss_bs(pred, target, num_cls=4)
+        loss = fuse.sum() + outs[1].sum()
+        if passion:                                   # train.py:243-280 with imb_beta = modal_weight = 1
+            sep_m, kl_m, proto_m = (outs[2] * mk).sum(0), (outs[3] * mk).sum(0), (outs[4] * mk).sum(0)
+            d = outs[5][0]
+            rp_mask = ((mk[0] * (d / (d.sum() / mk[0].sum()) - 1)) > 0).float()
+            loss = loss + (rp_mask * sep_m).sum() + 0.5 * kl_m.sum() + 0.1 * (rp_mask * proto_m).sum()
+        else:
+            loss = loss + (outs[2] * mk).sum()
+        losses.append(float(loss))
+        accs.append(float((pred.argmax(1) == lab).float().mean()))
+        print(f"step {it}: loss {losses[-1]:.6f} acc {accs[-1]:.4f} ({time.time() - t0:.1f} s fwd)", flush=True)
+        if it == K:
+            break
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+    pred = pred.detach()
+    top2 = pred.topk(2, dim=1).values
+    margin = (top2[:, 0] - top2[:, 1]).reshape(-1)
+    am = pred.argmax(1).reshape(-1).numpy().astype(np.uint8)
+    sd = m.state_dict()
+    rec = {"S": S, "K": K, "passion": passion, "lr": LR, "mask": mask.numpy(), "means": np.array(MEANS, np.float32),
+           "losses": np.array(losses), "accs": np.array(accs), "argmax_packed": pack2(am),
+           "close_idx": np.nonzero((margin < 1e-3).numpy())[0].astype(np.int32), "margin_min": float(margin.min()),
+           "frac_margin_lt_1e2": float((margin < 1e-2).float().mean()),
+           "pred_slice": pred[:, :, S // 2].numpy(), "pred_sum": pred.double().sum((2, 3, 4)).numpy(),
+           "label_packed": pack2(lab.reshape(-1).numpy())}
+    for key in ("flair_encoder.e1_c1.weight", "t2_encoder.e1_c2.conv.bias", "decoder_fuse.seg_layer.weight", "decoder_fuse.d1_c2.conv.bias",
+                "decoder_sep.seg_layer.weight", "multimodal_decode_conv.bias"):
+        rec["final::" + key] = sd[key].numpy()
+    out = os.path.join(mg.OUT, f"traj_{mode}_{S}.npz")
+    np.savez_compressed(out, **rec)
+    print("wrote", out, "final loss", losses[-1], "acc", accs[-1], "voxels with margin < 1e-3:", len(rec["close_idx"]),
+          "< 1e-2:", rec["frac_margin_lt_1e2"])
+
+
+if __name__ == "__main__":
+    main()
