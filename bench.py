@@ -46,9 +46,11 @@ def parse():
                     help="untimed set-up iterations before the W warm-up steps: the caching allocator keeps one pool per HIP "
                          "stream (the four encoder branches run on their own streams) and needs a few iterations to stop "
                          "calling hipMalloc; part of building the step, like compiling a graph would be")
-    ap.add_argument("--workload", default="mmformer128", choices=["mmformer128", "mmformer128_passion", "rfnet128_passion"],
+    ap.add_argument("--workload", default="mmformer128", choices=["mmformer128", "mmformer128_passion", "rfnet128_passion", "mmformer_depth"],
                     help="BASELINE.json configs[1] (default) / configs[2] (+ PASSION self-distillation, masks sampled from the "
-                         "brats_split mr2468 distribution) / configs[3] (RFNet + PASSION, batch 2 per GPU)")
+                         "brats_split mr2468 distribution) / configs[3] (RFNet + PASSION, batch 2 per GPU) / configs[4] (mmformer_depth: "
+                         "ONE 240 x 240 x 155 volume per step, padded to 160 planes -- to a multiple of 16 N for N ranks -- and split "
+                         "along D over the ranks with halo exchange: strong scaling)")
     ap.add_argument("--size", type=int, default=128)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--masks", default=None, choices=[None, "full", "split"],
@@ -57,6 +59,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=2, help="timed oracle steps of the cpu_baseline leg (after 1 warm-up)")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-dice", action="store_true", help="skip the dice_vs_ref leg (fixture replay after the timed region)")
     return ap.parse_args()
 
 
@@ -122,6 +125,46 @@ def cpu_baseline(passion, S, steps, mask_row, modal_weight):
                       f"{t:.2f} s/step on {cores} threads"}
 
 
+def dice_vs_ref(device, dtype, S):
+    """'mean Dice vs ref', the second half of BASELINE.json's metric, on committed fixtures of the imported reference at the
+    metric's size (outside the timed region):
+      trained   : tests/golden/traj_plain_128.npz -- the reference took K AdamW(amsgrad) steps on a 4x128^3 volume whose
+                  intensities carry the label; the product replays the K steps in the benchmarked dtype from the same seed and
+                  its final argmax mask is held against the reference's: mean Dice over WT / TC / ET (predict.py:78-124) and
+                  the exact number of differing voxels;
+      random_init: tests/golden/model_full128_idt_plain_1111.npz -- one forward of the seed-1037 model (near ties at almost
+                  every voxel: the hardest case for a reduced-precision path)."""
+    import numpy as np
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from _util import build_product_model, gold, mask_dice, replay_trajectory, synth, unpack2
+    out = {}
+    if S != 128:
+        return None
+    tpath = os.path.join(ROOT, "tests", "golden", "traj_plain_128.npz")
+    if os.path.exists(tpath):
+        g = gold("traj_plain_128.npz")
+        _, losses, pred = replay_trajectory(g, dtype, device)
+        got = pred.argmax(1).reshape(-1).cpu().numpy().astype(np.uint8)
+        d, n = mask_dice(got, unpack2(g["argmax_packed"], S ** 3))
+        out["trained"] = {"mean_dice": round(d, 6), "differing_voxels": n, "of": S ** 3, "steps_replayed": int(g["K"]),
+                          "loss_final": round(float(losses[-1]), 5), "loss_final_ref": round(float(g["losses"][-1]), 5),
+                          "fixture": "tests/golden/traj_plain_128.npz"}
+    g = gold("model_full128_idt_plain_1111.npz")
+    m = build_product_model(S, small=False).to(device)
+    m.mask_type, m.use_passion, m.is_training, m.compute_dtype = "idt", False, False, dtype
+    x, _ = synth(1, S, blobs=bool(g["blobs"]))
+    with torch.no_grad():
+        pred = m(x.to(device), torch.from_numpy(g["mask"]).to(device))
+    got = pred.argmax(1).reshape(-1).cpu().numpy().astype(np.uint8)
+    d, n = mask_dice(got, unpack2(g["argmax_packed"], S ** 3))
+    out["random_init"] = {"mean_dice": round(d, 6), "differing_voxels": n, "of": S ** 3,
+                          "reference_ties_below_1e-4": int(len(g["close_idx"])), "fixture": "tests/golden/model_full128_idt_plain_1111.npz"}
+    out["value"] = out.get("trained", out["random_init"])["mean_dice"]
+    out["what"] = "mean Dice (WT, TC, ET) of the product's argmax mask in the benchmarked dtype against the imported reference's f32 mask"
+    return out
+
+
 def measured_copy_gbs(device):
     """device-to-device copy of 1 GiB (read + write counted), the 'measured peak' SURVEY 8(d) asks for beside the nominal one"""
     import torch
@@ -181,13 +224,22 @@ def main():
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
 
     is_rfnet = args.workload.startswith("rfnet")
-    cfg_no = 3 if is_rfnet else (2 if passion else 1)
+    is_depth = args.workload == "mmformer_depth"
+    cfg_no = 4 if is_depth else (3 if is_rfnet else (2 if passion else 1))
     mask_mode = args.masks or ("split" if cfg_no == 2 else "full")
     batch = 2 if is_rfnet else 1
     torch.manual_seed(1037)
     if is_rfnet:
         from passion_amd.models import rfnet
         model = rfnet.Model(num_cls=4).to(ctx.device)
+    elif is_depth:
+        # configs[4]: the whole 240 x 240 x 155 volume, D padded to 160 (and on to a multiple of 16 * world so that every level
+        # splits evenly: 160 / 160 / 192 / 256 planes at 1 / 2 / 4 / 8 ranks); token grid (Dp / 16, 15, 15)
+        unit = 16 * ctx.world
+        Dp = -(-160 // unit) * unit
+        mmformer.patch_size = (Dp // 16, 15, 15)
+        model = mmformer.Model(num_cls=4).to(ctx.device)
+        mmformer.patch_size = 5
     else:
         mmformer.patch_size = S // 16
         model = mmformer.Model(num_cls=4).to(ctx.device)
@@ -210,15 +262,39 @@ def main():
     def eager_step():
         mk = masks[it_no[0] % len(masks)]
         it_no[0] += 1
-        return ptrain.train_step(model, opt, x, mk, target, 4.0, state, reducer)
+        # a FRESH tensor object over the same storage every step: ops.target_to_cl keeps the converted channels-last copy on the
+        # tensor object it was given (forward and loss assembly of one step share it), so re-using one object would take the
+        # float64 -> f32 conversion of the label volume (100 MB per step) out of all steps but the first.  A real loop hands over
+        # a new batch every iteration.
+        return ptrain.train_step(model, opt, x, mk, target.view(target.shape), 4.0, state, reducer)
 
     step = eager_step
+    if is_depth:
+        from passion_amd import depth
+        shard = depth.DepthCtx(rank=ctx.rank, world=ctx.world) if ctx.world == 1 else depth.DepthCtx()
+        Dl = Dp // ctx.world
+        g = torch.Generator().manual_seed(7)              # the SAME volume on every rank; each keeps its slab
+        xv = torch.randn(1, 4, Dp, 240, 240, generator=g)
+        lab = torch.randint(0, 4, (1, Dp, 240, 240), generator=g)
+        sl = slice(ctx.rank * Dl, (ctx.rank + 1) * Dl)
+        xs = xv[:, :, sl].contiguous().to(ctx.device)
+        ts = torch.nn.functional.one_hot(lab[:, sl], 4).permute(0, 4, 1, 2, 3).double().contiguous().to(ctx.device)
+        del xv, lab
+        model.is_training = True
+
+        def step():
+            loss_, _, _, _ = depth.sharded_step_loss(model, shard, xs, mask_full[:1], ts.view(ts.shape), Dp)
+            opt.zero_grad()
+            loss_.backward()
+            reducer.all_reduce_grads()
+            opt.step()
+            return loss_.detach()
     # warm-up; with the roofline leg on, its event pairs bracket EVERY conv / attention launch so that the kernel family that
     # dominates the step is known before the timed region starts -- there only that family (and the attention kernels,
     # a few launches) keeps its event pairs (326 event pairs per step cost ~5 % of throughput, one family ~1.5 %)
     for _ in range(args.prime):
         step()
-    want_events = not args.no_roofline
+    want_events = not args.no_roofline and not is_depth      # the roofline leg belongs to the data-parallel step
     if want_events:
         ops.prof_read()
         ops.prof_enable(CONV_KINDS | ATTN_KINDS | FINISH_KIND)
@@ -294,6 +370,19 @@ def main():
     grad_bytes = sum(p.numel() for p in model.parameters() if p.requires_grad) * 4
     mask_txt = ("masks sampled per step from brats_split mr2468 (mask_id histogram), modal_weight from it"
                 if mask_mode == "split" else "all modalities present")
+    if is_depth:
+        out = {"metric": "train volumes/sec (one 4-modality 240x240x155 volume, depth-sharded over the GPUs)",
+               "value": round(args.steps / dt, 4), "unit": "volumes/s", "n_gpus": ctx.world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+               "dtype": "bf16" if dtype == torch.bfloat16 else "f32", "data": "synthetic",
+               "config": {"workload": f"mmformer plain train step on ONE 4x240x240x{Dp} volume (155 planes zero-padded), D split into "
+                                      f"{ctx.world} slabs of {Dp // ctx.world} planes: halo exchange per 3x3x3 conv, InstanceNorm sums all-reduced, "
+                                      "level-5 tokens gathered (BASELINE.json configs[4])",
+                          "global_batch": 1, "parallelism": f"depth{ctx.world}", "dist_backend": ctx.backend,
+                          "world_size_seen": dist.get_world_size() if dist.is_initialized() else 1,
+                          "final_loss": round(final_loss, 5), "launch": "eager"}}
+        print(json.dumps(out), flush=True)
+        return
     out = {
         "metric": "train volumes/sec (4-modality 128^3, bs=%d/GPU)" % batch, "value": round(batch * ctx.world * args.steps / dt, 4),
         "unit": "volumes/s", "n_gpus": ctx.world, "steps": args.steps, "warmup": args.warmup,
@@ -326,18 +415,29 @@ def main():
             ak = [r for r in alone_recs if r[4] == dom]
             alone_ms = sum(r[1] for r in ak) / len(ak) if ak else None
             alone_ach = (sum(r[2] for r in ak) / (sum(r[1] for r in ak) * 1e-3) / 1e9) if ak else None
-            out["roofline"] = {"kernel": f"{dom} ({WHAT[rk[0][0]]})", "bound": "hbm", "achieved": round(ach, 2),
-                               "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic,
-                               "measured_copy_peak": round(copy_gbs, 1), "frac_of_measured_copy": round(ach / copy_gbs, 5),
-                               "avg_launch_ms_single_stream": round(alone_ms, 5) if alone_ms else None,
-                               "frac_single_stream": round(alone_ach / HBM_PEAK_GBS, 5) if alone_ach else None,
-                               "launches_per_step": len(rk) // args.steps, "avg_launch_ms": round(ms / len(rk), 5),
-                               "algorithmic_bytes_per_launch": round(by / len(rk), 1),
-                               "tflops": round(fl / (ms * 1e-3) / 1e12, 3),
-                               "events": "live, inside the timed region (this kernel's launches only; finish / attention figures: "
-                                         "warm-up steps, equally live)",
-                               **dgrad_complete(dom, live_all, alone_recs, [r for r in live_all if r[4] == dom], ak),
-                               "ms_per_step_by_family": {FAM[k]: round(v / max(1, args.warmup), 3) for k, v in sorted(fam_warm.items())}}
+            wf = dgrad_complete(dom, live_all, alone_recs, [r for r in live_all if r[4] == dom], ak)
+            rl = {"kernel": f"{dom} ({WHAT[rk[0][0]]})", "bound": "hbm", "achieved": round(ach, 2),
+                  "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic,
+                  "frac_is": "live: this kernel's launches inside the timed region, other streams' kernels sharing the CUs",
+                  "frac_live": round(ach / HBM_PEAK_GBS, 5),
+                  "frac_single_stream": round(alone_ach / HBM_PEAK_GBS, 5) if alone_ach else None,
+                  "measured_copy_peak": round(copy_gbs, 1), "frac_of_measured_copy": round(ach / copy_gbs, 5),
+                  "avg_launch_ms_single_stream": round(alone_ms, 5) if alone_ms else None,
+                  "launches_per_step": len(rk) // args.steps, "avg_launch_ms": round(ms / len(rk), 5),
+                  "algorithmic_bytes_per_launch": round(by / len(rk), 1),
+                  "tflops": round(fl / (ms * 1e-3) / 1e12, 3),
+                  "events": "live, inside the timed region (this kernel's launches only; finish / attention figures: "
+                            "warm-up steps, equally live)",
+                  **wf,
+                  "ms_per_step_by_family": {FAM[k]: round(v / max(1, args.warmup), 3) for k, v in sorted(fam_warm.items())}}
+            if "with_finish" in wf:
+                # an input gradient is not complete before its finish kernels (halo fold + second half of the InstanceNorm
+                # backward) have run: while they exist the headline is the kernel WITH them; the kernel alone stays under
+                # frac_live / frac_single_stream
+                rl["achieved"], rl["frac"] = wf["with_finish"]["achieved"], wf["with_finish"]["frac"]
+                rl["frac_is"] = "live, the kernel together with its finish launches (same algorithmic bytes over dgrad + finish time)"
+                rl["frac_of_measured_copy"] = round(rl["achieved"] / copy_gbs, 5)
+            out["roofline"] = rl
         # ---- attention: the one dense contraction on MFMA (north_star): achieved TFLOP/s of the fused kernels
         att = {}
         for name, kinds in (("forward", (4,)), ("backward", (5,))):
@@ -354,9 +454,16 @@ def main():
         if att:
             ppath = os.path.join(ROOT, "profiles", "attention_pmc.json")
             if os.path.exists(ppath):
-                att["mfma_busy"] = json.load(open(ppath))
+                att["mfma_busy"] = {"note": "STATIC: read from the committed rocprofv3 --pmc pass below, not measured in this run "
+                                            "(tools/pmc_attention.sh regenerates it)",
+                                    "source": "profiles/attention_pmc.json", "source_mtime": int(os.path.getmtime(ppath)),
+                                    **json.load(open(ppath))}
             att["peak_tflops"] = MFMA_BF16_PEAK_TF
             out["attention"] = att
+    if not is_rfnet and not args.no_dice:
+        dv = dice_vs_ref(ctx.device, dtype, S)
+        if dv:
+            out["dice_vs_ref"] = dv
     if not args.no_cpu_baseline and ctx.world == 1 and not is_rfnet:
         out["cpu_baseline"] = cpu_baseline(passion, S, args.cpu_steps, masks[0][0], modal_weight)
     print(json.dumps(out), flush=True)

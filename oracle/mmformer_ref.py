@@ -118,9 +118,9 @@ def _tokens(x):  # (B,C,p,p,p) -> (B,N,C)
     return x.flatten(2).transpose(1, 2)
 
 
-def _untoken(t, p):  # (B,N,C) -> (B,C,p,p,p)
+def _untoken(t, p):  # (B,N,C) -> (B,C,pD,pH,pW); the reference's grid is a cube (mmformer.py:427), p = (pD, pH, pW) generalises it
     B, N, C = t.shape
-    return t.transpose(1, 2).reshape(B, C, p, p, p)
+    return t.transpose(1, 2).reshape(B, C, *p)
 
 
 def _seg_losses(pred, target, up_op=None):
@@ -135,7 +135,7 @@ def forward(P, x, mask, target=None, temp=1.0, mask_type="idt", use_passion=Fals
     if mask_type != "pdt":
         x = x * mask[:, :, None, None, None].to(x.dtype)                       # Q9 (mmformer.py:397-398)
     enc = [encoder(P, f"{m}_encoder", x[:, i:i + 1]) for i, m in enumerate(MODALS)]
-    p = enc[0][4].shape[-1]
+    p = tuple(enc[0][4].shape[-3:])      # token grid; the reference hard-codes a cube of patch_size (mmformer.py:21,427,444)
 
     def stack(lvl):
         return torch.stack([enc[i][lvl] for i in range(4)], 1)                 # (B,4,C,D,H,W)
@@ -163,7 +163,7 @@ def forward(P, x, mask, target=None, temp=1.0, mask_type="idt", use_passion=Fals
         feats = intra if tok_mask is None else intra * tok_mask[:, :, None, None, None, None].to(intra.dtype)
         tok = torch.cat([_tokens(feats[:, i]) for i in range(4)], 1)
         tok = transformer(P, "multimodal_transformer", tok, pos_cat, drop_p)
-        vol = tok.reshape(B, p, p, p, -1).permute(0, 4, 1, 2, 3)
+        vol = tok.reshape(B, *p, -1).permute(0, 4, 1, 2, 3)
         return _conv(P, "multimodal_decode_conv", vol)
 
     fuse_pred, preds, de_f_avg = decoder_fuse(P, xs + [inter()])

@@ -180,15 +180,17 @@ class GatherDFn(torch.autograd.Function):
 
 def global_stats(x, shard, eps=1e-5):
     """InstanceNorm (mean, rstd) per (b, c) over the WHOLE volume from the ranks' slabs: local statistics kernel, then one
-    all-reduce of (sum x, sum x^2) -- SURVEY 8e "per IN: all-reduce of (sum x, sum x^2) * C floats" """
+    all-reduce of (n, sum x, sum x^2) in double -- SURVEY 8e "per IN: all-reduce of (sum x, sum x^2) * C floats" """
     st = ops.instnorm_stats(x.detach(), eps).double()                       # (B, C, 2) = mean, rstd of the slab
-    V = float(x[0, ..., 0].numel())
-    mean, var = st[..., 0], st[..., 1].pow(-2) - eps
-    sums = torch.stack([mean * V, (var + mean * mean) * V], -1).contiguous()
-    shard.all_reduce(sums)
-    Vg = V * shard.world
-    gm = sums[..., 0] / Vg
-    gv = (sums[..., 1] / Vg - gm * gm).clamp_min(0)
+    n = float(x[0, ..., 0].numel())                                         # voxels of THIS rank's slab (slabs may differ in size)
+    mean, var = st[..., 0], (st[..., 1].pow(-2) - eps).clamp_min(0)
+    # parallel-variance combination in double (Chan et al.): all-reduce (n, n * mean, M2 + n * mean^2); the between-rank term
+    # sum n_r (mean_r - mean_g)^2 is formed from the reduced moments, so only the ranks' DIFFERENCES of means meet in it
+    mom = torch.stack([torch.full_like(mean, n), mean * n, (var + mean * mean) * n], -1).contiguous()
+    shard.all_reduce(mom)
+    ng = mom[..., 0]
+    gm = mom[..., 1] / ng
+    gv = (mom[..., 2] / ng - gm * gm).clamp_min(0)
     return torch.stack([gm, (gv + eps).rsqrt()], -1).float().contiguous()
 
 
@@ -408,12 +410,12 @@ def sharded_step_loss(model, shard, x, mask, target, Dg):
         own5 = encs[i][4].with_mask(mask, i) if idt else encs[i][4]
         tokv = conv(getattr(model, f"{m}_encode_conv"), own5, shard, dg5, norm=False).t
         tok = GatherDFn.apply(tokv, shard)
-        p = tok.shape[2]
+        pH, pW = tok.shape[2], tok.shape[3]                     # token grid (Dg / 16, pH, pW): not necessarily a cube
         tok = tok.reshape(B, -1, model.token_dim)
         tok = model._transformer(getattr(model, f"{m}_transformer"), tok, pos[i])
         intra.append(tok * mask[:, i].view(B, 1, 1).to(tok.dtype))
     tok = model._transformer(model.multimodal_transformer, torch.cat(intra, 1), torch.cat(pos, 1))
-    volf = tok.to(dt).contiguous().view(B, dg5, p, p, model.token_dim * 4)
+    volf = tok.to(dt).contiguous().view(B, dg5, pH, pW, model.token_dim * 4)
     Dl5 = encs[0][4].t.shape[1]
     mine = volf[:, shard.rank * Dl5:(shard.rank + 1) * Dl5].contiguous()
     x5 = conv(model.multimodal_decode_conv, Slab(mine, shard), shard, dg5, norm=False)

@@ -14,7 +14,9 @@ materialise (they are per-segment masks of the conv loader), InstanceNorm statis
 computed once and shared by all its consumers (the five decoder_fuse passes re-use them).
 
 Module-level constants are read at construction time, as in the reference, so
-`mmformer.patch_size = S // 16` selects a crop edge S (the reference hard-codes 80 -> 5).
+`mmformer.patch_size = S // 16` selects a crop edge S (the reference hard-codes 80 -> 5).  Beyond the reference:
+`mmformer.patch_size = (pD, pH, pW)` builds the position embeddings for a NON-CUBE token grid (a (16 pD, 16 pH, 16 pW) volume:
+BASELINE.json configs[4]'s 240 x 240 x 160 is (10, 15, 15) with D first); an int keeps the reference's cube.
 """
 import numpy as np
 import torch
@@ -45,6 +47,11 @@ ENC_STREAMS = _os.environ.get("PASSION_ENC_STREAMS", "1") != "0"
 if hasattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch"):
     torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
 INTRA_STREAMS = _os.environ.get("PASSION_INTRA_STREAMS", "1") != "0"   # intra-modal transformers stay on their encoder's stream
+
+
+def n_tokens(ps):
+    """tokens per modality of a token grid given as the reference's cube edge (int) or as (pD, pH, pW)"""
+    return int(ps) ** 3 if isinstance(ps, int) else int(np.prod(ps))
 
 
 def _up2(f):
@@ -394,7 +401,7 @@ class Model(nn.Module):
         for m in MODALS:
             setattr(self, f"{m}_encode_conv", nn.Conv3d(basic_dims * 16, td, kernel_size=1, stride=1, padding=0))
         for m in MODALS:
-            setattr(self, f"{m}_pos", nn.Parameter(torch.zeros(1, patch_size ** 3, td)))
+            setattr(self, f"{m}_pos", nn.Parameter(torch.zeros(1, n_tokens(patch_size), td)))
         for m in MODALS:
             setattr(self, f"{m}_transformer", Transformer(embedding_dim=td, depth=depth, heads=num_heads, mlp_dim=mlp_dim))
         self.multimodal_transformer = Transformer(embedding_dim=td, depth=depth, heads=num_heads, mlp_dim=mlp_dim,
@@ -444,7 +451,7 @@ class Model(nn.Module):
             toks = [(t.unsqueeze(0) * tok_mask[:, i].view(P, B, 1, 1).to(t.dtype)).view(P * B, t.shape[1], t.shape[2])
                     for i, t in enumerate(intra)]
         tok = self._transformer(self.multimodal_transformer, torch.cat(toks, 1), pos_cat)
-        vol = tok.to(self.compute_dtype).contiguous().view(P * B, p, p, p, self.token_dim * num_modals)
+        vol = tok.to(self.compute_dtype).contiguous().view(P * B, *p, self.token_dim * num_modals)
         return run_pointwise(self.multimodal_decode_conv, Feat(vol))
 
     def _enc_streams(self, dev):
@@ -495,8 +502,7 @@ class Model(nn.Module):
             depends on encoder i only, so it stays on that encoder's stream"""
             m = MODALS[i]
             own5 = encs[i][4].with_mask(mask, i) if idt else encs[i][4]
-            pp = own5.t.shape[1]
-            tok = run_pointwise(getattr(self, f"{m}_encode_conv"), own5).t.view(B, pp ** 3, self.token_dim)
+            tok = run_pointwise(getattr(self, f"{m}_encode_conv"), own5).t.view(B, -1, self.token_dim)
             tok = self._transformer(getattr(self, f"{m}_transformer"), tok, pos[i])
             return tok * mask[:, i].view(B, 1, 1).to(tok.dtype)
 
@@ -539,7 +545,7 @@ class Model(nn.Module):
                 sts = [s_[i] for s_ in sbufs] if training else None
                 if streams:
                     streams[i].wait_stream(main)
-                    if training and _os.environ.get("PASSION_DBG_NOREC") is None:
+                    if training:
                         for b_ in bufs + sbufs:              # allocated on the main stream, written and (backward) read on this one
                             b_.record_stream(streams[i])
                     with torch.cuda.stream(streams[i]):
@@ -556,7 +562,7 @@ class Model(nn.Module):
         if streams:
             for s_ in streams:
                 main.wait_stream(s_)
-        p = encs[0][4].t.shape[1]
+        p = tuple(encs[0][4].t.shape[1:4])       # token grid (pD, pH, pW); the reference's is the cube patch_size^3
 
         # ---- the masks of every pass through the fusion path: teacher (+ the four uni-modal students,
         # mmformer.py:468-531).  All P passes share the encoder features, so they run as ONE virtual batch of

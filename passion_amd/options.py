@@ -32,6 +32,8 @@ def build_parser():
     p.add_argument('--dtype', default='fp32', choices=['fp32', 'bf16'], help='activation storage dtype')
     p.add_argument('--synthetic', action='store_true', default=False, help='synthetic volumes instead of the npy dataset')
     p.add_argument('--iters_per_epoch', default=0, type=int, help='synthetic mode: iterations per epoch')
+    p.add_argument('--stop_after_epoch', default=-1, type=int,
+                   help='leave after the checkpoint of this epoch (0-based) is written; --resume continues the run')
     return p
 
 

@@ -53,7 +53,7 @@ def init(backend=None):
     return Ctx(rank, world, local, device, backend)
 
 
-_DDP_DEBUG = os.environ.get("PASSION_DDP_DEBUG") == "1"
+WIRE_BF16 = os.environ.get("PASSION_DDP_BF16") == "1"    # gradients travel as bf16 (half the xGMI bytes); default: f32 on the wire
 
 
 class GradReducer:
@@ -86,7 +86,8 @@ class GradReducer:
                 cur, cur_bytes = [], 0
         if cur:
             self.buckets.append(cur)
-        self.flat = [torch.zeros(sum(p.numel() for p in b), dtype=torch.float32, device=self.params[0].device)
+        self.wire_dtype = torch.bfloat16 if (WIRE_BF16 and self.params[0].is_cuda) else torch.float32
+        self.flat = [torch.zeros(sum(p.numel() for p in b), dtype=self.wire_dtype, device=self.params[0].device)
                      for b in self.buckets]
         self.overlap = overlap and ctx.world > 1 and hasattr(torch.Tensor, "register_post_accumulate_grad_hook")
         self._pending = [len(b) for b in self.buckets]       # gradients still missing per bucket in this backward
@@ -106,8 +107,6 @@ class GradReducer:
         def hook(_param):
             if self._on_gpu:
                 self._streams[bi].add(_raw_stream())     # raw handle: a Stream object costs 10 us to build, per parameter
-                if _DDP_DEBUG and self.ctx.rank == 0:
-                    print(f"[ddp] hook bucket {bi} param {self._names.get(id(_param))} stream {_raw_stream():#x} pending {self._pending[bi] - 1}", flush=True)
             self._pending[bi] -= 1
             # Collectives must be issued in the same order on every rank.  Readiness order can differ between ranks (a
             # parameter that got no gradient on one of them), so buckets are launched strictly by index: bucket k goes out
@@ -133,9 +132,6 @@ class GradReducer:
         bucket, flat = self.buckets[bi], self.flat[bi]
         if self._on_gpu:
             cur = torch.cuda.current_stream()
-            if _DDP_DEBUG and self.ctx.rank == 0:
-                print(f"[ddp] launch bucket {bi} on {cur.cuda_stream:#x}, noted {[hex(r) for r in self._streams[bi]]}, "
-                      f"missing grads {[self._names.get(id(p)) for p in bucket if p.grad is None]}", flush=True)
             for raw in self._streams[bi]:
                 if raw != cur.cuda_stream:
                     ev = torch.cuda.Event()
@@ -154,11 +150,17 @@ class GradReducer:
         for bi, (bucket, flat) in enumerate(zip(self.buckets, self.flat)):
             self._works[bi].wait()
             views = flat.split([p.numel() for p in bucket])
+            if self.wire_dtype != torch.float32:             # bf16 on the wire: back to f32 gradients, one multi-tensor launch
+                have = [(p, v) for p, v in zip(bucket, views) if p.grad is not None]
+                torch._foreach_copy_([p.grad.view(-1) for p, _ in have], [v for _, v in have])
+                for p, v in zip(bucket, views):
+                    if p.grad is None:
+                        p.grad = v.view_as(p).float()
+                continue
+            # f32: the reduced gradient IS the bucket slice -- p.grad becomes a view of the flat buffer (no copy back; the
+            # optimizer reads it, zero_grad(set_to_none) drops it, the next backward's pack overwrites the buffer after that)
             for p, v in zip(bucket, views):
-                if p.grad is None:
-                    p.grad = v.view_as(p).clone()
-                else:
-                    p.grad.copy_(v.view_as(p))
+                p.grad = v.view_as(p)
         self._pending = [len(b) for b in self.buckets]
         self._works = [None] * len(self.buckets)
         self._next = 0

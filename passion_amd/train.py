@@ -28,6 +28,17 @@ class LossState:
         self.eta, self.eta_ext = eta, eta_ext
         self.epoch_dist_m = torch.zeros(4, device=device)
 
+    def state_dict(self):
+        """plain tensors / floats only: the checkpoint stays loadable with torch.load(weights_only=True)"""
+        return {"imb_beta": self.imb_beta.detach().cpu(), "modal_weight": self.modal_weight.detach().cpu(), "eta": float(self.eta),
+                "eta_ext": float(self.eta_ext)}
+
+    def load_state_dict(self, sd):
+        dev = self.imb_beta.device
+        self.imb_beta = sd["imb_beta"].to(dev).float()
+        self.modal_weight = sd["modal_weight"].to(dev).float()
+        self.eta, self.eta_ext = float(sd["eta"]), float(sd.get("eta_ext", self.eta_ext))
+
     def end_epoch(self, epoch, warmup=False):
         """train.py:325-335: beta <- clamp(beta - eta*rp_epoch, .1, 4), renormalised to |beta|_2 = 2"""
         from .parallel import all_reduce_sum_
@@ -147,7 +158,7 @@ def split_modal_weight(batch_size=1, world=1):
     """modal_weight = iter_per_epoch / modal_num of the mr2468 split (train.py:163-171)"""
     hist = np.asarray(SPLIT_MR2468_HIST, dtype=np.float64)
     modal_num = (hist[:, None] * np.asarray(MASK_TABLE, dtype=np.float64)).sum(0)
-    return torch.tensor((int(hist.sum()) // (batch_size * world)) / modal_num, dtype=torch.float32)
+    return torch.tensor(-(-int(hist.sum()) // (batch_size * world)) / modal_num, dtype=torch.float32)   # len(DataLoader): ceil
 
 
 def sample_split_masks(rng, n):
@@ -163,7 +174,7 @@ def epoch_order(n, epoch, seed, world, rank, batch_size, iters):
     global batch `it` = the ranks' rows `it` side by side.  Every rank gets exactly `iters` rows: each step issues collectives."""
     perm = np.random.RandomState(seed + epoch).permutation(n)
     gb = batch_size * world
-    if n < gb:                      # fewer subjects than one global batch: wrap around
+    if n < iters * gb:              # the last global batch of ceil(n / gb) iterations is short: wrap around
         perm = np.resize(perm, gb * max(1, iters))
     return perm[:iters * gb].reshape(iters, world, batch_size)[:, rank]
 
@@ -202,6 +213,16 @@ def main(argv=None):
         optimizer.load_state_dict(ckpt["optim_dict"])
         start_epoch = int(ckpt["epoch"]) + 1
     state = LossState(ctx.device)
+    resumed_state = False
+    if ckpt is not None and not args.use_pretrain:
+        # every checkpoint is written after end_epoch() has moved imb_beta (and, every 100 epochs, eta): a continued run must
+        # pick those up, or it silently follows another loss weighting than the uninterrupted one
+        if "loss_state" in ckpt:
+            state.load_state_dict(ckpt["loss_state"])
+            resumed_state = True
+        elif args.use_passion and ctx.rank == 0:
+            print("[train] the checkpoint carries no PASSION loss state (a reference checkpoint?): imb_beta = 1, eta = 0.01 again",
+                  flush=True)
     data = None
     gb = args.batch_size * ctx.world                    # global batch: one DataParallel batch of the reference = all ranks' samples
     if not args.synthetic:      # the reference's npy dataset through the GPU input pipeline (train.py:112-131)
@@ -210,17 +231,24 @@ def main(argv=None):
         data = Brats_loadall_train_nii_idt(transforms=args.train_transforms, root=args.datasetPath, num_cls=4,
                                            mask_type=args.mask_type, train_file=csv, device=ctx.device)
     # iterations per epoch from a RANK-INDEPENDENT quantity: every step issues collectives (rp_mask, gradient buckets), so all
-    # ranks must run the same number of steps; the len(data) % gb left-over subjects of an epoch's permutation are dropped
-    iters = args.iters_per_epoch or (10 if data is None else max(1, len(data) // gb))
+    # ranks must run the same number of steps.  The reference's DataLoader has no drop_last (train.py:122-128): an epoch is
+    # ceil(N / batch) iterations and the last batch is short; here the last global batch is wrap-padded with the first subjects of
+    # the epoch's permutation instead (every rank keeps a full batch).  `iter_ref` = the reference's iter_per_epoch, which feeds
+    # modal_weight and the pdt normaliser (train.py:160,171) whatever --iters_per_epoch says.
+    iter_ref = 10 if data is None else -(-len(data) // gb)
+    iters = args.iters_per_epoch or iter_ref
     modal_num = None
     if data is not None:        # initial imbalance weights (train.py:163-171): iterations per epoch / subjects that have the modality
         modal_num = torch.zeros(4, device=ctx.device)
         for sample_mask in data.samples_masks:
             modal_num += torch.tensor(eval(sample_mask), dtype=torch.float32, device=ctx.device)
-        state.modal_weight = iters / modal_num
-    rng = np.random.RandomState(args.seed + ctx.rank)
+        if not resumed_state:
+            state.modal_weight = iter_ref / modal_num
     loss = torch.zeros((), device=ctx.device)
     for epoch in range(start_epoch, args.num_epochs):
+        # per-epoch random streams (synthetic masks, dropout): epoch e of a resumed run draws what epoch e of the uninterrupted run drew
+        rng = np.random.RandomState(args.seed + ctx.rank + 7919 * epoch)
+        torch.manual_seed(args.seed + 7919 * epoch)
         lr = float(poly_lr(args.lr, epoch, args.num_epochs))     # python float: keeps the checkpoint weights_only-loadable
         for g_ in optimizer.param_groups:
             g_["lr"] = lr
@@ -237,7 +265,7 @@ def main(argv=None):
                 target = torch.stack([s_[1] for s_ in samples])
                 mk = torch.stack([s_[2] for s_ in samples])
             loss = train_step(model, optimizer, x, mk, target, args.temp, state, reducer,
-                              warmup=epoch < args.region_fusion_start_epoch, modal_num=modal_num, iter_per_epoch=iters)
+                              warmup=epoch < args.region_fusion_start_epoch, modal_num=modal_num, iter_per_epoch=iter_ref)
         torch.cuda.synchronize()
         if args.use_passion:
             state.end_epoch(epoch, epoch < args.region_fusion_start_epoch)
@@ -246,7 +274,11 @@ def main(argv=None):
                   f"{iters * gb / (time.time() - t0):.3f} vol/s", flush=True)
             os.makedirs(args.savepath, exist_ok=True)
             torch.save({"epoch": epoch, "state_dict": {"module." + k: v for k, v in model.state_dict().items()},
-                        "optim_dict": optimizer.state_dict()}, os.path.join(args.savepath, "model_last.pth"))
+                        "optim_dict": optimizer.state_dict(), "loss_state": state.state_dict()},
+                       os.path.join(args.savepath, "model_last.pth"))
+        if epoch == args.stop_after_epoch:
+            break
+    return model, state
 
 
 if __name__ == "__main__":

@@ -91,3 +91,101 @@ def flash_keep_mask(B, N, p, seed, H=8):
     u = np.stack([x & np.uint64(0xffff), x >> np.uint64(16)], -1).reshape(B * H * N, 2 * npair)[:, :N]
     keep = (u >= thr).reshape(B, H, N, N)
     return torch.from_numpy(keep), 1.0 / (1.0 - thr / 65536.0)
+
+
+# ---- multi-step fixtures (tools/make_golden_traj.py) ------------------------------------------------------------------------
+def signal_volume(S, means, seed=7):
+    """blob labels and x = 0.5 * noise + a class-dependent mean per modality (make_golden_traj.signal_volume)"""
+    x, target = synth(1, S, seed=seed, blobs=True)
+    lab = target.argmax(1)
+    x = 0.5 * x + torch.as_tensor(np.asarray(means), dtype=torch.float32)[:, lab[0]].unsqueeze(0)
+    return x, target
+
+
+def unpack2(packed, n):
+    p = np.asarray(packed)
+    out = np.empty((p.size, 4), dtype=np.uint8)
+    for j in range(4):
+        out[:, j] = (p >> (2 * j)) & 3
+    return out.reshape(-1)[:n]
+
+
+def replay_trajectory(g, dtype, dev, on_step=None):
+    """the product takes the fixture's K AdamW(amsgrad) steps from the same seed / inputs / learning rate (dropout off, as the
+    fixture) -> (model, per-step losses [K + 1], final prediction (1,4,S,S,S)); the step is passion_amd.train's"""
+    from passion_amd import train as ptrain
+    S, K, passion = int(g["S"]), int(g["K"]), bool(g["passion"])
+    m = build_product_model(S, small=False).to(dev)
+    m.mask_type, m.use_passion, m.is_training, m.compute_dtype = "idt", passion, True, dtype
+    x, target = signal_volume(S, g["means"])
+    x, target, mask = x.to(dev), target.to(dev), torch.from_numpy(g["mask"]).to(dev)
+    opt = ptrain.make_optimizer(m, lr=float(g["lr"]), weight_decay=1e-4)
+    losses, pred = [], None
+    for it in range(K + 1):
+        outs = m(x, mask, target=target, temp=4.0)
+        loss = ptrain.assemble_loss(outs, target, mask, "idt", passion)
+        losses.append(loss.detach())
+        pred = outs[0].detach()
+        if on_step is not None:
+            on_step(it, outs, loss)
+        if it == K:
+            break
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+    return m, torch.stack(losses).double().cpu().numpy(), pred
+
+
+def mask_dice(a, b):
+    """mean Dice (WT, TC, ET as predict.py:78-124 forms them) between two integer label volumes + the differing-voxel count"""
+    a, b = np.asarray(a).reshape(-1), np.asarray(b).reshape(-1)
+    d = []
+    for cls in ((1, 2, 3), (1, 3), (3,)):
+        oa, ob = np.isin(a, cls), np.isin(b, cls)
+        d.append((2.0 * (oa & ob).sum() + 1e-8) / (oa.sum() + ob.sum() + 1e-8))
+    return float(np.mean(d)), int((a != b).sum())
+
+
+def build_model_grid(grid, small=True, seed=11):
+    """product Model for a (pD, pH, pW) token grid (a (16 pD, 16 pH, 16 pW) volume) -- beyond the reference, whose grid is a cube
+    (mmformer.py:21,342-345): conv weights of the small-constants fixture where shapes agree (small=True), random position
+    embeddings.  -> model in eval() mode on the CPU"""
+    from passion_amd.models import mmformer
+    keep = {k: getattr(mmformer, k) for k in FULL_DIMS}
+    keep_ps = mmformer.patch_size
+    try:
+        for k, v in (SMALL_DIMS if small else FULL_DIMS).items():
+            setattr(mmformer, k, v)
+        mmformer.patch_size = tuple(grid)
+        torch.manual_seed(seed)
+        m = mmformer.Model(num_cls=4)
+    finally:
+        for k, v in keep.items():
+            setattr(mmformer, k, v)
+        mmformer.patch_size = keep_ps
+    sd = m.state_dict()
+    with torch.no_grad():
+        if small:
+            for k, v in small_weights().items():
+                if sd[k].shape == v.shape:
+                    sd[k].copy_(v)
+        g = torch.Generator().manual_seed(seed + 1)
+        for n in ("flair_pos", "t1ce_pos", "t1_pos", "t2_pos"):
+            sd[n].copy_(torch.randn(sd[n].shape, generator=g) * 0.1)
+    m.eval()
+    return m
+
+
+def synth_box(B, shape, seed=7):
+    """synthetic (B,4,D,H,W) volume + ellipsoid blob labels for a non-cube shape"""
+    g = torch.Generator().manual_seed(seed)
+    D, H, W = shape
+    x = torch.randn(B, 4, D, H, W, generator=g)
+    zz, yy, xx = torch.meshgrid(torch.arange(D, dtype=torch.float32), torch.arange(H, dtype=torch.float32),
+                                torch.arange(W, dtype=torch.float32), indexing="ij")
+    r = (((zz - D / 2) / D) ** 2 + ((yy - H / 2) / H) ** 2 + ((xx - W / 2) / W) ** 2).sqrt()
+    lab = torch.zeros(B, D, H, W, dtype=torch.long)
+    lab[:, r < 0.35] = 2
+    lab[:, r < 0.25] = 1
+    lab[:, r < 0.12] = 3
+    return x, F.one_hot(lab, 4).permute(0, 4, 1, 2, 3).double()

@@ -197,3 +197,74 @@ def test_rfnet_absent_modality_and_batch_independence():
     assert torch.equal(a, b)
     assert torch.equal(a[:1], c)
     assert float((a.sum(1) - 1).abs().max()) < 1e-5
+
+
+def test_rfnet_128_batch2_passion_training_step():
+    """BASELINE.json configs[3] AT ITS STATED SHAPE: RFNet, 4 x 128^3, batch 2, PASSION self-distillation, bf16 -- one full
+    training step (rfnet.py:217-403 forward with the four students + train.py:228-280 assembly + backward + AdamW(amsgrad)).
+    The CPU oracle cannot hold this size (RSS > 62 GB), so the step is held to size-independent properties; the
+    reference fixture at 96^3 runs on the same build in tests/test_benchsize_gpu.py.
+      * every output / loss / gradient is finite, every parameter receives a gradient;
+      * an absent modality's voxels are never read, THROUGH THE BACKWARD: changing them changes no loss and no gradient, bit for
+        bit (the bf16 step repeats bit for bit);
+      * PASSION's teacher is the plain forward: pred / prm_loss / sep_loss of the two steps agree;
+      * gradients are linear in the loss scale;
+      * the optimizer step moves every parameter."""
+    dev = _dev()
+    from passion_amd import train as ptrain
+    from passion_amd.models import rfnet
+    torch.manual_seed(1037)
+    m = rfnet.Model(num_cls=4).to(dev)
+    m.mask_type, m.compute_dtype, m.use_passion, m.is_training = "idt", torch.bfloat16, True, True
+    m.eval()                                     # RFNet has no dropout; eval() only fixes the mode flag
+    x, t = synth(2, S, blobs=True)
+    x, t = x.to(dev), t.to(dev)
+    mask = torch.tensor([[True, True, False, True], [False, True, True, True]], device=dev)
+    names = [k for k, _ in m.named_parameters()]
+
+    def step(xx, scale=1.0, passion=True):
+        m.use_passion = passion
+        m.zero_grad(set_to_none=True)
+        outs = m(xx, mask, target=t, temp=4.0)
+        st = ptrain.LossState(dev, modal_weight=torch.tensor([2.43, 1.62, 1.19, 5.09]))
+        loss = ptrain.assemble_loss(outs, t, mask, "idt", passion, st) * scale
+        loss.backward()
+        torch.cuda.synchronize()
+        return [o.detach().clone() for o in outs], loss.detach().clone(), {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}
+
+    outs, loss, grads = step(x)
+    assert len(outs) == 6 and all(bool(torch.isfinite(o).all()) for o in outs) and bool(torch.isfinite(loss))
+    assert outs[0].shape == (2, 4, S, S, S) and float((outs[0].sum(1) - 1).abs().max()) < 1e-5
+    missing = [k for k in names if k not in grads]
+    assert not missing, missing
+    assert all(bool(torch.isfinite(g).all()) for g in grads.values())
+    assert sum(float(g.abs().sum()) > 0 for g in grads.values()) > 0.95 * len(grads)
+    # absent modalities (sample 0: t1, sample 1: flair) carry arbitrary data: nothing may change, forward or backward
+    x2 = x.clone()
+    x2[0, 2] = torch.randn_like(x2[0, 2]) * 40 - 3
+    x2[1, 0] = 77.0
+    outs2, loss2, grads2 = step(x2)
+    assert all(torch.equal(a, b) for a, b in zip(outs, outs2)) and torch.equal(loss, loss2)
+    assert all(torch.equal(grads[k], grads2[k]) for k in grads)
+    # twice the loss -> twice the gradients (to bf16 / fixed-point rounding on the bulk of every checked tensor)
+    _, _, g2x = step(x, scale=2.0)
+    for k in ("flair_encoder.e1_c1.conv.weight", "decoder_fuse.RFM1.region_fusion.fusion_layer.0.conv.weight", "decoder_sep.d1_c2.conv.weight",
+              "decoder_fuse.prm_generator1.prm_layer.1.weight"):
+        r = float((g2x[k] - 2 * grads[k]).abs().mean()) / float((2 * grads[k]).abs().mean())
+        assert r < 5e-2, (k, r)
+    # teacher == plain forward
+    outs_p, _, _ = step(x, passion=False)
+    d = (outs_p[0] - outs[0]).abs()
+    print(f"RFNet 128^3 b2: PASSION teacher vs plain forward max |dp| {float(d.max()):.2e}, mean {float(d.mean()):.2e}; loss {float(loss):.4f}")
+    assert float(d.mean()) < MEAN_TOL and float(d.max()) < MAX_TOL
+    for u, v in zip(outs_p[1:], outs[1:3]):
+        assert torch.allclose(u, v, rtol=2e-2, atol=1e-4)
+    # the optimizer step of train.py:95-96 on these gradients
+    step(x)
+    before = {k: p.detach().clone() for k, p in m.named_parameters()}
+    opt = ptrain.make_optimizer(m)
+    opt.step()
+    torch.cuda.synchronize()
+    moved = sum(not torch.equal(before[k], p.detach()) for k, p in m.named_parameters())
+    assert moved > 0.95 * len(before), (moved, len(before))
+    assert all(bool(torch.isfinite(p).all()) for p in m.parameters())

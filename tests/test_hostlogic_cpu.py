@@ -88,3 +88,34 @@ def test_dropout_hash_statistics():
     keep2, _ = flash_keep_mask(1, 1024, 0.1, 0x123456789abcdf0)
     k2 = keep2.float().reshape(-1, 1024)
     assert abs(float(((k2 - k2.mean()) * kc).mean() / kc.var())) < 5e-3
+
+
+def test_last_global_batch_is_wrap_padded_like_a_dataloader_without_drop_last():
+    """reference train.py:122-128: DataLoader(shuffle=True) without drop_last -> ceil(N / batch) iterations per epoch"""
+    from passion_amd import train as ptrain
+    n, world, bs = 219, 8, 1
+    iters = -(-n // (bs * world))            # 28
+    rows = [ptrain.epoch_order(n, 0, 1037, world, r, bs, iters) for r in range(world)]
+    assert all(o.shape == (iters, bs) for o in rows)
+    flat = np.concatenate([o.reshape(-1) for o in rows])
+    assert set(flat.tolist()) == set(range(n))                               # every subject is seen
+    assert len(flat) == iters * world and len(flat) - n == 5                 # 5 wrap-around subjects fill the last global batch
+
+
+def test_loss_state_round_trips_through_a_weights_only_checkpoint(tmp_path):
+    """a resumed PASSION run must continue with the imb_beta / eta / modal_weight of the interrupted one"""
+    from passion_amd import train as ptrain
+    st = ptrain.LossState(torch.device("cpu"), modal_weight=torch.tensor([2.43, 1.62, 1.19, 5.09]))
+    st.epoch_dist_m += torch.tensor([0.4, 0.1, 0.3, 0.2])
+    st.end_epoch(100)                        # moves imb_beta, and eta (epoch % 100 == 0)
+    assert abs(st.eta - 0.015) < 1e-12 and not torch.allclose(st.imb_beta, torch.ones(4))
+    path = str(tmp_path / "ck.pth")
+    torch.save({"epoch": 100, "loss_state": st.state_dict()}, path)
+    ck = torch.load(path, map_location="cpu", weights_only=True)
+    st2 = ptrain.LossState(torch.device("cpu"))
+    st2.load_state_dict(ck["loss_state"])
+    assert torch.equal(st2.imb_beta, st.imb_beta) and torch.equal(st2.modal_weight, st.modal_weight) and st2.eta == st.eta
+    for s_ in (st, st2):
+        s_.epoch_dist_m += torch.tensor([0.2, 0.3, 0.1, 0.4])
+        s_.end_epoch(101)
+    assert torch.equal(st2.imb_beta, st.imb_beta)

@@ -101,3 +101,23 @@ def test_full_model_seeded_construction_matches_reference():
     gn = grad_norms((k, v.grad) for k, v in P.items())
     for k, ref in zip(g["grad_keys"], g["grad_norms"]):
         assert abs(gn[str(k)] - ref) < 5e-4 * ref + 1e-7, (k, gn[str(k)], ref)
+
+
+def test_oracle_follows_the_reference_training_trajectory():
+    """multi-step pin (tools/make_golden_traj.py: the imported reference took K AdamW(amsgrad) steps, train.py:95-96,228-289):
+    the oracle's forward + loss assembly + torch AdamW reproduce the loss of the first steps of the 32^3 PASSION trajectory"""
+    from _util import signal_volume
+    g = gold("traj_passion_32.npz")
+    S, steps = int(g["S"]), 6
+    m = build_product_model(S, small=False)
+    P = {k: v.detach().clone().requires_grad_(True) for k, v in m.state_dict().items()}
+    opt = torch.optim.AdamW([{"params": list(P.values()), "lr": float(g["lr"]), "weight_decay": 1e-4}], betas=(0.9, 0.999), eps=1e-08,
+                            amsgrad=True)
+    x, target = signal_volume(S, g["means"])
+    mask = _t(g["mask"])
+    for it in range(steps + 1):
+        loss, outs, _ = train_step_ref.train_step(P, x, mask, target, 4.0, "idt", bool(g["passion"]))
+        assert abs(float(loss.detach()) - g["losses"][it]) < 2e-4 * abs(g["losses"][it]), (it, float(loss.detach()), g["losses"][it])
+        opt.zero_grad()
+        loss.backward()
+        opt.step()

@@ -84,6 +84,10 @@ def main():
     rec = {"S": S, "K": K, "passion": passion, "lr": LR, "mask": mask.numpy(), "means": np.array(MEANS, np.float32),
            "losses": np.array(losses), "accs": np.array(accs), "argmax_packed": pack2(am),
            "close_idx": np.nonzero((margin < 1e-3).numpy())[0].astype(np.int32), "margin_min": float(margin.min()),
+           # K steps amplify rounding differences of the trajectory itself (two f32 runs of different kernels drift ~1e-4 in the
+           # weights): voxels the reference decides by less than 2e-2 / 1e-1 may legitimately flip
+           "close2_idx": np.nonzero((margin < 2e-2).numpy())[0].astype(np.int32),
+           "close3_idx": np.nonzero((margin < 1e-1).numpy())[0].astype(np.int32),
            "frac_margin_lt_1e2": float((margin < 1e-2).float().mean()),
            "pred_slice": pred[:, :, S // 2].numpy(), "pred_sum": pred.double().sum((2, 3, 4)).numpy(),
            "label_packed": pack2(lab.reshape(-1).numpy())}
