@@ -1,0 +1,64 @@
+"""CPU: pin oracle/m2ftrans_ref.py against the fixtures the imported reference m2ftrans.Model produced
+(tools/make_golden_m2f.py): outputs, the five loss tensors, the assembled loss, rp_mask, gradient norms, gradient tensors.
+
+Gradient tolerances: this random-init post-norm network amplifies f32 rounding -- the REFERENCE ITSELF, run with 1 instead of 8
+CPU threads (other summation orders, same code), moves its module gradient norms by up to 1.6e-4 and single gradient tensors by up
+to 3.5e-3 of their maximum (measured in the build container, PASSION steps idt 1011 / pdt 1101).  The forward is held to 2e-5."""
+GN_TOL, G_TOL = 1e-3, 1e-2
+import numpy as np
+import pytest
+import torch
+
+from _util import gold, grad_norms, rel, synth
+from oracle import m2ftrans_ref, train_step_ref
+
+TAGS = ["idt_passion_1011", "idt_passion_b2", "idt_plain_1111", "pdt_passion_1101"]
+
+
+def m2f_weights():
+    w = gold("weights_m2f.npz")
+    return {k: torch.from_numpy(w[k].astype(np.float32)) for k in w.files}
+
+
+def run_oracle(g, P):
+    S, B = int(g["S"]), int(g["B"])
+    x, target = synth(B, S, blobs=bool(g["blobs"]))
+    mask = torch.from_numpy(g["mask"])
+    passion, mask_type = bool(g["passion"]), str(g["mask_type"])
+    P = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    outs = m2ftrans_ref.forward(P, x, mask, target, float(g["temp"]), mask_type, passion, True, 0.0)
+    loss, parts = train_step_ref.assemble_loss(outs, target, mask, mask_type, passion)
+    return P, loss, outs, parts
+
+
+@pytest.mark.parametrize("tag", TAGS)
+def test_m2ftrans_oracle_matches_reference(tag):
+    g = gold(f"m2ftrans_{tag}.npz")
+    P, loss, outs, parts = run_oracle(g, m2f_weights())
+    S = int(g["S"])
+    assert rel(outs[0][:, :, S // 2], g["pred_slice"]) < 2e-5
+    assert rel(outs[0].double().sum((2, 3, 4)), g["pred_sum"]) < 2e-5
+    assert (outs[0].argmax(1).numpy().astype(np.uint8) == g["argmax"]).mean() > 0.9999
+    for n, o in zip(["prm_loss", "sep_loss", "kl_loss", "proto_loss", "dist"], outs[1:]):
+        assert rel(o, g[n]) < 2e-5, n
+    assert abs(float(loss.detach()) - float(g["loss"])) < 1e-4 * abs(float(g["loss"]))
+    if "rp_mask" in g.files:
+        assert np.array_equal(parts["rp_mask"].numpy(), g["rp_mask"])
+    loss.backward()
+    gn = grad_norms((k, v.grad) for k, v in P.items())
+    for k, ref in zip(g["grad_keys"], g["grad_norms"]):
+        assert abs(gn[str(k)] - ref) < GN_TOL * ref + 1e-7, (k, gn[str(k)], ref)
+    for key in g.files:
+        if key.startswith("grad::"):
+            if np.abs(g[key]).max() < 1e-6:
+                assert P[key[6:]].grad is None or P[key[6:]].grad.abs().max() < 1e-6
+                continue
+            assert rel(P[key[6:]].grad, g[key]) < G_TOL, key
+
+
+def test_m2ftrans_state_dict_layout():
+    """801 keys at the reference's full constants; the fixture weights carry the small-constants layout with the same names"""
+    w = m2f_weights()
+    assert len(w) == 801 and w["pos"].shape == (1, 40, 64) and w["fusion"].shape == (1, 8, 64)
+    assert w["decoder_fusion.CT5.layers.0.ffn1.dwconv.weight"].shape == (256, 4, 3, 3, 3)
+    assert w["decoder_fusion.CT4.layers.1.cross_attn.key_map_t2.conv2.weight"].shape == (32, 1, 3, 3, 3)
