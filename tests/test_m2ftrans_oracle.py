@@ -3,8 +3,9 @@
 
 Gradient tolerances: this random-init post-norm network amplifies f32 rounding -- the REFERENCE ITSELF, run with 1 instead of 8
 CPU threads (other summation orders, same code), moves its module gradient norms by up to 1.6e-4 and single gradient tensors by up
-to 3.5e-3 of their maximum (measured in the build container, PASSION steps idt 1011 / pdt 1101).  The forward is held to 2e-5."""
-GN_TOL, G_TOL = 1e-3, 1e-2
+to 3.5e-3 of their maximum (measured in the build container, PASSION steps idt 1011 / pdt 1101); this oracle run with 8 / 4 / 1
+threads lands 1.2e-3 / 1e-6 / 0 away from the fixture's t2_encoder norm.  The forward is held to 2e-5."""
+GN_TOL, G_TOL = 3e-3, 2e-2
 import numpy as np
 import pytest
 import torch
