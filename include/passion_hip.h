@@ -244,6 +244,29 @@ int passion_flash_attn_fwd(const void* qkv, int B, int N, int H, int Dh, float s
 int passion_flash_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse, int B, int N, int H, int Dh,
                            float scale, float drop_p, uint64_t seed, float* delta, void* dqkv, void* stream);
 
+/* ---- m2ftrans backbone (reference code/models/m2ftrans.py, code/models/blocks.py:25-297, code/models/mask.py) ----
+ * gconv3d: grouped 3x3x3 Conv3d with C input = C output channels in groups of `cpg` (1: DepthWiseConvBlock.conv2, blocks.py:45-47,
+ * nn.Conv3d(C, C, 3, 1, 1, groups=C); 4: GroupConvBlock.dwconv, blocks.py:77-79, groups = C / 4), zero padding, stride 1.
+ * x, y, dy, dx: channels-last [B][D][H][W][C] in `dtype`; weight: the reference layout [C][cpg][3][3][3] f32; bias [C] f32 or NULL.
+ * bwd: dx / (dweight [C][cpg][27], dbias [C]) may be NULL; fixed-order sums (bitwise reproducible). */
+int passion_gconv3d_fwd(const void* x, const float* weight, const float* bias, void* y, int dtype, int B, int D, int H, int W, int C,
+                        int cpg, void* stream);
+int passion_gconv3d_bwd(const void* x, const float* weight, const void* dy, void* dx, float* dweight, float* dbias, int dtype, int B,
+                        int D, int H, int W, int C, int cpg, void* stream);
+/* Weight_Attention (m2ftrans.py:420-460): y[b][v][:] = x[b % Bx][v][:] * w[b][v >> k] -- a [Bx][D][H][W][C] feature map scaled by the
+ * nearest-upsampled (x 2^k per axis) weight maps w [Bv][D >> k][H >> k][W >> k] f32 of Bv / Bx masked passes (teacher + students)
+ * in one launch.  bwd: dx[bx] = sum over the passes of dy * w (w carries no gradient: the attention maps are detached, :380). */
+int passion_scale_nearest_fwd(const void* x, const float* w, void* y, int dtype, int Bv, int Bx, int D, int H, int W, int C, int k,
+                              void* stream);
+int passion_scale_nearest_bwd(const void* dy, const float* w, void* dx, int dtype, int Bv, int Bx, int D, int H, int W, int C, int k,
+                              void* stream);
+/* MaskedAttention (m2ftrans.py:318-351): passion_attn_scores_fwd with the block mask of mask_gen_fusion (mask.py:5-22) applied
+ * before the row softmax (masked_fill(-inf)): the N tokens form G groups of N / G; query group i may look at key group j iff
+ * allow[b][i][j] != 0 (allow: [B][G][G] bytes).  Masked probabilities are exactly 0, so passion_attn_pv_* / passion_attn_scores_bwd
+ * apply unchanged. */
+int passion_attn_scores_masked_fwd(const void* qkv, int dtype, int B, int N, int H, int Dh, float scale, const uint8_t* allow, int G,
+                                   float* probs, void* stream);
+
 /* Attention dropout (nn.Dropout on the attention probabilities, code/models/mmformer.py:222) in one pass and without a
  * stored mask: y[i] = keep(i) ? x[i] / (1 - p) : 0 with keep(i) ~ Bernoulli(1 - p) drawn from a counter-based hash of
  * (seed, i).  The same (seed, p) reproduces the mask, which is how the backward applies it to dprobs.  y may alias x. */

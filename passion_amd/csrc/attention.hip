@@ -288,8 +288,35 @@ __global__ __launch_bounds__(256) void row_softmax_bwd_kernel(const float* __res
     for (int i = lane; i < n; i += 64) g[i] = scale * p[i] * (g[i] - dot);
 }
 
+// in-place softmax of row (b, h, q) of scores [B][H][N][N] over the keys the block mask allows: allow[b][q / n][key / n], n = N / G
+__global__ __launch_bounds__(256) void masked_softmax_kernel(float* __restrict__ s, const uint8_t* __restrict__ allow, long rows, int N,
+                                                             int H, int G) {
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const int q = (int)(row % N);
+    const int b = (int)(row / ((long)N * H));
+    const int n = N / G;
+    const uint8_t* al = allow + ((long)b * G + q / n) * G;
+    float* r = s + row * N;
+    float m = -INFINITY;
+    for (int i = lane; i < N; i += 64) if (al[i / n]) m = fmaxf(m, r[i]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    float sum = 0.f;
+    for (int i = lane; i < N; i += 64) {
+        const float e = al[i / n] ? expf(r[i] - m) : 0.f;
+        r[i] = e;
+        sum += e;
+    }
+    sum = wave_sum(sum);
+    const float inv = 1.f / sum;
+    for (int i = lane; i < N; i += 64) r[i] *= inv;
+}
+
 template <typename T>
-int attn_scores(const void* qkv, int B, int N, int H, int Dh, float scale, float* probs, hipStream_t st) {
+int attn_scores(const void* qkv, int B, int N, int H, int Dh, float scale, float* probs, hipStream_t st, const uint8_t* allow = nullptr,
+                int G = 0) {
     const long rs = 3L * H * Dh;
     GemmP p;
     p.A = qkv; p.Bm = reinterpret_cast<const T*>(qkv) + (long)H * Dh; p.C = probs;
@@ -301,7 +328,8 @@ int attn_scores(const void* qkv, int B, int N, int H, int Dh, float scale, float
     if (rc) return rc;
     const long rows = (long)B * H * N;
     const dim3 grid((unsigned)((rows + 3) / 4));
-    if (N == 2048) hipLaunchKernelGGL(row_softmax_reg_kernel<8>, grid, dim3(256), 0, st, probs, rows);
+    if (allow) hipLaunchKernelGGL(masked_softmax_kernel, grid, dim3(256), 0, st, probs, allow, rows, N, H, G);
+    else if (N == 2048) hipLaunchKernelGGL(row_softmax_reg_kernel<8>, grid, dim3(256), 0, st, probs, rows);
     else if (N == 1024) hipLaunchKernelGGL(row_softmax_reg_kernel<4>, grid, dim3(256), 0, st, probs, rows);
     else if (N == 512) hipLaunchKernelGGL(row_softmax_reg_kernel<2>, grid, dim3(256), 0, st, probs, rows);
     else if (N == 256) hipLaunchKernelGGL(row_softmax_reg_kernel<1>, grid, dim3(256), 0, st, probs, rows);
@@ -377,6 +405,13 @@ extern "C" int passion_attn_scores_fwd(const void* qkv, int dtype, int B, int N,
                                        void* stream) {
     if (dtype == PASSION_F32) return attn_scores<float>(qkv, B, N, H, Dh, scale, probs, (hipStream_t)stream);
     if (dtype == PASSION_BF16) return attn_scores<bf16_t>(qkv, B, N, H, Dh, scale, probs, (hipStream_t)stream);
+    return -1007;
+}
+extern "C" int passion_attn_scores_masked_fwd(const void* qkv, int dtype, int B, int N, int H, int Dh, float scale, const uint8_t* allow, int G,
+                                              float* probs, void* stream) {
+    if (!allow || G <= 0 || N % G) return -1003;
+    if (dtype == PASSION_F32) return attn_scores<float>(qkv, B, N, H, Dh, scale, probs, (hipStream_t)stream, allow, G);
+    if (dtype == PASSION_BF16) return attn_scores<bf16_t>(qkv, B, N, H, Dh, scale, probs, (hipStream_t)stream, allow, G);
     return -1007;
 }
 extern "C" int passion_attn_pv_fwd(const float* probs, const void* qkv, int dtype, int B, int N, int H, int Dh, void* out,

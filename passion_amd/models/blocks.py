@@ -320,3 +320,141 @@ class region_aware_modal_fusion(nn.Module):
                          for i in range(self.num_cls)], 1)        # (B, region, modality)
         R = ops.region_mix(prm, msk, w, ys)
         return [self.region_fusion(Feat(R)), _chain(self.short_cut, x)]
+
+
+# ------------------------------------------------------------------------------------------------
+# m2ftrans blocks: cross-token channel attention on the 8^3 / 16^3 token volumes
+# ------------------------------------------------------------------------------------------------
+def _bf16(t):
+    return t.dtype == torch.bfloat16
+
+
+def _pw(conv, x):
+    """1x1x1 nn.Conv3d on a channels-last tensor = a token GEMM (hipBLASLt through ops.linear, bf16 operand images kept)"""
+    return ops.linear(x, conv.weight, conv.bias, _bf16(x))
+
+
+def _ln(norm, x):
+    return torch.nn.functional.layer_norm(x, (x.shape[-1],), norm.weight, norm.bias, norm.eps)
+
+
+class DepthWiseConvBlock(nn.Module):
+    """1x1 -> LN -> GELU -> depthwise 3x3x3 -> LN -> GELU -> 1x1 -> LN (reference blocks.py:32-63) on (B,D,H,W,C) tensors"""
+
+    def __init__(self, in_channels, out_channels):
+        super().__init__()
+        mid = in_channels
+        self.conv1 = nn.Conv3d(in_channels, mid, 1, 1)
+        self.norm1 = nn.LayerNorm(mid, eps=1e-6)
+        self.act1 = nn.GELU()
+        self.conv2 = nn.Conv3d(mid, mid, 3, 1, 1, groups=mid)
+        self.norm2 = nn.LayerNorm(mid, eps=1e-6)
+        self.act2 = nn.GELU()
+        self.conv3 = nn.Conv3d(mid, out_channels, 1, 1)
+        self.norm3 = nn.LayerNorm(out_channels, eps=1e-6)
+
+    def forward(self, x):
+        gelu = torch.nn.functional.gelu
+        x = gelu(_ln(self.norm1, _pw(self.conv1, x)))
+        x = gelu(_ln(self.norm2, ops.group_conv3d(x, self.conv2.weight, self.conv2.bias)))
+        return _ln(self.norm3, _pw(self.conv3, x))
+
+
+class GroupConvBlock(nn.Module):
+    """reference blocks.py:65-109: 1x1 expand -> LN -> GELU -> grouped 3x3x3 (groups = embed_dims) -> LN -> GELU -> 1x1 -> LN,
+    residual, GELU"""
+
+    def __init__(self, embed_dims=8, expand_ratio=4, proj_drop=0.):
+        super().__init__()
+        self.pwconv1 = nn.Conv3d(embed_dims, embed_dims * expand_ratio, 1, 1)
+        self.norm1 = nn.LayerNorm(embed_dims * expand_ratio, eps=1e-6)
+        self.act1 = nn.GELU()
+        self.dwconv = nn.Conv3d(embed_dims * expand_ratio, embed_dims * expand_ratio, 3, 1, 1, groups=embed_dims)
+        self.norm2 = nn.LayerNorm(embed_dims * expand_ratio, eps=1e-6)
+        self.act2 = nn.GELU()
+        self.pwconv2 = nn.Conv3d(embed_dims * expand_ratio, embed_dims, 1, 1)
+        self.norm3 = nn.LayerNorm(embed_dims, eps=1e-6)
+        self.final_act = nn.GELU()
+        self.proj_drop = nn.Dropout(proj_drop)
+
+    def forward(self, x, identity=None):
+        gelu = torch.nn.functional.gelu
+        h = gelu(_ln(self.norm1, _pw(self.pwconv1, x)))
+        h = gelu(_ln(self.norm2, ops.group_conv3d(h, self.dwconv.weight, self.dwconv.bias)))
+        h = _ln(self.norm3, _pw(self.pwconv2, h))
+        return gelu((x if identity is None else identity) + self.proj_drop(h))
+
+
+class MultiMaskAttentionLayer(nn.Module):
+    """channel attention of a query volume over the channels of the four modality volumes, absent modalities masked out
+    (reference blocks.py:246-297, mask_gen_cross4 of mask.py:25-36)"""
+
+    def __init__(self, kv_dim=8, query_dim=4, attn_drop=0., proj_drop=0.):
+        super().__init__()
+        self.attn_drop = nn.Dropout(attn_drop)
+        self.query_map = DepthWiseConvBlock(query_dim, query_dim)
+        for m in ("flair", "t1ce", "t1", "t2"):
+            setattr(self, f"key_map_{m}", DepthWiseConvBlock(kv_dim, kv_dim))
+            setattr(self, f"value_map_{m}", DepthWiseConvBlock(kv_dim, kv_dim))
+        self.out_project = DepthWiseConvBlock(query_dim, query_dim)
+        self.proj_drop = nn.Dropout(proj_drop)
+
+    def forward(self, query, key, value, mask):
+        """query (B,D,H,W,Cq); key = value = the four (B,D,H,W,C) volumes; mask (B,4) bool"""
+        B = query.shape[0]
+        L_ = query.shape[1] * query.shape[2] * query.shape[3]
+        mods = ("flair", "t1ce", "t1", "t2")
+        q = self.query_map(query).reshape(B, L_, -1)
+        k = torch.cat([getattr(self, f"key_map_{m}")(f).reshape(B, L_, -1) for m, f in zip(mods, key)], 2)       # (B, L, 4C)
+        v = torch.cat([getattr(self, f"value_map_{m}")(f).reshape(B, L_, -1) for m, f in zip(mods, value)], 2)
+        att = torch.bmm(q.transpose(1, 2), k).float() * L_ ** -0.5                                                # (B, Cq, 4C)
+        keep = mask.repeat_interleave(k.shape[2] // 4, dim=1).unsqueeze(1)
+        att = self.attn_drop(att.masked_fill(~keep, float("-inf")).softmax(-1)).to(v.dtype)
+        x = torch.bmm(v, att.transpose(1, 2)).reshape(query.shape)                                                 # (B, L, Cq)
+        return query + self.proj_drop(self.out_project(x))
+
+
+class MultiMaskCrossBlock(nn.Module):
+    """reference blocks.py:206-244"""
+
+    def __init__(self, feature_channels=128, num_classes=128, expand_ratio=4, drop_rate=0., attn_drop_rate=0., ffn_feature_maps=True):
+        super().__init__()
+        self.ffn_feature_maps = ffn_feature_maps
+        self.cross_attn = MultiMaskAttentionLayer(kv_dim=feature_channels, query_dim=num_classes, attn_drop=attn_drop_rate,
+                                                  proj_drop=drop_rate)
+        if ffn_feature_maps:
+            self.ffn2 = GroupConvBlock(embed_dims=feature_channels, expand_ratio=expand_ratio)
+        self.ffn1 = GroupConvBlock(embed_dims=num_classes, expand_ratio=expand_ratio)
+
+    def forward(self, kernels, feature_maps, mask):
+        kernels = self.cross_attn(query=kernels, key=feature_maps, value=feature_maps, mask=mask)
+        kernels = self.ffn1(kernels, identity=kernels)
+        if self.ffn_feature_maps:
+            feature_maps = tuple(self.ffn2(f, identity=f) for f in feature_maps)
+        return kernels, feature_maps
+
+
+class fusion_postnorm(nn.Module):
+    """masked concat of the four modality features -> 1x1 -> 3x3x3 -> 1x1 post-norm convs (reference blocks.py:567-580)"""
+
+    def __init__(self, in_channel=64, num_cls=4):
+        super().__init__()
+        self.fusion_layer = nn.Sequential(general_conv3d(in_channel * num_cls, in_channel, k_size=1, padding=0, stride=1),
+                                          general_conv3d(in_channel, in_channel, k_size=3, padding=1, stride=1),
+                                          general_conv3d(in_channel, in_channel, k_size=1, padding=0, stride=1))
+
+    def forward(self, x, mask=None):
+        """x: the four modality Feats carrying (mask, column)"""
+        return _chain(self.fusion_layer, x)
+
+
+class prm_fusion_pk(nn.Module):
+    """reference blocks.py:481-493 -> logits (channels-last f32)"""
+
+    def __init__(self, in_channel=64, norm="in", num_cls=4):
+        super().__init__()
+        self.prm_layer = nn.Sequential(general_conv3d(in_channel, 16, k_size=1, stride=1, padding=0),
+                                       nn.Conv3d(16, num_cls, kernel_size=1, padding=0, stride=1, bias=True))
+
+    def forward(self, x1):
+        return _chain(self.prm_layer, x1).t

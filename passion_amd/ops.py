@@ -933,6 +933,133 @@ class AttentionFn(torch.autograd.Function):
         return dqkv, None, None, None
 
 
+class MaskedAttentionFn(torch.autograd.Function):
+    """MaskedAttention core of the m2ftrans bottleneck (reference m2ftrans.py:336-349): softmax over the keys the block mask
+    allows (mask.py:5-22), attention dropout, @ v.  qkv (B,N,3,H,Dh), allow (B,G,G) uint8 over G groups of N / G tokens.
+    -> (out (B,N,H*Dh), attn (B,H,N,N) f32 = the probabilities AFTER dropout, which the reference hands on detached (:380))."""
+
+    @staticmethod
+    def forward(ctx, qkv, allow, heads, scale, drop_p):
+        L.require_gpu(qkv, allow)
+        qkv = qkv.contiguous()
+        allow = allow.contiguous()
+        B, N, C3 = qkv.shape
+        Dh = C3 // 3 // heads
+        G = allow.shape[1]
+        assert allow.dtype == torch.uint8 and allow.shape == (B, G, G) and N % G == 0
+        lib = L.load()
+        dt = L.dtype_code(qkv.dtype)
+        probs = torch.empty(B, heads, N, N, dtype=torch.float32, device=qkv.device)
+        L.check(lib.passion_attn_scores_masked_fwd(_p(qkv), dt, B, N, heads, Dh, float(scale), _p(allow), G, _p(probs), L.stream_ptr()),
+                "passion_attn_scores_masked_fwd")
+        pd, seed = probs, 0
+        if drop_p > 0.0:
+            seed = _draw_seed()
+            pd = torch.empty_like(probs)
+            L.check(lib.passion_dropout(_p(probs), _p(pd), probs.numel(), float(drop_p), seed, L.stream_ptr()), "passion_dropout")
+        out = torch.empty(B, N, heads * Dh, dtype=qkv.dtype, device=qkv.device)
+        L.check(lib.passion_attn_pv_fwd(_p(pd), _p(qkv), dt, B, N, heads, Dh, _p(out), L.stream_ptr()), "passion_attn_pv_fwd")
+        ctx.heads, ctx.scale, ctx.drop_p, ctx.seed = heads, float(scale), drop_p, seed
+        ctx.save_for_backward(qkv, probs, pd if drop_p > 0.0 else None)
+        ctx.mark_non_differentiable(pd)
+        return out, pd
+
+    @staticmethod
+    def backward(ctx, dout, _dattn):
+        qkv, probs, pd = ctx.saved_tensors
+        B, N, C3 = qkv.shape
+        H = ctx.heads
+        Dh = C3 // 3 // H
+        lib = L.load()
+        dt = L.dtype_code(qkv.dtype)
+        dout = dout.contiguous()
+        dqkv = torch.empty_like(qkv)
+        dprobs = torch.empty_like(probs)
+        L.check(lib.passion_attn_pv_bwd(_p(pd if pd is not None else probs), _p(qkv), _p(dout), dt, B, N, H, Dh, _p(dprobs), _p(dqkv),
+                                        L.stream_ptr()), "passion_attn_pv_bwd")
+        if pd is not None:
+            L.check(lib.passion_dropout(_p(dprobs), _p(dprobs), dprobs.numel(), float(ctx.drop_p), ctx.seed, L.stream_ptr()),
+                    "passion_dropout")
+        L.check(lib.passion_attn_scores_bwd(_p(probs), _p(dprobs), _p(qkv), dt, B, N, H, Dh, ctx.scale, _p(dqkv), L.stream_ptr()),
+                "passion_attn_scores_bwd")
+        return dqkv, None, None, None, None
+
+
+def masked_attention(qkv, allow, heads, scale, drop_p=0.0):
+    return MaskedAttentionFn.apply(qkv, allow, heads, scale, drop_p)
+
+
+class GroupConvFn(torch.autograd.Function):
+    """grouped 3x3x3 Conv3d (zero padding, stride 1, in = out channels, `cpg` channels per group) on channels-last tensors:
+    DepthWiseConvBlock.conv2 / GroupConvBlock.dwconv of the m2ftrans cross-token blocks (reference blocks.py:45-47, 77-79)"""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        L.require_gpu(x, weight)
+        x = x.contiguous()
+        B, D, H, W, C = x.shape
+        cpg = weight.shape[1]
+        assert weight.shape == (C, cpg, 3, 3, 3) and weight.dtype == torch.float32
+        w = weight.detach().contiguous()
+        b32 = bias.detach().float().contiguous() if bias is not None else None
+        y = torch.empty_like(x)
+        L.check(L.load().passion_gconv3d_fwd(_p(x), _p(w), _p(b32), _p(y), L.dtype_code(x.dtype), B, D, H, W, C, cpg, L.stream_ptr()),
+                "passion_gconv3d_fwd")
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        B, D, H, W, C = x.shape
+        cpg = w.shape[1]
+        dy = dy.contiguous()
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        dw = torch.empty_like(w) if ctx.needs_input_grad[1] else None
+        db = torch.empty(C, dtype=torch.float32, device=x.device) if (ctx.has_bias and ctx.needs_input_grad[2] and dw is not None) else None
+        L.check(L.load().passion_gconv3d_bwd(_p(x), _p(w), _p(dy), _p(dx), _p(dw), _p(db), L.dtype_code(x.dtype), B, D, H, W, C, cpg,
+                                             L.stream_ptr()), "passion_gconv3d_bwd")
+        return dx, dw, db
+
+
+def group_conv3d(x, weight, bias):
+    return GroupConvFn.apply(x, weight, bias)
+
+
+class ScaleNearestFn(torch.autograd.Function):
+    """y[b] = x[b % Bx] * nearest_upsample(w[b], 2^k): Weight_Attention of m2ftrans (reference m2ftrans.py:443-458); x (Bx,D,H,W,C),
+    w (Bv, D >> k, H >> k, W >> k) f32 without gradient (the attention maps are detached), Bv / Bx masked passes in one launch"""
+
+    @staticmethod
+    def forward(ctx, x, w, k):
+        L.require_gpu(x, w)
+        x, w = x.contiguous(), w.contiguous().float()
+        Bx, D, H, W, C = x.shape
+        Bv = w.shape[0]
+        assert Bv % Bx == 0 and w.shape[1:] == (D >> k, H >> k, W >> k)
+        y = torch.empty(Bv, D, H, W, C, dtype=x.dtype, device=x.device)
+        L.check(L.load().passion_scale_nearest_fwd(_p(x), _p(w), _p(y), L.dtype_code(x.dtype), Bv, Bx, D, H, W, C, k, L.stream_ptr()),
+                "passion_scale_nearest_fwd")
+        ctx.k, ctx.shape = k, x.shape
+        ctx.save_for_backward(w)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (w,) = ctx.saved_tensors
+        Bx, D, H, W, C = ctx.shape
+        dy = dy.contiguous()
+        dx = torch.empty(ctx.shape, dtype=dy.dtype, device=dy.device)
+        L.check(L.load().passion_scale_nearest_bwd(_p(dy), _p(w), _p(dx), L.dtype_code(dy.dtype), w.shape[0], Bx, D, H, W, C, ctx.k,
+                                                   L.stream_ptr()), "passion_scale_nearest_bwd")
+        return dx, None, None
+
+
+def scale_nearest(x, w, k):
+    return ScaleNearestFn.apply(x, w.detach(), k)
+
+
 FLASH = True      # A/B switch (tests compare the two paths)
 
 

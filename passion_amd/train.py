@@ -194,8 +194,12 @@ def main(argv=None):
     elif args.model == "rfnet":
         from .models import rfnet
         model = rfnet.Model(num_cls=4).to(ctx.device)
+    elif args.model == "m2ftrans":
+        from .models import m2ftrans
+        m2ftrans.patch_size = args.patch // 16
+        model = m2ftrans.Model(num_cls=4).to(ctx.device)
     else:
-        raise SystemExit("m2ftrans is out of this build's scope (SURVEY.md 2.1 row 7)")
+        raise SystemExit(f"unknown --model {args.model!r} (mmformer, rfnet, m2ftrans)")
     model.mask_type, model.use_passion = args.mask_type, args.use_passion
     model.compute_dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     model.train()

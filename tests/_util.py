@@ -189,3 +189,30 @@ def synth_box(B, shape, seed=7):
     lab[:, r < 0.25] = 1
     lab[:, r < 0.12] = 3
     return x, F.one_hot(lab, 4).permute(0, 4, 1, 2, 3).double()
+
+
+M2F_SMALL = dict(basic_dims=4, mlp_dim=128)
+M2F_FULL = dict(basic_dims=8, mlp_dim=4096)
+
+
+def build_m2ftrans(S, small=True, seed=1037):
+    """product m2ftrans.Model built like tools/make_golden_m2f.py builds the reference one (seed 1037, pos from seed 1038);
+    small=True: the small-constants layout + the fixture's weights (strict load)"""
+    from passion_amd.models import m2ftrans
+    keep = {k: getattr(m2ftrans, k) for k in M2F_FULL}
+    keep_ps = m2ftrans.patch_size
+    try:
+        for k, v in (M2F_SMALL if small else M2F_FULL).items():
+            setattr(m2ftrans, k, v)
+        m2ftrans.patch_size = S // 16
+        torch.manual_seed(seed)
+        m = m2ftrans.Model(num_cls=4)
+    finally:
+        for k, v in keep.items():
+            setattr(m2ftrans, k, v)
+        m2ftrans.patch_size = keep_ps
+    g = torch.Generator().manual_seed(seed + 1)
+    with torch.no_grad():
+        m.pos.copy_(torch.randn(m.pos.shape, generator=g) * 0.1)
+    m.eval()
+    return m

@@ -1,0 +1,193 @@
+"""GPU parity of the m2ftrans product path: the three m2ftrans-specific HIP ops against float64 PyTorch CPU
+references, and the whole m2ftrans.Model (f32 mode) against the golden vectors of the imported reference (forward 1e-3; the
+gradient tolerances follow the f32 noise level of this network measured on the reference itself, tests/test_m2ftrans_oracle.py);
+bf16 mode at full constants is held to the f32 run of the same model."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from _util import build_m2ftrans, gold, grad_norms, rel, synth
+from test_m2ftrans_oracle import TAGS
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    return torch.device("cuda:0")
+
+
+def cl(x):
+    return x.permute(0, 2, 3, 4, 1).contiguous()
+
+
+def nc(x):
+    return x.permute(0, 4, 1, 2, 3).contiguous()
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("cpg,C", [(1, 16), (4, 32), (1, 64), (4, 8)])
+def test_group_conv3d(dtype, cpg, C):
+    """DepthWiseConvBlock.conv2 (groups = C) / GroupConvBlock.dwconv (4 channels per group), blocks.py:45-47,77-79"""
+    from passion_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(3)
+    B, D, H, W = 2, 5, 6, 4
+    x = torch.randn(B, C, D, H, W, generator=g).to(dtype).double()
+    w = (torch.randn(C, cpg, 3, 3, 3, generator=g) * 0.3).double()
+    b = torch.randn(C, generator=g).double()
+    gy = torch.randn(B, C, D, H, W, generator=g).to(dtype).double()
+    xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    yr = F.conv3d(xr, wr, br, padding=1, groups=C // cpg)
+    yr.backward(gy)
+    xd = cl(x).to(dev, dtype).requires_grad_(True)
+    wd, bd = w.float().to(dev).requires_grad_(True), b.float().to(dev).requires_grad_(True)
+    y = ops.group_conv3d(xd, wd, bd)
+    y.backward(cl(gy).to(dev, dtype))
+    tol = 1e-5 if dtype == torch.float32 else 2e-2
+    assert rel(nc(y.detach().float()), yr) < tol
+    assert rel(nc(xd.grad.float()), xr.grad) < tol
+    assert rel(wd.grad, wr.grad) < tol and rel(bd.grad, br.grad) < tol
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("C,k,passes", [(8, 2, 1), (4, 1, 3), (16, 3, 5)])
+def test_scale_nearest(dtype, C, k, passes):
+    """Weight_Attention (m2ftrans.py:443-458): x * nearest-upsampled weight map, several passes over the same features"""
+    from passion_amd import ops
+    if dtype == torch.bfloat16 and C % 8:
+        pytest.skip("bf16 tensors carry multiples of 8 channels")
+    dev = _dev()
+    g = torch.Generator().manual_seed(5)
+    Bx, p = 2, 2
+    S = p << k
+    x = torch.randn(Bx, C, S, S, S, generator=g).to(dtype).double()
+    w = torch.rand(passes * Bx, 1, p, p, p, generator=g).double()
+    gy = torch.randn(passes * Bx, C, S, S, S, generator=g).to(dtype).double()
+    xr = x.clone().requires_grad_(True)
+    wu = w
+    for _ in range(k):
+        wu = F.interpolate(wu, scale_factor=2, mode="nearest")
+    yr = xr.repeat(passes, 1, 1, 1, 1) * wu
+    yr.backward(gy)
+    xd = cl(x).to(dev, dtype).requires_grad_(True)
+    y = ops.scale_nearest(xd, w[:, 0].float().to(dev), k)
+    y.backward(cl(gy).to(dev, dtype))
+    tol = 1e-6 if dtype == torch.float32 else 1e-2
+    assert rel(nc(y.detach().float()), yr) < tol
+    assert rel(nc(xd.grad.float()), xr.grad) < tol * 2
+
+
+@pytest.mark.parametrize("dtype,Dh", [(torch.float32, 8), (torch.float32, 16), (torch.bfloat16, 16)])
+def test_masked_attention(dtype, Dh):
+    """MaskedAttention (m2ftrans.py:336-349) under the block mask of mask.py:5-22, 5 groups of n tokens"""
+    from passion_amd import ops
+    from passion_amd.models.m2ftrans import fusion_allow
+    dev = _dev()
+    g = torch.Generator().manual_seed(9)
+    B, Hh, n = 3, 8, 8
+    N = 5 * n
+    C = Hh * Dh
+    qkv = (torch.randn(B, N, 3 * C, generator=g) * 0.7).to(dtype).double()
+    mask = torch.tensor([[True, True, True, True], [False, True, False, True], [False, False, True, False]])
+    go = torch.randn(B, N, C, generator=g).to(dtype).double()
+    qr = qkv.clone().requires_grad_(True)
+    q4 = qr.reshape(B, N, 3, Hh, Dh).permute(2, 0, 3, 1, 4)
+    allow = fusion_allow(mask)
+    am = allow.bool().repeat_interleave(n, 1).repeat_interleave(n, 2)[:, None]
+    att = ((q4[0] @ q4[1].transpose(-2, -1)) * Dh ** -0.5).masked_fill(~am, float("-inf")).softmax(-1)
+    outr = (att @ q4[2]).transpose(1, 2).reshape(B, N, C)
+    outr.backward(go)
+    qd = qkv.to(dev, dtype).requires_grad_(True)
+    out, attn = ops.masked_attention(qd, allow.to(dev), Hh, Dh ** -0.5, 0.0)
+    out.backward(go.to(dev, dtype))
+    tol = 2e-5 if dtype == torch.float32 else 3e-2
+    assert rel(attn, att) < tol and float(attn.cpu()[~am.expand_as(att)].abs().max()) == 0.0
+    assert rel(out.detach().float(), outr) < tol
+    assert rel(qd.grad.float(), qr.grad) < tol * 3
+
+
+def _run(g, dtype):
+    from passion_amd import train as ptrain
+    dev = _dev()
+    S, B = int(g["S"]), int(g["B"])
+    m = build_m2ftrans(S, small=True)
+    from test_m2ftrans_oracle import m2f_weights
+    m.load_state_dict(m2f_weights(), strict=True)
+    m = m.to(dev)
+    m.mask_type, m.use_passion, m.is_training, m.compute_dtype = str(g["mask_type"]), bool(g["passion"]), True, dtype
+    x, target = synth(B, S, blobs=bool(g["blobs"]))
+    mask = torch.from_numpy(g["mask"]).to(dev)
+    x, target = x.to(dev), target.to(dev)
+    outs = m(x, mask, target=target, temp=float(g["temp"]))
+    loss = ptrain.assemble_loss(outs, target, mask, m.mask_type, m.use_passion)
+    loss.backward()
+    torch.cuda.synchronize()
+    return m, outs, loss
+
+
+@pytest.mark.parametrize("tag", TAGS)
+def test_m2ftrans_model_matches_reference_f32(tag):
+    from passion_amd import train as ptrain
+    g = gold(f"m2ftrans_{tag}.npz")
+    m, outs, loss = _run(g, torch.float32)
+    S = int(g["S"])
+    pred = outs[0]
+    assert rel(pred[:, :, S // 2], g["pred_slice"]) < 1e-3
+    assert rel(pred.double().sum((2, 3, 4)), g["pred_sum"]) < 1e-3
+    for n, o in zip(["prm_loss", "sep_loss", "kl_loss", "proto_loss", "dist"], outs[1:]):
+        assert rel(o, g[n]) < 1e-3, (n, o, g[n])
+    assert abs(float(loss) - float(g["loss"])) < 1e-3 * abs(float(g["loss"])), (float(loss), float(g["loss"]))
+    diff = pred.argmax(1).cpu().numpy().astype(np.uint8) != g["argmax"]
+    if diff.any():                                      # only ties of the two best classes may differ
+        top2 = pred.detach().cpu().topk(2, dim=1).values
+        assert float((top2[:, 0] - top2[:, 1])[torch.from_numpy(diff)].max()) < 1e-5
+    if "rp_mask" in g.files:
+        mk = torch.from_numpy(g["mask"]).float().to(pred.device)
+        assert torch.equal(ptrain.relative_preference(outs[5], mk, str(g["mask_type"]) != "pdt").cpu(), torch.from_numpy(g["rp_mask"]))
+    gn = grad_norms((k, p.grad) for k, p in m.named_parameters())
+    worst = 0.0
+    for k, ref in zip(g["grad_keys"], g["grad_norms"]):
+        if ref > 1e-8:
+            worst = max(worst, abs(gn[str(k)] - ref) / ref)
+        assert abs(gn[str(k)] - ref) < 5e-3 * ref + 1e-6, (k, gn[str(k)], ref)
+    params = dict(m.named_parameters())
+    worst_t = 0.0
+    for key in g.files:
+        if key.startswith("grad::") and np.abs(g[key]).max() > 1e-6:
+            e = rel(params[key[6:]].grad, g[key])
+            worst_t = max(worst_t, e)
+            assert e < 3e-2, (key, e)
+    print(f"[m2ftrans {tag} f32] worst module gradient norm error {worst:.2e}, worst gradient tensor error {worst_t:.2e}")
+
+
+def test_m2ftrans_full_dims_bf16_tracks_f32():
+    """full constants (basic_dims 8, mlp 4096, 128-wide bottleneck tokens with 16-wide heads), 64^3, PASSION step with a missing
+    modality: the bf16 storage path against the f32 path of the same model"""
+    from passion_amd import train as ptrain
+    dev = _dev()
+    S = 64
+    res = {}
+    for dtype in (torch.float32, torch.bfloat16):
+        m = build_m2ftrans(S, small=False).to(dev)
+        m.mask_type, m.use_passion, m.is_training, m.compute_dtype = "idt", True, True, dtype
+        x, target = synth(1, S, blobs=True)
+        mask = torch.tensor([[True, False, True, True]], device=dev)
+        outs = m(x.to(dev), mask, target=target.to(dev), temp=4.0)
+        loss = ptrain.assemble_loss(outs, target.to(dev), mask, "idt", True)
+        loss.backward()
+        torch.cuda.synchronize()
+        res[dtype] = ([o.detach().float().cpu() for o in outs], float(loss), grad_norms((k, p.grad) for k, p in m.named_parameters()))
+        assert all(bool(torch.isfinite(p.grad).all()) for p in m.parameters() if p.grad is not None)
+    (o32, l32, g32), (o16, l16, g16) = res[torch.float32], res[torch.bfloat16]
+    assert len(o32) == 6 and o32[0].shape == (1, 4, S, S, S)
+    print(f"[m2ftrans full dims 64^3] loss f32 {l32:.5f} bf16 {l16:.5f}; pred max |d| {float((o32[0] - o16[0]).abs().max()):.2e}")
+    assert abs(l32 - l16) < 2e-2 * abs(l32)
+    assert float((o32[0] - o16[0]).abs().mean()) < 2e-2
+    for a, b in zip(o32[1:], o16[1:]):
+        assert torch.allclose(a, b, rtol=1e-1, atol=2e-2)
+    for k in g32:
+        if g32[k] > 1e-6:
+            assert abs(g32[k] - g16[k]) < 0.25 * g32[k], (k, g32[k], g16[k])

@@ -63,3 +63,18 @@ def test_m2ftrans_state_dict_layout():
     assert len(w) == 801 and w["pos"].shape == (1, 40, 64) and w["fusion"].shape == (1, 8, 64)
     assert w["decoder_fusion.CT5.layers.0.ffn1.dwconv.weight"].shape == (256, 4, 3, 3, 3)
     assert w["decoder_fusion.CT4.layers.1.cross_attn.key_map_t2.conv2.weight"].shape == (32, 1, 3, 3, 3)
+
+
+def test_product_m2ftrans_tree_and_seeded_construction_match_the_reference():
+    """same 801 state-dict keys in the same order, same shapes, and -- built under torch.manual_seed(1037) -- the same values as
+    the reference Model's (the fixture stores them rounded to float16): module tree, registration order and RNG stream agree"""
+    from _util import build_m2ftrans
+    m = build_m2ftrans(32, small=True)
+    sd = m.state_dict()
+    w = m2f_weights()
+    assert list(sd.keys()) == list(w.keys())
+    assert all(sd[k].shape == w[k].shape for k in w)
+    worst = max(float((sd[k] - w[k]).abs().max() / (w[k].abs().max() + 1e-12)) for k in w)
+    assert worst < 1e-3, worst                      # float16 rounding of the fixture
+    missing = m.load_state_dict(w, strict=True)
+    assert not missing.missing_keys and not missing.unexpected_keys
