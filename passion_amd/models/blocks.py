@@ -335,7 +335,9 @@ def _pw(conv, x):
 
 
 def _ln(norm, x):
-    return torch.nn.functional.layer_norm(x, (x.shape[-1],), norm.weight, norm.bias, norm.eps)
+    """LayerNorm over the channels of a channels-last tensor: f32 statistics and affine, result in the tensor's dtype"""
+    y = torch.nn.functional.layer_norm(x.float(), (x.shape[-1],), norm.weight, norm.bias, norm.eps)
+    return y if x.dtype == torch.float32 else y.to(x.dtype)
 
 
 class DepthWiseConvBlock(nn.Module):

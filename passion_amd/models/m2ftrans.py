@@ -382,7 +382,7 @@ class Model(nn.Module):
         if P > 1:
             embed = embed.repeat(P, 1, 1)
         chunks, attn = self.Bottleneck(embed, masks_all, bf16)
-        vols = [c.to(dt).reshape(P * B, p, p, p, C5) for c in chunks]
+        vols = [c.to(dt).reshape(P * B, p, p, p, C5).contiguous() for c in chunks]      # chunk() views keep the (5 n C) batch stride
         # Weight_Attention (:420-460): first layer, fusion queries, summed over heads and queries -> one (p,p,p) map per modality
         wsum = attn[0][:, :, 4 * n:, :].sum((1, 2))                                   # (PB, 5n)
         wmaps = [wsum[:, i * n:(i + 1) * n].reshape(P * B, p, p, p) for i in range(4)]

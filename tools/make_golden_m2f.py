@@ -66,6 +66,26 @@ def case(m2f, crit, tag, S, B, mask, mask_type, passion, blobs, temp=4.0):
     gn = mg.grad_norms(model)
     rec["grad_keys"] = np.array(sorted(gn))
     rec["grad_norms"] = np.array([gn[k] for k in sorted(gn)])
+    # the same step by the reference in FLOAT64 (model.double()): the arbiter for this network's f32 noise (two f32 runs of the
+    # reference with different thread counts differ by up to 1.6e-4 in these norms; a GPU f32 run by several 1e-3 on the
+    # random-label case)
+    m64 = build(m2f, S).double()
+    m64.mask_type, m64.use_passion, m64.is_training = mask_type, passion, True
+    o64 = m64(x.double(), mask_t, target=target, temp=temp)
+    f64 = crit.softmax_weighted_loss_bs(o64[0], target, num_cls=4) + crit.dice_loss_bs(o64[0], target, num_cls=4)
+    l64 = f64.sum() + o64[1].sum()
+    if passion:
+        rp64 = torch.zeros(4, dtype=torch.float64)
+        for b in range(B):
+            rp64 += mk[b].double() * (o64[5][b] / (o64[5][b].sum() / mk[b].sum()) - 1)
+        r64 = (rp64 > 0).double()
+        l64 = l64 + (r64 * (o64[2] * mk).sum(0)).sum() + 0.5 * (o64[3] * mk).sum() + 0.1 * (r64 * (o64[4] * mk).sum(0)).sum()
+    else:
+        l64 = l64 + (o64[2] * mk).sum()
+    l64.backward()
+    g64 = mg.grad_norms(m64)
+    rec["loss_f64"] = float(l64)
+    rec["grad_norms_f64"] = np.array([g64[k] for k in sorted(gn)])
     sd = dict(model.named_parameters())
     for key in GRAD_KEYS:
         if sd[key].grad is not None:
