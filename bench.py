@@ -147,7 +147,8 @@ def dice_vs_ref(device, dtype, S):
         _, losses, pred = replay_trajectory(g, dtype, device)
         got = pred.argmax(1).reshape(-1).cpu().numpy().astype(np.uint8)
         d, n = mask_dice(got, unpack2(g["argmax_packed"], S ** 3))
-        out["trained"] = {"mean_dice": round(d, 6), "differing_voxels": n, "of": S ** 3, "steps_replayed": int(g["K"]),
+        out["trained"] = {"mean_dice": round(d, 6), "dice_wt_tc_et": [round(v, 6) for v in mask_dice.last], "differing_voxels": n,
+                          "agreement": round(1.0 - n / S ** 3, 6), "of": S ** 3, "steps_replayed": int(g["K"]),
                           "loss_final": round(float(losses[-1]), 5), "loss_final_ref": round(float(g["losses"][-1]), 5),
                           "fixture": "tests/golden/traj_plain_128.npz"}
     g = gold("model_full128_idt_plain_1111.npz")
@@ -158,7 +159,8 @@ def dice_vs_ref(device, dtype, S):
         pred = m(x.to(device), torch.from_numpy(g["mask"]).to(device))
     got = pred.argmax(1).reshape(-1).cpu().numpy().astype(np.uint8)
     d, n = mask_dice(got, unpack2(g["argmax_packed"], S ** 3))
-    out["random_init"] = {"mean_dice": round(d, 6), "differing_voxels": n, "of": S ** 3,
+    out["random_init"] = {"mean_dice": round(d, 6), "dice_wt_tc_et": [round(v, 6) for v in mask_dice.last], "differing_voxels": n,
+                          "agreement": round(1.0 - n / S ** 3, 6), "of": S ** 3,
                           "reference_ties_below_1e-4": int(len(g["close_idx"])), "fixture": "tests/golden/model_full128_idt_plain_1111.npz"}
     out["value"] = out.get("trained", out["random_init"])["mean_dice"]
     out["what"] = "mean Dice (WT, TC, ET) of the product's argmax mask in the benchmarked dtype against the imported reference's f32 mask"

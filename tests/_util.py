@@ -143,6 +143,7 @@ def mask_dice(a, b):
     for cls in ((1, 2, 3), (1, 3), (3,)):
         oa, ob = np.isin(a, cls), np.isin(b, cls)
         d.append((2.0 * (oa & ob).sum() + 1e-8) / (oa.sum() + ob.sum() + 1e-8))
+    mask_dice.last = [float(v) for v in d]            # (WT, TC, ET) of the call just made
     return float(np.mean(d)), int((a != b).sum())
 
 
