@@ -111,6 +111,8 @@ int launch_conv_lean(ConvK& k, int ksize, int stride, int mode, const void* pack
 bool lean_covers(const ConvK& k, int stride, bool dgrad);
 int launch_conv_march(ConvK& k, int ksize, int stride, int mode, const void* packed_bf16, hipStream_t st);   // conv_march.hip
 extern int g_conv_march;
+int launch_conv_s2_dgrad(ConvK& k, const void* packed_bf16, hipStream_t st);   // conv_s2_dgrad.hip: stride-2 padded-domain dgrad, gather form
+extern int g_conv_s2;
 bool conv_march_covers(const ConvK& k, int ksize, int stride, int mode, int* K8out);
 int launch_wgrad_lean(ConvK& k, int ksize, int stride, int MT, int gx, int gy, float* dWslab, float* dbslab, hipStream_t st);   // conv_wgrad_lean.hip
 bool wgrad_lean_covers(const ConvK& k, int ksize, int stride, int MT, int gx, int gy);

@@ -849,6 +849,10 @@ int launch_conv_lean(ConvK& k, int ksize, int stride, int mode, const void* pack
         if (rc <= 0) return rc;
     }
     const bool dgrad = mode >= 1;
+    if (stride == 2 && mode == 2 && ksize == 3) {   // gather form (conv_s2_dgrad.hip); > 0 = not covered: the zero-stuffed path below
+        const int rc = launch_conv_s2_dgrad(k, packed_bf16, st);
+        if (rc <= 0) return rc;
+    }
     if (stride != 1 && !(stride == 2 && mode == 2)) return 1;
     if (!(k.slope >= 0.f && k.slope <= 1.f)) return 1;      // the loader's LeakyReLU is max(t, slope * t)
     if (mode == 2 && ksize != 3) return 1;

@@ -111,6 +111,57 @@ def test_conv_block_fwd_bwd(case, dtype):
         assert e < tol * 3, f"dx[{i}] {e}"
 
 
+S2_CASES = [
+    # (Cin, Cout, (D,H,W), normalised input, modality mask): the stride-2 convs of encoder levels 2..5 (mmformer.py:33,38,43,48) and
+    # ragged / non-cube volumes; conv_s2_dgrad.hip (gather form: 1-8 taps per parity class) vs the zero-stuffed lean kernel
+    (8, 16, (16, 16, 16), True, False),
+    (8, 16, (10, 12, 20), True, True),
+    (16, 32, (8, 24, 16), True, False),
+    (32, 64, (8, 8, 8), True, False),
+    (64, 128, (4, 4, 4), True, False),
+    (8, 16, (6, 18, 30), False, False),
+    (16, 32, (32, 32, 32), True, False),
+]
+
+
+@pytest.mark.parametrize("case", S2_CASES, ids=[str(i) for i in range(len(S2_CASES))])
+def test_stride2_dgrad_gather_kernel(case):
+    from passion_amd import ops
+    dev = _dev()
+    Cin, Cout, (D, H, W), norm, use_mask = case
+    dtype = torch.bfloat16
+    B = 3
+    g = torch.Generator().manual_seed(17)
+    x = (torch.randn(B, Cin, D, H, W, generator=g, dtype=torch.float64) * 1.5 + 0.3).to(dtype).double()
+    w = torch.randn(Cout, Cin, 3, 3, 3, generator=g, dtype=torch.float64) / (Cin * 27) ** 0.5
+    b = torch.randn(Cout, generator=g, dtype=torch.float64)
+    mask = torch.tensor([[True], [False], [True]]) if use_mask else None
+    gy = torch.randn(B, Cout, D // 2, H // 2, W // 2, generator=g, dtype=torch.float64).to(dtype).double()
+    xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    yr = ref_conv_block([xr], [norm], [None if mask is None else mask[:, 0].double()], wr, br, 3, 2, 1, None)
+    yr.backward(gy)
+    got = {}
+    for s2 in (1, 0):
+        old = ops.set_option("conv_s2", s2)
+        try:
+            xd = cl(x).to(dev, dtype).requires_grad_(True)
+            wd, bd = w.float().to(dev).requires_grad_(True), b.float().to(dev).requires_grad_(True)
+            md = mask.to(dev) if mask is not None else None
+            seg = ops.SegIn(xd, stats=ops.instnorm_stats(xd.detach()) if norm else None, mask=md, mask_col=0)
+            y = ops.conv_block([seg], wd, bd, D, H, W, ksize=3, stride=2, pad_mode=1)
+            y.backward(cl(gy).to(dev, dtype))
+            torch.cuda.synchronize()
+            got[s2] = nc(xd.grad.float()).cpu()
+        finally:
+            ops.set_option("conv_s2", old)
+    tol = TOL[dtype]
+    e1, e0 = relerr(got[1], xr.grad), relerr(got[0], xr.grad)
+    assert e1 < tol * 3, f"gather-form dx {e1} (zero-stuffed kernel: {e0})"
+    assert e1 < 1.5 * e0 + 2e-3                      # same bf16 operands, same f32 accumulation: as close as the kernel it replaces
+    if use_mask:
+        assert float(got[1][1].abs().max()) == 0.0   # absent modality: no gradient
+
+
 PATH_CASES = [
     # bigger volumes: several bricks per persistent workgroup, interior + border + partial bricks
     ([8], 8, 3, 1, 1, (12, 24, 40), True, False, True),
