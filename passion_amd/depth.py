@@ -300,8 +300,59 @@ class ShardedWceDiceFn(torch.autograd.Function):
         return dp, None, None, None
 
 
+class AllReduceSumFn(torch.autograd.Function):
+    """sum over the ranks of a small tensor of partial sums.  Every rank goes on to form the SAME global loss from the result and
+    differentiates its own copy, so the gradient with respect to the local partial sums is the incoming gradient itself (identity):
+    each rank accounts for the paths through its own slab, the weight gradients are summed over the ranks afterwards."""
+
+    @staticmethod
+    def forward(ctx, t, shard):
+        out = t.detach().clone().contiguous()
+        shard.all_reduce(out)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, None
+
+
+def sharded_kl(ps, pt, temp, shard):
+    """temp_kl_loss_bs (criterions.py:92-103) of slabs of already softmaxed (+ upsampled) probabilities: the kernel's mean over the
+    local voxels, averaged over the (equal) slabs"""
+    return AllReduceSumFn.apply(ops.kl_probs(ps, pt, temp), shard) / shard.world
+
+
+def sharded_proto(fs, ft, target_cl, shard):
+    """prototype_passion_loss_bs (criterions.py:144-180) over slabs, TWO rounds of reductions: (1) the per-class voxel
+    counts and feature sums -> global prototypes (and the global decision which classes every sample holds, :157); (2) the sums of
+    the squared / absolute differences of the student's and the teacher's cosine-similarity maps.  fs (B,Dl,H,W,Cf) student
+    features (gradient), ft teacher features (detached), target_cl (B,Dl,H,W,4) f32 one-hot.  -> ((B,1) loss, (B,1) dist).
+    torch elementwise ops on the slab: this mode is bound by its exchanges, not by these passes."""
+    eps = 1e-5
+    fs32, ft32 = fs.float(), ft.detach().float()
+    B = fs.shape[0]
+    tc = target_cl.reshape(B, -1, 4)                                            # (B, V, 4)
+    f_s, f_t = fs32.reshape(B, -1, fs.shape[-1]), ft32.reshape(B, -1, ft.shape[-1])
+    cnt = AllReduceSumFn.apply(tc.sum(1), shard)                                # round 1: (B, 4) voxel counts ...
+    sums = AllReduceSumFn.apply(torch.cat([torch.einsum("bvk,bvc->bkc", tc, f_s), torch.einsum("bvk,bvc->bkc", tc, f_t)], 2), shard)
+    Cf = fs.shape[-1]
+    keep = (cnt > 0).all(0)                                                     # a class takes part only if EVERY sample has it (:157)
+    proto_s = sums[..., :Cf] / (cnt.unsqueeze(-1) + eps)                        # (B, 4, Cf)
+    proto_t = sums[..., Cf:] / (cnt.unsqueeze(-1) + eps)
+
+    def cos(f, pr):                                                             # F.cosine_similarity(dim = channel, eps): (B, V, 4)
+        num = torch.einsum("bvc,bkc->bvk", f, pr)
+        return num / (f.norm(dim=2, keepdim=True).clamp_min(eps) * pr.norm(dim=2).unsqueeze(1).clamp_min(eps))
+
+    diff = (cos(f_s, proto_s) - cos(f_t, proto_t))[..., keep]
+    part = torch.stack([(diff * diff).sum((1, 2)), diff.abs().sum((1, 2))], 1)  # round 2: (B, 2) local sums
+    tot = AllReduceSumFn.apply(part, shard)
+    n = float(f_s.shape[1] * shard.world) * float(keep.sum())                   # mean over (classes kept, global voxels)
+    return (tot[:, 0:1] / n), (tot[:, 1:2] / n).detach()
+
+
 # ------------------------------------------------------------------------------------------------------------------
-# the plain mmformer training forward on slabs
+# the mmformer training forward on slabs
 # ------------------------------------------------------------------------------------------------------------------
 class Slab:
     """a slab (B, Dl, H, W, C) + its global InstanceNorm statistics (computed once, shared by the consumers) + modality mask"""
@@ -369,11 +420,13 @@ def seg_pair(probs_cl, target_cl, shard):
     return ShardedWceDiceFn.apply(probs_cl, target_cl, shard, "cl")
 
 
-def sharded_step_loss(model, shard, x, mask, target, Dg):
-    """mmformer.Model.forward (training, no self-distillation: reference mmformer.py:381-465,533-561,637-657) + train.py's plain
-    loss assembly (:413-440) for ONE volume whose D axis is split over the ranks.
+def sharded_step_loss(model, shard, x, mask, target, Dg, temp=4.0, state=None):
+    """mmformer.Model.forward (training; reference mmformer.py:381-465,533-561,637-657, and with model.use_passion the four uni-modal
+    students + KL / prototype losses of :468-633) + train.py's loss assembly (:413-440 plain, :228-280 PASSION) for ONE volume
+    whose D axis is split over the ranks.
     x (B, 4, Dl, H, W), target (B, 4, Dl, H, W): this rank's slabs; Dg: depth of the whole volume.
-    -> (loss, pred_local (B, 4, Dl, H, W), prm_loss (B, 1), sep_loss (B, 4)); the losses are global (equal on every rank)"""
+    -> (loss, pred_local (B, 4, Dl, H, W), prm_loss (B, 1), sep_loss (B, 4)[, kl_loss, proto_loss, dist (B, 4) each]); the losses are
+    global (equal on every rank)"""
     from .models.mmformer import MODALS
     B, _, Dl, H, W = x.shape
     dt = model.compute_dtype
@@ -414,13 +467,8 @@ def sharded_step_loss(model, shard, x, mask, target, Dg):
         tok = tok.reshape(B, -1, model.token_dim)
         tok = model._transformer(getattr(model, f"{m}_transformer"), tok, pos[i])
         intra.append(tok * mask[:, i].view(B, 1, 1).to(tok.dtype))
-    tok = model._transformer(model.multimodal_transformer, torch.cat(intra, 1), torch.cat(pos, 1))
-    volf = tok.to(dt).contiguous().view(B, dg5, pH, pW, model.token_dim * 4)
+    pos_cat = torch.cat(pos, 1)
     Dl5 = encs[0][4].t.shape[1]
-    mine = volf[:, shard.rank * Dl5:(shard.rank + 1) * Dl5].contiguous()
-    x5 = conv(model.multimodal_decode_conv, Slab(mine, shard), shard, dg5, norm=False)
-
-    xs = [[encs[i][l].with_mask(mask, i) if idt else encs[i][l] for i in range(4)] for l in range(4)]
     dgs = [Dg, Dg // 2, Dg // 4, Dg // 8, Dg // 16]
     df = model.decoder_fuse
 
@@ -429,19 +477,31 @@ def sharded_step_loss(model, shard, x, mask, target, Dg):
         h = conv(mod.fusion_layer[1].conv, h, shard, dg)
         return conv(mod.fusion_layer[2].conv, h, shard, dg)
 
-    f5 = rfm(df.RFM5, [x5], dgs[4])
-    preds = {4: conv(df.seg_d4, f5, shard, dgs[4], norm=False, out_dtype=torch.float32).t}
-    h = conv(df.d4_c1.conv, up(f5, 2, shard, dgs[4]), shard, dgs[3])
-    f1 = None
-    for lvl in (4, 3, 2, 1):
-        r = rfm(getattr(df, f"RFM{lvl}"), xs[lvl - 1], dgs[lvl - 1])
-        f = conv(getattr(df, f"d{lvl}_out").conv, conv(getattr(df, f"d{lvl}_c2").conv, [r, h], shard, dgs[lvl - 1]), shard, dgs[lvl - 1])
-        if lvl > 1:
-            preds[lvl - 1] = conv(getattr(df, f"seg_d{lvl - 1}"), f, shard, dgs[lvl - 1], norm=False, out_dtype=torch.float32).t
-            h = conv(getattr(df, f"d{lvl - 1}_c1").conv, up(f, 2, shard, dgs[lvl - 1]), shard, dgs[lvl - 2])
-        else:
-            f1 = f
-    logits = conv(df.seg_layer, f1, shard, Dg, norm=False, out_dtype=torch.float32).t
+    def fuse_pass(m_feat, m_tok):
+        """one pass through the inter-modal transformer + decoder_fuse (reference mmformer.py:436-465 teacher, :469-531 students):
+        m_feat (B,4) masks the encoder features, m_tok (B,4) or None the level-5 tokens.  -> logits, the four deep-supervision
+        logits, the full-resolution feature map (de_x1)"""
+        toks = intra if m_tok is None else [t * m_tok[:, i].view(B, 1, 1).to(t.dtype) for i, t in enumerate(intra)]
+        tok = model._transformer(model.multimodal_transformer, torch.cat(toks, 1), pos_cat)
+        volf = tok.to(dt).contiguous().view(B, dg5, pH, pW, model.token_dim * 4)
+        mine = volf[:, shard.rank * Dl5:(shard.rank + 1) * Dl5].contiguous()
+        x5 = conv(model.multimodal_decode_conv, Slab(mine, shard), shard, dg5, norm=False)
+        xs = [[encs[i][l].with_mask(m_feat, i) if m_feat is not None else encs[i][l] for i in range(4)] for l in range(4)]
+        f5 = rfm(df.RFM5, [x5], dgs[4])
+        preds = {4: conv(df.seg_d4, f5, shard, dgs[4], norm=False, out_dtype=torch.float32).t}
+        h = conv(df.d4_c1.conv, up(f5, 2, shard, dgs[4]), shard, dgs[3])
+        f1 = None
+        for lvl in (4, 3, 2, 1):
+            r = rfm(getattr(df, f"RFM{lvl}"), xs[lvl - 1], dgs[lvl - 1])
+            f = conv(getattr(df, f"d{lvl}_out").conv, conv(getattr(df, f"d{lvl}_c2").conv, [r, h], shard, dgs[lvl - 1]), shard, dgs[lvl - 1])
+            if lvl > 1:
+                preds[lvl - 1] = conv(getattr(df, f"seg_d{lvl - 1}"), f, shard, dgs[lvl - 1], norm=False, out_dtype=torch.float32).t
+                h = conv(getattr(df, f"d{lvl - 1}_c1").conv, up(f, 2, shard, dgs[lvl - 1]), shard, dgs[lvl - 2])
+            else:
+                f1 = f
+        return conv(df.seg_layer, f1, shard, Dg, norm=False, out_dtype=torch.float32).t, preds, f1.t
+
+    logits, preds, f1_teacher = fuse_pass(mask if idt else None, None)
     pred_cl = ops.softmax_classes(logits, 1.0, "cl")
 
     tcl = ops.target_to_cl(target)
@@ -468,6 +528,39 @@ def sharded_step_loss(model, shard, x, mask, target, Dg):
         prm_loss = prm_loss + 0.5 ** (j + 1) * seg_pair(up(pj, 2 ** (j + 1), shard, dgs[j + 1]).t, tcl, shard).sum(1, keepdim=True)
     fuse = seg_pair(pred_cl, tcl, shard).sum()
     mk = maskf if idt else torch.ones_like(maskf)
-    loss = fuse + (sep_loss * mk).sum() + prm_loss.sum()
     pred = ops.to_ncdhw(pred_cl.detach())
-    return loss, pred, prm_loss, sep_loss
+    if not getattr(model, "use_passion", False):
+        loss = fuse + (sep_loss * mk).sum() + prm_loss.sum()
+        return loss, pred, prm_loss, sep_loss
+
+    # ---- PASSION: the four uni-modal students (one pass each through the fusion path) against the detached teacher
+    from .train import relative_preference
+    inv_t = 1.0 / temp
+    onehot = torch.eye(4, dtype=torch.bool, device=x.device)
+    pt_full = ops.softmax_classes(logits.detach(), inv_t, "cl")
+    pt_deep = [up(Slab(ops.softmax_classes(preds[j + 1].detach(), inv_t, "cl"), shard), 2 ** (j + 1), shard, dgs[j + 1]).t for j in range(4)]
+    kl_loss, proto_loss, dist = (torch.zeros(B, 4, device=x.device) for _ in range(3))
+    for i in range(4):
+        m_i = onehot[i].expand(B, 4)
+        m_feat = (mask & m_i) if idt else m_i                         # idt: absent-by-data modalities stay zero as well
+        m_tok = onehot[2 if i == 3 else i].expand(B, 4)               # the T2 student masks its tokens with T1's one-hot (:522)
+        lo_i, preds_i, f1_i = fuse_pass(m_feat, m_tok)
+        kl = sharded_kl(ops.softmax_classes(lo_i, inv_t, "cl"), pt_full, temp, shard)
+        for j in range(4):
+            ps = up(Slab(ops.softmax_classes(preds_i[j + 1], inv_t, "cl"), shard), 2 ** (j + 1), shard, dgs[j + 1]).t
+            kl = kl + 0.5 ** (j + 1) * sharded_kl(ps, pt_deep[j], temp, shard)
+        pl, dd = sharded_proto(f1_i, f1_teacher, tcl, shard)
+        gate = (maskf * eye[i]) if idt else eye[i].expand(B, 4)
+        # a sample whose only present modality is i: student == teacher, the reference gets exact zeros (see models/mmformer.py)
+        only = (mask & (mask.sum(1, keepdim=True) == 1))[:, i:i + 1]
+        differs = torch.ones(B, 1, device=x.device) if i == 3 else (~only).float()
+        kl_loss = kl_loss + gate * kl * differs
+        proto_loss = proto_loss + gate * pl * differs
+        dist = dist + gate * dd * differs
+    beta = state.imb_beta if state is not None else torch.ones(4, device=x.device)
+    w = state.modal_weight if (state is not None and idt) else torch.ones(4, device=x.device)
+    red = (lambda t: (t * mk).sum(0))
+    rp_mask = relative_preference(dist, mk, idt)
+    loss = fuse + (rp_mask * beta * w * red(sep_loss)).sum() + prm_loss.sum() + 0.5 * (beta * w * red(kl_loss)).sum() \
+        + 0.1 * (rp_mask * w * red(proto_loss)).sum()
+    return loss, pred, prm_loss, sep_loss, kl_loss, proto_loss, dist

@@ -34,18 +34,31 @@ def _free_port():
     return p
 
 
-def _setup(shape, dtype, dev):
-    """model (full dims, built like tools/make_golden_128.py builds the reference one), volume, target, mask"""
+def _setup(shape, dtype, dev, fixture=None):
+    """model (full dims, built like tools/make_golden_128.py builds the reference one), volume, target, mask; with `fixture`
+    (a 128^3 golden file): its PASSION flag, label kind and modality mask"""
     import _util
     grid = tuple(s // 16 for s in shape)
     m = _util.build_model_grid(grid, small=False, seed=1037).to(dev)
-    m.mask_type, m.use_passion, m.compute_dtype, m.is_training = "idt", False, dtype, True
+    g = _util.gold(fixture) if fixture else None
+    m.mask_type, m.use_passion, m.compute_dtype, m.is_training = "idt", bool(g["passion"]) if g is not None else False, dtype, True
     if shape[0] == shape[1] == shape[2]:
-        x, target = _util.synth(1, shape[0], blobs=False)         # the 128^3 fixture's input (uniform random labels)
+        x, target = _util.synth(1, shape[0], blobs=bool(g["blobs"]) if g is not None else False)      # the 128^3 fixtures' inputs
     else:
         x, target = _util.synth_box(1, shape)
-    mask = torch.ones(1, 4, dtype=torch.bool)
+    mask = torch.from_numpy(g["mask"]) if g is not None else torch.ones(1, 4, dtype=torch.bool)
     return m, x.to(dev), target.to(dev), mask.to(dev)
+
+
+def _state(fixture, dev):
+    import _util
+    from passion_amd import train as ptrain
+    if not fixture:
+        return None
+    g = _util.gold(fixture)
+    st = ptrain.LossState(dev, modal_weight=torch.from_numpy(g["modal_weight"]))
+    st.imb_beta = torch.from_numpy(g["imb_beta"]).to(dev)
+    return st
 
 
 def _collect(m, loss, pred, prm, sep):
@@ -53,7 +66,7 @@ def _collect(m, loss, pred, prm, sep):
             "grads": {k: p.grad.detach().cpu() for k, p in m.named_parameters() if p.grad is not None}}
 
 
-def _worker(rank, world, port, out, shape, dtype_name):
+def _worker(rank, world, port, out, shape, dtype_name, fixture=None):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
@@ -61,16 +74,19 @@ def _worker(rank, world, port, out, shape, dtype_name):
     from passion_amd import depth, parallel
     ctx = parallel.init()
     shard = depth.DepthCtx()
-    m, x, target, mask = _setup(shape, getattr(torch, dtype_name), ctx.device)
+    m, x, target, mask = _setup(shape, getattr(torch, dtype_name), ctx.device, fixture)
     D = shape[0]
     Dl = D // world
     sl = slice(rank * Dl, (rank + 1) * Dl)
-    loss, pred, prm, sep = depth.sharded_step_loss(m, shard, x[:, :, sl].contiguous(), mask, target[:, :, sl].contiguous(), D)
+    res = depth.sharded_step_loss(m, shard, x[:, :, sl].contiguous(), mask, target[:, :, sl].contiguous(), D, 4.0, _state(fixture, ctx.device))
+    loss, pred, prm, sep = res[:4]
     loss.backward()
     red = parallel.GradReducer(m, ctx, overlap=False)
     red.all_reduce_grads()
     torch.cuda.synchronize()
     got = _collect(m, loss, pred, prm, sep)
+    for name, t in zip(("kl", "proto", "dist"), res[4:]):
+        got[name] = t.detach().cpu()
     if rank != 0:
         got["grads"] = {}                                 # identical on every rank after the SUM: one copy is enough
     torch.save(got, f"{out}.{rank}")
@@ -78,9 +94,9 @@ def _worker(rank, world, port, out, shape, dtype_name):
     torch.distributed.destroy_process_group()
 
 
-def _sharded(tmp_path, shape, dtype_name, tag):
+def _sharded(tmp_path, shape, dtype_name, tag, fixture=None):
     out = str(tmp_path / tag)
-    mp.spawn(_worker, args=(2, _free_port(), out, shape, dtype_name), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, _free_port(), out, shape, dtype_name, fixture), nprocs=2, join=True)
     parts = [torch.load(f"{out}.{r}") for r in range(2)]
     assert abs(parts[0]["loss"] - parts[1]["loss"]) <= 1e-6 * abs(parts[0]["loss"])
     got = dict(parts[0])
@@ -147,6 +163,30 @@ def test_128_f32_two_ranks_against_the_reference_fixture(tmp_path):
     for key in g.files:
         if key.startswith("grad::") and np.abs(g[key]).max() > 1e-6:
             assert _util.rel(sh["grads"][key[6:]], g[key]) < 5e-3, (key, _util.rel(sh["grads"][key[6:]], g[key]))
+
+
+def test_128_f32_passion_two_ranks_against_the_reference_fixture(tmp_path):
+    """PASSION under depth sharding (students one by one through the fusion path, KL means and the two-round prototype reduction
+    over the ranks): configs[2]'s fixture from the imported reference -- brats_split mask, non-unit modal_weight / imb_beta"""
+    import _util
+    fx = "model_full128_idt_passion_split.npz"
+    g = _util.gold(fx)
+    S = 128
+    sh = _sharded(tmp_path, (S, S, S), "float32", "s128pas", fx)
+    assert _util.rel(sh["pred"][:, :, S // 2], g["pred_slice"]) < 1e-3
+    for key, name in (("prm", "prm_loss"), ("sep", "sep_loss"), ("kl", "kl_loss"), ("proto", "proto_loss"), ("dist", "dist")):
+        assert _util.rel(sh[key], g[name]) < 1e-3, (name, sh[key], g[name])
+    assert abs(sh["loss"] - float(g["loss"])) < 1e-3 * abs(float(g["loss"])), (sh["loss"], float(g["loss"]))
+    gn = _util.grad_norms(sh["grads"].items())
+    for k, ref in zip(g["grad_keys"], g["grad_norms"]):
+        assert abs(gn[str(k)] - ref) < 3e-3 * ref + 1e-6, (k, gn[str(k)], ref)
+    worst = 0.0
+    for key in g.files:
+        if key.startswith("grad::") and np.abs(g[key]).max() > 1e-6:
+            e = _util.rel(sh["grads"][key[6:]], g[key])
+            worst = max(worst, e)
+            assert e < 5e-3, (key, e)
+    print(f"[depth 128^3 f32 PASSION, 2 ranks] loss {sh['loss']:.6f} vs reference {float(g['loss']):.6f}; worst gradient tensor error {worst:.2e}")
 
 
 def test_128_bf16_two_ranks_track_the_unsharded_step(tmp_path):
