@@ -301,19 +301,27 @@ class ShardedWceDiceFn(torch.autograd.Function):
 
 
 class AllReduceSumFn(torch.autograd.Function):
-    """sum over the ranks of a small tensor of partial sums.  Every rank goes on to form the SAME global loss from the result and
-    differentiates its own copy, so the gradient with respect to the local partial sums is the incoming gradient itself (identity):
-    each rank accounts for the paths through its own slab, the weight gradients are summed over the ranks afterwards."""
+    """sum over the ranks of a small tensor of partial sums.  Every rank differentiates its own copy of the (global) loss and the
+    parameter gradients are summed over the ranks afterwards, so what the backward must be depends on what consumes the sum:
+      reduce_grad=False  the sum feeds a computation every rank repeats identically (the last reduction of a loss term): the
+                         gradient with respect to the local partial sum is the incoming gradient itself;
+      reduce_grad=True   the sum feeds RANK-LOCAL work whose results are reduced again later (the global prototypes, which every
+                         rank's similarity maps depend on): the gradient is the sum of all ranks' incoming gradients -- another
+                         all-reduce.  (With the identity here only the terms 'my maps x my features' would survive.)"""
 
     @staticmethod
-    def forward(ctx, t, shard):
+    def forward(ctx, t, shard, reduce_grad=False):
+        ctx.shard, ctx.reduce_grad = shard, reduce_grad
         out = t.detach().clone().contiguous()
         shard.all_reduce(out)
         return out
 
     @staticmethod
     def backward(ctx, g):
-        return g, None
+        if ctx.reduce_grad:
+            g = g.contiguous().clone()
+            ctx.shard.all_reduce(g)
+        return g, None, None
 
 
 def sharded_kl(ps, pt, temp, shard):
@@ -334,7 +342,7 @@ def sharded_proto(fs, ft, target_cl, shard):
     tc = target_cl.reshape(B, -1, 4)                                            # (B, V, 4)
     f_s, f_t = fs32.reshape(B, -1, fs.shape[-1]), ft32.reshape(B, -1, ft.shape[-1])
     cnt = AllReduceSumFn.apply(tc.sum(1), shard)                                # round 1: (B, 4) voxel counts ...
-    sums = AllReduceSumFn.apply(torch.cat([torch.einsum("bvk,bvc->bkc", tc, f_s), torch.einsum("bvk,bvc->bkc", tc, f_t)], 2), shard)
+    sums = AllReduceSumFn.apply(torch.cat([torch.einsum("bvk,bvc->bkc", tc, f_s), torch.einsum("bvk,bvc->bkc", tc, f_t)], 2), shard, True)
     Cf = fs.shape[-1]
     keep = (cnt > 0).all(0)                                                     # a class takes part only if EVERY sample has it (:157)
     proto_s = sums[..., :Cf] / (cnt.unsqueeze(-1) + eps)                        # (B, 4, Cf)
