@@ -90,7 +90,9 @@ def test_f32_follows_the_reference_trajectory(name):
     assert rel(pred[:, :, S // 2], g["pred_slice"]) < 5e-2      # probabilities after K steps of two f32 implementations: 2.4e-2 measured
     sd = m.state_dict()
     for key in g.files:
-        if key.startswith("final::"):
+        # weights only: a conv bias in front of an InstanceNorm has an exactly zero gradient, what reaches AdamW is ~1e-9 of
+        # rounding noise, and Adam turns noise of any size into steps of ~0.1 lr -- those biases random-walk in BOTH programs
+        if key.startswith("final::") and not key.endswith("bias"):
             assert rel(sd[key[7:]], g[key]) < 1e-2, (key, rel(sd[key[7:]], g[key]))
 
 
