@@ -151,3 +151,17 @@ def test_config3_rfnet96_passion_split_f32_vs_reference():
 def test_config3_rfnet96_passion_split_bf16():
     g = gold("rfnet_96_idt_passion_split.npz")
     _check_bf16(g, *_run(g, torch.bfloat16, rfnet=True), "cfg3 bf16 (96^3)")
+
+
+def test_reference_default_crop_80_f32_vs_reference():
+    """the reference's OWN configuration (patch_size 5: 80^3 crops, options.py:50; levels 80 / 40 / 20 / 10 / 5 are ragged against the
+    4 x 8 x 8 bricks and 80 % 16 != 0 keeps the marching kernels out: the lean / general kernel paths), PASSION step with the
+    brats_split mask, against a fixture of the imported reference (tools/make_golden_128.py crop80)"""
+    g = gold("model_full80_idt_passion_split.npz")
+    assert int(g["S"]) == 80
+    _check_f32(g, *_run(g, torch.float32), "crop 80 f32")
+
+
+def test_reference_default_crop_80_bf16():
+    g = gold("model_full80_idt_passion_split.npz")
+    _check_bf16(g, *_run(g, torch.bfloat16), "crop 80 bf16")

@@ -193,6 +193,8 @@ def main():
         mm_case("full128_idt_passion_split", True, mask, modal_weight, imb_beta)
     if "rfnet" in what:
         rf_case("96_idt_passion_split", mask, modal_weight, imb_beta)
+    if "crop80" in what:        # the reference's OWN configuration: patch_size 5 = 80^3 crops (mmformer.py:21, options.py:50), PASSION, brats_split mask
+        mm_case("full80_idt_passion_split", True, mask, modal_weight, imb_beta, S=80)
 
 
 if __name__ == "__main__":
