@@ -510,6 +510,9 @@ class Model(nn.Module):
             # ---- the four encoders as grouped launches over the stacked batch (encoders_grouped); the per-modality tensors the
             # fusion path reads are the four batch slices of every level (ops.unstack: shared storage, no copy either way)
             stacked_feats = encoders_grouped([getattr(self, f"{m}_encoder") for m in MODALS], x, mask if idt else None, dt)
+            if training:                               # tells train_step when only the encoders' backward is left (ops.BackwardMarkerFn)
+                f5 = stacked_feats[4]
+                stacked_feats[4] = Feat(ops.backward_marker(f5.t), f5.mask, f5.mask_col, _stats=f5._stats)
             per_level = []
             for l, f in enumerate(stacked_feats):
                 ts = ops.unstack(f.t, 4)

@@ -581,6 +581,32 @@ def unstack(t, n):
     return UnstackFn.apply(t, n)
 
 
+_MARKER_CB = [None]
+
+
+class BackwardMarkerFn(torch.autograd.Function):
+    """identity whose backward node tells the training step how far the backward has come.  Model.forward puts it on the deepest
+    encoder output: autograd runs nodes in reverse creation order among the ready ones, every decoder / transformer / loss node
+    was created after every encoder node and none of them depends on an encoder node's backward, so when this node runs all
+    of THEIR parameter gradients have been enqueued and only the encoders' backward is left (train.train_step uses that to start
+    the optimizer on those parameters under the encoder backward)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        cb = _MARKER_CB[0]
+        if cb is not None:
+            cb()
+        return g
+
+
+def backward_marker(x):
+    return BackwardMarkerFn.apply(x) if (x.requires_grad and _MARKER_CB[0] is not None) else x
+
+
 def stack_slots(buf, parts):
     return StackFn.apply([buf], *parts)
 

@@ -17,6 +17,14 @@ class FusedAdamW(torch.optim.Optimizer):
         defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=amsgrad)
         super().__init__(params, defaults)
         self._tables = {}
+        self._stepped = set()        # data_ptr of the parameters step_ready() already updated in this iteration
+
+    @torch.no_grad()
+    def step_ready(self):
+        """update, on the CURRENT stream, every parameter that has a gradient now and was not updated yet in this iteration; the
+        closing step() takes the rest.  Called from the backward (ops.BackwardMarkerFn) when only the encoders' backward is left:
+        the AdamW pass over the decoder / transformer parameters (33 of 35.6 M) then runs under it instead of after it."""
+        self._step_impl(partial=True)
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -24,13 +32,18 @@ class FusedAdamW(torch.optim.Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
+        self._step_impl(partial=False)
+        self._stepped.clear()
+        return loss
+
+    def _step_impl(self, partial):
         lib = L.load()
         host = L.host() if all(p.is_cuda for g in self.param_groups for p in g["params"]) else None
         for gi, group in enumerate(self.param_groups):
             allp = group["params"]
             if host is not None:         # one C++ pass over the parameters instead of a few hundred attribute reads
                 pptr, gptr = host.param_grad_ptrs(allp)
-                live = [i for i, q in enumerate(gptr) if q]
+                live = [i for i, q in enumerate(gptr) if q and pptr[i] not in self._stepped]
                 ps = [allp[i] for i in live]
             else:
                 ps = [p for p in allp if p.grad is not None]
@@ -41,7 +54,7 @@ class FusedAdamW(torch.optim.Optimizer):
             # moments) is built once per set of live parameters: the step is host-bound, 288 parameters x a few dict
             # lookups and CPU-tensor increments were 1.2 ms of it
             key = tuple(live) if live is not None else tuple(id(p) for p in ps)
-            cache = self._tables.get(gi)
+            cache = self._tables.get((gi, key))
             cur_pptr = [pptr[i] for i in live] if live is not None else [p.data_ptr() for p in ps]
             if cache is None or cache["key"] != key or cache["pptr"] != cur_pptr:
                 self._sync_steps()      # the live counts are in the old table: bring the per-parameter tensors up to date first
@@ -71,8 +84,13 @@ class FusedAdamW(torch.optim.Optimizer):
                     subs.append({"idx": idx, "p": arr(sp), "m": arr(ms), "v": arr(vs), "vm": arr(vm),
                                  "numel": (c_int64 * n)(*[p.numel() for p in sp]), "g": (c_void_p * n)(), "step": step0,
                                  "step_tensors": [self.state[p]["step"] for p in sp]})
+                # tables of another partition of the same parameters (a full step() after partial ones, or the reverse) are
+                # stale from here on: their step counts must never be written back again
+                pset = set(cur_pptr)
+                for k2 in [k2 for k2, c2 in self._tables.items() if k2[0] == gi and not pset.isdisjoint(c2["pptr"])]:
+                    del self._tables[k2]
                 cache = {"key": key, "pptr": cur_pptr, "subs": subs}
-                self._tables[gi] = cache
+                self._tables[(gi, key)] = cache
             b1, b2 = group["betas"]
             for sub in cache["subs"]:
                 garr = sub["g"]
@@ -95,7 +113,8 @@ class FusedAdamW(torch.optim.Optimizer):
             # the kernel wrote the parameters behind autograd's back: bump their version counters, the packed-weight
             # caches (ops.pack_weight / repack_stale) and any saved-tensor checks key on them
             torch.autograd.graph.increment_version(ps)
-        return loss
+            if partial:
+                self._stepped.update(cur_pptr)
 
     def zero_grad(self, set_to_none=True):
         host = L.host() if set_to_none and all(p.is_cuda for g in self.param_groups for p in g["params"]) else None

@@ -118,18 +118,55 @@ def poly_lr(base_lr, epoch, num_epochs, power=0.9):
     return round(base_lr * np.power(1 - np.float32(epoch) / np.float32(num_epochs), power), 8)
 
 
+EARLY_STEP = os.environ.get("PASSION_EARLY_STEP", "1") != "0"    # AdamW of the non-encoder parameters under the encoder backward
+
+
+def _early_step_callback(model, optimizer):
+    """-> callback for ops.BackwardMarkerFn (single process): when the backward reaches the encoders, every other parameter's
+    gradient has been enqueued (on the main stream or on one of the model's side streams): AdamW for those 33 of 35.6 M
+    parameters goes to a stream of its own, behind events of all of them, and runs UNDER the encoder backward (which touches
+    none of those weights) instead of after it.  The closing optimizer.step() updates the encoders and joins."""
+    dev = next(model.parameters()).device
+    st = model.__dict__.setdefault("_opt_stream", {})
+    if dev not in st:
+        st[dev] = (torch.cuda.Stream(device=dev), torch.cuda.Event())
+    opt_stream, done = st[dev]
+
+    def cb():
+        cur = torch.cuda.current_stream(dev)
+        side = model.__dict__.get("_streams_dev", {}).get(dev, [])
+        for s_ in {id(s_): s_ for s_ in [cur] + list(side)}.values():
+            ev = torch.cuda.Event()
+            ev.record(s_)
+            opt_stream.wait_event(ev)
+        with torch.cuda.stream(opt_stream):
+            optimizer.step_ready()
+            done.record(opt_stream)
+        model.__dict__["_opt_pending"] = done
+    return cb
+
+
 def train_step(model, optimizer, x, mask, target, temp=4.0, state=None, reducer=None, warmup=False, modal_num=None,
                iter_per_epoch=None):
     """one iteration: forward, loss assembly, backward, (gradient all-reduce,) optimizer step"""
+    from . import ops
     net = model
     net.is_training = True
-    outs = net(x, mask, target=target, temp=temp)
-    loss = assemble_loss(outs, target, mask, net.mask_type, net.use_passion, state, warmup, modal_num, iter_per_epoch)
-    optimizer.zero_grad()            # set_to_none: no 288 fill launches, backward assigns the fresh gradients
-    loss.backward()
+    early = EARLY_STEP and hasattr(optimizer, "step_ready") and (reducer is None or reducer.ctx.world == 1) and x.is_cuda
+    ops._MARKER_CB[0] = _early_step_callback(net, optimizer) if early else None
+    try:
+        outs = net(x, mask, target=target, temp=temp)
+        loss = assemble_loss(outs, target, mask, net.mask_type, net.use_passion, state, warmup, modal_num, iter_per_epoch)
+        optimizer.zero_grad()            # set_to_none: no 288 fill launches, backward assigns the fresh gradients
+        loss.backward()
+    finally:
+        ops._MARKER_CB[0] = None
     if reducer is not None:
         reducer.all_reduce_grads()
     optimizer.step()
+    pending = net.__dict__.pop("_opt_pending", None)
+    if pending is not None:              # the early part ran on its own stream: the next forward (weight re-pack) waits for it
+        torch.cuda.current_stream(x.device).wait_event(pending)
     return loss.detach()
 
 
