@@ -211,6 +211,20 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_launch(args)               # never returns; nothing above has initialised the GPU
 
+    # N > 1: every rank's host threads (Python main thread, autograd engine, HIP runtime) on their own cores BEFORE anything
+    # touches the GPU or spawns a thread pool -- eight ranks x ~11 ms of host work per step on shared cores is the first scaling
+    # risk (round 2 saw load averages of 30-40 on the pool's hosts)
+    world_env, local_env = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
+    if world_env > 1 and hasattr(os, "sched_setaffinity"):
+        try:
+            cpus = sorted(os.sched_getaffinity(0))
+            per = max(2, len(cpus) // world_env)
+            mine = cpus[(local_env * per) % len(cpus):][:per] or cpus
+            os.sched_setaffinity(0, mine)
+            os.environ.setdefault("OMP_NUM_THREADS", str(max(1, min(8, per - 1))))
+        except OSError:
+            pass
+
     import torch
     import torch.distributed as dist
     from passion_amd import ops, parallel
