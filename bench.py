@@ -468,12 +468,17 @@ def main():
                                        "largest_launch": {"kernel": big[4], "gflop": round(big[3] / 1e9, 3), "ms": round(big[1], 4),
                                                           "tflops": round(big[3] / (big[1] * 1e-3) / 1e12, 2)}}
         if att:
-            ppath = os.path.join(ROOT, "profiles", "attention_pmc.json")
-            if os.path.exists(ppath):
-                att["mfma_busy"] = {"note": "STATIC: read from the committed rocprofv3 --pmc pass below, not measured in this run "
-                                            "(tools/pmc_attention.sh regenerates it)",
-                                    "source": "profiles/attention_pmc.json", "source_mtime": int(os.path.getmtime(ppath)),
-                                    **json.load(open(ppath))}
+            # counters cannot be read inside a timed run: the committed rocprofv3 --pmc pass over THIS command (bench.py with this
+            # workload: the instantiations and shapes benchmarked here), tools/pmc_attention_bench.sh
+            pname = "r03_attention_pmc_bench_passion.json" if passion else "r03_attention_pmc_bench_plain.json"
+            ppath = os.path.join(ROOT, "profiles", pname)
+            if os.path.exists(ppath) and not is_rfnet:
+                pj = json.load(open(ppath))
+                att["mfma_busy"] = {"note": "STATIC: read from the committed rocprofv3 --pmc pass over this same bench command, not "
+                                            "measured in this run (tools/pmc_attention_bench.sh regenerates it)",
+                                    "source": "profiles/" + pname, "source_mtime": int(os.path.getmtime(ppath)),
+                                    "all_flash_kernels_mfma_busy_frac": pj.get("all_flash_kernels_mfma_busy_frac"),
+                                    "kernels": {k: v.get("mfma_busy_frac") for k, v in pj.get("kernels", {}).items()}}
             att["peak_tflops"] = MFMA_BF16_PEAK_TF
             out["attention"] = att
     if not is_rfnet and not args.no_dice:

@@ -7,14 +7,14 @@ R=$PWD
 mkdir -p $R/gpurun_out/pmc_traffic
 cd /tmp && export TMPDIR=/tmp
 for C in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $C --output-format csv -d $R/gpurun_out/pmc_traffic/$C -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline "$@" > $R/gpurun_out/pmc_traffic/$C.log 2>&1
+  rocprofv3 --pmc $C --output-format csv -d $R/gpurun_out/pmc_traffic/$C -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-dice "$@" > $R/gpurun_out/pmc_traffic/$C.log 2>&1
 done
 cd $R
 python3 - "$OUT" <<'PY'
 import csv, glob, collections, json, re, sys
 fam = collections.defaultdict(lambda: collections.defaultdict(list))
 def family(k):                      # kernel instantiation, spelled like the names bench.py gets from the library
-    m = re.search(r"((conv_march_kernel|conv_lean_kernel_occ4|conv_lean_kernel|wgrad_lean_kernel|wgrad_march_kernel|conv_bf16_kernel|conv_wgrad_bf16_kernel)<[0-9a-z, ]+>)", k)
+    m = re.search(r"((conv_march_kernel|conv_s2_dgrad_kernel|conv_lean_kernel_occ4|conv_lean_kernel|wgrad_lean_kernel|wgrad_march_kernel|conv_bf16_kernel|conv_wgrad_bf16_kernel)<[0-9a-z, ]+>)", k)
     return m.group(1) if m else None
 for f in glob.glob("gpurun_out/pmc_traffic/*/*/*counter_collection.csv"):
     for r in csv.DictReader(open(f)):
