@@ -129,7 +129,12 @@ def _early_step_callback(model, optimizer):
     dev = next(model.parameters()).device
     st = model.__dict__.setdefault("_opt_stream", {})
     if dev not in st:
-        st[dev] = (torch.cuda.Stream(device=dev), torch.cuda.Event())
+        # HIP maps streams onto GPU_MAX_HW_QUEUES = 4 hardware queues (more cost 40 %) and streams that share a queue
+        # serialise: the model's fourth side stream carries nothing while the encoders run grouped on the main stream -- the
+        # optimizer takes it instead of a stream of its own (PASSION_OPT_OWN_STREAM=1: a new stream, for A/B)
+        side = model.__dict__.get("_streams_dev", {}).get(dev, [])
+        own = os.environ.get("PASSION_OPT_OWN_STREAM") == "1" or len(side) < 4
+        st[dev] = (torch.cuda.Stream(device=dev) if own else side[3], torch.cuda.Event())
     opt_stream, done = st[dev]
 
     def cb():
