@@ -21,6 +21,9 @@
 #include "passion_hip.h"
 #include "prof.h"
 
+int g_flash_split = 0;      // option "flash_split" / PASSION_FLASH_SPLIT: 0 = automatic, n = that many splits (1 = the unsplit kernels)
+namespace pconv { int stream_scratch(hipStream_t st, size_t zero_bytes, size_t plain_bytes, void** zero, void** plain); }   // api.cpp
+
 namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -50,6 +53,12 @@ struct FlashP {
     unsigned thr;               // keep when the 16-bit uniform >= thr; 0 = no dropout
     float inv_keep;
     unsigned s0, s1;            // seed halves
+    // split-K (small batches: fewer query tiles than SIMDs): `nsplit` workgroups share a query (key) tile, each walks 1 / nsplit of
+    // the key (query) blocks and leaves UNNORMALISED f32 partials; flash_combine_* merges them (fixed order: bit-reproducible)
+    int nsplit;
+    float* po;                  // query-major: [nsplit][B][H][N][64] partial O (forward) / dQ (backward); key-major: dK then dV
+    float* pm;                  // forward: [nsplit][B][H][N] running reference (log2 units) ...
+    float* pl;                  // ... and row sum of the split
 };
 
 // two rounds of (24-bit multiply-add, xorshift): every instruction is full rate on the vector ALU
@@ -139,7 +148,7 @@ __device__ __forceinline__ float half_sum(float v) {
 // query-major kernels: MODE 0 = forward (out, lse), MODE 1 = backward dQ
 // grid (ceil(N / (32 NW)), H, B), block 64 NW: wave w owns queries q0 .. q0+31
 template <int NW, int MODE>
-__global__ __launch_bounds__(64 * NW) void flash_q_kernel(FlashP p) {
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2))) void flash_q_kernel(FlashP p) {
     constexpr int NT = 64 * NW;
     constexpr int KIMG = BLK * RS, VIMG = (MODE == 0) ? BLK * TS : BLK * RS;
     extern __shared__ __attribute__((aligned(16))) char lds[];      // [2][K image | V image]
@@ -149,9 +158,11 @@ __global__ __launch_bounds__(64 * NW) void flash_q_kernel(FlashP p) {
     const bf16_t* qb = p.qkv + (long)b * N * rs + hh * DH;
     const bf16_t* kbase = qb + (long)p.H * DH;
     const bf16_t* vbase = qb + 2L * p.H * DH;
-    const int q0 = (blockIdx.x * NW + wv) * 32, q = q0 + (lane & 31);
+    const int split = blockIdx.x % p.nsplit;
+    const int q0 = ((blockIdx.x / p.nsplit) * NW + wv) * 32, q = q0 + (lane & 31);
     const bool qok = q < N;
-    const int nblk = (N + BLK - 1) / BLK;
+    const int nblk_all = (N + BLK - 1) / BLK;
+    const int kb0 = (int)((long)split * nblk_all / p.nsplit), nblk = (int)((long)(split + 1) * nblk_all / p.nsplit);   // key blocks [kb0, nblk)
 
     // B operands held for the whole kernel: Q^T (and dO^T) of this wave's 32 queries
     bf16x8 qf[4], dof[MODE == 1 ? 4 : 1];
@@ -176,13 +187,13 @@ __global__ __launch_bounds__(64 * NW) void flash_q_kernel(FlashP p) {
     float m_run = -INFINITY, l_run = 0.f;
 
     u32x4 kr[512 / NT], vr[512 / NT];
-    fetch_tile<NT>(kr, kbase, rs, 0, N, tid);
-    fetch_tile<NT>(vr, vbase, rs, 0, N, tid);
-    commit_tile<NT>(kr, lds, RS, tid);
-    commit_tile<NT>(vr, lds + KIMG, MODE == 0 ? TS : RS, tid);
+    fetch_tile<NT>(kr, kbase, rs, kb0 * BLK, N, tid);
+    fetch_tile<NT>(vr, vbase, rs, kb0 * BLK, N, tid);
+    commit_tile<NT>(kr, lds + (kb0 & 1) * (KIMG + VIMG), RS, tid);
+    commit_tile<NT>(vr, lds + (kb0 & 1) * (KIMG + VIMG) + KIMG, MODE == 0 ? TS : RS, tid);
     __syncthreads();
 
-    for (int kb = 0; kb < nblk; ++kb) {
+    for (int kb = kb0; kb < nblk; ++kb) {
         const char* kimg = lds + (kb & 1) * (KIMG + VIMG);
         const char* vimg = kimg + KIMG;
         if (kb + 1 < nblk) {
@@ -314,6 +325,21 @@ __global__ __launch_bounds__(64 * NW) void flash_q_kernel(FlashP p) {
         __syncthreads();
     }
 
+    if (p.nsplit > 1) {
+        // partials of this split: O^T (or dQ^T) unnormalised in f32, [split][b][h][q][d]; forward also (reference, row sum)
+        const long row = (((long)split * p.B + b) * p.H + hh) * N + q;
+        if (qok) {
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) p.po[row * DH + dt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h] = o[dt][r];
+        }
+        if (MODE == 0) {
+            const float l_tot = half_sum(l_run);
+            if (qok && h == 0) { p.pm[row] = m_run; p.pl[row] = l_tot; }
+        }
+        return;
+    }
     // ---- epilogue: scale, transpose through LDS (the tile buffers are free after the last barrier), whole 128-byte rows out
     float f;
     if (MODE == 0) {
@@ -348,7 +374,7 @@ __global__ __launch_bounds__(64 * NW) void flash_q_kernel(FlashP p) {
 // key-major backward kernel: dK, dV.  grid (ceil(N / (32 NW)), H, B); wave w owns keys k0 .. k0+31 and walks the queries in
 // steps of 64 (Q and dO staged in LDS, read by rows for S / dP and transposed for dK^T / dV^T; lse, delta beside them)
 template <int NW>
-__global__ __launch_bounds__(64 * NW) void flash_k_kernel(FlashP p) {
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2))) void flash_k_kernel(FlashP p) {
     constexpr int NT = 64 * NW;
     constexpr int IMG = BLK * RS, BUF = 2 * IMG + 2 * BLK * 4;
     extern __shared__ __attribute__((aligned(16))) char lds[];      // [2][Q image | dO image | lse[64] | delta[64]]
@@ -359,9 +385,11 @@ __global__ __launch_bounds__(64 * NW) void flash_k_kernel(FlashP p) {
     const bf16_t* dob = p.dout + (long)b * N * os + hh * DH;
     const float* lseb = p.lse + ((long)b * p.H + hh) * N;
     const float* dltb = p.delta + ((long)b * p.H + hh) * N;
-    const int k0 = (blockIdx.x * NW + wv) * 32, key = k0 + (lane & 31);
+    const int split = blockIdx.x % p.nsplit;
+    const int k0 = ((blockIdx.x / p.nsplit) * NW + wv) * 32, key = k0 + (lane & 31);
     const bool kok = key < N;
-    const int nblk = (N + BLK - 1) / BLK;
+    const int nblk_all = (N + BLK - 1) / BLK;
+    const int qb0 = (int)((long)split * nblk_all / p.nsplit), nblk = (int)((long)(split + 1) * nblk_all / p.nsplit);   // query blocks [qb0, nblk)
 
     bf16x8 kf[4], vf[4];                                  // B operands: K^T, V^T of this wave's 32 keys
 #pragma unroll
@@ -397,11 +425,11 @@ __global__ __launch_bounds__(64 * NW) void flash_k_kernel(FlashP p) {
             reinterpret_cast<float*>(buf + 2 * IMG + BLK * 4)[tid] = tr;
         }
     };
-    fetch_rows(0);
-    commit_rows(lds);
+    fetch_rows(qb0 * BLK);
+    commit_rows(lds + (qb0 & 1) * BUF);
     __syncthreads();
 
-    for (int qbk = 0; qbk < nblk; ++qbk) {
+    for (int qbk = qb0; qbk < nblk; ++qbk) {
         const char* qimg = lds + (qbk & 1) * BUF;
         const char* dimg = qimg + IMG;
         const float* lsev = reinterpret_cast<const float*>(qimg + 2 * IMG);
@@ -440,19 +468,27 @@ __global__ __launch_bounds__(64 * NW) void flash_k_kernel(FlashP p) {
             for (int g4 = 0; g4 < 4; ++g4) {
                 const f32x4 l4 = *reinterpret_cast<const f32x4*>(lsev + qt * 32 + 8 * g4 + 4 * h);
                 const f32x4 d4 = *reinterpret_cast<const f32x4*>(dltv + qt * 32 + 8 * g4 + 4 * h);
+                bool keep[4] = {true, true, true, true};
+                if (p.thr) {
+                    // lanes 2i, 2i + 1 hold the two keys of one hash word and the same queries: each hashes every other row
+                    // (its own half for itself, the other half to the neighbour through a quad permute)
+#pragma unroll
+                    for (int jp = 0; jp < 2; ++jp) {
+                        const unsigned qq = (unsigned)(q0 + qt * 32 + 8 * g4 + 4 * h + 2 * jp) + khalf;
+                        const unsigned u = drop_hash((bhrow + qq) * npair + kpair, p.s0, p.s1);
+                        const unsigned mine = __builtin_amdgcn_ubfe(u, 16u * khalf, 16u), send = __builtin_amdgcn_ubfe(u, 16u - 16u * khalf, 16u);
+                        const unsigned recv = (unsigned)__builtin_amdgcn_update_dpp(0, (int)send, 0xB1, 0xf, 0xf, false);      // quad_perm [1,0,3,2]
+                        const bool km = mine >= p.thr, ko = recv >= p.thr;
+                        keep[2 * jp] = khalf ? ko : km;
+                        keep[2 * jp + 1] = khalf ? km : ko;
+                    }
+                }
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int r = 4 * g4 + j;
-                    float pr = kok ? __builtin_amdgcn_exp2f(__builtin_fmaf(sa[r], p.c, -l4[j])) : 0.f;
-                    float dpv = da[r], pdv = pr;
-                    if (p.thr) {
-                        const unsigned qq = (unsigned)(q0 + qt * 32 + 8 * g4 + 4 * h + j);
-                        const unsigned u = drop_hash((bhrow + qq) * npair + kpair, p.s0, p.s1);
-                        const bool keep = ((khalf ? (u >> 16) : (u & 0xffffu)) >= p.thr);
-                        dpv = keep ? dpv * p.inv_keep : 0.f;
-                        pdv = keep ? pr * p.inv_keep : 0.f;
-                    }
-                    pd[r] = pdv;
+                    const float pr = kok ? __builtin_amdgcn_exp2f(__builtin_fmaf(sa[r], p.c, -l4[j])) : 0.f;
+                    const float dpv = keep[j] ? da[r] * p.inv_keep : 0.f;
+                    pd[r] = keep[j] ? pr * p.inv_keep : 0.f;
                     sa[r] = pr * (dpv - d4[j]);               // dS
                 }
             }
@@ -471,6 +507,22 @@ __global__ __launch_bounds__(64 * NW) void flash_k_kernel(FlashP p) {
         __syncthreads();
     }
 
+    if (p.nsplit > 1) {
+        // partial dK^T / dV^T of this query range, unscaled f32: po = [dK | dV], each [split][b][h][key][d]
+        const long row = (((long)split * p.B + b) * p.H + hh) * N + key;
+        const long half_ = (long)p.nsplit * p.B * p.H * N * DH;
+        if (kok) {
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int d = dt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    p.po[row * DH + d] = dk[dt][r];
+                    p.po[half_ + row * DH + d] = dv[dt][r];
+                }
+        }
+        return;
+    }
     // ---- epilogue: dK = scale * dK^T^T, dV through LDS, whole rows out
     char* obuf = lds + wv * (2 * 32 * RS);
 #pragma unroll
@@ -524,6 +576,84 @@ __global__ __launch_bounds__(256) void flash_delta_kernel(const bf16_t* __restri
     }
 }
 
+// merge of the forward partials: out[b][q][h][:] = sum_s 2^(m_s - M) O_s / sum_s 2^(m_s - M) l_s * inv_keep, lse = M + log2(L).
+// one thread per (b, h, q, 8 consecutive d); splits in index order (fixed).
+__global__ __launch_bounds__(256) void flash_combine_fwd_kernel(FlashP p) {
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;
+    const long row = t >> 3;                      // (b * H + h) * N + q
+    const int c8 = (int)(t & 7);
+    const long rows = (long)p.B * p.H * p.N;
+    if (row >= rows) return;
+    float M = -INFINITY;
+    for (int s = 0; s < p.nsplit; ++s) M = fmaxf(M, p.pm[s * rows + row]);
+    float L = 0.f, acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+    for (int s = 0; s < p.nsplit; ++s) {
+        const float w = __builtin_amdgcn_exp2f(p.pm[s * rows + row] - M);
+        L = __builtin_fmaf(w, p.pl[s * rows + row], L);
+        const f32x4 a = *reinterpret_cast<const f32x4*>(p.po + (s * rows + row) * DH + c8 * 8), c = *reinterpret_cast<const f32x4*>(p.po + (s * rows + row) * DH + c8 * 8 + 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { acc[j] = __builtin_fmaf(w, a[j], acc[j]); acc[4 + j] = __builtin_fmaf(w, c[j], acc[4 + j]); }
+    }
+    const float f = p.inv_keep / L;
+    const int q = (int)(row % p.N);
+    const long bh = row / p.N;
+    const int hh = (int)(bh % p.H);
+    const long b = bh / p.H;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] *= f;
+    VecIO<bf16_t, 8>::store(p.out + ((b * p.N + q) * p.H + hh) * DH + c8 * 8, acc);
+    if (c8 == 0) p.lse[row] = M + __builtin_amdgcn_logf(L);
+}
+
+// merge of the backward partials: slot 0 (dQ) from pq [nsplit][B][H][N][64] * scale, slots 1, 2 (dK * scale, dV) from pk = [dK | dV]
+__global__ __launch_bounds__(256) void flash_combine_bwd_kernel(FlashP p, const float* pq, const float* pk) {
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;
+    const long row = t >> 3;
+    const int c8 = (int)(t & 7);
+    const long rows = (long)p.B * p.H * p.N;
+    if (row >= rows) return;
+    const int q = (int)(row % p.N);
+    const long bh = row / p.N;
+    const int hh = (int)(bh % p.H);
+    const long b = bh / p.H;
+    const long half_ = (long)p.nsplit * rows * DH;
+    bf16_t* dst = p.dqkv + (b * p.N + q) * (3L * p.H * DH) + hh * DH + c8 * 8;
+#pragma unroll
+    for (int which = 0; which < 3; ++which) {
+        const float* src = which == 0 ? pq : (which == 1 ? pk : pk + half_);
+        float acc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+        for (int s = 0; s < p.nsplit; ++s) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(src + (s * rows + row) * DH + c8 * 8), c = *reinterpret_cast<const f32x4*>(src + (s * rows + row) * DH + c8 * 8 + 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { acc[j] += a[j]; acc[4 + j] += c[j]; }
+        }
+        const float f = which == 2 ? 1.f : p.scale;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] *= f;
+        VecIO<bf16_t, 8>::store(dst + (long)which * p.H * DH, acc);
+    }
+}
+
+// split-K factor (measured, tools/attn_split_sweep.sh: B=1 N=2048 0.276 -> 0.165 ms fwd+bwd at 4, B=2 0.308 -> 0.277 at 2,
+// B=5 0.723 -> 0.662 at 2, B=4 N=512 0.087 -> 0.081 at 4; B=20 N=512 loses): double while the launch has fewer than two waves
+// per SIMD and a split keeps >= 2 blocks, once more below 4 per SIMD when a split keeps >= 16 blocks
+int pick_split(int B, int N, int H) {
+    const long tiles = (long)((N + 31) / 32) * H * B;
+    const int nblk = (N + BLK - 1) / BLK;
+    int s = 1;
+    if (g_flash_split > 0) s = g_flash_split;
+    else {
+        while (tiles * s < 2048 && nblk / (2 * s) >= 2) s *= 2;
+        if (tiles * s < 4096 && nblk / (2 * s) >= 16) s *= 2;
+    }
+    while (s > 1 && s > nblk) --s;
+    return s;
+}
+
 int set_dropout(FlashP& p, float drop_p, uint64_t seed) {
     if (!(drop_p >= 0.f && drop_p < 1.f)) return -1003;
     p.thr = (unsigned)(drop_p * 65536.0f + 0.5f);
@@ -540,8 +670,8 @@ int grant_lds(K kern, int bytes) {
 }
 
 // waves per workgroup: 4 when that still gives the chip >= 2 workgroups per CU, else fewer
-int pick_nw(int B, int N, int H) {
-    const long tiles = (long)((N + 31) / 32) * H * B;
+int pick_nw(int B, int N, int H, int nsplit) {
+    const long tiles = (long)((N + 31) / 32) * H * B * nsplit;
     return tiles >= 4 * 512 ? 4 : (tiles >= 2 * 256 ? 2 : 1);
 }
 
@@ -559,9 +689,17 @@ extern "C" int passion_flash_attn_fwd(const void* qkv, int B, int N, int H, int 
     int rc = set_dropout(p, drop_p, seed);
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
-    const int nw = pick_nw(B, N, H);
-    const dim3 grid((N + 32 * nw - 1) / (32 * nw), H, B);
+    const int nsplit = pick_split(B, N, H);
+    const int nw = pick_nw(B, N, H, nsplit);
+    const dim3 grid((N + 32 * nw - 1) / (32 * nw) * nsplit, H, B);
     const int bytes = 2 * (BLK * RS + BLK * TS);
+    const size_t rows = (size_t)B * H * N;
+    p.nsplit = nsplit;
+    if (nsplit > 1) {
+        void* plain = nullptr;
+        if ((rc = pconv::stream_scratch(st, 0, nsplit * rows * (DH + 2) * sizeof(float), nullptr, &plain))) return rc;
+        p.po = (float*)plain; p.pm = p.po + nsplit * rows * DH; p.pl = p.pm + nsplit * rows;
+    }
     ProfScope prof(4, 2.0 * B * N * H * Dh * 2 * 2, 4.0 * B * H * (double)N * N * Dh, st);
     passion_prof_tag("flash_q_kernel<%d, 0>", nw);
     static bool granted = false;
@@ -573,6 +711,10 @@ extern "C" int passion_flash_attn_fwd(const void* qkv, int B, int N, int H, int 
     else if (nw == 2) hipLaunchKernelGGL((flash_q_kernel<2, 0>), grid, dim3(128), bytes, st, p);
     else hipLaunchKernelGGL((flash_q_kernel<1, 0>), grid, dim3(64), bytes, st, p);
     LAUNCH_RET();
+    if (nsplit > 1) {
+        hipLaunchKernelGGL(flash_combine_fwd_kernel, dim3((unsigned)((rows * 8 + 255) / 256)), dim3(256), 0, st, p);
+        LAUNCH_RET();
+    }
     return 0;
 }
 
@@ -590,9 +732,20 @@ extern "C" int passion_flash_attn_bwd(const void* qkv, const void* out, const vo
     const long rows8 = (long)B * N * H * 8;
     hipLaunchKernelGGL(flash_delta_kernel, dim3((unsigned)((rows8 + 255) / 256)), dim3(256), 0, st, (const bf16_t*)out, (const bf16_t*)dout, delta, B, N, H);
     LAUNCH_RET();
-    const int nw = pick_nw(B, N, H);
-    const dim3 grid((N + 32 * nw - 1) / (32 * nw), H, B);
+    const int nsplit = pick_split(B, N, H);
+    const int nw = pick_nw(B, N, H, nsplit);
+    const dim3 grid((N + 32 * nw - 1) / (32 * nw) * nsplit, H, B);
     const int qbytes = 2 * (2 * BLK * RS);
+    const size_t rows = (size_t)B * H * N;
+    p.nsplit = nsplit;
+    float *pq = nullptr, *pk = nullptr;
+    if (nsplit > 1) {
+        void* plain = nullptr;
+        if ((rc = pconv::stream_scratch(st, 0, 3 * nsplit * rows * DH * sizeof(float), nullptr, &plain))) return rc;
+        pq = (float*)plain; pk = pq + nsplit * rows * DH;
+    }
+    FlashP pkk = p;
+    p.po = pq; pkk.po = pk;
     const int kbytes_min = 2 * (2 * BLK * RS + 2 * BLK * 4);
     passion_prof_tag("flash_q_kernel<%d, 1> + flash_k_kernel<%d>", nw, nw);
     static bool granted = false;
@@ -605,14 +758,18 @@ extern "C" int passion_flash_attn_bwd(const void* qkv, const void* out, const vo
     const int kbytes = kbytes_min > nw * 2 * 32 * RS ? kbytes_min : nw * 2 * 32 * RS;      // the epilogue stages 2 x [32][64] per wave
     if (nw == 4) {
         hipLaunchKernelGGL((flash_q_kernel<4, 1>), grid, dim3(256), qbytes, st, p);
-        hipLaunchKernelGGL((flash_k_kernel<4>), grid, dim3(256), kbytes, st, p);
+        hipLaunchKernelGGL((flash_k_kernel<4>), grid, dim3(256), kbytes, st, pkk);
     } else if (nw == 2) {
         hipLaunchKernelGGL((flash_q_kernel<2, 1>), grid, dim3(128), qbytes, st, p);
-        hipLaunchKernelGGL((flash_k_kernel<2>), grid, dim3(128), kbytes, st, p);
+        hipLaunchKernelGGL((flash_k_kernel<2>), grid, dim3(128), kbytes, st, pkk);
     } else {
         hipLaunchKernelGGL((flash_q_kernel<1, 1>), grid, dim3(64), qbytes, st, p);
-        hipLaunchKernelGGL((flash_k_kernel<1>), grid, dim3(64), kbytes, st, p);
+        hipLaunchKernelGGL((flash_k_kernel<1>), grid, dim3(64), kbytes, st, pkk);
     }
     LAUNCH_RET();
+    if (nsplit > 1) {
+        hipLaunchKernelGGL(flash_combine_bwd_kernel, dim3((unsigned)((rows * 8 + 255) / 256)), dim3(256), 0, st, p, (const float*)pq, (const float*)pk);
+        LAUNCH_RET();
+    }
     return 0;
 }

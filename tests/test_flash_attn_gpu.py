@@ -104,10 +104,44 @@ def test_flash_attention_dropout_mask_forward_and_backward(B, N, p):
     assert e_out < 1.5e-2 and e_g < 3e-2
 
 
-def test_flash_attention_is_bitwise_reproducible():
+@pytest.mark.parametrize("B,N,split,p", [(1, 2048, 0, 0.0), (1, 2048, 4, 0.1), (1, 500, 8, 0.1), (2, 125, 2, 0.0), (4, 512, 0, 0.1), (1, 100, 3, 0.1), (5, 2048, 2, 0.1)])
+def test_flash_attention_split_keys(B, N, split, p):
+    """small batches split the key (query) range of a tile over several workgroups and merge f32 partials (option "flash_split",
+    0 = the automatic choice of the benchmarked step: B = 1, N = 2048 -> 4): same mask, same result as the f64 restatement,
+    and within bf16 rounding of the unsplit kernels"""
     from passion_amd import ops
     dev = torch.device("cuda:0")
-    qkv, go = _inputs(5, 2048, seed=21)
+    qkv, go = _inputs(B, N, seed=31)
+    keep, inv_keep = None, 1.0
+    if p:
+        torch.manual_seed(99)
+        keep, inv_keep = _hash_keep(B, N, p, ops._draw_seed())
+    outr, gr = _reference(qkv, go, keep, inv_keep)
+    res = {}
+    for sp in (1, split):
+        old = ops.set_option("flash_split", sp)
+        try:
+            qd = qkv.to(dev).requires_grad_(True)
+            torch.manual_seed(99)
+            out = ops.attention(qd, H, DH ** -0.5, p)
+            out.backward(go.to(dev))
+            res[sp] = (out.detach().clone(), qd.grad.clone())
+        finally:
+            ops.set_option("flash_split", old)
+    e_out, e_g = _relerr(res[split][0], outr), _relerr(res[split][1], gr)
+    d_out, d_g = _relerr(res[split][0], res[1][0].double().cpu()), _relerr(res[split][1], res[1][1].double().cpu())
+    print(f"flash split={split} B={B} N={N} p={p}: vs f64 out {e_out:.2e} dqkv {e_g:.2e}; vs unsplit out {d_out:.2e} dqkv {d_g:.2e}")
+    assert e_out < 1.5e-2 and e_g < 3e-2 and d_out < 1e-2 and d_g < 1.6e-2
+    for i, nm in enumerate("qkv"):
+        sl = slice(i * H * DH, (i + 1) * H * DH)
+        assert _relerr(res[split][1][..., sl], gr[..., sl]) < 3e-2, nm
+
+
+@pytest.mark.parametrize("B", [5, 1])
+def test_flash_attention_is_bitwise_reproducible(B):
+    from passion_amd import ops
+    dev = torch.device("cuda:0")
+    qkv, go = _inputs(B, 2048, seed=21)
     outs = []
     for _ in range(2):
         qd = qkv.to(dev).requires_grad_(True)
