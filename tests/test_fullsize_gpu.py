@@ -71,6 +71,40 @@ def test_absent_modality_is_never_read(model):
     assert float((s - 1).abs().max()) < 1e-5 and bool(torch.isfinite(a).all())
 
 
+def test_a_batch_mate_cannot_change_a_sample_bit_for_bit(model):
+    """the sharp form of batch independence for the bf16 benchmarked kernels: with the batch SIZE fixed (same workgroup split,
+    same summation order) a sample's outputs, and every weight gradient of a loss that only looks at that sample, must not move
+    by one bit when its batch mate's volume, label AND modality mask change -- a statistic, a mask byte, a weight-gradient slot
+    or a scratch region shared between samples would (the mate's own contribution to those gradients is an exact zero).
+    (The tolerance test below compares batch sizes 2 and 1, where the split itself differs.)"""
+    dev = _dev()
+    x, t = synth(2, S)
+    x, t = x.to(dev), t.to(dev)
+    model.is_training, model.use_passion = True, False
+    res = []
+    for variant in range(2):
+        xv, tv = x.clone(), t.clone()
+        mask = torch.tensor([[True, True, True, True], [True, False, False, True]], device=dev)
+        if variant:
+            xv[0] = torch.randn_like(xv[0]) * 3 + 1
+            tv[0] = tv[0].flip(1)
+            mask[0] = torch.tensor([False, True, True, False], device=dev)
+        outs = model(xv, mask, target=tv, temp=4.0)
+        # a loss of sample 1 alone: its gradient must not see sample 0 either
+        loss = (outs[0][1:].float() * torch.linspace(0.5, 1.5, 4, device=dev).view(1, 4, 1, 1, 1)).sum() + outs[1][1:].sum() + outs[2][1:].sum()
+        loss.backward()
+        res.append((outs[0][1:].detach().clone(), [o[1:].detach().clone() for o in outs[1:3]],
+                    {n: q.grad.clone() for n, q in model.named_parameters() if q.grad is not None}))
+        model.zero_grad(set_to_none=True)
+    assert torch.equal(res[0][0], res[1][0])
+    for u, v in zip(res[0][1], res[1][1]):
+        assert torch.equal(u, v)
+    assert len(res[0][2]) > 200 and res[0][2].keys() == res[1][2].keys()
+    bad = [n for n in res[0][2] if not torch.equal(res[0][2][n], res[1][2][n])]
+    assert not bad, bad[:8]
+    assert all(bool(torch.isfinite(v).all()) for v in res[0][2].values())
+
+
 def test_samples_of_a_batch_are_independent(model):
     dev = _dev()
     x, t = synth(2, S)
