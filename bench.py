@@ -46,7 +46,7 @@ def parse():
                     help="untimed set-up iterations before the W warm-up steps: the caching allocator keeps one pool per HIP "
                          "stream (the four encoder branches run on their own streams) and needs a few iterations to stop "
                          "calling hipMalloc; part of building the step, like compiling a graph would be")
-    ap.add_argument("--workload", default="mmformer128", choices=["mmformer128", "mmformer128_passion", "rfnet128_passion", "mmformer_depth"],
+    ap.add_argument("--workload", default="mmformer128", choices=["mmformer128", "mmformer128_passion", "rfnet128_passion", "mmformer_depth", "m2ftrans128", "m2ftrans128_passion"],
                     help="BASELINE.json configs[1] (default) / configs[2] (+ PASSION self-distillation, masks sampled from the "
                          "brats_split mr2468 distribution) / configs[3] (RFNet + PASSION, batch 2 per GPU) / configs[4] (mmformer_depth: "
                          "ONE 240 x 240 x 155 volume per step, padded to 160 planes -- to a multiple of 16 N for N ranks -- and split "
@@ -241,6 +241,7 @@ def main():
 
     is_rfnet = args.workload.startswith("rfnet")
     is_depth = args.workload == "mmformer_depth"
+    is_m2f = args.workload.startswith("m2ftrans")          # measured beside the configs, not one of them
     cfg_no = 4 if is_depth else (3 if is_rfnet else (2 if passion else 1))
     mask_mode = args.masks or ("split" if cfg_no == 2 else "full")
     batch = 2 if is_rfnet else 1
@@ -248,6 +249,10 @@ def main():
     if is_rfnet:
         from passion_amd.models import rfnet
         model = rfnet.Model(num_cls=4).to(ctx.device)
+    elif is_m2f:
+        from passion_amd.models import m2ftrans
+        m2ftrans.patch_size = S // 16
+        model = m2ftrans.Model(num_cls=4).to(ctx.device)
     elif is_depth:
         # configs[4]: the whole 240 x 240 x 155 volume, D padded to 160 (and on to a multiple of 16 * world so that every level
         # splits evenly: 160 / 160 / 192 / 256 planes at 1 / 2 / 4 / 8 ranks); token grid (Dp / 16, 15, 15)
@@ -404,9 +409,9 @@ def main():
         "unit": "volumes/s", "n_gpus": ctx.world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "bf16" if dtype == torch.bfloat16 else "f32", "data": "synthetic",
-        "config": {"workload": f"{'rfnet' if is_rfnet else 'mmformer'}{'+PASSION' if passion else ''} train step, 4x{S}^3 volume, "
+        "config": {"workload": f"{'rfnet' if is_rfnet else ('m2ftrans' if is_m2f else 'mmformer')}{'+PASSION' if passion else ''} train step, 4x{S}^3 volume, "
                                f"batch {batch}/GPU, mask_type idt, {mask_txt}, AdamW(amsgrad)"
-                               f"{'' if is_rfnet else ', dropout 0.1'} (BASELINE.json configs[{cfg_no}])",
+                               f"{'' if is_rfnet else ', dropout 0.1'} ({'SURVEY 8(f) N4, the m2ftrans backbone' if is_m2f else f'BASELINE.json configs[{cfg_no}]'})",
                    "global_batch": batch * ctx.world, "parallelism": f"dp{ctx.world} (RCCL grad all-reduce, sum)",
                    "world_size_seen": dist.get_world_size() if dist.is_initialized() else 1, "dist_backend": ctx.backend,
                    "allreduce_bytes_per_step": grad_bytes if ctx.world > 1 else 0,

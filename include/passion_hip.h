@@ -267,6 +267,22 @@ int passion_scale_nearest_bwd(const void* dy, const float* w, void* dx, int dtyp
 int passion_attn_scores_masked_fwd(const void* qkv, int dtype, int B, int N, int H, int Dh, float scale, const uint8_t* allow, int G,
                                    float* probs, void* stream);
 
+/* LayerNorm over the channels of a channels-last token volume fused with what follows it in the cross-token blocks
+ * (DepthWiseConvBlock / GroupConvBlock, blocks.py:32-109):  y = act(LN(x) * gamma + beta [+ res]),  act 0 = identity, 1 = GELU
+ * (erf form).  x, res (or NULL), y, dy, dx, dres (or NULL): [rows][C] in `dtype`; the rows form rows / rows_per_group groups
+ * with their own gamma / beta [G][C] f32 (G blocks of equal shape in one launch: the key_map_* / value_map_* blocks of
+ * MultiMaskAttentionLayer, blocks.py:246-297).  stat [rows][2] f32 = (mean, rstd), written by fwd and read by bwd.
+ * C: a multiple of 8 with C / 8 a power of two, <= 512 (passion_ln_act_supported).  bwd: dres = dy * act'(z) (only needed with
+ * act = 1: with act = 0 the residual's gradient is dy itself); dgamma / dbeta [G][C] f32 through `part`
+ * (passion_ln_act_part_floats floats), folded in a fixed order. */
+int passion_ln_act_supported(int64_t rows, int C, int64_t rows_per_group);
+int64_t passion_ln_act_part_floats(int64_t rows, int C, int64_t rows_per_group);
+int passion_ln_act_fwd(const void* x, const float* gamma, const float* beta, const void* res, void* y, float* stat, int dtype,
+                       int64_t rows, int C, int64_t rows_per_group, float eps, int act, void* stream);
+int passion_ln_act_bwd(const void* x, const float* gamma, const float* beta, const void* res, const float* stat, const void* dy,
+                       void* dx, void* dres, float* part, float* dgamma, float* dbeta, int dtype, int64_t rows, int C,
+                       int64_t rows_per_group, int act, void* stream);
+
 /* Attention dropout (nn.Dropout on the attention probabilities, code/models/mmformer.py:222) in one pass and without a
  * stored mask: y[i] = keep(i) ? x[i] / (1 - p) : 0 with keep(i) ~ Bernoulli(1 - p) drawn from a counter-based hash of
  * (seed, i).  The same (seed, p) reproduces the mask, which is how the backward applies it to dprobs.  y may alias x. */

@@ -1,0 +1,225 @@
+// Token-volume ops of the m2ftrans cross-token blocks (reference code/models/blocks.py:32-109 DepthWiseConvBlock /
+// GroupConvBlock): LayerNorm over the channels of a channels-last tensor, fused with what follows it in the reference --
+//     y = act(LN(x) * gamma + beta [+ res]),   act = identity | GELU (erf form, torch's default)
+// forward and backward, for G independent weight sets over G equal row groups of one launch (the four key_map_* and four
+// value_map_* blocks of a MultiMaskAttentionLayer share every shape: blocks.py:246-297).  torch needs a cast, a LayerNorm and
+// a cast (forward) plus five kernels (backward) per call and a step of the model has 170 of them: the model was bound by
+// the host's launch rate (3800 launches per step), not by the GPU.
+// Layout: a row = C channels, C / 8 lanes per row (one 16-byte access per lane and tensor for bf16), 64 / (C / 8) rows per
+// wavefront; row moments by butterfly shuffles inside the row's lanes.  Backward: gamma / beta gradients as per-block partial
+// sums (rows of one group only) folded in block order by a second kernel: no atomics, results repeat bit for bit.
+#include "common.h"
+#include "passion_hip.h"
+
+namespace {
+
+constexpr int LN_MAX_C = 512;
+constexpr float INV_SQRT2 = 0.70710678118654752f, INV_SQRT_2PI = 0.39894228040143268f;
+
+template <typename T> __device__ __forceinline__ void ld8(const T* p, float (&v)[8]);
+template <> __device__ __forceinline__ void ld8<bf16_t>(const bf16_t* p, float (&v)[8]) { VecIO<bf16_t, 8>::load(p, v); }
+template <> __device__ __forceinline__ void ld8<float>(const float* p, float (&v)[8]) {
+    const f32x4 a = load4(p), b = load4(p + 4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { v[j] = a[j]; v[4 + j] = b[j]; }
+}
+template <typename T> __device__ __forceinline__ void st8(T* p, const float (&v)[8]);
+template <> __device__ __forceinline__ void st8<bf16_t>(bf16_t* p, const float (&v)[8]) { VecIO<bf16_t, 8>::store(p, v); }
+template <> __device__ __forceinline__ void st8<float>(float* p, const float (&v)[8]) {
+    store4(p, (f32x4){v[0], v[1], v[2], v[3]});
+    store4(p + 4, (f32x4){v[4], v[5], v[6], v[7]});
+}
+
+// sum over the `lpr` (power of two) consecutive lanes that hold one row
+__device__ __forceinline__ float row_sum(float v, int lpr) {
+    for (int o = lpr >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+__device__ __forceinline__ float gelu_f(float z) { return 0.5f * z * (1.f + erff(z * INV_SQRT2)); }
+__device__ __forceinline__ float gelu_d(float z) {
+    return 0.5f * (1.f + erff(z * INV_SQRT2)) + z * INV_SQRT_2PI * __expf(-0.5f * z * z);
+}
+
+// rows [0, rows) in G = rows / rpg groups; gamma / beta: [G][C]
+template <typename T>
+__global__ __launch_bounds__(256) void ln_act_fwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                         const T* __restrict__ res, T* __restrict__ y, float* __restrict__ stat,
+                                                         long rows, int C, long rpg, float eps, int act) {
+    const int lpr = C >> 3, rpw = 64 / lpr;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int sub = lane / lpr, cl = (lane % lpr) * 8;
+    const float invC = 1.f / (float)C;
+    for (long r0 = ((long)blockIdx.x * 4 + wv) * rpw; r0 < rows; r0 += (long)gridDim.x * 4 * rpw) {
+        const long r = r0 + sub;
+        const bool ok = r < rows;
+        const long rr = ok ? r : rows - 1;
+        float v[8];
+        ld8<T>(x + rr * C + cl, v);
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s += v[j];
+        const float mean = row_sum(s, lpr) * invC;
+        float q = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { v[j] -= mean; q = __builtin_fmaf(v[j], v[j], q); }
+        const float rstd = 1.f / sqrtf(row_sum(q, lpr) * invC + eps);
+        const long g = rr / rpg;
+        float ga[8], be[8], rv[8];
+        ld8<float>(gamma + g * C + cl, ga);
+        ld8<float>(beta + g * C + cl, be);
+        if (res) ld8<T>(res + rr * C + cl, rv);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float z = __builtin_fmaf(v[j] * rstd, ga[j], be[j]);
+            if (res) z += rv[j];
+            v[j] = act ? gelu_f(z) : z;
+        }
+        if (ok) {
+            st8<T>(y + r * C + cl, v);
+            if ((lane % lpr) == 0) { stat[2 * r] = mean; stat[2 * r + 1] = rstd; }
+        }
+    }
+}
+
+// grid (nblk, G): block (k, g) owns rows g * rpg + [k * chunk, (k + 1) * chunk) and leaves its column sums in part[g][k][2][C]
+template <typename T>
+__global__ __launch_bounds__(256) void ln_act_bwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                         const T* __restrict__ res, const float* __restrict__ stat, const T* __restrict__ dy,
+                                                         T* __restrict__ dx, T* __restrict__ dres, float* __restrict__ part,
+                                                         int C, long rpg, long chunk, int act) {
+    __shared__ float red[4 * 64 * 16];                 // [wave][lane][2][8]
+    const int lpr = C >> 3, rpw = 64 / lpr;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int sub = lane / lpr, cl = (lane % lpr) * 8;
+    const float invC = 1.f / (float)C;
+    const int g = blockIdx.y;
+    const long lo = (long)blockIdx.x * chunk, hi = lo + chunk < rpg ? lo + chunk : rpg;
+    float ga[8], be[8], ag[8], ab[8];
+    ld8<float>(gamma + (long)g * C + cl, ga);
+    if (act) ld8<float>(beta + (long)g * C + cl, be);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { ag[j] = 0.f; ab[j] = 0.f; }
+    for (long r0 = lo + (long)wv * rpw; r0 < hi; r0 += 4 * rpw) {
+        const long rl = r0 + sub;
+        const bool ok = rl < hi;
+        const long r = (long)g * rpg + (ok ? rl : hi - 1);
+        float xv[8], gv[8], rv[8];
+        ld8<T>(x + r * C + cl, xv);
+        ld8<T>(dy + r * C + cl, gv);
+        if (act && res) ld8<T>(res + r * C + cl, rv);
+        const float mean = stat[2 * r], rstd = stat[2 * r + 1];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float xh = (xv[j] - mean) * rstd;
+            float dz = gv[j];
+            if (act) {
+                float z = __builtin_fmaf(xh, ga[j], be[j]);
+                if (res) z += rv[j];
+                dz *= gelu_d(z);
+            }
+            if (!ok) dz = 0.f;
+            gv[j] = dz;                                  // dz (= dres)
+            xv[j] = xh;
+            ag[j] = __builtin_fmaf(dz, xh, ag[j]);
+            ab[j] += dz;
+            const float dh = dz * ga[j];
+            s1 += dh;
+            s2 = __builtin_fmaf(dh, xh, s2);
+        }
+        const float m1 = row_sum(s1, lpr) * invC, m2 = row_sum(s2, lpr) * invC;
+        float o[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = rstd * (gv[j] * ga[j] - m1 - xv[j] * m2);
+        if (ok) {
+            st8<T>(dx + r * C + cl, o);
+            if (dres) st8<T>(dres + r * C + cl, gv);
+        }
+    }
+    // column sums: lanes with the same channel slice (lane % lpr) over the 4 waves and rpw row slots, fixed order
+    float* mine = red + ((wv * 64 + lane) * 16);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { mine[j] = ag[j]; mine[8 + j] = ab[j]; }
+    __syncthreads();
+    float* out = part + ((long)g * gridDim.x + blockIdx.x) * 2 * C;
+    for (int i = threadIdx.x; i < 2 * C; i += 256) {
+        const int k = i / C, c = i % C, sl = c >> 3, j = c & 7;
+        float t = 0.f;
+        for (int w2 = 0; w2 < 4; ++w2)
+            for (int s = 0; s < rpw; ++s) t += red[((w2 * 64 + s * lpr + sl) * 16) + k * 8 + j];
+        out[i] = t;
+    }
+}
+
+// dgamma[g][c] = sum_k part[g][k][0][c], dbeta[g][c] = sum_k part[g][k][1][c]
+__global__ __launch_bounds__(256) void ln_fold_kernel(const float* __restrict__ part, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                      int G, int nblk, int C) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long)G * 2 * C) return;
+    const int c = (int)(i % C), k = (int)((i / C) % 2), g = (int)(i / (2L * C));
+    const float* p = part + (long)g * nblk * 2 * C + (long)k * C + c;
+    float t = 0.f;
+    for (int b = 0; b < nblk; ++b) t += p[(long)b * 2 * C];
+    (k ? dbeta : dgamma)[(long)g * C + c] = t;
+}
+
+bool ln_shape_ok(long rows, int C, long rpg) {
+    if (rows <= 0 || rpg <= 0 || rows % rpg || C < 8 || C > LN_MAX_C || (C & 7)) return false;
+    const int lpr = C >> 3;
+    return (lpr & (lpr - 1)) == 0;
+}
+
+int ln_nblk(long rpg, int C) {
+    const int rpw = 64 / (C >> 3);
+    const long per_pass = 4L * rpw;                       // rows one block covers per loop trip
+    long n = (rpg + 4 * per_pass - 1) / (4 * per_pass);   // >= 4 trips per block
+    return (int)hmax(1, hmin(n, 256));
+}
+
+}  // namespace
+
+extern "C" int passion_ln_act_supported(int64_t rows, int C, int64_t rows_per_group) { return ln_shape_ok(rows, C, rows_per_group) ? 1 : 0; }
+
+extern "C" int64_t passion_ln_act_part_floats(int64_t rows, int C, int64_t rows_per_group) {
+    if (!ln_shape_ok(rows, C, rows_per_group)) return 0;
+    return (rows / rows_per_group) * (long)ln_nblk(rows_per_group, C) * 2 * C;
+}
+
+extern "C" int passion_ln_act_fwd(const void* x, const float* gamma, const float* beta, const void* res, void* y, float* stat, int dtype,
+                                  int64_t rows, int C, int64_t rows_per_group, float eps, int act, void* stream) {
+    if (!ln_shape_ok(rows, C, rows_per_group)) return -1003;
+    if (dtype != PASSION_F32 && dtype != PASSION_BF16) return -1007;
+    const int rpw = 64 / (C >> 3);
+    const long groups = (rows + 4L * rpw - 1) / (4L * rpw);
+    const unsigned grid = (unsigned)hmin(groups, 8192);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == PASSION_F32)
+        hipLaunchKernelGGL(ln_act_fwd_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)x, gamma, beta, (const float*)res, (float*)y, stat,
+                           rows, C, rows_per_group, eps, act);
+    else
+        hipLaunchKernelGGL(ln_act_fwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, (const bf16_t*)x, gamma, beta, (const bf16_t*)res, (bf16_t*)y, stat,
+                           rows, C, rows_per_group, eps, act);
+    LAUNCH_RET();
+    return 0;
+}
+
+extern "C" int passion_ln_act_bwd(const void* x, const float* gamma, const float* beta, const void* res, const float* stat, const void* dy,
+                                  void* dx, void* dres, float* part, float* dgamma, float* dbeta, int dtype, int64_t rows, int C,
+                                  int64_t rows_per_group, int act, void* stream) {
+    if (!ln_shape_ok(rows, C, rows_per_group)) return -1003;
+    if (dtype != PASSION_F32 && dtype != PASSION_BF16) return -1007;
+    const int G = (int)(rows / rows_per_group), nblk = ln_nblk(rows_per_group, C);
+    const long chunk = (rows_per_group + nblk - 1) / nblk;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == PASSION_F32)
+        hipLaunchKernelGGL(ln_act_bwd_kernel<float>, dim3(nblk, G), dim3(256), 0, st, (const float*)x, gamma, beta, (const float*)res, stat,
+                           (const float*)dy, (float*)dx, (float*)dres, part, C, rows_per_group, chunk, act);
+    else
+        hipLaunchKernelGGL(ln_act_bwd_kernel<bf16_t>, dim3(nblk, G), dim3(256), 0, st, (const bf16_t*)x, gamma, beta, (const bf16_t*)res, stat,
+                           (const bf16_t*)dy, (bf16_t*)dx, (bf16_t*)dres, part, C, rows_per_group, chunk, act);
+    LAUNCH_RET();
+    hipLaunchKernelGGL(ln_fold_kernel, dim3((unsigned)(((long)G * 2 * C + 255) / 256)), dim3(256), 0, st, part, dgamma, dbeta, G, nblk, C);
+    LAUNCH_RET();
+    return 0;
+}

@@ -334,10 +334,18 @@ def _pw(conv, x):
     return ops.linear(x, conv.weight, conv.bias, _bf16(x))
 
 
-def _ln(norm, x):
-    """LayerNorm over the channels of a channels-last tensor: f32 statistics and affine, result in the tensor's dtype"""
-    y = torch.nn.functional.layer_norm(x.float(), (x.shape[-1],), norm.weight, norm.bias, norm.eps)
-    return y if x.dtype == torch.float32 else y.to(x.dtype)
+def _ln(norm, x, act=False, res=None):
+    """act(LayerNorm over the channels of a channels-last tensor [+ res]), act = GELU or nothing: one fused launch
+    (ops.ln_act, csrc/token_ops.hip: f32 statistics and affine, result in the tensor's dtype); channel counts the kernel does
+    not take go through torch"""
+    C = x.shape[-1]
+    if x.is_cuda and C % 8 == 0 and C <= 512 and ((C // 8) & (C // 8 - 1)) == 0:
+        return ops.ln_act(x, norm, act, res)
+    y = torch.nn.functional.layer_norm(x.float(), (C,), norm.weight, norm.bias, norm.eps)
+    y = y if x.dtype == torch.float32 else y.to(x.dtype)
+    if res is not None:
+        y = y + res
+    return torch.nn.functional.gelu(y) if act else y
 
 
 class DepthWiseConvBlock(nn.Module):
@@ -356,9 +364,8 @@ class DepthWiseConvBlock(nn.Module):
         self.norm3 = nn.LayerNorm(out_channels, eps=1e-6)
 
     def forward(self, x):
-        gelu = torch.nn.functional.gelu
-        x = gelu(_ln(self.norm1, _pw(self.conv1, x)))
-        x = gelu(_ln(self.norm2, ops.group_conv3d(x, self.conv2.weight, self.conv2.bias)))
+        x = _ln(self.norm1, _pw(self.conv1, x), act=True)
+        x = _ln(self.norm2, ops.group_conv3d(x, self.conv2.weight, self.conv2.bias), act=True)
         return _ln(self.norm3, _pw(self.conv3, x))
 
 
@@ -380,11 +387,13 @@ class GroupConvBlock(nn.Module):
         self.proj_drop = nn.Dropout(proj_drop)
 
     def forward(self, x, identity=None):
-        gelu = torch.nn.functional.gelu
-        h = gelu(_ln(self.norm1, _pw(self.pwconv1, x)))
-        h = gelu(_ln(self.norm2, ops.group_conv3d(h, self.dwconv.weight, self.dwconv.bias)))
+        h = _ln(self.norm1, _pw(self.pwconv1, x), act=True)
+        h = _ln(self.norm2, ops.group_conv3d(h, self.dwconv.weight, self.dwconv.bias), act=True)
+        idt = x if identity is None else identity
+        if not (self.training and self.proj_drop.p > 0):
+            return _ln(self.norm3, _pw(self.pwconv2, h), act=True, res=idt)        # LN -> + identity -> GELU in one launch
         h = _ln(self.norm3, _pw(self.pwconv2, h))
-        return gelu((x if identity is None else identity) + self.proj_drop(h))
+        return torch.nn.functional.gelu(idt + self.proj_drop(h))
 
 
 class MultiMaskAttentionLayer(nn.Module):

@@ -1015,6 +1015,76 @@ def masked_attention(qkv, allow, heads, scale, drop_p=0.0):
     return MaskedAttentionFn.apply(qkv, allow, heads, scale, drop_p)
 
 
+_F32_STACKS = {}
+
+
+def f32_stack(params):
+    """G same-shaped f32 parameters back to back in one (G, *shape) buffer, re-stacked only when one of them changed"""
+    if len(params) == 1:
+        return params[0].detach().unsqueeze(0)
+    key = tuple(id(p) for p in params)
+    ver = tuple((p.data_ptr(), p._version) for p in params)
+    ent = _F32_STACKS.get(key)
+    if ent is None or ent[1] != ver or ent[0].device != params[0].device:
+        buf = ent[0] if ent is not None and ent[0].device == params[0].device else None
+        buf = torch.stack([p.detach() for p in params], out=buf) if buf is not None else torch.stack([p.detach() for p in params])
+        ent = _F32_STACKS[key] = (buf, ver)
+    return ent[0]
+
+
+class LnActFn(torch.autograd.Function):
+    """y = act(LayerNorm_C(x) * gamma + beta [+ res]) for G row groups with their own (gamma, beta): the LayerNorm -> GELU pairs
+    and the LayerNorm -> residual -> GELU tail of DepthWiseConvBlock / GroupConvBlock (reference blocks.py:32-109), one launch
+    forward, two backward (csrc/token_ops.hip).  x: (G, R, C) or any (..., C) with G = 1; params: G gammas then G betas."""
+
+    @staticmethod
+    def forward(ctx, x, res, act, eps, G, *params):
+        L.require_gpu(x)
+        x = x.contiguous()
+        C = x.shape[-1]
+        rows = x.numel() // C
+        gam, bet = f32_stack(params[:G]), f32_stack(params[G:])
+        if res is not None:
+            res = res.contiguous()
+            assert res.shape == x.shape and res.dtype == x.dtype
+        y = torch.empty_like(x)
+        stat = torch.empty(rows, 2, dtype=torch.float32, device=x.device)
+        L.check(L.load().passion_ln_act_fwd(_p(x), _p(gam), _p(bet), _p(res), _p(y), _p(stat), L.dtype_code(x.dtype), rows, C, rows // G,
+                                            float(eps), int(act), L.stream_ptr()), "passion_ln_act_fwd")
+        ctx.save_for_backward(x, res if act else None, stat, gam, bet)
+        ctx.act, ctx.G, ctx.has_res = int(act), G, res is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, res, stat, gam, bet = ctx.saved_tensors
+        G, C = ctx.G, x.shape[-1]
+        rows = x.numel() // C
+        dy = dy.contiguous()
+        lib = L.load()
+        dx = torch.empty_like(x)
+        dres = torch.empty_like(x) if (ctx.has_res and ctx.act) else None
+        part = torch.empty(lib.passion_ln_act_part_floats(rows, C, rows // G), dtype=torch.float32, device=x.device)
+        dgb = torch.empty(2, G, C, dtype=torch.float32, device=x.device)
+        L.check(lib.passion_ln_act_bwd(_p(x), _p(gam), _p(bet), _p(res), _p(stat), _p(dy), _p(dx), _p(dres), _p(part), _p(dgb[0]), _p(dgb[1]),
+                                       L.dtype_code(x.dtype), rows, C, rows // G, ctx.act, L.stream_ptr()), "passion_ln_act_bwd")
+        if ctx.has_res and not ctx.act:
+            dres = dy
+        return (dx, dres, None, None, None, *[dgb[0, g] for g in range(G)], *[dgb[1, g] for g in range(G)])
+
+
+def ln_act(x, norms, act=False, res=None):
+    """norms: one nn.LayerNorm or a list of G (x then is (G, R, C), group g normalised with norms[g]'s affine)"""
+    if not isinstance(norms, (list, tuple)):
+        norms = [norms]
+    G, C = len(norms), x.shape[-1]
+    rows = x.numel() // C
+    assert G == 1 or x.shape[0] == G
+    if not (x.is_cuda and L.load().passion_ln_act_supported(rows, C, rows // G)):
+        raise RuntimeError(f"ln_act: unsupported shape rows={rows} C={C} G={G} (C / 8 must be a power of two, C <= 512) or not on the GPU")
+    return LnActFn.apply(x, res, bool(act), norms[0].eps, G, *[n.weight for n in norms], *[n.bias for n in norms])
+
+
 class GroupConvFn(torch.autograd.Function):
     """grouped 3x3x3 Conv3d (zero padding, stride 1, in = out channels, `cpg` channels per group) on channels-last tensors:
     DepthWiseConvBlock.conv2 / GroupConvBlock.dwconv of the m2ftrans cross-token blocks (reference blocks.py:45-47, 77-79)"""
