@@ -247,12 +247,16 @@ int passion_flash_attn_bwd(const void* qkv, const void* out, const void* dout, c
 /* ---- m2ftrans backbone (reference code/models/m2ftrans.py, code/models/blocks.py:25-297, code/models/mask.py) ----
  * gconv3d: grouped 3x3x3 Conv3d with C input = C output channels in groups of `cpg` (1: DepthWiseConvBlock.conv2, blocks.py:45-47,
  * nn.Conv3d(C, C, 3, 1, 1, groups=C); 4: GroupConvBlock.dwconv, blocks.py:77-79, groups = C / 4), zero padding, stride 1.
- * x, y, dy, dx: channels-last [B][D][H][W][C] in `dtype`; weight: the reference layout [C][cpg][3][3][3] f32; bias [C] f32 or NULL.
- * bwd: dx / (dweight [C][cpg][27], dbias [C]) may be NULL; fixed-order sums (bitwise reproducible). */
+ * x, y, dy, dx: channels-last [B][D][H][W][C] in `dtype`; weight: `wsets` sets in the reference layout [wsets][C][cpg][3][3][3] f32,
+ * bias [wsets][C] f32 or NULL; sample b uses set b / (B / wsets) (the four key_map_* and four value_map_* blocks of a
+ * MultiMaskAttentionLayer, blocks.py:246-297, as one batch; wsets > 1 needs C % 64 == 0 or C in {8, 16, 32}).
+ * bwd: dx / (dweight [wsets][C][cpg][27], dbias [wsets][C]) may be NULL; `part`: passion_gconv3d_part_floats floats of scratch
+ * for the weight gradient (may be NULL when that returns 0); fixed-order sums (bitwise reproducible). */
+int64_t passion_gconv3d_part_floats(int B, int D, int H, int W, int C, int cpg, int wsets);
 int passion_gconv3d_fwd(const void* x, const float* weight, const float* bias, void* y, int dtype, int B, int D, int H, int W, int C,
-                        int cpg, void* stream);
-int passion_gconv3d_bwd(const void* x, const float* weight, const void* dy, void* dx, float* dweight, float* dbias, int dtype, int B,
-                        int D, int H, int W, int C, int cpg, void* stream);
+                        int cpg, int wsets, void* stream);
+int passion_gconv3d_bwd(const void* x, const float* weight, const void* dy, void* dx, float* dweight, float* dbias, float* part, int dtype,
+                        int B, int D, int H, int W, int C, int cpg, int wsets, void* stream);
 /* Weight_Attention (m2ftrans.py:420-460): y[b][v][:] = x[b % Bx][v][:] * w[b][v >> k] -- a [Bx][D][H][W][C] feature map scaled by the
  * nearest-upsampled (x 2^k per axis) weight maps w [Bv][D >> k][H >> k][W >> k] f32 of Bv / Bx masked passes (teacher + students)
  * in one launch.  bwd: dx[bx] = sum over the passes of dy * w (w carries no gradient: the attention maps are detached, :380). */

@@ -107,9 +107,10 @@ SIGNATURES = {
     "passion_flash_attn_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_float,
                                        ctypes.c_uint64, c_void_p, c_void_p, c_void_p]),
     "passion_dropout": (c_int, [c_void_p, c_void_p, c_int64, ctypes.c_float, ctypes.c_uint64, c_void_p]),
-    "passion_gconv3d_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
-    "passion_gconv3d_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
-                                    c_int, c_void_p]),
+    "passion_gconv3d_part_floats": (c_int64, [c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
+    "passion_gconv3d_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "passion_gconv3d_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                                    c_int, c_int, c_int, c_void_p]),
     "passion_ln_act_supported": (c_int, [c_int64, c_int, c_int64]),
     "passion_ln_act_part_floats": (c_int64, [c_int64, c_int, c_int64]),
     "passion_ln_act_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int, c_int64, c_float, c_int,

@@ -116,6 +116,160 @@ __global__ __launch_bounds__(256) void gconv_wgrad_kernel(const T* __restrict__ 
     }
 }
 
+// ---- channel-vectorised forms (round 3): the scalar kernels above spend a 2-byte load per multiply-add and, in the weight
+// gradient, one wavefront per weight striding through the volume (6.7 ms of a 50 ms m2ftrans step).  Here a thread owns the
+// 8 consecutive channels of one voxel (one 16-byte access per tap), a block owns a range of CB <= 64 channels whose weights
+// it stages in LDS as tab[tap][i][c], and `wsets` weight sets share a launch: sample b uses set b / (B / wsets) -- the four
+// key_map_* and four value_map_* blocks of MultiMaskAttentionLayer (blocks.py:246-297) run as ONE batch of 8 B samples.
+// Forward and input gradient are the same kernel over differently staged tables (gather form, taps mirrored).
+template <typename T> __device__ __forceinline__ void gld8(const T* p, float (&v)[8]);
+template <> __device__ __forceinline__ void gld8<bf16_t>(const bf16_t* p, float (&v)[8]) { VecIO<bf16_t, 8>::load(p, v); }
+template <> __device__ __forceinline__ void gld8<float>(const float* p, float (&v)[8]) {
+    const f32x4 a = load4(p), b = load4(p + 4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { v[j] = a[j]; v[4 + j] = b[j]; }
+}
+template <typename T> __device__ __forceinline__ void gst8(T* p, const float (&v)[8]);
+template <> __device__ __forceinline__ void gst8<bf16_t>(bf16_t* p, const float (&v)[8]) { VecIO<bf16_t, 8>::store(p, v); }
+template <> __device__ __forceinline__ void gst8<float>(float* p, const float (&v)[8]) {
+    store4(p, (f32x4){v[0], v[1], v[2], v[3]});
+    store4(p + 4, (f32x4){v[4], v[5], v[6], v[7]});
+}
+
+// grid (voxel blocks, C / CB, B).  DGRAD = false: y = bias + sum_t sum_i w[co][i][t] x[v + t - 1][g cpg + i];
+// DGRAD = true: dx = sum_t sum_o w[g cpg + o][ci - g cpg][26 - t] dy[v + t - 1][g cpg + o]
+template <typename T, int CPG, bool DGRAD>
+__global__ __launch_bounds__(256) void gconv_vec_kernel(const T* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                                                        T* __restrict__ y, int B, int D, int H, int W, int C, int CB, int wsets) {
+    extern __shared__ float tab[];                        // [27][CPG][CB]
+    const int b = blockIdx.z, c0 = blockIdx.y * CB;
+    const int set = b / (B / wsets);
+    const float* ws = w + (long)set * C * CPG * 27;
+    for (int i = threadIdx.x; i < 27 * CPG * CB; i += 256) {
+        const int c = i % CB, k = (i / CB) % CPG, t = i / (CB * CPG);
+        const int ch = c0 + c, gb = (ch / CPG) * CPG;
+        tab[i] = DGRAD ? ws[((long)(gb + k) * CPG + (ch - gb)) * 27 + (26 - t)] : ws[((long)ch * CPG + k) * 27 + t];
+    }
+    __syncthreads();
+    const int nsl = CB >> 3, vpb = 256 / nsl;
+    const int sl = threadIdx.x % nsl, vi = threadIdx.x / nsl;
+    const long V = (long)D * H * W;
+    const long v = (long)blockIdx.x * vpb + vi;
+    if (v >= V) return;
+    const int ww = (int)(v % W), hh = (int)((v / W) % H), dd = (int)(v / ((long)W * H));
+    const int cl = sl * 8, ch = c0 + cl;
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = (!DGRAD && bias) ? bias[(long)set * C + ch + j] : 0.f;
+    const T* xb = x + (long)b * V * C + ch;
+    for (int td = 0; td < 3; ++td) {
+        const int zd = dd + td - 1;
+        if (zd < 0 || zd >= D) continue;
+        for (int th = 0; th < 3; ++th) {
+            const int zh = hh + th - 1;
+            if (zh < 0 || zh >= H) continue;
+#pragma unroll
+            for (int tw = 0; tw < 3; ++tw) {
+                const int zw = ww + tw - 1;
+                if (zw < 0 || zw >= W) continue;
+                float xv[8];
+                gld8<T>(xb + (((long)zd * H + zh) * W + zw) * C, xv);
+                const float* tp = tab + (td * 9 + th * 3 + tw) * CPG * CB + cl;
+#pragma unroll
+                for (int k = 0; k < CPG; ++k) {
+                    const f32x4 wa = *reinterpret_cast<const f32x4*>(tp + k * CB), wb = *reinterpret_cast<const f32x4*>(tp + k * CB + 4);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        acc[j] = __builtin_fmaf(wa[j], CPG == 1 ? xv[j] : xv[(j / CPG) * CPG + k], acc[j]);
+                        acc[4 + j] = __builtin_fmaf(wb[j], CPG == 1 ? xv[4 + j] : xv[((4 + j) / CPG) * CPG + k], acc[4 + j]);
+                    }
+                }
+            }
+        }
+    }
+    gst8<T>(y + ((long)b * V + v) * C + ch, acc);
+}
+
+// weight gradient, partial over a chunk of voxels: grid (chunks, C / CB, wsets); thread = (tap lane 0..31: 27 taps, lane 27 = bias,
+// rest idle) x (8-channel slice): part[chunk][set][c][i][28] (column 27 of i = 0: the bias gradient)
+template <typename T, int CPG>
+__global__ __launch_bounds__(256) void gconv_wgrad_vec_kernel(const T* __restrict__ x, const T* __restrict__ dy, float* __restrict__ part,
+                                                              int B, int D, int H, int W, int C, int CB, int wsets, int chunk) {
+    const int set = blockIdx.z, c0 = blockIdx.y * CB;
+    const int nsl = CB >> 3, nvl = 256 / (32 * nsl);          // voxel lanes: threads beyond the 32 x nsl (tap, slice) pairs split the chunk
+    const int tl = threadIdx.x & 31, sl = (threadIdx.x >> 5) % nsl, vl = (threadIdx.x >> 5) / nsl;
+    const int bper = B / wsets;
+    const long V = (long)D * H * W, Q = (long)bper * V;        // voxels of this weight set
+    const long lo = (long)blockIdx.x * chunk, hi = lo + chunk < Q ? lo + chunk : Q;
+    const int td = tl / 9 - 1, th = (tl / 3) % 3 - 1, tw = tl % 3 - 1;
+    const int ch = c0 + sl * 8;
+    float acc[8][CPG];
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+        for (int k = 0; k < CPG; ++k) acc[j][k] = 0.f;
+    if (tl < 28) {
+        for (long q = lo + vl; q < hi; q += nvl) {
+            const long bq = (long)set * bper + q / V, v = q % V;
+            float g[8];
+            gld8<T>(dy + (bq * V + v) * C + ch, g);
+            if (tl == 27) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[j][0] += g[j];
+                continue;
+            }
+            const int ww = (int)(v % W), hh = (int)((v / W) % H), dd = (int)(v / ((long)W * H));
+            const int zd = dd + td, zh = hh + th, zw = ww + tw;
+            if (zd < 0 || zd >= D || zh < 0 || zh >= H || zw < 0 || zw >= W) continue;
+            float xv[8];
+            gld8<T>(x + (bq * V + ((long)zd * H + zh) * W + zw) * C + ch, xv);
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+#pragma unroll
+                for (int k = 0; k < CPG; ++k) acc[j][k] = __builtin_fmaf(g[j], CPG == 1 ? xv[j] : xv[(j / CPG) * CPG + k], acc[j][k]);
+        }
+    }
+    // the nvl voxel lanes of a (tap, slice) pair, in lane order
+    extern __shared__ float red[];                         // [nvl][nsl][32][8 * CPG]
+    float* mine = red + (((long)vl * nsl + sl) * 32 + tl) * (8 * CPG);
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+        for (int k = 0; k < CPG; ++k) mine[j * CPG + k] = acc[j][k];
+    __syncthreads();
+    if (vl == 0 && tl < 28) {
+        float* out = part + (((long)blockIdx.x * wsets + set) * C + ch) * CPG * 28;
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+            for (int k = 0; k < CPG; ++k) {
+                float t = 0.f;
+                for (int u = 0; u < nvl; ++u) t += red[(((long)u * nsl + sl) * 32 + tl) * (8 * CPG) + j * CPG + k];
+                if (tl < 27 || k == 0) out[((long)j * CPG + k) * 28 + tl] = t;
+            }
+    }
+}
+
+// dw[set][c][i][t] = sum_chunks part[..][t], db[set][c] = sum_chunks part[..][i = 0][27]
+__global__ __launch_bounds__(256) void gconv_wfold_kernel(const float* __restrict__ part, float* __restrict__ dw, float* __restrict__ db,
+                                                          int nchunk, long n_ci, int cpg) {         // n_ci = wsets * C * cpg
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_ci * 28) return;
+    const long ci = i / 28;
+    const int t = (int)(i % 28);
+    float s = 0.f;
+    for (int k = 0; k < nchunk; ++k) s += part[((long)k * n_ci + ci) * 28 + t];
+    if (t < 27) dw[ci * 27 + t] = s;
+    else if (db && ci % cpg == 0) db[ci / cpg] = s;          // the bias column rides with i == 0
+}
+
+int gconv_cb(int C) {                                        // channel range of a block, 0 = the scalar kernels
+    if (C % 64 == 0) return 64;
+    if (C == 8 || C == 16 || C == 32) return C;
+    return 0;
+}
+constexpr int GC_CHUNK = 128;                                // voxels per weight-gradient chunk
+
 // y[b][v][c] = x[b % Bx][v][c] * w[b][v >> k per axis]
 template <typename T, int VEC>
 __global__ __launch_bounds__(256) void scale_nearest_fwd_kernel(const T* __restrict__ x, const float* __restrict__ w, T* __restrict__ y,
@@ -171,27 +325,75 @@ unsigned grid_for(long total) { return (unsigned)((total + 255) / 256 > 16384 ? 
 
 }  // namespace
 
+extern "C" int64_t passion_gconv3d_part_floats(int B, int D, int H, int W, int C, int cpg, int wsets) {
+    if (B <= 0 || wsets <= 0 || B % wsets || !gconv_cb(C) || (cpg != 1 && cpg != 4)) return 0;
+    const long Q = (long)(B / wsets) * D * H * W;
+    return ((Q + GC_CHUNK - 1) / GC_CHUNK) * (long)wsets * C * cpg * 28;
+}
+
+#define GCONV_VEC(TT, CPGV, DG, SRC, DST, BIAS)                                                                                              \
+    hipLaunchKernelGGL((gconv_vec_kernel<TT, CPGV, DG>), dim3((unsigned)((V + vpb - 1) / vpb), C / CB, B), dim3(256), 27 * CPGV * CB * 4, st, \
+                       (const TT*)(SRC), weight, BIAS, (TT*)(DST), B, D, H, W, C, CB, wsets)
+
 extern "C" int passion_gconv3d_fwd(const void* x, const float* weight, const float* bias, void* y, int dtype, int B, int D, int H, int W,
-                                   int C, int cpg, void* stream) {
-    if (B <= 0 || C <= 0 || cpg <= 0 || C % cpg) return -1003;
+                                   int C, int cpg, int wsets, void* stream) {
+    if (B <= 0 || C <= 0 || cpg <= 0 || C % cpg || wsets <= 0 || B % wsets) return -1003;
+    if (dtype != PASSION_F32 && dtype != PASSION_BF16) return -1007;
     const long total = (long)B * D * H * W * C;
     hipStream_t st = (hipStream_t)stream;
+    const int CB = gconv_cb(C);
+    if (CB && (cpg == 1 || cpg == 4)) {
+        const long V = (long)D * H * W;
+        const int vpb = 256 / (CB >> 3);
+        if (dtype == PASSION_F32) { if (cpg == 1) GCONV_VEC(float, 1, false, x, y, bias); else GCONV_VEC(float, 4, false, x, y, bias); }
+        else { if (cpg == 1) GCONV_VEC(bf16_t, 1, false, x, y, bias); else GCONV_VEC(bf16_t, 4, false, x, y, bias); }
+        LAUNCH_RET();
+        return 0;
+    }
+    if (wsets != 1) return -1003;
     if (dtype == PASSION_F32)
         hipLaunchKernelGGL(gconv_fwd_kernel<float>, dim3(grid_for(total)), dim3(256), 0, st, (const float*)x, weight, bias, (float*)y, B, D, H, W, C, cpg);
-    else if (dtype == PASSION_BF16)
+    else
         hipLaunchKernelGGL(gconv_fwd_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, st, (const bf16_t*)x, weight, bias, (bf16_t*)y, B, D, H, W, C, cpg);
-    else return -1007;
     LAUNCH_RET();
     return 0;
 }
 
-extern "C" int passion_gconv3d_bwd(const void* x, const float* weight, const void* dy, void* dx, float* dweight, float* dbias, int dtype,
-                                   int B, int D, int H, int W, int C, int cpg, void* stream) {
-    if (B <= 0 || C <= 0 || cpg <= 0 || C % cpg) return -1003;
+#define GCONV_WG(TT, CPGV)                                                                                                                   \
+    hipLaunchKernelGGL((gconv_wgrad_vec_kernel<TT, CPGV>), dim3((unsigned)nchunk, C / CB, wsets), dim3(256), 256 * 8 * CPGV * 4, st,          \
+                       (const TT*)x, (const TT*)dy, part, B, D, H, W, C, CB, wsets, GC_CHUNK)
+
+extern "C" int passion_gconv3d_bwd(const void* x, const float* weight, const void* dy, void* dx, float* dweight, float* dbias, float* part,
+                                   int dtype, int B, int D, int H, int W, int C, int cpg, int wsets, void* stream) {
+    if (B <= 0 || C <= 0 || cpg <= 0 || C % cpg || wsets <= 0 || B % wsets) return -1003;
     const long total = (long)B * D * H * W * C;
     const long nout = (long)C * cpg * 27;
     hipStream_t st = (hipStream_t)stream;
     if (dtype != PASSION_F32 && dtype != PASSION_BF16) return -1007;
+    const int CB = gconv_cb(C);
+    if (CB && (cpg == 1 || cpg == 4)) {
+        const long V = (long)D * H * W;
+        const int vpb = 256 / (CB >> 3);
+        if (dx) {
+            const float* nobias = nullptr;
+            if (dtype == PASSION_F32) { if (cpg == 1) GCONV_VEC(float, 1, true, dy, dx, nobias); else GCONV_VEC(float, 4, true, dy, dx, nobias); }
+            else { if (cpg == 1) GCONV_VEC(bf16_t, 1, true, dy, dx, nobias); else GCONV_VEC(bf16_t, 4, true, dy, dx, nobias); }
+            LAUNCH_RET();
+        }
+        if (dweight) {
+            if (!part) return -1003;
+            const long Q = (long)(B / wsets) * V;
+            const long nchunk = (Q + GC_CHUNK - 1) / GC_CHUNK;
+            if (dtype == PASSION_F32) { if (cpg == 1) GCONV_WG(float, 1); else GCONV_WG(float, 4); }
+            else { if (cpg == 1) GCONV_WG(bf16_t, 1); else GCONV_WG(bf16_t, 4); }
+            LAUNCH_RET();
+            const long n_ci = (long)wsets * C * cpg;
+            hipLaunchKernelGGL(gconv_wfold_kernel, dim3((unsigned)((n_ci * 28 + 255) / 256)), dim3(256), 0, st, part, dweight, dbias, (int)nchunk, n_ci, cpg);
+            LAUNCH_RET();
+        }
+        return 0;
+    }
+    if (wsets != 1) return -1003;
     if (dx) {
         if (dtype == PASSION_F32)
             hipLaunchKernelGGL(gconv_dgrad_kernel<float>, dim3(grid_for(total)), dim3(256), 0, st, (const float*)dy, weight, (float*)dx, B, D, H, W, C, cpg);

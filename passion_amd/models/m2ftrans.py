@@ -56,7 +56,7 @@ class MultiCrossToken(nn.Module):
                                                          ffn_feature_maps=i != num_layers - 1) for i in range(num_layers)])
 
     def forward(self, inputs, kernels, mask):
-        feature_maps = inputs
+        feature_maps = torch.stack(list(inputs))        # (4, B, D, H, W, C): the blocks treat the four modalities as one batch
         for layer in self.layers:
             kernels, feature_maps = layer(kernels, feature_maps, mask)
         return kernels

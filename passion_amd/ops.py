@@ -1087,40 +1087,47 @@ def ln_act(x, norms, act=False, res=None):
 
 class GroupConvFn(torch.autograd.Function):
     """grouped 3x3x3 Conv3d (zero padding, stride 1, in = out channels, `cpg` channels per group) on channels-last tensors:
-    DepthWiseConvBlock.conv2 / GroupConvBlock.dwconv of the m2ftrans cross-token blocks (reference blocks.py:45-47, 77-79)"""
+    DepthWiseConvBlock.conv2 / GroupConvBlock.dwconv of the m2ftrans cross-token blocks (reference blocks.py:45-47, 77-79).
+    G weight sets in one launch: x is (G * B, D, H, W, C) and samples [g B, (g + 1) B) use set g; params: G weights then G biases."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias):
-        L.require_gpu(x, weight)
+    def forward(ctx, x, G, has_bias, *params):
+        L.require_gpu(x)
         x = x.contiguous()
         B, D, H, W, C = x.shape
-        cpg = weight.shape[1]
-        assert weight.shape == (C, cpg, 3, 3, 3) and weight.dtype == torch.float32
-        w = weight.detach().contiguous()
-        b32 = bias.detach().float().contiguous() if bias is not None else None
+        w = f32_stack(params[:G]).contiguous()
+        cpg = w.shape[2]
+        assert w.shape == (G, C, cpg, 3, 3, 3) and w.dtype == torch.float32 and B % G == 0
+        b32 = f32_stack(params[G:]).contiguous() if has_bias else None
         y = torch.empty_like(x)
-        L.check(L.load().passion_gconv3d_fwd(_p(x), _p(w), _p(b32), _p(y), L.dtype_code(x.dtype), B, D, H, W, C, cpg, L.stream_ptr()),
+        L.check(L.load().passion_gconv3d_fwd(_p(x), _p(w), _p(b32), _p(y), L.dtype_code(x.dtype), B, D, H, W, C, cpg, G, L.stream_ptr()),
                 "passion_gconv3d_fwd")
         ctx.save_for_backward(x, w)
-        ctx.has_bias = bias is not None
+        ctx.has_bias, ctx.G = has_bias, G
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, w = ctx.saved_tensors
         B, D, H, W, C = x.shape
-        cpg = w.shape[1]
+        G, cpg = ctx.G, w.shape[2]
         dy = dy.contiguous()
+        lib = L.load()
         dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
-        dw = torch.empty_like(w) if ctx.needs_input_grad[1] else None
-        db = torch.empty(C, dtype=torch.float32, device=x.device) if (ctx.has_bias and ctx.needs_input_grad[2] and dw is not None) else None
-        L.check(L.load().passion_gconv3d_bwd(_p(x), _p(w), _p(dy), _p(dx), _p(dw), _p(db), L.dtype_code(x.dtype), B, D, H, W, C, cpg,
-                                             L.stream_ptr()), "passion_gconv3d_bwd")
-        return dx, dw, db
+        dw = torch.empty_like(w)
+        db = torch.empty(G, C, dtype=torch.float32, device=x.device) if ctx.has_bias else None
+        n = lib.passion_gconv3d_part_floats(B, D, H, W, C, cpg, G)
+        part = torch.empty(n, dtype=torch.float32, device=x.device) if n else None
+        L.check(lib.passion_gconv3d_bwd(_p(x), _p(w), _p(dy), _p(dx), _p(dw), _p(db), _p(part), L.dtype_code(x.dtype), B, D, H, W, C, cpg, G,
+                                        L.stream_ptr()), "passion_gconv3d_bwd")
+        return (dx, None, None, *[dw[g] for g in range(G)], *([db[g] for g in range(G)] if ctx.has_bias else []))
 
 
 def group_conv3d(x, weight, bias):
-    return GroupConvFn.apply(x, weight, bias)
+    """weight / bias: one parameter each, or lists of G (x then holds G * B samples, B per weight set)"""
+    ws = list(weight) if isinstance(weight, (list, tuple)) else [weight]
+    bs = (list(bias) if isinstance(bias, (list, tuple)) else [bias]) if bias is not None else []
+    return GroupConvFn.apply(x, len(ws), bool(bs), *ws, *bs)
 
 
 class ScaleNearestFn(torch.autograd.Function):

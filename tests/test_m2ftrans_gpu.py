@@ -53,6 +53,41 @@ def test_group_conv3d(dtype, cpg, C):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("cpg,C,G,shape", [(1, 64, 8, (2, 5, 6, 4)), (4, 128, 1, (3, 8, 8, 8)), (4, 256, 2, (1, 4, 9, 5)), (1, 32, 4, (2, 3, 3, 7)),
+                                           (1, 8, 1, (1, 16, 16, 16)), (4, 64, 3, (1, 6, 5, 4))])
+def test_group_conv3d_weight_sets(dtype, cpg, C, G, shape):
+    """the channel-vectorised kernels with G weight sets over G * B samples (the key_map_* / value_map_* blocks as one batch)
+    against G float64 F.conv3d calls; twice for bit equality"""
+    from passion_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(17 + C)
+    B, D, H, W = shape
+    x = torch.randn(G * B, C, D, H, W, generator=g).to(dtype).double()
+    gy = torch.randn(G * B, C, D, H, W, generator=g).to(dtype).double()
+    ws = [(torch.randn(C, cpg, 3, 3, 3, generator=g) * 0.3) for _ in range(G)]
+    bs = [torch.randn(C, generator=g) for _ in range(G)]
+    xr = x.clone().requires_grad_(True)
+    wr = [w.double().requires_grad_(True) for w in ws]
+    br = [b.double().requires_grad_(True) for b in bs]
+    yr = torch.cat([F.conv3d(xr[i * B:(i + 1) * B], wr[i], br[i], padding=1, groups=C // cpg) for i in range(G)])
+    yr.backward(gy)
+    outs = []
+    for _ in range(2):
+        xd = cl(x).to(dev, dtype).requires_grad_(True)
+        wd = [w.to(dev).requires_grad_(True) for w in ws]
+        bd = [b.to(dev).requires_grad_(True) for b in bs]
+        y = ops.group_conv3d(xd, wd if G > 1 else wd[0], bd if G > 1 else bd[0])
+        y.backward(cl(gy).to(dev, dtype))
+        outs.append((y.detach().clone(), xd.grad.clone(), torch.stack([w.grad for w in wd]), torch.stack([b.grad for b in bd])))
+    tol = 1e-5 if dtype == torch.float32 else 2e-2
+    y, dx, dw, db = outs[0]
+    assert rel(nc(y.float()), yr.detach()) < tol and rel(nc(dx.float()), xr.grad) < tol
+    assert rel(dw, torch.stack([w.grad for w in wr])) < tol and rel(db, torch.stack([b.grad for b in br])) < tol
+    for a, b in zip(outs[0], outs[1]):
+        assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("C,k,passes", [(8, 2, 1), (4, 1, 3), (16, 3, 5)])
 def test_scale_nearest(dtype, C, k, passes):
     """Weight_Attention (m2ftrans.py:443-458): x * nearest-upsampled weight map, several passes over the same features"""
