@@ -209,24 +209,40 @@ __global__ __launch_bounds__(256) void gconv_wgrad_vec_kernel(const T* __restric
 #pragma unroll
         for (int k = 0; k < CPG; ++k) acc[j][k] = 0.f;
     if (tl < 28) {
-        for (long q = lo + vl; q < hi; q += nvl) {
-            const long bq = (long)set * bper + q / V, v = q % V;
-            float g[8];
-            gld8<T>(dy + (bq * V + v) * C + ch, g);
+        // four voxels per trip, every load issued before the first use (clamped addresses, zero weights for what does not exist):
+        // a trip costs one memory latency, not eight
+        for (long q0 = lo + vl; q0 < hi; q0 += 4L * nvl) {
+            float g[4][8], xv[4][8];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const long q = q0 + (long)u * nvl;
+                const bool live = q < hi;
+                const long qc = live ? q : lo;
+                const long bq = (long)set * bper + qc / V, v = qc % V;
+                gld8<T>(dy + (bq * V + v) * C + ch, g[u]);
+                const int ww = (int)(v % W), hh = (int)((v / W) % H), dd = (int)(v / ((long)W * H));
+                const int zd = dd + td, zh = hh + th, zw = ww + tw;
+                const bool in = tl < 27 && zd >= 0 && zd < D && zh >= 0 && zh < H && zw >= 0 && zw < W;
+                const long vx = in ? ((long)zd * H + zh) * W + zw : v;
+                gld8<T>(x + (bq * V + vx) * C + ch, xv[u]);
+                const float keep = live ? 1.f : 0.f;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { g[u][j] *= keep; if (!in) xv[u][j] = 0.f; }
+            }
             if (tl == 27) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) acc[j][0] += g[j];
-                continue;
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc[j][0] += g[u][j];
+            } else {
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+#pragma unroll
+                        for (int k = 0; k < CPG; ++k)
+                            acc[j][k] = __builtin_fmaf(g[u][j], CPG == 1 ? xv[u][j] : xv[u][(j / CPG) * CPG + k], acc[j][k]);
             }
-            const int ww = (int)(v % W), hh = (int)((v / W) % H), dd = (int)(v / ((long)W * H));
-            const int zd = dd + td, zh = hh + th, zw = ww + tw;
-            if (zd < 0 || zd >= D || zh < 0 || zh >= H || zw < 0 || zw >= W) continue;
-            float xv[8];
-            gld8<T>(x + (bq * V + ((long)zd * H + zh) * W + zw) * C + ch, xv);
-#pragma unroll
-            for (int j = 0; j < 8; ++j)
-#pragma unroll
-                for (int k = 0; k < CPG; ++k) acc[j][k] = __builtin_fmaf(g[j], CPG == 1 ? xv[j] : xv[(j / CPG) * CPG + k], acc[j][k]);
         }
     }
     // the nvl voxel lanes of a (tap, slice) pair, in lane order
@@ -268,7 +284,7 @@ int gconv_cb(int C) {                                        // channel range of
     if (C == 8 || C == 16 || C == 32) return C;
     return 0;
 }
-constexpr int GC_CHUNK = 128;                                // voxels per weight-gradient chunk
+constexpr int GC_CHUNK = 32;                                // voxels per weight-gradient chunk
 
 // y[b][v][c] = x[b % Bx][v][c] * w[b][v >> k per axis]
 template <typename T, int VEC>

@@ -199,10 +199,18 @@ def run_conv_auto(conv, feats, out_dtype=None, post=False):
     b = _pad_axis(b, 0, mult) if b is not None else None
     padded = w is not conv.weight
     cache = None if padded else conv.__dict__.setdefault("_passion_pack", {})
+    # a post-norm conv's output is always normalised by its consumer: the conv leaves the InstanceNorm statistics of what it
+    # stores from its own epilogue where the kernel can (ops.conv_block want_stats) instead of two or three launches on first use
+    want = post and FUSE_STATS and feats[0].t.is_cuda
     y = ops.conv_block([_seg_auto(f) for f in feats], w, b, D, H, W, ksize=conv.kernel_size[0], stride=conv.stride[0],
-                       pad_mode=PAD[conv.padding_mode], out_dtype=out_dtype, pack_cache=cache)
+                       pad_mode=PAD[conv.padding_mode], out_dtype=out_dtype, pack_cache=cache, want_stats=want)
+    st = None
+    if want:
+        y, st = y
     c_real = cout if y.shape[-1] != cout else None
-    return PFeat(y, c_real=c_real) if post else Feat(y, c_real=c_real)
+    if post:
+        return PFeat(y, _stats=[st] if st is not None else None, c_real=c_real)
+    return Feat(y, c_real=c_real)
 
 
 class general_conv3d(nn.Module):
