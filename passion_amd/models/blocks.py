@@ -213,6 +213,39 @@ def run_conv_auto(conv, feats, out_dtype=None, post=False):
     return Feat(y, c_real=c_real)
 
 
+GROUPED_ENC_POST = _os.environ.get("PASSION_GROUPED_ENC", "1") != "0"
+
+
+def encoders_grouped_post(encs, x, mask, dtype, levels):
+    """The four post-norm modality encoders (reference m2ftrans.py:63-104 / rfnet.py:15-48, four Encoder() instances of identical shape) over the stacked
+    batch [flair | t1ce | t1 | t2] (4B samples): every conv is ONE grouped launch (ops.conv_block_grouped: sample s uses the
+    weights of encoder s // B), the residual x + c3(c2(x)) one norm_act launch -- a quarter of the launches of the per-modality
+    loop.  x: (B,4,D,H,W); mask (B,4) bool or None.  -> `levels` Feats of shape (4B, D_l, H_l, W_l, C_l), modality-major."""
+    B, K, D, H, W = x.shape
+    xs = torch.empty(K, B, D, H, W, 1, dtype=dtype, device=x.device)
+    xs.view(K, B, D, H, W).copy_(x.transpose(0, 1))
+    xs = xs.view(K * B, D, H, W, 1)
+    gmask = mask.t().reshape(K * B, 1).contiguous() if mask is not None else None      # row m * B + b = mask[b, m]
+
+    def gconv(name, f, first=False):
+        convs = [getattr(e, name).conv for e in encs]
+        c0 = convs[0]
+        d, h, w = f.t.shape[1:4]
+        seg = ops.SegIn(f.t, mask=gmask, mask_col=0) if first else f.seg(isinstance(f, PFeat))
+        r = ops.conv_block_grouped([seg], [c.weight for c in convs], [c.bias for c in convs], d, h, w, ksize=c0.kernel_size[0],
+                                   stride=c0.stride[0], pad_mode=L.PAD_REFLECT, out_dtype=dtype, want_stats=True)
+        return PFeat(r[0], _stats=[r[1]])
+
+    r1 = gconv("e1_c1", Feat(xs), first=True)
+    feats = []
+    for lvl in range(1, levels + 1):
+        if lvl > 1:
+            r1 = gconv(f"e{lvl}_c1", feats[-1])
+        r3 = gconv(f"e{lvl}_c3", gconv(f"e{lvl}_c2", r1))
+        feats.append(Feat(ops.norm_act(r1.t, r1.stats(), r3.t, r3.stats())))
+    return feats
+
+
 class general_conv3d(nn.Module):
     """Conv3d -> InstanceNorm -> LeakyReLU(0.2) (reference blocks.py:354-370).  The conv launches here; the
     norm + activation happen in the loader of whichever conv consumes the returned PFeat."""

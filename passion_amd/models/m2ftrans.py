@@ -21,7 +21,7 @@ import torch.nn.functional as F
 from .. import _lib as L
 from .. import ops
 from ..utils import criterions as crit
-from .blocks import (Feat, PFeat, MultiMaskCrossBlock, fusion_postnorm, general_conv3d, materialize, prm_fusion_pk, run_conv_auto)
+from .blocks import (GROUPED_ENC_POST as GROUPED_ENC, Feat, PFeat, MultiMaskCrossBlock, encoders_grouped_post, fusion_postnorm, general_conv3d, materialize, prm_fusion_pk, run_conv_auto)
 from .mmformer import Linear
 
 basic_dims = 8
@@ -94,39 +94,6 @@ class Encoder(nn.Module):
             r3 = getattr(self, f"e{lvl}_c3")(getattr(self, f"e{lvl}_c2")(r1))
             feats.append(Feat(ops.norm_act(r1.t, r1.stats(), r3.t, r3.stats())))      # x + c3(c2(x)) on activated values
         return feats
-
-
-GROUPED_ENC = os.environ.get("PASSION_GROUPED_ENC", "1") != "0"
-
-
-def encoders_grouped(encs, x, mask, dtype):
-    """The four modality encoders (reference m2ftrans.py:63-104, four Encoder() instances of identical shape) over the stacked
-    batch [flair | t1ce | t1 | t2] (4B samples): every conv is ONE grouped launch (ops.conv_block_grouped: sample s uses the
-    weights of encoder s // B), the residual x + c3(c2(x)) one norm_act launch -- a quarter of the launches of the per-modality
-    loop.  x: (B,4,D,H,W); mask (B,4) bool or None.  -> five Feats of shape (4B, D_l, H_l, W_l, C_l), modality-major."""
-    B, K, D, H, W = x.shape
-    xs = torch.empty(K, B, D, H, W, 1, dtype=dtype, device=x.device)
-    xs.view(K, B, D, H, W).copy_(x.transpose(0, 1))
-    xs = xs.view(K * B, D, H, W, 1)
-    gmask = mask.t().reshape(K * B, 1).contiguous() if mask is not None else None      # row m * B + b = mask[b, m]
-
-    def gconv(name, f, first=False):
-        convs = [getattr(e, name).conv for e in encs]
-        c0 = convs[0]
-        d, h, w = f.t.shape[1:4]
-        seg = ops.SegIn(f.t, mask=gmask, mask_col=0) if first else f.seg(isinstance(f, PFeat))
-        r = ops.conv_block_grouped([seg], [c.weight for c in convs], [c.bias for c in convs], d, h, w, ksize=c0.kernel_size[0],
-                                   stride=c0.stride[0], pad_mode=L.PAD_REFLECT, out_dtype=dtype, want_stats=True)
-        return PFeat(r[0], _stats=[r[1]])
-
-    r1 = gconv("e1_c1", Feat(xs), first=True)
-    feats = []
-    for lvl in range(1, 6):
-        if lvl > 1:
-            r1 = gconv(f"e{lvl}_c1", feats[-1])
-        r3 = gconv(f"e{lvl}_c3", gconv(f"e{lvl}_c2", r1))
-        feats.append(Feat(ops.norm_act(r1.t, r1.stats(), r3.t, r3.stats())))
-    return feats
 
 
 class Decoder_sep(nn.Module):
@@ -400,7 +367,7 @@ class Model(nn.Module):
         xin = x.to(dt).contiguous()
         grouped = GROUPED_ENC and bf16
         if grouped:
-            stk = encoders_grouped([getattr(self, f"{m}_encoder") for m in MODALS], xin, mask if idt else None, dt)
+            stk = encoders_grouped_post([getattr(self, f"{m}_encoder") for m in MODALS], xin, mask if idt else None, dt, 5)
             encs = [[Feat(stk[l].t[i * B:(i + 1) * B]) for l in range(5)] for i in range(4)]
         else:
             encs = [getattr(self, f"{m}_encoder")(xin, i, mask if idt else None, dt) for i, m in enumerate(MODALS)]

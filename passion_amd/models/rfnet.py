@@ -14,7 +14,7 @@ import torch.nn as nn
 from .. import _lib as L
 from .. import ops
 from ..utils import criterions as crit
-from .blocks import (Feat, PFeat, general_conv3d, materialize, prm_generator_laststage_pk, prm_generator_pk,
+from .blocks import (GROUPED_ENC_POST, Feat, PFeat, encoders_grouped_post, general_conv3d, materialize, prm_generator_laststage_pk, prm_generator_pk,
                      region_aware_modal_fusion, run_conv_auto)
 
 basic_dims = 8
@@ -206,7 +206,13 @@ class Model(nn.Module):
         streams = self._enc_streams(dev) if ENC_STREAMS else None
         main = torch.cuda.current_stream(dev) if streams else None
         encs = [None] * 4
+        grouped = GROUPED_ENC_POST and dt == torch.bfloat16
+        if grouped:          # every encoder layer as one grouped launch over the 4B stacked samples
+            stk = encoders_grouped_post([getattr(self, f"{m}_encoder") for m in MODALS], xin, mask if idt else None, dt, 4)
+            encs = [[Feat(stk[l].t[i * B:(i + 1) * B]) for l in range(4)] for i in range(4)]
         for i, m in enumerate(MODALS):
+            if grouped:
+                break
             if streams:
                 streams[i].wait_stream(main)
                 with torch.cuda.stream(streams[i]):
@@ -217,7 +223,7 @@ class Model(nn.Module):
                             f._stats[0].record_stream(main)
             else:
                 encs[i] = getattr(self, f"{m}_encoder")(xin, i, mask if idt else None, dt)
-        if streams:
+        if streams and not grouped:
             for s_ in streams:
                 main.wait_stream(s_)
         training = self.is_training
@@ -248,7 +254,10 @@ class Model(nn.Module):
         tcl = ops.target_to_cl(target)
         # decoder_sep (shared weights) once over the four modalities stacked along the batch axis
         sep_mask = mask.t().reshape(4 * B, 1).contiguous() if idt else None       # row i*B+b = mask[b, i]
-        stacked = [Feat(torch.cat([encs[i][l].t for i in range(4)], 0), sep_mask, 0) for l in range(4)]
+        if grouped:
+            stacked = [Feat(stk[l].t, sep_mask, 0) for l in range(4)]
+        else:
+            stacked = [Feat(torch.cat([encs[i][l].t for i in range(4)], 0), sep_mask, 0) for l in range(4)]
         sep_all = self.decoder_sep(*stacked)
         eye = torch.eye(4, device=dev)
         maskf = mask.float()
