@@ -7,6 +7,10 @@ mkdir -p $R/gpurun_out/prof_$TAG
 python3 bench.py > $R/gpurun_out/${TAG}_bench_mmformer128.json 2> $R/gpurun_out/${TAG}_bench_mmformer128.err
 python3 bench.py --workload mmformer128_passion --no-cpu-baseline > $R/gpurun_out/${TAG}_bench_mmformer128_passion_split.json 2>/dev/null
 python3 bench.py --workload rfnet128_passion --no-cpu-baseline > $R/gpurun_out/${TAG}_bench_rfnet128_passion.json 2>/dev/null
+python3 bench.py --workload m2ftrans128 --no-cpu-baseline --no-dice > $R/gpurun_out/${TAG}_bench_m2ftrans128.json 2>/dev/null
+python3 bench.py --workload m2ftrans128_passion --no-cpu-baseline --no-dice > $R/gpurun_out/${TAG}_bench_m2ftrans128_passion.json 2>/dev/null
+python3 bench.py --workload mmformer_depth --no-cpu-baseline --no-dice > $R/gpurun_out/${TAG}_bench_depth_n1.json 2>/dev/null
+python3 bench.py --size 80 --no-cpu-baseline --no-dice --no-roofline > $R/gpurun_out/${TAG}_bench_mmformer80.json 2>/dev/null
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_$TAG/plain -o p --output-format csv -- python3 $R/bench.py --no-cpu-baseline --no-dice > $R/gpurun_out/prof_$TAG/plain.log 2>&1
 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_$TAG/passion -o p --output-format csv -- python3 $R/bench.py --workload mmformer128_passion --no-cpu-baseline --no-dice > $R/gpurun_out/prof_$TAG/passion.log 2>&1
