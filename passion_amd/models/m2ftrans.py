@@ -368,7 +368,8 @@ class Model(nn.Module):
         grouped = GROUPED_ENC and bf16
         if grouped:
             stk = encoders_grouped_post([getattr(self, f"{m}_encoder") for m in MODALS], xin, mask if idt else None, dt, 5)
-            encs = [[Feat(stk[l].t[i * B:(i + 1) * B]) for l in range(5)] for i in range(4)]
+            parts = [ops.unstack(stk[l].t, 4) for l in range(5)]      # storage-sharing slices; backward: one cat, no zero-filled slices
+            encs = [[Feat(parts[l][i]) for l in range(5)] for i in range(4)]
         else:
             encs = [getattr(self, f"{m}_encoder")(xin, i, mask if idt else None, dt) for i, m in enumerate(MODALS)]
         def gated(t, i):
