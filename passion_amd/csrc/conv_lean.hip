@@ -884,6 +884,14 @@ int launch_conv_lean(ConvK& k, int ksize, int stride, int mode, const void* pack
     k.sums_rep = SUMS_REP_LEAN;
     k.sums_fixed = k.sums_float_only ? 0 : 1;
     const int mtiles = k.Mpad / 16;
+    if (ksize == 1 && mode == 0 && stride == 1) {             // wide volumes: the streaming pointwise kernel (conv_pw.hip); > 0 = not covered
+        const int rc = launch_conv_pw_fwd(k, K8, st);
+        if (rc <= 0) return rc;
+    }
+    if (ksize == 1 && mode == 1 && stride == 1) {
+        const int rc = launch_conv_pw_dgrad(k, K8, st);
+        if (rc <= 0) return rc;
+    }
     if (ksize == 1) return dgrad ? launch_lean_geo<1, 1>(k, K8, cmax, mtiles, st) : launch_lean_geo<1, 0>(k, K8, cmax, mtiles, st);
     if (mode == 2 && stride == 2) return launch_lean_geo<3, 2, 2>(k, K8, cmax, mtiles, st);
     if (mode == 2) return launch_lean_geo<3, 2>(k, K8, cmax, mtiles, st);

@@ -1,0 +1,442 @@
+// Pointwise (1x1x1, stride 1) bf16 forward conv of general_conv3d_prenorm / general_conv3d (reference code/models/blocks.py:300-316,
+// 354-370) for the wide volumes: Cin <= 128 over up to PASSION_MAX_SEG concatenated (masked, normalised) segments, Cout <= 32.
+// A 1x1x1 conv over a channels-last tensor is a streaming GEMM whose MFMA B operand IS the memory layout: for
+// v_mfma_f32_16x16x32_bf16, lane (n, g) wants 8 consecutive K values of column n -- the 16 bytes of channels 8 g .. 8 g + 7 of
+// voxel n.  So there is no LDS stage, no halo, no barrier: every lane loads its own operand straight from HBM (InstanceNorm +
+// LeakyReLU applied in registers on the way), the weights of the whole K axis live in registers as A fragments, four 16-voxel
+// tiles per wavefront are in flight per trip, and the epilogue stores 8 bytes per lane (16 voxels x 4 rows).  The lean brick
+// kernel (conv_lean.hip, KS = 1) staged bricks through LDS with two barriers per brick for these layers and reached 2.6-2.9 TB/s;
+// they are 7 % of a mmformer step and 19 % of an RFNet step.
+// Same descriptors, masks (absent modalities read as zeros, several masked passes over the same features: SegD.bmod), grouped
+// weight sets and fused output statistics (FwdStats) as the other forward kernels.
+#include <cstdlib>
+#include "conv_common.h"
+#include "prof.h"
+
+namespace pconv { extern int g_conv_target; int g_conv_pw = 1; }      // option "conv_pw" / PASSION_CONV_PW=0: back to the lean kernel (A/B)
+using namespace pconv;
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+template <typename T> __device__ __forceinline__ T gload(const void* ptr) {
+    return *reinterpret_cast<const T __attribute__((address_space(1)))*>(reinterpret_cast<unsigned long long>(ptr));
+}
+__device__ __forceinline__ bf16x8 zero8() {
+    bf16x8 z;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) z[j] = (__bf16)0.f;
+    return z;
+}
+
+
+// grid (nwg_b, B): workgroup x of sample b walks the 256-voxel chunks x, x + nwg_b, ...
+#ifndef PW_TT1
+#define PW_TT1 4
+#endif
+#define PW_TT(NS) ((NS) == 1 ? PW_TT1 : 4)
+// TT 16-voxel tiles per wavefront and trip: 16 loads of 16 bytes in flight per lane whatever the K depth (with 8 input channels
+// only a quarter of the lanes load data: bytes in flight, not the memory pipes, bound the first version at 3 TB/s)
+template <int NSTEP, int MT>
+__global__ __launch_bounds__(256) void conv_pw_fwd_kernel(ConvK p, int K8, long V) {
+    constexpr int TT = PW_TT(NSTEP);
+    __shared__ float lsum[4 * MT * 16 * 2 + MT * 16 * 2];
+    const int tid = threadIdx.x, lane = tid & 63, n = lane & 15, g = lane >> 4, wv = tid >> 6;
+    const int b = blockIdx.y;
+
+    // ---- this lane's K blocks: q = 4 s + g -> segment, source pointer, mask, statistics
+    const bf16_t* src[NSTEP];
+    unsigned cst[NSTEP];
+    bool live[NSTEP], hn[NSTEP];
+    f32x2 sc[NSTEP][4], sh[NSTEP][4];
+    bf16x8 wfr[NSTEP][MT];
+#pragma unroll
+    for (int s = 0; s < NSTEP; ++s) {
+        const int q = 4 * s + g;
+        src[s] = reinterpret_cast<const bf16_t*>(p.seg[0].x);
+        cst[s] = 0u; live[s] = false; hn[s] = false;
+        const uint8_t* mptr = nullptr;
+        const float* sptr = nullptr;
+        int rr = q;
+        bool found = false;
+#pragma unroll
+        for (int s2 = 0; s2 < PASSION_MAX_SEG; ++s2) {
+            if (s2 < p.nseg && !found) {
+                const SegD& sd = p.seg[s2];
+                const int nb = sd.C / 8;
+                if (rr < nb) {
+                    found = true;
+                    const int bs = sd.bsrc(b), c0 = rr * 8;
+                    src[s] = reinterpret_cast<const bf16_t*>(sd.x) + (long)bs * sd.bstride + c0;
+                    cst[s] = (unsigned)sd.C;
+                    if (sd.mask) mptr = sd.mask + (long)b * sd.mask_ld + sd.mask_col;
+                    if (sd.stats) sptr = sd.stats + ((long)bs * sd.C + c0) * 2;
+                }
+                rr -= nb;
+            }
+        }
+        live[s] = found && q < K8;
+        if (mptr && gload<uint8_t>(mptr) == 0) live[s] = false;
+        hn[s] = sptr != nullptr;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { sc[s][c] = (f32x2){1.f, 1.f}; sh[s][c] = (f32x2){0.f, 0.f}; }
+        if (hn[s]) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const f32x4 st4 = gload<f32x4>(sptr + 4 * c);          // (mean, rstd) of channels 2c, 2c + 1
+                sc[s][c] = (f32x2){st4[1], st4[3]};
+                sh[s][c] = (f32x2){-st4[0] * st4[1], -st4[2] * st4[3]};
+            }
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            wfr[s][mt] = zero8();
+            if (q < K8) wfr[s][mt] = gload<bf16x8>(reinterpret_cast<const bf16x8*>(p.wpack) + wvec_of(p, b) + ((long)q * p.Mpad + mt * 16 + n));
+        }
+    }
+    f32x4 biasv[MT];
+    bool row_ok[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        row_ok[mt] = mt * 16 + g * 4 < p.Cout;
+        biasv[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (bias_of(p, b) && row_ok[mt]) biasv[mt] = load4(bias_of(p, b) + mt * 16 + g * 4);
+    }
+    const f32x2 slope2 = {p.slope, p.slope};
+    const bool fstats = p.fst.stats != nullptr;
+    float s1[MT][4], s2v[MT][4];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { s1[mt][j] = 0.f; s2v[mt][j] = 0.f; }
+    char* yb = reinterpret_cast<char*>(p.y) + (long)b * V * p.Cout * (p.y_f32 ? 4 : 2);
+
+    for (long v0 = ((long)blockIdx.x * 4 + wv) * (16 * TT); v0 < V; v0 += (long)gridDim.x * 4 * (16 * TT)) {
+        // every load of the trip before the first use
+        u32x4 raw[NSTEP][TT];
+#pragma unroll
+        for (int t = 0; t < TT; ++t) {
+            const long v = v0 + t * 16 + n;
+            const long vc = v < V ? v : V - 1;
+#pragma unroll
+            for (int s = 0; s < NSTEP; ++s) raw[s][t] = gload<u32x4>(src[s] + vc * cst[s]);
+        }
+        f32x4 acc[MT][TT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int t = 0; t < TT; ++t) acc[mt][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < NSTEP; ++s) {
+#pragma unroll
+            for (int t = 0; t < TT; ++t) {
+                u32x4 o = raw[s][t];
+                if (hn[s]) {
+                    bf16x8 ob;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const f32x2 xv = {__uint_as_float(o[c] << 16), __uint_as_float(o[c] & 0xffff0000u)};
+                        f32x2 tv = __builtin_elementwise_fma(xv, sc[s][c], sh[s][c]);
+                        const f32x2 ts = tv * slope2;
+                        tv.x = fmaxf(tv.x, ts.x);
+                        tv.y = fmaxf(tv.y, ts.y);
+                        ob[2 * c] = (__bf16)tv.x; ob[2 * c + 1] = (__bf16)tv.y;
+                    }
+                    o = __builtin_bit_cast(u32x4, ob);
+                }
+                if (!live[s]) o = (u32x4){0u, 0u, 0u, 0u};
+                const bf16x8 bfr = __builtin_bit_cast(bf16x8, o);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) acc[mt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfr[s][mt], bfr, acc[mt][t], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < TT; ++t) {
+            const long v = v0 + t * 16 + n;
+            const bool valid = v < V;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const f32x4 val = acc[mt][t] + biasv[mt];
+                const long el = v * p.Cout + mt * 16 + g * 4;
+                if (p.y_f32) {
+                    if (valid && row_ok[mt]) *reinterpret_cast<f32x4*>(yb + el * 4) = val;
+                } else {
+                    unsigned pk[2];
+                    float rb[4];
+                    round4_bf16(val, pk, rb);
+                    if (valid && row_ok[mt]) *reinterpret_cast<u32x2*>(yb + el * 2) = (u32x2){pk[0], pk[1]};
+                    if (fstats) {
+                        const float vf = valid ? 1.f : 0.f;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const float r = rb[j] * vf;
+                            s1[mt][j] += r;
+                            s2v[mt][j] = __builtin_fmaf(r, r, s2v[mt][j]);
+                        }
+                    }
+                }
+            }
+        }
+    }
+
+    if (fstats) {
+        // 16 voxel lanes (shuffles) -> 4 waves (LDS, fixed order) -> this workgroup's slot
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float a1 = group16_sum(s1[mt][j]), a2 = group16_sum(s2v[mt][j]);
+                if (n == 0) {
+                    lsum[((wv * MT + mt) * 16 + g * 4 + j) * 2 + 0] = a1;
+                    lsum[((wv * MT + mt) * 16 + g * 4 + j) * 2 + 1] = a2;
+                }
+            }
+        __syncthreads();
+        float* wsum = lsum + 4 * MT * 16 * 2;
+        if (tid < MT * 16 * 2) {
+            const int c = tid >> 1, k2 = tid & 1;               // c = mt * 16 + row
+            float t = 0.f;
+#pragma unroll
+            for (int w2 = 0; w2 < 4; ++w2) t += lsum[((w2 * MT * 16) + c) * 2 + k2];
+            wsum[tid] = t;
+        }
+        __syncthreads();
+        fwd_stats_commit(p.fst, p.Cout, b, blockIdx.x, 0, MT * 16, wsum, tid);
+    }
+}
+
+// ---- input gradient of the same convs (conv_lean.hip MODE 1 semantics): g'[ci][v] = sum_co W[co][ci] dY[co][v], back through
+// LeakyReLU / the modality mask in the epilogue, the InstanceNorm-backward sums (sum g', sum g' x_hat per (sample, channel)) as one
+// fixed-point atomic per workgroup and value (order-independent: bit-reproducible), g' stored into the segments' dx tensors; the
+// finish kernel (conv.hip) turns it into dx.  K axis = the Cout channels of dY (no normalisation), rows = Cin in 16-row tiles.
+struct alignas(16) PwEpi {       // the four output rows (= forward input channels) of one lane group of one row tile
+    const bf16_t* x;
+    bf16_t* dx;
+    int C, ok, has_stats;
+    float mval;
+    float mean[4], rstd[4];
+};
+
+template <int NSTEP, int MT>
+__global__ __launch_bounds__(256) void conv_pw_dgrad_kernel(ConvK p, int K8, long V) {
+    constexpr int TT = 4;
+    __shared__ float lsum[4 * MT * 16 * 2];
+    __shared__ PwEpi edesc[MT * 4];
+    const int tid = threadIdx.x, lane = tid & 63, n = lane & 15, g = lane >> 4, wv = tid >> 6;
+    const int b = blockIdx.y;
+    if (tid < MT * 4) {
+        const int cg = (tid / 4) * 16 + (tid % 4) * 4;
+        PwEpi d;
+        d.x = reinterpret_cast<const bf16_t*>(p.seg[0].x); d.dx = nullptr; d.C = 0; d.ok = 0; d.has_stats = 0; d.mval = 1.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { d.mean[j] = 0.f; d.rstd[j] = 1.f; }
+#pragma unroll
+        for (int s2 = 0; s2 < PASSION_MAX_SEG; ++s2) {
+            if (s2 < p.nseg && cg < p.Cin) {
+                const SegD& sd = p.seg[s2];
+                if (cg >= sd.cbase && cg < sd.cbase + sd.C && sd.dx != nullptr) {
+                    const int cl = cg - sd.cbase, bs = sd.bsrc(b);
+                    d.ok = 1; d.C = sd.C; d.has_stats = sd.stats != nullptr;
+                    d.x = reinterpret_cast<const bf16_t*>(sd.x) + (long)bs * sd.bstride + cl;
+                    d.dx = reinterpret_cast<bf16_t*>(sd.dx) + (long)b * sd.bstride + cl;
+                    if (sd.mask) d.mval = sd.mask[(long)b * sd.mask_ld + sd.mask_col] ? 1.f : 0.f;
+                    if (sd.stats) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            d.mean[j] = sd.stats[((long)bs * sd.C + cl + j) * 2 + 0];
+                            d.rstd[j] = sd.stats[((long)bs * sd.C + cl + j) * 2 + 1];
+                        }
+                    }
+                }
+            }
+        }
+        edesc[tid] = d;
+    }
+    // A fragments: the transposed weight images (rows = Cin padded to 16, K = Cout in blocks of 8)
+    bf16x8 wfr[NSTEP][MT];
+    const bf16_t* src = reinterpret_cast<const bf16_t*>(p.dy) + (long)b * V * p.Cout;
+#pragma unroll
+    for (int s = 0; s < NSTEP; ++s) {
+        const int q = 4 * s + g;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            wfr[s][mt] = zero8();
+            if (q < K8) wfr[s][mt] = gload<bf16x8>(reinterpret_cast<const bf16x8*>(p.wpack) + wvec_of(p, b) + ((long)q * p.Mpad + mt * 16 + n));
+        }
+    }
+    __syncthreads();
+    // per-lane copies of what the epilogue needs every trip
+    const bf16_t* ex[MT];
+    unsigned eC[MT];
+    bool e_ok[MT], e_hs[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const PwEpi& e = edesc[mt * 4 + g];
+        ex[mt] = e.x; eC[mt] = (unsigned)e.C; e_ok[mt] = e.ok != 0; e_hs[mt] = e.has_stats != 0;
+    }
+    float s1[MT][4], s2v[MT][4];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { s1[mt][j] = 0.f; s2v[mt][j] = 0.f; }
+    const unsigned cdy = (unsigned)p.Cout;
+
+    for (long v0 = ((long)blockIdx.x * 4 + wv) * (16 * TT); v0 < V; v0 += (long)gridDim.x * 4 * (16 * TT)) {
+        u32x4 raw[NSTEP][TT];
+        u32x2 xpre[MT][TT];
+#pragma unroll
+        for (int t = 0; t < TT; ++t) {
+            const long v = v0 + t * 16 + n;
+            const long vc = v < V ? v : V - 1;
+#pragma unroll
+            for (int s = 0; s < NSTEP; ++s) {
+                const int q = 4 * s + g;
+                raw[s][t] = gload<u32x4>(src + vc * cdy + (q < K8 ? q * 8 : 0));
+            }
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) xpre[mt][t] = gload<u32x2>(ex[mt] + vc * eC[mt]);
+        }
+        f32x4 acc[MT][TT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int t = 0; t < TT; ++t) acc[mt][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < NSTEP; ++s)
+#pragma unroll
+            for (int t = 0; t < TT; ++t) {
+                const bf16x8 bfr = __builtin_bit_cast(bf16x8, raw[s][t]);      // blocks past K8 meet zero weights
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) acc[mt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfr[s][mt], bfr, acc[mt][t], 0, 0, 0);
+            }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const PwEpi& e = edesc[mt * 4 + g];
+            f32x4 mean, rstd;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { mean[j] = e.mean[j]; rstd[j] = e.rstd[j]; }
+            const float f_pos = e.mval, f_neg = e_hs[mt] ? e.mval * p.slope : e.mval;       // LeakyReLU' x modality mask
+            bf16_t* dxp = e.dx;
+#pragma unroll
+            for (int t = 0; t < TT; ++t) {
+                const long v = v0 + t * 16 + n;
+                const bool valid = e_ok[mt] && v < V;
+                const u32x2 xr = xpre[mt][t];
+                const float xv[4] = {__uint_as_float(xr.x << 16), __uint_as_float(xr.x & 0xffff0000u),
+                                     __uint_as_float(xr.y << 16), __uint_as_float(xr.y & 0xffff0000u)};
+                const float vf = (valid && e_hs[mt]) ? 1.f : 0.f;
+                f32x4 gv = acc[mt][t];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float xh = (xv[j] - mean[j]) * rstd[j];
+                    const float gg = gv[j] * (xh > 0.f ? f_pos : f_neg);
+                    gv[j] = gg;
+                    const float gs = gg * vf;
+                    s1[mt][j] += gs;
+                    s2v[mt][j] = __builtin_fmaf(gs, xh, s2v[mt][j]);
+                }
+                if (valid) store4(dxp + v * eC[mt], gv);
+            }
+        }
+    }
+    // one reduction per workgroup: 16 voxel lanes (shuffles) -> 4 waves (LDS, fixed order) -> one replica of the global sums
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const bool st = e_ok[mt] && e_hs[mt];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float a1 = group16_sum(s1[mt][j]), a2 = group16_sum(s2v[mt][j]);
+            if (n == 0) {
+                lsum[((wv * MT + mt) * 16 + g * 4 + j) * 2 + 0] = st ? a1 : 0.f;
+                lsum[((wv * MT + mt) * 16 + g * 4 + j) * 2 + 1] = st ? a2 : 0.f;
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < MT * 16 * 2; i += 256) {
+        const int row = i >> 1, k2 = i & 1;
+        const float t = ((lsum[(0 * MT * 16 + row) * 2 + k2] + lsum[(1 * MT * 16 + row) * 2 + k2]) + lsum[(2 * MT * 16 + row) * 2 + k2]) +
+                        lsum[(3 * MT * 16 + row) * 2 + k2];
+        if (row < p.Cin && t != 0.f) {
+            const long idx = (long)(blockIdx.x % p.sums_rep) * p.B * p.Cin * 2 + ((long)b * p.Cin + row) * 2 + k2;
+            if (p.sums_fixed) {
+                double v = (double)t * 1099511627776.0;                      // 2^40
+                v = fmin(fmax(v, -9.0e18), 9.0e18);
+                atomicAdd(reinterpret_cast<unsigned long long*>(p.sums) + idx, (unsigned long long)(long long)llrint(v));
+            } else {
+                atomicAdd(&p.sums[idx], t);
+            }
+        }
+    }
+}
+
+template <int NSTEP, int MT>
+int launch_pw_dgrad(ConvK& k, int K8, hipStream_t st) {
+    const long V = (long)k.Di * k.Hi * k.Wi;
+    const long chunks = (V + 255) / 256;
+    const long nwg_b = hmax(1, hmin(chunks / 2 > 0 ? chunks / 2 : 1, (g_conv_target + k.B - 1) / k.B));
+    passion_prof_tag("conv_pw_dgrad_kernel<%d, %d>", NSTEP, MT);
+    hipLaunchKernelGGL((conv_pw_dgrad_kernel<NSTEP, MT>), dim3((unsigned)nwg_b, k.B), dim3(256), 0, st, k, K8, V);
+    LAUNCH_RET();
+    return 0;
+}
+
+template <int NSTEP, int MT>
+int launch_pw(ConvK& k, int K8, hipStream_t st) {
+    const long V = (long)k.Do * k.Ho * k.Wo;
+    const long chunks = (V + 64 * PW_TT(NSTEP) - 1) / (64 * PW_TT(NSTEP));      // voxels of a workgroup trip
+    // about g_conv_target workgroups per launch, each at least two trips
+    static const int wgs = []() { const char* e = getenv("PASSION_PW_WGS"); return e && atoi(e) > 0 ? atoi(e) : 0; }();
+    const long target = wgs ? wgs : g_conv_target;
+    long nwg_b = hmax(1, hmin(chunks / 2 > 0 ? chunks / 2 : 1, (target + k.B - 1) / k.B));
+    k.fst.stats = nullptr;
+    if (k.fst_want && !k.y_f32) {
+        const int rc = fwd_stats_setup(k, (int)nwg_b, 1, st);
+        if (rc) return rc < 0 ? rc : -rc;
+    }
+    passion_prof_tag("conv_pw_fwd_kernel<%d, %d>", NSTEP, MT);
+    hipLaunchKernelGGL((conv_pw_fwd_kernel<NSTEP, MT>), dim3((unsigned)nwg_b, k.B), dim3(256), 0, st, k, K8, V);
+    LAUNCH_RET();
+    return 0;
+}
+
+}  // namespace
+
+namespace pconv {
+
+// 0 = launched, < 0 = HIP error, 1 = shape not covered (the caller goes on to the lean kernel).  k.wpack / k.Mpad set by the caller.
+int launch_conv_pw_fwd(ConvK& k, int K8, hipStream_t st) {
+    if (!g_conv_pw || k.residual || k.bd_rows) return 1;
+    if (!(k.slope >= 0.f && k.slope <= 1.f)) return 1;
+    if (K8 < 1 || K8 > 16 || k.Mpad > 32) return 1;
+    if (k.y_f32 && k.fst_want) return 1;
+    const long V = (long)k.Do * k.Ho * k.Wo;
+    if (V < 32768) return 1;                                  // the deep levels: few voxels, many channels -- the lean kernel's ground
+    if (V * (long)(k.Cin > k.Cout ? k.Cin : k.Cout) >= (1L << 31)) return 1;      // 32-bit element offsets inside a sample
+    const int nstep = (K8 + 3) / 4, mt = k.Mpad / 16;
+#define PW_CASE(NS, M) if (nstep <= NS && mt == M) return launch_pw<NS, M>(k, K8, st);
+    PW_CASE(1, 1) PW_CASE(2, 1) PW_CASE(4, 1) PW_CASE(1, 2) PW_CASE(2, 2) PW_CASE(4, 2)
+#undef PW_CASE
+    return 1;
+}
+
+// the input gradient (conv_lean.hip mode 1 for ksize 1): K8 = blocks of 8 dY channels; k.wpack (transposed images), k.Mpad = pad16(Cin),
+// k.sums_rep / sums_fixed set by the caller
+int launch_conv_pw_dgrad(ConvK& k, int K8, hipStream_t st) {
+    if (!g_conv_pw || k.bd_rows || k.y_f32) return 1;
+    if (K8 < 1 || K8 > 16 || k.Mpad > 128) return 1;
+    const long V = (long)k.Di * k.Hi * k.Wi;
+    if (V < 32768) return 1;
+    for (int s = 0; s < k.nseg; ++s) if (k.seg[s].C % 4) return 1;
+    const int nstep = (K8 + 3) / 4, mt = k.Mpad / 16;
+#define PWD_CASE(NS, M) if (nstep <= NS && mt == M) return launch_pw_dgrad<NS, M>(k, K8, st);
+    PWD_CASE(1, 1) PWD_CASE(1, 2) PWD_CASE(1, 4) PWD_CASE(1, 8) PWD_CASE(2, 1) PWD_CASE(2, 2) PWD_CASE(2, 4) PWD_CASE(4, 1) PWD_CASE(4, 2) PWD_CASE(4, 4)
+#undef PWD_CASE
+    return 1;
+}
+
+}  // namespace pconv

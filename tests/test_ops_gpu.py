@@ -111,6 +111,65 @@ def test_conv_block_fwd_bwd(case, dtype):
         assert e < tol * 3, f"dx[{i}] {e}"
 
 
+PW_CASES = [
+    # (segC list, Cout, (D,H,W), norm, use_mask): 1x1x1 convs over >= 32768 voxels -> conv_pw.hip (LDS-free streaming GEMM)
+    ([8, 8, 8, 8], 8, (32, 32, 32), True, True),
+    ([16], 16, (33, 32, 40), True, False),
+    ([16, 16, 16, 16], 16, (32, 32, 40), True, True),
+    ([32, 32, 32], 32, (32, 32, 32), True, False),
+    ([8], 8, (64, 64, 64), False, False),
+    ([128], 32, (32, 32, 33), True, False),
+]
+
+
+@pytest.mark.parametrize("case", PW_CASES, ids=[str(i) for i in range(len(PW_CASES))])
+def test_pointwise_streaming_kernel(case):
+    """conv_pw.hip against the float64 reference (forward; its backward stays on the lean kernels and is checked through the
+    same call), and against the lean kernel it replaces: same bf16 inputs, same MFMA products, so the two agree to the rounding of
+    the f32 accumulation order"""
+    from passion_amd import ops
+    dev = _dev()
+    segC, Cout, (D, H, W), norm, use_mask = case
+    dtype, B = torch.bfloat16, 2
+    g = torch.Generator().manual_seed(23 + Cout)
+    xs = [(torch.randn(B, c, D, H, W, generator=g, dtype=torch.float64) * 1.5 + 0.3).to(dtype).double() for c in segC]
+    cin = sum(segC)
+    w = torch.randn(Cout, cin, 1, 1, 1, generator=g, dtype=torch.float64) / cin ** 0.5
+    b = torch.randn(Cout, generator=g, dtype=torch.float64)
+    mask = torch.tensor([[True, False, True, True], [False, True, True, False]])[:, :len(segC)] if use_mask else None
+    gy = torch.randn(B, Cout, D, H, W, generator=g, dtype=torch.float64).to(dtype).double()
+    xr = [x.clone().requires_grad_(True) for x in xs]
+    wr, br = w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    masks = [None if mask is None else mask[:, i].double() for i in range(len(segC))]
+    yr = ref_conv_block(xr, [norm] * len(segC), masks, wr, br, 1, 1, 0, None)
+    yr.backward(gy)
+    md = mask.to(dev) if mask is not None else None
+    res = {}
+    for pw in (1, 0):
+        old = ops.set_option("conv_pw", pw)
+        try:
+            xd = [cl(x).to(dev, dtype).requires_grad_(True) for x in xs]
+            wd, bd = w.float().to(dev).requires_grad_(True), b.float().to(dev).requires_grad_(True)
+            segs = [ops.SegIn(x, stats=ops.instnorm_stats(x.detach()) if norm else None, mask=md, mask_col=i) for i, x in enumerate(xd)]
+            y, st = ops.conv_block(segs, wd, bd, D, H, W, ksize=1, stride=1, pad_mode=0, want_stats=True)
+            y.backward(cl(gy).to(dev, dtype))
+            res[pw] = (y.detach().clone(), st.clone(), wd.grad.clone(), [x.grad.clone() for x in xd])
+        finally:
+            ops.set_option("conv_pw", old)
+    y, st, dw, dxs = res[1]
+    assert relerr(nc(y.float()), yr) < TOL[dtype], relerr(nc(y.float()), yr)
+    assert relerr(dw, wr.grad) < 2 * TOL[dtype]
+    for i in range(len(segC)):
+        assert relerr(nc(dxs[i].float()), xr[i].grad) < 3 * TOL[dtype]
+    # against the lean kernel: identical up to the order of the f32 accumulation (one bf16 rounding step at most, rarely)
+    d = (y.float() - res[0][0].float()).abs()
+    assert float(d.max()) <= 2.0 ** -7 * float(y.float().abs().max()) and float((d > 0).float().mean()) < 0.05
+    want = ops.instnorm_stats(y)
+    std = 1.0 / want[..., 1]
+    assert float(((st[..., 0] - want[..., 0]).abs() / (std + want[..., 0].abs())).max()) < 2e-5
+    assert float(((st[..., 1] - want[..., 1]).abs() / want[..., 1]).max()) < 1e-4
+
+
 S2_CASES = [
     # (Cin, Cout, (D,H,W), normalised input, modality mask): the stride-2 convs of encoder levels 2..5 (mmformer.py:33,38,43,48) and
     # ragged / non-cube volumes; conv_s2_dgrad.hip (gather form: 1-8 taps per parity class) vs the zero-stuffed lean kernel
@@ -663,6 +722,8 @@ FUSED_STATS_CASES = [
     ([8], 8, 3, 2, 1, (10, 12, 20), torch.bfloat16, False, "stride 2, ragged bricks"),
     ([8], 8, 3, 1, 1, (10, 12, 20), torch.bfloat16, False, "ragged bricks: statistics kernels after the conv"),
     ([8], 8, 3, 1, 1, (8, 8, 16), torch.float32, False, "f32 storage: statistics kernels after the conv"),
+    ([16], 16, 1, 1, 0, (32, 32, 32), torch.bfloat16, False, "pointwise streaming kernel (conv_pw.hip), one K step"),
+    ([16, 16, 16, 16], 32, 1, 1, 0, (33, 32, 40), torch.bfloat16, False, "pointwise streaming kernel, two K steps x two row tiles, ragged"),
 ]
 
 
