@@ -115,7 +115,7 @@ int launch_conv_s2_dgrad(ConvK& k, const void* packed_bf16, hipStream_t st);   /
 extern int g_conv_s2;
 int launch_conv_pw_fwd(ConvK& k, int K8, hipStream_t st);   // conv_pw.hip: 1x1x1 forward as a streaming GEMM (wide volumes)
 int launch_conv_pw_dgrad(ConvK& k, int K8, hipStream_t st);
-extern int g_conv_pw;
+extern int g_conv_pw, g_conv_pw8;
 bool conv_march_covers(const ConvK& k, int ksize, int stride, int mode, int* K8out);
 int launch_wgrad_lean(ConvK& k, int ksize, int stride, int MT, int gx, int gy, float* dWslab, float* dbslab, hipStream_t st);   // conv_wgrad_lean.hip
 bool wgrad_lean_covers(const ConvK& k, int ksize, int stride, int MT, int gx, int gy);

@@ -13,7 +13,7 @@
 #include "conv_common.h"
 #include "prof.h"
 
-namespace pconv { extern int g_conv_target; int g_conv_pw = 1; }      // option "conv_pw" / PASSION_CONV_PW=0: back to the lean kernel (A/B)
+namespace pconv { extern int g_conv_target; int g_conv_pw = 1, g_conv_pw8 = 1; }      // option "conv_pw" / PASSION_CONV_PW=0: back to the lean kernel (A/B)
 using namespace pconv;
 
 namespace {
@@ -385,6 +385,266 @@ int launch_pw_dgrad(ConvK& k, int K8, hipStream_t st) {
     return 0;
 }
 
+// ---- 8-channel K axis (Cin = 8 forward; Cout <= 8 gradient: the level-1 d1_out convs and the logit heads).  With K = 8 the
+// 16x16x32 form above feeds data through a quarter of its lanes (3.0 TB/s).  v_mfma_f32_32x32x8_bf16 has K = 8 exactly: lane
+// (col, h) holds channels 4h .. 4h + 3 of voxel col -- EVERY lane loads 8 useful bytes, a wavefront instruction covers 32 voxels
+// = 512 contiguous bytes, and the result rows 8i + 4h + j give lane (col, h) four consecutive output channels of its voxel.
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ float group32_sum(float v) {
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// forward, one 8-channel segment, Cout <= 8 (bf16 or f32 out).  grid (nwg_b, B)
+__global__ __launch_bounds__(256) void conv_pw8_fwd_kernel(ConvK p, long V) {
+    constexpr int TT = 8;
+    __shared__ float lsum[4 * 8 * 2 + 16];
+    const int tid = threadIdx.x, lane = tid & 63, col = lane & 31, h = lane >> 5, wv = tid >> 6;
+    const int b = blockIdx.y;
+    const SegD& sd = p.seg[0];
+    const int bs = sd.bsrc(b);
+    const bf16_t* src = reinterpret_cast<const bf16_t*>(sd.x) + (long)bs * sd.bstride + 4 * h;
+    bool live = true;
+    if (sd.mask) live = gload<uint8_t>(sd.mask + (long)b * sd.mask_ld + sd.mask_col) != 0;
+    const bool hn = sd.stats != nullptr;
+    f32x2 sc[2] = {{1.f, 1.f}, {1.f, 1.f}}, sh[2] = {{0.f, 0.f}, {0.f, 0.f}};
+    if (hn) {
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const f32x4 st4 = gload<f32x4>(sd.stats + ((long)bs * 8 + 4 * h + 2 * c) * 2);
+            sc[c] = (f32x2){st4[1], st4[3]};
+            sh[c] = (f32x2){-st4[0] * st4[1], -st4[2] * st4[3]};
+        }
+    }
+    // A fragment: W[row = col][4h .. 4h + 3] from the packed image [blk 0][Mpad rows] of 8 bf16
+    s16x4 wf = {0, 0, 0, 0};
+    if (col < p.Mpad) {
+        const u32x2 w2 = gload<u32x2>(reinterpret_cast<const char*>(p.wpack) + (wvec_of(p, b) + col) * 16 + 8 * h);
+        wf = __builtin_bit_cast(s16x4, w2);
+    }
+    const bool row_ok = 4 * h < p.Cout;
+    f32x4 biasv = {0.f, 0.f, 0.f, 0.f};
+    if (bias_of(p, b) && row_ok) biasv = load4(bias_of(p, b) + 4 * h);
+    const f32x2 slope2 = {p.slope, p.slope};
+    const bool fstats = p.fst.stats != nullptr;
+    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2v[4] = {0.f, 0.f, 0.f, 0.f};
+    char* yb = reinterpret_cast<char*>(p.y) + (long)b * V * p.Cout * (p.y_f32 ? 4 : 2);
+
+    for (long v0 = ((long)blockIdx.x * 4 + wv) * (32 * TT); v0 < V; v0 += (long)gridDim.x * 4 * (32 * TT)) {
+        u32x2 raw[TT];
+#pragma unroll
+        for (int t = 0; t < TT; ++t) {
+            const long v = v0 + t * 32 + col;
+            raw[t] = gload<u32x2>(src + (v < V ? v : V - 1) * 8);
+        }
+#pragma unroll
+        for (int t = 0; t < TT; ++t) {
+            u32x2 o = raw[t];
+            if (hn) {
+                unsigned pk[2];
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    const f32x2 xv = {__uint_as_float(o[c] << 16), __uint_as_float(o[c] & 0xffff0000u)};
+                    f32x2 tv = __builtin_elementwise_fma(xv, sc[c], sh[c]);
+                    const f32x2 ts = tv * slope2;
+                    tv.x = fmaxf(tv.x, ts.x);
+                    tv.y = fmaxf(tv.y, ts.y);
+                    const __bf16 lo = (__bf16)tv.x, hi = (__bf16)tv.y;
+                    pk[c] = (unsigned)__builtin_bit_cast(unsigned short, lo) | ((unsigned)__builtin_bit_cast(unsigned short, hi) << 16);
+                }
+                o = (u32x2){pk[0], pk[1]};
+            }
+            if (!live) o = (u32x2){0u, 0u};
+            f32x16 acc;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc[j] = 0.f;
+            acc = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(wf, __builtin_bit_cast(s16x4, o), acc, 0, 0, 0);
+            const long v = v0 + t * 32 + col;
+            const bool valid = v < V;
+            const f32x4 val = (f32x4){acc[0], acc[1], acc[2], acc[3]} + biasv;          // rows 4h .. 4h + 3
+            const long el = v * p.Cout + 4 * h;
+            if (p.y_f32) {
+                if (valid && row_ok) *reinterpret_cast<f32x4*>(yb + el * 4) = val;
+            } else {
+                unsigned pk[2];
+                float rb[4];
+                round4_bf16(val, pk, rb);
+                if (valid && row_ok) *reinterpret_cast<u32x2*>(yb + el * 2) = (u32x2){pk[0], pk[1]};
+                if (fstats) {
+                    const float vf = valid ? 1.f : 0.f;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float r = rb[j] * vf;
+                        s1[j] += r;
+                        s2v[j] = __builtin_fmaf(r, r, s2v[j]);
+                    }
+                }
+            }
+        }
+    }
+    if (fstats) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float a1 = group32_sum(s1[j]), a2 = group32_sum(s2v[j]);
+            if (col == 0) { lsum[(wv * 8 + 4 * h + j) * 2 + 0] = a1; lsum[(wv * 8 + 4 * h + j) * 2 + 1] = a2; }
+        }
+        __syncthreads();
+        float* wsum = lsum + 4 * 8 * 2;
+        if (tid < 16) {
+            float t = 0.f;
+#pragma unroll
+            for (int w2 = 0; w2 < 4; ++w2) t += lsum[w2 * 16 + tid];
+            wsum[tid] = t;
+        }
+        __syncthreads();
+        fwd_stats_commit(p.fst, p.Cout, b, blockIdx.x, 0, 8, wsum, tid);
+    }
+}
+
+// gradient with a K axis of <= 8 dY channels (bf16, or f32 with Cout <= 4 per 16 bytes ... two loads for 8): rows = Cin <= 32
+template <int RT>                  // row tiles of 8 (Cin <= 8 RT)
+__global__ __launch_bounds__(256) void conv_pw8_dgrad_kernel(ConvK p, long V) {
+    constexpr int TT = 4;
+    __shared__ float lsum[4 * RT * 8 * 2];
+    __shared__ PwEpi edesc[RT * 2];
+    const int tid = threadIdx.x, lane = tid & 63, col = lane & 31, h = lane >> 5, wv = tid >> 6;
+    const int b = blockIdx.y;
+    if (tid < RT * 2) {
+        const int cg = (tid / 2) * 8 + (tid % 2) * 4;
+        PwEpi d;
+        d.x = reinterpret_cast<const bf16_t*>(p.seg[0].x); d.dx = nullptr; d.C = 0; d.ok = 0; d.has_stats = 0; d.mval = 1.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { d.mean[j] = 0.f; d.rstd[j] = 1.f; }
+#pragma unroll
+        for (int s2 = 0; s2 < PASSION_MAX_SEG; ++s2) {
+            if (s2 < p.nseg && cg < p.Cin) {
+                const SegD& sd = p.seg[s2];
+                if (cg >= sd.cbase && cg < sd.cbase + sd.C && sd.dx != nullptr) {
+                    const int cl = cg - sd.cbase, bs = sd.bsrc(b);
+                    d.ok = 1; d.C = sd.C; d.has_stats = sd.stats != nullptr;
+                    d.x = reinterpret_cast<const bf16_t*>(sd.x) + (long)bs * sd.bstride + cl;
+                    d.dx = reinterpret_cast<bf16_t*>(sd.dx) + (long)b * sd.bstride + cl;
+                    if (sd.mask) d.mval = sd.mask[(long)b * sd.mask_ld + sd.mask_col] ? 1.f : 0.f;
+                    if (sd.stats) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            d.mean[j] = sd.stats[((long)bs * sd.C + cl + j) * 2 + 0];
+                            d.rstd[j] = sd.stats[((long)bs * sd.C + cl + j) * 2 + 1];
+                        }
+                    }
+                }
+            }
+        }
+        edesc[tid] = d;
+    }
+    // A fragment: transposed image row = col (< Mpad), dY channels 4h .. 4h + 3
+    s16x4 wf = {0, 0, 0, 0};
+    if (col < p.Mpad) {
+        const u32x2 w2 = gload<u32x2>(reinterpret_cast<const char*>(p.wpack) + (wvec_of(p, b) + col) * 16 + 8 * h);
+        wf = __builtin_bit_cast(s16x4, w2);
+    }
+    const bool kf32 = p.y_f32 != 0;
+    const char* src = reinterpret_cast<const char*>(p.dy) + (long)b * V * p.Cout * (kf32 ? 4 : 2);
+    const bool k_ok = 4 * h < p.Cout;                       // this lane's four dY channels exist (Cout is 4 or 8 here)
+    __syncthreads();
+    const bf16_t* ex[RT];
+    unsigned eC[RT];
+    bool e_ok[RT], e_hs[RT];
+#pragma unroll
+    for (int i = 0; i < RT; ++i) {
+        const PwEpi& e = edesc[i * 2 + h];
+        ex[i] = e.x; eC[i] = (unsigned)e.C; e_ok[i] = e.ok != 0; e_hs[i] = e.has_stats != 0;
+    }
+    float s1[RT][4], s2v[RT][4];
+#pragma unroll
+    for (int i = 0; i < RT; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { s1[i][j] = 0.f; s2v[i][j] = 0.f; }
+
+    for (long v0 = ((long)blockIdx.x * 4 + wv) * (32 * TT); v0 < V; v0 += (long)gridDim.x * 4 * (32 * TT)) {
+        u32x2 raw[TT];
+        u32x2 xpre[RT][TT];
+#pragma unroll
+        for (int t = 0; t < TT; ++t) {
+            const long v = v0 + t * 32 + col;
+            const long vc = v < V ? v : V - 1;
+            if (kf32) {
+                f32x4 f = {0.f, 0.f, 0.f, 0.f};
+                f = gload<f32x4>(src + (vc * p.Cout + (k_ok ? 4 * h : 0)) * 4);
+                unsigned pk[2];
+                float rb[4];
+                round4_bf16(f, pk, rb);
+                raw[t] = (u32x2){pk[0], pk[1]};
+            } else {
+                raw[t] = gload<u32x2>(src + (vc * p.Cout + (k_ok ? 4 * h : 0)) * 2);
+            }
+            if (!k_ok) raw[t] = (u32x2){0u, 0u};
+#pragma unroll
+            for (int i = 0; i < RT; ++i) xpre[i][t] = gload<u32x2>(ex[i] + vc * eC[i]);
+        }
+#pragma unroll
+        for (int t = 0; t < TT; ++t) {
+            f32x16 acc;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc[j] = 0.f;
+            acc = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(wf, __builtin_bit_cast(s16x4, raw[t]), acc, 0, 0, 0);
+            const long v = v0 + t * 32 + col;
+#pragma unroll
+            for (int i = 0; i < RT; ++i) {
+                const PwEpi& e = edesc[i * 2 + h];
+                const float f_pos = e.mval, f_neg = e_hs[i] ? e.mval * p.slope : e.mval;
+                const bool valid = e_ok[i] && v < V;
+                const u32x2 xr = xpre[i][t];
+                const float xv[4] = {__uint_as_float(xr.x << 16), __uint_as_float(xr.x & 0xffff0000u),
+                                     __uint_as_float(xr.y << 16), __uint_as_float(xr.y & 0xffff0000u)};
+                const float vf = (valid && e_hs[i]) ? 1.f : 0.f;
+                f32x4 gv = {acc[4 * i], acc[4 * i + 1], acc[4 * i + 2], acc[4 * i + 3]};      // rows 8 i + 4 h + j
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float xh = (xv[j] - e.mean[j]) * e.rstd[j];
+                    const float gg = gv[j] * (xh > 0.f ? f_pos : f_neg);
+                    gv[j] = gg;
+                    const float gs = gg * vf;
+                    s1[i][j] += gs;
+                    s2v[i][j] = __builtin_fmaf(gs, xh, s2v[i][j]);
+                }
+                if (valid) store4(e.dx + v * eC[i], gv);
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < RT; ++i) {
+        const bool st = e_ok[i] && e_hs[i];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float a1 = group32_sum(s1[i][j]), a2 = group32_sum(s2v[i][j]);
+            if (col == 0) {
+                lsum[((wv * RT + i) * 8 + 4 * h + j) * 2 + 0] = st ? a1 : 0.f;
+                lsum[((wv * RT + i) * 8 + 4 * h + j) * 2 + 1] = st ? a2 : 0.f;
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < RT * 8 * 2; i += 256) {
+        const int row = i >> 1, k2 = i & 1;
+        const float t = ((lsum[(0 * RT * 8 + row) * 2 + k2] + lsum[(1 * RT * 8 + row) * 2 + k2]) + lsum[(2 * RT * 8 + row) * 2 + k2]) +
+                        lsum[(3 * RT * 8 + row) * 2 + k2];
+        if (row < p.Cin && t != 0.f) {
+            const long idx = (long)(blockIdx.x % p.sums_rep) * p.B * p.Cin * 2 + ((long)b * p.Cin + row) * 2 + k2;
+            if (p.sums_fixed) {
+                double v = (double)t * 1099511627776.0;
+                v = fmin(fmax(v, -9.0e18), 9.0e18);
+                atomicAdd(reinterpret_cast<unsigned long long*>(p.sums) + idx, (unsigned long long)(long long)llrint(v));
+            } else {
+                atomicAdd(&p.sums[idx], t);
+            }
+        }
+    }
+}
+
 template <int NSTEP, int MT>
 int launch_pw(ConvK& k, int K8, hipStream_t st) {
     const long V = (long)k.Do * k.Ho * k.Wo;
@@ -416,6 +676,19 @@ int launch_conv_pw_fwd(ConvK& k, int K8, hipStream_t st) {
     if (k.y_f32 && k.fst_want) return 1;
     const long V = (long)k.Do * k.Ho * k.Wo;
     if (V < 32768) return 1;                                  // the deep levels: few voxels, many channels -- the lean kernel's ground
+    if (g_conv_pw8 && K8 == 1 && k.nseg == 1 && k.seg[0].C == 8 && k.Cout <= 8 && k.Cout % 4 == 0) {
+        const long chunks = (V + 1023) / 1024;
+        const long nwg_b = hmax(1, hmin(chunks / 2 > 0 ? chunks / 2 : 1, (g_conv_target + k.B - 1) / k.B));
+        k.fst.stats = nullptr;
+        if (k.fst_want && !k.y_f32) {
+            const int rc = fwd_stats_setup(k, (int)nwg_b, 1, st);
+            if (rc) return rc < 0 ? rc : -rc;
+        }
+        passion_prof_tag("conv_pw8_fwd_kernel");
+        hipLaunchKernelGGL(conv_pw8_fwd_kernel, dim3((unsigned)nwg_b, k.B), dim3(256), 0, st, k, V);
+        LAUNCH_RET();
+        return 0;
+    }
     if (V * (long)(k.Cin > k.Cout ? k.Cin : k.Cout) >= (1L << 31)) return 1;      // 32-bit element offsets inside a sample
     const int nstep = (K8 + 3) / 4, mt = k.Mpad / 16;
 #define PW_CASE(NS, M) if (nstep <= NS && mt == M) return launch_pw<NS, M>(k, K8, st);
@@ -427,11 +700,23 @@ int launch_conv_pw_fwd(ConvK& k, int K8, hipStream_t st) {
 // the input gradient (conv_lean.hip mode 1 for ksize 1): K8 = blocks of 8 dY channels; k.wpack (transposed images), k.Mpad = pad16(Cin),
 // k.sums_rep / sums_fixed set by the caller
 int launch_conv_pw_dgrad(ConvK& k, int K8, hipStream_t st) {
-    if (!g_conv_pw || k.bd_rows || k.y_f32) return 1;
-    if (K8 < 1 || K8 > 16 || k.Mpad > 128) return 1;
+    if (!g_conv_pw || k.bd_rows) return 1;
     const long V = (long)k.Di * k.Hi * k.Wi;
     if (V < 32768) return 1;
     for (int s = 0; s < k.nseg; ++s) if (k.seg[s].C % 4) return 1;
+    if (g_conv_pw8 && K8 == 1 && (k.Cout == 4 || k.Cout == 8) && k.Mpad <= 32) {       // dY of <= 8 channels (bf16, or the f32 logit gradient)
+        const int rt = (k.Cin + 7) / 8;
+        const long chunks = (V + 511) / 512;
+        const long nwg_b = hmax(1, hmin(chunks / 2 > 0 ? chunks / 2 : 1, (g_conv_target + k.B - 1) / k.B));
+        passion_prof_tag("conv_pw8_dgrad_kernel<%d>", rt);
+#define PW8D(R) if (rt == R) hipLaunchKernelGGL((conv_pw8_dgrad_kernel<R>), dim3((unsigned)nwg_b, k.B), dim3(256), 0, st, k, V);
+        PW8D(1) PW8D(2) PW8D(3) PW8D(4)
+#undef PW8D
+        LAUNCH_RET();
+        return 0;
+    }
+    if (k.y_f32) return 1;
+    if (K8 < 1 || K8 > 16 || k.Mpad > 128) return 1;
     const int nstep = (K8 + 3) / 4, mt = k.Mpad / 16;
 #define PWD_CASE(NS, M) if (nstep <= NS && mt == M) return launch_pw_dgrad<NS, M>(k, K8, st);
     PWD_CASE(1, 1) PWD_CASE(1, 2) PWD_CASE(1, 4) PWD_CASE(1, 8) PWD_CASE(2, 1) PWD_CASE(2, 2) PWD_CASE(2, 4) PWD_CASE(4, 1) PWD_CASE(4, 2) PWD_CASE(4, 4)

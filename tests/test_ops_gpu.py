@@ -119,6 +119,9 @@ PW_CASES = [
     ([32, 32, 32], 32, (32, 32, 32), True, False),
     ([8], 8, (64, 64, 64), False, False),
     ([128], 32, (32, 32, 33), True, False),
+    ([8], 8, (33, 40, 32), True, True),               # 8-channel K axis: the 32x32x8 MFMA form (forward and gradient)
+    ([16], 8, (32, 32, 32), True, False),             # its gradient has 16 rows over a K of 8
+    ([8, 8, 8], 8, (32, 32, 32), True, True),         # gradient: 24 rows (three segments) over a K of 8
 ]
 
 
@@ -270,12 +273,16 @@ def test_conv_kernel_paths(case, path):
             ops.set_option(k, v)
 
 
-@pytest.mark.parametrize("segC,Cout,k,norm", [([16], 4, 1, False), ([8, 8], 4, 1, True), ([8], 4, 3, True), ([32], 8, 1, False)])
-def test_conv_f32_logit_head(segC, Cout, k, norm):
+@pytest.mark.parametrize("segC,Cout,k,norm,dims", [([16], 4, 1, False, (8, 16, 24)), ([8, 8], 4, 1, True, (8, 16, 24)), ([8], 4, 3, True, (8, 16, 24)),
+                                                   ([32], 8, 1, False, (8, 16, 24)),
+                                                   # >= 32768 voxels: the streaming pointwise kernels (conv_pw.hip; 8 channels: 32x32x8 MFMA form)
+                                                   ([8], 4, 1, True, (32, 32, 33)), ([16], 4, 1, True, (33, 32, 32)), ([8], 8, 1, False, (32, 32, 32)),
+                                                   ([8, 8, 8, 8], 4, 1, True, (32, 32, 32))])
+def test_conv_f32_logit_head(segC, Cout, k, norm, dims):
     """bf16 activations -> f32 logits (segmentation / region-probability heads): forward, dgrad with f32 dY, wgrad"""
     from passion_amd import ops
     dev = _dev()
-    B, D, H, W = 2, 8, 16, 24
+    B, (D, H, W) = 2, dims
     g = torch.Generator().manual_seed(13)
     xs = [(torch.randn(B, c, D, H, W, generator=g, dtype=torch.float64) * 1.2 + 0.2).to(torch.bfloat16).double() for c in segC]
     cin = sum(segC)

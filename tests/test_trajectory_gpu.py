@@ -4,7 +4,9 @@ almost every voxel and cannot tell bf16 rounding from a small kernel bug (VERDIC
 same seed (forward, train.py loss assembly, backward, FusedAdamW).
 
 What is asserted, and why in this form:
-  * the LOSS OF EVERY STEP against the reference's trajectory: f32 1e-3 (plain) / 2e-3 (PASSION), bf16 (the benchmarked kernels:
+  * the LOSS OF EVERY STEP against the reference's trajectory: f32 1e-3 (plain) / 4e-3 (PASSION: the f32 kernels add their
+    InstanceNorm-backward sums with float atomics -- order-dependent, unlike the fixed-point sums of the bf16 path -- and 21 PASSION
+    steps amplify that: eight runs of the same build gave a largest step error between 7.8e-4 and 1.7e-3), bf16 (the benchmarked kernels:
     marching / lean bf16 convs, flash attention, side streams) 5e-3.  A wrong gradient anywhere bends the trajectory within a few
     steps; 30 steps within 2e-3 in bf16 is the strongest statement this suite makes about the benchmarked backward.
     PASSION's loss contains a DISCRETE gate (rp_mask, train.py:266-270: sign of a relative distance): the fixture stores the
@@ -26,7 +28,7 @@ from _util import gold, mask_dice, rel, replay_trajectory, unpack2
 pytestmark = pytest.mark.gpu
 
 CASES = ["traj_plain_64.npz", "traj_passion_32.npz"]
-LOSS_TOL = {(torch.float32, False): 1e-3, (torch.float32, True): 2e-3, (torch.bfloat16, False): 5e-3, (torch.bfloat16, True): 1e-2}
+LOSS_TOL = {(torch.float32, False): 1e-3, (torch.float32, True): 4e-3, (torch.bfloat16, False): 5e-3, (torch.bfloat16, True): 1e-2}
 # measured on MI355X (printed below): f32 311 / 262144 differing voxels (64^3, Dice 0.981), 81 / 32768 (32^3 PASSION, Dice 0.928: the
 # enhancing class has ~60 voxels there); bf16 1848 / 262144 (17 with a reference margin >= 0.1, Dice 0.889)
 MASK = {torch.float32: dict(diff=0.003, far=2e-4, acc=1e-3, dice=0.90), torch.bfloat16: dict(diff=0.02, far=2e-3, acc=4e-3, dice=0.80)}
