@@ -658,6 +658,7 @@ int fill_params(const passion_conv_desc_t* d, ConvK& k) {
     for (int g = 0; g < PASSION_MAX_GROUPS; ++g) k.biasg[g] = nullptr;
     k.bd_rows = 0; k.bd_k8 = 0;
     k.y_f32 = 0;
+    k.spos = nullptr; k.pwm = nullptr;
     if (d->ksize != 1 && d->ksize != 3) return -1002;
     if (d->stride != 1 && d->stride != 2) return -1003;
     if (d->ksize == 1 && d->stride != 1) return -1003;
@@ -863,9 +864,16 @@ static long pass_scratch_floats(const ConvK& k, const passion_conv_desc_t* d) {
 }
 // scratch layout (floats): [InstanceNorm-backward sums | wgrad slab] then, from a 128-byte boundary, [padded-domain gradient]
 // [per-pass gradients or the masked pass sums]
+// pointwise layers (nt == 1): + the indicator slab [gx][Cout Cin], the per-sample folds [B][2 Cout Cin + Cout] and the means
+// [B][Cin][2] of the finish-free backward (conv_pw.hip)
+static long pw_extra_floats(const ConvK& k, int gx, int nt) {
+    if (nt != 1) return 0;
+    const long nW = (long)k.Cout * k.Cin;
+    return ((long)gx * nW + (long)k.B * (2 * nW + k.Cout) + (long)k.B * k.Cin * 2 + 31) / 32 * 32;
+}
 static long slab_end_floats(const ConvK& k, int gx, int nt) {
     const long n = (long)2 * k.B * k.Cin * SUMS_SLOTS + (long)gx * ((long)k.Cout * k.Cin * nt + k.Cout);
-    return (n + 31) / 32 * 32;
+    return (n + 31) / 32 * 32 + pw_extra_floats(k, gx, nt);
 }
 static long padout_floats(const ConvK& k) {     // bf16 [B][D+2][H+2][W+2][Cin]
     return (((long)k.B * (k.Di + 2) * (k.Hi + 2) * pad8(k.Wi + 2) * k.Cin + 1) / 2 + 4 + 31) / 32 * 32;      // rows padded to 8 voxels
@@ -1072,7 +1080,21 @@ static int conv3d_bwd_impl(const passion_conv_desc_t* d, const float* packed, co
     for (int s = 0; s < k.nseg; ++s) {
         if (k.seg[s].dx) { need_dx = true; if (k.seg[s].stats) need_norm = true; }
     }
-    Companion* comp = (phase == 0 && pconv::g_wgrad_fork && need_dx && (dweight || dbias)) ? companion(st) : nullptr;
+    // Pointwise layers, whole backward in one call, every input gradient normalised: the weight gradient runs FIRST and also
+    // leaves what the InstanceNorm-backward means are made of (conv_pw.hip); the input-gradient kernel then writes dx
+    // itself -- no sums, no finish pass.
+    bool pw_final = false;
+    WgPlan wpl{};
+    if (phase == 0 && !ga && parts == 3 && d->ksize == 1 && d->stride == 1 && pconv::g_conv_pwfinal && pconv::g_conv_lean && !g_passion_force_f32_mfma &&
+        d->x_dtype == PASSION_BF16 && d->y_dtype == PASSION_BF16 && need_dx && need_norm && dweight && dbias && sums && !use_blockdiag(k, d)) {
+        k.Mpad = pad16(k.Cout);
+        wpl = plan_wgrad(k, d);
+        bool all_norm = true;
+        for (int s = 0; s < k.nseg; ++s) if (k.seg[s].dx && !k.seg[s].stats) all_norm = false;
+        pw_final = all_norm && wpl.bf16 && wgrad_bf16_chunk(k, 1, 1) != 16 && wgrad_lean_covers(k, 1, 1, wpl.MT, wpl.gx, wpl.gy) &&
+                   wpl.gx % k.B == 0 && conv_pw_dgrad_covers(k);
+    }
+    Companion* comp = (phase == 0 && pconv::g_wgrad_fork && need_dx && (dweight || dbias) && !pw_final) ? companion(st) : nullptr;
     hipStream_t caller_st = st;
     if (comp) {                                      // fork: the weight-gradient work below goes to the companion stream
         HIP_RET(hipEventRecord(comp->fork, caller_st));
@@ -1094,7 +1116,8 @@ static int conv3d_bwd_impl(const passion_conv_desc_t* d, const float* packed, co
         float* bslab = wslab + nW;
         // the fold of the slab rides in the finish launch at the end of this call when one follows (FoldJob); the wgrad kernel then
         // clears the InstanceNorm-backward sums itself
-        defer_fold = !comp && phase == 0 && (parts & 2) && need_dx && (ga || (dweight && dbias == dweight + nW));
+        defer_fold = !comp && phase == 0 && (parts & 2) && need_dx && (ga || (dweight && dbias == dweight + nW)) && !pw_final;
+        if (pw_final) k.spos = wslab + (long)w.gx * k.wslot;
         if (defer_fold && zsums) { k.zero_ptr = zsums; k.zero_n = zn; }
         {
             ProfScope prof(3, conv_bytes(k, xs, ys) + (double)nt * k.Cin * k.Cout * 4,
@@ -1125,6 +1148,9 @@ static int conv3d_bwd_impl(const passion_conv_desc_t* d, const float* packed, co
             if (rc) return rc;
         }
         k.zero_ptr = nullptr; k.zero_n = 0;
+        if (pw_final) {
+            // folded per sample below (launch_pw_ident), which also writes dweight / dbias
+        } else
         if (defer_fold) {
             fj.part = wslab; fj.n = k.wslot; fj.stride = k.wslot; fj.R = w.gx; fj.G = 1;
             fj.out[0] = dweight;
@@ -1167,6 +1193,26 @@ static int conv3d_bwd_impl(const passion_conv_desc_t* d, const float* packed, co
     if (comp) {
         HIP_RET(hipEventRecord(comp->done, comp->side));
         st = caller_st;
+    }
+    if (pw_final) {
+        // per-sample folds + contraction -> (m1, m2) / V, then the input gradient with its final epilogue; nothing else follows
+        const long nW = (long)k.Cout * k.Cin;
+        const float* wslab = sums + (long)2 * k.B * k.Cin * SUMS_SLOTS;
+        float* sslab = const_cast<float*>(wslab) + (long)wpl.gx * k.wslot;
+        float* dwb = sslab + (long)wpl.gx * nW;
+        float* pb = dwb + (long)k.B * (nW + k.Cout);
+        float* mb = pb + (long)k.B * nW;
+        const bf16_t* wdg = reinterpret_cast<const bf16_t*>(packed + f32_pack_floats(k.Cin, k.Cout, 1)) + (long)pad8(k.Cin) * pad16(k.Cout);
+        k.spos = nullptr;
+        rc = launch_pw_ident(k, wslab, k.wslot, sslab, wpl.gx / k.B, wdg, dwb, pb, mb, dweight, dbias, st);
+        if (rc) return rc;
+        k.pwm = mb;
+        k.sums = nullptr; k.sums_rep = 1; k.sums_fixed = 0; k.sums_float_only = 0;
+        k.tilesD = cdiv(k.Di, TD); k.tilesH = cdiv(k.Hi, TH); k.tilesW = cdiv(k.Wi, TW);
+        ProfScope prof(2, conv_bytes(k, xs, ys) + (double)k.Cin * k.Cout * 4, 2.0 * k.B * k.Do * k.Ho * k.Wo * (double)k.Cout * k.Cin, st);
+        rc = launch_conv_lean(k, 1, 1, 1, packed + f32_pack_floats(k.Cin, k.Cout, 1), st);
+        if (rc > 0) rc = -1020;                      // planned for the pointwise kernels: must be covered
+        return rc;
     }
     // ---- dgrad ----
     if (!need_dx || !(parts & 2)) return 0;

@@ -13,7 +13,7 @@
 #include "conv_common.h"
 #include "prof.h"
 
-namespace pconv { extern int g_conv_target; int g_conv_pw = 1, g_conv_pw8 = 1; }      // option "conv_pw" / PASSION_CONV_PW=0: back to the lean kernel (A/B)
+namespace pconv { extern int g_conv_target; int g_conv_pw = 1, g_conv_pw8 = 1, g_conv_pwfinal = 1; }      // option "conv_pw" / PASSION_CONV_PW=0: back to the lean kernel (A/B)
 using namespace pconv;
 
 namespace {
@@ -221,7 +221,9 @@ struct alignas(16) PwEpi {       // the four output rows (= forward input channe
     float mean[4], rstd[4];
 };
 
-template <int NSTEP, int MT>
+// FINAL: the InstanceNorm-backward means (p.pwm: m1, m2 per (sample, channel), from the weight gradient -- pw_ident_kernel below)
+// are known before the kernel starts: the epilogue writes dx = rstd (g' - m1 - x_hat m2) itself and no finish pass follows.
+template <int NSTEP, int MT, bool FINAL>
 __global__ __launch_bounds__(256) void conv_pw_dgrad_kernel(ConvK p, int K8, long V) {
     constexpr int TT = 4;
     __shared__ float lsum[4 * MT * 16 * 2];
@@ -278,11 +280,15 @@ __global__ __launch_bounds__(256) void conv_pw_dgrad_kernel(ConvK p, int K8, lon
         const PwEpi& e = edesc[mt * 4 + g];
         ex[mt] = e.x; eC[mt] = (unsigned)e.C; e_ok[mt] = e.ok != 0; e_hs[mt] = e.has_stats != 0;
     }
-    float s1[MT][4], s2v[MT][4];
+    float s1[MT][4], s2v[MT][4];                               // FINAL: (m1, m2) of the lane's rows instead of running sums
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { s1[mt][j] = 0.f; s2v[mt][j] = 0.f; }
+        for (int j = 0; j < 4; ++j) {
+            s1[mt][j] = 0.f; s2v[mt][j] = 0.f;
+            const int row = mt * 16 + g * 4 + j;
+            if (FINAL && row < p.Cin) { s1[mt][j] = p.pwm[((long)b * p.Cin + row) * 2]; s2v[mt][j] = p.pwm[((long)b * p.Cin + row) * 2 + 1]; }
+        }
     const unsigned cdy = (unsigned)p.Cout;
 
     for (long v0 = ((long)blockIdx.x * 4 + wv) * (16 * TT); v0 < V; v0 += (long)gridDim.x * 4 * (16 * TT)) {
@@ -334,15 +340,20 @@ __global__ __launch_bounds__(256) void conv_pw_dgrad_kernel(ConvK p, int K8, lon
                 for (int j = 0; j < 4; ++j) {
                     const float xh = (xv[j] - mean[j]) * rstd[j];
                     const float gg = gv[j] * (xh > 0.f ? f_pos : f_neg);
-                    gv[j] = gg;
-                    const float gs = gg * vf;
-                    s1[mt][j] += gs;
-                    s2v[mt][j] = __builtin_fmaf(gs, xh, s2v[mt][j]);
+                    if (FINAL) {
+                        gv[j] = e_hs[mt] ? rstd[j] * (gg - s1[mt][j] - xh * s2v[mt][j]) : gg;
+                    } else {
+                        gv[j] = gg;
+                        const float gs = gg * vf;
+                        s1[mt][j] += gs;
+                        s2v[mt][j] = __builtin_fmaf(gs, xh, s2v[mt][j]);
+                    }
                 }
                 if (valid) store4(dxp + v * eC[mt], gv);
             }
         }
     }
+    if (FINAL) return;
     // one reduction per workgroup: 16 voxel lanes (shuffles) -> 4 waves (LDS, fixed order) -> one replica of the global sums
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
@@ -379,8 +390,9 @@ int launch_pw_dgrad(ConvK& k, int K8, hipStream_t st) {
     const long V = (long)k.Di * k.Hi * k.Wi;
     const long chunks = (V + 255) / 256;
     const long nwg_b = hmax(1, hmin(chunks / 2 > 0 ? chunks / 2 : 1, (g_conv_target + k.B - 1) / k.B));
-    passion_prof_tag("conv_pw_dgrad_kernel<%d, %d>", NSTEP, MT);
-    hipLaunchKernelGGL((conv_pw_dgrad_kernel<NSTEP, MT>), dim3((unsigned)nwg_b, k.B), dim3(256), 0, st, k, K8, V);
+    passion_prof_tag("conv_pw_dgrad_kernel<%d, %d, %d>", NSTEP, MT, k.pwm ? 1 : 0);
+    if (k.pwm) hipLaunchKernelGGL((conv_pw_dgrad_kernel<NSTEP, MT, true>), dim3((unsigned)nwg_b, k.B), dim3(256), 0, st, k, K8, V);
+    else hipLaunchKernelGGL((conv_pw_dgrad_kernel<NSTEP, MT, false>), dim3((unsigned)nwg_b, k.B), dim3(256), 0, st, k, K8, V);
     LAUNCH_RET();
     return 0;
 }
@@ -505,7 +517,7 @@ __global__ __launch_bounds__(256) void conv_pw8_fwd_kernel(ConvK p, long V) {
 }
 
 // gradient with a K axis of <= 8 dY channels (bf16, or f32 with Cout <= 4 per 16 bytes ... two loads for 8): rows = Cin <= 32
-template <int RT>                  // row tiles of 8 (Cin <= 8 RT)
+template <int RT, bool FINAL>      // row tiles of 8 (Cin <= 8 RT); FINAL as above
 __global__ __launch_bounds__(256) void conv_pw8_dgrad_kernel(ConvK p, long V) {
     constexpr int TT = 4;
     __shared__ float lsum[4 * RT * 8 * 2];
@@ -562,7 +574,11 @@ __global__ __launch_bounds__(256) void conv_pw8_dgrad_kernel(ConvK p, long V) {
 #pragma unroll
     for (int i = 0; i < RT; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { s1[i][j] = 0.f; s2v[i][j] = 0.f; }
+        for (int j = 0; j < 4; ++j) {
+            s1[i][j] = 0.f; s2v[i][j] = 0.f;
+            const int row = 8 * i + 4 * h + j;
+            if (FINAL && row < p.Cin) { s1[i][j] = p.pwm[((long)b * p.Cin + row) * 2]; s2v[i][j] = p.pwm[((long)b * p.Cin + row) * 2 + 1]; }
+        }
 
     for (long v0 = ((long)blockIdx.x * 4 + wv) * (32 * TT); v0 < V; v0 += (long)gridDim.x * 4 * (32 * TT)) {
         u32x2 raw[TT];
@@ -606,15 +622,20 @@ __global__ __launch_bounds__(256) void conv_pw8_dgrad_kernel(ConvK p, long V) {
                 for (int j = 0; j < 4; ++j) {
                     const float xh = (xv[j] - e.mean[j]) * e.rstd[j];
                     const float gg = gv[j] * (xh > 0.f ? f_pos : f_neg);
-                    gv[j] = gg;
-                    const float gs = gg * vf;
-                    s1[i][j] += gs;
-                    s2v[i][j] = __builtin_fmaf(gs, xh, s2v[i][j]);
+                    if (FINAL) {
+                        gv[j] = e_hs[i] ? e.rstd[j] * (gg - s1[i][j] - xh * s2v[i][j]) : gg;
+                    } else {
+                        gv[j] = gg;
+                        const float gs = gg * vf;
+                        s1[i][j] += gs;
+                        s2v[i][j] = __builtin_fmaf(gs, xh, s2v[i][j]);
+                    }
                 }
                 if (valid) store4(e.dx + v * eC[i], gv);
             }
         }
     }
+    if (FINAL) return;
 #pragma unroll
     for (int i = 0; i < RT; ++i) {
         const bool st = e_ok[i] && e_hs[i];
@@ -697,8 +718,108 @@ int launch_conv_pw_fwd(ConvK& k, int K8, hipStream_t st) {
     return 1;
 }
 
+// ---- the InstanceNorm-backward means of a pointwise layer FROM ITS WEIGHT GRADIENT.  LeakyReLU is positively
+// homogeneous, a = lrelu(x_hat) = x_hat s with s = lrelu'(x_hat) in {1, slope}; with g = W^T dY and g' = mask s g:
+//   sum_v g'[ci] x_hat[ci] = sum_co W[co][ci] dW_b[co][ci]                      (dW_b: this sample's weight gradient)
+//   sum_v g'[ci]           = sum_co W[co][ci] (slope db_b[co] mask + (1 - slope) P_b[co][ci]),  P_b = sum_v dY[co] [x_hat[ci] > 0]
+// (P_b: the second slab of wgrad_lean_kernel<1, *>; W: the bf16 values the dgrad multiplies with).  Two folds per sample and one
+// tiny contraction replace the sums of the dgrad epilogue -- and with the means known BEFORE the dgrad, its epilogue writes dx.
+// per-sample folds of both slabs in one launch: grid (ceil(nA / 16) + ceil(nB / 16), B)
+__global__ __launch_bounds__(256) void pw_fold_sample_kernel(const float* __restrict__ partA, long nA, long strideA, float* __restrict__ outA,
+                                                             const float* __restrict__ partB, long nB, long strideB, float* __restrict__ outB, int R) {
+    __shared__ float red[16][17];
+    const int li = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    const int xa = (int)((nA + 15) / 16);
+    const bool second = (int)blockIdx.x >= xa;
+    const float* part = second ? partB : partA;
+    const long n = second ? nB : nA, stride = second ? strideB : strideA;
+    float* out = second ? outB : outA;
+    const long i = (long)(second ? blockIdx.x - xa : blockIdx.x) * 16 + li;
+    const float* pb = part + (long)blockIdx.y * R * stride;
+    float a = 0.f;
+    if (i < n)
+        for (int r = sl; r < R; r += 16) a += pb[(long)r * stride + i];
+    red[sl][li] = a;
+    __syncthreads();
+    if (sl == 0 && i < n) {
+        float t = 0.f;
+#pragma unroll
+        for (int k2 = 0; k2 < 16; ++k2) t += red[k2][li];
+        out[(long)blockIdx.y * n + i] = t;
+    }
+}
+
+// blocks 0 .. B - 1: the means of sample b; blocks >= B: the weight / bias gradient = the sum of the per-sample folds (sample order).
+// dwb [B][Cout Cin + Cout] (= [dW_b | db_b]), pb [B][Cout Cin]; wdg: bf16 [Cout / 8][mpad][8] (rows = input channels)
+__global__ __launch_bounds__(128) void pw_ident_kernel(ConvK p, const float* __restrict__ dwb, const float* __restrict__ pb, const bf16_t* __restrict__ wdg,
+                                                       int mpad, float inv_v, float* __restrict__ out, float* __restrict__ dweight, float* __restrict__ dbias) {
+    const long nW = (long)p.Cout * p.Cin;
+    if ((int)blockIdx.x >= p.B) {
+        const long i = (long)(blockIdx.x - p.B) * 128 + threadIdx.x;
+        if (i >= nW + p.Cout) return;
+        float t = 0.f;
+        for (int b2 = 0; b2 < p.B; ++b2) t += dwb[(long)b2 * (nW + p.Cout) + i];
+        if (i < nW) dweight[i] = t; else dbias[i - nW] = t;
+        return;
+    }
+    const int b = blockIdx.x, ci = threadIdx.x;
+    if (ci >= p.Cin) return;
+    float mval = 1.f;
+    bool hs = false;
+#pragma unroll
+    for (int s2 = 0; s2 < PASSION_MAX_SEG; ++s2) {
+        if (s2 < p.nseg) {
+            const SegD& sd = p.seg[s2];
+            if (ci >= sd.cbase && ci < sd.cbase + sd.C) {
+                hs = sd.stats != nullptr && sd.dx != nullptr;
+                if (sd.mask) mval = sd.mask[(long)b * sd.mask_ld + sd.mask_col] ? 1.f : 0.f;
+            }
+        }
+    }
+    const float* dw = dwb + (long)b * (nW + p.Cout);
+    const float* pp = pb + (long)b * nW;
+    float m1 = 0.f, m2 = 0.f;
+    for (int co = 0; co < p.Cout; ++co) {
+        const float w = (float)wdg[((long)(co >> 3) * mpad + ci) * 8 + (co & 7)];
+        m2 = __builtin_fmaf(w, dw[(long)co * p.Cin + ci], m2);
+        m1 = __builtin_fmaf(w, p.slope * dw[nW + co] * mval + (1.f - p.slope) * pp[(long)co * p.Cin + ci], m1);
+    }
+    out[((long)b * p.Cin + ci) * 2 + 0] = hs ? m1 * inv_v : 0.f;
+    out[((long)b * p.Cin + ci) * 2 + 1] = hs ? m2 * inv_v : 0.f;
+}
+
 // the input gradient (conv_lean.hip mode 1 for ksize 1): K8 = blocks of 8 dY channels; k.wpack (transposed images), k.Mpad = pad16(Cin),
 // k.sums_rep / sums_fixed set by the caller
+// shapes whose gradient the kernels below take (so that conv.hip may plan the finish-free order: weight gradient first)
+bool conv_pw_dgrad_covers(const ConvK& k) {
+    if (!g_conv_pw || k.bd_rows || k.y_f32) return false;
+    const long V = (long)k.Di * k.Hi * k.Wi;
+    if (V < 32768 || k.Cout % 8 || k.Cin > 128) return false;
+    if ((long)k.B * V * k.Cin < (24L << 20)) return false;        // small tensors: the two extra launches and the lost dgrad || wgrad overlap cost more than the finish pass
+    const int K8 = k.Cout / 8, mpad = pad16(k.Cin);
+    for (int s = 0; s < k.nseg; ++s) if (k.seg[s].C % 8 || k.seg[s].bmod > 0) return false;
+    if (g_conv_pw8 && K8 == 1 && mpad <= 32) return true;
+    const int nstep = (K8 + 3) / 4, mt = mpad / 16;
+    if (K8 > 16) return false;
+    return (nstep == 1 && (mt == 1 || mt == 2 || mt == 4 || mt == 8)) || (nstep == 2 && (mt == 1 || mt == 2 || mt == 4)) ||
+           (nstep <= 4 && nstep > 2 && (mt == 1 || mt == 2 || mt == 4));
+}
+
+// per-sample folds of the two partial slabs (one launch), then the contraction with the weights -> out [B][Cin][2] = (m1, m2) / V
+// together with the weight / bias gradient itself (the sum of the per-sample folds): two launches in all
+int launch_pw_ident(const ConvK& k, const float* wslab, long wslot, const float* sslab, int wgs_per_b, const void* wdg_bf16, float* dwb, float* pb,
+                    float* out, float* dweight, float* dbias, hipStream_t st) {
+    const long nW = (long)k.Cout * k.Cin;
+    const unsigned gx = (unsigned)((nW + k.Cout + 15) / 16 + (nW + 15) / 16);
+    hipLaunchKernelGGL(pw_fold_sample_kernel, dim3(gx, k.B), dim3(256), 0, st, wslab, nW + k.Cout, wslot, dwb, sslab, nW, nW, pb, wgs_per_b);
+    LAUNCH_RET();
+    const double V = (double)k.Di * k.Hi * k.Wi;
+    hipLaunchKernelGGL(pw_ident_kernel, dim3((unsigned)(k.B + (nW + k.Cout + 127) / 128)), dim3(128), 0, st, k, (const float*)dwb, (const float*)pb,
+                       (const bf16_t*)wdg_bf16, pad16(k.Cin), (float)(1.0 / V), out, dweight, dbias);
+    LAUNCH_RET();
+    return 0;
+}
+
 int launch_conv_pw_dgrad(ConvK& k, int K8, hipStream_t st) {
     if (!g_conv_pw || k.bd_rows) return 1;
     const long V = (long)k.Di * k.Hi * k.Wi;
@@ -708,8 +829,9 @@ int launch_conv_pw_dgrad(ConvK& k, int K8, hipStream_t st) {
         const int rt = (k.Cin + 7) / 8;
         const long chunks = (V + 511) / 512;
         const long nwg_b = hmax(1, hmin(chunks / 2 > 0 ? chunks / 2 : 1, (g_conv_target + k.B - 1) / k.B));
-        passion_prof_tag("conv_pw8_dgrad_kernel<%d>", rt);
-#define PW8D(R) if (rt == R) hipLaunchKernelGGL((conv_pw8_dgrad_kernel<R>), dim3((unsigned)nwg_b, k.B), dim3(256), 0, st, k, V);
+        passion_prof_tag("conv_pw8_dgrad_kernel<%d, %d>", rt, k.pwm ? 1 : 0);
+#define PW8D(R) if (rt == R) { if (k.pwm) hipLaunchKernelGGL((conv_pw8_dgrad_kernel<R, true>), dim3((unsigned)nwg_b, k.B), dim3(256), 0, st, k, V); \
+                            else hipLaunchKernelGGL((conv_pw8_dgrad_kernel<R, false>), dim3((unsigned)nwg_b, k.B), dim3(256), 0, st, k, V); }
         PW8D(1) PW8D(2) PW8D(3) PW8D(4)
 #undef PW8D
         LAUNCH_RET();

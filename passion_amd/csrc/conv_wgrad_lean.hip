@@ -45,6 +45,10 @@ __global__ __launch_bounds__(256) void wgrad_lean_kernel(ConvK p, float* __restr
     constexpr int NKS = TD * TH * TW / 32;            // K steps per brick
     __shared__ __attribute__((aligned(16))) char lact[VOL * VS];
     __shared__ __attribute__((aligned(16))) char ldy[TD * TH * TW * DYS];
+    // KS == 1 with p.spos: the 0/1 image of x_hat > 0 (present blocks only) -- the B operand of columns 8..15, whose sums give
+    // sum_v dY[v][co] [x_hat[v][ci] > 0]; the bias sums then come from one more MFMA per K step against a tile of ones
+    __shared__ __attribute__((aligned(16))) char lind[KS == 1 ? VOL * VS : 16];
+    const bool ident = KS == 1 && p.spos != nullptr;
 
     const int tid = threadIdx.x, lane = tid & 63, n = lane & 15, g = lane >> 4;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform: branches on it stay scalar
@@ -145,7 +149,11 @@ __global__ __launch_bounds__(256) void wgrad_lean_kernel(ConvK p, float* __restr
         if (tap >= NTAP) tap = 0;                      // padded column: reads finite data, dropped at the flush
         const int tw = tap % KS, th = (tap / KS) % KS, td = tap / (KS * KS);
         boff[j] = blane + ((td * IH + th) * IW + tw) * VS + (pq & 1) * 8;
+        if (ident && (pq >> 1)) boff[j] = (int)(lind - lact) + blane + (pq & 1) * 8;      // second half of the tile: the indicator image
     }
+    f32x4 accb[MT];                                   // ident: the bias sums (tile of ones)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) accb[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
     f32x4 acc[MT][NTW];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
@@ -233,6 +241,19 @@ __global__ __launch_bounds__(256) void wgrad_lean_kernel(ConvK p, float* __restr
                 o = __builtin_bit_cast(u32x4, ob);
             }
             *reinterpret_cast<u32x4*>(lact + (tid + 256 * r) * VS) = o;
+            if (KS == 1 && ident) {
+                u32x4 iv = (u32x4){0u, 0u, 0u, 0u};
+                if (has_norm && ((okbits >> r) & 1u)) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const float v0 = __uint_as_float(ra[r][c] << 16), v1 = __uint_as_float(ra[r][c] & 0xffff0000u);
+                        const unsigned i0 = (v0 - mean[2 * c]) * rstd[2 * c] > 0.f ? 0x3f80u : 0u;            // bf16 1.0
+                        const unsigned i1 = (v1 - mean[2 * c + 1]) * rstd[2 * c + 1] > 0.f ? 0x3f80u : 0u;
+                        iv[c] = i0 | (i1 << 16);
+                    }
+                }
+                *reinterpret_cast<u32x4*>(lind + (tid + 256 * r) * VS) = iv;
+            }
         }
 #pragma unroll
         for (int r = 0; r < DR; ++r) *reinterpret_cast<u32x4*>(ldy + dlds[r]) = rd[r];
@@ -260,11 +281,15 @@ __global__ __launch_bounds__(256) void wgrad_lean_kernel(ConvK p, float* __restr
 #pragma unroll
             for (int j = 0; j < NTW; ++j) {
                 bf16x8 bv = tr_read8(bp + boff[j], bp + boff[j] + 4 * VS);
-                if (j == JB && bias_wave && n >= 8) bv = ones;        // padding half of the last tile (the lane RECEIVES column n)
+                if (j == JB && bias_wave && n >= 8 && !ident) bv = ones;        // padding half of the last tile (the lane RECEIVES column n)
                 // (tiles past NTILES on waves 2/3 are computed and dropped at the flush: no branch around an MFMA)
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt)
                     acc[mt][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mt], bv, acc[mt][j], 0, 0, 0);
+            }
+            if (KS == 1 && ident) {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) accb[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mt], ones, accb[mt], 0, 0, 0);
             }
         }
     }
@@ -280,6 +305,13 @@ __global__ __launch_bounds__(256) void wgrad_lean_kernel(ConvK p, float* __restr
 #pragma unroll
                 for (int r = 0; r < 4; ++r) red[(((wv * MT + mt) * NTW + j) * 64 + lane) * 4 + r] = acc[mt][j][r];
         }
+        float* redb = red + 4 * MT * NTW * 64 * 4;           // ident: [4 waves][MT][64 lanes][4] bias partials
+        if (KS == 1 && ident) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) redb[((wv * MT + mt) * 64 + lane) * 4 + r] = accb[mt][r];
+        }
         __syncthreads();
         if (wv != 0) return;
 #pragma unroll
@@ -293,6 +325,15 @@ __global__ __launch_bounds__(256) void wgrad_lean_kernel(ConvK p, float* __restr
                     for (int w2 = 0; w2 < 4; ++w2) t += red[(((w2 * MT + mt) * NTW + j) * 64 + lane) * 4 + r];
                     acc[mt][j][r] = t;
                 }
+            if (KS == 1 && ident) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float t = 0.f;
+#pragma unroll
+                    for (int w2 = 0; w2 < 4; ++w2) t += redb[((w2 * MT + mt) * 64 + lane) * 4 + r];
+                    accb[mt][r] = t;
+                }
+            }
         }
     }
     // ---- this workgroup's slot of the partial-sum slab (plain stores; reduce_parts_kernel folds the slots)
@@ -302,8 +343,19 @@ __global__ __launch_bounds__(256) void wgrad_lean_kernel(ConvK p, float* __restr
         for (int j = 0; j < NTW; ++j) {
             const int nt = (KSPLIT == 1) ? wv + 4 * j : j;
             const int tap = 2 * nt + (n >> 3), c = n & 7;
-            if (nt >= NTILES || tap >= NTAP) continue;
             const long ci = cbase + c0 + c;
+            if (KS == 1 && ident && nt == 0 && n >= 8) {          // columns 8..15: the indicator sums of channels c0 .. c0 + 7
+                float* sp = p.spos + (long)bx * ((long)p.Cout * p.Cin);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int co = (mg * MT + mt) * 16 + g * 4 + r;
+                        if (co < p.Cout) sp[(long)co * p.Cin + ci] = acc[mt][j][r];
+                    }
+                continue;
+            }
+            if (nt >= NTILES || tap >= NTAP) continue;
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -313,6 +365,17 @@ __global__ __launch_bounds__(256) void wgrad_lean_kernel(ConvK p, float* __restr
                 }
         }
     }
+    if (KS == 1 && ident) {
+        if (bias_block && n == 0) {                               // every column of the ones tile holds the bias sums
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int co = (mg * MT + mt) * 16 + g * 4 + r;
+                    if (co < p.Cout) dbias[(long)bx * p.wslot + co] = accb[mt][r];
+                }
+        }
+    } else
     if (bias_block && (KSPLIT == 4 || wv == WB) && n == 8) {       // column 8 of the last tile = bias sums
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)

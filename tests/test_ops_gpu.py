@@ -148,20 +148,27 @@ def test_pointwise_streaming_kernel(case):
     yr.backward(gy)
     md = mask.to(dev) if mask is not None else None
     res = {}
-    for pw in (1, 0):
-        old = ops.set_option("conv_pw", pw)
+    for pw in (1, 0, 2):                       # 2: streaming kernels, but dgrad + finish instead of the finish-free backward
+        old = ops.set_option("conv_pw", 1 if pw else 0)
+        oldf = ops.set_option("conv_pwfinal", 0 if pw == 2 else 1)
         try:
             xd = [cl(x).to(dev, dtype).requires_grad_(True) for x in xs]
             wd, bd = w.float().to(dev).requires_grad_(True), b.float().to(dev).requires_grad_(True)
             segs = [ops.SegIn(x, stats=ops.instnorm_stats(x.detach()) if norm else None, mask=md, mask_col=i) for i, x in enumerate(xd)]
             y, st = ops.conv_block(segs, wd, bd, D, H, W, ksize=1, stride=1, pad_mode=0, want_stats=True)
             y.backward(cl(gy).to(dev, dtype))
-            res[pw] = (y.detach().clone(), st.clone(), wd.grad.clone(), [x.grad.clone() for x in xd])
+            res[pw] = (y.detach().clone(), st.clone(), wd.grad.clone(), [x.grad.clone() for x in xd], bd.grad.clone())
         finally:
             ops.set_option("conv_pw", old)
-    y, st, dw, dxs = res[1]
+            ops.set_option("conv_pwfinal", oldf)
+    y, st, dw, dxs, db = res[1]
     assert relerr(nc(y.float()), yr) < TOL[dtype], relerr(nc(y.float()), yr)
-    assert relerr(dw, wr.grad) < 2 * TOL[dtype]
+    assert relerr(dw, wr.grad) < 2 * TOL[dtype] and relerr(db, br.grad) < 2 * TOL[dtype]
+    # the finish-free backward (InstanceNorm-backward means from the weight gradient: conv_pw.hip) against dgrad + finish: the same
+    # input gradient up to the bf16 rounding of the stored values, the same weight / bias gradient up to the f32 summation order
+    for a, c in zip(dxs, res[2][3]):
+        assert relerr(a.float(), c.float()) < 1e-2, relerr(a.float(), c.float())
+    assert relerr(dw, res[2][2]) < 1e-4 and relerr(db, res[2][4]) < 1e-4
     for i in range(len(segC)):
         assert relerr(nc(dxs[i].float()), xr[i].grad) < 3 * TOL[dtype]
     # against the lean kernel: identical up to the order of the f32 accumulation (one bf16 rounding step at most, rarely)
