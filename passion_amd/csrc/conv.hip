@@ -15,6 +15,7 @@
 // [tap][Cout][CinPad] image, plus "mirror taps" that implement the adjoint of reflect padding,
 // and an epilogue that goes back through LeakyReLU and accumulates the two InstanceNorm-backward
 // sums per (b, channel).
+#include <cstdio>
 #include <mutex>
 #include <vector>
 #include "conv_common.h"
@@ -658,7 +659,7 @@ int fill_params(const passion_conv_desc_t* d, ConvK& k) {
     for (int g = 0; g < PASSION_MAX_GROUPS; ++g) k.biasg[g] = nullptr;
     k.bd_rows = 0; k.bd_k8 = 0;
     k.y_f32 = 0;
-    k.spos = nullptr; k.pwm = nullptr;
+    k.spos = nullptr; k.pwm = nullptr; k.pw_done = 0;
     if (d->ksize != 1 && d->ksize != 3) return -1002;
     if (d->stride != 1 && d->stride != 2) return -1003;
     if (d->ksize == 1 && d->stride != 1) return -1003;
@@ -1085,14 +1086,27 @@ static int conv3d_bwd_impl(const passion_conv_desc_t* d, const float* packed, co
     // itself -- no sums, no finish pass.
     bool pw_final = false;
     WgPlan wpl{};
+    const bool pw_bd = d->ksize == 1 && use_blockdiag(k, d);       // batched passes: one dgrad over the masked sum of the passes
     if (phase == 0 && !ga && parts == 3 && d->ksize == 1 && d->stride == 1 && pconv::g_conv_pwfinal && pconv::g_conv_lean && !g_passion_force_f32_mfma &&
-        d->x_dtype == PASSION_BF16 && d->y_dtype == PASSION_BF16 && need_dx && need_norm && dweight && dbias && sums && !use_blockdiag(k, d)) {
+        d->x_dtype == PASSION_BF16 && d->y_dtype == PASSION_BF16 && need_dx && need_norm && dweight && dbias && sums) {
         k.Mpad = pad16(k.Cout);
         wpl = plan_wgrad(k, d);
-        bool all_norm = true;
-        for (int s = 0; s < k.nseg; ++s) if (k.seg[s].dx && !k.seg[s].stats) all_norm = false;
-        pw_final = all_norm && wpl.bf16 && wgrad_bf16_chunk(k, 1, 1) != 16 && wgrad_lean_covers(k, 1, 1, wpl.MT, wpl.gx, wpl.gy) &&
-                   wpl.gx % k.B == 0 && conv_pw_dgrad_covers(k);
+        bool all_norm = true, any_bmod = false;
+        for (int s = 0; s < k.nseg; ++s) {
+            if (k.seg[s].dx && !k.seg[s].stats) all_norm = false;
+            if (k.seg[s].bmod > 0) any_bmod = true;
+        }
+        const int bphys = pw_bd ? k.seg[0].bmod : k.B;
+        const int kblocks = pw_bd ? k.nseg * k.Cout / 8 : k.Cout / 8;
+        pw_final = all_norm && (pw_bd || !any_bmod) && wpl.bf16 && wgrad_bf16_chunk(k, 1, 1) != 16 &&
+                   wgrad_lean_covers(k, 1, 1, wpl.MT, wpl.gx, wpl.gy) && conv_pw_dgrad_covers(k, kblocks, bphys);
+        static const bool dbg = getenv("PASSION_PWFINAL_DBG") != nullptr;
+        if (dbg) fprintf(stderr, "[pwfinal] B=%d V=%ld Cin=%d Cout=%d nseg=%d: final=%d all_norm=%d bd=%d any_bmod=%d bf16=%d chunk=%d leancov=%d gxmod=%d pwcov=%d\n",
+                         k.B, (long)k.Di * k.Hi * k.Wi, k.Cin, k.Cout, k.nseg, (int)pw_final, (int)all_norm, (int)pw_bd, (int)any_bmod, (int)wpl.bf16,
+                         wgrad_bf16_chunk(k, 1, 1), (int)wgrad_lean_covers(k, 1, 1, wpl.MT, wpl.gx, wpl.gy), wpl.gx % k.B, (int)conv_pw_dgrad_covers(k, kblocks, bphys));
+    } else if (d->ksize == 1 && getenv("PASSION_PWFINAL_DBG")) {
+        fprintf(stderr, "[pwfinal] B=%d V=%ld Cin=%d Cout=%d: not planned (phase %d ga %d parts %d need_dx %d need_norm %d dW %d db %d dt %d/%d)\n", k.B,
+                (long)k.Di * k.Hi * k.Wi, k.Cin, k.Cout, phase, ga != nullptr, parts, (int)need_dx, (int)need_norm, dweight != nullptr, dbias != nullptr, d->x_dtype, d->y_dtype);
     }
     Companion* comp = (phase == 0 && pconv::g_wgrad_fork && need_dx && (dweight || dbias) && !pw_final) ? companion(st) : nullptr;
     hipStream_t caller_st = st;
@@ -1195,7 +1209,8 @@ static int conv3d_bwd_impl(const passion_conv_desc_t* d, const float* packed, co
         st = caller_st;
     }
     if (pw_final) {
-        // per-sample folds + contraction -> (m1, m2) / V, then the input gradient with its final epilogue; nothing else follows
+        // per-sample folds + contraction -> (m1, m2) / V (over the passes of a batched launch), then the input gradient with its
+        // final epilogue; no finish pass follows
         const long nW = (long)k.Cout * k.Cin;
         const float* wslab = sums + (long)2 * k.B * k.Cin * SUMS_SLOTS;
         float* sslab = const_cast<float*>(wslab) + (long)wpl.gx * k.wslot;
@@ -1204,15 +1219,21 @@ static int conv3d_bwd_impl(const passion_conv_desc_t* d, const float* packed, co
         float* mb = pb + (long)k.B * nW;
         const bf16_t* wdg = reinterpret_cast<const bf16_t*>(packed + f32_pack_floats(k.Cin, k.Cout, 1)) + (long)pad8(k.Cin) * pad16(k.Cout);
         k.spos = nullptr;
-        rc = launch_pw_ident(k, wslab, k.wslot, sslab, wpl.gx / k.B, wdg, dwb, pb, mb, dweight, dbias, st);
+        // slots of sample b: the wgs_per_b consecutive ones from b * wgs_per_b on (wgrad_lean_kernel; spare slots past the last sample are zero)
+        const int wg_tiles = cdiv(k.Do, TD) * cdiv(k.Ho, TH) * cdiv(k.Wo, TW);
+        const int wgs_per_b = (wg_tiles + k.per - 1) / k.per;
+        rc = launch_pw_ident(k, wslab, k.wslot, sslab, wgs_per_b, wdg, dwb, pb, mb, dweight, dbias, pw_bd ? k.seg[0].bmod : k.B, st);
         if (rc) return rc;
         k.pwm = mb;
-        k.sums = nullptr; k.sums_rep = 1; k.sums_fixed = 0; k.sums_float_only = 0;
-        k.tilesD = cdiv(k.Di, TD); k.tilesH = cdiv(k.Hi, TH); k.tilesW = cdiv(k.Wi, TW);
-        ProfScope prof(2, conv_bytes(k, xs, ys) + (double)k.Cin * k.Cout * 4, 2.0 * k.B * k.Do * k.Ho * k.Wo * (double)k.Cout * k.Cin, st);
-        rc = launch_conv_lean(k, 1, 1, 1, packed + f32_pack_floats(k.Cin, k.Cout, 1), st);
-        if (rc > 0) rc = -1020;                      // planned for the pointwise kernels: must be covered
-        return rc;
+        if (!pw_bd) {
+            k.sums = nullptr; k.sums_rep = 1; k.sums_fixed = 0; k.sums_float_only = 0;
+            k.tilesD = cdiv(k.Di, TD); k.tilesH = cdiv(k.Hi, TH); k.tilesW = cdiv(k.Wi, TW);
+            ProfScope prof(2, conv_bytes(k, xs, ys) + (double)k.Cin * k.Cout * 4, 2.0 * k.B * k.Do * k.Ho * k.Wo * (double)k.Cout * k.Cin, st);
+            rc = launch_conv_lean(k, 1, 1, 1, packed + f32_pack_floats(k.Cin, k.Cout, 1), st);
+            if (rc > 0 || (rc == 0 && !k.pw_done)) rc = -1020;      // planned for the pointwise kernels: must be covered
+            return rc;
+        }
+        // batched passes: the common path below sums the passes' dY and runs the block-diagonal dgrad (with k.pwm: its final form)
     }
     // ---- dgrad ----
     if (!need_dx || !(parts & 2)) return 0;
@@ -1297,6 +1318,7 @@ static int conv3d_bwd_impl(const passion_conv_desc_t* d, const float* packed, co
         else if (blockdiag) {
             rc = launch_conv_lean(k, d->ksize, d->stride, 1, packed + f32_pack_floats(k.Cin, k.bd_k8 * 8, nt), st);
             if (rc > 0) rc = -1018;              // planned for the lean kernel: must be covered
+            if (pw_final) return (rc == 0 && !k.pw_done) ? -1020 : rc;      // the pointwise kernel wrote dx itself (k.pwm): nothing to finish
         }
         else if (d->x_dtype == PASSION_BF16 && d->y_dtype == PASSION_BF16) {
             if (bf16_eligible(k, true) && !g_passion_force_f32_mfma)

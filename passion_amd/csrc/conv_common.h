@@ -78,6 +78,7 @@ struct ConvK {
     float* spos;           // 1x1x1 wgrad (conv_wgrad_lean.hip): second partial slab [slot][Cout][Cin] of sum_v dY[v][co] * [x_hat[v][ci] > 0]
                            // (the InstanceNorm-backward sums of the pointwise layers come from the weight gradient: conv_pw.hip)
     const float* pwm;      // pointwise "final" dgrad: (m1, m2) per (sample, input channel), already divided by V
+    int pw_done;           // set by the pointwise gradient launchers (conv.hip checks that a planned final dgrad really ran there)
     FwdStats fst;          // forward: statistics of y from the kernel's epilogue (fst.stats != nullptr)
     float* fst_want;       // forward: the caller wants statistics of y here (a launcher that fuses them moves it to fst.stats)
     float fst_eps;
@@ -118,9 +119,9 @@ int launch_conv_s2_dgrad(ConvK& k, const void* packed_bf16, hipStream_t st);   /
 extern int g_conv_s2;
 int launch_conv_pw_fwd(ConvK& k, int K8, hipStream_t st);   // conv_pw.hip: 1x1x1 forward as a streaming GEMM (wide volumes)
 int launch_conv_pw_dgrad(ConvK& k, int K8, hipStream_t st);
-bool conv_pw_dgrad_covers(const ConvK& k);
+bool conv_pw_dgrad_covers(const ConvK& k, int kblocks, int bphys);
 int launch_pw_ident(const ConvK& k, const float* wslab, long wslot, const float* sslab, int wgs_per_b, const void* wdg_bf16, float* dwb, float* pb,
-                    float* out, float* dweight, float* dbias, hipStream_t st);
+                    float* out, float* dweight, float* dbias, int bm, hipStream_t st);
 extern int g_conv_pwfinal;
 extern int g_conv_pw, g_conv_pw8;
 bool conv_march_covers(const ConvK& k, int ksize, int stride, int mode, int* K8out);

@@ -267,7 +267,13 @@ __global__ __launch_bounds__(256) void conv_pw_dgrad_kernel(ConvK p, int K8, lon
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             wfr[s][mt] = zero8();
-            if (q < K8) wfr[s][mt] = gload<bf16x8>(reinterpret_cast<const bf16x8*>(p.wpack) + wvec_of(p, b) + ((long)q * p.Mpad + mt * 16 + n));
+            const int row = mt * 16 + n;
+            if (p.bd_rows) {        // batched passes summed first (conv.hip): K block q = (segment q / bd_k8, block q % bd_k8 of the real Cout); a row sees its own segment only
+                if (q < K8 && row / p.bd_rows == q / p.bd_k8)
+                    wfr[s][mt] = gload<bf16x8>(reinterpret_cast<const bf16x8*>(p.wpack) + wvec_of(p, b) + ((long)(q % p.bd_k8) * p.Mpad + row));
+            } else if (q < K8) {
+                wfr[s][mt] = gload<bf16x8>(reinterpret_cast<const bf16x8*>(p.wpack) + wvec_of(p, b) + ((long)q * p.Mpad + row));
+            }
         }
     }
     __syncthreads();
@@ -394,6 +400,7 @@ int launch_pw_dgrad(ConvK& k, int K8, hipStream_t st) {
     if (k.pwm) hipLaunchKernelGGL((conv_pw_dgrad_kernel<NSTEP, MT, true>), dim3((unsigned)nwg_b, k.B), dim3(256), 0, st, k, K8, V);
     else hipLaunchKernelGGL((conv_pw_dgrad_kernel<NSTEP, MT, false>), dim3((unsigned)nwg_b, k.B), dim3(256), 0, st, k, K8, V);
     LAUNCH_RET();
+    k.pw_done = 1;
     return 0;
 }
 
@@ -752,7 +759,8 @@ __global__ __launch_bounds__(256) void pw_fold_sample_kernel(const float* __rest
 // blocks 0 .. B - 1: the means of sample b; blocks >= B: the weight / bias gradient = the sum of the per-sample folds (sample order).
 // dwb [B][Cout Cin + Cout] (= [dW_b | db_b]), pb [B][Cout Cin]; wdg: bf16 [Cout / 8][mpad][8] (rows = input channels)
 __global__ __launch_bounds__(128) void pw_ident_kernel(ConvK p, const float* __restrict__ dwb, const float* __restrict__ pb, const bf16_t* __restrict__ wdg,
-                                                       int mpad, float inv_v, float* __restrict__ out, float* __restrict__ dweight, float* __restrict__ dbias) {
+                                                       int mpad, float inv_v, float* __restrict__ out, float* __restrict__ dweight, float* __restrict__ dbias,
+                                                       int bm) {
     const long nW = (long)p.Cout * p.Cin;
     if ((int)blockIdx.x >= p.B) {
         const long i = (long)(blockIdx.x - p.B) * 128 + threadIdx.x;
@@ -762,9 +770,12 @@ __global__ __launch_bounds__(128) void pw_ident_kernel(ConvK p, const float* __r
         if (i < nW) dweight[i] = t; else dbias[i - nW] = t;
         return;
     }
+    // physical sample b = the passes p * bm + b of a batched launch (SegD.bmod; bm = B without passes): the dgrad then runs once
+    // over the masked sum of the passes' dY (conv.hip, block-diagonal form), so the means are the sums over the passes
     const int b = blockIdx.x, ci = threadIdx.x;
-    if (ci >= p.Cin) return;
-    float mval = 1.f;
+    if (ci >= p.Cin || b >= bm) return;
+    const uint8_t* mk = nullptr;
+    int mld = 0, mcol = 0;
     bool hs = false;
 #pragma unroll
     for (int s2 = 0; s2 < PASSION_MAX_SEG; ++s2) {
@@ -772,17 +783,20 @@ __global__ __launch_bounds__(128) void pw_ident_kernel(ConvK p, const float* __r
             const SegD& sd = p.seg[s2];
             if (ci >= sd.cbase && ci < sd.cbase + sd.C) {
                 hs = sd.stats != nullptr && sd.dx != nullptr;
-                if (sd.mask) mval = sd.mask[(long)b * sd.mask_ld + sd.mask_col] ? 1.f : 0.f;
+                mk = sd.mask; mld = sd.mask_ld; mcol = sd.mask_col;
             }
         }
     }
-    const float* dw = dwb + (long)b * (nW + p.Cout);
-    const float* pp = pb + (long)b * nW;
     float m1 = 0.f, m2 = 0.f;
-    for (int co = 0; co < p.Cout; ++co) {
-        const float w = (float)wdg[((long)(co >> 3) * mpad + ci) * 8 + (co & 7)];
-        m2 = __builtin_fmaf(w, dw[(long)co * p.Cin + ci], m2);
-        m1 = __builtin_fmaf(w, p.slope * dw[nW + co] * mval + (1.f - p.slope) * pp[(long)co * p.Cin + ci], m1);
+    for (int bv = b; bv < p.B; bv += bm) {
+        const float mval = (mk && mk[(long)bv * mld + mcol] == 0) ? 0.f : 1.f;
+        const float* dw = dwb + (long)bv * (nW + p.Cout);
+        const float* pp = pb + (long)bv * nW;
+        for (int co = 0; co < p.Cout; ++co) {
+            const float w = (float)wdg[((long)(co >> 3) * mpad + ci) * 8 + (co & 7)];
+            m2 = __builtin_fmaf(w, dw[(long)co * p.Cin + ci], m2);
+            m1 = __builtin_fmaf(w, p.slope * dw[nW + co] * mval + (1.f - p.slope) * pp[(long)co * p.Cin + ci], m1);
+        }
     }
     out[((long)b * p.Cin + ci) * 2 + 0] = hs ? m1 * inv_v : 0.f;
     out[((long)b * p.Cin + ci) * 2 + 1] = hs ? m2 * inv_v : 0.f;
@@ -791,13 +805,14 @@ __global__ __launch_bounds__(128) void pw_ident_kernel(ConvK p, const float* __r
 // the input gradient (conv_lean.hip mode 1 for ksize 1): K8 = blocks of 8 dY channels; k.wpack (transposed images), k.Mpad = pad16(Cin),
 // k.sums_rep / sums_fixed set by the caller
 // shapes whose gradient the kernels below take (so that conv.hip may plan the finish-free order: weight gradient first)
-bool conv_pw_dgrad_covers(const ConvK& k) {
-    if (!g_conv_pw || k.bd_rows || k.y_f32) return false;
+// `kblocks`: 8-channel blocks of the gradient's K axis (Cout / 8; nseg * Cout / 8 for the block-diagonal form of batched passes)
+bool conv_pw_dgrad_covers(const ConvK& k, int kblocks, int bphys) {
+    if (!g_conv_pw || k.y_f32) return false;
     const long V = (long)k.Di * k.Hi * k.Wi;
     if (V < 32768 || k.Cout % 8 || k.Cin > 128) return false;
-    if ((long)k.B * V * k.Cin < (24L << 20)) return false;        // small tensors: the two extra launches and the lost dgrad || wgrad overlap cost more than the finish pass
-    const int K8 = k.Cout / 8, mpad = pad16(k.Cin);
-    for (int s = 0; s < k.nseg; ++s) if (k.seg[s].C % 8 || k.seg[s].bmod > 0) return false;
+    if ((long)bphys * V * k.Cin < (24L << 20)) return false;      // small tensors: the two extra launches and the lost dgrad || wgrad overlap cost more than the finish pass
+    const int K8 = kblocks, mpad = pad16(k.Cin);
+    for (int s = 0; s < k.nseg; ++s) if (k.seg[s].C % 8) return false;
     if (g_conv_pw8 && K8 == 1 && mpad <= 32) return true;
     const int nstep = (K8 + 3) / 4, mt = mpad / 16;
     if (K8 > 16) return false;
@@ -808,24 +823,24 @@ bool conv_pw_dgrad_covers(const ConvK& k) {
 // per-sample folds of the two partial slabs (one launch), then the contraction with the weights -> out [B][Cin][2] = (m1, m2) / V
 // together with the weight / bias gradient itself (the sum of the per-sample folds): two launches in all
 int launch_pw_ident(const ConvK& k, const float* wslab, long wslot, const float* sslab, int wgs_per_b, const void* wdg_bf16, float* dwb, float* pb,
-                    float* out, float* dweight, float* dbias, hipStream_t st) {
+                    float* out, float* dweight, float* dbias, int bm, hipStream_t st) {
     const long nW = (long)k.Cout * k.Cin;
     const unsigned gx = (unsigned)((nW + k.Cout + 15) / 16 + (nW + 15) / 16);
     hipLaunchKernelGGL(pw_fold_sample_kernel, dim3(gx, k.B), dim3(256), 0, st, wslab, nW + k.Cout, wslot, dwb, sslab, nW, nW, pb, wgs_per_b);
     LAUNCH_RET();
     const double V = (double)k.Di * k.Hi * k.Wi;
     hipLaunchKernelGGL(pw_ident_kernel, dim3((unsigned)(k.B + (nW + k.Cout + 127) / 128)), dim3(128), 0, st, k, (const float*)dwb, (const float*)pb,
-                       (const bf16_t*)wdg_bf16, pad16(k.Cin), (float)(1.0 / V), out, dweight, dbias);
+                       (const bf16_t*)wdg_bf16, pad16(k.Cin), (float)(1.0 / V), out, dweight, dbias, bm);
     LAUNCH_RET();
     return 0;
 }
 
 int launch_conv_pw_dgrad(ConvK& k, int K8, hipStream_t st) {
-    if (!g_conv_pw || k.bd_rows) return 1;
+    if (!g_conv_pw) return 1;
     const long V = (long)k.Di * k.Hi * k.Wi;
     if (V < 32768) return 1;
     for (int s = 0; s < k.nseg; ++s) if (k.seg[s].C % 4) return 1;
-    if (g_conv_pw8 && K8 == 1 && (k.Cout == 4 || k.Cout == 8) && k.Mpad <= 32) {       // dY of <= 8 channels (bf16, or the f32 logit gradient)
+    if (g_conv_pw8 && !k.bd_rows && K8 == 1 && (k.Cout == 4 || k.Cout == 8) && k.Mpad <= 32) {       // dY of <= 8 channels (bf16, or the f32 logit gradient)
         const int rt = (k.Cin + 7) / 8;
         const long chunks = (V + 511) / 512;
         const long nwg_b = hmax(1, hmin(chunks / 2 > 0 ? chunks / 2 : 1, (g_conv_target + k.B - 1) / k.B));
@@ -835,6 +850,7 @@ int launch_conv_pw_dgrad(ConvK& k, int K8, hipStream_t st) {
         PW8D(1) PW8D(2) PW8D(3) PW8D(4)
 #undef PW8D
         LAUNCH_RET();
+        k.pw_done = 1;
         return 0;
     }
     if (k.y_f32) return 1;

@@ -314,12 +314,16 @@ def test_conv_f32_logit_head(segC, Cout, k, norm, dims):
 
 
 # 3x3x3 over two segments, and the shape of the fusion blocks' first conv (blocks.py:536): 1x1x1 over four modality segments
-@pytest.mark.parametrize("ks,nseg,C", [(3, 2, 8), (1, 4, 8), (1, 4, 16)])
-def test_conv_batched_passes(ks, nseg, C):
+@pytest.mark.parametrize("ks,nseg,C,dims", [(3, 2, 8, (8, 8, 16)), (1, 4, 8, (8, 8, 16)), (1, 4, 16, (8, 8, 16)),
+                                            # >= 32768 voxels: block-diagonal dgrad on the streaming pointwise kernel, finish-free
+                                            (1, 4, 8, (32, 32, 48)), (1, 4, 16, (32, 32, 32)), (1, 2, 8, (32, 64, 32)),
+                                            # >= 24 M input elements: the means from the weight gradient, summed over the passes
+                                            (1, 4, 16, (64, 64, 64)), (1, 4, 8, (64, 96, 64))])
+def test_conv_batched_passes(ks, nseg, C, dims):
     """SegIn.bmod: P masked passes over the same B samples in one launch == P separate launches, gradients summed"""
     from passion_amd import ops
     dev = _dev()
-    B, P, Cout, D, H, W = 2, 3, C, 8, 8, 16
+    B, P, Cout, (D, H, W) = 2, 3, C, dims
     g = torch.Generator().manual_seed(5)
     xs = [(torch.randn(B, D, H, W, C, generator=g) * 1.3).to(dev, torch.bfloat16) for _ in range(nseg)]
     w = (torch.randn(Cout, nseg * C, ks, ks, ks, generator=g) / (nseg * C * ks ** 3) ** 0.5).to(dev)
