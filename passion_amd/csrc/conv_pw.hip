@@ -809,14 +809,14 @@ __global__ __launch_bounds__(128) void pw_ident_kernel(ConvK p, const float* __r
 bool conv_pw_dgrad_covers(const ConvK& k, int kblocks, int bphys) {
     if (!g_conv_pw || k.y_f32) return false;
     const long V = (long)k.Di * k.Hi * k.Wi;
-    if (V < 32768 || k.Cout % 8 || k.Cin > 128) return false;
+    if (V < 32768 || k.Cout % 8 || k.Cin > 64) return false;
     if ((long)bphys * V * k.Cin < (24L << 20)) return false;      // small tensors: the two extra launches and the lost dgrad || wgrad overlap cost more than the finish pass
     const int K8 = kblocks, mpad = pad16(k.Cin);
     for (int s = 0; s < k.nseg; ++s) if (k.seg[s].C % 8) return false;
     if (g_conv_pw8 && K8 == 1 && mpad <= 32) return true;
     const int nstep = (K8 + 3) / 4, mt = mpad / 16;
     if (K8 > 16) return false;
-    return (nstep == 1 && (mt == 1 || mt == 2 || mt == 4 || mt == 8)) || (nstep == 2 && (mt == 1 || mt == 2 || mt == 4)) ||
+    return (nstep == 1 && (mt == 1 || mt == 2 || mt == 4)) || (nstep == 2 && (mt == 1 || mt == 2 || mt == 4)) ||
            (nstep <= 4 && nstep > 2 && (mt == 1 || mt == 2 || mt == 4));
 }
 
@@ -854,10 +854,10 @@ int launch_conv_pw_dgrad(ConvK& k, int K8, hipStream_t st) {
         return 0;
     }
     if (k.y_f32) return 1;
-    if (K8 < 1 || K8 > 16 || k.Mpad > 128) return 1;
+    if (K8 < 1 || K8 > 16 || k.Mpad > 64) return 1;           // 128 rows: 512 registers and spills -- the lean kernel's
     const int nstep = (K8 + 3) / 4, mt = k.Mpad / 16;
 #define PWD_CASE(NS, M) if (nstep <= NS && mt == M) return launch_pw_dgrad<NS, M>(k, K8, st);
-    PWD_CASE(1, 1) PWD_CASE(1, 2) PWD_CASE(1, 4) PWD_CASE(1, 8) PWD_CASE(2, 1) PWD_CASE(2, 2) PWD_CASE(2, 4) PWD_CASE(4, 1) PWD_CASE(4, 2) PWD_CASE(4, 4)
+    PWD_CASE(1, 1) PWD_CASE(1, 2) PWD_CASE(1, 4) PWD_CASE(2, 1) PWD_CASE(2, 2) PWD_CASE(2, 4) PWD_CASE(4, 1) PWD_CASE(4, 2) PWD_CASE(4, 4)
 #undef PWD_CASE
     return 1;
 }
