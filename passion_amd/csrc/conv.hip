@@ -1087,8 +1087,9 @@ static int conv3d_bwd_impl(const passion_conv_desc_t* d, const float* packed, co
     bool pw_final = false;
     WgPlan wpl{};
     const bool pw_bd = d->ksize == 1 && use_blockdiag(k, d);       // batched passes: one dgrad over the masked sum of the passes
+    const bool pw_f32 = d->y_dtype == PASSION_F32 && d->x_dtype == PASSION_BF16 && d->ksize == 1 && lean_f32_head(k, d);     // logit heads: f32 dY
     if (phase == 0 && !ga && parts == 3 && d->ksize == 1 && d->stride == 1 && pconv::g_conv_pwfinal && pconv::g_conv_lean && !g_passion_force_f32_mfma &&
-        d->x_dtype == PASSION_BF16 && d->y_dtype == PASSION_BF16 && need_dx && need_norm && dweight && dbias && sums) {
+        d->x_dtype == PASSION_BF16 && (d->y_dtype == PASSION_BF16 || pw_f32) && need_dx && need_norm && dweight && dbias && sums) {
         k.Mpad = pad16(k.Cout);
         wpl = plan_wgrad(k, d);
         bool all_norm = true, any_bmod = false;
@@ -1097,9 +1098,11 @@ static int conv3d_bwd_impl(const passion_conv_desc_t* d, const float* packed, co
             if (k.seg[s].bmod > 0) any_bmod = true;
         }
         const int bphys = pw_bd ? k.seg[0].bmod : k.B;
-        const int kblocks = pw_bd ? k.nseg * k.Cout / 8 : k.Cout / 8;
+        const int kblocks = pw_bd ? k.nseg * k.Cout / 8 : (k.Cout + 7) / 8;
+        k.y_f32 = pw_f32 ? 1 : 0;
         pw_final = all_norm && (pw_bd || !any_bmod) && wpl.bf16 && wgrad_bf16_chunk(k, 1, 1) != 16 &&
                    wgrad_lean_covers(k, 1, 1, wpl.MT, wpl.gx, wpl.gy) && conv_pw_dgrad_covers(k, kblocks, bphys);
+        k.y_f32 = 0;
         static const bool dbg = getenv("PASSION_PWFINAL_DBG") != nullptr;
         if (dbg) fprintf(stderr, "[pwfinal] B=%d V=%ld Cin=%d Cout=%d nseg=%d: final=%d all_norm=%d bd=%d any_bmod=%d bf16=%d chunk=%d leancov=%d gxmod=%d pwcov=%d\n",
                          k.B, (long)k.Di * k.Hi * k.Wi, k.Cin, k.Cout, k.nseg, (int)pw_final, (int)all_norm, (int)pw_bd, (int)any_bmod, (int)wpl.bf16,
@@ -1229,7 +1232,9 @@ static int conv3d_bwd_impl(const passion_conv_desc_t* d, const float* packed, co
             k.sums = nullptr; k.sums_rep = 1; k.sums_fixed = 0; k.sums_float_only = 0;
             k.tilesD = cdiv(k.Di, TD); k.tilesH = cdiv(k.Hi, TH); k.tilesW = cdiv(k.Wi, TW);
             ProfScope prof(2, conv_bytes(k, xs, ys) + (double)k.Cin * k.Cout * 4, 2.0 * k.B * k.Do * k.Ho * k.Wo * (double)k.Cout * k.Cin, st);
+            k.y_f32 = pw_f32 ? 1 : 0;
             rc = launch_conv_lean(k, 1, 1, 1, packed + f32_pack_floats(k.Cin, k.Cout, 1), st);
+            k.y_f32 = 0;
             if (rc > 0 || (rc == 0 && !k.pw_done)) rc = -1020;      // planned for the pointwise kernels: must be covered
             return rc;
         }

@@ -807,9 +807,12 @@ __global__ __launch_bounds__(128) void pw_ident_kernel(ConvK p, const float* __r
 // shapes whose gradient the kernels below take (so that conv.hip may plan the finish-free order: weight gradient first)
 // `kblocks`: 8-channel blocks of the gradient's K axis (Cout / 8; nseg * Cout / 8 for the block-diagonal form of batched passes)
 bool conv_pw_dgrad_covers(const ConvK& k, int kblocks, int bphys) {
-    if (!g_conv_pw || k.y_f32) return false;
+    if (!g_conv_pw) return false;
     const long V = (long)k.Di * k.Hi * k.Wi;
-    if (V < 32768 || k.Cout % 8 || k.Cin > 64) return false;
+    if (V < 32768 || k.Cin > 64) return false;
+    if (k.y_f32) {                   // f32 dY of a logit head: the 8-channel form only
+        if (!(g_conv_pw8 && kblocks == 1 && (k.Cout == 4 || k.Cout == 8) && pad16(k.Cin) <= 32)) return false;
+    } else if (k.Cout % 8) return false;
     if ((long)bphys * V * k.Cin < (24L << 20)) return false;      // small tensors: the two extra launches and the lost dgrad || wgrad overlap cost more than the finish pass
     const int K8 = kblocks, mpad = pad16(k.Cin);
     for (int s = 0; s < k.nseg; ++s) if (k.seg[s].C % 8) return false;
