@@ -33,7 +33,10 @@ int passion_abi_version(void);
 /* developer A/B switches, also read from the environment at load time (PASSION_CONV_LEAN, PASSION_CONV_PADOUT,
  * PASSION_FORCE_F32_MFMA, ...): "conv_lean", "conv_padout", "force_f32_mfma", "conv_target", "conv_merge",
  * "wgrad_wide", "conv_dbg", "conv_march", "conv_c1" (0: general kernel for the first encoder layer), "wgrad_march" (0: wgrad_lean_kernel also where the marching weight-gradient kernel
- * applies; environment PASSION_WGRAD_MARCH=0).  PASSION_UPSAMPLE_SHARED=0 (environment only) keeps the flat x2 upsampling
+ * applies; environment PASSION_WGRAD_MARCH=0), "conv_s2" (0: zero-stuffed stride-2 input gradient), "conv_pw" / "conv_pw8" (0: the
+ * 1x1x1 layers on the lean brick kernels instead of the streaming ones / the 8-channel 32x32x8 form), "conv_pwfinal" (0: pointwise
+ * backward as dgrad + finish pass instead of the finish-free order with the means from the weight gradient), "flash_split" (n > 0:
+ * that many key splits in the fused attention, 0 = automatic).  PASSION_UPSAMPLE_SHARED=0 (environment only) keeps the flat x2 upsampling
  * kernels for bf16 tensors.  Returns the previous value, -1 for an unknown name.  The parity tests use it to run the
  * same conv through the general and the lean kernels. */
 int passion_set_option(const char* name, int value);
