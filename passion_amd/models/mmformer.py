@@ -537,7 +537,8 @@ class Model(nn.Module):
             bufs = sbufs = None
             if training:
                 c = self.flair_encoder.e1_c1.out_channels
-                bufs = [torch.empty(4, B, S >> l, S >> l, S >> l, c << l, dtype=dt, device=dev) for l in range(5)]
+                Dv, Hv, Wv = x.shape[2:]              # any (16 pD, 16 pH, 16 pW) volume, not only cubes
+                bufs = [torch.empty(4, B, Dv >> l, Hv >> l, Wv >> l, c << l, dtype=dt, device=dev) for l in range(5)]
                 sbufs = [torch.empty(4, B, c << l, 2, dtype=torch.float32, device=dev) for l in range(5)]
             # The four encoders are independent until the fusion: each runs on its own HIP stream (forward, and -- autograd
             # replays every node on the stream of its forward -- backward too), so the small deep-level launches of one
