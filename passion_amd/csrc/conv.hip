@@ -659,7 +659,7 @@ int fill_params(const passion_conv_desc_t* d, ConvK& k) {
     for (int g = 0; g < PASSION_MAX_GROUPS; ++g) k.biasg[g] = nullptr;
     k.bd_rows = 0; k.bd_k8 = 0;
     k.y_f32 = 0;
-    k.spos = nullptr; k.pwm = nullptr; k.pw_done = 0;
+    k.spos = nullptr; k.pwm = nullptr; k.pw_done = 0; k.march_k8 = 0;
     if (d->ksize != 1 && d->ksize != 3) return -1002;
     if (d->stride != 1 && d->stride != 2) return -1003;
     if (d->ksize == 1 && d->stride != 1) return -1003;

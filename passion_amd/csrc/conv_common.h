@@ -78,6 +78,7 @@ struct ConvK {
     float* spos;           // 1x1x1 wgrad (conv_wgrad_lean.hip): second partial slab [slot][Cout][Cin] of sum_v dY[v][co] * [x_hat[v][ci] > 0]
                            // (the InstanceNorm-backward sums of the pointwise layers come from the weight gradient: conv_pw.hip)
     const float* pwm;      // pointwise "final" dgrad: (m1, m2) per (sample, input channel), already divided by V
+    int march_k8;          // conv_march.hip: real 8-channel blocks when a launch pads its K axis to a power of two (0 = NB)
     int pw_done;           // set by the pointwise gradient launchers (conv.hip checks that a planned final dgrad really ran there)
     FwdStats fst;          // forward: statistics of y from the kernel's epilogue (fst.stats != nullptr)
     float* fst_want;       // forward: the caller wants statistics of y here (a launcher that fuses them moves it to fst.stats)

@@ -648,6 +648,8 @@ MARCH_CASES = [
     ([8, 8], 16, 3, 1, 1, (16, 16, 64), True, True, False),
     ([16], 8, 3, 1, 1, (40, 32, 32), True, False, False),      # several depth segments per tile
     ([8], 4, 3, 1, 1, (5, 8, 32), True, False, False),         # 4 output channels (RFNet-style narrow head input)
+    ([8, 8, 8], 8, 3, 1, 1, (10, 16, 32), True, True, False),  # three segments: forward as NB = 4 with an empty block (RFNet's level-1 decoder concat)
+    ([8, 8, 8], 16, 3, 1, 1, (8, 8, 16), True, False, False),
 ]
 MARCH_PATHS = {"march": {}, "march_one_segment": {"conv_target": 1}, "march_many_segments": {"conv_target": 100000},
                "march_off": {"conv_march": 0}}
