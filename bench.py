@@ -431,7 +431,8 @@ def main():
                 # rocprofv3 spells a bool template argument true / false, the library's tag 1 / 0
                 import re as _re
                 alt = _re.sub(r", (0|1)>$", lambda m: ", false>" if m.group(1) == "0" else ", true>", dom)
-                traffic = tj.get(dom, tj.get(alt))
+                alt2 = alt[:-1] + ", 1>"          # ... and prints a defaulted trailing template argument (conv_march_kernel's row tiles)
+                traffic = tj.get(dom, tj.get(alt, tj.get(alt2)))
             copy_gbs = measured_copy_gbs(ctx.device)
             ak = [r for r in alone_recs if r[4] == dom]
             alone_ms = sum(r[1] for r in ak) / len(ak) if ak else None

@@ -80,13 +80,15 @@ struct MarchP {
     int k8;                        // 8-channel blocks of the K axis that exist (<= NB: a 24-channel concat runs as NB = 4 with an empty block)
 };
 
-template <int NB, int TW, int MODE, bool HAS_RES>
-__global__ __launch_bounds__(256) void conv_march_kernel(ConvK p, MarchP mp) {
+// MT: 16-row tiles of the output (MODE 2 only: gradients with 17 .. 32 rows, e.g. the input gradient of a 24 / 32 -> 8 conv)
+template <int NB, int TW, int MODE, bool HAS_RES, int MT = 1>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((MT == 2 && NB == 1) ? 2 : 1)))      // 264 registers uncapped: one wave per SIMD
+void conv_march_kernel(ConvK p, MarchP mp) {
     using G = GeoM<NB, TW>;
     constexpr bool DG = (MODE == 2);
     constexpr int NIT = G::NIT, NSTEP = G::NSTEP, NTW = G::NTW, VS = G::VS, RSB = G::RSB, PLANE = G::PLANE;
     extern __shared__ __attribute__((aligned(16))) char lds[];            // [NSLOT planes]
-    __shared__ float lsum[4 * 16 * 2 + 32];               // [wave][row][2] partial sums, then the workgroup's 16 x 2 totals
+    __shared__ float lsum[4 * MT * 16 * 2 + MT * 32];     // [wave][row][2] partial sums, then the workgroup's 16 MT x 2 totals
 
     const int tid = threadIdx.x, lane = tid & 63, n = lane & 15, g = (lane >> 4) & 3;
     const int wv = rfl(tid >> 6);
@@ -182,12 +184,15 @@ __global__ __launch_bounds__(256) void conv_march_kernel(ConvK p, MarchP mp) {
     for (int j = 0; j < ND; ++j) fetch(j, raw[j]);
 
     // weights: all A fragments of the K axis in registers.  pair q = 4 s + g -> (tap, block)
-    bf16x8 wfr[NSTEP];
+    bf16x8 wfr[MT][NSTEP];
 #pragma unroll
     for (int s = 0; s < NSTEP; ++s) {
         const int q = min(4 * s + g, G::Q - 1), tap = q / NB, blk = q % NB;
-        wfr[s] = gload<bf16x8>(reinterpret_cast<const bf16x8*>(p.wpack) + wvec_of(p, b) + ((long)tap * mp.k8 + min(blk, mp.k8 - 1)) * p.Mpad + n);
-        if (4 * s + g >= G::Q || blk >= mp.k8) wfr[s] = zero8();
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            wfr[mt][s] = gload<bf16x8>(reinterpret_cast<const bf16x8*>(p.wpack) + wvec_of(p, b) + ((long)tap * mp.k8 + min(blk, mp.k8 - 1)) * p.Mpad + mt * 16 + n);
+            if (4 * s + g >= G::Q || blk >= mp.k8) wfr[mt][s] = zero8();
+        }
     }
     // mask byte + statistics of the staged block
     unsigned mbyte = 1u;
@@ -199,33 +204,38 @@ __global__ __launch_bounds__(256) void conv_march_kernel(ConvK p, MarchP mp) {
         for (int c = 0; c < 4; ++c) st4[c] = gload<f32x4>(sptr + 4 * c);       // (mean, rstd) of channels 2c, 2c + 1
     }
     // MODE 2 epilogue: the four output rows (= forward input channels 4 g .. 4 g + 3) of this lane
-    const bf16_t* ex = nullptr;
-    int eC = 4;
-    bool e_ok = false, e_st = false;
-    float emval = 1.f;
-    f32x4 emean = {0.f, 0.f, 0.f, 0.f}, erstd = {1.f, 1.f, 1.f, 1.f};
-    if (DG) {
-        const int cg = g * 4;
-        const uint8_t* emp = nullptr;
-        const float* esp = nullptr;
+    const bf16_t* ex[MT];
+    int eC[MT];
+    bool e_ok[MT], e_st[MT];
+    float emval[MT];
+    f32x4 emean[MT], erstd[MT];
 #pragma unroll
-        for (int s2 = 0; s2 < PASSION_MAX_SEG; ++s2) {
-            if (s2 < p.nseg && cg < p.Cin) {
-                const SegD& sd = p.seg[s2];
-                if (cg >= sd.cbase && cg < sd.cbase + sd.C && sd.dx != nullptr) {
-                    const int cl = cg - sd.cbase, bs = sd.bsrc(b);
-                    e_ok = true; eC = sd.C; e_st = sd.stats != nullptr;
-                    ex = reinterpret_cast<const bf16_t*>(sd.x) + (long)bs * sd.bstride + cl;
-                    if (sd.mask) emp = sd.mask + (long)b * sd.mask_ld + sd.mask_col;
-                    if (sd.stats) esp = sd.stats + ((long)bs * sd.C + cl) * 2;
+    for (int mt = 0; mt < MT; ++mt) {
+        ex[mt] = nullptr; eC[mt] = 4; e_ok[mt] = false; e_st[mt] = false; emval[mt] = 1.f;
+        emean[mt] = (f32x4){0.f, 0.f, 0.f, 0.f}; erstd[mt] = (f32x4){1.f, 1.f, 1.f, 1.f};
+        if (DG) {
+            const int cg = mt * 16 + g * 4;
+            const uint8_t* emp = nullptr;
+            const float* esp = nullptr;
+#pragma unroll
+            for (int s2 = 0; s2 < PASSION_MAX_SEG; ++s2) {
+                if (s2 < p.nseg && cg < p.Cin) {
+                    const SegD& sd = p.seg[s2];
+                    if (cg >= sd.cbase && cg < sd.cbase + sd.C && sd.dx != nullptr) {
+                        const int cl = cg - sd.cbase, bs = sd.bsrc(b);
+                        e_ok[mt] = true; eC[mt] = sd.C; e_st[mt] = sd.stats != nullptr;
+                        ex[mt] = reinterpret_cast<const bf16_t*>(sd.x) + (long)bs * sd.bstride + cl;
+                        if (sd.mask) emp = sd.mask + (long)b * sd.mask_ld + sd.mask_col;
+                        if (sd.stats) esp = sd.stats + ((long)bs * sd.C + cl) * 2;
+                    }
                 }
             }
-        }
-        if (emp) emval = gload<uint8_t>(emp) ? 1.f : 0.f;
-        if (esp) {
-            const f32x4 a = gload<f32x4>(esp), c2 = gload<f32x4>(esp + 4);
-            emean = (f32x4){a[0], a[2], c2[0], c2[2]};
-            erstd = (f32x4){a[1], a[3], c2[1], c2[3]};
+            if (emp) emval[mt] = gload<uint8_t>(emp) ? 1.f : 0.f;
+            if (esp) {
+                const f32x4 a = gload<f32x4>(esp), c2 = gload<f32x4>(esp + 4);
+                emean[mt] = (f32x4){a[0], a[2], c2[0], c2[2]};
+                erstd[mt] = (f32x4){a[1], a[3], c2[1], c2[3]};
+            }
         }
     }
     // zero the whole ring once: the guard ring and the out-of-volume halo of zero-padded / gradient planes stay zero
@@ -335,7 +345,9 @@ __global__ __launch_bounds__(256) void conv_march_kernel(ConvK p, MarchP mp) {
     f32x4 biasv = {0.f, 0.f, 0.f, 0.f};
     if (!DG && bias_of(p, b) && g * 4 < p.Cout) biasv = load4(bias_of(p, b) + g * 4);
     const bool row_ok = g * 4 < (DG ? p.Cin : p.Cout);
-    const float f_pos = emval, f_neg = e_st ? emval * p.slope : emval;       // LeakyReLU' x modality mask
+    float f_pos[MT], f_neg[MT];                                // LeakyReLU' x modality mask
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) { f_pos[mt] = emval[mt]; f_neg[mt] = e_st[mt] ? emval[mt] * p.slope : emval[mt]; }
     const int Wp = pad8(Sw + 2);
     bf16_t* ybase = DG ? reinterpret_cast<bf16_t*>(p.y) + (long)b * (Sd + 2) * (Sh + 2) * Wp * p.Cin
                        : reinterpret_cast<bf16_t*>(p.y) + (long)b * Sd * Sh * Sw * p.Cout;
@@ -344,39 +356,54 @@ __global__ __launch_bounds__(256) void conv_march_kernel(ConvK p, MarchP mp) {
     constexpr bool EOP = DG || HAS_RES;
     // lanes whose four rows do not exist (g * 4 >= channels) load from element 0 of a valid tensor: their x / residual is never used,
     // and "their" channels of the last voxel would lie past the end of the allocation
-    const bf16_t* ebase = DG ? (e_ok ? ex : reinterpret_cast<const bf16_t*>(p.seg[0].x))
-                             : reinterpret_cast<const bf16_t*>(p.residual) + (long)b * Sd * Sh * Sw * p.Cout + (row_ok ? g * 4 : 0);
-    const int eCs = DG ? (e_ok ? eC : 0) : (row_ok ? p.Cout : 0);
-    unsigned eel[TT], oel[TT];                                 // in-plane element offsets: operand / output
+    const bf16_t* ebase[MT];
+    int eCs[MT];
+    unsigned eplane[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        ebase[mt] = DG ? (e_ok[mt] ? ex[mt] : reinterpret_cast<const bf16_t*>(p.seg[0].x))
+                       : reinterpret_cast<const bf16_t*>(p.residual) + (long)b * Sd * Sh * Sw * p.Cout + (row_ok ? g * 4 : 0);
+        eCs[mt] = DG ? (e_ok[mt] ? eC[mt] : 0) : (row_ok ? p.Cout : 0);
+        eplane[mt] = (unsigned)(Sh * Sw) * (unsigned)eCs[mt];
+    }
+    unsigned eel[MT][TT], oel[TT];                             // in-plane element offsets: operand / output (row tile mt: + 16 mt channels)
 #pragma unroll
     for (int t = 0; t < TT; ++t) {
         const int rh = min(max(reflect_idx(tph[t], Sh), 0), Sh - 1), rw = min(max(reflect_idx(tpw[t], Sw), 0), Sw - 1);
-        eel[t] = (unsigned)(rh * Sw + rw) * (unsigned)eCs;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) eel[mt][t] = (unsigned)(rh * Sw + rw) * (unsigned)eCs[mt];
         oel[t] = DG ? (unsigned)((tph[t] + 1) * Wp + (tpw[t] + 1)) * (unsigned)p.Cin + (unsigned)(g * 4)
                     : (unsigned)(tph[t] * Sw + tpw[t]) * (unsigned)p.Cout + (unsigned)(g * 4);
     }
-    const unsigned eplane = (unsigned)(Sh * Sw) * (unsigned)eCs;
     const unsigned oplane = DG ? (unsigned)((Sh + 2) * Wp) * (unsigned)p.Cin : (unsigned)(Sh * Sw) * (unsigned)p.Cout;
-    u32x2 eop[ND][EOP ? TT : 1];
-    auto eload = [&](int jout, u32x2 (&dst)[EOP ? TT : 1]) {
+    u32x2 eop[ND][EOP ? MT * TT : 1];
+    auto eload = [&](int jout, u32x2 (&dst)[EOP ? MT * TT : 1]) {
         if (!EOP) return;
         const int dpos = dlo + jout;
-        const unsigned pb = (unsigned)min(max(reflect_idx(dpos, Sd), 0), Sd - 1) * eplane;
+        const unsigned pl = (unsigned)min(max(reflect_idx(dpos, Sd), 0), Sd - 1);
 #pragma unroll
-        for (int t = 0; t < TT; ++t) dst[t] = gload<u32x2>(ebase + (pb + eel[t]));
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int t = 0; t < TT; ++t) dst[mt * TT + t] = gload<u32x2>(ebase[mt] + (pl * eplane[mt] + eel[mt][t]));
     };
-    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2v[4] = {0.f, 0.f, 0.f, 0.f};
+    float s1[MT][4], s2v[MT][4];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { s1[mt][j] = 0.f; s2v[mt][j] = 0.f; }
     const bool fstats = !DG && p.fst.stats != nullptr;
 
     // output plane jout (position dlo + jout) from ring planes jout, jout + 1, jout + 2
     const int lanebase = (r0 + 2) * RSB + (n + 2) * VS;        // main tile t: + (t / NTW) * RSB + (t % NTW) * 16 * VS (an immediate)
     char* yb8 = reinterpret_cast<char*>(ybase);
-    auto compute = [&](int jout, const u32x2 (&eo)[EOP ? TT : 1]) {
+    auto compute = [&](int jout, const u32x2 (&eo)[EOP ? MT * TT : 1]) {
         const int dpos = dlo + jout;
         const bool pvalid = jout >= 0 && jout < L && !(nohalo && (dpos < 0 || dpos >= Sd));
-        f32x4 acc[TT];
+        f32x4 acc[MT][TT];
 #pragma unroll
-        for (int t = 0; t < TT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int t = 0; t < TT; ++t) acc[mt][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
         // B fragments one K step ahead of the MFMAs that consume them (the compiler alternates read / wait / MFMA otherwise)
         bf16x8 cur[TT], nxt[TT];
         auto bload = [&](int s, bf16x8 (&dst)[TT]) {
@@ -397,7 +424,10 @@ __global__ __launch_bounds__(256) void conv_march_kernel(ConvK p, MarchP mp) {
             __builtin_amdgcn_sched_barrier(0);                 // keep the reads of step s + 1 ahead of the MFMAs of step s
 #pragma unroll
             for (int t = 0; t < TT; ++t)
-                if (tile_on[t]) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfr[s], cur[t], acc[t], 0, 0, 0);
+                if (tile_on[t]) {
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) acc[mt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfr[mt][s], cur[t], acc[mt][t], 0, 0, 0);
+                }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int t = 0; t < TT; ++t) cur[t] = nxt[t];
@@ -411,7 +441,7 @@ __global__ __launch_bounds__(256) void conv_march_kernel(ConvK p, MarchP mp) {
             const bool valid = pvalid && ((vmask >> t) & 1u);
             const unsigned obyte = (ob + oel[t]) * 2u;         // < 2^32: one sample of the output / scratch volume
             if (!DG) {
-                f32x4 v = acc[t] + biasv;
+                f32x4 v = acc[0][t] + biasv;
                 if (HAS_RES) {
                     v[0] += __uint_as_float(eo[t].x << 16); v[1] += __uint_as_float(eo[t].x & 0xffff0000u);
                     v[2] += __uint_as_float(eo[t].y << 16); v[3] += __uint_as_float(eo[t].y & 0xffff0000u);
@@ -425,26 +455,29 @@ __global__ __launch_bounds__(256) void conv_march_kernel(ConvK p, MarchP mp) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const float r = rb[j] * vf;
-                        s1[j] += r;
-                        s2v[j] = __builtin_fmaf(r, r, s2v[j]);
+                        s1[0][j] += r;
+                        s2v[0][j] = __builtin_fmaf(r, r, s2v[0][j]);
                     }
                 }
             } else {
-                const u32x2 xr = eo[t];
-                const float xv[4] = {__uint_as_float(xr.x << 16), __uint_as_float(xr.x & 0xffff0000u),
-                                     __uint_as_float(xr.y << 16), __uint_as_float(xr.y & 0xffff0000u)};
-                const float vf = (valid && e_ok && e_st) ? 1.f : 0.f;
-                f32x4 gv = acc[t];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float xh = e_st ? (xv[j] - emean[j]) * erstd[j] : 1.f;
-                    const float gg = gv[j] * (xh > 0.f ? f_pos : f_neg);
-                    gv[j] = gg;
-                    const float gs = gg * vf;
-                    s1[j] += gs;
-                    s2v[j] = __builtin_fmaf(gs, xh, s2v[j]);
+                for (int mt = 0; mt < MT; ++mt) {
+                    const u32x2 xr = eo[mt * TT + t];
+                    const float xv[4] = {__uint_as_float(xr.x << 16), __uint_as_float(xr.x & 0xffff0000u),
+                                         __uint_as_float(xr.y << 16), __uint_as_float(xr.y & 0xffff0000u)};
+                    const float vf = (valid && e_ok[mt] && e_st[mt]) ? 1.f : 0.f;
+                    f32x4 gv = acc[mt][t];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float xh = e_st[mt] ? (xv[j] - emean[mt][j]) * erstd[mt][j] : 1.f;
+                        const float gg = gv[j] * (xh > 0.f ? f_pos[mt] : f_neg[mt]);
+                        gv[j] = gg;
+                        const float gs = gg * vf;
+                        s1[mt][j] += gs;
+                        s2v[mt][j] = __builtin_fmaf(gs, xh, s2v[mt][j]);
+                    }
+                    if (valid && e_ok[mt]) store4(reinterpret_cast<bf16_t*>(yb8 + obyte + mt * 32), gv);
                 }
-                if (valid && e_ok) store4(reinterpret_cast<bf16_t*>(yb8 + obyte), gv);
             }
         }
     };
@@ -480,44 +513,48 @@ __global__ __launch_bounds__(256) void conv_march_kernel(ConvK p, MarchP mp) {
         // order) -> this workgroup's own slot
         __syncthreads();
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float a1 = group16_sum(s1[j]), a2 = group16_sum(s2v[j]);
-            if (n == 0) {
-                lsum[(wv * 16 + g * 4 + j) * 2 + 0] = a1;
-                lsum[(wv * 16 + g * 4 + j) * 2 + 1] = a2;
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float a1 = group16_sum(s1[mt][j]), a2 = group16_sum(s2v[mt][j]);
+                if (n == 0) {
+                    lsum[((wv * MT + mt) * 16 + g * 4 + j) * 2 + 0] = a1;
+                    lsum[((wv * MT + mt) * 16 + g * 4 + j) * 2 + 1] = a2;
+                }
             }
-        }
         __syncthreads();
-        if (tid < 32) {
-            const int c = tid >> 1, k2 = tid & 1;
-            const float t = ((lsum[(0 * 16 + c) * 2 + k2] + lsum[(1 * 16 + c) * 2 + k2]) + lsum[(2 * 16 + c) * 2 + k2]) + lsum[(3 * 16 + c) * 2 + k2];
+        if (tid < 32 * MT) {
+            const int c = tid >> 1, k2 = tid & 1;                  // c = 16 mt + row
+            const float t = ((lsum[(0 * MT * 16 + c) * 2 + k2] + lsum[(1 * MT * 16 + c) * 2 + k2]) + lsum[(2 * MT * 16 + c) * 2 + k2]) +
+                            lsum[(3 * MT * 16 + c) * 2 + k2];
             if (DG) {
                 if (c < p.Cin) {
                     float* rs = p.sums + (long)(bx % mp.nwg_b) * p.B * p.Cin * 2;
                     rs[((long)b * p.Cin + c) * 2 + k2] = t;
                 }
             } else {
-                lsum[4 * 16 * 2 + tid] = t;
+                lsum[4 * MT * 16 * 2 + tid] = t;
             }
         }
         if (!DG) {
             __syncthreads();
-            fwd_stats_commit(p.fst, p.Cout, b, bx % mp.nwg_b, 0, 16, lsum + 4 * 16 * 2, tid);
+            fwd_stats_commit(p.fst, p.Cout, b, bx % mp.nwg_b, 0, 16, lsum + 4 * MT * 16 * 2, tid);
         }
     }
 }
 
-template <int NB, int TW, int MODE, bool HAS_RES>
+template <int NB, int TW, int MODE, bool HAS_RES, int MT = 1>
 int launch_march_res(ConvK& k, const MarchP& mp, hipStream_t st) {
     using G = GeoM<NB, TW>;
     static bool granted = false;
     if (!granted) {
-        HIP_RET(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_march_kernel<NB, TW, MODE, HAS_RES>),
+        HIP_RET(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_march_kernel<NB, TW, MODE, HAS_RES, MT>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS));
         granted = true;
     }
-    passion_prof_tag("conv_march_kernel<%d, %d, %d, %d>", NB, TW, MODE, HAS_RES ? 1 : 0);
-    hipLaunchKernelGGL((conv_march_kernel<NB, TW, MODE, HAS_RES>), dim3(k.B * mp.nwg_b), dim3(256), G::LDS, st, k, mp);
+    if (MT == 1) passion_prof_tag("conv_march_kernel<%d, %d, %d, %d>", NB, TW, MODE, HAS_RES ? 1 : 0);
+    else passion_prof_tag("conv_march_kernel<%d, %d, %d, %d, %d>", NB, TW, MODE, HAS_RES ? 1 : 0, MT);
+    hipLaunchKernelGGL((conv_march_kernel<NB, TW, MODE, HAS_RES, MT>), dim3(k.B * mp.nwg_b), dim3(256), G::LDS, st, k, mp);
     LAUNCH_RET();
     return 0;
 }
@@ -547,6 +584,10 @@ int launch_march_one(ConvK& k, hipStream_t st) {
         if (rc) return rc < 0 ? rc : -rc;
     }
     if (MODE == 0 && k.residual) return launch_march_res<NB, TW, MODE, true>(k, mp, st);
+    if (MODE == 2 && k.Mpad == 32) {
+        if (TW != 16 || NB > 2) return 1;            // two row tiles: the 16-wide tiling only
+        return launch_march_res<(NB > 2 ? 1 : NB), 16, 2, false, 2>(k, mp, st);
+    }
     return launch_march_res<NB, TW, MODE, false>(k, mp, st);
 }
 
@@ -561,7 +602,7 @@ bool conv_march_covers(const ConvK& k, int ksize, int stride, int mode, int* K8o
     if (k.y_f32 || k.bd_rows || !(k.slope >= 0.f && k.slope <= 1.f)) return false;
     if (k.Hi % MTH || k.Wi % 16 || k.Di < 4) return false;
     const int rows = mode == 2 ? k.Cin : k.Cout;               // M axis
-    if (rows > 16 || rows % 4) return false;
+    if (rows > (mode == 2 ? 32 : 16) || rows % 4) return false;
     int K8;
     if (mode == 2) {
         if (k.Cout % 8) return false;

@@ -650,6 +650,9 @@ MARCH_CASES = [
     ([8], 4, 3, 1, 1, (5, 8, 32), True, False, False),         # 4 output channels (RFNet-style narrow head input)
     ([8, 8, 8], 8, 3, 1, 1, (10, 16, 32), True, True, False),  # three segments: forward as NB = 4 with an empty block (RFNet's level-1 decoder concat)
     ([8, 8, 8], 16, 3, 1, 1, (8, 8, 16), True, False, False),
+    ([16, 16], 8, 3, 1, 1, (9, 16, 32), True, True, False),    # input gradient with 32 rows: two row tiles in the marching dgrad
+    ([32], 16, 3, 1, 1, (12, 8, 48), True, False, False),      # 32 rows over two K blocks (forward: lean kernel)
+    ([8, 16], 8, 3, 1, 1, (6, 24, 16), True, True, False),     # 24 rows, segments of different width
 ]
 MARCH_PATHS = {"march": {}, "march_one_segment": {"conv_target": 1}, "march_many_segments": {"conv_target": 100000},
                "march_off": {"conv_march": 0}}
