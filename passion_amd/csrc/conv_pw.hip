@@ -279,12 +279,13 @@ __global__ __launch_bounds__(256) void conv_pw_dgrad_kernel(ConvK p, int K8, lon
     __syncthreads();
     // per-lane copies of what the epilogue needs every trip
     const bf16_t* ex[MT];
-    unsigned eC[MT];
+    unsigned eC[MT], xS[MT];
     bool e_ok[MT], e_hs[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
         const PwEpi& e = edesc[mt * 4 + g];
         ex[mt] = e.x; eC[mt] = (unsigned)e.C; e_ok[mt] = e.ok != 0; e_hs[mt] = e.has_stats != 0;
+        xS[mt] = e_hs[mt] ? eC[mt] : 0u;               // inputs that were not normalised: x is not needed (LeakyReLU' = 1) -- every lane re-reads one cached address
     }
     float s1[MT][4], s2v[MT][4];                               // FINAL: (m1, m2) of the lane's rows instead of running sums
 #pragma unroll
@@ -310,7 +311,7 @@ __global__ __launch_bounds__(256) void conv_pw_dgrad_kernel(ConvK p, int K8, lon
                 raw[s][t] = gload<u32x4>(src + vc * cdy + (q < K8 ? q * 8 : 0));
             }
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) xpre[mt][t] = gload<u32x2>(ex[mt] + vc * eC[mt]);
+            for (int mt = 0; mt < MT; ++mt) xpre[mt][t] = gload<u32x2>(ex[mt] + vc * xS[mt]);
         }
         f32x4 acc[MT][TT];
 #pragma unroll
@@ -570,12 +571,13 @@ __global__ __launch_bounds__(256) void conv_pw8_dgrad_kernel(ConvK p, long V) {
     const bool k_ok = 4 * h < p.Cout;                       // this lane's four dY channels exist (Cout is 4 or 8 here)
     __syncthreads();
     const bf16_t* ex[RT];
-    unsigned eC[RT];
+    unsigned eC[RT], xS[RT];
     bool e_ok[RT], e_hs[RT];
 #pragma unroll
     for (int i = 0; i < RT; ++i) {
         const PwEpi& e = edesc[i * 2 + h];
         ex[i] = e.x; eC[i] = (unsigned)e.C; e_ok[i] = e.ok != 0; e_hs[i] = e.has_stats != 0;
+        xS[i] = e_hs[i] ? eC[i] : 0u;
     }
     float s1[RT][4], s2v[RT][4];
 #pragma unroll
@@ -606,7 +608,7 @@ __global__ __launch_bounds__(256) void conv_pw8_dgrad_kernel(ConvK p, long V) {
             }
             if (!k_ok) raw[t] = (u32x2){0u, 0u};
 #pragma unroll
-            for (int i = 0; i < RT; ++i) xpre[i][t] = gload<u32x2>(ex[i] + vc * eC[i]);
+            for (int i = 0; i < RT; ++i) xpre[i][t] = gload<u32x2>(ex[i] + vc * xS[i]);
         }
 #pragma unroll
         for (int t = 0; t < TT; ++t) {
