@@ -363,7 +363,7 @@ void conv_march_kernel(ConvK p, MarchP mp) {
     for (int mt = 0; mt < MT; ++mt) {
         ebase[mt] = DG ? (e_ok[mt] ? ex[mt] : reinterpret_cast<const bf16_t*>(p.seg[0].x))
                        : reinterpret_cast<const bf16_t*>(p.residual) + (long)b * Sd * Sh * Sw * p.Cout + (row_ok ? g * 4 : 0);
-        eCs[mt] = DG ? (e_ok[mt] ? eC[mt] : 0) : (row_ok ? p.Cout : 0);
+        eCs[mt] = DG ? ((e_ok[mt] && e_st[mt]) ? eC[mt] : 0) : (row_ok ? p.Cout : 0);      // x only where it is needed (x_hat for LeakyReLU' and the sums)
         eplane[mt] = (unsigned)(Sh * Sw) * (unsigned)eCs[mt];
     }
     unsigned eel[MT][TT], oel[TT];                             // in-plane element offsets: operand / output (row tile mt: + 16 mt channels)
