@@ -29,6 +29,9 @@ def step():
 for _ in range(5):
     step()
 torch.cuda.synchronize()
+if os.environ.get("PASSION_NOGC") == "1":
+    import gc
+    gc.collect(); gc.freeze(); gc.disable()
 import time
 t0 = time.perf_counter()
 for _ in range(K):
