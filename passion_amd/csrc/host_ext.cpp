@@ -58,7 +58,30 @@ struct ConvCfg {
     bool want_stats = false;     // also return the InstanceNorm statistics of y (fused into the conv kernel where it can be)
     OptT stats_out;              // ... written into this preallocated (B, Cout, 2) f32 slot
     double eps = 1e-5;
+    std::vector<at::Tensor> params;     // direct-gradient mode: the parameters (weights, then biases) whose .grad the backward fills itself
 };
+
+// Direct-gradient mode (set_direct_grads, single-process training): the conv nodes take DETACHED weights / biases and write the
+// parameters' .grad themselves (assign when it is None, add otherwise -- what AccumulateGrad does).  A step of the model has ~210
+// conv parameters: as many AccumulateGrad nodes less for the autograd engine, whose per-node cost (queueing, stream guards and,
+// on this ROCm build, one hipGetDeviceCount call per node) is ~5 us of host time each on a busy box.  Off whenever gradient hooks
+// matter (GradReducer's overlap for N > 1 ranks hangs post-accumulate hooks on those nodes).
+bool g_direct_grads = false;
+void set_direct_grads(bool on) { g_direct_grads = on; }
+bool get_direct_grads() { return g_direct_grads; }
+
+void give_grad(const at::Tensor& param, const at::Tensor& gr) {
+    if (!gr.defined() || !param.requires_grad()) return;
+    at::NoGradGuard ng;
+    at::Tensor& cur = const_cast<at::Tensor&>(param).mutable_grad();
+    if (!cur.defined()) cur = gr;
+    else cur.add_(gr);
+}
+
+bool any_requires_grad(at::TensorList xs) {
+    for (const at::Tensor& x : xs) if (x.requires_grad()) return true;
+    return false;
+}
 
 void fill_desc(passion_conv_desc_t& d, const std::vector<int64_t>& geo, const std::vector<int64_t>& seg, double slope,
                const std::vector<OptT>& stats, const std::vector<OptT>& masks, at::TensorList xs, const std::vector<at::Tensor>* dxs,
@@ -138,6 +161,7 @@ struct ConvBlockNode : public torch::autograd::Function<ConvBlockNode> {
         ctx->saved_data["packed"] = cfg.packed;
         ctx->saved_data["wshape"] = weight.sizes().vec();
         ctx->saved_data["flags"] = std::vector<int64_t>{bias.has_value(), residual.has_value()};
+        ctx->saved_data["params"] = c10::List<at::Tensor>(cfg.params);
         if (!cfg.want_stats) return {y};
         ctx->mark_non_differentiable({st});
         ctx->set_materialize_grads(false);       // no zeros_like(stats) (a fill launch) per backward call for the gradient nobody has
@@ -153,9 +177,12 @@ struct ConvBlockNode : public torch::autograd::Function<ConvBlockNode> {
         const at::Tensor packed = ctx->saved_data["packed"].toTensor();
         const bool has_bias = flags[0] != 0, has_res = flags[1] != 0;
         // autograd edges exist for the tensor arguments only: weight, [bias], [residual], xs...
+        const std::vector<at::Tensor> params = ctx->saved_data["params"].toTensorVector();
+        const bool direct = !params.empty();
         size_t e = 0;
-        const bool need_w = ctx->needs_input_grad(e++);
-        const bool need_b = has_bias && ctx->needs_input_grad(e);
+        const bool need_w = direct ? params[0].requires_grad() : ctx->needs_input_grad(e);
+        ++e;
+        const bool need_b = has_bias && (direct ? params[1].requires_grad() : ctx->needs_input_grad(e));
         if (has_bias) ++e;
         const bool need_res = has_res && ctx->needs_input_grad(e);
         if (has_res) ++e;
@@ -204,6 +231,11 @@ struct ConvBlockNode : public torch::autograd::Function<ConvBlockNode> {
               "passion_conv3d_bwd");
         variable_list out;
         out.reserve(4 + n);
+        if (direct) {
+            give_grad(params[0], dW);
+            if (has_bias) give_grad(params[1], db);
+            dW = at::Tensor(); db = at::Tensor();
+        }
         out.push_back(dW);
         out.push_back(db);
         out.push_back(need_res ? dy : at::Tensor());
@@ -219,7 +251,13 @@ std::vector<at::Tensor> conv_block(const at::Tensor& weight, const OptT& bias, c
                                    double slope, const at::Tensor& packed, const OptT& out, bool want_stats, const OptT& stats_out,
                                    double eps) {
     TORCH_CHECK(g.conv_fwd && g.conv_fwd_stats, "passion_amd host extension is not bound to libpassion_hip.so");
-    ConvCfg cfg{std::move(geo), std::move(seg), slope, std::move(stats), std::move(masks), packed, out, want_stats, stats_out, eps};
+    ConvCfg cfg{std::move(geo), std::move(seg), slope, std::move(stats), std::move(masks), packed, out, want_stats, stats_out, eps, {}};
+    // direct-gradient mode needs some OTHER differentiable input to keep the node in the graph (the first conv of a network has none)
+    if (g_direct_grads && at::GradMode::is_enabled() && (weight.requires_grad() || (bias && bias->requires_grad())) && any_requires_grad(xs)) {
+        cfg.params.push_back(weight);
+        if (bias) cfg.params.push_back(*bias);
+        return ConvBlockNode::apply(weight.detach(), bias ? OptT(bias->detach()) : OptT(), residual, at::TensorList(xs), std::move(cfg));
+    }
     return ConvBlockNode::apply(weight, bias, residual, at::TensorList(xs), std::move(cfg));
 }
 
@@ -275,6 +313,7 @@ struct GroupedConvNode : public torch::autograd::Function<GroupedConvNode> {
         ctx->saved_data["packed"] = cfg.packed;
         ctx->saved_data["wshape"] = weight.sizes().vec();
         ctx->saved_data["flags"] = std::vector<int64_t>{G, biases.empty() ? 0 : 1, residual.has_value()};
+        ctx->saved_data["params"] = c10::List<at::Tensor>(cfg.params);
         ctx->set_materialize_grads(false);
         if (!cfg.want_stats) return {y};
         ctx->mark_non_differentiable({st});
@@ -292,11 +331,13 @@ struct GroupedConvNode : public torch::autograd::Function<GroupedConvNode> {
         if (!grads[0].defined()) return variable_list(nout);
         const std::vector<OptT> stats = from_list(ctx->saved_data["stats"]), masks = from_list(ctx->saved_data["masks"]);
         const at::Tensor packed = ctx->saved_data["packed"].toTensor();
+        const std::vector<at::Tensor> params = ctx->saved_data["params"].toTensorVector();
+        const bool direct = !params.empty();
         size_t e = 0;
         bool need_w = false;
-        for (int g2 = 0; g2 < G; ++g2) need_w = need_w || ctx->needs_input_grad(e + g2);
+        for (int g2 = 0; g2 < G; ++g2) need_w = need_w || (direct ? params[g2].requires_grad() : ctx->needs_input_grad(e + g2));
         e += G;
-        if (has_bias) { for (int g2 = 0; g2 < G; ++g2) need_w = need_w || ctx->needs_input_grad(e + g2); e += G; }
+        if (has_bias) { for (int g2 = 0; g2 < G; ++g2) need_w = need_w || (direct ? params[G + g2].requires_grad() : ctx->needs_input_grad(e + g2)); e += G; }
         const bool need_res = has_res && ctx->needs_input_grad(e);
         if (has_res) ++e;
         const at::Tensor dy = grads[0].contiguous();
@@ -327,9 +368,15 @@ struct GroupedConvNode : public torch::autograd::Function<GroupedConvNode> {
               "passion_conv3d_bwd_grouped");
         variable_list out;
         out.reserve(nout);
-        for (int g2 = 0; g2 < G; ++g2) out.push_back(need_w ? wbuf[g2].narrow(0, 0, nW).view(wshape) : at::Tensor());
+        if (direct && need_w) {
+            for (int g2 = 0; g2 < G; ++g2) {
+                give_grad(params[g2], wbuf[g2].narrow(0, 0, nW).view(wshape));
+                if (has_bias) give_grad(params[G + g2], wbuf[g2].narrow(0, nW, Cout));
+            }
+        }
+        for (int g2 = 0; g2 < G; ++g2) out.push_back((need_w && !direct) ? wbuf[g2].narrow(0, 0, nW).view(wshape) : at::Tensor());
         if (has_bias)
-            for (int g2 = 0; g2 < G; ++g2) out.push_back(need_w ? wbuf[g2].narrow(0, nW, Cout) : at::Tensor());
+            for (int g2 = 0; g2 < G; ++g2) out.push_back((need_w && !direct) ? wbuf[g2].narrow(0, nW, Cout) : at::Tensor());
         out.push_back(need_res ? dy : at::Tensor());
         for (int i = 0; i < n; ++i) out.push_back(dxs[i]);
         out.push_back(at::Tensor());     // cfg
@@ -342,7 +389,16 @@ std::vector<at::Tensor> conv_block_grouped(const std::vector<at::Tensor>& weight
                                            std::vector<int64_t> seg, std::vector<int64_t> geo, double slope, const at::Tensor& packed,
                                            const OptT& out, bool want_stats, const OptT& stats_out, double eps) {
     TORCH_CHECK(g.conv_fwd_grouped && g.conv_bwd_grouped, "passion_amd host extension is not bound to libpassion_hip.so");
-    ConvCfg cfg{std::move(geo), std::move(seg), slope, std::move(stats), std::move(masks), packed, out, want_stats, stats_out, eps};
+    ConvCfg cfg{std::move(geo), std::move(seg), slope, std::move(stats), std::move(masks), packed, out, want_stats, stats_out, eps, {}};
+    bool wreq = false;
+    for (const at::Tensor& w : weights) wreq = wreq || w.requires_grad();
+    for (const at::Tensor& b : biases) wreq = wreq || b.requires_grad();
+    if (g_direct_grads && at::GradMode::is_enabled() && wreq && any_requires_grad(xs)) {
+        std::vector<at::Tensor> wd, bd;
+        for (const at::Tensor& w : weights) { cfg.params.push_back(w); wd.push_back(w.detach()); }
+        for (const at::Tensor& b : biases) { cfg.params.push_back(b); bd.push_back(b.detach()); }
+        return GroupedConvNode::apply(at::TensorList(wd), at::TensorList(bd), residual, at::TensorList(xs), std::move(cfg));
+    }
     return GroupedConvNode::apply(at::TensorList(weights), at::TensorList(biases), residual, at::TensorList(xs), std::move(cfg));
 }
 
@@ -399,5 +455,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     m.def("conv_block_grouped", &conv_block_grouped);
     m.def("param_grad_ptrs", &param_grad_ptrs);
     m.def("drop_grads", &drop_grads);
+    m.def("set_direct_grads", &set_direct_grads, "conv nodes write the parameters' .grad themselves (no AccumulateGrad nodes); single-process training only");
+    m.def("get_direct_grads", &get_direct_grads);
     m.def("instnorm_stats", &instnorm_stats);
 }

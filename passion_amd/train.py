@@ -119,6 +119,7 @@ def poly_lr(base_lr, epoch, num_epochs, power=0.9):
 
 
 EARLY_STEP = os.environ.get("PASSION_EARLY_STEP", "1") != "0"    # AdamW of the non-encoder parameters under the encoder backward
+DIRECT_GRADS = os.environ.get("PASSION_DIRECT_GRADS", "1") != "0"  # single process: the conv nodes fill .grad themselves (no AccumulateGrad nodes)
 
 
 def _early_step_callback(model, optimizer):
@@ -159,6 +160,13 @@ def train_step(model, optimizer, x, mask, target, temp=4.0, state=None, reducer=
     net.is_training = True
     early = EARLY_STEP and hasattr(optimizer, "step_ready") and (reducer is None or reducer.ctx.world == 1) and x.is_cuda
     ops._MARKER_CB[0] = _early_step_callback(net, optimizer) if early else None
+    from . import _lib as L
+    host = L.host() if x.is_cuda else None
+    # ~210 AccumulateGrad nodes less per step for the autograd engine (csrc/host_ext.cpp); with more than one rank the
+    # GradReducer's overlap hangs hooks on exactly those nodes, so only here
+    direct = DIRECT_GRADS and host is not None and (reducer is None or reducer.ctx.world == 1)
+    if direct:
+        host.set_direct_grads(True)
     try:
         outs = net(x, mask, target=target, temp=temp)
         loss = assemble_loss(outs, target, mask, net.mask_type, net.use_passion, state, warmup, modal_num, iter_per_epoch)
@@ -166,6 +174,8 @@ def train_step(model, optimizer, x, mask, target, temp=4.0, state=None, reducer=
         loss.backward()
     finally:
         ops._MARKER_CB[0] = None
+        if direct:
+            host.set_direct_grads(False)
     if reducer is not None:
         reducer.all_reduce_grads()
     optimizer.step()
