@@ -253,7 +253,9 @@ std::vector<at::Tensor> conv_block(const at::Tensor& weight, const OptT& bias, c
     TORCH_CHECK(g.conv_fwd && g.conv_fwd_stats, "passion_amd host extension is not bound to libpassion_hip.so");
     ConvCfg cfg{std::move(geo), std::move(seg), slope, std::move(stats), std::move(masks), packed, out, want_stats, stats_out, eps, {}};
     // direct-gradient mode needs some OTHER differentiable input to keep the node in the graph (the first conv of a network has none)
-    if (g_direct_grads && at::GradMode::is_enabled() && (weight.requires_grad() || (bias && bias->requires_grad())) && any_requires_grad(xs)) {
+    // ... and LEAF parameters: a padded copy of a weight (blocks.run_conv_auto) sends its gradient on through autograd
+    if (g_direct_grads && at::GradMode::is_enabled() && (weight.requires_grad() || (bias && bias->requires_grad())) && weight.is_leaf() &&
+        (!bias || bias->is_leaf()) && any_requires_grad(xs)) {
         cfg.params.push_back(weight);
         if (bias) cfg.params.push_back(*bias);
         return ConvBlockNode::apply(weight.detach(), bias ? OptT(bias->detach()) : OptT(), residual, at::TensorList(xs), std::move(cfg));
@@ -390,10 +392,10 @@ std::vector<at::Tensor> conv_block_grouped(const std::vector<at::Tensor>& weight
                                            const OptT& out, bool want_stats, const OptT& stats_out, double eps) {
     TORCH_CHECK(g.conv_fwd_grouped && g.conv_bwd_grouped, "passion_amd host extension is not bound to libpassion_hip.so");
     ConvCfg cfg{std::move(geo), std::move(seg), slope, std::move(stats), std::move(masks), packed, out, want_stats, stats_out, eps, {}};
-    bool wreq = false;
-    for (const at::Tensor& w : weights) wreq = wreq || w.requires_grad();
-    for (const at::Tensor& b : biases) wreq = wreq || b.requires_grad();
-    if (g_direct_grads && at::GradMode::is_enabled() && wreq && any_requires_grad(xs)) {
+    bool wreq = false, leaves = true;
+    for (const at::Tensor& w : weights) { wreq = wreq || w.requires_grad(); leaves = leaves && w.is_leaf(); }
+    for (const at::Tensor& b : biases) { wreq = wreq || b.requires_grad(); leaves = leaves && b.is_leaf(); }
+    if (g_direct_grads && at::GradMode::is_enabled() && wreq && leaves && any_requires_grad(xs)) {
         std::vector<at::Tensor> wd, bd;
         for (const at::Tensor& w : weights) { cfg.params.push_back(w); wd.push_back(w.detach()); }
         for (const at::Tensor& b : biases) { cfg.params.push_back(b); bd.push_back(b.detach()); }

@@ -174,6 +174,36 @@ def bf16_param(p):
     return _CastGradFn.apply(p, ent[1])
 
 
+# Direct-gradient mode (train.train_step, single process; csrc/host_ext.cpp has the conv nodes' half): the Functions below are
+# then given their parameters inside an opaque box instead of as tensor arguments and write `.grad` themselves (assign when it is
+# None, add otherwise -- what AccumulateGrad does), so autograd builds no AccumulateGrad node per parameter: a few hundred nodes
+# less per step for an engine whose per-node cost is host time (m2ftrans, whose step is bound by the host, has ~700 of them).
+_DIRECT = [False]
+
+
+class _Box:
+    __slots__ = ("params",)
+
+    def __init__(self, params):
+        self.params = tuple(params)
+
+
+def _give(p, g):
+    if p is None or g is None or not p.requires_grad:
+        return
+    with torch.no_grad():
+        if p.grad is None:
+            p.grad = g
+        else:
+            p.grad.add_(g)
+
+
+def _direct(x, params):
+    """the mode is on, the node stays in the graph through x, and every parameter is a LEAF (a padded / sliced view of a parameter
+    has to send its gradient on through autograd)"""
+    return _DIRECT[0] and torch.is_grad_enabled() and x.requires_grad and all(p is None or p.is_leaf for p in params)
+
+
 class LinearFn(torch.autograd.Function):
     """y = x W^T + b for the token GEMMs (reference mmformer.py nn.Linear): the GEMMs stay on torch (hipBLASLt),
     the bias gradient is the library's fixed-order column sum (passion_colsum) instead of torch's `grad.sum(0)`, whose reduce
@@ -183,24 +213,30 @@ class LinearFn(torch.autograd.Function):
     dtype (their kept bf16 images, or the parameters themselves)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, w, b):
+    def forward(ctx, x, weight, bias, w, b, box=None):
         ctx.save_for_backward(x, w)
-        ctx.wshape = weight.shape
+        ctx.box = box                         # direct-gradient mode: (weight, bias) in here, the tensor slots hold None
+        ctx.wshape = (box.params[0] if box is not None else weight).shape
         return F.linear(x, w, b)
 
     @staticmethod
     def backward(ctx, g):
         x, w = ctx.saved_tensors
+        box = ctx.box
         g2 = g.reshape(-1, g.shape[-1])
         if not g2.is_contiguous():
             g2 = g2.contiguous()
         x2 = x.reshape(-1, x.shape[-1])
         dx = torch.mm(g2, w).view(x.shape) if ctx.needs_input_grad[0] else None
-        dw = None
-        if ctx.needs_input_grad[1]:
-            dw = _mm_f32(g2.t(), x2).view(ctx.wshape)
-        db = colsum(g2) if ctx.needs_input_grad[2] else None
-        return dx, dw, db, None, None
+        need_w = box.params[0].requires_grad if box is not None else ctx.needs_input_grad[1]
+        need_b = (box.params[1] is not None and box.params[1].requires_grad) if box is not None else ctx.needs_input_grad[2]
+        dw = _mm_f32(g2.t(), x2).view(ctx.wshape) if need_w else None
+        db = colsum(g2) if need_b else None
+        if box is not None:
+            _give(box.params[0], dw)
+            _give(box.params[1], db)
+            dw = db = None
+        return dx, dw, db, None, None, None
 
 
 _MM_F32 = [None]      # torch.mm(bf16, bf16, out_dtype=f32) exists on this build?
@@ -241,6 +277,8 @@ def linear(x, weight, bias, bf16):
         w, b = weight.detach(), (bias.detach() if bias is not None else None)
     if w.dim() > 2:              # the (Cout, Cin, 1, 1, 1) weight of a 1x1x1 conv run as a token GEMM
         w = w.view(w.shape[0], -1)
+    if _direct(x, (weight, bias)):
+        return LinearFn.apply(x, None, None, w, b, _Box((weight, bias)))
     return LinearFn.apply(x, weight, bias, w, b)
 
 
@@ -283,6 +321,10 @@ class GroupedLinearFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, b, n, *params):
         ctx.save_for_backward(x, w)
+        ctx.box = None
+        if len(params) == 1 and isinstance(params[0], _Box):      # direct-gradient mode
+            ctx.box = params[0]
+            params = ctx.box.params
         ctx.n, ctx.has_bias, ctx.wshape = n, b is not None, params[0].shape
         if b is None:
             return torch.bmm(x, w.transpose(1, 2))
@@ -304,6 +346,10 @@ class GroupedLinearFn(torch.autograd.Function):
         if ctx.has_bias:
             db = colsum_batched(g)
             grads += [db[i] for i in range(n)]
+        if ctx.box is not None:
+            for p_, g_ in zip(ctx.box.params, grads):
+                _give(p_, g_)
+            return dx, None, None, None, None
         return (dx, None, None, None, *grads)
 
 
@@ -327,6 +373,8 @@ def linear_grouped(x, weights, biases, bf16):
     if w.dim() > 3:              # (G, Cout, Cin, 1, 1, 1) weights of 1x1x1 convs run as token GEMMs
         w = w.view(n, w.shape[1], -1)
     params = list(weights) + (list(biases) if biases is not None else [])
+    if _direct(x, params):
+        return GroupedLinearFn.apply(x, w, b, n, _Box(params))
     return GroupedLinearFn.apply(x, w, b, n, *params)
 
 
@@ -1040,6 +1088,10 @@ class LnActFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, res, act, eps, G, *params):
         L.require_gpu(x)
+        ctx.box = None
+        if len(params) == 1 and isinstance(params[0], _Box):      # direct-gradient mode
+            ctx.box = params[0]
+            params = ctx.box.params
         x = x.contiguous()
         C = x.shape[-1]
         rows = x.numel() // C
@@ -1070,6 +1122,11 @@ class LnActFn(torch.autograd.Function):
                                        L.dtype_code(x.dtype), rows, C, rows // G, ctx.act, L.stream_ptr()), "passion_ln_act_bwd")
         if ctx.has_res and not ctx.act:
             dres = dy
+        if ctx.box is not None:
+            for g in range(G):
+                _give(ctx.box.params[g], dgb[0, g])
+                _give(ctx.box.params[G + g], dgb[1, g])
+            return dx, dres, None, None, None, None
         return (dx, dres, None, None, None, *[dgb[0, g] for g in range(G)], *[dgb[1, g] for g in range(G)])
 
 
@@ -1082,7 +1139,10 @@ def ln_act(x, norms, act=False, res=None):
     assert G == 1 or x.shape[0] == G
     if not (x.is_cuda and L.load().passion_ln_act_supported(rows, C, rows // G)):
         raise RuntimeError(f"ln_act: unsupported shape rows={rows} C={C} G={G} (C / 8 must be a power of two, C <= 512) or not on the GPU")
-    return LnActFn.apply(x, res, bool(act), norms[0].eps, G, *[n.weight for n in norms], *[n.bias for n in norms])
+    params = [n.weight for n in norms] + [n.bias for n in norms]
+    if _direct(x, params):
+        return LnActFn.apply(x, res, bool(act), norms[0].eps, G, _Box(params))
+    return LnActFn.apply(x, res, bool(act), norms[0].eps, G, *params)
 
 
 class GroupConvFn(torch.autograd.Function):
@@ -1093,6 +1153,10 @@ class GroupConvFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, G, has_bias, *params):
         L.require_gpu(x)
+        ctx.box = None
+        if len(params) == 1 and isinstance(params[0], _Box):      # direct-gradient mode
+            ctx.box = params[0]
+            params = ctx.box.params
         x = x.contiguous()
         B, D, H, W, C = x.shape
         w = f32_stack(params[:G]).contiguous()
@@ -1120,6 +1184,12 @@ class GroupConvFn(torch.autograd.Function):
         part = torch.empty(n, dtype=torch.float32, device=x.device) if n else None
         L.check(lib.passion_gconv3d_bwd(_p(x), _p(w), _p(dy), _p(dx), _p(dw), _p(db), _p(part), L.dtype_code(x.dtype), B, D, H, W, C, cpg, G,
                                         L.stream_ptr()), "passion_gconv3d_bwd")
+        if ctx.box is not None:
+            for g in range(G):
+                _give(ctx.box.params[g], dw[g])
+                if ctx.has_bias:
+                    _give(ctx.box.params[G + g], db[g])
+            return dx, None, None, None
         return (dx, None, None, *[dw[g] for g in range(G)], *([db[g] for g in range(G)] if ctx.has_bias else []))
 
 
@@ -1127,6 +1197,8 @@ def group_conv3d(x, weight, bias):
     """weight / bias: one parameter each, or lists of G (x then holds G * B samples, B per weight set)"""
     ws = list(weight) if isinstance(weight, (list, tuple)) else [weight]
     bs = (list(bias) if isinstance(bias, (list, tuple)) else [bias]) if bias is not None else []
+    if _direct(x, ws + bs):
+        return GroupConvFn.apply(x, len(ws), bool(bs), _Box(ws + bs))
     return GroupConvFn.apply(x, len(ws), bool(bs), *ws, *bs)
 
 

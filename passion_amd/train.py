@@ -167,6 +167,7 @@ def train_step(model, optimizer, x, mask, target, temp=4.0, state=None, reducer=
     direct = DIRECT_GRADS and host is not None and (reducer is None or reducer.ctx.world == 1)
     if direct:
         host.set_direct_grads(True)
+        ops._DIRECT[0] = True
     try:
         outs = net(x, mask, target=target, temp=temp)
         loss = assemble_loss(outs, target, mask, net.mask_type, net.use_passion, state, warmup, modal_num, iter_per_epoch)
@@ -176,6 +177,7 @@ def train_step(model, optimizer, x, mask, target, temp=4.0, state=None, reducer=
         ops._MARKER_CB[0] = None
         if direct:
             host.set_direct_grads(False)
+            ops._DIRECT[0] = False
     if reducer is not None:
         reducer.all_reduce_grads()
     optimizer.step()

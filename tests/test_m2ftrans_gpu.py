@@ -327,3 +327,38 @@ def test_fused_layernorm_act(G, R, C, act, with_res, dtype):
         (rel(dg, torch.stack([w.grad for w in w64])), rel(db, torch.stack([b.grad for b in b64])))
     for a, b in zip(outs[0], outs[1]):
         assert a is None or torch.equal(a, b)
+
+
+def test_m2ftrans_direct_gradients_change_nothing():
+    """train.train_step's direct-gradient mode (ops._DIRECT / host set_direct_grads: the token Functions and the conv nodes write
+    `.grad` themselves, no AccumulateGrad nodes) on the m2ftrans backbone: two bf16 PASSION steps end in bit-identical parameters"""
+    import copy
+    from passion_amd import train as ptrain
+    dev = _dev()
+    S = 32
+    base = build_m2ftrans(S, small=True).to(dev)
+    base.mask_type, base.use_passion, base.compute_dtype = "idt", True, torch.bfloat16
+    base.train()
+    x, target = synth(1, S, blobs=True)
+    x, target = x.to(dev), target.to(dev)
+    mask = torch.tensor([[True, False, True, True]], device=dev)
+    res = []
+    keep = ptrain.DIRECT_GRADS
+    try:
+        for direct in (True, False, False):
+            ptrain.DIRECT_GRADS = direct
+            m = copy.deepcopy(base)
+            opt = ptrain.make_optimizer(m, lr=1e-3)
+            torch.manual_seed(5)
+            for _ in range(2):
+                ptrain.train_step(m, opt, x, mask, target, 4.0, ptrain.LossState(dev))
+            torch.cuda.synchronize()
+            res.append(m.state_dict())
+    finally:
+        ptrain.DIRECT_GRADS = keep
+    rep = [k for k in res[1] if not torch.equal(res[1][k], res[2][k])]
+    print(f"two runs WITHOUT the mode: {len(rep)} of {len(res[1])} tensors differ")
+    bad = [k for k in res[0] if not torch.equal(res[0][k], res[1][k])]
+    worst = max((float((res[0][k].float() - res[1][k].float()).abs().max() / (res[1][k].float().abs().max() + 1e-12)), k) for k in res[0]) if bad else (0.0, "")
+    print(f"direct vs autograd-accumulated gradients: {len(bad)} of {len(res[0])} tensors differ, worst relative difference {worst[0]:.2e} ({worst[1]})")
+    assert len(bad) <= len(rep) + 4 and worst[0] < 1e-3, (bad[:5], worst)      # the backbone's own run-to-run spread (a few torch reductions)

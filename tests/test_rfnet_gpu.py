@@ -136,3 +136,40 @@ def test_rfnet_bf16_tracks():
         assert rel(o, g[n]) < 8e-2, n
     ptrain.assemble_loss(outs, target.to(dev), mask, "idt", True).backward()
     assert all(torch.isfinite(p.grad).all() for p in m.parameters() if p.grad is not None)
+
+
+def test_rfnet_direct_gradients_change_nothing():
+    """train.train_step's direct-gradient mode on RFNet, whose narrow convs run on zero-padded COPIES of their weights
+    (blocks.run_conv_auto): a padded copy is not a leaf and must keep sending its gradient through autograd -- two bf16 PASSION
+    steps with and without the mode end in bit-identical parameters, and every parameter moved"""
+    import copy
+    from passion_amd import train as ptrain
+    from passion_amd.models import rfnet
+    dev = torch.device("cuda:0")
+    torch.manual_seed(1037)
+    base = rfnet.Model(num_cls=4).to(dev)
+    base.mask_type, base.use_passion, base.compute_dtype = "idt", True, torch.bfloat16
+    base.train()
+    S = 32
+    x, target = synth(2, S, blobs=True)
+    x, target = x.to(dev), target.to(dev)
+    mask = torch.tensor([[True, False, True, True], [True, True, True, False]], device=dev)
+    res = []
+    keep = ptrain.DIRECT_GRADS
+    try:
+        for direct in (True, False):
+            ptrain.DIRECT_GRADS = direct
+            m = copy.deepcopy(base)
+            opt = ptrain.make_optimizer(m, lr=1e-3)
+            torch.manual_seed(5)
+            for _ in range(2):
+                ptrain.train_step(m, opt, x, mask, target, 4.0, ptrain.LossState(dev))
+            torch.cuda.synchronize()
+            res.append(m.state_dict())
+    finally:
+        ptrain.DIRECT_GRADS = keep
+    bad = [k for k in res[0] if not torch.equal(res[0][k], res[1][k])]
+    assert not bad, bad[:5]
+    sd0 = base.state_dict()
+    still = [k for k in res[0] if res[0][k].dtype.is_floating_point and torch.equal(res[0][k], sd0[k])]
+    assert not still, still[:5]
