@@ -26,7 +26,7 @@ import torch.nn.functional as F
 from .. import _lib as L
 from .. import ops
 from ..utils import criterions as crit
-from .blocks import Feat, fusion_prenorm, general_conv3d_prenorm, run_conv, run_pointwise
+from .blocks import Feat, _ln, _ln_ok, fusion_prenorm, general_conv3d_prenorm, run_conv, run_pointwise
 
 basic_dims = 8
 transformer_basic_dims = 512
@@ -174,6 +174,8 @@ def intra_grouped(model, x5, mask, B, bf16):
     training = trs[0].training
 
     def gnorm(mods, t):
+        if _ln_ok(t):
+            return ops.ln_act(t, mods)               # one launch, four affine sets (csrc/token_ops.hip)
         n = F.layer_norm(t, (C,), None, None, mods[0].eps)
         return torch.addcmul(_gstack([m.bias for m in mods]).unsqueeze(1), n, _gstack([m.weight for m in mods]).unsqueeze(1))
 
@@ -329,7 +331,7 @@ class PreNorm(nn.Module):
         self.fn = fn
 
     def forward(self, x):
-        return self.fn(self.norm(x))
+        return self.fn(_ln(self.norm, x))
 
 
 class PreNormDrop(nn.Module):
@@ -340,7 +342,7 @@ class PreNormDrop(nn.Module):
         self.fn = fn
 
     def forward(self, x):
-        return self.dropout(self.fn(self.norm(x)))
+        return self.dropout(self.fn(_ln(self.norm, x)))
 
 
 class GELU(nn.Module):
