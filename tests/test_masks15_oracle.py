@@ -1,0 +1,47 @@
+"""CPU: the three oracle networks in INFERENCE mode over all 15 modality subsets (reference predict.py:14-19 evaluates exactly
+these masks) against tests/golden/masks15.npz, produced by the imported reference (tools/make_golden_masks.py)."""
+import numpy as np
+import pytest
+import torch
+
+from _util import gold, rel, small_weights, synth
+from oracle import m2ftrans_ref, mmformer_ref, rfnet_ref
+from test_m2ftrans_oracle import m2f_weights
+from test_rfnet_oracle import rfnet_weights
+
+NETS = {"mmformer": (mmformer_ref, small_weights), "rfnet": (rfnet_ref, rfnet_weights), "m2ftrans": (m2ftrans_ref, m2f_weights)}
+
+
+def check_sweep(g, name, pred, tol, rows=None):
+    """pred: (n, 4, S, S, S) probabilities for the fixture's masks `rows` (all 15 by default)"""
+    S = int(g["S"])
+    rows = list(range(15)) if rows is None else rows
+    pred = pred.detach().float().cpu()
+    assert rel(pred[:, :, S // 2], g[name + "_pred_slice"][rows]) < tol
+    assert rel(pred.double().sum((2, 3, 4)), g[name + "_pred_sum"][rows]) < tol
+    am = pred.argmax(1).numpy().astype(np.uint8)
+    for i, r in enumerate(rows):
+        diff = am[i] != g[name + "_argmax"][r]
+        tie = np.unpackbits(g[name + "_tie"][r]).astype(bool).reshape(S, S, S)
+        assert not (diff & ~tie).any(), (name, r, int((diff & ~tie).sum()))     # flips only where the reference's margin is < 1e-3
+        assert diff.sum() <= max(4, tie.sum() // 4), (name, r, int(diff.sum()))
+
+
+def test_fixture_masks_are_the_fifteen_subsets():
+    g = gold("masks15.npz")
+    m = g["masks"]
+    assert m.shape == (15, 4) and len({tuple(r) for r in m.tolist()}) == 15 and m.any(1).all()
+
+
+@pytest.mark.parametrize("name", list(NETS))
+def test_oracle_inference_over_all_masks(name):
+    g = gold("masks15.npz")
+    S = int(g["S"])
+    ref, weights = NETS[name]
+    x, _ = synth(1, S, blobs=False)
+    mask = torch.from_numpy(g["masks"])
+    W = weights()
+    with torch.no_grad():                                   # one subset per call, as the fixture was made (a batch of 15 takes other
+        pred = torch.cat([ref.forward(W, x, mask[i:i + 1]) for i in range(15)])      # f32 GEMM paths: 4.5e-5 on m2ftrans)
+    assert pred.shape == (15, 4, S, S, S)
+    check_sweep(g, name, pred, 2e-5)

@@ -1,0 +1,78 @@
+#!/usr/bin/env python
+"""Golden fixture of the INFERENCE path over all 15 modality subsets (the "erasure" cases of this domain: reference
+predict.py:14-19 evaluates every checkpoint on exactly these masks) from the IMPORTED reference (/root/reference/code, build
+container only; same shims and builders as tools/make_golden.py / make_golden_m2f.py: small-constants mmformer / m2ftrans and the
+full RFNet with float16-representable weights, identical to the committed weights_small / weights_m2f / weights_rfnet fixtures --
+asserted below).  model.is_training = False, model.eval(), torch.no_grad(): forward returns the fused prediction only.
+
+    python tools/make_golden_masks.py      -> tests/golden/masks15.npz
+
+Per model: argmax (15, S, S, S) uint8, the mid-depth slice of the probabilities (15, 4, S, S), their per-class sums (15, 4) and
+`tie` (15, S^3 / 8 packed bits): voxels whose top-2 margin is below 1e-3 in the reference, where an argmax may legitimately flip."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import make_golden as mg  # noqa: E402
+
+S = 32
+MASKS = [[bool(k >> (3 - i) & 1) for i in range(4)] for k in range(1, 16)]      # 0001 .. 1111 over (flair, t1ce, t1, t2)
+
+
+def same_as_fixture(model, name):
+    w = np.load(os.path.join(mg.OUT, name))
+    sd = model.state_dict()
+    assert set(w.files) == set(sd.keys()), name
+    for k in w.files:
+        assert np.array_equal(w[k].astype(np.float32), sd[k].numpy()), (name, k)
+
+
+def sweep(model, x):
+    model.is_training = False
+    model.eval()
+    am, sl, sm, tie = [], [], [], []
+    with torch.no_grad():
+        for mk in MASKS:
+            pred = model(x, torch.tensor([mk]))
+            assert pred.shape == (1, 4, S, S, S)
+            am.append(pred.argmax(1)[0].numpy().astype(np.uint8))
+            sl.append(pred[0, :, S // 2].numpy())
+            sm.append(pred[0].double().sum((1, 2, 3)).numpy())
+            top2 = pred[0].topk(2, dim=0).values
+            tie.append(np.packbits(((top2[0] - top2[1]) < 1e-3).numpy().reshape(-1)))
+    return {"argmax": np.stack(am), "pred_slice": np.stack(sl), "pred_sum": np.stack(sm), "tie": np.stack(tie)}
+
+
+def main():
+    torch.set_num_threads(8)
+    mmformer, _ = mg.import_reference()
+    from models import m2ftrans, rfnet
+    import make_golden_m2f as m2g
+    x, _ = mg.synth(1, S, blobs=False)
+    out = {"S": np.array(S), "masks": np.array(MASKS)}
+    m = mg.build(mmformer, S, True)
+    same_as_fixture(m, "weights_small.npz")
+    for k, v in sweep(m, x).items():
+        out["mmformer_" + k] = v
+    torch.manual_seed(1037)
+    r = rfnet.Model(num_cls=4)
+    with torch.no_grad():
+        for p_ in r.parameters():
+            p_.copy_(p_.half().float())
+    same_as_fixture(r, "weights_rfnet.npz")
+    for k, v in sweep(r, x).items():
+        out["rfnet_" + k] = v
+    f = m2g.build(m2ftrans, S)
+    same_as_fixture(f, "weights_m2f.npz")
+    for k, v in sweep(f, x).items():
+        out["m2ftrans_" + k] = v
+    np.savez_compressed(os.path.join(mg.OUT, "masks15.npz"), **out)
+    for name in ("mmformer", "rfnet", "m2ftrans"):
+        print(name, "ties per mask:", [int(np.unpackbits(t).sum()) for t in out[name + "_tie"]])
+
+
+if __name__ == "__main__":
+    main()
