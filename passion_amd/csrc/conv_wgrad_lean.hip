@@ -395,8 +395,16 @@ __global__ __launch_bounds__(256) void wgrad_lean_kernel(ConvK p, float* __restr
 // kernel spent 136 us per launch on it.  Here a thread owns voxels, keeps the 9 x 8 partial sums of one depth tap (+ 8 bias sums) in
 // registers as channel pairs (v_pk_fma_f32: two channels per instruction), and the workgroup folds them once at the end
 // into its slot of the partial slab ([co][tap] | dbias, the same layout the other wgrad kernels fill).
-__global__ __launch_bounds__(256) void wgrad_c1_kernel(ConvK p, float* __restrict__ dW, float* __restrict__ dbias) {
+__global__ __launch_bounds__(256) void wgrad_c1_kernel(ConvK p, float* __restrict__ dW, float* __restrict__ dbias, int nact) {
     wgrad_clear(p);
+    // the slab has gridDim.x slots (the fold's contract); only the first `nact` workgroups of a row sum voxels, the others flush a
+    // zero slot: with one workgroup per slot a thread owned < 3 voxels and the launch was all prologue + LDS fold (69 us for 38 MB)
+    if ((int)blockIdx.x >= nact) {
+        const int t = threadIdx.x, td0 = blockIdx.y;
+        if (dW && t < 72) dW[(long)blockIdx.x * p.wslot + (t % 8) * 27 + td0 * 9 + t / 8] = 0.f;
+        if (dbias && td0 == 0 && t < 8) dbias[(long)blockIdx.x * p.wslot + t] = 0.f;
+        return;
+    }
     typedef float f32x2 __attribute__((ext_vector_type(2)));
     __shared__ float red[256 * 33];
     __shared__ float red2[8][32];
@@ -419,22 +427,15 @@ __global__ __launch_bounds__(256) void wgrad_c1_kernel(ConvK p, float* __restric
     // Software pipeline: the 9 neighbour loads + the dY vector of the next two voxels are issued before the packed FMAs
     // of the current two.
     struct Vox { unsigned short x[9]; uint4 dy; unsigned okbits; };
-    auto fetch = [&](unsigned i, Vox& o) {
-        o.okbits = 0u;
-        o.dy = make_uint4(0u, 0u, 0u, 0u);
-#pragma unroll
-        for (int t = 0; t < 9; ++t) o.x[t] = 0;
-        if (i >= total) return;
-        unsigned b, v, w, h, d;
-        if (pow2) { b = i >> lv; v = i & (V - 1); w = v & (W - 1); h = (v >> lw) & (H - 1); d = v >> (lw + lh); }
-        else { b = i / V; v = i - b * V; const unsigned r = v / W; w = v - r * W; d = r / H; h = r - d * H; }
-        o.dy = *reinterpret_cast<const uint4*>(dy + (long)i * 8);
-        const bool present = !sd.mask || sd.mask[(long)b * sd.mask_ld + sd.mask_col];      // absent modality: its input is zero
-        const unsigned short* xb = reinterpret_cast<const unsigned short*>(sd.x) + (long)sd.bsrc((int)b) * sd.bstride;
-        int cd = (int)d + td - 1;
-        const bool okd = reflect || (cd >= 0 && cd < D);
-        cd = cd < 0 ? -cd : (cd >= D ? 2 * D - 2 - cd : cd);
-        cd = min(max(cd, 0), D - 1);
+    // A thread's voxels are `stride` apart.  When that is a whole number of planes (the 128^3 / 64^3 volumes: 256 workgroups x 256
+    // threads = 4 / 16 planes) its (h, w) never changes: the reflected in-plane offsets and their validity bits are computed ONCE
+    // (per voxel they were ~120 of the ~200 VALU instructions of a voxel-tap; the kernel is VALU-bound, not byte-bound)
+    const unsigned HW = (unsigned)H * W;
+    const unsigned stride = (unsigned)nact * 256u;
+    const bool fixed_hw = stride % HW == 0u;
+    int off9[9];
+    unsigned okhw = 0u;
+    auto hw_setup = [&](unsigned h, unsigned w) {
         int ih[3], iw[3];
         unsigned okh = 0, okw = 0;
 #pragma unroll
@@ -446,15 +447,43 @@ __global__ __launch_bounds__(256) void wgrad_c1_kernel(ConvK p, float* __restric
             cw = cw < 0 ? -cw : (cw >= W ? 2 * W - 2 - cw : cw);
             ih[t] = min(max(ch, 0), H - 1); iw[t] = min(max(cw, 0), W - 1);
         }
+        okhw = 0u;
 #pragma unroll
-        for (int th = 0; th < 3; ++th) {
-            const unsigned short* row = xb + ((long)cd * H + ih[th]) * W;
+        for (int th = 0; th < 3; ++th)
 #pragma unroll
             for (int tw = 0; tw < 3; ++tw) {
-                o.x[th * 3 + tw] = row[iw[tw]];
-                if (present && okd && ((okh >> th) & (okw >> tw) & 1u)) o.okbits |= 1u << (th * 3 + tw);
+                off9[th * 3 + tw] = ih[th] * W + iw[tw];
+                if ((okh >> th) & (okw >> tw) & 1u) okhw |= 1u << (th * 3 + tw);
             }
+    };
+    {
+        const unsigned v0 = (blockIdx.x * 256u + tid) % HW;
+        hw_setup(v0 / (unsigned)W, v0 % (unsigned)W);
+    }
+    auto fetch = [&](unsigned i, Vox& o) {
+        o.okbits = 0u;
+        o.dy = make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+        for (int t = 0; t < 9; ++t) o.x[t] = 0;
+        if (i >= total) return;
+        unsigned b, d;
+        if (pow2) { b = i >> lv; d = (i >> (lw + lh)) & (unsigned)(D - 1); }
+        else { b = i / V; d = (i - b * V) / HW; }
+        if (!fixed_hw) {
+            const unsigned r = (i - b * V) - d * HW;
+            hw_setup(r / (unsigned)W, r % (unsigned)W);
         }
+        o.dy = *reinterpret_cast<const uint4*>(dy + (long)i * 8);
+        const bool present = !sd.mask || sd.mask[(long)b * sd.mask_ld + sd.mask_col];      // absent modality: its input is zero
+        const unsigned short* xb = reinterpret_cast<const unsigned short*>(sd.x) + (long)sd.bsrc((int)b) * sd.bstride;
+        int cd = (int)d + td - 1;
+        const bool okd = reflect || (cd >= 0 && cd < D);
+        cd = cd < 0 ? -cd : (cd >= D ? 2 * D - 2 - cd : cd);
+        cd = min(max(cd, 0), D - 1);
+        const unsigned short* pl = xb + (long)cd * HW;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) o.x[t] = pl[off9[t]];
+        if (present && okd) o.okbits = okhw;
     };
     auto accumulate = [&](const Vox& q) {
         const unsigned dw[4] = {q.dy.x, q.dy.y, q.dy.z, q.dy.w};
@@ -473,9 +502,8 @@ __global__ __launch_bounds__(256) void wgrad_c1_kernel(ConvK p, float* __restric
             for (int c = 0; c < 4; ++c) acc[t][c] = __builtin_elementwise_fma(x2, dy2[c], acc[t][c]);
         }
     };
-    const unsigned stride = gridDim.x * 256u;
     unsigned i = blockIdx.x * 256u + tid;
-    Vox n0, n1;
+    Vox n0, n1;                            // (four voxels in flight with unconditional loads: 220 registers, two waves per SIMD, 65 us)
     fetch(i, n0);
     fetch(i + stride, n1);
     for (; i < total; i += 2 * stride) {
@@ -563,7 +591,9 @@ int launch_wgrad_c1(ConvK& k, int ksize, int stride, int gx, int gy, float* dW, 
     if (ksize != 3 || stride != 1 || k.nseg != 1 || k.Cin != 1 || k.seg[0].C != 1 || k.Cout != 8 || k.seg[0].stats || gy != 1 || k.y_f32) return 1;
     if ((long)k.B * k.Di * k.Hi * k.Wi >= (1L << 31)) return 1;
     passion_prof_tag("wgrad_c1_kernel");
-    hipLaunchKernelGGL(wgrad_c1_kernel, dim3(gx, 3), dim3(256), 0, st, k, dW, db);
+    static const int act_env = getenv("PASSION_C1_ACT") ? atoi(getenv("PASSION_C1_ACT")) : 256;
+    const int nact = act_env > 0 && act_env < gx ? act_env : gx;
+    hipLaunchKernelGGL(wgrad_c1_kernel, dim3(gx, 3), dim3(256), 0, st, k, dW, db, nact);
     LAUNCH_RET();
     return 0;
 }

@@ -937,6 +937,49 @@ def test_wgrad_march_equals_lean_kernel_sums():
 
 
 @pytest.mark.parametrize("pad_mode", [1, 0], ids=["reflect", "zeros"])
+@pytest.mark.parametrize("B,shape", [(2, (32, 32, 64)), (1, (5, 32, 16)), (3, (20, 16, 32))])
+def test_first_layer_weight_gradient(B, shape, pad_mode):
+    """wgrad_c1_kernel (conv_wgrad_lean.hip: one raw input channel, 8 outputs, bf16) against autograd in float64 on the same
+    bf16-rounded operands; the first case has more slab slots (512 bricks) than summing workgroups (256): the spare slots must
+    be flushed with zeros; a masked sample contributes nothing to dW but its dY still counts in the bias gradient"""
+    from passion_amd import ops
+    dev = _dev()
+    D, H, W = shape
+    g = torch.Generator().manual_seed(21)
+    x = (torch.randn(B, D, H, W, 1, generator=g) * 1.3 + 0.2).to(torch.bfloat16)
+    w = torch.randn(8, 1, 3, 3, 3, generator=g) / 4
+    b = torch.randn(8, generator=g)
+    mask = torch.ones(B, 1, dtype=torch.bool)
+    if B > 1:
+        mask[1, 0] = False
+    gy = torch.randn(B, D, H, W, 8, generator=g).to(torch.bfloat16)
+    wr = w.to(torch.bfloat16).double().requires_grad_(True)
+    br = b.double().requires_grad_(True)
+    xm = (x.double() * mask.view(-1, 1, 1, 1, 1)).permute(0, 4, 1, 2, 3)
+    yr = F.conv3d(F.pad(xm, (1,) * 6, mode="reflect" if pad_mode == 1 else "constant"), wr, br)
+    yr.backward(gy.double().permute(0, 4, 1, 2, 3))
+    ops.prof_read()
+    ops.prof_enable(15)
+    try:
+        wd, bd = w.to(dev).requires_grad_(True), b.to(dev).requires_grad_(True)
+        y = ops.conv_block([ops.SegIn(x.to(dev), mask=mask.to(dev), mask_col=0)], wd, bd, D, H, W, ksize=3, stride=1, pad_mode=pad_mode)
+        y.backward(gy.to(dev))
+        torch.cuda.synchronize()
+    finally:
+        ops.prof_enable(0)
+    names = [r[4] for r in ops.prof_read()]
+    assert "wgrad_c1_kernel" in names, names
+    assert relerr(wd.grad, wr.grad) < 1e-5
+    assert relerr(bd.grad, br.grad) < 1e-5
+    first = wd.grad.clone()
+    wd.grad = None
+    bd.grad = None
+    y = ops.conv_block([ops.SegIn(x.to(dev), mask=mask.to(dev), mask_col=0)], wd, bd, D, H, W, ksize=3, stride=1, pad_mode=pad_mode)
+    y.backward(gy.to(dev))
+    assert torch.equal(first, wd.grad)                     # fixed-order fold: bit-reproducible
+
+
+@pytest.mark.parametrize("pad_mode", [1, 0], ids=["reflect", "zeros"])
 @pytest.mark.parametrize("shape", [(20, 16, 32), (5, 32, 16)])
 def test_first_layer_forward_kernel(shape, pad_mode):
     """conv_c1_fwd.hip (one raw input channel -> 8, bf16): against the f64 reference, against the general kernel, statistics of
