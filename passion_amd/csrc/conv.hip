@@ -273,33 +273,50 @@ struct FoldJob {
     int R, G, main_x;              // main_x == 0: no job, the whole grid is the finish kernel's; else the finish kernel's share of x
     int fold_x;                    // blocks x >= main_x fold (fold blocks FIRST in every row was measured: 3 us slower per finish launch)
 };
-__device__ __forceinline__ void fold_block(const FoldJob& fj, long id) {
-    __shared__ float red[16][17];
-    const long nb16 = (fj.n + 15) / 16;
-    if (id >= nb16 * fj.G) return;                 // block-uniform
-    const int g = (int)(id / nb16);
-    const int li = threadIdx.x & 15, sl = threadIdx.x >> 4;
-    const long i = (id % nb16) * 16 + li;
-    const float* pg = fj.part + (long)g * fj.R * fj.stride;
+// Values per block of a fold over R slots: 16 slices x 16 values for the long folds of small weights (1024 slots x 1.7 K values at the
+// fine levels), whole rows of values for the short folds of big weights (level 5: 8 slots x 442 K values took 27 K blocks with 16
+// loading lanes each -- 65 us for a 14 MB slab).  The order of the adds is a function of R alone.
+__host__ __device__ inline int fold_vpb(int R) { return R >= 64 ? 16 : (R >= 16 ? 64 : 256); }
+__host__ __device__ inline long fold_nblocks(long n, int R) { const int v = fold_vpb(R); return (n + v - 1) / v; }
+
+// one block's share of the fold: value i = sum over the slots, slices of the slot axis over the thread groups
+__device__ __forceinline__ float fold_value(const float* __restrict__ pg, long stride, int R, long n, long blk, long& i_out, bool& owner) {
+    __shared__ float red[256 + 16];
+    const int vpb = fold_vpb(R), nsl = 256 / vpb;
+    const int li = threadIdx.x % vpb, sl = threadIdx.x / vpb;
+    const long i = blk * vpb + li;
     float a = 0.f;
-    if (i < fj.n) {                                // four loads in flight per thread; the order of the adds is fixed all the same
+    if (i < n) {                                   // four loads in flight per thread; the order of the adds is fixed all the same
         float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
         int r = sl;
-        for (; r + 48 < fj.R; r += 64) {
-            a0 += pg[(long)r * fj.stride + i];
-            a1 += pg[(long)(r + 16) * fj.stride + i];
-            a2 += pg[(long)(r + 32) * fj.stride + i];
-            a3 += pg[(long)(r + 48) * fj.stride + i];
+        for (; r + 3 * nsl < R; r += 4 * nsl) {
+            a0 += pg[(long)r * stride + i];
+            a1 += pg[(long)(r + nsl) * stride + i];
+            a2 += pg[(long)(r + 2 * nsl) * stride + i];
+            a3 += pg[(long)(r + 3 * nsl) * stride + i];
         }
-        for (; r < fj.R; r += 16) a0 += pg[(long)r * fj.stride + i];
+        for (; r < R; r += nsl) a0 += pg[(long)r * stride + i];
         a = (a0 + a1) + (a2 + a3);
     }
-    red[sl][li] = a;
+    i_out = i;
+    owner = sl == 0 && i < n;
+    if (nsl == 1) return a;                        // block-uniform
+    red[sl * (vpb + 1) + li] = a;
     __syncthreads();
-    if (sl == 0 && i < fj.n) {
-        float t = 0.f;
-#pragma unroll
-        for (int k2 = 0; k2 < 16; ++k2) t += red[k2][li];
+    float t = 0.f;
+    if (owner)
+        for (int k2 = 0; k2 < nsl; ++k2) t += red[k2 * (vpb + 1) + li];
+    return t;
+}
+
+__device__ __forceinline__ void fold_block(const FoldJob& fj, long id) {
+    const long nb = fold_nblocks(fj.n, fj.R);
+    if (id >= nb * fj.G) return;                   // block-uniform
+    const int g = (int)(id / nb);
+    long i;
+    bool owner;
+    const float t = fold_value(fj.part + (long)g * fj.R * fj.stride, fj.stride, fj.R, fj.n, id % nb, i, owner);
+    if (owner) {
         float* o = fj.out[0];
 #pragma unroll
         for (int g2 = 1; g2 < PASSION_MAX_GROUPS; ++g2) if (g == g2) o = fj.out[g2];
@@ -587,21 +604,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(ConvK p, float* __restr
 __global__ __launch_bounds__(256) void reduce_parts_kernel(const float* __restrict__ part, int R, long n, long stride,
                                                            float* __restrict__ out, float* __restrict__ zero_ptr = nullptr,
                                                            long zero_n = 0) {
-    __shared__ float red[16][17];
     for (long z = (long)blockIdx.x * 256 + threadIdx.x; z < zero_n; z += (long)gridDim.x * 256) zero_ptr[z] = 0.f;
-    const int li = threadIdx.x & 15, sl = threadIdx.x >> 4;
-    const long i = (long)blockIdx.x * 16 + li;
-    float a = 0.f;
-    if (i < n)
-        for (int r = sl; r < R; r += 16) a += part[(long)r * stride + i];
-    red[sl][li] = a;
-    __syncthreads();
-    if (sl == 0 && i < n) {
-        float t = 0.f;
-#pragma unroll
-        for (int k2 = 0; k2 < 16; ++k2) t += red[k2][li];
-        out[i] = t;
-    }
+    long i;
+    bool owner;
+    const float t = fold_value(part, stride, R, n, blockIdx.x, i, owner);      // grid = fold_nblocks(n, R)
+    if (owner) out[i] = t;
 }
 
 // The same fold for a grouped launch (blockIdx.y = weight set): group g's slots are the Rg consecutive ones from g * Rg on, its
@@ -609,23 +616,12 @@ __global__ __launch_bounds__(256) void reduce_parts_kernel(const float* __restri
 struct RedOuts { float* p[PASSION_MAX_GROUPS]; };
 __global__ __launch_bounds__(256) void reduce_parts_grouped_kernel(const float* __restrict__ part, int Rg, long n, long stride, RedOuts outs,
                                                                    float* __restrict__ zero_ptr = nullptr, long zero_n = 0) {
-    __shared__ float red[16][17];
     if (blockIdx.y == 0)
         for (long z = (long)blockIdx.x * 256 + threadIdx.x; z < zero_n; z += (long)gridDim.x * 256) zero_ptr[z] = 0.f;
-    const int li = threadIdx.x & 15, sl = threadIdx.x >> 4;
-    const long i = (long)blockIdx.x * 16 + li;
-    const float* pg = part + (long)blockIdx.y * Rg * stride;
-    float a = 0.f;
-    if (i < n)
-        for (int r = sl; r < Rg; r += 16) a += pg[(long)r * stride + i];
-    red[sl][li] = a;
-    __syncthreads();
-    if (sl == 0 && i < n) {
-        float t = 0.f;
-#pragma unroll
-        for (int k2 = 0; k2 < 16; ++k2) t += red[k2][li];
-        outs.p[blockIdx.y][i] = t;
-    }
+    long i;
+    bool owner;
+    const float t = fold_value(part + (long)blockIdx.y * Rg * stride, stride, Rg, n, blockIdx.x, i, owner);
+    if (owner) outs.p[blockIdx.y][i] = t;
 }
 
 // weight [Cout][Cin][ntap] -> fwd image [tap][Cin][CoutPad] and dgrad image [tap][Cout][CinPad]
@@ -1184,25 +1180,25 @@ static int conv3d_bwd_impl(const passion_conv_desc_t* d, const float* packed, co
             const int wgs_per_b = (tiles_per_b + k.per - 1) / k.per;
             RedOuts ro;
             for (int g = 0; g < PASSION_MAX_GROUPS; ++g) ro.p[g] = g < ga->G ? ga->dW[g] : nullptr;
-            hipLaunchKernelGGL(reduce_parts_grouped_kernel, dim3((unsigned)((k.wslot + 15) / 16), ga->G), dim3(256), 0, st, wslab,
+            hipLaunchKernelGGL(reduce_parts_grouped_kernel, dim3((unsigned)fold_nblocks(k.wslot, k.bgroup * wgs_per_b), ga->G), dim3(256), 0, st, wslab,
                                k.bgroup * wgs_per_b, k.wslot, k.wslot, ro, zsums, zn);
             LAUNCH_RET();
             sums_cleared = zsums != nullptr;
         } else
         if (dweight && dbias == dweight + nW) {      // caller keeps [dW | dbias] in one buffer: one fold for both
-            hipLaunchKernelGGL(reduce_parts_kernel, dim3((unsigned)((k.wslot + 15) / 16)), dim3(256), 0, st, wslab, w.gx, k.wslot,
+            hipLaunchKernelGGL(reduce_parts_kernel, dim3((unsigned)fold_nblocks(k.wslot, w.gx)), dim3(256), 0, st, wslab, w.gx, k.wslot,
                                k.wslot, dweight, zsums, zn);
             LAUNCH_RET();
             sums_cleared = zsums != nullptr;
         } else {
             if (dweight) {
-                hipLaunchKernelGGL(reduce_parts_kernel, dim3((unsigned)((nW + 15) / 16)), dim3(256), 0, st, wslab, w.gx, nW, k.wslot, dweight,
+                hipLaunchKernelGGL(reduce_parts_kernel, dim3((unsigned)fold_nblocks(nW, w.gx)), dim3(256), 0, st, wslab, w.gx, nW, k.wslot, dweight,
                                    zsums, zn);
                 LAUNCH_RET();
                 sums_cleared = zsums != nullptr;
             }
             if (dbias) {
-                hipLaunchKernelGGL(reduce_parts_kernel, dim3((k.Cout + 15) / 16), dim3(256), 0, st, bslab, w.gx, (long)k.Cout, k.wslot, dbias);
+                hipLaunchKernelGGL(reduce_parts_kernel, dim3((unsigned)fold_nblocks(k.Cout, w.gx)), dim3(256), 0, st, bslab, w.gx, (long)k.Cout, k.wslot, dbias);
                 LAUNCH_RET();
             }
         }
@@ -1354,7 +1350,7 @@ static int conv3d_bwd_impl(const passion_conv_desc_t* d, const float* packed, co
     if (k.sums_fixed && phase == 0) rep = -rep;          // fixed-point replicas: folded (exactly) by the finish kernels
     if (phase != 2 && need_norm && rep > 0 && (rep > SUMS_REP_LEAN || phase == 1)) {          // many replicas: fold them first (in place, replica 0)
         const int nw = 2 * k.B * k.Cin;
-        hipLaunchKernelGGL(reduce_parts_kernel, dim3((nw + 15) / 16), dim3(256), 0, st, sums, k.sums_rep, (long)nw, (long)nw, sums);
+        hipLaunchKernelGGL(reduce_parts_kernel, dim3((unsigned)fold_nblocks(nw, k.sums_rep)), dim3(256), 0, st, sums, k.sums_rep, (long)nw, (long)nw, sums);
         LAUNCH_RET();
         rep = 1;
     }
@@ -1376,7 +1372,7 @@ static int conv3d_bwd_impl(const passion_conv_desc_t* d, const float* packed, co
         void* out = sum_passes ? real_dx[s] : sg.dx;
         FoldJob fjl = fj;                             // the pending fold goes with the first finish launch
         fjl.main_x = 0; fjl.fold_x = 0;
-        const long fold_blocks = defer_fold ? ((fj.n + 15) / 16) * fj.G : 0;
+        const long fold_blocks = defer_fold ? fold_nblocks(fj.n, fj.R) * fj.G : 0;
         if (padout) {
             const int rowv = k.Wi * sg.C / (v8 ? 8 : 4);
             const int rpb = 256 / (rowv < 256 ? rowv : 256);
@@ -1407,7 +1403,7 @@ static int conv3d_bwd_impl(const passion_conv_desc_t* d, const float* packed, co
     if (defer_fold) {                                 // no finish kernel ran (raw input, no padded domain): the fold on its own
         RedOuts ro;
         for (int g = 0; g < PASSION_MAX_GROUPS; ++g) ro.p[g] = fj.out[g];
-        hipLaunchKernelGGL(reduce_parts_grouped_kernel, dim3((unsigned)((fj.n + 15) / 16), fj.G), dim3(256), 0, st, fj.part, fj.R, fj.n, fj.stride, ro,
+        hipLaunchKernelGGL(reduce_parts_grouped_kernel, dim3((unsigned)fold_nblocks(fj.n, fj.R), fj.G), dim3(256), 0, st, fj.part, fj.R, fj.n, fj.stride, ro,
                            (float*)nullptr, 0L);
         LAUNCH_RET();
     }
