@@ -1074,7 +1074,8 @@ def f32_stack(params):
     ver = tuple((p.data_ptr(), p._version) for p in params)
     ent = _F32_STACKS.get(key)
     if ent is None or ent[1] != ver or ent[0].device != params[0].device:
-        buf = ent[0] if ent is not None and ent[0].device == params[0].device else None
+        want = (len(params), *params[0].shape)             # ids are reused once a model is gone: the old buffer may have another shape
+        buf = ent[0] if ent is not None and ent[0].device == params[0].device and tuple(ent[0].shape) == want else None
         buf = torch.stack([p.detach() for p in params], out=buf) if buf is not None else torch.stack([p.detach() for p in params])
         ent = _F32_STACKS[key] = (buf, ver)
     return ent[0]
