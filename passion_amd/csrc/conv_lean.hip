@@ -57,7 +57,7 @@ struct alignas(16) EpiDesc {     // dgrad epilogue: the four output rows (= forw
     float mean[4], rstd[4];
 };
 static_assert(sizeof(EpiDesc) == 64, "EpiDesc layout");
-constexpr int MAXBLK = 32;       // K <= 256 channels
+constexpr int MAXBLK = 64;       // K <= 512 channels in 32-channel chunks (the chunk mask has 32 bits: 8-channel chunks stop at 256)
 constexpr int DESC_BYTES = MAXBLK * (int)sizeof(BlkDesc);
 
 // Values that are the same in every lane but arrive through LDS or per-thread arithmetic look divergent to the compiler:
@@ -839,13 +839,14 @@ namespace pconv {
 // returns 0 = launched, < 0 = HIP error, 1 = shape not covered (caller falls back to the general kernel)
 bool lean_covers(const ConvK& k, int stride, bool dgrad) {
     if (stride != 1 && !(stride == 2 && dgrad)) return false;     // stride 2: only the padded-domain dgrad (mode 2)
-    if (dgrad) return (k.Cout % 8 == 0 || k.y_f32) && (k.Cout + 7) / 8 <= MAXBLK;
-    int K8 = 0;
+    if (dgrad) return (k.Cout % 8 == 0 || k.y_f32) && (k.Cout + 7) / 8 <= (k.Cout >= 32 ? MAXBLK : 32);
+    int K8 = 0, cmax = 0;
     for (int s = 0; s < k.nseg; ++s) {
         if (k.seg[s].C % 8) return false;
         K8 += k.seg[s].C / 8;
+        cmax = k.seg[s].C > cmax ? k.seg[s].C : cmax;
     }
-    return K8 * 8 == k.Cin && K8 <= MAXBLK;
+    return K8 * 8 == k.Cin && K8 <= (cmax >= 32 ? MAXBLK : 32);
 }
 
 int launch_conv_lean(ConvK& k, int ksize, int stride, int mode, const void* packed_bf16, hipStream_t st) {
@@ -876,7 +877,7 @@ int launch_conv_lean(ConvK& k, int ksize, int stride, int mode, const void* pack
         }
         if (K8 * 8 != k.Cin) return 1;
     }
-    if (K8 > MAXBLK) return 1;
+    if (K8 > (cmax >= 32 ? MAXBLK : 32)) return 1;
     if (dgrad) {
         k.Mpad = pad16(k.Cin);
         const int cout_w = k.bd_rows ? k.bd_k8 * 8 : k.Cout;      // the packed images are those of the real weight

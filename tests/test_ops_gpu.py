@@ -60,6 +60,10 @@ CONV_CASES = [
     ([128, 128], 64, 3, 1, 1, (4, 4, 4), True, False, False),
     ([2048], 512, 1, 1, 0, (2, 2, 2), False, False, False),
     ([8], 8, 3, 1, 1, (3, 5, 2), True, False, False),
+    # 33 .. 64 blocks of the K axis (the level-5 fusion block's 4 x 128 -> 128 pointwise conv; lean kernels, 32-channel chunks)
+    ([128, 128, 128, 128], 128, 1, 1, 0, (8, 8, 8), True, True, False),
+    ([128, 128, 128, 128], 64, 3, 1, 1, (4, 4, 8), True, True, False),
+    ([256, 128], 32, 3, 1, 0, (4, 8, 8), True, False, False),
 ]
 
 
