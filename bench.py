@@ -187,6 +187,25 @@ FAM = {0: "fwd3", 1: "fwd1", 2: "dgrad", 3: "wgrad", 4: "attn_fwd", 5: "attn_bwd
 WHAT = {0: "fused InstanceNorm+LeakyReLU+Conv3d 3x3x3 forward", 1: "fused InstanceNorm+LeakyReLU+Conv3d 1x1x1 forward",
         2: "conv input gradient + LeakyReLU'/mask + InstanceNorm-backward sums",
         3: "conv weight + bias gradient (InstanceNorm+LeakyReLU recomputed in the loader)"}
+_STALL = {}
+
+
+def gpu_stall(device, ms):
+    """keep the current stream busy for ~ms milliseconds (torch.cuda._sleep, calibrated once with an event pair)"""
+    import torch
+    if ms <= 0:
+        return
+    if "cyc_per_ms" not in _STALL:
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        torch.cuda._sleep(2_000_000)
+        e1.record()
+        torch.cuda.synchronize()
+        _STALL["cyc_per_ms"] = 2_000_000 / max(e0.elapsed_time(e1), 1e-3)
+    torch.cuda._sleep(int(min(ms, 50.0) * _STALL["cyc_per_ms"]))
+
+
 CONV_KINDS = 0xF
 ATTN_KINDS = 0x30
 FINISH_KIND = 0x40
@@ -319,12 +338,15 @@ def main():
     if want_events:
         ops.prof_read()
         ops.prof_enable(CONV_KINDS | ATTN_KINDS | FINISH_KIND)
+    torch.cuda.synchronize()
+    t_warm = time.perf_counter()
     for _ in range(args.warmup):
         wl = step()
         if os.environ.get("BENCH_DEBUG") == "2":
             print(f"[bench] warmup loss {float(wl):.5f}", file=sys.stderr)
     parallel.barrier(ctx)
     torch.cuda.synchronize()
+    step_ms_warm = (time.perf_counter() - t_warm) * 1e3 / max(args.warmup, 1) if args.warmup else 15.0
     fam_warm = {}
     dom, dom_kind = None, 2
     warm_recs, alone_recs = [], []
@@ -343,6 +365,10 @@ def main():
         mmformer.ENC_STREAMS = False
         ops.prof_enable(CONV_KINDS | ATTN_KINDS | FINISH_KIND)
         for _ in range(3):
+            # The stream is held by a spin kernel while the host enqueues the step: an event pair also times the wait for a launch
+            # the host has not issued yet, and on a slow host that made the 20-40 us launches of the deep levels look 1.5x longer
+            # (one box: the small lean dgrad launches "outweighed" the marching kernel and became the reported one).
+            gpu_stall(ctx.device, 0.75 * step_ms_warm)
             eager_step()
         torch.cuda.synchronize()
         ops.prof_enable(0)

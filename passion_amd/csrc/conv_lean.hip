@@ -813,10 +813,11 @@ template <int KS, int MODE, int S = 1>
 int launch_lean_geo(ConvK& k, int K8, int cmax, int mtiles, hipStream_t st) {
     const long tiles = (long)k.B * k.tilesD * k.tilesH * k.tilesW;
     // row tiles per workgroup: two share a staged brick, but their weight fragments (2 x 27.6 KB per 32-channel chunk) leave room for
-    // ONE workgroup per CU.  The padded-domain dgrad of a grouped level-3 launch (4 x 34^3, 32 -> 32: 900 bricks) ran 69.9 us that way
-    // and 41.8 us with one row tile (two workgroups per CU); the forward (512 bricks, fused statistics) is better off with two.
+    // ONE workgroup per CU.  One row tile for the padded-domain dgrad (PASSION_LEAN_MT_TILES=4096) ran the grouped level-3 launch
+    // (4 x 34^3, 32 -> 32: 900 bricks) in 41.8 instead of 69.9 us ALONE, but inside the training step the same launches stayed at
+    // ~115 us and the step rate did not move (83.9 vs 83.9 vol/s): not adopted.
     static const long mt_env = []() { const char* e = getenv("PASSION_LEAN_MT_TILES"); return e ? atol(e) : 0L; }();
-    const long mt_tiles = mt_env > 0 ? mt_env : (MODE == 0 ? 512L : 4096L);
+    const long mt_tiles = mt_env > 0 ? mt_env : 512L;
     if (cmax >= 32) {                 // 32-channel chunks; weight fragments of a chunk fit LDS up to two row tiles
         int MT = (mtiles % 2 == 0) ? 2 : 1;
         while (MT > 1 && tiles * (mtiles / MT) < mt_tiles) MT >>= 1;

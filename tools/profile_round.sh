@@ -11,6 +11,7 @@ python3 bench.py --workload m2ftrans128 --no-cpu-baseline --no-dice > $R/gpurun_
 python3 bench.py --workload m2ftrans128_passion --no-cpu-baseline --no-dice > $R/gpurun_out/${TAG}_bench_m2ftrans128_passion.json 2>/dev/null
 python3 bench.py --workload mmformer_depth --no-cpu-baseline --no-dice > $R/gpurun_out/${TAG}_bench_depth_n1.json 2>/dev/null
 python3 bench.py --size 80 --no-cpu-baseline --no-dice --no-roofline > $R/gpurun_out/${TAG}_bench_mmformer80.json 2>/dev/null
+python3 tools/launch_table.py 128 300 2>/dev/null > $R/gpurun_out/${TAG}_launch_table.txt
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_$TAG/plain -o p --output-format csv -- python3 $R/bench.py --no-cpu-baseline --no-dice > $R/gpurun_out/prof_$TAG/plain.log 2>&1
 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_$TAG/passion -o p --output-format csv -- python3 $R/bench.py --workload mmformer128_passion --no-cpu-baseline --no-dice > $R/gpurun_out/prof_$TAG/passion.log 2>&1
