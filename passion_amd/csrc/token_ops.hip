@@ -152,16 +152,33 @@ __global__ __launch_bounds__(256) void ln_act_bwd_kernel(const T* __restrict__ x
     }
 }
 
-// dgamma[g][c] = sum_k part[g][k][0][c], dbeta[g][c] = sum_k part[g][k][1][c]
+// dgamma[g][c] = sum_k part[g][k][0][c], dbeta[g][c] = sum_k part[g][k][1][c].  A block owns 16 consecutive values of one group; 16
+// slices of the partial-block axis per value (one thread per value walked up to 256 dependent-latency loads: 21 us per launch, and
+// m2ftrans runs ~100 LayerNorm backwards per step), folded through LDS in slice order: the order of the adds is fixed.
 __global__ __launch_bounds__(256) void ln_fold_kernel(const float* __restrict__ part, float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                       int G, int nblk, int C) {
-    const long i = (long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= (long)G * 2 * C) return;
-    const int c = (int)(i % C), k = (int)((i / C) % 2), g = (int)(i / (2L * C));
-    const float* p = part + (long)g * nblk * 2 * C + (long)k * C + c;
+    __shared__ float red[16][17];
+    const int li = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    const long i = (long)blockIdx.x * 16 + li;            // value index inside (g, k, c); 2 C is a multiple of 16
+    const int g = (int)(i / (2L * C)), kc = (int)(i % (2L * C));
     float t = 0.f;
-    for (int b = 0; b < nblk; ++b) t += p[(long)b * 2 * C];
-    (k ? dbeta : dgamma)[(long)g * C + c] = t;
+    if (g < G) {
+        const float* p = part + (long)g * nblk * 2 * C + kc;
+        float t0 = 0.f, t1 = 0.f;
+        int b = sl;
+        for (; b + 16 < nblk; b += 32) { t0 += p[(long)b * 2 * C]; t1 += p[(long)(b + 16) * 2 * C]; }
+        if (b < nblk) t0 += p[(long)b * 2 * C];
+        t = t0 + t1;
+    }
+    red[sl][li] = t;
+    __syncthreads();
+    if (sl == 0 && g < G) {
+        float a = 0.f;
+#pragma unroll
+        for (int k2 = 0; k2 < 16; ++k2) a += red[k2][li];
+        const int k = kc / C, c = kc % C;
+        (k ? dbeta : dgamma)[(long)g * C + c] = a;
+    }
 }
 
 bool ln_shape_ok(long rows, int C, long rpg) {
@@ -219,7 +236,7 @@ extern "C" int passion_ln_act_bwd(const void* x, const float* gamma, const float
         hipLaunchKernelGGL(ln_act_bwd_kernel<bf16_t>, dim3(nblk, G), dim3(256), 0, st, (const bf16_t*)x, gamma, beta, (const bf16_t*)res, stat,
                            (const bf16_t*)dy, (bf16_t*)dx, (bf16_t*)dres, part, C, rows_per_group, chunk, act);
     LAUNCH_RET();
-    hipLaunchKernelGGL(ln_fold_kernel, dim3((unsigned)(((long)G * 2 * C + 255) / 256)), dim3(256), 0, st, part, dgamma, dbeta, G, nblk, C);
+    hipLaunchKernelGGL(ln_fold_kernel, dim3((unsigned)(((long)G * 2 * C + 15) / 16)), dim3(256), 0, st, part, dgamma, dbeta, G, nblk, C);
     LAUNCH_RET();
     return 0;
 }
