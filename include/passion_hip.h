@@ -315,8 +315,10 @@ int passion_norm_act_bwd(const void* x, const float* stats, const void* dout, vo
 int64_t passion_region_scratch_floats(int B, int64_t V, int C);
 int passion_region_gap_fwd(const void* const* y, const uint8_t* mask, int mask_ld, const float* prob,
                            int dtype, int B, int64_t V, int C, int bmod, float* scratch, float* sums, void* stream);
+/* bmod > 0 (B = P * bmod virtual samples, pass p of physical sample bp is row p * bmod + bp): dy[m] holds bmod samples, the SUM of
+   the passes' gradients (f32 sum, one rounding) */
 int passion_region_gap_bwd(void* const* dy, const uint8_t* mask, int mask_ld, const float* prob,
-                           const float* gS, int dtype, int B, int64_t V, int C, void* stream);
+                           const float* gS, int dtype, int B, int64_t V, int C, int bmod, void* stream);
 /* region_mix: out[b][v][i*C + c] = prob_i(v) * sum_m w[b][i][m] * y_m[c](v);  w: [B][4][4] f32 */
 int passion_region_mix_fwd(const void* const* y, const uint8_t* mask, int mask_ld, const float* prob,
                            const float* w, void* out, int dtype, int B, int64_t V, int C, int bmod, void* stream);

@@ -131,7 +131,7 @@ SIGNATURES = {
     "passion_region_gap_fwd": (c_int, [POINTER(c_void_p), c_void_p, c_int, c_void_p, c_int, c_int, c_int64, c_int,
                                        c_int, c_void_p, c_void_p, c_void_p]),
     "passion_region_gap_bwd": (c_int, [POINTER(c_void_p), c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int64,
-                                       c_int, c_void_p]),
+                                       c_int, c_int, c_void_p]),
     "passion_region_mix_fwd": (c_int, [POINTER(c_void_p), c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int,
                                        c_int64, c_int, c_int, c_void_p]),
     "passion_region_mix_bwd": (c_int, [POINTER(c_void_p), POINTER(c_void_p), c_void_p, c_int, c_void_p, c_void_p,

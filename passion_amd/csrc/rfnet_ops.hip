@@ -200,23 +200,30 @@ __global__ __launch_bounds__(256) void region_gap_kernel(Mod4 md, const float* _
 
 // dy_m[c](v) = sum_i gS[b][i][m][c] * prob_i(v)   (prob is detached in the reference, blocks.py / rfnet.py:128)
 template <typename T>
-__global__ void region_gap_bwd_kernel(Mod4 md, const float* __restrict__ prob, const float* __restrict__ gS, long V, int C) {
-    const int b = blockIdx.y, cvn = C / 4;
+__global__ void region_gap_bwd_kernel(Mod4 md, const float* __restrict__ prob, const float* __restrict__ gS, long V, int C, int P, int Bphys) {
+    // P masked passes over the same Bphys samples (virtual sample b = p * Bphys + bp): their gradients wrt y add up, summed here in
+    // f32 and written once (the per-pass tensors + a torch sum were 2 x P tensor passes per modality and level)
+    const int bp = blockIdx.y, cvn = C / 4;
     const long nvec = V * cvn;
     for (long it = (long)blockIdx.x * blockDim.x + threadIdx.x; it < nvec; it += (long)gridDim.x * blockDim.x) {
         const int c = (int)(it % cvn) * 4;
         const long v = it / cvn;
-        const f32x4 pr = load4(prob + ((long)b * V + v) * 4);
+        f32x4 r[4];
 #pragma unroll
-        for (int m = 0; m < 4; ++m) {
-            if (!md.dy[m]) continue;
-            f32x4 r = {0.f, 0.f, 0.f, 0.f};
-            if (md.present(m, b)) {
+        for (int m = 0; m < 4; ++m) r[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int p = 0; p < P; ++p) {
+            const int b = p * Bphys + bp;
+            const f32x4 pr = load4(prob + ((long)b * V + v) * 4);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) r += pr[i] * load4(gS + (((long)b * 4 + i) * 4 + m) * C + c);
+            for (int m = 0; m < 4; ++m) {
+                if (!md.dy[m] || !md.present(m, b)) continue;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) r[m] += pr[i] * load4(gS + (((long)b * 4 + i) * 4 + m) * C + c);
             }
-            store4(reinterpret_cast<T*>(md.dy[m]) + ((long)b * V + v) * C + c, r);
         }
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+            if (md.dy[m]) store4(reinterpret_cast<T*>(md.dy[m]) + ((long)bp * V + v) * C + c, r[m]);
     }
 }
 
@@ -248,49 +255,77 @@ __global__ void region_mix_fwd_kernel(Mod4 md, const float* __restrict__ prob, c
 }
 
 // dy_m[c] = sum_i w[i][m] prob_i dR[i*C+c];  dw[b][i][m] = sum_{v,c} dR[i*C+c] prob_i y_m[c]  -> part[blk][b][16]
-template <typename T>
+// PP >= P masked passes over the same Bphys samples in one launch (virtual sample b = p * Bphys + bp, all passes read y[bp]): a block
+// row owns a PHYSICAL sample, y is loaded once per voxel, dy is the f32 sum over the passes written once, dw stays per pass.
+template <typename T, int PP>
 __global__ __launch_bounds__(256) void region_mix_bwd_kernel(Mod4 md, const float* __restrict__ prob, const float* __restrict__ w,
-                                                             const T* __restrict__ dR, long V, int C, float* __restrict__ part) {
+                           const T* __restrict__ dR, long V, int C, float* __restrict__ part, int P, int Bphys) {
     __shared__ float red[4][16];
-    const int b = blockIdx.y, cvn = C / 4, tid = threadIdx.x;
+    __shared__ __attribute__((aligned(16))) float wls[PP][16];          // [pass][i * 4 + m], zero for absent modalities
+    const int bp = blockIdx.y, cvn = C / 4, tid = threadIdx.x;
+    const int Bv = P * Bphys;
     const long nvec = V * cvn;
-    float wl[4][4], dw[4][4];
+    if (tid < PP * 16) {
+        const int p = tid / 16, im = tid % 16, b = p * Bphys + bp;
+        wls[p][im] = (p < P && md.present(im % 4, b)) ? w[(long)b * 16 + im] : 0.f;
+    }
+    unsigned pres = 0u;                        // bit p * 4 + m: modality m present in pass p
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int p = 0; p < PP; ++p)
 #pragma unroll
-        for (int m = 0; m < 4; ++m) { wl[i][m] = md.present(m, b) ? w[((long)b * 4 + i) * 4 + m] : 0.f; dw[i][m] = 0.f; }
+        for (int m = 0; m < 4; ++m)
+            if (p < P && md.present(m, p * Bphys + bp)) pres |= 1u << (p * 4 + m);
+    float dw[PP][16];
+#pragma unroll
+    for (int p = 0; p < PP; ++p)
+#pragma unroll
+        for (int k = 0; k < 16; ++k) dw[p][k] = 0.f;
+    __syncthreads();
     for (long it = (long)blockIdx.x * 256 + tid; it < nvec; it += (long)gridDim.x * 256) {
         const int c = (int)(it % cvn) * 4;
         const long v = it / cvn;
-        const f32x4 pr = load4(prob + ((long)b * V + v) * 4);
-        f32x4 g[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) g[i] = pr[i] * load4(dR + ((long)b * V + v) * 4 * C + i * C + c);
+        f32x4 y[4], r[4];
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
-            if (!md.present(m, b)) {
-                if (md.dy[m]) store4(reinterpret_cast<T*>(md.dy[m]) + ((long)b * V + v) * C + c, (f32x4){0.f, 0.f, 0.f, 0.f});
-                continue;
-            }
-            const f32x4 y = load4(reinterpret_cast<const T*>(md.y[m]) + ((long)md.ysrc(b) * V + v) * C + c);
+            y[m] = load4(reinterpret_cast<const T*>(md.y[m]) + ((long)bp * V + v) * C + c);
+            r[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
 #pragma unroll
-            for (int i = 0; i < 4; ++i) dw[i][m] += g[i][0] * y[0] + g[i][1] * y[1] + g[i][2] * y[2] + g[i][3] * y[3];
-            if (md.dy[m]) {
-                const f32x4 r = wl[0][m] * g[0] + wl[1][m] * g[1] + wl[2][m] * g[2] + wl[3][m] * g[3];
-                store4(reinterpret_cast<T*>(md.dy[m]) + ((long)b * V + v) * C + c, r);
+        for (int p = 0; p < PP; ++p) {
+            if (p >= P) continue;
+            // one pass of loads at a time: hoisting all PP passes' loads cost 256 registers + 37 spilled dwords (423 us per launch
+            // against 267 for the per-pass kernel this replaces)
+            if (PP > 1) asm volatile("" ::: "memory");
+            const long b = (long)p * Bphys + bp;
+            const f32x4 pr = load4(prob + (b * V + v) * 4);
+            f32x4 g[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) g[i] = pr[i] * load4(dR + (b * V + v) * 4 * C + i * C + c);
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                if (!((pres >> (p * 4 + m)) & 1u)) continue;               // block-uniform
+#pragma unroll
+                for (int i = 0; i < 4; ++i) dw[p][i * 4 + m] += g[i][0] * y[m][0] + g[i][1] * y[m][1] + g[i][2] * y[m][2] + g[i][3] * y[m][3];
+                r[m] += wls[p][m] * g[0] + wls[p][4 + m] * g[1] + wls[p][8 + m] * g[2] + wls[p][12 + m] * g[3];
             }
         }
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+            if (md.dy[m]) store4(reinterpret_cast<T*>(md.dy[m]) + ((long)bp * V + v) * C + c, r[m]);
     }
     const int wv = tid >> 6, lane = tid & 63;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int p = 0; p < PP; ++p) {
+        if (p >= P) continue;
 #pragma unroll
-        for (int m = 0; m < 4; ++m) {
-            const float s = wave_sum(dw[i][m]);
-            if (lane == 0) red[wv][i * 4 + m] = s;
+        for (int k = 0; k < 16; ++k) {
+            const float s_ = wave_sum(dw[p][k]);
+            if (lane == 0) red[wv][k] = s_;
         }
-    __syncthreads();
-    if (tid < 16) part[((long)blockIdx.x * gridDim.y + b) * 16 + tid] = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+        __syncthreads();
+        if (tid < 16) part[((long)blockIdx.x * Bv + (p * Bphys + bp)) * 16 + tid] = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+        __syncthreads();
+    }
 }
 
 inline int egrid(long n) { return (int)hmin((n + 255) / 256, 4096); }
@@ -375,17 +410,21 @@ extern "C" int passion_region_gap_fwd(const void* const* y, const uint8_t* mask,
 }
 
 // gS: [B][4][4][C] gradient wrt S; writes dy[m] (skipped when NULL)
+// bmod > 0: B = P * bmod virtual samples (P masked passes over bmod physical ones, virtual b = p * bmod + bp); dy[m] then holds bmod
+// samples: the SUM of the passes' gradients
 extern "C" int passion_region_gap_bwd(void* const* dy, const uint8_t* mask, int mask_ld, const float* prob, const float* gS, int dtype,
-                                      int B, int64_t V, int C, void* stream) {
+                                      int B, int64_t V, int C, int bmod, void* stream) {
     if (C % 4) return -1021;
+    if (bmod < 0 || (bmod > 0 && B % bmod)) return -1022;
     Mod4 md;
     int rc = fill_mod(md, nullptr, dy, mask, mask_ld);
     if (rc) return rc;
-    dim3 grid(egrid(V * (C / 4)), B);
+    const int Bphys = bmod > 0 ? bmod : B, P = B / Bphys;
+    dim3 grid(egrid(V * (C / 4)), Bphys);
     hipStream_t st = (hipStream_t)stream;
     DISPATCH_T(dtype,
-               hipLaunchKernelGGL(region_gap_bwd_kernel<float>, grid, dim3(256), 0, st, md, prob, gS, (long)V, C),
-               hipLaunchKernelGGL(region_gap_bwd_kernel<bf16_t>, grid, dim3(256), 0, st, md, prob, gS, (long)V, C));
+               hipLaunchKernelGGL(region_gap_bwd_kernel<float>, grid, dim3(256), 0, st, md, prob, gS, (long)V, C, P, Bphys),
+               hipLaunchKernelGGL(region_gap_bwd_kernel<bf16_t>, grid, dim3(256), 0, st, md, prob, gS, (long)V, C, P, Bphys));
     LAUNCH_RET();
     return 0;
 }
@@ -406,7 +445,8 @@ extern "C" int passion_region_mix_fwd(const void* const* y, const uint8_t* mask,
     return 0;
 }
 
-// dR: [B][V][4*C]; writes dy[m] (skipped when NULL) and dw [B][4][4]; scratch: passion_region_scratch_floats
+// dR: [B][V][4*C]; writes dy[m] (skipped when NULL) and dw [B][4][4]; scratch: passion_region_scratch_floats.
+// bmod > 0 (B = P * bmod virtual samples, P <= 8 passes over bmod physical ones): dy[m] holds bmod samples, the SUM over the passes
 extern "C" int passion_region_mix_bwd(const void* const* y, void* const* dy, const uint8_t* mask, int mask_ld, const float* prob,
                                       const float* w, const void* dR, int dtype, int B, int64_t V, int C, int bmod, float* scratch,
                                       float* dw, void* stream) {
@@ -415,11 +455,20 @@ extern "C" int passion_region_mix_bwd(const void* const* y, void* const* dy, con
     int rc = fill_mod(md, y, dy, mask, mask_ld, bmod);
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
+    if (bmod < 0 || (bmod > 0 && B % bmod)) return -1022;
+    const int Bphys = bmod > 0 ? bmod : B, P = B / Bphys;
+    if (P > 8) return -1022;
     const int gx = rgrid((long)V * (C / 4));
-    dim3 rg(gx, B);
-    DISPATCH_T(dtype,
-               hipLaunchKernelGGL(region_mix_bwd_kernel<float>, rg, dim3(256), 0, st, md, prob, w, (const float*)dR, (long)V, C, scratch),
-               hipLaunchKernelGGL(region_mix_bwd_kernel<bf16_t>, rg, dim3(256), 0, st, md, prob, w, (const bf16_t*)dR, (long)V, C, scratch));
+    dim3 rg(gx, Bphys);
+#define MIX_BWD(PPV)                                                                                                                         \
+    DISPATCH_T(dtype,                                                                                                                        \
+               hipLaunchKernelGGL((region_mix_bwd_kernel<float, PPV>), rg, dim3(256), 0, st, md, prob, w, (const float*)dR, (long)V, C, scratch, P, Bphys),  \
+               hipLaunchKernelGGL((region_mix_bwd_kernel<bf16_t, PPV>), rg, dim3(256), 0, st, md, prob, w, (const bf16_t*)dR, (long)V, C, scratch, P, Bphys))
+    if (P == 1) { MIX_BWD(1); }
+    else if (P <= 3) { MIX_BWD(3); }
+    else if (P <= 5) { MIX_BWD(5); }
+    else { MIX_BWD(8); }
+#undef MIX_BWD
     LAUNCH_RET();
     const long n = (long)B * 16;
     hipLaunchKernelGGL(fold_kernel, dim3((unsigned)((n + 15) / 16)), dim3(256), 0, st, scratch, gx, n, dw);

@@ -1326,12 +1326,10 @@ class RegionGapFn(torch.autograd.Function):
         prob, mask = ctx.saved_tensors
         Bv, V, C, dt, shape, bmod = ctx.meta
         gS = gS.contiguous().float()
-        vshape = (Bv,) + tuple(shape[1:])
-        dys = [torch.empty(vshape, dtype=dt, device=prob.device) if ctx.needs_input_grad[2 + m] else None for m in range(4)]
+        # bmod: the passes' gradients add up -- inside the kernel (f32 sum over the passes, written once in the shape of y)
+        dys = [torch.empty(tuple(shape), dtype=dt, device=prob.device) if ctx.needs_input_grad[2 + m] else None for m in range(4)]
         L.check(L.load().passion_region_gap_bwd(_ptr4(dys), _p(mask), mask.shape[1] if mask is not None else 0, _p(prob),
-                                                _p(gS), L.dtype_code(dt), Bv, V, C, L.stream_ptr()), "passion_region_gap_bwd")
-        if bmod:       # the passes' gradients add up
-            dys = [d.view(Bv // bmod, *shape).sum(0) if d is not None else None for d in dys]
+                                                _p(gS), L.dtype_code(dt), Bv, V, C, bmod, L.stream_ptr()), "passion_region_gap_bwd")
         return (None, None, *dys)
 
 
@@ -1363,7 +1361,7 @@ class RegionMixFn(torch.autograd.Function):
         V = D * H * W
         lib = L.load()
         dR = dR.contiguous()
-        vshape = (Bv, D, H, W, C)
+        vshape = (Bp, D, H, W, C)             # bmod: the sum over the passes, formed inside the kernel
         dys = [torch.empty(vshape, dtype=ys[m].dtype, device=prob.device) if ctx.needs_input_grad[3 + m] else None
                for m in range(4)]
         scratch = torch.empty(lib.passion_region_scratch_floats(Bv, V, C), dtype=torch.float32, device=prob.device)
@@ -1371,8 +1369,6 @@ class RegionMixFn(torch.autograd.Function):
         L.check(lib.passion_region_mix_bwd(_ptr4(ys), _ptr4(dys), _p(mask), mask.shape[1] if mask is not None else 0,
                                            _p(prob), _p(w), _p(dR), L.dtype_code(ys[0].dtype), Bv, V, C, bmod, _p(scratch),
                                            _p(dw), L.stream_ptr()), "passion_region_mix_bwd")
-        if bmod:
-            dys = [d.view(Bv // bmod, Bp, D, H, W, C).sum(0) if d is not None else None for d in dys]
         return (None, None, dw, *dys)
 
 

@@ -81,6 +81,45 @@ def test_region_gap_and_mix(dtype):
         assert rel(nc(a.grad.float()), b.grad) < tol * 3
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("P", [2, 5, 7])
+def test_region_gap_and_mix_masked_passes(dtype, P):
+    """P masked passes over the same B samples in one launch (prob / mask / w hold P * B rows, row p * B + b; PASSION's teacher +
+    students): outputs per pass, the gradient wrt y is the SUM over the passes (formed inside the backward kernels), dw per pass"""
+    from passion_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(4)
+    B, C, S = 2, 8, 6
+    ys = [torch.randn(B, C, S, S, S, generator=g).to(dtype).double() for _ in range(4)]
+    prob = torch.softmax(torch.randn(P * B, 4, S, S, S, generator=g) * 2, 1).double()
+    mask = torch.rand(P * B, 4, generator=g) > 0.4
+    mask[:, 2] |= ~mask.any(1)
+    w = torch.rand(P * B, 4, 4, generator=g).double()
+    yr = [y.clone().requires_grad_(True) for y in ys]
+    wr = w.clone().requires_grad_(True)
+    yv = [y.repeat(P, 1, 1, 1, 1) for y in yr]                                            # virtual sample p * B + b reads y[b]
+    ym = [y * mask[:, m].view(P * B, 1, 1, 1, 1).double() for m, y in enumerate(yv)]
+    Sref = torch.stack([torch.stack([(ym[m] * prob[:, i:i + 1]).sum((2, 3, 4)) for m in range(4)], 1) for i in range(4)], 1)
+    Rref = torch.cat([prob[:, i:i + 1] * sum(wr[:, i, m].view(P * B, 1, 1, 1, 1) * ym[m] for m in range(4)) for i in range(4)], 1)
+    gS = torch.randn(Sref.shape, generator=g, dtype=torch.float64)
+    gR = torch.randn(Rref.shape, generator=g, dtype=torch.float64).to(dtype).double()
+    ((Sref * gS).sum() + (Rref * gR).sum()).backward()
+
+    yd = [cl(y).to(dev, dtype).requires_grad_(True) for y in ys]
+    wd = w.float().to(dev).requires_grad_(True)
+    pd, md = cl(prob).float().to(dev), mask.to(dev)
+    Sd, _ = ops.region_gap(pd, md, yd)
+    Rd = ops.region_mix(pd, md, wd, yd)
+    ((Sd * gS.float().to(dev)).sum() + (Rd.float() * cl(gR).float().to(dev)).sum()).backward()
+    tol = 2e-4 if dtype == torch.float32 else 3e-2
+    assert rel(Sd, Sref) < tol
+    assert rel(nc(Rd.detach().float()), Rref) < tol
+    assert rel(wd.grad, wr.grad) < tol * 3
+    for a, b in zip(yd, yr):
+        assert a.grad.shape == a.shape
+        assert rel(nc(a.grad.float()), b.grad) < tol * 3
+
+
 def build_rfnet():
     from passion_amd.models import rfnet
     torch.manual_seed(1037)
