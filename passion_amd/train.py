@@ -55,7 +55,7 @@ class LossState:
 
 
 def assemble_loss(outs, target, mask, mask_type="idt", use_passion=True, state=None, warmup=False, modal_num=None,
-                  iter_per_epoch=None):
+                  iter_per_epoch=None, rp_override=None):
     """Per-iteration loss (train.py:228-280 / :413-440), no host synchronisation.  `modal_num` / `iter_per_epoch`: the
     normaliser of the epoch accumulators (train.py:295-304: / modal_num for mask_type 'idt', / iter_per_epoch otherwise)."""
     pred = outs[0]
@@ -74,7 +74,9 @@ def assemble_loss(outs, target, mask, mask_type="idt", use_passion=True, state=N
     beta = state.imb_beta if state is not None else torch.ones(4, device=dev)
     w = (state.modal_weight if (state is not None and idt) else torch.ones(4, device=dev))
     kl_m, proto_m, dist_bs = red(outs[3]), red(outs[4]), outs[5]
-    rp_mask = relative_preference(dist_bs, mk, idt)
+    # rp_override: a given relative-preference gate instead of this step's own (tests: replaying a reference trajectory whose
+    # discrete gates are known, so that a near-tie flipped by rounding does not end the comparison)
+    rp_mask = relative_preference(dist_bs, mk, idt) if rp_override is None else rp_override.to(device=dev, dtype=torch.float32)
     kl = (beta * w * kl_m).sum()
     proto = (rp_mask * w * proto_m).sum()
     if state is not None:

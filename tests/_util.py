@@ -110,9 +110,11 @@ def unpack2(packed, n):
     return out.reshape(-1)[:n]
 
 
-def replay_trajectory(g, dtype, dev, on_step=None):
+def replay_trajectory(g, dtype, dev, on_step=None, force_gates=None):
     """the product takes the fixture's K AdamW(amsgrad) steps from the same seed / inputs / learning rate (dropout off, as the
-    fixture) -> (model, per-step losses [K + 1], final prediction (1,4,S,S,S)); the step is passion_amd.train's"""
+    fixture) -> (model, per-step losses [K + 1], final prediction (1,4,S,S,S)); the step is passion_amd.train's.
+    force_gates [K + 1][4]: PASSION's relative-preference gate of every step is the given one (the reference's) instead of the sign of
+    the product's own relative distances"""
     from passion_amd import train as ptrain
     S, K, passion = int(g["S"]), int(g["K"]), bool(g["passion"])
     m = build_product_model(S, small=False).to(dev)
@@ -123,7 +125,8 @@ def replay_trajectory(g, dtype, dev, on_step=None):
     losses, pred = [], None
     for it in range(K + 1):
         outs = m(x, mask, target=target, temp=4.0)
-        loss = ptrain.assemble_loss(outs, target, mask, "idt", passion)
+        forced = torch.from_numpy(np.asarray(force_gates[it], dtype=np.float32)) if force_gates is not None else None
+        loss = ptrain.assemble_loss(outs, target, mask, "idt", passion, rp_override=forced)
         losses.append(loss.detach())
         pred = outs[0].detach()
         if on_step is not None:

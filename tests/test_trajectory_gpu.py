@@ -11,7 +11,9 @@ What is asserted, and why in this form:
     steps; 30 steps within 2e-3 in bf16 is the strongest statement this suite makes about the benchmarked backward.
     PASSION's loss contains a DISCRETE gate (rp_mask, train.py:266-270: sign of a relative distance): the fixture stores the
     reference's gate of every step, and a step is compared only while every gate so far agreed (a flipped gate changes the
-    loss by tens of percent and everything after it; f32 never flips, bf16 is reported).
+    loss by tens of percent and everything after it).  f32 runs free and never flips.  bf16 runs under the reference's gates
+    (`rp_override`) so that all steps stay comparable; its OWN gates are recorded and may differ only where the reference's signed
+    distance (fixture `rp_vals`) is a near tie (< 1e-2: e.g. step 4, modality t1ce: -0.0043).
   * the FINAL ARGMAX MASK: K steps amplify rounding differences of the trajectory itself (two f32 implementations drift ~1e-4
     in the weights), so voxels flip where the reference's own top-2 margin is small.  Asserted: (a) the differing voxels are few,
     (b) almost none of them is a voxel the reference decides by a margin >= 0.1 (fixture list close3_idx), (c) voxel accuracy
@@ -31,12 +33,18 @@ CASES = ["traj_plain_64.npz", "traj_passion_32.npz"]
 LOSS_TOL = {(torch.float32, False): 1e-3, (torch.float32, True): 4e-3, (torch.bfloat16, False): 5e-3, (torch.bfloat16, True): 1e-2}
 # measured on MI355X (printed below): f32 311 / 262144 differing voxels (64^3, Dice 0.981), 81 / 32768 (32^3 PASSION, Dice 0.928: the
 # enhancing class has ~60 voxels there); bf16 1848 / 262144 (17 with a reference margin >= 0.1, Dice 0.889)
-MASK = {torch.float32: dict(diff=0.003, far=2e-4, acc=1e-3, dice=0.90), torch.bfloat16: dict(diff=0.02, far=2e-3, acc=4e-3, dice=0.80)}
+# bf16 PASSION at 32^3 (all 21 steps under the reference's gates): 458 / 32768 differing voxels, 69 with a reference margin >= 0.1, Dice 0.791
+# (the enhancing class has ~60 voxels), accuracy vs the label 0.8774 against the reference's 0.8776
+MASK = {torch.float32: dict(diff=0.003, far=2e-4, acc=1e-3, dice=0.90), torch.bfloat16: dict(diff=0.02, far=2e-3, acc=4e-3, dice=0.80),
+        (torch.bfloat16, True): dict(diff=0.02, far=4e-3, acc=4e-3, dice=0.75)}
 
 
 def _gates(outs, mask):
     from passion_amd import train as ptrain
     return ptrain.relative_preference(outs[5], mask.float(), True).cpu().numpy()
+
+
+GATE_TIE = 1e-2        # a gate the reference decides by a relative distance below this may flip under bf16 rounding
 
 
 def _replay(name, dtype):
@@ -46,7 +54,10 @@ def _replay(name, dtype):
     mask = torch.from_numpy(g["mask"]).to(dev)
     gates = []
     hook = (lambda it, outs, loss: gates.append(_gates(outs, mask))) if passion else None
-    m, losses, pred = replay_trajectory(g, dtype, dev, on_step=hook)
+    # bf16: the steps run under the REFERENCE's gates (the fixture holds them and the signed distances they are the sign of), the
+    # product's own gates are recorded beside them: a gate may differ only where the reference's decision is a near tie
+    force = g["rp_masks"] if (passion and dtype == torch.bfloat16) else None
+    m, losses, pred = replay_trajectory(g, dtype, dev, on_step=hook, force_gates=force)
     return g, m, losses, pred, (np.stack(gates) if passion else None)
 
 
@@ -58,9 +69,16 @@ def _check(name, dtype):
     err = np.abs(losses - ref) / np.abs(ref)
     upto = len(ref)
     if passion:
-        same = (gates == g["rp_masks"]).all(1)
-        upto = int(np.argmin(same)) if not same.all() else len(ref)
-        print(f"[{tag}] relative-preference gate agrees with the reference's for the first {upto} of {len(ref)} steps")
+        differs = gates != g["rp_masks"]
+        same = (~differs).all(1)
+        first = int(np.argmin(same)) if not same.all() else len(ref)
+        print(f"[{tag}] relative-preference gate agrees with the reference's for the first {first} of {len(ref)} steps; "
+              f"{int(differs.sum())} of {differs.size} decisions differ, the reference's |distance| there: "
+              f"{np.array2string(np.abs(g['rp_vals'][differs]), precision=4)}")
+        if dtype == torch.float32:
+            upto = first                                # free-running: comparable while every gate so far agreed
+        else:                                           # gates forced to the reference's: every step is comparable
+            assert (np.abs(g["rp_vals"][differs]) < GATE_TIE).all(), np.abs(g["rp_vals"][differs])
     print(f"[{tag}] per-step loss error over the comparable steps: max {err[:upto].max():.2e} (step {int(err[:upto].argmax())}); "
           f"all steps {np.array2string(err, precision=1, max_line_width=400)}")
     got = pred.argmax(1).reshape(-1).cpu().numpy().astype(np.uint8)
@@ -72,12 +90,10 @@ def _check(name, dtype):
     acc, acc_ref = float((got == lab).mean()), float(g["accs"][-1])
     print(f"[{tag}] final mask vs reference: {ndiff} of {S ** 3} voxels differ ({far} of them where the reference's margin is >= 0.1), "
           f"mean Dice WT/TC/ET {dice:.5f}; accuracy vs label {acc:.4f} (reference {acc_ref:.4f})")
-    t = MASK[dtype]
+    t = MASK.get((dtype, passion), MASK[dtype])
     assert err[:upto].max() < LOSS_TOL[(dtype, passion)], err
     if dtype == torch.float32:
         assert upto == len(ref), "the f32 path flipped a relative-preference gate"
-    else:
-        assert upto >= 5
     if upto == len(ref):                               # same gates all the way: the final states are comparable
         assert ndiff <= t["diff"] * S ** 3 and far <= max(2, t["far"] * S ** 3), (ndiff, far)
         assert abs(acc - acc_ref) < t["acc"] and dice > t["dice"], (acc, acc_ref, dice)

@@ -53,7 +53,7 @@ def main():
     mk = mask.float()
     opt = torch.optim.AdamW([{"params": m.parameters(), "lr": LR, "weight_decay": 1e-4}], betas=(0.9, 0.999), eps=1e-08,
                             amsgrad=True)            # train.py:95-96
-    losses, accs, rps = [], [], []
+    losses, accs, rps, rpv = [], [], [], []
     lab = target.argmax(1)
     for it in range(K + 1):
         t0 = time.time()
@@ -64,8 +64,10 @@ def main():
         if passion:                                   # train.py:243-280 with imb_beta = modal_weight = 1
             sep_m, kl_m, proto_m = (outs[2] * mk).sum(0), (outs[3] * mk).sum(0), (outs[4] * mk).sum(0)
             d = outs[5][0]
-            rp_mask = ((mk[0] * (d / (d.sum() / mk[0].sum()) - 1)) > 0).float()
+            rp = mk[0] * (d / (d.sum() / mk[0].sum()) - 1)
+            rp_mask = (rp > 0).float()
             rps.append(rp_mask.numpy().copy())
+            rpv.append(rp.detach().numpy().copy())
             loss = loss + (rp_mask * sep_m).sum() + 0.5 * kl_m.sum() + 0.1 * (rp_mask * proto_m).sum()
         else:
             loss = loss + (outs[2] * mk).sum()
@@ -94,6 +96,7 @@ def main():
            "label_packed": pack2(lab.reshape(-1).numpy())}
     if passion:
         rec["rp_masks"] = np.stack(rps)        # the relative-preference gate of every step (train.py:266-270): a DISCRETE switch
+        rec["rp_vals"] = np.stack(rpv)         # ... and the signed relative distance it is the sign of: how close each decision was
     for key in ("flair_encoder.e1_c1.weight", "t2_encoder.e1_c2.conv.bias", "decoder_fuse.seg_layer.weight", "decoder_fuse.d1_c2.conv.bias",
                 "decoder_sep.seg_layer.weight", "multimodal_decode_conv.bias"):
         rec["final::" + key] = sd[key].numpy()
