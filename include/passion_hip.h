@@ -284,10 +284,12 @@ int passion_attn_scores_masked_fwd(const void* qkv, int dtype, int B, int N, int
  * (passion_ln_act_part_floats floats), folded in a fixed order. */
 int passion_ln_act_supported(int64_t rows, int C, int64_t rows_per_group);
 int64_t passion_ln_act_part_floats(int64_t rows, int C, int64_t rows_per_group);
+/* out_dtype: type of y (fwd) and dy (bwd): the input's dtype, or PASSION_BF16 for an f32 input without residual -- the f32 residual
+ * stream of the transformers (mmformer.py:282-313) normalised straight into the bf16 operand of the GEMM that follows. */
 int passion_ln_act_fwd(const void* x, const float* gamma, const float* beta, const void* res, void* y, float* stat, int dtype,
-                       int64_t rows, int C, int64_t rows_per_group, float eps, int act, void* stream);
+                       int out_dtype, int64_t rows, int C, int64_t rows_per_group, float eps, int act, void* stream);
 int passion_ln_act_bwd(const void* x, const float* gamma, const float* beta, const void* res, const float* stat, const void* dy,
-                       void* dx, void* dres, float* part, float* dgamma, float* dbeta, int dtype, int64_t rows, int C,
+                       void* dx, void* dres, float* part, float* dgamma, float* dbeta, int dtype, int out_dtype, int64_t rows, int C,
                        int64_t rows_per_group, int act, void* stream);
 
 /* Attention dropout (nn.Dropout on the attention probabilities, code/models/mmformer.py:222) in one pass and without a

@@ -113,10 +113,10 @@ SIGNATURES = {
                                     c_int, c_int, c_int, c_void_p]),
     "passion_ln_act_supported": (c_int, [c_int64, c_int, c_int64]),
     "passion_ln_act_part_floats": (c_int64, [c_int64, c_int, c_int64]),
-    "passion_ln_act_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int, c_int64, c_float, c_int,
-                                   c_void_p]),
+    "passion_ln_act_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64, c_int, c_int64, c_float,
+                                   c_int, c_void_p]),
     "passion_ln_act_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                                   c_int, c_int64, c_int, c_int64, c_int, c_void_p]),
+                                   c_int, c_int, c_int64, c_int, c_int64, c_int, c_void_p]),
     "passion_scale_nearest_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "passion_scale_nearest_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "passion_attn_scores_masked_fwd": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p, c_int, c_void_p, c_void_p]),

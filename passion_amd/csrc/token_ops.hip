@@ -42,9 +42,10 @@ __device__ __forceinline__ float gelu_d(float z) {
 }
 
 // rows [0, rows) in G = rows / rpg groups; gamma / beta: [G][C]
-template <typename T>
+// TO: type of y (and of dy in the backward): f32 tokens normalised straight into the bf16 operand of the GEMM that follows
+template <typename T, typename TO>
 __global__ __launch_bounds__(256) void ln_act_fwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                         const T* __restrict__ res, T* __restrict__ y, float* __restrict__ stat,
+                                                         const T* __restrict__ res, TO* __restrict__ y, float* __restrict__ stat,
                                                          long rows, int C, long rpg, float eps, int act) {
     const int lpr = C >> 3, rpw = 64 / lpr;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -76,16 +77,16 @@ __global__ __launch_bounds__(256) void ln_act_fwd_kernel(const T* __restrict__ x
             v[j] = act ? gelu_f(z) : z;
         }
         if (ok) {
-            st8<T>(y + r * C + cl, v);
+            st8<TO>(y + r * C + cl, v);
             if ((lane % lpr) == 0) { stat[2 * r] = mean; stat[2 * r + 1] = rstd; }
         }
     }
 }
 
 // grid (nblk, G): block (k, g) owns rows g * rpg + [k * chunk, (k + 1) * chunk) and leaves its column sums in part[g][k][2][C]
-template <typename T>
+template <typename T, typename TO>
 __global__ __launch_bounds__(256) void ln_act_bwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                         const T* __restrict__ res, const float* __restrict__ stat, const T* __restrict__ dy,
+                                                         const T* __restrict__ res, const float* __restrict__ stat, const TO* __restrict__ dy,
                                                          T* __restrict__ dx, T* __restrict__ dres, float* __restrict__ part,
                                                          int C, long rpg, long chunk, int act) {
     __shared__ float red[4 * 64 * 16];                 // [wave][lane][2][8]
@@ -106,7 +107,7 @@ __global__ __launch_bounds__(256) void ln_act_bwd_kernel(const T* __restrict__ x
         const long r = (long)g * rpg + (ok ? rl : hi - 1);
         float xv[8], gv[8], rv[8];
         ld8<T>(x + r * C + cl, xv);
-        ld8<T>(dy + r * C + cl, gv);
+        ld8<TO>(dy + r * C + cl, gv);
         if (act && res) ld8<T>(res + r * C + cl, rv);
         const float mean = stat[2 * r], rstd = stat[2 * r + 1];
         float s1 = 0.f, s2 = 0.f;
@@ -203,38 +204,41 @@ extern "C" int64_t passion_ln_act_part_floats(int64_t rows, int C, int64_t rows_
     return (rows / rows_per_group) * (long)ln_nblk(rows_per_group, C) * 2 * C;
 }
 
+// out_dtype: type of y / dy; the input's type, or bf16 for f32 input (no residual then)
+#define LN_DISPATCH(KERNEL, ...)                                                                                         \
+    if (dtype == PASSION_F32 && out_dtype == PASSION_F32) { KERNEL(float, float, __VA_ARGS__); }                          \
+    else if (dtype == PASSION_BF16 && out_dtype == PASSION_BF16) { KERNEL(bf16_t, bf16_t, __VA_ARGS__); }                 \
+    else if (dtype == PASSION_F32 && out_dtype == PASSION_BF16 && !res) { KERNEL(float, bf16_t, __VA_ARGS__); }           \
+    else return -1007;
+
 extern "C" int passion_ln_act_fwd(const void* x, const float* gamma, const float* beta, const void* res, void* y, float* stat, int dtype,
-                                  int64_t rows, int C, int64_t rows_per_group, float eps, int act, void* stream) {
+                                  int out_dtype, int64_t rows, int C, int64_t rows_per_group, float eps, int act, void* stream) {
     if (!ln_shape_ok(rows, C, rows_per_group)) return -1003;
-    if (dtype != PASSION_F32 && dtype != PASSION_BF16) return -1007;
     const int rpw = 64 / (C >> 3);
     const long groups = (rows + 4L * rpw - 1) / (4L * rpw);
     const unsigned grid = (unsigned)hmin(groups, 8192);
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == PASSION_F32)
-        hipLaunchKernelGGL(ln_act_fwd_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)x, gamma, beta, (const float*)res, (float*)y, stat,
-                           rows, C, rows_per_group, eps, act);
-    else
-        hipLaunchKernelGGL(ln_act_fwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, (const bf16_t*)x, gamma, beta, (const bf16_t*)res, (bf16_t*)y, stat,
-                           rows, C, rows_per_group, eps, act);
+#define LN_FWD(T, TO, dummy)                                                                                                                   \
+    hipLaunchKernelGGL((ln_act_fwd_kernel<T, TO>), dim3(grid), dim3(256), 0, st, (const T*)x, gamma, beta, (const T*)res, (TO*)y, stat, rows, C, \
+                       rows_per_group, eps, act)
+    LN_DISPATCH(LN_FWD, 0)
+#undef LN_FWD
     LAUNCH_RET();
     return 0;
 }
 
 extern "C" int passion_ln_act_bwd(const void* x, const float* gamma, const float* beta, const void* res, const float* stat, const void* dy,
-                                  void* dx, void* dres, float* part, float* dgamma, float* dbeta, int dtype, int64_t rows, int C,
+                                  void* dx, void* dres, float* part, float* dgamma, float* dbeta, int dtype, int out_dtype, int64_t rows, int C,
                                   int64_t rows_per_group, int act, void* stream) {
     if (!ln_shape_ok(rows, C, rows_per_group)) return -1003;
-    if (dtype != PASSION_F32 && dtype != PASSION_BF16) return -1007;
     const int G = (int)(rows / rows_per_group), nblk = ln_nblk(rows_per_group, C);
     const long chunk = (rows_per_group + nblk - 1) / nblk;
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == PASSION_F32)
-        hipLaunchKernelGGL(ln_act_bwd_kernel<float>, dim3(nblk, G), dim3(256), 0, st, (const float*)x, gamma, beta, (const float*)res, stat,
-                           (const float*)dy, (float*)dx, (float*)dres, part, C, rows_per_group, chunk, act);
-    else
-        hipLaunchKernelGGL(ln_act_bwd_kernel<bf16_t>, dim3(nblk, G), dim3(256), 0, st, (const bf16_t*)x, gamma, beta, (const bf16_t*)res, stat,
-                           (const bf16_t*)dy, (bf16_t*)dx, (bf16_t*)dres, part, C, rows_per_group, chunk, act);
+#define LN_BWD(T, TO, dummy)                                                                                                                   \
+    hipLaunchKernelGGL((ln_act_bwd_kernel<T, TO>), dim3(nblk, G), dim3(256), 0, st, (const T*)x, gamma, beta, (const T*)res, stat, (const TO*)dy, \
+                       (T*)dx, (T*)dres, part, C, rows_per_group, chunk, act)
+    LN_DISPATCH(LN_BWD, 0)
+#undef LN_BWD
     LAUNCH_RET();
     hipLaunchKernelGGL(ln_fold_kernel, dim3((unsigned)(((long)G * 2 * C + 15) / 16)), dim3(256), 0, st, part, dgamma, dbeta, G, nblk, C);
     LAUNCH_RET();

@@ -375,13 +375,13 @@ def _pw(conv, x):
     return ops.linear(x, conv.weight, conv.bias, _bf16(x))
 
 
-def _ln(norm, x, act=False, res=None):
+def _ln(norm, x, act=False, res=None, out_dtype=None):
     """act(LayerNorm over the channels of a channels-last tensor [+ res]), act = GELU or nothing: one fused launch
     (ops.ln_act, csrc/token_ops.hip: f32 statistics and affine, result in the tensor's dtype); channel counts the kernel does
     not take go through torch"""
     C = x.shape[-1]
     if x.is_cuda and C % 8 == 0 and C <= 512 and ((C // 8) & (C // 8 - 1)) == 0:
-        return ops.ln_act(x, norm, act, res)
+        return ops.ln_act(x, norm, act, res, out_dtype)
     y = torch.nn.functional.layer_norm(x.float(), (C,), norm.weight, norm.bias, norm.eps)
     y = y if x.dtype == torch.float32 else y.to(x.dtype)
     if res is not None:

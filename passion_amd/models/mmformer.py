@@ -174,8 +174,8 @@ def intra_grouped(model, x5, mask, B, bf16):
     training = trs[0].training
 
     def gnorm(mods, t):
-        if _ln_ok(t):
-            return ops.ln_act(t, mods)               # one launch, four affine sets (csrc/token_ops.hip)
+        if _ln_ok(t):                                # one launch, four affine sets, straight into the GEMM's bf16 operand
+            return ops.ln_act(t, mods, out_dtype=torch.bfloat16 if bf16 else None)
         n = F.layer_norm(t, (C,), None, None, mods[0].eps)
         return torch.addcmul(_gstack([m.bias for m in mods]).unsqueeze(1), n, _gstack([m.weight for m in mods]).unsqueeze(1))
 
@@ -315,6 +315,11 @@ class SelfAttention(nn.Module):
         return self.proj_drop(self.proj(x))
 
 
+def _autocast_bf16():
+    """bf16 when the token GEMMs run under bf16 autocast (their Linear casts its input then: the LayerNorm in front writes it directly)"""
+    return torch.bfloat16 if (torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") == torch.bfloat16) else None
+
+
 class Residual(nn.Module):
     def __init__(self, fn):
         super().__init__()
@@ -331,7 +336,7 @@ class PreNorm(nn.Module):
         self.fn = fn
 
     def forward(self, x):
-        return self.fn(_ln(self.norm, x))
+        return self.fn(_ln(self.norm, x, out_dtype=_autocast_bf16()))
 
 
 class PreNormDrop(nn.Module):
@@ -342,7 +347,7 @@ class PreNormDrop(nn.Module):
         self.fn = fn
 
     def forward(self, x):
-        return self.dropout(self.fn(_ln(self.norm, x)))
+        return self.dropout(self.fn(_ln(self.norm, x, out_dtype=_autocast_bf16())))
 
 
 class GELU(nn.Module):

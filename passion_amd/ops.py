@@ -1090,7 +1090,7 @@ class LnActFn(torch.autograd.Function):
     forward, two backward (csrc/token_ops.hip).  x: (G, R, C) or any (..., C) with G = 1; params: G gammas then G betas."""
 
     @staticmethod
-    def forward(ctx, x, res, act, eps, G, *params):
+    def forward(ctx, x, res, act, eps, G, out_dtype, *params):
         L.require_gpu(x)
         ctx.box = None
         if len(params) == 1 and isinstance(params[0], _Box):      # direct-gradient mode
@@ -1103,12 +1103,13 @@ class LnActFn(torch.autograd.Function):
         if res is not None:
             res = res.contiguous()
             assert res.shape == x.shape and res.dtype == x.dtype
-        y = torch.empty_like(x)
+        out_dtype = x.dtype if out_dtype is None else out_dtype     # bf16 out of an f32 input: the cast the next GEMM would launch
+        y = torch.empty(x.shape, dtype=out_dtype, device=x.device)
         stat = torch.empty(rows, 2, dtype=torch.float32, device=x.device)
-        L.check(L.load().passion_ln_act_fwd(_p(x), _p(gam), _p(bet), _p(res), _p(y), _p(stat), L.dtype_code(x.dtype), rows, C, rows // G,
-                                            float(eps), int(act), L.stream_ptr()), "passion_ln_act_fwd")
+        L.check(L.load().passion_ln_act_fwd(_p(x), _p(gam), _p(bet), _p(res), _p(y), _p(stat), L.dtype_code(x.dtype), L.dtype_code(out_dtype),
+                                            rows, C, rows // G, float(eps), int(act), L.stream_ptr()), "passion_ln_act_fwd")
         ctx.save_for_backward(x, res if act else None, stat, gam, bet)
-        ctx.act, ctx.G, ctx.has_res = int(act), G, res is not None
+        ctx.act, ctx.G, ctx.has_res, ctx.out_dtype = int(act), G, res is not None, out_dtype
         return y
 
     @staticmethod
@@ -1117,25 +1118,29 @@ class LnActFn(torch.autograd.Function):
         G, C = ctx.G, x.shape[-1]
         rows = x.numel() // C
         dy = dy.contiguous()
+        if dy.dtype != ctx.out_dtype:
+            dy = dy.to(ctx.out_dtype)
         lib = L.load()
         dx = torch.empty_like(x)
         dres = torch.empty_like(x) if (ctx.has_res and ctx.act) else None
         part = torch.empty(lib.passion_ln_act_part_floats(rows, C, rows // G), dtype=torch.float32, device=x.device)
         dgb = torch.empty(2, G, C, dtype=torch.float32, device=x.device)
         L.check(lib.passion_ln_act_bwd(_p(x), _p(gam), _p(bet), _p(res), _p(stat), _p(dy), _p(dx), _p(dres), _p(part), _p(dgb[0]), _p(dgb[1]),
-                                       L.dtype_code(x.dtype), rows, C, rows // G, ctx.act, L.stream_ptr()), "passion_ln_act_bwd")
+                                       L.dtype_code(x.dtype), L.dtype_code(ctx.out_dtype), rows, C, rows // G, ctx.act, L.stream_ptr()),
+                "passion_ln_act_bwd")
         if ctx.has_res and not ctx.act:
             dres = dy
         if ctx.box is not None:
             for g in range(G):
                 _give(ctx.box.params[g], dgb[0, g])
                 _give(ctx.box.params[G + g], dgb[1, g])
-            return dx, dres, None, None, None, None
-        return (dx, dres, None, None, None, *[dgb[0, g] for g in range(G)], *[dgb[1, g] for g in range(G)])
+            return dx, dres, None, None, None, None, None
+        return (dx, dres, None, None, None, None, *[dgb[0, g] for g in range(G)], *[dgb[1, g] for g in range(G)])
 
 
-def ln_act(x, norms, act=False, res=None):
-    """norms: one nn.LayerNorm or a list of G (x then is (G, R, C), group g normalised with norms[g]'s affine)"""
+def ln_act(x, norms, act=False, res=None, out_dtype=None):
+    """norms: one nn.LayerNorm or a list of G (x then is (G, R, C), group g normalised with norms[g]'s affine).
+    out_dtype=torch.bfloat16 with an f32 x (no res): the result leaves in bf16, what the GEMM behind it would cast it to"""
     if not isinstance(norms, (list, tuple)):
         norms = [norms]
     G, C = len(norms), x.shape[-1]
@@ -1144,9 +1149,11 @@ def ln_act(x, norms, act=False, res=None):
     if not (x.is_cuda and L.load().passion_ln_act_supported(rows, C, rows // G)):
         raise RuntimeError(f"ln_act: unsupported shape rows={rows} C={C} G={G} (C / 8 must be a power of two, C <= 512) or not on the GPU")
     params = [n.weight for n in norms] + [n.bias for n in norms]
+    if out_dtype is not None and (out_dtype == x.dtype or res is not None or x.dtype != torch.float32):
+        out_dtype = None
     if _direct(x, params):
-        return LnActFn.apply(x, res, bool(act), norms[0].eps, G, _Box(params))
-    return LnActFn.apply(x, res, bool(act), norms[0].eps, G, *params)
+        return LnActFn.apply(x, res, bool(act), norms[0].eps, G, out_dtype, _Box(params))
+    return LnActFn.apply(x, res, bool(act), norms[0].eps, G, out_dtype, *params)
 
 
 class GroupConvFn(torch.autograd.Function):

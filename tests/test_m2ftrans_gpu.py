@@ -329,6 +329,36 @@ def test_fused_layernorm_act(G, R, C, act, with_res, dtype):
         assert a is None or torch.equal(a, b)
 
 
+@pytest.mark.parametrize("G,R,C", [(1, 2048, 512), (4, 512, 512), (2, 77, 64)])
+def test_fused_layernorm_bf16_out_of_f32_tokens(G, R, C):
+    """ln_act(x f32, out_dtype=bf16) -- the f32 residual stream of the mmformer transformers normalised straight into the bf16
+    operand of the next GEMM -- is BIT FOR BIT the f32 kernel followed by torch's cast, forward and backward (the backward reads a
+    bf16 dy where the other path casts it to f32 first)"""
+    from passion_amd import ops
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(7 * G + C)
+    x = (torch.randn(G, R, C, generator=g) * 2 + 0.5)
+    go = torch.randn(G, R, C, generator=g).to(torch.bfloat16)
+    outs = []
+    for mixed in (False, True):
+        nd = [torch.nn.LayerNorm(C, eps=1e-5).to(dev) for _ in range(G)]
+        gg = torch.Generator().manual_seed(3)
+        for n in nd:
+            with torch.no_grad():
+                n.weight.copy_((torch.rand(C, generator=gg) + 0.5).to(dev))
+                n.bias.copy_((torch.randn(C, generator=gg) * 0.3).to(dev))
+        xd = x.to(dev).requires_grad_(True)
+        y = ops.ln_act(xd, nd if G > 1 else nd[0], out_dtype=torch.bfloat16 if mixed else None)
+        if not mixed:
+            y = y.to(torch.bfloat16)
+        assert y.dtype == torch.bfloat16
+        y.backward(go.to(dev))
+        outs.append((y.detach().clone(), xd.grad.clone(), torch.stack([n.weight.grad for n in nd]), torch.stack([n.bias.grad for n in nd])))
+    assert outs[1][1].dtype == torch.float32
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+
+
 def test_m2ftrans_direct_gradients_change_nothing():
     """train.train_step's direct-gradient mode (ops._DIRECT / host set_direct_grads: the token Functions and the conv nodes write
     `.grad` themselves, no AccumulateGrad nodes) on the m2ftrans backbone: two bf16 PASSION steps end in bit-identical parameters"""
