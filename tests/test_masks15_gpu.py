@@ -6,7 +6,7 @@ import pytest
 import torch
 
 from _util import build_m2ftrans, build_product_model, gold, mask_dice, rel, synth
-from test_masks15_oracle import check_sweep
+from test_masks15_oracle import check_sweep, check_train
 
 pytestmark = pytest.mark.gpu
 NAMES = ["mmformer", "rfnet", "m2ftrans"]
@@ -73,3 +73,24 @@ def test_inference_over_all_masks_bf16(name):
     print(f"[masks15 bf16 {name}] mean |dp| per subset max {float(mad.max()):.2e}; mask agreement min {agree.min():.4f}")
     assert float(mad.max()) < 2e-2, mad
     assert agree.min() > 0.9, agree
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_passion_training_outputs_over_all_masks(name):
+    """training-mode forward with the PASSION heads (teacher + students, prototypes, distances) for every modality subset against
+    the imported reference (masks15_train.npz), f32 1e-3; subsets whose reference output is exactly zero (a single present
+    modality has no student to distil) must come out zero"""
+    from passion_amd.utils import criterions
+    g = gold("masks15_train.npz")
+    S = int(g["S"])
+    dev = _dev()
+    m = _build(name, S).to(dev)
+    m.is_training, m.mask_type, m.use_passion, m.compute_dtype = True, "idt", True, torch.float32
+    m.eval()
+    x, target = synth(1, S, blobs=True)
+    x, target = x.to(dev), target.to(dev)
+    with torch.no_grad():
+        for row in range(15):
+            mask = torch.from_numpy(g["masks"][row:row + 1]).to(dev)
+            outs = m(x, mask, target=target, temp=4.0)
+            check_train(g, name, row, outs, criterions.seg_pair_bs(outs[0], target), 1e-3)

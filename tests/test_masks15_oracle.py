@@ -45,3 +45,35 @@ def test_oracle_inference_over_all_masks(name):
         pred = torch.cat([ref.forward(W, x, mask[i:i + 1]) for i in range(15)])      # f32 GEMM paths: 4.5e-5 on m2ftrans)
     assert pred.shape == (15, 4, S, S, S)
     check_sweep(g, name, pred, 2e-5)
+
+
+TRAIN_KEYS = ["prm_loss", "sep_loss", "kl_loss", "proto_loss", "dist"]
+
+
+def check_train(g, name, row, outs, fuse_bs, tol):
+    """outs: Model.forward's training tuple for fixture mask `row`; fuse_bs: the (B, 1) loss pair of the fused prediction"""
+    assert rel(outs[0].detach().double().sum((2, 3, 4)), g[name + "_pred_sum"][row]) < tol
+    assert rel(fuse_bs, g[name + "_fuse_loss_bs"][row]) < tol
+    for n, o in zip(TRAIN_KEYS, outs[1:]):
+        ref = g[f"{name}_{n}"][row]
+        if np.abs(ref).max() == 0.0:                       # e.g. a single present modality: no student differs from the teacher
+            assert float(o.detach().abs().max()) < 1e-6, (name, row, n)
+        else:
+            assert rel(o, ref) < tol, (name, row, n, o, ref)
+
+
+@pytest.mark.parametrize("name", list(NETS))
+def test_oracle_passion_training_outputs_over_all_masks(name):
+    """training-mode forward with the PASSION heads for every modality subset (masks15_train.npz, tools/make_golden_masks.py)"""
+    from oracle import criterions_ref as C
+    g = gold("masks15_train.npz")
+    S = int(g["S"])
+    ref, weights = NETS[name]
+    x, target = synth(1, S, blobs=True)
+    W = weights()
+    with torch.no_grad():
+        for row in range(15):
+            mask = torch.from_numpy(g["masks"][row:row + 1])
+            outs = ref.forward(W, x, mask, target, 4.0, "idt", True, True)
+            fuse = C.softmax_weighted_loss_bs(outs[0], target) + C.dice_loss_bs(outs[0], target)
+            check_train(g, name, row, outs, fuse, 5e-5)

@@ -5,7 +5,7 @@ container only; same shims and builders as tools/make_golden.py / make_golden_m2
 full RFNet with float16-representable weights, identical to the committed weights_small / weights_m2f / weights_rfnet fixtures --
 asserted below).  model.is_training = False, model.eval(), torch.no_grad(): forward returns the fused prediction only.
 
-    python tools/make_golden_masks.py      -> tests/golden/masks15.npz
+    python tools/make_golden_masks.py      -> tests/golden/masks15.npz, masks15_train.npz (the PASSION training outputs per subset)
 
 Per model: argmax (15, S, S, S) uint8, the mid-depth slice of the probabilities (15, 4, S, S), their per-class sums (15, 4) and
 `tie` (15, S^3 / 8 packed bits): voxels whose top-2 margin is below 1e-3 in the reference, where an argmax may legitimately flip."""
@@ -46,9 +46,26 @@ def sweep(model, x):
     return {"argmax": np.stack(am), "pred_slice": np.stack(sl), "pred_sum": np.stack(sm), "tie": np.stack(tie)}
 
 
+def sweep_train(model, crit, x, target):
+    """training-mode forward with the PASSION heads (mask_type idt, temp 4, dropout off) per subset: the fused prediction's loss pair
+    and the five loss / distance outputs of Model.forward (reference mmformer.py:610-659 and its rfnet / m2ftrans twins)"""
+    model.is_training, model.mask_type, model.use_passion = True, "idt", True
+    model.eval()
+    rec = {k: [] for k in ("fuse_loss_bs", "prm_loss", "sep_loss", "kl_loss", "proto_loss", "dist", "pred_sum")}
+    with torch.no_grad():
+        for mk in MASKS:
+            outs = model(x, torch.tensor([mk]), target=target, temp=4.0)
+            pred = outs[0]
+            rec["fuse_loss_bs"].append((crit.softmax_weighted_loss_bs(pred, target, num_cls=4) + crit.dice_loss_bs(pred, target, num_cls=4)).numpy())
+            rec["pred_sum"].append(pred.double().sum((2, 3, 4)).numpy())
+            for n, o in zip(["prm_loss", "sep_loss", "kl_loss", "proto_loss", "dist"], outs[1:]):
+                rec[n].append(o.detach().numpy())
+    return {k: np.stack(v) for k, v in rec.items()}
+
+
 def main():
     torch.set_num_threads(8)
-    mmformer, _ = mg.import_reference()
+    mmformer, crit = mg.import_reference()
     from models import m2ftrans, rfnet
     import make_golden_m2f as m2g
     x, _ = mg.synth(1, S, blobs=False)
@@ -70,6 +87,13 @@ def main():
     for k, v in sweep(f, x).items():
         out["m2ftrans_" + k] = v
     np.savez_compressed(os.path.join(mg.OUT, "masks15.npz"), **out)
+    xb, tb = mg.synth(1, S, blobs=True)
+    tr = {"S": np.array(S), "masks": np.array(MASKS)}
+    for name, mod in (("mmformer", m), ("rfnet", r), ("m2ftrans", f)):
+        for k, v in sweep_train(mod, crit, xb, tb).items():
+            tr[f"{name}_{k}"] = v
+    np.savez_compressed(os.path.join(mg.OUT, "masks15_train.npz"), **tr)
+    print("masks15_train.npz:", {k: v.shape for k, v in tr.items() if k.startswith("mmformer_")})
     for name in ("mmformer", "rfnet", "m2ftrans"):
         print(name, "ties per mask:", [int(np.unpackbits(t).sum()) for t in out[name + "_tie"]])
 
