@@ -75,8 +75,9 @@ def test_inference_over_all_masks_bf16(name):
     assert agree.min() > 0.9, agree
 
 
+@pytest.mark.parametrize("mask_type", ["idt", "pdt"])
 @pytest.mark.parametrize("name", NAMES)
-def test_passion_training_outputs_over_all_masks(name):
+def test_passion_training_outputs_over_all_masks(name, mask_type):
     """training-mode forward with the PASSION heads (teacher + students, prototypes, distances) for every modality subset against
     the imported reference (masks15_train.npz), f32 1e-3; subsets whose reference output is exactly zero (a single present
     modality has no student to distil) must come out zero"""
@@ -85,7 +86,7 @@ def test_passion_training_outputs_over_all_masks(name):
     S = int(g["S"])
     dev = _dev()
     m = _build(name, S).to(dev)
-    m.is_training, m.mask_type, m.use_passion, m.compute_dtype = True, "idt", True, torch.float32
+    m.is_training, m.mask_type, m.use_passion, m.compute_dtype = True, mask_type, True, torch.float32
     m.eval()
     x, target = synth(1, S, blobs=True)
     x, target = x.to(dev), target.to(dev)
@@ -93,4 +94,4 @@ def test_passion_training_outputs_over_all_masks(name):
         for row in range(15):
             mask = torch.from_numpy(g["masks"][row:row + 1]).to(dev)
             outs = m(x, mask, target=target, temp=4.0)
-            check_train(g, name, row, outs, criterions.seg_pair_bs(outs[0], target), 1e-3)
+            check_train(g, name + ("_pdt" if mask_type == "pdt" else ""), row, outs, criterions.seg_pair_bs(outs[0], target), 1e-3)

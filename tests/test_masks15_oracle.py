@@ -51,7 +51,8 @@ TRAIN_KEYS = ["prm_loss", "sep_loss", "kl_loss", "proto_loss", "dist"]
 
 
 def check_train(g, name, row, outs, fuse_bs, tol):
-    """outs: Model.forward's training tuple for fixture mask `row`; fuse_bs: the (B, 1) loss pair of the fused prediction"""
+    """outs: Model.forward's training tuple for fixture mask `row`; fuse_bs: the (B, 1) loss pair of the fused prediction;
+    name: 'mmformer' | 'rfnet' | 'm2ftrans', + '_pdt' for the mask_type 'pdt' sweep"""
     assert rel(outs[0].detach().double().sum((2, 3, 4)), g[name + "_pred_sum"][row]) < tol
     assert rel(fuse_bs, g[name + "_fuse_loss_bs"][row]) < tol
     for n, o in zip(TRAIN_KEYS, outs[1:]):
@@ -62,9 +63,11 @@ def check_train(g, name, row, outs, fuse_bs, tol):
             assert rel(o, ref) < tol, (name, row, n, o, ref)
 
 
+@pytest.mark.parametrize("mask_type", ["idt", "pdt"])
 @pytest.mark.parametrize("name", list(NETS))
-def test_oracle_passion_training_outputs_over_all_masks(name):
-    """training-mode forward with the PASSION heads for every modality subset (masks15_train.npz, tools/make_golden_masks.py)"""
+def test_oracle_passion_training_outputs_over_all_masks(name, mask_type):
+    """training-mode forward with the PASSION heads for every modality subset (masks15_train.npz, tools/make_golden_masks.py),
+    both mask types (train.py:234-237: 'pdt' takes its own branch in forward)"""
     from oracle import criterions_ref as C
     g = gold("masks15_train.npz")
     S = int(g["S"])
@@ -74,6 +77,6 @@ def test_oracle_passion_training_outputs_over_all_masks(name):
     with torch.no_grad():
         for row in range(15):
             mask = torch.from_numpy(g["masks"][row:row + 1])
-            outs = ref.forward(W, x, mask, target, 4.0, "idt", True, True)
+            outs = ref.forward(W, x, mask, target, 4.0, mask_type, True, True)
             fuse = C.softmax_weighted_loss_bs(outs[0], target) + C.dice_loss_bs(outs[0], target)
-            check_train(g, name, row, outs, fuse, 5e-5)
+            check_train(g, name + ("_pdt" if mask_type == "pdt" else ""), row, outs, fuse, 5e-5)

@@ -46,10 +46,10 @@ def sweep(model, x):
     return {"argmax": np.stack(am), "pred_slice": np.stack(sl), "pred_sum": np.stack(sm), "tie": np.stack(tie)}
 
 
-def sweep_train(model, crit, x, target):
+def sweep_train(model, crit, x, target, mask_type="idt"):
     """training-mode forward with the PASSION heads (mask_type idt, temp 4, dropout off) per subset: the fused prediction's loss pair
     and the five loss / distance outputs of Model.forward (reference mmformer.py:610-659 and its rfnet / m2ftrans twins)"""
-    model.is_training, model.mask_type, model.use_passion = True, "idt", True
+    model.is_training, model.mask_type, model.use_passion = True, mask_type, True
     model.eval()
     rec = {k: [] for k in ("fuse_loss_bs", "prm_loss", "sep_loss", "kl_loss", "proto_loss", "dist", "pred_sum")}
     with torch.no_grad():
@@ -92,6 +92,8 @@ def main():
     for name, mod in (("mmformer", m), ("rfnet", r), ("m2ftrans", f)):
         for k, v in sweep_train(mod, crit, xb, tb).items():
             tr[f"{name}_{k}"] = v
+        for k, v in sweep_train(mod, crit, xb, tb, "pdt").items():          # mask_type 'pdt' (train.py:234-237): its own branch in forward
+            tr[f"{name}_pdt_{k}"] = v
     np.savez_compressed(os.path.join(mg.OUT, "masks15_train.npz"), **tr)
     print("masks15_train.npz:", {k: v.shape for k, v in tr.items() if k.startswith("mmformer_")})
     for name in ("mmformer", "rfnet", "m2ftrans"):
