@@ -6,7 +6,7 @@ import pytest
 import torch
 
 from _util import build_m2ftrans, build_product_model, gold, mask_dice, rel, synth
-from test_masks15_oracle import check_sweep, check_train
+from test_masks15_oracle import STEP_GTOL, STEP_GTOL_ROW, check_step, check_sweep, check_train
 
 pytestmark = pytest.mark.gpu
 NAMES = ["mmformer", "rfnet", "m2ftrans"]
@@ -95,3 +95,33 @@ def test_passion_training_outputs_over_all_masks(name, mask_type):
             mask = torch.from_numpy(g["masks"][row:row + 1]).to(dev)
             outs = m(x, mask, target=target, temp=4.0)
             check_train(g, name + ("_pdt" if mask_type == "pdt" else ""), row, outs, criterions.seg_pair_bs(outs[0], target), 1e-3)
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_training_step_gradients_over_all_masks(name):
+    """forward + train.assemble_loss + backward of the product for EVERY modality subset against the imported reference: loss 1e-3,
+    the relative-preference gate, the gradient norm of every top-level module -- the encoders of absent modalities must end
+    with exactly no gradient, shared decoders with the present ones' only"""
+    from _util import grad_norms
+    from passion_amd import train as ptrain
+    g = gold("masks15_train.npz")
+    S = int(g["S"])
+    dev = _dev()
+    m = _build(name, S).to(dev)
+    m.is_training, m.mask_type, m.use_passion, m.compute_dtype = True, "idt", True, torch.float32
+    m.eval()
+    x, target = synth(1, S, blobs=True)
+    x, target = x.to(dev), target.to(dev)
+    worst = 0.0
+    for row in range(15):
+        mask = torch.from_numpy(g["masks"][row:row + 1]).to(dev)
+        m.zero_grad(set_to_none=True)
+        outs = m(x, mask, target=target, temp=4.0)
+        loss = ptrain.assemble_loss(outs, target, mask, "idt", True)
+        loss.backward()
+        rp = ptrain.relative_preference(outs[5], mask.float(), True).cpu().numpy()
+        gn = grad_norms((k, p.grad) for k, p in m.named_parameters())
+        w = check_step(g, name, row, loss.detach(), rp, gn, 1e-3, STEP_GTOL_ROW.get((name, row), STEP_GTOL[name]))
+        if (name, row) not in STEP_GTOL_ROW:
+            worst = max(worst, w)
+    print(f"[masks15 step {name}] worst relative gradient-norm error over the subsets held to {STEP_GTOL[name]:g}: {worst:.2e}")

@@ -63,6 +63,31 @@ def sweep_train(model, crit, x, target, mask_type="idt"):
     return {k: np.stack(v) for k, v in rec.items()}
 
 
+def sweep_grads(model, crit, x, target):
+    """one training step's loss (train.py:228-280 with imb_beta = modal_weight = 1, as tools/make_golden.py assembles it) and the
+    gradient norm of every top-level module, per subset: a masked modality's encoder must end up with a zero gradient, the shared
+    decoders with the gradient of the present ones only"""
+    model.is_training, model.mask_type, model.use_passion = True, "idt", True
+    model.eval()
+    losses, rps, norms, keys = [], [], [], None
+    for mk in MASKS:
+        mask_t = torch.tensor([mk])
+        outs = model(x, mask_t, target=target, temp=4.0)
+        fuse = crit.softmax_weighted_loss_bs(outs[0], target, num_cls=4) + crit.dice_loss_bs(outs[0], target, num_cls=4)
+        m_ = mask_t.float()
+        sep_m, kl_m, proto_m = (outs[2] * m_).sum(0), (outs[3] * m_).sum(0), (outs[4] * m_).sum(0)
+        rp = m_[0] * (outs[5][0] / (outs[5][0].sum() / m_[0].sum()) - 1)
+        rp_mask = (rp > 0).float()
+        loss = fuse.sum() + outs[1].sum() + (rp_mask * sep_m).sum() + 0.5 * kl_m.sum() + 0.1 * (rp_mask * proto_m).sum()
+        model.zero_grad()
+        loss.backward()
+        gn = mg.grad_norms(model)
+        keys = sorted(gn) if keys is None else keys
+        assert sorted(gn) == keys
+        losses.append(float(loss)); rps.append(rp_mask.numpy().copy()); norms.append([gn[k] for k in keys])
+    return {"loss": np.array(losses), "rp_mask": np.stack(rps), "grad_norms": np.array(norms), "grad_keys": np.array(keys)}
+
+
 def main():
     torch.set_num_threads(8)
     mmformer, crit = mg.import_reference()
@@ -94,6 +119,9 @@ def main():
             tr[f"{name}_{k}"] = v
         for k, v in sweep_train(mod, crit, xb, tb, "pdt").items():          # mask_type 'pdt' (train.py:234-237): its own branch in forward
             tr[f"{name}_pdt_{k}"] = v
+    for name, mod in (("mmformer", m), ("rfnet", r), ("m2ftrans", f)):
+        for k, v in sweep_grads(mod, crit, xb, tb).items():
+            tr[f"{name}_step_{k}"] = v
     np.savez_compressed(os.path.join(mg.OUT, "masks15_train.npz"), **tr)
     print("masks15_train.npz:", {k: v.shape for k, v in tr.items() if k.startswith("mmformer_")})
     for name in ("mmformer", "rfnet", "m2ftrans"):
