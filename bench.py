@@ -58,6 +58,11 @@ def parse():
                          "(default: full for configs[1]/[3], split for configs[2])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=2, help="timed oracle steps of the cpu_baseline leg (after 1 warm-up)")
+    ap.add_argument("--launch", default="auto", choices=["auto", "graph", "eager"],
+                    help="graph: the training step is recorded once as a HIP graph (passion_amd.graph.GraphedStep: train.train_step under "
+                         "stream capture after the warm-up steps) and the timed steps replay it, with the batch / AdamW scalars / dropout "
+                         "seeds handed over through device memory; eager: every launch issued from Python each step.  auto = graph on one "
+                         "GPU for the data-parallel workloads, eager for N > 1 (gradient all-reduce from autograd hooks) and the depth path")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-dice", action="store_true", help="skip the dice_vs_ref leg (fixture replay after the timed region)")
     return ap.parse_args()
@@ -308,6 +313,18 @@ def main():
         # a new batch every iteration.
         return ptrain.train_step(model, opt, x, mk, target.view(target.shape), 4.0, state, reducer)
 
+    use_graph = (args.launch == "graph" or (args.launch == "auto" and os.environ.get("PASSION_BENCH_GRAPH", "1") != "0")) \
+        and ctx.world == 1 and not is_depth
+    gstep = None
+    if use_graph:
+        from passion_amd.graph import GraphedStep
+        gstep = GraphedStep(model, opt, 4.0, state, warm=2)       # two eager steps on the recording's own stream first (per-stream scratch, allocator pool)
+
+    def graph_step():
+        mk = masks[it_no[0] % len(masks)]
+        it_no[0] += 1
+        return gstep(x, mk, target.view(target.shape))       # batch copied into the recording's static tensors every step
+
     step = eager_step
     if is_depth:
         from passion_amd import depth
@@ -393,6 +410,21 @@ def main():
         torch.cuda.synchronize()
         ops.prof_filter(*flt)
         ops.prof_enable(1 << dom_kind)
+        if use_graph:
+            # a replayed graph cannot carry host-readable event pairs (hipEventElapsedTime refuses event nodes): the reported
+            # kernel's live launches are timed in eager steps of this process right here, all streams running, then the events go off
+            for _ in range(max(3, args.warmup)):
+                eager_step()
+            torch.cuda.synchronize()
+            ops.prof_enable(0)
+            ops.prof_filter()
+            graph_live_recs = ops.prof_read()
+    if use_graph:
+        step = graph_step
+        for _ in range(5):                          # two eager steps on the capture stream, the recording (+ its replay), two more replays
+            step()
+        parallel.barrier(ctx)
+        torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
@@ -410,7 +442,7 @@ def main():
     dt = parallel.all_reduce_max(ctx, dt)
     final_loss = float(loss)
 
-    timed_recs = ops.prof_read() if want_events else []
+    timed_recs = (graph_live_recs if use_graph else ops.prof_read()) if want_events else []
 
     if ctx.rank != 0:
         return
@@ -441,7 +473,9 @@ def main():
                    "global_batch": batch * ctx.world, "parallelism": f"dp{ctx.world} (RCCL grad all-reduce, sum)",
                    "world_size_seen": dist.get_world_size() if dist.is_initialized() else 1, "dist_backend": ctx.backend,
                    "allreduce_bytes_per_step": grad_bytes if ctx.world > 1 else 0,
-                   "final_loss": round(final_loss, 5), "launch": "eager"},
+                   "final_loss": round(final_loss, 5),
+                   "launch": ("HIP graph replay of train.train_step (recorded once after the warm-up; batch, AdamW scalars and dropout "
+                              "seeds through device memory)" if use_graph else "eager")},
     }
     if want_events:
         recs = [r for r in timed_recs if r[1] >= 0]
@@ -466,16 +500,20 @@ def main():
             wf = dgrad_complete(dom, live_all, alone_recs, [r for r in live_all if r[4] == dom], ak)
             rl = {"kernel": f"{dom} ({WHAT[rk[0][0]]})", "bound": "hbm", "achieved": round(ach, 2),
                   "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic,
-                  "frac_is": "live: this kernel's launches inside the timed region, other streams' kernels sharing the CUs",
+                  "frac_is": ("live: this kernel's launches in eager steps next to the timed region, other streams' kernels sharing the CUs"
+                              if use_graph else "live: this kernel's launches inside the timed region, other streams' kernels sharing the CUs"),
                   "frac_live": round(ach / HBM_PEAK_GBS, 5),
                   "frac_single_stream": round(alone_ach / HBM_PEAK_GBS, 5) if alone_ach else None,
                   "measured_copy_peak": round(copy_gbs, 1), "frac_of_measured_copy": round(ach / copy_gbs, 5),
                   "avg_launch_ms_single_stream": round(alone_ms, 5) if alone_ms else None,
-                  "launches_per_step": len(rk) // args.steps, "avg_launch_ms": round(ms / len(rk), 5),
+                  "launches_per_step": len(rk) // (max(3, args.warmup) if use_graph else args.steps), "avg_launch_ms": round(ms / len(rk), 5),
                   "algorithmic_bytes_per_launch": round(by / len(rk), 1),
                   "tflops": round(fl / (ms * 1e-3) / 1e12, 3),
-                  "events": "live, inside the timed region (this kernel's launches only; finish / attention figures: "
-                            "warm-up steps, equally live)",
+                  "events": ("live eager steps of this process right before the timed region, all streams running (the timed steps "
+                             "replay a HIP graph, which cannot carry host-readable event pairs); finish / attention figures: warm-up steps, "
+                             "equally live" if use_graph else
+                             "live, inside the timed region (this kernel's launches only; finish / attention figures: "
+                             "warm-up steps, equally live)"),
                   **wf,
                   "ms_per_step_by_family": {FAM[k]: round(v / max(1, args.warmup), 3) for k, v in sorted(fam_warm.items())}}
             if "with_finish" in wf:

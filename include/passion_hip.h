@@ -344,6 +344,20 @@ int passion_adamw_step(int n, float* const* params, const float* const* grads, f
                        float* const* exp_avg_sq, float* const* max_exp_avg_sq, const int64_t* numel, double lr,
                        double beta1, double beta2, double eps, double weight_decay, int64_t step, int amsgrad,
                        void* stream);
+/* ---- a training step recorded once as a HIP graph and replayed (code/train.py:222-289 is the same launch sequence every
+ * iteration): whatever changes from replay to replay must come from device memory, not from kernel arguments.
+ * passion_adamw_hyper: the three step-dependent scalars of the update on the host, out3 = {lr * weight_decay, lr / (1 - beta1^step),
+ * 1 / sqrt(1 - beta2^step)}; passion_adamw_step_dev: the same update as passion_adamw_step reading them from hyper_dev (device,
+ * 3 floats) when the kernel runs.  passion_write_words: n <= 16 32-bit words (HOST array, passed by value) stored to dst (device)
+ * by a one-block kernel on `stream` -- how the host hands the next replay its scalars.  passion_set_step_words(dev): from now on
+ * every attention-dropout launch (passion_flash_attn_*, passion_dropout) adds the 64-bit word at dev[0..1] to its seed when it
+ * RUNS (NULL = off, the default): a replay then draws fresh masks, and forward / backward of one replay agree. */
+int passion_adamw_hyper(double lr, double beta1, double beta2, double weight_decay, int64_t step, float* out3);
+int passion_adamw_step_dev(int n, float* const* params, const float* const* grads, float* const* exp_avg,
+                           float* const* exp_avg_sq, float* const* max_exp_avg_sq, const int64_t* numel,
+                           double beta1, double beta2, double eps, int amsgrad, const float* hyper_dev, void* stream);
+int passion_write_words(void* dst, int n, const uint32_t* words, void* stream);
+void passion_set_step_words(const void* dev_words);
 
 /* ---- training input pipeline on the GPU -------------------------------------------------
  * One sample: crop [S0][S1][S2][C] f32 (the RandCrop3D window, code/data/transforms.py:217-230) and its labels

@@ -140,6 +140,11 @@ SIGNATURES = {
                                 c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "passion_adamw_step": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_double, c_double,
                                    c_double, c_double, c_double, c_int64, c_int, c_void_p]),
+    "passion_adamw_hyper": (c_int, [c_double, c_double, c_double, c_double, c_int64, c_void_p]),
+    "passion_adamw_step_dev": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_double, c_double, c_double,
+                                       c_int, c_void_p, c_void_p]),
+    "passion_write_words": (c_int, [c_void_p, c_int, c_void_p, c_void_p]),
+    "passion_set_step_words": (None, [c_void_p]),
     "passion_set_option": (c_int, [c_char_p, c_int]),
     "passion_prof_enable": (None, [c_int]),
     "passion_prof_filter": (None, [c_double, c_double]),

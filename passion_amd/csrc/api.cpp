@@ -59,6 +59,23 @@ void passion_prof_tag(const char* fmt, ...) {
 
 extern "C" int passion_abi_version(void) { return 1; }
 
+// ---- step words: what changes from one replay of a captured training step to the next lives in device memory
+const unsigned* g_passion_step_words = nullptr;
+extern "C" void passion_set_step_words(const void* dev_words) { g_passion_step_words = static_cast<const unsigned*>(dev_words); }
+namespace {
+struct Words16 { uint32_t w[16]; };
+__global__ void write_words_kernel(uint32_t* dst, int n, Words16 v) {
+    if ((int)threadIdx.x < n) dst[threadIdx.x] = v.w[threadIdx.x];
+}
+}  // namespace
+extern "C" int passion_write_words(void* dst, int n, const uint32_t* words, void* stream) {
+    if (n < 0 || n > 16 || !dst) return -1003;
+    Words16 v;
+    for (int i = 0; i < 16; ++i) v.w[i] = i < n ? words[i] : 0u;
+    hipLaunchKernelGGL(write_words_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, static_cast<uint32_t*>(dst), n, v);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
 // ---- per-stream scratch (conv_common.h): tickets (kept zero by the kernels that use them) + uninitialised slots
 #include "conv_common.h"
 namespace {

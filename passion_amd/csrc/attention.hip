@@ -434,12 +434,14 @@ extern "C" int passion_attn_scores_bwd(const float* probs, float* dprobs, const 
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+extern const unsigned* g_passion_step_words;      // api.cpp
 // Attention dropout, mask regenerated from (seed, index): torch's rand_like / >= / two multiplies were four passes over
 // the (B, H, N, N) f32 probabilities forward (168 M elements for the inter-modal transformer with the five PASSION
 // passes) plus a stored mask; this is one pass each way.  splitmix64 of (seed, index / 4) yields four 16-bit uniforms.
 namespace {
 __global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ x, float* __restrict__ y, long n4, long n, unsigned thr,
-                                                      float inv_keep, unsigned long long seed) {
+                                                      float inv_keep, unsigned long long seed, const unsigned* soff) {
+    if (soff) seed += (unsigned long long)soff[0] | ((unsigned long long)soff[1] << 32);     // replayed HIP graph: passion_set_step_words
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
         unsigned long long z = (unsigned long long)i + seed * 0x9E3779B97F4A7C15ull;
         z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
@@ -468,7 +470,7 @@ extern "C" int passion_dropout(const float* x, float* y, int64_t n, float p, uin
     long gx = (n4 + 255) / 256;
     if (gx > 65536) gx = 65536;
     hipLaunchKernelGGL(dropout_kernel, dim3((unsigned)gx), dim3(256), 0, (hipStream_t)stream, x, y, n4, (long)n, thr, 1.0f / (1.0f - p),
-                       (unsigned long long)seed);
+                       (unsigned long long)seed, g_passion_step_words);
     LAUNCH_RET();
     return 0;
 }

@@ -23,6 +23,7 @@
 
 int g_flash_split = 0;      // option "flash_split" / PASSION_FLASH_SPLIT: 0 = automatic, n = that many splits (1 = the unsplit kernels)
 namespace pconv { int stream_scratch(hipStream_t st, size_t zero_bytes, size_t plain_bytes, void** zero, void** plain); }   // api.cpp
+extern const unsigned* g_passion_step_words;      // api.cpp: passion_set_step_words
 
 namespace {
 
@@ -53,6 +54,7 @@ struct FlashP {
     unsigned thr;               // keep when the 16-bit uniform >= thr; 0 = no dropout
     float inv_keep;
     unsigned s0, s1;            // seed halves
+    const unsigned* soff;       // device words added to the seed at run time (a replayed HIP graph: passion_set_step_words), or nullptr
     // split-K (small batches: fewer query tiles than SIMDs): `nsplit` workgroups share a query (key) tile, each walks 1 / nsplit of
     // the key (query) blocks and leaves UNNORMALISED f32 partials; flash_combine_* merges them (fixed order: bit-reproducible)
     int nsplit;
@@ -149,6 +151,7 @@ __device__ __forceinline__ float half_sum(float v) {
 // grid (ceil(N / (32 NW)), H, B), block 64 NW: wave w owns queries q0 .. q0+31
 template <int NW, int MODE>
 __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2))) void flash_q_kernel(FlashP p) {
+    const unsigned ds0 = p.s0 + (p.soff ? p.soff[0] : 0u), ds1 = p.s1 + (p.soff ? p.soff[1] : 0u);
     constexpr int NT = 64 * NW;
     constexpr int KIMG = BLK * RS, VIMG = (MODE == 0) ? BLK * TS : BLK * RS;
     extern __shared__ __attribute__((aligned(16))) char lds[];      // [2][K image | V image]
@@ -291,7 +294,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2))) vo
 #pragma unroll
                 for (int r = 0; r < 16; r += 2) {
                     const unsigned key = (unsigned)(key0 + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h);
-                    const unsigned u = drop_hash(rowpair + (key >> 1), p.s0, p.s1);
+                    const unsigned u = drop_hash(rowpair + (key >> 1), ds0, ds1);
                     const bool k0 = (u & 0xffffu) >= p.thr, k1 = (u >> 16) >= p.thr;
                     if (MODE == 0) {
                         st[kt][r] = k0 ? st[kt][r] : 0.f;
@@ -375,6 +378,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2))) vo
 // steps of 64 (Q and dO staged in LDS, read by rows for S / dP and transposed for dK^T / dV^T; lse, delta beside them)
 template <int NW>
 __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2))) void flash_k_kernel(FlashP p) {
+    const unsigned ds0 = p.s0 + (p.soff ? p.soff[0] : 0u), ds1 = p.s1 + (p.soff ? p.soff[1] : 0u);
     constexpr int NT = 64 * NW;
     constexpr int IMG = BLK * RS, BUF = 2 * IMG + 2 * BLK * 4;
     extern __shared__ __attribute__((aligned(16))) char lds[];      // [2][Q image | dO image | lse[64] | delta[64]]
@@ -475,7 +479,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2))) vo
 #pragma unroll
                     for (int jp = 0; jp < 2; ++jp) {
                         const unsigned qq = (unsigned)(q0 + qt * 32 + 8 * g4 + 4 * h + 2 * jp) + khalf;
-                        const unsigned u = drop_hash((bhrow + qq) * npair + kpair, p.s0, p.s1);
+                        const unsigned u = drop_hash((bhrow + qq) * npair + kpair, ds0, ds1);
                         const unsigned mine = __builtin_amdgcn_ubfe(u, 16u * khalf, 16u), send = __builtin_amdgcn_ubfe(u, 16u - 16u * khalf, 16u);
                         const unsigned recv = (unsigned)__builtin_amdgcn_update_dpp(0, (int)send, 0xB1, 0xf, 0xf, false);      // quad_perm [1,0,3,2]
                         const bool km = mine >= p.thr, ko = recv >= p.thr;
@@ -660,6 +664,7 @@ int set_dropout(FlashP& p, float drop_p, uint64_t seed) {
     p.inv_keep = p.thr ? 1.0f / (1.0f - (float)p.thr / 65536.0f) : 1.0f;
     p.s0 = (unsigned)(seed & 0xffffffffu);
     p.s1 = (unsigned)(seed >> 32);
+    p.soff = g_passion_step_words;
     return 0;
 }
 

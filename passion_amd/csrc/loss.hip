@@ -793,7 +793,10 @@ struct AdamEnt { float* p; const float* g; float* m; float* v; float* vmax; long
 struct AdamTable { AdamEnt e[ADAM_MAX]; };
 
 __global__ __launch_bounds__(256) void adamw_multi_kernel(AdamTable t, float lr_wd, float omb1, float b2, float omb2, float step_size,
-                                                          float inv_bc2_sqrt, float eps, int amsgrad) {
+                                                          float inv_bc2_sqrt, float eps, int amsgrad, const float* hyp) {
+    if (hyp) {      // a replayed HIP graph: the step-dependent scalars come from device memory (passion_adamw_step_dev)
+        lr_wd = hyp[0]; step_size = hyp[1]; inv_bc2_sqrt = hyp[2];
+    }
     const AdamEnt& q = t.e[blockIdx.y];
     const long n4 = q.n / 4;
     const bool vec = ((((size_t)q.p | (size_t)q.g | (size_t)q.m | (size_t)q.v | (size_t)q.vmax) & 15) == 0);
@@ -828,9 +831,35 @@ __global__ __launch_bounds__(256) void adamw_multi_kernel(AdamTable t, float lr_
 }
 }  // namespace
 
+extern "C" int passion_adamw_hyper(double lr, double beta1d, double beta2d, double weight_decay, int64_t step, float* out3) {
+    if (step < 1) return -1031;
+    const double bc1 = 1.0 - pow(beta1d, (double)step), bc2 = 1.0 - pow(beta2d, (double)step);
+    out3[0] = (float)(lr * weight_decay); out3[1] = (float)(lr / bc1); out3[2] = (float)(1.0 / sqrt(bc2));
+    return 0;
+}
+
+static int adamw_step_impl(int n, float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
+                           float* const* max_exp_avg_sq, const int64_t* numel, double lr, double beta1d, double beta2d, double eps,
+                           double weight_decay, int64_t step, int amsgrad, const float* hyp, void* stream);
+
 extern "C" int passion_adamw_step(int n, float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
                                   float* const* max_exp_avg_sq, const int64_t* numel, double lr, double beta1d, double beta2d, double eps,
                                   double weight_decay, int64_t step, int amsgrad, void* stream) {
+    return adamw_step_impl(n, params, grads, exp_avg, exp_avg_sq, max_exp_avg_sq, numel, lr, beta1d, beta2d, eps, weight_decay, step, amsgrad,
+                           nullptr, stream);
+}
+
+extern "C" int passion_adamw_step_dev(int n, float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
+                                      float* const* max_exp_avg_sq, const int64_t* numel, double beta1d, double beta2d, double eps,
+                                      int amsgrad, const float* hyper_dev, void* stream) {
+    if (!hyper_dev) return -1031;
+    return adamw_step_impl(n, params, grads, exp_avg, exp_avg_sq, max_exp_avg_sq, numel, 0.0, beta1d, beta2d, eps, 0.0, 1, amsgrad, hyper_dev,
+                           stream);
+}
+
+static int adamw_step_impl(int n, float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
+                           float* const* max_exp_avg_sq, const int64_t* numel, double lr, double beta1d, double beta2d, double eps,
+                           double weight_decay, int64_t step, int amsgrad, const float* hyp, void* stream) {
     if (step < 1) return -1031;
     const float beta2 = (float)beta2d;
     const double bc1 = 1.0 - pow(beta1d, (double)step), bc2 = 1.0 - pow(beta2d, (double)step);
@@ -846,7 +875,7 @@ extern "C" int passion_adamw_step(int n, float* const* params, const float* cons
         }
         const int gx = (int)hmax(1, hmin(256, (nmax / 4 + 255) / 256));
         hipLaunchKernelGGL(adamw_multi_kernel, dim3(gx, m), dim3(256), 0, (hipStream_t)stream, t, (float)(lr * weight_decay),
-                           (float)(1.0 - (double)beta1d), beta2, (float)(1.0 - (double)beta2d), step_size, inv_bc2_sqrt, (float)eps, amsgrad);
+                           (float)(1.0 - (double)beta1d), beta2, (float)(1.0 - (double)beta2d), step_size, inv_bc2_sqrt, (float)eps, amsgrad, hyp);
         LAUNCH_RET();
     }
     return 0;

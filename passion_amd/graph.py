@@ -1,0 +1,109 @@
+"""One training iteration recorded as a HIP graph and replayed.
+
+The reference's hot loop (code/train.py:222-289: forward, loss assembly, backward, optimizer.step()) issues the same launches in
+the same order every iteration; on the MI355X build that is ~620 launches on five streams, and the host needs ~11 ms to enqueue
+what the GPU executes in ~12.  `GraphedStep` keeps train.train_step as the ONLY definition of the step -- it calls it
+eagerly for the first `warm` iterations (allocator pools, per-stream scratch of the library, LDS grants, packed weight images), then
+records one call of it with torch.cuda.graph (stream capture: the side streams of the model become branches of the graph) and
+replays the recording from then on.  What differs between iterations lives in device memory:
+  * the batch: x / mask / target are copied into the static tensors the recording reads (the label volume is converted to its f32
+    channels-last image inside the recording, every replay);
+  * AdamW's step-dependent scalars and the learning rate: passion_adamw_step_dev reads them from device words that
+    FusedAdamW.graph_tick() rewrites before every replay (optim.py), so `param_groups[i]["lr"]` may change between replays;
+  * attention dropout: the kernels add a 64-bit device word to the seed they were recorded with (passion_set_step_words); the word is
+    redrawn from torch's CPU generator before every replay.  torch's own dropout (token dropout of the transformers) is handled by
+    torch's graph-safe Philox state.
+Everything else (modality masks, imb_beta / modal_weight, the relative-preference gate, the epoch accumulators) already was
+device-side data (train.assemble_loss has no host synchronisation).
+
+Single process only: with more than one rank the gradient all-reduce is issued from autograd hooks (parallel.GradReducer) and the
+step stays eager.
+"""
+import ctypes
+from ctypes import c_void_p
+
+import torch
+
+from . import _lib as L
+from . import train as ptrain
+
+
+class GraphedStep:
+    def __init__(self, model, optimizer, temp=4.0, state=None, warmup=False, modal_num=None, iter_per_epoch=None, warm=3):
+        if not hasattr(optimizer, "begin_capture"):
+            raise L.PassionHipError("GraphedStep needs passion_amd.optim.FusedAdamW (train.make_optimizer on a GPU model)")
+        self.model, self.optimizer = model, optimizer
+        self.kw = dict(temp=temp, state=state, reducer=None, warmup=warmup, modal_num=modal_num, iter_per_epoch=iter_per_epoch)
+        self.warm = int(warm)
+        self.calls = 0
+        self.graph = None
+        self.stream = None
+        self.sig = None
+        self.replays = 0
+
+    # ------------------------------------------------------------------------------------------
+    def _signature(self, x, mask, target):
+        m = self.model
+        return (tuple(x.shape), x.dtype, tuple(mask.shape), tuple(target.shape), target.dtype, m.mask_type, bool(m.use_passion),
+                m.compute_dtype, bool(m.training))
+
+    def _eager(self, x, mask, target):
+        dev = x.device
+        cur = torch.cuda.current_stream(dev)
+        self.stream.wait_stream(cur)
+        with torch.cuda.stream(self.stream):
+            loss = ptrain.train_step(self.model, self.optimizer, x, mask, target, **self.kw)
+        cur.wait_stream(self.stream)
+        return loss
+
+    def _record(self, x, mask, target):
+        dev = x.device
+        lib = L.load()
+        self.sx, self.smask, self.starget = x.clone(), mask.to(device=dev, dtype=torch.bool).clone(), target.clone()
+        self.words = torch.zeros(32, dtype=torch.float32, device=dev)      # [0, 2): dropout seed offset; [16, 32): AdamW scalars
+        self.hyper = self.words[16:]
+        torch.cuda.synchronize(dev)
+        g = torch.cuda.CUDAGraph()
+        lib.passion_set_step_words(c_void_p(self.words.data_ptr()))
+        self.optimizer.begin_capture(self.hyper)
+        try:
+            with torch.cuda.graph(g, stream=self.stream):
+                # a view: ops.target_to_cl keeps the converted copy on the tensor OBJECT it is given
+                self.loss = ptrain.train_step(self.model, self.optimizer, self.sx, self.smask, self.starget.view(self.starget.shape),
+                                              **self.kw)
+        finally:
+            lib.passion_set_step_words(None)
+            self.cap = self.optimizer.end_capture()
+        self.graph = g
+
+    def _replay(self, x, mask, target):
+        if x is not self.sx:
+            self.sx.copy_(x, non_blocking=True)
+        if mask is not self.smask:
+            self.smask.copy_(mask, non_blocking=True)
+        if target is not self.starget:
+            self.starget.copy_(target, non_blocking=True)
+        seed = int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())      # CPU generator: follows torch.manual_seed
+        w = (ctypes.c_uint32 * 2)(seed & 0xffffffff, (seed >> 32) & 0xffffffff)
+        L.check(L.load().passion_write_words(self.words.data_ptr(), 2, ctypes.cast(w, c_void_p), L.stream_ptr()), "passion_write_words")
+        self.optimizer.graph_tick(self.cap)
+        self.graph.replay()
+        self.replays += 1
+        return self.loss
+
+    def __call__(self, x, mask, target):
+        """one training iteration on (x, mask, target); returns the loss (a static tensor once the step is recorded: the next call
+        overwrites it)"""
+        L.require_gpu(x)
+        sig = self._signature(x, mask, target)
+        if self.sig is not None and sig != self.sig:
+            raise L.PassionHipError(f"GraphedStep was built for {self.sig}, called with {sig}: build another one (or call train_step)")
+        self.sig = sig
+        if self.stream is None:
+            self.stream = torch.cuda.Stream(device=x.device)
+        self.calls += 1
+        if self.graph is None:
+            if self.calls <= self.warm:
+                return self._eager(x, mask, target)
+            self._record(x, mask, target)          # records, does not execute: the replay below is this call's iteration
+        return self._replay(x, mask, target)

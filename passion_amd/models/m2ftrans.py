@@ -278,11 +278,8 @@ def fusion_allow(mask):
     """mask_gen_fusion (reference mask.py:5-22) in block form: (B,5,5) bytes -- a modality's tokens attend to themselves, the
     fusion tokens to the present modalities and to themselves"""
     B = mask.shape[0]
-    allow = torch.zeros(B, 5, 5, dtype=torch.uint8, device=mask.device)
-    idx = torch.arange(4, device=mask.device)
-    allow[:, idx, idx] = 1
+    allow = torch.eye(5, dtype=torch.uint8, device=mask.device).unsqueeze(0).repeat(B, 1, 1)      # (no index tensors: capturable)
     allow[:, 4, :4] = mask.to(torch.uint8)
-    allow[:, 4, 4] = 1
     return allow
 
 

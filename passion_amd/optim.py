@@ -18,6 +18,7 @@ class FusedAdamW(torch.optim.Optimizer):
         super().__init__(params, defaults)
         self._tables = {}
         self._stepped = set()        # data_ptr of the parameters step_ready() already updated in this iteration
+        self._capture = None         # HIP-graph capture (passion_amd.graph): {"hyper": device f32 [4 slots x 4], "subs": [...]}
 
     @torch.no_grad()
     def step_ready(self):
@@ -105,6 +106,19 @@ class FusedAdamW(torch.optim.Optimizer):
                         if not g.is_contiguous():
                             g = p.grad = g.contiguous()
                         garr[j] = g.data_ptr()
+                if self._capture is not None:
+                    # being recorded into a HIP graph: the step-dependent scalars (lr * wd, lr / bias correction 1, 1 / sqrt(bias
+                    # correction 2)) are read from device memory by the kernel; graph_tick() counts the step and writes them
+                    # before every replay
+                    cap = self._capture
+                    slot = len(cap["subs"])
+                    if slot >= 4:
+                        raise L.PassionHipError("FusedAdamW: more than four distinct step counts in one recorded step")
+                    cap["subs"].append((sub, group))
+                    L.check(lib.passion_adamw_step_dev(len(sub["idx"]), sub["p"], garr, sub["m"], sub["v"], sub["vm"], sub["numel"],
+                                                       float(b1), float(b2), float(group["eps"]), 1 if group["amsgrad"] else 0,
+                                                       cap["hyper"].data_ptr() + 16 * slot, L.stream_ptr()), "passion_adamw_step_dev")
+                    continue
                 sub["step"] += 1
                 L.check(lib.passion_adamw_step(len(sub["idx"]), sub["p"], garr, sub["m"], sub["v"], sub["vm"], sub["numel"],
                                                float(group["lr"]), float(b1), float(b2), float(group["eps"]),
@@ -115,6 +129,33 @@ class FusedAdamW(torch.optim.Optimizer):
             torch.autograd.graph.increment_version(ps)
             if partial:
                 self._stepped.update(cur_pptr)
+
+    # ---- a recorded training step (passion_amd.graph.GraphedStep)
+    def begin_capture(self, hyper):
+        """hyper: device f32 tensor of >= 16 elements; until end_capture() the launches read their scalars from it"""
+        self._capture = {"hyper": hyper, "subs": []}
+
+    def end_capture(self):
+        cap, self._capture = self._capture, None
+        return cap
+
+    def graph_tick(self, cap):
+        """before a replay of the step recorded under `cap`: count the step of every launch in it and hand the kernels their
+        scalars (one tiny launch on the current stream, values passed by value: nothing on the host has to outlive the call)"""
+        import ctypes
+        lib = L.load()
+        words = (ctypes.c_float * 16)()
+        out3 = (ctypes.c_float * 3)()
+        for slot, (sub, group) in enumerate(cap["subs"]):
+            sub["step"] += 1
+            b1, b2 = group["betas"]
+            L.check(lib.passion_adamw_hyper(float(group["lr"]), float(b1), float(b2), float(group["weight_decay"]), sub["step"],
+                                            ctypes.cast(out3, c_void_p)), "passion_adamw_hyper")
+            words[4 * slot:4 * slot + 3] = out3[:]
+        L.check(lib.passion_write_words(cap["hyper"].data_ptr(), 4 * len(cap["subs"]), ctypes.cast(words, c_void_p), L.stream_ptr()),
+                "passion_write_words")
+        # the kernels write the parameters behind autograd's back (see _step_impl)
+        torch.autograd.graph.increment_version([p for g in self.param_groups for p in g["params"]])
 
     def zero_grad(self, set_to_none=True):
         host = L.host() if set_to_none and all(p.is_cuda for g in self.param_groups for p in g["params"]) else None
