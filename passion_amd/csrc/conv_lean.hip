@@ -899,6 +899,10 @@ int launch_conv_lean(ConvK& k, int ksize, int stride, int mode, const void* pack
         const int rc = launch_conv_pw_dgrad(k, K8, st);
         if (rc <= 0) return rc;
     }
+    {   // levels 3..5: K chunks side by side, weights straight from L2 (conv_deep.hip); > 0 = not covered: the brick kernels below
+        const int rc = launch_conv_deep(k, ksize, stride, mode, st);
+        if (rc <= 0) return rc;
+    }
     if (ksize == 1) return dgrad ? launch_lean_geo<1, 1>(k, K8, cmax, mtiles, st) : launch_lean_geo<1, 0>(k, K8, cmax, mtiles, st);
     if (mode == 2 && stride == 2) return launch_lean_geo<3, 2, 2>(k, K8, cmax, mtiles, st);
     if (mode == 2) return launch_lean_geo<3, 2>(k, K8, cmax, mtiles, st);

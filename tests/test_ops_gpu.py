@@ -64,6 +64,17 @@ CONV_CASES = [
     ([128, 128, 128, 128], 128, 1, 1, 0, (8, 8, 8), True, True, False),
     ([128, 128, 128, 128], 64, 3, 1, 1, (4, 4, 8), True, True, False),
     ([256, 128], 32, 3, 1, 0, (4, 8, 8), True, False, False),
+    # levels 3..5 at their sizes in a 128^3 step and in the reference's 80^3 crop (conv_deep.hip: K chunks side by side)
+    ([32], 32, 3, 1, 1, (32, 32, 32), True, False, True),
+    ([64], 64, 3, 1, 1, (16, 16, 16), True, False, False),
+    ([128], 128, 3, 1, 1, (8, 8, 8), True, False, True),
+    ([64, 64], 64, 3, 1, 1, (16, 16, 16), True, True, False),
+    ([128], 128, 3, 1, 0, (8, 8, 8), True, False, False),
+    ([128], 128, 3, 1, 1, (5, 5, 5), True, False, False),
+    ([64], 64, 3, 1, 1, (10, 10, 10), True, False, False),
+    ([32, 32], 32, 3, 1, 1, (20, 20, 20), True, False, False),
+    ([64], 64, 1, 1, 0, (16, 16, 16), True, False, False),
+    ([64, 64, 64, 64], 64, 1, 1, 0, (10, 10, 10), True, True, False),
 ]
 
 

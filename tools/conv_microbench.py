@@ -11,7 +11,7 @@ stride = int(sys.argv[6]) if len(sys.argv) > 6 else 1
 iters = int(sys.argv[7]) if len(sys.argv) > 7 else 50
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
-segs_c = [8] * (cin // 8) if cin > 8 and cin <= 32 else [cin]
+segs_c = [8] * (cin // 8) if cin > 8 and cin <= 32 and not os.environ.get('MB_ONESEG') else [cin]
 NB = int(os.environ.get('MB_BATCH', '1'))
 xs = [torch.randn(NB, S, S, S, c, device=dev).to(torch.bfloat16).requires_grad_(mode == "bwd") for c in segs_c]
 w = (torch.randn(cout, cin, k, k, k, device=dev) / (cin * k ** 3) ** 0.5).requires_grad_(True)
@@ -48,4 +48,4 @@ for kind in range(4):
     r = [x for x in recs if x[0] == kind]
     if r:
         ms = sum(x[1] for x in r) / len(r)
-        print(f"  {names[kind]}: {ms*1e3:.1f} us  {r[0][2]/ms/1e6:.0f} GB/s  {r[0][3]/ms/1e9:.1f} TFLOP/s")
+        print(f"  {names[kind]}: {ms*1e3:.1f} us  {r[0][2]/ms/1e6:.0f} GB/s  {r[0][3]/ms/1e9:.1f} TFLOP/s  {r[0][4]}")
