@@ -1103,7 +1103,7 @@ static int conv3d_bwd_impl(const passion_conv_desc_t* d, const float* packed, co
         if (dbg) fprintf(stderr, "[pwfinal] B=%d V=%ld Cin=%d Cout=%d nseg=%d: final=%d all_norm=%d bd=%d any_bmod=%d bf16=%d chunk=%d leancov=%d gxmod=%d pwcov=%d\n",
                          k.B, (long)k.Di * k.Hi * k.Wi, k.Cin, k.Cout, k.nseg, (int)pw_final, (int)all_norm, (int)pw_bd, (int)any_bmod, (int)wpl.bf16,
                          wgrad_bf16_chunk(k, 1, 1), (int)wgrad_lean_covers(k, 1, 1, wpl.MT, wpl.gx, wpl.gy), wpl.gx % k.B, (int)conv_pw_dgrad_covers(k, kblocks, bphys));
-    } else if (d->ksize == 1 && getenv("PASSION_PWFINAL_DBG")) {
+    } else if (d->ksize == 1 && []() { static const bool dbg2 = getenv("PASSION_PWFINAL_DBG") != nullptr; return dbg2; }()) {
         fprintf(stderr, "[pwfinal] B=%d V=%ld Cin=%d Cout=%d: not planned (phase %d ga %d parts %d need_dx %d need_norm %d dW %d db %d dt %d/%d)\n", k.B,
                 (long)k.Di * k.Hi * k.Wi, k.Cin, k.Cout, phase, ga != nullptr, parts, (int)need_dx, (int)need_norm, dweight != nullptr, dbias != nullptr, d->x_dtype, d->y_dtype);
     }

@@ -350,6 +350,12 @@ class Model(nn.Module):
             cache[dev] = [getattr(self, f"masks_mod{i}").to(dev) for i in range(4)]
         return cache[dev]
 
+    @property
+    def module(self):
+        """the reference reaches the model through DataParallel's `.module` (code/train.py:91-92,212: model.module.mask_type = ...);
+        with one process per GPU there is no wrapper, the model answers for it"""
+        return self
+
     def forward(self, x, mask, target=None, temp=1.0):
         L.require_gpu(x)
         ops.repack_stale()
@@ -446,7 +452,13 @@ class Model(nn.Module):
         for i in range(4):
             # a sample whose data mask IS one-hot i feeds student i exactly what the teacher saw: the reference gets 0 exactly
             # (and train.py:266-267 turns that 0/0 into an all-false rp_mask); rows of one batched launch may round differently
+            # -- with dropout OFF.  Under model.train() the reference runs every student through its own Bottleneck / decoder_fusion
+            # call with fresh dropout (m2ftrans.py:585-641: MaskedTransformer 0.1, MultiCrossToken 0.1): student != teacher, the terms
+            # are positive and feed epoch_dist_m / the relative-preference gate; the rows of the batched launch draw different
+            # dropout masks here as well, so nothing is imposed then
             differs = (~(mask == onehots[i]).all(1)).float().view(B, 1)
+            if self.training:
+                differs = torch.ones_like(differs)
             proto_loss = proto_loss + gates[i] * pl_all[i] * differs
             dist = dist + gates[i] * d_all[i] * differs
             kl_loss = kl_loss + gates[i] * kl_all[i] * differs

@@ -482,6 +482,12 @@ class Model(nn.Module):
             cache[dev] = [getattr(self, f"masks_mod{i}").to(dev) for i in range(4)]
         return cache[dev]
 
+    @property
+    def module(self):
+        """the reference reaches the model through DataParallel's `.module` (code/train.py:91-92,212: model.module.mask_type = ...);
+        with one process per GPU there is no wrapper, the model answers for it"""
+        return self
+
     def forward(self, x, mask, target=None, temp=1.0):
         L.require_gpu(x)
         ops.repack_stale()       # all conv weights the optimizer touched, one launch
@@ -712,9 +718,15 @@ class Model(nn.Module):
         # kernels) gets kl = proto = dist = 0 *exactly* -- and train.py:266-267 then turns that 0/0 into an all-false rp_mask.
         # Teacher and student are different rows of one batched launch here (GEMM rounding may differ per row), so the identity
         # is imposed instead of hoped for.  (Not for T2: its tokens are T1's, mmformer.py:522.)
+        # With dropout LIVE (model.train(): the reference's training loop) every pass of the reference draws its own dropout masks in
+        # the inter-modal transformer (mmformer.py:468-531), so such a student differs from the teacher and its kl / proto / dist are
+        # small positive numbers there, as they are here (teacher and students are different rows of the batched dropout): nothing
+        # is imposed then.
         only = mask & (mask.sum(1, keepdim=True) == 1)                                # [b, i]: i is sample b's only modality
         differs = (~only).float()
         differs[:, 3] = 1.0
+        if self.training:
+            differs = torch.ones_like(differs)
         gd = gate * differs
         kl_loss = gd * kl_all.view(4, B).t()
         proto_loss = gd * pl_all.view(4, B).t()

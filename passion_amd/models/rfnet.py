@@ -193,6 +193,12 @@ class Model(nn.Module):
             cache[dev] = [getattr(self, f"masks_mod{i}").to(dev) for i in range(4)]
         return cache[dev]
 
+    @property
+    def module(self):
+        """the reference reaches the model through DataParallel's `.module` (code/train.py:91-92,212: model.module.mask_type = ...);
+        with one process per GPU there is no wrapper, the model answers for it"""
+        return self
+
     def forward(self, x, mask, target=None, temp=1.0):
         L.require_gpu(x)
         ops.repack_stale()       # all conv weights the optimizer touched, one launch

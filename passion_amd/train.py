@@ -161,6 +161,8 @@ def train_step(model, optimizer, x, mask, target, temp=4.0, state=None, reducer=
     net = model
     net.is_training = True
     early = EARLY_STEP and hasattr(optimizer, "step_ready") and (reducer is None or reducer.ctx.world == 1) and x.is_cuda
+    if hasattr(optimizer, "_stepped"):
+        optimizer._stepped.clear()       # a backward that raised after the early part left its marks: this iteration starts clean
     ops._MARKER_CB[0] = _early_step_callback(net, optimizer) if early else None
     from . import _lib as L
     host = L.host() if x.is_cuda else None
@@ -242,6 +244,18 @@ def main(argv=None):
     from .models import mmformer
     from .options import args_parser
     args = args_parser(argv)
+    # --gpu (reference train.py:33: CUDA_VISIBLE_DEVICES = args.gpu): honoured for a single process when the box has those devices
+    # and nothing else selected one; under torchrun LOCAL_RANK picks the device.  Said aloud when it is not applied.
+    if "WORLD_SIZE" not in os.environ and not any(v in os.environ for v in ("HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES",
+                                                                          "PASSION_DEVICE_INDEX")):
+        try:
+            ids = [int(t) for t in str(args.gpu).split(",") if t.strip() != ""]
+        except ValueError:
+            ids = []
+        if ids and max(ids) < torch.cuda.device_count():       # device_count() does not initialise the GPU
+            os.environ["HIP_VISIBLE_DEVICES"] = ",".join(str(i) for i in ids)
+        elif ids:
+            print(f"[train] --gpu {args.gpu}: this box has {torch.cuda.device_count()} device(s); using device 0", flush=True)
     ctx = parallel.init()
     torch.manual_seed(args.seed)
     if args.model == "mmformer":
