@@ -330,6 +330,23 @@ int passion_region_mix_bwd(const void* const* y, void* const* dy, const uint8_t*
 /* bmod > 0: y holds only bmod samples and (virtual) sample b of the B given reads y[b % bmod] -- the masked passes of the
  * PASSION students over the same features in one launch; mask, prob, w, out, dy stay indexed by b. */
 
+/* ---- the deep-supervision terms with the x k upsampling inside (code/models/mmformer.py:366-370, 540-544: up2 / up4 / up8 / up16 of
+ * a coarse softmax, then softmax_weighted_loss_bs + dice_loss_bs, criterions.py:59-76, 25-38; the students' temp_kl_loss_bs against the
+ * upsampled teacher, criterions.py:92-103).  probs_coarse / ps_coarse / pt_coarse: f32 channels-last [B][D][H][W][4] (teacher: Bt
+ * samples, student b against teacher b % Bt); target: [Bt][(D k)(H k)(W k)][4].  The x k map is blended in registers from the coarse
+ * one (align_corners=True, the arithmetic of passion_upsample_fwd) and never materialised.  sums / work as for the plain entry points;
+ * backward: scratch of passion_up_loss_bwd_scratch_floats(B, D, H, W, k) floats (the separable adjoint's two intermediates), result =
+ * gradient wrt the COARSE map.  (D k)(H k)(W k) < 2^23; -1021 otherwise (callers then upsample explicitly). */
+int passion_wce_dice_up_fwd(const float* probs_coarse, const float* target, int B, int Bt, int D, int H, int W, int k,
+                            float* sums, float* out, void* stream);
+int passion_wce_dice_up_bwd(const float* probs_coarse, const float* target, const float* sums, const float* g,
+                            float* dprobs_coarse, int B, int Bt, int D, int H, int W, int k, float* scratch, void* stream);
+int passion_kl_up_fwd(const float* ps_coarse, const float* pt_coarse, int B, int Bt, int D, int H, int W, int k, float temp,
+                      float* out, float* work, void* stream);
+int passion_kl_up_bwd(const float* ps_coarse, const float* pt_coarse, const float* g, float* dps_coarse, int B, int Bt, int D,
+                      int H, int W, int k, float temp, float* scratch, void* stream);
+int64_t passion_up_loss_bwd_scratch_floats(int B, int D, int H, int W, int k);
+
 /* ---- bias gradient of the token GEMMs (nn.Linear of code/models/mmformer.py:196-199, 254-262): out[c] = sum_r g[r][c],
  * g [R][C] row-major (dtype), out f32 [C], C even.  Fixed summation order (bit-reproducible, also next to other streams).
  * work: f32 scratch of passion_colsum_work_floats(C) floats. */

@@ -81,6 +81,13 @@ SIGNATURES = {
                                      c_int64, c_int, c_void_p, c_void_p, c_void_p]),
     "passion_wce_dice_bwd": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p,
                                      c_void_p, c_void_p, c_int, c_int, c_int64, c_int, c_void_p]),
+    "passion_wce_dice_up_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "passion_wce_dice_up_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p,
+                                        c_void_p]),
+    "passion_kl_up_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p]),
+    "passion_kl_up_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p,
+                                  c_void_p]),
+    "passion_up_loss_bwd_scratch_floats": (c_int64, [c_int, c_int, c_int, c_int, c_int]),
     "passion_colsum_work_floats": (c_int64, [c_int]),
     "passion_colsum": (c_int, [c_void_p, c_int, c_int64, c_int, c_void_p, c_void_p, c_void_p]),
     "passion_colsum_batched": (c_int, [c_void_p, c_int, c_int, c_int64, c_int, c_void_p, c_void_p, c_void_p]),

@@ -14,6 +14,63 @@ namespace {
 
 constexpr int NC = 4;  // classes
 
+// ---------------------------------------------------------------- x k trilinear sampling of a coarse 4-class tensor (align_corners=True)
+// The deep-supervision terms (reference mmformer.py:366-370, 540-544; criterions.py:59-76, 92-103) score nn.Upsample(x k) of a
+// coarse probability map against the full-size label.  The kernels below read the COARSE map (cache resident: at most 64^3 x 16
+// bytes) and blend the eight neighbours in registers -- same source index arithmetic and association as resample.hip's forward
+// -- so the x k map is never written or read (k = 2 .. 16: 33 MB per map and sample at 128^3, forward and backward).
+struct UpG { int D, H, W, k, Do, Ho, Wo; float sd, sh, sw, inv_wo, inv_ho; };      // coarse dims, factor, fine dims, axis scales
+struct USrc { int i0, i1; float l0, l1; };
+__device__ __forceinline__ USrc u_src(int o, float scale, int in) {
+    USrc s;
+    const float r = scale * (float)o;
+    s.i0 = (int)r;
+    if (s.i0 > in - 1) s.i0 = in - 1;
+    s.i1 = s.i0 + (s.i0 < in - 1 ? 1 : 0);
+    s.l1 = r - (float)s.i0;
+    s.l0 = 1.f - s.l1;
+    return s;
+}
+__device__ __forceinline__ float u_weight(int o, int i, float scale, int in) {      // weight with which output o reads input i
+    const USrc s = u_src(o, scale, in);
+    float w = 0.f;
+    if (s.i0 == i) w += s.l0;
+    if (s.i1 == i) w += s.l1;
+    return w;
+}
+__device__ __forceinline__ void u_range(int i, float scale, int out, int& lo, int& hi) {
+    if (scale <= 0.f) { lo = 0; hi = out - 1; return; }
+    lo = (int)floorf((float)(i - 1) / scale) - 1;
+    hi = (int)ceilf((float)(i + 1) / scale) + 1;
+    if (lo < 0) lo = 0;
+    if (hi > out - 1) hi = out - 1;
+}
+// fine voxel index -> (od, oh, ow); fine volumes here have < 2^23 voxels (checked by the launchers): (v + 0.5) / n through the reciprocal is exact
+__device__ __forceinline__ void u_split(const UpG& g, long v, int& od, int& oh, int& ow) {
+    const int t = (int)(((float)v + 0.5f) * g.inv_wo);
+    ow = (int)v - t * g.Wo;
+    od = (int)(((float)t + 0.5f) * g.inv_ho);
+    oh = t - od * g.Ho;
+}
+// value at fine voxel (od, oh, ow) of sample base xb: ((w-blend) h-blend) d-blend, as upsample_fwd_kernel
+__device__ __forceinline__ f32x4 u_sample(const float* __restrict__ xb, const UpG& g, const USrc& a, const USrc& e, const USrc& f) {
+    const int di[2] = {a.i0, a.i1}, hi[2] = {e.i0, e.i1};
+    const float dl[2] = {a.l0, a.l1}, hl[2] = {e.l0, e.l1};
+    f32x4 r = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        f32x4 rh = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const float* row = xb + (((long)di[p] * g.H + hi[q]) * g.W) * 4;
+            const f32x4 t0 = load4(row + f.i0 * 4), t1 = load4(row + f.i1 * 4);
+            rh += hl[q] * (f.l0 * t0 + f.l1 * t1);
+        }
+        r += dl[p] * rh;
+    }
+    return r;
+}
+
 // ---------------------------------------------------------------- softmax
 __global__ void softmax_fwd_kernel(const float* __restrict__ lg, long lsb, long lsv, long lsc, float* __restrict__ pr,
                                    long psb, long psv, long psc, int B, long V, float inv_temp) {
@@ -145,7 +202,7 @@ constexpr int RED_BLOCKS_MAX = 1024;
 __global__ __launch_bounds__(256) void wce_dice_sums_kernel(const float* __restrict__ pr, long psb, long psv, long psc,
                                                             const float* __restrict__ tg, long V,
                                                             float* __restrict__ sums, float* __restrict__ part,
-                                                            unsigned* __restrict__ counter, float* __restrict__ out, int Bt) {
+                                                            unsigned* __restrict__ counter, float* __restrict__ out, int Bt, UpG ug) {
     __shared__ float red[4][16];
     const int b = blockIdx.y, bt = b % Bt;              // target of sample b (several predictions per target: Bt < B)
     float a[16];
@@ -153,7 +210,13 @@ __global__ __launch_bounds__(256) void wce_dice_sums_kernel(const float* __restr
     for (int j = 0; j < 16; ++j) a[j] = 0.f;
     for (long v = (long)blockIdx.x * blockDim.x + threadIdx.x; v < V; v += (long)gridDim.x * blockDim.x) {
         float p[NC];
-        if (psc == 1) {
+        if (ug.k > 1) {                                     // pr: the coarse map [B][D][H][W][4]; V: fine voxels
+            int od, oh, ow;
+            u_split(ug, v, od, oh, ow);
+            const f32x4 t = u_sample(pr + (long)b * ug.D * ug.H * ug.W * 4, ug, u_src(od, ug.sd, ug.D), u_src(oh, ug.sh, ug.H), u_src(ow, ug.sw, ug.W));
+#pragma unroll
+            for (int c = 0; c < NC; ++c) p[c] = t[c];
+        } else if (psc == 1) {
             f32x4 t = load4(pr + b * psb + v * psv);
 #pragma unroll
             for (int c = 0; c < NC; ++c) p[c] = t[c];
@@ -230,12 +293,23 @@ __global__ void wce_dice_bwd_kernel(const float* __restrict__ pr, long psb, long
 // against one teacher)
 __global__ __launch_bounds__(256) void kl_fwd_kernel(const float* __restrict__ ps, const float* __restrict__ pt, long V,
                                                      float k, float* __restrict__ out, float* __restrict__ part,
-                                                     unsigned* __restrict__ counter, int Bt) {
+                                                     unsigned* __restrict__ counter, int Bt, UpG ug) {
     __shared__ float red[4];
     const int b = blockIdx.y, bt = b % Bt;
     float a = 0.f;
+    const long vc = (long)ug.D * ug.H * ug.W * 4;           // ug.k > 1: ps / pt are the coarse maps, V the fine voxels
     for (long v = (long)blockIdx.x * blockDim.x + threadIdx.x; v < V; v += (long)gridDim.x * blockDim.x) {
-        const f32x4 s = load4(ps + ((long)b * V + v) * 4), t = load4(pt + ((long)bt * V + v) * 4);
+        f32x4 s, t;
+        if (ug.k > 1) {
+            int od, oh, ow;
+            u_split(ug, v, od, oh, ow);
+            const USrc sa = u_src(od, ug.sd, ug.D), se = u_src(oh, ug.sh, ug.H), sf = u_src(ow, ug.sw, ug.W);
+            s = u_sample(ps + b * vc, ug, sa, se, sf);
+            t = u_sample(pt + bt * vc, ug, sa, se, sf);
+        } else {
+            s = load4(ps + ((long)b * V + v) * 4);
+            t = load4(pt + ((long)bt * V + v) * 4);
+        }
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
             const float sc = fminf(fmaxf(s[c], 0.005f), 1.0f), tc = fminf(fmaxf(t[c], 0.005f), 1.0f);
@@ -263,6 +337,75 @@ __global__ void kl_bwd_kernel(const float* __restrict__ ps, const float* __restr
             d[c] = (s[c] >= 0.005f && s[c] <= 1.0f) ? -gk * tc / s[c] : 0.f;
         }
         store4(dps + ((long)b * V + v) * 4, d);
+    }
+}
+
+
+// Backward of the x k terms: the adjoint of the interpolation is separable (A_d x A_h x A_w, resample.hip).  Its first pass -- the W
+// axis, the contiguous and largest reduction -- is fused with the loss gradient: a thread owns (b, od, oh, iw), walks the fine ow
+// that read coarse column iw, forms the fine probability (eight coarse loads, the D / H taps fixed for the thread), the
+// gradient of the loss wrt it, and sums with the W weights.  tmp [B][Do][Ho][W][4] goes through the H and D axis passes.
+// MODE 0: weighted CE + Dice (coef = the 16 sums of the forward, g = (B, 2)); MODE 1: temperature KL (pt = coarse teacher map, g = (B,)).
+template <int MODE>
+__global__ __launch_bounds__(256) void up_loss_bwdw_kernel(const float* __restrict__ pc, const float* __restrict__ pt,
+                                                           const float* __restrict__ tg, const float* __restrict__ sums,
+                                                           const float* __restrict__ g, float* __restrict__ tmp, UpG ug, int Bt,
+                                                           float kk) {
+    const int b = blockIdx.y, bt = b % Bt;
+    const long V = (long)ug.Do * ug.Ho * ug.Wo, vc = (long)ug.D * ug.H * ug.W * 4;
+    float kce[NC], kd1[NC], kd2[NC], gk = 0.f;
+    if (MODE == 0) {
+        const float* s = sums + b * 16;
+        const float rt = s[8] + s[9] + s[10] + s[11];
+        const float g_ce = g[b * 2 + 0], g_dice = g[b * 2 + 1];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const float w = 1.0f - s[8 + c] / rt;
+            const float den = s[4 + c] + s[8 + c] + 1e-7f;
+            kce[c] = -g_ce * w / (float)V;
+            kd1[c] = -g_dice * 2.0f / ((float)NC * den);
+            kd2[c] = g_dice * 2.0f * s[c] / ((float)NC * den * den);
+        }
+    } else {
+        gk = g[b] * kk;
+    }
+    const float* xb = pc + b * vc;
+    const float* tb = pt + bt * vc;
+    const long items = (long)ug.Do * ug.Ho * ug.W;
+    const float inv_w = 1.0f / (float)ug.W;
+    for (long it = (long)blockIdx.x * blockDim.x + threadIdx.x; it < items; it += (long)gridDim.x * blockDim.x) {
+        const int r = (int)(((float)it + 0.5f) * inv_w), iw = (int)it - r * ug.W;       // r = od * Ho + oh (< 2^23 items)
+        const int od = (int)(((float)r + 0.5f) * ug.inv_ho), oh = r - od * ug.Ho;
+        const USrc a = u_src(od, ug.sd, ug.D), e = u_src(oh, ug.sh, ug.H);
+        int lo, hi;
+        u_range(iw, ug.sw, ug.Wo, lo, hi);
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int ow = lo; ow <= hi; ++ow) {
+            const float ww = u_weight(ow, iw, ug.sw, ug.W);
+            if (ww == 0.f) continue;
+            const USrc f = u_src(ow, ug.sw, ug.W);
+            const f32x4 p = u_sample(xb, ug, a, e, f);
+            const long v = (long)r * ug.Wo + ow;
+            f32x4 d;
+            if (MODE == 0) {
+                const f32x4 t = load4(tg + ((long)bt * V + v) * 4);
+#pragma unroll
+                for (int c = 0; c < NC; ++c) {
+                    float dc = kd1[c] * t[c] + kd2[c];
+                    if (p[c] >= 0.005f && p[c] <= 1.0f) dc += kce[c] * t[c] / p[c];
+                    d[c] = dc;
+                }
+            } else {
+                const f32x4 t = u_sample(tb, ug, a, e, f);
+#pragma unroll
+                for (int c = 0; c < NC; ++c) {
+                    const float tc = fminf(fmaxf(t[c], 0.005f), 1.0f);
+                    d[c] = (p[c] >= 0.005f && p[c] <= 1.0f) ? -gk * tc / p[c] : 0.f;
+                }
+            }
+            acc += ww * d;
+        }
+        store4(tmp + ((long)b * items + it) * 4, acc);
     }
 }
 
@@ -651,9 +794,94 @@ extern "C" int passion_wce_dice_fwd(const float* probs, int64_t psb, int64_t psv
     float* part = sums + 16 * (size_t)B + ((B + 3) & ~3);
     { const int rc_ = tickets(st, B, &counter); if (rc_) return rc_; }
     hipLaunchKernelGGL(wce_dice_sums_kernel, dim3(vgrid_red(V), B), dim3(256), 0, st, probs, (long)psb, (long)psv,
-                       (long)psc, target, (long)V, sums, part, counter, out, Bt);
+                       (long)psc, target, (long)V, sums, part, counter, out, Bt, UpG{1, 1, 1, 1, 1, 1, 1, 0.f, 0.f, 0.f, 1.f, 1.f});
     LAUNCH_RET();
     return 0;
+}
+
+namespace pconv { int upsample_axis_f32(const float* in, float* out, long outer, int Ni, int No, long inner, hipStream_t st); }   // resample.hip
+static int up_geo(int D, int H, int W, int k, UpG& g) {
+    if (k < 2 || D < 1 || H < 1 || W < 1) return -1011;
+    g.D = D; g.H = H; g.W = W; g.k = k; g.Do = D * k; g.Ho = H * k; g.Wo = W * k;
+    if ((long)g.Do * g.Ho * g.Wo >= (1L << 23)) return -1021;       // u_split's reciprocal arithmetic
+    g.sd = g.Do > 1 ? (float)(D - 1) / (float)(g.Do - 1) : 0.f;
+    g.sh = g.Ho > 1 ? (float)(H - 1) / (float)(g.Ho - 1) : 0.f;
+    g.sw = g.Wo > 1 ? (float)(W - 1) / (float)(g.Wo - 1) : 0.f;
+    g.inv_wo = 1.0f / (float)g.Wo; g.inv_ho = 1.0f / (float)g.Ho;
+    return 0;
+}
+
+extern "C" int passion_wce_dice_up_fwd(const float* probs_coarse, const float* target, int B, int Bt, int D, int H, int W, int k,
+                                       float* sums, float* out, void* stream) {
+    UpG ug;
+    { const int rc_ = up_geo(D, H, W, k, ug); if (rc_) return rc_; }
+    if (Bt <= 0) Bt = B;
+    if (B % Bt) return -1017;
+    hipStream_t st = (hipStream_t)stream;
+    unsigned* counter = nullptr;
+    float* part = sums + 16 * (size_t)B + ((B + 3) & ~3);
+    { const int rc_ = tickets(st, B, &counter); if (rc_) return rc_; }
+    const long V = (long)ug.Do * ug.Ho * ug.Wo;
+    hipLaunchKernelGGL(wce_dice_sums_kernel, dim3(vgrid_red(V), B), dim3(256), 0, st, probs_coarse, 0L, 0L, 1L, target, V, sums, part, counter,
+                       out, Bt, ug);
+    LAUNCH_RET();
+    return 0;
+}
+
+extern "C" int64_t passion_up_loss_bwd_scratch_floats(int B, int D, int H, int W, int k) {
+    return (int64_t)B * D * k * H * k * W * 4 + (int64_t)B * D * k * H * W * 4;
+}
+
+// tmp [B][Do][Ho][W][4] <- fused loss gradient + W pass; then the H and D passes of the separable adjoint -> d(coarse map)
+template <int MODE>
+static int up_loss_bwd(const float* pc, const float* pt, const float* tg, const float* sums, const float* g, float* dpc, int B, int Bt,
+                       const UpG& ug, float kk, float* scratch, hipStream_t st) {
+    float* t1 = scratch;
+    float* t2 = scratch + (long)B * ug.Do * ug.Ho * ug.W * 4;
+    const long items = (long)ug.Do * ug.Ho * ug.W;
+    if (items >= (1L << 23)) return -1021;
+    hipLaunchKernelGGL(up_loss_bwdw_kernel<MODE>, dim3((unsigned)hmin((items + 255) / 256, 4096), B), dim3(256), 0, st, pc, pt, tg, sums, g, t1, ug,
+                       Bt, kk);
+    LAUNCH_RET();
+    int rc = pconv::upsample_axis_f32(t1, t2, (long)B * ug.Do, ug.H, ug.Ho, (long)ug.W, st);
+    if (rc) return rc;
+    return pconv::upsample_axis_f32(t2, dpc, (long)B, ug.D, ug.Do, (long)ug.H * ug.W, st);
+}
+
+extern "C" int passion_wce_dice_up_bwd(const float* probs_coarse, const float* target, const float* sums, const float* g, float* dprobs_coarse,
+                                       int B, int Bt, int D, int H, int W, int k, float* scratch, void* stream) {
+    UpG ug;
+    { const int rc_ = up_geo(D, H, W, k, ug); if (rc_) return rc_; }
+    if (Bt <= 0) Bt = B;
+    if (B % Bt || !scratch) return -1017;
+    return up_loss_bwd<0>(probs_coarse, probs_coarse, target, sums, g, dprobs_coarse, B, Bt, ug, 0.f, scratch, (hipStream_t)stream);
+}
+
+extern "C" int passion_kl_up_fwd(const float* ps_coarse, const float* pt_coarse, int B, int Bt, int D, int H, int W, int k, float temp, float* out,
+                                 float* work, void* stream) {
+    UpG ug;
+    { const int rc_ = up_geo(D, H, W, k, ug); if (rc_) return rc_; }
+    if (Bt <= 0) Bt = B;
+    if (B % Bt) return -1017;
+    hipStream_t st = (hipStream_t)stream;
+    unsigned* counter = nullptr;
+    { const int rc_ = tickets(st, B, &counter); if (rc_) return rc_; }
+    const long V = (long)ug.Do * ug.Ho * ug.Wo;
+    const float kk = temp * temp / ((float)NC * (float)V);
+    hipLaunchKernelGGL(kl_fwd_kernel, dim3(vgrid_red(V), B), dim3(256), 0, st, ps_coarse, pt_coarse, V, kk, out, work + ((B + 3) & ~3), counter, Bt, ug);
+    LAUNCH_RET();
+    return 0;
+}
+
+extern "C" int passion_kl_up_bwd(const float* ps_coarse, const float* pt_coarse, const float* g, float* dps_coarse, int B, int Bt, int D, int H,
+                                 int W, int k, float temp, float* scratch, void* stream) {
+    UpG ug;
+    { const int rc_ = up_geo(D, H, W, k, ug); if (rc_) return rc_; }
+    if (Bt <= 0) Bt = B;
+    if (B % Bt || !scratch) return -1017;
+    const long V = (long)ug.Do * ug.Ho * ug.Wo;
+    const float kk = temp * temp / ((float)NC * (float)V);
+    return up_loss_bwd<1>(ps_coarse, pt_coarse, nullptr, nullptr, g, dps_coarse, B, Bt, ug, kk, scratch, (hipStream_t)stream);
 }
 extern "C" int64_t passion_wce_dice_sums_floats(int B) { return 16 * (int64_t)B + red_extra_floats(B, 16); }
 extern "C" int64_t passion_kl_work_floats(int B) { return red_extra_floats(B, 1); }
@@ -680,7 +908,7 @@ extern "C" int passion_kl_fwd(const float* ps, const float* pt, int B, int Bt, i
     { const int rc_ = tickets(st, B, &counter); if (rc_) return rc_; }
     const float k = temp * temp / ((float)NC * (float)V);
     hipLaunchKernelGGL(kl_fwd_kernel, dim3(vgrid_red(V), B), dim3(256), 0, st, ps, pt, (long)V, k, out,
-                       work + ((B + 3) & ~3), counter, Bt);
+                       work + ((B + 3) & ~3), counter, Bt, UpG{1, 1, 1, 1, 1, 1, 1, 0.f, 0.f, 0.f, 1.f, 1.f});
     LAUNCH_RET();
     return 0;
 }

@@ -806,6 +806,13 @@ extern "C" int passion_upsample_fwd_stats(const void* x, void* y, int dtype, int
     return 0;
 }
 
+// one axis pass of the separable adjoint on f32 4-channel vectors, for the fused loss gradients of loss.hip
+namespace pconv {
+int upsample_axis_f32(const float* in, float* out, long outer, int Ni, int No, long inner, hipStream_t st) {
+    return launch_axis<float, float>(in, out, outer, Ni, No, inner, st);
+}
+}  // namespace pconv
+
 extern "C" int64_t passion_upsample_bwd_scratch_floats(int B, int D, int H, int W, int C, int k) {
     if (k <= 2) return 0;
     return (int64_t)B * D * k * H * k * W * C + (int64_t)B * D * k * H * W * C;

@@ -441,7 +441,7 @@ class Model(nn.Module):
 
         inv_t = 1.0 / temp
         pt_full = ops.softmax_classes(fuse_pred.detach(), inv_t, "cl")
-        pt_deep = [ops.upsample(ops.softmax_classes(pp.detach(), inv_t, "cl"), ups[j]) for j, pp in enumerate(preds)]
+        pt_deep = [ops.softmax_classes(pp.detach(), inv_t, "cl") for pp in preds]        # coarse: crit.kl_cl upsamples inside the kernel
         f1_teacher, f1_stud = materialize(de_f_all[0]).t.split([B, 4 * B], 0)
         pl_all, d_all = ops.proto_loss(f1_stud, f1_teacher.detach(), tcl)
         kl_all = crit.kl_cl(fuse_stud, pt_full, temp)

@@ -706,7 +706,7 @@ class Model(nn.Module):
         # ---- PASSION losses of the four students against the (detached) teacher
         inv_t = 1.0 / temp
         pt_full = ops.softmax_classes(fuse_pred.detach(), inv_t, "cl")
-        pt_deep = [ops.upsample(ops.softmax_classes(pp.detach(), inv_t, "cl"), 2 ** (j + 1)) for j, pp in enumerate(preds)]
+        pt_deep = [ops.softmax_classes(pp.detach(), inv_t, "cl") for pp in preds]        # coarse: crit.kl_cl upsamples inside the kernel
         f_teacher = f1_teacher.detach()
         # The four students are rows of ONE batch: every loss runs once over 4B samples against the B teacher samples (the kernels
         # index teacher / target with b % B) instead of four times -- a quarter of the ~190 loss-chain launches of a PASSION step

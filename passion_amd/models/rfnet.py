@@ -284,7 +284,7 @@ class Model(nn.Module):
 
         inv_t = 1.0 / temp
         pt_full = ops.softmax_classes(fuse_pred.detach(), inv_t, "cl")
-        pt_deep = [ops.upsample(ops.softmax_classes(pp.detach(), inv_t, "cl"), ups[j]) for j, pp in enumerate(preds)]
+        pt_deep = [ops.softmax_classes(pp.detach(), inv_t, "cl") for pp in preds]        # coarse: crit.kl_cl upsamples inside the kernel
         f1_teacher, f1_stud = materialize(de_f_all[0]).t.split([B, 4 * B], 0)
         f_teacher = f1_teacher.detach()
         # the four students as one batch of 4B against the B teacher samples (kernels index teacher / target with b % B)

@@ -6,6 +6,8 @@ hand-written HIP kernel, and raises if the library or a GPU tensor is missing.
 """
 from ctypes import byref, c_void_p
 
+import os
+
 import torch
 import torch.nn.functional as F
 
@@ -879,6 +881,96 @@ class KLFn(torch.autograd.Function):
 
 def kl_probs(ps, pt, temp):
     return KLFn.apply(ps, pt.detach(), temp)
+
+
+UP_FUSED = os.environ.get("PASSION_LOSS_UP_FUSED", "1") != "0"      # x k upsampling inside the loss kernels (A/B: 0 = materialise)
+
+
+def _up_ok(coarse, k):
+    """the fused kernels take f32 4-class maps on the GPU whose x k volume has < 2^23 voxels"""
+    B, D, H, W, C = coarse.shape
+    return UP_FUSED and k > 1 and coarse.is_cuda and C == 4 and coarse.dtype == torch.float32 and D * H * W * k ** 3 < (1 << 23)
+
+
+class WceDiceUpFn(torch.autograd.Function):
+    """(weighted CE, Dice) of nn.Upsample(x k)(coarse probabilities) against the full-size label -- the deep-supervision terms of
+    reference mmformer.py:540-544 -- without the x k map: the kernels blend the coarse neighbours in registers, the backward runs
+    the separable adjoint with its first (W) pass fused into the loss gradient."""
+
+    @staticmethod
+    def forward(ctx, probs_c, target_cl, k):
+        L.require_gpu(probs_c, target_cl)
+        probs_c = probs_c.contiguous()
+        B, D, H, W, C = probs_c.shape
+        lib = L.load()
+        scratch = torch.empty(lib.passion_wce_dice_sums_floats(B), dtype=torch.float32, device=probs_c.device)
+        sums = scratch[:B * 16].view(B, 16)
+        out = torch.empty(B, 2, dtype=torch.float32, device=probs_c.device)
+        L.check(lib.passion_wce_dice_up_fwd(_p(probs_c), _p(target_cl), B, target_cl.shape[0], D, H, W, int(k), _p(scratch), _p(out),
+                                            L.stream_ptr()), "passion_wce_dice_up_fwd")
+        ctx.k = int(k)
+        ctx.save_for_backward(probs_c, target_cl, sums)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        probs_c, target_cl, sums = ctx.saved_tensors
+        B, D, H, W, C = probs_c.shape
+        g = g.contiguous().float()
+        lib = L.load()
+        dp = torch.empty_like(probs_c)
+        scratch = torch.empty(lib.passion_up_loss_bwd_scratch_floats(B, D, H, W, ctx.k), dtype=torch.float32, device=g.device)
+        L.check(lib.passion_wce_dice_up_bwd(_p(probs_c), _p(target_cl), _p(sums), _p(g), _p(dp), B, target_cl.shape[0], D, H, W, ctx.k,
+                                            _p(scratch), L.stream_ptr()), "passion_wce_dice_up_bwd")
+        return dp, None, None
+
+
+def wce_dice_up(probs_coarse, target_cl, k):
+    """-> (B,2) of the x k upsampled coarse probabilities (channels-last f32); falls back to upsample + wce_dice where the fused
+    kernels do not apply"""
+    if not _up_ok(probs_coarse, k):
+        return wce_dice(upsample(probs_coarse, k), target_cl, "cl")
+    return WceDiceUpFn.apply(probs_coarse, target_cl, k)
+
+
+class KLUpFn(torch.autograd.Function):
+    """temp_kl_loss_bs (reference criterions.py:92-103) of x k upsampled student probabilities against the x k upsampled teacher's,
+    both given as COARSE maps (softmaxed with 1 / T)"""
+
+    @staticmethod
+    def forward(ctx, ps_c, pt_c, temp, k):
+        L.require_gpu(ps_c, pt_c)
+        ps_c, pt_c = ps_c.contiguous(), pt_c.contiguous()
+        B, D, H, W, C = ps_c.shape
+        Bt = pt_c.shape[0]
+        assert B % Bt == 0 and pt_c.shape[1:] == ps_c.shape[1:]
+        lib = L.load()
+        out = torch.empty(B, dtype=torch.float32, device=ps_c.device)
+        work = torch.empty(lib.passion_kl_work_floats(B), dtype=torch.float32, device=ps_c.device)
+        L.check(lib.passion_kl_up_fwd(_p(ps_c), _p(pt_c), B, Bt, D, H, W, int(k), float(temp), _p(out), _p(work), L.stream_ptr()),
+                "passion_kl_up_fwd")
+        ctx.temp, ctx.k = float(temp), int(k)
+        ctx.save_for_backward(ps_c, pt_c)
+        return out.unsqueeze(1)
+
+    @staticmethod
+    def backward(ctx, g):
+        ps_c, pt_c = ctx.saved_tensors
+        B, D, H, W, C = ps_c.shape
+        g = g.contiguous().float().view(-1)
+        lib = L.load()
+        dps = torch.empty_like(ps_c)
+        scratch = torch.empty(lib.passion_up_loss_bwd_scratch_floats(B, D, H, W, ctx.k), dtype=torch.float32, device=g.device)
+        L.check(lib.passion_kl_up_bwd(_p(ps_c), _p(pt_c), _p(g), _p(dps), B, pt_c.shape[0], D, H, W, ctx.k, ctx.temp, _p(scratch),
+                                      L.stream_ptr()), "passion_kl_up_bwd")
+        return dps, None, None, None
+
+
+def kl_probs_up(ps_coarse, pt_coarse, temp, k):
+    """KL of the x k upsampled maps; pt_coarse carries no gradient"""
+    if not _up_ok(ps_coarse, k):
+        return kl_probs(upsample(ps_coarse, k), upsample(pt_coarse.detach(), k), temp)
+    return KLUpFn.apply(ps_coarse, pt_coarse.detach(), temp, k)
 
 
 class ProtoFn(torch.autograd.Function):

@@ -27,7 +27,9 @@ def _factor(up_op):
 
 def seg_losses_cl(probs_cl, target_cl, up=1):
     """(B,2) = (weighted CE, Dice) of channels-last probabilities, optionally upsampled x`up` first"""
-    return ops.wce_dice(ops.upsample(probs_cl, up), target_cl, "cl")
+    if up > 1:           # the x k map is never materialised (ops.wce_dice_up: blended in registers, forward and backward)
+        return ops.wce_dice_up(probs_cl, target_cl, up)
+    return ops.wce_dice(probs_cl, target_cl, "cl")
 
 
 def _seg_pair(output, target, up_op):
@@ -63,17 +65,19 @@ def dice_loss_bs(output, target, num_cls=4, eps=1e-7, up_op=None):
     return _seg_pair(output, target, up_op)[:, 1:2]
 
 
-def kl_cl(logit_s_cl, pt_up_cl, temp, up=1):
-    """student logits (channels-last f32) vs already softmaxed+upsampled teacher probabilities"""
-    ps = ops.upsample(ops.softmax_classes(logit_s_cl, 1.0 / temp), up)
-    return ops.kl_probs(ps, pt_up_cl, temp)
+def kl_cl(logit_s_cl, pt_cl, temp, up=1):
+    """student logits (channels-last f32) vs the teacher's softmaxed probabilities, both at the student's resolution; up > 1: the
+    loss is taken on the x`up` upsampled maps of both (mmformer.py:366-370 / criterions.py:92-103), inside the kernel"""
+    ps = ops.softmax_classes(logit_s_cl, 1.0 / temp)
+    if up > 1:
+        return ops.kl_probs_up(ps, pt_cl, temp, up)
+    return ops.kl_probs(ps, pt_cl, temp)
 
 
 def temp_kl_loss_bs(logit_s, logit_t, target=None, num_cls=4, temp=1.0, up_op=None):
     k = _factor(up_op)
     ls, lt = _NcdhwToCl.apply(logit_s.float()), ops.to_channels_last(logit_t.detach().float())
-    pt = ops.upsample(ops.softmax_classes(lt, 1.0 / temp), k)
-    return kl_cl(ls, pt, temp, k)
+    return kl_cl(ls, ops.softmax_classes(lt, 1.0 / temp), temp, k)
 
 
 def prototype_passion_loss_bs(feature_s, feature_t, target, logit_s=None, logit_t=None, num_cls=4, temp=1.0,
