@@ -63,6 +63,10 @@ def parse():
                          "stream capture after the warm-up steps) and the timed steps replay it, with the batch / AdamW scalars / dropout "
                          "seeds handed over through device memory; eager: every launch issued from Python each step.  auto = graph on one "
                          "GPU for the data-parallel workloads, eager for N > 1 (gradient all-reduce from autograd hooks) and the depth path")
+    ap.add_argument("--ddp-mode", action="store_true",
+                    help="one GPU, but the step every rank of an N > 1 run executes: process group on RCCL (world size 1), GradReducer's "
+                         "overlap hooks and buckets, async all_reduce, no early optimizer step / direct gradients, eager launch -- the "
+                         "per-rank baseline the scaling numbers should be read against")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-dice", action="store_true", help="skip the dice_vs_ref leg (fixture replay after the timed region)")
     return ap.parse_args()
@@ -239,6 +243,8 @@ def main():
     # touches the GPU or spawns a thread pool -- eight ranks x ~11 ms of host work per step on shared cores is the first scaling
     # risk (round 2 saw load averages of 30-40 on the pool's hosts)
     world_env, local_env = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
+    if int(os.environ.get("RANK", "0")) != 0:
+        os.dup2(2, 1)                   # only rank 0 owns stdout (the launcher merges the ranks' streams; see emit())
     if world_env > 1 and hasattr(os, "sched_setaffinity"):
         try:
             cpus = sorted(os.sched_getaffinity(0))
@@ -249,6 +255,15 @@ def main():
         except OSError:
             pass
 
+    if args.ddp_mode:
+        os.environ["PASSION_DDP_FORCE"] = "1"
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if "MASTER_PORT" not in os.environ:
+            import socket
+            s_ = socket.socket()
+            s_.bind(("127.0.0.1", 0))
+            os.environ["MASTER_PORT"] = str(s_.getsockname()[1])
+            s_.close()
     import torch
     import torch.distributed as dist
     from passion_amd import ops, parallel
@@ -314,7 +329,7 @@ def main():
         return ptrain.train_step(model, opt, x, mk, target.view(target.shape), 4.0, state, reducer)
 
     use_graph = (args.launch == "graph" or (args.launch == "auto" and os.environ.get("PASSION_BENCH_GRAPH", "1") != "0")) \
-        and ctx.world == 1 and not is_depth
+        and ctx.world == 1 and not is_depth and not args.ddp_mode
     gstep = None
     if use_graph:
         from passion_amd.graph import GraphedStep
@@ -444,6 +459,15 @@ def main():
 
     timed_recs = (graph_live_recs if use_graph else ops.prof_read()) if want_events else []
 
+    def emit(line):
+        """the ONE JSON line, and the last thing on stdout: librccl writes "Librccl path : ..." to stdout when a process that used it
+        exits (seen after a world-1 run), so rank 0 leaves without running exit handlers; the other ranks' stdout was pointed at
+        stderr when they started"""
+        print(line, flush=True)
+        if dist.is_initialized():
+            sys.stderr.flush()
+            os._exit(0)
+
     if ctx.rank != 0:
         return
     grad_bytes = sum(p.numel() for p in model.parameters() if p.requires_grad) * 4
@@ -460,7 +484,7 @@ def main():
                           "global_batch": 1, "parallelism": f"depth{ctx.world}", "dist_backend": ctx.backend,
                           "world_size_seen": dist.get_world_size() if dist.is_initialized() else 1,
                           "final_loss": round(final_loss, 5), "launch": "eager"}}
-        print(json.dumps(out), flush=True)
+        emit(json.dumps(out))
         return
     out = {
         "metric": "train volumes/sec (4-modality 128^3, bs=%d/GPU)" % batch, "value": round(batch * ctx.world * args.steps / dt, 4),
@@ -474,6 +498,7 @@ def main():
                    "world_size_seen": dist.get_world_size() if dist.is_initialized() else 1, "dist_backend": ctx.backend,
                    "allreduce_bytes_per_step": grad_bytes if ctx.world > 1 else 0,
                    "final_loss": round(final_loss, 5),
+                   "ddp_mode": bool(args.ddp_mode),
                    "launch": ("HIP graph replay of train.train_step (recorded once after the warm-up; batch, AdamW scalars and dropout "
                               "seeds through device memory)" if use_graph else "eager")},
     }
@@ -557,7 +582,7 @@ def main():
             out["dice_vs_ref"] = dv
     if not args.no_cpu_baseline and ctx.world == 1 and not is_rfnet:
         out["cpu_baseline"] = cpu_baseline(passion, S, args.cpu_steps, masks[0][0], modal_weight)
-    print(json.dumps(out), flush=True)
+    emit(json.dumps(out))
 
 
 if __name__ == "__main__":

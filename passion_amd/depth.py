@@ -35,8 +35,9 @@ class DepthCtx:
     """rank r of `world` owns planes [r * D / world, (r + 1) * D / world) of every level (D divisible by world at every level it
     is split; below that the caller gathers)"""
 
-    def __init__(self, rank=None, world=None, group=None):
+    def __init__(self, rank=None, world=None, group=None, loopback=False):
         self.group = group
+        self.loopback = loopback         # world 1: exchange() still goes through batch_isend_irecv, every plane sent to this rank itself
         self.rank = dist.get_rank(group) if rank is None else rank
         self.world = dist.get_world_size(group) if world is None else world
         self.backend = dist.get_backend(group) if dist.is_initialized() else "none"
@@ -57,6 +58,16 @@ class DepthCtx:
     def exchange(self, to_lo, to_hi):
         """send `to_lo` / `to_hi` to the neighbours, return what they sent (None at the global ends).  Point-to-point; the gloo
         rehearsal transport cannot move device tensors, so there the planes travel through host memory."""
+        if self.world == 1 and self.loopback and dist.is_initialized():
+            # the calls of the N > 1 path against the real transport on a one-GPU box: a grouped send / recv pair per direction,
+            # peer = this rank; what comes back is what was sent (the caller's ends stay global ends: the planes are dropped)
+            r_lo, r_hi = torch.empty_like(to_lo), torch.empty_like(to_hi)
+            reqs = [dist.P2POp(dist.isend, to_lo, self.rank, self.group), dist.P2POp(dist.irecv, r_lo, self.rank, self.group),
+                    dist.P2POp(dist.isend, to_hi, self.rank, self.group), dist.P2POp(dist.irecv, r_hi, self.rank, self.group)]
+            for w in dist.batch_isend_irecv(reqs):
+                w.wait()
+            self.last_loopback = (r_lo, r_hi)
+            return None, None
         if self.world == 1:
             return None, None
         via_host = self.backend == "gloo" and to_lo.is_cuda

@@ -28,6 +28,13 @@ class Ctx:
     backend: str
 
 
+# PASSION_DDP_FORCE=1: the N > 1 code path -- process group, overlap hooks, bucket packing across streams, async all_reduce on
+# RCCL's stream, reduced gradients as views of the buckets -- also in a single process (a SUM over one rank is the identity).
+# One-GPU boxes can then drive librccl with exactly the calls the 8-GPU run issues (tests/test_rccl_world1_gpu.py,
+# bench.py --ddp-mode).
+FORCE = os.environ.get("PASSION_DDP_FORCE") == "1"
+
+
 def init(backend=None):
     """reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* (torchrun); single process if absent"""
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -43,7 +50,7 @@ def init(backend=None):
     else:
         device = torch.device("cpu")
     backend = backend or os.environ.get("PASSION_DIST_BACKEND") or ("nccl" if use_gpu else "gloo")
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or FORCE) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if use_gpu and backend == "nccl":
@@ -89,13 +96,14 @@ class GradReducer:
         self.wire_dtype = torch.bfloat16 if (WIRE_BF16 and self.params[0].is_cuda) else torch.float32
         self.flat = [torch.zeros(sum(p.numel() for p in b), dtype=self.wire_dtype, device=self.params[0].device)
                      for b in self.buckets]
-        self.overlap = overlap and ctx.world > 1 and hasattr(torch.Tensor, "register_post_accumulate_grad_hook")
+        self.active = ctx.world > 1 or (FORCE and dist.is_initialized())
+        self.overlap = overlap and self.active and hasattr(torch.Tensor, "register_post_accumulate_grad_hook")
         self._pending = [len(b) for b in self.buckets]       # gradients still missing per bucket in this backward
         self._works = [None] * len(self.buckets)
         self._next = 0                                       # first bucket that has not been launched in this backward
         self._streams = [set() for _ in self.buckets]        # streams that produced gradients of the bucket in this backward
         self._on_gpu = self.params[0].is_cuda
-        if ctx.world > 1:
+        if self.active:
             for p in model.parameters():
                 dist.broadcast(p.data, src=0)
         if self.overlap:
@@ -143,7 +151,7 @@ class GradReducer:
         self._works[bi] = dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True)
 
     def all_reduce_grads(self):
-        if self.ctx.world == 1:
+        if not self.active:
             return
         for bi in range(self._next, len(self.buckets)):  # not (completely) produced by this backward, or overlap off
             self._launch(bi)
@@ -170,7 +178,7 @@ def all_reduce_sum_(t):
     """in-place SUM of a (small, detached) tensor over all ranks; a no-op in a single process.  Used for the two places where
     the reference's loss assembly couples the samples of the GLOBAL batch (DataParallel gathers the per-sample outputs before
     train.py:266-270 forms rp_iter, and :325 sums epoch_dist_m over every sample of the epoch)."""
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or FORCE):
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return t
 

@@ -160,7 +160,7 @@ def train_step(model, optimizer, x, mask, target, temp=4.0, state=None, reducer=
     from . import ops
     net = model
     net.is_training = True
-    early = EARLY_STEP and hasattr(optimizer, "step_ready") and (reducer is None or reducer.ctx.world == 1) and x.is_cuda
+    early = EARLY_STEP and hasattr(optimizer, "step_ready") and (reducer is None or not reducer.active) and x.is_cuda
     if hasattr(optimizer, "_stepped"):
         optimizer._stepped.clear()       # a backward that raised after the early part left its marks: this iteration starts clean
     ops._MARKER_CB[0] = _early_step_callback(net, optimizer) if early else None
@@ -168,7 +168,7 @@ def train_step(model, optimizer, x, mask, target, temp=4.0, state=None, reducer=
     host = L.host() if x.is_cuda else None
     # ~210 AccumulateGrad nodes less per step for the autograd engine (csrc/host_ext.cpp); with more than one rank the
     # GradReducer's overlap hangs hooks on exactly those nodes, so only here
-    direct = DIRECT_GRADS and host is not None and (reducer is None or reducer.ctx.world == 1)
+    direct = DIRECT_GRADS and host is not None and (reducer is None or not reducer.active)
     if direct:
         host.set_direct_grads(True)
         ops._DIRECT[0] = True
