@@ -777,7 +777,12 @@ double conv_bytes(const ConvK& k, int xs, int ys) {
 
 }  // namespace
 
-namespace pconv { int g_conv_padout = 1; }   // PASSION_CONV_PADOUT=0: reflect adjoint through mirror taps everywhere (A/B)
+// PASSION_CONV_MARCHFINAL=1 / option "conv_marchfinal": the finish-free backward of the finest 3x3x3 layers (below).  Built, exact
+// (tests/test_ops_gpu.py::test_finish_free_marching_backward_equals_dgrad_plus_finish) and OFF by default: on 4 x 128^3, 8 -> 8 it
+// trades the 101 us finish pass for +57 us in the weight gradient (the indicator tiles double an LDS-bound MFMA phase), +28 us of
+// folds and +11 us in the input gradient (the column mirror lengthens the edge workgroups' critical path): 351 against 355 us per
+// layer, and 150 against 120 us at batch 1.
+namespace pconv { int g_conv_padout = 1; int g_conv_marchfinal = 0; }   // PASSION_CONV_PADOUT=0: reflect adjoint through mirror taps everywhere (A/B)
 
 // dgrad over the padded domain (conv_lean.hip MODE 2) + folding finish kernel: 3x3x3 stride-1 reflect-padded bf16 convs
 // (the finish kernel folds the halo planes; for inputs normalised in the loader it also completes InstanceNorm backward)
@@ -864,6 +869,10 @@ static long pass_scratch_floats(const ConvK& k, const passion_conv_desc_t* d) {
 // pointwise layers (nt == 1): + the indicator slab [gx][Cout Cin], the per-sample folds [B][2 Cout Cin + Cout] and the means
 // [B][Cin][2] of the finish-free backward (conv_pw.hip)
 static long pw_extra_floats(const ConvK& k, int gx, int nt) {
+    if (nt == 27 && k.Cout == 8 && k.Cin <= 16) {      // 3x3x3 layers of the finest level: indicator slab (slot stride = the weight slab's),
+        const long nW = (long)k.Cout * k.Cin * 27;      // per-sample folds [B][2 nW + Cout], means [B][Cin][2] (march_final below)
+        return ((long)gx * (nW + k.Cout) + (long)k.B * (2 * nW + k.Cout) + (long)k.B * k.Cin * 2 + 31) / 32 * 32;
+    }
     if (nt != 1) return 0;
     const long nW = (long)k.Cout * k.Cin;
     return ((long)gx * nW + (long)k.B * (2 * nW + k.Cout) + (long)k.B * k.Cin * 2 + 31) / 32 * 32;
@@ -1106,6 +1115,65 @@ static int conv3d_bwd_impl(const passion_conv_desc_t* d, const float* packed, co
     } else if (d->ksize == 1 && []() { static const bool dbg2 = getenv("PASSION_PWFINAL_DBG") != nullptr; return dbg2; }()) {
         fprintf(stderr, "[pwfinal] B=%d V=%ld Cin=%d Cout=%d: not planned (phase %d ga %d parts %d need_dx %d need_norm %d dW %d db %d dt %d/%d)\n", k.B,
                 (long)k.Di * k.Hi * k.Wi, k.Cin, k.Cout, phase, ga != nullptr, parts, (int)need_dx, (int)need_norm, dweight != nullptr, dbias != nullptr, d->x_dtype, d->y_dtype);
+    }
+    // 3x3x3 stride-1 reflect layers of the finest level (8 output channels, <= 16 input channels: e1_c2 / e1_c3 grouped, d1_c1, d1_c2 of
+    // both decoders), every input gradient normalised: the same order -- weight gradient first, with the indicator slab
+    // (conv_wgrad_march.hip), per-sample folds + means (march_ident_kernel), then the FOLD-FREE marching input gradient that
+    // writes dx itself (conv_march.hip FIN).  No padded scratch volume, no sums, no in_bwd_finish_pad launch.
+    if (phase == 0 && parts == 3 && d->ksize == 3 && d->stride == 1 && d->pad_mode == PASSION_PAD_REFLECT && pconv::g_conv_marchfinal &&
+        pconv::g_conv_lean && !g_passion_force_f32_mfma && d->x_dtype == PASSION_BF16 && d->y_dtype == PASSION_BF16 && need_dx && need_norm &&
+        dweight && sums && k.Cout == 8 && k.Cin <= 16 && !pconv::g_wgrad_fork) {
+        bool ok = true;
+        for (int s = 0; s < k.nseg; ++s) if (!k.seg[s].dx || !k.seg[s].stats || k.seg[s].bmod > 0) ok = false;
+        k.Mpad = pad16(k.Cout);
+        const WgPlan w = plan_wgrad(k, d);
+        ConvK kd = k;                                    // would the marching input gradient take it?
+        kd.Mpad = pad16(k.Cin);
+        ok = ok && w.bf16 && w.MT == 1 && k.Hi % 8 == 0 && k.Wi % 16 == 0 && k.Di >= 8 && k.Hi >= 16 && k.Wi >= 32 && wgrad_lean_covers(k, 3, 1, w.MT, w.gx, w.gy) &&
+             pconv::g_wgrad_march && pconv::conv_march_covers(kd, 3, 1, 2, nullptr) && kd.Mpad == 16 && w.gx % k.B == 0;
+        if (ok) {
+            const long nW = (long)k.Cout * k.Cin * nt;
+            k.wslot = nW + k.Cout;
+            float* wslab = sums + (long)2 * k.B * k.Cin * SUMS_SLOTS;
+            float* sslab = wslab + (long)w.gx * k.wslot;
+            float* dwb = sslab + (long)w.gx * k.wslot;
+            float* pb = dwb + (long)k.B * (nW + k.Cout);
+            float* mb = pb + (long)k.B * nW;
+            k.spos = sslab;
+            {
+                ProfScope prof(3, conv_bytes(k, xs, ys) + (double)nt * k.Cin * k.Cout * 4, 2.0 * 2.0 * k.B * k.Do * k.Ho * k.Wo * (double)k.Cout * k.Cin * nt, st);
+                rc = launch_wgrad_march(k, 3, 1, w.MT, w.gx, w.gy, wslab, wslab + nW, st);
+            }
+            k.spos = nullptr;
+            if (rc > 0) rc = -1023;                      // planned for the marching kernels: must be covered
+            if (rc) return rc;
+            const int tiles_per_b = k.tilesD * k.tilesH * k.tilesW;
+            const int wgs_per_b = (tiles_per_b + k.per - 1) / k.per;
+            const int G = ga ? ga->G : 1;
+            float* dw_out[PASSION_MAX_GROUPS] = {nullptr, nullptr, nullptr, nullptr};
+            float* db_out[PASSION_MAX_GROUPS] = {nullptr, nullptr, nullptr, nullptr};
+            for (int g = 0; g < G; ++g) {
+                dw_out[g] = ga ? ga->dW[g] : dweight;
+                db_out[g] = ga ? (ga->dW[g] ? ga->dW[g] + nW : nullptr) : dbias;
+            }
+            const bf16_t* wdg = reinterpret_cast<const bf16_t*>(packed + f32_pack_floats(k.Cin, k.Cout, nt)) + (long)nt * pad8(k.Cin) * pad16(k.Cout);
+            {
+                // what stands between the weight gradient and the input gradient: counted with the input gradient (kind 6)
+                ProfScope prof(6, conv_bytes(k, xs, ys) + (double)nt * k.Cin * k.Cout * 4, 0.0, st);
+                passion_prof_tag("finish of conv_march_kernel<1, 16, 2, 0, 1, 1>");
+                rc = launch_march_ident(k, wslab, k.wslot, sslab, wgs_per_b, wdg, ga ? ga->stride * 2 : 0, dwb, pb, mb, dw_out, db_out, G, st);
+            }
+            if (rc) return rc;
+            k.pwm = mb;
+            k.sums = nullptr; k.sums_rep = 1; k.sums_fixed = 0; k.sums_float_only = 0;
+            k.tilesD = cdiv(k.Di, TD); k.tilesH = cdiv(k.Hi, TH); k.tilesW = cdiv(k.Wi, TW);
+            {
+                ProfScope prof(2, conv_bytes(k, xs, ys) + (double)nt * k.Cin * k.Cout * 4, 2.0 * k.B * k.Do * k.Ho * k.Wo * (double)k.Cout * k.Cin * nt, st);
+                rc = launch_conv_march(k, 3, 1, 2, packed + f32_pack_floats(k.Cin, k.Cout, nt), st);
+            }
+            if (rc > 0 || (rc == 0 && !k.pw_done)) rc = -1023;
+            return rc;
+        }
     }
     Companion* comp = (phase == 0 && pconv::g_wgrad_fork && need_dx && (dweight || dbias) && !pw_final) ? companion(st) : nullptr;
     hipStream_t caller_st = st;

@@ -126,6 +126,9 @@ bool conv_pw_dgrad_covers(const ConvK& k, int kblocks, int bphys);
 int launch_pw_ident(const ConvK& k, const float* wslab, long wslot, const float* sslab, int wgs_per_b, const void* wdg_bf16, float* dwb, float* pb,
                     float* out, float* dweight, float* dbias, int bm, hipStream_t st);
 extern int g_conv_pwfinal;
+int launch_march_ident(const ConvK& k, const float* wslab, long wslot, const float* sslab, int wgs_per_b, const void* wdg_bf16, long wset_el,
+                       float* dwb, float* pb, float* out, float* const* dw_out, float* const* db_out, int G, hipStream_t st);   // conv_pw.hip
+extern int g_conv_marchfinal;
 extern int g_conv_pw, g_conv_pw8;
 bool conv_march_covers(const ConvK& k, int ksize, int stride, int mode, int* K8out);
 int launch_wgrad_lean(ConvK& k, int ksize, int stride, int MT, int gx, int gy, float* dWslab, float* dbslab, hipStream_t st);   // conv_wgrad_lean.hip

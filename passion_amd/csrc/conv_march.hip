@@ -17,6 +17,7 @@
 //     the staged plane; the InstanceNorm-backward sums leave the workgroup as ONE plain store into its own slot (no atomics:
 //     the fold in conv.hip is fixed-order, so the gradients are bitwise reproducible).
 #include <cstdlib>
+#include <type_traits>
 #include "conv_common.h"
 #include "prof.h"
 
@@ -33,8 +34,10 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 constexpr int MTH = 8;                   // tile rows (two per wave)
 constexpr int NSLOT = 4, ND = 4;         // LDS ring slots; planes in flight in registers
 
-template <int NB, int TW> struct GeoM {
-    static constexpr int EH = MTH + 4, EW = TW + 4;          // staged plane: tile + halo 1 + zero guard ring 1
+// FIN (the fold-free input gradient, below): three more zero columns -- voxel (row 1, column TW + 5) has an all-zero 3 x 3
+// neighbourhood, the address a lane reads from when a mirror pass does not concern it -- and a fifth plane slot that stays zero
+template <int NB, int TW, bool FIN = false> struct GeoM {
+    static constexpr int EH = MTH + 4, EW = TW + 4 + (FIN ? 3 : 0);          // staged plane: tile + halo 1 + zero guard ring 1
     static constexpr int VS = 16 * NB;                        // bytes per voxel
     static constexpr int RSB = EW * VS;
     static constexpr int PLANE = EH * RSB;
@@ -42,7 +45,9 @@ template <int NB, int TW> struct GeoM {
     static constexpr int CH = SV * NB, NIT = (CH + 255) / 256;
     static constexpr int Q = 27 * NB, NSTEP = (Q + 3) / 4;
     static constexpr int NTW = TW / 16;                       // 16-voxel column tiles per row
-    static constexpr int LDS = NSLOT * PLANE;
+    static constexpr int RING = (NSLOT + (FIN ? 1 : 0)) * PLANE;
+    static constexpr int LDS = RING + (FIN ? 1024 : 0);       // FIN: + [16 channels][16 rows] f32 of the column mirror tile
+    static constexpr int ZPATCH = 1 * RSB + (TW + 5) * VS;     // FIN: see above
 };
 
 struct alignas(16) MBlk {          // one 8-channel block of the K axis, resolved for this workgroup's sample
@@ -81,10 +86,18 @@ struct MarchP {
 };
 
 // MT: 16-row tiles of the output (MODE 2 only: gradients with 17 .. 32 rows, e.g. the input gradient of a 24 / 32 -> 8 conv)
-template <int NB, int TW, int MODE, bool HAS_RES, int MT = 1>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((MT == 2 && NB == 1) ? 2 : 1)))      // 264 registers uncapped: one wave per SIMD
+// FIN (MODE 2, MT 1): the FOLD-FREE input gradient with its final epilogue.  The adjoint of reflect padding adds the padded-domain
+// values at positions -1 / S of an axis onto positions 1 / S - 2; instead of computing those halo outputs as tiles of their own,
+// storing them and folding in a finish pass, the tap loop is run again for the target tile with the lane's base address moved to
+// the mirror position (rows / columns: two staged voxels further out, where the zero guard ring supplies what lies outside; depth:
+// only the taps whose plane exists, the others read a zero plane) and accumulates into the SAME accumulator.  With the
+// InstanceNorm-backward means known beforehand (p.pwm: from the weight gradient, conv_pw.hip / march_ident_kernel) the epilogue
+// writes dx = rstd (g - m1 - x_hat m2) itself: no scratch volume, no sums, no finish kernel.
+template <int NB, int TW, int MODE, bool HAS_RES, int MT = 1, bool FIN = false>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(((MT == 2 && NB == 1) || FIN) ? 2 : 1)))      // 264 registers uncapped: one wave per SIMD
 void conv_march_kernel(ConvK p, MarchP mp) {
-    using G = GeoM<NB, TW>;
+    static_assert(!FIN || (MODE == 2 && MT == 1), "final form: input gradient, one row tile");
+    using G = GeoM<NB, TW, FIN>;
     constexpr bool DG = (MODE == 2);
     constexpr int NIT = G::NIT, NSTEP = G::NSTEP, NTW = G::NTW, VS = G::VS, RSB = G::RSB, PLANE = G::PLANE;
     extern __shared__ __attribute__((aligned(16))) char lds[];            // [NSLOT planes]
@@ -104,7 +117,7 @@ void conv_march_kernel(ConvK p, MarchP mp) {
     const int dseg = r;
     const int h0 = th_i * MTH, w0 = tw_i * TW;
     // output planes [dlo, dhi) in "position" coordinates: MODE 0: 0 .. Sd-1; MODE 2: -1 .. Sd (the padded domain)
-    const int dfirst = DG ? -1 : 0, dcount = DG ? Sd + 2 : Sd;
+    const int dfirst = (DG && !FIN) ? -1 : 0, dcount = (DG && !FIN) ? Sd + 2 : Sd;
     const int dlo = dfirst + dseg * mp.planes_per_seg;
     const int dhi = min(dlo + mp.planes_per_seg, dfirst + dcount);
     const int L = dhi - dlo;
@@ -238,8 +251,27 @@ void conv_march_kernel(ConvK p, MarchP mp) {
             }
         }
     }
+    // FIN: where the lane's four rows go (the segment's dx, channels 4 g ..) and their means (m1, m2) / V
+    bf16_t* fdx = nullptr;
+    f32x4 fm1 = {0.f, 0.f, 0.f, 0.f}, fm2 = {0.f, 0.f, 0.f, 0.f};
+    if (FIN) {
+        const int cg = g * 4;
+#pragma unroll
+        for (int s2 = 0; s2 < PASSION_MAX_SEG; ++s2) {
+            if (s2 < p.nseg && cg < p.Cin) {
+                const SegD& sd = p.seg[s2];
+                if (cg >= sd.cbase && cg < sd.cbase + sd.C && sd.dx != nullptr)
+                    fdx = reinterpret_cast<bf16_t*>(sd.dx) + (long)b * sd.bstride + (cg - sd.cbase);
+            }
+        }
+        if (cg < p.Cin) {
+            const f32x4 a = gload<f32x4>(p.pwm + ((long)b * p.Cin + cg) * 2), c2 = gload<f32x4>(p.pwm + ((long)b * p.Cin + cg) * 2 + 4);
+            fm1 = (f32x4){a[0], a[2], c2[0], c2[2]};
+            fm2 = (f32x4){a[1], a[3], c2[1], c2[3]};
+        }
+    }
     // zero the whole ring once: the guard ring and the out-of-volume halo of zero-padded / gradient planes stay zero
-    for (int i = tid; i < G::LDS / 16; i += 256) reinterpret_cast<u32x4*>(lds)[i] = (u32x4){0u, 0u, 0u, 0u};
+    for (int i = tid; i < G::RING / 16; i += 256) reinterpret_cast<u32x4*>(lds)[i] = (u32x4){0u, 0u, 0u, 0u};
 
     // per-lane LDS offset of step s relative to the lane's output voxel and the plane of its depth tap
     int toff[NSTEP], tdsel[NSTEP];
@@ -292,7 +324,8 @@ void conv_march_kernel(ConvK p, MarchP mp) {
     // ---- output side: the column tiles of this lane.  t < NT: main tiles (row r0 + t / NTW, columns 16 (t % NTW) + n);
     // MODE 2 adds up to two halo tiles per wave (edge workgroups): the halo rows (position -1 / Sh) over the tile's columns and
     // the halo columns (position -1 / Sw) over rows h0 - 1 .. h0 + MTH, dealt over the four waves
-    constexpr int NT = 2 * NTW, TT = DG ? NT + 2 : NT;
+    constexpr int NT = 2 * NTW, TT = (DG ? NT + 2 : NT);      // MODE 2: + two halo tiles (FIN: two mirror tiles, below)
+    constexpr int ET = FIN ? NT : TT;                          // tiles with an epilogue
     const int r0 = 2 * wv;
     int vb[TT], tph[TT], tpw[TT];                              // LDS offset of the lane's voxel in a plane slot; its (h, w) position
     unsigned vmask = 0u;                                       // bit t: the lane's voxel of tile t exists
@@ -306,7 +339,7 @@ void conv_march_kernel(ConvK p, MarchP mp) {
     // zero-padded convs (the fusion blocks' 3x3x3 conv): the adjoint has no halo outputs -- positions -1 and S of every axis
     // are neither computed nor counted; the finish kernel then reads the interior of the padded scratch only (fold = 0)
     const bool nohalo = DG && p.pad_mode != PASSION_PAD_REFLECT;
-    if (DG) {
+    if (DG && !FIN) {
         const bool top = h0 == 0, bot = h0 + MTH == Sh, left = w0 == 0, right = w0 + TW == Sw;
 #pragma unroll
         for (int xslot = 0; xslot < 2; ++xslot) {
@@ -341,6 +374,30 @@ void conv_march_kernel(ConvK p, MarchP mp) {
     bool tile_on[TT];
 #pragma unroll
     for (int t = 0; t < TT; ++t) tile_on[t] = t < NT || __any((vmask >> t) & 1u);
+    // FIN (16-wide tiles: tile 0 = row r0, tile 1 = row r0 + 1): the mirror tiles.  Each is the tap loop read from mirror positions and
+    // joins its target accumulators after the loop; a wave carries at most one.
+    //   X0, rows (waves 0 / 3 of the top / bottom workgroups): the voxels of row 1 / Sh - 2 two staged rows further out (padded row
+    //   -1 / Sh), lane for lane with the target tile;
+    //   X1, columns (wave 1 of the left / right workgroups): lane n = row h0 - 1 + n of the padded column -1 / Sw (rows -1 / Sh = the
+    //   corners, only in top / bottom workgroups); its 16 x 16 values cross to the waves that own the rows through 1 KB of LDS
+    //   (one more barrier per plane, in these workgroups only), lane 1 / 14 of their tiles takes them.
+    bool xh = false, xw = false, wtop = false, wbot = false;
+    int xh_tgt = 0, wlane = 1;
+    if (FIN) {
+        static_assert(!FIN || NTW == 1, "final form: 16-wide tiles");
+        const bool top = h0 == 0, bot = h0 + MTH == Sh, left = w0 == 0, right = w0 + TW == Sw;
+        const bool hlo = top && wv == 0, hhi = bot && wv == 3;       // this wave holds row 1 (its second row) / row Sh - 2 (its first)
+        xh = hlo || hhi; xw = left || right;                         // (Sh >= 16, Sw >= 32: one edge per axis at most)
+        wtop = top && xw; wbot = bot && xw;
+        xh_tgt = hlo ? 1 : 0;
+        wlane = left ? 1 : 14;
+        const int colv = (left ? 1 : TW + 2) * VS;                   // staged column of padded column -1 / Sw
+        const bool cval = n <= MTH + 1 && (n >= 1 || top) && (n <= MTH || bot);
+        vb[NT + 0] = hlo ? vb[1] - 2 * RSB : vb[0] + 2 * RSB;
+        vb[NT + 1] = cval ? (n + 1) * RSB + colv : G::ZPATCH;
+        tile_on[NT + 0] = xh; tile_on[NT + 1] = xw && wv == 1;
+        tph[NT] = tph[NT + 1] = h0; tpw[NT] = tpw[NT + 1] = w0;
+    }
 
     f32x4 biasv = {0.f, 0.f, 0.f, 0.f};
     if (!DG && bias_of(p, b) && g * 4 < p.Cout) biasv = load4(bias_of(p, b) + g * 4);
@@ -349,7 +406,8 @@ void conv_march_kernel(ConvK p, MarchP mp) {
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) { f_pos[mt] = emval[mt]; f_neg[mt] = e_st[mt] ? emval[mt] * p.slope : emval[mt]; }
     const int Wp = pad8(Sw + 2);
-    bf16_t* ybase = DG ? reinterpret_cast<bf16_t*>(p.y) + (long)b * (Sd + 2) * (Sh + 2) * Wp * p.Cin
+    bf16_t* ybase = FIN ? fdx
+                  : DG ? reinterpret_cast<bf16_t*>(p.y) + (long)b * (Sd + 2) * (Sh + 2) * Wp * p.Cin
                        : reinterpret_cast<bf16_t*>(p.y) + (long)b * Sd * Sh * Sw * p.Cout;
     // epilogue operand of a tile, one 8-byte load per lane: MODE 0 the residual (HAS_RES), MODE 2 x (for x_hat); in-plane element
     // offset per tile (clamped / reflected to a valid voxel), plane offset added per step
@@ -366,25 +424,27 @@ void conv_march_kernel(ConvK p, MarchP mp) {
         eCs[mt] = DG ? ((e_ok[mt] && e_st[mt]) ? eC[mt] : 0) : (row_ok ? p.Cout : 0);      // x only where it is needed (x_hat for LeakyReLU' and the sums)
         eplane[mt] = (unsigned)(Sh * Sw) * (unsigned)eCs[mt];
     }
-    unsigned eel[MT][TT], oel[TT];                             // in-plane element offsets: operand / output (row tile mt: + 16 mt channels)
+    unsigned eel[MT][ET], oel[ET];                             // in-plane element offsets: operand / output (row tile mt: + 16 mt channels)
 #pragma unroll
-    for (int t = 0; t < TT; ++t) {
+    for (int t = 0; t < ET; ++t) {
         const int rh = min(max(reflect_idx(tph[t], Sh), 0), Sh - 1), rw = min(max(reflect_idx(tpw[t], Sw), 0), Sw - 1);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) eel[mt][t] = (unsigned)(rh * Sw + rw) * (unsigned)eCs[mt];
-        oel[t] = DG ? (unsigned)((tph[t] + 1) * Wp + (tpw[t] + 1)) * (unsigned)p.Cin + (unsigned)(g * 4)
+        oel[t] = FIN ? (unsigned)(tph[t] * Sw + tpw[t]) * (unsigned)eC[0]
+               : DG ? (unsigned)((tph[t] + 1) * Wp + (tpw[t] + 1)) * (unsigned)p.Cin + (unsigned)(g * 4)
                     : (unsigned)(tph[t] * Sw + tpw[t]) * (unsigned)p.Cout + (unsigned)(g * 4);
     }
-    const unsigned oplane = DG ? (unsigned)((Sh + 2) * Wp) * (unsigned)p.Cin : (unsigned)(Sh * Sw) * (unsigned)p.Cout;
-    u32x2 eop[ND][EOP ? MT * TT : 1];
-    auto eload = [&](int jout, u32x2 (&dst)[EOP ? MT * TT : 1]) {
+    const unsigned oplane = FIN ? (unsigned)(Sh * Sw) * (unsigned)eC[0]
+                          : DG ? (unsigned)((Sh + 2) * Wp) * (unsigned)p.Cin : (unsigned)(Sh * Sw) * (unsigned)p.Cout;
+    u32x2 eop[ND][EOP ? MT * ET : 1];
+    auto eload = [&](int jout, u32x2 (&dst)[EOP ? MT * ET : 1]) {
         if (!EOP) return;
         const int dpos = dlo + jout;
         const unsigned pl = (unsigned)min(max(reflect_idx(dpos, Sd), 0), Sd - 1);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-            for (int t = 0; t < TT; ++t) dst[mt * TT + t] = gload<u32x2>(ebase[mt] + (pl * eplane[mt] + eel[mt][t]));
+            for (int t = 0; t < ET; ++t) dst[mt * ET + t] = gload<u32x2>(ebase[mt] + (pl * eplane[mt] + eel[mt][t]));
     };
     float s1[MT][4], s2v[MT][4];
 #pragma unroll
@@ -396,7 +456,8 @@ void conv_march_kernel(ConvK p, MarchP mp) {
     // output plane jout (position dlo + jout) from ring planes jout, jout + 1, jout + 2
     const int lanebase = (r0 + 2) * RSB + (n + 2) * VS;        // main tile t: + (t / NTW) * RSB + (t % NTW) * 16 * VS (an immediate)
     char* yb8 = reinterpret_cast<char*>(ybase);
-    auto compute = [&](int jout, const u32x2 (&eo)[EOP ? MT * TT : 1]) {
+    auto compute = [&](auto edgec, int jout, const u32x2 (&eo)[EOP ? MT * ET : 1]) {
+        constexpr int EDGE = decltype(edgec)::value;             // FIN: bit 0 = this wave may hold the row mirror tile, bit 1 = the column tile
         const int dpos = dlo + jout;
         const bool pvalid = jout >= 0 && jout < L && !(nohalo && (dpos < 0 || dpos >= Sd));
         f32x4 acc[MT][TT];
@@ -405,38 +466,90 @@ void conv_march_kernel(ConvK p, MarchP mp) {
 #pragma unroll
             for (int t = 0; t < TT; ++t) acc[mt][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
         // B fragments one K step ahead of the MFMAs that consume them (the compiler alternates read / wait / MFMA otherwise)
-        bf16x8 cur[TT], nxt[TT];
-        auto bload = [&](int s, bf16x8 (&dst)[TT]) {
-            const int soff = toff[s] + ((jout + tdsel[s]) & (NSLOT - 1)) * PLANE;
-            const char* base = lds + lanebase + soff;
-#pragma unroll
-            for (int t = 0; t < NT; ++t)
-                dst[t] = *reinterpret_cast<const bf16x8*>(base + (t / NTW) * RSB + (t % NTW) * 16 * VS);
-#pragma unroll
-            for (int t = NT; t < TT; ++t)
-                if (tile_on[t]) dst[t] = *reinterpret_cast<const bf16x8*>(lds + vb[t] + soff);
-        };
-        if (!(p.dbg & 2)) {
-        bload(0, cur);
-#pragma unroll
-        for (int s = 0; s < NSTEP; ++s) {
-            if (s + 1 < NSTEP) bload(s + 1, nxt);
-            __builtin_amdgcn_sched_barrier(0);                 // keep the reads of step s + 1 ahead of the MFMAs of step s
-#pragma unroll
-            for (int t = 0; t < TT; ++t)
-                if (tile_on[t]) {
-#pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) acc[mt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfr[mt][s], cur[t], acc[mt][t], 0, 0, 0);
+        // dm (FIN): 0 the planes of this output; 1 / 2: the padded plane -1 / Sd seen from output 1 / Sd - 2 -- only the taps that
+        // read depth 0 / Sd - 1 have a plane (ring plane jout / jout + 2), the others read the zero slot
+        // The tap loop over the tiles of bit mask M (compile time), B fragments one K step ahead.  RT: the run-time depth-mirror form
+        // (FIN) -- dm 1 / 2 = the padded plane -1 / Sd seen from output 1 / Sd - 2: only the taps that read depth 0 / Sd - 1 have a
+        // plane (ring plane jout / jout + 2), the others read the zero slot; the mirror tiles are switched by tile_on there.
+        auto mfma_loop = [&](auto maskc, auto rtc, int dm) {
+            constexpr unsigned M = decltype(maskc)::value;
+            constexpr bool RT = decltype(rtc)::value;
+            bf16x8 cur[TT], nxt[TT];
+            auto bload = [&](int s, bf16x8 (&dst)[TT]) {
+                int pl = ((jout + tdsel[s]) & (NSLOT - 1)) * PLANE;
+                if (RT) {
+                    const int want = dm == 1 ? 2 : 0, from = dm == 1 ? jout : jout + 2;
+                    pl = (tdsel[s] == want) ? (from & (NSLOT - 1)) * PLANE : NSLOT * PLANE;
                 }
-            __builtin_amdgcn_sched_barrier(0);
+                const int soff = toff[s] + pl;
+                const char* base = lds + lanebase + soff;
 #pragma unroll
-            for (int t = 0; t < TT; ++t) cur[t] = nxt[t];
-        }
+                for (int t = 0; t < TT; ++t) {
+                    if (!((M >> t) & 1u)) continue;
+                    if (t < NT) dst[t] = *reinterpret_cast<const bf16x8*>(base + (t / NTW) * RSB + (t % NTW) * 16 * VS);
+                    else if ((FIN && !RT) || tile_on[t]) dst[t] = *reinterpret_cast<const bf16x8*>(lds + vb[t] + soff);
+                }
+            };
+            bload(0, cur);
+#pragma unroll
+            for (int s = 0; s < NSTEP; ++s) {
+                if (s + 1 < NSTEP) bload(s + 1, nxt);
+                __builtin_amdgcn_sched_barrier(0);                 // keep the reads of step s + 1 ahead of the MFMAs of step s
+#pragma unroll
+                for (int t = 0; t < TT; ++t)
+                    if (((M >> t) & 1u) && (t < NT || (FIN && !RT) || tile_on[t])) {
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt) acc[mt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfr[mt][s], cur[t], acc[mt][t], 0, 0, 0);
+                    }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int t = 0; t < TT; ++t) cur[t] = nxt[t];
+            }
+        };
+        constexpr unsigned MALL = (1u << TT) - 1u, MMAIN = (1u << NT) - 1u;
+        if (!(p.dbg & 2)) {
+            if constexpr (FIN) {
+                // one loop with the wave's tiles in flight together (at most three).  EDGE = the workgroup's edge class (bit 0 top /
+                // bottom, bit 1 left / right): each class runs its own copy of the plane loop.  (Measured on 4 x 128^3, 8 -> 8: mirror
+                // tiles as loops of their own = chains of dependent LDS reads and MFMAs, 194 us; both mirror tiles in every wave (zero
+                // patch where there is none) = the LDS read path saturates, 187 us; the column tile in all four waves of an edge
+                // workgroup = those workgroups run 45 % longer and set the kernel's duration, 183 us.)
+                constexpr unsigned M0 = MMAIN | (1u << NT), M1 = MMAIN | (2u << NT);
+                if ((EDGE & 1) && xh) mfma_loop(std::integral_constant<unsigned, M0>{}, std::false_type{}, 0);
+                else if ((EDGE & 2) && wv == 1) mfma_loop(std::integral_constant<unsigned, M1>{}, std::false_type{}, 0);
+                else mfma_loop(std::integral_constant<unsigned, MMAIN>{}, std::false_type{}, 0);
+                const bool m1p = dpos == 1, m2p = dpos == Sd - 2;      // two planes of a volume
+                if (m1p || m2p) {
+#pragma unroll 1
+                    for (int ps = (m1p ? 1 : 2); ps <= (m2p ? 2 : 1); ++ps) mfma_loop(std::integral_constant<unsigned, MALL>{}, std::true_type{}, ps);
+                }
+                if ((EDGE & 1) && xh) { if (xh_tgt) acc[0][1] += acc[0][NT]; else acc[0][0] += acc[0][NT]; }
+                if constexpr ((EDGE & 2) != 0) {
+                    float* xbuf = reinterpret_cast<float*>(lds + G::RING);
+                    if (wv == 1) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) xbuf[(g * 4 + j) * 16 + n] = acc[0][NT + 1][j];
+                    }
+                    __syncthreads();                                   // (the barrier at the top of the next plane separates this read from the next write)
+                    const float here = n == wlane ? 1.f : 0.f;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float* xr = xbuf + (g * 4 + j) * 16;
+                        float a0 = xr[r0 + 1], a1 = xr[r0 + 2];
+                        if (wtop && wv == 0) a1 += xr[0];              // the corners: padded row -1 onto row 1, row Sh onto row Sh - 2
+                        if (wbot && wv == 3) a0 += xr[MTH + 1];
+                        acc[0][0][j] += here * a0;
+                        acc[0][1][j] += here * a1;
+                    }
+                }
+            } else {
+                mfma_loop(std::integral_constant<unsigned, MALL>{}, std::false_type{}, 0);
+            }
         }
         if (p.dbg & 4) return;
-        const unsigned ob = (unsigned)(DG ? dpos + 1 : dpos) * oplane;
+        const unsigned ob = (unsigned)((DG && !FIN) ? dpos + 1 : dpos) * oplane;
 #pragma unroll
-        for (int t = 0; t < TT; ++t) {
+        for (int t = 0; t < ET; ++t) {
             if (!tile_on[t]) continue;
             const bool valid = pvalid && ((vmask >> t) & 1u);
             const unsigned obyte = (ob + oel[t]) * 2u;         // < 2^32: one sample of the output / scratch volume
@@ -462,7 +575,7 @@ void conv_march_kernel(ConvK p, MarchP mp) {
             } else {
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) {
-                    const u32x2 xr = eo[mt * TT + t];
+                    const u32x2 xr = eo[mt * ET + t];
                     const float xv[4] = {__uint_as_float(xr.x << 16), __uint_as_float(xr.x & 0xffff0000u),
                                          __uint_as_float(xr.y << 16), __uint_as_float(xr.y & 0xffff0000u)};
                     const float vf = (valid && e_ok[mt] && e_st[mt]) ? 1.f : 0.f;
@@ -471,10 +584,14 @@ void conv_march_kernel(ConvK p, MarchP mp) {
                     for (int j = 0; j < 4; ++j) {
                         const float xh = e_st[mt] ? (xv[j] - emean[mt][j]) * erstd[mt][j] : 1.f;
                         const float gg = gv[j] * (xh > 0.f ? f_pos[mt] : f_neg[mt]);
-                        gv[j] = gg;
-                        const float gs = gg * vf;
-                        s1[mt][j] += gs;
-                        s2v[mt][j] = __builtin_fmaf(gs, xh, s2v[mt][j]);
+                        if (FIN) {                             // second half of the InstanceNorm backward, means known beforehand
+                            gv[j] = e_st[mt] ? erstd[mt][j] * (gg - fm1[j] - xh * fm2[j]) : gg;
+                        } else {
+                            gv[j] = gg;
+                            const float gs = gg * vf;
+                            s1[mt][j] += gs;
+                            s2v[mt][j] = __builtin_fmaf(gs, xh, s2v[mt][j]);
+                        }
                     }
                     if (valid && e_ok[mt]) store4(reinterpret_cast<bf16_t*>(yb8 + obyte + mt * 32), gv);
                 }
@@ -494,21 +611,32 @@ void conv_march_kernel(ConvK p, MarchP mp) {
         commit(j, raw[j]);
         fetch(j + ND, raw[j]);
     }
-    for (int j0 = 3; j0 < L + 3; j0 += ND) {
+    auto run = [&](auto edgec) {
+        for (int j0 = 3; j0 < L + 3; j0 += ND) {
 #pragma unroll
-        for (int jj = 0; jj < ND; ++jj) {
-            const int j = j0 + jj;                             // raw slot (3 + jj) & 3, output j - 3 in operand slot jj
-            __syncthreads();
-            if (!(p.dbg & 1)) {                                // developer timing switches (PASSION_CONV_DBG): 1 no staging, 2 no MFMA loop, 4 no epilogue
-                commit(j, raw[(3 + jj) & 3]);
-                fetch(j + ND, raw[(3 + jj) & 3]);
+            for (int jj = 0; jj < ND; ++jj) {
+                const int j = j0 + jj;                             // raw slot (3 + jj) & 3, output j - 3 in operand slot jj
+                __syncthreads();
+                if (!(p.dbg & 1)) {                                // developer timing switches (PASSION_CONV_DBG): 1 no staging, 2 no MFMA loop, 4 no epilogue
+                    commit(j, raw[(3 + jj) & 3]);
+                    fetch(j + ND, raw[(3 + jj) & 3]);
+                }
+                compute(edgec, j - 3, eop[jj]);
+                eload(j - 3 + ND, eop[jj]);
             }
-            compute(j - 3, eop[jj]);
-            eload(j - 3 + ND, eop[jj]);
         }
+    };
+    if constexpr (FIN) {
+        const bool ewg_h = (h0 == 0 || h0 + MTH == Sh) && !(p.dbg & (8 | 256)), ewg_w = xw && !(p.dbg & (8 | 128));
+        if (!ewg_h && !ewg_w) run(std::integral_constant<int, 0>{});
+        else if (ewg_h && !ewg_w) run(std::integral_constant<int, 1>{});
+        else if (!ewg_h) run(std::integral_constant<int, 2>{});
+        else run(std::integral_constant<int, 3>{});
+    } else {
+        run(std::integral_constant<int, 0>{});
     }
 
-    if (DG || fstats) {
+    if ((DG && !FIN) || fstats) {
         // InstanceNorm-backward sums (MODE 2) / statistics of y (MODE 0): 16 voxel lanes (shuffles) -> 4 waves (LDS, fixed
         // order) -> this workgroup's own slot
         __syncthreads();
@@ -543,18 +671,19 @@ void conv_march_kernel(ConvK p, MarchP mp) {
     }
 }
 
-template <int NB, int TW, int MODE, bool HAS_RES, int MT = 1>
+template <int NB, int TW, int MODE, bool HAS_RES, int MT = 1, bool FIN = false>
 int launch_march_res(ConvK& k, const MarchP& mp, hipStream_t st) {
-    using G = GeoM<NB, TW>;
+    using G = GeoM<NB, TW, FIN>;
     static bool granted = false;
     if (!granted) {
-        HIP_RET(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_march_kernel<NB, TW, MODE, HAS_RES, MT>),
+        HIP_RET(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_march_kernel<NB, TW, MODE, HAS_RES, MT, FIN>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS));
         granted = true;
     }
-    if (MT == 1) passion_prof_tag("conv_march_kernel<%d, %d, %d, %d>", NB, TW, MODE, HAS_RES ? 1 : 0);
+    if (FIN) passion_prof_tag("conv_march_kernel<%d, %d, %d, %d, %d, 1>", NB, TW, MODE, HAS_RES ? 1 : 0, MT);
+    else if (MT == 1) passion_prof_tag("conv_march_kernel<%d, %d, %d, %d>", NB, TW, MODE, HAS_RES ? 1 : 0);
     else passion_prof_tag("conv_march_kernel<%d, %d, %d, %d, %d>", NB, TW, MODE, HAS_RES ? 1 : 0, MT);
-    hipLaunchKernelGGL((conv_march_kernel<NB, TW, MODE, HAS_RES, MT>), dim3(k.B * mp.nwg_b), dim3(256), G::LDS, st, k, mp);
+    hipLaunchKernelGGL((conv_march_kernel<NB, TW, MODE, HAS_RES, MT, FIN>), dim3(k.B * mp.nwg_b), dim3(256), G::LDS, st, k, mp);
     LAUNCH_RET();
     return 0;
 }
@@ -564,17 +693,23 @@ int launch_march_one(ConvK& k, hipStream_t st) {
     using G = GeoM<NB, TW>;
     MarchP mp;
     mp.tilesH = k.Hi / MTH; mp.tilesW = k.Wi / TW;
-    const int dcount = MODE == 2 ? k.Di + 2 : k.Di;
+    const bool fin = MODE == 2 && k.pwm != nullptr;          // fold-free input gradient with the final epilogue (means in k.pwm)
+    const int dcount = (MODE == 2 && !fin) ? k.Di + 2 : k.Di;
     const int tiles = mp.tilesH * mp.tilesW;
     // D segments: about g_conv_target workgroups per launch, at least 8 output planes per segment (2 halo planes each)
     int nseg = (int)hmax(1, (g_conv_target + (long)k.B * tiles - 1) / ((long)k.B * tiles));
     static const int min_planes = []() { const char* e = getenv("PASSION_MARCH_PLANES"); return e && atoi(e) > 0 ? atoi(e) : 16; }();
     nseg = (int)hmin(nseg, hmax(1, dcount / min_planes));
-    if (MODE == 2) nseg = (int)hmin(nseg, hmax(1, SUMS_SLOTS / tiles));      // one sums slot per workgroup of a sample
+    if (MODE == 2 && !fin) nseg = (int)hmin(nseg, hmax(1, SUMS_SLOTS / tiles));      // one sums slot per workgroup of a sample
     mp.planes_per_seg = (dcount + nseg - 1) / nseg;
     mp.nseg_d = (dcount + mp.planes_per_seg - 1) / mp.planes_per_seg;
     mp.nwg_b = mp.nseg_d * tiles;
     mp.k8 = k.march_k8 > 0 ? k.march_k8 : NB;
+    if (fin) {
+        if (TW != 16 || NB != 1 || k.Mpad != 16 || k.pad_mode != PASSION_PAD_REFLECT || k.Wi < 32 || k.Hi < 16) return 1;    // (a tile touches one edge per axis at most)
+        k.pw_done = 1;
+        return launch_march_res<1, 16, 2, false, 1, true>(k, mp, st);
+    }
     if (MODE == 2) {
         if (mp.nwg_b > SUMS_SLOTS) return 1;
         k.sums_rep = mp.nwg_b;

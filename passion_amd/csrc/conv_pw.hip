@@ -804,6 +804,59 @@ __global__ __launch_bounds__(128) void pw_ident_kernel(ConvK p, const float* __r
     out[((long)b * p.Cin + ci) * 2 + 1] = hs ? m2 * inv_v : 0.f;
 }
 
+// The same for a 3x3x3 layer (27 taps; conv_wgrad_march.hip leaves the indicator slab): blocks 0 .. B - 1: the means of sample b, one
+// thread per input channel; blocks >= B: the weight / bias gradient of every weight set = the sum of its samples' folds (sample order).
+// dwb [B][Cout Cin 27 + Cout], pb [B][Cout Cin 27]; wdg: bf16 dgrad image [27][Cout / 8][mpad][8] of set 0, sets wset_el elements apart.
+struct MarchOuts { float* dw[PASSION_MAX_GROUPS]; float* db[PASSION_MAX_GROUPS]; };
+__global__ __launch_bounds__(128) void march_ident_kernel(ConvK p, const float* __restrict__ dwb, const float* __restrict__ pb, const bf16_t* __restrict__ wdg,
+                                                          long wset_el, int mpad, float inv_v, float* __restrict__ out, MarchOuts mo, int G) {
+    const long nW = (long)p.Cout * p.Cin * 27;
+    const int bg = p.B / G;                                     // samples per weight set
+    if ((int)blockIdx.x >= p.B) {
+        const long i = (long)(blockIdx.x - p.B) * 128 + threadIdx.x;
+        if (i >= nW + p.Cout) return;
+        for (int g2 = 0; g2 < G; ++g2) {
+            float t = 0.f;
+            for (int b2 = g2 * bg; b2 < (g2 + 1) * bg; ++b2) t += dwb[(long)b2 * (nW + p.Cout) + i];
+            if (i < nW) { if (mo.dw[g2]) mo.dw[g2][i] = t; }
+            else if (mo.db[g2]) mo.db[g2][i - nW] = t;
+        }
+        return;
+    }
+    const int b = blockIdx.x, ci = threadIdx.x;
+    if (ci >= p.Cin) return;
+    const uint8_t* mk = nullptr;
+    int mld = 0, mcol = 0;
+    bool hs = false;
+#pragma unroll
+    for (int s2 = 0; s2 < PASSION_MAX_SEG; ++s2) {
+        if (s2 < p.nseg) {
+            const SegD& sd = p.seg[s2];
+            if (ci >= sd.cbase && ci < sd.cbase + sd.C) {
+                hs = sd.stats != nullptr && sd.dx != nullptr;
+                mk = sd.mask; mld = sd.mask_ld; mcol = sd.mask_col;
+            }
+        }
+    }
+    const float mval = (mk && mk[(long)b * mld + mcol] == 0) ? 0.f : 1.f;
+    const float* dw = dwb + (long)b * (nW + p.Cout);
+    const float* pp = pb + (long)b * nW;
+    const bf16_t* w0 = wdg + (long)(b / bg) * wset_el;
+    const int K8 = p.Cout / 8;
+    float m1 = 0.f, m2 = 0.f;
+    for (int co = 0; co < p.Cout; ++co) {
+        const float dbv = p.slope * dw[nW + co] * mval;
+        for (int t = 0; t < 27; ++t) {
+            const float w = (float)w0[(((long)t * K8 + (co >> 3)) * mpad + ci) * 8 + (co & 7)];
+            const long e = ((long)co * p.Cin + ci) * 27 + t;
+            m2 = __builtin_fmaf(w, dw[e], m2);
+            m1 = __builtin_fmaf(w, dbv + (1.f - p.slope) * pp[e], m1);
+        }
+    }
+    out[((long)b * p.Cin + ci) * 2 + 0] = hs ? m1 * inv_v : 0.f;
+    out[((long)b * p.Cin + ci) * 2 + 1] = hs ? m2 * inv_v : 0.f;
+}
+
 // the input gradient (conv_lean.hip mode 1 for ksize 1): K8 = blocks of 8 dY channels; k.wpack (transposed images), k.Mpad = pad16(Cin),
 // k.sums_rep / sums_fixed set by the caller
 // shapes whose gradient the kernels below take (so that conv.hip may plan the finish-free order: weight gradient first)
@@ -836,6 +889,23 @@ int launch_pw_ident(const ConvK& k, const float* wslab, long wslot, const float*
     const double V = (double)k.Di * k.Hi * k.Wi;
     hipLaunchKernelGGL(pw_ident_kernel, dim3((unsigned)(k.B + (nW + k.Cout + 127) / 128)), dim3(128), 0, st, k, (const float*)dwb, (const float*)pb,
                        (const bf16_t*)wdg_bf16, pad16(k.Cin), (float)(1.0 / V), out, dweight, dbias, bm);
+    LAUNCH_RET();
+    return 0;
+}
+
+// 3x3x3 (conv.hip: march_final): per-sample folds of the weight-gradient slab and the indicator slab (both with slot stride wslot),
+// the means, and dW / db of each of the G weight sets.  dw_out[g] / db_out[g]: nullptr = not wanted.
+int launch_march_ident(const ConvK& k, const float* wslab, long wslot, const float* sslab, int wgs_per_b, const void* wdg_bf16, long wset_el,
+                       float* dwb, float* pb, float* out, float* const* dw_out, float* const* db_out, int G, hipStream_t st) {
+    const long nW = (long)k.Cout * k.Cin * 27;
+    const unsigned gx = (unsigned)((nW + k.Cout + 15) / 16 + (nW + 15) / 16);
+    hipLaunchKernelGGL(pw_fold_sample_kernel, dim3(gx, k.B), dim3(256), 0, st, wslab, nW + k.Cout, wslot, dwb, sslab, nW, wslot, pb, wgs_per_b);
+    LAUNCH_RET();
+    MarchOuts mo;
+    for (int g = 0; g < PASSION_MAX_GROUPS; ++g) { mo.dw[g] = g < G ? dw_out[g] : nullptr; mo.db[g] = g < G ? db_out[g] : nullptr; }
+    const double V = (double)k.Di * k.Hi * k.Wi;
+    hipLaunchKernelGGL(march_ident_kernel, dim3((unsigned)(k.B + (nW + k.Cout + 127) / 128)), dim3(128), 0, st, k, (const float*)dwb, (const float*)pb,
+                       (const bf16_t*)wdg_bf16, wset_el, pad16(k.Cin), (float)(1.0 / V), out, mo, G);
     LAUNCH_RET();
     return 0;
 }

@@ -64,12 +64,16 @@ struct WMarchP {
     int nseg_d, planes_per_seg;    // D segments per tile; a unit = (tile, segment), dealt round-robin to the sample's workgroups
 };
 
-template <int DBG>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void wgrad_march_kernel(ConvK p, WMarchP mp, float* __restrict__ dW, float* __restrict__ dbias) {
+// IND: a second set of column tiles over the 0/1 image of x_hat > 0 (same taps, same rows): P[co][ci][tap] = sum_vox dY[vox][co] *
+// [x_hat[vox + tap][ci] > 0] goes to the slab p.spos.  With it the InstanceNorm-backward means of the layer follow from this
+// weight gradient (march_ident_kernel below; conv_pw.hip has the identities) and the input-gradient kernel writes dx itself.
+template <int DBG, bool IND>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(IND ? 3 : 4, IND ? 3 : 4))) void wgrad_march_kernel(ConvK p, WMarchP mp, float* __restrict__ dW, float* __restrict__ dbias) {
     wgrad_clear(p);
-    __shared__ __attribute__((aligned(16))) char lds[LDS_BYTES];
+    __shared__ __attribute__((aligned(16))) char lds[LDS_BYTES + (IND ? XBYTES : 0)];
     char* const lx = lds;
     char* const ly = lds + XBYTES;
+    char* const li = lds + XBYTES + YBYTES;           // IND: ring of the indicator planes (behind the reduction buffer's span)
 
     const int tid = threadIdx.x, lane = tid & 63, n = lane & 15, g = lane >> 4;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -136,9 +140,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     const int h = pq >> 1;
     const int xlane = (row * XRW + col) * 16 + (pq & 1) * 8;
     const int xlaneA = xlane + h * 16, xlaneB = xlane + h * (XRW * 16);
-    f32x4 acc[NT];
+    f32x4 acc[NT], acc2[IND ? NT : 1];
 #pragma unroll
     for (int j = 0; j < NT; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < (IND ? NT : 1); ++j) acc2[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const bool bias_block = (dbias != nullptr) && (gb0 == 0);
     f32x2 bsum[4];
 #pragma unroll
@@ -193,6 +199,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             const bool yin = pl >= dlo && pl < dhi;       // (stages past the unit's end are never committed)
             if (xthr) {
                 u32x4 o = (u32x4){0u, 0u, 0u, 0u};    // zero padding is applied AFTER norm + activation
+                u32x4 oi = (u32x4){0u, 0u, 0u, 0u};   // IND: bf16 1.0 where x_hat > 0 (0x3f80 per half)
                 if (xok && okd) {
                     o = ra[u];
                     if (has_norm) {
@@ -201,6 +208,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                         for (int c = 0; c < 4; ++c) {      // bf16 pairs -> f32: low half = even channel
                             const f32x2 xv = {__uint_as_float(ra[u][c] << 16), __uint_as_float(ra[u][c] & 0xffff0000u)};
                             f32x2 t = __builtin_elementwise_fma(xv, sc[c], sh[c]);
+                            if (IND) oi[c] = (t.x > 0.f ? 0x3f80u : 0u) | (t.y > 0.f ? 0x3f800000u : 0u);
                             const f32x2 ts = t * slope2;   // LeakyReLU for 0 <= slope <= 1: max(t, slope t)
                             t.x = fmaxf(t.x, ts.x);
                             t.y = fmaxf(t.y, ts.y);
@@ -210,6 +218,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                     }
                 }
                 *reinterpret_cast<u32x4*>(lx + u * XSLOT + xlds) = o;
+                if (IND) *reinterpret_cast<u32x4*>(li + u * XSLOT + xlds) = oi;
             }
             if (ythr) {
                 const u32x4 o = yin ? rd[u] : (u32x4){0u, 0u, 0u, 0u};
@@ -234,6 +243,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                 const bf16x8 bv = tr_read8(bp, bp + 64);
                 if (DBG & 16) acc[j][0] += (float)bv[0] + (float)a[0];
                 else acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bv, acc[j], 0, 0, 0);
+                if (IND) {
+                    const char* bi = bp + (li - lx);
+                    const bf16x8 iv = tr_read8(bi, bi + 64);
+                    acc2[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, iv, acc2[j], 0, 0, 0);
+                }
             }
         };
 
@@ -264,34 +278,43 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 
     // ---- the four waves hold partial sums over disjoint voxels of the SAME outputs: combine through LDS in fixed order, and
     // write this workgroup's slot of the partial-sum slab (plain stores; reduce_parts_kernel folds the slots)
-    __syncthreads();
     f32x4* red = reinterpret_cast<f32x4*>(lds);
+    auto flush = [&](const f32x4 (&av)[NT], float* slab) {
+        __syncthreads();
 #pragma unroll
-    for (int j = 0; j < NT; ++j) red[(wv * NT + j) * 64 + lane] = acc[j];
-    __syncthreads();
-    if (dW && exist) {
-        float* slot = dW + (long)bx * p.wslot;
-        for (int e = tid; e < NT * 64; e += 256) {
-            const int j = e >> 6, l2 = e & 63, n2 = l2 & 15, g2 = l2 >> 4;
-            f32x4 v = red[e];
+        for (int j = 0; j < NT; ++j) red[(wv * NT + j) * 64 + lane] = av[j];
+        __syncthreads();
+        if (slab && exist) {
+            float* slot = slab + (long)bx * p.wslot;
+            for (int e = tid; e < NT * 64; e += 256) {
+                const int j = e >> 6, l2 = e & 63, n2 = l2 & 15, g2 = l2 >> 4;
+                f32x4 v = red[e];
 #pragma unroll
-            for (int w2 = 1; w2 < 4; ++w2) {
-                const f32x4 o = red[w2 * NT * 64 + e];
+                for (int w2 = 1; w2 < 4; ++w2) {
+                    const f32x4 o = red[w2 * NT * 64 + e];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] += o[r];
-            }
-            const int h2 = n2 >> 3, ci = n2 & 7, jj = j < 4 ? j : j - 5;
-            const int dsel = (j == 4) ? h2 : (j > 4 ? 1 : 0), s = g2 >> 1;
-            const int hw = (j == 4) ? 8 : (jj < 3 ? 3 * jj + h2 : 2 + 3 * h2);
-            if (s == 1 && dsel == 0) continue;        // depth tap 0 a second time
-            const int tap = (dsel + s) * 9 + hw;
-            const long cig = cbase + c0 + ci;
+                    for (int r = 0; r < 4; ++r) v[r] += o[r];
+                }
+                const int h2 = n2 >> 3, ci = n2 & 7, jj = j < 4 ? j : j - 5;
+                const int dsel = (j == 4) ? h2 : (j > 4 ? 1 : 0), s = g2 >> 1;
+                const int hw = (j == 4) ? 8 : (jj < 3 ? 3 * jj + h2 : 2 + 3 * h2);
+                if (s == 1 && dsel == 0) continue;        // depth tap 0 a second time
+                const int tap = (dsel + s) * 9 + hw;
+                const long cig = cbase + c0 + ci;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int co = (g2 & 1) * 4 + r;
-                slot[((long)co * p.Cin + cig) * 27 + tap] = v[r];
+                for (int r = 0; r < 4; ++r) {
+                    const int co = (g2 & 1) * 4 + r;
+                    slot[((long)co * p.Cin + cig) * 27 + tap] = v[r];
+                }
             }
         }
+    };
+    flush(acc, dW);
+    if (IND) {                                         // the indicator slab: same slots (stride p.wslot), base p.spos
+        f32x4 a2[NT];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) a2[j] = acc2[j];
+        flush(a2, p.spos);
     }
     if (bias_block) {
         __syncthreads();
@@ -350,12 +373,18 @@ int launch_wgrad_march(ConvK& k, int ksize, int stride, int MT, int gx, int gy, 
     }
     mp.planes_per_seg = (k.Di + best - 1) / best;
     mp.nseg_d = (k.Di + mp.planes_per_seg - 1) / mp.planes_per_seg;
+    if (k.spos) {                  // finish-free backward (conv.hip: march_final): the indicator slab rides along
+        passion_prof_tag("wgrad_march_kernel<0, 1>");
+        hipLaunchKernelGGL((wgrad_march_kernel<0, true>), dim3(gx, gy), dim3(256), 0, st, k, mp, dW, db);
+        LAUNCH_RET();
+        return 0;
+    }
     passion_prof_tag("wgrad_march_kernel<0>");
     switch (g_conv_dbg) {          // developer timing builds; 0 is the product
-#define WM_CASE(D) case D: hipLaunchKernelGGL(wgrad_march_kernel<D>, dim3(gx, gy), dim3(256), 0, st, k, mp, dW, db); break;
+#define WM_CASE(D) case D: hipLaunchKernelGGL((wgrad_march_kernel<D, false>), dim3(gx, gy), dim3(256), 0, st, k, mp, dW, db); break;
         WM_CASE(1) WM_CASE(2) WM_CASE(8) WM_CASE(16) WM_CASE(32) WM_CASE(33) WM_CASE(3) WM_CASE(34)
 #undef WM_CASE
-        default: hipLaunchKernelGGL(wgrad_march_kernel<0>, dim3(gx, gy), dim3(256), 0, st, k, mp, dW, db);
+        default: hipLaunchKernelGGL((wgrad_march_kernel<0, false>), dim3(gx, gy), dim3(256), 0, st, k, mp, dW, db);
     }
     LAUNCH_RET();
     return 0;

@@ -75,6 +75,12 @@ CONV_CASES = [
     ([32, 32], 32, 3, 1, 1, (20, 20, 20), True, False, False),
     ([64], 64, 1, 1, 0, (16, 16, 16), True, False, False),
     ([64, 64, 64, 64], 64, 1, 1, 0, (10, 10, 10), True, True, False),
+    # the finest level's 3x3x3 layers (8 output channels, H % 8 = W % 16 = 0, D >= 8): finish-free backward -- weight gradient with
+    # the indicator slab first, means from it, fold-free marching input gradient (conv_march.hip FIN); one / two tiles per axis
+    ([8], 8, 3, 1, 1, (8, 8, 16), True, False, False),
+    ([16], 8, 3, 1, 1, (16, 16, 32), True, False, True),
+    ([8, 8], 8, 3, 1, 1, (8, 16, 16), True, True, False),
+    ([8], 8, 3, 1, 1, (24, 24, 48), True, False, False),
 ]
 
 
@@ -124,6 +130,43 @@ def test_conv_block_fwd_bwd(case, dtype):
     for i in range(len(segC)):
         e = relerr(nc(xd[i].grad.float()), xr[i].grad)
         assert e < tol * 3, f"dx[{i}] {e}"
+
+
+@pytest.mark.parametrize("shape", [([8], (8, 8, 16)), ([8, 8], (16, 16, 32)), ([16], (40, 24, 48)), ([8], (130, 16, 32))])
+def test_finish_free_marching_backward_equals_dgrad_plus_finish(shape):
+    """the finest level's backward in its two forms on the same inputs: (weight gradient with indicator slab -> means -> fold-free
+    marching input gradient with the final epilogue) against (weight gradient, padded-domain input gradient, finish kernel): input
+    gradients to the bf16 rounding of the stored values, weight / bias gradients to the f32 summation order; twice for bit equality"""
+    from passion_amd import ops
+    dev = _dev()
+    segC, (D, H, W) = shape
+    dtype, B = torch.bfloat16, 3
+    g = torch.Generator().manual_seed(41 + D)
+    xs = [(torch.randn(B, D, H, W, c, generator=g) * 1.5 + 0.3).to(dtype) for c in segC]
+    cin = sum(segC)
+    w = torch.randn(8, cin, 3, 3, 3, generator=g) / (cin * 27) ** 0.5
+    b = torch.randn(8, generator=g)
+    gy = torch.randn(B, D, H, W, 8, generator=g).to(dtype)
+    mask = torch.tensor([[True, True], [False, True], [True, False]])[:, :len(segC)].to(dev) if len(segC) > 1 else None
+    res = {}
+    for mode in (1, 0, 1):
+        old = ops.set_option("conv_marchfinal", mode)
+        try:
+            xd = [x.to(dev).requires_grad_(True) for x in xs]
+            wd, bd = w.to(dev).requires_grad_(True), b.to(dev).requires_grad_(True)
+            segs = [ops.SegIn(x, stats=ops.instnorm_stats(x.detach()), mask=mask, mask_col=i) for i, x in enumerate(xd)]
+            y = ops.conv_block(segs, wd, bd, D, H, W, ksize=3, stride=1, pad_mode=1)
+            y.backward(gy.to(dev))
+            torch.cuda.synchronize()
+            out = (wd.grad.clone(), bd.grad.clone(), [x.grad.clone() for x in xd])
+            if mode in res:
+                assert torch.equal(out[0], res[mode][0]) and all(torch.equal(a, c) for a, c in zip(out[2], res[mode][2]))
+            res[mode] = out
+        finally:
+            ops.set_option("conv_marchfinal", old)
+    assert relerr(res[1][0], res[0][0]) < 1e-4 and relerr(res[1][1], res[0][1]) < 1e-4
+    for a, c in zip(res[1][2], res[0][2]):
+        assert relerr(a.float(), c.float()) < 1.5e-2, relerr(a.float(), c.float())
 
 
 PW_CASES = [

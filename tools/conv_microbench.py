@@ -30,7 +30,7 @@ for _ in range(3):
     if mode == "bwd":
         y.backward(gy)
 torch.cuda.synchronize()
-ops.prof_enable(15)
+ops.prof_enable(15 | 64)
 t0 = time.time()
 for _ in range(iters):
     y = run()
@@ -40,11 +40,11 @@ torch.cuda.synchronize()
 dt = (time.time() - t0) / iters
 ops.prof_enable(0)
 recs = ops.prof_read()
-names = {0: "fwd_k3", 1: "fwd_k1", 2: "dgrad", 3: "wgrad"}
+names = {0: "fwd_k3", 1: "fwd_k1", 2: "dgrad", 3: "wgrad", 6: "finish"}
 So = S // stride
 alg = NB * (cin * S ** 3 + cout * So ** 3) * 2
 print(f"{mode} cin={cin} (segments {segs_c}) cout={cout} S={S} k={k} stride={stride}: wall {dt*1e6:.1f} us/iter, algorithmic {alg/1e6:.1f} MB")
-for kind in range(4):
+for kind in (0, 1, 2, 3, 6):
     r = [x for x in recs if x[0] == kind]
     if r:
         ms = sum(x[1] for x in r) / len(r)
