@@ -153,13 +153,28 @@ def dice_vs_ref(device, dtype, S):
     tpath = os.path.join(ROOT, "tests", "golden", "traj_plain_128.npz")
     if os.path.exists(tpath):
         g = gold("traj_plain_128.npz")
-        _, losses, pred = replay_trajectory(g, dtype, device)
-        got = pred.argmax(1).reshape(-1).cpu().numpy().astype(np.uint8)
-        d, n = mask_dice(got, unpack2(g["argmax_packed"], S ** 3))
-        out["trained"] = {"mean_dice": round(d, 6), "dice_wt_tc_et": [round(v, 6) for v in mask_dice.last], "differing_voxels": n,
-                          "agreement": round(1.0 - n / S ** 3, 6), "of": S ** 3, "steps_replayed": int(g["K"]),
-                          "loss_final": round(float(losses[-1]), 5), "loss_final_ref": round(float(g["losses"][-1]), 5),
-                          "fixture": "tests/golden/traj_plain_128.npz"}
+        ref_mask = unpack2(g["argmax_packed"], S ** 3)
+        label = unpack2(g["label_packed"], S ** 3)
+        d_ref_label, _ = mask_dice(ref_mask, label)
+        ref_label = [round(v, 6) for v in mask_dice.last]
+        # the benchmarked dtype, and f32 = the mode north_star states its tolerance for (expected: the reference's mask up to its own
+        # near ties).  Beside "vs the reference's mask" (near ties flip with rounding: the enhancing class is 0.7 % of the volume) each
+        # replay is scored against the LABEL volume like the reference itself: model quality, not tie-breaking.
+        for tag, dt_ in ((("trained", dtype),) if dtype == torch.float32 else (("trained", dtype), ("trained_f32", torch.float32))):
+            _, losses, pred = replay_trajectory(g, dt_, device)
+            got = pred.argmax(1).reshape(-1).cpu().numpy().astype(np.uint8)
+            d, n = mask_dice(got, ref_mask)
+            rec = {"mean_dice": round(d, 6), "dice_wt_tc_et": [round(v, 6) for v in mask_dice.last], "differing_voxels": n,
+                   "agreement": round(1.0 - n / S ** 3, 6), "of": S ** 3, "steps_replayed": int(g["K"]),
+                   "dtype": "bf16" if dt_ == torch.bfloat16 else "f32",
+                   "loss_final": round(float(losses[-1]), 5), "loss_final_ref": round(float(g["losses"][-1]), 5),
+                   "fixture": "tests/golden/traj_plain_128.npz"}
+            d_lab, _ = mask_dice(got, label)
+            rec["vs_label"] = {"mean_dice": round(d_lab, 6), "dice_wt_tc_et": [round(v, 6) for v in mask_dice.last],
+                               "reference_mean_dice": round(d_ref_label, 6), "reference_dice_wt_tc_et": ref_label}
+            out[tag] = rec
+            del pred
+            torch.cuda.empty_cache()
     g = gold("model_full128_idt_plain_1111.npz")
     m = build_product_model(S, small=False).to(device)
     m.mask_type, m.use_passion, m.is_training, m.compute_dtype = "idt", False, False, dtype
@@ -177,19 +192,22 @@ def dice_vs_ref(device, dtype, S):
 
 
 def measured_copy_gbs(device):
-    """device-to-device copy of 1 GiB (read + write counted), the 'measured peak' SURVEY 8(d) asks for beside the nominal one"""
+    """device-to-device copy of 1 GiB (read + write counted) with the library's 16-bytes-per-lane streaming kernel: the 'measured
+    peak' SURVEY 8(d) asks for beside the nominal one (the guide's float4 copy: 6.29 TB/s)"""
     import torch
-    a = torch.empty(1 << 29, dtype=torch.bfloat16, device=device)
+    from passion_amd import _lib as L
+    a = torch.empty(1 << 30, dtype=torch.uint8, device=device)
     b = torch.empty_like(a)
+    lib = L.load()
     for _ in range(2):
-        b.copy_(a)
+        L.check(lib.passion_stream_copy(b.data_ptr(), a.data_ptr(), a.numel(), L.stream_ptr()), "passion_stream_copy")
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(5):
-        b.copy_(a)
+        L.check(lib.passion_stream_copy(b.data_ptr(), a.data_ptr(), a.numel(), L.stream_ptr()), "passion_stream_copy")
     e1.record()
     torch.cuda.synchronize()
-    return 5 * 2 * a.numel() * 2 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+    return 5 * 2 * a.numel() / (e0.elapsed_time(e1) * 1e-3) / 1e9
 
 
 FAM = {0: "fwd3", 1: "fwd1", 2: "dgrad", 3: "wgrad", 4: "attn_fwd", 5: "attn_bwd", 6: "dgrad_finish"}
@@ -510,8 +528,10 @@ def main():
             ms, by, fl = sum(r[1] for r in rk), sum(r[2] for r in rk), sum(r[3] for r in rk)
             ach = by / (ms * 1e-3) / 1e9
             traffic = None
-            tpath = os.path.join(ROOT, "profiles", "traffic.json")
-            if os.path.exists(tpath):
+            # counter traffic of THIS workload's launches (tools/pmc_traffic.sh profiles/traffic_<workload>.json --workload ...): the
+            # average over the same set of launches as the algorithmic bytes above; no file for the workload = null
+            tpath = os.path.join(ROOT, "profiles", f"traffic_{args.workload}.json")
+            if os.path.exists(tpath) and S == 128:
                 tj = json.load(open(tpath)).get("bytes_per_launch", {})
                 # rocprofv3 spells a bool template argument true / false, the library's tag 1 / 0
                 import re as _re

@@ -374,6 +374,9 @@ int passion_adamw_step_dev(int n, float* const* params, const float* const* grad
                            float* const* exp_avg_sq, float* const* max_exp_avg_sq, const int64_t* numel,
                            double beta1, double beta2, double eps, int amsgrad, const float* hyper_dev, void* stream);
 int passion_write_words(void* dst, int n, const uint32_t* words, void* stream);
+/* streaming device copy of `bytes` (multiple of 16, 16-byte aligned pointers): 16 bytes per lane, grid-stride -- the measured
+ * HBM copy rate bench.py quotes beside the 8 TB/s nominal peak */
+int passion_stream_copy(void* dst, const void* src, int64_t bytes, void* stream);
 void passion_set_step_words(const void* dev_words);
 
 /* ---- training input pipeline on the GPU -------------------------------------------------

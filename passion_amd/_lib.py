@@ -152,6 +152,7 @@ SIGNATURES = {
                                        c_int, c_void_p, c_void_p]),
     "passion_write_words": (c_int, [c_void_p, c_int, c_void_p, c_void_p]),
     "passion_set_step_words": (None, [c_void_p]),
+    "passion_stream_copy": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
     "passion_set_option": (c_int, [c_char_p, c_int]),
     "passion_prof_enable": (None, [c_int]),
     "passion_prof_filter": (None, [c_double, c_double]),

@@ -226,4 +226,8 @@ def test_240x240x160_two_ranks(tmp_path, dtype_name):
               f"{worst2[0]:.2e} ({worst2[1]}), max norm {worstm[0]:.2e} ({worstm[1]})")
     else:
         un = _unsharded(shape, torch.bfloat16)
-        _compare(sh, un, ref, "depth 240x240x160 bf16, 2 ranks")
+        # floor 3e-3 (2e-3 until round 4): with the deep levels on conv_deep.hip -- K chunks summed side by side instead of one after the
+        # other: another f32 order, other bf16 roundings of the 10 x 15 x 15 / 20 x 30 x 30 tensors -- one level-1 weight gradient sits at
+        # e_sh = 1.56e-2 against e_un = 0.66e-2 (2.35 x); the kernel itself holds the float64 bound on these slab shapes
+        # (tests/test_ops_gpu.py CONV_CASES (10, 15, 15) / (6, 30, 30) / (7, 30, 30)).  A wrong halo term is O(1).
+        _compare(sh, un, ref, "depth 240x240x160 bf16, 2 ranks", floor=3e-3)

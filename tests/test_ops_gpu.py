@@ -75,6 +75,9 @@ CONV_CASES = [
     ([32, 32], 32, 3, 1, 1, (20, 20, 20), True, False, False),
     ([64], 64, 1, 1, 0, (16, 16, 16), True, False, False),
     ([64, 64, 64, 64], 64, 1, 1, 0, (10, 10, 10), True, True, False),
+    ([128], 128, 3, 1, 1, (10, 15, 15), True, False, True),          # levels 5 / 4 of a 240 x 240 x 160 volume (depth-sharded slabs: few planes)
+    ([64, 64], 64, 3, 1, 1, (6, 30, 30), True, True, False),
+    ([64], 32, 3, 1, 0, (7, 30, 30), True, False, False),
     # the finest level's 3x3x3 layers (8 output channels, H % 8 = W % 16 = 0, D >= 8): finish-free backward -- weight gradient with
     # the indicator slab first, means from it, fold-free marching input gradient (conv_march.hip FIN); one / two tiles per axis
     ([8], 8, 3, 1, 1, (8, 8, 16), True, False, False),
