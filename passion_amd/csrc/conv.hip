@@ -745,7 +745,11 @@ WgPlan plan_wgrad(const ConvK& k, const passion_conv_desc_t* d) {
     w.MT = w.bf16 ? ((mtiles % 2 == 0) ? 2 : 1) : ((mtiles % 2 == 0 && d->stride == 1) ? 2 : 1);
     w.gy = w.chunks * (mtiles / w.MT);
     const long total = (long)k.B * cdiv(k.Do, TD) * cdiv(k.Ho, TH) * cdiv(k.Wo, TW);
-    w.gx = (int)hmin(total, hmax(1, 1024 / w.gy));
+    // workgroups of a launch = slots of the partial slab x gy.  Small volumes (levels 3..5: <= 512 bricks) take fewer slots: the
+    // slab (slots x Cout Cin taps floats: 28 MB at 1024 / gy slots for a 64 -> 64 conv over 4 x 16^3) is written, then read by the fold
+    static const long wg_small = []() { const char* e = getenv("PASSION_WGRAD_WGS_SMALL"); return e && atol(e) > 0 ? atol(e) : 1024L; }();
+    const long wg_target = total <= 512 ? wg_small : 1024L;
+    w.gx = (int)hmin(total, hmax(1, wg_target / w.gy));
     return w;
 }
 

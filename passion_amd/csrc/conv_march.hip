@@ -83,6 +83,7 @@ struct MarchP {
     int tilesH, tilesW;
     int nwg_b;                     // workgroups per sample
     int k8;                        // 8-channel blocks of the K axis that exist (<= NB: a 24-channel concat runs as NB = 4 with an empty block)
+    unsigned* tickets;             // MODE 2: one zeroed counter per sample (left at zero): the workgroup that arrives last folds the sample's sums slots
 };
 
 // MT: 16-row tiles of the output (MODE 2 only: gradients with 17 .. 32 rows, e.g. the input gradient of a 24 / 32 -> 8 conv)
@@ -658,7 +659,7 @@ void conv_march_kernel(ConvK p, MarchP mp) {
             if (DG) {
                 if (c < p.Cin) {
                     float* rs = p.sums + (long)(bx % mp.nwg_b) * p.B * p.Cin * 2;
-                    rs[((long)b * p.Cin + c) * 2 + k2] = t;
+                    st_agent(&rs[((long)b * p.Cin + c) * 2 + k2], t);
                 }
             } else {
                 lsum[4 * MT * 16 * 2 + tid] = t;
@@ -667,6 +668,38 @@ void conv_march_kernel(ConvK p, MarchP mp) {
         if (!DG) {
             __syncthreads();
             fwd_stats_commit(p.fst, p.Cout, b, bx % mp.nwg_b, 0, 16, lsum + 4 * MT * 16 * 2, tid);
+        } else if (mp.tickets) {
+            // The sample's slots are folded HERE, by the workgroup that takes the last ticket (fixed slot order, in double: the sums
+            // repeat bit for bit), into slot 0: the finish kernel reads one replica and the separate fold launch (14 per step) is gone.
+            __shared__ int last_wg;
+            __shared__ double fpart[256];
+            stores_done();
+            __syncthreads();
+            if (tid == 0) last_wg = atomicAdd(&mp.tickets[b], 1u) == (unsigned)(mp.nwg_b - 1);
+            __syncthreads();
+            if (last_wg) {
+                acquire_agent();
+                const int NV = p.Cin * 2;                      // <= 64 values per sample
+                const int SL = 256 / 64, v = tid & 63, sl = tid >> 6;
+                double a = 0.0;
+                if (v < NV) {
+                    const float* s0 = p.sums + ((long)b * p.Cin) * 2 + v;
+                    const long rstride = (long)p.B * p.Cin * 2;
+                    int r = sl;
+                    for (; r + 7 * SL < mp.nwg_b; r += 8 * SL) {
+                        float tv[8];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) tv[u] = ld_agent(&s0[(long)(r + u * SL) * rstride]);
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) a += (double)tv[u];
+                    }
+                    for (; r < mp.nwg_b; r += SL) a += (double)ld_agent(&s0[(long)r * rstride]);
+                }
+                fpart[tid] = a;
+                __syncthreads();
+                if (tid < NV) p.sums[((long)b * p.Cin) * 2 + tid] = (float)(((fpart[tid] + fpart[64 + tid]) + fpart[128 + tid]) + fpart[192 + tid]);
+                if (tid == 0) __hip_atomic_store(&mp.tickets[b], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
     }
 }
@@ -692,6 +725,7 @@ template <int NB, int TW, int MODE>
 int launch_march_one(ConvK& k, hipStream_t st) {
     using G = GeoM<NB, TW>;
     MarchP mp;
+    mp.tickets = nullptr;
     mp.tilesH = k.Hi / MTH; mp.tilesW = k.Wi / TW;
     const bool fin = MODE == 2 && k.pwm != nullptr;          // fold-free input gradient with the final epilogue (means in k.pwm)
     const int dcount = (MODE == 2 && !fin) ? k.Di + 2 : k.Di;
@@ -713,6 +747,14 @@ int launch_march_one(ConvK& k, hipStream_t st) {
     if (MODE == 2) {
         if (mp.nwg_b > SUMS_SLOTS) return 1;
         k.sums_rep = mp.nwg_b;
+        static const bool fold_in = []() { const char* e = getenv("PASSION_MARCH_FOLD"); return !(e && e[0] == '0'); }();
+        if (fold_in && k.Cin <= 32) {                // the last workgroup of a sample folds its slots: one replica for the finish kernel
+            void* zero = nullptr;
+            const int rc = stream_scratch(st, (size_t)k.B * sizeof(unsigned), 0, &zero, nullptr);
+            if (rc) return rc;
+            mp.tickets = static_cast<unsigned*>(zero);
+            k.sums_rep = 1;
+        }
     }
     if (MODE == 0 && k.fst_want) {
         const int rc = fwd_stats_setup(k, mp.nwg_b, 1, st);
