@@ -868,7 +868,8 @@ bool conv_pw_dgrad_covers(const ConvK& k, int kblocks, int bphys) {
     if (k.y_f32) {                   // f32 dY of a logit head: the 8-channel form only
         if (!(g_conv_pw8 && kblocks == 1 && (k.Cout == 4 || k.Cout == 8) && pad16(k.Cin) <= 32)) return false;
     } else if (k.Cout % 8) return false;
-    if ((long)bphys * V * k.Cin < (24L << 20)) return false;      // small tensors: the two extra launches and the lost dgrad || wgrad overlap cost more than the finish pass
+    static const long pwf_min = []() { const char* e = getenv("PASSION_PWFINAL_MIN_M"); return e ? atol(e) : 8L; }();      // M elements (24 while the step was host-bound; 8 measured best under graph replay)
+    if ((long)bphys * V * k.Cin < (pwf_min << 20)) return false;      // small tensors: the two extra launches and the lost dgrad || wgrad overlap cost more than the finish pass
     const int K8 = kblocks, mpad = pad16(k.Cin);
     for (int s = 0; s < k.nseg; ++s) if (k.seg[s].C % 8) return false;
     if (g_conv_pw8 && K8 == 1 && mpad <= 32) return true;
