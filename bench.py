@@ -585,8 +585,11 @@ def main():
         if att:
             # counters cannot be read inside a timed run: the committed rocprofv3 --pmc pass over THIS command (bench.py with this
             # workload: the instantiations and shapes benchmarked here), tools/pmc_attention_bench.sh
-            pname = "r03_attention_pmc_bench_passion.json" if passion else "r03_attention_pmc_bench_plain.json"
-            ppath = os.path.join(ROOT, "profiles", pname)
+            pname = "attention_pmc_bench_passion.json" if passion else "attention_pmc_bench_plain.json"
+            ppath = os.path.join(ROOT, "profiles", "r04_" + pname)
+            if not os.path.exists(ppath):
+                ppath = os.path.join(ROOT, "profiles", "r03_" + pname)
+            pname = os.path.basename(ppath)
             if os.path.exists(ppath) and not is_rfnet:
                 pj = json.load(open(ppath))
                 att["mfma_busy"] = {"note": "STATIC: read from the committed rocprofv3 --pmc pass over this same bench command, not "

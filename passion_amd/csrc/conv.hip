@@ -376,6 +376,30 @@ __global__ __launch_bounds__(256) void in_bwd_finish_kernel(const T* __restrict_
 // The same finish for a dgrad that ran over the padded domain (conv_lean.hip MODE 2): dxp is [B][D+2][H+2][W+2][Cin_tot]
 // with the gradient of padded position op-1 at coordinate op; the reflect adjoint folds the halo planes back:
 // plane 1 also receives plane -1, plane S-2 also receives plane S (per axis, so up to 8 terms at the corners).
+// streaming accesses of the finish kernels: every byte is touched once (bit 1 of `fold`: non-temporal loads of the gradient scratch,
+// bit 2: non-temporal stores of dx, bit 3: non-temporal loads of x)
+typedef unsigned int nt_u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int nt_u32x2 __attribute__((ext_vector_type(2)));
+template <typename T, int VEC> __device__ __forceinline__ void vload_nt(const T* p, float (&v)[VEC], bool nt) {
+    if (nt && sizeof(T) == 2 && VEC == 8) {
+        const nt_u32x4 u = __builtin_nontemporal_load(reinterpret_cast<const nt_u32x4*>(p));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { v[2 * j] = __uint_as_float(u[j] << 16); v[2 * j + 1] = __uint_as_float(u[j] & 0xffff0000u); }
+    } else {
+        VecIO<T, VEC>::load(p, v);
+    }
+}
+template <typename T, int VEC> __device__ __forceinline__ void vstore_nt(T* p, const float (&v)[VEC], bool nt) {
+    if (nt && sizeof(T) == 2 && VEC == 8) {
+        union { bf16_t h[8]; nt_u32x4 u; } t;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) t.h[j] = (bf16_t)v[j];
+        __builtin_nontemporal_store(t.u, reinterpret_cast<nt_u32x4*>(p));
+    } else {
+        VecIO<T, VEC>::store(p, v);
+    }
+}
+
 // One (d, h) row of W voxels per loop trip: the row's halo planes are resolved once (wave-uniform flags, no indexed
 // local arrays -- those live in scratch memory), only the two W positions 1 and W-2 gather an extra column.
 template <typename T, int VEC>
@@ -391,6 +415,8 @@ __global__ __launch_bounds__(256) void in_bwd_finish_pad_kernel(T* __restrict__ 
     const int b = blockIdx.y;
     const int bs = bmod > 0 ? b % bmod : b;
     const long V = (long)D * H * W;
+    const bool nt_g = (fold & 2) != 0, nt_dx = (fold & 4) != 0, nt_x = (fold & 8) != 0;
+    fold &= 1;
     if (stats) finish_coefs(coef, stats, sums, b, bs, C, Cin_tot, cbase, rep, rep_stride, vscale / (float)V);
     __syncthreads();
     const int cvn = C / VEC, rowv = W * cvn;
@@ -416,7 +442,7 @@ __global__ __launch_bounds__(256) void in_bwd_finish_pad_kernel(T* __restrict__ 
 #pragma unroll
             for (int j = 0; j < VEC; ++j) { g[j] = 0.f; xv[j] = 0.f; }
             if (present) {
-                if (stats) VecIO<T, VEC>::load(xb + e, xv);
+                if (stats) vload_nt<T, VEC>(xb + e, xv, nt_x);
                 const bool wlo = fold && (w == 1), whi = fold && (w == W - 2);
 #pragma unroll
                 for (int a = 0; a < 3; ++a) {
@@ -426,7 +452,7 @@ __global__ __launch_bounds__(256) void in_bwd_finish_pad_kernel(T* __restrict__ 
                         if (!hok[e2]) continue;
                         const T* rowp = pb + dsrc[a] * pplane + hsrc[e2] * prow + c;
                         float t[VEC];
-                        VecIO<T, VEC>::load(rowp + (long)(w + 1) * Cin_tot, t);
+                        vload_nt<T, VEC>(rowp + (long)(w + 1) * Cin_tot, t, nt_g);
 #pragma unroll
                         for (int j = 0; j < VEC; ++j) g[j] += t[j];
                         if (wlo) {
@@ -448,7 +474,7 @@ __global__ __launch_bounds__(256) void in_bwd_finish_pad_kernel(T* __restrict__ 
                         g[j] = own ? __builtin_fmaf(coef[c + j][0], g[j], __builtin_fmaf(coef[c + j][1], xv[j], coef[c + j][2])) : coef[c + j][0] * g[j];
                 }
             }
-            VecIO<T, VEC>::store(dxb + e, g);
+            vstore_nt<T, VEC>(dxb + e, g, nt_dx);
         }
     }
 }
@@ -1448,16 +1474,19 @@ static int conv3d_bwd_impl(const passion_conv_desc_t* d, const float* packed, co
         if (padout) {
             const int rowv = k.Wi * sg.C / (v8 ? 8 : 4);
             const int rpb = 256 / (rowv < 256 ? rowv : 256);
-            dim3 pg((unsigned)hmin(((long)k.Di * k.Hi + rpb - 1) / rpb, 4096), k.B);
+            static const int fin_nt = []() { const char* e = getenv("PASSION_FINISH_NT"); return e ? atoi(e) : 0; }();
+            static const long fin_blocks = []() { const char* e = getenv("PASSION_FINISH_BLOCKS"); return e && atol(e) > 0 ? atol(e) : 4096L; }();
+            const int foldarg = (d->pad_mode == PASSION_PAD_REFLECT ? 1 : 0) | (fin_nt << 1);
+            dim3 pg((unsigned)hmin(((long)k.Di * k.Hi + rpb - 1) / rpb, fin_blocks), k.B);
             if (defer_fold) { fjl.main_x = (int)pg.x; fjl.fold_x = (int)((fold_blocks + pg.y - 1) / pg.y); pg.x += (unsigned)fjl.fold_x; }
             if (v8)
                 hipLaunchKernelGGL((in_bwd_finish_pad_kernel<bf16_t, 8>), pg, dim3(256), 0, st, (bf16_t*)sg.dx, (const bf16_t*)sg.x,
                                    (const bf16_t*)dxp, sg.stats, sums, sg.mask, sg.mask_col, sg.mask_ld, k.Di, k.Hi, k.Wi, sg.C,
-                                   sg.bstride, k.Cin, sg.cbase, sg.bmod, rep, rs, vscale, dwin_lo, dwin_hi, fjl, d->pad_mode == PASSION_PAD_REFLECT ? 1 : 0);
+                                   sg.bstride, k.Cin, sg.cbase, sg.bmod, rep, rs, vscale, dwin_lo, dwin_hi, fjl, foldarg);
             else
                 hipLaunchKernelGGL((in_bwd_finish_pad_kernel<bf16_t, 4>), pg, dim3(256), 0, st, (bf16_t*)sg.dx, (const bf16_t*)sg.x,
                                    (const bf16_t*)dxp, sg.stats, sums, sg.mask, sg.mask_col, sg.mask_ld, k.Di, k.Hi, k.Wi, sg.C,
-                                   sg.bstride, k.Cin, sg.cbase, sg.bmod, rep, rs, vscale, dwin_lo, dwin_hi, fjl, d->pad_mode == PASSION_PAD_REFLECT ? 1 : 0);
+                                   sg.bstride, k.Cin, sg.cbase, sg.bmod, rep, rs, vscale, dwin_lo, dwin_hi, fjl, foldarg);
         } else if (defer_fold) { fjl.main_x = (int)grid.x; fjl.fold_x = (int)((fold_blocks + grid.y - 1) / grid.y); grid.x += (unsigned)fjl.fold_x; }
         if (padout) {}
         else if (d->x_dtype == PASSION_F32)

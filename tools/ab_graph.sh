@@ -1,5 +1,5 @@
 #!/bin/bash
-# A/B of environment switches on the graph-replayed bench.  usage: tools/r04_ab.sh "LABEL:ENV=.. ENV=.." ... [-- bench args]
+# A/B of environment switches on the graph-replayed bench.  usage: tools/ab_graph.sh "LABEL:ENV=.. ENV=.." ... [-- bench args]
 cfgs=(); while [ $# -gt 0 ] && [ "$1" != "--" ]; do cfgs+=("$1"); shift; done; [ "$1" == "--" ] && shift
 REPS=${REPS:-2}
 for r in $(seq 1 $REPS); do

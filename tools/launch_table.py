@@ -40,6 +40,8 @@ recs = [r for r in ops.prof_read() if r[1] >= 0]
 kinds = {0: "fwd3", 1: "fwd1", 2: "dgrad", 3: "wgrad", 4: "attn", 5: "attn", 6: "finish"}
 tot = sum(r[1] for r in recs)
 print(f"{len(recs)} timed launches, {tot:.2f} ms on one stream")
+small = [r for r in recs if r[2] < 40e6]
+print(f"launches that move < 40 MB: {len(small)} launches, {sum(r[1] for r in small):.2f} ms ({sum(r[2] for r in small) / 1e6:.0f} MB algorithmic)")
 fam = {}
 for r in recs:
     f = fam.setdefault((kinds.get(r[0], str(r[0])), r[4]), [0, 0.0, 0.0])

@@ -1,5 +1,5 @@
 #!/bin/bash
-# rocprofv3 kernel trace of the (graph-replayed) bench step -> timeline / per-kernel totals of one step.  usage: tools/r04_trace.sh TAG [bench args]
+# rocprofv3 kernel trace of the (graph-replayed) bench step -> timeline / per-kernel totals of one step.  usage: tools/trace_graph.sh TAG [bench args]
 TAG=$1; shift
 R=$PWD
 mkdir -p $R/gpurun_out/tr_$TAG
