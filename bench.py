@@ -347,11 +347,11 @@ def main():
         return ptrain.train_step(model, opt, x, mk, target.view(target.shape), 4.0, state, reducer)
 
     use_graph = (args.launch == "graph" or (args.launch == "auto" and os.environ.get("PASSION_BENCH_GRAPH", "1") != "0")) \
-        and ctx.world == 1 and not is_depth and not args.ddp_mode
+        and not is_depth and (not reducer.active or (not passion and os.environ.get("PASSION_BENCH_GRAPH_DDP", "1") != "0"))
     gstep = None
     if use_graph:
         from passion_amd.graph import GraphedStep
-        gstep = GraphedStep(model, opt, 4.0, state, warm=2)       # two eager steps on the recording's own stream first (per-stream scratch, allocator pool)
+        gstep = GraphedStep(model, opt, 4.0, state, warm=2, reducer=reducer if reducer.active else None)       # two eager steps on the recording's own stream first (per-stream scratch, allocator pool)
 
     def graph_step():
         mk = masks[it_no[0] % len(masks)]
@@ -517,8 +517,10 @@ def main():
                    "allreduce_bytes_per_step": grad_bytes if ctx.world > 1 else 0,
                    "final_loss": round(final_loss, 5),
                    "ddp_mode": bool(args.ddp_mode),
-                   "launch": ("HIP graph replay of train.train_step (recorded once after the warm-up; batch, AdamW scalars and dropout "
-                              "seeds through device memory)" if use_graph else "eager")},
+                   "launch": (("HIP graph replay of forward + loss + backward, then the eager tail of train.train_step: bucketed RCCL all-reduce of "
+                               "the static gradient tensors + AdamW (no collective is recorded)" if reducer.active else
+                               "HIP graph replay of train.train_step (recorded once after the warm-up; batch, AdamW scalars and dropout "
+                               "seeds through device memory)") if use_graph else "eager")},
     }
     if want_events:
         recs = [r for r in timed_recs if r[1] >= 0]

@@ -16,8 +16,12 @@ replays the recording from then on.  What differs between iterations lives in de
 Everything else (modality masks, imb_beta / modal_weight, the relative-preference gate, the epoch accumulators) already was
 device-side data (train.assemble_loss has no host synchronisation).
 
-Single process only: with more than one rank the gradient all-reduce is issued from autograd hooks (parallel.GradReducer) and the
-step stays eager.
+More than one rank (`reducer` given and active): HYBRID -- the recording holds forward + loss + backward only (no collective is
+recorded: the reducer's hooks are suspended), every replay is followed by the eager tail of train.train_step: the bucketed RCCL
+all-reduce of the (static) gradient tensors and the optimizer step.  The compute keeps the graph's launch cost (the eager N > 1 step
+is host-bound: 14.6 ms of enqueue on a slow host against 11 ms of GPU work), the collectives are the same eager calls the tests cover.
+The all-reduce is not overlapped with the backward in this mode (PASSION_DDP_BF16=1 halves its bytes).  Plain training only: PASSION's
+relative-preference gate is a 4-float all-reduce inside the loss assembly, such steps stay eager for N > 1.
 """
 import ctypes
 from ctypes import c_void_p
@@ -29,11 +33,16 @@ from . import train as ptrain
 
 
 class GraphedStep:
-    def __init__(self, model, optimizer, temp=4.0, state=None, warmup=False, modal_num=None, iter_per_epoch=None, warm=3):
+    def __init__(self, model, optimizer, temp=4.0, state=None, warmup=False, modal_num=None, iter_per_epoch=None, warm=3, reducer=None):
         if not hasattr(optimizer, "begin_capture"):
             raise L.PassionHipError("GraphedStep needs passion_amd.optim.FusedAdamW (train.make_optimizer on a GPU model)")
         self.model, self.optimizer = model, optimizer
-        self.kw = dict(temp=temp, state=state, reducer=None, warmup=warmup, modal_num=modal_num, iter_per_epoch=iter_per_epoch)
+        self.hybrid = reducer is not None and getattr(reducer, "active", False)
+        if self.hybrid and model.use_passion:
+            raise L.PassionHipError("GraphedStep with a gradient reducer records plain training steps only (PASSION's gate is a collective)")
+        self.reducer = reducer
+        self.kw = dict(temp=temp, state=state, reducer=reducer if self.hybrid else None, warmup=warmup, modal_num=modal_num,
+                       iter_per_epoch=iter_per_epoch)
         self.warm = int(warm)
         self.calls = 0
         self.graph = None
@@ -65,15 +74,21 @@ class GraphedStep:
         torch.cuda.synchronize(dev)
         g = torch.cuda.CUDAGraph()
         lib.passion_set_step_words(c_void_p(self.words.data_ptr()))
-        self.optimizer.begin_capture(self.hyper)
+        if not self.hybrid:
+            self.optimizer.begin_capture(self.hyper)
+        else:
+            self.reducer.suspended = True
         try:
             with torch.cuda.graph(g, stream=self.stream):
                 # a view: ops.target_to_cl keeps the converted copy on the tensor OBJECT it is given
                 self.loss = ptrain.train_step(self.model, self.optimizer, self.sx, self.smask, self.starget.view(self.starget.shape),
-                                              **self.kw)
+                                              phase="fb" if self.hybrid else "all", **self.kw)
         finally:
             lib.passion_set_step_words(None)
-            self.cap = self.optimizer.end_capture()
+            if not self.hybrid:
+                self.cap = self.optimizer.end_capture()
+        if self.hybrid:          # the gradient tensors the recording writes (its backward assigned them after zero_grad): static from here on
+            self.grads = [(p, p.grad) for g_ in self.optimizer.param_groups for p in g_["params"] if p.grad is not None]
         self.graph = g
 
     def _replay(self, x, mask, target):
@@ -86,9 +101,14 @@ class GraphedStep:
         seed = int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())      # CPU generator: follows torch.manual_seed
         w = (ctypes.c_uint32 * 2)(seed & 0xffffffff, (seed >> 32) & 0xffffffff)
         L.check(L.load().passion_write_words(self.words.data_ptr(), 2, ctypes.cast(w, c_void_p), L.stream_ptr()), "passion_write_words")
-        self.optimizer.graph_tick(self.cap)
+        if not self.hybrid:
+            self.optimizer.graph_tick(self.cap)
         self.graph.replay()
         self.replays += 1
+        if self.hybrid:
+            for p, g_ in self.grads:          # (the previous tail left views of the reduced buckets there)
+                p.grad = g_
+            ptrain.train_step(self.model, self.optimizer, None, None, None, phase="tail", reducer=self.reducer)
         return self.loss
 
     def __call__(self, x, mask, target):

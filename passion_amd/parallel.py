@@ -103,6 +103,8 @@ class GradReducer:
         self._next = 0                                       # first bucket that has not been launched in this backward
         self._streams = [set() for _ in self.buckets]        # streams that produced gradients of the bucket in this backward
         self._on_gpu = self.params[0].is_cuda
+        self.suspended = False          # hooks off: a recorded forward + backward (graph.GraphedStep, hybrid) -- every bucket is then
+                                        # launched by all_reduce_grads(), after the replay
         if self.active:
             for p in model.parameters():
                 dist.broadcast(p.data, src=0)
@@ -113,6 +115,8 @@ class GradReducer:
 
     def _make_hook(self, bi):
         def hook(_param):
+            if self.suspended:
+                return
             if self._on_gpu:
                 self._streams[bi].add(_raw_stream())     # raw handle: a Stream object costs 10 us to build, per parameter
             self._pending[bi] -= 1

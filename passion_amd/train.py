@@ -155,12 +155,18 @@ def _early_step_callback(model, optimizer):
 
 
 def train_step(model, optimizer, x, mask, target, temp=4.0, state=None, reducer=None, warmup=False, modal_num=None,
-               iter_per_epoch=None):
-    """one iteration: forward, loss assembly, backward, (gradient all-reduce,) optimizer step"""
+               iter_per_epoch=None, phase="all"):
+    """one iteration: forward, loss assembly, backward, (gradient all-reduce,) optimizer step.
+    phase: "all"; "fb" = forward + loss + backward only (what graph.GraphedStep records for N > 1), "tail" = all-reduce + optimizer step"""
+    if phase == "tail":
+        if reducer is not None:
+            reducer.all_reduce_grads()
+        optimizer.step()
+        return None
     from . import ops
     net = model
     net.is_training = True
-    early = EARLY_STEP and hasattr(optimizer, "step_ready") and (reducer is None or not reducer.active) and x.is_cuda
+    early = EARLY_STEP and hasattr(optimizer, "step_ready") and (reducer is None or not reducer.active) and x.is_cuda and phase == "all"
     if hasattr(optimizer, "_stepped"):
         optimizer._stepped.clear()       # a backward that raised after the early part left its marks: this iteration starts clean
     ops._MARKER_CB[0] = _early_step_callback(net, optimizer) if early else None
@@ -182,6 +188,8 @@ def train_step(model, optimizer, x, mask, target, temp=4.0, state=None, reducer=
         if direct:
             host.set_direct_grads(False)
             ops._DIRECT[0] = False
+    if phase == "fb":
+        return loss.detach()
     if reducer is not None:
         reducer.all_reduce_grads()
     optimizer.step()

@@ -40,8 +40,20 @@ x, target = synth(2, S, blobs=True)
 mask = torch.tensor([[True, False, True, True], [True, True, True, False]])
 x, target, mask = x.to(dev), target.to(dev), mask.to(dev)
 losses = []
-for it in range(3):
-    losses.append(float(ptrain.train_step(m, opt, x, mask, target.view(target.shape), 4.0, state, red)))
+if os.environ.get("W1_GRAPH") == "1":
+    # the N > 1 form of graph.GraphedStep: forward + loss + backward replayed, RCCL all-reduce + AdamW eager after every replay
+    from passion_amd.graph import GraphedStep
+    m.use_passion = False
+    gs = GraphedStep(m, opt, 4.0, None, warm=1, reducer=red)
+    assert gs.hybrid == force
+    for it in range(4):
+        losses.append(float(gs(x, mask, target.view(target.shape))))
+    assert gs.replays == 3
+else:
+    if os.environ.get("W1_PLAIN") == "1":
+        m.use_passion = False
+    for it in range(4 if os.environ.get("W1_PLAIN") == "1" else 3):
+        losses.append(float(ptrain.train_step(m, opt, x, mask, target.view(target.shape), 4.0, state if m.use_passion else None, red)))
 torch.cuda.synchronize()
 if force:
     # gradients of the last step are views of the reducer's flat buckets (no copy back)
@@ -64,7 +76,7 @@ print("done", losses)
 '''
 
 
-def _run(tmp, force):
+def _run(tmp, force, extra=None):
     import socket
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -73,7 +85,8 @@ def _run(tmp, force):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
     env.pop("WORLD_SIZE", None)
     env["PASSION_DDP_FORCE"] = "1" if force else "0"
-    out = os.path.join(tmp, f"r{int(force)}.pt")
+    env.update(extra or {})
+    out = os.path.join(tmp, f"r{int(force)}{len(extra or {})}{'g' if (extra or {}).get('W1_GRAPH') else ''}.pt")
     p = subprocess.run([sys.executable, "-c", SCRIPT, ROOT, out], env=env, capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stdout[-1500:] + p.stderr[-3000:]
     return torch.load(out, weights_only=True)
@@ -87,3 +100,15 @@ def test_ddp_code_path_on_rccl_at_world_size_one_equals_the_single_process_step(
     bad = [k for k in a["sd"] if not torch.equal(a["sd"][k], b["sd"][k])]
     assert not bad, bad[:5]
     assert torch.equal(a["beta"], b["beta"])
+
+
+def test_hybrid_graph_step_with_eager_rccl_tail_equals_the_eager_step(tmp_path):
+    """what bench.py runs for N > 1: GraphedStep(reducer=...) -- the recording holds forward + loss + backward, every replay is followed
+    by the bucketed all-reduce (RCCL, world size 1) and AdamW, eagerly -- against four eager single-process steps, bit for bit"""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    a = _run(str(tmp_path), True, {"W1_GRAPH": "1"})
+    b = _run(str(tmp_path), False, {"W1_PLAIN": "1"})
+    assert a["losses"] == b["losses"], (a["losses"], b["losses"])
+    bad = [k for k in a["sd"] if not torch.equal(a["sd"][k], b["sd"][k])]
+    assert not bad, bad[:5]
