@@ -116,6 +116,8 @@ int launch_conv_lean(ConvK& k, int ksize, int stride, int mode, const void* pack
 bool lean_covers(const ConvK& k, int stride, bool dgrad);
 int launch_conv_march(ConvK& k, int ksize, int stride, int mode, const void* packed_bf16, hipStream_t st);   // conv_march.hip
 extern int g_conv_march;
+int launch_conv_pair(ConvK& k, int mode, hipStream_t st);   // conv_pair.hip: 8-channel K axis, <= 8 rows: two output planes per MFMA tile
+extern int g_conv_pair;
 int launch_conv_deep(ConvK& k, int ksize, int stride, int mode, hipStream_t st);   // conv_deep.hip: 32-channel-chunk K axes over small volumes (levels 3..5)
 extern int g_conv_deep;
 int launch_conv_s2_dgrad(ConvK& k, const void* packed_bf16, hipStream_t st);   // conv_s2_dgrad.hip: stride-2 padded-domain dgrad, gather form

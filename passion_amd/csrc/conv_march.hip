@@ -100,6 +100,14 @@ void conv_march_kernel(ConvK p, MarchP mp) {
     static_assert(!FIN || (MODE == 2 && MT == 1), "final form: input gradient, one row tile");
     using G = GeoM<NB, TW, FIN>;
     constexpr bool DG = (MODE == 2);
+    // B fragments are requested PD K-steps ahead of the MFMAs that consume them.  Measured (tools/march_pd.sh, 8 -> 8 / 16 -> 8 at
+    // 4 x 128^3, 16 -> 16 at 4 x 64^3): PD 1 .. 4 give the same times to 1 % wherever the extra registers keep the waves per SIMD --
+    // LDS latency is not what the tap loop waits for (the loop is bound by VALU issue: ~210 VALU instructions per plane and wave
+    // against 21 MFMAs) -- and 40 % slower where they do not (16 -> 8 forward at PD >= 2: 260 registers).
+#ifndef MARCH_PD
+#define MARCH_PD 1
+#endif
+    constexpr int PD = FIN ? 1 : MARCH_PD;
     constexpr int NIT = G::NIT, NSTEP = G::NSTEP, NTW = G::NTW, VS = G::VS, RSB = G::RSB, PLANE = G::PLANE;
     extern __shared__ __attribute__((aligned(16))) char lds[];            // [NSLOT planes]
     __shared__ float lsum[4 * MT * 16 * 2 + MT * 32];     // [wave][row][2] partial sums, then the workgroup's 16 MT x 2 totals
@@ -475,7 +483,7 @@ void conv_march_kernel(ConvK p, MarchP mp) {
         auto mfma_loop = [&](auto maskc, auto rtc, int dm) {
             constexpr unsigned M = decltype(maskc)::value;
             constexpr bool RT = decltype(rtc)::value;
-            bf16x8 cur[TT], nxt[TT];
+            bf16x8 bq[NSTEP][TT];                                  // (fully unrolled: only PD + 1 steps' worth is ever live)
             auto bload = [&](int s, bf16x8 (&dst)[TT]) {
                 int pl = ((jout + tdsel[s]) & (NSLOT - 1)) * PLANE;
                 if (RT) {
@@ -491,20 +499,19 @@ void conv_march_kernel(ConvK p, MarchP mp) {
                     else if ((FIN && !RT) || tile_on[t]) dst[t] = *reinterpret_cast<const bf16x8*>(lds + vb[t] + soff);
                 }
             };
-            bload(0, cur);
+#pragma unroll
+            for (int s = 0; s < PD && s < NSTEP; ++s) bload(s, bq[s]);
 #pragma unroll
             for (int s = 0; s < NSTEP; ++s) {
-                if (s + 1 < NSTEP) bload(s + 1, nxt);
-                __builtin_amdgcn_sched_barrier(0);                 // keep the reads of step s + 1 ahead of the MFMAs of step s
+                if (s + PD < NSTEP) bload(s + PD, bq[s + PD]);
+                __builtin_amdgcn_sched_barrier(0);                 // keep the reads of step s + PD ahead of the MFMAs of step s
 #pragma unroll
                 for (int t = 0; t < TT; ++t)
                     if (((M >> t) & 1u) && (t < NT || (FIN && !RT) || tile_on[t])) {
 #pragma unroll
-                        for (int mt = 0; mt < MT; ++mt) acc[mt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfr[mt][s], cur[t], acc[mt][t], 0, 0, 0);
+                        for (int mt = 0; mt < MT; ++mt) acc[mt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfr[mt][s], bq[s][t], acc[mt][t], 0, 0, 0);
                     }
                 __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int t = 0; t < TT; ++t) cur[t] = nxt[t];
             }
         };
         constexpr unsigned MALL = (1u << TT) - 1u, MMAIN = (1u << NT) - 1u;
@@ -814,6 +821,10 @@ int launch_conv_march(ConvK& k, int ksize, int stride, int mode, const void* pac
         k.wpack = packed_bf16;
     }
     k.dbg = g_conv_dbg;
+    if (K8 == 1) {                                         // <= 8 rows: the depth-pair kernel (conv_pair.hip)
+        const int rc = launch_conv_pair(k, mode, st);
+        if (rc <= 0) return rc;
+    }
 #define MARCH_CASE(NBv)                                                                             \
     if (K8 == NBv) {                                                                                \
         if (w32) return mode == 2 ? launch_march_one<NBv, 32, 2>(k, st) : launch_march_one<NBv, 32, 0>(k, st); \

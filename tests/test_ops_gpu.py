@@ -84,6 +84,15 @@ CONV_CASES = [
     ([16], 8, 3, 1, 1, (16, 16, 32), True, False, True),
     ([8, 8], 8, 3, 1, 1, (8, 16, 16), True, True, False),
     ([8], 8, 3, 1, 1, (24, 24, 48), True, False, False),
+    # 8-channel K axis, <= 8 rows: the depth-pair kernel (conv_pair.hip) -- 32-wide forward tiles with a residual, a masked
+    # modality, zero padding (no halo outputs), an odd depth (falls back to conv_march.hip), four output channels, no statistics
+    ([8], 8, 3, 1, 1, (16, 16, 32), True, False, True),
+    ([8], 8, 3, 1, 1, (10, 8, 32), True, True, False),
+    ([8], 8, 3, 1, 0, (8, 16, 32), True, False, False),
+    ([8], 8, 3, 1, 1, (7, 8, 16), True, False, False),
+    ([8], 4, 3, 1, 1, (8, 8, 16), True, False, False),
+    ([8], 8, 3, 1, 1, (12, 16, 16), False, False, True),
+    ([8], 8, 3, 1, 1, (40, 32, 32), True, False, False),
 ]
 
 
