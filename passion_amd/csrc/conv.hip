@@ -400,31 +400,87 @@ template <typename T, int VEC> __device__ __forceinline__ void vstore_nt(T* p, c
     }
 }
 
+// The final-form marching input gradient (conv_pair.hip SF / conv_march.hip FIN) wrote dx = rstd (g - m1 - x_hat m2) for every
+// voxel from the INTERIOR taps and left the halo outputs of the padded domain (positions -1 / S of an axis, already multiplied by
+// LeakyReLU' x mask of the voxel they mirror) in the shell of the padded scratch.  The adjoint of reflect padding adds them onto
+// positions 1 / S - 2: dx += rstd * (sum of the <= 7 shell voxels that mirror onto this one).  One thread per (target voxel, four
+// channels); targets = voxels with a coordinate in {1, S - 2}, enumerated as three disjoint sets (planes, rows, columns); ~6 S^2
+// voxels, a few microseconds instead of a three-tensor pass.
+__global__ __launch_bounds__(256) void shell_fold_kernel(bf16_t* __restrict__ dx, const bf16_t* __restrict__ dxp, const float* __restrict__ stats,
+                                                         int D, int H, int W, int C, long bstride, int Cin_tot, int cbase, int B) {
+    const int Wp = pconv::pad8(W + 2), c4n = C / 4;
+    const long nD = 2L * H * W, nH = 2L * (D - 2) * W, nW = 2L * (D - 2) * (H - 2), T = nD + nH + nW;
+    const long total = (long)B * T * c4n;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int c = (int)(i % c4n) * 4;
+        long r = i / c4n;
+        const int b = (int)(r / T);
+        r -= (long)b * T;
+        int d, h, w;
+        if (r < nD) { d = r < (long)H * W ? 1 : D - 2; r %= (long)H * W; h = (int)(r / W); w = (int)(r % W); }
+        else if (r < nD + nH) {
+            r -= nD;
+            const int side = (int)(r / ((long)(D - 2) * W)); r %= (long)(D - 2) * W;
+            d = (int)(r / W); d = d == 0 ? 0 : d + 1;            // the D - 2 planes that are not targets themselves: 0, 2 .. D - 3, D - 1
+            if (d == D - 2) d = D - 1;
+            h = side ? H - 2 : 1; w = (int)(r % W);
+        } else {
+            r -= nD + nH;
+            const int side = (int)(r / ((long)(D - 2) * (H - 2))); r %= (long)(D - 2) * (H - 2);
+            d = (int)(r / (H - 2)); d = d == 0 ? 0 : d + 1;
+            if (d == D - 2) d = D - 1;
+            h = (int)(r % (H - 2)); h = h == 0 ? 0 : h + 1;
+            if (h == H - 2) h = H - 1;
+            w = side ? W - 2 : 1;
+        }
+        const int md = d == 1 ? -1 : (d == D - 2 ? D : -2), mh = h == 1 ? -1 : (h == H - 2 ? H : -2), mw = w == 1 ? -1 : (w == W - 2 ? W : -2);
+        float a[4] = {0.f, 0.f, 0.f, 0.f};
+        const bf16_t* sp = dxp + (long)b * (D + 2) * (H + 2) * Wp * Cin_tot + cbase + c;
+        for (int ad = 0; ad <= (md > -2 ? 1 : 0); ++ad)
+            for (int ah = 0; ah <= (mh > -2 ? 1 : 0); ++ah)
+                for (int aw = 0; aw <= (mw > -2 ? 1 : 0); ++aw) {
+                    if (!(ad | ah | aw)) continue;
+                    const int qd = ad ? md : d, qh = ah ? mh : h, qw = aw ? mw : w;
+                    const f32x4 v = load4(sp + (((long)(qd + 1) * (H + 2) + (qh + 1)) * Wp + (qw + 1)) * Cin_tot);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) a[j] += v[j];
+                }
+        bf16_t* o = dx + (long)b * bstride + (((long)d * H + h) * W + w) * C + c;
+        f32x4 cur = load4(o);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) cur[j] += stats[((long)b * C + c + j) * 2 + 1] * a[j];
+        store4(o, cur);
+    }
+}
+
 // One (d, h) row of W voxels per loop trip: the row's halo planes are resolved once (wave-uniform flags, no indexed
 // local arrays -- those live in scratch memory), only the two W positions 1 and W-2 gather an extra column.
+// The segments of a concatenated input share ONE launch (round 4): the scratch holds the gradient with all Cin channels interleaved per
+// voxel, so a launch per segment read every line of it once per segment (the decoders' c1 convs: two 8-channel halves of 32-byte
+// voxels -- 222 us per finish against 98 for the same bytes in one segment); here a block walks its rows segment after segment, the
+// second visit of a line comes from L2.  Segments of one launch have the same channel count (the launcher groups them).
+struct FinSeg { void* dx; const void* x; const float* stats; const uint8_t* mask; long bstride; int C, cbase, mask_col, mask_ld, bmod, coff; };
+struct FinSegs { FinSeg s[PASSION_MAX_SEG]; int n; };
 template <typename T, int VEC>
-__global__ __launch_bounds__(256) void in_bwd_finish_pad_kernel(T* __restrict__ dx, const T* __restrict__ x, const T* __restrict__ dxp,
-                                                                const float* __restrict__ stats, const float* __restrict__ sums,
-                                                                const uint8_t* mask, int mask_col, int mask_ld, int D, int H, int W, int C,
-                                                                long bstride, int Cin_tot, int cbase, int bmod, int rep, long rep_stride,
-                                                                float vscale, int dwin_lo, int dwin_hi, FoldJob fj, int fold) {
+__global__ __launch_bounds__(256) void in_bwd_finish_pad_kernel(FinSegs fs, const T* __restrict__ dxp, const float* __restrict__ sums, int D, int H, int W,
+                                                                int Cin_tot, int rep, long rep_stride, float vscale, int dwin_lo, int dwin_hi, FoldJob fj,
+                                                                int fold) {
     if (fj.main_x && (int)blockIdx.x >= fj.main_x) { fold_block(fj, (long)(blockIdx.x - fj.main_x) * gridDim.y + blockIdx.y); return; }
     const int gdx = fj.main_x ? fj.main_x : (int)gridDim.x;
     const int bix = (int)blockIdx.x;
     __shared__ float coef[FIN_MAXC][3];
     const int b = blockIdx.y;
-    const int bs = bmod > 0 ? b % bmod : b;
     const long V = (long)D * H * W;
     const bool nt_g = (fold & 2) != 0, nt_dx = (fold & 4) != 0, nt_x = (fold & 8) != 0;
     fold &= 1;
-    if (stats) finish_coefs(coef, stats, sums, b, bs, C, Cin_tot, cbase, rep, rep_stride, vscale / (float)V);
+    for (int s = 0; s < fs.n; ++s) {
+        const FinSeg& q = fs.s[s];
+        if (q.stats) finish_coefs(coef + q.coff, q.stats, sums, b, q.bmod > 0 ? b % q.bmod : b, q.C, Cin_tot, q.cbase, rep, rep_stride, vscale / (float)V);
+    }
     __syncthreads();
+    const int C = fs.s[0].C;
     const int cvn = C / VEC, rowv = W * cvn;
-    const bool present = mask ? (mask[(long)b * mask_ld + mask_col] != 0) : true;
-    T* dxb = dx + (long)b * bstride;
-    const T* xb = x + (long)bs * bstride;
     const int Wp = pconv::pad8(W + 2);                     // row pitch of the padded scratch (conv_lean.hip MODE 2)
-    const T* pb = dxp + (long)b * (D + 2) * (H + 2) * Wp * Cin_tot + cbase;
     const int tpr = rowv < 256 ? rowv : 256;              // threads that work on one row; 256 / tpr rows in flight per block
     const int rpb = 256 / tpr, rsub = threadIdx.x / tpr, tin = threadIdx.x % tpr;
     const long prow = (long)Wp * Cin_tot, pplane = (long)(H + 2) * prow;
@@ -435,46 +491,55 @@ __global__ __launch_bounds__(256) void in_bwd_finish_pad_kernel(T* __restrict__ 
         // source planes of this row: the own one, plus the halo plane folded onto planes 1 / S-2 (reflect adjoint)
         const int dsrc[3] = {d + 1, 0, D + 1}, hsrc[3] = {h + 1, 0, H + 1};
         const bool dok[3] = {true, fold && d == 1, fold && d == D - 2}, hok[3] = {true, fold && h == 1, fold && h == H - 2};   // fold = 0: zero-padded conv
-        for (int i = tin; i < rowv; i += tpr) {
-            const int w = i / cvn, c = (i % cvn) * VEC;
-            const long e = ((long)r * W + w) * C + c;
-            float g[VEC], xv[VEC];
+        for (int s = 0; s < fs.n; ++s) {
+            const FinSeg& q = fs.s[s];
+            const float* stats = q.stats;
+            const bool present = q.mask ? (q.mask[(long)b * q.mask_ld + q.mask_col] != 0) : true;
+            T* dxb = reinterpret_cast<T*>(q.dx) + (long)b * q.bstride;
+            const T* xb = reinterpret_cast<const T*>(q.x) + (long)(q.bmod > 0 ? b % q.bmod : b) * q.bstride;
+            const T* pb = dxp + (long)b * (D + 2) * (H + 2) * Wp * Cin_tot + q.cbase;
+            const float (*cf)[3] = coef + q.coff;
+            for (int i = tin; i < rowv; i += tpr) {
+                const int w = i / cvn, c = (i % cvn) * VEC;
+                const long e = ((long)r * W + w) * C + c;
+                float g[VEC], xv[VEC];
 #pragma unroll
-            for (int j = 0; j < VEC; ++j) { g[j] = 0.f; xv[j] = 0.f; }
-            if (present) {
-                if (stats) vload_nt<T, VEC>(xb + e, xv, nt_x);
-                const bool wlo = fold && (w == 1), whi = fold && (w == W - 2);
+                for (int j = 0; j < VEC; ++j) { g[j] = 0.f; xv[j] = 0.f; }
+                if (present) {
+                    if (stats) vload_nt<T, VEC>(xb + e, xv, nt_x);
+                    const bool wlo = fold && (w == 1), whi = fold && (w == W - 2);
 #pragma unroll
-                for (int a = 0; a < 3; ++a) {
-                    if (!dok[a]) continue;
+                    for (int a = 0; a < 3; ++a) {
+                        if (!dok[a]) continue;
 #pragma unroll
-                    for (int e2 = 0; e2 < 3; ++e2) {
-                        if (!hok[e2]) continue;
-                        const T* rowp = pb + dsrc[a] * pplane + hsrc[e2] * prow + c;
-                        float t[VEC];
-                        vload_nt<T, VEC>(rowp + (long)(w + 1) * Cin_tot, t, nt_g);
-#pragma unroll
-                        for (int j = 0; j < VEC; ++j) g[j] += t[j];
-                        if (wlo) {
-                            VecIO<T, VEC>::load(rowp, t);
+                        for (int e2 = 0; e2 < 3; ++e2) {
+                            if (!hok[e2]) continue;
+                            const T* rowp = pb + dsrc[a] * pplane + hsrc[e2] * prow + c;
+                            float t[VEC];
+                            vload_nt<T, VEC>(rowp + (long)(w + 1) * Cin_tot, t, nt_g);
 #pragma unroll
                             for (int j = 0; j < VEC; ++j) g[j] += t[j];
-                        }
-                        if (whi) {
-                            VecIO<T, VEC>::load(rowp + (long)(W + 1) * Cin_tot, t);
+                            if (wlo) {
+                                VecIO<T, VEC>::load(rowp, t);
 #pragma unroll
-                            for (int j = 0; j < VEC; ++j) g[j] += t[j];
+                                for (int j = 0; j < VEC; ++j) g[j] += t[j];
+                            }
+                            if (whi) {
+                                VecIO<T, VEC>::load(rowp + (long)(W + 1) * Cin_tot, t);
+#pragma unroll
+                                for (int j = 0; j < VEC; ++j) g[j] += t[j];
+                            }
                         }
                     }
-                }
-                if (stats) {                               // else: input was not normalised in the loader, fold only
-                    const bool own = d >= dwin_lo && d < dwin_hi;      // depth-sharded halo planes: only the rstd * g term is ours
+                    if (stats) {                               // else: input was not normalised in the loader, fold only
+                        const bool own = d >= dwin_lo && d < dwin_hi;      // depth-sharded halo planes: only the rstd * g term is ours
 #pragma unroll
-                    for (int j = 0; j < VEC; ++j)
-                        g[j] = own ? __builtin_fmaf(coef[c + j][0], g[j], __builtin_fmaf(coef[c + j][1], xv[j], coef[c + j][2])) : coef[c + j][0] * g[j];
+                        for (int j = 0; j < VEC; ++j)
+                            g[j] = own ? __builtin_fmaf(cf[c + j][0], g[j], __builtin_fmaf(cf[c + j][1], xv[j], cf[c + j][2])) : cf[c + j][0] * g[j];
+                    }
                 }
+                vstore_nt<T, VEC>(dxb + e, g, nt_dx);
             }
-            vstore_nt<T, VEC>(dxb + e, g, nt_dx);
         }
     }
 }
@@ -1072,6 +1137,11 @@ extern "C" int passion_conv3d_fwd_stats(const passion_conv_desc_t* d, const floa
 // of the caller's stream and run under the dgrad + InstanceNorm-finish kernels; the caller's stream waits for them before
 // the call returns, so nothing changes for the caller (ordering, buffer lifetimes).  Experimental: PASSION_WGRAD_FORK=1 /
 // option "wgrad_fork".
+// Round 4, under graph replay (where the fork would cost the host nothing): a conv whose backward runs on the capture's ORIGIN stream
+// forks and replays correctly (tools/fork_capture_probe.py conv1 / conv3 / the whole model with its side streams off), the same conv on
+// a torch side stream crashes inside torch's capture_end (hipStreamEndCapture / instantiate) -- with the companions joined to the
+// origin beforehand too, and with the forked section left empty; a stand-alone HIP program with the same stream / event pattern
+// (tools/capture_nest_probe.hip: nested forks, re-used events, memset nodes) does not.  Unresolved; off.
 namespace pconv { int g_wgrad_fork = 0; }   // measured: no gain on the 128^3 step (42.6 vs 42.4 vol/s) -> off by default
 namespace {
 struct Companion { hipStream_t caller, side; hipEvent_t fork, done; };
@@ -1197,11 +1267,27 @@ static int conv3d_bwd_impl(const passion_conv_desc_t* d, const float* packed, co
             k.pwm = mb;
             k.sums = nullptr; k.sums_rep = 1; k.sums_fixed = 0; k.sums_float_only = 0;
             k.tilesD = cdiv(k.Di, TD); k.tilesH = cdiv(k.Hi, TH); k.tilesW = cdiv(k.Wi, TW);
+            bf16_t* shell = use_padout(k, d) ? reinterpret_cast<bf16_t*>(sums + slab_end_floats(k, w.gx, nt)) : nullptr;      // the padded scratch: only its shell is used
+            k.y = shell;
             {
                 ProfScope prof(2, conv_bytes(k, xs, ys) + (double)nt * k.Cin * k.Cout * 4, 2.0 * k.B * k.Do * k.Ho * k.Wo * (double)k.Cout * k.Cin * nt, st);
                 rc = launch_conv_march(k, 3, 1, 2, packed + f32_pack_floats(k.Cin, k.Cout, nt), st);
             }
             if (rc > 0 || (rc == 0 && !k.pw_done)) rc = -1023;
+            if (rc == 0 && k.pw_done == 2) {             // interior written in final form, halo outputs in the shell: fold them
+                char dg_tag[64];
+                snprintf(dg_tag, sizeof(dg_tag), "%s", passion_prof_last_tag());
+                ProfScope prof(6, 0.0, 0.0, st);
+                passion_prof_tag("finish of %s", dg_tag);
+                for (int s = 0; s < k.nseg; ++s) {
+                    const SegD& sg = k.seg[s];
+                    const long T = 2L * k.Hi * k.Wi + 2L * (k.Di - 2) * k.Wi + 2L * (k.Di - 2) * (k.Hi - 2);
+                    const long items = (long)k.B * T * (sg.C / 4);
+                    hipLaunchKernelGGL(shell_fold_kernel, dim3((unsigned)hmin((items + 255) / 256, 4096)), dim3(256), 0, st, (bf16_t*)sg.dx, shell, sg.stats,
+                                       k.Di, k.Hi, k.Wi, sg.C, sg.bstride, k.Cin, sg.cbase, k.B);
+                    LAUNCH_RET();
+                }
+            }
             return rc;
         }
     }
@@ -1457,39 +1543,62 @@ static int conv3d_bwd_impl(const passion_conv_desc_t* d, const float* packed, co
     const long win_lo = (long)dwin_lo * hw, win_hi = (long)dwin_hi * hw;
     // ---- InstanceNorm backward finish (in place on dx) ----
     const long V = (long)k.Di * k.Hi * k.Wi;
-    for (int s = 0; s < k.nseg; ++s) {
+    const long rs = (long)2 * k.B * k.Cin;
+    if (padout) {
+        // one launch per group of segments with the same channel count (FinSegs): the scratch is read from HBM once
+        bool done[PASSION_MAX_SEG] = {false, false, false, false};
+        static const int fin_nt = []() { const char* e = getenv("PASSION_FINISH_NT"); return e ? atoi(e) : 0; }();
+        static const long fin_blocks = []() { const char* e = getenv("PASSION_FINISH_BLOCKS"); return e && atol(e) > 0 ? atol(e) : 4096L; }();
+        static const bool fin_merge = []() { const char* e = getenv("PASSION_FINISH_MERGE"); return !(e && e[0] == '0'); }();
+        for (int s = 0; s < k.nseg; ++s) {
+            const SegD& sg = k.seg[s];
+            if (done[s] || !sg.dx) continue;
+            if (sg.C > FIN_MAXC) return -1013;            // coefficient table of the finish kernels
+            const bool v8 = d->x_dtype == PASSION_BF16 && sg.C % 8 == 0 && k.Cin % 8 == 0 && sg.cbase % 8 == 0;
+            FinSegs fs;
+            fs.n = 0;
+            int coff = 0;
+            for (int s2 = s; s2 < k.nseg; ++s2) {
+                const SegD& q = k.seg[s2];
+                const bool v8q = d->x_dtype == PASSION_BF16 && q.C % 8 == 0 && k.Cin % 8 == 0 && q.cbase % 8 == 0;
+                if (done[s2] || !q.dx || q.C != sg.C || v8q != v8 || coff + q.C > FIN_MAXC || (fs.n > 0 && !fin_merge)) continue;
+                fs.s[fs.n++] = FinSeg{q.dx, q.x, q.stats, q.mask, q.bstride, q.C, q.cbase, q.mask_col, q.mask_ld, q.bmod, coff};
+                coff += q.C;
+                done[s2] = true;
+            }
+            FoldJob fjl = fj;                             // the pending fold goes with the first finish launch
+            fjl.main_x = 0; fjl.fold_x = 0;
+            const long fold_blocks = defer_fold ? fold_nblocks(fj.n, fj.R) * fj.G : 0;
+            const int rowv = k.Wi * sg.C / (v8 ? 8 : 4);
+            const int rpb = 256 / (rowv < 256 ? rowv : 256);
+            const int foldarg = (d->pad_mode == PASSION_PAD_REFLECT ? 1 : 0) | (fin_nt << 1);
+            dim3 pg((unsigned)hmin(((long)k.Di * k.Hi + rpb - 1) / rpb, fin_blocks), k.B);
+            if (defer_fold) { fjl.main_x = (int)pg.x; fjl.fold_x = (int)((fold_blocks + pg.y - 1) / pg.y); pg.x += (unsigned)fjl.fold_x; }
+            if (v8)
+                hipLaunchKernelGGL((in_bwd_finish_pad_kernel<bf16_t, 8>), pg, dim3(256), 0, st, fs, (const bf16_t*)dxp, sums, k.Di, k.Hi, k.Wi, k.Cin, rep, rs,
+                                   vscale, dwin_lo, dwin_hi, fjl, foldarg);
+            else
+                hipLaunchKernelGGL((in_bwd_finish_pad_kernel<bf16_t, 4>), pg, dim3(256), 0, st, fs, (const bf16_t*)dxp, sums, k.Di, k.Hi, k.Wi, k.Cin, rep, rs,
+                                   vscale, dwin_lo, dwin_hi, fjl, foldarg);
+            LAUNCH_RET();
+            defer_fold = false;
+        }
+    }
+    for (int s = 0; s < k.nseg && !padout; ++s) {
         const SegD& sg = k.seg[s];
         const bool sum_passes = real_dx[s] != nullptr;
-        if (!sg.dx || (!sg.stats && !padout && !sum_passes)) continue;
+        if (!sg.dx || (!sg.stats && !sum_passes)) continue;
         if (sg.C > FIN_MAXC) return -1013;            // coefficient table of the finish kernels
         const bool v8 = d->x_dtype == PASSION_BF16 && sg.C % 8 == 0 && k.Cin % 8 == 0 && sg.cbase % 8 == 0;
         const long nvec = V * sg.C / (v8 ? 8 : 4);
         const int passes = sum_passes ? k.B / sg.bmod : 1;
         dim3 grid((unsigned)hmin((nvec + 255) / 256, 2048), sum_passes ? sg.bmod : k.B);
-        const long rs = (long)2 * k.B * k.Cin;
         void* out = sum_passes ? real_dx[s] : sg.dx;
         FoldJob fjl = fj;                             // the pending fold goes with the first finish launch
         fjl.main_x = 0; fjl.fold_x = 0;
         const long fold_blocks = defer_fold ? fold_nblocks(fj.n, fj.R) * fj.G : 0;
-        if (padout) {
-            const int rowv = k.Wi * sg.C / (v8 ? 8 : 4);
-            const int rpb = 256 / (rowv < 256 ? rowv : 256);
-            static const int fin_nt = []() { const char* e = getenv("PASSION_FINISH_NT"); return e ? atoi(e) : 0; }();
-            static const long fin_blocks = []() { const char* e = getenv("PASSION_FINISH_BLOCKS"); return e && atol(e) > 0 ? atol(e) : 4096L; }();
-            const int foldarg = (d->pad_mode == PASSION_PAD_REFLECT ? 1 : 0) | (fin_nt << 1);
-            dim3 pg((unsigned)hmin(((long)k.Di * k.Hi + rpb - 1) / rpb, fin_blocks), k.B);
-            if (defer_fold) { fjl.main_x = (int)pg.x; fjl.fold_x = (int)((fold_blocks + pg.y - 1) / pg.y); pg.x += (unsigned)fjl.fold_x; }
-            if (v8)
-                hipLaunchKernelGGL((in_bwd_finish_pad_kernel<bf16_t, 8>), pg, dim3(256), 0, st, (bf16_t*)sg.dx, (const bf16_t*)sg.x,
-                                   (const bf16_t*)dxp, sg.stats, sums, sg.mask, sg.mask_col, sg.mask_ld, k.Di, k.Hi, k.Wi, sg.C,
-                                   sg.bstride, k.Cin, sg.cbase, sg.bmod, rep, rs, vscale, dwin_lo, dwin_hi, fjl, foldarg);
-            else
-                hipLaunchKernelGGL((in_bwd_finish_pad_kernel<bf16_t, 4>), pg, dim3(256), 0, st, (bf16_t*)sg.dx, (const bf16_t*)sg.x,
-                                   (const bf16_t*)dxp, sg.stats, sums, sg.mask, sg.mask_col, sg.mask_ld, k.Di, k.Hi, k.Wi, sg.C,
-                                   sg.bstride, k.Cin, sg.cbase, sg.bmod, rep, rs, vscale, dwin_lo, dwin_hi, fjl, foldarg);
-        } else if (defer_fold) { fjl.main_x = (int)grid.x; fjl.fold_x = (int)((fold_blocks + grid.y - 1) / grid.y); grid.x += (unsigned)fjl.fold_x; }
-        if (padout) {}
-        else if (d->x_dtype == PASSION_F32)
+        if (defer_fold) { fjl.main_x = (int)grid.x; fjl.fold_x = (int)((fold_blocks + grid.y - 1) / grid.y); grid.x += (unsigned)fjl.fold_x; }
+        if (d->x_dtype == PASSION_F32)
             hipLaunchKernelGGL((in_bwd_finish_kernel<float, 4>), grid, dim3(256), 0, st, (const float*)sg.dx, (float*)out, (const float*)sg.x,
                                sg.stats, sums, sg.mask, sg.mask_col, sg.mask_ld, V, sg.C, sg.bstride, k.Cin, sg.cbase, sg.bmod, passes, rep, rs, vscale, win_lo, win_hi, fjl);
         else if (v8)

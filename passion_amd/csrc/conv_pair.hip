@@ -71,9 +71,15 @@ struct PairP {
     unsigned* tickets;             // MODE 2: one zeroed counter per sample (left at zero): the workgroup that arrives last folds the sample's sums slots
 };
 
-template <int TW, int MODE, bool HAS_RES>
+// SF (MODE 2): the FINAL form of the input gradient.  The InstanceNorm-backward means are known beforehand (p.pwm: m1 = mean g,
+// m2 = mean g x_hat per (sample, channel), from the weight gradient -- conv_wgrad_march.hip IND / march_ident_kernel), so the
+// epilogue of an INTERIOR position writes dx = rstd (g - m1 - x_hat m2) straight into the dx tensor; only the halo outputs (the
+// shell of the padded domain: positions -1 / S of an axis) still go to the padded scratch, and a small kernel folds that shell onto
+// the positions 1 / S - 2 it mirrors (shell_fold_kernel, conv.hip).  No sums, no second pass over the volume.
+template <int TW, int MODE, bool HAS_RES, bool SF = false>
 __global__ __launch_bounds__(256)
 void conv_pair_kernel(ConvK p, PairP mp) {
+    static_assert(!SF || MODE == 2, "final form: input gradient");
     using G = GeoP<TW>;
     constexpr bool DG = (MODE == 2);
     constexpr int NIT = G::NIT, NTW = G::NTW, VS = G::VS, RSB = G::RSB, PLANE = G::PLANE;
@@ -200,6 +206,13 @@ void conv_pair_kernel(ConvK p, PairP mp) {
         }
     }
     const float f_pos = row_ok ? emval : 0.f, f_neg = e_st ? f_pos * p.slope : f_pos;      // LeakyReLU' x modality mask
+    f32x4 fm1 = {0.f, 0.f, 0.f, 0.f}, fm2 = {0.f, 0.f, 0.f, 0.f};             // SF: the means (m1, m2) of the lane's four channels
+    if (SF && row_ok) {
+        const float* mp2 = p.pwm + ((long)b * p.Cin + cgl) * 2;
+        const f32x4 a = gload<f32x4>(mp2), c2 = gload<f32x4>(mp2 + 4);
+        fm1 = (f32x4){a[0], a[2], c2[0], c2[2]};
+        fm2 = (f32x4){a[1], a[3], c2[1], c2[3]};
+    }
     // zero the whole ring once: the guard ring and the out-of-volume halo of zero-padded / gradient planes stay zero
     for (int i = tid; i < G::RING / 16; i += 256) reinterpret_cast<u32x4*>(lds)[i] = (u32x4){0u, 0u, 0u, 0u};
 
@@ -308,6 +321,13 @@ void conv_pair_kernel(ConvK p, PairP mp) {
     }
     const unsigned oplane_b = (DG ? (unsigned)((Sh + 2) * Wp) * (unsigned)p.Cin : (unsigned)(Sh * Sw) * (unsigned)p.Cout) * 2u;
     unsigned ob = (unsigned)(dlo + half + (DG ? 1 : 0)) * oplane_b;      // the lane's output plane of pair 0; + 2 planes per pair
+    // SF: interior outputs go to dx itself (unpadded layout)
+    char* fdx = SF ? reinterpret_cast<char*>(reinterpret_cast<bf16_t*>(sd0.dx) + (long)b * sd0.bstride) : nullptr;
+    unsigned fel[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) fel[t] = ((unsigned)(tph[t] * Sw + tpw[t]) * (unsigned)sd0.C + (unsigned)cgl) * 2u;
+    const unsigned fplane_b = (unsigned)(Sh * Sw) * (unsigned)sd0.C * 2u;
+    unsigned fb = (unsigned)(dlo + half) * fplane_b;                     // (plane -1: wraps, never stored)
     const float vfx[2] = {((vmask >> NT) & 1u) ? 1.f : 0.f, ((vmask >> (NT + 1)) & 1u) ? 1.f : 0.f};
     u32x2 eop[2][EOP ? TT : 1];
     auto eload = [&](auto nxc, int o, u32x2 (&dst)[EOP ? TT : 1]) {
@@ -375,24 +395,43 @@ void conv_pair_kernel(ConvK p, PairP mp) {
                     const u32x2 xr = eo[t];
                     const float xv[4] = {__uint_as_float(xr.x << 16), __uint_as_float(xr.x & 0xffff0000u),
                                          __uint_as_float(xr.y << 16), __uint_as_float(xr.y & 0xffff0000u)};
-                    f32x4 gv;
+                    f32x4 gv, fv;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const float xh = __builtin_fmaf(xv[j], ersd[j], eshf[j]);
                         const float gg = acc[t][j] * (xh > 0.f ? f_pos : f_neg);
                         gv[j] = gg;
-                        const float gs = t < NT ? gg : gg * vfx[t < NT ? 0 : t - NT];
-                        s1[j] += gs;
-                        s2v[j] = __builtin_fmaf(gs, xh, s2v[j]);
+                        if (SF) {                              // second half of the InstanceNorm backward, means known beforehand
+                            fv[j] = e_st ? ersd[j] * __builtin_fmaf(-xh, fm2[j], gg - fm1[j]) : gg;
+                        } else {
+                            const float gs = t < NT ? gg : gg * vfx[t < NT ? 0 : t - NT];
+                            s1[j] += gs;
+                            s2v[j] = __builtin_fmaf(gs, xh, s2v[j]);
+                        }
                     }
                     union { bf16_t h[4]; u32x2 u; } pk;
+                    if (SF && t < NT) {
+                        // interior plane: final value into dx; the padded planes -1 / Sd (the first / last pair of the volume) into the shell
+                        const int dposl = dlo + 2 * o + half;
+                        const bool pin = dposl >= 0 && dposl < Sd;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) pk.h[j] = (bf16_t)gv[j];
-                    if (row_ok && ((vmask >> t) & 1u)) gstore_at<u32x2>(ybase, off, pk.u);
+                        for (int j = 0; j < 4; ++j) pk.h[j] = (bf16_t)fv[j];
+                        if (row_ok && pin) gstore_at<u32x2>(fdx, fb + fel[t < NT ? t : 0], pk.u);
+                        if (dlo + 2 * o < 0 || dlo + 2 * o + 1 >= Sd) {          // (uniform)
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) pk.h[j] = (bf16_t)gv[j];
+                            if (row_ok && !pin) gstore_at<u32x2>(ybase, off, pk.u);
+                        }
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) pk.h[j] = (bf16_t)gv[j];
+                        if (row_ok && ((vmask >> t) & 1u)) gstore_at<u32x2>(ybase, off, pk.u);
+                    }
                 }
             }
         }
         ob += 2u * oplane_b;
+        if (SF) fb += 2u * fplane_b;
     };
 
     // ---- pipeline.  Iteration i: barrier; commit planes 2 i, 2 i + 1; fetch planes 2 i + 4, 2 i + 5; compute pair i - 2 (ring
@@ -426,7 +465,7 @@ void conv_pair_kernel(ConvK p, PairP mp) {
     else if (nx == 1) run(std::integral_constant<int, DG ? 1 : 0>{});
     else run(std::integral_constant<int, DG ? 2 : 0>{});
 
-    if (DG || fstats) {
+    if ((DG && !SF) || fstats) {
         // InstanceNorm-backward sums (MODE 2) / statistics of y (MODE 0): 16 voxel lanes (shuffles) -> 4 waves x 2 planes (LDS, fixed
         // order) -> this workgroup's own slot
         const float keep = (!DG || e_st) ? 1.f : 0.f;          // no statistics: nothing to sum
@@ -493,17 +532,18 @@ void conv_pair_kernel(ConvK p, PairP mp) {
     }
 }
 
-template <int TW, int MODE, bool HAS_RES>
+template <int TW, int MODE, bool HAS_RES, bool SF = false>
 int launch_pair_res(ConvK& k, const PairP& mp, hipStream_t st) {
     using G = GeoP<TW>;
     static bool granted = false;
     if (!granted) {
-        HIP_RET(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_pair_kernel<TW, MODE, HAS_RES>),
+        HIP_RET(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_pair_kernel<TW, MODE, HAS_RES, SF>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, G::RING));
         granted = true;
     }
-    passion_prof_tag("conv_pair_kernel<%d, %d, %d>", TW, MODE, HAS_RES ? 1 : 0);
-    hipLaunchKernelGGL((conv_pair_kernel<TW, MODE, HAS_RES>), dim3(k.B * mp.nwg_b), dim3(256), G::RING, st, k, mp);
+    if (SF) passion_prof_tag("conv_pair_kernel<%d, %d, %d, 1>", TW, MODE, HAS_RES ? 1 : 0);
+    else passion_prof_tag("conv_pair_kernel<%d, %d, %d>", TW, MODE, HAS_RES ? 1 : 0);
+    hipLaunchKernelGGL((conv_pair_kernel<TW, MODE, HAS_RES, SF>), dim3(k.B * mp.nwg_b), dim3(256), G::RING, st, k, mp);
     LAUNCH_RET();
     return 0;
 }
@@ -520,10 +560,15 @@ int launch_pair_one(ConvK& k, hipStream_t st) {
     int nseg = (int)hmax(1, (g_conv_target + (long)k.B * tiles - 1) / ((long)k.B * tiles));
     static const int min_planes = []() { const char* e = getenv("PASSION_MARCH_PLANES"); return e && atoi(e) > 0 ? atoi(e) : 16; }();
     nseg = (int)hmin(nseg, hmax(1, dcount / min_planes));
-    if (MODE == 2) nseg = (int)hmin(nseg, hmax(1, SUMS_SLOTS / tiles));      // one sums slot per workgroup of a sample
+    if (MODE == 2 && !k.pwm) nseg = (int)hmin(nseg, hmax(1, SUMS_SLOTS / tiles));      // one sums slot per workgroup of a sample
     mp.planes_per_seg = ((dcount + nseg - 1) / nseg + 1) & ~1;
     mp.nseg_d = (dcount + mp.planes_per_seg - 1) / mp.planes_per_seg;
     mp.nwg_b = mp.nseg_d * tiles;
+    if (MODE == 2 && k.pwm) {                        // final form (means in k.pwm): reflect padding, statistics on the input
+        if (TW != 16 || nohalo || !k.seg[0].stats || !k.y) return 1;
+        k.pw_done = 2;                               // 2: the shell of the padded scratch still has to be folded (shell_fold_kernel)
+        return launch_pair_res<16, 2, false, true>(k, mp, st);
+    }
     if (MODE == 2) {
         if (mp.nwg_b > SUMS_SLOTS) return 1;
         k.sums_rep = mp.nwg_b;
@@ -551,7 +596,7 @@ namespace pconv {
 // 0 = launched, < 0 = HIP error, 1 = shape not covered (conv_march.hip goes on with its own kernel).  Called by launch_conv_march
 // once conv_march_covers() holds with K8 = 1 and k.Mpad / k.wpack / k.dbg are set.
 int launch_conv_pair(ConvK& k, int mode, hipStream_t st) {
-    if (!g_conv_pair || k.pwm || k.nseg != 1 || k.Mpad != 16) return 1;
+    if (!g_conv_pair || k.nseg != 1 || k.Mpad != 16) return 1;
     const SegD& s0 = k.seg[0];
     const int rows = mode == 2 ? k.Cin : k.Cout;
     if (rows > 8 || rows % 4) return 1;

@@ -144,7 +144,8 @@ def test_conv_block_fwd_bwd(case, dtype):
         assert e < tol * 3, f"dx[{i}] {e}"
 
 
-@pytest.mark.parametrize("shape", [([8], (8, 8, 16)), ([8, 8], (16, 16, 32)), ([16], (40, 24, 48)), ([8], (130, 16, 32))])
+@pytest.mark.parametrize("shape", [([8], (8, 8, 16)), ([8, 8], (16, 16, 32)), ([16], (40, 24, 48)), ([8], (130, 16, 32)), ([8], (24, 24, 48)),
+                                   ([8], (16, 16, 32)), ([8], (10, 32, 64))])
 def test_finish_free_marching_backward_equals_dgrad_plus_finish(shape):
     """the finest level's backward in its two forms on the same inputs: (weight gradient with indicator slab -> means -> fold-free
     marching input gradient with the final epilogue) against (weight gradient, padded-domain input gradient, finish kernel): input
