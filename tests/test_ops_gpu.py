@@ -93,6 +93,10 @@ CONV_CASES = [
     ([8], 4, 3, 1, 1, (8, 8, 16), True, False, False),
     ([8], 8, 3, 1, 1, (12, 16, 16), False, False, True),
     ([8], 8, 3, 1, 1, (40, 32, 32), True, False, False),
+    # the encoders' first stride-2 layer (8 -> 16): marching gather-form input gradient (conv_s2_dgrad.hip, conv_s2_march_kernel)
+    ([8], 16, 3, 2, 1, (16, 32, 48), True, False, False),
+    ([8], 16, 3, 2, 1, (36, 20, 34), True, True, False),
+    ([8], 16, 3, 2, 1, (6, 8, 8), False, False, False),
 ]
 
 
