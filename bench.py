@@ -535,11 +535,25 @@ def main():
             tpath = os.path.join(ROOT, "profiles", f"traffic_{args.workload}.json")
             if os.path.exists(tpath) and S == 128:
                 tj = json.load(open(tpath)).get("bytes_per_launch", {})
-                # rocprofv3 spells a bool template argument true / false, the library's tag 1 / 0
+                # rocprofv3 spells a bool template argument true / false and prints defaulted trailing arguments, the library's tag
+                # has 1 / 0 and stops at the last argument it sets: same kernel = same name and one argument list a prefix of the other
                 import re as _re
-                alt = _re.sub(r", (0|1)>$", lambda m: ", false>" if m.group(1) == "0" else ", true>", dom)
-                alt2 = alt[:-1] + ", 1>"          # ... and prints a defaulted trailing template argument (conv_march_kernel's row tiles)
-                traffic = tj.get(dom, tj.get(alt, tj.get(alt2)))
+
+                def _canon(name):
+                    m = _re.match(r"\s*([A-Za-z_0-9]+)\s*(?:<(.*)>)?\s*$", name)
+                    if not m:
+                        return name, []
+                    a = [x.strip() for x in (m.group(2) or "").split(",") if x.strip()]
+                    return m.group(1), ["1" if x == "true" else "0" if x == "false" else x for x in a]
+                db, da = _canon(dom)
+                best = None
+                for kname, kval in tj.items():
+                    kb, ka = _canon(kname)
+                    if kb == db and (ka[:len(da)] == da or da[:len(ka)] == ka):
+                        extra = sum(int(x) for x in ka[len(da):] if x.isdigit())      # defaulted arguments: the smallest (1 row tile, false)
+                        if best is None or extra < best[0]:
+                            best = (extra, kval)
+                traffic = best[1] if best else None
             copy_gbs = measured_copy_gbs(ctx.device)
             ak = [r for r in alone_recs if r[4] == dom]
             alone_ms = sum(r[1] for r in ak) / len(ak) if ak else None

@@ -821,7 +821,7 @@ int launch_conv_march(ConvK& k, int ksize, int stride, int mode, const void* pac
         k.wpack = packed_bf16;
     }
     k.dbg = g_conv_dbg;
-    if (K8 == 1) {                                         // <= 8 rows: the depth-pair kernel (conv_pair.hip)
+    if (K8 == 1 || (K8 == 2 && mode == 0)) {               // <= 8 rows: the depth-pair kernel (conv_pair.hip)
         const int rc = launch_conv_pair(k, mode, st);
         if (rc <= 0) return rc;
     }

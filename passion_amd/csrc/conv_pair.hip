@@ -33,16 +33,19 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int MTH = 8;                   // tile rows (two per wave)
 constexpr int NSLOT = 8;                 // LDS ring slots (planes)
-constexpr int NSTEP = 9;                 // K steps of 32 = 4 taps x 8 channels; 36 (depth, row, column) taps
 
-template <int TW> struct GeoP {
+// NB: 8-channel blocks of the K axis (1; 2 = a 16-channel input, forward only: the decoders' 16 -> 8 convs over a concat of two
+// 8-channel tensors); K steps of 32 = 4 (tap, block) pairs, 36 NB pairs
+template <int TW, int NB = 1> struct GeoP {
     static constexpr int EH = MTH + 4, EW = TW + 4;           // staged plane: tile + halo 1 + zero guard ring 1
-    static constexpr int VS = 16, RSB = EW * VS;
-    static constexpr int PLANE = TW == 16 ? 4096 : 8192;      // slot size (>= EH * RSB = 3840 / 6912)
+    static constexpr int VS = 16 * NB, RSB = EW * VS;
+    static constexpr int PLANE = (TW == 16 ? 4096 : 8192) * NB;      // slot size (>= EH * RSB = 3840 / 6912 per block), a power of two
     static constexpr int SV = (MTH + 2) * (TW + 2);           // voxels fetched per plane
-    static constexpr int NIT = (SV + 255) / 256;
+    static constexpr int CH = SV * NB;                        // 16-byte chunks fetched per plane
+    static constexpr int NIT = (CH + 255) / 256;
     static constexpr int NTW = TW / 16;
     static constexpr int RING = NSLOT * PLANE;
+    static constexpr int NSTEP = 9 * NB;
     static_assert(EH * RSB <= PLANE, "slot size");
 };
 
@@ -76,13 +79,14 @@ struct PairP {
 // epilogue of an INTERIOR position writes dx = rstd (g - m1 - x_hat m2) straight into the dx tensor; only the halo outputs (the
 // shell of the padded domain: positions -1 / S of an axis) still go to the padded scratch, and a small kernel folds that shell onto
 // the positions 1 / S - 2 it mirrors (shell_fold_kernel, conv.hip).  No sums, no second pass over the volume.
-template <int TW, int MODE, bool HAS_RES, bool SF = false>
+template <int TW, int MODE, bool HAS_RES, bool SF = false, int NB = 1>
 __global__ __launch_bounds__(256)
 void conv_pair_kernel(ConvK p, PairP mp) {
     static_assert(!SF || MODE == 2, "final form: input gradient");
-    using G = GeoP<TW>;
+    static_assert(NB == 1 || MODE == 0, "16-channel K axis: forward only");
+    using G = GeoP<TW, NB>;
     constexpr bool DG = (MODE == 2);
-    constexpr int NIT = G::NIT, NTW = G::NTW, VS = G::VS, RSB = G::RSB, PLANE = G::PLANE;
+    constexpr int NIT = G::NIT, NTW = G::NTW, VS = G::VS, RSB = G::RSB, PLANE = G::PLANE, NSTEP = G::NSTEP;
     constexpr int NT = 2 * NTW, TT = DG ? NT + 2 : NT;        // main tiles per wave; MODE 2: + up to two halo tiles (edge workgroups)
     constexpr bool EOP = DG || HAS_RES;
     extern __shared__ __attribute__((aligned(16))) char lds[];            // [NSLOT planes]
@@ -116,15 +120,37 @@ void conv_pair_kernel(ConvK p, PairP mp) {
     // the first four planes, the weights, the mask byte and the InstanceNorm statistics
     const SegD& sd0 = p.seg[0];
     const int bs0 = sd0.bsrc(b);
+    const int jb = tid % NB;                                   // 256 % NB == 0: a thread always stages the same 8-channel block
     const bf16_t* src;
+    unsigned Cst = 8;                                          // channels per voxel of the staged block's tensor
     const uint8_t* mptr = nullptr;
     const float* sptr = nullptr;
     if (DG) {
         src = reinterpret_cast<const bf16_t*>(p.dy) + (long)b * Sd * Sh * Sw * 8;
-    } else {
+    } else if (NB == 1) {
         src = reinterpret_cast<const bf16_t*>(sd0.x) + (long)bs0 * sd0.bstride;
         if (sd0.mask) mptr = sd0.mask + (long)b * sd0.mask_ld + sd0.mask_col;
         if (sd0.stats) sptr = sd0.stats + (long)bs0 * 8 * 2;
+    } else {                                                   // block jb of the virtual concat: one 16-channel segment or two of 8
+        src = reinterpret_cast<const bf16_t*>(sd0.x);
+        int rr = jb;
+        bool found = false;
+#pragma unroll
+        for (int s2 = 0; s2 < PASSION_MAX_SEG; ++s2) {
+            if (s2 < p.nseg && !found) {
+                const SegD& sd = p.seg[s2];
+                const int nb = sd.C / 8;
+                if (rr < nb) {
+                    found = true;
+                    const int bs = sd.bsrc(b), c0 = rr * 8;
+                    src = reinterpret_cast<const bf16_t*>(sd.x) + (long)bs * sd.bstride + c0;
+                    Cst = (unsigned)sd.C;
+                    if (sd.mask) mptr = sd.mask + (long)b * sd.mask_ld + sd.mask_col;
+                    if (sd.stats) sptr = sd.stats + ((long)bs * sd.C + c0) * 2;
+                }
+                rr -= nb;
+            }
+        }
     }
     const bool reflect = !DG && p.pad_mode == PASSION_PAD_REFLECT;
     unsigned srcel[NIT];                                       // in-plane source byte offset (clamped)
@@ -132,18 +158,18 @@ void conv_pair_kernel(ConvK p, PairP mp) {
     unsigned keepbits = 0u;                                    // bit u: chunk u carries data (else it stays zero)
 #pragma unroll
     for (int u = 0; u < NIT; ++u) {
-        const int c = u * 256 + tid, sv = min(c, G::SV - 1);
+        const int c = u * 256 + tid, sv = min(c, G::CH - 1) / NB;
         const int zh = sv / (TW + 2), zw = sv % (TW + 2);
         int ih = h0 - 1 + zh, iw = w0 - 1 + zw;
-        bool ok = c < G::SV;
+        bool ok = c < G::CH;
         if (reflect) { ih = reflect_idx(ih, Sh); iw = reflect_idx(iw, Sw); }
         else ok = ok && ih >= 0 && ih < Sh && iw >= 0 && iw < Sw;
         ih = min(max(ih, 0), Sh - 1); iw = min(max(iw, 0), Sw - 1);
-        srcel[u] = (unsigned)(ih * Sw + iw) * 16u;
-        dstoff[u] = (zh + 1) * RSB + (zw + 1) * VS;
+        srcel[u] = (unsigned)(ih * Sw + iw) * Cst * 2u;
+        dstoff[u] = (zh + 1) * RSB + (zw + 1) * VS + jb * 16;
         if (ok) keepbits |= 1u << u;
     }
-    const unsigned plane_b = (unsigned)(Sh * Sw) * 16u;
+    const unsigned plane_b = (unsigned)(Sh * Sw) * Cst * 2u;
     // virtual input planes of this segment: v = dlo - 1 + j, j = 0 .. L + 1 (the pair loop also touches L + 2, L + 3: dead)
     auto plane_of = [&](int j, bool& live) {                  // source plane of virtual plane j; live = it holds data
         int v = dlo - 1 + j;
@@ -173,14 +199,14 @@ void conv_pair_kernel(ConvK p, PairP mp) {
     const int lanebase = (r0 + 2) * RSB + (n + 2) * VS;        // main tile t: + (t / NTW) * RSB + (t % NTW) * 16 * VS (an immediate)
 #pragma unroll
     for (int s = 0; s < NSTEP; ++s) {
-        const int q = 4 * s + g, pd = q / 9, r9 = q % 9, th = r9 / 3, tw = r9 % 3;
+        const int q = 4 * s + g, tq = q / NB, blk = q % NB, pd = tq / 9, r9 = tq % 9, th = r9 / 3, tw = r9 % 3;
         const int kd = pd - (n >> 3);
         const bool wok = kd >= 0 && kd <= 2 && (n & 7) < rows;
         const int kdc = min(max(kd, 0), 2);
         const int tap = DG ? (2 - kdc) * 9 + (2 - th) * 3 + (2 - tw) : kdc * 9 + th * 3 + tw;
-        wfr[s] = gload<bf16x8>(reinterpret_cast<const bf16x8*>(p.wpack) + wvec_of(p, b) + (long)tap * p.Mpad + (n & 7));
+        wfr[s] = gload<bf16x8>(reinterpret_cast<const bf16x8*>(p.wpack) + wvec_of(p, b) + ((long)tap * NB + blk) * p.Mpad + (n & 7));
         if (!wok) wfr[s] = zero8();
-        pre[s] = pd * PLANE + (th - 1) * RSB + (tw - 1) * VS + lanebase;
+        pre[s] = pd * PLANE + (th - 1) * RSB + (tw - 1) * VS + blk * 16 + lanebase;
     }
     // mask byte + statistics of the staged block
     unsigned mbyte = 1u;
@@ -250,7 +276,7 @@ void conv_pair_kernel(ConvK p, PairP mp) {
                 o = __builtin_bit_cast(u32x4, ob);
             }
             if (!((keep >> u) & 1u)) o = (u32x4){0u, 0u, 0u, 0u};
-            if (u * 256 + tid < G::SV) *reinterpret_cast<u32x4*>(slot + dstoff[u]) = o;
+            if (u * 256 + tid < G::CH) *reinterpret_cast<u32x4*>(slot + dstoff[u]) = o;
         }
     };
 
@@ -532,23 +558,24 @@ void conv_pair_kernel(ConvK p, PairP mp) {
     }
 }
 
-template <int TW, int MODE, bool HAS_RES, bool SF = false>
+template <int TW, int MODE, bool HAS_RES, bool SF = false, int NB = 1>
 int launch_pair_res(ConvK& k, const PairP& mp, hipStream_t st) {
-    using G = GeoP<TW>;
+    using G = GeoP<TW, NB>;
     static bool granted = false;
     if (!granted) {
-        HIP_RET(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_pair_kernel<TW, MODE, HAS_RES, SF>),
+        HIP_RET(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_pair_kernel<TW, MODE, HAS_RES, SF, NB>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, G::RING));
         granted = true;
     }
-    if (SF) passion_prof_tag("conv_pair_kernel<%d, %d, %d, 1>", TW, MODE, HAS_RES ? 1 : 0);
+    if (NB > 1) passion_prof_tag("conv_pair_kernel<%d, %d, %d, 0, %d>", TW, MODE, HAS_RES ? 1 : 0, NB);
+    else if (SF) passion_prof_tag("conv_pair_kernel<%d, %d, %d, 1>", TW, MODE, HAS_RES ? 1 : 0);
     else passion_prof_tag("conv_pair_kernel<%d, %d, %d>", TW, MODE, HAS_RES ? 1 : 0);
-    hipLaunchKernelGGL((conv_pair_kernel<TW, MODE, HAS_RES, SF>), dim3(k.B * mp.nwg_b), dim3(256), G::RING, st, k, mp);
+    hipLaunchKernelGGL((conv_pair_kernel<TW, MODE, HAS_RES, SF, NB>), dim3(k.B * mp.nwg_b), dim3(256), G::RING, st, k, mp);
     LAUNCH_RET();
     return 0;
 }
 
-template <int TW, int MODE>
+template <int TW, int MODE, int NB = 1>
 int launch_pair_one(ConvK& k, hipStream_t st) {
     PairP mp;
     mp.tickets = nullptr;
@@ -585,8 +612,8 @@ int launch_pair_one(ConvK& k, hipStream_t st) {
         const int rc = fwd_stats_setup(k, mp.nwg_b, 1, st);
         if (rc) return rc < 0 ? rc : -rc;
     }
-    if (MODE == 0 && k.residual) return launch_pair_res<TW, MODE, true>(k, mp, st);
-    return launch_pair_res<TW, MODE, false>(k, mp, st);
+    if (MODE == 0 && k.residual) return launch_pair_res<TW, MODE, true, false, NB>(k, mp, st);
+    return launch_pair_res<TW, MODE, false, false, NB>(k, mp, st);
 }
 
 }  // namespace
@@ -596,12 +623,14 @@ namespace pconv {
 // 0 = launched, < 0 = HIP error, 1 = shape not covered (conv_march.hip goes on with its own kernel).  Called by launch_conv_march
 // once conv_march_covers() holds with K8 = 1 and k.Mpad / k.wpack / k.dbg are set.
 int launch_conv_pair(ConvK& k, int mode, hipStream_t st) {
-    if (!g_conv_pair || k.nseg != 1 || k.Mpad != 16) return 1;
+    if (!g_conv_pair || k.Mpad != 16) return 1;
     const SegD& s0 = k.seg[0];
     const int rows = mode == 2 ? k.Cin : k.Cout;
     if (rows > 8 || rows % 4) return 1;
-    if (mode == 0) { if (s0.C != 8) return 1; }
-    else if (k.Cout != 8 || !s0.dx || s0.cbase != 0 || s0.C != k.Cin) return 1;
+    int K8 = 0;
+    for (int s = 0; s < k.nseg; ++s) { if (k.seg[s].C % 8) return 1; K8 += k.seg[s].C / 8; }
+    if (mode == 0) { if (K8 * 8 != k.Cin || K8 > 2 || (K8 == 1 && k.nseg != 1)) return 1; }
+    else if (k.nseg != 1 || k.Cout != 8 || !s0.dx || s0.cbase != 0 || s0.C != k.Cin) return 1;
     const bool nohalo = mode == 2 && k.pad_mode != PASSION_PAD_REFLECT;
     if (((mode == 2 && !nohalo) ? k.Di + 2 : k.Di) % 2) return 1;            // pairs of planes
     const long vox = (long)k.Di * k.Hi * k.Wi, pvox = (long)(k.Di + 2) * (k.Hi + 2) * pad8(k.Wi + 2);
@@ -610,6 +639,8 @@ int launch_conv_pair(ConvK& k, int mode, hipStream_t st) {
     bool w32 = (k.Wi % 32 == 0) && mode == 0;
     if (force_tw == 16) w32 = false;
     if (force_tw == 32 && k.Wi % 32 == 0) w32 = true;
+    static const bool nb2 = []() { const char* e = getenv("PASSION_PAIR_NB2"); return !(e && e[0] == '0'); }();
+    if (mode == 0 && K8 == 2) return nb2 ? launch_pair_one<16, 0, 2>(k, st) : 1;      // 64 KB ring with 16-wide tiles (32-wide: 128 KB)
     if (w32) return mode == 2 ? launch_pair_one<32, 2>(k, st) : launch_pair_one<32, 0>(k, st);
     return mode == 2 ? launch_pair_one<16, 2>(k, st) : launch_pair_one<16, 0>(k, st);
 }

@@ -14,7 +14,9 @@ python3 - "$OUT" "$@" <<'PY'
 import csv, glob, collections, json, re, sys
 fam = collections.defaultdict(lambda: collections.defaultdict(list))
 def family(k):                      # kernel instantiation, spelled like the names bench.py gets from the library
-    m = re.search(r"((conv_march_kernel|conv_deep_kernel|conv_pw8_fwd_kernel|conv_pw8_dgrad_kernel|conv_pw_fwd_kernel|conv_pw_dgrad_kernel|conv_s2_dgrad_kernel|conv_lean_kernel_occ4|conv_lean_kernel|wgrad_lean_kernel|wgrad_march_kernel|conv_bf16_kernel|conv_wgrad_bf16_kernel)<[0-9a-z, ]+>)", k)
+    m = re.search(r"((conv_march_kernel|conv_pair_kernel|conv_deep_kernel|conv_pw8_fwd_kernel|conv_pw8_dgrad_kernel|conv_pw_fwd_kernel|conv_pw_dgrad_kernel|conv_s2_dgrad_kernel|conv_lean_kernel_occ4|conv_lean_kernel|wgrad_lean_kernel|wgrad_march_kernel|conv_bf16_kernel|conv_wgrad_bf16_kernel)<[0-9a-z, ]+>)", k)
+    if not m and "conv_s2_march_kernel" in k:
+        return "conv_s2_march_kernel"
     return m.group(1) if m else None
 for f in glob.glob("gpurun_out/pmc_traffic/*/*/*counter_collection.csv"):
     for r in csv.DictReader(open(f)):
