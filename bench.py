@@ -428,6 +428,9 @@ def main():
         for r in alone_recs:                        # per kernel instantiation, as rocprofv3 names it
             if r[0] < 4:
                 tot[r[4]] = tot.get(r[4], 0.0) + r[1]
+        for r in alone_recs:                        # an input gradient is ranked as it is reported: together with its finish launches
+            if r[0] == 6 and r[4].startswith("finish of ") and r[4][len("finish of "):] in tot:
+                tot[r[4][len("finish of "):]] += r[1]
         flt = (0.0, 1e300)
         if tot:
             dom = max(tot, key=tot.get)
