@@ -333,7 +333,7 @@ def test_zero_padded_dgrad_on_the_marching_kernel(case):
     finally:
         ops.prof_enable(0)
     names = {r[4] for r in ops.prof_read()}
-    assert any(n.startswith("conv_march_kernel") for n in names), names
+    assert any(n.startswith("conv_march_kernel") or n.startswith("conv_pair_kernel") for n in names), names      # (8 rows: the depth-pair form)
 
 
 PATHS = {"lean": {}, "lean_mirror_taps": {"conv_padout": 0}, "general": {"conv_lean": 0}, "few_workgroups": {"conv_target": 8}}
