@@ -76,17 +76,29 @@ _PACK_REGISTRY = {}     # id(cache dict) -> (weakref to the weight parameter, ca
 _PACK_TABLE = {}        # the pointer tables of the last multi-weight re-pack
 
 
-def repack_stale():
+_PACK_MANAGED = [False]      # train.train_step re-packs right behind the optimizer (below): the call at the top of Model.forward has nothing to do
+
+
+def repack_stale(only=None, exclude=None):
     """Re-pack, in ONE launch, every registered conv weight whose version moved since it was packed (i.e. all of
     them after an optimizer step) into its existing buffer.  Called at the top of Model.forward: the per-conv
-    pack_weight() calls below then all hit their caches."""
+    pack_weight() calls below then all hit their caches.
+    only / exclude: sets of parameter data_ptr()s -- train.train_step packs the decoder / transformer weights right behind their
+    early AdamW pass on the optimizer's stream (under the encoder backward) and the rest behind the closing step, so that the
+    next forward does not start with a 0.14 ms pass over all weights on the critical stream."""
     capturing = torch.cuda.is_current_stream_capturing()   # a graph replays after optimizer steps: record all of them
+    if capturing and _PACK_MANAGED[0] and only is None and exclude is None:
+        return 0                                 # the recording holds the two packs behind the optimizer passes instead
     stale = []
     for key in list(_PACK_REGISTRY):
         ref, cache = _PACK_REGISTRY[key]
         w = ref()
         if w is None:
             del _PACK_REGISTRY[key]
+            continue
+        if only is not None and w.data_ptr() not in only:
+            continue
+        if exclude is not None and w.data_ptr() in exclude:
             continue
         if (capturing or cache.get("key") != (w.data_ptr(), w._version)) and w.is_cuda and w.dtype == torch.float32 \
                 and w.is_contiguous():
@@ -96,14 +108,17 @@ def repack_stale():
     n = len(stale)
     from ctypes import c_int as _ci
     sig = tuple((w.data_ptr(), cache["packed"].data_ptr()) for w, cache in stale)
-    tab = _PACK_TABLE.get("tab")
-    if tab is None or tab[0] != sig:         # the same few hundred pointers every step: build the tables once
+    tabs = _PACK_TABLE.setdefault("tabs", {})
+    tab = tabs.get(sig)
+    if tab is None:                          # the same few hundred pointers every step (two sets with the early optimizer pass): build the tables once
+        if len(tabs) > 8:
+            tabs.clear()
         ptrs, outs = (c_void_p * n)(), (c_void_p * n)()
         cin, cout, ks = (_ci * n)(), (_ci * n)(), (_ci * n)()
         for i, (w, cache) in enumerate(stale):
             ptrs[i], outs[i] = w.data_ptr(), cache["packed"].data_ptr()
             cout[i], cin[i], ks[i] = w.shape[0], w.shape[1], w.shape[2]
-        tab = _PACK_TABLE["tab"] = (sig, ptrs, cin, cout, ks, outs)
+        tab = tabs[sig] = (sig, ptrs, cin, cout, ks, outs)
     _, ptrs, cin, cout, ks, outs = tab
     L.check(L.load().passion_conv_pack_weights(n, ptrs, cin, cout, ks, outs, L.stream_ptr()), "passion_conv_pack_weights")
     for w, cache in stale:

@@ -121,6 +121,7 @@ def poly_lr(base_lr, epoch, num_epochs, power=0.9):
 
 
 EARLY_STEP = os.environ.get("PASSION_EARLY_STEP", "1") != "0"    # AdamW of the non-encoder parameters under the encoder backward
+PACK_BEHIND_STEP = os.environ.get("PASSION_PACK_BEHIND_STEP", "1") != "0"   # conv weight images re-packed right behind the optimizer passes, not at the top of the next forward
 DIRECT_GRADS = os.environ.get("PASSION_DIRECT_GRADS", "1") != "0"  # single process: the conv nodes fill .grad themselves (no AccumulateGrad nodes)
 
 
@@ -147,8 +148,12 @@ def _early_step_callback(model, optimizer):
             ev = torch.cuda.Event()
             ev.record(s_)
             opt_stream.wait_event(ev)
+        from . import ops as _ops
         with torch.cuda.stream(opt_stream):
             optimizer.step_ready()
+            if PACK_BEHIND_STEP:                 # ... and their MFMA operand images, still under the encoder backward
+                model.__dict__["_early_packed"] = set(optimizer._stepped)
+                _ops.repack_stale(only=model.__dict__["_early_packed"])
             done.record(opt_stream)
         model.__dict__["_opt_pending"] = done
     return cb
@@ -158,12 +163,12 @@ def train_step(model, optimizer, x, mask, target, temp=4.0, state=None, reducer=
                iter_per_epoch=None, phase="all"):
     """one iteration: forward, loss assembly, backward, (gradient all-reduce,) optimizer step.
     phase: "all"; "fb" = forward + loss + backward only (what graph.GraphedStep records for N > 1), "tail" = all-reduce + optimizer step"""
+    from . import ops
     if phase == "tail":
         if reducer is not None:
             reducer.all_reduce_grads()
         optimizer.step()
         return None
-    from . import ops
     net = model
     net.is_training = True
     early = EARLY_STEP and hasattr(optimizer, "step_ready") and (reducer is None or not reducer.active) and x.is_cuda and phase == "all"
@@ -178,6 +183,9 @@ def train_step(model, optimizer, x, mask, target, temp=4.0, state=None, reducer=
     if direct:
         host.set_direct_grads(True)
         ops._DIRECT[0] = True
+    managed = PACK_BEHIND_STEP and x.is_cuda and phase == "all"
+    ops._PACK_MANAGED[0] = managed
+    net.__dict__.pop("_early_packed", None)
     try:
         outs = net(x, mask, target=target, temp=temp)
         loss = assemble_loss(outs, target, mask, net.mask_type, net.use_passion, state, warmup, modal_num, iter_per_epoch)
@@ -185,6 +193,7 @@ def train_step(model, optimizer, x, mask, target, temp=4.0, state=None, reducer=
         loss.backward()
     finally:
         ops._MARKER_CB[0] = None
+        ops._PACK_MANAGED[0] = False
         if direct:
             host.set_direct_grads(False)
             ops._DIRECT[0] = False
@@ -193,8 +202,10 @@ def train_step(model, optimizer, x, mask, target, temp=4.0, state=None, reducer=
     if reducer is not None:
         reducer.all_reduce_grads()
     optimizer.step()
+    if managed:                          # the images of what this closing step updated (the encoders; everything without the early pass)
+        ops.repack_stale(exclude=net.__dict__.pop("_early_packed", set()))
     pending = net.__dict__.pop("_opt_pending", None)
-    if pending is not None:              # the early part ran on its own stream: the next forward (weight re-pack) waits for it
+    if pending is not None:              # the early part ran on its own stream: the next forward waits for it
         torch.cuda.current_stream(x.device).wait_event(pending)
     return loss.detach()
 
