@@ -1548,7 +1548,10 @@ static int conv3d_bwd_impl(const passion_conv_desc_t* d, const float* packed, co
         // one launch per group of segments with the same channel count (FinSegs): the scratch is read from HBM once
         bool done[PASSION_MAX_SEG] = {false, false, false, false};
         static const int fin_nt = []() { const char* e = getenv("PASSION_FINISH_NT"); return e ? atoi(e) : 0; }();
-        static const long fin_blocks = []() { const char* e = getenv("PASSION_FINISH_BLOCKS"); return e && atol(e) > 0 ? atol(e) : 4096L; }();
+        // blocks per sample: every block first builds its coefficient table (dependent loads of the statistics and the sums: ~2 us of
+        // latency) before it streams its rows -- 4096 blocks of four rows each paid that too often (4 x 128^3, 8 channels: 117 us;
+        // 2048: 107; 1024: 105; 512: 124)
+        static const long fin_blocks = []() { const char* e = getenv("PASSION_FINISH_BLOCKS"); return e && atol(e) > 0 ? atol(e) : 1536L; }();
         static const bool fin_merge = []() { const char* e = getenv("PASSION_FINISH_MERGE"); return !(e && e[0] == '0'); }();
         for (int s = 0; s < k.nseg; ++s) {
             const SegD& sg = k.seg[s];

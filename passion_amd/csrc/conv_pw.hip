@@ -823,8 +823,10 @@ __global__ __launch_bounds__(128) void march_ident_kernel(ConvK p, const float* 
         }
         return;
     }
-    const int b = blockIdx.x, ci = threadIdx.x;
-    if (ci >= p.Cin) return;
+    // 128 threads: (input channel ci, slice of the (co, tap) axis); slices meet in LDS in fixed order.  pb == nullptr: m2 only
+    // ("m2 first", conv.hip): the indicator slab does not exist and m1 comes from the input gradient's own sums.
+    __shared__ float red[2][128];
+    const int b = blockIdx.x, ci = threadIdx.x % p.Cin, part = threadIdx.x / p.Cin, nparts = 128 / p.Cin;      // Cin <= 16 (launcher)
     const uint8_t* mk = nullptr;
     int mld = 0, mcol = 0;
     bool hs = false;
@@ -840,21 +842,27 @@ __global__ __launch_bounds__(128) void march_ident_kernel(ConvK p, const float* 
     }
     const float mval = (mk && mk[(long)b * mld + mcol] == 0) ? 0.f : 1.f;
     const float* dw = dwb + (long)b * (nW + p.Cout);
-    const float* pp = pb + (long)b * nW;
+    const float* pp = pb ? pb + (long)b * nW : nullptr;
     const bf16_t* w0 = wdg + (long)(b / bg) * wset_el;
     const int K8 = p.Cout / 8;
     float m1 = 0.f, m2 = 0.f;
-    for (int co = 0; co < p.Cout; ++co) {
-        const float dbv = p.slope * dw[nW + co] * mval;
-        for (int t = 0; t < 27; ++t) {
+    if (part < nparts) {
+        for (int e0 = part; e0 < p.Cout * 27; e0 += nparts) {
+            const int co = e0 / 27, t = e0 % 27;
             const float w = (float)w0[(((long)t * K8 + (co >> 3)) * mpad + ci) * 8 + (co & 7)];
             const long e = ((long)co * p.Cin + ci) * 27 + t;
             m2 = __builtin_fmaf(w, dw[e], m2);
-            m1 = __builtin_fmaf(w, dbv + (1.f - p.slope) * pp[e], m1);
+            if (pp) m1 = __builtin_fmaf(w, p.slope * dw[nW + co] * mval + (1.f - p.slope) * pp[e], m1);
         }
     }
-    out[((long)b * p.Cin + ci) * 2 + 0] = hs ? m1 * inv_v : 0.f;
-    out[((long)b * p.Cin + ci) * 2 + 1] = hs ? m2 * inv_v : 0.f;
+    red[0][threadIdx.x] = m1; red[1][threadIdx.x] = m2;
+    __syncthreads();
+    if (threadIdx.x < p.Cin) {
+        float a1 = 0.f, a2 = 0.f;
+        for (int q = 0; q < nparts; ++q) { a1 += red[0][q * p.Cin + ci]; a2 += red[1][q * p.Cin + ci]; }
+        out[((long)b * p.Cin + ci) * 2 + 0] = hs ? a1 * inv_v : 0.f;
+        out[((long)b * p.Cin + ci) * 2 + 1] = hs ? a2 * inv_v : 0.f;
+    }
 }
 
 // the input gradient (conv_lean.hip mode 1 for ksize 1): K8 = blocks of 8 dY channels; k.wpack (transposed images), k.Mpad = pad16(Cin),
@@ -899,7 +907,9 @@ int launch_pw_ident(const ConvK& k, const float* wslab, long wslot, const float*
 int launch_march_ident(const ConvK& k, const float* wslab, long wslot, const float* sslab, int wgs_per_b, const void* wdg_bf16, long wset_el,
                        float* dwb, float* pb, float* out, float* const* dw_out, float* const* db_out, int G, hipStream_t st) {
     const long nW = (long)k.Cout * k.Cin * 27;
-    const unsigned gx = (unsigned)((nW + k.Cout + 15) / 16 + (nW + 15) / 16);
+    if (k.Cin > 16) return -1024;
+    const unsigned gx = (unsigned)((nW + k.Cout + 15) / 16 + (sslab ? (nW + 15) / 16 : 0));      // sslab == nullptr: no indicator slab, m2 only
+    if (!sslab) pb = nullptr;
     hipLaunchKernelGGL(pw_fold_sample_kernel, dim3(gx, k.B), dim3(256), 0, st, wslab, nW + k.Cout, wslot, dwb, sslab, nW, wslot, pb, wgs_per_b);
     LAUNCH_RET();
     MarchOuts mo;
