@@ -120,7 +120,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvK p) {
     using G = Geo<KS, S, DG>;
     constexpr int CK = G::CK;
     __shared__ float lds[CK * G::PLANE];
-    __shared__ float lsum[DG ? MT * 16 * 2 : 1];
+    __shared__ float lsum[DG ? 4 * MT * 16 * 2 : 1];
 
     const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, n = lane & 15, kq = lane >> 4;
     int bid = xcd_swizzle(blockIdx.x, gridDim.x);
@@ -1497,6 +1497,9 @@ static int conv3d_bwd_impl(const passion_conv_desc_t* d, const float* packed, co
             }
         }
         // TI = dy dtype, TO = x/dx dtype
+        // the one-brick-per-workgroup kernels below (f32 parity mode, ragged / stride-2 bf16 shapes): fixed-point sums over a few
+        // replicas, so that these gradients repeat bit for bit too (the lean launchers set their own)
+        if (!padout && phase == 0 && !k.sums_float_only) { k.sums_rep = SUMS_REP_LEAN; k.sums_fixed = 1; }
         if (padout) rc = 0;
         else if (d->x_dtype == PASSION_F32 && d->y_dtype == PASSION_F32)
             rc = launch_conv_geo<float, float, 1>(k, d->ksize, d->stride, mtiles, st);

@@ -128,7 +128,7 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(ConvK p) {
     constexpr bool WLDS = wlds_fits(CKB, MT);
     constexpr int WV = G::NSTEP * 4 * MT * 16;          // 16-byte weight vectors per chunk
     bf16x8* wl = reinterpret_cast<bf16x8*>(dyn_lds + brick_bytes<KS, S, DG, CKB>());
-    __shared__ float lsum[DG ? MT * 16 * 2 : 5 * MT * 16 * 2];     // forward: [wave][row][2] + the workgroup's totals (fused statistics)
+    __shared__ float lsum[DG ? 4 * MT * 16 * 2 : 5 * MT * 16 * 2];     // forward: [wave][row][2] + the workgroup's totals (fused statistics)
 
     const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, n = lane & 15, g = lane >> 4;
     int bid = xcd_swizzle(blockIdx.x, gridDim.x);

@@ -373,13 +373,17 @@ __device__ __forceinline__ void epilogue_fwd_stats(const ConvK& p, const f32x4 (
     fwd_stats_commit(p.fst, p.Cout, b, wq, mg * MT * 16, MT * 16, wsum, tid);
 }
 
-// rows are input channels of the forward conv.  lsum: shared float[MT*16*2], zeroed here.
+// rows are input channels of the forward conv.  lsum: shared float[4 * MT*16*2] (one slice per wave), zeroed here.
+// The workgroup's sums are formed in a fixed order (lanes by shuffles, waves through their own LDS slices) and added to the global
+// replicas as 2^-40 fixed-point 64-bit integers when p.sums_fixed is set (order-independent: the f32 parity mode and the general
+// bf16 kernels repeat bit for bit, like the lean / marching kernels), as float atomics otherwise (depth-sharded phases).
 template <typename TO, int MT>
 __device__ __forceinline__ void epilogue_dgrad(const ConvK& p, const f32x4 (&acc)[MT][4], float* lsum, int b, int mg,
                                                int od, int ow, const int (&oh4)[4], int kq, int n, int tid) {
     const int Od = p.Di, Oh = p.Hi, Ow = p.Wi;
     const int nrows = MT * 16;
-    for (int i = tid; i < nrows * 2; i += 256) lsum[i] = 0.f;
+    const int wv = tid >> 6;
+    for (int i = tid; i < 4 * nrows * 2; i += 256) lsum[i] = 0.f;
     __syncthreads();
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
@@ -430,24 +434,30 @@ __device__ __forceinline__ void epilogue_dgrad(const ConvK& p, const f32x4 (&acc
                 store4(dx + vox * sd.C + cl, g);
             }
         }
-        // reduce the per-channel sums over the 16 voxel lanes, then over waves through LDS
+        // reduce the per-channel sums over the 16 voxel lanes; one lane per (wave, row) leaves them in the wave's LDS slice
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             float a1 = group16_sum(s1[j]), a2 = group16_sum(s2v[j]);
             if (n == 0 && seg_ok && p.seg[sg].stats) {
-                atomicAdd(&lsum[(mt * 16 + kq * 4 + j) * 2 + 0], a1);
-                atomicAdd(&lsum[(mt * 16 + kq * 4 + j) * 2 + 1], a2);
+                lsum[(wv * nrows + mt * 16 + kq * 4 + j) * 2 + 0] = a1;
+                lsum[(wv * nrows + mt * 16 + kq * 4 + j) * 2 + 1] = a2;
             }
         }
     }
     __syncthreads();
-    for (int i = tid; i < nrows; i += 256) {
-        const int cg = mg * MT * 16 + i;
-        if (cg < p.Cin && (lsum[i * 2] != 0.f || lsum[i * 2 + 1] != 0.f)) {
-            // thousands of bricks add into the same 2*Cin words: spread them over SUMS_REP replicas (folded afterwards)
-            float* rs = p.sums + (long)(blockIdx.x % p.sums_rep) * p.B * p.Cin * 2;
-            atomicAdd(&rs[((long)b * p.Cin + cg) * 2 + 0], lsum[i * 2 + 0]);
-            atomicAdd(&rs[((long)b * p.Cin + cg) * 2 + 1], lsum[i * 2 + 1]);
+    for (int i = tid; i < nrows * 2; i += 256) {
+        const int cg = mg * MT * 16 + (i >> 1);
+        const float t = ((lsum[i] + lsum[nrows * 2 + i]) + lsum[2 * nrows * 2 + i]) + lsum[3 * nrows * 2 + i];      // waves in order
+        if (cg < p.Cin && t != 0.f) {
+            // thousands of bricks add into the same 2*Cin words: spread them over the replicas (folded afterwards)
+            const long idx = (long)(blockIdx.x % p.sums_rep) * p.B * p.Cin * 2 + ((long)b * p.Cin + cg) * 2 + (i & 1);
+            if (p.sums_fixed) {
+                double v = (double)t * 1099511627776.0;                          // 2^40
+                v = fmin(fmax(v, -9.0e18), 9.0e18);
+                atomicAdd(reinterpret_cast<unsigned long long*>(p.sums) + idx, (unsigned long long)(long long)llrint(v));
+            } else {
+                atomicAdd(&p.sums[idx], t);
+            }
         }
     }
 }
