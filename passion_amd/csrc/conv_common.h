@@ -286,6 +286,37 @@ __device__ __forceinline__ void fwd_stats_commit(const FwdStats& fs, int Cout, i
     if (tid == 0) __hip_atomic_store(&tk[fs.ngroup], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// Marching input gradients (conv_march.hip, conv_pair.hip, conv_s2_dgrad.hip): the workgroup that took the last ticket of sample b folds
+// the sample's nslots sums slots (slot r at sums + r * B * Cin * 2) into slot 0, in double, in a fixed order.  All 256 threads load:
+// value v = tid % NVP, slot slice tid / NVP (NVP = the power of two >= 2 Cin), eight loads in flight per thread -- with 64 loading
+// threads (the first version) the tail of a 1024-slot fold was ~14 us of a 52 us launch at batch 1.
+__device__ __forceinline__ void fold_sums_slots(float* sums, int b, int B, int Cin, int nslots, int tid, double* fpart /* LDS [256] */) {
+    const int NV = Cin * 2;                                    // <= 64
+    const int NVP = NV <= 16 ? 16 : (NV <= 32 ? 32 : 64), SL = 256 / NVP;
+    const int v = tid & (NVP - 1), sl = tid / NVP;
+    double a = 0.0;
+    if (v < NV) {
+        const float* s0 = sums + ((long)b * Cin) * 2 + v;
+        const long rstride = (long)B * Cin * 2;
+        int r = sl;
+        for (; r + 7 * SL < nslots; r += 8 * SL) {
+            float tv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) tv[u] = ld_agent(&s0[(long)(r + u * SL) * rstride]);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a += (double)tv[u];
+        }
+        for (; r < nslots; r += SL) a += (double)ld_agent(&s0[(long)r * rstride]);
+    }
+    fpart[tid] = a;
+    __syncthreads();
+    if (tid < NV) {
+        double t = 0.0;
+        for (int q = 0; q < SL; ++q) t += fpart[q * NVP + tid];
+        sums[((long)b * Cin) * 2 + tid] = (float)t;
+    }
+}
+
 // v -> the four bf16 values that get stored (packed) and what they read back as
 __device__ __forceinline__ void round4_bf16(const f32x4& v, unsigned (&packed)[2], float (&r)[4]) {
     union { bf16_t h[4]; unsigned u[2]; } t;

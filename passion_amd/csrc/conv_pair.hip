@@ -533,25 +533,7 @@ void conv_pair_kernel(ConvK p, PairP mp) {
             __syncthreads();
             if (last_wg) {
                 acquire_agent();
-                const int NV = p.Cin * 2;                      // <= 16 values per sample
-                const int SL = 256 / 64, v = tid & 63, sl = tid >> 6;
-                double a = 0.0;
-                if (v < NV) {
-                    const float* s0 = p.sums + ((long)b * p.Cin) * 2 + v;
-                    const long rstride = (long)p.B * p.Cin * 2;
-                    int r2 = sl;
-                    for (; r2 + 7 * SL < mp.nwg_b; r2 += 8 * SL) {
-                        float tv[8];
-#pragma unroll
-                        for (int u = 0; u < 8; ++u) tv[u] = ld_agent(&s0[(long)(r2 + u * SL) * rstride]);
-#pragma unroll
-                        for (int u = 0; u < 8; ++u) a += (double)tv[u];
-                    }
-                    for (; r2 < mp.nwg_b; r2 += SL) a += (double)ld_agent(&s0[(long)r2 * rstride]);
-                }
-                fpart[tid] = a;
-                __syncthreads();
-                if (tid < NV) p.sums[((long)b * p.Cin) * 2 + tid] = (float)(((fpart[tid] + fpart[64 + tid]) + fpart[128 + tid]) + fpart[192 + tid]);
+                fold_sums_slots(p.sums, b, p.B, p.Cin, mp.nwg_b, tid, fpart);
                 if (tid == 0) __hip_atomic_store(&mp.tickets[b], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }

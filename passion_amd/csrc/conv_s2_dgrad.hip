@@ -505,17 +505,7 @@ __global__ __launch_bounds__(256) void conv_s2_march_kernel(ConvK p, S2MP mp) {
         __syncthreads();
         if (last_wg) {
             acquire_agent();
-            const int NV = p.Cin * 2;
-            const int SL = 256 / 64, v = tid & 63, sl = tid >> 6;
-            double a = 0.0;
-            if (v < NV) {
-                const float* s0 = p.sums + ((long)b * p.Cin) * 2 + v;
-                const long rstride = (long)p.B * p.Cin * 2;
-                for (int r2 = sl; r2 < mp.nwg_b; r2 += SL) a += (double)ld_agent(&s0[(long)r2 * rstride]);
-            }
-            fpart[tid] = a;
-            __syncthreads();
-            if (tid < NV) p.sums[((long)b * p.Cin) * 2 + tid] = (float)(((fpart[tid] + fpart[64 + tid]) + fpart[128 + tid]) + fpart[192 + tid]);
+            fold_sums_slots(p.sums, b, p.B, p.Cin, mp.nwg_b, tid, fpart);
             if (tid == 0) __hip_atomic_store(&mp.tickets[b], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
