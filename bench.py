@@ -455,10 +455,26 @@ def main():
             ops.prof_enable(0)
             ops.prof_filter()
             graph_live_recs = ops.prof_read()
+    graph_note = None
     if use_graph:
         step = graph_step
-        for _ in range(5):                          # two eager steps on the capture stream, the recording (+ its replay), two more replays
-            step()
+        failed = 0.0
+        try:
+            for _ in range(5):                      # two eager steps on the capture stream, the recording (+ its replay), two more replays
+                step()
+            torch.cuda.synchronize()
+        except Exception as e:                      # noqa: BLE001 -- a recording that cannot be made must not cost the measurement
+            failed, graph_note = 1.0, f"{type(e).__name__}: {e}"[:300]
+            print(f"[bench] graph recording failed on rank {ctx.rank}, falling back to the eager step: {graph_note}", file=sys.stderr)
+        if parallel.all_reduce_max(ctx, failed) > 0:        # every rank takes the same path (the eager N > 1 step has collectives inside)
+            use_graph, step = False, eager_step
+            graph_note = graph_note or "another rank could not record the step"
+            try:
+                torch.cuda.synchronize()
+            except Exception:                       # noqa: BLE001
+                pass
+            for _ in range(2):
+                step()
         parallel.barrier(ctx)
         torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -478,7 +494,8 @@ def main():
     dt = parallel.all_reduce_max(ctx, dt)
     final_loss = float(loss)
 
-    timed_recs = (graph_live_recs if use_graph else ops.prof_read()) if want_events else []
+    graph_events = use_graph or graph_note is not None      # the reported kernel's launches were timed in the eager steps before the recording
+    timed_recs = (graph_live_recs if graph_events else ops.prof_read()) if want_events else []
 
     def emit(line):
         """the ONE JSON line, and the last thing on stdout: librccl writes "Librccl path : ..." to stdout when a process that used it
@@ -523,7 +540,7 @@ def main():
                    "launch": (("HIP graph replay of forward + loss + backward, then the eager tail of train.train_step: bucketed RCCL all-reduce of "
                                "the static gradient tensors + AdamW (no collective is recorded)" if reducer.active else
                                "HIP graph replay of train.train_step (recorded once after the warm-up; batch, AdamW scalars and dropout "
-                               "seeds through device memory)") if use_graph else "eager")},
+                               "seeds through device memory)") if use_graph else ("eager" if not graph_note else "eager (the HIP-graph recording failed: " + graph_note + ")"))},
     }
     if want_events:
         recs = [r for r in timed_recs if r[1] >= 0]
@@ -570,7 +587,7 @@ def main():
                   "frac_single_stream": round(alone_ach / HBM_PEAK_GBS, 5) if alone_ach else None,
                   "measured_copy_peak": round(copy_gbs, 1), "frac_of_measured_copy": round(ach / copy_gbs, 5),
                   "avg_launch_ms_single_stream": round(alone_ms, 5) if alone_ms else None,
-                  "launches_per_step": len(rk) // (max(3, args.warmup) if use_graph else args.steps), "avg_launch_ms": round(ms / len(rk), 5),
+                  "launches_per_step": len(rk) // (max(3, args.warmup) if graph_events else args.steps), "avg_launch_ms": round(ms / len(rk), 5),
                   "algorithmic_bytes_per_launch": round(by / len(rk), 1),
                   "tflops": round(fl / (ms * 1e-3) / 1e12, 3),
                   "events": ("live eager steps of this process right before the timed region, all streams running (the timed steps "
