@@ -341,6 +341,252 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(IND ? 3 : 4
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// SIXTEEN output channels (the 64^3 level: 16 -> 16, 32 -> 16): the same march with all 16 MFMA rows holding dY of the CURRENT
+// plane, so a K plane needs the three X planes P - 1 .. P + 1 and the 27 taps x 8 channels are 14 column tiles (tile j = taps 2 j,
+// 2 j + 1 for the lane halves; tap 27 does not exist).  wgrad_lean_kernel<3, 1> ran these layers at 1.2-1.6 TB/s (a 4x8x8 brick
+// re-stages 2.34x its voxels as halo and pays two barriers per brick).
+constexpr int Y16SLOT = WTH * WTW * 32 + 64;
+constexpr int NT16 = 14;
+constexpr int Y16BYTES = NSL * Y16SLOT;
+constexpr int RED16_BYTES = 4 * (NT16 / 2) * 64 * 16;          // the waves' partial sums meet in two halves of seven tiles
+constexpr int LDS16_BYTES = (XBYTES + Y16BYTES > RED16_BYTES) ? XBYTES + Y16BYTES : RED16_BYTES;
+
+__global__ __launch_bounds__(256) void wgrad_march16_kernel(ConvK p, WMarchP mp, float* __restrict__ dW, float* __restrict__ dbias) {
+    wgrad_clear(p);
+    __shared__ __attribute__((aligned(16))) char lds[LDS16_BYTES];
+    char* const lx = lds;
+    char* const ly = lds + XBYTES;
+
+    const int tid = threadIdx.x, lane = tid & 63, n = lane & 15, g = lane >> 4;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int q = n >> 2, pq = n & 3;
+    const int gb0 = blockIdx.y;                       // this workgroup's 8-channel block of the virtual concat
+    const int Sd = p.Di, Sh = p.Hi, Sw = p.Wi;
+
+    const int bx = xcd_swizzle(blockIdx.x, gridDim.x);
+    const int b = bx / mp.wgs_per_b;                  // >= B: spare workgroup, flushes a zero slot
+    const int i0 = bx % mp.wgs_per_b;
+    const int nunits = (b < p.B) ? mp.ncols * mp.nseg_d : 0;
+
+    int sg = 0, c0 = 0, C = 8, cbase = 0;
+    bool exist = false;
+    {
+        int r = gb0;
+#pragma unroll
+        for (int s2 = 0; s2 < PASSION_MAX_SEG; ++s2) {
+            if (s2 < p.nseg && !exist) {
+                const int nb = p.seg[s2].C / 8;
+                if (r < nb) { exist = true; sg = s2; c0 = r * 8; C = p.seg[s2].C; cbase = p.seg[s2].cbase; }
+                r -= nb;
+            }
+        }
+    }
+    const bf16_t* src = nullptr;
+    bool present = false, has_norm = false;
+    f32x2 sc[4], sh[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { sc[c] = (f32x2){1.f, 1.f}; sh[c] = (f32x2){0.f, 0.f}; }
+    if (exist && i0 < nunits) {
+#pragma unroll
+        for (int s2 = 0; s2 < PASSION_MAX_SEG; ++s2) {
+            if (s2 == sg) {
+                const SegD& sd = p.seg[s2];
+                const int bs = sd.bsrc(b);
+                present = !sd.mask || sd.mask[(long)b * sd.mask_ld + sd.mask_col] != 0;
+                src = reinterpret_cast<const bf16_t*>(sd.x) + (long)bs * sd.bstride + c0;
+                has_norm = sd.stats != nullptr;
+                if (sd.stats) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const f32x4 st4 = *reinterpret_cast<const f32x4*>(sd.stats + ((long)bs * sd.C + c0 + 2 * c) * 2);
+                        sc[c] = (f32x2){st4[1], st4[3]};
+                        sh[c] = (f32x2){uniform(-st4[0] * st4[1]), uniform(-st4[2] * st4[3])};
+                    }
+                }
+            }
+        }
+    }
+    const bf16_t* dyb = reinterpret_cast<const bf16_t*>(p.dy) + (long)(b < p.B ? b : 0) * Sd * Sh * Sw * 16;      // Cout == 16
+
+    // per-lane constants of the MFMA loop (see wgrad_march_kernel): wave wv owns tile rows 2 wv, 2 wv + 1; lane (q, pq) LOADS 8 bytes of
+    // voxel q: A = channels 4 pq .. of dY (rows = the 16 output channels), B = channels (pq & 1) * 4 .. of tap 2 j + (pq >> 1) of tile j
+    const int row = 2 * wv + (g >> 1), col = (g & 1) * 8 + q;
+    const int yoff = (row * WTW + col) * 32 + pq * 8;
+    const int h = pq >> 1;
+    const int xlane = (row * XRW + col) * 16 + (pq & 1) * 8;
+    int boff[NT16];                                   // in-plane byte offset of the lane's tap of tile j; its plane (0 .. 2) in bits 30..31
+#pragma unroll
+    for (int j = 0; j < NT16; ++j) {
+        const int t = min(2 * j + h, 26);
+        boff[j] = xlane + tapoff(t % 9) + ((t / 9) << 28);
+    }
+    f32x4 acc[NT16];
+#pragma unroll
+    for (int j = 0; j < NT16; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const bool bias_block = (dbias != nullptr) && (gb0 == 0);
+    f32x2 bsum[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) bsum[c] = (f32x2){0.f, 0.f};
+    const f32x2 slope2 = {p.slope, p.slope};
+
+    // staging roles: threads 0..179 one voxel of the X plane (tile + halo); every thread one 16-byte half of a dY voxel
+    const bool xthr = tid < XVOX;
+    const int zh = tid / (WTW + 2), zw = tid % (WTW + 2);
+    const int xlds = (zh * XRW + zw) * 16;
+    const int yv = tid >> 1, yhalf = tid & 1, vh = yv >> 4, vw = yv & 15;
+    const int ylds = yv * 32 + yhalf * 16;
+    const bool reflect = p.pad_mode == PASSION_PAD_REFLECT;
+
+    for (int unit = i0; unit < nunits; unit += mp.wgs_per_b) {
+        const int colidx = unit % mp.ncols, dseg = unit / mp.ncols;
+        const int h0 = (colidx / mp.tilesW) * WTH, w0 = (colidx % mp.tilesW) * WTW;
+        const int dlo = dseg * mp.planes_per_seg, dhi = min(dlo + mp.planes_per_seg, Sd);
+        const int L = dhi - dlo;
+        if (L <= 0) continue;
+        bool xok = xthr && present;
+        unsigned xel, yel;
+        {
+            int s_h = h0 - 1 + (xthr ? zh : 1), s_w = w0 - 1 + (xthr ? zw : 1);
+            if (reflect) { s_h = reflect_idx(s_h, Sh); s_w = reflect_idx(s_w, Sw); }
+            else xok = xok && s_h >= 0 && s_h < Sh && s_w >= 0 && s_w < Sw;
+            s_h = min(max(s_h, 0), Sh - 1); s_w = min(max(s_w, 0), Sw - 1);
+            xel = (unsigned)(s_h * Sw + s_w) * (unsigned)C;
+            yel = (unsigned)((h0 + vh) * Sw + w0 + vw) * 16u + (unsigned)yhalf * 8u;
+        }
+        const unsigned xplane_el = (unsigned)(Sh * Sw) * (unsigned)C, yplane_el = (unsigned)(Sh * Sw) * 16u;
+        u32x4 ra[NSL], rd[NSL];
+        // stage j = X plane dlo - 1 + j and dY plane dlo - 1 + j (zero outside [dlo, dhi))
+        auto fetch = [&](int u, int j) {
+            const int pl = dlo - 1 + j;
+            int xp = reflect ? reflect_idx(pl, Sd) : pl;
+            xp = min(max(xp, 0), Sd - 1);
+            const int yp = min(max(pl, dlo), dhi - 1);
+            ra[u] = gload<u32x4>(src + ((unsigned)xp * xplane_el + xel));
+            rd[u] = gload<u32x4>(dyb + ((unsigned)yp * yplane_el + yel));
+        };
+        auto commit = [&](int u, int j) {
+            const int pl = dlo - 1 + j;
+            const bool okd = reflect || (pl >= 0 && pl < Sd);
+            const bool yin = pl >= dlo && pl < dhi;
+            if (xthr) {
+                u32x4 o = (u32x4){0u, 0u, 0u, 0u};    // zero padding is applied AFTER norm + activation
+                if (xok && okd) {
+                    o = ra[u];
+                    if (has_norm) {
+                        bf16x8 ob;
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            const f32x2 xv = {__uint_as_float(ra[u][c] << 16), __uint_as_float(ra[u][c] & 0xffff0000u)};
+                            f32x2 t = __builtin_elementwise_fma(xv, sc[c], sh[c]);
+                            const f32x2 ts = t * slope2;
+                            t.x = fmaxf(t.x, ts.x);
+                            t.y = fmaxf(t.y, ts.y);
+                            ob[2 * c] = (__bf16)t.x; ob[2 * c + 1] = (__bf16)t.y;
+                        }
+                        o = __builtin_bit_cast(u32x4, ob);
+                    }
+                }
+                *reinterpret_cast<u32x4*>(lx + u * XSLOT + xlds) = o;
+            }
+            const u32x4 oy = yin ? rd[u] : (u32x4){0u, 0u, 0u, 0u};
+            *reinterpret_cast<u32x4*>(ly + u * Y16SLOT + ylds) = oy;
+            if (bias_block && yin) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    bsum[c] += (f32x2){__uint_as_float(oy[c] << 16), __uint_as_float(oy[c] & 0xffff0000u)};
+            }
+        };
+        // K plane from the ring slots s0, s1, s2 of X planes P - 1, P, P + 1; dY of plane P sits in slot s1
+        auto compute = [&](int s0, int s1, int s2) {
+            const char* ya = ly + yoff + s1 * Y16SLOT;
+            const bf16x8 a = tr_read8(ya, ya + 128);
+            const int so[3] = {s0 * XSLOT, s1 * XSLOT, s2 * XSLOT};
+#pragma unroll
+            for (int j = 0; j < NT16; ++j) {
+                const int pd = boff[j] >> 28;                          // per lane half only for tile 4 (taps 8 | 9)
+                const char* bp = lx + (boff[j] & 0x0fffffff) + (pd == 0 ? so[0] : (pd == 1 ? so[1] : so[2]));
+                const bf16x8 bv = tr_read8(bp, bp + 64);
+                acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bv, acc[j], 0, 0, 0);
+            }
+        };
+
+        // pipeline.  iteration j: barrier; commit stage j; fetch stage j + NSL; compute K plane j - 3 (stages j - 3 .. j - 1, all committed
+        // before this barrier; slot j & 3 held stage j - 4, last read in iteration j - 1).  Dead iterations commit zero dY planes.
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < NSL; ++u) fetch(u, u);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {                 // stages 0 .. 2: nothing to compute yet
+            __syncthreads();
+            commit(j, j);
+            fetch(j, j + NSL);
+        }
+        for (int j0 = 3; j0 < L + 3; j0 += NSL) {
+#pragma unroll
+            for (int jj = 0; jj < NSL; ++jj) {
+                const int j = j0 + jj, u = (3 + jj) % NSL;
+                __syncthreads();
+                commit(u, j);
+                fetch(u, j + NSL);
+                compute((u + 1) % NSL, (u + 2) % NSL, (u + 3) % NSL);
+            }
+        }
+    }
+
+    // the four waves hold partial sums over disjoint voxels of the same outputs: combine through LDS in fixed order (two halves of seven
+    // tiles: the buffer shares the ring's space), write this workgroup's slot of the partial-sum slab
+    f32x4* red = reinterpret_cast<f32x4*>(lds);
+    constexpr int HT = NT16 / 2;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < HT; ++j) red[(wv * HT + j) * 64 + lane] = acc[half * HT + j];
+        __syncthreads();
+        if (dW && exist) {
+            float* slot = dW + (long)bx * p.wslot;
+            for (int e = tid; e < HT * 64; e += 256) {
+                const int j = half * HT + (e >> 6), l2 = e & 63, n2 = l2 & 15, g2 = l2 >> 4;
+                f32x4 v = red[e];
+#pragma unroll
+                for (int w2 = 1; w2 < 4; ++w2) {
+                    const f32x4 o = red[w2 * HT * 64 + e];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] += o[r];
+                }
+                const int tap = 2 * j + (n2 >> 3), ci = n2 & 7;
+                if (tap > 26) continue;
+                const long cig = cbase + c0 + ci;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) slot[((long)(g2 * 4 + r) * p.Cin + cig) * 27 + tap] = v[r];
+            }
+        }
+    }
+    if (bias_block) {
+        __syncthreads();
+        float* bred = reinterpret_cast<float*>(lds);              // [256][9]: thread t holds channels 8 (t & 1) .. of voxel t >> 1
+        float* bred2 = bred + 256 * 9;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) bred[tid * 9 + c] = bsum[c >> 1][c & 1];
+        __syncthreads();
+        if (tid < 128) {                                          // (channel 0 .. 15) x (8 slices of 16 voxels)
+            const int c = tid & 15, part = tid >> 4;
+            float sacc = 0.f;
+            for (int v = part * 16; v < part * 16 + 16; ++v) sacc += bred[(2 * v + (c >> 3)) * 9 + (c & 7)];
+            bred2[part * 16 + c] = sacc;
+        }
+        __syncthreads();
+        if (tid < 16) {
+            float sacc = 0.f;
+#pragma unroll
+            for (int part = 0; part < 8; ++part) sacc += bred2[part * 16 + tid];
+            dbias[(long)bx * p.wslot + tid] = sacc;
+        }
+    }
+}
+
 }  // namespace
 
 namespace pconv {
@@ -349,7 +595,12 @@ namespace pconv {
 // kernel: gx slots in sample order, gy = 8-channel blocks of the virtual concat; k.per is set so that the grouped fold
 // (conv.hip) derives the same workgroups-per-sample from it.
 int launch_wgrad_march(ConvK& k, int ksize, int stride, int MT, int gx, int gy, float* dW, float* db, hipStream_t st) {
-    if (!g_wgrad_march || ksize != 3 || stride != 1 || k.Cout != 8 || k.y_f32 || MT != 1) return 1;
+    static const bool m16 = []() { const char* e = getenv("PASSION_WGRAD_MARCH16"); return !(e && e[0] == '0'); }();
+    // measured at 64^3 (tools/conv_microbench.py): 32 -> 16 at batch 4 62.6 us against 75.0 on wgrad_lean_kernel<3, 1>, 16 -> 16 at batch 4
+    // 41.8 against 44.3, 16 -> 16 at batch 1 30.0 against 23.4 (a column of 64 planes does not amortise the prologue and the flush):
+    // only where the launch has enough (sample, channel block) pairs
+    const bool c16 = k.Cout == 16 && m16 && !k.spos && k.B * (k.Cin / 8) >= 8;
+    if (!g_wgrad_march || ksize != 3 || stride != 1 || !(k.Cout == 8 || c16) || k.y_f32 || MT != 1) return 1;
     if (!wgrad_lean_covers(k, ksize, stride, MT, gx, gy)) return 1;
     if (k.Hi % WTH || k.Wi % WTW || k.Di < 8) return 1;
     k.Mpad = pad16(k.Cout);
@@ -373,6 +624,12 @@ int launch_wgrad_march(ConvK& k, int ksize, int stride, int MT, int gx, int gy, 
     }
     mp.planes_per_seg = (k.Di + best - 1) / best;
     mp.nseg_d = (k.Di + mp.planes_per_seg - 1) / mp.planes_per_seg;
+    if (c16) {
+        passion_prof_tag("wgrad_march16_kernel");
+        hipLaunchKernelGGL(wgrad_march16_kernel, dim3(gx, gy), dim3(256), 0, st, k, mp, dW, db);
+        LAUNCH_RET();
+        return 0;
+    }
     if (k.spos) {                  // finish-free backward (conv.hip: march_final): the indicator slab rides along
         passion_prof_tag("wgrad_march_kernel<0, 1>");
         hipLaunchKernelGGL((wgrad_march_kernel<0, true>), dim3(gx, gy), dim3(256), 0, st, k, mp, dW, db);

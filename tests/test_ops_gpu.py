@@ -97,6 +97,11 @@ CONV_CASES = [
     ([8], 16, 3, 2, 1, (16, 32, 48), True, False, False),
     ([8], 16, 3, 2, 1, (36, 20, 34), True, True, False),
     ([8], 16, 3, 2, 1, (6, 8, 8), False, False, False),
+    # sixteen output channels on marching-eligible volumes: wgrad_march16_kernel (conv_wgrad_march.hip)
+    ([16], 16, 3, 1, 1, (16, 16, 32), True, False, True),
+    ([16, 16], 16, 3, 1, 1, (8, 16, 16), True, True, False),
+    ([16], 16, 3, 1, 0, (9, 8, 16), True, False, False),
+    ([8, 8, 8], 16, 3, 1, 1, (12, 24, 16), False, False, False),
 ]
 
 
