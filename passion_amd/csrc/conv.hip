@@ -838,8 +838,10 @@ WgPlan plan_wgrad(const ConvK& k, const passion_conv_desc_t* d) {
     const long total = (long)k.B * cdiv(k.Do, TD) * cdiv(k.Ho, TH) * cdiv(k.Wo, TW);
     // workgroups of a launch = slots of the partial slab x gy.  Small volumes (levels 3..5: <= 512 bricks) take fewer slots: the
     // slab (slots x Cout Cin taps floats: 28 MB at 1024 / gy slots for a 64 -> 64 conv over 4 x 16^3) is written, then read by the fold
-    static const long wg_small = []() { const char* e = getenv("PASSION_WGRAD_WGS_SMALL"); return e && atol(e) > 0 ? atol(e) : 1024L; }();
-    const long wg_target = total <= 512 ? wg_small : 1024L;
+    // (measured per layer, weight gradient + the finish launch that folds its slab, 4 samples: 64 -> 64 over 16^3: 56.1 us at 1024 workgroups,
+    // 42.7 at 512, 40.0 at 256, 47.3 at 128; 128 -> 128 over 8^3: 39.2 / 39.2 / 34.4; 32 -> 32 over 32^3: 62.8 / 54.6 / 58.3 / 75.9)
+    static const long wg_small = []() { const char* e = getenv("PASSION_WGRAD_WGS_SMALL"); return e && atol(e) > 0 ? atol(e) : 0L; }();
+    const long wg_target = total <= 512 ? (wg_small ? wg_small : (total <= 64 ? 256L : 512L)) : 1024L;
     w.gx = (int)hmin(total, hmax(1, wg_target / w.gy));
     return w;
 }
