@@ -14,7 +14,7 @@ def gold(name):
     return np.load(os.path.join(GOLD, name), allow_pickle=False)
 
 
-def synth(B, S, seed=7, blobs=False):
+def synth(B, S, seed=7, blobs=False, radii=(0.35, 0.25, 0.12)):
     """same generator as tools/make_golden.py (SURVEY 8d synthetic inputs)"""
     g = torch.Generator().manual_seed(seed)
     x = torch.randn(B, 4, S, S, S, generator=g)
@@ -22,9 +22,9 @@ def synth(B, S, seed=7, blobs=False):
         zz, yy, xx = torch.meshgrid(*[torch.arange(S, dtype=torch.float32)] * 3, indexing="ij")
         r = ((zz - S / 2) ** 2 + (yy - S / 2) ** 2 + (xx - S / 2) ** 2).sqrt()
         lab = torch.zeros(B, S, S, S, dtype=torch.long)
-        lab[:, r < S * 0.35] = 2
-        lab[:, r < S * 0.25] = 1
-        lab[:, r < S * 0.12] = 3
+        lab[:, r < S * radii[0]] = 2
+        lab[:, r < S * radii[1]] = 1
+        lab[:, r < S * radii[2]] = 3
     else:
         lab = torch.randint(0, 4, (B, S, S, S), generator=g)
     return x, F.one_hot(lab, 4).permute(0, 4, 1, 2, 3).double()
@@ -94,9 +94,10 @@ def flash_keep_mask(B, N, p, seed, H=8):
 
 
 # ---- multi-step fixtures (tools/make_golden_traj.py) ------------------------------------------------------------------------
-def signal_volume(S, means, seed=7):
-    """blob labels and x = 0.5 * noise + a class-dependent mean per modality (make_golden_traj.signal_volume)"""
-    x, target = synth(1, S, seed=seed, blobs=True)
+def signal_volume(S, means, seed=7, radii=None):
+    """blob labels and x = 0.5 * noise + a class-dependent mean per modality (make_golden_traj.signal_volume); radii: the three sphere
+    radii of the labels as fractions of S (a fixture that stores them; default: make_golden.synth's)"""
+    x, target = synth(1, S, seed=seed, blobs=True, **({} if radii is None else {"radii": tuple(float(v) for v in radii)}))
     lab = target.argmax(1)
     x = 0.5 * x + torch.as_tensor(np.asarray(means), dtype=torch.float32)[:, lab[0]].unsqueeze(0)
     return x, target
@@ -119,7 +120,7 @@ def replay_trajectory(g, dtype, dev, on_step=None, force_gates=None):
     S, K, passion = int(g["S"]), int(g["K"]), bool(g["passion"])
     m = build_product_model(S, small=False).to(dev)
     m.mask_type, m.use_passion, m.is_training, m.compute_dtype = "idt", passion, True, dtype
-    x, target = signal_volume(S, g["means"])
+    x, target = signal_volume(S, g["means"], radii=g["radii"] if "radii" in g.files else None)
     x, target, mask = x.to(dev), target.to(dev), torch.from_numpy(g["mask"]).to(dev)
     opt = ptrain.make_optimizer(m, lr=float(g["lr"]), weight_decay=1e-4)
     losses, pred = [], None

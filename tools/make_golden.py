@@ -34,16 +34,16 @@ def import_reference():
     return mmformer, criterions
 
 
-def synth(B, S, seed=7, blobs=False):
+def synth(B, S, seed=7, blobs=False, radii=(0.35, 0.25, 0.12)):
     g = torch.Generator().manual_seed(seed)
     x = torch.randn(B, 4, S, S, S, generator=g)
     if blobs:
         zz, yy, xx = torch.meshgrid(*[torch.arange(S, dtype=torch.float32)] * 3, indexing="ij")
         r = ((zz - S / 2) ** 2 + (yy - S / 2) ** 2 + (xx - S / 2) ** 2).sqrt()
         lab = torch.zeros(B, S, S, S, dtype=torch.long)
-        lab[:, r < S * 0.35] = 2
-        lab[:, r < S * 0.25] = 1
-        lab[:, r < S * 0.12] = 3
+        lab[:, r < S * radii[0]] = 2
+        lab[:, r < S * radii[1]] = 1
+        lab[:, r < S * radii[2]] = 3
     else:
         lab = torch.randint(0, 4, (B, S, S, S), generator=g)
     target = F.one_hot(lab, 4).permute(0, 4, 1, 2, 3).double()   # float64 one-hot (datasets_nii.py:151-153)

@@ -26,9 +26,9 @@ LR = 1e-3          # options.py:11 default is 2e-4; the fixture uses a larger st
 MEANS = [[0., 1.5, -1.0, 2.0], [0., -1.0, 1.5, 1.0], [0., 1.0, 1.0, -1.5], [0., -1.5, 0.5, 1.5]]   # [modality][class]
 
 
-def signal_volume(S, seed=7):
+def signal_volume(S, seed=7, radii=None):
     """blob labels (make_golden.synth) and x = 0.5 * noise + a class-dependent mean per modality"""
-    x, target = mg.synth(1, S, seed=seed, blobs=True)
+    x, target = mg.synth(1, S, seed=seed, blobs=True, **({} if radii is None else {"radii": radii}))
     lab = target.argmax(1)
     x = 0.5 * x + torch.tensor(MEANS)[:, lab[0]].unsqueeze(0)
     return x, target
@@ -48,7 +48,10 @@ def main():
     mmformer, crit = mg.import_reference()
     m = mg.build(mmformer, S, small=False)            # eval(): dropout off; weights by torch.manual_seed(1037) construction order
     m.mask_type, m.use_passion, m.is_training = "idt", passion, True
-    x, target = signal_volume(S)
+    # TRAJ_RADII="0.40,0.30,0.20": larger label spheres (the default enhancing-tumour sphere is 0.7 % of the volume: after a few dozen
+    # steps the reference itself has not learned it, and Dice against its mask measures tie-breaking there -- VERDICT r3 item 8)
+    radii = tuple(float(v) for v in os.environ["TRAJ_RADII"].split(",")) if os.environ.get("TRAJ_RADII") else None
+    x, target = signal_volume(S, radii=radii)
     mask = torch.tensor([[True, True, False, True]])
     mk = mask.float()
     opt = torch.optim.AdamW([{"params": m.parameters(), "lr": LR, "weight_decay": 1e-4}], betas=(0.9, 0.999), eps=1e-08,
@@ -94,6 +97,8 @@ def main():
            "frac_margin_lt_1e2": float((margin < 1e-2).float().mean()),
            "pred_slice": pred[:, :, S // 2].numpy(), "pred_sum": pred.double().sum((2, 3, 4)).numpy(),
            "label_packed": pack2(lab.reshape(-1).numpy())}
+    if radii is not None:
+        rec["radii"] = np.array(radii, np.float64)
     if passion:
         rec["rp_masks"] = np.stack(rps)        # the relative-preference gate of every step (train.py:266-270): a DISCRETE switch
         rec["rp_vals"] = np.stack(rpv)         # ... and the signed relative distance it is the sign of: how close each decision was
