@@ -1,5 +1,5 @@
 """which ATen ops (the torch glue between the library's kernels) a training step still launches: count, device time, shapes.
-    python tools/torch_ops_table.py [workload passion 0/1]"""
+    python tools/torch_ops_table.py [passion 0/1] [mmformer | rfnet | m2ftrans]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -9,10 +9,19 @@ from passion_amd import train as ptrain
 from passion_amd.models import mmformer
 
 passion = len(sys.argv) > 1 and sys.argv[1] == "1"
+backbone = sys.argv[2] if len(sys.argv) > 2 else "mmformer"      # mmformer | rfnet | m2ftrans
 dev = torch.device("cuda:0")
 mmformer.patch_size = 8
 torch.manual_seed(1037)
-m = mmformer.Model(num_cls=4).to(dev)
+if backbone == "rfnet":
+    from passion_amd.models import rfnet
+    m = rfnet.Model(num_cls=4).to(dev)
+elif backbone == "m2ftrans":
+    from passion_amd.models import m2ftrans
+    m2ftrans.patch_size = 8
+    m = m2ftrans.Model(num_cls=4).to(dev)
+else:
+    m = mmformer.Model(num_cls=4).to(dev)
 m.mask_type, m.use_passion, m.compute_dtype = "idt", passion, torch.bfloat16
 m.train()
 opt = ptrain.make_optimizer(m)
