@@ -779,7 +779,8 @@ extern "C" int passion_upsample_fwd_stats(const void* x, void* y, int dtype, int
     // workgroups in all and >= 16 rows each (measured, x2 to 128^3 x 16 at batch 4: 1024 per sample 146 us, 512: 120, 256: 101, 128: 145;
     // to 64^3 x 32: 90 -> 33 us; at batch 1 the old 1024 stays best: 46 us against 71 at 256)
     static const long stats_blocks = []() { const char* e = getenv("PASSION_UPSAMPLE_STATS_BLOCKS"); return e && atol(e) > 0 ? atol(e) : 0L; }();
-    const long row_blocks = stats_blocks ? stats_blocks : hmax(1, hmin(hmax(128, 1024 / B), nrows / 16));
+    // (f32 = the parity mode keeps its 1024: the order of its sums is part of trajectories that are compared gate by gate)
+    const long row_blocks = stats_blocks ? stats_blocks : (dtype == PASSION_BF16 ? hmax(1, hmin(hmax(128, 1024 / B), nrows / 16)) : 1024L);
     const int blocks = (int)hmin(rows ? nrows : (total + 255) / 256, rows ? row_blocks : 1024L);
     pconv::FwdStats fs;
     const int rc = pconv::fwd_stats_setup_raw(fs, B, C, blocks, 1, 1.0 / ((double)D * k * H * k * W * k), eps, stats, st);
