@@ -962,8 +962,10 @@ def test_grouped_conv_equals_the_four_convs(case, bg):
             assert torch.equal(a, b)
     if with_res:
         assert torch.equal(drg, drr)
+    # (the grouped launch and a single set may take different weight-gradient kernels -- wgrad_march16_kernel wants >= 8 (sample, channel
+    # block) pairs, the slab of a small volume has fewer slots: the same bf16 products summed in another f32 order)
     for a, b in zip(dwg + dbg, dwr + dbr):
-        assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max()) + 1e-6
+        assert float((a - b).abs().max()) <= 1e-4 * float(b.abs().max()) + 1e-6
 
 
 WGRAD_MARCH_CASES = [
