@@ -963,9 +963,10 @@ def test_grouped_conv_equals_the_four_convs(case, bg):
     if with_res:
         assert torch.equal(drg, drr)
     # (the grouped launch and a single set may take different weight-gradient kernels -- wgrad_march16_kernel wants >= 8 (sample, channel
-    # block) pairs, the slab of a small volume has fewer slots: the same bf16 products summed in another f32 order)
+    # block) pairs -- and the marching kernels normalise as fma(x, rstd, -mean rstd), the lean one as (x - mean) rstd: a last-bit
+    # difference of x_hat before its bf16 rounding moves a few operands by one bf16 ulp, 2e-4 of the largest weight gradient measured)
     for a, b in zip(dwg + dbg, dwr + dbr):
-        assert float((a - b).abs().max()) <= 1e-4 * float(b.abs().max()) + 1e-6
+        assert float((a - b).abs().max()) <= 5e-4 * float(b.abs().max()) + 1e-6
 
 
 WGRAD_MARCH_CASES = [
