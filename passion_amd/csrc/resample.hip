@@ -611,6 +611,121 @@ __global__ __launch_bounds__(256) void upsample_shared_bwd_kernel(const T* __res
     }
 }
 
+// The same adjoint over 2 x 2 BLOCKS of input rows (id, ih): the dY rows that reach a block are the union of its four rows' candidates
+// (<= 8 per axis instead of 4 x <= 6) and every one of them is loaded ONCE per block and added into up to four accumulators --
+// upsample_shared_bwd_kernel loads ~20 dY rows per input row (1.3 GB out of L2 for 268 MB of dY at 4 x 64^3 x 16: L2-bound at
+// 1.5 TB/s), this one ~10.
+__device__ __forceinline__ float sgpr_f(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
+template <typename T, int VEC, int ROWV>
+__global__ __launch_bounds__(256) void upsample_shared_bwd2_kernel(const T* __restrict__ dy, T* __restrict__ dx, int D, int H, int W,
+                                                                   int C, int k) {
+    constexpr int NC = 6, NC2 = 8, NP = VEC / 2;
+    extern __shared__ __attribute__((aligned(16))) float vrow[];          // [4][Wo * C]
+    __shared__ float wts[2][2][2][NC2];                                    // [buffer][axis d / h][row of the pair][candidate]
+    __shared__ int los[2][2];
+    const int Do = D * k, Ho = H * k, Wo = W * k, cvn = C / VEC;
+    const int b = blockIdx.y, tid = threadIdx.x;
+    const float sd = axis_scale(D, Do), sh = axis_scale(H, Ho), sw = axis_scale(W, Wo);
+    const int rowvec = Wo * cvn, srcvec = W * cvn;
+    const T* dys = dy + (long)b * Do * Ho * Wo * C;
+    T* dxs = dx + (long)b * D * H * W * C;
+    const bool in_thr = tid < srcvec;
+    const int iw = in_thr ? tid / cvn : 0, cvi = tid % cvn;
+    const int wlo = max(0, (int)floorf((float)(iw - 1) / sw));
+    float ww[NC];
+#pragma unroll
+    for (int f = 0; f < NC; ++f) ww[f] = (in_thr && wlo + f < Wo) ? axis_weight(wlo + f, iw, sw, W) : 0.f;
+    const int voff = wlo * C + cvi * VEC;
+    const int Dp = (D + 1) / 2, Hp = (H + 1) / 2, nunits = Dp * Hp;
+    auto unit_weights = [&](int u, int bufw) {                             // threads 0 .. 31: (axis, row of the pair, candidate)
+        if (tid < 32 && u < nunits) {
+            const int ax = tid >> 4, j = (tid >> 3) & 1, a = tid & 7;
+            const int ip = ax ? u % Hp : u / Hp, i = 2 * ip + j, in = D + ax * (H - D), out = in * k;   // (no select tables in scratch)
+            const float sc = ax ? sh : sd;
+            const int lo = max(0, (int)floorf((float)(2 * ip - 1) / sc));
+            wts[bufw][ax][j][a] = (i < in && lo + a < out) ? axis_weight(lo + a, i, sc, in) : 0.f;
+            if (j == 0 && a == 0) los[bufw][ax] = lo;
+        }
+    };
+    unit_weights(blockIdx.x, 0);
+    __syncthreads();
+    int buf = 0;
+    for (int u = blockIdx.x; u < nunits; u += gridDim.x, buf ^= 1) {
+        unit_weights(u + gridDim.x, buf ^ 1);                              // visible after this iteration's barriers
+        const int idp = u / Hp, ihp = u % Hp;
+        const int dlo = __builtin_amdgcn_readfirstlane(los[buf][0]), hlo = __builtin_amdgcn_readfirstlane(los[buf][1]);
+        float wd[2][NC2], wh[2][NC2];
+#pragma unroll
+        for (int a = 0; a < NC2; ++a) {
+            wd[0][a] = sgpr_f(wts[buf][0][0][a]); wd[1][a] = sgpr_f(wts[buf][0][1][a]);   // workgroup-uniform: scalar registers
+            wh[0][a] = sgpr_f(wts[buf][1][0][a]); wh[1][a] = sgpr_f(wts[buf][1][1][a]);
+        }
+#pragma unroll
+        for (int uu = 0; uu < ROWV; ++uu) {
+            const int t = tid + 256 * uu;
+            if (t >= rowvec) continue;
+            f32x2_r acc[2][2][NP];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int p = 0; p < NP; ++p) acc[i][j][p] = (f32x2_r){0.f, 0.f};
+#pragma unroll
+            for (int a = 0; a < NC2; ++a) {
+                if (wd[0][a] == 0.f && wd[1][a] == 0.f) continue;          // workgroup-uniform
+#pragma unroll
+                for (int e = 0; e < NC2; ++e) {
+                    if (wh[0][e] == 0.f && wh[1][e] == 0.f) continue;
+                    float tv[VEC];                                         // (all 8 rows of a plane in flight first: 138 registers, slower)
+                    VecIO<T, VEC>::load(dys + (((long)(dlo + a)) * Ho + (hlo + e)) * Wo * C + (long)t * VEC, tv);
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) {
+                            const float wde = wd[i][a] * wh[j][e];
+                            const f32x2_r w2 = {wde, wde};
+#pragma unroll
+                            for (int p = 0; p < NP; ++p) acc[i][j][p] = __builtin_elementwise_fma(w2, (f32x2_r){tv[2 * p], tv[2 * p + 1]}, acc[i][j][p]);
+                        }
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int p = 0; p < NP; ++p) *reinterpret_cast<f32x2_r*>(vrow + (i * 2 + j) * (Wo * C) + t * VEC + 2 * p) = acc[i][j][p];
+        }
+        __syncthreads();
+        if (in_thr) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int id = 2 * idp + i, ih = 2 * ihp + j;
+                    const float* v = vrow + (i * 2 + j) * (Wo * C);
+                    f32x2_r o[NP];
+#pragma unroll
+                    for (int p = 0; p < NP; ++p) o[p] = (f32x2_r){0.f, 0.f};
+#pragma unroll
+                    for (int f = 0; f < NC; ++f)
+                        if (ww[f] != 0.f) {                                // (also keeps the reads inside the row)
+                            const f32x2_r w2 = {ww[f], ww[f]};
+#pragma unroll
+                            for (int p = 0; p < NP; ++p)
+                                o[p] = __builtin_elementwise_fma(w2, *reinterpret_cast<const f32x2_r*>(v + voff + f * C + 2 * p), o[p]);
+                        }
+                    float out[VEC];
+#pragma unroll
+                    for (int p = 0; p < NP; ++p) { out[2 * p] = o[p].x; out[2 * p + 1] = o[p].y; }
+                    if (id < D && ih < H) VecIO<T, VEC>::store(dxs + (((long)id * H + ih) * W + iw) * C + cvi * VEC, out);
+                }
+        }
+        __syncthreads();                                                   // the rows are rewritten by the next unit
+    }
+}
+
 // ---- depth-sharded variant (BASELINE.json configs[4]: one volume split along D over the ranks).
 // A rank holds input planes [id0, id0 + Dl_in) of a volume of Dg planes (its slab plus one halo plane from each neighbour)
 // and produces output planes [od0, od0 + Dl_out) of the k Dg output planes: the D axis uses GLOBAL align_corners coordinates,
@@ -842,6 +957,13 @@ extern "C" int passion_upsample_bwd(const void* dy, void* dx, int dtype, int B, 
         const bool one = (long)W * k * (C / (C % 8 == 0 ? 8 : 4)) <= 256;
         const bf16_t* g = (const bf16_t*)dy;
         bf16_t* o = (bf16_t*)dx;
+        static const bool bwd2 = []() { const char* e = getenv("PASSION_UPSAMPLE_BWD2"); return !(e && e[0] == '0'); }();
+        const size_t dyn2 = (size_t)4 * W * k * C * sizeof(float);
+        const long units2 = (long)((D + 1) / 2) * ((H + 1) / 2);
+        if (bwd2 && C % 8 == 0 && one && dyn2 <= 65536 && units2 * B >= 2048) {   // 2 x 2 blocks of input rows (large planes only:
+            const int rb2 = (int)hmin(units2, 2048);                              //  fewer, heavier workgroups)
+            hipLaunchKernelGGL((upsample_shared_bwd2_kernel<bf16_t, 8, 1>), dim3(rb2, B), dim3(256), dyn2, st, g, o, D, H, W, C, k);
+        } else
         if (C % 8 == 0) {
             if (one) hipLaunchKernelGGL((upsample_shared_bwd_kernel<bf16_t, 8, 1>), dim3(rb, B), dim3(256), dyn, st, g, o, D, H, W, C, k);
             else hipLaunchKernelGGL((upsample_shared_bwd_kernel<bf16_t, 8, 2>), dim3(rb, B), dim3(256), dyn, st, g, o, D, H, W, C, k);

@@ -481,7 +481,8 @@ def test_instnorm_stats(dtype, shape):
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("k,C,shape", [(2, 8, (4, 6, 8)), (2, 128, (2, 2, 2)), (4, 4, (4, 4, 4)), (8, 4, (2, 4, 2)),
-                                       (16, 4, (2, 2, 2)), (2, 32, (3, 4, 40)), (2, 16, (5, 3, 24))])   # last two: two / one vector per thread and row
+                                       (16, 4, (2, 2, 2)), (2, 32, (3, 4, 40)), (2, 16, (5, 3, 24)),    # two / one vector per thread and row
+                                       (2, 16, (45, 91, 6)), (2, 8, (64, 64, 5))])   # bf16: the 2 x 2-row-block adjoint (>= 2048 blocks, odd D and H)
 def test_upsample(k, C, shape, dtype):
     from passion_amd import ops
     dev = _dev()
