@@ -782,7 +782,11 @@ bool conv_march_covers(const ConvK& k, int ksize, int stride, int mode, int* K8o
         }
         if (K8 * 8 != k.Cin) return false;
     }
-    if (K8 != 1 && K8 != 2 && !(K8 == 3 && mode == 0)) return false;   // 32 input channels: the 108 weight registers cost the second wave per SIMD -- lean kernel; a 24-channel concat (three 8-channel segments: RFNet's level-1 decoder) runs as NB = 4 with an empty block: 1270 -> 819 us at 10 x 128^3
+    // 32 input channels forward (NB = 4: 108 weight registers, one wave per SIMD) beats the lean kernel from 2^19 voxels up
+    // (4 x 64^3, 32 -> 16: 97 -> 54 us; 128^3, 32 -> 8: 173 -> 103; 4 x 32^3: 21 -> 36, stays lean); tools/k84_bench.sh
+    static const bool k84 = []() { const char* e = getenv("PASSION_MARCH_K84"); return !(e && e[0] == '0'); }();
+    const bool big4 = K8 == 4 && mode == 0 && k84 && (long)k.B * k.Di * k.Hi * k.Wi >= (1L << 19);
+    if (K8 != 1 && K8 != 2 && !(K8 == 3 && mode == 0) && !big4) return false;   // a 24-channel concat (three 8-channel segments: RFNet's level-1 decoder) runs as NB = 4 with an empty block: 1270 -> 819 us at 10 x 128^3
     if (K8out) *K8out = K8;
     return true;
 }
@@ -816,6 +820,7 @@ int launch_conv_march(ConvK& k, int ksize, int stride, int mode, const void* pac
     MARCH_CASE(2)
 #undef MARCH_CASE
     if (K8 == 3 && mode == 0) { k.march_k8 = 3; const int rc = launch_march_one<4, 16, 0>(k, st); k.march_k8 = 0; return rc; }
+    if (K8 == 4 && mode == 0) return launch_march_one<4, 16, 0>(k, st);
     return 1;
 }
 

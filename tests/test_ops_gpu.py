@@ -341,6 +341,22 @@ def test_zero_padded_dgrad_on_the_marching_kernel(case):
     assert any(n.startswith("conv_march_kernel") or n.startswith("conv_pair_kernel") for n in names), names      # (8 rows: the depth-pair form)
 
 
+@pytest.mark.parametrize("case", [([16, 16], 16, 3, 1, 1, (32, 64, 128), True, True, True), ([32], 8, 3, 1, 0, (64, 64, 64), True, False, False)],
+                         ids=["cat16+16", "32to8_zero_pad"])
+def test_marching_forward_with_32_input_channels(case):
+    """from 2^19 voxels up a 32-channel K axis runs the marching forward with four 8-channel blocks (conv_march_kernel<4, 16, 0, *>:
+    the decoders' 32 -> 16 layers at 64^3, RFNet's 32-channel layers at 128^3) -- against the f64 reference like every other path"""
+    from passion_amd import ops
+    ops.prof_read()
+    ops.prof_enable(1 << 0)
+    try:
+        test_conv_block_fwd_bwd(case, torch.bfloat16)
+    finally:
+        ops.prof_enable(0)
+    names = {r[4] for r in ops.prof_read()}
+    assert any(n.startswith("conv_march_kernel<4, 16, 0") for n in names), names
+
+
 PATHS = {"lean": {}, "lean_mirror_taps": {"conv_padout": 0}, "general": {"conv_lean": 0}, "few_workgroups": {"conv_target": 8}}
 
 
