@@ -79,7 +79,9 @@ class GraphedStep:
         else:
             self.reducer.suspended = True
         try:
-            with torch.cuda.graph(g, stream=self.stream):
+            # hybrid (a process group is up): thread-local capture rules, so that what the collective backend's watchdog thread
+            # calls meanwhile (event queries on finished work) is neither refused nor able to invalidate this recording
+            with torch.cuda.graph(g, stream=self.stream, capture_error_mode="thread_local" if self.hybrid else "global"):
                 # a view: ops.target_to_cl keeps the converted copy on the tensor OBJECT it is given
                 self.loss = ptrain.train_step(self.model, self.optimizer, self.sx, self.smask, self.starget.view(self.starget.shape),
                                               phase="fb" if self.hybrid else "all", **self.kw)
