@@ -99,3 +99,52 @@ def test_two_ranks_sum_gradients_across_side_streams(tmp_path, dtype):
         err = float((g - w).abs().max())
         assert err <= tol, (k, err, tol, "vs rank 0 alone", float((g - per[0][k]).abs().max()), "vs rank 1 alone",
                             float((g - per[1][k]).abs().max()), "vs 2 x rank 0", float((g - 2 * per[0][k]).abs().max()))
+
+
+def _hybrid_worker(rank, world, port, out, graphed):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port), PASSION_DEVICE_INDEX="0", PASSION_DIST_BACKEND="gloo")
+    from _util import build_product_model
+    from passion_amd import parallel
+    from passion_amd import train as ptrain
+    from passion_amd.graph import GraphedStep
+    ctx = parallel.init()
+    dev = ctx.device
+    m = build_product_model(32, small=False).to(dev)
+    m.mask_type, m.use_passion, m.compute_dtype = "idt", False, torch.bfloat16
+    m.train()
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.0
+    opt = ptrain.make_optimizer(m, lr=1e-3)
+    red = parallel.GradReducer(m, ctx, bucket_mb=1.0)
+    x, target, _ = ptrain.synthetic_batch(1, 32, dev, seed=3 + rank)          # every rank its own sample
+    mask = torch.ones(1, 4, dtype=torch.bool, device=dev)
+    step = (GraphedStep(m, opt, 4.0, None, warm=2, reducer=red) if graphed
+            else (lambda a, b, c: ptrain.train_step(m, opt, a, b, c, 4.0, None, reducer=red)))
+    losses = [step(x, mask, target.view(target.shape)).clone() for _ in range(6)]
+    torch.cuda.synchronize()
+    if rank == 0:
+        torch.save({"p": {k: v.detach().cpu() for k, v in m.state_dict().items()}, "loss": torch.stack(losses).double().cpu(),
+                    "replays": getattr(step, "replays", -1), "hybrid": getattr(step, "hybrid", None)}, out)
+    parallel.barrier(ctx)
+    torch.distributed.destroy_process_group()
+
+
+def test_two_ranks_hybrid_graph_equals_the_eager_two_rank_step(tmp_path):
+    """what bench.py runs for N > 1 (graph.GraphedStep with a reducer: forward + backward replayed, bucketed all-reduce + AdamW after
+    every replay) against the eager two-rank train_step: six iterations, rank 0's losses and every parameter bit for bit"""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    res = []
+    for graphed in (False, True):
+        out = str(tmp_path / f"h{int(graphed)}.pt")
+        mp.spawn(_hybrid_worker, args=(2, _free_port(), out, graphed), nprocs=2, join=True)
+        res.append(torch.load(out))
+    eager, graph = res
+    assert graph["hybrid"] is True and graph["replays"] >= 4
+    assert torch.equal(eager["loss"], graph["loss"]), (eager["loss"], graph["loss"])
+    bad = [k for k in eager["p"] if not torch.equal(eager["p"][k], graph["p"][k])]
+    assert not bad, bad[:5]
