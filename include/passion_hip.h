@@ -195,6 +195,15 @@ int passion_wce_dice_fwd(const float* probs, int64_t psb, int64_t psv, int64_t p
 int passion_wce_dice_bwd(const float* probs, int64_t psb, int64_t psv, int64_t psc,
                          const float* target, const float* sums, const float* g, float* dprobs,
                          int B, int Bt, int64_t V, int C, void* stream);
+/* The same two losses straight from LOGITS (f32 channels-last [B][V][C], contiguous): softmax(logits * inv_temp) is formed inside the
+ * pass and never stored -- nn.Softmax(dim=1) at the end of Decoder_sep (code/models/mmformer.py:112-113) followed by
+ * softmax_weighted_loss_bs + dice_loss_bs on its output (:546-549), whose 4 B probability volumes have no other reader in training.
+ * sums / out / Bt as passion_wce_dice_fwd; the backward writes d(loss)/d(logits) (through the softmax Jacobian), g: [B][2].  Results
+ * are bit for bit those of passion_softmax_fwd -> passion_wce_dice_fwd and passion_wce_dice_bwd -> passion_softmax_bwd. */
+int passion_softmax_wce_dice_fwd(const float* logits, const float* target, int B, int Bt, int64_t V, int C, float inv_temp,
+                                 float* sums, float* out, void* stream);
+int passion_softmax_wce_dice_bwd(const float* logits, const float* target, const float* sums, const float* g, float* dlogits,
+                                 int B, int Bt, int64_t V, int C, float inv_temp, void* stream);
 /* temp_kl_loss_bs (criterions.py:92-103) on already softmaxed(/T) [and upsampled] probabilities.
  * out[b] = T^2 * mean_{c,v} pt*(log pt - log ps) with both clamped to [0.005,1].
  * work: f32 scratch of passion_kl_work_floats(B) floats (fixed-order reduction slots).

@@ -81,6 +81,8 @@ SIGNATURES = {
                                      c_int64, c_int, c_void_p, c_void_p, c_void_p]),
     "passion_wce_dice_bwd": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p,
                                      c_void_p, c_void_p, c_int, c_int, c_int64, c_int, c_void_p]),
+    "passion_softmax_wce_dice_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int64, c_int, c_float, c_void_p, c_void_p, c_void_p]),
+    "passion_softmax_wce_dice_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64, c_int, c_float, c_void_p]),
     "passion_wce_dice_up_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "passion_wce_dice_up_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p,
                                         c_void_p]),

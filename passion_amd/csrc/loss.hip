@@ -199,10 +199,30 @@ constexpr int RED_BLOCKS_MAX = 1024;
 
 // ---------------------------------------------------------------- weighted CE + Dice
 // sums[b][0..3]=num_c, [4..7]=l_c (sum p), [8..11]=r_c (sum t), [12..15]=sum t_c*log(clamp p_c)
+// the class probabilities of one voxel from its logits: the arithmetic of softmax_fwd_kernel, operation for operation (a fused pass
+// sees bit for bit the probabilities the two-pass form stores)
+__device__ __forceinline__ void softmax4(const f32x4 t, float inv_temp, float (&p)[NC]) {
+    float z[NC], m = -INFINITY;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) z[c] = t[c] * inv_temp;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) m = fmaxf(m, z[c]);
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) { z[c] = expf(z[c] - m); s += z[c]; }
+    const float inv = 1.f / s;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) p[c] = z[c] * inv;
+}
+
+// LG: `pr` holds channels-last LOGITS (psc == 1) and the probabilities are formed here (softmax4, inv_temp) instead of being read:
+// decoder_sep's 4 B predictions never exist in memory (passion_softmax_wce_dice_fwd)
+template <bool LG = false>
 __global__ __launch_bounds__(256) void wce_dice_sums_kernel(const float* __restrict__ pr, long psb, long psv, long psc,
                                                             const float* __restrict__ tg, long V,
                                                             float* __restrict__ sums, float* __restrict__ part,
-                                                            unsigned* __restrict__ counter, float* __restrict__ out, int Bt, UpG ug) {
+                                                            unsigned* __restrict__ counter, float* __restrict__ out, int Bt, UpG ug,
+                                                            float inv_temp = 1.f) {
     __shared__ float red[4][16];
     const int b = blockIdx.y, bt = b % Bt;              // target of sample b (several predictions per target: Bt < B)
     float a[16];
@@ -210,6 +230,9 @@ __global__ __launch_bounds__(256) void wce_dice_sums_kernel(const float* __restr
     for (int j = 0; j < 16; ++j) a[j] = 0.f;
     for (long v = (long)blockIdx.x * blockDim.x + threadIdx.x; v < V; v += (long)gridDim.x * blockDim.x) {
         float p[NC];
+        if (LG) {
+            softmax4(load4(pr + b * psb + v * psv), inv_temp, p);
+        } else
         if (ug.k > 1) {                                     // pr: the coarse map [B][D][H][W][4]; V: fine voxels
             int od, oh, ow;
             u_split(ug, v, od, oh, ow);
@@ -285,6 +308,43 @@ __global__ void wce_dice_bwd_kernel(const float* __restrict__ pr, long psb, long
             if (p >= 0.005f && p <= 1.0f) d += kce[c] * t[c] / p;
             dp[b * psb + v * psv + c * psc] = d;
         }
+    }
+}
+
+// d(loss)/d(logits) in one pass: the probabilities from the logits again (softmax4), the gradient wrt them as wce_dice_bwd_kernel forms
+// it, through the softmax Jacobian as softmax_bwd_kernel applies it -- the same operations in the same order, without the two f32
+// tensors (probabilities, their gradient) in between
+__global__ __launch_bounds__(256) void softmax_wce_dice_bwd_kernel(const float* __restrict__ lg, const float* __restrict__ tg,
+                                                                   const float* __restrict__ sums, const float* __restrict__ g,
+                                                                   float* __restrict__ dl, long V, int Bt, float inv_temp) {
+    const int b = blockIdx.y, bt = b % Bt;
+    const float* s = sums + b * 16;
+    const float rt = s[8] + s[9] + s[10] + s[11];
+    const float g_ce = g[b * 2 + 0], g_dice = g[b * 2 + 1];
+    float kce[NC], kd1[NC], kd2[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const float w = 1.0f - s[8 + c] / rt;
+        const float den = s[4 + c] + s[8 + c] + 1e-7f;
+        kce[c] = -g_ce * w / (float)V;
+        kd1[c] = -g_dice * 2.0f / ((float)NC * den);
+        kd2[c] = g_dice * 2.0f * s[c] / ((float)NC * den * den);
+    }
+    for (long v = (long)blockIdx.x * blockDim.x + threadIdx.x; v < V; v += (long)gridDim.x * blockDim.x) {
+        const f32x4 t = load4(tg + ((long)bt * V + v) * 4);
+        float p[NC], d[NC], dot = 0.f;
+        softmax4(load4(lg + ((long)b * V + v) * 4), inv_temp, p);
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            float dc = kd1[c] * t[c] + kd2[c];
+            if (p[c] >= 0.005f && p[c] <= 1.0f) dc += kce[c] * t[c] / p[c];
+            d[c] = dc;
+            dot += p[c] * dc;
+        }
+        f32x4 o;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) o[c] = p[c] * (d[c] - dot) * inv_temp;
+        store4(dl + ((long)b * V + v) * 4, o);
     }
 }
 
@@ -406,6 +466,81 @@ __global__ __launch_bounds__(256) void up_loss_bwdw_kernel(const float* __restri
             acc += ww * d;
         }
         store4(tmp + ((long)b * items + it) * 4, acc);
+    }
+}
+
+// The same pass with one thread per FINE voxel: a workgroup takes whole rows (od, oh), every thread forms the loss gradient of one
+// fine voxel (eight coarse loads, one label load) into LDS, then the row's W coarse columns gather their fine columns from LDS -- in
+// up_loss_bwdw_kernel's order and with its weights, so the result is bit for bit the same.  That kernel walks a thread's 2k + 1 fine
+// columns one after the other (k = 16: 131 072 threads with 33 dependent iterations each, 100 us for 33 MB of labels).
+template <int MODE>
+__global__ __launch_bounds__(256) void up_loss_bwdw_rows_kernel(const float* __restrict__ pc, const float* __restrict__ pt,
+                                                                const float* __restrict__ tg, const float* __restrict__ sums,
+                                                                const float* __restrict__ g, float* __restrict__ tmp, UpG ug, int Bt,
+                                                                float kk, int rpb) {
+    extern __shared__ __attribute__((aligned(16))) float drow[];          // [rpb][Wo][4]
+    const int b = blockIdx.y, bt = b % Bt;
+    const long V = (long)ug.Do * ug.Ho * ug.Wo, vc = (long)ug.D * ug.H * ug.W * 4;
+    float kce[NC], kd1[NC], kd2[NC], gk = 0.f;
+    if (MODE == 0) {
+        const float* s = sums + b * 16;
+        const float rt = s[8] + s[9] + s[10] + s[11];
+        const float g_ce = g[b * 2 + 0], g_dice = g[b * 2 + 1];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const float w = 1.0f - s[8 + c] / rt;
+            const float den = s[4 + c] + s[8 + c] + 1e-7f;
+            kce[c] = -g_ce * w / (float)V;
+            kd1[c] = -g_dice * 2.0f / ((float)NC * den);
+            kd2[c] = g_dice * 2.0f * s[c] / ((float)NC * den * den);
+        }
+    } else {
+        gk = g[b] * kk;
+    }
+    const float* xb = pc + b * vc;
+    const float* tb = pt + bt * vc;
+    const int nrows = ug.Do * ug.Ho, tid = threadIdx.x;
+    for (int r0 = blockIdx.x * rpb; r0 < nrows; r0 += gridDim.x * rpb) {
+        const int nr = nrows - r0 < rpb ? nrows - r0 : rpb;
+        __syncthreads();                                               // the previous rows' readers are done
+        for (int i = tid; i < nr * ug.Wo; i += 256) {
+            const int rr = i / ug.Wo, ow = i - rr * ug.Wo, r = r0 + rr;
+            const int od = (int)(((float)r + 0.5f) * ug.inv_ho), oh = r - od * ug.Ho;
+            const USrc a = u_src(od, ug.sd, ug.D), e = u_src(oh, ug.sh, ug.H), f = u_src(ow, ug.sw, ug.W);
+            const f32x4 p = u_sample(xb, ug, a, e, f);
+            const long v = (long)r * ug.Wo + ow;
+            f32x4 d;
+            if (MODE == 0) {
+                const f32x4 t = load4(tg + ((long)bt * V + v) * 4);
+#pragma unroll
+                for (int c = 0; c < NC; ++c) {
+                    float dc = kd1[c] * t[c] + kd2[c];
+                    if (p[c] >= 0.005f && p[c] <= 1.0f) dc += kce[c] * t[c] / p[c];
+                    d[c] = dc;
+                }
+            } else {
+                const f32x4 t = u_sample(tb, ug, a, e, f);
+#pragma unroll
+                for (int c = 0; c < NC; ++c) {
+                    const float tc = fminf(fmaxf(t[c], 0.005f), 1.0f);
+                    d[c] = (p[c] >= 0.005f && p[c] <= 1.0f) ? -gk * tc / p[c] : 0.f;
+                }
+            }
+            *reinterpret_cast<f32x4*>(drow + (long)i * 4) = d;
+        }
+        __syncthreads();
+        for (int i = tid; i < nr * ug.W; i += 256) {
+            const int rr = i / ug.W, iw = i - rr * ug.W;
+            int lo, hi;
+            u_range(iw, ug.sw, ug.Wo, lo, hi);
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            for (int ow = lo; ow <= hi; ++ow) {
+                const float ww = u_weight(ow, iw, ug.sw, ug.W);
+                if (ww == 0.f) continue;
+                acc += ww * *reinterpret_cast<const f32x4*>(drow + ((long)rr * ug.Wo + ow) * 4);
+            }
+            store4(tmp + ((long)b * nrows * ug.W + (long)(r0 + rr) * ug.W + iw) * 4, acc);
+        }
     }
 }
 
@@ -793,7 +928,7 @@ extern "C" int passion_wce_dice_fwd(const float* probs, int64_t psb, int64_t psv
     unsigned* counter = nullptr;
     float* part = sums + 16 * (size_t)B + ((B + 3) & ~3);
     { const int rc_ = tickets(st, B, &counter); if (rc_) return rc_; }
-    hipLaunchKernelGGL(wce_dice_sums_kernel, dim3(vgrid_red(V), B), dim3(256), 0, st, probs, (long)psb, (long)psv,
+    hipLaunchKernelGGL(wce_dice_sums_kernel<false>, dim3(vgrid_red(V), B), dim3(256), 0, st, probs, (long)psb, (long)psv,
                        (long)psc, target, (long)V, sums, part, counter, out, Bt, UpG{1, 1, 1, 1, 1, 1, 1, 0.f, 0.f, 0.f, 1.f, 1.f});
     LAUNCH_RET();
     return 0;
@@ -822,7 +957,7 @@ extern "C" int passion_wce_dice_up_fwd(const float* probs_coarse, const float* t
     float* part = sums + 16 * (size_t)B + ((B + 3) & ~3);
     { const int rc_ = tickets(st, B, &counter); if (rc_) return rc_; }
     const long V = (long)ug.Do * ug.Ho * ug.Wo;
-    hipLaunchKernelGGL(wce_dice_sums_kernel, dim3(vgrid_red(V), B), dim3(256), 0, st, probs_coarse, 0L, 0L, 1L, target, V, sums, part, counter,
+    hipLaunchKernelGGL(wce_dice_sums_kernel<false>, dim3(vgrid_red(V), B), dim3(256), 0, st, probs_coarse, 0L, 0L, 1L, target, V, sums, part, counter,
                        out, Bt, ug);
     LAUNCH_RET();
     return 0;
@@ -840,6 +975,13 @@ static int up_loss_bwd(const float* pc, const float* pt, const float* tg, const 
     float* t2 = scratch + (long)B * ug.Do * ug.Ho * ug.W * 4;
     const long items = (long)ug.Do * ug.Ho * ug.W;
     if (items >= (1L << 23)) return -1021;
+    static const bool rows = []() { const char* e = getenv("PASSION_UPLOSS_ROWS"); return !(e && e[0] == '0'); }();
+    if (rows && ug.Wo <= 1024) {                      // one thread per fine voxel, whole rows per workgroup (16 KB of LDS at most)
+        const int rpb = ug.Wo >= 256 ? 1 : 256 / ug.Wo;
+        const long nrows = (long)ug.Do * ug.Ho;
+        hipLaunchKernelGGL(up_loss_bwdw_rows_kernel<MODE>, dim3((unsigned)hmin((nrows + rpb - 1) / rpb, 8192), B), dim3(256),
+                           (size_t)rpb * ug.Wo * 4 * sizeof(float), st, pc, pt, tg, sums, g, t1, ug, Bt, kk, rpb);
+    } else
     hipLaunchKernelGGL(up_loss_bwdw_kernel<MODE>, dim3((unsigned)hmin((items + 255) / 256, 4096), B), dim3(256), 0, st, pc, pt, tg, sums, g, t1, ug,
                        Bt, kk);
     LAUNCH_RET();
@@ -894,6 +1036,32 @@ extern "C" int passion_wce_dice_bwd(const float* probs, int64_t psb, int64_t psv
     if (B % Bt) return -1017;
     hipLaunchKernelGGL(wce_dice_bwd_kernel, dim3(vgrid(V), B), dim3(256), 0, (hipStream_t)stream, probs, (long)psb,
                        (long)psv, (long)psc, target, sums, g, dprobs, (long)V, Bt);
+    LAUNCH_RET();
+    return 0;
+}
+
+extern "C" int passion_softmax_wce_dice_fwd(const float* logits, const float* target, int B, int Bt, int64_t V, int C, float inv_temp,
+                                            float* sums, float* out, void* stream) {
+    if (C != NC) return -1012;
+    if (Bt <= 0) Bt = B;
+    if (B % Bt) return -1017;
+    hipStream_t st = (hipStream_t)stream;
+    unsigned* counter = nullptr;
+    float* part = sums + 16 * (size_t)B + ((B + 3) & ~3);
+    { const int rc_ = tickets(st, B, &counter); if (rc_) return rc_; }
+    hipLaunchKernelGGL(wce_dice_sums_kernel<true>, dim3(vgrid_red(V), B), dim3(256), 0, st, logits, (long)V * NC, (long)NC, 1L, target, (long)V,
+                       sums, part, counter, out, Bt, UpG{1, 1, 1, 1, 1, 1, 1, 0.f, 0.f, 0.f, 1.f, 1.f}, inv_temp);
+    LAUNCH_RET();
+    return 0;
+}
+
+extern "C" int passion_softmax_wce_dice_bwd(const float* logits, const float* target, const float* sums, const float* g, float* dlogits,
+                                            int B, int Bt, int64_t V, int C, float inv_temp, void* stream) {
+    if (C != NC) return -1012;
+    if (Bt <= 0) Bt = B;
+    if (B % Bt) return -1017;
+    hipLaunchKernelGGL(softmax_wce_dice_bwd_kernel, dim3(vgrid(V), B), dim3(256), 0, (hipStream_t)stream, logits, target, sums, g, dlogits,
+                       (long)V, Bt, inv_temp);
     LAUNCH_RET();
     return 0;
 }

@@ -111,7 +111,7 @@ class Decoder_sep(nn.Module):
         self.seg_layer = nn.Conv3d(in_channels=c, out_channels=num_cls, kernel_size=1, stride=1, padding=0, bias=True)
         self.softmax = nn.Softmax(dim=1)
 
-    def forward(self, x1, x2, x3, x4, x5):
+    def forward(self, x1, x2, x3, x4, x5, probs=True):
         skips = (x1, x2, x3, x4)
         h = self.d4_c1(_up2_mat(x5))
         for lvl in (4, 3, 2, 1):
@@ -119,7 +119,7 @@ class Decoder_sep(nn.Module):
             if lvl > 1:
                 h = getattr(self, f"d{lvl - 1}_c1")(_up2_mat(h))
         logits = run_conv_auto(self.seg_layer, h, out_dtype=torch.float32).t
-        return ops.softmax_classes(logits, 1.0, "cl")
+        return ops.softmax_classes(logits, 1.0, "cl") if probs else logits      # (logits: ops.sep_wce_dice forms the softmax itself)
 
 
 class Decoder_fusion(nn.Module):
@@ -422,7 +422,7 @@ class Model(nn.Module):
             stacked = [Feat(stk[l].t, sep_mask, 0) for l in range(5)]
         else:
             stacked = [Feat(torch.cat([encs[i][l].t for i in range(4)], 0), sep_mask, 0) for l in range(5)]
-        sep_all = self.decoder_sep(*stacked)
+        sep_all = self.decoder_sep(*stacked, probs=not ops.SEP_LOSS_FUSED)
         eye = torch.eye(4, device=dev)
         maskf = mask.float()
         gates = [(maskf * eye[i]) if idt else eye[i].expand(B, 4) for i in range(4)]
@@ -432,7 +432,7 @@ class Model(nn.Module):
         for j, pp in enumerate(preds):                                                # weights 1/2 .. 1/32 (:649-653)
             pair = crit.seg_losses_cl(ops.softmax_classes(pp, 1.0, "cl"), tcl, ups[j])
             prm_loss = prm_loss + 0.5 ** (j + 1) * pair.sum(1, keepdim=True)
-        sep_pair = ops.wce_dice(sep_all, tcl, "cl").sum(1, keepdim=True).view(4, B, 1)
+        sep_pair = ops.sep_wce_dice(sep_all, tcl).sum(1, keepdim=True).view(4, B, 1)
         sep_loss = torch.zeros(B, 4, device=dev)
         for i in range(4):
             sep_loss = sep_loss + gates[i] * sep_pair[i]

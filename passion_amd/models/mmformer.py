@@ -224,7 +224,7 @@ class Decoder_sep(nn.Module):
         self.seg_layer = nn.Conv3d(in_channels=c, out_channels=num_cls, kernel_size=1, stride=1, padding=0, bias=True)
         self.softmax = nn.Softmax(dim=1)
 
-    def forward(self, x1, x2, x3, x4, x5):
+    def forward(self, x1, x2, x3, x4, x5, probs=True):
         skips = (x1, x2, x3, x4)
         h = self.d4_c1(_up2(x5))
         for lvl in (4, 3, 2, 1):
@@ -232,7 +232,7 @@ class Decoder_sep(nn.Module):
             if lvl > 1:
                 h = getattr(self, f"d{lvl - 1}_c1")(_up2(h))
         logits = run_conv(self.seg_layer, h, norm=False, out_dtype=torch.float32).t
-        return ops.softmax_classes(logits, 1.0, "cl")
+        return ops.softmax_classes(logits, 1.0, "cl") if probs else logits      # (logits: the loss forms the softmax itself, ops.sep_wce_dice)
 
 
 class Decoder_fuse(nn.Module):
@@ -625,10 +625,10 @@ class Model(nn.Module):
                         if f._stats[0] is not None:
                             f._stats[0].record_stream(streams[0])
                 with torch.cuda.stream(streams[0]):
-                    sep_all = self.decoder_sep(*stacked)
+                    sep_all = self.decoder_sep(*stacked, probs=not ops.SEP_LOSS_FUSED)
                     sep_all.record_stream(main)
             else:
-                sep_all = self.decoder_sep(*stacked)
+                sep_all = self.decoder_sep(*stacked, probs=not ops.SEP_LOSS_FUSED)
 
         # The fusion blocks of levels 4..1 read encoder features only: on a side stream they run under the transformers' chain of
         # tiny launches (forward) and under the decoder's own backward chain (autograd replays them on that stream)
@@ -675,7 +675,7 @@ class Model(nn.Module):
 
         def sep_losses():
             # the four per-modality predictions (4B samples, modality-major) against the B label volumes in one launch
-            return gate * ops.wce_dice(sep_all, tcl, "cl").sum(1).view(4, B).t()
+            return gate * ops.sep_wce_dice(sep_all, tcl).sum(1).view(4, B).t()
 
         if streams and LOSS_STREAMS:
             # Both are side branches of the graph: on side streams their backward (softmax / upsample / loss gradients) runs under

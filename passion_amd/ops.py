@@ -863,6 +863,54 @@ def wce_dice(probs, target_cl, layout="cl"):
     return WceDiceFn.apply(probs, target_cl, layout)
 
 
+class SoftmaxWceDiceFn(torch.autograd.Function):
+    """wce_dice(softmax_classes(logits, inv_temp), target) without the probabilities in memory: decoder_sep's predictions (reference
+    mmformer.py:112-113 nn.Softmax, :546-549 the two losses) have no other reader in training.  Bit for bit the two-op form."""
+
+    @staticmethod
+    def forward(ctx, logits, target_cl, inv_temp):
+        L.require_gpu(logits, target_cl)
+        logits = logits.contiguous()
+        assert logits.dtype == torch.float32 and target_cl.dtype == torch.float32
+        B, C = logits.shape[0], logits.shape[-1]
+        V = logits.numel() // (B * C)
+        lib = L.load()
+        scratch = torch.empty(lib.passion_wce_dice_sums_floats(B), dtype=torch.float32, device=logits.device)
+        sums = scratch[:B * 16].view(B, 16)
+        out = torch.empty(B, 2, dtype=torch.float32, device=logits.device)
+        L.check(lib.passion_softmax_wce_dice_fwd(_p(logits), _p(target_cl), B, target_cl.shape[0], V, C, float(inv_temp), _p(scratch), _p(out),
+                                                 L.stream_ptr()), "passion_softmax_wce_dice_fwd")
+        ctx.inv_temp = float(inv_temp)
+        ctx.save_for_backward(logits, target_cl, sums)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        logits, target_cl, sums = ctx.saved_tensors
+        B, C = logits.shape[0], logits.shape[-1]
+        V = logits.numel() // (B * C)
+        g = g.contiguous().float()
+        dl = torch.empty_like(logits)
+        L.check(L.load().passion_softmax_wce_dice_bwd(_p(logits), _p(target_cl), _p(sums), _p(g), _p(dl), B, target_cl.shape[0], V, C,
+                                                      ctx.inv_temp, L.stream_ptr()), "passion_softmax_wce_dice_bwd")
+        return dl, None, None
+
+
+def softmax_wce_dice(logits, target_cl, inv_temp=1.0):
+    """logits f32 channels-last (B, D, H, W, 4) -> (B, 2) = (weighted CE, Dice) of softmax(logits * inv_temp) against target_cl"""
+    return SoftmaxWceDiceFn.apply(logits, target_cl, inv_temp)
+
+
+# decoder_sep's loss from its logits (one pass forward, one backward) instead of softmax -> probabilities -> losses; =0: the two-op form
+SEP_LOSS_FUSED = __import__("os").environ.get("PASSION_SEP_LOSS_FUSED", "1") != "0"
+
+
+def sep_wce_dice(sep_out, target_cl):
+    """(B', 2) losses of decoder_sep's output against the label volumes; sep_out = its logits when SEP_LOSS_FUSED (the decoders are
+    called with probs=not SEP_LOSS_FUSED), else its probabilities"""
+    return softmax_wce_dice(sep_out, target_cl, 1.0) if SEP_LOSS_FUSED else wce_dice(sep_out, target_cl, "cl")
+
+
 class KLFn(torch.autograd.Function):
     """temp_kl_loss_bs (reference criterions.py:92-103) on probabilities that were already
     softmaxed with 1/T (and upsampled).  Teacher side carries no gradient (it is detached upstream)."""

@@ -117,3 +117,42 @@ def test_public_criterions_against_the_reference_values():
         assert rel(PC.softmax_weighted_loss_bs(torch.softmax(lo, 1), t, 4, up), g[f"wce_up{k}"]) < 1e-5
         assert rel(PC.dice_loss_bs(torch.softmax(lo, 1), t, 4, up_op=up), g[f"dice_up{k}"]) < 1e-5
         assert rel(PC.temp_kl_loss_bs(lo, lo_t, t, 4, 4.0, up), g[f"kl_up{k}"]) < 1e-5
+
+
+_ROWS_SCRIPT = r'''
+import sys, torch
+sys.path.insert(0, sys.argv[1])
+from passion_amd import ops
+dev = torch.device("cuda:0")
+out = {}
+for k, dims, B, Bt in [(2, (8, 12, 10), 2, 2), (4, (8, 8, 8), 4, 1), (16, (8, 8, 8), 1, 1), (8, (4, 6, 5), 5, 1), (2, (3, 4, 130), 1, 1)]:
+    g = torch.Generator().manual_seed(k * 100 + B)
+    ps = torch.softmax(torch.randn(B, *dims, 4, generator=g) * 2, -1).to(dev).requires_grad_(True)
+    pt = torch.softmax(torch.randn(Bt, *dims, 4, generator=g) * 2, -1).to(dev)
+    fine = tuple(d * k for d in dims)
+    tcl = torch.nn.functional.one_hot(torch.randint(0, 4, (Bt, *fine), generator=g), 4).float().to(dev).contiguous()
+    w = torch.randn(B, 2, generator=g).to(dev)
+    (ops.wce_dice_up(ps, tcl, k) * w).sum().backward()
+    out[f"wce{k}_{B}"] = ps.grad.clone().cpu()
+    ps.grad = None
+    (ops.kl_probs_up(ps, pt, 4.0, k) * w[:, 0]).sum().backward()
+    out[f"kl{k}_{B}"] = ps.grad.clone().cpu()
+torch.save(out, sys.argv[2])
+'''
+
+
+def test_row_parallel_loss_gradient_equals_the_column_walk(tmp_path):
+    """up_loss_bwdw_rows_kernel (one thread per fine voxel, whole rows through LDS; the default) against up_loss_bwdw_kernel (a thread walks
+    its fine columns; PASSION_UPLOSS_ROWS=0): the coarse-map gradients of both fused losses bit for bit, incl. rows wider than a workgroup"""
+    _dev()
+    import subprocess
+    res = []
+    for v in ("0", "1"):
+        out = str(tmp_path / f"rows{v}.pt")
+        env = dict(os.environ, PASSION_UPLOSS_ROWS=v)
+        subprocess.run([sys.executable, "-c", _ROWS_SCRIPT, ROOT, out], check=True, env=env, timeout=600)
+        res.append(torch.load(out))
+    assert set(res[0]) == set(res[1]) and len(res[0]) == 10
+    for k_ in res[0]:
+        assert torch.equal(res[0][k_], res[1][k_]), (k_, float((res[0][k_] - res[1][k_]).abs().max()))
+        assert float(res[0][k_].abs().max()) > 0

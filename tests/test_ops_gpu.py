@@ -516,6 +516,28 @@ def test_upsample(k, C, shape, dtype):
     assert relerr(nc(xd.grad.float()), xr.grad) < tol * 2
 
 
+@pytest.mark.parametrize("B,Bt,dims,inv_temp", [(4, 1, (16, 16, 16), 1.0), (2, 2, (8, 12, 10), 1.0), (8, 2, (6, 6, 6), 0.25), (4, 1, (64, 64, 32), 1.0)])
+def test_losses_straight_from_the_logits_equal_the_two_op_form(B, Bt, dims, inv_temp):
+    """ops.softmax_wce_dice (decoder_sep's loss: the probabilities are never stored) against ops.softmax_classes -> ops.wce_dice:
+    losses and the gradient wrt the logits bit for bit, with several predictions per label volume (Bt < B) and a temperature"""
+    from passion_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(B * 31 + Bt)
+    logits = (torch.randn(B, *dims, 4, generator=g) * 3.0).to(dev)
+    lab = torch.randint(0, 4, (Bt, *dims), generator=g)
+    tcl = F.one_hot(lab, 4).float().to(dev).contiguous()
+    gout = torch.randn(B, 2, generator=g).to(dev)
+    la = logits.clone().requires_grad_(True)
+    oa = ops.wce_dice(ops.softmax_classes(la, inv_temp, "cl"), tcl, "cl")
+    oa.backward(gout)
+    lb = logits.clone().requires_grad_(True)
+    ob = ops.softmax_wce_dice(lb, tcl, inv_temp)
+    ob.backward(gout)
+    assert torch.equal(oa, ob), (oa, ob)
+    assert torch.equal(la.grad, lb.grad), float((la.grad - lb.grad).abs().max())
+    assert float(lb.grad.abs().max()) > 0
+
+
 def _ref_wce(p, t):
     B = p.shape[0]
     out = 0
