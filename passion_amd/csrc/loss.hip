@@ -713,6 +713,18 @@ __global__ __launch_bounds__(256) void proto_bwd1_kernel(const T* __restrict__ f
     for (int c = 0; c < NC; ++c)
 #pragma unroll
         for (int h = 0; h < CF; ++h) gp[c][h] = 0.f;
+    // per-class constants of this sample: every quotient by a prototype norm is a product from here on (the loop below had 82 f32
+    // divisions per voxel, ~12 instructions each: 534 us for 340 MB at 4 x 128^3; three are left, those by the voxel's own norm: 373 us.
+    // Tried on top and slower: prototypes in LDS + two voxels per iteration (439 us; the compiler fills whatever register budget the
+    // occupancy target leaves and spills inside the loop when told to fit three waves))
+    float inp[NC], inpt[NC], cpk[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const float Np = fmaxf(P.nps[c], eps);
+        inp[c] = 1.f / Np;
+        inpt[c] = 1.f / fmaxf(P.npt[c], eps);
+        cpk[c] = (P.nps[c] > eps) ? 1.f / (P.nps[c] * Np) : 0.f;
+    }
     for (long v = (long)blockIdx.x * blockDim.x + threadIdx.x; v < V; v += (long)gridDim.x * blockDim.x) {
         float a[CF], e[CF], da_[CF];
         load8(fs + ((long)b * V + v) * cf, a, cf);
@@ -722,22 +734,37 @@ __global__ __launch_bounds__(256) void proto_bwd1_kernel(const T* __restrict__ f
         for (int h = 0; h < CF; ++h) { na += a[h] * a[h]; ne += e[h] * e[h]; da_[h] = 0.f; }
         const float nra = sqrtf(na), nre = sqrtf(ne);
         const float Na = fmaxf(nra, eps), ia = 1.f / Na, ie = 1.f / fmaxf(nre, eps);
+        const float cak = (nra > eps) ? 1.f / (nra * Na) : 0.f;
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
             if (P.valid[c] == 0.f) continue;
             float da = 0.f, de = 0.f;
 #pragma unroll
             for (int h = 0; h < CF; ++h) { da += a[h] * P.ps[c][h]; de += e[h] * P.pt[c][h]; }
-            const float Np = fmaxf(P.nps[c], eps);
-            const float sim_s = da * ia / Np, sim_t = de * ie / fmaxf(P.npt[c], eps);
-            const float gs = kk * (sim_s - sim_t);  // dL/dsim_s
             // d sim / d fs = p/(Na Np) - [|fs|>eps] sim fs/(|fs| Na) ;  d sim / d p = fs/(Na Np) - [|p|>eps] sim p/(|p| Np)
-            const float ca = (nra > eps) ? sim_s / (nra * Na) : 0.f;
-            const float cp = (P.nps[c] > eps) ? sim_s / (P.nps[c] * Np) : 0.f;
+            if (sizeof(T) == 4) {
+                // f32 parity mode: the quotients as the forward forms them (its 20-step PASSION trajectory against the imported reference
+                // sits at 9.5e-4 of a 1e-3 bound, and one ulp here moves a later step by 3e-4)
+                const float Np = fmaxf(P.nps[c], eps);
+                const float sim_s = da * ia / Np, sim_t = de * ie / fmaxf(P.npt[c], eps);
+                const float gs = kk * (sim_s - sim_t);  // dL/dsim_s
+                const float ca = (nra > eps) ? sim_s / (nra * Na) : 0.f;
+                const float cp = (P.nps[c] > eps) ? sim_s / (P.nps[c] * Np) : 0.f;
+#pragma unroll
+                for (int h = 0; h < CF; ++h) {
+                    da_[h] += gs * (P.ps[c][h] * ia / Np - ca * a[h]);
+                    gp[c][h] += gs * (a[h] * ia / Np - cp * P.ps[c][h]);
+                }
+                continue;
+            }
+            const float iaNp = ia * inp[c];
+            const float sim_s = da * iaNp, sim_t = de * ie * inpt[c];
+            const float gs = kk * (sim_s - sim_t);  // dL/dsim_s
+            const float w1 = gs * iaNp, wa = gs * (sim_s * cak), wp = gs * (sim_s * cpk[c]);
 #pragma unroll
             for (int h = 0; h < CF; ++h) {
-                da_[h] += gs * (P.ps[c][h] * ia / Np - ca * a[h]);
-                gp[c][h] += gs * (a[h] * ia / Np - cp * P.ps[c][h]);
+                da_[h] += w1 * P.ps[c][h] - wa * a[h];
+                gp[c][h] += w1 * a[h] - wp * P.ps[c][h];
             }
         }
         store8(dfs + ((long)b * V + v) * cf, da_, cf);
