@@ -660,6 +660,9 @@ __global__ __launch_bounds__(256) void proto_loss_kernel(const T* __restrict__ f
     Protos P;
     load_protos(work, b, B, P);
     float al = 0.f, ad = 0.f;
+    float inp[NC], inpt[NC];                   // bf16 storage: the quotients by the prototype norms as products (as proto_bwd1_kernel)
+#pragma unroll
+    for (int c = 0; c < NC; ++c) { inp[c] = 1.f / fmaxf(P.nps[c], eps); inpt[c] = 1.f / fmaxf(P.npt[c], eps); }
     for (long v = (long)blockIdx.x * blockDim.x + threadIdx.x; v < V; v += (long)gridDim.x * blockDim.x) {
         float a[CF], e[CF];
         load8(fs + ((long)b * V + v) * cf, a, cf);
@@ -674,7 +677,8 @@ __global__ __launch_bounds__(256) void proto_loss_kernel(const T* __restrict__ f
             float da = 0.f, de = 0.f;
 #pragma unroll
             for (int h = 0; h < CF; ++h) { da += a[h] * P.ps[c][h]; de += e[h] * P.pt[c][h]; }
-            const float sim_s = da * ia / fmaxf(P.nps[c], eps), sim_t = de * ie / fmaxf(P.npt[c], eps);
+            const float sim_s = sizeof(T) == 4 ? da * ia / fmaxf(P.nps[c], eps) : da * (ia * inp[c]);
+            const float sim_t = sizeof(T) == 4 ? de * ie / fmaxf(P.npt[c], eps) : de * ie * inpt[c];
             const float d = sim_s - sim_t;
             al += d * d;
             ad += sqrtf(d * d);
@@ -881,6 +885,14 @@ inline int vgrid(long V) { return (int)hmin((V + 255) / 256, 2048); }
 // cannot hide its load latency (kl_fwd 46 us, proto_bwd1 231 us per launch at 128^3): 512 blocks measured +5 % on the whole
 // PASSION step, 1024 the same (PASSION_RED_BLOCKS to override)
 inline int vgrid_red(long V) { return (int)hmin((V + 256 * 4 - 1) / (256 * 4), hmin((long)g_red_blocks, (long)RED_BLOCKS_MAX)); }
+// the prototype kernels pay per THREAD for their 2 x 32 prototype components (64 quotients each) and per BLOCK for 32 / 68 column
+// sums (wave reductions, a slot, the last block's fold over all slots): at 4 x 128^3 proto_sums 177 / 113 / 84 us and proto_bwd1
+// 408 / 373 / 297 us with 1024 / 512 / 256 blocks per sample (PASSION_RED_BLOCKS_PROTO to override)
+// (128: proto_bwd1 265 us, proto_sums 108; 64: 379 / 175) -> 256 for the forward's two kernels, half of that for proto_bwd1
+int g_red_blocks_proto = []() { const char* e = getenv("PASSION_RED_BLOCKS_PROTO"); return e && atoi(e) > 0 ? atoi(e) : 256; }();
+inline int vgrid_red_proto(long V, int div = 1) {
+    return (int)hmin((V + 256 * 4 - 1) / (256 * 4), hmin((long)hmax(1, g_red_blocks_proto / div), (long)RED_BLOCKS_MAX));
+}
 // scratch behind a reduction's own floats: B ticket counters (+ padding to 4), then B * RED_BLOCKS_MAX * J partial-sum slots
 inline long red_extra_floats(int B, int J) { return (long)((B + 3) & ~3) + (long)B * RED_BLOCKS_MAX * J; }
 
@@ -1130,7 +1142,7 @@ extern "C" int passion_proto_fwd(const void* fs, const void* ft, int dtype, cons
     unsigned* counter = nullptr;                     // every word of `work` that is read is written first by these kernels
     float* part = work + (long)B * PW + 8 + ((B + 3) & ~3);
     { const int rc_ = tickets(st, B, &counter); if (rc_) return rc_; }
-    dim3 grid(vgrid_red(V), B);
+    dim3 grid(vgrid_red_proto(V), B);
     if (dtype == PASSION_F32)
         hipLaunchKernelGGL(proto_sums_kernel<float>, grid, dim3(256), 0, st, (const float*)fs, (const float*)ft, target, (long)V, work, Cf, part, counter, Bt);
     else if (dtype == PASSION_BF16)
@@ -1161,7 +1173,7 @@ extern "C" int passion_proto_bwd(const void* fs, const void* ft, int dtype, cons
     unsigned* counter = nullptr;
     float* part = work + (long)B * PW + 8 + ((B + 3) & ~3);
     { const int rc_ = tickets(st, B, &counter); if (rc_) return rc_; }
-    dim3 grid(vgrid_red(V), B);
+    dim3 grid(vgrid_red_proto(V, 2), B);
     dim3 grid2(vgrid(V), B);
     if (dtype == PASSION_F32) {
         hipLaunchKernelGGL(proto_bwd1_kernel<float>, grid, dim3(256), 0, st, (const float*)fs, (const float*)ft, g, (long)V, B, work, (float*)dfs, Cf, part, counter, Bt);
