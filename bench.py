@@ -192,6 +192,27 @@ def dice_vs_ref(device, dtype, S):
     return out
 
 
+# SURVEY.md 8(d) census of one training FORWARD at 4 x 128^3, batch 1: Melem (10^6 elements of conv input + output, every conv-block call
+# counted once; InstanceNorm statistics / activation / padding not counted again).  A step = forward + dgrad + wgrad = 3 x these.
+CENSUS_MELEM = {"mmformer128": 1772.0, "mmformer128_passion": 3423.0, "rfnet128_passion": 5571.0, "mmformer_depth": 1772.0}
+
+
+def step_roofline(workload, batch, voxels, dtype_bytes, ms_per_step, launch_bytes=None):
+    """the WHOLE step against the HBM roofline: SURVEY 8(d)'s algorithmic bytes of the conv path of one step (per GPU) / the timed
+    ms_per_step / 8 TB/s -- the figure that has to move.  launch_bytes: the same rule summed over the conv launches the library
+    timed in one live step (cross-check of the census constant; it differs by the levels the census books differently, a few %)."""
+    melem = CENSUS_MELEM.get(workload)
+    if melem is None:
+        return None
+    gb = melem * 1e6 * (voxels / float(128 ** 3)) * batch * dtype_bytes * 3.0 / 1e9
+    out = {"algorithmic_GB_per_step": round(gb, 3), "rule": "SURVEY 8(d) census Melem x bytes/element x batch x (voxels / 128^3) x 3 (forward, "
+           "input gradient, weight gradient); per GPU", "achieved": round(gb / (ms_per_step * 1e-3), 1), "unit": "GB/s",
+           "peak": HBM_PEAK_GBS, "frac": round(gb / (ms_per_step * 1e-3) / HBM_PEAK_GBS, 5)}
+    if launch_bytes:
+        out["algorithmic_GB_per_step_from_launch_records"] = round(launch_bytes / 1e9, 3)
+    return out
+
+
 def measured_copy_gbs(device):
     """device-to-device copy of 1 GiB (read + write counted) with the library's 16-bytes-per-lane streaming kernel: the 'measured
     peak' SURVEY 8(d) asks for beside the nominal one (the guide's float4 copy: 6.29 TB/s)"""
@@ -372,14 +393,37 @@ def main():
         ts = torch.nn.functional.one_hot(lab[:, sl], 4).permute(0, 4, 1, 2, 3).double().contiguous().to(ctx.device)
         del xv, lab
         model.is_training = True
+        if ctx.world == 1 and args.ddp_mode:                 # one GPU, the N > 1 calls: halo planes / sums / gradient buckets through RCCL, peer = self
+            shard = depth.DepthCtx(rank=0, world=1, loopback=True)
 
-        def step():
-            loss_, _, _, _ = depth.sharded_step_loss(model, shard, xs, mask_full[:1], ts.view(ts.shape), Dp)
-            opt.zero_grad()
-            loss_.backward()
-            reducer.all_reduce_grads()
-            opt.step()
-            return loss_.detach()
+        def depth_eager():
+            return depth.sharded_train_step(model, opt, shard, xs, mask_full[:1], ts.view(ts.shape), Dp, reducer=reducer)
+        step = depth_eager
+        depth_eager()                                        # one eager step, its collectives counted (a replayed step issues the same ones)
+        shard.n_exchange = shard.n_allreduce = 0
+        depth_eager()
+        depth_coll = {"halo_exchanges": shard.n_exchange, "all_reduces_on_the_data_path": shard.n_allreduce,
+                      "gradient_buckets": len(reducer.buckets) if reducer.active else 0}
+        depth_graph = args.launch == "graph" or (args.launch == "auto" and os.environ.get("PASSION_BENCH_GRAPH", "1") != "0")
+        depth_note = None
+        if depth_graph:
+            # the sharded step recorded as ONE HIP graph, its RCCL calls included (depth.GraphedDepthStep): eager, the host needs
+            # ~84 ms per step whatever the slab size
+            dstep = depth.GraphedDepthStep(model, opt, shard, Dp, reducer=reducer, warm=2)
+            failed = 0.0
+            try:
+                for _ in range(4):
+                    dstep(xs, mask_full[:1], ts)
+                torch.cuda.synchronize()
+            except Exception as e:                          # noqa: BLE001 -- a recording that cannot be made must not cost the measurement
+                failed, depth_note = 1.0, f"{type(e).__name__}: {e}"[:300]
+                print(f"[bench] depth recording failed on rank {ctx.rank}: {depth_note}", file=sys.stderr)
+            if parallel.all_reduce_max(ctx, failed) > 0:
+                depth_graph = False
+                depth_note = depth_note or "another rank could not record the step"
+            else:
+                def step():
+                    return dstep(xs, mask_full[:1], ts)
     # warm-up; with the roofline leg on, its event pairs bracket EVERY conv / attention launch so that the kernel family that
     # dominates the step is known before the timed region starts -- there only that family (and the attention kernels,
     # a few launches) keeps its event pairs (326 event pairs per step cost ~5 % of throughput, one family ~1.5 %)
@@ -498,16 +542,30 @@ def main():
     graph_events = use_graph or graph_note is not None      # the reported kernel's launches were timed in the eager steps before the recording
     timed_recs = (graph_live_recs if graph_events else ops.prof_read()) if want_events else []
 
+    def leave():
+        """every rank: meet once more (rank 0 arrives last: its Dice / CPU legs run after the others are done), then take the process
+        group down in order -- communicators are not torn down against a peer that still works"""
+        if dist.is_initialized():
+            try:
+                dist.barrier()
+                dist.destroy_process_group()
+            except Exception as e:                      # noqa: BLE001 -- the measurement is out already
+                print(f"[bench] process-group shutdown: {type(e).__name__}: {e}"[:200], file=sys.stderr)
+
     def emit(line):
         """the ONE JSON line, and the last thing on stdout: librccl writes "Librccl path : ..." to stdout when a process that used it
-        exits (seen after a world-1 run), so rank 0 leaves without running exit handlers; the other ranks' stdout was pointed at
-        stderr when they started"""
+        exits (seen after a world-1 run), so stdout is pointed at /dev/null right behind the line; exit handlers and the process
+        group's shutdown then run normally (the other ranks' stdout was pointed at stderr when they started)"""
         print(line, flush=True)
-        if dist.is_initialized():
-            sys.stderr.flush()
-            os._exit(0)
+        sys.stdout.flush()
+        try:
+            os.dup2(os.open(os.devnull, os.O_WRONLY), 1)
+        except OSError:
+            pass
+        leave()
 
     if ctx.rank != 0:
+        leave()
         return
     grad_bytes = sum(p.numel() for p in model.parameters() if p.requires_grad) * 4
     mask_txt = ("masks sampled per step from brats_split mr2468 (mask_id histogram), modal_weight from it"
@@ -522,7 +580,14 @@ def main():
                                       "level-5 tokens gathered (BASELINE.json configs[4])",
                           "global_batch": 1, "parallelism": f"depth{ctx.world}", "dist_backend": ctx.backend,
                           "world_size_seen": dist.get_world_size() if dist.is_initialized() else 1,
-                          "final_loss": round(final_loss, 5), "launch": "eager"}}
+                          "final_loss": round(final_loss, 5), "ddp_mode": bool(args.ddp_mode),
+                          "launch": ("HIP graph replay of depth.sharded_train_step: forward, backward, halo / statistics / token exchanges (RCCL), "
+                                     "gradient all-reduce and AdamW in ONE recording" if depth_graph else
+                                     ("eager" if not depth_note else "eager (the HIP-graph recording failed: " + depth_note + ")"))}}
+        sr = step_roofline("mmformer_depth", 1, 240.0 * 240.0 * Dp / ctx.world, 2 if dtype == torch.bfloat16 else 4, 1e3 * dt / args.steps)
+        out["roofline"] = {"bound": "hbm", "step": sr, "step_frac": sr["frac"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "note": "whole-step figure only (per GPU: this rank's slab); the per-kernel leg belongs to the data-parallel workloads"}
+        out["config"]["collectives_per_step"] = depth_coll
         emit(json.dumps(out))
         return
     out = {
@@ -623,19 +688,33 @@ def main():
             # counters cannot be read inside a timed run: the committed rocprofv3 --pmc pass over THIS command (bench.py with this
             # workload: the instantiations and shapes benchmarked here), tools/pmc_attention_bench.sh
             pname = "attention_pmc_bench_passion.json" if passion else "attention_pmc_bench_plain.json"
-            ppath = os.path.join(ROOT, "profiles", "r04_" + pname)
-            if not os.path.exists(ppath):
-                ppath = os.path.join(ROOT, "profiles", "r03_" + pname)
-            pname = os.path.basename(ppath)
-            if os.path.exists(ppath) and not is_rfnet:
+            ppath = next((os.path.join(ROOT, "profiles", r + pname) for r in ("r05_", "r04_", "r03_")
+                          if os.path.exists(os.path.join(ROOT, "profiles", r + pname))), None)
+            if ppath is not None and not is_rfnet:
+                import hashlib
                 pj = json.load(open(ppath))
-                att["mfma_busy"] = {"note": "STATIC: read from the committed rocprofv3 --pmc pass over this same bench command, not "
-                                            "measured in this run (tools/pmc_attention_bench.sh regenerates it)",
-                                    "source": "profiles/" + pname, "source_mtime": int(os.path.getmtime(ppath)),
-                                    "all_flash_kernels_mfma_busy_frac": pj.get("all_flash_kernels_mfma_busy_frac"),
-                                    "kernels": {k: v.get("mfma_busy_frac") for k, v in pj.get("kernels", {}).items()}}
+                src_now = hashlib.sha256(open(os.path.join(ROOT, "passion_amd", "csrc", "flash_attn.hip"), "rb").read()).hexdigest()
+                fresh = pj.get("flash_attn_sha256") == src_now
+                mb = {"note": "STATIC: read from the committed rocprofv3 --pmc pass over this same bench command, not measured in this run "
+                              "(tools/pmc_attention_bench.sh regenerates it; the file records the sha256 of csrc/flash_attn.hip it was taken on)",
+                      "source": "profiles/" + os.path.basename(ppath), "measured_on_this_kernel_source": fresh}
+                if fresh:
+                    mb["all_flash_kernels_mfma_busy_frac"] = pj.get("all_flash_kernels_mfma_busy_frac")
+                    mb["kernels"] = {k: v.get("mfma_busy_frac") for k, v in pj.get("kernels", {}).items()}
+                else:       # a counter pass over ANOTHER version of the kernels says nothing about the ones timed above: refused, not quoted
+                    mb["refused"] = "the committed counter pass was taken on another version of csrc/flash_attn.hip"
+                att["mfma_busy"] = mb
             att["peak_tflops"] = MFMA_BF16_PEAK_TF
             out["attention"] = att
+    # the whole step against the HBM roofline: the figure the timed region itself yields
+    lb = None
+    if want_events and warm_recs and args.warmup:
+        lb = sum(r[2] for r in warm_recs if r[0] < 4) / args.warmup
+    sr = step_roofline(args.workload, batch, float(S) ** 3, 2 if dtype == torch.bfloat16 else 4, 1e3 * dt / args.steps, lb)
+    if sr is not None:
+        out.setdefault("roofline", {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s"})
+        out["roofline"]["step"] = sr
+        out["roofline"]["step_frac"] = sr["frac"]
     if not is_rfnet and not args.no_dice:
         dv = dice_vs_ref(ctx.device, dtype, S)
         if dv:

@@ -152,6 +152,20 @@ int passion_upsample_bwd(const void* dy, void* dx, int dtype, int B, int D, int 
  * accumulating (backward: the neighbour's gradient of our boundary plane).  The exchange itself is torch.distributed (RCCL). */
 int passion_halo_pack(const void* x, void* buf, int dtype, int B, int D, int64_t P, int d, void* stream);
 int passion_halo_unpack(const void* buf, void* y, int dtype, int B, int D, int64_t P, int d, int accumulate, void* stream);
+/* round 5: the extended slab (B, n_lo + Dl + n_hi, P) of a 3x3x3 conv / upsampling input in ONE launch -- planes below n_lo - 1 and above
+ * n_lo + Dl zero, plane n_lo - 1 / n_lo + Dl from its source (mode 0 zeros, 1 the (B, P) buffer lo / hi = the neighbour's plane,
+ * 2 plane lo_pl / hi_pl of x itself = reflect at a global end) -- and its adjoint: gx = the owned planes of g, plus the halo plane's
+ * gradient onto plane fold_lo / fold_hi (-1: none) where the halo was a reflection; send (2, B, P) = the two halo planes' gradients
+ * (zeros where n_lo / n_hi = 0), which go back to their owners.  (passion_amd/depth.py HaloExtendFn; a zero-padded crop's adjoint is
+ * the same launch with modes 0.) */
+int passion_halo_extend(const void* x, const void* lo, const void* hi, void* ext, int dtype, int B, int Dl, int64_t P, int n_lo, int n_hi,
+                        int lo_mode, int hi_mode, int lo_pl, int hi_pl, void* stream);
+int passion_halo_extend_bwd(const void* g, void* gx, void* send, int dtype, int B, int Dl, int64_t P, int n_lo, int n_hi, int fold_lo, int fold_hi,
+                            void* stream);
+/* InstanceNorm statistics of a volume whose D axis is split over the ranks ("per IN: all-reduce of (sum x, sum x^2)"): the
+ * (mean, rstd) pairs of a rank's slab of n voxels -> (n, n mean, n (var + mean^2)) in double, which the ranks SUM; and back. */
+int passion_stats_to_moments(const float* stats, double* mom, int64_t BC, double n, double eps, void* stream);
+int passion_moments_to_stats(const double* mom, float* stats, int64_t BC, double eps, void* stream);
 /* trilinear x k (align_corners=True) where the D axis is one window of a larger volume: the rank holds input planes
  * [id0, id0 + Dl_in) of Dg and produces output planes [od0, od0 + Dl_out) of k*Dg with GLOBAL source coordinates;
  * bwd = the adjoint restricted to those outputs, gradient of every local input plane (halo planes included). */

@@ -58,6 +58,11 @@ SIGNATURES = {
                                          c_int, c_int, c_void_p]),
     "passion_halo_pack": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int64, c_int, c_void_p]),
     "passion_halo_unpack": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int64, c_int, c_int, c_void_p]),
+    "passion_halo_extend": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int64, c_int, c_int, c_int, c_int, c_int, c_int,
+                                    c_void_p]),
+    "passion_halo_extend_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int64, c_int, c_int, c_int, c_int, c_void_p]),
+    "passion_stats_to_moments": (c_int, [c_void_p, c_void_p, c_int64, c_double, c_double, c_void_p]),
+    "passion_moments_to_stats": (c_int, [c_void_p, c_void_p, c_int64, c_double, c_void_p]),
     "passion_upsample_window_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                             c_int, c_void_p]),
     "passion_upsample_window_bwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,

@@ -1149,6 +1149,17 @@ namespace {
 struct Companion { hipStream_t caller, side; hipEvent_t fork, done; };
 std::vector<Companion> g_comp;
 std::mutex g_comp_mu;
+// the dependency set of a capturing stream (the nodes its next launch would depend on); false = the stream is not capturing
+bool capture_tail(hipStream_t st, std::vector<hipGraphNode_t>& out) {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    unsigned long long id = 0;
+    hipGraph_t graph = nullptr;
+    const hipGraphNode_t* deps = nullptr;
+    size_t n = 0;
+    if (hipStreamGetCaptureInfo_v2(st, &cs, &id, &graph, &deps, &n) != hipSuccess || cs != hipStreamCaptureStatusActive) return false;
+    out.assign(deps, deps + n);
+    return true;
+}
 Companion* companion(hipStream_t caller) {
     std::lock_guard<std::mutex> lk(g_comp_mu);
     for (auto& c : g_comp) if (c.caller == caller) return &c;
@@ -1293,7 +1304,16 @@ static int conv3d_bwd_impl(const passion_conv_desc_t* d, const float* packed, co
             return rc;
         }
     }
-    Companion* comp = (phase == 0 && pconv::g_wgrad_fork && need_dx && (dweight || dbias) && !pw_final) ? companion(st) : nullptr;
+    Companion* comp = (phase == 0 && pconv::g_wgrad_fork == 1 && need_dx && (dweight || dbias) && !pw_final) ? companion(st) : nullptr;
+    // option "wgrad_fork" = 2 (round 5): the same fork WITHOUT a second stream, for a step that is being recorded as a HIP graph: the
+    // capturing stream's dependency set is read before the weight-gradient launches (hipStreamGetCaptureInfo_v2), put back behind
+    // them (hipStreamUpdateCaptureDependencies: the input-gradient + finish launches then depend on what the weight gradient depended
+    // on, not on it) and the weight gradient's tail is added to the set again at the end of the call -- two branches of the graph,
+    // no stream, no event node.  Outside a capture the launches stay in stream order.
+    std::vector<hipGraphNode_t> cap_d0, cap_dw;
+    bool capfork = false;
+    if (!comp && phase == 0 && pconv::g_wgrad_fork == 2 && need_dx && (dweight || dbias) && !pw_final) capfork = capture_tail(st, cap_d0);
+    const bool forked = comp || capfork;
     hipStream_t caller_st = st;
     if (comp) {                                      // fork: the weight-gradient work below goes to the companion stream
         HIP_RET(hipEventRecord(comp->fork, caller_st));
@@ -1301,7 +1321,7 @@ static int conv3d_bwd_impl(const passion_conv_desc_t* d, const float* packed, co
         st = comp->side;
     }
     // cleared by the weight-gradient fold when that runs on the same stream as the dgrad
-    float* zsums = (need_norm && sums && !comp) ? sums : nullptr;
+    float* zsums = (need_norm && sums && !forked) ? sums : nullptr;
     bool defer_fold = false;
     FoldJob fj{nullptr, {nullptr, nullptr, nullptr, nullptr}, 0, 0, 0, 0, 0, 0};
     const long zn = zsums ? (long)2 * k.B * k.Cin * SUMS_REP : 0;
@@ -1315,7 +1335,7 @@ static int conv3d_bwd_impl(const passion_conv_desc_t* d, const float* packed, co
         float* bslab = wslab + nW;
         // the fold of the slab rides in the finish launch at the end of this call when one follows (FoldJob); the wgrad kernel then
         // clears the InstanceNorm-backward sums itself
-        defer_fold = !comp && phase == 0 && (parts & 2) && need_dx && (ga || (dweight && dbias == dweight + nW)) && !pw_final;
+        defer_fold = !forked && phase == 0 && (parts & 2) && need_dx && (ga || (dweight && dbias == dweight + nW)) && !pw_final;
         if (pw_final) k.spos = wslab + (long)w.gx * k.wslot;
         if (defer_fold && zsums) { k.zero_ptr = zsums; k.zero_n = zn; }
         {
@@ -1392,6 +1412,10 @@ static int conv3d_bwd_impl(const passion_conv_desc_t* d, const float* packed, co
     if (comp) {
         HIP_RET(hipEventRecord(comp->done, comp->side));
         st = caller_st;
+    }
+    if (capfork) {                                   // the launches below hang off what the weight gradient hung off
+        if (!capture_tail(st, cap_dw)) return -1024;
+        HIP_RET(hipStreamUpdateCaptureDependencies(st, cap_d0.data(), cap_d0.size(), hipStreamSetCaptureDependencies));
     }
     if (pw_final) {
         // per-sample folds + contraction -> (m1, m2) / V (over the passes of a batched launch), then the input gradient with its
@@ -1626,6 +1650,7 @@ static int conv3d_bwd_impl(const passion_conv_desc_t* d, const float* packed, co
         LAUNCH_RET();
     }
     if (comp) HIP_RET(hipStreamWaitEvent(caller_st, comp->done, 0));     // join
+    if (capfork && !cap_dw.empty()) HIP_RET(hipStreamUpdateCaptureDependencies(st, cap_dw.data(), cap_dw.size(), hipStreamAddCaptureDependencies));
     return 0;
 }
 

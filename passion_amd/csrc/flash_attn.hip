@@ -13,14 +13,22 @@
 //     a key-major one for dK, dV.  S and dP are recomputed in both: 7 MFMA products instead of 5, no dQ reduction.
 //   * online softmax with a lazy rescale: the running reference only moves when a block exceeds it by 2^8 (bf16 / f32 have the
 //     exponent range; the row sum uses the same reference, so nothing is approximated).
-//   * attention dropout: a counter-based mask, bit (b, h, q, key) = 16 bits of a two-round 24-bit-multiply hash of
-//     (seed, ((b H + h) N + q) ceil(N / 2) + key / 2): v_mad_u32_u24 is full rate (v_mul_lo_u32 is quarter rate), a query-major
-//     lane gets two keys per hash; the backward regenerates the same bits.  The 1 / (1 - p) factor is folded into the final row
-//     normalisation.  tests/test_ops_gpu.py restates the hash in numpy.
+//   * attention dropout (round 5): a counter-based mask whose cost is 2.5 vector instructions per score instead of 5.  One 32-bit
+//     word serves the two keys (2 kp, 2 kp + 1) of a query row: word(row, kp) = mix(R(row) + C(kp)), R and C two-round hashes of
+//     (seed, (b H + h) N + q) and (seed, kp) that are formed ONCE per row / key pair (query-major kernels: R once per lane, C
+//     for the block's 32 pairs by one wavefront into LDS; key-major kernel: C once per lane, R for the block's 64 queries into
+//     LDS beside lse / delta), mix(x) = one xorshift + one 24-bit multiply-add (tests/_util.py restates it in numpy;
+//     tests/test_hostlogic_cpu.py holds its keep rate and its row / column / diagonal correlations at the noise floor).
+//     keep = (signed 16-bit field >= thr - 32768).  The forward applies it to the PACKED bf16 probabilities (v_pk_sub_i16 clamp,
+//     v_pk_ashrrev_i16, v_bfi: 1.5 instructions per pair) and takes the row sum of the undropped ones from one more MFMA against
+//     a tile of ones instead of 32 v_add_f32 per block; the 1 / (1 - p) factor is folded into the final row normalisation.
+//     The backward regenerates the same bits (key-major: lanes 2i, 2i + 1 hold the two keys of a pair and the same queries --
+//     each hashes every other row, one quad permute + one v_perm_b32 put both rows' fields of a lane's key into one register).
 #include "common.h"
 #include "passion_hip.h"
 #include "prof.h"
 
+int g_flash_pp = 1;         // option "flash_pp" / PASSION_FLASH_PP: the ping-pong query-major kernels (0 off, 1 where the launch fills the chip, 2 always)
 int g_flash_split = 0;      // option "flash_split" / PASSION_FLASH_SPLIT: 0 = automatic, n = that many splits (1 = the unsplit kernels)
 namespace pconv { int stream_scratch(hipStream_t st, size_t zero_bytes, size_t plain_bytes, void** zero, void** plain); }   // api.cpp
 extern const unsigned* g_passion_step_words;      // api.cpp: passion_set_step_words
@@ -51,7 +59,7 @@ struct FlashP {
     int B, N, H;
     float c;                    // scale * log2(e)
     float scale;
-    unsigned thr;               // keep when the 16-bit uniform >= thr; 0 = no dropout
+    unsigned thr;               // keep when the signed 16-bit field >= thr - 32768 (thr = p * 65536); 0 = no dropout
     float inv_keep;
     unsigned s0, s1;            // seed halves
     const unsigned* soff;       // device words added to the seed at run time (a replayed HIP graph: passion_set_step_words), or nullptr
@@ -63,7 +71,8 @@ struct FlashP {
     float* pl;                  // ... and row sum of the split
 };
 
-// two rounds of (24-bit multiply-add, xorshift): every instruction is full rate on the vector ALU
+// two rounds of (24-bit multiply-add, xorshift): every instruction is full rate on the vector ALU.  The per-row / per-key-pair halves
+// of the dropout word (formed once per row / pair, not per score)
 __device__ __forceinline__ unsigned drop_hash(unsigned pair, unsigned s0, unsigned s1) {
     unsigned x = pair ^ s0;
     x = __umul24(x, 0xB5297Au) + (x >> 9);
@@ -72,6 +81,19 @@ __device__ __forceinline__ unsigned drop_hash(unsigned pair, unsigned s0, unsign
     x = __umul24(x, 0x68E31Du) + (x >> 11);
     x ^= x >> 14;
     return x;
+}
+__device__ __forceinline__ unsigned row_word(unsigned row, unsigned s0, unsigned s1) { return drop_hash(row, s0, s1); }
+__device__ __forceinline__ unsigned pair_word(unsigned kp, unsigned s0, unsigned s1) { return drop_hash(kp ^ 0x5BD1E995u, s1, s0 + 0x2545F491u); }
+// the word of (row, key pair) from the sum of the two halves: 4 instructions
+__device__ __forceinline__ unsigned drop_mix(unsigned x) {
+    x ^= x >> 15;
+    return __umul24(x, 0x68E31Du) + (x >> 11);
+}
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+// 0xFFFF in every 16-bit field of `u` that is DROPPED (signed field < thr - 32768), 0 where it is kept
+__device__ __forceinline__ unsigned drop_fields(unsigned u, s16x2 thr2) {
+    const s16x2 d = __builtin_elementwise_sub_sat(__builtin_bit_cast(s16x2, u), thr2);
+    return __builtin_bit_cast(unsigned, d >> 15);
 }
 
 __device__ __forceinline__ bf16x8 zero8() {
@@ -147,14 +169,17 @@ __device__ __forceinline__ float half_sum(float v) {
 #define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
 
 // --------------------------------------------------------------------------------------------------------------
-// query-major kernels: MODE 0 = forward (out, lse), MODE 1 = backward dQ
+// query-major kernels: MODE 0 = forward (out, lse), MODE 1 = backward dQ; DROP: attention dropout on (its own instantiation: one path
+// through the loop -- with both in one kernel the register allocator spilled the dQ kernel's accumulators around the branch)
 // grid (ceil(N / (32 NW)), H, B), block 64 NW: wave w owns queries q0 .. q0+31
-template <int NW, int MODE>
+template <int NW, int MODE, bool DROP>
 __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2))) void flash_q_kernel(FlashP p) {
     const unsigned ds0 = p.s0 + (p.soff ? p.soff[0] : 0u), ds1 = p.s1 + (p.soff ? p.soff[1] : 0u);
     constexpr int NT = 64 * NW;
     constexpr int KIMG = BLK * RS, VIMG = (MODE == 0) ? BLK * TS : BLK * RS;
-    extern __shared__ __attribute__((aligned(16))) char lds[];      // [2][K image | V image]
+    constexpr int CTAB = 128;                                       // the block's 32 key-pair words C(kp), as [h][16] in a lane's register order
+    constexpr int BUFQ = KIMG + VIMG + CTAB;
+    extern __shared__ __attribute__((aligned(16))) char lds[];      // [2][K image | V image | pair words]
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, h = lane >> 5;
     const int hh = blockIdx.y, b = blockIdx.z, N = p.N;
     const long rs = 3L * p.H * DH;
@@ -183,22 +208,37 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2))) vo
         lse2 = p.lse[((long)b * p.H + hh) * N + q];
         dlt = p.delta[((long)b * p.H + hh) * N + q];
     }
-    const unsigned npair = (unsigned)(N + 1) >> 1;
-    const unsigned rowpair = ((unsigned)(b * p.H + hh) * (unsigned)N + (unsigned)q) * npair;
+    // dropout: this lane's row half of every word it will need, once; the pair halves of a block come from LDS
+    const unsigned rq = DROP ? row_word((unsigned)(b * p.H + hh) * (unsigned)N + (unsigned)q, ds0, ds1) : 0u;
+    const short ths = (short)((int)p.thr - 32768);
+    const s16x2 thr2 = {ths, ths};
+    const int thr_hi = ((int)p.thr - 32768) * 65536;
+    // thread t < 32 forms the word of the block's pair t and stores it where lane half h2 = (t >> 1) & 1 reads its i-th register pair:
+    // pair t = kt * 16 + 4 * (r >> 2) + 2 h2 + j  <->  i = kt * 8 + 2 * (r >> 2) + j
+    const int ct_slot = ((tid >> 1) & 1) * 16 + (tid >> 4) * 8 + 2 * ((tid >> 2) & 3) + (tid & 1);
+    auto put_pairs = [&](int kb_, char* buf) {
+        if (DROP && tid < 32) reinterpret_cast<unsigned*>(buf + KIMG + VIMG)[ct_slot] = pair_word((unsigned)(kb_ * (BLK / 2) + tid), ds0, ds1);
+    };
 
     f32x16 o[2] = {zero16(), zero16()};          // forward: O^T[d][q]; backward: dQ^T[d][q]
-    float m_run = -INFINITY, l_run = 0.f;
+    f32x16 lacc = zero16();                      // forward: every register = the running row sum of this lane's query (ones . P^T)
+    float m_run = -INFINITY;
+    bf16x8 ones;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ones[j] = (__bf16)1.0f;
 
     u32x4 kr[512 / NT], vr[512 / NT];
     fetch_tile<NT>(kr, kbase, rs, kb0 * BLK, N, tid);
     fetch_tile<NT>(vr, vbase, rs, kb0 * BLK, N, tid);
-    commit_tile<NT>(kr, lds + (kb0 & 1) * (KIMG + VIMG), RS, tid);
-    commit_tile<NT>(vr, lds + (kb0 & 1) * (KIMG + VIMG) + KIMG, MODE == 0 ? TS : RS, tid);
+    commit_tile<NT>(kr, lds + (kb0 & 1) * BUFQ, RS, tid);
+    commit_tile<NT>(vr, lds + (kb0 & 1) * BUFQ + KIMG, MODE == 0 ? TS : RS, tid);
+    put_pairs(kb0, lds + (kb0 & 1) * BUFQ);
     __syncthreads();
 
     for (int kb = kb0; kb < nblk; ++kb) {
-        const char* kimg = lds + (kb & 1) * (KIMG + VIMG);
+        const char* kimg = lds + (kb & 1) * BUFQ;
         const char* vimg = kimg + KIMG;
+        const u32x4* ctab = reinterpret_cast<const u32x4*>(vimg + VIMG) + 4 * h;
         if (kb + 1 < nblk) {
             fetch_tile<NT>(kr, kbase, rs, (kb + 1) * BLK, N, tid);
             fetch_tile<NT>(vr, vbase, rs, (kb + 1) * BLK, N, tid);
@@ -252,6 +292,8 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2))) vo
                 for (int r = 0; r < 16; ++r)
                     if (key0 + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h >= N) st[kt][r] = -INFINITY;
         }
+        // pair halves of this lane's 16 register pairs: ctab[2 kt + s][jj] <-> registers 8 s + 2 jj, + 1 of tile kt (read where they are
+        // used: held for the whole block they cost the dQ kernel its 256-register budget)
         if (MODE == 0) {
             // ---- online softmax, lazy reference
             float mx = -INFINITY;
@@ -265,65 +307,72 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2))) vo
                 const float m_new = move ? mx : m_run;
                 const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);     // first block: exp2(-inf) = 0
                 m_run = m_new;
-                l_run *= alpha;
+                lacc[0] *= alpha;                        // the other fifteen registers hold the same sum and are never read
 #pragma unroll
                 for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
             }
-            float psum = 0.f;
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(st[kt][r], p.c, -m_run));
-                    st[kt][r] = e;
-                    psum += e;
+                for (int r = 0; r < 16; ++r) st[kt][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(st[kt][r], p.c, -m_run));
+            // ---- row sum: ones . P^T on the matrix pipe (all keys of the tile, both lane halves); O^T += V^T . (P^T, dropped):
+            // the mask is applied to the packed bf16 pairs (register pair (r, r + 1) = keys 2 kp, 2 kp + 1 = the word's two fields)
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    const bf16x8 pu = pack8(st[kt], s);
+                    lacc = MFMA32(ones, pu, lacc);
+                    bf16x8 pf = pu;
+                    if (DROP) {
+                        u32x4 pw = __builtin_bit_cast(u32x4, pu);
+                        const u32x4 c4 = ctab[2 * kt + s];
+#pragma unroll
+                        for (int jj = 0; jj < 4; ++jj) pw[jj] &= ~drop_fields(drop_mix(rq + c4[jj]), thr2);
+                        pf = __builtin_bit_cast(bf16x8, pw);
+                    }
+#pragma unroll
+                    for (int dt = 0; dt < 2; ++dt) o[dt] = MFMA32(tfr[kt][s][dt], pf, o[dt]);
                 }
-            l_run += psum;
         } else {
             // ---- P^T from the saved log-sum-exp; dS^T = P^T o (dP^T_dropped - delta)
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) st[kt][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(st[kt][r], p.c, -lse2));
-        }
-        if (p.thr) {           // dropout bits of this lane's 32 (query, key) elements: two keys per hash
+            if (DROP) {
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 16; r += 2) {
+                        const unsigned u = drop_mix(rq + ctab[2 * kt + (r >> 3)][(r & 7) >> 1]);
+                        const float t0 = (short)(u & 0xffffu) >= ths ? p.inv_keep : 0.f, t1 = (int)u >= thr_hi ? p.inv_keep : 0.f;
+                        st[kt][r] *= __builtin_fmaf(dp[kt][r], t0, -dlt);
+                        st[kt][r + 1] *= __builtin_fmaf(dp[kt][r + 1], t1, -dlt);
+                    }
+            } else {
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) st[kt][r] *= (dp[kt][r] - dlt);
+            }
+            // ---- dQ^T += K^T . dS^T
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-                for (int r = 0; r < 16; r += 2) {
-                    const unsigned key = (unsigned)(key0 + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h);
-                    const unsigned u = drop_hash(rowpair + (key >> 1), ds0, ds1);
-                    const bool k0 = (u & 0xffffu) >= p.thr, k1 = (u >> 16) >= p.thr;
-                    if (MODE == 0) {
-                        st[kt][r] = k0 ? st[kt][r] : 0.f;
-                        st[kt][r + 1] = k1 ? st[kt][r + 1] : 0.f;
-                    } else {
-                        dp[kt][r] = k0 ? dp[kt][r] * p.inv_keep : 0.f;
-                        dp[kt][r + 1] = k1 ? dp[kt][r + 1] * p.inv_keep : 0.f;
-                    }
+                for (int s = 0; s < 2; ++s) {
+                    const bf16x8 pf = pack8(st[kt], s);
+#pragma unroll
+                    for (int dt = 0; dt < 2; ++dt) o[dt] = MFMA32(tfr[kt][s][dt], pf, o[dt]);
                 }
         }
-        if (MODE == 1) {
-#pragma unroll
-            for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) st[kt][r] *= (dp[kt][r] - dlt);
-        }
-        // ---- O^T += V^T . P^T   /   dQ^T += K^T . dS^T
-#pragma unroll
-        for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                const bf16x8 pf = pack8(st[kt], s);
-#pragma unroll
-                for (int dt = 0; dt < 2; ++dt) o[dt] = MFMA32(tfr[kt][s][dt], pf, o[dt]);
-            }
         if (kb + 1 < nblk) {
-            char* nk = lds + ((kb + 1) & 1) * (KIMG + VIMG);
+            char* nk = lds + ((kb + 1) & 1) * BUFQ;
             commit_tile<NT>(kr, nk, RS, tid);
             commit_tile<NT>(vr, nk + KIMG, MODE == 0 ? TS : RS, tid);
+            put_pairs(kb + 1, nk);
         }
         __syncthreads();
     }
@@ -338,7 +387,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2))) vo
                 for (int r = 0; r < 16; ++r) p.po[row * DH + dt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h] = o[dt][r];
         }
         if (MODE == 0) {
-            const float l_tot = half_sum(l_run);
+            const float l_tot = lacc[0];
             if (qok && h == 0) { p.pm[row] = m_run; p.pl[row] = l_tot; }
         }
         return;
@@ -346,7 +395,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2))) vo
     // ---- epilogue: scale, transpose through LDS (the tile buffers are free after the last barrier), whole 128-byte rows out
     float f;
     if (MODE == 0) {
-        const float l_tot = half_sum(l_run);
+        const float l_tot = lacc[0];
         f = p.inv_keep / l_tot;
         if (qok && h == 0) p.lse[((long)b * p.H + hh) * N + q] = m_run + __builtin_amdgcn_logf(l_tot);
     } else {
@@ -374,14 +423,294 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2))) vo
 }
 
 // --------------------------------------------------------------------------------------------------------------
+// Ping-pong form of the query-major kernels (round 5) for launches that fill the chip.
+//
+// What the counters said about flash_q_kernel<4, *> at a saturating shape (B = 16, N = 2048: profiles/r05_attention_pmc_*): a wave
+// needs ~1300 cycles of vector issue and 640 cycles of MFMA per 64-key block, the two co-resident waves of a SIMD take 4300 cycles
+// for a block each -- the SUM of both waves' phases, not their maximum: two waves that run the same program from the same start
+// stay in lockstep, both in their MFMA phase (sharing one matrix pipe), then both in their softmax phase (sharing one vector issue
+// port); a start-up stagger does not survive (tried).  Here the phases are held apart by construction: a workgroup is EIGHT waves
+// (waves w and w + 4 share a SIMD), group A = waves 0-3, group B = waves 4-7, each wave owns 32 queries as before, and the loop is
+// cut into two kinds of segment separated by workgroup barriers
+//     M(j):  second product of block j - 1 (O^T += V^T . P^T  /  dQ^T += K^T . dS^T, + the row-sum MFMAs), then S(j) (and dP(j))
+//     V(j):  softmax / dropout / dS arithmetic of block j, left as packed bf16 operands for M(j + 1)
+// with B one segment behind A: while one wave of a SIMD issues MFMAs, its partner issues the vector work.  K / V tiles live in a
+// ring of three LDS slots (tile j + 1 is committed in the phase in which B still reads tile j - 1 as the second product's operand),
+// fetched two phases ahead into registers.
+// grid (ceil(N / 256) * nsplit, H, B), block 512.
+template <int MODE, bool DROP>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void flash_qpp_kernel(FlashP p) {
+    const unsigned ds0 = p.s0 + (p.soff ? p.soff[0] : 0u), ds1 = p.s1 + (p.soff ? p.soff[1] : 0u);
+    constexpr int KIMG = BLK * RS, VIMG = (MODE == 0) ? BLK * TS : BLK * RS, VST = (MODE == 0) ? TS : RS;
+    constexpr int CTAB = 128;
+    extern __shared__ __attribute__((aligned(16))) char lds[];      // K images [3] | V images [3] | pair words [3]
+    char* const kring = lds;
+    char* const vring = lds + 3 * KIMG;
+    char* const cring = vring + 3 * VIMG;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, h = lane >> 5;
+    const int grp = __builtin_amdgcn_readfirstlane(wv >> 2);
+    const int hh = blockIdx.y, b = blockIdx.z, N = p.N;
+    const long rs = 3L * p.H * DH;
+    const bf16_t* qb = p.qkv + (long)b * N * rs + hh * DH;
+    const bf16_t* kbase = qb + (long)p.H * DH;
+    const bf16_t* vbase = qb + 2L * p.H * DH;
+    const int split = blockIdx.x % p.nsplit;
+    const int q0 = ((blockIdx.x / p.nsplit) * 8 + wv) * 32, q = q0 + (lane & 31);
+    const bool qok = q < N;
+    const int nblk_all = (N + BLK - 1) / BLK;
+    const int kb0 = (int)((long)split * nblk_all / p.nsplit), nblk = (int)((long)(split + 1) * nblk_all / p.nsplit);
+    const int nb = nblk - kb0;                                       // key blocks of this split: kb0 + j, j = 0 .. nb - 1
+
+    bf16x8 qf[4], dof[MODE == 1 ? 4 : 1];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        qf[s] = zero8();
+        if (qok) qf[s] = *reinterpret_cast<const bf16x8*>(qb + (long)q * rs + 16 * s + 8 * h);
+        if (MODE == 1) {
+            dof[s] = zero8();
+            if (qok) dof[s] = *reinterpret_cast<const bf16x8*>(p.dout + ((long)b * N + q) * (p.H * DH) + hh * DH + 16 * s + 8 * h);
+        }
+    }
+    float lse2 = 0.f, dlt = 0.f;
+    if (MODE == 1 && qok) {
+        lse2 = p.lse[((long)b * p.H + hh) * N + q];
+        dlt = p.delta[((long)b * p.H + hh) * N + q];
+    }
+    const unsigned rq = DROP ? row_word((unsigned)(b * p.H + hh) * (unsigned)N + (unsigned)q, ds0, ds1) : 0u;
+    const short ths = (short)((int)p.thr - 32768);
+    const s16x2 thr2 = {ths, ths};
+    const int thr_hi = ((int)p.thr - 32768) * 65536;
+    const int ct_slot = ((tid >> 1) & 1) * 16 + (tid >> 4) * 8 + 2 * ((tid >> 2) & 3) + (tid & 1);
+
+    // tile traffic: thread tid owns the 16-byte chunk (row tid >> 3, column block tid & 7) of every K / V tile
+    const int trow = tid >> 3, tc8 = tid & 7;
+    auto gtile = [&](const bf16_t* base, int j) -> u32x4 {
+        const int row = (kb0 + j) * BLK + trow;
+        u32x4 r = {0u, 0u, 0u, 0u};
+        if (j < nb && row < N) r = *reinterpret_cast<const u32x4*>(base + (long)row * rs + tc8 * 8);
+        return r;
+    };
+    auto commit = [&](int slot, int j, const u32x4& kr, const u32x4& vr) {
+        *reinterpret_cast<u32x4*>(kring + slot * KIMG + trow * RS + tc8 * 16) = kr;
+        *reinterpret_cast<u32x4*>(vring + slot * VIMG + trow * VST + tc8 * 16) = vr;
+        if (DROP && tid < 32) reinterpret_cast<unsigned*>(cring + slot * CTAB)[ct_slot] = pair_word((unsigned)((kb0 + j) * (BLK / 2) + tid), ds0, ds1);
+    };
+
+    f32x16 o[2] = {zero16(), zero16()};
+    f32x16 lacc = zero16();
+    float m_run = -INFINITY;
+    bf16x8 ones;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ones[j] = (__bf16)1.0f;
+    f32x16 st[2], dp[MODE == 1 ? 2 : 1];
+    bf16x8 pu[MODE == 0 ? 4 : 1], pd[4];           // packed operands of the second product: [2 kt + s]
+
+    u32x4 kreg = gtile(kbase, 0), vreg = gtile(vbase, 0);
+    commit(0, 0, kreg, vreg);
+    kreg = gtile(kbase, 1);                          // committed in phase 1
+    vreg = gtile(vbase, 1);
+    __syncthreads();
+
+    // ring slots of the tiles a segment touches, kept as counters (no division in the loop)
+    int sj = 0;            // slot of block j = the block of THIS wave's current segment pair: advanced when its V segment is done
+    int sprev = 2;         // slot of block j - 1
+    int cslot = 1;         // slot the next commit writes (tile jc)
+    int jc = 1;
+    for (int ph = 0; ph <= 2 * nb + 1; ++ph) {
+        const int s = ph - grp;
+        if (s >= 0 && s <= 2 * nb) {
+            const int j = s >> 1;
+            if (!(s & 1)) {
+                // ================= M(j)
+                if (j > 0) {
+                    const char* timg = (MODE == 0) ? vring + sprev * VIMG : kring + sprev * KIMG;
+                    constexpr int tstride = (MODE == 0) ? TS : RS;
+                    bf16x8 tfr[2][2][2];
+#pragma unroll
+                    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                            for (int dt = 0; dt < 2; ++dt) tfr[kt][s2][dt] = tr_frag(timg, tstride, kt * 32 + 16 * s2, dt * 32, lane);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                        for (int s2 = 0; s2 < 2; ++s2) {
+                            if (MODE == 0) lacc = MFMA32(ones, pu[MODE == 0 ? 2 * kt + s2 : 0], lacc);
+#pragma unroll
+                            for (int dt = 0; dt < 2; ++dt) o[dt] = MFMA32(tfr[kt][s2][dt], pd[2 * kt + s2], o[dt]);
+                        }
+                }
+                if (j < nb) {
+                    const char* kimg = kring + sj * KIMG;
+                    const char* vimg = vring + sj * VIMG;
+                    bf16x8 kfr[2][4];
+#pragma unroll
+                    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                        for (int s2 = 0; s2 < 4; ++s2) kfr[kt][s2] = row_frag(kimg, RS, kt * 32, s2, lane);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int kt = 0; kt < 2; ++kt) {
+                        st[kt] = zero16();
+#pragma unroll
+                        for (int s2 = 0; s2 < 4; ++s2) st[kt] = MFMA32(kfr[kt][s2], qf[s2], st[kt]);
+                    }
+                    if (MODE == 1) {
+#pragma unroll
+                        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                            for (int s2 = 0; s2 < 4; ++s2) kfr[kt][s2] = row_frag(vimg, RS, kt * 32, s2, lane);
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int kt = 0; kt < 2; ++kt) {
+                            dp[kt] = zero16();
+#pragma unroll
+                            for (int s2 = 0; s2 < 4; ++s2) dp[kt] = MFMA32(kfr[kt][s2], dof[s2], dp[kt]);
+                        }
+                    }
+                }
+            } else {
+                // ================= V(j)
+                const u32x4* ctab = reinterpret_cast<const u32x4*>(cring + sj * CTAB) + 4 * h;
+                const int key0 = (kb0 + j) * BLK;
+                if (key0 + BLK > N) {
+#pragma unroll
+                    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            if (key0 + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h >= N) st[kt][r] = -INFINITY;
+                }
+                if (MODE == 0) {
+                    float mx = -INFINITY;
+#pragma unroll
+                    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[kt][r]);
+                    mx = half_max(mx) * p.c;
+                    const bool move = mx > m_run + LAZY;
+                    if (__any(move)) {
+                        const float m_new = move ? mx : m_run;
+                        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+                        m_run = m_new;
+                        lacc[0] *= alpha;
+#pragma unroll
+                        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+                    }
+#pragma unroll
+                    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) st[kt][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(st[kt][r], p.c, -m_run));
+#pragma unroll
+                    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                        for (int s2 = 0; s2 < 2; ++s2) {
+                            const bf16x8 pk = pack8(st[kt], s2);
+                            pu[MODE == 0 ? 2 * kt + s2 : 0] = pk;
+                            bf16x8 pf = pk;
+                            if (DROP) {
+                                u32x4 pw = __builtin_bit_cast(u32x4, pk);
+                                const u32x4 c4 = ctab[2 * kt + s2];
+#pragma unroll
+                                for (int jj = 0; jj < 4; ++jj) pw[jj] &= ~drop_fields(drop_mix(rq + c4[jj]), thr2);
+                                pf = __builtin_bit_cast(bf16x8, pw);
+                            }
+                            pd[2 * kt + s2] = pf;
+                        }
+                } else {
+#pragma unroll
+                    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) st[kt][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(st[kt][r], p.c, -lse2));
+                    if (DROP) {
+#pragma unroll
+                        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                            for (int r = 0; r < 16; r += 2) {
+                                const unsigned u = drop_mix(rq + ctab[2 * kt + (r >> 3)][(r & 7) >> 1]);
+                                const float t0 = (short)(u & 0xffffu) >= ths ? p.inv_keep : 0.f, t1 = (int)u >= thr_hi ? p.inv_keep : 0.f;
+                                st[kt][r] *= __builtin_fmaf(dp[kt][r], t0, -dlt);
+                                st[kt][r + 1] *= __builtin_fmaf(dp[kt][r + 1], t1, -dlt);
+                            }
+                    } else {
+#pragma unroll
+                        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) st[kt][r] *= (dp[kt][r] - dlt);
+                    }
+#pragma unroll
+                    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                        for (int s2 = 0; s2 < 2; ++s2) pd[2 * kt + s2] = pack8(st[kt], s2);
+                }
+                sprev = sj;
+                sj = sj == 2 ? 0 : sj + 1;
+            }
+        }
+        if (ph & 1) {           // odd phase 2 jc - 1: tile jc into its slot (fetched two phases ago), fetch tile jc + 1
+            if (jc < nb) commit(cslot, jc, kreg, vreg);
+            ++jc;
+            cslot = cslot == 2 ? 0 : cslot + 1;
+            kreg = gtile(kbase, jc);
+            vreg = gtile(vbase, jc);
+        }
+        __syncthreads();
+    }
+
+    if (p.nsplit > 1) {
+        const long row = (((long)split * p.B + b) * p.H + hh) * N + q;
+        if (qok) {
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) p.po[row * DH + dt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h] = o[dt][r];
+        }
+        if (MODE == 0) {
+            if (qok && h == 0) { p.pm[row] = m_run; p.pl[row] = lacc[0]; }
+        }
+        return;
+    }
+    float f;
+    if (MODE == 0) {
+        const float l_tot = lacc[0];
+        f = p.inv_keep / l_tot;
+        if (qok && h == 0) p.lse[((long)b * p.H + hh) * N + q] = m_run + __builtin_amdgcn_logf(l_tot);
+    } else {
+        f = p.scale;
+    }
+    char* obuf = lds + wv * (32 * RS);            // [32 queries][64 d] bf16 per wave (the rings are free after the last barrier)
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            union { bf16_t hv[4]; uint2 u; } t;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) t.hv[j] = (bf16_t)(o[dt][4 * g4 + j] * f);
+            *reinterpret_cast<uint2*>(obuf + (lane & 31) * RS + (dt * 32 + 8 * g4 + 4 * h) * 2) = t.u;
+        }
+    __syncthreads();
+    bf16_t* dst = (MODE == 0) ? p.out + (long)b * N * (p.H * DH) + hh * DH : p.dqkv + (long)b * N * rs + hh * DH;
+    const long drs = (MODE == 0) ? (long)p.H * DH : rs;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int ci = i * 64 + lane, row = ci >> 3, c8 = ci & 7;
+        if (q0 + row < N)
+            *reinterpret_cast<u32x4*>(dst + (long)(q0 + row) * drs + c8 * 8) = *reinterpret_cast<const u32x4*>(obuf + row * RS + c8 * 16);
+    }
+}
+
+// --------------------------------------------------------------------------------------------------------------
 // key-major backward kernel: dK, dV.  grid (ceil(N / (32 NW)), H, B); wave w owns keys k0 .. k0+31 and walks the queries in
 // steps of 64 (Q and dO staged in LDS, read by rows for S / dP and transposed for dK^T / dV^T; lse, delta beside them)
-template <int NW>
+template <int NW, bool DROP>
 __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2))) void flash_k_kernel(FlashP p) {
     const unsigned ds0 = p.s0 + (p.soff ? p.soff[0] : 0u), ds1 = p.s1 + (p.soff ? p.soff[1] : 0u);
     constexpr int NT = 64 * NW;
-    constexpr int IMG = BLK * RS, BUF = 2 * IMG + 2 * BLK * 4;
-    extern __shared__ __attribute__((aligned(16))) char lds[];      // [2][Q image | dO image | lse[64] | delta[64]]
+    constexpr int IMG = BLK * RS, BUF = 2 * IMG + 3 * BLK * 4;
+    extern __shared__ __attribute__((aligned(16))) char lds[];      // [2][Q image | dO image | lse[64] | delta[64] | row words[64]]
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, h = lane >> 5;
     const int hh = blockIdx.y, b = blockIdx.z, N = p.N;
     const long rs = 3L * p.H * DH, os = (long)p.H * DH;
@@ -404,14 +733,21 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2))) vo
             vf[s] = *reinterpret_cast<const bf16x8*>(qb + (long)key * rs + 2 * p.H * DH + 16 * s + 8 * h);
         }
     }
-    const unsigned npair = (unsigned)(N + 1) >> 1;
     const unsigned bhrow = (unsigned)(b * p.H + hh) * (unsigned)N;
-    const unsigned kpair = (unsigned)key >> 1;
     const int khalf = key & 1;
+    // dropout: the pair half of every word of this lane's key, once; the row halves of a block's 64 queries come from LDS
+    const unsigned ck = DROP ? pair_word((unsigned)key >> 1, ds0, ds1) : 0u;
+    const short ths = (short)((int)p.thr - 32768);
+    const int thr_hi = ((int)p.thr - 32768) * 65536;
+    // lanes 2i, 2i + 1 (keys 2 kp, 2 kp + 1, the same queries) share a word per query: each forms the word of every other row (2 jp + khalf)
+    // and takes the neighbour's through a quad permute; v_perm_b32 then puts THIS key's field of row 2 jp into the high half of one
+    // register and that of row 2 jp + 1 into the low half (selector bytes: 0-3 = the neighbour's word, 4-7 = the own one)
+    const unsigned psel = khalf ? 0x03020706u : 0x05040100u;
 
     f32x16 dk[2] = {zero16(), zero16()}, dv[2] = {zero16(), zero16()};       // dK^T[d][key], dV^T[d][key]
     u32x4 qr[512 / NT], dr[512 / NT];
     float lr = 0.f, tr = 0.f;                             // thread tid < 64: lse / delta of query q0 + tid
+    unsigned rw = 0u;                                     // ... and the row half of its dropout words
     auto fetch_rows = [&](int q0) {
         fetch_tile<NT>(qr, qb, rs, q0, N, tid);
         fetch_tile<NT>(dr, dob, os, q0, N, tid);
@@ -419,6 +755,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2))) vo
             const bool ok = q0 + tid < N;
             lr = ok ? lseb[q0 + tid] : INFINITY;           // exp2(. - inf) = 0: queries past N contribute nothing
             tr = ok ? dltb[q0 + tid] : 0.f;
+            if (DROP) rw = row_word(bhrow + (unsigned)(q0 + tid), ds0, ds1);
         }
     };
     auto commit_rows = [&](char* buf) {
@@ -427,6 +764,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2))) vo
         if (tid < BLK) {
             reinterpret_cast<float*>(buf + 2 * IMG)[tid] = lr;
             reinterpret_cast<float*>(buf + 2 * IMG + BLK * 4)[tid] = tr;
+            if (DROP) reinterpret_cast<unsigned*>(buf + 2 * IMG + 2 * BLK * 4)[tid] = rw;
         }
     };
     fetch_rows(qb0 * BLK);
@@ -438,6 +776,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2))) vo
         const char* dimg = qimg + IMG;
         const float* lsev = reinterpret_cast<const float*>(qimg + 2 * IMG);
         const float* dltv = lsev + BLK;
+        const unsigned* rwv = reinterpret_cast<const unsigned*>(dltv + BLK) + khalf;
         if (qbk + 1 < nblk) fetch_rows((qbk + 1) * BLK);
         const int q0 = qbk * BLK;
 #pragma unroll
@@ -472,28 +811,24 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2))) vo
             for (int g4 = 0; g4 < 4; ++g4) {
                 const f32x4 l4 = *reinterpret_cast<const f32x4*>(lsev + qt * 32 + 8 * g4 + 4 * h);
                 const f32x4 d4 = *reinterpret_cast<const f32x4*>(dltv + qt * 32 + 8 * g4 + 4 * h);
-                bool keep[4] = {true, true, true, true};
-                if (p.thr) {
-                    // lanes 2i, 2i + 1 hold the two keys of one hash word and the same queries: each hashes every other row
-                    // (its own half for itself, the other half to the neighbour through a quad permute)
+                float t4[4] = {1.f, 1.f, 1.f, 1.f};         // keep ? 1 / (1 - p) : 0
+                if (DROP) {
 #pragma unroll
                     for (int jp = 0; jp < 2; ++jp) {
-                        const unsigned qq = (unsigned)(q0 + qt * 32 + 8 * g4 + 4 * h + 2 * jp) + khalf;
-                        const unsigned u = drop_hash((bhrow + qq) * npair + kpair, ds0, ds1);
-                        const unsigned mine = __builtin_amdgcn_ubfe(u, 16u * khalf, 16u), send = __builtin_amdgcn_ubfe(u, 16u - 16u * khalf, 16u);
-                        const unsigned recv = (unsigned)__builtin_amdgcn_update_dpp(0, (int)send, 0xB1, 0xf, 0xf, false);      // quad_perm [1,0,3,2]
-                        const bool km = mine >= p.thr, ko = recv >= p.thr;
-                        keep[2 * jp] = khalf ? ko : km;
-                        keep[2 * jp + 1] = khalf ? km : ko;
+                        const unsigned u = drop_mix(rwv[qt * 32 + 8 * g4 + 4 * h + 2 * jp] + ck);        // row 2 jp + khalf of the group
+                        const unsigned recv = (unsigned)__builtin_amdgcn_update_dpp(0, (int)u, 0xB1, 0xf, 0xf, false);      // quad_perm [1,0,3,2]
+                        const unsigned w = __builtin_amdgcn_perm(u, recv, psel);
+                        t4[2 * jp] = (int)w >= thr_hi ? p.inv_keep : 0.f;
+                        t4[2 * jp + 1] = (short)(w & 0xffffu) >= ths ? p.inv_keep : 0.f;
                     }
                 }
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int r = 4 * g4 + j;
-                    const float pr = kok ? __builtin_amdgcn_exp2f(__builtin_fmaf(sa[r], p.c, -l4[j])) : 0.f;
-                    const float dpv = keep[j] ? da[r] * p.inv_keep : 0.f;
-                    pd[r] = keep[j] ? pr * p.inv_keep : 0.f;
-                    sa[r] = pr * (dpv - d4[j]);               // dS
+                    // (a lane whose key lies past N computes on a zero K row: its column of dK^T / dV^T is its own and is never stored)
+                    const float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(sa[r], p.c, -l4[j]));
+                    pd[r] = pr * t4[j];
+                    sa[r] = pr * __builtin_fmaf(da[r], t4[j], -d4[j]);               // dS = P o (dP_dropped - delta)
                 }
             }
             // ---- dV^T += dO^T . P_dropped,  dK^T += Q^T . dS   (sum over the 32 queries = rows of the accumulators)
@@ -680,6 +1015,13 @@ int pick_nw(int B, int N, int H, int nsplit) {
     return tiles >= 4 * 512 ? 4 : (tiles >= 2 * 256 ? 2 : 1);
 }
 
+// the eight-wave ping-pong kernels: when the launch has at least one 8-wave workgroup per CU (option "flash_pp": 0 off, 1 automatic, 2 always)
+bool use_pp(int B, int N, int H, int nsplit) {
+    if (g_flash_pp == 0) return false;
+    if (g_flash_pp == 2) return true;
+    return (long)((N + 255) / 256) * H * B * nsplit >= 256;
+}
+
 }  // namespace
 
 extern "C" int passion_flash_attn_supported(int dtype, int Dh) { return dtype == PASSION_BF16 && Dh == DH; }
@@ -697,7 +1039,7 @@ extern "C" int passion_flash_attn_fwd(const void* qkv, int B, int N, int H, int 
     const int nsplit = pick_split(B, N, H);
     const int nw = pick_nw(B, N, H, nsplit);
     const dim3 grid((N + 32 * nw - 1) / (32 * nw) * nsplit, H, B);
-    const int bytes = 2 * (BLK * RS + BLK * TS);
+    const int bytes = 2 * (BLK * RS + BLK * TS + 128);
     const size_t rows = (size_t)B * H * N;
     p.nsplit = nsplit;
     if (nsplit > 1) {
@@ -709,12 +1051,31 @@ extern "C" int passion_flash_attn_fwd(const void* qkv, int B, int N, int H, int 
     passion_prof_tag("flash_q_kernel<%d, 0>", nw);
     static bool granted = false;
     if (!granted) {
-        if ((rc = grant_lds(flash_q_kernel<4, 0>, bytes)) || (rc = grant_lds(flash_q_kernel<2, 0>, bytes)) || (rc = grant_lds(flash_q_kernel<1, 0>, bytes))) return rc;
+        if ((rc = grant_lds(flash_q_kernel<4, 0, false>, bytes)) || (rc = grant_lds(flash_q_kernel<2, 0, false>, bytes)) || (rc = grant_lds(flash_q_kernel<1, 0, false>, bytes)) ||
+            (rc = grant_lds(flash_q_kernel<4, 0, true>, bytes)) || (rc = grant_lds(flash_q_kernel<2, 0, true>, bytes)) || (rc = grant_lds(flash_q_kernel<1, 0, true>, bytes))) return rc;
         granted = true;
     }
-    if (nw == 4) hipLaunchKernelGGL((flash_q_kernel<4, 0>), grid, dim3(256), bytes, st, p);
-    else if (nw == 2) hipLaunchKernelGGL((flash_q_kernel<2, 0>), grid, dim3(128), bytes, st, p);
-    else hipLaunchKernelGGL((flash_q_kernel<1, 0>), grid, dim3(64), bytes, st, p);
+    const int pp_bytes = 3 * (BLK * RS + BLK * TS + 128);
+    if (use_pp(B, N, H, nsplit)) {           // eight-wave ping-pong form: the launch fills the chip
+        static bool granted_pp = false;
+        if (!granted_pp) {
+            if ((rc = grant_lds(flash_qpp_kernel<0, false>, pp_bytes)) || (rc = grant_lds(flash_qpp_kernel<0, true>, pp_bytes))) return rc;
+            granted_pp = true;
+        }
+        passion_prof_tag("flash_qpp_kernel<0>");
+        const dim3 gpp((N + 255) / 256 * nsplit, H, B);
+        if (p.thr) hipLaunchKernelGGL((flash_qpp_kernel<0, true>), gpp, dim3(512), pp_bytes, st, p);
+        else hipLaunchKernelGGL((flash_qpp_kernel<0, false>), gpp, dim3(512), pp_bytes, st, p);
+    } else
+    if (p.thr) {
+        if (nw == 4) hipLaunchKernelGGL((flash_q_kernel<4, 0, true>), grid, dim3(256), bytes, st, p);
+        else if (nw == 2) hipLaunchKernelGGL((flash_q_kernel<2, 0, true>), grid, dim3(128), bytes, st, p);
+        else hipLaunchKernelGGL((flash_q_kernel<1, 0, true>), grid, dim3(64), bytes, st, p);
+    } else {
+        if (nw == 4) hipLaunchKernelGGL((flash_q_kernel<4, 0, false>), grid, dim3(256), bytes, st, p);
+        else if (nw == 2) hipLaunchKernelGGL((flash_q_kernel<2, 0, false>), grid, dim3(128), bytes, st, p);
+        else hipLaunchKernelGGL((flash_q_kernel<1, 0, false>), grid, dim3(64), bytes, st, p);
+    }
     LAUNCH_RET();
     if (nsplit > 1) {
         hipLaunchKernelGGL(flash_combine_fwd_kernel, dim3((unsigned)((rows * 8 + 255) / 256)), dim3(256), 0, st, p);
@@ -740,7 +1101,7 @@ extern "C" int passion_flash_attn_bwd(const void* qkv, const void* out, const vo
     const int nsplit = pick_split(B, N, H);
     const int nw = pick_nw(B, N, H, nsplit);
     const dim3 grid((N + 32 * nw - 1) / (32 * nw) * nsplit, H, B);
-    const int qbytes = 2 * (2 * BLK * RS);
+    const int qbytes = 2 * (2 * BLK * RS + 128);
     const size_t rows = (size_t)B * H * N;
     p.nsplit = nsplit;
     float *pq = nullptr, *pk = nullptr;
@@ -751,26 +1112,38 @@ extern "C" int passion_flash_attn_bwd(const void* qkv, const void* out, const vo
     }
     FlashP pkk = p;
     p.po = pq; pkk.po = pk;
-    const int kbytes_min = 2 * (2 * BLK * RS + 2 * BLK * 4);
+    const int kbytes_min = 2 * (2 * BLK * RS + 3 * BLK * 4);
     passion_prof_tag("flash_q_kernel<%d, 1> + flash_k_kernel<%d>", nw, nw);
     static bool granted = false;
     if (!granted) {
         const int kb4 = kbytes_min > 4 * 2 * 32 * RS ? kbytes_min : 4 * 2 * 32 * RS;
-        if ((rc = grant_lds(flash_q_kernel<4, 1>, qbytes)) || (rc = grant_lds(flash_q_kernel<2, 1>, qbytes)) || (rc = grant_lds(flash_q_kernel<1, 1>, qbytes)) ||
-            (rc = grant_lds(flash_k_kernel<4>, kb4)) || (rc = grant_lds(flash_k_kernel<2>, kb4)) || (rc = grant_lds(flash_k_kernel<1>, kb4))) return rc;
+        if ((rc = grant_lds(flash_q_kernel<4, 1, false>, qbytes)) || (rc = grant_lds(flash_q_kernel<2, 1, false>, qbytes)) || (rc = grant_lds(flash_q_kernel<1, 1, false>, qbytes)) ||
+            (rc = grant_lds(flash_q_kernel<4, 1, true>, qbytes)) || (rc = grant_lds(flash_q_kernel<2, 1, true>, qbytes)) || (rc = grant_lds(flash_q_kernel<1, 1, true>, qbytes)) ||
+            (rc = grant_lds(flash_k_kernel<4, false>, kb4)) || (rc = grant_lds(flash_k_kernel<2, false>, kb4)) || (rc = grant_lds(flash_k_kernel<1, false>, kb4)) ||
+            (rc = grant_lds(flash_k_kernel<4, true>, kb4)) || (rc = grant_lds(flash_k_kernel<2, true>, kb4)) || (rc = grant_lds(flash_k_kernel<1, true>, kb4))) return rc;
         granted = true;
     }
     const int kbytes = kbytes_min > nw * 2 * 32 * RS ? kbytes_min : nw * 2 * 32 * RS;      // the epilogue stages 2 x [32][64] per wave
-    if (nw == 4) {
-        hipLaunchKernelGGL((flash_q_kernel<4, 1>), grid, dim3(256), qbytes, st, p);
-        hipLaunchKernelGGL((flash_k_kernel<4>), grid, dim3(256), kbytes, st, pkk);
-    } else if (nw == 2) {
-        hipLaunchKernelGGL((flash_q_kernel<2, 1>), grid, dim3(128), qbytes, st, p);
-        hipLaunchKernelGGL((flash_k_kernel<2>), grid, dim3(128), kbytes, st, pkk);
-    } else {
-        hipLaunchKernelGGL((flash_q_kernel<1, 1>), grid, dim3(64), qbytes, st, p);
-        hipLaunchKernelGGL((flash_k_kernel<1>), grid, dim3(64), kbytes, st, pkk);
+    const bool qpp = use_pp(B, N, H, nsplit);
+    if (qpp) {
+        const int pp_bytes = 3 * (2 * BLK * RS + 128);
+        static bool granted_pp = false;
+        if (!granted_pp) {
+            if ((rc = grant_lds(flash_qpp_kernel<1, false>, pp_bytes)) || (rc = grant_lds(flash_qpp_kernel<1, true>, pp_bytes))) return rc;
+            granted_pp = true;
+        }
+        const dim3 gpp((N + 255) / 256 * nsplit, H, B);
+        if (p.thr) hipLaunchKernelGGL((flash_qpp_kernel<1, true>), gpp, dim3(512), pp_bytes, st, p);
+        else hipLaunchKernelGGL((flash_qpp_kernel<1, false>), gpp, dim3(512), pp_bytes, st, p);
     }
+#define FLASH_BWD(NWV, DR) do { if (!qpp) hipLaunchKernelGGL((flash_q_kernel<NWV, 1, DR>), grid, dim3(64 * NWV), qbytes, st, p); \
+                                hipLaunchKernelGGL((flash_k_kernel<NWV, DR>), grid, dim3(64 * NWV), kbytes, st, pkk); } while (0)
+    if (p.thr) {
+        if (nw == 4) FLASH_BWD(4, true); else if (nw == 2) FLASH_BWD(2, true); else FLASH_BWD(1, true);
+    } else {
+        if (nw == 4) FLASH_BWD(4, false); else if (nw == 2) FLASH_BWD(2, false); else FLASH_BWD(1, false);
+    }
+#undef FLASH_BWD
     LAUNCH_RET();
     if (nsplit > 1) {
         hipLaunchKernelGGL(flash_combine_bwd_kernel, dim3((unsigned)((rows * 8 + 255) / 256)), dim3(256), 0, st, p, (const float*)pq, (const float*)pk);

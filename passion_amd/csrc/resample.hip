@@ -823,6 +823,93 @@ __global__ __launch_bounds__(256) void halo_unpack_kernel(const T* __restrict__ 
     }
 }
 
+// ---- depth sharding, round 5: ONE launch per halo extension / its adjoint, two tiny ones per global InstanceNorm statistic.
+// (The first form built an extended slab from torch.zeros + copy_ + two plane packs + two plane puts, its adjoint from seven
+// launches, the global statistics from ~20 elementwise torch ops on (B, C) tensors: ~17 000 launches per 240 x 240 x 160 step, and
+// the step was bound by them on the host AND on the GPU.)
+// ext (B, n_lo + Dl + n_hi, P): planes below n_lo - 1 and above n_lo + Dl zero; plane n_lo - 1 / n_lo + Dl from the low / high source:
+// mode 0 zeros, 1 a (B, P) buffer (the neighbour's plane), 2 plane `pl` of x itself (reflect at a global end)
+__global__ __launch_bounds__(256) void halo_extend_kernel(const uint4* __restrict__ x, const uint4* __restrict__ lo, const uint4* __restrict__ hi,
+                                                          uint4* __restrict__ ext, int B, int Dl, long P8, int n_lo, int n_hi, int lo_mode, int hi_mode,
+                                                          int lo_pl, int hi_pl) {
+    const int De = n_lo + Dl + n_hi;
+    const long total = (long)B * De * P8;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long e = i % P8, bz = i / P8;
+        const int z = (int)(bz % De);
+        const long b = bz / De;
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (z >= n_lo && z < n_lo + Dl) v = x[(b * Dl + (z - n_lo)) * P8 + e];
+        else if (z == n_lo - 1) { if (lo_mode == 1) v = lo[b * P8 + e]; else if (lo_mode == 2) v = x[(b * Dl + lo_pl) * P8 + e]; }
+        else if (z == n_lo + Dl) { if (hi_mode == 1) v = hi[b * P8 + e]; else if (hi_mode == 2) v = x[(b * Dl + hi_pl) * P8 + e]; }
+        ext[i] = v;
+    }
+}
+
+// adjoint: gx (B, Dl, P) = the owned planes of g (+ the halo plane's gradient folded onto plane fold_lo / fold_hi: reflect at a global end);
+// send (2, B, P) = gradients of the two halo planes (zeros where there is none): they go back to their owners
+template <typename T>
+__global__ __launch_bounds__(256) void halo_extend_bwd_kernel(const T* __restrict__ g, T* __restrict__ gx, T* __restrict__ send, int B, int Dl, long P,
+                                                              int n_lo, int n_hi, int fold_lo, int fold_hi) {
+    constexpr int VE = 16 / (int)sizeof(T);
+    const int De = n_lo + Dl + n_hi;
+    const long PV = P / VE, nown = (long)B * Dl * PV, total = nown + 2L * B * PV;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        if (i < nown) {
+            const long e = i % PV, bd = i / PV;
+            const int d = (int)(bd % Dl);
+            const long b = bd / Dl;
+            union { uint4 u; T t[VE]; } a, c;
+            a.u = *reinterpret_cast<const uint4*>(g + ((b * De + n_lo + d) * P + e * VE));
+            if ((d == fold_lo && n_lo > 0) || (d == fold_hi && n_hi > 0)) {
+                float acc[VE];
+#pragma unroll
+                for (int j = 0; j < VE; ++j) acc[j] = to_f32(a.t[j]);
+                if (d == fold_lo && n_lo > 0) {
+                    c.u = *reinterpret_cast<const uint4*>(g + ((b * De + n_lo - 1) * P + e * VE));
+#pragma unroll
+                    for (int j = 0; j < VE; ++j) acc[j] += to_f32(c.t[j]);
+                }
+                if (d == fold_hi && n_hi > 0) {
+                    c.u = *reinterpret_cast<const uint4*>(g + ((b * De + n_lo + Dl) * P + e * VE));
+#pragma unroll
+                    for (int j = 0; j < VE; ++j) acc[j] += to_f32(c.t[j]);
+                }
+#pragma unroll
+                for (int j = 0; j < VE; ++j) a.t[j] = from_f32<T>(acc[j]);
+            }
+            *reinterpret_cast<uint4*>(gx + i * VE) = a.u;
+        } else if (send) {
+            const long k = i - nown, e = k % PV, sb = k / PV;
+            const int which = (int)(sb / B);
+            const long b = sb % B;
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            if (which == 0 && n_lo > 0) v = *reinterpret_cast<const uint4*>(g + ((b * De + n_lo - 1) * P + e * VE));
+            if (which == 1 && n_hi > 0) v = *reinterpret_cast<const uint4*>(g + ((b * De + n_lo + Dl) * P + e * VE));
+            *reinterpret_cast<uint4*>(send + k * VE) = v;
+        }
+    }
+}
+
+// (mean, rstd) f32 of a rank's slab (n voxels) -> the three moments the ranks sum (double): n, n mean, n (var + mean^2)
+__global__ __launch_bounds__(256) void stats_moments_kernel(const float* __restrict__ st, double* __restrict__ mom, long BC, double n, double eps) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= BC) return;
+    const double mean = st[2 * i], rstd = st[2 * i + 1];
+    double var = 1.0 / (rstd * rstd) - eps;
+    if (var < 0.0) var = 0.0;
+    mom[3 * i] = n; mom[3 * i + 1] = mean * n; mom[3 * i + 2] = (var + mean * mean) * n;
+}
+__global__ __launch_bounds__(256) void moments_stats_kernel(const double* __restrict__ mom, float* __restrict__ st, long BC, double eps) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= BC) return;
+    const double ng = mom[3 * i], gm = mom[3 * i + 1] / ng;
+    double gv = mom[3 * i + 2] / ng - gm * gm;
+    if (gv < 0.0) gv = 0.0;
+    st[2 * i] = (float)gm;
+    st[2 * i + 1] = (float)(1.0 / sqrt(gv + eps));
+}
+
 }  // namespace
 
 // 32-bit index arithmetic unless the tensor (or the grid-stride overshoot) would overflow it
@@ -1036,6 +1123,51 @@ extern "C" int passion_halo_pack(const void* x, void* buf, int dtype, int B, int
     const long P8 = P * es / 16, total = (long)B * P8;
     const int blocks = (int)hmin((total + 255) / 256, 8192);
     hipLaunchKernelGGL(halo_pack_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float*)x, (float*)buf, B, D, P8, d);
+    LAUNCH_RET();
+    return 0;
+}
+
+extern "C" int passion_halo_extend(const void* x, const void* lo, const void* hi, void* ext, int dtype, int B, int Dl, int64_t P, int n_lo, int n_hi,
+                                   int lo_mode, int hi_mode, int lo_pl, int hi_pl, void* stream) {
+    const int es = dtype == PASSION_BF16 ? 2 : 4;
+    if (B < 1 || Dl < 1 || n_lo < 0 || n_hi < 0 || (P * es) % 16) return -1011;
+    if ((lo_mode == 1 && !lo) || (hi_mode == 1 && !hi) || (lo_mode == 2 && (lo_pl < 0 || lo_pl >= Dl)) || (hi_mode == 2 && (hi_pl < 0 || hi_pl >= Dl))) return -1011;
+    if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(ext) | reinterpret_cast<uintptr_t>(lo) | reinterpret_cast<uintptr_t>(hi)) & 15) return -1005;
+    const long P8 = P * es / 16, total = (long)B * (n_lo + Dl + n_hi) * P8;
+    const int blocks = (int)hmin((total + 255) / 256, 16384);
+    hipLaunchKernelGGL(halo_extend_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const uint4*)x, (const uint4*)lo, (const uint4*)hi, (uint4*)ext,
+                       B, Dl, P8, n_lo, n_hi, lo_mode, hi_mode, lo_pl, hi_pl);
+    LAUNCH_RET();
+    return 0;
+}
+
+extern "C" int passion_halo_extend_bwd(const void* g, void* gx, void* send, int dtype, int B, int Dl, int64_t P, int n_lo, int n_hi, int fold_lo, int fold_hi,
+                                       void* stream) {
+    const int es = dtype == PASSION_BF16 ? 2 : 4;
+    if (B < 1 || Dl < 1 || n_lo < 0 || n_hi < 0 || (P * es) % 16) return -1011;
+    if ((reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(gx) | reinterpret_cast<uintptr_t>(send)) & 15) return -1005;
+    const long total = ((long)B * Dl + 2L * B) * (P * es / 16);
+    const int blocks = (int)hmin((total + 255) / 256, 16384);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == PASSION_F32)
+        hipLaunchKernelGGL(halo_extend_bwd_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)g, (float*)gx, (float*)send, B, Dl, (long)P, n_lo, n_hi, fold_lo, fold_hi);
+    else if (dtype == PASSION_BF16)
+        hipLaunchKernelGGL(halo_extend_bwd_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, (const bf16_t*)g, (bf16_t*)gx, (bf16_t*)send, B, Dl, (long)P, n_lo, n_hi, fold_lo, fold_hi);
+    else
+        return -1007;
+    LAUNCH_RET();
+    return 0;
+}
+
+extern "C" int passion_stats_to_moments(const float* stats, double* mom, int64_t BC, double n, double eps, void* stream) {
+    if (BC < 1) return -1011;
+    hipLaunchKernelGGL(stats_moments_kernel, dim3((unsigned)((BC + 255) / 256)), dim3(256), 0, (hipStream_t)stream, stats, mom, (long)BC, n, eps);
+    LAUNCH_RET();
+    return 0;
+}
+extern "C" int passion_moments_to_stats(const double* mom, float* stats, int64_t BC, double eps, void* stream) {
+    if (BC < 1) return -1011;
+    hipLaunchKernelGGL(moments_stats_kernel, dim3((unsigned)((BC + 255) / 256)), dim3(256), 0, (hipStream_t)stream, mom, stats, (long)BC, eps);
     LAUNCH_RET();
     return 0;
 }

@@ -21,6 +21,7 @@ activation (dim 1 of the channels-last tensors) at every level; what couples the
 `sharded_step_loss` is the plain (non-PASSION) mmformer training forward in this mode; tests/test_depth_*.py hold it against the
 unsharded model (world 2, gloo rehearsal transport on one GPU).  Unmeasured on multi-GPU hardware.
 """
+import os
 from ctypes import byref, c_void_p
 
 import torch
@@ -35,9 +36,16 @@ class DepthCtx:
     """rank r of `world` owns planes [r * D / world, (r + 1) * D / world) of every level (D divisible by world at every level it
     is split; below that the caller gathers)"""
 
-    def __init__(self, rank=None, world=None, group=None, loopback=False):
+    def __init__(self, rank=None, world=None, group=None, loopback=False, halo_by_gather=None):
         self.group = group
-        self.loopback = loopback         # world 1: exchange() still goes through batch_isend_irecv, every plane sent to this rank itself
+        self.loopback = loopback         # world 1: exchange() still goes through the transport, every plane sent to this rank itself
+        # halo planes through ONE all_gather of every rank's (first, last) plane instead of grouped send / recv pairs: what a recorded
+        # step needs on this stack -- batch_isend_irecv under stream capture segfaults (ROCm 7.2 / torch 2.10 / RCCL 2.26,
+        # tools/rccl_capture_probe.py micro_p2p), all_reduce / all_gather record and replay.  world x the bytes of the point-to-point
+        # form (planes are <= 1 MB); GraphedDepthStep turns it on, PASSION_DEPTH_HALO=gather|p2p forces either
+        env = os.environ.get("PASSION_DEPTH_HALO")
+        self.halo_by_gather = (env == "gather") if env in ("gather", "p2p") else bool(halo_by_gather)
+        self.n_exchange = self.n_allreduce = 0          # collectives issued (per step: read and reset by the caller)
         self.rank = dist.get_rank(group) if rank is None else rank
         self.world = dist.get_world_size(group) if world is None else world
         self.backend = dist.get_backend(group) if dist.is_initialized() else "none"
@@ -51,13 +59,27 @@ class DepthCtx:
         return self.rank + 1 if self.rank < self.world - 1 else None
 
     def all_reduce(self, t):
-        if self.world > 1:
+        # loopback (world 1 on the real transport): the SUM over one rank is the identity, the CALL is the one every rank of an N > 1
+        # job issues -- what tests/test_rccl_world1_gpu.py and the recorded step (GraphedDepthStep) exercise on a one-GPU box
+        if self.world > 1 or (self.loopback and dist.is_initialized()):
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+            self.n_allreduce += 1
         return t
 
     def exchange(self, to_lo, to_hi):
         """send `to_lo` / `to_hi` to the neighbours, return what they sent (None at the global ends).  Point-to-point; the gloo
         rehearsal transport cannot move device tensors, so there the planes travel through host memory."""
+        if self.halo_by_gather and dist.is_initialized() and (self.world > 1 or self.loopback) and not (self.backend == "gloo" and to_lo.is_cuda):
+            mine = torch.stack([to_lo, to_hi])                                  # (2, B', P)
+            every = torch.empty((self.world,) + tuple(mine.shape), dtype=mine.dtype, device=mine.device)
+            dist.all_gather_into_tensor(every, mine, group=self.group)
+            self.n_exchange += 1
+            if self.world == 1:
+                self.last_loopback = (every[0, 0], every[0, 1])
+                return None, None
+            # the low neighbour's LAST plane is my low halo, the high neighbour's FIRST plane my high halo
+            return (every[self.rank - 1, 1] if self.lo is not None else None), (every[self.rank + 1, 0] if self.hi is not None else None)
+        self.n_exchange += 1 if (self.world > 1 or self.loopback) else 0
         if self.world == 1 and self.loopback and dist.is_initialized():
             # the calls of the N > 1 path against the real transport on a one-GPU box: a grouped send / recv pair per direction,
             # peer = this rank; what comes back is what was sent (the caller's ends stay global ends: the planes are dropped)
@@ -112,18 +134,39 @@ def _put_plane(buf, y, d, accumulate):
         y[:, d] = buf.view(y[:, d].shape)
 
 
+def _exchange_active(shard):
+    return shard.world > 1 or (shard.loopback and dist.is_initialized())
+
+
 class HaloExtendFn(torch.autograd.Function):
     """(B', Dl, ...) slab -> (B', n_lo + Dl + n_hi, ...): n_hi in {0, 1} planes from the high neighbour, n_lo in {0, 1, 2} from the
     low one (2 = one zero plane in front of the halo plane: the stride-2 convs read planes 2j-1 .. 2j+1; 0 / n_hi = 0 at a global
     end of a ZERO-padded pre-norm conv: its padding is zero AFTER norm + activation, so there the conv's own padding is used and
     no plane is added).  At the global ends of the other ops the halo plane is reflect (plane 1 / Dl-2) or zeros.
     hi_used: the op reads a high halo at all (stride-1 convs, upsampling) -- tells the backward whether the low neighbour sent a
-    gradient for my first plane."""
+    gradient for my first plane.
+    GPU tensors (round 5): the extended slab is ONE launch (passion_halo_extend: owned planes, both halo planes from their sources,
+    zero planes), its adjoint one more (passion_halo_extend_bwd: owned planes + reflect folds + the two send planes); the first
+    form's torch.zeros / copy_ / plane packs / plane puts were ~13 launches per conv and direction."""
 
     @staticmethod
     def forward(ctx, x, shard, reflect, n_lo, n_hi, hi_used=True):
         x = x.contiguous()
         Dl = x.shape[1]
+        ctx.shard, ctx.reflect, ctx.n_lo, ctx.n_hi, ctx.Dl, ctx.hi_used = shard, reflect, n_lo, n_hi, Dl, hi_used
+        ctx.fast = x.is_cuda and Dl > 1 and (x[0, 0].numel() * x.element_size()) % 16 == 0
+        if ctx.fast:
+            Bp, P = x.shape[0], x[0, 0].numel()
+            r_lo = r_hi = None
+            if _exchange_active(shard):
+                r_lo, r_hi = shard.exchange(_plane(x, 0), _plane(x, Dl - 1))
+            ext = torch.empty((Bp, n_lo + Dl + n_hi) + tuple(x.shape[2:]), dtype=x.dtype, device=x.device)
+            lo_mode = 0 if not n_lo else (1 if r_lo is not None else (2 if reflect else 0))
+            hi_mode = 0 if not n_hi else (1 if r_hi is not None else (2 if reflect else 0))
+            L.check(L.load().passion_halo_extend(_p(x), _p(r_lo) if lo_mode == 1 else c_void_p(0), _p(r_hi) if hi_mode == 1 else c_void_p(0), _p(ext),
+                                                 L.dtype_code(x.dtype), Bp, Dl, P, n_lo, n_hi, lo_mode, hi_mode, 1, Dl - 2, L.stream_ptr()),
+                    "passion_halo_extend")
+            return ext
         ext = torch.zeros((x.shape[0], n_lo + Dl + n_hi) + tuple(x.shape[2:]), dtype=x.dtype, device=x.device)
         ext[:, n_lo:n_lo + Dl].copy_(x)
         r_lo, r_hi = shard.exchange(_plane(x, 0), _plane(x, Dl - 1))       # my first plane goes down, my last plane goes up
@@ -139,13 +182,29 @@ class HaloExtendFn(torch.autograd.Function):
                 _put_plane(r_hi, ext, n_lo + Dl, False)
             elif reflect:
                 _put_plane(_plane(x, Dl - 2) if Dl > 1 else r_lo, ext, n_lo + Dl, False)
-        ctx.shard, ctx.reflect, ctx.n_lo, ctx.n_hi, ctx.Dl, ctx.hi_used = shard, reflect, n_lo, n_hi, Dl, hi_used
         return ext
 
     @staticmethod
     def backward(ctx, g):
         shard, n_lo, n_hi, Dl = ctx.shard, ctx.n_lo, ctx.n_hi, ctx.Dl
         g = g.contiguous()
+        if ctx.fast:
+            Bp, P = g.shape[0], g[0, 0].numel()
+            gx = torch.empty((Bp, Dl) + tuple(g.shape[2:]), dtype=g.dtype, device=g.device)
+            active = _exchange_active(shard)
+            send = torch.empty(2, Bp, P, dtype=g.dtype, device=g.device) if active else None
+            # a halo plane that was a reflection of my own plane 1 / Dl - 2 (global end): its gradient folds onto that plane
+            fold_lo = 1 if (ctx.reflect and n_lo and shard.lo is None) else -1
+            fold_hi = Dl - 2 if (ctx.reflect and n_hi and shard.hi is None) else -1
+            L.check(L.load().passion_halo_extend_bwd(_p(g), _p(gx), _p(send) if active else c_void_p(0), L.dtype_code(g.dtype), Bp, Dl, P, n_lo, n_hi,
+                                                     fold_lo, fold_hi, L.stream_ptr()), "passion_halo_extend_bwd")
+            if active:
+                r_lo, r_hi = shard.exchange(send[0], send[1])
+                if r_hi is not None:                  # the high neighbour's low halo was my last plane
+                    _put_plane(r_hi, gx, Dl - 1, True)
+                if r_lo is not None and ctx.hi_used:  # the low neighbour's high halo was my first plane
+                    _put_plane(r_lo, gx, 0, True)
+            return gx, None, None, None, None, None
         gx = g[:, n_lo:n_lo + Dl].contiguous()
         # gradient of the halo planes: back to their owners (the low halo is the low neighbour's LAST plane)
         zero = torch.zeros(g.shape[0], g[0, 0].numel(), dtype=g.dtype, device=g.device)
@@ -167,6 +226,30 @@ class HaloExtendFn(torch.autograd.Function):
             if shard.hi is None and n_hi:
                 _put_plane(g_hi, gx, Dl - 2, True)
         return gx, None, None, None, None, None
+
+
+class CropDFn(torch.autograd.Function):
+    """planes [o0, o0 + n) of a (B', D, ...) tensor (the output planes of an extended slab this rank owns); backward: the gradient
+    with zero planes around it in ONE launch (autograd's slice backward is zeros + copy_: two launches, twice the bytes)"""
+
+    @staticmethod
+    def forward(ctx, y, o0, n):
+        ctx.o0, ctx.n, ctx.D = o0, n, y.shape[1]
+        return y[:, o0:o0 + n].contiguous()       # one sample: a view
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous()
+        Bp, P = g.shape[0], g[0, 0].numel()
+        n_lo, n_hi = ctx.o0, ctx.D - ctx.o0 - ctx.n
+        if not g.is_cuda or (P * g.element_size()) % 16:
+            out = torch.zeros((Bp, ctx.D) + tuple(g.shape[2:]), dtype=g.dtype, device=g.device)
+            out[:, ctx.o0:ctx.o0 + ctx.n].copy_(g)
+            return out, None, None
+        out = torch.empty((Bp, ctx.D) + tuple(g.shape[2:]), dtype=g.dtype, device=g.device)
+        L.check(L.load().passion_halo_extend(_p(g), c_void_p(0), c_void_p(0), _p(out), L.dtype_code(g.dtype), Bp, ctx.n, P, n_lo, n_hi, 0, 0, 0, 0,
+                                             L.stream_ptr()), "passion_halo_extend")
+        return out, None, None
 
 
 class GatherDFn(torch.autograd.Function):
@@ -191,9 +274,22 @@ class GatherDFn(torch.autograd.Function):
 
 def global_stats(x, shard, eps=1e-5):
     """InstanceNorm (mean, rstd) per (b, c) over the WHOLE volume from the ranks' slabs: local statistics kernel, then one
-    all-reduce of (n, sum x, sum x^2) in double -- SURVEY 8e "per IN: all-reduce of (sum x, sum x^2) * C floats" """
-    st = ops.instnorm_stats(x.detach(), eps).double()                       # (B, C, 2) = mean, rstd of the slab
+    all-reduce of (n, n mean, n (var + mean^2)) in double -- SURVEY 8e "per IN: all-reduce of (sum x, sum x^2) * C floats".
+    GPU: two tiny launches around the all-reduce (passion_stats_to_moments / passion_moments_to_stats); a single rank without a
+    transport has nothing to combine."""
+    st = ops.instnorm_stats(x.detach(), eps)                                # (B, C, 2) = mean, rstd of the slab
+    if not _exchange_active(shard):
+        return st
     n = float(x[0, ..., 0].numel())                                         # voxels of THIS rank's slab (slabs may differ in size)
+    if x.is_cuda:
+        BC = st.shape[0] * st.shape[1]
+        mom = torch.empty(st.shape[0], st.shape[1], 3, dtype=torch.float64, device=x.device)
+        L.check(L.load().passion_stats_to_moments(_p(st), _p(mom), BC, n, float(eps), L.stream_ptr()), "passion_stats_to_moments")
+        shard.all_reduce(mom)
+        out = torch.empty_like(st)
+        L.check(L.load().passion_moments_to_stats(_p(mom), _p(out), BC, float(eps), L.stream_ptr()), "passion_moments_to_stats")
+        return out
+    st = st.double()
     mean, var = st[..., 0], (st[..., 1].pow(-2) - eps).clamp_min(0)
     # parallel-variance combination in double (Chan et al.): all-reduce (n, n * mean, M2 + n * mean^2); the between-rank term
     # sum n_r (mean_r - mean_g)^2 is formed from the reduced moments, so only the ranks' DIFFERENCES of means meet in it
@@ -420,8 +516,8 @@ def conv(mod, feats, shard, Dg, norm=True, residual=None, out_dtype=None):
     y = ShardedConvFn.apply(cfg, shard, win, Dg_ext, mod.weight, mod.bias, packed, *[s.x for s in segs])
     if k == 3:
         o0 = 1 if stride == 2 else n_lo
-        y = y[:, o0:o0 + (Dl // stride)]                      # drop the output planes that belong to the neighbours
-    y = y.contiguous()
+        if y.shape[1] != Dl // stride:
+            y = CropDFn.apply(y, o0, Dl // stride)            # drop the output planes that belong to the neighbours
     if residual is not None:
         y = y + residual
     return Slab(y, shard)
@@ -583,3 +679,46 @@ def sharded_step_loss(model, shard, x, mask, target, Dg, temp=4.0, state=None):
     loss = fuse + (rp_mask * beta * w * red(sep_loss)).sum() + prm_loss.sum() + 0.5 * (beta * w * red(kl_loss)).sum() \
         + 0.1 * (rp_mask * w * red(proto_loss)).sum()
     return loss, pred, prm_loss, sep_loss, kl_loss, proto_loss, dist
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# the sharded training step, eager and as ONE HIP graph
+# ------------------------------------------------------------------------------------------------------------------
+def sharded_train_step(model, optimizer, shard, x, mask, target, Dg, temp=4.0, state=None, reducer=None):
+    """one iteration on this rank's slab: sharded forward + loss, backward (halo gradients, InstanceNorm-backward sums and gathered
+    tokens exchanged inside it), SUM of the weight gradients over the ranks, AdamW.  -> loss (detached; equal on every rank)"""
+    host = L.host() if x.is_cuda else None
+    direct = host is not None and (reducer is None or not reducer.active)      # as train.train_step: no AccumulateGrad nodes in one process
+    model.is_training = True
+    if direct:
+        host.set_direct_grads(True)
+        ops._DIRECT[0] = True
+    try:
+        loss = sharded_step_loss(model, shard, x, mask, target, Dg, temp, state)[0]
+        optimizer.zero_grad()
+        loss.backward()
+    finally:
+        if direct:
+            host.set_direct_grads(False)
+            ops._DIRECT[0] = False
+    if reducer is not None:
+        reducer.all_reduce_grads()
+    optimizer.step()
+    return loss.detach()
+
+
+def GraphedDepthStep(model, optimizer, shard, Dg, temp=4.0, state=None, reducer=None, warm=2):
+    """The sharded step recorded ONCE as a HIP graph and replayed (graph.GraphedStep with this step as its body): the eager form
+    needs ~84 ms of host time per 240x240x160 volume -- per conv a halo pack / exchange / unpack, per InstanceNorm tensor a statistics
+    all-reduce, a two-phase backward around the all-reduce of its sums, all issued from Python -- whatever the slab size, so it could
+    not scale with the number of GPUs.  Recorded, the host's share is one hipGraphLaunch; the RCCL calls (batch_isend_irecv of the
+    halo planes, all_reduce of the sums, all_gather of the level-5 tokens, the gradient buckets) are nodes of the same graph: torch's
+    ProcessGroupNCCL runs them on its own stream behind events, which stream capture follows like any other fork."""
+    from .graph import GraphedStep
+
+    if os.environ.get("PASSION_DEPTH_HALO") != "p2p":
+        shard.halo_by_gather = True          # from the first (eager) call on: the recorded step and its warm-up issue the same collectives
+
+    def body(x, mask, target):
+        return sharded_train_step(model, optimizer, shard, x, mask, target, Dg, temp, state, reducer)
+    return GraphedStep(model, optimizer, temp, state, warm=warm, reducer=reducer, step_fn=body)

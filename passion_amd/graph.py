@@ -24,6 +24,7 @@ The all-reduce is not overlapped with the backward in this mode (PASSION_DDP_BF1
 relative-preference gate is a 4-float all-reduce inside the loss assembly, such steps stay eager for N > 1.
 """
 import ctypes
+import os
 from ctypes import c_void_p
 
 import torch
@@ -33,17 +34,32 @@ from . import train as ptrain
 
 
 class GraphedStep:
-    def __init__(self, model, optimizer, temp=4.0, state=None, warmup=False, modal_num=None, iter_per_epoch=None, warm=3, reducer=None):
+    def __init__(self, model, optimizer, temp=4.0, state=None, warmup=False, modal_num=None, iter_per_epoch=None, warm=3, reducer=None,
+                 step_fn=None, record_collectives=None):
         if not hasattr(optimizer, "begin_capture"):
             raise L.PassionHipError("GraphedStep needs passion_amd.optim.FusedAdamW (train.make_optimizer on a GPU model)")
         self.model, self.optimizer = model, optimizer
-        self.hybrid = reducer is not None and getattr(reducer, "active", False)
+        active = reducer is not None and getattr(reducer, "active", False)
+        # record_collectives: the RCCL calls of the step (gradient buckets, PASSION's 4-float gate, the depth path's halo planes and
+        # InstanceNorm sums) are recorded INTO the graph -- torch's ProcessGroupNCCL issues them on its own stream behind events, which
+        # stream capture follows like any other fork (tools/rccl_capture_probe.py: all_reduce / all_gather / batch_isend_irecv under
+        # torch.cuda.graph on this stack).  Default (None): PASSION_GRAPH_COLLECTIVES=1 or a custom step body.
+        if record_collectives is None:
+            record_collectives = step_fn is not None or os.environ.get("PASSION_GRAPH_COLLECTIVES") == "1"
+        self.full = bool(active and record_collectives)          # N > 1, everything in ONE recording
+        self.hybrid = active and not self.full
         if self.hybrid and model.use_passion:
-            raise L.PassionHipError("GraphedStep with a gradient reducer records plain training steps only (PASSION's gate is a collective)")
+            raise L.PassionHipError("GraphedStep (hybrid) with a gradient reducer records plain training steps only: PASSION's gate is a "
+                                    "collective (record_collectives=True / PASSION_GRAPH_COLLECTIVES=1 records it)")
         self.reducer = reducer
-        self.kw = dict(temp=temp, state=state, reducer=reducer if self.hybrid else None, warmup=warmup, modal_num=modal_num,
+        self.step_fn = step_fn           # callable(x, mask, target) -> loss: ONE whole iteration (depth.GraphedDepthStep); None = train.train_step
+        self.state = state
+        self.kw = dict(temp=temp, state=state, reducer=reducer if active else None, warmup=warmup, modal_num=modal_num,
                        iter_per_epoch=iter_per_epoch)
-        self.warm = int(warm)
+        # the first calls run eagerly on the recording's stream: AdamW creates its moment tensors, the library its per-stream scratch, the
+        # conv weights their packed images.  Recorded instead, those allocations and their zero-fills would become graph nodes (every
+        # replay re-zeroing the moments) -- so at least one eager call is not negotiable
+        self.warm = max(1, int(warm))
         self.calls = 0
         self.graph = None
         self.stream = None
@@ -53,15 +69,20 @@ class GraphedStep:
     # ------------------------------------------------------------------------------------------
     def _signature(self, x, mask, target):
         m = self.model
+        st = self.state
+        # the recording holds ADDRESSES: of the loss state's tensors (LossState updates them in place; a rebound tensor would leave the
+        # replay reading a freed allocation) -- and values that were python scalars when it was made (warmup, temp)
+        st_sig = None if st is None else (st.imb_beta.data_ptr(), st.modal_weight.data_ptr(), st.epoch_dist_m.data_ptr())
         return (tuple(x.shape), x.dtype, tuple(mask.shape), tuple(target.shape), target.dtype, m.mask_type, bool(m.use_passion),
-                m.compute_dtype, bool(m.training))
+                m.compute_dtype, bool(m.training), bool(self.kw["warmup"]), float(self.kw["temp"]), st_sig)
 
     def _eager(self, x, mask, target):
         dev = x.device
         cur = torch.cuda.current_stream(dev)
         self.stream.wait_stream(cur)
         with torch.cuda.stream(self.stream):
-            loss = ptrain.train_step(self.model, self.optimizer, x, mask, target, **self.kw)
+            loss = self.step_fn(x, mask, target) if self.step_fn is not None else \
+                ptrain.train_step(self.model, self.optimizer, x, mask, target, **self.kw)
         cur.wait_stream(self.stream)
         return loss
 
@@ -74,21 +95,42 @@ class GraphedStep:
         torch.cuda.synchronize(dev)
         g = torch.cuda.CUDAGraph()
         lib.passion_set_step_words(c_void_p(self.words.data_ptr()))
+        if len(self.optimizer.state) == 0:
+            raise L.PassionHipError("GraphedStep: the optimizer has no state yet -- its moment tensors would be created (and zero-filled on "
+                                    "every replay) inside the recording; run an eager step first")
         if not self.hybrid:
             self.optimizer.begin_capture(self.hyper)
         else:
             self.reducer.suspended = True
+        import torch.distributed as dist
+        pg_up = dist.is_available() and dist.is_initialized()
+        if pg_up and dist.get_backend() == "nccl":
+            # the collective backend's watchdog thread polls the end events of the eager steps' collectives (every 100 ms); an event query
+            # that meets a stream which has meanwhile begun capturing is refused on this stack (hipErrorCapturedEvent) and takes the
+            # process down (tools/rccl_capture_probe.py depthc at 32 x 48 x 48: the small volume's warm-up ends milliseconds before the
+            # recording starts).  Everything is complete (synchronize above): let the watchdog retire it first
+            import time
+            time.sleep(0.35)
+        ok = False
         try:
-            # hybrid (a process group is up): thread-local capture rules, so that what the collective backend's watchdog thread
+            # a process group is up: thread-local capture rules, so that what the collective backend's watchdog thread
             # calls meanwhile (event queries on finished work) is neither refused nor able to invalidate this recording
-            with torch.cuda.graph(g, stream=self.stream, capture_error_mode="thread_local" if self.hybrid else "global"):
+            with torch.cuda.graph(g, stream=self.stream, capture_error_mode="thread_local" if pg_up else "global"):
                 # a view: ops.target_to_cl keeps the converted copy on the tensor OBJECT it is given
-                self.loss = ptrain.train_step(self.model, self.optimizer, self.sx, self.smask, self.starget.view(self.starget.shape),
-                                              phase="fb" if self.hybrid else "all", **self.kw)
+                tv = self.starget.view(self.starget.shape)
+                if self.step_fn is not None:
+                    self.loss = self.step_fn(self.sx, self.smask, tv)
+                else:
+                    self.loss = ptrain.train_step(self.model, self.optimizer, self.sx, self.smask, tv,
+                                                  phase="fb" if self.hybrid else "all", **self.kw)
+            ok = True
         finally:
             lib.passion_set_step_words(None)
             if not self.hybrid:
                 self.cap = self.optimizer.end_capture()
+            elif not ok:
+                self.reducer.suspended = False       # no recording: the caller's eager steps keep their overlapped all-reduce
+        self._tables_id = id(self.optimizer._tables)
         if self.hybrid:          # the gradient tensors the recording writes (its backward assigned them after zero_grad): static from here on
             self.grads = [(p, p.grad) for g_ in self.optimizer.param_groups for p in g_["params"] if p.grad is not None]
         self.graph = g
@@ -100,6 +142,15 @@ class GraphedStep:
             self.smask.copy_(mask, non_blocking=True)
         if target is not self.starget:
             self.starget.copy_(target, non_blocking=True)
+        if id(self.optimizer._tables) != self._tables_id:
+            raise L.PassionHipError("GraphedStep: optimizer.load_state_dict() replaced the moment tensors this recording updates; build a "
+                                    "new GraphedStep")
+        if not self.hybrid and self.step_fn is None:
+            # the recording re-packs the conv weight images BEHIND its optimizer passes (for the next replay's forward): a weight changed
+            # from outside since (load_state_dict, an eager step, weight averaging) is re-packed here, eagerly -- a host-side version
+            # check, no launch when nothing moved
+            from . import ops
+            ops.repack_stale()
         seed = int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())      # CPU generator: follows torch.manual_seed
         w = (ctypes.c_uint32 * 2)(seed & 0xffffffff, (seed >> 32) & 0xffffffff)
         L.check(L.load().passion_write_words(self.words.data_ptr(), 2, ctypes.cast(w, c_void_p), L.stream_ptr()), "passion_write_words")
@@ -107,6 +158,9 @@ class GraphedStep:
             self.optimizer.graph_tick(self.cap)
         self.graph.replay()
         self.replays += 1
+        if not self.hybrid and self.step_fn is None:
+            from . import ops
+            ops.mark_packed_fresh()               # ... the replay has re-packed every image from the weights it wrote (graph_tick moved their versions)
         if self.hybrid:
             for p, g_ in self.grads:          # (the previous tail left views of the reduced buckets there)
                 p.grad = g_

@@ -126,6 +126,19 @@ def repack_stale(only=None, exclude=None):
     return n
 
 
+def mark_packed_fresh():
+    """after a graph replay that re-packed every registered image from the weights it had just written (graph.GraphedStep): the
+    images match the parameters' CURRENT versions -- note that, so that the next repack_stale() only launches for weights somebody
+    changed from outside the recording"""
+    for key in list(_PACK_REGISTRY):
+        ref, cache = _PACK_REGISTRY[key]
+        w = ref()
+        if w is None:
+            del _PACK_REGISTRY[key]
+        elif "packed" in cache:
+            cache["key"] = (w.data_ptr(), w._version)
+
+
 # ------------------------------------------------------------------------------------------------
 # bf16 images of the token-GEMM (nn.Linear) parameters
 # ------------------------------------------------------------------------------------------------

@@ -34,9 +34,9 @@ class LossState:
                 "eta_ext": float(self.eta_ext)}
 
     def load_state_dict(self, sd):
-        dev = self.imb_beta.device
-        self.imb_beta = sd["imb_beta"].to(dev).float()
-        self.modal_weight = sd["modal_weight"].to(dev).float()
+        # in place: a recorded step (graph.GraphedStep) reads these tensors by ADDRESS
+        self.imb_beta.copy_(sd["imb_beta"].to(self.imb_beta.device).float())
+        self.modal_weight.copy_(sd["modal_weight"].to(self.modal_weight.device).float())
         self.eta, self.eta_ext = float(sd["eta"]), float(sd.get("eta_ext", self.eta_ext))
 
     def end_epoch(self, epoch, warmup=False):
@@ -49,7 +49,7 @@ class LossState:
             if epoch % 100 == 0:
                 self.eta *= self.eta_ext
             beta = torch.clamp(self.imb_beta - self.eta * rp_epoch, 0.1, 4.0)
-            self.imb_beta = 2 * beta / beta.pow(2).sum().sqrt()
+            self.imb_beta.copy_(2 * beta / beta.pow(2).sum().sqrt())       # in place: a recorded step reads this tensor by address
         self.epoch_dist_m.zero_()
         return rp_epoch
 
@@ -336,7 +336,7 @@ def main(argv=None):
         for sample_mask in data.samples_masks:
             modal_num += torch.tensor(eval(sample_mask), dtype=torch.float32, device=ctx.device)
         if not resumed_state:
-            state.modal_weight = iter_ref / modal_num
+            state.modal_weight.copy_(iter_ref / modal_num)
     loss = torch.zeros((), device=ctx.device)
     for epoch in range(start_epoch, args.num_epochs):
         # per-epoch random streams (synthetic masks, dropout): epoch e of a resumed run draws what epoch e of the uninterrupted run drew

@@ -74,22 +74,33 @@ def rel(a, b):
     return ((a - b).abs().max() / (b.abs().max() + 1e-12)).item()
 
 
-def flash_keep_mask(B, N, p, seed, H=8):
-    """numpy restatement of drop_hash (flash_attn.hip): keep[b, h, q, key]"""
-    thr = int(p * 65536.0 + 0.5)
-    s0, s1 = np.uint64(seed & 0xffffffff), np.uint64(seed >> 32)
+def _drop_hash(x, s0, s1):
+    """two rounds of (24-bit multiply-add, xorshift) on uint64-held 32-bit words: drop_hash of flash_attn.hip"""
     m32, m24 = np.uint64(0xffffffff), np.uint64(0xffffff)
-    npair = (N + 1) // 2
-    rows = np.arange(B * H * N, dtype=np.uint64)[:, None] * np.uint64(npair)
-    pair = ((rows + np.arange(npair, dtype=np.uint64)[None, :]) & m32)
-    x = (pair ^ s0) & m32
+    x = (x ^ s0) & m32
     x = ((x & m24) * np.uint64(0xB5297A) + (x >> np.uint64(9))) & m32
     x ^= x >> np.uint64(15)
     x = (x + s1) & m32
     x = ((x & m24) * np.uint64(0x68E31D) + (x >> np.uint64(11))) & m32
     x ^= x >> np.uint64(14)
+    return x
+
+
+def flash_keep_mask(B, N, p, seed, H=8):
+    """numpy restatement of the attention-dropout mask of flash_attn.hip: keep[b, h, q, key].  One 32-bit word per (query row, key
+    pair): word = mix(R(row) + C(pair)), R / C two-round hashes of (seed, (b H + h) N + q) / (seed, pair), mix = xorshift + one
+    24-bit multiply-add; key 2 kp takes the low 16-bit field, key 2 kp + 1 the high one; keep = signed field >= thr - 32768"""
+    thr = int(p * 65536.0 + 0.5)
+    s0, s1 = np.uint64(seed & 0xffffffff), np.uint64(seed >> 32)
+    m32, m24 = np.uint64(0xffffffff), np.uint64(0xffffff)
+    npair = (N + 1) // 2
+    R = _drop_hash(np.arange(B * H * N, dtype=np.uint64), s0, s1)
+    C = _drop_hash(np.arange(npair, dtype=np.uint64) ^ np.uint64(0x5BD1E995), s1, (s0 + np.uint64(0x2545F491)) & m32)
+    x = (R[:, None] + C[None, :]) & m32
+    x ^= x >> np.uint64(15)
+    x = ((x & m24) * np.uint64(0x68E31D) + (x >> np.uint64(11))) & m32
     u = np.stack([x & np.uint64(0xffff), x >> np.uint64(16)], -1).reshape(B * H * N, 2 * npair)[:, :N]
-    keep = (u >= thr).reshape(B, H, N, N)
+    keep = (((u + np.uint64(32768)) & np.uint64(0xffff)) >= thr).reshape(B, H, N, N)       # signed 16-bit field >= thr - 32768
     return torch.from_numpy(keep), 1.0 / (1.0 - thr / 65536.0)
 
 

@@ -77,17 +77,32 @@ def test_fixture_argmax_packing_roundtrip():
 
 
 def test_dropout_hash_statistics():
-    """CPU-side property of the mask generator itself (keep rate, independence of neighbours / rows / seeds)"""
-    keep, _ = flash_keep_mask(1, 1024, 0.1, 0x123456789abcdef)
-    k = keep.float().reshape(-1, 1024)
-    assert abs(float(k.mean()) - 0.9) < 2e-3
-    kc = k - k.mean()
-    for lag in (1, 2, 3, 16, 64):
-        assert abs(float((kc[:, :-lag] * kc[:, lag:]).mean() / kc.var())) < 5e-3
-    assert abs(float((kc[:-1] * kc[1:]).mean() / kc.var())) < 5e-3
-    keep2, _ = flash_keep_mask(1, 1024, 0.1, 0x123456789abcdf0)
-    k2 = keep2.float().reshape(-1, 1024)
-    assert abs(float(((k2 - k2.mean()) * kc).mean() / kc.var())) < 5e-3
+    """CPU-side property of the mask generator itself.  A word of the mask is mix(R(row) + C(key pair)) -- a row half and a column half
+    that the kernels form once each (csrc/flash_attn.hip) -- so beside the keep rate the test holds what such a construction could
+    get wrong: correlation along a row (every lag up to 40, and the power-of-two lags), between rows, along diagonals, between the two
+    fields of one word, between seeds; at p = 0.1 (the reference's attn_drop) and at p = 0.5 (where a biased bit shows most)"""
+    N = 1024
+    for p, seed in ((0.1, 0x123456789abcdef), (0.5, 77)):
+        keep, inv = flash_keep_mask(1, N, p, seed)
+        k = keep.float().reshape(-1, N)                       # 8 heads x 1024 rows
+        assert abs(float(k.mean()) - (1 - p)) < 2e-3
+        assert abs(inv - 1.0 / (1.0 - round(p * 65536) / 65536.0)) < 1e-12
+        kc = k - k.mean()
+        v = float(kc.var())
+        tol = 4e-3                                            # noise floor of one estimate: (8 * 1024 * 1024)^-1/2 = 3.5e-4
+        for lag in list(range(1, 41)) + [64, 128, 256, 512]:
+            assert abs(float((kc[:, :-lag] * kc[:, lag:]).mean()) / v) < tol, ("column lag", lag)
+        for lag in list(range(1, 17)) + [32, 64, 1024, 2048]:
+            assert abs(float((kc[:-lag] * kc[lag:]).mean()) / v) < tol, ("row lag", lag)
+        for dr, dc in ((1, 1), (1, 2), (2, 1), (3, 5), (32, 32), (1, 16), (16, 1)):
+            assert abs(float((kc[:-dr, :-dc] * kc[dr:, dc:]).mean()) / v) < tol, ("diagonal", dr, dc)
+        assert abs(float((kc[:, 0::2] * kc[:, 1::2]).mean()) / v) < tol      # the two 16-bit fields of a word
+        # no row and no column is favoured: the spread of their keep rates is the binomial one
+        assert 0.9 < float(k.mean(1).std()) / (p * (1 - p) / N) ** 0.5 < 1.1
+        assert 0.9 < float(k.mean(0).std()) / (p * (1 - p) / k.shape[0]) ** 0.5 < 1.1
+        keep2, _ = flash_keep_mask(1, N, p, seed + 1)
+        k2 = keep2.float().reshape(-1, N)
+        assert abs(float(((k2 - k2.mean()) * kc).mean()) / v) < tol
 
 
 def test_last_global_batch_is_wrap_padded_like_a_dataloader_without_drop_last():

@@ -148,3 +148,94 @@ def test_two_ranks_hybrid_graph_equals_the_eager_two_rank_step(tmp_path):
     assert torch.equal(eager["loss"], graph["loss"]), (eager["loss"], graph["loss"])
     bad = [k for k in eager["p"] if not torch.equal(eager["p"][k], graph["p"][k])]
     assert not bad, bad[:5]
+
+
+# ---- BASELINE.json configs[3]: the RFNet backbone under the same reducer ------------------------------------------------------
+def _rfnet_step(m, opt, rank, dev, red=None):
+    """two AdamW steps of rfnet.Model + PASSION on this rank's own batch of 2 (configs[3]: batch 2 per GPU); -> loss of the second"""
+    from passion_amd import train as ptrain
+    x, target, _ = ptrain.synthetic_batch(2, 32, dev, seed=11 + rank)
+    mask = torch.tensor([[True, False, True, True], [True, True, True, True]], device=dev) if rank == 0 else \
+        torch.tensor([[False, True, True, False], [True, True, False, True]], device=dev)
+    state = ptrain.LossState(dev)
+    loss = None
+    for _ in range(2):
+        loss = ptrain.train_step(m, opt, x, mask, target.view(target.shape), 4.0, state, red)
+    return loss
+
+
+def _rfnet_model(dev):
+    from passion_amd.models import rfnet
+    torch.manual_seed(5)
+    m = rfnet.Model(num_cls=4).to(dev)
+    m.mask_type, m.use_passion, m.compute_dtype = "idt", True, torch.bfloat16
+    m.train()
+    return m
+
+
+def _rfnet_worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port), PASSION_DEVICE_INDEX="0", PASSION_DIST_BACKEND="gloo")
+    from passion_amd import parallel
+    from passion_amd import train as ptrain
+    ctx = parallel.init()
+    m = _rfnet_model(ctx.device)
+    red = parallel.GradReducer(m, ctx, bucket_mb=0.25)          # RFNet has 2.4 M parameters: small buckets, so that several go out from inside backward
+    opt = ptrain.make_optimizer(m, lr=1e-3)
+    # one backward alone first: the summed gradients themselves (before AdamW's normalisation hides their scale)
+    x, target, _ = ptrain.synthetic_batch(2, 32, ctx.device, seed=11 + rank)
+    mask = torch.ones(2, 4, dtype=torch.bool, device=ctx.device)
+    m.is_training = True
+    outs = m(x, mask, target=target, temp=4.0)
+    ptrain.assemble_loss(outs, target, mask, "idt", True).backward()
+    red.all_reduce_grads()
+    torch.cuda.synchronize()
+    g = {k: p.grad.detach().float().cpu().clone() for k, p in m.named_parameters() if p.grad is not None}
+    for p in m.parameters():
+        p.grad = None
+    loss = _rfnet_step(m, opt, rank, ctx.device, red)
+    torch.cuda.synchronize()
+    if rank == 0:
+        torch.save({"g": g, "p": {k: v.detach().cpu() for k, v in m.state_dict().items()}, "loss": float(loss), "nb": len(red.buckets),
+                    "overlap": red.overlap}, out)
+    parallel.barrier(ctx)
+    torch.distributed.destroy_process_group()
+
+
+def test_rfnet_two_ranks_sum_gradients_and_stay_in_step(tmp_path):
+    """configs[3] (RFNet, batch 2 per GPU, PASSION, DDP): rfnet.Model under GradReducer with two ranks -- its own stream layout
+    (grouped post-norm encoders, the region-fusion branch, decoder_sep's side stream) and its many `add_` gradient sums under the
+    overlap hooks.  The reduced gradients of one backward are the sum of the two ranks' gradients computed one after the other in
+    one process (a bucket packed before its gradients were written, or a rank's share missing, is an O(1) error; the bound is the
+    run-to-run noise of the backbone's sums); two AdamW steps on per-rank batches with different masks then run through the same
+    reducer (per-step bookkeeping, buckets that complete in another order) and leave finite parameters"""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from passion_amd import train as ptrain
+    out = str(tmp_path / "rf.pt")
+    mp.spawn(_rfnet_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    got = torch.load(out)
+    assert got["overlap"] and got["nb"] >= 4
+    dev = torch.device("cuda:0")
+    m = _rfnet_model(dev)
+    want = {}
+    for rank in range(2):
+        x, target, _ = ptrain.synthetic_batch(2, 32, dev, seed=11 + rank)
+        mask = torch.ones(2, 4, dtype=torch.bool, device=dev)
+        m.is_training = True
+        for p in m.parameters():
+            p.grad = None
+        outs = m(x, mask, target=target, temp=4.0)
+        ptrain.assemble_loss(outs, target, mask, "idt", True).backward()
+        torch.cuda.synchronize()
+        for k, p in m.named_parameters():
+            if p.grad is not None:
+                want[k] = want.get(k, 0) + p.grad.detach().float().cpu()
+    assert set(want) == set(got["g"])
+    bad = [(k, float((got["g"][k] - w).abs().max()), float(w.abs().max())) for k, w in want.items()
+           if float((got["g"][k] - w).abs().max()) > 2e-5 * float(w.abs().max()) + 1e-7]
+    exact = sum(torch.equal(got["g"][k], w) for k, w in want.items())
+    print(f"rfnet 2 ranks: {exact} of {len(want)} reduced gradient tensors equal the single-process sum bit for bit")
+    assert not bad, bad[:5]
+    assert all(torch.isfinite(v).all() for v in got["p"].values()) and got["loss"] == got["loss"]

@@ -48,6 +48,8 @@ for k, d in agg.items():
     tot_cyc += cyc * n
     res["kernels"][k[:120]] = e
 res["all_attention_kernels_mfma_busy_frac"] = round(tot_busy / (1024.0 * tot_cyc), 4) if tot_cyc else None
+import hashlib, os
+res["flash_attn_sha256"] = hashlib.sha256(open(os.path.join("passion_amd", "csrc", "flash_attn.hip"), "rb").read()).hexdigest()   # bench.py refuses the file for any other source
 json.dump(res, open(out_path, "w"), indent=1)
 print(json.dumps(res, indent=1))
 PY
