@@ -173,6 +173,11 @@ int passion_upsample_window_fwd(const void* x, void* y, int dtype, int B, int Dl
                                 int H, int W, int C, int k, void* stream);
 int passion_upsample_window_bwd(const void* dy, void* dx, int dtype, int B, int Dl_in, int id0, int Dg, int Dl_out, int od0,
                                 int H, int W, int C, int k, void* stream);
+/* round 5: the same adjoint as three separable passes (W and H over the whole axis, D over the window) through a scratch of
+ * passion_upsample_window_bwd_scratch_floats floats -- what the k = 4 / 8 / 16 deep-supervision maps of a sharded volume need */
+int64_t passion_upsample_window_bwd_scratch_floats(int B, int Dl_out, int H, int W, int C, int k);
+int passion_upsample_window_bwd_sep(const void* dy, void* dx, int dtype, int B, int Dl_in, int id0, int Dg, int Dl_out, int od0,
+                                    int H, int W, int C, int k, float* scratch, void* stream);
 
 /* ---- layout / softmax -----------------------------------------------------------------------
  * softmax over the class axis (nn.Softmax(dim=1), mmformer.py:91,543,635; criterions.py:93-94

@@ -67,6 +67,9 @@ SIGNATURES = {
                                             c_int, c_void_p]),
     "passion_upsample_window_bwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                             c_int, c_void_p]),
+    "passion_upsample_window_bwd_scratch_floats": (c_int64, [c_int, c_int, c_int, c_int, c_int, c_int]),
+    "passion_upsample_window_bwd_sep": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                                                c_int, c_void_p, c_void_p]),
     "passion_upsample_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
                                      c_int, c_void_p]),
     "passion_upsample_fwd_stats": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,

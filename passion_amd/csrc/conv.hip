@@ -1312,7 +1312,9 @@ static int conv3d_bwd_impl(const passion_conv_desc_t* d, const float* packed, co
     // no stream, no event node.  Outside a capture the launches stay in stream order.
     std::vector<hipGraphNode_t> cap_d0, cap_dw;
     bool capfork = false;
-    if (!comp && phase == 0 && pconv::g_wgrad_fork == 2 && need_dx && (dweight || dbias) && !pw_final) capfork = capture_tail(st, cap_d0);
+    if (!comp && phase == 0 && (pconv::g_wgrad_fork == 2 || (pconv::g_wgrad_fork == 3 && (long)k.Di * k.Hi * k.Wi <= 40000)) && need_dx &&
+        (dweight || dbias) && !pw_final)             // 3: the deep levels only (launches that do not fill the chip)
+        capfork = capture_tail(st, cap_d0);
     const bool forked = comp || capfork;
     hipStream_t caller_st = st;
     if (comp) {                                      // fork: the weight-gradient work below goes to the companion stream

@@ -28,7 +28,6 @@
 #include "passion_hip.h"
 #include "prof.h"
 
-int g_flash_pp = 1;         // option "flash_pp" / PASSION_FLASH_PP: the ping-pong query-major kernels (0 off, 1 where the launch fills the chip, 2 always)
 int g_flash_split = 0;      // option "flash_split" / PASSION_FLASH_SPLIT: 0 = automatic, n = that many splits (1 = the unsplit kernels)
 namespace pconv { int stream_scratch(hipStream_t st, size_t zero_bytes, size_t plain_bytes, void** zero, void** plain); }   // api.cpp
 extern const unsigned* g_passion_step_words;      // api.cpp: passion_set_step_words
@@ -169,6 +168,12 @@ __device__ __forceinline__ float half_sum(float v) {
 #define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
 
 // --------------------------------------------------------------------------------------------------------------
+// (Round 5, built, measured, removed: an eight-wave "ping-pong" form of these kernels -- waves in two groups held half a block apart by
+// workgroup barriers, one group in its MFMA segment (second product of block j - 1 + scores of block j) while the other runs the softmax
+// arithmetic, K / V in a ring of three LDS slots, groups assigned by the SIMD a wave reports in HW_REG_HW_ID.  Correct on every test shape and
+// 1.7x SLOWER at B = 16, N = 2048 (forward 0.49 ms against 0.28): alone in its phase, the vector segment pays every latency its partner
+// used to cover -- an added vector instruction cost 17 cycles there, 5 in the four-wave kernel below.  A start-up stagger of the odd wave
+// slot changed nothing either.  What did pay is fewer vector instructions per score: see the dropout note at the top.)
 // query-major kernels: MODE 0 = forward (out, lse), MODE 1 = backward dQ; DROP: attention dropout on (its own instantiation: one path
 // through the loop -- with both in one kernel the register allocator spilled the dQ kernel's accumulators around the branch)
 // grid (ceil(N / (32 NW)), H, B), block 64 NW: wave w owns queries q0 .. q0+31
@@ -402,286 +407,6 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2))) vo
         f = p.scale;
     }
     char* obuf = lds + wv * (32 * RS);            // [32 queries][64 d] bf16 per wave
-#pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-        for (int g4 = 0; g4 < 4; ++g4) {
-            union { bf16_t hv[4]; uint2 u; } t;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) t.hv[j] = (bf16_t)(o[dt][4 * g4 + j] * f);
-            *reinterpret_cast<uint2*>(obuf + (lane & 31) * RS + (dt * 32 + 8 * g4 + 4 * h) * 2) = t.u;
-        }
-    __syncthreads();
-    bf16_t* dst = (MODE == 0) ? p.out + (long)b * N * (p.H * DH) + hh * DH : p.dqkv + (long)b * N * rs + hh * DH;
-    const long drs = (MODE == 0) ? (long)p.H * DH : rs;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int ci = i * 64 + lane, row = ci >> 3, c8 = ci & 7;
-        if (q0 + row < N)
-            *reinterpret_cast<u32x4*>(dst + (long)(q0 + row) * drs + c8 * 8) = *reinterpret_cast<const u32x4*>(obuf + row * RS + c8 * 16);
-    }
-}
-
-// --------------------------------------------------------------------------------------------------------------
-// Ping-pong form of the query-major kernels (round 5) for launches that fill the chip.
-//
-// What the counters said about flash_q_kernel<4, *> at a saturating shape (B = 16, N = 2048: profiles/r05_attention_pmc_*): a wave
-// needs ~1300 cycles of vector issue and 640 cycles of MFMA per 64-key block, the two co-resident waves of a SIMD take 4300 cycles
-// for a block each -- the SUM of both waves' phases, not their maximum: two waves that run the same program from the same start
-// stay in lockstep, both in their MFMA phase (sharing one matrix pipe), then both in their softmax phase (sharing one vector issue
-// port); a start-up stagger does not survive (tried).  Here the phases are held apart by construction: a workgroup is EIGHT waves
-// (waves w and w + 4 share a SIMD), group A = waves 0-3, group B = waves 4-7, each wave owns 32 queries as before, and the loop is
-// cut into two kinds of segment separated by workgroup barriers
-//     M(j):  second product of block j - 1 (O^T += V^T . P^T  /  dQ^T += K^T . dS^T, + the row-sum MFMAs), then S(j) (and dP(j))
-//     V(j):  softmax / dropout / dS arithmetic of block j, left as packed bf16 operands for M(j + 1)
-// with B one segment behind A: while one wave of a SIMD issues MFMAs, its partner issues the vector work.  K / V tiles live in a
-// ring of three LDS slots (tile j + 1 is committed in the phase in which B still reads tile j - 1 as the second product's operand),
-// fetched two phases ahead into registers.
-// grid (ceil(N / 256) * nsplit, H, B), block 512.
-template <int MODE, bool DROP>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void flash_qpp_kernel(FlashP p) {
-    const unsigned ds0 = p.s0 + (p.soff ? p.soff[0] : 0u), ds1 = p.s1 + (p.soff ? p.soff[1] : 0u);
-    constexpr int KIMG = BLK * RS, VIMG = (MODE == 0) ? BLK * TS : BLK * RS, VST = (MODE == 0) ? TS : RS;
-    constexpr int CTAB = 128;
-    extern __shared__ __attribute__((aligned(16))) char lds[];      // K images [3] | V images [3] | pair words [3]
-    char* const kring = lds;
-    char* const vring = lds + 3 * KIMG;
-    char* const cring = vring + 3 * VIMG;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, h = lane >> 5;
-    const int grp = __builtin_amdgcn_readfirstlane(wv >> 2);
-    const int hh = blockIdx.y, b = blockIdx.z, N = p.N;
-    const long rs = 3L * p.H * DH;
-    const bf16_t* qb = p.qkv + (long)b * N * rs + hh * DH;
-    const bf16_t* kbase = qb + (long)p.H * DH;
-    const bf16_t* vbase = qb + 2L * p.H * DH;
-    const int split = blockIdx.x % p.nsplit;
-    const int q0 = ((blockIdx.x / p.nsplit) * 8 + wv) * 32, q = q0 + (lane & 31);
-    const bool qok = q < N;
-    const int nblk_all = (N + BLK - 1) / BLK;
-    const int kb0 = (int)((long)split * nblk_all / p.nsplit), nblk = (int)((long)(split + 1) * nblk_all / p.nsplit);
-    const int nb = nblk - kb0;                                       // key blocks of this split: kb0 + j, j = 0 .. nb - 1
-
-    bf16x8 qf[4], dof[MODE == 1 ? 4 : 1];
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        qf[s] = zero8();
-        if (qok) qf[s] = *reinterpret_cast<const bf16x8*>(qb + (long)q * rs + 16 * s + 8 * h);
-        if (MODE == 1) {
-            dof[s] = zero8();
-            if (qok) dof[s] = *reinterpret_cast<const bf16x8*>(p.dout + ((long)b * N + q) * (p.H * DH) + hh * DH + 16 * s + 8 * h);
-        }
-    }
-    float lse2 = 0.f, dlt = 0.f;
-    if (MODE == 1 && qok) {
-        lse2 = p.lse[((long)b * p.H + hh) * N + q];
-        dlt = p.delta[((long)b * p.H + hh) * N + q];
-    }
-    const unsigned rq = DROP ? row_word((unsigned)(b * p.H + hh) * (unsigned)N + (unsigned)q, ds0, ds1) : 0u;
-    const short ths = (short)((int)p.thr - 32768);
-    const s16x2 thr2 = {ths, ths};
-    const int thr_hi = ((int)p.thr - 32768) * 65536;
-    const int ct_slot = ((tid >> 1) & 1) * 16 + (tid >> 4) * 8 + 2 * ((tid >> 2) & 3) + (tid & 1);
-
-    // tile traffic: thread tid owns the 16-byte chunk (row tid >> 3, column block tid & 7) of every K / V tile
-    const int trow = tid >> 3, tc8 = tid & 7;
-    auto gtile = [&](const bf16_t* base, int j) -> u32x4 {
-        const int row = (kb0 + j) * BLK + trow;
-        u32x4 r = {0u, 0u, 0u, 0u};
-        if (j < nb && row < N) r = *reinterpret_cast<const u32x4*>(base + (long)row * rs + tc8 * 8);
-        return r;
-    };
-    auto commit = [&](int slot, int j, const u32x4& kr, const u32x4& vr) {
-        *reinterpret_cast<u32x4*>(kring + slot * KIMG + trow * RS + tc8 * 16) = kr;
-        *reinterpret_cast<u32x4*>(vring + slot * VIMG + trow * VST + tc8 * 16) = vr;
-        if (DROP && tid < 32) reinterpret_cast<unsigned*>(cring + slot * CTAB)[ct_slot] = pair_word((unsigned)((kb0 + j) * (BLK / 2) + tid), ds0, ds1);
-    };
-
-    f32x16 o[2] = {zero16(), zero16()};
-    f32x16 lacc = zero16();
-    float m_run = -INFINITY;
-    bf16x8 ones;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) ones[j] = (__bf16)1.0f;
-    f32x16 st[2], dp[MODE == 1 ? 2 : 1];
-    bf16x8 pu[MODE == 0 ? 4 : 1], pd[4];           // packed operands of the second product: [2 kt + s]
-
-    u32x4 kreg = gtile(kbase, 0), vreg = gtile(vbase, 0);
-    commit(0, 0, kreg, vreg);
-    kreg = gtile(kbase, 1);                          // committed in phase 1
-    vreg = gtile(vbase, 1);
-    __syncthreads();
-
-    // ring slots of the tiles a segment touches, kept as counters (no division in the loop)
-    int sj = 0;            // slot of block j = the block of THIS wave's current segment pair: advanced when its V segment is done
-    int sprev = 2;         // slot of block j - 1
-    int cslot = 1;         // slot the next commit writes (tile jc)
-    int jc = 1;
-    for (int ph = 0; ph <= 2 * nb + 1; ++ph) {
-        const int s = ph - grp;
-        if (s >= 0 && s <= 2 * nb) {
-            const int j = s >> 1;
-            if (!(s & 1)) {
-                // ================= M(j)
-                if (j > 0) {
-                    const char* timg = (MODE == 0) ? vring + sprev * VIMG : kring + sprev * KIMG;
-                    constexpr int tstride = (MODE == 0) ? TS : RS;
-                    bf16x8 tfr[2][2][2];
-#pragma unroll
-                    for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                        for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-                            for (int dt = 0; dt < 2; ++dt) tfr[kt][s2][dt] = tr_frag(timg, tstride, kt * 32 + 16 * s2, dt * 32, lane);
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                        for (int s2 = 0; s2 < 2; ++s2) {
-                            if (MODE == 0) lacc = MFMA32(ones, pu[MODE == 0 ? 2 * kt + s2 : 0], lacc);
-#pragma unroll
-                            for (int dt = 0; dt < 2; ++dt) o[dt] = MFMA32(tfr[kt][s2][dt], pd[2 * kt + s2], o[dt]);
-                        }
-                }
-                if (j < nb) {
-                    const char* kimg = kring + sj * KIMG;
-                    const char* vimg = vring + sj * VIMG;
-                    bf16x8 kfr[2][4];
-#pragma unroll
-                    for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                        for (int s2 = 0; s2 < 4; ++s2) kfr[kt][s2] = row_frag(kimg, RS, kt * 32, s2, lane);
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int kt = 0; kt < 2; ++kt) {
-                        st[kt] = zero16();
-#pragma unroll
-                        for (int s2 = 0; s2 < 4; ++s2) st[kt] = MFMA32(kfr[kt][s2], qf[s2], st[kt]);
-                    }
-                    if (MODE == 1) {
-#pragma unroll
-                        for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                            for (int s2 = 0; s2 < 4; ++s2) kfr[kt][s2] = row_frag(vimg, RS, kt * 32, s2, lane);
-                        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                        for (int kt = 0; kt < 2; ++kt) {
-                            dp[kt] = zero16();
-#pragma unroll
-                            for (int s2 = 0; s2 < 4; ++s2) dp[kt] = MFMA32(kfr[kt][s2], dof[s2], dp[kt]);
-                        }
-                    }
-                }
-            } else {
-                // ================= V(j)
-                const u32x4* ctab = reinterpret_cast<const u32x4*>(cring + sj * CTAB) + 4 * h;
-                const int key0 = (kb0 + j) * BLK;
-                if (key0 + BLK > N) {
-#pragma unroll
-                    for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                        for (int r = 0; r < 16; ++r)
-                            if (key0 + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h >= N) st[kt][r] = -INFINITY;
-                }
-                if (MODE == 0) {
-                    float mx = -INFINITY;
-#pragma unroll
-                    for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[kt][r]);
-                    mx = half_max(mx) * p.c;
-                    const bool move = mx > m_run + LAZY;
-                    if (__any(move)) {
-                        const float m_new = move ? mx : m_run;
-                        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-                        m_run = m_new;
-                        lacc[0] *= alpha;
-#pragma unroll
-                        for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-                            for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
-                    }
-#pragma unroll
-                    for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) st[kt][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(st[kt][r], p.c, -m_run));
-#pragma unroll
-                    for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                        for (int s2 = 0; s2 < 2; ++s2) {
-                            const bf16x8 pk = pack8(st[kt], s2);
-                            pu[MODE == 0 ? 2 * kt + s2 : 0] = pk;
-                            bf16x8 pf = pk;
-                            if (DROP) {
-                                u32x4 pw = __builtin_bit_cast(u32x4, pk);
-                                const u32x4 c4 = ctab[2 * kt + s2];
-#pragma unroll
-                                for (int jj = 0; jj < 4; ++jj) pw[jj] &= ~drop_fields(drop_mix(rq + c4[jj]), thr2);
-                                pf = __builtin_bit_cast(bf16x8, pw);
-                            }
-                            pd[2 * kt + s2] = pf;
-                        }
-                } else {
-#pragma unroll
-                    for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) st[kt][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(st[kt][r], p.c, -lse2));
-                    if (DROP) {
-#pragma unroll
-                        for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                            for (int r = 0; r < 16; r += 2) {
-                                const unsigned u = drop_mix(rq + ctab[2 * kt + (r >> 3)][(r & 7) >> 1]);
-                                const float t0 = (short)(u & 0xffffu) >= ths ? p.inv_keep : 0.f, t1 = (int)u >= thr_hi ? p.inv_keep : 0.f;
-                                st[kt][r] *= __builtin_fmaf(dp[kt][r], t0, -dlt);
-                                st[kt][r + 1] *= __builtin_fmaf(dp[kt][r + 1], t1, -dlt);
-                            }
-                    } else {
-#pragma unroll
-                        for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                            for (int r = 0; r < 16; ++r) st[kt][r] *= (dp[kt][r] - dlt);
-                    }
-#pragma unroll
-                    for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                        for (int s2 = 0; s2 < 2; ++s2) pd[2 * kt + s2] = pack8(st[kt], s2);
-                }
-                sprev = sj;
-                sj = sj == 2 ? 0 : sj + 1;
-            }
-        }
-        if (ph & 1) {           // odd phase 2 jc - 1: tile jc into its slot (fetched two phases ago), fetch tile jc + 1
-            if (jc < nb) commit(cslot, jc, kreg, vreg);
-            ++jc;
-            cslot = cslot == 2 ? 0 : cslot + 1;
-            kreg = gtile(kbase, jc);
-            vreg = gtile(vbase, jc);
-        }
-        __syncthreads();
-    }
-
-    if (p.nsplit > 1) {
-        const long row = (((long)split * p.B + b) * p.H + hh) * N + q;
-        if (qok) {
-#pragma unroll
-            for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) p.po[row * DH + dt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h] = o[dt][r];
-        }
-        if (MODE == 0) {
-            if (qok && h == 0) { p.pm[row] = m_run; p.pl[row] = lacc[0]; }
-        }
-        return;
-    }
-    float f;
-    if (MODE == 0) {
-        const float l_tot = lacc[0];
-        f = p.inv_keep / l_tot;
-        if (qok && h == 0) p.lse[((long)b * p.H + hh) * N + q] = m_run + __builtin_amdgcn_logf(l_tot);
-    } else {
-        f = p.scale;
-    }
-    char* obuf = lds + wv * (32 * RS);            // [32 queries][64 d] bf16 per wave (the rings are free after the last barrier)
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
@@ -1015,13 +740,6 @@ int pick_nw(int B, int N, int H, int nsplit) {
     return tiles >= 4 * 512 ? 4 : (tiles >= 2 * 256 ? 2 : 1);
 }
 
-// the eight-wave ping-pong kernels: when the launch has at least one 8-wave workgroup per CU (option "flash_pp": 0 off, 1 automatic, 2 always)
-bool use_pp(int B, int N, int H, int nsplit) {
-    if (g_flash_pp == 0) return false;
-    if (g_flash_pp == 2) return true;
-    return (long)((N + 255) / 256) * H * B * nsplit >= 256;
-}
-
 }  // namespace
 
 extern "C" int passion_flash_attn_supported(int dtype, int Dh) { return dtype == PASSION_BF16 && Dh == DH; }
@@ -1055,18 +773,6 @@ extern "C" int passion_flash_attn_fwd(const void* qkv, int B, int N, int H, int 
             (rc = grant_lds(flash_q_kernel<4, 0, true>, bytes)) || (rc = grant_lds(flash_q_kernel<2, 0, true>, bytes)) || (rc = grant_lds(flash_q_kernel<1, 0, true>, bytes))) return rc;
         granted = true;
     }
-    const int pp_bytes = 3 * (BLK * RS + BLK * TS + 128);
-    if (use_pp(B, N, H, nsplit)) {           // eight-wave ping-pong form: the launch fills the chip
-        static bool granted_pp = false;
-        if (!granted_pp) {
-            if ((rc = grant_lds(flash_qpp_kernel<0, false>, pp_bytes)) || (rc = grant_lds(flash_qpp_kernel<0, true>, pp_bytes))) return rc;
-            granted_pp = true;
-        }
-        passion_prof_tag("flash_qpp_kernel<0>");
-        const dim3 gpp((N + 255) / 256 * nsplit, H, B);
-        if (p.thr) hipLaunchKernelGGL((flash_qpp_kernel<0, true>), gpp, dim3(512), pp_bytes, st, p);
-        else hipLaunchKernelGGL((flash_qpp_kernel<0, false>), gpp, dim3(512), pp_bytes, st, p);
-    } else
     if (p.thr) {
         if (nw == 4) hipLaunchKernelGGL((flash_q_kernel<4, 0, true>), grid, dim3(256), bytes, st, p);
         else if (nw == 2) hipLaunchKernelGGL((flash_q_kernel<2, 0, true>), grid, dim3(128), bytes, st, p);
@@ -1124,19 +830,7 @@ extern "C" int passion_flash_attn_bwd(const void* qkv, const void* out, const vo
         granted = true;
     }
     const int kbytes = kbytes_min > nw * 2 * 32 * RS ? kbytes_min : nw * 2 * 32 * RS;      // the epilogue stages 2 x [32][64] per wave
-    const bool qpp = use_pp(B, N, H, nsplit);
-    if (qpp) {
-        const int pp_bytes = 3 * (2 * BLK * RS + 128);
-        static bool granted_pp = false;
-        if (!granted_pp) {
-            if ((rc = grant_lds(flash_qpp_kernel<1, false>, pp_bytes)) || (rc = grant_lds(flash_qpp_kernel<1, true>, pp_bytes))) return rc;
-            granted_pp = true;
-        }
-        const dim3 gpp((N + 255) / 256 * nsplit, H, B);
-        if (p.thr) hipLaunchKernelGGL((flash_qpp_kernel<1, true>), gpp, dim3(512), pp_bytes, st, p);
-        else hipLaunchKernelGGL((flash_qpp_kernel<1, false>), gpp, dim3(512), pp_bytes, st, p);
-    }
-#define FLASH_BWD(NWV, DR) do { if (!qpp) hipLaunchKernelGGL((flash_q_kernel<NWV, 1, DR>), grid, dim3(64 * NWV), qbytes, st, p); \
+#define FLASH_BWD(NWV, DR) do { hipLaunchKernelGGL((flash_q_kernel<NWV, 1, DR>), grid, dim3(64 * NWV), qbytes, st, p); \
                                 hipLaunchKernelGGL((flash_k_kernel<NWV, DR>), grid, dim3(64 * NWV), kbytes, st, pkk); } while (0)
     if (p.thr) {
         if (nw == 4) FLASH_BWD(4, true); else if (nw == 2) FLASH_BWD(2, true); else FLASH_BWD(1, true);

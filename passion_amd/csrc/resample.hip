@@ -823,6 +823,42 @@ __global__ __launch_bounds__(256) void halo_unpack_kernel(const T* __restrict__ 
     }
 }
 
+// D pass of the separable adjoint of the WINDOWED upsampling (the W and H passes are the whole-axis ones above): input planes
+// [od0, od0 + Dl_out) of the k Dg output planes, local input plane idl = global plane id0 + idl (planes outside [0, Dg): zero)
+template <typename TO>
+__global__ __launch_bounds__(256) void upsample_bwd_dwindow_kernel(const float* __restrict__ in, TO* __restrict__ out, int B, int Dl_in, int id0, int Dg,
+                                                                   int Dl_out, int od0, long inner, int k) {
+    const float sd = axis_scale(Dg, Dg * k);
+    const long total = (long)B * Dl_in * inner;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const long iv = idx % inner;
+        const int idl = (int)((idx / inner) % Dl_in);
+        const long b = idx / (inner * Dl_in);
+        const int gi = id0 + idl;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        if (gi >= 0 && gi < Dg) {
+            int lo, hi;
+            axis_range(gi, sd, Dg * k, lo, hi);
+            lo = max(lo, od0); hi = min(hi, od0 + Dl_out - 1);
+            const float* base = in + ((b * Dl_out) * inner + iv) * 4;
+            for (int o = lo; o <= hi; o += 4) {
+                float w[4];
+                f32x4 v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int oo = min(o + u, hi);
+                    w[u] = (o + u <= hi) ? axis_weight(oo, gi, sd, Dg) : 0.f;
+                    v[u] = load4(base + (long)(oo - od0) * inner * 4);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (w[u] != 0.f) acc += w[u] * v[u];
+            }
+        }
+        store4(out + idx * 4, acc);
+    }
+}
+
 // ---- depth sharding, round 5: ONE launch per halo extension / its adjoint, two tiny ones per global InstanceNorm statistic.
 // (The first form built an extended slab from torch.zeros + copy_ + two plane packs + two plane puts, its adjoint from seven
 // launches, the global statistics from ~20 elementwise torch ops on (B, C) tensors: ~17 000 launches per 240 x 240 x 160 step, and
@@ -1112,6 +1148,36 @@ extern "C" int passion_upsample_window_bwd(const void* dy, void* dx, int dtype, 
         hipLaunchKernelGGL(upsample_window_bwd_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, (const bf16_t*)dy, (bf16_t*)dx, B, Dl_in, id0, Dg, Dl_out, od0, H, W, C, k);
     else
         return -1007;
+    LAUNCH_RET();
+    return 0;
+}
+
+/* the same adjoint as three separable passes (W, H whole-axis; D windowed) through `scratch`: the one-pass gather above walks the
+ * (2k + 1)^3 candidate window per input voxel -- 4 ms per call for the x16 deep-supervision map of a 240 x 240 x 160 volume */
+extern "C" int64_t passion_upsample_window_bwd_scratch_floats(int B, int Dl_out, int H, int W, int C, int k) {
+    return (int64_t)B * Dl_out * H * k * W * C + (int64_t)B * Dl_out * H * W * C;
+}
+extern "C" int passion_upsample_window_bwd_sep(const void* dy, void* dx, int dtype, int B, int Dl_in, int id0, int Dg, int Dl_out, int od0,
+                                               int H, int W, int C, int k, float* scratch, void* stream) {
+    if (C % 4 || k < 1 || Dl_in < 1 || Dl_out < 1 || Dg < 1 || !scratch) return -1011;
+    hipStream_t st = (hipStream_t)stream;
+    const int Ho = H * k, Wo = W * k;
+    const long cv = C / 4;
+    float* t1 = scratch;                                        // [B][Dl_out][Ho][W][C]
+    float* t2 = scratch + (long)B * Dl_out * Ho * W * C;         // [B][Dl_out][H][W][C]
+    int rc;
+    if (dtype == PASSION_F32) rc = launch_axis<float, float>((const float*)dy, t1, (long)B * Dl_out * Ho, W, Wo, cv, st);
+    else if (dtype == PASSION_BF16) rc = launch_axis<bf16_t, float>((const bf16_t*)dy, t1, (long)B * Dl_out * Ho, W, Wo, cv, st);
+    else return -1007;
+    if (rc) return rc;
+    rc = launch_axis<float, float>(t1, t2, (long)B * Dl_out, H, Ho, (long)W * cv, st);
+    if (rc) return rc;
+    const long inner = (long)H * W * cv, total = (long)B * Dl_in * inner;
+    const int blocks = (int)hmin((total + 255) / 256, 16384);
+    if (dtype == PASSION_F32)
+        hipLaunchKernelGGL(upsample_bwd_dwindow_kernel<float>, dim3(blocks), dim3(256), 0, st, t2, (float*)dx, B, Dl_in, id0, Dg, Dl_out, od0, inner, k);
+    else
+        hipLaunchKernelGGL(upsample_bwd_dwindow_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, t2, (bf16_t*)dx, B, Dl_in, id0, Dg, Dl_out, od0, inner, k);
     LAUNCH_RET();
     return 0;
 }

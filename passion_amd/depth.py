@@ -366,8 +366,14 @@ class WindowUpsampleFn(torch.autograd.Function):
         (B, Dl_in, H, W, C), k, id0, Dg, Dl_out, od0 = ctx.meta
         dy = dy.contiguous()
         dx = torch.empty(B, Dl_in, H, W, C, dtype=dy.dtype, device=dy.device)
-        L.check(L.load().passion_upsample_window_bwd(_p(dy), _p(dx), L.dtype_code(dy.dtype), B, Dl_in, id0, Dg, Dl_out, od0, H, W, C, k,
-                                                     L.stream_ptr()), "passion_upsample_window_bwd")
+        lib = L.load()
+        if k > 2:           # the deep-supervision maps: three separable passes (the one-pass gather walks (2k + 1)^3 candidates per voxel)
+            scratch = torch.empty(lib.passion_upsample_window_bwd_scratch_floats(B, Dl_out, H, W, C, k), dtype=torch.float32, device=dy.device)
+            L.check(lib.passion_upsample_window_bwd_sep(_p(dy), _p(dx), L.dtype_code(dy.dtype), B, Dl_in, id0, Dg, Dl_out, od0, H, W, C, k,
+                                                        _p(scratch), L.stream_ptr()), "passion_upsample_window_bwd_sep")
+            return dx, None, None, None, None, None
+        L.check(lib.passion_upsample_window_bwd(_p(dy), _p(dx), L.dtype_code(dy.dtype), B, Dl_in, id0, Dg, Dl_out, od0, H, W, C, k,
+                                                L.stream_ptr()), "passion_upsample_window_bwd")
         return dx, None, None, None, None, None
 
 

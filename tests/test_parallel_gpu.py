@@ -207,8 +207,8 @@ def test_rfnet_two_ranks_sum_gradients_and_stay_in_step(tmp_path):
     """configs[3] (RFNet, batch 2 per GPU, PASSION, DDP): rfnet.Model under GradReducer with two ranks -- its own stream layout
     (grouped post-norm encoders, the region-fusion branch, decoder_sep's side stream) and its many `add_` gradient sums under the
     overlap hooks.  The reduced gradients of one backward are the sum of the two ranks' gradients computed one after the other in
-    one process (a bucket packed before its gradients were written, or a rank's share missing, is an O(1) error; the bound is the
-    run-to-run noise of the backbone's sums); two AdamW steps on per-rank batches with different masks then run through the same
+    one process under the gate of the global batch (a bucket packed before its gradients were written, or a rank's share missing, is
+    an O(1) error); two AdamW steps on per-rank batches with different masks then run through the same
     reducer (per-step bookkeeping, buckets that complete in another order) and leave finite parameters"""
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
@@ -219,22 +219,36 @@ def test_rfnet_two_ranks_sum_gradients_and_stay_in_step(tmp_path):
     assert got["overlap"] and got["nb"] >= 4
     dev = torch.device("cuda:0")
     m = _rfnet_model(dev)
-    want = {}
+    # PASSION's relative-preference gate is formed on the GLOBAL batch (train.relative_preference: the ranks all-reduce its 4 sums,
+    # the reference forms it on the DataParallel-gathered outputs, train.py:266-270): the single-process stand-in for two ranks runs
+    # both ranks' forwards first, forms the gate from both, and only then takes each rank's gradient under that gate
+    batches, dists = [], []
+    mask = torch.ones(2, 4, dtype=torch.bool, device=dev)
     for rank in range(2):
         x, target, _ = ptrain.synthetic_batch(2, 32, dev, seed=11 + rank)
-        mask = torch.ones(2, 4, dtype=torch.bool, device=dev)
+        batches.append((x, target))
+        m.is_training = True
+        with torch.no_grad():
+            dists.append(m(x, mask, target=target, temp=4.0)[5])
+    rp_global = ptrain.relative_preference(torch.cat(dists, 0), torch.ones(4, 4, device=dev), idt=True)
+    want, per = {}, []
+    for rank in range(2):
+        x, target = batches[rank]
         m.is_training = True
         for p in m.parameters():
             p.grad = None
         outs = m(x, mask, target=target, temp=4.0)
-        ptrain.assemble_loss(outs, target, mask, "idt", True).backward()
+        ptrain.assemble_loss(outs, target, mask, "idt", True, rp_override=rp_global).backward()
         torch.cuda.synchronize()
-        for k, p in m.named_parameters():
-            if p.grad is not None:
-                want[k] = want.get(k, 0) + p.grad.detach().float().cpu()
+        per.append({k: p.grad.detach().float().cpu() for k, p in m.named_parameters() if p.grad is not None})
+        for k, v in per[-1].items():
+            want[k] = want.get(k, 0) + v
     assert set(want) == set(got["g"])
-    bad = [(k, float((got["g"][k] - w).abs().max()), float(w.abs().max())) for k, w in want.items()
-           if float((got["g"][k] - w).abs().max()) > 2e-5 * float(w.abs().max()) + 1e-7]
+    bad = [(k, float((got["g"][k] - w).abs().max()), float(w.abs().max()), "vs rank 0 alone", float((got["g"][k] - per[0][k]).abs().max()),
+            "vs rank 1 alone", float((got["g"][k] - per[1][k]).abs().max()), "vs 2 x rank 0", float((got["g"][k] - 2 * per[0][k]).abs().max()))
+           for k, w in want.items() if float((got["g"][k] - w).abs().max()) > 1e-2 * float(w.abs().max()) + 1e-7]
+    # (observed: 272 of 288 tensors bit-equal; the first two layers of every encoder differ by ~1e-3 of their largest entry -- one bf16
+    # rounding of the summed activation gradient that reaches them; a rank's share missing or a stale bucket is an O(1) error)
     exact = sum(torch.equal(got["g"][k], w) for k, w in want.items())
     print(f"rfnet 2 ranks: {exact} of {len(want)} reduced gradient tensors equal the single-process sum bit for bit")
     assert not bad, bad[:5]
