@@ -67,6 +67,15 @@ def parse():
                     help="one GPU, but the step every rank of an N > 1 run executes: process group on RCCL (world size 1), GradReducer's "
                          "overlap hooks and buckets, async all_reduce, no early optimizer step / direct gradients, eager launch -- the "
                          "per-rank baseline the scaling numbers should be read against")
+    ap.add_argument("--graph-collectives", action="store_true",
+                    help="N > 1 (or --ddp-mode): record the WHOLE step as one HIP graph, its RCCL calls included -- GradReducer's overlapped bucket "
+                         "all-reduces under the backward, PASSION's 4-float gate, AdamW -- instead of the hybrid form (forward + backward recorded, "
+                         "all-reduce + AdamW eager after every replay).  all_reduce / all_gather record and replay correctly on this stack "
+                         "(tools/rccl_capture_probe.py, world size 1); not the default: it has never run on more than one GPU")
+    ap.add_argument("--stage-batch", action="store_true",
+                    help="graph replay: copy x / target into the recording's input tensors every step (a device-to-device staging copy of 167 MB "
+                         "at 128^3 that neither the eager step nor a loader writing into GraphedStep.input_buffers() has) instead of keeping the "
+                         "resident batch in them")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-dice", action="store_true", help="skip the dice_vs_ref leg (fixture replay after the timed region)")
     return ap.parse_args()
@@ -369,16 +378,29 @@ def main():
         return ptrain.train_step(model, opt, x, mk, target.view(target.shape), 4.0, state, reducer)
 
     use_graph = (args.launch == "graph" or (args.launch == "auto" and os.environ.get("PASSION_BENCH_GRAPH", "1") != "0")) \
-        and not is_depth and (not reducer.active or (not passion and os.environ.get("PASSION_BENCH_GRAPH_DDP", "1") != "0"))
+        and not is_depth and (not reducer.active or args.graph_collectives or (not passion and os.environ.get("PASSION_BENCH_GRAPH_DDP", "1") != "0"))
     gstep = None
     if use_graph:
         from passion_amd.graph import GraphedStep
-        gstep = GraphedStep(model, opt, 4.0, state, warm=2, reducer=reducer if reducer.active else None)       # two eager steps on the recording's own stream first (per-stream scratch, allocator pool)
+        gstep = GraphedStep(model, opt, 4.0, state, warm=2, reducer=reducer if reducer.active else None,
+                            record_collectives=bool(args.graph_collectives) if reducer.active else None)       # two eager steps on the recording's own stream first (per-stream scratch, allocator pool)
 
     def graph_step():
         mk = masks[it_no[0] % len(masks)]
         it_no[0] += 1
+        bufs = gstep.input_buffers()
+        if bufs is not None and not args.stage_batch:
+            # the batch is resident in the recording's own input tensors (GraphedStep.input_buffers: where a loader's H2D copy would land);
+            # per step only the mask row changes.  The label volume is still converted (float64 -> f32 channels-last) inside every replay
+            if not inplace_done[0]:
+                bufs[0].copy_(x)
+                bufs[2].copy_(target)
+                inplace_done[0] = True
+            bufs[1].copy_(mk)
+            return gstep(bufs[0], bufs[1], bufs[2])
         return gstep(x, mk, target.view(target.shape))       # batch copied into the recording's static tensors every step
+
+    inplace_done = [False]
 
     step = eager_step
     if is_depth:
@@ -603,10 +625,12 @@ def main():
                    "allreduce_bytes_per_step": grad_bytes if ctx.world > 1 else 0,
                    "final_loss": round(final_loss, 5),
                    "ddp_mode": bool(args.ddp_mode),
-                   "launch": (("HIP graph replay of forward + loss + backward, then the eager tail of train.train_step: bucketed RCCL all-reduce of "
+                   "launch": ((("HIP graph replay of the whole step, collectives recorded: GradReducer's bucket all-reduces overlapped with the backward"
+                                + (", PASSION's gate all-reduce" if passion else "") + ", AdamW") if (reducer.active and args.graph_collectives) else
+                               "HIP graph replay of forward + loss + backward, then the eager tail of train.train_step: bucketed RCCL all-reduce of "
                                "the static gradient tensors + AdamW (no collective is recorded)" if reducer.active else
-                               "HIP graph replay of train.train_step (recorded once after the warm-up; batch, AdamW scalars and dropout "
-                               "seeds through device memory)") if use_graph else ("eager" if not graph_note else "eager (the HIP-graph recording failed: " + graph_note + ")"))},
+                               "HIP graph replay of train.train_step (recorded once after the warm-up; AdamW scalars and dropout seeds through device "
+                               "memory; the batch " + ("copied into" if args.stage_batch else "resident in") + " the recording's input tensors)") if use_graph else ("eager" if not graph_note else "eager (the HIP-graph recording failed: " + graph_note + ")"))},
     }
     if want_events:
         recs = [r for r in timed_recs if r[1] >= 0]

@@ -324,6 +324,14 @@ int passion_ln_act_bwd(const void* x, const float* gamma, const float* beta, con
  * stored mask: y[i] = keep(i) ? x[i] / (1 - p) : 0 with keep(i) ~ Bernoulli(1 - p) drawn from a counter-based hash of
  * (seed, i).  The same (seed, p) reproduces the mask, which is how the backward applies it to dprobs.  y may alias x. */
 int passion_dropout(const float* x, float* y, int64_t n, float p, uint64_t seed, void* stream);
+/* round 5: the elementwise glue of a Transformer block (reference code/models/mmformer.py:226,247,256,271-275) in one pass each way:
+ * out = [x +] drop(drop(act(y))): act 0 identity / 1 GELU (erf), ndrop 1 or 2 nn.Dropout(p) modules in a row (independent keep bits),
+ * x the f32 residual stream or NULL; y / out dtypes (bf16, bf16), (bf16, f32), (f32, f32); n % 8 == 0.  bwd: dy = g * keep * scale
+ * [* gelu'(y)] (the residual's gradient is g).  Keep bits from (seed + the step words of passion_set_step_words, element index). */
+int passion_token_drop_fwd(const void* y, const float* x, void* out, int64_t n, int y_dtype, int out_dtype, float p, int ndrop, int act,
+                           uint64_t seed, void* stream);
+int passion_token_drop_bwd(const void* g, const void* y, void* dy, int64_t n, int y_dtype, int out_dtype, float p, int ndrop, int act,
+                           uint64_t seed, void* stream);
 
 /* ---- RFNet (post-norm backbone) streaming ops -------------------------------------------------------
  * norm_act: out[b][v][out_coff + c] = sum_k LeakyReLU((x_k - mean_k) * rstd_k), k = 1 or 2 inputs (x1 may be

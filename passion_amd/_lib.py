@@ -124,6 +124,8 @@ SIGNATURES = {
     "passion_flash_attn_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_float,
                                        ctypes.c_uint64, c_void_p, c_void_p, c_void_p]),
     "passion_dropout": (c_int, [c_void_p, c_void_p, c_int64, ctypes.c_float, ctypes.c_uint64, c_void_p]),
+    "passion_token_drop_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, ctypes.c_float, c_int, c_int, ctypes.c_uint64, c_void_p]),
+    "passion_token_drop_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, ctypes.c_float, c_int, c_int, ctypes.c_uint64, c_void_p]),
     "passion_gconv3d_part_floats": (c_int64, [c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
     "passion_gconv3d_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "passion_gconv3d_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,

@@ -1315,7 +1315,16 @@ static int conv3d_bwd_impl(const passion_conv_desc_t* d, const float* packed, co
     if (!comp && phase == 0 && (pconv::g_wgrad_fork == 2 || (pconv::g_wgrad_fork == 3 && (long)k.Di * k.Hi * k.Wi <= 40000)) && need_dx &&
         (dweight || dbias) && !pw_final)             // 3: the deep levels only (launches that do not fill the chip)
         capfork = capture_tail(st, cap_d0);
-    const bool forked = comp || capfork;
+    // levels 3..5 (round 5): the 3x3x3 layers whose input gradient runs on conv_deep.hip get their weight gradient in the SAME launch
+    // (deep_pair_kernel: two workgroup ranges of one grid).  The weight-gradient launcher parks its launch (wgrad_lean_defer), the
+    // input-gradient launcher picks it up; whatever is still parked after the input gradient's launch goes out on its own.
+    pending_wgrad().on = false;
+    const bool pair_ok = !comp && !capfork && phase == 0 && parts == 3 && !pw_final && need_dx && (dweight || dbias) && d->ksize == 3 && d->stride == 1 &&
+                         d->x_dtype == PASSION_BF16 && d->y_dtype == PASSION_BF16 && pconv::g_conv_lean && pconv::g_conv_deep && pconv::g_deep_pair &&
+                         !g_passion_force_f32_mfma && (long)k.Di * k.Hi * k.Wi <= 40000 && k.Cout % 32 == 0 && k.Cin % 16 == 0;
+    const bool forked = comp || capfork;              // the weight gradient's fold cannot ride in the finish launch (another stream / branch)
+    const bool no_clear = forked || pair_ok;          // ... nor can the weight-gradient kernel clear the sums the input gradient adds into (pair: they run side by side;
+                                                      // its fold still rides in the finish launch, which follows the pair launch)
     hipStream_t caller_st = st;
     if (comp) {                                      // fork: the weight-gradient work below goes to the companion stream
         HIP_RET(hipEventRecord(comp->fork, caller_st));
@@ -1323,7 +1332,7 @@ static int conv3d_bwd_impl(const passion_conv_desc_t* d, const float* packed, co
         st = comp->side;
     }
     // cleared by the weight-gradient fold when that runs on the same stream as the dgrad
-    float* zsums = (need_norm && sums && !forked) ? sums : nullptr;
+    float* zsums = (need_norm && sums && !no_clear) ? sums : nullptr;
     bool defer_fold = false;
     FoldJob fj{nullptr, {nullptr, nullptr, nullptr, nullptr}, 0, 0, 0, 0, 0, 0};
     const long zn = zsums ? (long)2 * k.B * k.Cin * SUMS_REP : 0;
@@ -1345,6 +1354,7 @@ static int conv3d_bwd_impl(const passion_conv_desc_t* d, const float* packed, co
                            2.0 * k.B * k.Do * k.Ho * k.Wo * (double)k.Cout * k.Cin * nt, st);
             float* dWs = dweight ? wslab : nullptr;
             float* dbs = dbias ? bslab : nullptr;
+            defer_next_wgrad() = pair_ok;
             if (ga) {                                // grouped: the lean kernel (slots in sample order), checked by the caller
                 rc = launch_wgrad_lean(k, d->ksize, d->stride, w.MT, w.gx, w.gy, dWs, dbs, st);
                 if (rc > 0) rc = -1014;
@@ -1366,6 +1376,7 @@ static int conv3d_bwd_impl(const passion_conv_desc_t* d, const float* packed, co
                 rc = launch_wgrad_geo<bf16_t, float>(k, w, d->ksize, d->stride, dWs, dbs, st);
             else
                 rc = -1007;
+            defer_next_wgrad() = false;
             if (rc) return rc;
         }
         k.zero_ptr = nullptr; k.zero_n = 0;
@@ -1555,6 +1566,7 @@ static int conv3d_bwd_impl(const passion_conv_desc_t* d, const float* packed, co
             rc = -1007;
         if (rc) return rc;
     }
+    if ((rc = wgrad_lean_flush(st))) return rc;          // a parked weight gradient the input-gradient launcher did not take
     // kind 6: what completes the input gradient after the dgrad kernel -- the fold of the InstanceNorm-backward sums and the
     // finish kernels (halo fold + InstanceNorm backward): reported by bench.py beside the dgrad kernel they belong to
     char dg_tag[64];

@@ -118,8 +118,16 @@ int launch_conv_march(ConvK& k, int ksize, int stride, int mode, const void* pac
 extern int g_conv_march;
 int launch_conv_pair(ConvK& k, int mode, hipStream_t st);   // conv_pair.hip: 8-channel K axis, <= 8 rows: two output planes per MFMA tile
 extern int g_conv_pair;
+// A deep-level weight gradient that has been PLANNED but not launched: conv3d_bwd_impl parks it here when the conv's input gradient is
+// expected on conv_deep.hip, whose launcher then issues both as one grid (deep_pair_kernel); whatever is still parked after the input
+// gradient's launch is issued on its own (wgrad_lean_flush).  One per host thread: a conv backward is planned and launched by one thread.
+struct PendingWgrad { bool on; ConvK k; int MT, gx, gy; float* dW; float* db; };
+PendingWgrad& pending_wgrad();                                                            // conv_deep.hip
+bool& defer_next_wgrad();                                                                 // conv_deep.hip: set by conv3d_bwd_impl around its weight-gradient launch
+int wgrad_lean_defer(ConvK& k, int ksize, int stride, int MT, int gx, int gy, float* dW, float* db);     // conv_wgrad_lean.hip: 0 = parked, 1 = not this shape
+int wgrad_lean_flush(hipStream_t st);                                                     // launches a parked weight gradient, if any
 int launch_conv_deep(ConvK& k, int ksize, int stride, int mode, hipStream_t st);   // conv_deep.hip: 32-channel-chunk K axes over small volumes (levels 3..5)
-extern int g_conv_deep;
+extern int g_conv_deep, g_deep_pair;
 int launch_conv_s2_dgrad(ConvK& k, const void* packed_bf16, hipStream_t st);   // conv_s2_dgrad.hip: stride-2 padded-domain dgrad, gather form
 extern int g_conv_s2;
 int launch_conv_pw_fwd(ConvK& k, int K8, hipStream_t st);   // conv_pw.hip: 1x1x1 forward as a streaming GEMM (wide volumes)

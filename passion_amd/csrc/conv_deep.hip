@@ -22,8 +22,18 @@
 #include <cstdlib>
 #include "conv_common.h"
 #include "prof.h"
+#include "wgrad_lean_body.h"
 
-namespace pconv { extern int g_conv_dbg; int g_conv_deep = 1; }
+namespace pconv {
+extern int g_conv_dbg;
+int g_conv_deep = 1;
+int g_deep_pair = 0;          // option "deep_pair" / PASSION_DEEP_PAIR=1: input gradient + weight gradient of a deep-level 3x3x3 conv as one launch.
+                              // OFF: measured 1.0-1.3 % SLOWER on the plain and the PASSION step (6 interleaved runs each): the
+                              // weight gradient can then no longer clear the InstanceNorm-backward sums in its own launch (a memset node per conv
+                              // takes the launch's place), and the launches it removes already ran beside other streams
+PendingWgrad& pending_wgrad() { static thread_local PendingWgrad pw{}; return pw; }
+bool& defer_next_wgrad() { static thread_local bool f = false; return f; }
+}
 using namespace pconv;
 
 namespace {
@@ -110,7 +120,7 @@ __device__ __forceinline__ ChunkHdr chunk_hdr(const ConvK& p, int b, int c, long
 // MODE 0 forward; 1 input gradient written in place (KS 1 only); 2 input gradient over the padded domain (KS 3)
 // MAXU: staged voxels per thread and chunk (64 voxel slots x 4 blocks per pass over the staged region)
 template <int KS, int MODE, int NKW, int NMW, int NNW, int MAXU>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void conv_deep_kernel(ConvK p, DeepP q) {
+__device__ __forceinline__ void conv_deep_body(const ConvK& p, const DeepP& q, const int bxi, const int byi, const int gxn) {
     static_assert(NKW * NMW * NNW == 4, "four waves");
     static_assert(MODE == 0 || (MODE == 1 && KS == 1) || (MODE == 2 && KS == 3), "modes");
     constexpr bool DG = MODE >= 1;
@@ -127,13 +137,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
     ChunkDesc* desc = reinterpret_cast<ChunkDesc*>(lds + q.red_off);
 
     // ---- which outputs: sample b, plane od, flat run [f0, f0 + FT) of the plane
-    const int bx = xcd_swizzle(blockIdx.x, gridDim.x);
+    const int bx = xcd_swizzle(bxi, gxn);
     const int fx = bx % q.nfx, od = (bx / q.nfx) % q.Od, b = bx / (q.nfx * q.Od);
     const int f0 = fx * q.FT, f1 = min(f0 + q.FT, q.PF) - 1;
     const int h_lo = fdiv(f0, q.inv_ow), h_hi = fdiv(f1, q.inv_ow);
     const int NRc = KS == 3 ? h_hi - h_lo + 3 : 1;               // staged rows of this workgroup
     const int RS = q.RW * VS, PS = NRc * RS, CS = NPL * PS;      // row / plane / chunk strides of the staged region
-    const int mtile = blockIdx.y * NMW + mq;                     // 16-row tile of the M axis
+    const int mtile = byi * NMW + mq;                     // 16-row tile of the M axis
     const int Sd = p.Di, Sh = p.Hi, Sw = p.Wi;
     const long vol = (long)Sd * Sh * Sw;
     const int K8 = q.K8;
@@ -228,7 +238,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
     }
     if (DG && tid >= 192 && tid < 192 + NMW * 16) {              // epilogue descriptors: one thread per output row
         const int e = (tid - 192) >> 4, r = (tid - 192) & 15;
-        const int cg = (blockIdx.y * NMW + e) * 16 + r;
+        const int cg = (byi * NMW + e) * 16 + r;
         EpiD& d = edesc[e];
         if (r == 0) { d.x = nullptr; d.dx = nullptr; d.C = 16; d.ok = 0; d.has_stats = 0; d.mval = 1.f; }
         d.mean[r] = 0.f; d.rstd[r] = 1.f;
@@ -451,14 +461,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
     }
     __syncthreads();
     if (!DG) {
-        fwd_stats_commit(p.fst, p.Cout, b, od * q.nfx + fx, blockIdx.y * NMW * 16, NMW * 16, wsum, tid);
+        fwd_stats_commit(p.fst, p.Cout, b, od * q.nfx + fx, byi * NMW * 16, NMW * 16, wsum, tid);
     } else {
         for (int i = tid; i < NMW * 16 * 2; i += 256) {
             const int row = i >> 1, k2 = i & 1;
-            const int cg = blockIdx.y * NMW * 16 + row;
+            const int cg = byi * NMW * 16 + row;
             const float t = wsum[i];
             if (cg < p.Cin && t != 0.f) {
-                const long idx = (long)(blockIdx.x % p.sums_rep) * p.B * p.Cin * 2 + ((long)b * p.Cin + cg) * 2 + k2;
+                const long idx = (long)(bxi % p.sums_rep) * p.B * p.Cin * 2 + ((long)b * p.Cin + cg) * 2 + k2;
                 if (p.sums_fixed) {
                     double v = (double)t * 1099511627776.0;                      // 2^40
                     v = fmin(fmax(v, -9.0e18), 9.0e18);
@@ -468,6 +478,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
                 }
             }
         }
+    }
+}
+
+template <int KS, int MODE, int NKW, int NMW, int NNW, int MAXU>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void conv_deep_kernel(ConvK p, DeepP q) {
+    conv_deep_body<KS, MODE, NKW, NMW, NNW, MAXU>(p, q, (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.x);
+}
+
+// Input gradient (conv_deep_body, MODE 2) and weight gradient (wgrad_lean_body) of ONE 3x3x3 deep-level conv as two workgroup ranges of
+// one grid: workgroups [0, nd) are the input gradient's (gxd x gyd), the rest the weight gradient's (gxw x gyw).  Both read (x, dY), neither
+// depends on the other, each is 64..256 workgroups bound by its own latency chain (descriptor -> loads -> MFMA -> epilogue): side by side
+// they cost what the longer one costs, and a conv backward at levels 3..5 is two launches (this one, the finish) instead of three.
+template <int NKW, int NMW, int NNW, int MAXU, int MT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void deep_pair_kernel(ConvK pd, DeepP q, ConvK pw, float* __restrict__ dW,
+                                                                                                 float* __restrict__ dbias, int gxd, int gyd, int gxw) {
+    const int bid = (int)blockIdx.x, nd = gxd * gyd;
+    if (bid < nd) {
+        conv_deep_body<3, 2, NKW, NMW, NNW, MAXU>(pd, q, bid % gxd, bid / gxd, gxd);
+    } else {
+        const int w = bid - nd;
+        pconv_wl::wgrad_lean_body<3, MT>(pw, dW, dbias, w % gxw, w / gxw, gxw);
     }
 }
 
@@ -496,12 +527,34 @@ long deep_geometry(DeepP& q, int nkw, int nmw, int nnw, int* nv_max) {
     return bytes <= 160 * 1024 - 4096 ? bytes : 0;
 }
 
+// the pair launch: 0 = launched (the parked weight gradient is consumed), 1 = not for this instantiation
+template <int NKW, int NMW, int NNW, int MAXU>
+int launch_deep_pair(ConvK& k, DeepP& q, long bytes, int gx, int gy, hipStream_t st) {
+    PendingWgrad& pw = pending_wgrad();
+    constexpr long WG_STATIC = 33 * 1024;                 // static LDS of the weight-gradient body (activation, dY and indicator images) + the input gradient's own
+    if (!pw.on || pw.MT != 2 || !g_deep_pair || bytes + WG_STATIC > 160 * 1024) return 1;
+    static int attr_bytes = 0;
+    if (bytes > attr_bytes) {
+        HIP_RET(hipFuncSetAttribute(reinterpret_cast<const void*>(&deep_pair_kernel<NKW, NMW, NNW, MAXU, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+        attr_bytes = (int)bytes;
+    }
+    passion_prof_tag("deep_pair_kernel<%d, %d, %d, %d> (conv_deep_kernel<3, 2, ...> + wgrad_lean_kernel<3, 2>)", NKW, NMW, NNW, MAXU);
+    pw.on = false;
+    hipLaunchKernelGGL((deep_pair_kernel<NKW, NMW, NNW, MAXU, 2>), dim3(gx * gy + pw.gx * pw.gy), dim3(256), (size_t)bytes, st, k, q, pw.k, pw.dW, pw.db, gx, gy, pw.gx);
+    LAUNCH_RET();
+    return 0;
+}
+
 template <int KS, int MODE, int NKW, int NMW, int NNW, int MAXU>
 int launch_deep_one(ConvK& k, DeepP& q, int mtiles, hipStream_t st) {
     int nv = 0;
     const long bytes = deep_geometry<KS>(q, NKW, NMW, NNW, &nv);
     if (!bytes || (nv + 63) / 64 > MAXU) return 1;
     const int gx = k.B * q.Od * q.nfx, gy = (mtiles + NMW - 1) / NMW;
+    if constexpr (KS == 3 && MODE == 2 && ((NKW == 1 && MAXU == 12) || (NKW == 2 && NMW == 2))) {      // the instantiations the steps use (tools/launch_table.py)
+        const int rc = launch_deep_pair<NKW, NMW, NNW, MAXU>(k, q, bytes, gx, gy, st);
+        if (rc <= 0) return rc;
+    }
     k.fst.stats = nullptr;
     if (MODE == 0 && k.fst_want) {
         const int rc = fwd_stats_setup(k, q.Od * q.nfx, gy, st);

@@ -197,6 +197,118 @@ int ln_nblk(long rpg, int C) {
 
 }  // namespace
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// The elementwise glue of the reference's Transformer blocks (code/models/mmformer.py:230-313) as ONE pass each way:
+//     out = [x +] drop_2(drop_1(act(y)))          act = identity | GELU (erf form), drop_i = nn.Dropout(p) in training mode
+// -- `x + self.dropout(self.proj_drop(proj(...)))` (SelfAttention.proj_drop inside PreNormDrop.dropout inside Residual: two dropouts
+// in a row, :226 / :256 / :247), `dropout(gelu(h))` (FeedForward :271-273) and `x + dropout(h)` (:275 / :247).  torch ran them as 2-4
+// launches forward (GELU, fused_dropout x 1-2, add) and as many backward (masked_scale, gelu_backward) over (tokens, 512 ... 4096)
+// tensors: ~1 ms of ATen launches per step in all.  Keep bits: 16-bit fields of a two-round counter hash of (seed, element index)
+// (field >= thr keeps; two dropouts take the two fields of one word: independent, as the reference's two modules are); the seed is
+// drawn per call from torch's generator, a replayed HIP graph adds its step words (passion_set_step_words) like the attention kernels.
+extern const unsigned* g_passion_step_words;      // api.cpp: passion_set_step_words
+namespace {
+__device__ __forceinline__ unsigned tok_hash(unsigned i, unsigned s0, unsigned s1) {
+    unsigned x = i ^ s0;
+    x = __umul24(x, 0xB5297Au) + (x >> 9);
+    x ^= x >> 15;
+    x += s1;
+    x = __umul24(x, 0x68E31Du) + (x >> 11);
+    x ^= x >> 14;
+    return x;
+}
+// scale * keep of element i (ndrop = 1: the low field; 2: both)
+__device__ __forceinline__ float tok_keep(unsigned i, unsigned s0, unsigned s1, unsigned thr, int ndrop, float scale) {
+    if (!thr) return 1.f;
+    const unsigned u = tok_hash(i, s0, s1);
+    const bool k = (u & 0xffffu) >= thr && (ndrop < 2 || (u >> 16) >= thr);
+    return k ? scale : 0.f;
+}
+
+template <typename TY, typename TO>
+__global__ __launch_bounds__(256) void token_drop_fwd_kernel(const TY* __restrict__ y, const float* __restrict__ x, TO* __restrict__ out, long n8,
+                                                             unsigned thr, float scale, unsigned s0, unsigned s1, const unsigned* soff, int ndrop, int act) {
+    if (soff) { s0 += soff[0]; s1 += soff[1]; }
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
+        float v[8], r[8];
+        ld8<TY>(y + i * 8, v);
+        if (x) ld8<float>(x + i * 8, r);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float z = act ? gelu_f(v[j]) : v[j];
+            z *= tok_keep((unsigned)(i * 8 + j), s0, s1, thr, ndrop, scale);
+            v[j] = x ? r[j] + z : z;
+        }
+        st8<TO>(out + i * 8, v);
+    }
+}
+// dy = g * keep * scale [* gelu'(y)]
+template <typename TY, typename TO>
+__global__ __launch_bounds__(256) void token_drop_bwd_kernel(const TO* __restrict__ g, const TY* __restrict__ y, TY* __restrict__ dy, long n8,
+                                                             unsigned thr, float scale, unsigned s0, unsigned s1, const unsigned* soff, int ndrop, int act) {
+    if (soff) { s0 += soff[0]; s1 += soff[1]; }
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
+        float gv[8], v[8];
+        ld8<TO>(g + i * 8, gv);
+        if (act) ld8<TY>(y + i * 8, v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float z = gv[j] * tok_keep((unsigned)(i * 8 + j), s0, s1, thr, ndrop, scale);
+            if (act) z *= gelu_d(v[j]);
+            gv[j] = z;
+        }
+        st8<TY>(dy + i * 8, gv);
+    }
+}
+
+}  // namespace
+
+// y_dtype / out_dtype: PASSION_BF16 | PASSION_F32 ((bf16, bf16), (bf16, f32), (f32, f32)); x: f32 residual or NULL; n % 8 == 0; act 0 / 1 (GELU)
+extern "C" int passion_token_drop_fwd(const void* y, const float* x, void* out, int64_t n, int y_dtype, int out_dtype, float p, int ndrop, int act,
+                                      uint64_t seed, void* stream) {
+    if (n < 8 || n % 8 || n >= (1LL << 32) || !(p >= 0.f && p < 1.f) || ndrop < 1 || ndrop > 2) return -1011;
+    if ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(out)) & 15) return -1005;
+    const unsigned thr = (unsigned)(p * 65536.0f + 0.5f);
+    const float keep = 1.0f - (float)thr / 65536.0f, scale = thr ? (ndrop == 2 ? 1.0f / (keep * keep) : 1.0f / keep) : 1.0f;
+    const long n8 = n / 8;
+    const int blocks = (int)((n8 + 255) / 256 < 4096 ? (n8 + 255) / 256 : 4096);
+    const unsigned s0 = (unsigned)(seed & 0xffffffffu), s1 = (unsigned)(seed >> 32);
+    hipStream_t st = (hipStream_t)stream;
+    if (y_dtype == PASSION_BF16 && out_dtype == PASSION_BF16)
+        hipLaunchKernelGGL((token_drop_fwd_kernel<bf16_t, bf16_t>), dim3(blocks), dim3(256), 0, st, (const bf16_t*)y, x, (bf16_t*)out, n8, thr, scale, s0, s1, g_passion_step_words, ndrop, act);
+    else if (y_dtype == PASSION_BF16 && out_dtype == PASSION_F32)
+        hipLaunchKernelGGL((token_drop_fwd_kernel<bf16_t, float>), dim3(blocks), dim3(256), 0, st, (const bf16_t*)y, x, (float*)out, n8, thr, scale, s0, s1, g_passion_step_words, ndrop, act);
+    else if (y_dtype == PASSION_F32 && out_dtype == PASSION_F32)
+        hipLaunchKernelGGL((token_drop_fwd_kernel<float, float>), dim3(blocks), dim3(256), 0, st, (const float*)y, x, (float*)out, n8, thr, scale, s0, s1, g_passion_step_words, ndrop, act);
+    else
+        return -1007;
+    LAUNCH_RET();
+    return 0;
+}
+
+// g: gradient of out (out_dtype); dy (y_dtype) = g * keep * scale [* gelu'(y)]; the residual's gradient is g itself
+extern "C" int passion_token_drop_bwd(const void* g, const void* y, void* dy, int64_t n, int y_dtype, int out_dtype, float p, int ndrop, int act,
+                                      uint64_t seed, void* stream) {
+    if (n < 8 || n % 8 || n >= (1LL << 32) || !(p >= 0.f && p < 1.f) || ndrop < 1 || ndrop > 2 || (act && !y)) return -1011;
+    if ((reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(dy)) & 15) return -1005;
+    const unsigned thr = (unsigned)(p * 65536.0f + 0.5f);
+    const float keep = 1.0f - (float)thr / 65536.0f, scale = thr ? (ndrop == 2 ? 1.0f / (keep * keep) : 1.0f / keep) : 1.0f;
+    const long n8 = n / 8;
+    const int blocks = (int)((n8 + 255) / 256 < 4096 ? (n8 + 255) / 256 : 4096);
+    const unsigned s0 = (unsigned)(seed & 0xffffffffu), s1 = (unsigned)(seed >> 32);
+    hipStream_t st = (hipStream_t)stream;
+    if (y_dtype == PASSION_BF16 && out_dtype == PASSION_BF16)
+        hipLaunchKernelGGL((token_drop_bwd_kernel<bf16_t, bf16_t>), dim3(blocks), dim3(256), 0, st, (const bf16_t*)g, (const bf16_t*)y, (bf16_t*)dy, n8, thr, scale, s0, s1, g_passion_step_words, ndrop, act);
+    else if (y_dtype == PASSION_BF16 && out_dtype == PASSION_F32)
+        hipLaunchKernelGGL((token_drop_bwd_kernel<bf16_t, float>), dim3(blocks), dim3(256), 0, st, (const float*)g, (const bf16_t*)y, (bf16_t*)dy, n8, thr, scale, s0, s1, g_passion_step_words, ndrop, act);
+    else if (y_dtype == PASSION_F32 && out_dtype == PASSION_F32)
+        hipLaunchKernelGGL((token_drop_bwd_kernel<float, float>), dim3(blocks), dim3(256), 0, st, (const float*)g, (const float*)y, (float*)dy, n8, thr, scale, s0, s1, g_passion_step_words, ndrop, act);
+    else
+        return -1007;
+    LAUNCH_RET();
+    return 0;
+}
+
 extern "C" int passion_ln_act_supported(int64_t rows, int C, int64_t rows_per_group) { return ln_shape_ok(rows, C, rows_per_group) ? 1 : 0; }
 
 extern "C" int64_t passion_ln_act_part_floats(int64_t rows, int C, int64_t rows_per_group) {

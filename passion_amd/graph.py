@@ -167,6 +167,12 @@ class GraphedStep:
             ptrain.train_step(self.model, self.optimizer, None, None, None, phase="tail", reducer=self.reducer)
         return self.loss
 
+    def input_buffers(self):
+        """-> (x, mask, target): the tensors the recording reads, or None before it exists.  A loader may write the next batch straight
+        into them (the H2D copy's destination) and hand THEM to __call__: the staging copies of _replay (x: 4 B / voxel, the float64
+        label volume: 32 B / voxel -- 0.1 ms per 128^3 step) are then skipped, as the eager step has none either"""
+        return (self.sx, self.smask, self.starget) if self.graph is not None else None
+
     def __call__(self, x, mask, target):
         """one training iteration on (x, mask, target); returns the loss (a static tensor once the step is recorded: the next call
         overwrites it)"""

@@ -185,16 +185,23 @@ def intra_grouped(model, x5, mask, B, bf16):
     p_att = sa[0].attn_drop.p if training else 0.0
     o = ops.attention(qkv.view(G * B, N, 3 * C), sa[0].num_heads, sa[0].scale, p_att)               # batch 4B
     o = ops.linear_grouped(o.reshape(G, B * N, C), [m.proj.weight for m in sa], [m.proj.bias for m in sa], bf16)
-    o = F.dropout(o, sa[0].proj_drop.p, training)
-    o = F.dropout(o, att[0].dropout.p, training)
-    xr = o + xr
+    fuse = FUSE_TOKEN_GLUE and training and xr.dtype == torch.float32 and sa[0].proj_drop.p == att[0].dropout.p
+    if fuse and ops.token_drop_ok(o, xr):
+        xr = ops.token_drop(o, xr, att[0].dropout.p, 2, 0)
+    else:
+        o = F.dropout(o, sa[0].proj_drop.p, training)
+        o = F.dropout(o, att[0].dropout.p, training)
+        xr = o + xr
     ff = [f.fn.net for f in ffn]
     h = gnorm([f.norm for f in ffn], xr)
     h = ops.linear_grouped(h, [n[0].weight for n in ff], [n[0].bias for n in ff], bf16)
-    h = F.dropout(F.gelu(h), ff[0][2].p, training)
+    h = ops.token_drop(h, None, ff[0][2].p, 1, 1) if (fuse and ops.token_drop_ok(h)) else F.dropout(F.gelu(h), ff[0][2].p, training)
     h = ops.linear_grouped(h, [n[3].weight for n in ff], [n[3].bias for n in ff], bf16)
-    h = F.dropout(h, ff[0][4].p, training)
-    xr = h + xr
+    if fuse and ops.token_drop_ok(h, xr):
+        xr = ops.token_drop(h, xr, ff[0][4].p, 1, 0)
+    else:
+        h = F.dropout(h, ff[0][4].p, training)
+        xr = h + xr
     gm = mask.t().reshape(G, B, 1, 1).to(xr.dtype)
     return xr.view(G, B, N, C) * gm
 
@@ -308,16 +315,20 @@ class SelfAttention(nn.Module):
         self.proj = Linear(dim, dim)
         self.proj_drop = nn.Dropout(dropout_rate)
 
-    def forward(self, x):
+    def forward(self, x, drop=True):
         qkv = self.qkv(x)
         p = self.attn_drop.p if self.training else 0.0
         x = ops.attention(qkv, self.num_heads, self.scale, p)
-        return self.proj_drop(self.proj(x))
+        x = self.proj(x)
+        return self.proj_drop(x) if drop else x          # drop=False: the caller applies proj_drop together with what follows (Residual)
 
 
 def _autocast_bf16():
     """bf16 when the token GEMMs run under bf16 autocast (their Linear casts its input then: the LayerNorm in front writes it directly)"""
     return torch.bfloat16 if (torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") == torch.bfloat16) else None
+
+
+FUSE_TOKEN_GLUE = _os.environ.get("PASSION_FUSE_TOKEN_GLUE", "1") != "0"   # dropout / GELU / residual adds of the transformer blocks in one launch each (ops.token_drop)
 
 
 class Residual(nn.Module):
@@ -326,6 +337,17 @@ class Residual(nn.Module):
         self.fn = fn
 
     def forward(self, x):
+        f = self.fn
+        if FUSE_TOKEN_GLUE and self.training and x.is_cuda and x.dtype == torch.float32:
+            # training on the GPU: the block's dropouts and its residual add in one pass (the reference's op sequence, mmformer.py:247,256,226 /
+            # :247,262,271-275, with the masks of its nn.Dropout modules drawn by the kernel)
+            if isinstance(f, PreNormDrop) and isinstance(f.fn, SelfAttention):
+                y = f.fn(_ln(f.norm, x, out_dtype=_autocast_bf16()), drop=False)
+                if f.fn.proj_drop.p == f.dropout.p and ops.token_drop_ok(y, x):
+                    return ops.token_drop(y, x, f.dropout.p, 2, 0)
+                return f.dropout(f.fn.proj_drop(y)) + x
+            if isinstance(f, PreNorm) and isinstance(f.fn, FeedForward):
+                return f.fn(_ln(f.norm, x, out_dtype=_autocast_bf16()), residual=x)
         return self.fn(x) + x
 
 
@@ -361,8 +383,15 @@ class FeedForward(nn.Module):
         self.net = nn.Sequential(Linear(dim, hidden_dim), GELU(), nn.Dropout(p=dropout_rate),
                                  Linear(hidden_dim, dim), nn.Dropout(p=dropout_rate))
 
-    def forward(self, x):
-        return self.net(x)
+    def forward(self, x, residual=None):
+        """residual given (training on the GPU, Residual.forward): -> residual + net(x), GELU + dropout and dropout + add as one launch each"""
+        if residual is None:
+            return self.net(x)
+        l1, _, d1, l2, d2 = self.net
+        h = l1(x)
+        h = ops.token_drop(h, None, d1.p, 1, 1) if ops.token_drop_ok(h) else d1(F.gelu(h))
+        h = l2(h)
+        return ops.token_drop(h, residual, d2.p, 1, 0) if ops.token_drop_ok(h, residual) else d2(h) + residual
 
 
 class Transformer(nn.Module):

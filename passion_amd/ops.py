@@ -1093,6 +1093,50 @@ def _draw_seed():
     return int(torch.empty((), dtype=torch.int64).random_().item()) & (2 ** 64 - 1)
 
 
+class TokenDropFn(torch.autograd.Function):
+    """out = [x +] dropout(dropout(act(y))) in one launch each way (csrc/token_ops.hip token_drop_*): the glue of the reference's
+    Transformer blocks -- `x + self.dropout(self.proj_drop(proj))` (mmformer.py:226,247,256), `dropout(gelu(h))` (:271-273),
+    `x + dropout(h)` (:275,247).  y: GEMM output (bf16 under autocast, else f32); x: the f32 residual stream or None;
+    ndrop: nn.Dropout modules in a row (independent masks); act: 0 identity, 1 GELU.  The masks are regenerated in the backward from the
+    forward's seed (drawn from torch's generator: follows torch.manual_seed)."""
+
+    @staticmethod
+    def forward(ctx, y, x, p, ndrop, act):
+        L.require_gpu(y)
+        y = y.contiguous()
+        out_dtype = torch.float32 if x is not None else y.dtype
+        out = torch.empty(y.shape, dtype=out_dtype, device=y.device)
+        seed = _draw_seed() if p > 0 else 0
+        xs = x.contiguous() if x is not None else None
+        L.check(L.load().passion_token_drop_fwd(_p(y), _p(xs), _p(out), y.numel(), L.dtype_code(y.dtype), L.dtype_code(out_dtype), float(p), ndrop, act,
+                                                seed, L.stream_ptr()), "passion_token_drop_fwd")
+        ctx.meta = (float(p), ndrop, act, seed, x is not None)
+        ctx.save_for_backward(y if act else y.new_empty(0))
+        ctx.ydtype, ctx.yshape = y.dtype, y.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        p, ndrop, act, seed, has_x = ctx.meta
+        (y,) = ctx.saved_tensors
+        g = g.contiguous()
+        dy = torch.empty(ctx.yshape, dtype=ctx.ydtype, device=g.device)
+        L.check(L.load().passion_token_drop_bwd(_p(g), _p(y) if act else c_void_p(0), _p(dy), dy.numel(), L.dtype_code(ctx.ydtype), L.dtype_code(g.dtype),
+                                                p, ndrop, act, seed, L.stream_ptr()), "passion_token_drop_bwd")
+        return dy, (g if has_x else None), None, None, None
+
+
+def token_drop_ok(y, x=None):
+    """the fused kernel takes GPU tensors of 8-element multiples in (bf16 | f32) with an f32 residual"""
+    return (y.is_cuda and y.dtype in (torch.bfloat16, torch.float32) and y.numel() % 8 == 0 and y.numel() < 2 ** 32 and
+            (x is None or (x.dtype == torch.float32 and x.shape == y.shape)))
+
+
+def token_drop(y, x=None, p=0.0, ndrop=1, act=0):
+    """[x +] dropout^ndrop(act(y)) (training-mode dropout with probability p each)"""
+    return TokenDropFn.apply(y, x, float(p), int(ndrop), int(act))
+
+
 class FlashAttentionFn(torch.autograd.Function):
     """fused attention for bf16, 64-wide heads (csrc/flash_attn.hip): no (B,H,N,N) tensor, backward recomputes from the row
     log-sum-exp; attention dropout is a counter-based mask regenerated in the backward from the forward's seed"""

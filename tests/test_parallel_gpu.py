@@ -246,9 +246,10 @@ def test_rfnet_two_ranks_sum_gradients_and_stay_in_step(tmp_path):
     assert set(want) == set(got["g"])
     bad = [(k, float((got["g"][k] - w).abs().max()), float(w.abs().max()), "vs rank 0 alone", float((got["g"][k] - per[0][k]).abs().max()),
             "vs rank 1 alone", float((got["g"][k] - per[1][k]).abs().max()), "vs 2 x rank 0", float((got["g"][k] - 2 * per[0][k]).abs().max()))
-           for k, w in want.items() if float((got["g"][k] - w).abs().max()) > 1e-2 * float(w.abs().max()) + 1e-7]
+           for k, w in want.items() if float((got["g"][k] - w).abs().max()) > 1e-2 * float(w.abs().max()) + 1e-4]
     # (observed: 272 of 288 tensors bit-equal; the first two layers of every encoder differ by ~1e-3 of their largest entry -- one bf16
-    # rounding of the summed activation gradient that reaches them; a rank's share missing or a stale bucket is an O(1) error)
+    # rounding of the summed activation gradient that reaches them -- and the conv biases in front of an InstanceNorm have an analytically
+    # ZERO gradient, theirs is rounding noise of 1e-5: hence the absolute floor; a rank's share missing or a stale bucket is an O(1) error)
     exact = sum(torch.equal(got["g"][k], w) for k, w in want.items())
     print(f"rfnet 2 ranks: {exact} of {len(want)} reduced gradient tensors equal the single-process sum bit for bit")
     assert not bad, bad[:5]
