@@ -226,7 +226,10 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2))) vo
     };
 
     f32x16 o[2] = {zero16(), zero16()};          // forward: O^T[d][q]; backward: dQ^T[d][q]
-    f32x16 lacc = zero16();                      // forward: every register = the running row sum of this lane's query (ones . P^T)
+    f32x16 lacc = zero16();                      // forward with dropout: every register = the running row sum of this lane's query (ones . P^T)
+    float l_run = 0.f;                           // forward without dropout: the row sum in f32, as before round 5 -- the evaluation / parity path
+                                                 // keeps its arithmetic (the sum of the bf16-rounded probabilities moved the bf16 PASSION
+                                                 // trajectory by one near-tie gate decision: test_trajectory_gpu)
     float m_run = -INFINITY;
     bf16x8 ones;
 #pragma unroll
@@ -313,23 +316,29 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2))) vo
                 const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);     // first block: exp2(-inf) = 0
                 m_run = m_new;
                 lacc[0] *= alpha;                        // the other fifteen registers hold the same sum and are never read
+                l_run *= alpha;
 #pragma unroll
                 for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
             }
+            float psum = 0.f;
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) st[kt][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(st[kt][r], p.c, -m_run));
-            // ---- row sum: ones . P^T on the matrix pipe (all keys of the tile, both lane halves); O^T += V^T . (P^T, dropped):
+                for (int r = 0; r < 16; ++r) {
+                    st[kt][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(st[kt][r], p.c, -m_run));
+                    if (!DROP) psum += st[kt][r];
+                }
+            l_run += psum;
+            // ---- row sum (DROP): ones . P^T on the matrix pipe (all keys of the tile, both lane halves); O^T += V^T . (P^T, dropped):
             // the mask is applied to the packed bf16 pairs (register pair (r, r + 1) = keys 2 kp, 2 kp + 1 = the word's two fields)
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
                     const bf16x8 pu = pack8(st[kt], s);
-                    lacc = MFMA32(ones, pu, lacc);
+                    if (DROP) lacc = MFMA32(ones, pu, lacc);
                     bf16x8 pf = pu;
                     if (DROP) {
                         u32x4 pw = __builtin_bit_cast(u32x4, pu);
@@ -392,7 +401,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2))) vo
                 for (int r = 0; r < 16; ++r) p.po[row * DH + dt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h] = o[dt][r];
         }
         if (MODE == 0) {
-            const float l_tot = lacc[0];
+            const float l_tot = DROP ? lacc[0] : half_sum(l_run);
             if (qok && h == 0) { p.pm[row] = m_run; p.pl[row] = l_tot; }
         }
         return;
@@ -400,7 +409,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2))) vo
     // ---- epilogue: scale, transpose through LDS (the tile buffers are free after the last barrier), whole 128-byte rows out
     float f;
     if (MODE == 0) {
-        const float l_tot = lacc[0];
+        const float l_tot = DROP ? lacc[0] : half_sum(l_run);
         f = p.inv_keep / l_tot;
         if (qok && h == 0) p.lse[((long)b * p.H + hh) * N + q] = m_run + __builtin_amdgcn_logf(l_tot);
     } else {

@@ -13,7 +13,12 @@ python3 bench.py --workload mmformer128_passion --no-cpu-baseline > $O/${TAG}_be
 python3 bench.py --workload rfnet128_passion --no-cpu-baseline > $O/${TAG}_bench_rfnet128_passion.json 2>/dev/null
 python3 bench.py --workload m2ftrans128 --no-cpu-baseline --no-dice > $O/${TAG}_bench_m2ftrans128.json 2>/dev/null
 python3 bench.py --workload m2ftrans128_passion --no-cpu-baseline --no-dice > $O/${TAG}_bench_m2ftrans128_passion.json 2>/dev/null
-python3 bench.py --workload mmformer_depth --no-cpu-baseline --no-dice > $O/${TAG}_bench_depth_n1.json 2>/dev/null
+BENCH_HOST=1 python3 bench.py --workload mmformer_depth --no-cpu-baseline --no-dice > $O/${TAG}_bench_depth_n1.json 2> $O/${TAG}_bench_depth_n1.err
+BENCH_HOST=1 python3 bench.py --workload mmformer_depth --launch eager --no-cpu-baseline --no-dice > $O/${TAG}_bench_depth_n1_eager.json 2> $O/${TAG}_bench_depth_n1_eager.err
+BENCH_HOST=1 python3 bench.py --workload mmformer_depth --ddp-mode --no-cpu-baseline --no-dice > $O/${TAG}_bench_depth_n1_loopback.json 2> $O/${TAG}_bench_depth_n1_loopback.err
+BENCH_HOST=1 python3 bench.py --ddp-mode --graph-collectives --no-cpu-baseline --no-dice --no-roofline > $O/${TAG}_bench_mmformer128_ddpmode_fullgraph.json 2> $O/${TAG}_bench_mmformer128_ddpmode_fullgraph.err
+python3 bench.py --workload mmformer128_passion --ddp-mode --no-cpu-baseline --no-dice --no-roofline > $O/${TAG}_bench_mmformer128_passion_ddpmode_eager.json 2>/dev/null
+python3 bench.py --workload mmformer128_passion --ddp-mode --graph-collectives --no-cpu-baseline --no-dice --no-roofline > $O/${TAG}_bench_mmformer128_passion_ddpmode_fullgraph.json 2>/dev/null
 BENCH_HOST=1 python3 bench.py --size 80 --no-cpu-baseline --no-dice --no-roofline > $O/${TAG}_bench_mmformer80.json 2> $O/${TAG}_bench_mmformer80.err
 BENCH_HOST=1 python3 bench.py --size 80 --launch eager --no-cpu-baseline --no-dice --no-roofline > $O/${TAG}_bench_mmformer80_eager.json 2> $O/${TAG}_bench_mmformer80_eager.err
 python3 tools/launch_table.py 128 300 2>/dev/null > $O/${TAG}_launch_table.txt
@@ -39,7 +44,10 @@ rm -rf gpurun_out/pmc_attn_bench
 bash tools/pmc_attention.sh gpurun_out/${TAG}_attention_pmc_saturating.json --B 16 --N 2048 > /dev/null 2>&1
 bash tools/pmc_attention.sh gpurun_out/${TAG}_attention_pmc_saturating_nodrop.json --B 16 --N 2048 --drop 0 > /dev/null 2>&1
 rm -rf gpurun_out/pmc_attn
-for f in mmformer128 mmformer128_eager mmformer128_ddpmode mmformer128_passion_split rfnet128_passion m2ftrans128 m2ftrans128_passion depth_n1 mmformer80 mmformer80_eager; do
+bash tools/kstats_run.sh rfnet128_passion ${TAG}_rfnet > /dev/null 2>&1
+PASSION_BENCH_GRAPH=0 bash tools/kstats_run.sh mmformer_depth ${TAG}_depth > /dev/null 2>&1
+python3 tools/rccl_capture_probe.py micro_ar micro_ara micro_ag micro_agt micro_p2p depth depthc_g ddp ddpp 2>&1 | grep "^\[" > gpurun_out/${TAG}_rccl_capture_probe.txt
+for f in mmformer128 mmformer128_eager mmformer128_ddpmode mmformer128_ddpmode_fullgraph mmformer128_passion_split mmformer128_passion_ddpmode_eager mmformer128_passion_ddpmode_fullgraph rfnet128_passion m2ftrans128 m2ftrans128_passion depth_n1 depth_n1_eager depth_n1_loopback mmformer80 mmformer80_eager; do
   echo "$f: $(python3 -c "import json; d=json.loads(open('gpurun_out/${TAG}_bench_$f.json').read().strip().splitlines()[-1]); print(d['value'], d['ms_per_step'])" 2>/dev/null)"
 done
 grep -h "host enqueue" gpurun_out/${TAG}_bench_*.err
