@@ -843,6 +843,14 @@ WgPlan plan_wgrad(const ConvK& k, const passion_conv_desc_t* d) {
     static const long wg_small = []() { const char* e = getenv("PASSION_WGRAD_WGS_SMALL"); return e && atol(e) > 0 ? atol(e) : 0L; }();
     const long wg_target = total <= 512 ? (wg_small ? wg_small : (total <= 64 ? 256L : 512L)) : 1024L;
     w.gx = (int)hmin(total, hmax(1, wg_target / w.gy));
+    // 1x1x1 on the streaming kernel (conv_wgrad_pw.hip): one workgroup handles every input block of its voxels, so the launch has gx
+    // workgroups, not gx x gy -- give it the whole target
+    if (d->ksize == 1 && d->stride == 1 && w.bf16 && w.MT == mtiles && pconv::wgrad_pw_covers(k, d->y_dtype == PASSION_F32))
+    {
+        // ... and one or two input blocks leave room for six wavefronts per SIMD (conv_wgrad_pw.hip launches as many workgroups of
+        // these slots as are resident at once)
+        w.gx = (int)hmin(total, (k.Cin <= 16 && total > 512 ? 2 : 1) * wg_target);
+    }
     return w;
 }
 

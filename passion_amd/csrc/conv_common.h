@@ -128,6 +128,9 @@ int wgrad_lean_defer(ConvK& k, int ksize, int stride, int MT, int gx, int gy, fl
 int wgrad_lean_flush(hipStream_t st);                                                     // launches a parked weight gradient, if any
 int launch_conv_deep(ConvK& k, int ksize, int stride, int mode, hipStream_t st);   // conv_deep.hip: 32-channel-chunk K axes over small volumes (levels 3..5)
 extern int g_conv_deep, g_deep_pair;
+bool wgrad_pw_covers(const ConvK& k, bool y_f32);                                      // conv_wgrad_pw.hip: 1x1x1 weight gradient, streaming form
+int launch_wgrad_pw(ConvK& k, int MT, int gx, int gy, float* dW, float* db, hipStream_t st);
+extern int g_wgrad_pw, g_wgrad_pw_minvox;
 int launch_conv_s2_dgrad(ConvK& k, const void* packed_bf16, hipStream_t st);   // conv_s2_dgrad.hip: stride-2 padded-domain dgrad, gather form
 extern int g_conv_s2;
 int launch_conv_pw_fwd(ConvK& k, int K8, hipStream_t st);   // conv_pw.hip: 1x1x1 forward as a streaming GEMM (wide volumes)

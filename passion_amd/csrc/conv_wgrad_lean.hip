@@ -218,6 +218,10 @@ bool wgrad_lean_covers(const ConvK& k, int ksize, int stride, int MT, int gx, in
 
 int launch_wgrad_lean(ConvK& k, int ksize, int stride, int MT, int gx, int gy, float* dW, float* db, hipStream_t st) {
     if (!wgrad_lean_covers(k, ksize, stride, MT, gx, gy)) return 1;
+    if (ksize == 1) {
+        const int rc = launch_wgrad_pw(k, MT, gx, gy, dW, db, st);                       // 1x1x1: the streaming kernel (conv_wgrad_pw.hip)
+        if (rc <= 0) return rc;
+    }
     {
         const int rc = launch_wgrad_march(k, ksize, stride, MT, gx, gy, dW, db, st);     // 3x3x3 with 8 output channels
         if (rc <= 0) return rc;

@@ -260,6 +260,71 @@ def test_pointwise_streaming_kernel(case):
     assert float(((st[..., 1] - want[..., 1]).abs() / want[..., 1]).max()) < 1e-4
 
 
+WPW_CASES = PW_CASES + [
+    # ragged volumes (voxel counts that are no multiple of the 64-voxel chunks / of the slots), one and two samples' worth of slots
+    ([8], 8, (5, 7, 9), True, True),
+    ([16, 16], 32, (3, 11, 13), True, False),
+    ([16, 16, 16, 16], 24, (9, 16, 17), True, True),
+    ([32], 16, (4, 4, 4), False, False),
+    # >= 8 M input elements: conv.hip plans the finish-free backward, the weight gradient also leaves the indicator sums (IDENT)
+    ([8], 8, (64, 64, 128), True, False),
+    ([8, 8, 8, 8], 8, (32, 64, 64), True, True),
+    ([16], 16, (64, 64, 64), True, False),
+]
+
+
+@pytest.mark.parametrize("f32_head", [False, True], ids=["bf16_dy", "f32_logits"])
+@pytest.mark.parametrize("case", WPW_CASES, ids=[str(i) for i in range(len(WPW_CASES))])
+def test_streaming_pointwise_weight_gradient_equals_the_lean_kernel(case, f32_head):
+    """conv_wgrad_pw.hip (a wavefront streams 64 voxels at a time, every input block of a voxel in one workgroup) against
+    wgrad_lean_kernel<1, *>: the same bf16 operands and MFMA products, another order of the f32 sums -- weight, bias and (through the
+    indicator sums of the finish-free backward) input gradients; and against the float64 reference"""
+    from passion_amd import ops
+    dev = _dev()
+    segC, Cout, (D, H, W), norm, use_mask = case
+    if f32_head:
+        if Cout > 8:
+            pytest.skip("f32 logits: <= 8 classes")
+        Cout = 4
+    dtype, B = torch.bfloat16, 2
+    g = torch.Generator().manual_seed(101 + Cout + len(segC))
+    xs = [(torch.randn(B, c, D, H, W, generator=g, dtype=torch.float64) * 1.5 + 0.3).to(dtype).double() for c in segC]
+    cin = sum(segC)
+    w = torch.randn(Cout, cin, 1, 1, 1, generator=g, dtype=torch.float64) / cin ** 0.5
+    b = torch.randn(Cout, generator=g, dtype=torch.float64)
+    cols = torch.tensor([[True, False, True, True, False, True, True, True], [False, True, True, False, True, True, False, True]])
+    mask = cols[:, :len(segC)] if use_mask else None
+    # a gradient with a mean: the InstanceNorm-backward means (which the finish-free backward takes from this kernel's indicator
+    # sums) are then O(1) terms of dx, not 1 / sqrt(V) ones -- a wrong indicator column shows
+    gy = torch.randn(B, Cout, D, H, W, generator=g, dtype=torch.float64) * 0.5 + torch.linspace(0.5, 1.5, Cout, dtype=torch.float64).view(1, -1, 1, 1, 1)
+    gy = gy.float().double() if f32_head else gy.to(dtype).double()
+    xr = [x.clone().requires_grad_(True) for x in xs]
+    wr, br = w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    masks = [None if mask is None else mask[:, i].double() for i in range(len(segC))]
+    ref_conv_block(xr, [norm] * len(segC), masks, wr, br, 1, 1, 0, None).backward(gy)
+    md = mask.to(dev) if mask is not None else None
+    res = {}
+    oldmin = ops.set_option("wgrad_pw_minvox", 0)      # the product leaves launches under 2^20 voxels on the lean kernel
+    for on in (1, 0):
+        old = ops.set_option("wgrad_pw", on)
+        try:
+            xd = [cl(x).to(dev, dtype).requires_grad_(True) for x in xs]
+            wd, bd = w.float().to(dev).requires_grad_(True), b.float().to(dev).requires_grad_(True)
+            segs = [ops.SegIn(x, stats=ops.instnorm_stats(x.detach()) if norm else None, mask=md, mask_col=i) for i, x in enumerate(xd)]
+            y = ops.conv_block(segs, wd, bd, D, H, W, ksize=1, stride=1, pad_mode=0, out_dtype=torch.float32 if f32_head else None)
+            y.backward(cl(gy).to(dev, torch.float32 if f32_head else dtype))
+            res[on] = (wd.grad.clone(), bd.grad.clone(), [x.grad.clone() for x in xd])
+        finally:
+            ops.set_option("wgrad_pw", old)
+    ops.set_option("wgrad_pw_minvox", oldmin)
+    dw, db, dxs = res[1]
+    assert relerr(dw, wr.grad) < 2 * TOL[dtype] and relerr(db, br.grad) < 2 * TOL[dtype]
+    assert relerr(dw, res[0][0]) < 1e-4 and relerr(db, res[0][1]) < 1e-4, (relerr(dw, res[0][0]), relerr(db, res[0][1]))
+    for a, c, r in zip(dxs, res[0][2], xr):
+        assert relerr(a.float(), c.float()) < 5e-3, relerr(a.float(), c.float())      # one bf16 step of the stored gradient at most
+        assert relerr(nc(a.float()), r.grad) < 3 * TOL[dtype]
+
+
 S2_CASES = [
     # (Cin, Cout, (D,H,W), normalised input, modality mask): the stride-2 convs of encoder levels 2..5 (mmformer.py:33,38,43,48) and
     # ragged / non-cube volumes; conv_s2_dgrad.hip (gather form: 1-8 taps per parity class) vs the zero-stuffed lean kernel
