@@ -130,6 +130,11 @@ int passion_conv3d_bwd(const passion_conv_desc_t* d, const float* packed, const 
  * Same arguments and scratch in both calls.  Batched-pass segments (bmod) are not supported here (-1019). */
 int passion_conv3d_bwd_phase(const passion_conv_desc_t* d, const float* packed, const void* dy, float* dweight, float* dbias,
                              float* scratch, int phase, float vscale, int dwin_lo, int dwin_hi, void* stream);
+/* ... and of a grouped launch (passion_conv3d_bwd_grouped): the four modality encoders of a sharded volume, one launch per layer and
+ * phase (reference code/models/mmformer.py:385-388,397-415).  -1021: no grouped kernels for this shape / dtype (go set by set). */
+int passion_conv3d_bwd_grouped_phase(const passion_conv_desc_t* d, int G, const float* const* packed, const void* dy,
+                                     float* const* dW, float* scratch, int phase, float vscale, int dwin_lo, int dwin_hi,
+                                     void* stream);
 
 /* ---- trilinear resampling, align_corners=True ---------------------------------------------
  * Replaces nn.Upsample(scale_factor=k, mode='trilinear', align_corners=True)

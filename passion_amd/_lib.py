@@ -56,6 +56,8 @@ SIGNATURES = {
                                            c_void_p]),
     "passion_conv3d_bwd_phase": (c_int, [POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float,
                                          c_int, c_int, c_void_p]),
+    "passion_conv3d_bwd_grouped_phase": (c_int, [POINTER(ConvDesc), c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float,
+                                                 c_int, c_int, c_void_p]),
     "passion_halo_pack": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int64, c_int, c_void_p]),
     "passion_halo_unpack": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int64, c_int, c_int, c_void_p]),
     "passion_halo_extend": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int64, c_int, c_int, c_int, c_int, c_int, c_int,

@@ -1776,6 +1776,45 @@ extern "C" int passion_conv3d_bwd_grouped(const passion_conv_desc_t* d, int G, c
     return 0;
 }
 
+// the two-phase backward (below) of a grouped launch: the four modality encoders of a depth-sharded volume as one launch per layer
+// and phase.  Only where both gradients have a grouped kernel (bf16, 8-channel-aligned): -1021 otherwise, the caller goes set by set.
+extern "C" int passion_conv3d_bwd_grouped_phase(const passion_conv_desc_t* d, int G, const float* const* packed, const void* dy,
+                                                float* const* dW, float* sums, int phase, float vscale, int dwin_lo, int dwin_hi,
+                                                void* stream) {
+    if (phase != 1 && phase != 2) return -1003;
+    int rc = check_groups(d, G);
+    if (rc) return rc;
+    ConvK k;
+    rc = fill_params(d, k);
+    if (rc) return rc;
+    const int nt = d->ksize * d->ksize * d->ksize;
+    const long nW = (long)k.Cout * k.Cin * nt;
+    if (G == 1) return conv3d_bwd_impl(d, packed[0], dy, dW ? dW[0] : nullptr, dW ? dW[0] + nW : nullptr, sums, stream, phase, vscale, dwin_lo, dwin_hi);
+    long stride = 0;
+    const bool bf16 = d->x_dtype == PASSION_BF16 && d->y_dtype == PASSION_BF16 && !g_passion_force_f32_mfma && uniform_stride(packed, G, stride);
+    k.tilesD = cdiv(k.Do, TD); k.tilesH = cdiv(k.Ho, TH); k.tilesW = cdiv(k.Wo, TW);
+    const WgPlan w = plan_wgrad(k, d);
+    const bool native_wgrad = bf16 && dW && w.bf16 && pconv::g_conv_lean && wgrad_bf16_chunk(k, d->ksize, d->stride) != 16 &&
+                              !(k.Cin == 1) && wgrad_lean_covers(k, d->ksize, d->stride, w.MT, w.gx, w.gy);
+    if (!(bf16 && bf16_eligible(k, true))) return -1021;
+    if (native_wgrad || !dW || phase == 2) {
+        GroupArgs ga{G, stride, nullptr, phase == 2 ? nullptr : dW};
+        return conv3d_bwd_impl(d, packed[0], dy, nullptr, nullptr, sums, stream, phase, vscale, dwin_lo, dwin_hi, &ga, (dW && phase == 1 && native_wgrad) ? 3 : 2);
+    }
+    // stride-2 layers: weight gradients set by set (general kernels), then ONE input-gradient pass -- as passion_conv3d_bwd_grouped
+    const int bg = d->B / G;
+    const long vout = (long)k.Do * k.Ho * k.Wo * k.Cout;
+    for (int g = 0; g < G; ++g) {
+        passion_conv_desc_t s = sub_desc(d, g, bg);
+        for (int i = 0; i < s.nseg; ++i) s.seg[i].dx = nullptr;
+        rc = conv3d_bwd_impl(&s, packed[g], static_cast<const char*>(dy) + (long)g * bg * vout * 2, dW[g], dW[g] + nW, sums, stream, 0, 1.0f, 0, d->D,
+                             nullptr, 1);
+        if (rc) return rc;
+    }
+    GroupArgs gd{G, stride, nullptr, nullptr};
+    return conv3d_bwd_impl(d, packed[0], dy, nullptr, nullptr, sums, stream, 1, vscale, dwin_lo, dwin_hi, &gd, 2);
+}
+
 extern "C" int passion_conv3d_bwd(const passion_conv_desc_t* d, const float* packed, const void* dy, float* dweight,
                                   float* dbias, float* sums, void* stream) {
     return conv3d_bwd_impl(d, packed, dy, dweight, dbias, sums, stream, 0, 1.0f, 0, d ? d->D : 0);

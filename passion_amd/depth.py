@@ -31,6 +31,8 @@ from . import _lib as L
 from . import ops
 from .ops import _p
 
+GROUPED = os.environ.get("PASSION_DEPTH_GROUPED", "1") != "0"     # encoders grouped, decoder_sep batched (0: one modality at a time)
+
 
 class DepthCtx:
     """rank r of `world` owns planes [r * D / world, (r + 1) * D / world) of every level (D divisible by world at every level it
@@ -347,6 +349,60 @@ class ShardedConvFn(torch.autograd.Function):
         return (None, None, None, None, dW, db if ctx.has_bias else None, None, *dxs)
 
 
+class ShardedConvGroupedFn(torch.autograd.Function):
+    """ShardedConvFn for G weight sets over one stacked batch (sample s uses set s // (B / G)): the four modality encoders as ONE
+    launch per layer and phase (passion_conv3d_fwd_grouped / passion_conv3d_bwd_grouped_phase), one halo exchange, one statistics
+    all-reduce and one all-reduce of the InstanceNorm-backward sums instead of four of each"""
+
+    @staticmethod
+    def forward(ctx, cfg, shard, win, Dg, G, packed, x, *wb):
+        ws, bs = wb[:G], wb[G:]
+        L.require_gpu(ws[0], x)
+        lib = L.load()
+        Cout = ws[0].shape[0]
+        pad = cfg.ksize // 2
+        Do = (cfg.D + 2 * pad - cfg.ksize) // cfg.stride + 1
+        Ho = (cfg.H + 2 * pad - cfg.ksize) // cfg.stride + 1
+        Wo = (cfg.W + 2 * pad - cfg.ksize) // cfg.stride + 1
+        y = torch.empty(cfg.B, Do, Ho, Wo, Cout, dtype=cfg.out_dtype, device=x.device)
+        d = ops._fill_desc(cfg, (x,))
+        d.Cout = Cout
+        n4 = packed.numel() // G
+        pk = (c_void_p * G)(*[packed.data_ptr() + 4 * g * n4 for g in range(G)])
+        b32 = [b.detach().float().contiguous() for b in bs]
+        bp = (c_void_p * G)(*[b.data_ptr() for b in b32])
+        L.check(lib.passion_conv3d_fwd_grouped(byref(d), G, pk, bp, c_void_p(0), _p(y), c_void_p(0), 1e-5, L.stream_ptr()),
+                "passion_conv3d_fwd_grouped")
+        ctx.cfg, ctx.packed, ctx.G, ctx.wshape = cfg, packed, G, ws[0].shape
+        ctx.shard, ctx.win, ctx.Dg = shard, win, Dg
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        cfg, (x,), shard, G = ctx.cfg, ctx.saved_tensors, ctx.shard, ctx.G
+        lib = L.load()
+        dy = dy.contiguous()
+        dev = dy.device
+        nW, Cout = ctx.wshape.numel(), ctx.wshape[0]
+        buf = torch.empty(G, nW + Cout, dtype=torch.float32, device=dev)
+        dx = torch.empty_like(x) if ctx.needs_input_grad[6] else None
+        d = ops._fill_desc(cfg, (x,), [dx])
+        d.Cout = Cout
+        Cin = sum(s.C for s in cfg.segs)
+        scratch = torch.empty(lib.passion_conv_bwd_scratch_floats(byref(d)), dtype=torch.float32, device=dev)
+        vscale = float(cfg.D) / float(ctx.Dg)
+        n4 = ctx.packed.numel() // G
+        pk = (c_void_p * G)(*[ctx.packed.data_ptr() + 4 * g * n4 for g in range(G)])
+        dwp = (c_void_p * G)(*[buf[g].data_ptr() for g in range(G)])
+        args = (byref(d), G, pk, _p(dy), dwp, _p(scratch))
+        L.check(lib.passion_conv3d_bwd_grouped_phase(*args, 1, vscale, ctx.win[0], ctx.win[1], L.stream_ptr()), "passion_conv3d_bwd_grouped_phase 1")
+        if dx is not None:
+            shard.all_reduce(scratch[:2 * cfg.B * Cin])
+            L.check(lib.passion_conv3d_bwd_grouped_phase(*args, 2, vscale, ctx.win[0], ctx.win[1], L.stream_ptr()), "passion_conv3d_bwd_grouped_phase 2")
+        return (None, None, None, None, None, None, dx, *[buf[g, :nW].view(ctx.wshape) for g in range(G)], *[buf[g, nW:] for g in range(G)])
+
+
 class WindowUpsampleFn(torch.autograd.Function):
     """trilinear x k (align_corners=True) of an extended slab (planes [id0, id0 + Dl_in) of Dg) onto output planes
     [od0, od0 + Dl_out) of k * Dg"""
@@ -478,12 +534,17 @@ def sharded_proto(fs, ft, target_cl, shard):
 class Slab:
     """a slab (B, Dl, H, W, C) + its global InstanceNorm statistics (computed once, shared by the consumers) + modality mask"""
 
-    def __init__(self, t, shard, mask=None, col=0):
+    def __init__(self, t, shard, mask=None, col=0, part_of=None):
         self.t, self.shard, self.mask, self.col, self._st = t, shard, mask, col, None
+        self._part_of = part_of                               # (stacked Slab, first sample, samples): statistics = rows of the stack's
 
     def stats(self):
         if self._st is None:
-            self._st = global_stats(self.t, self.shard)
+            if self._part_of is not None:
+                whole, b0, nb = self._part_of
+                self._st = whole.stats()[b0:b0 + nb]
+            else:
+                self._st = global_stats(self.t, self.shard)
         return self._st
 
     def with_mask(self, mask, col):
@@ -498,6 +559,10 @@ def conv(mod, feats, shard, Dg, norm=True, residual=None, out_dtype=None):
     if not isinstance(feats, (list, tuple)):
         feats = [feats]
     from .models.blocks import PAD
+    mods = None
+    if isinstance(mod, (list, tuple)):                        # G weight sets over one stacked batch (ShardedConvGroupedFn)
+        mods, mod = list(mod), mod[0]
+        assert len(feats) == 1
     k, stride = mod.kernel_size[0], mod.stride[0]
     reflect = mod.padding_mode == "reflect"
     Dl = feats[0].t.shape[1]
@@ -515,11 +580,16 @@ def conv(mod, feats, shard, Dg, norm=True, residual=None, out_dtype=None):
     cfg.ksize, cfg.stride, cfg.pad_mode, cfg.slope = k, stride, PAD[mod.padding_mode], 0.2
     cfg.B, cfg.out = x0.shape[0], None
     cfg.out_dtype = out_dtype if out_dtype is not None else x0.dtype
-    cache = mod.__dict__.setdefault("_passion_pack", {})
-    packed = ops.pack_weight(mod.weight, cache)
+    if mods is None:
+        cache = mod.__dict__.setdefault("_passion_pack", {})
+        packed = ops.pack_weight(mod.weight, cache)
     win = (n_lo, n_lo + Dl)                                   # the planes of the extended slab this rank owns
     Dg_ext = Dg                                               # 1 / V_global = (D_ext / Dg) / V_ext
-    y = ShardedConvFn.apply(cfg, shard, win, Dg_ext, mod.weight, mod.bias, packed, *[s.x for s in segs])
+    if mods is not None:
+        gp = ops._group_pack([m.weight for m in mods])
+        y = ShardedConvGroupedFn.apply(cfg, shard, win, Dg_ext, len(mods), gp, segs[0].x, *[m.weight for m in mods], *[m.bias for m in mods])
+    else:
+        y = ShardedConvFn.apply(cfg, shard, win, Dg_ext, mod.weight, mod.bias, packed, *[s.x for s in segs])
     if k == 3:
         o0 = 1 if stride == 2 else n_lo
         if y.shape[1] != Dl // stride:
@@ -558,24 +628,39 @@ def sharded_step_loss(model, shard, x, mask, target, Dg, temp=4.0, state=None):
     xin = x.to(dt).contiguous()
     xe = HaloExtendFn.apply(xin.view(B * 4, Dl, H, W), shard, True, 1, 1).view(B, 4, Dl + 2, H, W)
     vol = (Dl + 2) * H * W
-    encs = []
-    for i, m in enumerate(MODALS):
-        enc = getattr(model, f"{m}_encoder")
+    # the four encoders as ONE grouped launch per layer over the stacked batch [flair | t1ce | t1 | t2] (as models/mmformer.py
+    # encoders_grouped): a quarter of the launches, halo exchanges and all-reduces; bf16 on the GPU (the grouped kernels), else one by one
+    grouped = GROUPED and x.is_cuda and dt == torch.bfloat16 and L.host() is not None
+    enc_mods = [getattr(model, f"{m}_encoder") for m in MODALS]
+    firsts = []
+    for i, enc in enumerate(enc_mods):                        # first layer: the raw input, one channel (no grouped weight gradient)
         seg = ops.SegIn(xe, mask=mask if idt else None, mask_col=i, C=1, offset=i * vol, bstride=4 * vol)
         cache = enc.e1_c1.__dict__.setdefault("_passion_pack", {})
         y = ops.conv_block([seg], enc.e1_c1.weight, enc.e1_c1.bias, Dl + 2, H, W, ksize=3, stride=1, pad_mode=L.PAD_REFLECT,
                            out_dtype=dt, pack_cache=cache)
-        f = Slab(y[:, 1:1 + Dl].contiguous(), shard)
-        feats = []
-        dg = Dg
+        firsts.append(y[:, 1:1 + Dl])
+
+    def encoder_levels(f, pick):
+        feats, dg = [], Dg
         for lvl in range(1, 6):
             if lvl > 1:
-                f = conv(getattr(enc, f"e{lvl}_c1").conv, f, shard, dg)
+                f = conv(pick(f"e{lvl}_c1"), f, shard, dg)
                 dg //= 2
-            h = conv(getattr(enc, f"e{lvl}_c2").conv, f, shard, dg)
-            f = conv(getattr(enc, f"e{lvl}_c3").conv, h, shard, dg, residual=f.t)
+            h = conv(pick(f"e{lvl}_c2"), f, shard, dg)
+            f = conv(pick(f"e{lvl}_c3"), h, shard, dg, residual=f.t)
             feats.append(f)
-        encs.append(feats)
+        return feats
+
+    stk = None
+    if grouped:
+        stk = encoder_levels(Slab(torch.cat(firsts, 0), shard), lambda name: [getattr(e, name).conv for e in enc_mods])
+        encs = [[None] * 5 for _ in range(4)]
+        for l, f in enumerate(stk):
+            for i, part in enumerate(ops.unstack(f.t, 4)):
+                encs[i][l] = Slab(part, shard, part_of=(f, i * B, B))
+    else:
+        encs = [encoder_levels(Slab(firsts[i].contiguous(), shard), lambda name, e=enc: getattr(e, name).conv)
+                for i, enc in enumerate(enc_mods)]
     dg5 = Dg // 16
     # ---- token path: gathered along D, replicated
     pos = [getattr(model, f"{m}_pos") for m in MODALS]
@@ -631,17 +716,23 @@ def sharded_step_loss(model, shard, x, mask, target, Dg, temp=4.0, state=None):
     sep_loss = torch.zeros(B, 4, device=x.device)
     eye = torch.eye(4, device=x.device)
     maskf = mask.float()
-    for i in range(4):
-        e = [encs[i][l].with_mask(mask, i) if idt else encs[i][l] for l in range(5)]
+    def sep_decoder(e):
         hh = conv(ds.d4_c1.conv, up(e[4], 2, shard, dgs[4]), shard, dgs[3])
         for lvl in (4, 3, 2, 1):
             hh = conv(getattr(ds, f"d{lvl}_out").conv, conv(getattr(ds, f"d{lvl}_c2").conv, [hh, e[lvl - 1]], shard, dgs[lvl - 1]),
                       shard, dgs[lvl - 1])
             if lvl > 1:
                 hh = conv(getattr(ds, f"d{lvl - 1}_c1").conv, up(hh, 2, shard, dgs[lvl - 1]), shard, dgs[lvl - 2])
-        sp = ops.softmax_classes(conv(ds.seg_layer, hh, shard, Dg, norm=False, out_dtype=torch.float32).t, 1.0, "cl")
+        return ops.softmax_classes(conv(ds.seg_layer, hh, shard, Dg, norm=False, out_dtype=torch.float32).t, 1.0, "cl")
+
+    if stk is not None:                                       # shared weights: ONE pass over the stack (row i B + b = modality i of sample b)
+        sep_mask = mask.t().reshape(4 * B, 1).contiguous() if idt else None
+        sps = ops.unstack(sep_decoder([f.with_mask(sep_mask, 0) if idt else f for f in stk]), 4)
+    else:
+        sps = [sep_decoder([encs[i][l].with_mask(mask, i) if idt else encs[i][l] for l in range(5)]) for i in range(4)]
+    for i in range(4):
         gate = (maskf * eye[i]) if idt else eye[i].expand(B, 4)
-        sep_loss = sep_loss + gate * seg_pair(sp, tcl, shard).sum(1, keepdim=True)
+        sep_loss = sep_loss + gate * seg_pair(sps[i], tcl, shard).sum(1, keepdim=True)
     # ---- deep supervision (mmformer.py:540-544): softmax -> x 2^(j+1) -> WCE + Dice, weights 1/2, 1/4, 1/8, 1/16
     prm_loss = torch.zeros(B, 1, device=x.device)
     for j in range(4):

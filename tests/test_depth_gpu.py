@@ -92,6 +92,37 @@ def test_one_rank_equals_the_unsharded_model():
     _check(got, m_ref, outs_ref, loss_ref)
 
 
+def test_grouped_encoders_equal_the_encoders_one_by_one():
+    """bf16 on the GPU runs the four encoders as grouped launches over the stacked batch and decoder_sep once over the stack
+    (depth.GROUPED): the same kernels' arithmetic per sample as one modality at a time -- loss and every gradient tensor agree to
+    the noise of this path's float atomics (the InstanceNorm-backward sums), far inside the bf16 bounds of the model tests"""
+    from passion_amd import depth
+    dev = torch.device("cuda:0")
+    x, target, mask = _data(dev)
+    res = {}
+    for grouped in (True, False):
+        old, depth.GROUPED = depth.GROUPED, grouped
+        try:
+            m = _model(dev)
+            m.compute_dtype = torch.bfloat16
+            loss, pred, prm, sep = depth.sharded_step_loss(m, depth.DepthCtx(rank=0, world=1), x, mask, target, S)
+            loss.backward()
+            res[grouped] = (float(loss), pred.float().cpu(), sep.detach().cpu(), {k: p.grad.float().cpu() for k, p in m.named_parameters() if p.grad is not None})
+        finally:
+            depth.GROUPED = old
+    (la, pa, sa, ga), (lb, pb, sb, gb) = res[True], res[False]
+    assert abs(la - lb) < 2e-4 * abs(lb), (la, lb)
+    assert float((pa - pb).abs().max()) < 2e-2 and float((sa - sb).abs().max()) < 2e-3 * float(sb.abs().max())
+    assert ga.keys() == gb.keys()
+    bad = []
+    for k in ga:
+        err, ref = float((ga[k] - gb[k]).abs().max()), float(gb[k].abs().max())
+        # (biases in front of an InstanceNorm: exactly zero gradients, 1e-4 of bf16 rounding noise on both sides)
+        if not err < 2e-2 * ref + (2e-4 if k.endswith(".bias") else 1e-5):
+            bad.append((k, err, ref))
+    assert not bad, bad
+
+
 def _worker(rank, world, port, out):
     sys.path.insert(0, ROOT)
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",

@@ -1,5 +1,5 @@
 """which ATen ops (the torch glue between the library's kernels) a training step still launches: count, device time, shapes.
-    python tools/torch_ops_table.py [passion 0/1] [mmformer | rfnet | m2ftrans]"""
+    python tools/torch_ops_table.py [passion 0/1] [mmformer | rfnet | m2ftrans] [batch]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -26,7 +26,7 @@ m.mask_type, m.use_passion, m.compute_dtype = "idt", passion, torch.bfloat16
 m.train()
 opt = ptrain.make_optimizer(m)
 state = ptrain.LossState(dev)
-x, target, mask = ptrain.synthetic_batch(1, 128, dev)
+x, target, mask = ptrain.synthetic_batch(int(sys.argv[3]) if len(sys.argv) > 3 else 1, 128, dev)
 for _ in range(4):
     ptrain.train_step(m, opt, x, mask, target.view(target.shape), 4.0, state)
 torch.cuda.synchronize()
