@@ -4,9 +4,11 @@ The reference has no counterpart (a full 240x240x155 forward is not defined by i
 north_star asks for, held to "sharded == unsharded" on the same volume.  Every rank owns a contiguous slab of D planes of every
 activation (dim 1 of the channels-last tensors) at every level; what couples the slabs:
 
-  3x3x3 conv (stride 1)   one halo plane from each neighbour (HaloExtendFn: passion_halo_pack / unpack + point-to-point over
-                          RCCL), reflect / zero only at the global ends; the conv runs over the extended slab and the two outer
-                          output planes are dropped.  Backward: the halo planes' gradients go back and are added.
+  3x3x3 conv (stride 1)   one halo plane from each neighbour (HaloExtendFn: the extended slab in one launch, passion_halo_extend; the
+                          planes travel point-to-point over RCCL, or by one all_gather per exchange where the step is recorded as a
+                          HIP graph -- batch_isend_irecv cannot be captured on this stack), reflect / zero only at the global ends;
+                          the conv runs over the extended slab and the two outer output planes are dropped.  Backward: the halo
+                          planes' gradients go back and are added (passion_halo_extend_bwd).
   3x3x3 conv (stride 2)   one plane from the low neighbour only
   InstanceNorm            statistics: the ranks' (sum x, sum x^2) all-reduced once per tensor (global_stats); backward: the conv
                           backward stops after its dgrad (passion_conv3d_bwd_phase 1), the (sum g, sum g x_hat) are all-reduced,
@@ -18,8 +20,11 @@ activation (dim 1 of the channels-last tensors) at every level; what couples the
   losses                  per-class partial sums all-reduced before the loss is formed (one (B,16) all-reduce per loss term)
   weight gradients        every rank's dW covers its slab: summed over the ranks by parallel.GradReducer like data parallel
 
-`sharded_step_loss` is the plain (non-PASSION) mmformer training forward in this mode; tests/test_depth_*.py hold it against the
-unsharded model (world 2, gloo rehearsal transport on one GPU).  Unmeasured on multi-GPU hardware.
+`sharded_step_loss` is the mmformer training forward (plain and PASSION) in this mode; tests/test_depth_*.py hold it against the
+unsharded model and the imported reference's fixtures (world 2, gloo rehearsal transport on one GPU).  In bf16 on the GPU the four
+encoders run as grouped launches over the stacked batch and decoder_sep once over the stack (GROUPED), as in the data-parallel step.
+`sharded_train_step` is the whole iteration, `GraphedDepthStep` the same as ONE recorded HIP graph, collectives included.
+Unmeasured on multi-GPU hardware.
 """
 import os
 from ctypes import byref, c_void_p
