@@ -237,7 +237,7 @@ __attribute__((constructor)) static void passion_read_env() {
     e = getenv("PASSION_CONV_PWFINAL");
     if (e && e[0] == '0') pconv::g_conv_pwfinal = 0;
     e = getenv("PASSION_CONV_MARCHFINAL");
-    if (e) pconv::g_conv_marchfinal = e[0] == '1' ? 1 : 0;
+    if (e) pconv::g_conv_marchfinal = e[0] == '1' ? 1 : (e[0] == '2' ? 2 : 0);
     e = getenv("PASSION_CONV_DEEP");
     if (e && e[0] == '0') pconv::g_conv_deep = 0;
     e = getenv("PASSION_WGRAD_PW");

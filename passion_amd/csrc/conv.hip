@@ -882,12 +882,15 @@ double conv_bytes(const ConvK& k, int xs, int ys) {
 
 }  // namespace
 
-// PASSION_CONV_MARCHFINAL=1 / option "conv_marchfinal": the finish-free backward of the finest 3x3x3 layers (below).  Built, exact
-// (tests/test_ops_gpu.py::test_finish_free_marching_backward_equals_dgrad_plus_finish) and OFF by default: on 4 x 128^3, 8 -> 8 it
-// trades the 101 us finish pass for +57 us in the weight gradient (the indicator tiles double an LDS-bound MFMA phase), +28 us of
-// folds and +11 us in the input gradient (the column mirror lengthens the edge workgroups' critical path): 351 against 355 us per
-// layer, and 150 against 120 us at batch 1.
-namespace pconv { int g_conv_padout = 1; int g_conv_marchfinal = 0; }   // PASSION_CONV_PADOUT=0: reflect adjoint through mirror taps everywhere (A/B)
+// option "conv_marchfinal" / PASSION_CONV_MARCHFINAL: the finish-free backward of the finest 3x3x3 layers (below): 0 off, 1 wherever it
+// applies, 2 (default) from 2^22 voxels per launch up.  Exact (tests/test_ops_gpu.py::test_finish_free_marching_backward_equals_dgrad_plus_finish).
+// Measured in isolation on 4 x 128^3, 8 -> 8 it trades the 101 us finish pass for +57 us in the weight gradient (the indicator tiles
+// double an LDS-bound MFMA phase), +28 us of folds and +11 us in the input gradient: 351 against 355 us per layer -- even, and round 4
+// left it off.  In the recorded step (round 5) it is ahead: the finish pass is the one kernel of this backward that runs ALONE on
+// the chip (1.15 ms of a 10.3 ms step), the weight gradient it loads instead runs beside the other streams: plain step +1.2 %,
+// PASSION +0.8 %, RFNet / m2ftrans +-0.  Small launches lose (150 against 120 us at one 128^3 sample; the 80^3 step -1.4 %): hence
+// the threshold.
+namespace pconv { int g_conv_padout = 1; int g_conv_marchfinal = 2; }   // PASSION_CONV_PADOUT=0: reflect adjoint through mirror taps everywhere (A/B)
 
 // dgrad over the padded domain (conv_lean.hip MODE 2) + folding finish kernel: 3x3x3 stride-1 reflect-padded bf16 convs
 // (the finish kernel folds the halo planes; for inputs normalised in the loader it also completes InstanceNorm backward)
@@ -1241,7 +1244,8 @@ static int conv3d_bwd_impl(const passion_conv_desc_t* d, const float* packed, co
     // both decoders), every input gradient normalised: the same order -- weight gradient first, with the indicator slab
     // (conv_wgrad_march.hip), per-sample folds + means (march_ident_kernel), then the FOLD-FREE marching input gradient that
     // writes dx itself (conv_march.hip FIN).  No padded scratch volume, no sums, no in_bwd_finish_pad launch.
-    if (phase == 0 && parts == 3 && d->ksize == 3 && d->stride == 1 && d->pad_mode == PASSION_PAD_REFLECT && pconv::g_conv_marchfinal &&
+    if (phase == 0 && parts == 3 && d->ksize == 3 && d->stride == 1 && d->pad_mode == PASSION_PAD_REFLECT &&
+        (pconv::g_conv_marchfinal == 1 || (pconv::g_conv_marchfinal == 2 && (long)k.B * k.Di * k.Hi * k.Wi >= (1L << 22))) &&
         pconv::g_conv_lean && !g_passion_force_f32_mfma && d->x_dtype == PASSION_BF16 && d->y_dtype == PASSION_BF16 && need_dx && need_norm &&
         dweight && sums && k.Cout == 8 && k.Cin <= 16 && !pconv::g_wgrad_fork) {
         bool ok = true;
