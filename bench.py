@@ -544,6 +544,34 @@ def main():
                 step()
         parallel.barrier(ctx)
         torch.cuda.synchronize()
+    # --launch auto: replay or eager, whichever this host is faster with.  A replayed kernel node costs the GPU a little more than a
+    # stream-ordered launch (0.3 ms per step over 458 nodes), an eager step costs the host 10-15 ms: on a fast host the eager step is
+    # ahead (99.8 against 97.0 vol/s on one box of this pool), on a slow one far behind (66 against 94).  Twelve untimed steps each,
+    # the same choice on every rank.
+    launch_probe = None
+    events_from_warmup = use_graph                   # the reported kernel's event pairs were taken in the eager steps above
+    if use_graph and args.launch == "auto" and os.environ.get("PASSION_BENCH_PROBE", "1") != "0":
+        def probe(fn, n=12):
+            torch.cuda.synchronize()
+            t_ = time.perf_counter()
+            for _ in range(n):
+                fn()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t_) / n
+        tg = probe(graph_step)
+        for _ in range(2):
+            eager_step()
+        te = probe(eager_step)
+        tg, te = parallel.all_reduce_max(ctx, tg), parallel.all_reduce_max(ctx, te)
+        launch_probe = {"graph_ms_per_step": round(1e3 * tg, 3), "eager_ms_per_step": round(1e3 * te, 3), "steps_each": 12,
+                        "rule": "eager if more than 1.5 % faster than the replay"}
+        if te < 0.985 * tg:
+            use_graph, step = False, eager_step
+        else:
+            for _ in range(2):
+                step()
+        parallel.barrier(ctx)
+        torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
@@ -561,7 +589,7 @@ def main():
     dt = parallel.all_reduce_max(ctx, dt)
     final_loss = float(loss)
 
-    graph_events = use_graph or graph_note is not None      # the reported kernel's launches were timed in the eager steps before the recording
+    graph_events = use_graph or events_from_warmup or graph_note is not None      # the reported kernel's launches were timed in the eager steps before the recording
     timed_recs = (graph_live_recs if graph_events else ops.prof_read()) if want_events else []
 
     def leave():
@@ -630,7 +658,8 @@ def main():
                                "HIP graph replay of forward + loss + backward, then the eager tail of train.train_step: bucketed RCCL all-reduce of "
                                "the static gradient tensors + AdamW (no collective is recorded)" if reducer.active else
                                "HIP graph replay of train.train_step (recorded once after the warm-up; AdamW scalars and dropout seeds through device "
-                               "memory; the batch " + ("copied into" if args.stage_batch else "resident in") + " the recording's input tensors)") if use_graph else ("eager" if not graph_note else "eager (the HIP-graph recording failed: " + graph_note + ")"))},
+                               "memory; the batch " + ("copied into" if args.stage_batch else "resident in") + " the recording's input tensors)") if use_graph else (("eager" if launch_probe is None else "eager (faster than the HIP-graph replay on this host: launch_probe)") if not graph_note else "eager (the HIP-graph recording failed: " + graph_note + ")")),
+                   "launch_probe": launch_probe},
     }
     if want_events:
         recs = [r for r in timed_recs if r[1] >= 0]

@@ -490,10 +490,16 @@ class Model(nn.Module):
         vol = tok.to(self.compute_dtype).contiguous().view(P * B, *p, self.token_dim * num_modals)
         return run_pointwise(self.multimodal_decode_conv, Feat(vol))
 
-    def _enc_streams(self, dev):
+    def _enc_streams(self, dev, vox=0):
+        """the four side streams of this model on `dev` (decoder_sep, the fusion blocks, the loss branches, the early optimizer pass).
+        They are TWO HIP streams for volumes of 128^3 and more, four below (PASSION_SIDE_STREAMS=n: n): with the main stream that is
+        three, resp. five, streams on the runtime's four hardware queues -- at 128^3 every kernel of the two finest levels fills the chip
+        and a third or fourth side stream only adds queue switches (plain step +0.7 %, the N > 1 code path +3.4 %), at 80^3 the
+        kernels are small enough for the concurrency to pay (-1.8 % with two).  Decided by the first forward on the device."""
         cache = self.__dict__.setdefault("_streams_dev", {})
         if dev not in cache:
-            n = max(1, min(4, int(_os.environ.get("PASSION_SIDE_STREAMS", "4"))))     # < 4: encoders share side streams
+            env = _os.environ.get("PASSION_SIDE_STREAMS")
+            n = max(1, min(4, int(env))) if env else (2 if vox >= 3 << 19 else 4)
             pool = [torch.cuda.Stream(device=dev) for _ in range(n)]
             cache[dev] = [pool[i % n] for i in range(4)]
         return cache[dev]
@@ -529,7 +535,7 @@ class Model(nn.Module):
         passion = training and self.use_passion
         mask = mask.to(device=dev, dtype=torch.bool).contiguous()
         grouped = GROUPED_ENC and x.is_cuda and L.host() is not None
-        streams = self._enc_streams(dev) if ENC_STREAMS and x.is_cuda else None
+        streams = self._enc_streams(dev, x.shape[2] * x.shape[3] * x.shape[4]) if ENC_STREAMS and x.is_cuda else None
         main = torch.cuda.current_stream(dev) if streams else None
         if streams:
             for s_ in streams:                           # (possibly a fresh copy made on the main stream) read on every side stream
