@@ -501,7 +501,8 @@ class Model(nn.Module):
             env = _os.environ.get("PASSION_SIDE_STREAMS")
             n = max(1, min(4, int(env))) if env else (2 if vox >= 3 << 19 else 4)
             pool = [torch.cuda.Stream(device=dev) for _ in range(n)]
-            cache[dev] = [pool[i % n] for i in range(4)]
+            smap = _os.environ.get("PASSION_SIDE_MAP")                 # A/B: which of the n streams each of the four roles takes, e.g. 0110
+            cache[dev] = [pool[int(c) % n] for c in smap] if smap and len(smap) == 4 else [pool[i % n] for i in range(4)]
         return cache[dev]
 
     def _deep_weights_on(self, dev):
