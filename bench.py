@@ -550,7 +550,9 @@ def main():
     # the same choice on every rank.
     launch_probe = None
     events_from_warmup = use_graph                   # the reported kernel's event pairs were taken in the eager steps above
-    if use_graph and args.launch == "auto" and os.environ.get("PASSION_BENCH_PROBE", "1") != "0":
+    under_profiler = any(k_.startswith(("ROCPROF", "ROCP_", "ROCTRACER")) for k_ in os.environ)      # (a counter pass serialises the streams: twelve eager
+                                                                                                      # RFNet steps after a replay never came back under --pmc)
+    if use_graph and args.launch == "auto" and args.steps >= 10 and not under_profiler and os.environ.get("PASSION_BENCH_PROBE", "1") != "0":
         def probe(fn, n=12):
             torch.cuda.synchronize()
             t_ = time.perf_counter()

@@ -7,6 +7,7 @@ pre-norm blocks: a conv returns its raw output, the consumer's loader normalises
 activated tensor is only materialised (ops.norm_act) for the encoder residuals, upsampling inputs and
 prototype features.  Region-aware modal fusion runs on region_gap / region_mix (blocks.py).
 """
+import os
 import numpy as np
 import torch
 import torch.nn as nn
@@ -183,7 +184,9 @@ class Model(nn.Module):
     def _enc_streams(self, dev):
         cache = self.__dict__.setdefault("_streams_dev", {})
         if dev not in cache:
-            cache[dev] = [torch.cuda.Stream(device=dev) for _ in range(4)]
+            n = max(1, min(4, int(os.environ.get("PASSION_SIDE_STREAMS", "4"))))      # < 4: the four roles share n streams (A/B)
+            pool = [torch.cuda.Stream(device=dev) for _ in range(n)]
+            cache[dev] = [pool[i % n] for i in range(4)]
         return cache[dev]
 
     def _onehots_on(self, dev):
