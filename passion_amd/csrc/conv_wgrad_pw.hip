@@ -41,8 +41,9 @@ __device__ __forceinline__ bf16x8 tr_read8(const char* p0, const char* p1) {
 }
 
 // NB = 8-channel blocks of the virtual concat (1, 2, 4, 8), DRN = 16-byte blocks of a dY row that hold channels (1: Cout <= 8, 2: <= 16,
-// 4: <= 32), IDENT = the indicator sums too.  A wavefront has U chunks of 64 voxels in flight (4 KB of x and dY or more): with one
-// chunk the 8 -> 8 layers had 2 KB per wavefront on its way, 10 MB over the chip -- Little's law wants ~16 MB at 8 TB/s.
+// 4: <= 32), IDENT = the indicator sums too.  A wavefront has PW_U chunks of 64 voxels in flight.  One is the measured optimum: with
+// two and four (4-8 KB per wavefront on its way) the registers of the staged chunks cost one to two wavefronts per SIMD and the
+// 32 -> 8 layers went from 157 to 218 us over 5 x 128^3 -- occupancy hides more latency here than a deeper prefetch (-DPW_U=n: A/B).
 template <int NB, int DRN, bool IDENT>
 __global__ __launch_bounds__(256) void wgrad_pw_kernel(ConvK p, float* __restrict__ dW, float* __restrict__ dbias, int wgs_per_b, long vpw) {
     wgrad_clear(p);
