@@ -18,6 +18,7 @@ from ..utils import criterions as crit
 from .blocks import (GROUPED_ENC_POST, Feat, PFeat, encoders_grouped_post, general_conv3d, materialize, prm_generator_laststage_pk, prm_generator_pk,
                      region_aware_modal_fusion, run_conv_auto)
 
+SIDE_BRANCHES = os.environ.get("PASSION_RFNET_SIDE", "1") != "0"      # decoder_sep and the deep-supervision losses on side streams (0: all on one stream)
 basic_dims = 8
 H = W = Z = 80
 num_cls = 4
@@ -248,6 +249,41 @@ class Model(nn.Module):
             onehots = [t.expand(B, 4).contiguous() for t in self._onehots_on(dev)]
             effs = [(mask & onehots[i]) if idt else onehots[i] for i in range(4)]
             masks_all = torch.cat([mask] + effs, 0).contiguous()
+        eye = torch.eye(4, device=dev)
+        maskf = mask.float()
+        gates = [(maskf * eye[i]) if idt else eye[i].expand(B, 4) for i in range(4)]
+        ups = (1, 2, 4, 8)
+        tcl = ops.target_to_cl(target) if training else None
+
+        def sep_branch():
+            """decoder_sep (shared weights) once over the four modalities stacked along the batch axis + its loss: depends on the encoders
+            only, like the fusion path"""
+            sep_mask = mask.t().reshape(4 * B, 1).contiguous() if idt else None       # row i*B+b = mask[b, i]
+            if grouped:
+                stacked = [Feat(stk[l].t, sep_mask, 0) for l in range(4)]
+            else:
+                stacked = [Feat(torch.cat([encs[i][l].t for i in range(4)], 0), sep_mask, 0) for l in range(4)]
+            sep_all = self.decoder_sep(*stacked, probs=not ops.SEP_LOSS_FUSED)
+            sep_pair = ops.sep_wce_dice(sep_all, tcl).sum(1, keepdim=True).view(4, B, 1)      # 4B predictions against the B label volumes
+            sep_loss = torch.zeros(B, 4, device=dev)
+            for i in range(4):
+                sep_loss = sep_loss + gates[i] * sep_pair[i]
+            return sep_loss
+
+        # Side streams (as models/mmformer.py; the encoders run grouped on the main stream here): decoder_sep with its loss on one, under
+        # the fusion decoder -- forward, and (autograd replays a node on its forward's stream) backward; the deep-supervision losses
+        # on another.  Until round 5 every launch of this model sat on ONE stream (1233 dispatches, 99.6 % of the step with exactly
+        # one kernel in flight): the deep-level launches of the two decoders now fill each other's gaps.
+        side = streams if (streams and training and SIDE_BRANCHES) else None
+        sep_loss = None
+        if side:
+            s0 = side[0]
+            s0.wait_stream(main)
+            for t_ in [tcl, mask] + gates + ([f.t for f in stk] if grouped else [f.t for e in encs for f in e]):
+                t_.record_stream(s0)                      # made on the main stream, read (forward and backward) on this one
+            with torch.cuda.stream(s0):
+                sep_loss = sep_branch()
+                sep_loss.record_stream(main)
         fuse_all, preds_all, de_f_all = self.decoder_fuse(*[[encs[i][l].with_mask(masks_all, i, P) for i in range(4)]
                                                             for l in range(4)])
         if P == 1:
@@ -261,27 +297,27 @@ class Model(nn.Module):
         if not training:
             return pred
 
-        tcl = ops.target_to_cl(target)
-        # decoder_sep (shared weights) once over the four modalities stacked along the batch axis
-        sep_mask = mask.t().reshape(4 * B, 1).contiguous() if idt else None       # row i*B+b = mask[b, i]
-        if grouped:
-            stacked = [Feat(stk[l].t, sep_mask, 0) for l in range(4)]
-        else:
-            stacked = [Feat(torch.cat([encs[i][l].t for i in range(4)], 0), sep_mask, 0) for l in range(4)]
-        sep_all = self.decoder_sep(*stacked, probs=not ops.SEP_LOSS_FUSED)
-        eye = torch.eye(4, device=dev)
-        maskf = mask.float()
-        gates = [(maskf * eye[i]) if idt else eye[i].expand(B, 4) for i in range(4)]
-        ups = (1, 2, 4, 8)
+        def deep_supervision():
+            prm = torch.zeros(B, 1, device=dev)
+            for j, pp in enumerate(preds):
+                pair = crit.seg_losses_cl(ops.softmax_classes(pp, 1.0, "cl"), tcl, ups[j])
+                prm = prm + 0.5 ** (j + 1) * pair.sum(1, keepdim=True)
+            return prm
 
-        prm_loss = torch.zeros(B, 1, device=dev)
-        for j, pp in enumerate(preds):
-            pair = crit.seg_losses_cl(ops.softmax_classes(pp, 1.0, "cl"), tcl, ups[j])
-            prm_loss = prm_loss + 0.5 ** (j + 1) * pair.sum(1, keepdim=True)
-        sep_pair = ops.sep_wce_dice(sep_all, tcl).sum(1, keepdim=True).view(4, B, 1)      # 4B predictions against the B label volumes
-        sep_loss = torch.zeros(B, 4, device=dev)
-        for i in range(4):
-            sep_loss = sep_loss + gates[i] * sep_pair[i]
+        if side:
+            s2 = side[2]
+            s2.wait_stream(main)
+            tcl.record_stream(s2)
+            for pp in preds:
+                pp.record_stream(s2)
+            with torch.cuda.stream(s2):
+                prm_loss = deep_supervision()
+                prm_loss.record_stream(main)
+            main.wait_stream(s0)
+            main.wait_stream(s2)
+        else:
+            sep_loss = sep_branch()
+            prm_loss = deep_supervision()
         if not passion:
             return pred, prm_loss, sep_loss
 
