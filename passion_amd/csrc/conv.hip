@@ -448,7 +448,7 @@ __global__ __launch_bounds__(256) void shell_fold_kernel(bf16_t* __restrict__ dx
         bf16_t* o = dx + (long)b * bstride + (((long)d * H + h) * W + w) * C + c;
         f32x4 cur = load4(o);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) cur[j] += stats[((long)b * C + c + j) * 2 + 1] * a[j];
+        for (int j = 0; j < 4; ++j) cur[j] += (stats ? stats[((long)b * C + c + j) * 2 + 1] : 1.f) * a[j];      // (raw input: nothing to scale by)
         store4(o, cur);
     }
 }
@@ -851,6 +851,10 @@ WgPlan plan_wgrad(const ConvK& k, const passion_conv_desc_t* d) {
         // these slots as are resident at once)
         w.gx = (int)hmin(total, (k.Cin <= 16 && total > 512 ? 2 : 1) * wg_target);
     }
+    // a whole number of slots per sample: the finish-free backward folds the slab per sample (march_ident_kernel, pw_ident_kernel); 1024
+    // slots over the 5- and 10-sample virtual batches of the PASSION passes kept those launches on the dgrad + finish path
+    // (only where that path can run: the weight gradients of every other launch keep their slot count -- and their f32 summation order)
+    if (w.gx > k.B && d->ksize == 3 && d->stride == 1 && k.Cout == 8 && k.Cin <= 16 && (long)k.B * k.Di * k.Hi * k.Wi >= (1L << 22)) w.gx -= w.gx % k.B;
     return w;
 }
 
@@ -1530,7 +1534,50 @@ static int conv3d_bwd_impl(const passion_conv_desc_t* d, const float* packed, co
             }
         }
     }
-    if (phase != 2) {
+    // RAW inputs of the finest 3x3x3 layers (nothing normalised in the loader: RFNet's post-norm general_conv3d, reference
+    // blocks.py:354-370 -- the activation in front of the conv is its own op there): no InstanceNorm backward follows the input gradient, so
+    // the finish pass over the padded scratch only folded the halo -- a copy of the whole tensor (in_bwd_finish_pad_kernel: 3.5 ms of a
+    // 47 ms RFNet step, alone on the chip).  The final-form kernels of the finish-free backward (conv_march.hip FIN, conv_pair.hip SF) write
+    // dx themselves; for a raw input their epilogue has no means to apply (k.pwm only has to be readable).
+    bool raw_done = false;
+    if (phase == 0 && padout && !blockdiag && need_dx && !need_norm && d->ksize == 3 && d->stride == 1 && d->pad_mode == PASSION_PAD_REFLECT &&
+        (pconv::g_conv_marchfinal == 1 || (pconv::g_conv_marchfinal == 2 && (long)k.B * k.Di * k.Hi * k.Wi >= (1L << 22))) &&
+        d->x_dtype == PASSION_BF16 && d->y_dtype == PASSION_BF16 && k.Cout == 8 && k.Cin <= 16 && k.Hi % 8 == 0 && k.Wi % 16 == 0 && k.Di >= 8 &&
+        k.Hi >= 16 && k.Wi >= 32) {
+        bool ok = true;
+        for (int s = 0; s < k.nseg; ++s) if (!k.seg[s].dx || k.seg[s].stats || k.seg[s].bmod > 0) ok = false;
+        if (ok) {
+            ConvK kf = k;
+            kf.pwm = sums;                               // read, never applied (no statistics on any segment)
+            kf.sums = nullptr; kf.sums_rep = 1; kf.sums_fixed = 0; kf.sums_float_only = 0;
+            kf.y = sums + slab_end_floats(k, plan_wgrad(k, d).gx, nt);      // the padded scratch: only its shell is used
+            kf.pw_done = 0;
+            {
+                ProfScope prof(2, conv_bytes(k, xs, ys) + (double)nt * k.Cin * k.Cout * 4, 2.0 * k.B * k.Do * k.Ho * k.Wo * (double)k.Cout * k.Cin * nt, st);
+                rc = launch_conv_march(kf, 3, 1, 2, packed + f32_pack_floats(k.Cin, k.Cout, nt), st);
+            }
+            if (rc < 0) return rc;
+            if (rc == 0 && kf.pw_done) {
+                raw_done = true;
+                if (kf.pw_done == 2) {                   // interior written in final form, halo outputs in the shell: fold them
+                    char dg_tag[64];
+                    snprintf(dg_tag, sizeof(dg_tag), "%s", passion_prof_last_tag());
+                    ProfScope prof(6, 0.0, 0.0, st);
+                    passion_prof_tag("finish of %s", dg_tag);
+                    for (int s = 0; s < k.nseg; ++s) {
+                        const SegD& sg = k.seg[s];
+                        const long T = 2L * k.Hi * k.Wi + 2L * (k.Di - 2) * k.Wi + 2L * (k.Di - 2) * (k.Hi - 2);
+                        const long items = (long)k.B * T * (sg.C / 4);
+                        hipLaunchKernelGGL(shell_fold_kernel, dim3((unsigned)hmin((items + 255) / 256, 4096)), dim3(256), 0, st, (bf16_t*)sg.dx,
+                                           reinterpret_cast<const bf16_t*>(kf.y), (const float*)nullptr, k.Di, k.Hi, k.Wi, sg.C, sg.bstride, k.Cin, sg.cbase, k.B);
+                        LAUNCH_RET();
+                    }
+                }
+            }
+            rc = 0;
+        }
+    }
+    if (phase != 2 && !raw_done) {
         ProfScope prof(2, conv_bytes(k, xs, ys) + (double)nt * k.Cin * k.Cout * 4,
                        2.0 * k.B * k.Do * k.Ho * k.Wo * (double)k.Cout * k.Cin * nt, st);
         if (padout) {
@@ -1599,7 +1646,7 @@ static int conv3d_bwd_impl(const passion_conv_desc_t* d, const float* packed, co
     // ---- InstanceNorm backward finish (in place on dx) ----
     const long V = (long)k.Di * k.Hi * k.Wi;
     const long rs = (long)2 * k.B * k.Cin;
-    if (padout) {
+    if (padout && !raw_done) {
         // one launch per group of segments with the same channel count (FinSegs): the scratch is read from HBM once
         bool done[PASSION_MAX_SEG] = {false, false, false, false};
         static const int fin_nt = []() { const char* e = getenv("PASSION_FINISH_NT"); return e ? atoi(e) : 0; }();
@@ -1642,7 +1689,7 @@ static int conv3d_bwd_impl(const passion_conv_desc_t* d, const float* packed, co
             defer_fold = false;
         }
     }
-    for (int s = 0; s < k.nseg && !padout; ++s) {
+    for (int s = 0; s < k.nseg && !padout && !raw_done; ++s) {
         const SegD& sg = k.seg[s];
         const bool sum_passes = real_dx[s] != nullptr;
         if (!sg.dx || (!sg.stats && !sum_passes)) continue;

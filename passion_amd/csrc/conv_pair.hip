@@ -574,7 +574,7 @@ int launch_pair_one(ConvK& k, hipStream_t st) {
     mp.nseg_d = (dcount + mp.planes_per_seg - 1) / mp.planes_per_seg;
     mp.nwg_b = mp.nseg_d * tiles;
     if (MODE == 2 && k.pwm) {                        // final form (means in k.pwm): reflect padding, statistics on the input
-        if (TW != 16 || nohalo || !k.seg[0].stats || !k.y) return 1;
+        if (TW != 16 || nohalo || !k.y) return 1;              // (a raw input -- no statistics -- takes the epilogue's `gg` branch: conv.hip raw_done)
         k.pw_done = 2;                               // 2: the shell of the padded scratch still has to be folded (shell_fold_kernel)
         return launch_pair_res<16, 2, false, true>(k, mp, st);
     }

@@ -155,10 +155,13 @@ def test_conv_block_fwd_bwd(case, dtype):
 
 @pytest.mark.parametrize("shape", [([8], (8, 8, 16)), ([8, 8], (16, 16, 32)), ([16], (40, 24, 48)), ([8], (130, 16, 32)), ([8], (24, 24, 48)),
                                    ([8], (16, 16, 32)), ([8], (10, 32, 64))])
-def test_finish_free_marching_backward_equals_dgrad_plus_finish(shape):
+@pytest.mark.parametrize("norm", [True, False], ids=["prenorm", "raw_input"])
+def test_finish_free_marching_backward_equals_dgrad_plus_finish(shape, norm):
     """the finest level's backward in its two forms on the same inputs: (weight gradient with indicator slab -> means -> fold-free
     marching input gradient with the final epilogue) against (weight gradient, padded-domain input gradient, finish kernel): input
-    gradients to the bf16 rounding of the stored values, weight / bias gradients to the f32 summation order; twice for bit equality"""
+    gradients to the bf16 rounding of the stored values, weight / bias gradients to the f32 summation order; twice for bit equality.
+    raw_input: nothing normalised in the loader (RFNet's post-norm convs) -- the final-form input gradient alone replaces the
+    padded-domain gradient + the finish pass that only folded its halo"""
     from passion_amd import ops
     dev = _dev()
     segC, (D, H, W) = shape
@@ -176,7 +179,7 @@ def test_finish_free_marching_backward_equals_dgrad_plus_finish(shape):
         try:
             xd = [x.to(dev).requires_grad_(True) for x in xs]
             wd, bd = w.to(dev).requires_grad_(True), b.to(dev).requires_grad_(True)
-            segs = [ops.SegIn(x, stats=ops.instnorm_stats(x.detach()), mask=mask, mask_col=i) for i, x in enumerate(xd)]
+            segs = [ops.SegIn(x, stats=ops.instnorm_stats(x.detach()) if norm else None, mask=mask, mask_col=i) for i, x in enumerate(xd)]
             y = ops.conv_block(segs, wd, bd, D, H, W, ksize=3, stride=1, pad_mode=1)
             y.backward(gy.to(dev))
             torch.cuda.synchronize()
