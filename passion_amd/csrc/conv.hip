@@ -1189,6 +1189,15 @@ Companion* companion(hipStream_t caller) {
 }
 }  // namespace
 
+// Grouped stride-2 3x3x3 layers (bf16, more than one input channel): their weight gradient has no lean kernel (stride 1 only); the
+// general bf16 kernel takes the stacked batch when every weight set can have the same whole number of slab slots (option
+// "wgrad_group_s2" / PASSION_WGRAD_GROUP_S2=0: one launch + fold per set as before round 6).
+namespace pconv { int g_wgrad_group_s2 = 1; }
+static bool grouped_general_wgrad(const ConvK& k, const passion_conv_desc_t* d, const WgPlan& w, int G) {
+    return pconv::g_wgrad_group_s2 && G > 1 && d->ksize == 3 && d->stride == 2 && w.bf16 && k.Cin > 1 && !g_passion_force_f32_mfma &&
+           d->x_dtype == PASSION_BF16 && d->y_dtype == PASSION_BF16 && wgrad_bf16_chunk(k, d->ksize, d->stride) == 8 && w.gx >= G;
+}
+
 // phase 0: the whole backward.  Depth-sharded volumes (one volume split along D over the ranks) need the InstanceNorm-backward
 // sums of ALL ranks before the gradient can be finished: phase 1 stops after the dgrad with the sums folded into
 // sums[0 .. 2 B Cin) (the caller all-reduces them), phase 2 runs only the finish with 1 / V scaled by vscale = V_local / V_global
@@ -1355,7 +1364,12 @@ static int conv3d_bwd_impl(const passion_conv_desc_t* d, const float* packed, co
     // ---- wgrad (+ bias grad): per-workgroup partial slabs, then a fixed-order fold (no atomics, deterministic) ----
     if (phase != 2 && (dweight || dbias) && (parts & 1)) {
         k.Mpad = pad16(k.Cout);
-        const WgPlan w = plan_wgrad(k, d);
+        WgPlan w = plan_wgrad(k, d);
+        // grouped stride-2 layers (e2_c1 .. e5_c1 of the four modality encoders): no lean kernel; the general bf16 weight gradient takes the
+        // whole stacked batch with its slots dealt to the weight sets in equal runs (conv_bf16.hip) -- one launch + one fold (riding in
+        // the finish launch) instead of one of each per modality
+        const bool grouped_general = ga && grouped_general_wgrad(k, d, w, ga->G);
+        if (grouped_general) w.gx -= w.gx % ga->G;
         const long nW = (long)k.Cout * k.Cin * nt;
         k.wslot = nW + k.Cout;                       // one slot = [dW | dbias] of one workgroup
         float* wslab = sums + (long)2 * k.B * k.Cin * SUMS_SLOTS;
@@ -1371,7 +1385,9 @@ static int conv3d_bwd_impl(const passion_conv_desc_t* d, const float* packed, co
             float* dWs = dweight ? wslab : nullptr;
             float* dbs = dbias ? bslab : nullptr;
             defer_next_wgrad() = pair_ok;
-            if (ga) {                                // grouped: the lean kernel (slots in sample order), checked by the caller
+            if (ga && grouped_general) {             // grouped stride-2 layers: the general bf16 kernel, slots dealt to the sets in equal runs
+                rc = launch_wgrad_bf16(k, d->ksize, d->stride, w.MT, w.gx, w.gy, dWs, dbs, st);
+            } else if (ga) {                         // grouped: the lean kernel (slots in sample order), checked by the caller
                 rc = launch_wgrad_lean(k, d->ksize, d->stride, w.MT, w.gx, w.gy, dWs, dbs, st);
                 if (rc > 0) rc = -1014;
             } else if (w.bf16 && d->y_dtype == PASSION_F32) {
@@ -1404,7 +1420,7 @@ static int conv3d_bwd_impl(const passion_conv_desc_t* d, const float* packed, co
             fj.out[0] = dweight;
             if (ga) {                                // one fold per weight set: R = its samples x workgroups per sample
                 const int tiles_per_b = k.tilesD * k.tilesH * k.tilesW;
-                fj.R = k.bgroup * ((tiles_per_b + k.per - 1) / k.per);
+                fj.R = grouped_general ? w.gx / ga->G : k.bgroup * ((tiles_per_b + k.per - 1) / k.per);
                 fj.G = ga->G;
                 for (int g = 0; g < ga->G; ++g) fj.out[g] = ga->dW[g];
             }
@@ -1412,11 +1428,12 @@ static int conv3d_bwd_impl(const passion_conv_desc_t* d, const float* packed, co
         } else
         if (ga) {                                    // one fold per weight set: Rg = its samples x workgroups per sample
             const int tiles_per_b = k.tilesD * k.tilesH * k.tilesW;
-            const int wgs_per_b = (tiles_per_b + k.per - 1) / k.per;
+            const int wgs_per_b = grouped_general ? 0 : (tiles_per_b + k.per - 1) / k.per;
+            const int Rg = grouped_general ? w.gx / ga->G : k.bgroup * wgs_per_b;
             RedOuts ro;
             for (int g = 0; g < PASSION_MAX_GROUPS; ++g) ro.p[g] = g < ga->G ? ga->dW[g] : nullptr;
-            hipLaunchKernelGGL(reduce_parts_grouped_kernel, dim3((unsigned)fold_nblocks(k.wslot, k.bgroup * wgs_per_b), ga->G), dim3(256), 0, st, wslab,
-                               k.bgroup * wgs_per_b, k.wslot, k.wslot, ro, zsums, zn);
+            hipLaunchKernelGGL(reduce_parts_grouped_kernel, dim3((unsigned)fold_nblocks(k.wslot, Rg), ga->G), dim3(256), 0, st, wslab,
+                               Rg, k.wslot, k.wslot, ro, zsums, zn);
             LAUNCH_RET();
             sums_cleared = zsums != nullptr;
         } else
@@ -1801,7 +1818,7 @@ extern "C" int passion_conv3d_bwd_grouped(const passion_conv_desc_t* d, int G, c
     k.tilesD = cdiv(k.Do, TD); k.tilesH = cdiv(k.Ho, TH); k.tilesW = cdiv(k.Wo, TW);
     const WgPlan w = plan_wgrad(k, d);
     const bool native_wgrad = bf16 && dW && w.bf16 && pconv::g_conv_lean && wgrad_bf16_chunk(k, d->ksize, d->stride) != 16 &&
-                              !(k.Cin == 1) && wgrad_lean_covers(k, d->ksize, d->stride, w.MT, w.gx, w.gy);
+                              !(k.Cin == 1) && (wgrad_lean_covers(k, d->ksize, d->stride, w.MT, w.gx, w.gy) || grouped_general_wgrad(k, d, w, G));
     GroupArgs ga{G, stride, nullptr, dW};
     const int bg = d->B / G;
     const long ys = d->y_dtype == PASSION_BF16 ? 2 : 4;

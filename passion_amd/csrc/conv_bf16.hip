@@ -541,8 +541,17 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(ConvK p, float* __
         }
     };
 
-    const int total_tiles = p.B * tiles_per_b;
+    // Grouped launch (p.bgroup > 0: G = B / bgroup weight sets, the stride-2 layers of the four modality encoders as ONE launch): the
+    // gridDim.x slots are dealt to the sets in equal runs (slots [g * per, (g + 1) * per) sum bricks of set g's samples only), so the
+    // grouped fold finds every set's partial sums back to back.  The launcher makes gridDim.x a multiple of G.
+    int total_tiles = p.B * tiles_per_b, tstep = (int)gridDim.x;
     int tile = xcd_swizzle(blockIdx.x, gridDim.x);   // per round of gridDim.x bricks every XCD works on one contiguous run
+    if (p.bgroup > 0) {
+        const int ngrp = p.B / p.bgroup, per = (int)gridDim.x / ngrp, grp = (int)blockIdx.x / per;
+        tile = grp * p.bgroup * tiles_per_b + (int)blockIdx.x % per;
+        total_tiles = (grp + 1) * p.bgroup * tiles_per_b;
+        tstep = per;
+    }
     bool have = tile < total_tiles;
     Regs R;
     if (have) fetch(tile, R);
@@ -551,7 +560,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(ConvK p, float* __
         commit(R);
         __syncthreads();
         const bool work = true;   // absent blocks were staged as zeros: their columns flush zeros
-        const int next = tile + gridDim.x;
+        const int next = tile + tstep;
         const bool have_n = next < total_tiles;
         Regs Rn;
         if (have_n) fetch(next, Rn);

@@ -1011,6 +1011,8 @@ GROUPED_CASES = [
     ([1], 8, 3, 1, 1, (8, 16, 16), torch.bfloat16, False, False, True),       # the first conv of an encoder (Cin = 1)
     ([16, 16], 16, 3, 1, 1, (8, 8, 16), torch.bfloat16, False, True, False),  # two segments
     ([8], 8, 3, 1, 1, (8, 8, 16), torch.float32, True, True, True),           # f32 storage: set by set
+    ([32], 64, 3, 2, 1, (16, 32, 32), torch.bfloat16, False, True, True),     # stride 2, several bricks per slab slot: the grouped general wgrad
+    ([16], 32, 3, 2, 1, (24, 16, 16), torch.bfloat16, False, True, False),    # stride 2, ragged brick count per sample
 ]
 
 
