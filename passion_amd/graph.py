@@ -93,7 +93,8 @@ class GraphedStep:
         self.words = torch.zeros(32, dtype=torch.float32, device=dev)      # [0, 2): dropout seed offset; [16, 32): AdamW scalars
         self.hyper = self.words[16:]
         torch.cuda.synchronize(dev)
-        g = torch.cuda.CUDAGraph()
+        dot = os.environ.get("PASSION_GRAPH_DOT")          # developer switch: the recording as a DOT file (nodes, edges: what depends on what)
+        g = torch.cuda.CUDAGraph(keep_graph=True) if dot else torch.cuda.CUDAGraph()
         lib.passion_set_step_words(c_void_p(self.words.data_ptr()))
         if len(self.optimizer.state) == 0:
             raise L.PassionHipError("GraphedStep: the optimizer has no state yet -- its moment tensors would be created (and zero-filled on "
@@ -130,6 +131,11 @@ class GraphedStep:
                 self.cap = self.optimizer.end_capture()
             elif not ok:
                 self.reducer.suspended = False       # no recording: the caller's eager steps keep their overlapped all-reduce
+        if dot and ok:
+            hip = ctypes.CDLL("libamdhip64.so")
+            rc = hip.hipGraphDebugDotPrint(c_void_p(g.raw_cuda_graph()), dot.encode(), 1)      # 1 = verbose
+            print(f"[GraphedStep] hipGraphDebugDotPrint -> {rc} ({dot})", flush=True)
+            g.instantiate()
         self._tables_id = id(self.optimizer._tables)
         if self.hybrid:          # the gradient tensors the recording writes (its backward assigned them after zero_grad): static from here on
             self.grads = [(p, p.grad) for g_ in self.optimizer.param_groups for p in g_["params"] if p.grad is not None]

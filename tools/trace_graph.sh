@@ -12,6 +12,7 @@ python3 tools/trace_last.py $T 70 > gpurun_out/${TAG}_trace_last.txt 2>&1
 python3 tools/trace_bins.py $T > gpurun_out/${TAG}_trace_bins.txt 2>&1
 python3 tools/trace_idle.py $T 12 > gpurun_out/${TAG}_trace_idle.txt 2>&1
 python3 tools/trace_conc.py $T > gpurun_out/${TAG}_trace_conc.txt 2>&1
+python3 tools/trace_seq.py $T > gpurun_out/${TAG}_trace_seq.txt 2>&1
 cp $(find gpurun_out/tr_$TAG -name "*kernel_stats.csv" | head -1) gpurun_out/${TAG}_kernel_stats.csv
 tail -2 gpurun_out/tr_$TAG/bench.log | cut -c1-400
 rm -rf gpurun_out/tr_$TAG
