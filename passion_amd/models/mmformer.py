@@ -142,9 +142,8 @@ def encoders_grouped(encs, x, mask, dtype):
     return feats
 
 
+SEP_LOSS_FIRST = _os.environ.get("PASSION_SEP_LOSS_FIRST", "1") != "0"
 LOSS_STREAMS = _os.environ.get("PASSION_LOSS_STREAMS", "1") != "0"     # deep-supervision / decoder_sep losses on side streams
-SEP_JOIN_EARLY = _os.environ.get("PASSION_SEP_JOIN_EARLY", "1") != "0"  # ... created before the deep-supervision nodes (0: last)
-SEP_BRANCH = _os.environ.get("PASSION_SEP_BRANCH", "1") != "0"         # decoder_sep + its loss behind one join node (ops.BranchJoinFn)
 FUSE_STREAM = _os.environ.get("PASSION_FUSE_STREAM", "1") != "0"       # fusion blocks of levels 4..1 on a side stream
 GROUPED_INTRA = _os.environ.get("PASSION_GROUPED_INTRA", "1") != "0"   # the four intra-modal transformers as batched GEMMs
 
@@ -492,24 +491,28 @@ class Model(nn.Module):
         vol = tok.to(self.compute_dtype).contiguous().view(P * B, *p, self.token_dim * num_modals)
         return run_pointwise(self.multimodal_decode_conv, Feat(vol))
 
-    def _enc_streams(self, dev, vox=0):
+    def _enc_streams(self, dev, vox=0, passion=False):
         """the four side streams of this model on `dev` (decoder_sep, the fusion blocks, the loss branches, the early optimizer pass).
         They are TWO HIP streams for volumes of 128^3 and more, four below (PASSION_SIDE_STREAMS=n: n): with the main stream that is
         three, resp. five, streams on the runtime's four hardware queues -- at 128^3 every kernel of the two finest levels fills the chip
         and a third or fourth side stream only adds queue switches (plain step +0.7 %, the N > 1 code path +3.4 %), at 80^3 the
         kernels are small enough for the concurrency to pay (-1.8 % with two).  Decided by the first forward on the device."""
-        cache = self.__dict__.setdefault("_streams_dev", {})
-        if dev not in cache:
+        pools = self.__dict__.setdefault("_stream_pool", {})
+        if dev not in pools:
             env = _os.environ.get("PASSION_SIDE_STREAMS")
             n = max(1, min(4, int(env))) if env else (2 if vox >= 3 << 19 else 4)
-            pool = [torch.cuda.Stream(device=dev) for _ in range(n)]
-            smap = _os.environ.get("PASSION_SIDE_MAP")                 # A/B: which of the n streams each of the four roles takes, e.g. 0110
-            # roles: decoder_sep (+ its loss), the fusion blocks, the deep-supervision losses, the early optimizer pass.  With decoder_sep's
-            # backward enqueued first (SEP_BRANCH) nothing the main chain waits for may sit behind it on its stream: the deep-supervision
-            # branch shares the fusion blocks' stream instead
-            default = [0, 1, 1, 0] if (SEP_BRANCH and n == 2) else [0, 1, 2, 3]
-            cache[dev] = [pool[int(c) % n] for c in smap] if smap and len(smap) == 4 else [pool[i % n] for i in default]
-        return cache[dev]
+            pools[dev] = [torch.cuda.Stream(device=dev) for _ in range(n)]
+        pool = pools[dev]
+        n = len(pool)
+        smap = _os.environ.get("PASSION_SIDE_MAP")                 # A/B: which of the n streams each of the four roles takes, e.g. 0110
+        # Two streams, plain step (round 6): the deep-supervision losses share the FUSION blocks' stream, not decoder_sep's -- their backward
+        # is what the fusion decoder's chain on the main stream waits for, level by level, and on decoder_sep's stream it sat behind that
+        # branch's chip-filling 4 B-sample launches (with decoder_sep's loss created first, below): 9.92 -> 9.69 ms per replayed step, 5 of 5
+        # runs (the old map under the new order: bimodal, 9.67 / 10.2).  The PASSION step keeps the old map (measured: 16.87 against 17.11)
+        default = [0, 1, 1, 0] if (n == 2 and not passion) else [0, 1, 2, 3]
+        roles = [pool[int(c) % n] for c in smap] if smap and len(smap) == 4 else [pool[i % n] for i in default]
+        self.__dict__.setdefault("_streams_dev", {})[dev] = roles      # (train._early_step_callback reads the roles of the last forward)
+        return roles
 
     def _deep_weights_on(self, dev):
         cache = self.__dict__.setdefault("_deep_w_dev", {})
@@ -542,7 +545,7 @@ class Model(nn.Module):
         passion = training and self.use_passion
         mask = mask.to(device=dev, dtype=torch.bool).contiguous()
         grouped = GROUPED_ENC and x.is_cuda and L.host() is not None
-        streams = self._enc_streams(dev, x.shape[2] * x.shape[3] * x.shape[4]) if ENC_STREAMS and x.is_cuda else None
+        streams = self._enc_streams(dev, x.shape[2] * x.shape[3] * x.shape[4], passion) if ENC_STREAMS and x.is_cuda else None
         main = torch.cuda.current_stream(dev) if streams else None
         if streams:
             for s_ in streams:                           # (possibly a fresh copy made on the main stream) read on every side stream
@@ -646,7 +649,6 @@ class Model(nn.Module):
         # decoder_sep (per-modality decoders, shared weights: ONE pass over the stacked modalities) depends on the encoders
         # only, like the fusion path: it goes to a side stream and overlaps with the transformers + decoder_fuse below
         sep_all = None
-        sep_outer = sep_inner = None
         if training:
             sep_mask = mask.t().reshape(4 * B, 1).contiguous() if idt else None      # row i*B+b = mask[b, i]
             stacked = []
@@ -658,12 +660,6 @@ class Model(nn.Module):
                 t = ops.stack_slots(bufs[l], [encs[i][l].t for i in range(4)])
                 st = [sbufs[l].view(4 * B, -1, 2)] if l < 4 else None               # filled by the encoders' next-level convs
                 stacked.append(Feat(t, sep_mask, 0, _stats=st))
-            # decoder_sep + its loss as a branch with a graph of its own, joined to the step's graph by ONE node created at the end of
-            # forward (ops.BranchJoinFn: its backward is then enqueued first instead of last)
-            if SEP_BRANCH and streams and LOSS_STREAMS and torch.is_grad_enabled() and all(f.t.requires_grad for f in stacked):
-                sep_outer = [f.t for f in stacked]
-                sep_inner = [t.detach().requires_grad_(True) for t in sep_outer]
-                stacked = [Feat(t, f.mask, f.mask_col, _stats=f._stats) for t, f in zip(sep_inner, stacked)]
             if streams:
                 streams[0].wait_stream(main)
                 if sep_mask is not None:
@@ -737,25 +733,20 @@ class Model(nn.Module):
             gate.record_stream(s0)
             for pp in preds:
                 pp.record_stream(s2)
-            # the join node of the decoder_sep branch BEFORE the deep-supervision nodes: the engine then enqueues the deep-supervision
-            # backward (which the fusion decoder's chain waits for), the branch's backward and the fusion decoder's chain in that order
-            # (measured, 3 x 100 replayed steps each: 9.72 ms; join last 9.96; no branch node 9.94)
-            if SEP_JOIN_EARLY:
+            # decoder_sep's loss FIRST (round 6): autograd runs ready nodes in reverse creation order, so the deep-supervision backward --
+            # which the fusion decoder's chain on the main stream waits for, level by level -- is then enqueued AHEAD of decoder_sep's
+            # loss gradient (a chip-filling 4 B-sample launch) instead of behind it on the stream the two share: 9.94 -> 9.72 ms per plain
+            # step (3 x 100 replayed steps each; PASSION +-0).  PASSION_SEP_LOSS_FIRST=0: the old order
+            if SEP_LOSS_FIRST:
                 with torch.cuda.stream(s0):
                     sep_loss = sep_losses()
-                    if sep_inner is not None:
-                        sep_loss = ops.branch_join(sep_loss, sep_inner, sep_outer)
-                        sep_inner = None
                     sep_loss.record_stream(main)
             with torch.cuda.stream(s2):
                 prm_loss = deep_supervision()
                 prm_loss.record_stream(main)
-            if not SEP_JOIN_EARLY:
+            if not SEP_LOSS_FIRST:
                 with torch.cuda.stream(s0):
                     sep_loss = sep_losses()
-                    if sep_inner is not None and not passion:
-                        sep_loss = ops.branch_join(sep_loss, sep_inner, sep_outer)
-                        sep_inner = None
                     sep_loss.record_stream(main)
             main.wait_stream(s0)
             main.wait_stream(s2)
@@ -794,9 +785,4 @@ class Model(nn.Module):
         kl_loss = gd * kl_all.view(4, B).t()
         proto_loss = gd * pl_all.view(4, B).t()
         dist = gd * d_all.view(4, B).t()
-        if sep_inner is not None:                    # the join node last: see ops.BranchJoinFn
-            with torch.cuda.stream(streams[0]):
-                sep_loss = ops.branch_join(sep_loss, sep_inner, sep_outer)
-                sep_loss.record_stream(main)
-            main.wait_stream(streams[0])
         return pred, prm_loss, sep_loss, kl_loss, proto_loss, dist

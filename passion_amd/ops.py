@@ -689,43 +689,6 @@ def stack_slots(buf, parts):
     return StackFn.apply([buf], *parts)
 
 
-class BranchJoinFn(torch.autograd.Function):
-    """A side branch of the step with a graph of its own (mmformer: decoder_sep + its loss, reference mmformer.py:436-466 -- it reads the
-    encoder features and feeds one loss term, nothing else).  The branch was run on DETACHED copies of its inputs (`inner_in`, leaves
-    that require grad), so autograd's graph of the step holds ONE node for it -- this one, created at the END of forward: the engine
-    runs ready nodes in reverse creation order, so the branch's whole backward (a re-entrant backward over the inner graph) is
-    enqueued FIRST, right behind the loss gradient, instead of behind every node created after the branch in forward (the fusion
-    decoder, the transformers, the fusion blocks).  Why the order matters although the branch has its own stream: a recorded step's
-    graph is launched node by node in creation order onto a handful of hardware queues, a queue is in order, and a node waiting for
-    its predecessors holds back whatever was enqueued behind it on that queue -- the branch's backward, ready 2 ms earlier, started
-    only when the fusion path's had drained (profiles/r06_trace_seq_before.txt).  Values are unchanged; only the order in which
-    gradient contributions meet in autograd's sums moves."""
-
-    @staticmethod
-    def forward(ctx, holder, *outer_in):
-        ctx.holder = holder
-        return holder["out"].detach()
-
-    @staticmethod
-    def backward(ctx, g):
-        h = ctx.holder
-        ctx.holder = None
-        for t in h["inner_in"]:
-            t.grad = None
-        torch.autograd.backward([h["out"]], [g])
-        grads = tuple(t.grad for t in h["inner_in"])
-        for t in h["inner_in"]:
-            t.grad = None
-        h.clear()
-        return (None,) + grads
-
-
-def branch_join(inner_out, inner_in, outer_in):
-    """inner_out: the branch's result, computed from `inner_in` (= [t.detach().requires_grad_() for t in outer_in]) under autograd;
-    -> the same values as a function of `outer_in` in the caller's graph (see BranchJoinFn).  Call it under the branch's stream."""
-    return BranchJoinFn.apply({"out": inner_out, "inner_in": list(inner_in)}, *outer_in)
-
-
 # ------------------------------------------------------------------------------------------------
 # trilinear upsampling
 # ------------------------------------------------------------------------------------------------
