@@ -792,21 +792,38 @@ def softmax_classes(logits, inv_temp=1.0, out_layout="cl"):
     return SoftmaxFn.apply(logits, inv_temp, out_layout)
 
 
+_TCL_STEP = [0]      # train.train_step counts its calls here: a conversion made under stream capture is valid for THAT step's recording only
+
+
 def target_to_cl(target):
-    """one-hot target (B,4,D,H,W) f64/f32 (datasets_nii.py:151-153) -> f32 channels-last (B,D,H,W,4)"""
+    """one-hot target (B,4,D,H,W) f64/f32 (datasets_nii.py:151-153) -> f32 channels-last (B,D,H,W,4).
+    The converted image is kept on the tensor OBJECT: Model.forward and the loss assembly of one step (train.assemble_loss ->
+    criterions.seg_pair_bs) convert once, also inside a recording (round 5 converted twice per recorded step: the cache was bypassed
+    while capturing).  A target that already IS channels-last in memory (one_hot(...).permute(0, 4, 1, 2, 3): what train.synthetic_batch
+    and a loader that permutes instead of copying hand over) is read through its strides -- `.contiguous()` used to copy the 32-byte-
+    per-voxel float64 volume to NCDHW first, only for the kernel to transpose it back."""
     L.require_gpu(target)
+    capturing = torch.cuda.is_current_stream_capturing()
     cached = getattr(target, "_passion_cl", None)
-    if cached is not None and cached[0] == target._version and not torch.cuda.is_current_stream_capturing():
-        return cached[1]
-    t = target.contiguous()
-    B, C, D, H, W = t.shape
-    out = torch.empty(B, D, H, W, C, dtype=torch.float32, device=t.device)
+    if cached is not None and cached[0] == target._version:
+        if len(cached) == 2:                       # made by a loader (data/transforms.py): plain data, valid outside recordings
+            if not capturing:
+                return cached[1]
+        elif cached[2] == (capturing, _TCL_STEP[0] if capturing else -1):
+            return cached[1]
+    B, C, D, H, W = target.shape
+    t = target
     if t.dtype not in (torch.float32, torch.float64):
         t = t.float()
-    L.check(L.load().passion_target_to_cl(_p(t), 1 if t.dtype == torch.float64 else 0, _p(out), B, D * H * W, C,
-                                          L.stream_ptr()), "passion_target_to_cl")
+    out = torch.empty(B, D, H, W, C, dtype=torch.float32, device=t.device)
+    if t.permute(0, 2, 3, 4, 1).is_contiguous() and not t.is_contiguous():
+        out.copy_(t.permute(0, 2, 3, 4, 1))        # same element order in memory: one streaming conversion
+    else:
+        t = t.contiguous()
+        L.check(L.load().passion_target_to_cl(_p(t), 1 if t.dtype == torch.float64 else 0, _p(out), B, D * H * W, C,
+                                              L.stream_ptr()), "passion_target_to_cl")
     try:
-        target._passion_cl = (target._version, out)
+        target._passion_cl = (target._version, out, (capturing, _TCL_STEP[0] if capturing else -1))
     except Exception:
         pass
     return out

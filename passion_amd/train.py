@@ -171,6 +171,7 @@ def train_step(model, optimizer, x, mask, target, temp=4.0, state=None, reducer=
         return None
     net = model
     net.is_training = True
+    ops._TCL_STEP[0] += 1                # ops.target_to_cl: one conversion of the label volume per step, recordings included
     early = EARLY_STEP and hasattr(optimizer, "step_ready") and (reducer is None or not reducer.active) and x.is_cuda and phase == "all"
     if hasattr(optimizer, "_stepped"):
         optimizer._stepped.clear()       # a backward that raised after the early part left its marks: this iteration starts clean
