@@ -1370,6 +1370,10 @@ static int conv3d_bwd_impl(const passion_conv_desc_t* d, const float* packed, co
         // the finish launch) instead of one of each per modality
         const bool grouped_general = ga && grouped_general_wgrad(k, d, w, ga->G);
         if (grouped_general) w.gx -= w.gx % ga->G;
+        // the first layer (Cin = 1) on the matrix cores: slots in sample order, so a grouped launch is one launch + one fold too
+        const bool c1m = w.bf16 && d->x_dtype == PASSION_BF16 && d->y_dtype == PASSION_BF16 && !g_passion_force_f32_mfma && pconv::g_conv_lean &&
+                         dweight && pconv::wgrad_c1m_covers(k, d->ksize, d->stride, w.gx);
+        const bool direct_slots = grouped_general || c1m;        // slab slots dealt to the weight sets in equal runs
         const long nW = (long)k.Cout * k.Cin * nt;
         k.wslot = nW + k.Cout;                       // one slot = [dW | dbias] of one workgroup
         float* wslab = sums + (long)2 * k.B * k.Cin * SUMS_SLOTS;
@@ -1385,7 +1389,10 @@ static int conv3d_bwd_impl(const passion_conv_desc_t* d, const float* packed, co
             float* dWs = dweight ? wslab : nullptr;
             float* dbs = dbias ? bslab : nullptr;
             defer_next_wgrad() = pair_ok;
-            if (ga && grouped_general) {             // grouped stride-2 layers: the general bf16 kernel, slots dealt to the sets in equal runs
+            if (c1m) {
+                rc = launch_wgrad_c1m(k, d->ksize, d->stride, w.gx, dWs, dbs, st);
+                if (rc > 0) rc = -1014;
+            } else if (ga && grouped_general) {      // grouped stride-2 layers: the general bf16 kernel, slots dealt to the sets in equal runs
                 rc = launch_wgrad_bf16(k, d->ksize, d->stride, w.MT, w.gx, w.gy, dWs, dbs, st);
             } else if (ga) {                         // grouped: the lean kernel (slots in sample order), checked by the caller
                 rc = launch_wgrad_lean(k, d->ksize, d->stride, w.MT, w.gx, w.gy, dWs, dbs, st);
@@ -1420,7 +1427,7 @@ static int conv3d_bwd_impl(const passion_conv_desc_t* d, const float* packed, co
             fj.out[0] = dweight;
             if (ga) {                                // one fold per weight set: R = its samples x workgroups per sample
                 const int tiles_per_b = k.tilesD * k.tilesH * k.tilesW;
-                fj.R = grouped_general ? w.gx / ga->G : k.bgroup * ((tiles_per_b + k.per - 1) / k.per);
+                fj.R = direct_slots ? w.gx / ga->G : k.bgroup * ((tiles_per_b + k.per - 1) / k.per);
                 fj.G = ga->G;
                 for (int g = 0; g < ga->G; ++g) fj.out[g] = ga->dW[g];
             }
@@ -1428,8 +1435,8 @@ static int conv3d_bwd_impl(const passion_conv_desc_t* d, const float* packed, co
         } else
         if (ga) {                                    // one fold per weight set: Rg = its samples x workgroups per sample
             const int tiles_per_b = k.tilesD * k.tilesH * k.tilesW;
-            const int wgs_per_b = grouped_general ? 0 : (tiles_per_b + k.per - 1) / k.per;
-            const int Rg = grouped_general ? w.gx / ga->G : k.bgroup * wgs_per_b;
+            const int wgs_per_b = direct_slots ? 0 : (tiles_per_b + k.per - 1) / k.per;
+            const int Rg = direct_slots ? w.gx / ga->G : k.bgroup * wgs_per_b;
             RedOuts ro;
             for (int g = 0; g < PASSION_MAX_GROUPS; ++g) ro.p[g] = g < ga->G ? ga->dW[g] : nullptr;
             hipLaunchKernelGGL(reduce_parts_grouped_kernel, dim3((unsigned)fold_nblocks(k.wslot, Rg), ga->G), dim3(256), 0, st, wslab,
@@ -1817,9 +1824,13 @@ extern "C" int passion_conv3d_bwd_grouped(const passion_conv_desc_t* d, int G, c
     const bool native_dgrad = bf16 && bf16_eligible(k, true);
     k.tilesD = cdiv(k.Do, TD); k.tilesH = cdiv(k.Ho, TH); k.tilesW = cdiv(k.Wo, TW);
     const WgPlan w = plan_wgrad(k, d);
+    const bool c1m = bf16 && dW && w.bf16 && pconv::g_conv_lean && pconv::wgrad_c1m_covers(k, d->ksize, d->stride, w.gx);      // first layer, matrix cores
     const bool native_wgrad = bf16 && dW && w.bf16 && pconv::g_conv_lean && wgrad_bf16_chunk(k, d->ksize, d->stride) != 16 &&
-                              !(k.Cin == 1) && (wgrad_lean_covers(k, d->ksize, d->stride, w.MT, w.gx, w.gy) || grouped_general_wgrad(k, d, w, G));
+                              ((!(k.Cin == 1) && (wgrad_lean_covers(k, d->ksize, d->stride, w.MT, w.gx, w.gy) || grouped_general_wgrad(k, d, w, G))) || c1m);
     GroupArgs ga{G, stride, nullptr, dW};
+    bool no_dx = true;                                // a raw input (the first layer's): there is no input gradient to run
+    for (int i = 0; i < d->nseg; ++i) if (d->seg[i].dx) no_dx = false;
+    if (no_dx && native_wgrad) return conv3d_bwd_impl(d, packed[0], dy, nullptr, nullptr, sums, stream, 0, 1.0f, 0, d->D, &ga, 1);
     const int bg = d->B / G;
     const long ys = d->y_dtype == PASSION_BF16 ? 2 : 4;
     const long vout = (long)k.Do * k.Ho * k.Wo * k.Cout;

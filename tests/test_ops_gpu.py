@@ -1013,6 +1013,7 @@ GROUPED_CASES = [
     ([8], 8, 3, 1, 1, (8, 8, 16), torch.float32, True, True, True),           # f32 storage: set by set
     ([32], 64, 3, 2, 1, (16, 32, 32), torch.bfloat16, False, True, True),     # stride 2, several bricks per slab slot: the grouped general wgrad
     ([16], 32, 3, 2, 1, (24, 16, 16), torch.bfloat16, False, True, False),    # stride 2, ragged brick count per sample
+    ([1], 8, 3, 1, 1, (16, 16, 32), torch.bfloat16, False, False, True),      # the first conv on the matrix-core weight gradient (conv_c1_mfma.hip)
 ]
 
 
@@ -1129,10 +1130,11 @@ def test_wgrad_march_equals_lean_kernel_sums():
 
 
 @pytest.mark.parametrize("pad_mode", [1, 0], ids=["reflect", "zeros"])
-@pytest.mark.parametrize("B,shape", [(2, (32, 32, 64)), (1, (5, 32, 16)), (3, (20, 16, 32))])
+@pytest.mark.parametrize("B,shape", [(2, (32, 32, 64)), (1, (5, 32, 16)), (3, (20, 16, 32)), (2, (9, 24, 128)), (1, (33, 8, 32))])
 def test_first_layer_weight_gradient(B, shape, pad_mode):
-    """wgrad_c1_kernel (conv_wgrad_lean.hip: one raw input channel, 8 outputs, bf16) against autograd in float64 on the same
-    bf16-rounded operands; the first case has more slab slots (512 bricks) than summing workgroups (256): the spare slots must
+    """wgrad_c1m_kernel (conv_c1_mfma.hip: one raw input channel, 8 outputs, bf16, on the matrix cores: reflect padding, W in {32, 64, 128},
+    H % 8 == 0) and wgrad_c1_kernel (conv_wgrad_lean.hip: every other shape) against autograd in float64 on the same
+    bf16-rounded operands; the first case has more slab slots (512 bricks) than summing workgroups: the spare slots must
     be flushed with zeros; a masked sample contributes nothing to dW but its dY still counts in the bias gradient"""
     from passion_amd import ops
     dev = _dev()
@@ -1160,7 +1162,8 @@ def test_first_layer_weight_gradient(B, shape, pad_mode):
     finally:
         ops.prof_enable(0)
     names = [r[4] for r in ops.prof_read()]
-    assert "wgrad_c1_kernel" in names, names
+    mfma = pad_mode == 1 and W in (32, 64, 128) and H % 8 == 0
+    assert (f"wgrad_c1m_kernel<{W}>" if mfma else "wgrad_c1_kernel") in names, names
     assert relerr(wd.grad, wr.grad) < 1e-5
     assert relerr(bd.grad, br.grad) < 1e-5
     first = wd.grad.clone()
