@@ -769,8 +769,10 @@ bool bf16_eligible(const ConvK& k, bool dgrad) {
 }
 
 int launch_conv_bf16(ConvK& k, int ksize, int stride, bool dgrad, const void* packed_bf16, hipStream_t st) {
-    if (!dgrad) {                            // first encoder layer: one input channel, eight outputs (conv_c1_fwd.hip)
-        const int rc = launch_conv_c1_fwd(k, ksize, stride, packed_bf16, st);
+    if (!dgrad) {                            // first encoder layer: one input channel, eight outputs (conv_c1_mfma.hip; other shapes: conv_c1_fwd.hip)
+        int rc = launch_conv_c1m_fwd(k, ksize, stride, packed_bf16, st);
+        if (rc <= 0) return rc;
+        rc = launch_conv_c1_fwd(k, ksize, stride, packed_bf16, st);
         if (rc <= 0) return rc;
     }
     if (g_conv_lean) {                       // lean persistent kernel for the stride-1, 8-channel-aligned shapes

@@ -215,6 +215,199 @@ __global__ __launch_bounds__(256) void wgrad_c1m_kernel(ConvK p, float* __restri
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Forward of the same layer on the matrix cores (the vector kernel conv_c1_fwd.hip: 216 FMAs per voxel, 102 us per grouped launch).
+//   y[v][co] = sum_tap W[co][tap] x[v + tap] + bias[co]
+// with the trick of conv_pair.hip: the 16 MFMA rows carry TWO output planes (rows 0..7: plane d, rows 8..15: plane d + 1), so the K axis
+// runs over the FOUR input planes d - 1 .. d + 2: K = 16 (plane, row tap) slots x 4 W offsets (-1 .. +2; the fourth and slots 12..15 carry
+// zero weights) = 64 = two v_mfma_f32_16x16x32_bf16 per 16 voxels x 2 planes.  Lane (voxel n, group g) of MFMA j holds K slots 8 j + 2 g and
+// + 1: two runs of four consecutive W positions starting at w - 1.  x is staged FOUR times, shifted by -1 .. +2, so that the run of
+// voxel n starts on an 8-byte boundary of copy n & 3: every fragment half is one aligned ds_read_b64.  A workgroup owns 8 rows x the
+// whole width and marches along D two planes at a time (ring of 6 plane slots); the weights (2 fragments) live in registers, the bias
+// is the accumulators' initial value, the epilogue rounds, stores 8 bytes per lane (32 lanes = 256 contiguous bytes of one plane) and
+// sums the InstanceNorm statistics of what it stored (slot / ticket fold of conv_common.h, as conv_c1_fwd.hip).
+typedef unsigned int u32x2c __attribute__((ext_vector_type(2)));
+
+template <int W> struct FGeo {
+    static constexpr int RS = W * 2 + 16;
+    static constexpr int COPY = XROWS * RS + 32;
+    static constexpr int SLOT = 4 * COPY;
+    static constexpr int NSL = 6;
+    static constexpr int LDS = NSL * SLOT;
+};
+
+struct C1FP { int nseg_d, planes_per_seg, tilesH, nwg_b; };
+
+template <int W>
+__global__ __launch_bounds__(256) void conv_c1m_fwd_kernel(ConvK p, C1FP mp) {
+    using G = FGeo<W>;
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    __shared__ float lsum[4 * 4 * 4 * 2 + 16];
+    const int tid = threadIdx.x, lane = tid & 63, n = lane & 15, g = lane >> 4, wv = tid >> 6;
+    const int D = p.Di, H = p.Hi;
+    const SegD& sd = p.seg[0];
+    const int b = blockIdx.y, wq = blockIdx.x;
+    const int th_i = wq % mp.tilesH, dseg = wq / mp.tilesH;
+    const int h0 = th_i * TH1;
+    const int d0 = dseg * mp.planes_per_seg, d1 = min(d0 + mp.planes_per_seg, D);      // even bounds (launcher)
+    const bool present = !sd.mask || sd.mask[(long)b * sd.mask_ld + sd.mask_col] != 0;
+    const unsigned short* xb = reinterpret_cast<const unsigned short*>(sd.x) + (long)sd.bsrc(b) * sd.bstride;
+
+    // ---- staging of one x plane: as in the weight gradient above, four shifted copies (copy c holds x[i + c - 1] at index i)
+    constexpr int CPR = W / 8;
+    const int xrow = tid / CPR, xc = tid % CPR;
+    const bool xon = tid < XROWS * CPR;
+    const int xh = min(max(reflect_idx(h0 - 1 + min(xrow, XROWS - 1), H), 0), H - 1);
+    auto xfetch = [&](int pl) -> u32x4 {
+        const int pd = min(max(reflect_idx(pl, D), 0), D - 1);
+        const u32x4 v = *reinterpret_cast<const u32x4 __attribute__((address_space(1)))*>(
+            reinterpret_cast<unsigned long long>(xb + ((long)pd * H + xh) * W + xc * 8));
+        return (xon && present) ? v : (u32x4){0u, 0u, 0u, 0u};
+    };
+    auto xcommit = [&](int slot, u32x4 v) {
+        unsigned up = __shfl_up(v[3], 1, 64) >> 16;                       // previous chunk's element 7
+        unsigned dn = __shfl_down(v[0], 1, 64);                           // next chunk's elements 0, 1
+        if (xc == 0) up = v[0] >> 16;                                     // x[-1] = x[1]
+        if (xc == CPR - 1) dn = (v[3] & 0xffffu) | (v[2] & 0xffff0000u);  // x[W] = x[W - 2], x[W + 1] = x[W - 3]
+        u32x4 c0, c2, c3;
+        c0[0] = up | (v[0] << 16);
+        c0[1] = (v[0] >> 16) | (v[1] << 16);
+        c0[2] = (v[1] >> 16) | (v[2] << 16);
+        c0[3] = (v[2] >> 16) | (v[3] << 16);
+        c2[0] = (v[0] >> 16) | (v[1] << 16);
+        c2[1] = (v[1] >> 16) | (v[2] << 16);
+        c2[2] = (v[2] >> 16) | (v[3] << 16);
+        c2[3] = (v[3] >> 16) | (dn << 16);
+        c3[0] = v[1]; c3[1] = v[2]; c3[2] = v[3]; c3[3] = dn;
+        if (xon) {
+            char* base = lds + slot * G::SLOT + xrow * G::RS + xc * 16;
+            *reinterpret_cast<u32x4*>(base) = c0;
+            *reinterpret_cast<u32x4*>(base + G::COPY) = v;
+            *reinterpret_cast<u32x4*>(base + 2 * G::COPY) = c2;
+            *reinterpret_cast<u32x4*>(base + 3 * G::COPY) = c3;
+        }
+    };
+
+    // ---- weights: A[m][k], k = 32 j + 8 g + e: K slot r = 8 j + 2 g + (e >> 2) = 3 pd + th (r < 12), W offset e & 3 (tw; 3: nothing);
+    // rows m < 8: channel m of plane d (depth tap pd), rows m >= 8: channel m - 8 of plane d + 1 (depth tap pd - 1)
+    bf16x8 wfr[2];
+    {
+        const bf16_t* wimg = reinterpret_cast<const bf16_t*>(p.wpack) + wvec_of(p, b) * 8;      // forward image [tap][1 block][16 rows][8]
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int r = 8 * j + 2 * g + (e >> 2), tw = e & 3, pd = r / 3, th = r % 3;
+                const int td = pd - (n >> 3), co = n & 7;
+                const bool ok = r < 12 && tw < 3 && td >= 0 && td <= 2;
+                const int tap = min(max(td, 0), 2) * 9 + th * 3 + min(tw, 2);
+                const bf16_t wv_ = wimg[((long)tap * 16 + co) * 8];
+                wfr[j][e] = ok ? (__bf16)wv_ : (__bf16)0.f;
+            }
+    }
+    // B addresses: lane (n, g) of MFMA j, half q2: K slot r = 8 j + 2 g + q2 (clamped to 11: zero weights beyond), copy n & 3, element
+    // index 4 (n >> 2) of the 16-voxel tile
+    int boff[2][2], bpd[2][2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int q2 = 0; q2 < 2; ++q2) {
+            const int r = min(8 * j + 2 * g + q2, 11), pd = r / 3, th = r % 3;
+            bpd[j][q2] = pd;
+            boff[j][q2] = (n & 3) * G::COPY + th * G::RS + (n >> 2) * 8;
+        }
+    const float* bias = bias_of(p, b);
+    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+    if (bias) bv = load4(bias + 4 * (g & 1));
+    const int half = g >> 1, cg = 4 * (g & 1);
+    char* yb = reinterpret_cast<char*>(p.y) + (long)b * D * H * W * 16 + cg * 2;
+    const bool fstats = p.fst.stats != nullptr;
+    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+
+    // ---- prologue: planes d0 - 1 .. d0 + 2 in ring slots 0 .. 3, planes d0 + 3, d0 + 4 in registers
+#pragma unroll
+    for (int j = 0; j < 4; ++j) xcommit(j, xfetch(d0 - 1 + j));
+    u32x4 xn0 = xfetch(d0 + 3), xn1 = xfetch(d0 + 4);
+    int base = 0;                                     // ring slot of plane d - 1
+    for (int d = d0; d < d1; d += 2) {
+        __syncthreads();                              // planes d - 1 .. d + 2 staged; the slots of planes d - 3, d - 2 free
+        if (d + 2 < d1) {
+            xcommit((base + 4) % G::NSL, xn0);
+            xcommit((base + 5) % G::NSL, xn1);
+            xn0 = xfetch(d + 5); xn1 = xfetch(d + 6);
+        }
+        int sl[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) sl[j] = ((base + j) % G::NSL) * G::SLOT;
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {
+            const int hl = 2 * wv + rr;
+#pragma unroll
+            for (int t = 0; t < W / 16; ++t) {
+                f32x4 acc = bv;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    union { u32x2c u[2]; bf16x8 v; } bf;
+#pragma unroll
+                    for (int q2 = 0; q2 < 2; ++q2) {
+                        int so = sl[0];
+                        if (bpd[j][q2] == 1) so = sl[1];
+                        if (bpd[j][q2] == 2) so = sl[2];
+                        if (bpd[j][q2] == 3) so = sl[3];
+                        bf.u[q2] = *reinterpret_cast<const u32x2c*>(lds + so + boff[j][q2] + hl * G::RS + t * 32);
+                    }
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfr[j], bf.v, acc, 0, 0, 0);
+                }
+                unsigned pk[2];
+                float rb[4];
+                round4_bf16(acc, pk, rb);
+                const long vox = (((long)(d + half) * H + h0 + hl) * W + t * 16 + n) * 16;
+                *reinterpret_cast<u32x2c __attribute__((address_space(1)))*>(reinterpret_cast<unsigned long long>(yb + vox)) = (u32x2c){pk[0], pk[1]};
+                if (fstats) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) { s1[c] += rb[c]; s2[c] = __builtin_fmaf(rb[c], rb[c], s2[c]); }
+                }
+            }
+        }
+        base = (base + 2) % G::NSL;
+    }
+    if (!fstats) return;
+    // statistics: 16 voxel lanes (shuffles) -> 4 waves x 4 lane groups (LDS, fixed order) -> the workgroup's slot
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const float a1 = group16_sum(s1[c]), a2 = group16_sum(s2[c]);
+        if (n == 0) {
+            lsum[((wv * 4 + g) * 4 + c) * 2 + 0] = a1;
+            lsum[((wv * 4 + g) * 4 + c) * 2 + 1] = a2;
+        }
+    }
+    __syncthreads();
+    if (tid < 16) {
+        const int c = tid >> 1, k2 = tid & 1, gq = c >> 2, j = c & 3;      // channel c = 4 gq + j: lane groups gq (plane d) and gq + 2 (plane d + 1)
+        float t = 0.f;
+#pragma unroll
+        for (int w2 = 0; w2 < 4; ++w2) t += lsum[((w2 * 4 + gq) * 4 + j) * 2 + k2] + lsum[((w2 * 4 + gq + 2) * 4 + j) * 2 + k2];
+        lsum[4 * 4 * 4 * 2 + tid] = t;
+    }
+    __syncthreads();
+    fwd_stats_commit(p.fst, 8, b, wq, 0, 8, lsum + 4 * 4 * 4 * 2, tid);
+}
+
+template <int W>
+int launch_c1m_fwd(ConvK& k, const C1FP& mp, hipStream_t st) {
+    using G = FGeo<W>;
+    static bool granted = false;
+    if (!granted) {
+        HIP_RET(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_c1m_fwd_kernel<W>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS));
+        granted = true;
+    }
+    passion_prof_tag("conv_c1m_fwd_kernel<%d>", W);
+    hipLaunchKernelGGL((conv_c1m_fwd_kernel<W>), dim3(mp.nwg_b, k.B), dim3(256), G::LDS, st, k, mp);
+    LAUNCH_RET();
+    return 0;
+}
+
 template <int W>
 int launch_c1m(ConvK& k, const C1MP& mp, int gx, float* dW, float* db, hipStream_t st) {
     using G = XGeo<W>;
@@ -255,6 +448,31 @@ int launch_wgrad_c1m(ConvK& k, int ksize, int stride, int gx, float* dW, float* 
     if (k.Wi == 128) return launch_c1m<128>(k, mp, gx, dW, db, st);
     if (k.Wi == 64) return launch_c1m<64>(k, mp, gx, dW, db, st);
     return launch_c1m<32>(k, mp, gx, dW, db, st);
+}
+
+// forward: the same shapes, an even depth.  0 = launched, 1 = not this shape (conv_c1_fwd.hip takes it), < 0 = HIP error
+int launch_conv_c1m_fwd(ConvK& k, int ksize, int stride, const void* packed_bf16, hipStream_t st) {
+    if (!g_c1_mfma || ksize != 3 || stride != 1 || k.nseg != 1 || k.Cin != 1 || k.seg[0].C != 1 || k.Cout != 8) return 1;
+    if (k.seg[0].stats || k.residual || k.y_f32 || k.seg[0].bmod > 0 || k.pad_mode != PASSION_PAD_REFLECT) return 1;
+    if (k.Hi % TH1 || (k.Wi != 32 && k.Wi != 64 && k.Wi != 128) || k.Di % 2 || k.Di < 4 || k.Hi < 2) return 1;
+    if ((long)k.Di * k.Hi * k.Wi * 16 >= (1L << 31)) return 1;
+    C1FP mp;
+    mp.tilesH = k.Hi / TH1;
+    // D segments: ~1024 workgroups per launch, at least 8 planes each, an even number of planes, at most 1024 statistics slots per sample
+    int nseg = (int)hmax(1, hmin((1024 + (long)k.B * mp.tilesH - 1) / ((long)k.B * mp.tilesH), k.Di / 8));
+    nseg = (int)hmin(nseg, hmax(1, 1024 / mp.tilesH));
+    mp.planes_per_seg = ((k.Di + nseg - 1) / nseg + 1) & ~1;
+    mp.nseg_d = (k.Di + mp.planes_per_seg - 1) / mp.planes_per_seg;
+    mp.nwg_b = mp.tilesH * mp.nseg_d;
+    k.Mpad = pad16(k.Cout);
+    k.wpack = packed_bf16;
+    if (k.fst_want) {
+        const int rc = fwd_stats_setup(k, mp.nwg_b, 1, st);
+        if (rc) return rc;
+    }
+    if (k.Wi == 128) return launch_c1m_fwd<128>(k, mp, st);
+    if (k.Wi == 64) return launch_c1m_fwd<64>(k, mp, st);
+    return launch_c1m_fwd<32>(k, mp, st);
 }
 
 }  // namespace pconv

@@ -153,6 +153,7 @@ extern int g_conv_c1;
 int launch_wgrad_c1(ConvK& k, int ksize, int stride, int gx, int gy, float* dWslab, float* dbslab, hipStream_t st);   // first layer, Cin = 1
 bool wgrad_c1m_covers(const ConvK& k, int ksize, int stride, int gx);                                                  // conv_c1_mfma.hip: the same on the matrix cores
 int launch_wgrad_c1m(ConvK& k, int ksize, int stride, int gx, float* dWslab, float* dbslab, hipStream_t st);
+int launch_conv_c1m_fwd(ConvK& k, int ksize, int stride, const void* packed_bf16, hipStream_t st);                     // ... and the forward
 extern int g_c1_mfma;
 extern int g_conv_lean;
 int launch_wgrad_bf16(ConvK& k, int ksize, int stride, int MT, int gx, int gy, float* dWslab, float* dbslab, hipStream_t st);

@@ -1175,7 +1175,7 @@ def test_first_layer_weight_gradient(B, shape, pad_mode):
 
 
 @pytest.mark.parametrize("pad_mode", [1, 0], ids=["reflect", "zeros"])
-@pytest.mark.parametrize("shape", [(20, 16, 32), (5, 32, 16)])
+@pytest.mark.parametrize("shape", [(20, 16, 32), (5, 32, 16), (10, 24, 128), (6, 8, 64)])
 def test_first_layer_forward_kernel(shape, pad_mode):
     """conv_c1_fwd.hip (one raw input channel -> 8, bf16): against the f64 reference, against the general kernel, statistics of
     the output from the same launch, masked samples, plain and grouped (four weight sets over one stacked batch)"""
@@ -1208,7 +1208,10 @@ def test_first_layer_forward_kernel(shape, pad_mode):
     finally:
         ops.prof_enable(0)
     names = [r[4] for r in ops.prof_read()]
-    assert names.count("conv_c1_fwd_kernel") == 2, names
+    mfma = pad_mode == 1 and W in (32, 64, 128) and H % 8 == 0 and D % 2 == 0 and D >= 4
+    vec = H % 16 == 0 and W % 16 == 0                      # the vector kernel's tiles (conv_c1_fwd.hip); everything else: the general kernel
+    want = f"conv_c1m_fwd_kernel<{W}>" if mfma else ("conv_c1_fwd_kernel" if vec else "conv_bf16_kernel<3, 1, 1, 0, 8>")
+    assert names.count(want) == 2, names
     assert relerr(nc(y.detach().float()), ref(ws[0], bs[0], slice(0, B))) < 1e-2
     for gi in range(4):
         assert relerr(nc(yg[gi:gi + 1].detach().float()), ref(ws[gi], bs[gi], slice(gi, gi + 1))) < 1e-2

@@ -3,7 +3,7 @@ duration (us), queue, workgroups, kernels already in flight when it starts, name
 import csv, sys, re
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-c1 = [i for i, r in enumerate(rows) if "conv_c1_fwd_kernel" in r["Kernel_Name"]]
+c1 = [i for i, r in enumerate(rows) if ("conv_c1_fwd_kernel" in r["Kernel_Name"] or "conv_c1m_fwd_kernel" in r["Kernel_Name"])]
 opt = [i for i, r in enumerate(rows) if "multi_tensor_apply" in r["Kernel_Name"] or "adamw_multi_kernel" in r["Kernel_Name"]]
 ends = [i for j, i in enumerate(opt) if j + 1 == len(opt) or opt[j + 1] - i > 200]
 if len(c1) >= 3:          # a step = from one first-layer forward to the next (the mmformer workloads)
