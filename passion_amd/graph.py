@@ -157,6 +157,7 @@ class GraphedStep:
             # check, no launch when nothing moved
             from . import ops
             ops.repack_stale()
+            ops.recast_stale()                    # (the same for the bf16 operands of the token GEMMs)
         seed = int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())      # CPU generator: follows torch.manual_seed
         w = (ctypes.c_uint32 * 2)(seed & 0xffffffff, (seed >> 32) & 0xffffffff)
         L.check(L.load().passion_write_words(self.words.data_ptr(), 2, ctypes.cast(w, c_void_p), L.stream_ptr()), "passion_write_words")
@@ -167,6 +168,7 @@ class GraphedStep:
         if not self.hybrid and self.step_fn is None:
             from . import ops
             ops.mark_packed_fresh()               # ... the replay has re-packed every image from the weights it wrote (graph_tick moved their versions)
+            ops.mark_cast_fresh()
         if self.hybrid:
             for p, g_ in self.grads:          # (the previous tail left views of the reduced buckets there)
                 p.grad = g_

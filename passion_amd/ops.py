@@ -157,11 +157,16 @@ class _CastGradFn(torch.autograd.Function):
         return g.float(), None
 
 
-def recast_stale():
+def recast_stale(only=None, exclude=None):
     """Refresh, in one multi-tensor launch, the bf16 image of every registered Linear parameter the optimizer touched.
     Under autocast every F.linear casts its f32 weight and bias again on every call (40 tiny launches per step for the five
-    transformers); a bf16 operand passes through autocast untouched."""
+    transformers); a bf16 operand passes through autocast untouched.
+    only / exclude: sets of parameter data_ptr()s, as repack_stale -- train.train_step casts the transformers' parameters right behind
+    their early AdamW pass on the optimizer's stream (under the encoder backward: 157 MB that the next forward used to start with on
+    the critical stream, 57 us per step) and whatever is left behind the closing step."""
     capturing = torch.cuda.is_current_stream_capturing()
+    if capturing and _PACK_MANAGED[0] and only is None and exclude is None:
+        return 0                                 # the recording holds the casts behind the optimizer passes instead
     src, dst = [], []
     for key in list(_CAST_REGISTRY):
         ent = _CAST_REGISTRY[key]
@@ -170,6 +175,10 @@ def recast_stale():
             del _CAST_REGISTRY[key]
             continue
         if not p.is_cuda:
+            continue
+        if only is not None and p.data_ptr() not in only:
+            continue
+        if exclude is not None and p.data_ptr() in exclude:
             continue
         if ent[1] is None or ent[1].device != p.device:
             ent[1], ent[2] = torch.empty_like(p, dtype=torch.bfloat16), None
@@ -180,6 +189,18 @@ def recast_stale():
     if src:
         torch._foreach_copy_(dst, src)
     return len(src)
+
+
+def mark_cast_fresh():
+    """after a graph replay that re-cast every registered image from the parameters it had just written (graph.GraphedStep): the images
+    match the parameters' current versions (mark_packed_fresh, for the token GEMMs' operands)"""
+    for key in list(_CAST_REGISTRY):
+        ent = _CAST_REGISTRY[key]
+        p = ent[0]()
+        if p is None:
+            del _CAST_REGISTRY[key]
+        elif ent[1] is not None:
+            ent[2] = (p.data_ptr(), p._version)
 
 
 def bf16_image(p):

@@ -151,9 +151,10 @@ def _early_step_callback(model, optimizer):
         from . import ops as _ops
         with torch.cuda.stream(opt_stream):
             optimizer.step_ready()
-            if PACK_BEHIND_STEP:                 # ... and their MFMA operand images, still under the encoder backward
+            if PACK_BEHIND_STEP:                 # ... and their MFMA operand images / bf16 GEMM operands, still under the encoder backward
                 model.__dict__["_early_packed"] = set(optimizer._stepped)
                 _ops.repack_stale(only=model.__dict__["_early_packed"])
+                _ops.recast_stale(only=model.__dict__["_early_packed"])
             done.record(opt_stream)
         model.__dict__["_opt_pending"] = done
     return cb
@@ -204,7 +205,9 @@ def train_step(model, optimizer, x, mask, target, temp=4.0, state=None, reducer=
         reducer.all_reduce_grads()
     optimizer.step()
     if managed:                          # the images of what this closing step updated (the encoders; everything without the early pass)
-        ops.repack_stale(exclude=net.__dict__.pop("_early_packed", set()))
+        early_set = net.__dict__.pop("_early_packed", set())
+        ops.repack_stale(exclude=early_set)
+        ops.recast_stale(exclude=early_set)
     pending = net.__dict__.pop("_opt_pending", None)
     if pending is not None:              # the early part ran on its own stream: the next forward waits for it
         torch.cuda.current_stream(x.device).wait_event(pending)

@@ -44,7 +44,10 @@ def _gates(outs, mask):
     return ptrain.relative_preference(outs[5], mask.float(), True).cpu().numpy()
 
 
-GATE_TIE = 1e-2        # a gate the reference decides by a relative distance below this may flip under bf16 rounding
+GATE_TIE = 2e-2        # a gate the reference decides by a relative distance below this may flip under bf16 rounding (the gates of the
+                       # replay are the reference's either way: this only bounds how close a decision the product's own gate may miss.
+                       # Round 6: the first layer on the matrix cores sums its 27 taps in another order; the gates that differ moved
+                       # from |distance| <= 0.0043 to one at 0.0155 in step 4+ of the 32^3 PASSION trajectory, per-step losses unchanged)
 
 
 def _replay(name, dtype):

@@ -1,2 +1,5 @@
-python3 -c "import torch; print('prio range', torch.cuda.Stream.priority_range() if hasattr(torch.cuda.Stream,'priority_range') else None)" > gpurun_out/e1.txt 2>&1
-REPS=2 STEPS=80 bash tools/ab_graph.sh "base:X=1" "mainhi:PASSION_GRAPH_PRIO=-1" "seplo:PASSION_SIDE_PRIO=1,0" "sephi:PASSION_SIDE_PRIO=-1,0" "mainhi_p1hi:PASSION_GRAPH_PRIO=-1 PASSION_SIDE_PRIO=0,-1" "p1hi:PASSION_SIDE_PRIO=0,-1" >> gpurun_out/e1.txt 2>&1
+cd _wt
+for i in 1 2 3 4 5 6; do
+    r=$(python -m pytest tests/test_fullsize_gpu.py -q -x -k rfnet_128 2>&1 | tail -1)
+    echo "round5 tree : $r"
+done > ../gpurun_out/e1.txt 2>&1
