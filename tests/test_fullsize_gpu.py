@@ -289,7 +289,27 @@ def test_rfnet_128_batch2_passion_training_step():
     x2[1, 0] = 77.0
     outs2, loss2, grads2 = step(x2)
     assert all(torch.equal(a, b) for a, b in zip(outs, outs2)) and torch.equal(loss, loss2)
-    assert all(torch.equal(grads[k], grads2[k]) for k in grads)
+    # The gradients: bit for bit with every launch on one stream.  With decoder_sep and the deep-supervision losses on side streams
+    # (round 5) the contributions to a feature's gradient that arrive from different streams do not always meet in autograd's bf16 sum
+    # in the same order (tools/rfnet_cold_probe.py: outputs and losses repeat, ~5 % of the elements of the finest stacked encoder
+    # feature's gradient move by ONE bf16 ulp between a process's first step and later ones; a join of the streams at the head of the
+    # backward, no allocator caching or serialised kernels each make the step repeat bit for bit; mmformer's steps repeat as they are):
+    # there the parameter gradients behind such a sum are held to that rounding, not to bit equality.
+    # (sums over 2 M voxels of signed values that nearly cancel -- the first layer's bias gradient -- turn that ulp noise into tens of
+    # per cent of a tiny number: the bound is relative to the tensor's norm OR absolute at 1e-3 of the largest gradient of the model)
+    gmax = max(float(g.abs().max()) for g in grads.values())
+    for k in grads:
+        d_ = (grads[k] - grads2[k]).float()
+        assert float(d_.norm()) <= 2e-2 * float(grads[k].float().norm()) or float(d_.abs().max()) <= 1e-3 * gmax, k
+    side_was = rfnet.SIDE_BRANCHES
+    rfnet.SIDE_BRANCHES = False
+    try:
+        o_a, l_a, g_a = step(x)
+        o_b, l_b, g_b = step(x2)
+    finally:
+        rfnet.SIDE_BRANCHES = side_was
+    assert all(torch.equal(a, b) for a, b in zip(o_a, o_b)) and torch.equal(l_a, l_b)
+    assert all(torch.equal(g_a[k], g_b[k]) for k in g_a)
     # twice the loss -> twice the gradients (to bf16 / fixed-point rounding on the bulk of every checked tensor)
     _, _, g2x = step(x, scale=2.0)
     for k in ("flair_encoder.e1_c1.conv.weight", "decoder_fuse.RFM1.region_fusion.fusion_layer.0.conv.weight", "decoder_sep.d1_c2.conv.weight",

@@ -1,5 +1,5 @@
-cd _wt
-for i in 1 2 3 4 5 6; do
+for i in 1 2 3 4; do
     r=$(python -m pytest tests/test_fullsize_gpu.py -q -x -k rfnet_128 2>&1 | tail -1)
-    echo "round5 tree : $r"
-done > ../gpurun_out/e1.txt 2>&1
+    echo "rfnet test : $r"
+done > gpurun_out/e1.txt 2>&1
+python -m pytest tests/test_fullsize_gpu.py tests/test_rfnet_gpu.py -q 2>&1 | tail -2 >> gpurun_out/e1.txt
