@@ -1024,45 +1024,47 @@ struct PackEnt { const float* w; float* out; int Cin, Cout, ntap, pad_; };
 struct PackTable { PackEnt e[PACK_MAX]; };
 
 __global__ __launch_bounds__(256) void pack_multi_kernel(PackTable t) {
+    // 32-bit index arithmetic throughout (an image has < 2^31 elements: checked by the launcher): the 64-bit divisions by run-time
+    // values of the first version were the kernel -- 105 us for the 24 M elements of the four encoders' images behind the closing
+    // optimizer pass, on the critical stream
     const PackEnt& q = t.e[blockIdx.y];
-    const int Cin = q.Cin, Cout = q.Cout, ntap = q.ntap;
-    const int CoutPad = pad16(Cout), CinPad = pad16(Cin);
-    const long nf = (long)ntap * Cin * CoutPad, nd = (long)ntap * Cout * CinPad;        // f32 images
-    const int ci8 = pad8(Cin), co8 = pad8(Cout);
-    const long bf = (long)ntap * ci8 * CoutPad, bd = (long)ntap * co8 * CinPad;         // bf16 images (follow the f32 ones)
+    const unsigned Cin = q.Cin, Cout = q.Cout, ntap = q.ntap;
+    const unsigned CoutPad = pad16(Cout), CinPad = pad16(Cin);
+    const unsigned nf = ntap * Cin * CoutPad, nd = ntap * Cout * CinPad;        // f32 images
+    const unsigned ci8 = pad8(Cin), co8 = pad8(Cout);
+    const unsigned bf = ntap * ci8 * CoutPad, bd = ntap * co8 * CinPad;         // bf16 images (follow the f32 ones)
     float* fwd = q.out;
     float* dg = q.out + nf;
     bf16_t* bfwd = reinterpret_cast<bf16_t*>(q.out + nf + nd);
     bf16_t* bdg = bfwd + bf;
     const float* w = q.w;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nf + nd + bf + bd; i += (long)gridDim.x * blockDim.x) {
+    const unsigned total = nf + nd + bf + bd;
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
         if (i < nf) {                       // [tap][Cin][CoutPad]
-            const int co = (int)(i % CoutPad);
-            const int ci = (int)((i / CoutPad) % Cin);
-            const int tap = (int)(i / ((long)CoutPad * Cin));
-            fwd[i] = (co < Cout) ? w[((long)co * Cin + ci) * ntap + tap] : 0.f;
+            const unsigned co = i % CoutPad, r = i / CoutPad;
+            const unsigned ci = r % Cin, tap = r / Cin;
+            fwd[i] = (co < Cout) ? w[(co * Cin + ci) * ntap + tap] : 0.f;
         } else if (i < nf + nd) {           // [tap][Cout][CinPad]
-            const long k = i - nf;
-            const int ci = (int)(k % CinPad);
-            const int co = (int)((k / CinPad) % Cout);
-            const int tap = (int)(k / ((long)CinPad * Cout));
-            dg[k] = (ci < Cin) ? w[((long)co * Cin + ci) * ntap + tap] : 0.f;
+            const unsigned k = i - nf;
+            const unsigned ci = k % CinPad, r = k / CinPad;
+            const unsigned co = r % Cout, tap = r / Cout;
+            dg[k] = (ci < Cin) ? w[(co * Cin + ci) * ntap + tap] : 0.f;
         } else if (i < nf + nd + bf) {      // bf16 [tap][CinPad8/8][CoutPad16][8]
-            const long k = i - nf - nd;
-            const int e = (int)(k % 8);
-            const int co = (int)((k / 8) % CoutPad);
-            const int cb = (int)((k / (8L * CoutPad)) % (ci8 / 8));
-            const int tap = (int)(k / (8L * CoutPad * (ci8 / 8)));
-            const int ci = cb * 8 + e;
-            bfwd[k] = (bf16_t)((co < Cout && ci < Cin) ? w[((long)co * Cin + ci) * ntap + tap] : 0.f);
+            const unsigned k = i - nf - nd;
+            const unsigned e = k & 7u, r = k >> 3;
+            const unsigned co = r % CoutPad, r2 = r / CoutPad;
+            const unsigned nb = ci8 >> 3;
+            const unsigned cb = r2 % nb, tap = r2 / nb;
+            const unsigned ci = cb * 8 + e;
+            bfwd[k] = (bf16_t)((co < Cout && ci < Cin) ? w[(co * Cin + ci) * ntap + tap] : 0.f);
         } else {                            // bf16 [tap][CoutPad8/8][CinPad16][8]
-            const long k = i - nf - nd - bf;
-            const int e = (int)(k % 8);
-            const int ci = (int)((k / 8) % CinPad);
-            const int cb = (int)((k / (8L * CinPad)) % (co8 / 8));
-            const int tap = (int)(k / (8L * CinPad * (co8 / 8)));
-            const int co = cb * 8 + e;
-            bdg[k] = (bf16_t)((co < Cout && ci < Cin) ? w[((long)co * Cin + ci) * ntap + tap] : 0.f);
+            const unsigned k = i - nf - nd - bf;
+            const unsigned e = k & 7u, r = k >> 3;
+            const unsigned ci = r % CinPad, r2 = r / CinPad;
+            const unsigned nb = co8 >> 3;
+            const unsigned cb = r2 % nb, tap = r2 / nb;
+            const unsigned co = cb * 8 + e;
+            bdg[k] = (bf16_t)((co < Cout && ci < Cin) ? w[(co * Cin + ci) * ntap + tap] : 0.f);
         }
     }
 }
@@ -1075,6 +1077,7 @@ extern "C" int passion_conv_pack_weights(int n, const float* const* weights, con
         for (int i = 0; i < m; ++i) {
             const int ks = ksize[i0 + i];
             if (ks != 1 && ks != 3) return -1002;
+            if (4L * ks * ks * ks * pad16(Cin[i0 + i]) * pad16(Cout[i0 + i]) >= (1L << 31)) return -1002;      // 32-bit indices in the kernel
             t.e[i] = PackEnt{weights[i0 + i], packed[i0 + i], Cin[i0 + i], Cout[i0 + i], ks * ks * ks, 0};
         }
         hipLaunchKernelGGL(pack_multi_kernel, dim3(192, m), dim3(256), 0, (hipStream_t)stream, t);
