@@ -746,8 +746,20 @@ __global__ __launch_bounds__(256) void pw_fold_sample_kernel(const float* __rest
     const long i = (long)(second ? blockIdx.x - xa : blockIdx.x) * 16 + li;
     const float* pb = part + (long)blockIdx.y * R * stride;
     float a = 0.f;
-    if (i < n)
-        for (int r = sl; r < R; r += 16) a += pb[(long)r * stride + i];
+    if (i < n) {
+        // eight loads in flight per thread, added in slot order (the sum's bits are those of the one-at-a-time loop: with up to 2048
+        // slots per sample -- a batch-1 launch of the streaming weight gradient -- that loop was a chain of 128 memory latencies,
+        // 35-50 us on the main stream for 1.2 MB)
+        int r = sl;
+        for (; r + 7 * 16 < R; r += 8 * 16) {
+            float t[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t[u] = pb[(long)(r + 16 * u) * stride + i];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a += t[u];
+        }
+        for (; r < R; r += 16) a += pb[(long)r * stride + i];
+    }
     red[sl][li] = a;
     __syncthreads();
     if (sl == 0 && i < n) {
