@@ -722,7 +722,13 @@ int launch_march_one(ConvK& k, hipStream_t st) {
     // D segments: about g_conv_target workgroups per launch, at least 8 output planes per segment (2 halo planes each)
     int nseg = (int)hmax(1, (g_conv_target + (long)k.B * tiles - 1) / ((long)k.B * tiles));
     static const int min_planes = []() { const char* e = getenv("PASSION_MARCH_PLANES"); return e && atoi(e) > 0 ? atoi(e) : 16; }();
+    const int nseg_want = nseg;
     nseg = (int)hmin(nseg, hmax(1, dcount / min_planes));
+    // a launch that would leave CUs without a workgroup (one 64^3 sample: 32 tiles x 4 segments = 128 workgroups, each a chain of 19
+    // planes) takes segments of 8 planes instead (round 6; PASSION_MARCH_FILL=0: off): 54 -> ~35 us for the batch-1 input gradients of
+    // the fusion decoder's level 2, which run alone on the main stream
+    static const bool fill = []() { const char* e = getenv("PASSION_MARCH_FILL"); return !(e && e[0] == '0'); }();
+    if (fill && (long)k.B * tiles * nseg < 256) nseg = (int)hmin(nseg_want, hmax(nseg, hmin(dcount / 8, (255 + (long)k.B * tiles) / ((long)k.B * tiles))));
     if (MODE == 2 && !fin) nseg = (int)hmin(nseg, hmax(1, SUMS_SLOTS / tiles));      // one sums slot per workgroup of a sample
     mp.planes_per_seg = (dcount + nseg - 1) / nseg;
     mp.nseg_d = (dcount + mp.planes_per_seg - 1) / mp.planes_per_seg;

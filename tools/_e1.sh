@@ -1,1 +1,1 @@
-REPS=3 STEPS=60 bash tools/ab_graph.sh "p_base:X=1" "p_mainhi:PASSION_GRAPH_PRIO=-1" "p_mainhi_p1hi:PASSION_GRAPH_PRIO=-1 PASSION_SIDE_PRIO=0,-1" "p_sephi:PASSION_SIDE_PRIO=-1,0" -- --workload mmformer128_passion > gpurun_out/e1.txt 2>&1
+REPS=4 STEPS=100 bash tools/ab_graph.sh "fill1:X=1" "fill0:PASSION_MARCH_FILL=0" > gpurun_out/e1.txt 2>&1
