@@ -68,7 +68,13 @@ struct WMarchP {
 // [x_hat[vox + tap][ci] > 0] goes to the slab p.spos.  With it the InstanceNorm-backward means of the layer follow from this
 // weight gradient (march_ident_kernel below; conv_pw.hip has the identities) and the input-gradient kernel writes dx itself.
 template <int DBG, bool IND>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(IND ? 3 : 4, IND ? 3 : 4))) void wgrad_march_kernel(ConvK p, WMarchP mp, float* __restrict__ dW, float* __restrict__ dbias) {
+#ifndef WM_IND_WAVES
+#define WM_IND_WAVES 2      // (round 6: 148 -> 134 us at 8 -> 8, 263 -> 228 at 16 -> 8 over 4 x 128^3 against three waves per SIMD: the 19 fragments of a plane in flight instead of a third of them; one wave: 199 / 346)
+#endif
+#ifndef WM_WAVES
+#define WM_WAVES 4
+#endif
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(IND ? WM_IND_WAVES : WM_WAVES, IND ? WM_IND_WAVES : WM_WAVES))) void wgrad_march_kernel(ConvK p, WMarchP mp, float* __restrict__ dW, float* __restrict__ dbias) {
     wgrad_clear(p);
     __shared__ __attribute__((aligned(16))) char lds[LDS_BYTES + (IND ? XBYTES : 0)];
     char* const lx = lds;
