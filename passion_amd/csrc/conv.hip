@@ -841,7 +841,12 @@ WgPlan plan_wgrad(const ConvK& k, const passion_conv_desc_t* d) {
     // (measured per layer, weight gradient + the finish launch that folds its slab, 4 samples: 64 -> 64 over 16^3: 56.1 us at 1024 workgroups,
     // 42.7 at 512, 40.0 at 256, 47.3 at 128; 128 -> 128 over 8^3: 39.2 / 39.2 / 34.4; 32 -> 32 over 32^3: 62.8 / 54.6 / 58.3 / 75.9)
     static const long wg_small = []() { const char* e = getenv("PASSION_WGRAD_WGS_SMALL"); return e && atol(e) > 0 ? atol(e) : 0L; }();
-    const long wg_target = total <= 512 ? (wg_small ? wg_small : (total <= 64 ? 256L : 512L)) : 1024L;
+    // the finest level's 3x3x3 layers with >= 4 M voxels (the marching weight gradient with its indicator slab, two workgroups per CU):
+    // 512 workgroups are ONE resident round (4 x 128^3, round 6: 8 -> 8 105.9 us against 115.7 at 1024, 16 -> 8 183.9 against 194.5;
+    // 768: 204 / 295 -- the (tile, D segment) units do not divide; 1536: 155 / 318; 2048: 133 / 212), and half the slab to fold
+    static const long wg_big = []() { const char* e = getenv("PASSION_WGRAD_WGS"); return e && atol(e) > 0 ? atol(e) : 0L; }();
+    const bool finest = d->ksize == 3 && d->stride == 1 && k.Cout == 8 && k.Cin <= 16 && (long)k.B * k.Di * k.Hi * k.Wi >= (1L << 22);
+    const long wg_target = total <= 512 ? (wg_small ? wg_small : (total <= 64 ? 256L : 512L)) : (wg_big ? wg_big : (finest && w.bf16 ? 512L : 1024L));
     w.gx = (int)hmin(total, hmax(1, wg_target / w.gy));
     // 1x1x1 on the streaming kernel (conv_wgrad_pw.hip): one workgroup handles every input block of its voxels, so the launch has gx
     // workgroups, not gx x gy -- give it the whole target
@@ -854,7 +859,7 @@ WgPlan plan_wgrad(const ConvK& k, const passion_conv_desc_t* d) {
     // a whole number of slots per sample: the finish-free backward folds the slab per sample (march_ident_kernel, pw_ident_kernel); 1024
     // slots over the 5- and 10-sample virtual batches of the PASSION passes kept those launches on the dgrad + finish path
     // (only where that path can run: the weight gradients of every other launch keep their slot count -- and their f32 summation order)
-    if (w.gx > k.B && d->ksize == 3 && d->stride == 1 && k.Cout == 8 && k.Cin <= 16 && (long)k.B * k.Di * k.Hi * k.Wi >= (1L << 22)) w.gx -= w.gx % k.B;
+    if (w.gx > k.B && finest) w.gx -= w.gx % k.B;
     return w;
 }
 

@@ -74,6 +74,15 @@ template <int DBG, bool IND>
 #ifndef WM_WAVES
 #define WM_WAVES 4
 #endif
+#ifndef WM_EARLY
+#define WM_EARLY 0          // a K plane's LDS reads and register-operand MFMAs ahead of the iteration's commit in program order
+#endif
+#ifndef WM_IND_DBG
+#define WM_IND_DBG 0        // developer timing builds of the indicator kernel (tools/build_variant.sh): the DBG bits below
+#endif
+#ifndef WM_CARRY
+#define WM_CARRY -1         // plane tiles carried in registers from one K plane to the next (below): -1 = the indicator kernel only, 0 / 1 = none / all
+#endif
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(IND ? WM_IND_WAVES : WM_WAVES, IND ? WM_IND_WAVES : WM_WAVES))) void wgrad_march_kernel(ConvK p, WMarchP mp, float* __restrict__ dW, float* __restrict__ dbias) {
     wgrad_clear(p);
     __shared__ __attribute__((aligned(16))) char lds[LDS_BYTES + (IND ? XBYTES : 0)];
@@ -146,7 +155,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(IND ? WM_IN
     const int h = pq >> 1;
     const int xlane = (row * XRW + col) * 16 + (pq & 1) * 8;
     const int xlaneA = xlane + h * 16, xlaneB = xlane + h * (XRW * 16);
+    constexpr bool CARRY = WM_CARRY < 0 ? IND : (WM_CARRY != 0);
     f32x4 acc[NT], acc2[IND ? NT : 1];
+    bf16x8 bprev[4], iprev[IND ? 4 : 1];              // plane P - 1's four in-plane tiles, carried from the plane before
 #pragma unroll
     for (int j = 0; j < NT; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -236,27 +247,51 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(IND ? WM_IN
                 }
             }
         };
-        auto compute = [&](int sp, int scur) {           // ring slots of plane P - 1 and of plane P
-            const char* ya = ly + yoff + (yprev ? sp : scur) * YSLOT;
-            const bf16x8 a = tr_read8(ya, ya + 64);
-            const int x4 = xlane + tapoff(8) + (h ? scur : sp) * XSLOT;
+        // Column tiles 0..3 of a K plane (plane P - 1's in-plane tap pairs) are the fragments tiles 5..8 read one plane earlier (same
+        // lanes, same addresses, the slot that was `scur` then): they stay in registers (round 6) -- 22 transposing reads per plane
+        // and wave instead of 38 (12 instead of 20 without the indicator) on the path that bounds this kernel.
+        auto plane_tile = [&](int jj, int slot) { return jj < 3 ? lx + xlaneA + slot * XSLOT + tapoff(3 * jj) : lx + xlaneB + slot * XSLOT + tapoff(2); };
+        auto load_prev = [&](int slot) {                 // a unit's first plane: nothing was read before it
 #pragma unroll
-            for (int j = 0; j < NT; ++j) {
-                const int pb = (j < 4 ? sp : scur) * XSLOT;
-                const int jj = j < 4 ? j : j - 5;
-                const char* bp = (j == 4) ? lx + x4 : (jj < 3 ? lx + xlaneA + pb + tapoff(3 * jj) : lx + xlaneB + pb + tapoff(2));
-                if ((DBG & 8) && j > 0) bp = lx + xlaneA + sp * XSLOT;
-                const bf16x8 bv = tr_read8(bp, bp + 64);
-                if (DBG & 16) acc[j][0] += (float)bv[0] + (float)a[0];
-                else acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bv, acc[j], 0, 0, 0);
-                if (IND) {
-                    const char* bi = bp + (li - lx);
-                    const bf16x8 iv = tr_read8(bi, bi + 64);
-                    acc2[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, iv, acc2[j], 0, 0, 0);
-                }
+            for (int jj = 0; jj < 4; ++jj) {
+                const char* bp = plane_tile(jj, slot);
+                bprev[jj] = tr_read8(bp, bp + 64);
+                if (IND) { const char* bi = bp + (li - lx); iprev[jj] = tr_read8(bi, bi + 64); }
             }
         };
-
+        // One K plane in three parts (round 6), so that what does not depend on this iteration's commit is in the instruction stream
+        // BEFORE it: the commit is VALU work behind execution-mask branches (basic-block boundaries the scheduler does not move
+        // LDS reads or MFMAs across), and its latency used to sit in front of the reads of every plane.
+        bf16x8 fa, fb[NT - 4], fi[IND ? NT - 4 : 1];
+        auto compute_reads = [&](int sp, int scur) {     // ring slots of plane P - 1 and of plane P: both committed before this barrier
+            const char* ya = ly + yoff + (yprev ? sp : scur) * YSLOT;
+            fa = tr_read8(ya, ya + 64);
+            const int x4 = xlane + tapoff(8) + (h ? scur : sp) * XSLOT;
+#pragma unroll
+            for (int j = (CARRY ? 4 : 0); j < NT; ++j) {
+                const int jj = j < 4 ? j : j - 5;
+                const char* bp = (j == 4) ? lx + x4 : plane_tile(jj, j < 4 ? sp : scur);
+                if ((DBG & 8) && j > 0) bp = lx + xlaneA + sp * XSLOT;
+                if (j < 4) { bprev[j] = tr_read8(bp, bp + 64); if (IND) { const char* bi = bp + (li - lx); iprev[j] = tr_read8(bi, bi + 64); } }
+                else { fb[j - 4] = tr_read8(bp, bp + 64); if (IND) { const char* bi = bp + (li - lx); fi[j - 4] = tr_read8(bi, bi + 64); } }
+            }
+        };
+        auto mma = [&](int j, const bf16x8& bv, const bf16x8& iv) {
+            if (DBG & 16) acc[j][0] += (float)bv[0] + (float)fa[0];
+            else acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, bv, acc[j], 0, 0, 0);
+            if (IND) acc2[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, iv, acc2[j], 0, 0, 0);
+        };
+        auto compute_prev = [&]() {                      // tiles 0..3: operands in registers since the plane before
+#pragma unroll
+            for (int j = 0; j < 4; ++j) mma(j, bprev[j], iprev[IND ? j : 0]);
+        };
+        auto compute_new = [&]() {
+#pragma unroll
+            for (int j = 4; j < NT; ++j) {
+                mma(j, fb[j - 4], fi[IND ? j - 4 : 0]);
+                if (j > 4) { bprev[j - 5] = fb[j - 4]; if (IND) iprev[j - 5] = fi[j - 4]; }
+            }
+        };
         // ---- pipeline.  iteration j: barrier; commit stage j; fetch stage j + NSL; compute K plane c = j - 2 from stages j - 2 and
         // j - 1, both committed before this barrier (slot j & 3 held stage j - 4, last read in iteration j - 2).  The body has no
         // branch around a load or an MFMA: dead iterations past the unit load clamped planes, commit ZERO dY planes and so add
@@ -269,15 +304,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(IND ? WM_IN
             __syncthreads();
             if (!(DBG & 32)) commit(j, j);
             fetch(j, j + NSL);
+            if (j == 1 && CARRY) load_prev(0);     // stage 0 is behind this iteration's barrier
         }
         for (int j0 = 2; j0 <= nstage; j0 += NSL) {
 #pragma unroll
             for (int jj = 0; jj < NSL; ++jj) {
                 const int j = j0 + jj, u = (2 + jj) % NSL;
                 __syncthreads();
+                if (!(DBG & 2) && WM_EARLY) { compute_reads((u + 2) % NSL, (u + 3) % NSL); compute_prev(); }
                 if (!(DBG & 32)) commit(u, j);
                 fetch(u, j + NSL);
-                if (!(DBG & 2)) compute((u + 2) % NSL, (u + 3) % NSL);
+                if (!(DBG & 2) && !WM_EARLY) { compute_reads((u + 2) % NSL, (u + 3) % NSL); compute_prev(); }
+                if (!(DBG & 2)) compute_new();
             }
         }
     }
@@ -638,7 +676,7 @@ int launch_wgrad_march(ConvK& k, int ksize, int stride, int MT, int gx, int gy, 
     }
     if (k.spos) {                  // finish-free backward (conv.hip: march_final): the indicator slab rides along
         passion_prof_tag("wgrad_march_kernel<0, 1>");
-        hipLaunchKernelGGL((wgrad_march_kernel<0, true>), dim3(gx, gy), dim3(256), 0, st, k, mp, dW, db);
+        hipLaunchKernelGGL((wgrad_march_kernel<WM_IND_DBG, true>), dim3(gx, gy), dim3(256), 0, st, k, mp, dW, db);
         LAUNCH_RET();
         return 0;
     }
