@@ -74,9 +74,6 @@ template <int DBG, bool IND>
 #ifndef WM_WAVES
 #define WM_WAVES 4
 #endif
-#ifndef WM_EARLY
-#define WM_EARLY 0          // a K plane's LDS reads and register-operand MFMAs ahead of the iteration's commit in program order
-#endif
 #ifndef WM_IND_DBG
 #define WM_IND_DBG 0        // developer timing builds of the indicator kernel (tools/build_variant.sh): the DBG bits below
 #endif
@@ -225,13 +222,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(IND ? WM_IN
                         for (int c = 0; c < 4; ++c) {      // bf16 pairs -> f32: low half = even channel
                             const f32x2 xv = {__uint_as_float(ra[u][c] << 16), __uint_as_float(ra[u][c] & 0xffff0000u)};
                             f32x2 t = __builtin_elementwise_fma(xv, sc[c], sh[c]);
-                            if (IND) oi[c] = (t.x > 0.f ? 0x3f80u : 0u) | (t.y > 0.f ? 0x3f800000u : 0u);
                             const f32x2 ts = t * slope2;   // LeakyReLU for 0 <= slope <= 1: max(t, slope t)
                             t.x = fmaxf(t.x, ts.x);
                             t.y = fmaxf(t.y, ts.y);
                             ob[2 * c] = (__bf16)t.x; ob[2 * c + 1] = (__bf16)t.y;
                         }
                         o = __builtin_bit_cast(u32x4, ob);
+                        if (IND) {                     // x_hat > 0 <=> the activated bf16 value is a positive number: min(max(v, 0), 1) * 0x3f80 on the
+                                                       // packed halves, three instructions per channel pair instead of two compares, two selects and an or
+                                                       // (as instructions: the vector form of this came back as compares and selects; 16 -> 8: 186 -> 181 us)
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) {
+                                unsigned v;
+                                asm("v_pk_max_i16 %0, %1, 0" : "=v"(v) : "v"(o[c]));
+                                asm("v_pk_min_i16 %0, %1, %2" : "=v"(v) : "v"(v), "v"(0x00010001u));
+                                asm("v_pk_mul_lo_u16 %0, %1, %2" : "=v"(oi[c]) : "v"(v), "v"(0x3f803f80u));
+                            }
+                        }
                     }
                 }
                 *reinterpret_cast<u32x4*>(lx + u * XSLOT + xlds) = o;
@@ -259,9 +266,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(IND ? WM_IN
                 if (IND) { const char* bi = bp + (li - lx); iprev[jj] = tr_read8(bi, bi + 64); }
             }
         };
-        // One K plane in three parts (round 6), so that what does not depend on this iteration's commit is in the instruction stream
-        // BEFORE it: the commit is VALU work behind execution-mask branches (basic-block boundaries the scheduler does not move
-        // LDS reads or MFMAs across), and its latency used to sit in front of the reads of every plane.
+        // One K plane: reads, the four tiles whose operands are in registers already, the five new ones.  (Measured and not kept, round 6,
+        // 8 -> 8 over 4 x 128^3 at 106 us: the reads and the register-operand MFMAs ahead of the iteration's commit in program order
+        // -- same time, and 44 against 34 us on the plain kernel; eight planes of loads in flight instead of four: 110; eight waves per
+        // workgroup, four that stage and four that multiply: 150 -- the staging waves alone take 128, 60 without their global loads,
+        // 93 when every load hits the same lines; three waves per SIMD over 768 slots with a three-way depth split: 147.)
         bf16x8 fa, fb[NT - 4], fi[IND ? NT - 4 : 1];
         auto compute_reads = [&](int sp, int scur) {     // ring slots of plane P - 1 and of plane P: both committed before this barrier
             const char* ya = ly + yoff + (yprev ? sp : scur) * YSLOT;
@@ -311,11 +320,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(IND ? WM_IN
             for (int jj = 0; jj < NSL; ++jj) {
                 const int j = j0 + jj, u = (2 + jj) % NSL;
                 __syncthreads();
-                if (!(DBG & 2) && WM_EARLY) { compute_reads((u + 2) % NSL, (u + 3) % NSL); compute_prev(); }
                 if (!(DBG & 32)) commit(u, j);
                 fetch(u, j + NSL);
-                if (!(DBG & 2) && !WM_EARLY) { compute_reads((u + 2) % NSL, (u + 3) % NSL); compute_prev(); }
-                if (!(DBG & 2)) compute_new();
+                if (!(DBG & 2)) { compute_reads((u + 2) % NSL, (u + 3) % NSL); compute_prev(); compute_new(); }
             }
         }
     }
