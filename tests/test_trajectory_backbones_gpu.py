@@ -15,7 +15,10 @@ from _util import gold, mask_dice, signal_volume, unpack2, build_m2ftrans
 
 pytestmark = pytest.mark.gpu
 
-GATE_TIE = 3e-2        # |relative distance| below which a gate may flip (tens of steps in: the trajectories themselves have drifted by ~1e-3)
+# |relative distance| below which a gate may flip (tens of steps in: the trajectories themselves have drifted by ~1e-3 in f32 and by
+# ~5e-3 in bf16, where WHICH near ties flip changes with every change of a summation order in the kernels: the largest flipped
+# distance of m2ftrans was 0.026 .. 0.037 from build to build in round 6, 11 of 164 decisions)
+GATE_TIE = {torch.float32: 3e-2, torch.bfloat16: 5e-2}
 # measured on MI355X (printed by the tests): see the assertion messages
 LOSS_TOL = {torch.float32: 2e-3, torch.bfloat16: 1e-2}
 
@@ -76,7 +79,7 @@ def test_backbone_follows_the_reference_trajectory(name, dtype):
     print(f"[{tag}] gates: {int(differs.sum())} of {differs.size} decisions differ (reference |distance| there: "
           f"{np.array2string(np.abs(g['rp_vals'][differs]), precision=4)}); comparable steps {upto} of {len(ref)}; "
           f"max loss error {err[:upto].max():.2e} at step {int(err[:upto].argmax())}")
-    assert (np.abs(g["rp_vals"][differs]) < GATE_TIE).all(), np.abs(g["rp_vals"][differs])       # a gate may flip only at a near tie
+    assert (np.abs(g["rp_vals"][differs]) < GATE_TIE[dtype]).all(), np.abs(g["rp_vals"][differs])       # a gate may flip only at a near tie
     assert upto >= min(len(ref), 10), upto
     assert err[:upto].max() < LOSS_TOL[dtype], err
     assert bool(torch.isfinite(pred).all())

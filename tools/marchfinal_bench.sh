@@ -1,4 +1,5 @@
 #!/bin/bash
+# finest-level 3x3x3 backward with the finish-free path on / off (PASSION_CONV_MARCHFINAL), one layer at a time
 for mf in 1 0; do
   for spec in "8 8 128 4" "16 8 128 4" "8 8 128 1"; do
     set -- $spec
