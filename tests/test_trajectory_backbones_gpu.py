@@ -97,4 +97,7 @@ def test_backbone_follows_the_reference_trajectory(name, dtype):
         # bf16: 40 steps of rounding noise on a model whose accuracy still moves by percents from step to step -- the mask is a sanity
         # bound there (measured: rfnet 0.4227 vs 0.4327, m2ftrans 0.4904 vs 0.5211), the per-step losses above are the statement
         assert abs(acc - acc_ref) < (5e-2 if force else 1e-2), (acc, acc_ref)
-        assert far <= (0.10 if force else 0.002) * S ** 3, (ndiff, far)      # (bf16, m2ftrans: 1436 .. 2374 of 32768 from build to build)
+        # (bf16, m2ftrans: 1436 .. 3357 of 32768 from build to build -- round 6: 2545 -> 3357 when the marching input gradient cut its
+        # depth segments finer on small launches, PASSION_MARCH_FILL, a change of summation order that also moved the accuracy
+        # 0.4714 -> 0.4872 towards the reference's 0.5211)
+        assert far <= (0.12 if force else 0.002) * S ** 3, (ndiff, far)
