@@ -82,6 +82,7 @@ struct MarchP {
     int nseg_d, planes_per_seg;    // D segments per tile and output planes per segment
     int tilesH, tilesW;
     int nwg_b;                     // workgroups per sample
+    int edge_first;                // input gradients: face tiles first in dispatch order (needs tilesH, tilesW >= 3)
     int k8;                        // 8-channel blocks of the K axis that exist (<= NB: a 24-channel concat runs as NB = 4 with an empty block)
     unsigned* tickets;             // MODE 2: one zeroed counter per sample (left at zero): the workgroup that arrives last folds the sample's sums slots
 };
@@ -121,9 +122,11 @@ void conv_march_kernel(ConvK p, MarchP mp) {
     const int bx = xcd_swizzle(blockIdx.x, gridDim.x);
     const int b = bx / mp.nwg_b;
     int r = bx % mp.nwg_b;
-    const int tw_i = r % mp.tilesW; r /= mp.tilesW;
-    const int th_i = r % mp.tilesH; r /= mp.tilesH;
+    int tw_i = r % mp.tilesW; r /= mp.tilesW;
+    int th_i = r % mp.tilesH; r /= mp.tilesH;
     const int dseg = r;
+    if (DG && mp.edge_first) face_tiles_first(mp.tilesH, mp.tilesW, th_i, tw_i);      // (conv_common.h)
+    const int slot = (dseg * mp.tilesH + th_i) * mp.tilesW + tw_i;                    // sums / statistics slot: by tile, whatever the dispatch order
     const int h0 = th_i * MTH, w0 = tw_i * TW;
     // output planes [dlo, dhi) in "position" coordinates: MODE 0: 0 .. Sd-1; MODE 2: -1 .. Sd (the padded domain)
     const int dfirst = (DG && !FIN) ? -1 : 0, dcount = (DG && !FIN) ? Sd + 2 : Sd;
@@ -665,7 +668,7 @@ void conv_march_kernel(ConvK p, MarchP mp) {
                             lsum[(3 * MT * 16 + c) * 2 + k2];
             if (DG) {
                 if (c < p.Cin) {
-                    float* rs = p.sums + (long)(bx % mp.nwg_b) * p.B * p.Cin * 2;
+                    float* rs = p.sums + (long)slot * p.B * p.Cin * 2;
                     st_agent(&rs[((long)b * p.Cin + c) * 2 + k2], t);
                 }
             } else {
@@ -674,7 +677,7 @@ void conv_march_kernel(ConvK p, MarchP mp) {
         }
         if (!DG) {
             __syncthreads();
-            fwd_stats_commit(p.fst, p.Cout, b, bx % mp.nwg_b, 0, 16, lsum + 4 * MT * 16 * 2, tid);
+            fwd_stats_commit(p.fst, p.Cout, b, slot, 0, 16, lsum + 4 * MT * 16 * 2, tid);
         } else if (mp.tickets) {
             // The sample's slots are folded HERE, by the workgroup that takes the last ticket (fixed slot order, in double: the sums
             // repeat bit for bit), into slot 0: the finish kernel reads one replica and the separate fold launch (14 per step) is gone.
@@ -720,7 +723,10 @@ int launch_march_one(ConvK& k, hipStream_t st) {
     const int dcount = (MODE == 2 && !fin) ? k.Di + 2 : k.Di;
     const int tiles = mp.tilesH * mp.tilesW;
     // D segments: about g_conv_target workgroups per launch, at least 8 output planes per segment (2 halo planes each)
-    int nseg = (int)hmax(1, (g_conv_target + (long)k.B * tiles - 1) / ((long)k.B * tiles));
+    // (final form, 16 -> 8 over 4 x 128^3 with the face tiles first: 1024 workgroups 180 us, 1536 178, 2048 173, 4096 186)
+    static const long fin_target = []() { const char* e = getenv("PASSION_MARCH_FIN_TARGET"); return e && atol(e) > 0 ? atol(e) : 2048L; }();
+    const long wg_target = ((fin) && fin_target) ? fin_target : (long)g_conv_target;
+    int nseg = (int)hmax(1, (wg_target + (long)k.B * tiles - 1) / ((long)k.B * tiles));
     static const int min_planes = []() { const char* e = getenv("PASSION_MARCH_PLANES"); return e && atoi(e) > 0 ? atoi(e) : 16; }();
     const int nseg_want = nseg;
     nseg = (int)hmin(nseg, hmax(1, dcount / min_planes));
@@ -733,6 +739,8 @@ int launch_march_one(ConvK& k, hipStream_t st) {
     mp.planes_per_seg = (dcount + nseg - 1) / nseg;
     mp.nseg_d = (dcount + mp.planes_per_seg - 1) / mp.planes_per_seg;
     mp.nwg_b = mp.nseg_d * tiles;
+    static const bool edge_first = []() { const char* e = getenv("PASSION_MARCH_EDGEFIRST"); return !(e && e[0] == '0'); }();
+    mp.edge_first = edge_first && mp.tilesH >= 3 && mp.tilesW >= 3;
     mp.k8 = k.march_k8 > 0 ? k.march_k8 : NB;
     if (fin) {
         if (TW != 16 || NB != 1 || k.Mpad != 16 || k.pad_mode != PASSION_PAD_REFLECT || k.Wi < 32 || k.Hi < 16) return 1;    // (a tile touches one edge per axis at most)

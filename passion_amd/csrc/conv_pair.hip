@@ -71,6 +71,7 @@ struct PairP {
     int nseg_d, planes_per_seg;    // D segments per tile and output planes per segment (even)
     int tilesH, tilesW;
     int nwg_b;                     // workgroups per sample
+    int edge_first;                // input gradients: face tiles first in dispatch order (needs tilesH, tilesW >= 3)
     unsigned* tickets;             // MODE 2: one zeroed counter per sample (left at zero): the workgroup that arrives last folds the sample's sums slots
 };
 
@@ -102,9 +103,11 @@ void conv_pair_kernel(ConvK p, PairP mp) {
     const int bx = xcd_swizzle(blockIdx.x, gridDim.x);
     const int b = bx / mp.nwg_b;
     int r = bx % mp.nwg_b;
-    const int tw_i = r % mp.tilesW; r /= mp.tilesW;
-    const int th_i = r % mp.tilesH; r /= mp.tilesH;
+    int tw_i = r % mp.tilesW; r /= mp.tilesW;
+    int th_i = r % mp.tilesH; r /= mp.tilesH;
     const int dseg = r;
+    if (DG && mp.edge_first) face_tiles_first(mp.tilesH, mp.tilesW, th_i, tw_i);      // (conv_common.h)
+    const int slot = (dseg * mp.tilesH + th_i) * mp.tilesW + tw_i;                    // sums / statistics slot: by tile, whatever the dispatch order
     const int h0 = th_i * MTH, w0 = tw_i * TW;
     // zero-padded convs (the fusion blocks' 3x3x3 conv): the adjoint has no halo outputs -- positions -1 and S of every axis are
     // neither computed nor counted; the finish kernel then reads the interior of the padded scratch only
@@ -512,7 +515,7 @@ void conv_pair_kernel(ConvK p, PairP mp) {
             for (int w = 0; w < 4; ++w) t += lsum[((w * 4 + gq) * 4 + j) * 2 + k2] + lsum[((w * 4 + gq + 2) * 4 + j) * 2 + k2];
             if (DG) {
                 if (c < p.Cin) {
-                    float* rs = p.sums + (long)(bx % mp.nwg_b) * p.B * p.Cin * 2;
+                    float* rs = p.sums + (long)slot * p.B * p.Cin * 2;
                     st_agent(&rs[((long)b * p.Cin + c) * 2 + k2], t);
                 }
             } else {
@@ -521,7 +524,7 @@ void conv_pair_kernel(ConvK p, PairP mp) {
         }
         if (!DG) {
             __syncthreads();
-            fwd_stats_commit(p.fst, p.Cout, b, bx % mp.nwg_b, 0, 8, lsum + 4 * 4 * 4 * 2, tid);
+            fwd_stats_commit(p.fst, p.Cout, b, slot, 0, 8, lsum + 4 * 4 * 4 * 2, tid);
         } else if (mp.tickets) {
             // the sample's slots are folded HERE, by the workgroup that takes the last ticket (fixed slot order, in double: the sums
             // repeat bit for bit), into slot 0: the finish kernel reads one replica
@@ -566,13 +569,15 @@ int launch_pair_one(ConvK& k, hipStream_t st) {
     const int dcount = (MODE == 2 && !nohalo) ? k.Di + 2 : k.Di;          // even (launch_conv_pair)
     const int tiles = mp.tilesH * mp.tilesW;
     // D segments: about g_conv_target workgroups per launch, at least 16 output planes per segment (two halo planes each), an even number
-    int nseg = (int)hmax(1, (g_conv_target + (long)k.B * tiles - 1) / ((long)k.B * tiles));
+    int nseg = (int)hmax(1, (g_conv_target + (long)k.B * tiles - 1) / ((long)k.B * tiles));      // (final form 8 -> 8: 1024 workgroups 122 us, 2048 133)
     static const int min_planes = []() { const char* e = getenv("PASSION_MARCH_PLANES"); return e && atoi(e) > 0 ? atoi(e) : 16; }();
     nseg = (int)hmin(nseg, hmax(1, dcount / min_planes));
     if (MODE == 2 && !k.pwm) nseg = (int)hmin(nseg, hmax(1, SUMS_SLOTS / tiles));      // one sums slot per workgroup of a sample
     mp.planes_per_seg = ((dcount + nseg - 1) / nseg + 1) & ~1;
     mp.nseg_d = (dcount + mp.planes_per_seg - 1) / mp.planes_per_seg;
     mp.nwg_b = mp.nseg_d * tiles;
+    static const bool edge_first = []() { const char* e = getenv("PASSION_MARCH_EDGEFIRST"); return !(e && e[0] == '0'); }();
+    mp.edge_first = edge_first && mp.tilesH >= 3 && mp.tilesW >= 3;
     if (MODE == 2 && k.pwm) {                        // final form (means in k.pwm): reflect padding, statistics on the input
         if (TW != 16 || nohalo || !k.y) return 1;              // (a raw input -- no statistics -- takes the epilogue's `gg` branch: conv.hip raw_done)
         k.pw_done = 2;                               // 2: the shell of the padded scratch still has to be folded (shell_fold_kernel)
