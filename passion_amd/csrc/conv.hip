@@ -819,6 +819,11 @@ static bool lean_f32_head(const ConvK& k, const passion_conv_desc_t* d) {
     return K8 * 8 == k.Cin && K8 <= 32;
 }
 
+// voxels per launch from which the finest 3x3x3 layers take the finish-free backward (option conv_marchfinal = 2).  2^22 until the
+// weight gradient with the indicator slab and the final-form input gradient got faster in round 6; re-measured then: 2 x 10^6 (one
+// 128^3 sample, four 80^3 ones) plain step 9.11 -> 9.03 ms, 80^3 step 5.69 -> 5.58, RFNet +0.8 %, m2ftrans +0.7 %, PASSION +-0;
+// 5 x 10^5 and "wherever it applies" the same to the noise
+static long marchfinal_minvox() { static const long v = []() { const char* e = getenv("PASSION_MARCHFINAL_MINVOX"); return e && atol(e) > 0 ? atol(e) : 2000000L; }(); return v; }
 WgPlan plan_wgrad(const ConvK& k, const passion_conv_desc_t* d) {
     WgPlan w;
     w.bf16 = (d->x_dtype == PASSION_BF16 && d->y_dtype == PASSION_BF16 && bf16_eligible(k, false) && !g_passion_force_f32_mfma) ||
@@ -845,7 +850,7 @@ WgPlan plan_wgrad(const ConvK& k, const passion_conv_desc_t* d) {
     // 512 workgroups are ONE resident round (4 x 128^3, round 6: 8 -> 8 105.9 us against 115.7 at 1024, 16 -> 8 183.9 against 194.5;
     // 768: 204 / 295 -- the (tile, D segment) units do not divide; 1536: 155 / 318; 2048: 133 / 212), and half the slab to fold
     static const long wg_big = []() { const char* e = getenv("PASSION_WGRAD_WGS"); return e && atol(e) > 0 ? atol(e) : 0L; }();
-    const bool finest = d->ksize == 3 && d->stride == 1 && k.Cout == 8 && k.Cin <= 16 && (long)k.B * k.Di * k.Hi * k.Wi >= (1L << 22);
+    const bool finest = d->ksize == 3 && d->stride == 1 && k.Cout == 8 && k.Cin <= 16 && (long)k.B * k.Di * k.Hi * k.Wi >= marchfinal_minvox();
     const long wg_target = total <= 512 ? (wg_small ? wg_small : (total <= 64 ? 256L : 512L)) : (wg_big ? wg_big : (finest && w.bf16 ? 512L : 1024L));
     w.gx = (int)hmin(total, hmax(1, wg_target / w.gy));
     // 1x1x1 on the streaming kernel (conv_wgrad_pw.hip): one workgroup handles every input block of its voxels, so the launch has gx
@@ -1266,7 +1271,7 @@ static int conv3d_bwd_impl(const passion_conv_desc_t* d, const float* packed, co
     // (conv_wgrad_march.hip), per-sample folds + means (march_ident_kernel), then the FOLD-FREE marching input gradient that
     // writes dx itself (conv_march.hip FIN).  No padded scratch volume, no sums, no in_bwd_finish_pad launch.
     if (phase == 0 && parts == 3 && d->ksize == 3 && d->stride == 1 && d->pad_mode == PASSION_PAD_REFLECT &&
-        (pconv::g_conv_marchfinal == 1 || (pconv::g_conv_marchfinal == 2 && (long)k.B * k.Di * k.Hi * k.Wi >= (1L << 22))) &&
+        (pconv::g_conv_marchfinal == 1 || (pconv::g_conv_marchfinal == 2 && (long)k.B * k.Di * k.Hi * k.Wi >= marchfinal_minvox())) &&
         pconv::g_conv_lean && !g_passion_force_f32_mfma && d->x_dtype == PASSION_BF16 && d->y_dtype == PASSION_BF16 && need_dx && need_norm &&
         dweight && sums && k.Cout == 8 && k.Cin <= 16 && !pconv::g_wgrad_fork) {
         bool ok = true;
@@ -1573,7 +1578,7 @@ static int conv3d_bwd_impl(const passion_conv_desc_t* d, const float* packed, co
     // dx themselves; for a raw input their epilogue has no means to apply (k.pwm only has to be readable).
     bool raw_done = false;
     if (phase == 0 && padout && !blockdiag && need_dx && !need_norm && d->ksize == 3 && d->stride == 1 && d->pad_mode == PASSION_PAD_REFLECT &&
-        (pconv::g_conv_marchfinal == 1 || (pconv::g_conv_marchfinal == 2 && (long)k.B * k.Di * k.Hi * k.Wi >= (1L << 22))) &&
+        (pconv::g_conv_marchfinal == 1 || (pconv::g_conv_marchfinal == 2 && (long)k.B * k.Di * k.Hi * k.Wi >= marchfinal_minvox())) &&
         d->x_dtype == PASSION_BF16 && d->y_dtype == PASSION_BF16 && k.Cout == 8 && k.Cin <= 16 && k.Hi % 8 == 0 && k.Wi % 16 == 0 && k.Di >= 8 &&
         k.Hi >= 16 && k.Wi >= 32) {
         bool ok = true;
