@@ -743,7 +743,7 @@ def main():
             # counters cannot be read inside a timed run: the committed rocprofv3 --pmc pass over THIS command (bench.py with this
             # workload: the instantiations and shapes benchmarked here), tools/pmc_attention_bench.sh
             pname = "attention_pmc_bench_passion.json" if passion else "attention_pmc_bench_plain.json"
-            ppath = next((os.path.join(ROOT, "profiles", r + pname) for r in ("r05_", "r04_", "r03_")
+            ppath = next((os.path.join(ROOT, "profiles", r + pname) for r in ("r06_", "r05_", "r04_", "r03_")
                           if os.path.exists(os.path.join(ROOT, "profiles", r + pname))), None)
             if ppath is not None and not is_rfnet:
                 import hashlib
