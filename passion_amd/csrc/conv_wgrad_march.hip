@@ -72,13 +72,14 @@ template <int DBG, bool IND>
 #define WM_IND_WAVES 2      // (round 6: 148 -> 134 us at 8 -> 8, 263 -> 228 at 16 -> 8 over 4 x 128^3 against three waves per SIMD: the 19 fragments of a plane in flight instead of a third of them; one wave: 199 / 346)
 #endif
 #ifndef WM_WAVES
-#define WM_WAVES 4
+#define WM_WAVES 2          // (round 6, with the plane tiles carried in registers: 32 -> 8 over 2 x 128^3 159 -> 138 us, 24 -> 8 206 -> 178, 8 -> 8 at batch 1 and
+                            // 512 slots 35 -> 28; four waves and 128 registers with the carry: 44, without: 35; three waves: 136 / 186 / 32)
 #endif
 #ifndef WM_IND_DBG
 #define WM_IND_DBG 0        // developer timing builds of the indicator kernel (tools/build_variant.sh): the DBG bits below
 #endif
 #ifndef WM_CARRY
-#define WM_CARRY -1         // plane tiles carried in registers from one K plane to the next (below): -1 = the indicator kernel only, 0 / 1 = none / all
+#define WM_CARRY 1          // plane tiles carried in registers from one K plane to the next (below): -1 = the indicator kernel only, 0 / 1 = none / all
 #endif
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(IND ? WM_IND_WAVES : WM_WAVES, IND ? WM_IND_WAVES : WM_WAVES))) void wgrad_march_kernel(ConvK p, WMarchP mp, float* __restrict__ dW, float* __restrict__ dbias) {
     wgrad_clear(p);
@@ -256,7 +257,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(IND ? WM_IN
         };
         // Column tiles 0..3 of a K plane (plane P - 1's in-plane tap pairs) are the fragments tiles 5..8 read one plane earlier (same
         // lanes, same addresses, the slot that was `scur` then): they stay in registers (round 6) -- 22 transposing reads per plane
-        // and wave instead of 38 (12 instead of 20 without the indicator) on the path that bounds this kernel.
+        // and wave instead of 38 (12 instead of 20 without the indicator).
         auto plane_tile = [&](int jj, int slot) { return jj < 3 ? lx + xlaneA + slot * XSLOT + tapoff(3 * jj) : lx + xlaneB + slot * XSLOT + tapoff(2); };
         auto load_prev = [&](int slot) {                 // a unit's first plane: nothing was read before it
 #pragma unroll
