@@ -520,9 +520,20 @@ int launch_s2_march(ConvK& k, hipStream_t st) {
     S2MP mp;
     mp.tilesH = (k.Ho + 1 + SM_TH - 1) / SM_TH; mp.tilesW = (k.Wo + 1 + SM_TW - 1) / SM_TW;
     const int tiles = mp.tilesH * mp.tilesW, dcount = k.Do + 1;
-    int nseg = (int)hmax(1, (g_conv_target + (long)k.B * tiles - 1) / ((long)k.B * tiles));
-    nseg = (int)hmin(nseg, hmax(1, dcount / 8));
-    nseg = (int)hmin(nseg, hmax(1, SUMS_SLOTS / tiles));
+    // D segments: one workgroup per CU is resident (272 registers), so the launch runs in rounds of 256 workgroups and a segment pays two
+    // halo planes: the split that minimises rounds x (planes per segment + 2) among those the target allows (round 6, 4 x 128^3: six
+    // segments = 1080 workgroups = 4.2 rounds 111 us, four = 720 = 2.8 rounds 101; five 109, seven 110, eight 124)
+    static const int s2_nseg = []() { const char* e = getenv("PASSION_S2_NSEG"); return e ? atoi(e) : 0; }();
+    int nseg_max = (int)hmax(1, (g_conv_target + (long)k.B * tiles - 1) / ((long)k.B * tiles));
+    nseg_max = (int)hmin(nseg_max, hmax(1, dcount / 8));
+    nseg_max = (int)hmin(nseg_max, hmax(1, SUMS_SLOTS / tiles));
+    int nseg = 1;
+    long best = -1;
+    for (int n = 1; n <= nseg_max; ++n) {
+        const long rounds = ((long)k.B * tiles * n + 255) / 256, cost = rounds * ((dcount + n - 1) / n + 2);
+        if (best < 0 || cost < best) { best = cost; nseg = n; }
+    }
+    if (s2_nseg > 0) nseg = (int)hmin(s2_nseg, nseg_max);
     mp.planes_per_seg = (dcount + nseg - 1) / nseg;
     mp.nseg_d = (dcount + mp.planes_per_seg - 1) / mp.planes_per_seg;
     mp.nwg_b = mp.nseg_d * tiles;
