@@ -774,6 +774,8 @@ int launch_conv_bf16(ConvK& k, int ksize, int stride, bool dgrad, const void* pa
         if (rc <= 0) return rc;
         rc = launch_conv_c1_fwd(k, ksize, stride, packed_bf16, st);
         if (rc <= 0) return rc;
+        rc = launch_conv_s2f(k, ksize, stride, packed_bf16, st);      // first stride-2 layer (8 -> 16): marching kernel (conv_s2_fwd.hip)
+        if (rc <= 0) return rc;
     }
     if (g_conv_lean) {                       // lean persistent kernel for the stride-1, 8-channel-aligned shapes
         const int rc = launch_conv_lean(k, ksize, stride, dgrad ? 1 : 0, packed_bf16, st);

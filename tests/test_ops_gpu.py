@@ -1174,6 +1174,64 @@ def test_first_layer_weight_gradient(B, shape, pad_mode):
     assert torch.equal(first, wd.grad)                     # fixed-order fold: bit-reproducible
 
 
+@pytest.mark.parametrize("norm", [True, False], ids=["prenorm", "raw"])
+@pytest.mark.parametrize("pad_mode", [1, 0], ids=["reflect", "zeros"])
+@pytest.mark.parametrize("shape", [(64, 128, 128), (16, 128, 256), (22, 48, 32), (64, 64, 64), (6, 16, 32), (16, 12, 32)])
+def test_first_stride2_layer_forward_kernel(shape, pad_mode, norm):
+    """conv_s2_fwd.hip (3x3x3, stride 2, 8 -> 16, bf16: the marching forward of e2_c1, reference mmformer.py:40-45): against the f64
+    reference, against the brick kernel it replaces, statistics of the output from the same launch, masked samples, plain and
+    grouped (four weight sets over one stacked batch); shapes it does not take (launches of fewer than 256 workgroups, Ho % 8) stay on the brick kernel"""
+    from passion_amd import ops
+    dev = _dev()
+    D, H, W = shape
+    B = 4
+    g = torch.Generator().manual_seed(23)
+    x = (torch.randn(B, 8, D, H, W, generator=g, dtype=torch.float64) * 1.4 + 0.25).to(torch.bfloat16).double()
+    ws = [torch.randn(16, 8, 3, 3, 3, generator=g, dtype=torch.float64) / (8 * 27) ** 0.5 for _ in range(4)]
+    bs = [torch.randn(16, generator=g, dtype=torch.float64) for _ in range(4)]
+    mask = torch.tensor([[True], [False], [True], [True]])
+    xd, md = cl(x).to(dev, torch.bfloat16), mask.to(dev)
+
+    def ref(wi, bi, samples):
+        return ref_conv_block([x[samples]], [norm], [mask[samples, 0].double()], wi.to(torch.bfloat16).double(), bi, 3, 2, pad_mode, None)
+
+    def seg():
+        return ops.SegIn(xd, stats=ops.instnorm_stats(xd) if norm else None, mask=md, mask_col=0)
+
+    ops.prof_read()
+    ops.prof_enable(1)
+    try:
+        wd, bd = ws[0].float().to(dev), bs[0].float().to(dev)
+        y, st = ops.conv_block([seg()], wd, bd, D, H, W, ksize=3, stride=2, pad_mode=pad_mode, want_stats=True)
+        wg, bg = [w.float().to(dev) for w in ws], [b.float().to(dev) for b in bs]
+        yg, stg = ops.conv_block_grouped([seg()], wg, bg, D, H, W, ksize=3, stride=2, pad_mode=pad_mode, want_stats=True)
+        torch.cuda.synchronize()
+    finally:
+        ops.prof_enable(0)
+    names = [r[4] for r in ops.prof_read()]
+    Do, tiles = D // 2, (H // 16) * (W // 32)
+    marching = (H // 2) % 8 == 0 and (W // 2) % 16 == 0 and Do >= 4 and B * tiles * max(1, min((1024 + B * tiles - 1) // (B * tiles), Do // 8)) >= 256
+    assert names.count("conv_s2f_kernel") == (2 if marching else 0), names
+    tol = TOL[torch.bfloat16]
+    assert relerr(nc(y.float()), ref(ws[0], bs[0], slice(0, B))) < tol
+    for gi in range(4):
+        assert relerr(nc(yg[gi:gi + 1].float()), ref(ws[gi], bs[gi], slice(gi, gi + 1))) < tol
+    assert float(y[1].abs().max()) == float(bs[0].to(torch.bfloat16).abs().max())      # absent modality: the bias alone
+    for yy, ss in ((y, st), (yg, stg)):
+        want = ops.instnorm_stats(yy)
+        std = 1.0 / want[..., 1]
+        assert float(((ss[..., 0] - want[..., 0]).abs() / (std + want[..., 0].abs())).max()) < 2e-5
+        assert float(((ss[..., 1] - want[..., 1]).abs() / want[..., 1]).max()) < 1e-4
+    old = ops.set_option("conv_s2f", 0)
+    try:
+        y0 = ops.conv_block([seg()], wd, bd, D, H, W, ksize=3, stride=2, pad_mode=pad_mode)
+    finally:
+        ops.set_option("conv_s2f", old)
+    # same bf16 products, f32 sums in another order: at most one bf16 ulp apart
+    assert relerr(y.float(), y0.float().double()) < 1e-2
+    assert float((y.float() - y0.float()).abs().mean()) < 2e-3
+
+
 @pytest.mark.parametrize("pad_mode", [1, 0], ids=["reflect", "zeros"])
 @pytest.mark.parametrize("shape", [(20, 16, 32), (5, 32, 16), (10, 24, 128), (6, 8, 64)])
 def test_first_layer_forward_kernel(shape, pad_mode):
