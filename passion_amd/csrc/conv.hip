@@ -1386,7 +1386,10 @@ static int conv3d_bwd_impl(const passion_conv_desc_t* d, const float* packed, co
         // the first layer (Cin = 1) on the matrix cores: slots in sample order, so a grouped launch is one launch + one fold too
         const bool c1m = w.bf16 && d->x_dtype == PASSION_BF16 && d->y_dtype == PASSION_BF16 && !g_passion_force_f32_mfma && pconv::g_conv_lean &&
                          dweight && pconv::wgrad_c1m_covers(k, d->ksize, d->stride, w.gx);
-        const bool direct_slots = grouped_general || c1m;        // slab slots dealt to the weight sets in equal runs
+        // the first stride-2 layer (8 -> 16) on its marching kernel (conv_s2_wgrad.hip): slots in sample order as well
+        const bool s2m = !c1m && w.bf16 && d->x_dtype == PASSION_BF16 && d->y_dtype == PASSION_BF16 && !g_passion_force_f32_mfma && pconv::g_conv_lean &&
+                         dweight && (!ga || grouped_general) && pconv::wgrad_s2m_covers(k, d->ksize, d->stride, w.gx);
+        const bool direct_slots = grouped_general || c1m || s2m;        // slab slots dealt to the weight sets in equal runs
         const long nW = (long)k.Cout * k.Cin * nt;
         k.wslot = nW + k.Cout;                       // one slot = [dW | dbias] of one workgroup
         float* wslab = sums + (long)2 * k.B * k.Cin * SUMS_SLOTS;
@@ -1404,6 +1407,9 @@ static int conv3d_bwd_impl(const passion_conv_desc_t* d, const float* packed, co
             defer_next_wgrad() = pair_ok;
             if (c1m) {
                 rc = launch_wgrad_c1m(k, d->ksize, d->stride, w.gx, dWs, dbs, st);
+                if (rc > 0) rc = -1014;
+            } else if (s2m) {
+                rc = launch_wgrad_s2m(k, d->ksize, d->stride, w.gx, dWs, dbs, st);
                 if (rc > 0) rc = -1014;
             } else if (ga && grouped_general) {      // grouped stride-2 layers: the general bf16 kernel, slots dealt to the sets in equal runs
                 rc = launch_wgrad_bf16(k, d->ksize, d->stride, w.MT, w.gx, w.gy, dWs, dbs, st);

@@ -157,6 +157,9 @@ int launch_conv_c1m_fwd(ConvK& k, int ksize, int stride, const void* packed_bf16
 extern int g_c1_mfma;
 int launch_conv_s2f(ConvK& k, int ksize, int stride, const void* packed_bf16, hipStream_t st);                         // conv_s2_fwd.hip: marching forward of the 8 -> 16 stride-2 conv
 extern int g_conv_s2f;
+bool wgrad_s2m_covers(const ConvK& k, int ksize, int stride, int gx);                                                   // conv_s2_wgrad.hip: its marching weight gradient
+int launch_wgrad_s2m(ConvK& k, int ksize, int stride, int gx, float* dWslab, float* dbslab, hipStream_t st);
+extern int g_wgrad_s2m;
 extern int g_conv_lean;
 int launch_wgrad_bf16(ConvK& k, int ksize, int stride, int MT, int gx, int gy, float* dWslab, float* dbslab, hipStream_t st);
 int wgrad_bf16_chunk(const ConvK& k, int ksize, int stride);

@@ -1176,6 +1176,75 @@ def test_first_layer_weight_gradient(B, shape, pad_mode):
 
 @pytest.mark.parametrize("norm", [True, False], ids=["prenorm", "raw"])
 @pytest.mark.parametrize("pad_mode", [1, 0], ids=["reflect", "zeros"])
+@pytest.mark.parametrize("shape", [(32, 128, 128), (16, 128, 256), (26, 128, 160)])
+def test_first_stride2_layer_weight_gradient(shape, pad_mode, norm):
+    """wgrad_s2m_kernel (conv_s2_wgrad.hip: 3x3x3, stride 2, 8 -> 16, bf16, launches of >= 2^18 output voxels): weight and bias gradient
+    against autograd in float64, against the brick kernel it replaces (the same bf16 products, another order of the f32 sums), a masked
+    sample, bit-reproducible, and a grouped launch (four weight sets over the stacked batch) against the sets one by one"""
+    from passion_amd import ops
+    dev = _dev()
+    D, H, W = shape
+    B = 4
+    g = torch.Generator().manual_seed(29)
+    x = (torch.randn(B, 8, D, H, W, generator=g, dtype=torch.float64) * 1.4 + 0.25).to(torch.bfloat16).double()
+    ws = [torch.randn(16, 8, 3, 3, 3, generator=g, dtype=torch.float64) / (8 * 27) ** 0.5 for _ in range(4)]
+    bs = [torch.randn(16, generator=g, dtype=torch.float64) for _ in range(4)]
+    mask = torch.tensor([[True], [False], [True], [True]])
+    gy = torch.randn(B, 16, D // 2, H // 2, W // 2, generator=g, dtype=torch.float64).to(torch.bfloat16).double()
+    wr, br = ws[0].to(torch.bfloat16).double().requires_grad_(True), bs[0].clone().requires_grad_(True)
+    ref_conv_block([x], [norm], [mask[:, 0].double()], wr, br, 3, 2, pad_mode, None).backward(gy)
+    xd, md, gyd = cl(x).to(dev, torch.bfloat16), mask.to(dev), cl(gy).to(dev, torch.bfloat16)
+
+    def seg(sl=slice(None)):
+        xs = xd[sl]
+        return ops.SegIn(xs, stats=ops.instnorm_stats(xs) if norm else None, mask=md[sl], mask_col=0)
+
+    def run(wi, bi, sl=slice(None)):
+        wd, bd = wi.float().to(dev).requires_grad_(True), bi.float().to(dev).requires_grad_(True)
+        y = ops.conv_block([seg(sl)], wd, bd, D, H, W, ksize=3, stride=2, pad_mode=pad_mode)
+        y.backward(gyd[sl])
+        torch.cuda.synchronize()
+        return wd.grad.clone(), bd.grad.clone()
+
+    ops.prof_read()
+    ops.prof_enable(15)
+    try:
+        dW1, db1 = run(ws[0], bs[0])
+    finally:
+        ops.prof_enable(0)
+    names = [r[4] for r in ops.prof_read()]
+    assert "wgrad_s2m_kernel" in names, names
+    tol = TOL[torch.bfloat16] if norm else 1e-5           # (raw input: the bf16 operands are the reference's own)
+    assert relerr(dW1, wr.grad) < tol, relerr(dW1, wr.grad)
+    assert relerr(db1, br.grad) < 1e-5
+    dW2, db2 = run(ws[0], bs[0])
+    assert torch.equal(dW1, dW2) and torch.equal(db1, db2)  # fixed-order fold: bit-reproducible
+    old = ops.set_option("wgrad_s2m", 0)
+    try:
+        dW0, db0 = run(ws[0], bs[0])
+    finally:
+        ops.set_option("wgrad_s2m", old)
+    assert relerr(dW1, dW0.double()) < 1e-4 and relerr(db1, db0.double()) < 1e-5
+    # grouped: sample g under weight set g
+    wg = [w.float().to(dev).requires_grad_(True) for w in ws]
+    bg = [b.float().to(dev).requires_grad_(True) for b in bs]
+    ops.prof_enable(15)
+    try:
+        yg = ops.conv_block_grouped([seg()], wg, bg, D, H, W, ksize=3, stride=2, pad_mode=pad_mode)
+        yg.backward(gyd)
+        torch.cuda.synchronize()
+    finally:
+        ops.prof_enable(0)
+    assert "wgrad_s2m_kernel" in [r[4] for r in ops.prof_read()]
+    for gi in range(4):
+        dWs, dbs = run(ws[gi], bs[gi], slice(gi, gi + 1))     # (one sample: below the kernel's launch size, the brick kernel)
+        assert relerr(wg[gi].grad, dWs.double()) < 1e-4, gi
+        assert relerr(bg[gi].grad, dbs.double()) < 1e-5, gi
+    assert float(wg[1].grad.abs().max()) == 0.0              # absent modality: no weight gradient, the bias gradient stays
+
+
+@pytest.mark.parametrize("norm", [True, False], ids=["prenorm", "raw"])
+@pytest.mark.parametrize("pad_mode", [1, 0], ids=["reflect", "zeros"])
 @pytest.mark.parametrize("shape", [(64, 128, 128), (16, 128, 256), (22, 48, 32), (64, 64, 64), (6, 16, 32), (16, 12, 32)])
 def test_first_stride2_layer_forward_kernel(shape, pad_mode, norm):
     """conv_s2_fwd.hip (3x3x3, stride 2, 8 -> 16, bf16: the marching forward of e2_c1, reference mmformer.py:40-45): against the f64
