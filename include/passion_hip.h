@@ -68,6 +68,9 @@ typedef struct {
     int32_t bmod;         /* > 0: x (and stats) hold only bmod samples; sample b reads x[b % bmod] -- several masked passes over
                              the same features batched into one launch.  mask stays indexed by b; dx has bmod samples too and
                              receives the SUM of the passes' gradients.  0: plain batch */
+    const void* dx_add;   /* backward only (round 6): a contiguous tensor of dx's shape and dtype that is ADDED into dx -- the gradient that
+                             reached x by another path (the identity branch of x + c3(c2(x)), code/models/mmformer.py:34-38: its sum with
+                             this conv's input gradient then costs no pass of its own).  NULL: none.  Not with bmod > 0 */
 } passion_seg_t;
 
 typedef struct {

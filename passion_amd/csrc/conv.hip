@@ -459,7 +459,8 @@ __global__ __launch_bounds__(256) void shell_fold_kernel(bf16_t* __restrict__ dx
 // voxel, so a launch per segment read every line of it once per segment (the decoders' c1 convs: two 8-channel halves of 32-byte
 // voxels -- 222 us per finish against 98 for the same bytes in one segment); here a block walks its rows segment after segment, the
 // second visit of a line comes from L2.  Segments of one launch have the same channel count (the launcher groups them).
-struct FinSeg { void* dx; const void* x; const float* stats; const uint8_t* mask; long bstride; int C, cbase, mask_col, mask_ld, bmod, coff; };
+struct FinSeg { void* dx; const void* x; const float* stats; const uint8_t* mask; long bstride; int C, cbase, mask_col, mask_ld, bmod, coff;
+                const void* add; };      // add: SegD.dx_add (contiguous [B][V][C]), folded into the write of dx
 struct FinSegs { FinSeg s[PASSION_MAX_SEG]; int n; };
 template <typename T, int VEC>
 __global__ __launch_bounds__(256) void in_bwd_finish_pad_kernel(FinSegs fs, const T* __restrict__ dxp, const float* __restrict__ sums, int D, int H, int W,
@@ -537,6 +538,12 @@ __global__ __launch_bounds__(256) void in_bwd_finish_pad_kernel(FinSegs fs, cons
                         for (int j = 0; j < VEC; ++j)
                             g[j] = own ? __builtin_fmaf(cf[c + j][0], g[j], __builtin_fmaf(cf[c + j][1], xv[j], cf[c + j][2])) : cf[c + j][0] * g[j];
                     }
+                }
+                if (q.add) {                               // the gradient that reached x by another path (the residual branch)
+                    float av[VEC];
+                    VecIO<T, VEC>::load(reinterpret_cast<const T*>(q.add) + (long)b * V * C + e, av);
+#pragma unroll
+                    for (int j = 0; j < VEC; ++j) g[j] += av[j];
                 }
                 vstore_nt<T, VEC>(dxb + e, g, nt_dx);
             }
@@ -766,6 +773,7 @@ int fill_params(const passion_conv_desc_t* d, ConvK& k) {
             const passion_seg_t& i = d->seg[s];
             o.x = i.x; o.stats = i.stats; o.mask = i.mask; o.dx = i.dx; o.bstride = i.bstride; o.C = i.C;
             o.mask_col = i.mask_col; o.mask_ld = i.mask_ld; o.cbase = cb; o.bmod = i.bmod;
+            o.dx_add = i.dx ? i.dx_add : nullptr;
             cb += i.C;
         } else {
             o = SegD{nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0, 0, 0};
@@ -1216,9 +1224,55 @@ static bool grouped_general_wgrad(const ConvK& k, const passion_conv_desc_t* d, 
 // sums[0 .. 2 B Cin) (the caller all-reduces them), phase 2 runs only the finish with 1 / V scaled by vscale = V_local / V_global
 // and the mean-subtraction terms restricted to the depth planes [dwin_lo, dwin_hi) the rank owns.
 // ga / parts: grouped launches (passion_conv3d_bwd_grouped).  parts bit 0: weight (+ bias) gradient, bit 1: input gradient.
+static int conv3d_bwd_core(const passion_conv_desc_t* d, const float* packed, const void* dy, float* dweight,
+                           float* dbias, float* sums, void* stream, int phase, float vscale, int dwin_lo, int dwin_hi,
+                           const GroupArgs* ga, int parts, unsigned* add_fused);
+
+// dx += add over [B][V][C] (dx with its batch stride, add contiguous): what is left of passion_seg_t.dx_add when the path a conv
+// backward took has no kernel that folds it into the write of dx
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void dx_add_kernel(T* __restrict__ dx, const T* __restrict__ add, long per, long bstride) {
+    const long b = blockIdx.y;
+    T* o = dx + b * bstride;
+    const T* a = add + b * per;
+    for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * VEC; i < per; i += (long)gridDim.x * 256 * VEC) {
+        if (i + VEC <= per) {
+            float u[VEC], v[VEC];
+            VecIO<T, VEC>::load(o + i, u);
+            VecIO<T, VEC>::load(a + i, v);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) u[j] += v[j];
+            VecIO<T, VEC>::store(o + i, u);
+        } else {
+            for (long j = i; j < per; ++j) o[j] = (T)((float)o[j] + (float)a[j]);
+        }
+    }
+}
+
 static int conv3d_bwd_impl(const passion_conv_desc_t* d, const float* packed, const void* dy, float* dweight,
                            float* dbias, float* sums, void* stream, int phase, float vscale, int dwin_lo, int dwin_hi,
                            const GroupArgs* ga = nullptr, int parts = 3) {
+    unsigned fused = 0u;
+    const int rc = conv3d_bwd_core(d, packed, dy, dweight, dbias, sums, stream, phase, vscale, dwin_lo, dwin_hi, ga, parts, &fused);
+    if (rc || !d || phase == 1 || !(parts & 2)) return rc;
+    for (int s = 0; s < d->nseg; ++s) {
+        const passion_seg_t& sg = d->seg[s];
+        if (!sg.dx || !sg.dx_add || ((fused >> s) & 1u)) continue;
+        if (sg.bmod > 0) return -1021;
+        const long per = (long)d->D * d->H * d->W * sg.C;
+        const dim3 grid((unsigned)hmin((per / 8 + 255) / 256 + 1, 2048), d->B);
+        if (d->x_dtype == PASSION_BF16)
+            hipLaunchKernelGGL((dx_add_kernel<bf16_t, 8>), grid, dim3(256), 0, (hipStream_t)stream, (bf16_t*)sg.dx, (const bf16_t*)sg.dx_add, per, (long)sg.bstride);
+        else
+            hipLaunchKernelGGL((dx_add_kernel<float, 4>), grid, dim3(256), 0, (hipStream_t)stream, (float*)sg.dx, (const float*)sg.dx_add, per, (long)sg.bstride);
+        LAUNCH_RET();
+    }
+    return 0;
+}
+
+static int conv3d_bwd_core(const passion_conv_desc_t* d, const float* packed, const void* dy, float* dweight,
+                           float* dbias, float* sums, void* stream, int phase, float vscale, int dwin_lo, int dwin_hi,
+                           const GroupArgs* ga, int parts, unsigned* add_fused) {
     ConvK k;
     int rc = fill_params(d, k);
     if (rc) return rc;
@@ -1325,6 +1379,7 @@ static int conv3d_bwd_impl(const passion_conv_desc_t* d, const float* packed, co
                 rc = launch_conv_march(k, 3, 1, 2, packed + f32_pack_floats(k.Cin, k.Cout, nt), st);
             }
             if (rc > 0 || (rc == 0 && !k.pw_done)) rc = -1023;
+            if (rc == 0 && k.pw_done == 2 && k.nseg == 1 && k.seg[0].dx_add && add_fused) *add_fused |= 1u;      // (conv_pair.hip added it in its epilogue)
             if (rc == 0 && k.pw_done == 2) {             // interior written in final form, halo outputs in the shell: fold them
                 char dg_tag[64];
                 snprintf(dg_tag, sizeof(dg_tag), "%s", passion_prof_last_tag());
@@ -1602,6 +1657,7 @@ static int conv3d_bwd_impl(const passion_conv_desc_t* d, const float* packed, co
             if (rc < 0) return rc;
             if (rc == 0 && kf.pw_done) {
                 raw_done = true;
+                if (kf.pw_done == 2 && kf.nseg == 1 && kf.seg[0].dx_add && add_fused) *add_fused |= 1u;
                 if (kf.pw_done == 2) {                   // interior written in final form, halo outputs in the shell: fold them
                     char dg_tag[64];
                     snprintf(dg_tag, sizeof(dg_tag), "%s", passion_prof_last_tag());
@@ -1710,7 +1766,8 @@ static int conv3d_bwd_impl(const passion_conv_desc_t* d, const float* packed, co
                 const SegD& q = k.seg[s2];
                 const bool v8q = d->x_dtype == PASSION_BF16 && q.C % 8 == 0 && k.Cin % 8 == 0 && q.cbase % 8 == 0;
                 if (done[s2] || !q.dx || q.C != sg.C || v8q != v8 || coff + q.C > FIN_MAXC || (fs.n > 0 && !fin_merge)) continue;
-                fs.s[fs.n++] = FinSeg{q.dx, q.x, q.stats, q.mask, q.bstride, q.C, q.cbase, q.mask_col, q.mask_ld, q.bmod, coff};
+                fs.s[fs.n++] = FinSeg{q.dx, q.x, q.stats, q.mask, q.bstride, q.C, q.cbase, q.mask_col, q.mask_ld, q.bmod, coff, q.dx_add};
+                if (q.dx_add && add_fused) *add_fused |= 1u << s2;
                 coff += q.C;
                 done[s2] = true;
             }
@@ -1785,6 +1842,7 @@ passion_conv_desc_t sub_desc(const passion_conv_desc_t* d, int g, int bg) {
         if (sg.stats) sg.stats += off * sg.C * 2;
         if (sg.mask) sg.mask += off * sg.mask_ld;
         if (sg.dx) sg.dx = static_cast<char*>(sg.dx) + off * sg.bstride * es;
+        if (sg.dx_add) sg.dx_add = static_cast<const char*>(sg.dx_add) + off * (long)d->D * d->H * d->W * sg.C * es;      // (contiguous)
     }
     return s;
 }

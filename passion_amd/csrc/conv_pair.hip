@@ -371,10 +371,21 @@ void conv_pair_kernel(ConvK p, PairP mp) {
     float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2v[4] = {0.f, 0.f, 0.f, 0.f};
     const bool fstats = !DG && p.fst.stats != nullptr;
 
+    // SF with HAS_RES (MODE 2): SegD.dx_add -- a contiguous tensor of dx's shape that is added into the final value (the gradient that
+    // reached x through the identity branch of a residual block): one more 8-byte load per lane and tile, requested before the tap loop
+    constexpr bool HAS_ADD = DG && SF && HAS_RES;
+    const char* abase = HAS_ADD ? reinterpret_cast<const char*>(sd0.dx_add) + (long)b * Sd * Sh * Sw * sd0.C * 2 : nullptr;
+
     // output pair o (positions dlo + 2 o, + 1) from ring planes 2 o .. 2 o + 3
     auto compute = [&](auto nxc, int o, const u32x2 (&eo)[EOP ? TT : 1]) {
         constexpr int NX = decltype(nxc)::value, TC = NT + NX;
         const unsigned sbv = (unsigned)((2 * o) & (NSLOT - 1)) * (unsigned)PLANE;
+        u32x2 addv[HAS_ADD ? NT : 1];
+        if constexpr (HAS_ADD) {
+            const unsigned pla = (unsigned)min(max(dlo + 2 * o + half, 0), Sd - 1) * fplane_b;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) addv[t] = gload_at<u32x2>(abase, pla + fel[t]);
+        }
         f32x4 acc[TC];
 #pragma unroll
         for (int t = 0; t < TC; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -443,6 +454,11 @@ void conv_pair_kernel(ConvK p, PairP mp) {
                         // interior plane: final value into dx; the padded planes -1 / Sd (the first / last pair of the volume) into the shell
                         const int dposl = dlo + 2 * o + half;
                         const bool pin = dposl >= 0 && dposl < Sd;
+                        if constexpr (HAS_ADD) {
+                            const u32x2 ar = addv[t < NT ? t : 0];
+                            fv[0] += __uint_as_float(ar.x << 16); fv[1] += __uint_as_float(ar.x & 0xffff0000u);
+                            fv[2] += __uint_as_float(ar.y << 16); fv[3] += __uint_as_float(ar.y & 0xffff0000u);
+                        }
 #pragma unroll
                         for (int j = 0; j < 4; ++j) pk.h[j] = (bf16_t)fv[j];
                         if (row_ok && pin) gstore_at<u32x2>(fdx, fb + fel[t < NT ? t : 0], pk.u);
@@ -581,6 +597,7 @@ int launch_pair_one(ConvK& k, hipStream_t st) {
     if (MODE == 2 && k.pwm) {                        // final form (means in k.pwm): reflect padding, statistics on the input
         if (TW != 16 || nohalo || !k.y) return 1;              // (a raw input -- no statistics -- takes the epilogue's `gg` branch: conv.hip raw_done)
         k.pw_done = 2;                               // 2: the shell of the padded scratch still has to be folded (shell_fold_kernel)
+        if (k.seg[0].dx_add) return launch_pair_res<16, 2, true, true>(k, mp, st);      // ... + the identity branch's gradient (conv.hip: add_fused)
         return launch_pair_res<16, 2, false, true>(k, mp, st);
     }
     if (MODE == 2) {

@@ -59,6 +59,7 @@ struct ConvCfg {
     OptT stats_out;              // ... written into this preallocated (B, Cout, 2) f32 slot
     double eps = 1e-5;
     std::vector<at::Tensor> params;     // direct-gradient mode: the parameters (weights, then biases) whose .grad the backward fills itself
+    bool pass_x = false;                // grouped node: hand xs[0] on as a further OUTPUT of the node (below)
 };
 
 // Direct-gradient mode (set_direct_grads, single-process training): the conv nodes take DETACHED weights / biases and write the
@@ -107,6 +108,7 @@ void fill_desc(passion_conv_desc_t& d, const std::vector<int64_t>& geo, const st
         sg.bstride = seg[i * SEG_INTS + 2];
         sg.bmod = (int)seg[i * SEG_INTS + 3];
         sg.dx = (dxs && (*dxs)[i].defined()) ? (*dxs)[i].data_ptr() : nullptr;
+        sg.dx_add = nullptr;
     }
 }
 
@@ -314,12 +316,17 @@ struct GroupedConvNode : public torch::autograd::Function<GroupedConvNode> {
         ctx->saved_data["masks"] = to_list(cfg.masks);
         ctx->saved_data["packed"] = cfg.packed;
         ctx->saved_data["wshape"] = weight.sizes().vec();
-        ctx->saved_data["flags"] = std::vector<int64_t>{G, biases.empty() ? 0 : 1, residual.has_value()};
+        ctx->saved_data["flags"] = std::vector<int64_t>{G, biases.empty() ? 0 : 1, residual.has_value(), cfg.pass_x ? 1 : 0};
         ctx->saved_data["params"] = c10::List<at::Tensor>(cfg.params);
         ctx->set_materialize_grads(false);
-        if (!cfg.want_stats) return {y};
-        ctx->mark_non_differentiable({st});
-        return {y, st};
+        // pass_x: xs[0] leaves the node again as its LAST output (autograd makes it a view with this node as grad_fn).  Whoever uses x
+        // beside this conv -- the identity branch of x + c3(c2(x)): c3's `residual` -- takes that output, so both gradients of x arrive
+        // in ONE backward call and the library adds the second into the write of dx (passion_seg_t.dx_add) instead of autograd
+        // summing two tensors in a launch of its own.
+        variable_list outs{y};
+        if (cfg.want_stats) { ctx->mark_non_differentiable({st}); outs.push_back(st); }
+        if (cfg.pass_x) outs.push_back(xs[0]);
+        return outs;
     }
 
     static variable_list backward(AutogradContext* ctx, variable_list grads) {
@@ -329,8 +336,14 @@ struct GroupedConvNode : public torch::autograd::Function<GroupedConvNode> {
                                    wshape = ctx->saved_data["wshape"].toIntVector(), flags = ctx->saved_data["flags"].toIntVector();
         const int G = (int)flags[0];
         const bool has_bias = flags[1] != 0, has_res = flags[2] != 0;
+        const bool pass_x = flags.size() > 3 && flags[3] != 0;
         const int nout = G + (has_bias ? G : 0) + 1 + n + 1;      // one per forward argument: weights, biases, residual (even absent), xs, cfg
-        if (!grads[0].defined()) return variable_list(nout);
+        at::Tensor xadd = (pass_x && grads.back().defined()) ? grads.back() : at::Tensor();      // the gradient that came in through the handed-on x
+        if (!grads[0].defined()) {
+            variable_list none(nout);
+            if (xadd.defined()) none[G + (has_bias ? G : 0) + 1] = xadd;      // y unused: the identity alone
+            return none;
+        }
         const std::vector<OptT> stats = from_list(ctx->saved_data["stats"]), masks = from_list(ctx->saved_data["masks"]);
         const at::Tensor packed = ctx->saved_data["packed"].toTensor();
         const std::vector<at::Tensor> params = ctx->saved_data["params"].toTensorVector();
@@ -362,6 +375,12 @@ struct GroupedConvNode : public torch::autograd::Function<GroupedConvNode> {
         }
         passion_conv_desc_t d;
         fill_desc(d, geo, seg, ctx->saved_data["slope"].toDouble(), stats, masks, xs, &dxs, Cout);
+        bool add_fused = false;
+        if (xadd.defined() && dxs[0].defined() && seg[3] == 0 && xadd.sizes() == dxs[0].sizes() && xadd.scalar_type() == dxs[0].scalar_type()) {
+            xadd = xadd.contiguous();
+            d.seg[0].dx_add = xadd.data_ptr();
+            add_fused = true;
+        }
         at::Tensor scratch = at::empty({g.conv_bwd_scratch(&d)}, f32);
         const int64_t pstride = packed.numel() / G;
         const float* pk[4];
@@ -380,6 +399,7 @@ struct GroupedConvNode : public torch::autograd::Function<GroupedConvNode> {
         if (has_bias)
             for (int g2 = 0; g2 < G; ++g2) out.push_back((need_w && !direct) ? wbuf[g2].narrow(0, nW, Cout) : at::Tensor());
         out.push_back(need_res ? dy : at::Tensor());
+        if (xadd.defined() && !add_fused) dxs[0] = dxs[0].defined() ? dxs[0] + xadd : xadd;      // (shapes the library does not take: autograd's way)
         for (int i = 0; i < n; ++i) out.push_back(dxs[i]);
         out.push_back(at::Tensor());     // cfg
         return out;
@@ -389,9 +409,11 @@ struct GroupedConvNode : public torch::autograd::Function<GroupedConvNode> {
 std::vector<at::Tensor> conv_block_grouped(const std::vector<at::Tensor>& weights, const std::vector<at::Tensor>& biases, const OptT& residual,
                                            const std::vector<at::Tensor>& xs, std::vector<OptT> stats, std::vector<OptT> masks,
                                            std::vector<int64_t> seg, std::vector<int64_t> geo, double slope, const at::Tensor& packed,
-                                           const OptT& out, bool want_stats, const OptT& stats_out, double eps) {
+                                           const OptT& out, bool want_stats, const OptT& stats_out, double eps, bool pass_x) {
     TORCH_CHECK(g.conv_fwd_grouped && g.conv_bwd_grouped, "passion_amd host extension is not bound to libpassion_hip.so");
     ConvCfg cfg{std::move(geo), std::move(seg), slope, std::move(stats), std::move(masks), packed, out, want_stats, stats_out, eps, {}};
+    cfg.pass_x = pass_x && at::GradMode::is_enabled() && any_requires_grad(xs);
+    const bool handed = cfg.pass_x;
     bool wreq = false, leaves = true;
     for (const at::Tensor& w : weights) { wreq = wreq || w.requires_grad(); leaves = leaves && w.is_leaf(); }
     for (const at::Tensor& b : biases) { wreq = wreq || b.requires_grad(); leaves = leaves && b.is_leaf(); }
@@ -399,9 +421,13 @@ std::vector<at::Tensor> conv_block_grouped(const std::vector<at::Tensor>& weight
         std::vector<at::Tensor> wd, bd;
         for (const at::Tensor& w : weights) { cfg.params.push_back(w); wd.push_back(w.detach()); }
         for (const at::Tensor& b : biases) { cfg.params.push_back(b); bd.push_back(b.detach()); }
-        return GroupedConvNode::apply(at::TensorList(wd), at::TensorList(bd), residual, at::TensorList(xs), std::move(cfg));
+        std::vector<at::Tensor> r = GroupedConvNode::apply(at::TensorList(wd), at::TensorList(bd), residual, at::TensorList(xs), std::move(cfg));
+        if (pass_x && !handed) r.push_back(xs[0]);
+        return r;
     }
-    return GroupedConvNode::apply(at::TensorList(weights), at::TensorList(biases), residual, at::TensorList(xs), std::move(cfg));
+    std::vector<at::Tensor> r = GroupedConvNode::apply(at::TensorList(weights), at::TensorList(biases), residual, at::TensorList(xs), std::move(cfg));
+    if (pass_x && !handed) r.push_back(xs[0]);      // (no graph: x itself)
+    return r;
 }
 
 at::Tensor instnorm_stats(const at::Tensor& x, double eps, const OptT& out) {

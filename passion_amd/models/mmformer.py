@@ -122,26 +122,39 @@ def encoders_grouped(encs, x, mask, dtype):
     xs = xs.view(K * B, D, H, W, 1)
     gmask = mask.t().reshape(K * B, 1).contiguous() if mask is not None else None      # row m * B + b = mask[b, m]
 
-    def gconv(name, f, residual=None, want_stats=True, first=False):
+    def gconv(name, f, residual=None, want_stats=True, first=False, pass_x=False):
         convs = [getattr(e, name) if first else getattr(e, name).conv for e in encs]
         c0 = convs[0]
         d, h, w = f.t.shape[1:4]
         seg = ops.SegIn(f.t, mask=gmask, mask_col=0) if first else f.seg(True)
         r = ops.conv_block_grouped([seg], [c.weight for c in convs], [c.bias for c in convs], d, h, w, ksize=c0.kernel_size[0],
                                    stride=c0.stride[0], pad_mode=L.PAD_REFLECT, residual=residual, out_dtype=dtype,
-                                   want_stats=want_stats)
+                                   want_stats=want_stats, pass_x=pass_x)
+        if pass_x:
+            return Feat(r[0], _stats=[r[1]]), r[2]
         return Feat(r[0], _stats=[r[1]]) if want_stats else Feat(r)
 
     f = gconv("e1_c1", Feat(xs), first=True)
     feats = []
     for lvl in range(1, 6):
-        if lvl > 1:
+        if lvl > 1 and RES_FUSE:
+            # the level's feature goes to the decoders / fusion blocks AND into the next level's stride-2 conv: that conv hands it on, the
+            # others read the handed-on tensor, and their (summed) gradient joins the conv's own input gradient inside its backward
+            fprev = f
+            f, xk = gconv(f"e{lvl}_c1", f, pass_x=True)
+            feats[-1] = Feat(xk, fprev.mask, fprev.mask_col, fprev._stats, fprev.passes, fprev.stats_out, fprev._act, fprev.c_real)
+        elif lvl > 1:
             f = gconv(f"e{lvl}_c1", f)
-        f = gconv(f"e{lvl}_c3", gconv(f"e{lvl}_c2", f), residual=f.t, want_stats=lvl < 5)
+        if RES_FUSE:     # x + c3(c2(x)): c2 hands x on to c3's residual input, the two gradients of x are summed inside c2's backward
+            y2, xres = gconv(f"e{lvl}_c2", f, pass_x=True)
+            f = gconv(f"e{lvl}_c3", y2, residual=xres, want_stats=lvl < 5)
+        else:
+            f = gconv(f"e{lvl}_c3", gconv(f"e{lvl}_c2", f), residual=f.t, want_stats=lvl < 5)
         feats.append(f)
     return feats
 
 
+RES_FUSE = _os.environ.get("PASSION_RES_FUSE", "1") != "0"             # encoder residual blocks: the identity branch's gradient added inside c2's backward
 SEP_LOSS_FIRST = _os.environ.get("PASSION_SEP_LOSS_FIRST", "1") != "0"
 LOSS_STREAMS = _os.environ.get("PASSION_LOSS_STREAMS", "1") != "0"     # deep-supervision / decoder_sep losses on side streams
 FUSE_STREAM = _os.environ.get("PASSION_FUSE_STREAM", "1") != "0"       # fusion blocks of levels 4..1 on a side stream

@@ -598,9 +598,10 @@ def _group_pack(weights):
 
 
 def conv_block_grouped(segs, weights, biases, D, H, W, ksize=3, stride=1, pad_mode=L.PAD_REFLECT, residual=None, out_dtype=None,
-                       slope=0.2, out=None, want_stats=False, stats_out=None, eps=1e-5):
+                       slope=0.2, out=None, want_stats=False, stats_out=None, eps=1e-5, pass_x=False):
     """conv_block for G weight sets over one stacked batch: sample b of the (B,...) segments uses weights[b // (B // G)] -- the
-    four modality encoders of mmformer as one launch per layer (passion_conv3d_fwd_grouped / _bwd_grouped)."""
+    four modality encoders of mmformer as one launch per layer (passion_conv3d_fwd_grouped / _bwd_grouped).
+    pass_x: the single segment's tensor comes back as a further result (see below)."""
     h = L.host()
     assert h is not None, "grouped conv blocks need the C++ host extension"
     x0 = segs[0].x
@@ -614,7 +615,10 @@ def conv_block_grouped(segs, weights, biases, D, H, W, ksize=3, stride=1, pad_mo
         seg_ints += (s.C, s.offset, s.bstride, s.bmod, s.mask_col)
     r = h.conv_block_grouped(list(weights), list(biases) if biases is not None else [], residual, [s.x for s in segs],
                              [s.stats for s in segs], [s.mask for s in segs], seg_ints,
-                             (B, D, H, W, ksize, stride, pad_mode, L.dtype_code(odt)), slope, packed, out, want_stats, stats_out, eps)
+                             (B, D, H, W, ksize, stride, pad_mode, L.dtype_code(odt)), slope, packed, out, want_stats, stats_out, eps, pass_x)
+    if pass_x:       # ... and the input again, as an output of this node: give THAT to whoever else reads x (a later conv's `residual`),
+        #              and the two gradients of x meet inside this conv's backward (passion_seg_t.dx_add) instead of in an autograd add
+        return (r[0], r[1], r[-1]) if want_stats else (r[0], r[-1])
     return (r[0], r[1]) if want_stats else r[0]
 
 

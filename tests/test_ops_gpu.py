@@ -1174,6 +1174,50 @@ def test_first_layer_weight_gradient(B, shape, pad_mode):
     assert torch.equal(first, wd.grad)                     # fixed-order fold: bit-reproducible
 
 
+@pytest.mark.parametrize("C,shape", [(32, (8, 8, 16)), (16, (16, 32, 32)), (8, (24, 32, 64)), (8, (64, 128, 128)), (16, (5, 6, 7))])
+def test_residual_gradient_joins_inside_the_conv_backward(C, shape):
+    """x + c3(c2(x)) (the encoders' residual blocks, reference mmformer.py:34-38) with c2 handing x on to c3's residual input
+    (conv_block_grouped(pass_x=True), passion_seg_t.dx_add): the gradient of x -- the identity branch's dy plus c2's input gradient --
+    against the same block with autograd summing the two (bf16: the joined form rounds once instead of twice), and the weight
+    gradients bit for bit; the shapes take the padded finish (levels 2..5), the final-form kernels + the library's own add (level 1)
+    and the general kernels"""
+    from passion_amd import ops
+    dev = _dev()
+    D, H, W = shape
+    B, G = 4, 4
+    g = torch.Generator().manual_seed(31)
+    x0 = (torch.randn(B, D, H, W, C, generator=g) * 1.2 + 0.1).to(torch.bfloat16).to(dev)
+    ws = [[(torch.randn(C, C, 3, 3, 3, generator=g) / (C * 27) ** 0.5).to(dev) for _ in range(G)] for _ in range(2)]
+    bs = [[torch.randn(C, generator=g).to(dev) for _ in range(G)] for _ in range(2)]
+    gy = torch.randn(B, D, H, W, C, generator=g).to(torch.bfloat16).to(dev)
+
+    def run(joined):
+        x = x0.clone().requires_grad_(True)
+        xin = x * 1.0                                                # (a non-leaf input, as an encoder level's)
+        w2, w3 = [w.clone().requires_grad_(True) for w in ws[0]], [w.clone().requires_grad_(True) for w in ws[1]]
+        b2, b3 = [b.clone().requires_grad_(True) for b in bs[0]], [b.clone().requires_grad_(True) for b in bs[1]]
+        seg = ops.SegIn(xin, stats=ops.instnorm_stats(xin.detach()))
+        if joined:
+            y2, st2, xres = ops.conv_block_grouped([seg], w2, b2, D, H, W, want_stats=True, pass_x=True)
+        else:
+            (y2, st2), xres = ops.conv_block_grouped([seg], w2, b2, D, H, W, want_stats=True), xin
+        y = ops.conv_block_grouped([ops.SegIn(y2, stats=st2)], w3, b3, D, H, W, residual=xres)
+        y.backward(gy)
+        torch.cuda.synchronize()
+        return y.detach(), x.grad, [w.grad for w in w2 + w3], [b.grad for b in b2 + b3]
+
+    y1, dx1, dw1, db1 = run(True)
+    y0, dx0, dw0, db0 = run(False)
+    assert torch.equal(y1, y0)
+    for a, b in zip(dw1 + db1, dw0 + db0):
+        assert torch.equal(a, b)
+    d = (dx1.float() - dx0.float()).abs()
+    scale = dx0.float().abs().mean()
+    assert float(d.max()) <= 2 ** -6 * float(dx0.float().abs().max()) and float(d.mean()) < 4e-3 * float(scale), (float(d.max()), float(d.mean()), float(scale))
+    # ... and against f32 arithmetic on the unjoined pieces: the joined sum is the closer one
+    assert relerr(dx1.float(), dx0.double()) < 1e-2
+
+
 @pytest.mark.parametrize("norm", [True, False], ids=["prenorm", "raw"])
 @pytest.mark.parametrize("pad_mode", [1, 0], ids=["reflect", "zeros"])
 @pytest.mark.parametrize("shape", [(32, 128, 128), (16, 128, 256), (26, 128, 160)])
