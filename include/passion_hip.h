@@ -29,6 +29,8 @@ extern "C" {
 #define PASSION_PAD_REFLECT 1
 #define PASSION_MAX_SEG 4
 
+/* 2 since passion_seg_t carries dx_add (round 6): a caller built against another layout must not pass descriptors */
+#define PASSION_ABI_VERSION 2
 int passion_abi_version(void);
 /* developer A/B switches, also read from the environment at load time (PASSION_CONV_LEAN, PASSION_CONV_PADOUT,
  * PASSION_FORCE_F32_MFMA, ...): "conv_lean", "conv_padout", "force_f32_mfma", "conv_target", "conv_merge",

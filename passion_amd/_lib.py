@@ -29,6 +29,9 @@ class ConvDesc(Structure):
                 ("lrelu_slope", c_float), ("seg", Seg * MAX_SEG)]
 
 
+ABI_VERSION = 2      # include/passion_hip.h PASSION_ABI_VERSION (2: passion_seg_t.dx_add)
+
+
 class ProfRec(Structure):
     _fields_ = [("kind", c_int32), ("ms", c_float), ("bytes", c_double), ("flops", c_double), ("name", c_char * 64)]
 
@@ -197,6 +200,8 @@ def load():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
+    if lib.passion_abi_version() != ABI_VERSION:
+        raise PassionHipError(f"{LIB_PATH} has ABI version {lib.passion_abi_version()}, this package binds version {ABI_VERSION}: rebuild it")
     _lib = lib
     return lib
 
@@ -228,6 +233,8 @@ def host():
     spec = importlib.util.spec_from_file_location("_passion_host", HOST_EXT_PATH)
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
+    if not hasattr(mod, "abi_version") or mod.abi_version() != ABI_VERSION:
+        raise PassionHipError(f"{HOST_EXT_PATH} was built against another descriptor layout than ABI version {ABI_VERSION}: rebuild it")
     addr = lambda name: ctypes.cast(getattr(lib, name), c_void_p).value
     mod.bind(addr("passion_conv3d_fwd"), addr("passion_conv3d_bwd"), addr("passion_conv_bwd_scratch_floats"),
              addr("passion_instnorm_stats"), addr("passion_instnorm_scratch_doubles"), addr("passion_conv3d_fwd_stats"),

@@ -479,6 +479,7 @@ void bind(uint64_t conv_fwd, uint64_t conv_bwd, uint64_t conv_bwd_scratch, uint6
 
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     m.def("bind", &bind, "addresses of the C-ABI entry points (from the ctypes handle of libpassion_hip.so)");
+    m.def("abi_version", []() { return PASSION_ABI_VERSION; }, "the descriptor layout this extension was compiled against (include/passion_hip.h)");
     m.def("conv_block", &conv_block);
     m.def("conv_block_grouped", &conv_block_grouped);
     m.def("param_grad_ptrs", &param_grad_ptrs);

@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
     lib = ctypes.CDLL(_lib.LIB_PATH)
     for s in header_symbols():
         assert hasattr(lib, s), f"{s} declared in passion_hip.h but not exported"
-    assert lib.passion_abi_version() == 1
+    assert lib.passion_abi_version() == 2
 
 
 def test_ctypes_table_matches_header():
@@ -40,9 +40,10 @@ def test_ctypes_table_matches_header():
 
 def test_struct_layout_matches_header():
     from passion_amd import _lib
-    # passion_seg_t: 4 pointers + int64 + 4 int32 = 56 bytes; conv desc: 12 x 4-byte fields + 4 segments
-    assert ctypes.sizeof(_lib.Seg) == 56
-    assert ctypes.sizeof(_lib.ConvDesc) == 48 + 4 * 56
+    # passion_seg_t: 4 pointers + int64 + 4 int32 + the dx_add pointer (round 6) = 64 bytes; conv desc: 12 x 4-byte fields + 4 segments
+    assert ctypes.sizeof(_lib.Seg) == 64
+    assert ctypes.sizeof(_lib.ConvDesc) == 48 + 4 * 64
+    assert _lib.Seg.dx_add.offset == 56
     assert ctypes.sizeof(_lib.ProfRec) == 24 + 64      # {kind, ms, bytes, flops, char name[64]}
 
 
