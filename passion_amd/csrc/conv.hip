@@ -854,12 +854,14 @@ WgPlan plan_wgrad(const ConvK& k, const passion_conv_desc_t* d) {
     // (measured per layer, weight gradient + the finish launch that folds its slab, 4 samples: 64 -> 64 over 16^3: 56.1 us at 1024 workgroups,
     // 42.7 at 512, 40.0 at 256, 47.3 at 128; 128 -> 128 over 8^3: 39.2 / 39.2 / 34.4; 32 -> 32 over 32^3: 62.8 / 54.6 / 58.3 / 75.9)
     static const long wg_small = []() { const char* e = getenv("PASSION_WGRAD_WGS_SMALL"); return e && atol(e) > 0 ? atol(e) : 0L; }();
-    // the finest level's 3x3x3 layers with >= 4 M voxels (the marching weight gradient with its indicator slab, two workgroups per CU):
-    // 512 workgroups are ONE resident round (4 x 128^3, round 6: 8 -> 8 105.9 us against 115.7 at 1024, 16 -> 8 183.9 against 194.5;
-    // 768: 204 / 295 -- the (tile, D segment) units do not divide; 1536: 155 / 318; 2048: 133 / 212), and half the slab to fold
-    static const long wg_big = []() { const char* e = getenv("PASSION_WGRAD_WGS"); return e && atol(e) > 0 ? atol(e) : 0L; }();
+    // large volumes: 512 slots.  The marching weight gradients hold two workgroups per CU, so 512 workgroups are ONE resident round, and
+    // the slab to fold is half as long (round 6, per launch over 4 x 128^3 / 4 x 64^3 against 1024 slots: indicator kernel 8 -> 8 115.7 ->
+    // 105.9 us, 16 -> 8 194.5 -> 183.9 (768: 204 / 295, the (tile, depth segment) units do not divide; 1536: 155 / 318; 2048: 133 / 212);
+    // wgrad_s2m_kernel 53.5 -> 45.6; wgrad_march16_kernel 16 -> 16 41.9 -> 34.0, 32 -> 16 62.2 -> 54.4; the streaming pointwise and the
+    // brick kernels do not care; PASSION step +0.7 %)
+    static const long wg_big = []() { const char* e = getenv("PASSION_WGRAD_WGS"); return e && atol(e) > 0 ? atol(e) : 512L; }();
     const bool finest = d->ksize == 3 && d->stride == 1 && k.Cout == 8 && k.Cin <= 16 && (long)k.B * k.Di * k.Hi * k.Wi >= marchfinal_minvox();
-    const long wg_target = total <= 512 ? (wg_small ? wg_small : (total <= 64 ? 256L : 512L)) : (wg_big ? wg_big : (finest && w.bf16 ? 512L : 1024L));
+    const long wg_target = total <= 512 ? (wg_small ? wg_small : (total <= 64 ? 256L : 512L)) : wg_big;
     w.gx = (int)hmin(total, hmax(1, wg_target / w.gy));
     // 1x1x1 on the streaming kernel (conv_wgrad_pw.hip): one workgroup handles every input block of its voxels, so the launch has gx
     // workgroups, not gx x gy -- give it the whole target
