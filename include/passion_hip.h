@@ -73,6 +73,8 @@ typedef struct {
     const void* dx_add;   /* backward only (round 6): a contiguous tensor of dx's shape and dtype that is ADDED into dx -- the gradient that
                              reached x by another path (the identity branch of x + c3(c2(x)), code/models/mmformer.py:34-38: its sum with
                              this conv's input gradient then costs no pass of its own).  NULL: none.  Not with bmod > 0 */
+    const void* dx_add2;  /* a second such tensor (x read by two further consumers: a level's feature goes to decoder_sep and to the fusion
+                             blocks); only with dx_add */
 } passion_seg_t;
 
 typedef struct {

@@ -19,7 +19,7 @@ MAX_SEG = 4
 class Seg(Structure):
     _fields_ = [("x", c_void_p), ("stats", c_void_p), ("mask", c_void_p), ("dx", c_void_p),
                 ("bstride", c_int64), ("C", c_int32), ("mask_col", c_int32),
-                ("mask_ld", c_int32), ("bmod", c_int32), ("dx_add", c_void_p)]
+                ("mask_ld", c_int32), ("bmod", c_int32), ("dx_add", c_void_p), ("dx_add2", c_void_p)]
 
 
 class ConvDesc(Structure):

@@ -57,7 +57,7 @@ void passion_prof_tag(const char* fmt, ...) {
     va_end(ap);
 }
 
-extern "C" int passion_abi_version(void) { return 2; }      // 2: passion_seg_t.dx_add (round 6)
+extern "C" int passion_abi_version(void) { return 2; }      // 2: passion_seg_t.dx_add, dx_add2 (round 6)
 
 // ---- step words: what changes from one replay of a captured training step to the next lives in device memory
 const unsigned* g_passion_step_words = nullptr;

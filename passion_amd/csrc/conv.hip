@@ -460,7 +460,7 @@ __global__ __launch_bounds__(256) void shell_fold_kernel(bf16_t* __restrict__ dx
 // voxels -- 222 us per finish against 98 for the same bytes in one segment); here a block walks its rows segment after segment, the
 // second visit of a line comes from L2.  Segments of one launch have the same channel count (the launcher groups them).
 struct FinSeg { void* dx; const void* x; const float* stats; const uint8_t* mask; long bstride; int C, cbase, mask_col, mask_ld, bmod, coff;
-                const void* add; };      // add: SegD.dx_add (contiguous [B][V][C]), folded into the write of dx
+                const void* add; const void* add2; };      // add, add2: SegD.dx_add, dx_add2 (contiguous [B][V][C]), folded into the write of dx
 struct FinSegs { FinSeg s[PASSION_MAX_SEG]; int n; };
 template <typename T, int VEC>
 __global__ __launch_bounds__(256) void in_bwd_finish_pad_kernel(FinSegs fs, const T* __restrict__ dxp, const float* __restrict__ sums, int D, int H, int W,
@@ -539,11 +539,16 @@ __global__ __launch_bounds__(256) void in_bwd_finish_pad_kernel(FinSegs fs, cons
                             g[j] = own ? __builtin_fmaf(cf[c + j][0], g[j], __builtin_fmaf(cf[c + j][1], xv[j], cf[c + j][2])) : cf[c + j][0] * g[j];
                     }
                 }
-                if (q.add) {                               // the gradient that reached x by another path (the residual branch)
+                if (q.add) {                               // the gradient that reached x by another path (the residual branch, the other readers)
                     float av[VEC];
                     VecIO<T, VEC>::load(reinterpret_cast<const T*>(q.add) + (long)b * V * C + e, av);
 #pragma unroll
                     for (int j = 0; j < VEC; ++j) g[j] += av[j];
+                    if (q.add2) {
+                        VecIO<T, VEC>::load(reinterpret_cast<const T*>(q.add2) + (long)b * V * C + e, av);
+#pragma unroll
+                        for (int j = 0; j < VEC; ++j) g[j] += av[j];
+                    }
                 }
                 vstore_nt<T, VEC>(dxb + e, g, nt_dx);
             }
@@ -774,6 +779,7 @@ int fill_params(const passion_conv_desc_t* d, ConvK& k) {
             o.x = i.x; o.stats = i.stats; o.mask = i.mask; o.dx = i.dx; o.bstride = i.bstride; o.C = i.C;
             o.mask_col = i.mask_col; o.mask_ld = i.mask_ld; o.cbase = cb; o.bmod = i.bmod;
             o.dx_add = i.dx ? i.dx_add : nullptr;
+            o.dx_add2 = o.dx_add ? i.dx_add2 : nullptr;
             cb += i.C;
         } else {
             o = SegD{nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0, 0, 0};
@@ -1259,15 +1265,19 @@ static int conv3d_bwd_impl(const passion_conv_desc_t* d, const float* packed, co
     if (rc || !d || phase == 1 || !(parts & 2)) return rc;
     for (int s = 0; s < d->nseg; ++s) {
         const passion_seg_t& sg = d->seg[s];
-        if (!sg.dx || !sg.dx_add || ((fused >> s) & 1u)) continue;
+        if (!sg.dx || !sg.dx_add) continue;
         if (sg.bmod > 0) return -1021;
         const long per = (long)d->D * d->H * d->W * sg.C;
         const dim3 grid((unsigned)hmin((per / 8 + 255) / 256 + 1, 2048), d->B);
-        if (d->x_dtype == PASSION_BF16)
-            hipLaunchKernelGGL((dx_add_kernel<bf16_t, 8>), grid, dim3(256), 0, (hipStream_t)stream, (bf16_t*)sg.dx, (const bf16_t*)sg.dx_add, per, (long)sg.bstride);
-        else
-            hipLaunchKernelGGL((dx_add_kernel<float, 4>), grid, dim3(256), 0, (hipStream_t)stream, (float*)sg.dx, (const float*)sg.dx_add, per, (long)sg.bstride);
-        LAUNCH_RET();
+        for (int which = 0; which < 2; ++which) {          // bit s: dx_add of segment s was folded into the write of dx; bit 8 + s: dx_add2
+            const void* add = which ? sg.dx_add2 : sg.dx_add;
+            if (!add || ((fused >> (which * 8 + s)) & 1u)) continue;
+            if (d->x_dtype == PASSION_BF16)
+                hipLaunchKernelGGL((dx_add_kernel<bf16_t, 8>), grid, dim3(256), 0, (hipStream_t)stream, (bf16_t*)sg.dx, (const bf16_t*)add, per, (long)sg.bstride);
+            else
+                hipLaunchKernelGGL((dx_add_kernel<float, 4>), grid, dim3(256), 0, (hipStream_t)stream, (float*)sg.dx, (const float*)add, per, (long)sg.bstride);
+            LAUNCH_RET();
+        }
     }
     return 0;
 }
@@ -1768,8 +1778,8 @@ static int conv3d_bwd_core(const passion_conv_desc_t* d, const float* packed, co
                 const SegD& q = k.seg[s2];
                 const bool v8q = d->x_dtype == PASSION_BF16 && q.C % 8 == 0 && k.Cin % 8 == 0 && q.cbase % 8 == 0;
                 if (done[s2] || !q.dx || q.C != sg.C || v8q != v8 || coff + q.C > FIN_MAXC || (fs.n > 0 && !fin_merge)) continue;
-                fs.s[fs.n++] = FinSeg{q.dx, q.x, q.stats, q.mask, q.bstride, q.C, q.cbase, q.mask_col, q.mask_ld, q.bmod, coff, q.dx_add};
-                if (q.dx_add && add_fused) *add_fused |= 1u << s2;
+                fs.s[fs.n++] = FinSeg{q.dx, q.x, q.stats, q.mask, q.bstride, q.C, q.cbase, q.mask_col, q.mask_ld, q.bmod, coff, q.dx_add, q.dx_add2};
+                if (q.dx_add && add_fused) *add_fused |= (1u << s2) | (q.dx_add2 ? 1u << (8 + s2) : 0u);
                 coff += q.C;
                 done[s2] = true;
             }
@@ -1845,6 +1855,7 @@ passion_conv_desc_t sub_desc(const passion_conv_desc_t* d, int g, int bg) {
         if (sg.mask) sg.mask += off * sg.mask_ld;
         if (sg.dx) sg.dx = static_cast<char*>(sg.dx) + off * sg.bstride * es;
         if (sg.dx_add) sg.dx_add = static_cast<const char*>(sg.dx_add) + off * (long)d->D * d->H * d->W * sg.C * es;      // (contiguous)
+        if (sg.dx_add2) sg.dx_add2 = static_cast<const char*>(sg.dx_add2) + off * (long)d->D * d->H * d->W * sg.C * es;
     }
     return s;
 }

@@ -26,6 +26,7 @@ struct SegD {
                 // features batched into one launch); dx and the mask are still indexed by b
     __host__ __device__ int bsrc(int b) const { return bmod > 0 ? b % bmod : b; }
     const void* dx_add;   // backward: added into dx by the kernel that writes dx in its final form (passion_seg_t.dx_add); nullptr: none
+    const void* dx_add2;  // ... and a second one (only with dx_add)
 };
 
 // InstanceNorm statistics of the conv's OUTPUT produced by the forward kernel itself (marching / lean bf16 kernels): every

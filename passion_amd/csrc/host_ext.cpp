@@ -59,7 +59,7 @@ struct ConvCfg {
     OptT stats_out;              // ... written into this preallocated (B, Cout, 2) f32 slot
     double eps = 1e-5;
     std::vector<at::Tensor> params;     // direct-gradient mode: the parameters (weights, then biases) whose .grad the backward fills itself
-    bool pass_x = false;                // grouped node: hand xs[0] on as a further OUTPUT of the node (below)
+    int pass_x = 0;                     // grouped node: hand xs[0] on as 1 or 2 further OUTPUTS of the node (below)
 };
 
 // Direct-gradient mode (set_direct_grads, single-process training): the conv nodes take DETACHED weights / biases and write the
@@ -109,6 +109,7 @@ void fill_desc(passion_conv_desc_t& d, const std::vector<int64_t>& geo, const st
         sg.bmod = (int)seg[i * SEG_INTS + 3];
         sg.dx = (dxs && (*dxs)[i].defined()) ? (*dxs)[i].data_ptr() : nullptr;
         sg.dx_add = nullptr;
+        sg.dx_add2 = nullptr;
     }
 }
 
@@ -316,7 +317,7 @@ struct GroupedConvNode : public torch::autograd::Function<GroupedConvNode> {
         ctx->saved_data["masks"] = to_list(cfg.masks);
         ctx->saved_data["packed"] = cfg.packed;
         ctx->saved_data["wshape"] = weight.sizes().vec();
-        ctx->saved_data["flags"] = std::vector<int64_t>{G, biases.empty() ? 0 : 1, residual.has_value(), cfg.pass_x ? 1 : 0};
+        ctx->saved_data["flags"] = std::vector<int64_t>{G, biases.empty() ? 0 : 1, residual.has_value(), cfg.pass_x};
         ctx->saved_data["params"] = c10::List<at::Tensor>(cfg.params);
         ctx->set_materialize_grads(false);
         // pass_x: xs[0] leaves the node again as its LAST output (autograd makes it a view with this node as grad_fn).  Whoever uses x
@@ -325,7 +326,8 @@ struct GroupedConvNode : public torch::autograd::Function<GroupedConvNode> {
         // summing two tensors in a launch of its own.
         variable_list outs{y};
         if (cfg.want_stats) { ctx->mark_non_differentiable({st}); outs.push_back(st); }
-        if (cfg.pass_x) outs.push_back(xs[0]);
+        if (cfg.pass_x >= 1) outs.push_back(xs[0]);
+        if (cfg.pass_x >= 2) outs.push_back(xs[0].alias());      // a second reader on another branch (passion_seg_t.dx_add2)
         return outs;
     }
 
@@ -336,12 +338,18 @@ struct GroupedConvNode : public torch::autograd::Function<GroupedConvNode> {
                                    wshape = ctx->saved_data["wshape"].toIntVector(), flags = ctx->saved_data["flags"].toIntVector();
         const int G = (int)flags[0];
         const bool has_bias = flags[1] != 0, has_res = flags[2] != 0;
-        const bool pass_x = flags.size() > 3 && flags[3] != 0;
+        const int pass_x = flags.size() > 3 ? (int)flags[3] : 0;
         const int nout = G + (has_bias ? G : 0) + 1 + n + 1;      // one per forward argument: weights, biases, residual (even absent), xs, cfg
-        at::Tensor xadd = (pass_x && grads.back().defined()) ? grads.back() : at::Tensor();      // the gradient that came in through the handed-on x
+        // the gradients that came in through the handed-on x (the last pass_x outputs)
+        at::Tensor xadd, xadd2;
+        for (int i = 0; i < pass_x; ++i) {
+            const at::Tensor& gr = grads[grads.size() - pass_x + i];
+            if (!gr.defined()) continue;
+            if (!xadd.defined()) xadd = gr; else xadd2 = gr;
+        }
         if (!grads[0].defined()) {
             variable_list none(nout);
-            if (xadd.defined()) none[G + (has_bias ? G : 0) + 1] = xadd;      // y unused: the identity alone
+            if (xadd.defined()) none[G + (has_bias ? G : 0) + 1] = xadd2.defined() ? xadd + xadd2 : xadd;      // y unused: the identity alone
             return none;
         }
         const std::vector<OptT> stats = from_list(ctx->saved_data["stats"]), masks = from_list(ctx->saved_data["masks"]);
@@ -379,7 +387,16 @@ struct GroupedConvNode : public torch::autograd::Function<GroupedConvNode> {
         if (xadd.defined() && dxs[0].defined() && seg[3] == 0 && xadd.sizes() == dxs[0].sizes() && xadd.scalar_type() == dxs[0].scalar_type()) {
             xadd = xadd.contiguous();
             d.seg[0].dx_add = xadd.data_ptr();
+            if (xadd2.defined() && xadd2.sizes() == xadd.sizes() && xadd2.scalar_type() == xadd.scalar_type()) {
+                xadd2 = xadd2.contiguous();
+                d.seg[0].dx_add2 = xadd2.data_ptr();
+            } else if (xadd2.defined()) {
+                xadd = xadd + xadd2;                     // (cannot happen with tensors handed on by this node: same shape and dtype)
+                d.seg[0].dx_add = xadd.data_ptr();
+            }
             add_fused = true;
+        } else if (xadd.defined() && xadd2.defined()) {
+            xadd = xadd + xadd2;
         }
         at::Tensor scratch = at::empty({g.conv_bwd_scratch(&d)}, f32);
         const int64_t pstride = packed.numel() / G;
@@ -409,11 +426,12 @@ struct GroupedConvNode : public torch::autograd::Function<GroupedConvNode> {
 std::vector<at::Tensor> conv_block_grouped(const std::vector<at::Tensor>& weights, const std::vector<at::Tensor>& biases, const OptT& residual,
                                            const std::vector<at::Tensor>& xs, std::vector<OptT> stats, std::vector<OptT> masks,
                                            std::vector<int64_t> seg, std::vector<int64_t> geo, double slope, const at::Tensor& packed,
-                                           const OptT& out, bool want_stats, const OptT& stats_out, double eps, bool pass_x) {
+                                           const OptT& out, bool want_stats, const OptT& stats_out, double eps, int64_t pass_x) {
     TORCH_CHECK(g.conv_fwd_grouped && g.conv_bwd_grouped, "passion_amd host extension is not bound to libpassion_hip.so");
     ConvCfg cfg{std::move(geo), std::move(seg), slope, std::move(stats), std::move(masks), packed, out, want_stats, stats_out, eps, {}};
-    cfg.pass_x = pass_x && at::GradMode::is_enabled() && any_requires_grad(xs);
-    const bool handed = cfg.pass_x;
+    TORCH_CHECK(pass_x >= 0 && pass_x <= 2, "conv_block_grouped: pass_x is 0, 1 or 2");
+    cfg.pass_x = (at::GradMode::is_enabled() && any_requires_grad(xs)) ? (int)pass_x : 0;
+    const bool handed = cfg.pass_x > 0;
     bool wreq = false, leaves = true;
     for (const at::Tensor& w : weights) { wreq = wreq || w.requires_grad(); leaves = leaves && w.is_leaf(); }
     for (const at::Tensor& b : biases) { wreq = wreq || b.requires_grad(); leaves = leaves && b.is_leaf(); }
@@ -422,11 +440,11 @@ std::vector<at::Tensor> conv_block_grouped(const std::vector<at::Tensor>& weight
         for (const at::Tensor& w : weights) { cfg.params.push_back(w); wd.push_back(w.detach()); }
         for (const at::Tensor& b : biases) { cfg.params.push_back(b); bd.push_back(b.detach()); }
         std::vector<at::Tensor> r = GroupedConvNode::apply(at::TensorList(wd), at::TensorList(bd), residual, at::TensorList(xs), std::move(cfg));
-        if (pass_x && !handed) r.push_back(xs[0]);
+        for (int i = 0; i < pass_x && !handed; ++i) r.push_back(xs[0]);
         return r;
     }
     std::vector<at::Tensor> r = GroupedConvNode::apply(at::TensorList(weights), at::TensorList(biases), residual, at::TensorList(xs), std::move(cfg));
-    if (pass_x && !handed) r.push_back(xs[0]);      // (no graph: x itself)
+    for (int i = 0; i < pass_x && !handed; ++i) r.push_back(xs[0]);      // (no graph: x itself)
     return r;
 }
 

@@ -25,11 +25,12 @@ class Feat:
     (teacher + uni-modal students) over the same B samples in one launch (ops.SegIn.bmod).
     `stats_out`: optional preallocated (B,C,2) slot the statistics are written into (one slice of the
     statistics of a stacked buffer)."""
-    __slots__ = ("t", "_stats", "mask", "mask_col", "passes", "stats_out", "_act", "c_real")
+    __slots__ = ("t", "_stats", "mask", "mask_col", "passes", "stats_out", "_act", "c_real", "alt")
 
     def __init__(self, t, mask=None, mask_col=0, _stats=None, passes=1, stats_out=None, _act=None, c_real=None):
         self.t, self.mask, self.mask_col, self.passes, self.stats_out = t, mask, mask_col, passes, stats_out
         self.c_real = c_real     # channels that carry data when the tensor was zero-padded to a multiple of 8 (RFNet)
+        self.alt = None          # a second alias of `t` handed on by the conv that reads it (mmformer.encoders_grouped): for another reader
         self._stats = _stats if _stats is not None else [None]   # shared between masked views of one tensor
         self._act = _act if _act is not None else [None]         # LeakyReLU(InstanceNorm(t)) when materialised
 

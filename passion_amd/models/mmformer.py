@@ -131,18 +131,24 @@ def encoders_grouped(encs, x, mask, dtype):
                                    stride=c0.stride[0], pad_mode=L.PAD_REFLECT, residual=residual, out_dtype=dtype,
                                    want_stats=want_stats, pass_x=pass_x)
         if pass_x:
-            return Feat(r[0], _stats=[r[1]]), r[2]
+            return (Feat(r[0], _stats=[r[1]]),) + tuple(r[2:])
         return Feat(r[0], _stats=[r[1]]) if want_stats else Feat(r)
 
     f = gconv("e1_c1", Feat(xs), first=True)
     feats = []
     for lvl in range(1, 6):
         if lvl > 1 and RES_FUSE:
-            # the level's feature goes to the decoders / fusion blocks AND into the next level's stride-2 conv: that conv hands it on, the
-            # others read the handed-on tensor, and their (summed) gradient joins the conv's own input gradient inside its backward
+            # the level's feature goes to decoder_sep, to the fusion blocks AND into the next level's stride-2 conv: that conv hands it on
+            # (twice: decoder_sep and the fusion path are different branches of the backward), the others read the handed-on tensors, and
+            # their gradients join the conv's own input gradient inside its backward (passion_seg_t.dx_add, dx_add2)
             fprev = f
-            f, xk = gconv(f"e{lvl}_c1", f, pass_x=True)
-            feats[-1] = Feat(xk, fprev.mask, fprev.mask_col, fprev._stats, fprev.passes, fprev.stats_out, fprev._act, fprev.c_real)
+            if RES_FUSE >= 2:
+                f, xa, xb = gconv(f"e{lvl}_c1", f, pass_x=2)
+            else:
+                f, xa = gconv(f"e{lvl}_c1", f, pass_x=1)
+                xb = None
+            feats[-1] = Feat(xa, fprev.mask, fprev.mask_col, fprev._stats, fprev.passes, fprev.stats_out, fprev._act, fprev.c_real)
+            feats[-1].alt = xb
         elif lvl > 1:
             f = gconv(f"e{lvl}_c1", f)
         if RES_FUSE:     # x + c3(c2(x)): c2 hands x on to c3's residual input, the two gradients of x are summed inside c2's backward
@@ -154,7 +160,8 @@ def encoders_grouped(encs, x, mask, dtype):
     return feats
 
 
-RES_FUSE = _os.environ.get("PASSION_RES_FUSE", "1") != "0"             # encoder residual blocks: the identity branch's gradient added inside c2's backward
+RES_FUSE = int(_os.environ.get("PASSION_RES_FUSE", "2"))               # gradient sums inside the conv backward: 0 off; 1 the residual blocks + one handed-on
+                                                                        # copy of every level's feature; 2: two copies (decoder_sep / fusion path)
 SEP_LOSS_FIRST = _os.environ.get("PASSION_SEP_LOSS_FIRST", "1") != "0"
 LOSS_STREAMS = _os.environ.get("PASSION_LOSS_STREAMS", "1") != "0"     # deep-supervision / decoder_sep losses on side streams
 FUSE_STREAM = _os.environ.get("PASSION_FUSE_STREAM", "1") != "0"       # fusion blocks of levels 4..1 on a side stream
@@ -586,7 +593,7 @@ class Model(nn.Module):
                 stacked_feats[4] = Feat(ops.backward_marker(f5.t), f5.mask, f5.mask_col, _stats=f5._stats)
             per_level = []
             for l, f in enumerate(stacked_feats):
-                ts = ops.unstack(f.t, 4)
+                ts = ops.unstack(f.alt if f.alt is not None else f.t, 4)      # (the fusion path's own handed-on copy of the level: encoders_grouped)
                 st = f._stats[0].view(4, B, -1, 2) if f._stats[0] is not None else None
                 per_level.append([Feat(ts[i], _stats=[st[i]] if st is not None else None) for i in range(4)])
             encs = [[per_level[l][i] for l in range(5)] for i in range(4)]

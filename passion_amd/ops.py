@@ -615,10 +615,12 @@ def conv_block_grouped(segs, weights, biases, D, H, W, ksize=3, stride=1, pad_mo
         seg_ints += (s.C, s.offset, s.bstride, s.bmod, s.mask_col)
     r = h.conv_block_grouped(list(weights), list(biases) if biases is not None else [], residual, [s.x for s in segs],
                              [s.stats for s in segs], [s.mask for s in segs], seg_ints,
-                             (B, D, H, W, ksize, stride, pad_mode, L.dtype_code(odt)), slope, packed, out, want_stats, stats_out, eps, pass_x)
-    if pass_x:       # ... and the input again, as an output of this node: give THAT to whoever else reads x (a later conv's `residual`),
-        #              and the two gradients of x meet inside this conv's backward (passion_seg_t.dx_add) instead of in an autograd add
-        return (r[0], r[1], r[-1]) if want_stats else (r[0], r[-1])
+                             (B, D, H, W, ksize, stride, pad_mode, L.dtype_code(odt)), slope, packed, out, want_stats, stats_out, eps, int(pass_x))
+    if pass_x:       # ... and the input again (pass_x = 1 or 2 times), as outputs of this node: give THOSE to whoever else reads x (a later
+        #              conv's `residual`, the decoders) and the gradients of x meet inside this conv's backward (passion_seg_t.dx_add,
+        #              dx_add2) instead of in autograd adds
+        n = int(pass_x)
+        return tuple(r[:2 if want_stats else 1]) + tuple(r[len(r) - n:])
     return (r[0], r[1]) if want_stats else r[0]
 
 

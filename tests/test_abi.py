@@ -40,10 +40,10 @@ def test_ctypes_table_matches_header():
 
 def test_struct_layout_matches_header():
     from passion_amd import _lib
-    # passion_seg_t: 4 pointers + int64 + 4 int32 + the dx_add pointer (round 6) = 64 bytes; conv desc: 12 x 4-byte fields + 4 segments
-    assert ctypes.sizeof(_lib.Seg) == 64
-    assert ctypes.sizeof(_lib.ConvDesc) == 48 + 4 * 64
-    assert _lib.Seg.dx_add.offset == 56
+    # passion_seg_t: 4 pointers + int64 + 4 int32 + the dx_add / dx_add2 pointers (round 6) = 72 bytes; conv desc: 12 x 4-byte fields + 4 segments
+    assert ctypes.sizeof(_lib.Seg) == 72
+    assert ctypes.sizeof(_lib.ConvDesc) == 48 + 4 * 72
+    assert _lib.Seg.dx_add.offset == 56 and _lib.Seg.dx_add2.offset == 64
     assert ctypes.sizeof(_lib.ProfRec) == 24 + 64      # {kind, ms, bytes, flops, char name[64]}
 
 

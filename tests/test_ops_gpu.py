@@ -1217,6 +1217,28 @@ def test_residual_gradient_joins_inside_the_conv_backward(C, shape):
     # ... and against f32 arithmetic on the unjoined pieces: the joined sum is the closer one
     assert relerr(dx1.float(), dx0.double()) < 1e-2
 
+    # two further readers (a level's feature: decoder_sep and the fusion blocks): pass_x = 2, both gradients join in one backward call
+    def run2(joined):
+        x = x0.clone().requires_grad_(True)
+        xin = x * 1.0
+        w2, b2 = [w.clone().requires_grad_(True) for w in ws[0]], [b.clone().requires_grad_(True) for b in bs[0]]
+        seg = ops.SegIn(xin, stats=ops.instnorm_stats(xin.detach()))
+        if joined:
+            y2, xa, xb = ops.conv_block_grouped([seg], w2, b2, D, H, W, pass_x=2)
+        else:
+            y2, xa, xb = ops.conv_block_grouped([seg], w2, b2, D, H, W), xin, xin
+        return y2, xa, xb, x
+
+    y2, xa, xb, x = run2(True)
+    torch.autograd.backward([y2, xa, xb], [gy, gy * 0.5, gy * 0.25])
+    torch.cuda.synchronize()
+    dxj = x.grad.clone()
+    y2, xa, xb, x = run2(False)
+    torch.autograd.backward([y2, xa, xb], [gy, gy * 0.5, gy * 0.25])
+    torch.cuda.synchronize()
+    d = (dxj.float() - x.grad.float()).abs()
+    assert float(d.max()) <= 2 ** -5 * float(x.grad.float().abs().max()) and float(d.mean()) < 6e-3 * float(x.grad.float().abs().mean())
+
 
 @pytest.mark.parametrize("norm", [True, False], ids=["prenorm", "raw"])
 @pytest.mark.parametrize("pad_mode", [1, 0], ids=["reflect", "zeros"])
