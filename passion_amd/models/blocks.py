@@ -215,6 +215,8 @@ def run_conv_auto(conv, feats, out_dtype=None, post=False):
 
 
 GROUPED_ENC_POST = _os.environ.get("PASSION_GROUPED_ENC", "1") != "0"
+RES_FUSE = int(_os.environ.get("PASSION_RES_FUSE", "2"))      # gradient sums inside the conv backward: 0 off; 1 the residual blocks + one handed-on copy of
+                                                              # every level's feature; 2: two copies (decoder_sep / fusion path)
 
 
 def encoders_grouped_post(encs, x, mask, dtype, levels):
@@ -228,22 +230,36 @@ def encoders_grouped_post(encs, x, mask, dtype, levels):
     xs = xs.view(K * B, D, H, W, 1)
     gmask = mask.t().reshape(K * B, 1).contiguous() if mask is not None else None      # row m * B + b = mask[b, m]
 
-    def gconv(name, f, first=False):
+    def gconv(name, f, first=False, pass_x=0):
         convs = [getattr(e, name).conv for e in encs]
         c0 = convs[0]
         d, h, w = f.t.shape[1:4]
         seg = ops.SegIn(f.t, mask=gmask, mask_col=0) if first else f.seg(isinstance(f, PFeat))
         r = ops.conv_block_grouped([seg], [c.weight for c in convs], [c.bias for c in convs], d, h, w, ksize=c0.kernel_size[0],
-                                   stride=c0.stride[0], pad_mode=L.PAD_REFLECT, out_dtype=dtype, want_stats=True)
+                                   stride=c0.stride[0], pad_mode=L.PAD_REFLECT, out_dtype=dtype, want_stats=True, pass_x=pass_x)
+        if pass_x:
+            return (PFeat(r[0], _stats=[r[1]]),) + tuple(r[2:])
         return PFeat(r[0], _stats=[r[1]])
 
+    # RES_FUSE (models/mmformer.py has the pre-norm twin): a tensor with several readers is handed on by the conv that reads it, the others
+    # take the handed-on copies, and their gradients join that conv's input gradient inside its backward (passion_seg_t.dx_add / dx_add2)
+    # instead of in autograd sums: r1 -> c2 and the residual; a level's feature -> the next level's stride-2 conv, decoder_sep, the fusion path
     r1 = gconv("e1_c1", Feat(xs), first=True)
     feats = []
     for lvl in range(1, levels + 1):
-        if lvl > 1:
+        if lvl > 1 and RES_FUSE >= 2:
+            r1, xa, xb = gconv(f"e{lvl}_c1", feats[-1], pass_x=2)
+            feats[-1] = Feat(xa)
+            feats[-1].alt = xb
+        elif lvl > 1:
             r1 = gconv(f"e{lvl}_c1", feats[-1])
-        r3 = gconv(f"e{lvl}_c3", gconv(f"e{lvl}_c2", r1))
-        feats.append(Feat(ops.norm_act(r1.t, r1.stats(), r3.t, r3.stats())))
+        if RES_FUSE:
+            y2, r1x = gconv(f"e{lvl}_c2", r1, pass_x=1)
+            r3 = gconv(f"e{lvl}_c3", y2)
+            feats.append(Feat(ops.norm_act(r1x, r1.stats(), r3.t, r3.stats())))
+        else:
+            r3 = gconv(f"e{lvl}_c3", gconv(f"e{lvl}_c2", r1))
+            feats.append(Feat(ops.norm_act(r1.t, r1.stats(), r3.t, r3.stats())))
     return feats
 
 

@@ -371,7 +371,7 @@ class Model(nn.Module):
         grouped = GROUPED_ENC and bf16
         if grouped:
             stk = encoders_grouped_post([getattr(self, f"{m}_encoder") for m in MODALS], xin, mask if idt else None, dt, 5)
-            parts = [ops.unstack(stk[l].t, 4) for l in range(5)]      # storage-sharing slices; backward: one cat, no zero-filled slices
+            parts = [ops.unstack(stk[l].alt if stk[l].alt is not None else stk[l].t, 4) for l in range(5)]      # storage-sharing slices; backward: one cat, no zero-filled slices
             encs = [[Feat(parts[l][i]) for l in range(5)] for i in range(4)]
         else:
             encs = [getattr(self, f"{m}_encoder")(xin, i, mask if idt else None, dt) for i, m in enumerate(MODALS)]

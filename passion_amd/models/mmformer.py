@@ -160,8 +160,7 @@ def encoders_grouped(encs, x, mask, dtype):
     return feats
 
 
-RES_FUSE = int(_os.environ.get("PASSION_RES_FUSE", "2"))               # gradient sums inside the conv backward: 0 off; 1 the residual blocks + one handed-on
-                                                                        # copy of every level's feature; 2: two copies (decoder_sep / fusion path)
+from .blocks import RES_FUSE      # (gradient sums inside the conv backward: see encoders_grouped)
 SEP_LOSS_FIRST = _os.environ.get("PASSION_SEP_LOSS_FIRST", "1") != "0"
 LOSS_STREAMS = _os.environ.get("PASSION_LOSS_STREAMS", "1") != "0"     # deep-supervision / decoder_sep losses on side streams
 FUSE_STREAM = _os.environ.get("PASSION_FUSE_STREAM", "1") != "0"       # fusion blocks of levels 4..1 on a side stream

@@ -219,7 +219,7 @@ class Model(nn.Module):
         grouped = GROUPED_ENC_POST and dt == torch.bfloat16
         if grouped:          # every encoder layer as one grouped launch over the 4B stacked samples
             stk = encoders_grouped_post([getattr(self, f"{m}_encoder") for m in MODALS], xin, mask if idt else None, dt, 4)
-            parts = [ops.unstack(stk[l].t, 4) for l in range(4)]      # storage-sharing slices; backward: one cat, no zero-filled slices
+            parts = [ops.unstack(stk[l].alt if stk[l].alt is not None else stk[l].t, 4) for l in range(4)]      # storage-sharing slices; backward: one cat, no zero-filled slices
             encs = [[Feat(parts[l][i]) for l in range(4)] for i in range(4)]
         for i, m in enumerate(MODALS):
             if grouped:
