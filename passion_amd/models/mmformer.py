@@ -162,6 +162,7 @@ def encoders_grouped(encs, x, mask, dtype):
 
 from .blocks import RES_FUSE      # (gradient sums inside the conv backward: see encoders_grouped)
 SEP_LOSS_FIRST = _os.environ.get("PASSION_SEP_LOSS_FIRST", "1") != "0"
+TCL_EARLY = _os.environ.get("PASSION_TCL_EARLY", "1") != "0"           # the label conversion at the top of the forward on the loss stream
 LOSS_STREAMS = _os.environ.get("PASSION_LOSS_STREAMS", "1") != "0"     # deep-supervision / decoder_sep losses on side streams
 FUSE_STREAM = _os.environ.get("PASSION_FUSE_STREAM", "1") != "0"       # fusion blocks of levels 4..1 on a side stream
 GROUPED_INTRA = _os.environ.get("PASSION_GROUPED_INTRA", "1") != "0"   # the four intra-modal transformers as batched GEMMs
@@ -573,6 +574,16 @@ class Model(nn.Module):
         intra = [None] * 4
         pos = [getattr(self, f"{m}_pos") for m in MODALS]
         stacked_feats = None
+        # the label volume in the losses' layout: it depends on the batch alone, so its conversion (a 33 MB strided copy that sat between
+        # the end of the forward and the first loss kernel: 37 us with nothing beside it) goes to a side stream at the very top
+        tcl, tcl_ev = None, None
+        if training and target is not None and streams and LOSS_STREAMS and TCL_EARLY:
+            s2 = streams[2]
+            s2.wait_stream(main)
+            with torch.cuda.stream(s2):
+                tcl = ops.target_to_cl(target)
+                tcl_ev = s2.record_event()
+            tcl.record_stream(main)
 
         def intra_tokens(i):
             """token conv + intra-modal transformer of modality i (mmformer.py:417-433): a chain of ~30 tiny launches that
@@ -726,7 +737,10 @@ class Model(nn.Module):
         if not training:
             return pred
 
-        tcl = ops.target_to_cl(target)
+        if tcl is None:
+            tcl = ops.target_to_cl(target)
+        else:
+            main.wait_event(tcl_ev)
         # Loss glue with as few tiny launches as possible (each is ~4 us of dependent latency on the main stream between forward and
         # backward, and twice that in host work): (B, 4) matrices instead of per-modality loops.  gate[b, i] = 1 if modality i of
         # sample b takes part (idt: present in the data; pdt: always) -- the reference's `* mask` / one-hot selection.

@@ -54,6 +54,27 @@ class LossState:
         return rp_epoch
 
 
+class _SumLossFn(torch.autograd.Function):
+    """fuse_loss + (sep * mask).sum() + prm_loss of the plain step (train.py:228-240 of the reference) as one concatenation + one sum, with the
+    constant gradients handed back directly: between the end of the forward and the first backward kernel these few-element
+    reductions, adds and their autograd twins were sixteen launches of ~5 us each in a row on the main stream (a recorded step
+    replays them one after the other: nothing else can run there); four are left."""
+
+    @staticmethod
+    def forward(ctx, pair, prm, sep, mk):
+        ctx.mk, ctx.shapes = mk, (pair.shape, prm.shape, sep.shape)
+        sm = sep * mk if mk is not None else sep
+        return torch.cat([pair.reshape(-1), prm.reshape(-1), sm.reshape(-1)]).sum()
+
+    @staticmethod
+    def backward(ctx, g):
+        ps, rs, ss = ctx.shapes
+        return g.expand(ps), g.expand(rs), (g * ctx.mk if ctx.mk is not None else g.expand(ss)), None
+
+
+SUM_LOSS_FUSED = os.environ.get("PASSION_SUM_LOSS_FUSED", "1") != "0"
+
+
 def assemble_loss(outs, target, mask, mask_type="idt", use_passion=True, state=None, warmup=False, modal_num=None,
                   iter_per_epoch=None, rp_override=None):
     """Per-iteration loss (train.py:228-280 / :413-440), no host synchronisation.  `modal_num` / `iter_per_epoch`: the
@@ -61,6 +82,9 @@ def assemble_loss(outs, target, mask, mask_type="idt", use_passion=True, state=N
     pred = outs[0]
     B = pred.shape[0]
     dev = pred.device
+    if SUM_LOSS_FUSED and not use_passion and not warmup and pred.is_cuda:
+        mk = mask.to(device=dev, dtype=torch.float32) if mask_type != "pdt" else None
+        return _SumLossFn.apply(criterions._seg_pair(pred, target, None), outs[1], outs[2], mk)
     # softmax_weighted_loss_bs + dice_loss_bs (train.py:228): both columns of ONE pass over the prediction
     fuse_loss = criterions.seg_pair_bs(pred, target).sum()
     prm_loss = outs[1].sum()
