@@ -163,6 +163,7 @@ def encoders_grouped(encs, x, mask, dtype):
 from .blocks import RES_FUSE      # (gradient sums inside the conv backward: see encoders_grouped)
 SEP_LOSS_FIRST = _os.environ.get("PASSION_SEP_LOSS_FIRST", "1") != "0"
 TCL_EARLY = _os.environ.get("PASSION_TCL_EARLY", "1") != "0"           # the label conversion at the top of the forward on the loss stream
+DS_EARLY = _os.environ.get("PASSION_DS_EARLY", "1") != "0"             # deep-supervision losses as soon as a level's logits exist (needs TCL_EARLY)
 LOSS_STREAMS = _os.environ.get("PASSION_LOSS_STREAMS", "1") != "0"     # deep-supervision / decoder_sep losses on side streams
 FUSE_STREAM = _os.environ.get("PASSION_FUSE_STREAM", "1") != "0"       # fusion blocks of levels 4..1 on a side stream
 GROUPED_INTRA = _os.environ.get("PASSION_GROUPED_INTRA", "1") != "0"   # the four intra-modal transformers as batched GEMMs
@@ -289,13 +290,15 @@ class Decoder_fuse(nn.Module):
         xs = (x1, x2, x3, x4)
         return {lvl: getattr(self, f"RFM{lvl}")(xs[lvl - 1]) for lvl in (4, 3, 2, 1)}
 
-    def forward(self, x1, x2, x3, x4, x5, mask=None, fused=None, wait=None):
+    def forward(self, x1, x2, x3, x4, x5, mask=None, fused=None, wait=None, on_pred=None):
         """x1..x4: lists of the four modality Feats (already carrying their masks); x5: fused level-5 Feat.
         fused: fuse_levels(x1..x4) computed beforehand (on another stream: `wait()` is called before their first use)"""
         xs = (x1, x2, x3, x4)
         feats, preds = {}, {}
         feats[5] = self.RFM5([x5], want_stats=False)        # feeds a logit head and an upsampling only
         preds[4] = run_conv(self.seg_d4, feats[5], norm=False, out_dtype=torch.float32).t
+        if on_pred is not None:                       # (Model.forward: the level's deep-supervision loss starts now, on its side stream)
+            on_pred(4, preds[4])
         h = self.d4_c1(_up2(feats[5]))
         if wait is not None:
             wait()
@@ -305,6 +308,8 @@ class Decoder_fuse(nn.Module):
             feats[lvl] = f
             if lvl > 1:
                 preds[lvl - 1] = run_conv(getattr(self, f"seg_d{lvl - 1}"), f, norm=False, out_dtype=torch.float32).t
+                if on_pred is not None:
+                    on_pred(lvl - 1, preds[lvl - 1])
                 h = getattr(self, f"d{lvl - 1}_c1")(_up2(f))
         logits = run_conv(self.seg_layer, feats[1], norm=False, out_dtype=torch.float32).t
         return logits, (preds[1], preds[2], preds[3], preds[4]), tuple(feats[i].t for i in (1, 2, 3, 4, 5))
@@ -724,7 +729,21 @@ class Model(nn.Module):
                     if f._stats[0] is not None:
                         f._stats[0].record_stream(main)
             wait = lambda: main.wait_stream(s1)           # noqa: E731
-        fuse_all, preds_all, feats_all = self.decoder_fuse(*xs, self._inter(intra, tok_mask, pos_cat, B, p, P), fused=fused, wait=wait)
+        # deep supervision EARLY: a level's logits exist long before the forward ends; softmax + loss sums of that level run on the loss
+        # stream as soon as they do (on a detached copy: ops.DeferredFn attaches the little graph later, where the node used to be
+        # created, so the backward's order does not change) instead of as a chain of four after the last conv of the forward
+        early_ds = {}
+        on_pred = None
+        if tcl is not None and DS_EARLY:
+            def on_pred(l, pp):
+                s2 = streams[2]
+                s2.wait_stream(main)
+                pp.record_stream(s2)
+                with torch.cuda.stream(s2):
+                    xd = pp[:B].detach().requires_grad_()
+                    early_ds[l] = [crit.seg_losses_cl(ops.softmax_classes(xd, 1.0, "cl"), tcl, 2 ** l), xd]
+        fuse_all, preds_all, feats_all = self.decoder_fuse(*xs, self._inter(intra, tok_mask, pos_cat, B, p, P), fused=fused, wait=wait,
+                                                           on_pred=on_pred)
         if P == 1:
             fuse_pred, preds = fuse_all, preds_all
         else:
@@ -748,7 +767,8 @@ class Model(nn.Module):
 
         def deep_supervision():
             # softmax -> upsample -> WCE + Dice (mmformer.py:540-544), weights 1/2, 1/4, 1/8, 1/16
-            pairs = [crit.seg_losses_cl(ops.softmax_classes(pp, 1.0, "cl"), tcl, 2 ** (j + 1)) for j, pp in enumerate(preds)]
+            pairs = [ops.DeferredFn.apply(pp, early_ds[j + 1]) if (j + 1) in early_ds
+                     else crit.seg_losses_cl(ops.softmax_classes(pp, 1.0, "cl"), tcl, 2 ** (j + 1)) for j, pp in enumerate(preds)]
             return (torch.stack(pairs, 0) * self._deep_weights_on(dev)).sum((0, 2)).view(B, 1)
 
         def sep_losses():

@@ -689,6 +689,28 @@ def unstack(t, n):
 _MARKER_CB = [None]
 
 
+class DeferredFn(torch.autograd.Function):
+    """y = f(x) where f was already RUN, earlier, on a detached copy `xd` of x (`early` = f(xd), with its own small autograd graph):
+    this node only attaches that graph to x.  The forward kernels of f then sit where they were launched (a side stream, under other
+    work) while the node -- and with it the place of f's backward in the engine's order, newest node first -- is where this call is.
+    Used for the deep-supervision losses (models/mmformer.py): their forward runs as soon as a level's logits exist instead of in a
+    chain between the end of the forward and the start of the backward."""
+
+    @staticmethod
+    def forward(ctx, x, box):
+        # box = [early, xd] as a plain list: handed over as tensors they would be differentiable INPUTS of this node and the engine
+        # would walk the little graph itself (with undefined gradients) besides the call below
+        ctx.box = box
+        return box[0].detach()
+
+    @staticmethod
+    def backward(ctx, g):
+        early, xd = ctx.box
+        ctx.box = None
+        (gx,) = torch.autograd.grad(early, xd, g)
+        return gx, None
+
+
 class BackwardMarkerFn(torch.autograd.Function):
     """identity whose backward node tells the training step how far the backward has come.  Model.forward puts it on the deepest
     encoder output: autograd runs nodes in reverse creation order among the ready ones, every decoder / transformer / loss node
