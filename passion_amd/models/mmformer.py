@@ -581,14 +581,16 @@ class Model(nn.Module):
         stacked_feats = None
         # the label volume in the losses' layout: it depends on the batch alone, so its conversion (a 33 MB strided copy that sat between
         # the end of the forward and the first loss kernel: 37 us with nothing beside it) goes to a side stream at the very top
-        tcl, tcl_ev = None, None
+        tcl, tcl_ev, gate_early = None, None, None
         if training and target is not None and streams and LOSS_STREAMS and TCL_EARLY:
             s2 = streams[2]
             s2.wait_stream(main)
             with torch.cuda.stream(s2):
                 tcl = ops.target_to_cl(target)
+                gate_early = mask.float() if idt else torch.ones(B, 4, device=dev)
                 tcl_ev = s2.record_event()
             tcl.record_stream(main)
+            gate_early.record_stream(main)
 
         def intra_tokens(i):
             """token conv + intra-modal transformer of modality i (mmformer.py:417-433): a chain of ~30 tiny launches that
@@ -760,10 +762,16 @@ class Model(nn.Module):
             tcl = ops.target_to_cl(target)
         else:
             main.wait_event(tcl_ev)
+            if DS_EARLY:
+                # the fusion prediction's own loss (train.assemble_loss forms it: reference train.py:228) on a detached copy NOW, on the main
+                # stream, while the side streams finish theirs -- it used to follow decoder_sep's loss and the joins; the node is attached
+                # where assemble_loss asks for the loss (utils/criterions._seg_pair), so the backward's order stays
+                xd = pred.detach().requires_grad_()
+                pred._passion_pair_box = (tcl, [ops.wce_dice(xd, tcl, "ncdhw"), xd])
         # Loss glue with as few tiny launches as possible (each is ~4 us of dependent latency on the main stream between forward and
         # backward, and twice that in host work): (B, 4) matrices instead of per-modality loops.  gate[b, i] = 1 if modality i of
         # sample b takes part (idt: present in the data; pdt: always) -- the reference's `* mask` / one-hot selection.
-        gate = mask.float() if idt else torch.ones(B, 4, device=dev)
+        gate = gate_early if gate_early is not None else (mask.float() if idt else torch.ones(B, 4, device=dev))
 
         def deep_supervision():
             # softmax -> upsample -> WCE + Dice (mmformer.py:540-544), weights 1/2, 1/4, 1/8, 1/16
@@ -781,7 +789,12 @@ class Model(nn.Module):
             # stream, the deep-supervision branch gets its own.
             s0, s2 = streams[0], streams[2]
             for s_ in (s0, s2):
-                s_.wait_stream(main)
+                # decoder_sep's loss needs decoder_sep's logits (its own stream), the labels and the gate (made at the top of the forward
+                # on the loss stream: an event) -- not the end of the fusion decoder's forward, which it used to wait for here
+                if s_ is s0 and s0 is not s2 and tcl_ev is not None and DS_EARLY:      # (PASSION's stream map gives both roles one stream: wait for main)
+                    s_.wait_event(tcl_ev)
+                else:
+                    s_.wait_stream(main)
                 tcl.record_stream(s_)
             gate.record_stream(s0)
             for pp in preds:

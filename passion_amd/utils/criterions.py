@@ -36,6 +36,10 @@ def _seg_pair(output, target, up_op):
     tcl = ops.target_to_cl(target)
     k = _factor(up_op)
     if k == 1:
+        box = getattr(output, "_passion_pair_box", None)      # Model.forward already ran this loss on a detached copy of its prediction
+        if box is not None and box[0] is tcl and torch.is_grad_enabled():
+            output._passion_pair_box = None
+            return ops.DeferredFn.apply(output, box[1])      # (models/mmformer.py: beside the side streams' losses instead of behind them)
         return ops.wce_dice(output.float(), tcl, "ncdhw")
     return seg_losses_cl(_NcdhwToCl.apply(output.float()), tcl, k)
 
