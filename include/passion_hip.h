@@ -38,7 +38,10 @@ int passion_abi_version(void);
  * applies; environment PASSION_WGRAD_MARCH=0), "conv_s2" (0: zero-stuffed stride-2 input gradient), "conv_pw" / "conv_pw8" (0: the
  * 1x1x1 layers on the lean brick kernels instead of the streaming ones / the 8-channel 32x32x8 form), "conv_pwfinal" (0: pointwise
  * backward as dgrad + finish pass instead of the finish-free order with the means from the weight gradient), "flash_split" (n > 0:
- * that many key splits in the fused attention, 0 = automatic).  PASSION_UPSAMPLE_SHARED=0 (environment only) keeps the flat x2 upsampling
+ * that many key splits in the fused attention, 0 = automatic); round 6: "wgrad_group_s2", "c1_mfma", "conv_s2f", "wgrad_s2m" (0: the named
+ * round-6 kernel back on the one it replaced) and "pack_f32" (0: passion_conv_pack_weight(s) write the two bf16 operand
+ * images only -- for a caller that runs every conv on bf16 tensors with 8-channel-aligned concat segments; the kernels that read the f32
+ * images then return -1024 instead of computing on stale ones).  PASSION_UPSAMPLE_SHARED=0 (environment only) keeps the flat x2 upsampling
  * kernels for bf16 tensors.  Returns the previous value, -1 for an unknown name.  The parity tests use it to run the
  * same conv through the general and the lean kernels. */
 int passion_set_option(const char* name, int value);

@@ -156,13 +156,13 @@ int fwd_stats_setup(ConvK& k, int nwg, int ny, hipStream_t st) {
 
 // run-time A/B switches (the same ones the environment sets at load time); returns the previous value, -1 = unknown name
 extern int g_passion_force_f32_mfma, g_flash_split;
-namespace pconv { extern int g_conv_s2f, g_wgrad_s2m; }
+namespace pconv { extern int g_conv_s2f, g_wgrad_s2m, g_pack_f32; }
 namespace pconv { extern int g_conv_merge, g_wgrad_wide, g_conv_dbg, g_conv_target, g_conv_lean, g_conv_padout, g_wgrad_fork, g_conv_blockdiag, g_conv_march, g_wgrad_march, g_conv_c1, g_conv_s2, g_conv_pw, g_conv_pw8, g_conv_pwfinal, g_conv_deep, g_conv_marchfinal, g_conv_pair, g_deep_pair, g_wgrad_pw, g_wgrad_pw_minvox, g_wgrad_group_s2, g_c1_mfma; }
 extern "C" int passion_set_option(const char* name, int value) {
     struct { const char* n; int* p; } opts[] = {
         {"force_f32_mfma", &g_passion_force_f32_mfma}, {"conv_lean", &pconv::g_conv_lean}, {"conv_padout", &pconv::g_conv_padout},
         {"conv_target", &pconv::g_conv_target}, {"conv_merge", &pconv::g_conv_merge}, {"wgrad_wide", &pconv::g_wgrad_wide},
-        {"conv_dbg", &pconv::g_conv_dbg}, {"wgrad_fork", &pconv::g_wgrad_fork}, {"conv_march", &pconv::g_conv_march}, {"wgrad_march", &pconv::g_wgrad_march}, {"conv_c1", &pconv::g_conv_c1}, {"conv_s2", &pconv::g_conv_s2}, {"conv_pw", &pconv::g_conv_pw}, {"conv_pw8", &pconv::g_conv_pw8}, {"conv_pwfinal", &pconv::g_conv_pwfinal}, {"flash_split", &g_flash_split}, {"conv_deep", &pconv::g_conv_deep}, {"deep_pair", &pconv::g_deep_pair}, {"conv_marchfinal", &pconv::g_conv_marchfinal}, {"conv_pair", &pconv::g_conv_pair}, {"wgrad_pw", &pconv::g_wgrad_pw}, {"wgrad_pw_minvox", &pconv::g_wgrad_pw_minvox}, {"wgrad_group_s2", &pconv::g_wgrad_group_s2}, {"c1_mfma", &pconv::g_c1_mfma}, {"conv_s2f", &pconv::g_conv_s2f}, {"wgrad_s2m", &pconv::g_wgrad_s2m}};
+        {"conv_dbg", &pconv::g_conv_dbg}, {"wgrad_fork", &pconv::g_wgrad_fork}, {"conv_march", &pconv::g_conv_march}, {"wgrad_march", &pconv::g_wgrad_march}, {"conv_c1", &pconv::g_conv_c1}, {"conv_s2", &pconv::g_conv_s2}, {"conv_pw", &pconv::g_conv_pw}, {"conv_pw8", &pconv::g_conv_pw8}, {"conv_pwfinal", &pconv::g_conv_pwfinal}, {"flash_split", &g_flash_split}, {"conv_deep", &pconv::g_conv_deep}, {"deep_pair", &pconv::g_deep_pair}, {"conv_marchfinal", &pconv::g_conv_marchfinal}, {"conv_pair", &pconv::g_conv_pair}, {"wgrad_pw", &pconv::g_wgrad_pw}, {"wgrad_pw_minvox", &pconv::g_wgrad_pw_minvox}, {"wgrad_group_s2", &pconv::g_wgrad_group_s2}, {"c1_mfma", &pconv::g_c1_mfma}, {"conv_s2f", &pconv::g_conv_s2f}, {"pack_f32", &pconv::g_pack_f32}, {"wgrad_s2m", &pconv::g_wgrad_s2m}};
     for (auto& o : opts) {
         const char *a = o.n, *b = name;
         while (*a && *a == *b) { ++a; ++b; }

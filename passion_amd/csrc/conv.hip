@@ -812,8 +812,13 @@ int launch_conv_mt(ConvK& k, int mtiles, hipStream_t st) {
     return 0;
 }
 
+// option "pack_f32" (round 6): 0 = passion_conv_pack_weights writes the bf16 operand images only.  A bf16 model never reads the two f32
+// images (they are 2/3 of the bytes a re-pack writes and half of its gather reads: the closing pack of the four encoders' weights
+// sits between two steps, 94 us); the f32 kernels refuse to run on images that were not packed instead of reading stale ones.
+// (pconv::g_pack_f32: conv_bf16.hip)
 template <typename TI, typename TO, int MODE>
 int launch_conv_geo(ConvK& k, int ksize, int stride, int mtiles, hipStream_t st) {
+    if (!pconv::g_pack_f32) return -1024;            // the f32 operand images are not being packed (option pack_f32 = 0)
     passion_prof_tag("conv_mfma_kernel<%s, %s, KS=%d, S=%d, MODE=%d>", sizeof(TI) == 4 ? "float" : "bf16", sizeof(TO) == 4 ? "float" : "bf16",
                      ksize, stride, MODE);
     if (ksize == 1) return launch_conv_mt<TI, TO, 1, 1, MODE>(k, mtiles, st);
@@ -1054,6 +1059,7 @@ __global__ __launch_bounds__(256) void pack_multi_kernel(PackTable t) {
     // values of the first version were the kernel -- 105 us for the 24 M elements of the four encoders' images behind the closing
     // optimizer pass, on the critical stream
     const PackEnt& q = t.e[blockIdx.y];
+    const bool want_f32 = q.pad_ != 0;             // (PackEnt.pad_: 1 = all four images, 0 = the bf16 ones only)
     const unsigned Cin = q.Cin, Cout = q.Cout, ntap = q.ntap;
     const unsigned CoutPad = pad16(Cout), CinPad = pad16(Cin);
     const unsigned nf = ntap * Cin * CoutPad, nd = ntap * Cout * CinPad;        // f32 images
@@ -1065,7 +1071,7 @@ __global__ __launch_bounds__(256) void pack_multi_kernel(PackTable t) {
     bf16_t* bdg = bfwd + bf;
     const float* w = q.w;
     const unsigned total = nf + nd + bf + bd;
-    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    for (unsigned i = (want_f32 ? 0u : nf + nd) + blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
         if (i < nf) {                       // [tap][Cin][CoutPad]
             const unsigned co = i % CoutPad, r = i / CoutPad;
             const unsigned ci = r % Cin, tap = r / Cin;
@@ -1104,7 +1110,7 @@ extern "C" int passion_conv_pack_weights(int n, const float* const* weights, con
             const int ks = ksize[i0 + i];
             if (ks != 1 && ks != 3) return -1002;
             if (4L * ks * ks * ks * pad16(Cin[i0 + i]) * pad16(Cout[i0 + i]) >= (1L << 31)) return -1002;      // 32-bit indices in the kernel
-            t.e[i] = PackEnt{weights[i0 + i], packed[i0 + i], Cin[i0 + i], Cout[i0 + i], ks * ks * ks, 0};
+            t.e[i] = PackEnt{weights[i0 + i], packed[i0 + i], Cin[i0 + i], Cout[i0 + i], ks * ks * ks, pconv::g_pack_f32 ? 1 : 0};
         }
         hipLaunchKernelGGL(pack_multi_kernel, dim3(192, m), dim3(256), 0, (hipStream_t)stream, t);
         LAUNCH_RET();

@@ -804,6 +804,7 @@ int launch_conv_bf16(ConvK& k, int ksize, int stride, bool dgrad, const void* pa
 
 int g_conv_dbg = 0;       // developer timing switch (PASSION_CONV_DBG): bit0 skip staging, bit1 skip MFMA, bit2 skip epilogue
 int g_conv_target = 1024; // persistent conv workgroups aimed at per launch (PASSION_CONV_TARGET)
+int g_pack_f32 = 1;       // option "pack_f32": 0 = weight packs write the bf16 operand images only (conv.hip: pack_multi_kernel, launch_conv_geo)
 int g_conv_lean = 1;      // PASSION_CONV_LEAN=0: general kernel everywhere (A/B)
 int g_conv_merge = 0, g_wgrad_wide = 0;   // A/B switches (environment: PASSION_CONV_MERGE, PASSION_WGRAD_WIDE)
 

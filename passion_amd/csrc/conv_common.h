@@ -163,6 +163,7 @@ bool wgrad_s2m_covers(const ConvK& k, int ksize, int stride, int gx);           
 int launch_wgrad_s2m(ConvK& k, int ksize, int stride, int gx, float* dWslab, float* dbslab, hipStream_t st);
 extern int g_wgrad_s2m;
 extern int g_conv_lean;
+extern int g_pack_f32;
 int launch_wgrad_bf16(ConvK& k, int ksize, int stride, int MT, int gx, int gy, float* dWslab, float* dbslab, hipStream_t st);
 int wgrad_bf16_chunk(const ConvK& k, int ksize, int stride);
 

@@ -358,6 +358,7 @@ class Model(nn.Module):
 
     def forward(self, x, mask, target=None, temp=1.0):
         L.require_gpu(x)
+        ops.set_pack_f32(self.compute_dtype != torch.bfloat16)      # a bf16 model never reads the f32 operand images of its weight packs
         ops.repack_stale()
         ops.recast_stale()
         B = x.size(0)

@@ -560,6 +560,7 @@ class Model(nn.Module):
 
     def forward(self, x, mask, target=None, temp=1.0):
         L.require_gpu(x)
+        ops.set_pack_f32(self.compute_dtype != torch.bfloat16)      # a bf16 model never reads the f32 operand images of its weight packs
         ops.repack_stale()       # all conv weights the optimizer touched, one launch
         ops.recast_stale()       # ... and the bf16 images of the token-GEMM parameters, one more
         B, S = x.size(0), x.size(2)

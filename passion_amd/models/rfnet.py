@@ -205,6 +205,7 @@ class Model(nn.Module):
 
     def forward(self, x, mask, target=None, temp=1.0):
         L.require_gpu(x)
+        ops.set_pack_f32(self.compute_dtype != torch.bfloat16)      # a bf16 model never reads the f32 operand images of its weight packs
         ops.repack_stale()       # all conv weights the optimizer touched, one launch
         B = x.size(0)
         dev, dt = x.device, self.compute_dtype

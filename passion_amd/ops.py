@@ -79,6 +79,33 @@ _PACK_TABLE = {}        # the pointer tables of the last multi-weight re-pack
 _PACK_MANAGED = [False]      # train.train_step re-packs right behind the optimizer (below): the call at the top of Model.forward has nothing to do
 
 
+_PACK_F32 = [True]      # the f32 operand images are part of a weight pack (False: a bf16 model -- set_pack_f32)
+_FORCE_F32 = [os.environ.get("PASSION_FORCE_F32_MFMA", "0") not in ("", "0")]      # bf16 tensors on the f32 kernels (library option force_f32_mfma)
+PACK_BF16_ONLY = os.environ.get("PASSION_PACK_BF16_ONLY", "1") != "0"
+_STICKY_F32 = [False]   # this process has run a bf16 conv that the library puts on its f32-image kernel (a concat with a segment whose channel
+                        # count is no multiple of 8: m2ftrans): the f32 images stay part of every pack from then on
+
+
+def _needs_f32_images(segs):
+    """conv_bf16.hip bf16_eligible(): a multi-segment bf16 conv with a ragged segment runs on the general kernel, which reads the f32 images"""
+    return segs[0].x.dtype != torch.bfloat16 or (len(segs) > 1 and any(s.C % 8 for s in segs))
+
+
+def _pkey(w):
+    """what a packed image was made from: the parameter's storage and version, and which images the pack wrote"""
+    return (w.data_ptr(), w._version, _PACK_F32[0])
+
+
+def set_pack_f32(on):
+    """A bf16 model never reads the two f32 operand images of a weight pack (two thirds of the bytes a re-pack writes): its forward
+    says so (models/*.py) and the library stops writing them (option pack_f32; its f32 kernels then refuse to run instead of reading
+    stale images).  The image set is part of every pack's cache key: an f32 model in the same process re-packs what it needs."""
+    on = bool(on) or _FORCE_F32[0] or _STICKY_F32[0] or not PACK_BF16_ONLY
+    if on != _PACK_F32[0]:
+        _PACK_F32[0] = on
+        set_option("pack_f32", 1 if on else 0)
+
+
 def repack_stale(only=None, exclude=None):
     """Re-pack, in ONE launch, every registered conv weight whose version moved since it was packed (i.e. all of
     them after an optimizer step) into its existing buffer.  Called at the top of Model.forward: the per-conv
@@ -100,7 +127,7 @@ def repack_stale(only=None, exclude=None):
             continue
         if exclude is not None and w.data_ptr() in exclude:
             continue
-        if (capturing or cache.get("key") != (w.data_ptr(), w._version)) and w.is_cuda and w.dtype == torch.float32 \
+        if (capturing or cache.get("key") != _pkey(w)) and w.is_cuda and w.dtype == torch.float32 \
                 and w.is_contiguous():
             stale.append((w, cache))
     if not stale:
@@ -122,7 +149,7 @@ def repack_stale(only=None, exclude=None):
     _, ptrs, cin, cout, ks, outs = tab
     L.check(L.load().passion_conv_pack_weights(n, ptrs, cin, cout, ks, outs, L.stream_ptr()), "passion_conv_pack_weights")
     for w, cache in stale:
-        cache["key"] = (w.data_ptr(), w._version)
+        cache["key"] = _pkey(w)
     return n
 
 
@@ -136,7 +163,7 @@ def mark_packed_fresh():
         if w is None:
             del _PACK_REGISTRY[key]
         elif "packed" in cache:
-            cache["key"] = (w.data_ptr(), w._version)
+            cache["key"] = _pkey(w)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -431,7 +458,7 @@ def linear_grouped(x, weights, biases, bf16):
 
 def pack_weight(weight, cache=None):
     """f32 (Cout,Cin,k,k,k) -> packed MFMA operand images (fwd + dgrad); cached per weight version."""
-    key = (weight.data_ptr(), weight._version)
+    key = _pkey(weight)
     if cache is not None and cache.get("key") == key:
         return cache["packed"]
     L.require_gpu(weight)
@@ -550,6 +577,9 @@ def conv_block(segs, weight, bias, D, H, W, ksize=3, stride=1, pad_mode=L.PAD_RE
     cfg.B, cfg.out = vb[0], out
     x0 = segs[0].x
     cfg.out_dtype = out_dtype if out_dtype is not None else (x0.dtype if x0.dtype != torch.float64 else torch.float32)
+    if not _PACK_F32[0] and _needs_f32_images(segs):
+        _STICKY_F32[0] = _STICKY_F32[0] or x0.dtype == torch.bfloat16
+        set_pack_f32(True)                       # (an f32 conv after a bf16 model in this process, or a ragged concat: all four images again)
     packed = pack_weight(weight, pack_cache)
     h = L.host()
     if h is not None:            # C++ autograd node (csrc/host_ext.cpp): same descriptor, same C-ABI calls
@@ -575,7 +605,7 @@ def _group_pack(weights):
     ent = _GROUP_PACKS.get(key)
     w0 = weights[0]
     if ent is not None and ent[0].device == w0.device and all(r() is w for r, w in zip(ent[1], weights)):
-        if any(c.get("key") != (w.data_ptr(), w._version) for c, w in zip(ent[2], weights)):
+        if any(c.get("key") != _pkey(w) for c, w in zip(ent[2], weights)):
             repack_stale()
         return ent[0]
     import weakref
@@ -589,7 +619,7 @@ def _group_pack(weights):
         cache = {"packed": buf[g * n4:g * n4 + n]}
         wd = w.detach()
         L.check(lib.passion_conv_pack_weight(_p(wd), Cin, Cout, k, _p(cache["packed"]), L.stream_ptr()), "passion_conv_pack_weight")
-        cache["key"] = (w.data_ptr(), w._version)
+        cache["key"] = _pkey(w)
         if w.is_leaf:
             _PACK_REGISTRY[id(cache)] = (weakref.ref(w), cache)
         caches.append(cache)
@@ -609,6 +639,9 @@ def conv_block_grouped(segs, weights, biases, D, H, W, ksize=3, stride=1, pad_mo
     B = x0.shape[0]
     assert B % len(weights) == 0 and all(s.bmod == 0 for s in segs)
     odt = out_dtype if out_dtype is not None else (x0.dtype if x0.dtype != torch.float64 else torch.float32)
+    if not _PACK_F32[0] and _needs_f32_images(segs):
+        _STICKY_F32[0] = _STICKY_F32[0] or x0.dtype == torch.bfloat16
+        set_pack_f32(True)
     packed = _group_pack(weights)
     seg_ints = []
     for s in segs:
@@ -1676,6 +1709,10 @@ def set_option(name, value):
     old = L.load().passion_set_option(name.encode(), int(value))
     if old < 0:
         raise ValueError(f"unknown libpassion_hip option {name!r}")
+    if name == "force_f32_mfma":
+        _FORCE_F32[0] = bool(int(value))
+        if _FORCE_F32[0]:
+            set_pack_f32(True)                   # bf16 tensors on the f32 kernels: those read the f32 images
     return old
 
 

@@ -1174,6 +1174,53 @@ def test_first_layer_weight_gradient(B, shape, pad_mode):
     assert torch.equal(first, wd.grad)                     # fixed-order fold: bit-reproducible
 
 
+def test_bf16_only_weight_pack():
+    """ops.set_pack_f32(False) (what a bf16 model's forward says): a re-pack writes the two bf16 operand images only; a bf16 conv gives the
+    same result bit for bit; an f32 conv on the same weight afterwards gets its f32 images back by itself (the image set is part of the
+    pack's cache key); a bf16 conv that the library runs on its f32-image kernel (ragged concat) switches the process back for good;
+    and the library refuses to run an f32-image kernel while it is told not to pack those images"""
+    from passion_amd import ops, _lib as L
+    dev = _dev()
+    g = torch.Generator().manual_seed(41)
+    D, H, W = 8, 16, 32
+    x = torch.randn(2, D, H, W, 16, generator=g).to(torch.bfloat16).to(dev)
+    w = (torch.randn(16, 16, 3, 3, 3, generator=g) / 20).to(dev)
+    b = torch.randn(16, generator=g).to(dev)
+    state = (ops._PACK_F32[0], ops._STICKY_F32[0])
+    try:
+        ops._STICKY_F32[0] = False
+        ops.set_pack_f32(True)
+        cache = {}
+        y_all = ops.conv_block([ops.SegIn(x, stats=ops.instnorm_stats(x))], w, b, D, H, W, pack_cache=cache)
+        ops.set_pack_f32(False)
+        assert not ops._PACK_F32[0]
+        y_bf = ops.conv_block([ops.SegIn(x, stats=ops.instnorm_stats(x))], w, b, D, H, W, pack_cache=cache)
+        assert cache["key"][2] is False and torch.equal(y_all, y_bf)
+        # the guard: an f32 conv straight through the C ABI while the option is off
+        xf = x.float()
+        with pytest.raises(RuntimeError, match="-1024"):
+            d = ops._ConvCfg()
+            d.segs, d.D, d.H, d.W, d.ksize, d.stride, d.pad_mode, d.slope, d.B, d.out, d.out_dtype = \
+                [ops.SegIn(xf)], D, H, W, 3, 1, L.PAD_REFLECT, 0.2, 2, None, torch.float32
+            ops.ConvBlockFn.apply(d, w, b, None, cache["packed"], xf)
+        # ... and through ops.conv_block: the f32 images come back by themselves
+        y32 = ops.conv_block([ops.SegIn(xf)], w, b, D, H, W, pack_cache=cache)
+        assert ops._PACK_F32[0] and cache["key"][2] is True and not ops._STICKY_F32[0]
+        ref = F.conv3d(F.pad(xf.permute(0, 4, 1, 2, 3).double(), (1,) * 6, mode="reflect"), w.double(), b.double())
+        assert relerr(nc(y32), ref.cpu()) < TOL[torch.float32]
+        # a ragged concat in bf16: the general kernel reads the f32 images -- all four from now on
+        ops.set_pack_f32(False)
+        x4 = torch.randn(2, D, H, W, 4, generator=g).to(torch.bfloat16).to(dev)
+        w2 = (torch.randn(8, 20, 3, 3, 3, generator=g) / 20).to(dev)
+        y_r = ops.conv_block([ops.SegIn(x), ops.SegIn(x4)], w2, None, D, H, W)
+        assert ops._STICKY_F32[0] and ops._PACK_F32[0] and bool(torch.isfinite(y_r.float()).all())
+        ops.set_pack_f32(False)
+        assert ops._PACK_F32[0]                  # sticky
+    finally:
+        ops._STICKY_F32[0] = state[1]
+        ops.set_pack_f32(state[0])
+
+
 @pytest.mark.parametrize("C,shape", [(32, (8, 8, 16)), (16, (16, 32, 32)), (8, (24, 32, 64)), (8, (64, 128, 128)), (16, (5, 6, 7))])
 def test_residual_gradient_joins_inside_the_conv_backward(C, shape):
     """x + c3(c2(x)) (the encoders' residual blocks, reference mmformer.py:34-38) with c2 handing x on to c3's residual input
