@@ -725,7 +725,9 @@ int launch_march_one(ConvK& k, hipStream_t st) {
     // D segments: about g_conv_target workgroups per launch, at least 8 output planes per segment (2 halo planes each)
     // (final form, 16 -> 8 over 4 x 128^3 with the face tiles first: 1024 workgroups 180 us, 1536 178, 2048 173, 4096 186)
     static const long fin_target = []() { const char* e = getenv("PASSION_MARCH_FIN_TARGET"); return e && atol(e) > 0 ? atol(e) : 2048L; }();
-    const long wg_target = ((fin) && fin_target) ? fin_target : (long)g_conv_target;
+    // (two row tiles -- the 32 -> 16 input gradient of level 2 -- hold ONE workgroup per CU (352 registers): 256 workgroups are one round;
+    //  4 x 64^3: 109 us at 512 .. 2048, 93 at 256)
+    const long wg_target = ((fin) && fin_target) ? fin_target : ((MODE == 2 && k.Mpad == 32) ? 256L : (long)g_conv_target);
     int nseg = (int)hmax(1, (wg_target + (long)k.B * tiles - 1) / ((long)k.B * tiles));
     static const int min_planes = []() { const char* e = getenv("PASSION_MARCH_PLANES"); return e && atoi(e) > 0 ? atoi(e) : 16; }();
     const int nseg_want = nseg;
